@@ -1,0 +1,123 @@
+"""Synthetic genomes and reads (SURVEY.md §8d "Synthetic inputs").
+
+The real GRCh38 / E. coli FASTA files are not available offline, so every
+configuration runs on a seeded synthetic genome of a stated size.  Reads follow
+the recipe of SURVEY.md §8d: 150 bp, both strands, per-read error profile drawn
+from {0, 0, 0.5 %, 2 %, 5 %} substitutions with indel rate = sub/5, 1 % of reads
+carry one N, 2 % are random sequence.
+
+Base codes follow the reference (src/bwa.cpp nst_nt4_table): A=0 C=1 G=2 T=3 N=4.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+READ_LEN = 150
+_ERR_PROFILE = np.array([0.0, 0.0, 0.005, 0.02, 0.05])
+
+
+def make_genome(n_bases: int, seed: int = 2024, repeat_frac: float = 0.10,
+                repeat_len: int = 300, n_families: int = 8,
+                repeat_div: float = 0.08) -> np.ndarray:
+    """Random genome (codes 0..3) with interspersed repeat families.
+
+    A fraction ``repeat_frac`` of the genome is overwritten with diverged copies
+    (substitution rate ``repeat_div``) of ``n_families`` consensus elements, so
+    SMEM intervals with s > 1 and multi-seed chains occur as they do on a real
+    genome (a uniformly random genome has essentially none).
+    """
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=n_bases, dtype=np.uint8)
+    if repeat_frac > 0 and n_bases >= 4 * repeat_len:
+        fams = rng.integers(0, 4, size=(n_families, repeat_len), dtype=np.uint8)
+        n_copies = int(n_bases * repeat_frac / repeat_len)
+        starts = rng.integers(0, n_bases - repeat_len, size=n_copies)
+        fam_id = rng.integers(0, n_families, size=n_copies)
+        # process in slabs to bound memory
+        slab = 1 << 16
+        for a in range(0, n_copies, slab):
+            st = starts[a:a + slab]
+            cp = fams[fam_id[a:a + slab]].copy()
+            mut = rng.random(cp.shape) < repeat_div
+            cp[mut] = (cp[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+            idx = st[:, None] + np.arange(repeat_len)[None, :]
+            g[idx.ravel()] = cp.ravel()
+    return g
+
+
+def revcomp(x: np.ndarray) -> np.ndarray:
+    """Reverse complement of a code array; N (4) stays N."""
+    r = x[..., ::-1]
+    return np.where(r < 4, 3 - r, r).astype(np.uint8)
+
+
+def make_reads(genome: np.ndarray, n_reads: int, seed: int = 12345,
+               read_len: int = READ_LEN, contig_bounds: np.ndarray | None = None):
+    """Return (reads[n_reads, read_len] uint8 codes, truth_pos int64, truth_rev bool).
+
+    ``contig_bounds`` (ascending start offsets plus the total length) keeps reads
+    from straddling contigs; None treats the genome as one contig.
+    """
+    rng = np.random.default_rng(seed)
+    n = genome.shape[0]
+    win = read_len + 24                      # slack for deletions
+    if contig_bounds is None:
+        pos = rng.integers(0, n - win, size=n_reads)
+    else:
+        cb = np.asarray(contig_bounds, dtype=np.int64)
+        lens = np.diff(cb)
+        ok = lens > win
+        w = np.where(ok, lens - win, 0).astype(np.float64)
+        c = rng.choice(len(lens), size=n_reads, p=w / w.sum())
+        pos = cb[c] + (rng.random(n_reads) * (lens[c] - win)).astype(np.int64)
+
+    reads = np.empty((n_reads, read_len), dtype=np.uint8)
+    prof = _ERR_PROFILE[rng.integers(0, len(_ERR_PROFILE), size=n_reads)]
+    is_rev = rng.random(n_reads) < 0.5
+    slab = 1 << 17
+    col = np.arange(win)[None, :]
+    for a in range(0, n_reads, slab):
+        b = min(a + slab, n_reads)
+        m = b - a
+        w_ = genome[(pos[a:b, None] + col).ravel()].reshape(m, win)
+        sub = prof[a:b, None]
+        ind = sub / 5.0
+        u = rng.random((m, read_len))
+        is_del = u < ind / 2
+        is_ins = (u >= ind / 2) & (u < ind)
+        shift = np.cumsum(is_del.astype(np.int32) - is_ins.astype(np.int32), axis=1)
+        src = np.clip(np.arange(read_len)[None, :] + shift, 0, win - 1)
+        r = np.take_along_axis(w_, src, axis=1)
+        rnd = rng.integers(0, 4, size=(m, read_len), dtype=np.uint8)
+        r = np.where(is_ins, rnd, r)
+        is_sub = rng.random((m, read_len)) < sub
+        r = np.where(is_sub, (r + 1 + (rnd % 3)) & 3, r).astype(np.uint8)
+        rv = is_rev[a:b]
+        r[rv] = revcomp(r[rv])
+        reads[a:b] = r
+    # 2 % random sequence
+    rand_read = rng.random(n_reads) < 0.02
+    k = int(rand_read.sum())
+    if k:
+        reads[rand_read] = rng.integers(0, 4, size=(k, read_len), dtype=np.uint8)
+    # 1 % carry one N
+    has_n = np.flatnonzero(rng.random(n_reads) < 0.01)
+    if has_n.size:
+        reads[has_n, rng.integers(0, read_len, size=has_n.size)] = 4
+    truth = np.where(rand_read, -1, pos)
+    return reads, truth.astype(np.int64), is_rev
+
+
+def flatten_reads(reads) -> tuple[np.ndarray, np.ndarray]:
+    """(enc_qdb bytes, cum_len int64[n+1]) from a 2-D array or a list of 1-D arrays.
+
+    enc_qdb is the reference's concatenated one-code-per-byte read buffer
+    (src/bwamem.cpp:700-706)."""
+    if isinstance(reads, np.ndarray) and reads.ndim == 2:
+        n, L = reads.shape
+        return np.ascontiguousarray(reads).reshape(-1), np.arange(n + 1, dtype=np.int64) * L
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    cum = np.zeros(len(reads) + 1, dtype=np.int64)
+    np.cumsum(lens, out=cum[1:])
+    enc = np.concatenate([np.asarray(r, dtype=np.uint8) for r in reads]) if len(reads) else np.zeros(0, np.uint8)
+    return enc, cum

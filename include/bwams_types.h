@@ -1,0 +1,77 @@
+/*
+ * bwams_types.h — plain-old-data records that cross the C-ABI boundary.
+ *
+ * Every record is byte-for-byte the layout the reference keeps in host memory,
+ * so a reference-side caller can hand its own arrays to the library without a
+ * conversion pass.  Reference definitions (file:line under /root/reference):
+ *   CP_OCC     src/FMI_search.h:64-68     (64 B checkpoint block, 64 BWT rows)
+ *   SMEM       src/FMI_search.h:85-93     (40 B without DEBUG)
+ *   SeqPair    src/bandedSWA.h:90-99      (56 B)
+ *   mem_opt_t  src/bwamem.h:89-124        (only the fields the hot path reads)
+ */
+#ifndef BWAMS_TYPES_H
+#define BWAMS_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One checkpoint of the FM-index: occurrence counts of A,C,G,T in BWT[0, 64*blk)
+ * followed by four one-hot bit strings; bit (63-j) of one_hot_bwt_str[c] is set
+ * iff BWT[64*blk + j] == c.  The sentinel row and the padding rows set no bit. */
+typedef struct bwams_cp_occ {
+    int64_t  cp_count[4];
+    uint64_t one_hot_bwt_str[4];
+} bwams_cp_occ_t;
+
+/* Bi-directional interval of the query span [m, n] (inclusive):
+ * k = first BWT row of the forward pattern, l = first row of its reverse
+ * complement, s = interval size. */
+typedef struct bwams_smem {
+    uint32_t rid;
+    uint32_t m, n;
+    uint32_t pad_;      /* the reference struct has 4 B of alignment padding here */
+    int64_t  k, l, s;
+} bwams_smem_t;
+
+/* One extension task.  idr/idq are byte offsets into the flat reference/query
+ * buffers (one base code 0..4 per byte); len1 = target length, len2 = query
+ * length, h0 = initial score.  The last six fields are outputs. */
+typedef struct bwams_seqpair {
+    int32_t idr, idq, id;
+    int32_t len1, len2;
+    int32_t h0;
+    int32_t seqid, regid;
+    int32_t score, tle, gtle, qle;
+    int32_t gscore, max_off;
+} bwams_seqpair_t;
+
+/* Seeding options: the subset of mem_opt_t read by mem_collect_smem
+ * (src/bwamem.cpp:648-786) and mem_chain_seeds' SA step (src/bwamem.cpp:861-873).
+ * Defaults: src/bwamem.cpp:135-171. */
+typedef struct bwams_seed_opt {
+    int32_t min_seed_len;   /* -k, default 19 */
+    float   split_factor;   /* -r, default 1.5 */
+    int32_t split_width;    /* default 10 */
+    int32_t max_mem_intv;   /* default 20; 0 disables round 3 */
+    int32_t max_occ;        /* -c, default 500 */
+} bwams_seed_opt_t;
+
+/* Extension options: the BandedPairWiseSW constructor arguments
+ * (src/bandedSWA.cpp:48-52).  mat is the 5x5 substitution matrix filled by
+ * bwa_fill_scmat (src/bwa.cpp) from a (match) and b (mismatch). */
+typedef struct bwams_sw_opt {
+    int32_t o_del, e_del, o_ins, e_ins;
+    int32_t zdrop;
+    int32_t end_bonus;
+    int8_t  mat[25];
+    int8_t  pad_[3];
+} bwams_sw_opt_t;
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* BWAMS_TYPES_H */

@@ -1,0 +1,114 @@
+/*
+ * bwams_oracle.h — CPU restatement of the reference's seed-and-extend hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and only as the checker.  The product path (bwa-mem-scale_amd/) never links
+ * or calls into this directory.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - banded-SW extension (orc_bsw_*): PINNED against the reference's own
+ *     src/bandedSWA.cpp compiled from where it lies (oracle/_ref, Makefile here).
+ *   - FM-index seeding (orc_fmi_*, orc_collect_smem, orc_sa_*): PARITY UNPINNED.
+ *     src/FMI_search.cpp and src/bwamem.cpp include the un-vendored safestringlib
+ *     (ext/safestringlib is an empty submodule) and cannot be compiled here
+ *     without writing stand-in headers, which this project does not do; the
+ *     reference ships no tests or golden vectors.  The restatement is instead
+ *     cross-checked against a from-definition brute-force model
+ *     (tests/test_oracle_fmi.py): Occ by counting, intervals by naive suffix
+ *     sorting, SMEM maximality by exhaustive substring search.
+ */
+#ifndef BWAMS_ORACLE_H
+#define BWAMS_ORACLE_H
+
+#include <stdint.h>
+#include "../include/bwams_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* In-memory FM-index exactly as FMI_search holds it after load_index
+ * (src/FMI_search.cpp:875-906): count[] already carries the +1. */
+typedef struct orc_fmi {
+    int64_t ref_seq_len;              /* 2*l_pac + 1 */
+    int64_t count[5];                 /* file values + 1 */
+    const bwams_cp_occ_t *cp_occ;     /* (ref_seq_len >> 6) + 1 blocks */
+    const int8_t  *sa_ms_byte;        /* (ref_seq_len >> 3) + 1 */
+    const uint32_t *sa_ls_word;       /* (ref_seq_len >> 3) + 1 */
+    int64_t sentinel_index;
+} orc_fmi_t;
+
+/* Event counters used to derive the algorithmic byte count of a workload
+ * (SURVEY.md §8d): one CP_OCC block is 64 B. */
+typedef struct orc_counters {
+    int64_t n_ext;            /* backwardExt calls */
+    int64_t n_ext_blocks;     /* distinct CP_OCC blocks those calls touch (1 or 2 each) */
+    int64_t n_sa_lookups;     /* SA entries produced */
+    int64_t n_lf_steps;       /* LF-mapping steps walked by SA lookups */
+    int64_t n_smem[3];        /* SMEMs emitted by round 1, 2, 3 */
+} orc_counters_t;
+
+/* Occ / backwardExt (src/FMI_search.h:76-83, src/FMI_search.cpp:2029-2056). */
+int64_t orc_fmi_occ(const orc_fmi_t *f, int64_t pos, int c);
+void orc_backward_ext(const orc_fmi_t *f, const bwams_smem_t *in, int a,
+                      bwams_smem_t *out, orc_counters_t *ctr);
+
+/* getSMEMsOnePosOneThread (src/FMI_search.cpp:1372-1606), FM-index only path
+ * (no all_smem table).  query_pos[] is in/out; returns SMEMs appended. */
+int64_t orc_smem_one_pos(const orc_fmi_t *f, const uint8_t *enc_qdb,
+                         int16_t *query_pos, const int32_t *min_intv,
+                         const int32_t *rid, int32_t num_reads,
+                         const int64_t *cum_len, int32_t min_seed_len,
+                         bwams_smem_t *out, orc_counters_t *ctr);
+
+/* getSMEMsAllPosOneThread (src/FMI_search.cpp:1608-1660). rid[]/min_intv[] are
+ * clobbered exactly as in the reference. */
+int64_t orc_smem_all_pos(const orc_fmi_t *f, const uint8_t *enc_qdb,
+                         int32_t *min_intv, int32_t *rid, int32_t num_reads,
+                         const int64_t *cum_len, int32_t min_seed_len,
+                         bwams_smem_t *out, orc_counters_t *ctr);
+
+/* bwtSeedStrategyAllPosOneThread (src/FMI_search.cpp:1662-1816), no last_smem
+ * table.  skip[i] != 0 mirrors seq_[i].perfect.exist. */
+int64_t orc_seed_strategy(const orc_fmi_t *f, const uint8_t *enc_qdb,
+                          const uint8_t *skip, int32_t max_intv,
+                          int32_t num_reads, const int64_t *cum_len,
+                          int32_t min_seed_len, bwams_smem_t *out,
+                          orc_counters_t *ctr);
+
+/* mem_collect_smem (src/bwamem.cpp:648-786): three rounds, then the
+ * (rid, m, n) ordering left by sortSMEMs + the per-read introsort.
+ * cum_len has nseq+1 entries.  Returns the SMEM count or -1 on overflow. */
+int64_t orc_collect_smem(const orc_fmi_t *f, const bwams_seed_opt_t *opt,
+                         const uint8_t *enc_qdb, const int64_t *cum_len,
+                         const uint8_t *skip, int32_t nseq,
+                         bwams_smem_t *out, int64_t cap, orc_counters_t *ctr);
+
+/* call_one_step driven to completion (src/FMI_search.cpp:2206-2259): the SA
+ * value of BWT row pos, with the sentinel quirk (returns 0). */
+int64_t orc_sa_entry(const orc_fmi_t *f, int64_t pos, orc_counters_t *ctr);
+
+/* get_sa_entries_prefetch as used by mem_chain_seeds
+ * (src/FMI_search.cpp:2261-2379, src/bwamem.cpp:861-873): for each SMEM the
+ * rows k, k+step, ... (at most max_occ).  sa_off gets n+1 prefix offsets.
+ * Returns the number of coordinates or -1 on overflow. */
+int64_t orc_sa_lookup(const orc_fmi_t *f, const bwams_smem_t *smem, int64_t n,
+                      int32_t max_occ, int64_t *coord, int64_t cap,
+                      int64_t *sa_off, orc_counters_t *ctr);
+
+/* scalarBandedSWA (src/bandedSWA.cpp:116-237). Returns the score. */
+int orc_bsw_scalar(const bwams_sw_opt_t *o, int qlen, const uint8_t *query,
+                   int tlen, const uint8_t *target, int32_t w, int h0,
+                   int *qle, int *tle, int *gtle, int *gscore, int *max_off,
+                   int64_t *cells);
+
+/* scalarBandedSWAWrapper (src/bandedSWA.cpp:242-260). */
+void orc_bsw_pairs(const bwams_sw_opt_t *o, bwams_seqpair_t *pairs,
+                   const uint8_t *ref, const uint8_t *qer, int64_t n,
+                   int32_t w, int64_t *cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,93 @@
+"""Shared fixtures: small seeded genomes/indexes/reads, cached per process."""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+
+from bwams import fmindex, simulate
+
+
+@functools.lru_cache(maxsize=None)
+def toy(n_bases: int = 20000, seed: int = 7, repeat_frac: float = 0.15):
+    g = simulate.make_genome(n_bases, seed=seed, repeat_frac=repeat_frac, repeat_len=200, n_families=3)
+    idx = fmindex.build_fmindex(g)
+    return g, idx
+
+
+@functools.lru_cache(maxsize=None)
+def toy_reads(n_bases: int = 20000, n_reads: int = 300, seed: int = 11):
+    g, idx = toy(n_bases)
+    reads, pos, rev = simulate.make_reads(g, n_reads, seed=seed)
+    return reads, pos, rev
+
+
+def naive_sa(text: np.ndarray) -> np.ndarray:
+    """Suffix array of text+'$' by direct comparison (small inputs only)."""
+    n = len(text)
+    b = bytes((text + 1).astype(np.uint8)) + b"\x00"
+    return np.array(sorted(range(n + 1), key=lambda i: b[i:]), dtype=np.int64)
+
+
+def make_pairs(n: int, seed: int = 5, max_q: int = 140, max_extra_t: int = 120, n_frac: float = 0.02,
+               h0_max: int = 150):
+    """Random extension tasks in the reference's SeqPair layout.
+
+    Targets are mutated copies of the query (substitutions, indels, or unrelated
+    tails) so that every exit path of the DP is exercised: z-drop, band shrink,
+    row maximum reaching zero, reaching the query end (gscore)."""
+    from oracle.loader import SEQPAIR_DTYPE
+    rng = np.random.default_rng(seed)
+    pairs = np.zeros(n, dtype=SEQPAIR_DTYPE)
+    refs, qers = [], []
+    ro = qo = 0
+    for i in range(n):
+        ql = int(rng.integers(1, max_q + 1))
+        q = rng.integers(0, 4, size=ql, dtype=np.uint8)
+        mode = rng.integers(0, 5)
+        t = list(q)
+        if mode >= 1:
+            rate = [0.0, 0.02, 0.08, 0.2, 0.5][mode]
+            out = []
+            for b in t:
+                u = rng.random()
+                if u < rate * 0.6:
+                    out.append((b + rng.integers(1, 4)) & 3)
+                elif u < rate * 0.8:
+                    continue
+                elif u < rate:
+                    out.extend([b, rng.integers(0, 4)])
+                else:
+                    out.append(b)
+            t = out
+        if rng.random() < 0.3:                     # a long gap somewhere
+            cut = int(rng.integers(0, len(t) + 1))
+            gap = int(rng.integers(1, 40))
+            if rng.random() < 0.5:
+                t = t[:cut] + list(rng.integers(0, 4, size=gap)) + t[cut:]
+            else:
+                t = t[:cut] + t[cut + gap:]
+        t = t + list(rng.integers(0, 4, size=int(rng.integers(0, max_extra_t))))
+        if len(t) == 0:
+            t = [0]
+        t = np.array(t, dtype=np.uint8)
+        nmask = rng.random(len(t)) < n_frac
+        t[nmask] = 4
+        q = q.copy()
+        q[rng.random(ql) < n_frac] = 4
+        pairs[i]["idr"], pairs[i]["idq"], pairs[i]["id"] = ro, qo, i
+        pairs[i]["len1"], pairs[i]["len2"] = len(t), ql
+        pairs[i]["h0"] = int(rng.integers(1, h0_max + 1))
+        pairs[i]["seqid"], pairs[i]["regid"] = i // 3, i % 3
+        refs.append(t); qers.append(q)
+        ro += len(t); qo += ql
+    return pairs, np.concatenate(refs), np.concatenate(qers)
+
+
+OUT_FIELDS = ("score", "tle", "gtle", "qle", "gscore", "max_off")
+
+
+def assert_pairs_equal(a, b, what=""):
+    for f in OUT_FIELDS:
+        bad = np.flatnonzero(a[f] != b[f])
+        assert bad.size == 0, f"{what}: field {f} differs at {bad[:5]}: {a[f][bad[:5]]} vs {b[f][bad[:5]]}; pair={a[bad[0]]}"

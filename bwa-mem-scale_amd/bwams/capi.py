@@ -1,0 +1,280 @@
+"""ctypes binding of the C-ABI in include/bwams.h (libbwams.so).
+
+Used by the tests and bench.py; a reference-side caller would bind the same
+symbols from C++.  There is no fallback: if the library or a
+gfx950 device is missing, calls raise BwamsError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG, "_build", "libbwams.so")
+
+SMEM_DTYPE = np.dtype([("rid", "<u4"), ("m", "<u4"), ("n", "<u4"), ("pad_", "<u4"),
+                       ("k", "<i8"), ("l", "<i8"), ("s", "<i8")])
+SEQPAIR_DTYPE = np.dtype([(n, "<i4") for n in
+                          ("idr", "idq", "id", "len1", "len2", "h0", "seqid", "regid",
+                           "score", "tle", "gtle", "qle", "gscore", "max_off")])
+
+# every symbol include/bwams.h declares
+SYMBOLS = [
+    "bwams_strerror", "bwams_last_error", "bwams_device_count",
+    "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
+    "bwams_index_bytes", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
+    "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
+    "bwams_batch_stats", "bwams_batch_sync",
+]
+
+
+class BwamsError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where}: error {code} {detail}")
+
+
+class SeedOpt(C.Structure):
+    _fields_ = [("min_seed_len", C.c_int32), ("split_factor", C.c_float),
+                ("split_width", C.c_int32), ("max_mem_intv", C.c_int32), ("max_occ", C.c_int32)]
+
+
+class SwOpt(C.Structure):
+    _fields_ = [("o_del", C.c_int32), ("e_del", C.c_int32), ("o_ins", C.c_int32),
+                ("e_ins", C.c_int32), ("zdrop", C.c_int32), ("end_bonus", C.c_int32),
+                ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3)]
+
+
+class FmiDesc(C.Structure):
+    _fields_ = [("ref_seq_len", C.c_int64), ("count", C.c_int64 * 5),
+                ("cp_occ", C.c_void_p), ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p),
+                ("sentinel_index", C.c_int64), ("ref_0123", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_ext", C.c_int64), ("n_ext_blocks", C.c_int64), ("n_sa_lookups", C.c_int64),
+                ("n_lf_steps", C.c_int64), ("n_smem", C.c_int64 * 3), ("bsw_cells", C.c_int64),
+                ("ms_smem_r1", C.c_float), ("ms_smem_r2", C.c_float), ("ms_smem_r3", C.c_float),
+                ("ms_sort", C.c_float), ("ms_sal", C.c_float), ("ms_seed_total", C.c_float),
+                ("ms_bsw", C.c_float)]
+
+
+def default_seed_opt() -> SeedOpt:
+    """mem_opt_init defaults (/root/reference/src/bwamem.cpp:135-171)."""
+    return SeedOpt(19, 1.5, 10, 20, 500)
+
+
+def default_sw_opt(end_bonus: int = 5, a: int = 1, b: int = 4) -> SwOpt:
+    o = SwOpt(6, 1, 6, 1, 100, end_bonus)
+    k = 0
+    for i in range(4):
+        for j in range(4):
+            o.mat[k] = a if i == j else -b
+            k += 1
+        o.mat[k] = -1
+        k += 1
+    for j in range(5):
+        o.mat[k] = -1
+        k += 1
+    return o
+
+
+def build(force: bool = False) -> str:
+    """Compile libbwams.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(PKG, "csrc")
+    cmd = ["make", "-s", "-C", csrc, "-j4"]
+    if force:
+        subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libbwams.so (must have been built; raises if it is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BwamsError(-1, "libbwams.so", f"not built: {LIB_PATH} (run __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+        L.bwams_strerror.restype = C.c_char_p
+        L.bwams_strerror.argtypes = [C.c_int]
+        L.bwams_last_error.restype = C.c_char_p
+        L.bwams_device_count.argtypes = [vp]
+        L.bwams_index_open.argtypes = [C.c_char_p, C.c_int, vp]
+        L.bwams_index_from_host.argtypes = [vp, C.c_int, vp]
+        L.bwams_index_from_device.argtypes = [vp, C.c_int, vp]
+        L.bwams_index_close.argtypes = [vp]
+        L.bwams_index_bytes.restype = i64
+        L.bwams_index_bytes.argtypes = [vp]
+        L.bwams_batch_create.argtypes = [vp, i64, i64, i64, i64, vp]
+        L.bwams_batch_destroy.argtypes = [vp]
+        L.bwams_seed_fmi.argtypes = [vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, vp, vp]
+        L.bwams_seed_upload.argtypes = [vp, vp, vp, vp, i64]
+        L.bwams_seed_run.argtypes = [vp, vp, C.c_int]
+        L.bwams_seed_counts.argtypes = [vp, vp, vp]
+        L.bwams_seed_fetch.argtypes = [vp, vp, i64, vp, i64, vp]
+        L.bwams_bsw_extend.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp]
+        L.bwams_bsw_upload.argtypes = [vp, vp, i64, vp, i64, vp, i64]
+        L.bwams_bsw_run.argtypes = [vp, i32, vp]
+        L.bwams_bsw_fetch.argtypes = [vp, vp, i64]
+        L.bwams_batch_stats.argtypes = [vp, vp]
+        L.bwams_batch_sync.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def _chk(rc: int, where: str):
+    if rc != 0:
+        L = lib()
+        raise BwamsError(rc, where, f"({L.bwams_strerror(rc).decode()}) {L.bwams_last_error().decode()}")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Index:
+    """FM-index resident in one GPU's HBM."""
+
+    def __init__(self, handle, keep=None):
+        self.h = handle
+        self._keep = keep
+
+    @classmethod
+    def open(cls, prefix: str, device: int = 0) -> "Index":
+        h = C.c_void_p()
+        _chk(lib().bwams_index_open(prefix.encode(), device, C.byref(h)), "bwams_index_open")
+        return cls(h)
+
+    @classmethod
+    def from_host(cls, idx, device: int = 0) -> "Index":
+        """idx: bwams.fmindex.FMIndex of numpy arrays."""
+        cp = np.ascontiguousarray(idx.cp_occ)
+        ms = np.ascontiguousarray(idx.sa_ms_byte)
+        ls = np.ascontiguousarray(idx.sa_ls_word)
+        ref = np.ascontiguousarray(idx.ref_0123) if idx.ref_0123 is not None else None
+        d = FmiDesc(int(idx.ref_seq_len), (C.c_int64 * 5)(*[int(x) for x in idx.count]),
+                    cp.ctypes.data, ms.ctypes.data, ls.ctypes.data, int(idx.sentinel_index),
+                    ref.ctypes.data if ref is not None else None)
+        h = C.c_void_p()
+        _chk(lib().bwams_index_from_host(C.byref(d), device, C.byref(h)), "bwams_index_from_host")
+        return cls(h)
+
+    @classmethod
+    def from_device(cls, idx, device: int = 0) -> "Index":
+        """idx: FMIndex whose arrays are torch tensors on `device` (kept alive here)."""
+        ref = idx.ref_0123
+        d = FmiDesc(int(idx.ref_seq_len), (C.c_int64 * 5)(*[int(x) for x in idx.count]),
+                    idx.cp_occ.data_ptr(), idx.sa_ms_byte.data_ptr(), idx.sa_ls_word.data_ptr(),
+                    int(idx.sentinel_index), ref.data_ptr() if ref is not None else None)
+        h = C.c_void_p()
+        _chk(lib().bwams_index_from_device(C.byref(d), device, C.byref(h)), "bwams_index_from_device")
+        return cls(h, keep=idx)
+
+    @property
+    def nbytes(self) -> int:
+        return lib().bwams_index_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().bwams_index_close(self.h)
+            self.h = None
+
+
+class Batch:
+    def __init__(self, index: Index, max_reads: int, max_bases: int, max_smem: int = 0, max_sa: int = 0):
+        self.index = index
+        self.h = C.c_void_p()
+        _chk(lib().bwams_batch_create(index.h, max_reads, max_bases, max_smem, max_sa, C.byref(self.h)),
+             "bwams_batch_create")
+        self.max_reads = max_reads
+        self.max_smem = max_smem if max_smem > 0 else 24 * max_reads + 1024
+        self.max_sa = max_sa if max_sa > 0 else 64 * max_reads + 1024
+
+    def seed(self, enc, cum, opt: SeedOpt | None = None, skip=None, with_sa: bool = True):
+        """One-call seeding on host buffers: (smems, sa_coord, sa_off)."""
+        opt = opt or default_seed_opt()
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        cum = np.ascontiguousarray(cum, dtype=np.int64)
+        sk = np.ascontiguousarray(skip, dtype=np.uint8) if skip is not None else None
+        nseq = len(cum) - 1
+        sm = np.zeros(self.max_smem, dtype=SMEM_DTYPE)
+        ns, na = C.c_int64(0), C.c_int64(0)
+        coord = np.zeros(self.max_sa, dtype=np.int64) if with_sa else None
+        off = np.zeros(self.max_smem + 1, dtype=np.int64) if with_sa else None
+        _chk(lib().bwams_seed_fmi(self.h, _p(enc), _p(cum), _p(sk), nseq, C.byref(opt), _p(sm), self.max_smem,
+                                  C.byref(ns), _p(coord), self.max_sa, _p(off), C.byref(na)), "bwams_seed_fmi")
+        n = ns.value
+        if with_sa:
+            return sm[:n].copy(), coord[:na.value].copy(), off[:n + 1].copy()
+        return sm[:n].copy(), None, None
+
+    # resident form
+    def seed_upload(self, enc, cum, skip=None):
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        cum = np.ascontiguousarray(cum, dtype=np.int64)
+        sk = np.ascontiguousarray(skip, dtype=np.uint8) if skip is not None else None
+        _chk(lib().bwams_seed_upload(self.h, _p(enc), _p(cum), _p(sk), len(cum) - 1), "bwams_seed_upload")
+
+    def seed_run(self, opt: SeedOpt | None = None, with_sa: bool = True):
+        opt = opt or default_seed_opt()
+        _chk(lib().bwams_seed_run(self.h, C.byref(opt), 1 if with_sa else 0), "bwams_seed_run")
+
+    def seed_counts(self):
+        ns, na = C.c_int64(0), C.c_int64(0)
+        _chk(lib().bwams_seed_counts(self.h, C.byref(ns), C.byref(na)), "bwams_seed_counts")
+        return ns.value, na.value
+
+    def seed_fetch(self):
+        ns, na = self.seed_counts()
+        sm = np.zeros(max(ns, 1), dtype=SMEM_DTYPE)
+        coord = np.zeros(max(na, 1), dtype=np.int64)
+        off = np.zeros(ns + 1, dtype=np.int64)
+        _chk(lib().bwams_seed_fetch(self.h, _p(sm), len(sm), _p(coord), len(coord), _p(off)), "bwams_seed_fetch")
+        return sm[:ns], coord[:na], off
+
+    def bsw(self, pairs, ref, qer, w: int, opt: SwOpt | None = None):
+        opt = opt or default_sw_opt()
+        p = np.ascontiguousarray(pairs).copy()
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        qer = np.ascontiguousarray(qer, dtype=np.uint8)
+        _chk(lib().bwams_bsw_extend(self.h, _p(p), len(p), _p(ref), len(ref), _p(qer), len(qer), w, C.byref(opt)),
+             "bwams_bsw_extend")
+        return p
+
+    def bsw_upload(self, pairs, ref, qer):
+        p = np.ascontiguousarray(pairs)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        qer = np.ascontiguousarray(qer, dtype=np.uint8)
+        _chk(lib().bwams_bsw_upload(self.h, _p(p), len(p), _p(ref), len(ref), _p(qer), len(qer)), "bwams_bsw_upload")
+        self._n_pairs = len(p)
+
+    def bsw_run(self, w: int, opt: SwOpt | None = None):
+        opt = opt or default_sw_opt()
+        _chk(lib().bwams_bsw_run(self.h, w, C.byref(opt)), "bwams_bsw_run")
+
+    def bsw_fetch(self):
+        p = np.zeros(self._n_pairs, dtype=SEQPAIR_DTYPE)
+        _chk(lib().bwams_bsw_fetch(self.h, _p(p), len(p)), "bwams_bsw_fetch")
+        return p
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _chk(lib().bwams_batch_stats(self.h, C.byref(s)), "bwams_batch_stats")
+        return s
+
+    def sync(self):
+        _chk(lib().bwams_batch_sync(self.h), "bwams_batch_sync")
+
+    def close(self):
+        if self.h:
+            lib().bwams_batch_destroy(self.h)
+            self.h = None

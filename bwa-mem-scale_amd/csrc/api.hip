@@ -1,0 +1,603 @@
+// api.hip — the C-ABI (include/bwams.h): index residency, batch buffers, and the
+// launch sequences of the seed and extend stages on the batch's HIP stream.
+//
+// There is no CPU fallback anywhere in this file: every entry point either runs
+// the HIP kernels on a gfx950 device or returns an error code.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "fmi_kernels.h"
+
+namespace bwams {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &s) { g_last_error = s; }
+
+static int check_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_last_error(std::string("no HIP device: ") + hipGetErrorString(e));
+        return BWAMS_ERR_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_last_error("device ordinal out of range");
+        return BWAMS_ERR_ARG;
+    }
+    hipDeviceProp_t p;
+    BWAMS_HIP(hipGetDeviceProperties(&p, device));
+    if (std::string(p.gcnArchName).rfind("gfx950", 0) != 0) {
+        set_last_error(std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+        return BWAMS_ERR_DEVICE;
+    }
+    return BWAMS_OK;
+}
+
+}  // namespace bwams
+
+using namespace bwams;
+
+extern "C" {
+
+const char *bwams_strerror(int code) {
+    switch (code) {
+        case BWAMS_OK: return "ok";
+        case BWAMS_ERR_DEVICE: return "no usable gfx950 device / HIP error";
+        case BWAMS_ERR_IO: return "index file missing or malformed";
+        case BWAMS_ERR_ARG: return "invalid argument";
+        case BWAMS_ERR_CAPACITY: return "output buffer too small";
+        case BWAMS_ERR_NOMEM: return "out of memory";
+        case BWAMS_ERR_UNSUPPORTED: return "unsupported input";
+    }
+    return "unknown error";
+}
+
+const char *bwams_last_error(void) { return g_last_error.c_str(); }
+
+int bwams_device_count(int *n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        set_last_error(hipGetErrorString(e));
+        return BWAMS_ERR_DEVICE;
+    }
+    *n = c;
+    return BWAMS_OK;
+}
+
+/* ------------------------------------------------------------------ index -- */
+
+static int index_finish(bwams_index *ix, const bwams_fmi_desc_t *d) {
+    ix->fmi.cp = reinterpret_cast<const uint4 *>(ix->d_cp);
+    ix->fmi.sa_ms = reinterpret_cast<const int8_t *>(ix->d_ms);
+    ix->fmi.sa_ls = reinterpret_cast<const uint32_t *>(ix->d_ls);
+    ix->fmi.ref = reinterpret_cast<const uint8_t *>(ix->d_ref);
+    for (int i = 0; i < 5; ++i) ix->fmi.count[i] = d->count[i];
+    ix->fmi.sentinel = d->sentinel_index;
+    ix->fmi.ref_seq_len = d->ref_seq_len;
+    return BWAMS_OK;
+}
+
+int bwams_index_from_host(const bwams_fmi_desc_t *d, int device, bwams_index_t **out) {
+    if (!d || !out || !d->cp_occ || !d->sa_ms_byte || !d->sa_ls_word || d->ref_seq_len <= 0) {
+        set_last_error("bwams_index_from_host: null or empty descriptor");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    BWAMS_HIP(hipSetDevice(device));
+    bwams_index *ix = new bwams_index();
+    ix->device = device;
+    ix->n_blk = (d->ref_seq_len >> 6) + 1;
+    ix->n_sa = (d->ref_seq_len >> 3) + 1;
+    const size_t b_cp = (size_t)ix->n_blk * 64, b_ms = (size_t)ix->n_sa, b_ls = (size_t)ix->n_sa * 4;
+    const size_t b_ref = d->ref_0123 ? (size_t)(d->ref_seq_len - 1) : 0;
+    BWAMS_HIP(hipMalloc(&ix->d_cp, b_cp));
+    BWAMS_HIP(hipMalloc(&ix->d_ms, b_ms));
+    BWAMS_HIP(hipMalloc(&ix->d_ls, b_ls));
+    BWAMS_HIP(hipMemcpy(ix->d_cp, d->cp_occ, b_cp, hipMemcpyHostToDevice));
+    BWAMS_HIP(hipMemcpy(ix->d_ms, d->sa_ms_byte, b_ms, hipMemcpyHostToDevice));
+    BWAMS_HIP(hipMemcpy(ix->d_ls, d->sa_ls_word, b_ls, hipMemcpyHostToDevice));
+    if (b_ref) {
+        BWAMS_HIP(hipMalloc(&ix->d_ref, b_ref));
+        BWAMS_HIP(hipMemcpy(ix->d_ref, d->ref_0123, b_ref, hipMemcpyHostToDevice));
+    }
+    ix->bytes = (int64_t)(b_cp + b_ms + b_ls + b_ref);
+    index_finish(ix, d);
+    *out = ix;
+    return BWAMS_OK;
+}
+
+int bwams_index_from_device(const bwams_fmi_desc_t *d, int device, bwams_index_t **out) {
+    if (!d || !out || !d->cp_occ || !d->sa_ms_byte || !d->sa_ls_word || d->ref_seq_len <= 0) {
+        set_last_error("bwams_index_from_device: null or empty descriptor");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    bwams_index *ix = new bwams_index();
+    ix->device = device;
+    ix->owns = false;
+    ix->n_blk = (d->ref_seq_len >> 6) + 1;
+    ix->n_sa = (d->ref_seq_len >> 3) + 1;
+    ix->d_cp = const_cast<bwams_cp_occ_t *>(d->cp_occ);
+    ix->d_ms = const_cast<int8_t *>(d->sa_ms_byte);
+    ix->d_ls = const_cast<uint32_t *>(d->sa_ls_word);
+    ix->d_ref = const_cast<uint8_t *>(d->ref_0123);
+    ix->bytes = ix->n_blk * 64 + ix->n_sa * 5 + (d->ref_0123 ? d->ref_seq_len - 1 : 0);
+    index_finish(ix, d);
+    *out = ix;
+    return BWAMS_OK;
+}
+
+int bwams_index_open(const char *prefix, int device, bwams_index_t **out) {
+    if (!prefix || !out) return BWAMS_ERR_ARG;
+    std::string path = std::string(prefix) + ".bwt.2bit.64";
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) {
+        set_last_error("cannot open " + path);
+        return BWAMS_ERR_IO;
+    }
+    struct stat st;
+    fstat(fd, &st);
+    const size_t fsz = (size_t)st.st_size;
+    if (fsz < 56) {
+        close(fd);
+        set_last_error(path + ": truncated");
+        return BWAMS_ERR_IO;
+    }
+    const uint8_t *m = (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        set_last_error("mmap failed: " + path);
+        return BWAMS_ERR_IO;
+    }
+    bwams_fmi_desc_t d;
+    memset(&d, 0, sizeof d);
+    memcpy(&d.ref_seq_len, m, 8);
+    int64_t cnt[5];
+    memcpy(cnt, m + 8, 40);
+    for (int i = 0; i < 5; ++i) d.count[i] = cnt[i] + 1;   // as the reference loader does (FMI_search.cpp:880-883)
+    const int64_t n_blk = (d.ref_seq_len >> 6) + 1, n_sa = (d.ref_seq_len >> 3) + 1;
+    const size_t need = 48 + (size_t)n_blk * 64 + (size_t)n_sa * 5 + 8;
+    if (d.ref_seq_len <= 0 || fsz != need) {
+        munmap((void *)m, fsz);
+        set_last_error(path + ": size does not match its header");
+        return BWAMS_ERR_IO;
+    }
+    size_t o = 48;
+    d.cp_occ = reinterpret_cast<const bwams_cp_occ_t *>(m + o);
+    o += (size_t)n_blk * 64;
+    d.sa_ms_byte = reinterpret_cast<const int8_t *>(m + o);
+    o += (size_t)n_sa;
+    // sa_ls_word is not 4-byte aligned in the file in general: stage through an aligned copy
+    std::vector<uint32_t> ls((size_t)n_sa);
+    memcpy(ls.data(), m + o, (size_t)n_sa * 4);
+    d.sa_ls_word = ls.data();
+    o += (size_t)n_sa * 4;
+    memcpy(&d.sentinel_index, m + o, 8);
+
+    // optional .0123
+    std::string rpath = std::string(prefix) + ".0123";
+    const uint8_t *rm = nullptr;
+    size_t rsz = 0;
+    int rfd = open(rpath.c_str(), O_RDONLY);
+    if (rfd >= 0) {
+        struct stat rs;
+        fstat(rfd, &rs);
+        rsz = (size_t)rs.st_size;
+        if (rsz == (size_t)(d.ref_seq_len - 1)) {
+            rm = (const uint8_t *)mmap(nullptr, rsz, PROT_READ, MAP_PRIVATE, rfd, 0);
+            if (rm == MAP_FAILED) rm = nullptr;
+        }
+        close(rfd);
+    }
+    d.ref_0123 = rm;
+    int rc = bwams_index_from_host(&d, device, out);
+    if (rm) munmap((void *)rm, rsz);
+    munmap((void *)m, fsz);
+    return rc;
+}
+
+int bwams_index_close(bwams_index_t *ix) {
+    if (!ix) return BWAMS_OK;
+    if (ix->owns) {
+        (void)hipSetDevice(ix->device);
+        (void)hipFree(ix->d_cp);
+        (void)hipFree(ix->d_ms);
+        (void)hipFree(ix->d_ls);
+        if (ix->d_ref) (void)hipFree(ix->d_ref);
+    }
+    delete ix;
+    return BWAMS_OK;
+}
+
+int64_t bwams_index_bytes(const bwams_index_t *ix) { return ix ? ix->bytes : 0; }
+
+/* ------------------------------------------------------------------ batch -- */
+
+int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, int64_t max_smem,
+                       int64_t max_sa, bwams_batch_t **out) {
+    if (!ix || !out || max_reads <= 0 || max_bases <= 0) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(ix->device));
+    bwams_batch *b = new bwams_batch();
+    b->idx = ix;
+    b->max_reads = max_reads;
+    b->max_bases = max_bases;
+    b->max_smem = max_smem > 0 ? max_smem : 24 * max_reads + 1024;
+    b->max_sa = max_sa > 0 ? max_sa : 64 * max_reads + 1024;
+    hipDeviceProp_t prop;
+    BWAMS_HIP(hipGetDeviceProperties(&prop, ix->device));
+    b->cu_count = prop.multiProcessorCount;
+    BWAMS_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    for (auto &e : b->ev) BWAMS_HIP(hipEventCreate(&e));
+
+    BWAMS_HIP(hipMalloc(&b->d_enc, (size_t)max_bases + 64));
+    BWAMS_HIP(hipMalloc(&b->d_cum, (size_t)(max_reads + 1) * 8));
+    BWAMS_HIP(hipMalloc(&b->d_skip, (size_t)max_reads));
+    BWAMS_HIP(hipMalloc(&b->d_pool, (size_t)b->max_smem * sizeof(bwams_smem_t)));
+    BWAMS_HIP(hipMalloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
+    BWAMS_HIP(hipMalloc(&b->d_keys, (size_t)b->max_smem * 8));
+    BWAMS_HIP(hipMalloc(&b->d_keys2, (size_t)b->max_smem * 8));
+    BWAMS_HIP(hipMalloc(&b->d_vals, (size_t)b->max_smem * 4));
+    BWAMS_HIP(hipMalloc(&b->d_vals2, (size_t)b->max_smem * 4));
+    BWAMS_HIP(hipMalloc(&b->d_work2, (size_t)b->max_smem * sizeof(Round2Work)));
+    BWAMS_HIP(hipMalloc(&b->d_sa_off, (size_t)(b->max_smem + 1) * 8));
+    BWAMS_HIP(hipMalloc(&b->d_sa_cnt, (size_t)(b->max_smem + 1) * 8));
+    BWAMS_HIP(hipMalloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
+    BWAMS_HIP(hipMalloc(&b->d_ctr, sizeof(DevCounters)));
+    BWAMS_HIP(hipHostMalloc(&b->h_ctr, sizeof(DevCounters)));
+    BWAMS_HIP(hipMemset(b->d_ctr, 0, sizeof(DevCounters)));
+
+    // rocPRIM temporary storage for the largest sort / scan this batch can issue
+    size_t t1 = 0, t2 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t1, b->d_keys, b->d_keys2, b->d_vals, b->d_vals2,
+                              (size_t)b->max_smem, 0, 64, b->stream);
+    (void)rocprim::exclusive_scan(nullptr, t2, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)b->max_smem + 1,
+                            rocprim::plus<int64_t>(), b->stream);
+    b->tmp_bytes = std::max(t1, t2);
+    BWAMS_HIP(hipMalloc(&b->d_tmp, b->tmp_bytes));
+    *out = b;
+    return BWAMS_OK;
+}
+
+int bwams_batch_destroy(bwams_batch_t *b) {
+    if (!b) return BWAMS_OK;
+    (void)hipSetDevice(b->idx->device);
+    (void)hipStreamSynchronize(b->stream);
+    void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev_k,
+                    b->d_prev_l, b->d_prev_s, b->d_prev_n, b->d_pairs, b->d_ref, b->d_qer};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (b->h_ctr) (void)hipHostFree(b->h_ctr);
+    for (auto &e : b->ev)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(b->stream);
+    delete b;
+    return BWAMS_OK;
+}
+
+int bwams_batch_sync(bwams_batch_t *b) {
+    if (!b) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+    return BWAMS_OK;
+}
+
+/* ---------------------------------------------------------------- seeding -- */
+
+int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, const uint8_t *skip,
+                      int64_t nseq) {
+    if (!b || !enc || !cum || nseq < 0) return BWAMS_ERR_ARG;
+    if (nseq > b->max_reads) {
+        set_last_error("bwams_seed_upload: more reads than the batch was created for");
+        return BWAMS_ERR_CAPACITY;
+    }
+    const int64_t base0 = cum[0];
+    const int64_t nb = cum[nseq] - base0;
+    if (base0 != 0 || nb > b->max_bases || nb < 0) {
+        set_last_error("bwams_seed_upload: cum_len must start at 0 and fit max_bases");
+        return nb > b->max_bases ? BWAMS_ERR_CAPACITY : BWAMS_ERR_ARG;
+    }
+    int mx = 0;
+    for (int64_t i = 0; i < nseq; ++i) {
+        const int64_t l = cum[i + 1] - cum[i];
+        if (l < 0 || l > 0xfffe) {
+            set_last_error("bwams_seed_upload: read length must be in [0, 65534]");
+            return BWAMS_ERR_UNSUPPORTED;
+        }
+        if (l > mx) mx = (int)l;
+    }
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    b->nseq = nseq;
+    b->nbases = nb;
+    b->max_read_len = mx;
+    b->has_skip = skip != nullptr;
+    b->seed_done = false;
+    if (nb) BWAMS_HIP(hipMemcpyAsync(b->d_enc, enc, (size_t)nb, hipMemcpyHostToDevice, b->stream));
+    BWAMS_HIP(hipMemcpyAsync(b->d_cum, cum, (size_t)(nseq + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    if (skip && nseq) BWAMS_HIP(hipMemcpyAsync(b->d_skip, skip, (size_t)nseq, hipMemcpyHostToDevice, b->stream));
+    // the source buffers belong to the caller: do not return before they are consumed
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+
+    // per-lane scratch for the previous-interval lists: (longest read + 1) entries per lane
+    const int cap = mx + 1;
+    const int64_t threads = seed_max_threads(b->cu_count);
+    if (cap > b->prev_cap || threads > b->prev_threads) {
+        for (void *p : {(void *)b->d_prev_k, (void *)b->d_prev_l, (void *)b->d_prev_s, (void *)b->d_prev_n})
+            if (p) (void)hipFree(p);
+        b->d_prev_k = b->d_prev_l = b->d_prev_s = nullptr;
+        b->d_prev_n = nullptr;
+        const size_t n = (size_t)cap * (size_t)threads;
+        BWAMS_HIP(hipMalloc(&b->d_prev_k, n * 8));
+        BWAMS_HIP(hipMalloc(&b->d_prev_l, n * 8));
+        BWAMS_HIP(hipMalloc(&b->d_prev_s, n * 8));
+        BWAMS_HIP(hipMalloc(&b->d_prev_n, n * 4));
+        b->prev_cap = cap;
+        b->prev_threads = threads;
+    }
+    return BWAMS_OK;
+}
+
+int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
+    if (!b || !opt) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    b->with_sa = with_sa != 0;
+    b->n_smem = b->n_sa = 0;
+
+    SeedLaunch a;
+    a.fmi = b->idx->fmi;
+    a.enc = b->d_enc;
+    a.cum = b->d_cum;
+    a.skip = b->has_skip ? b->d_skip : nullptr;
+    a.nseq = b->nseq;
+    a.min_seed_len = opt->min_seed_len;
+    a.pool = b->d_pool;
+    a.pool_cap = b->max_smem;
+    a.ctr = b->d_ctr;
+    a.prev_k = b->d_prev_k;
+    a.prev_l = b->d_prev_l;
+    a.prev_s = b->d_prev_s;
+    a.prev_n = b->d_prev_n;
+    a.prev_cap = b->prev_cap;
+    a.prev_threads = b->prev_threads;
+    const int split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
+
+    BWAMS_HIP(hipMemsetAsync(b->d_ctr, 0, sizeof(DevCounters), st));
+    BWAMS_HIP(hipEventRecord(b->ev[0], st));
+    if (b->nseq > 0) {
+        launch_smem_round1(a, b->cu_count, st);
+        BWAMS_HIP(hipEventRecord(b->ev[1], st));
+        launch_smem_round2(a, b->d_work2, b->max_smem, split_len, opt->split_width, b->cu_count, st);
+        BWAMS_HIP(hipEventRecord(b->ev[2], st));
+        SeedLaunch a3 = a;
+        a3.min_seed_len = opt->min_seed_len + 1;
+        if (opt->max_mem_intv > 0) launch_smem_round3(a3, opt->max_mem_intv, b->cu_count, st);
+        BWAMS_HIP(hipEventRecord(b->ev[3], st));
+    } else {
+        for (int i = 1; i <= 3; ++i) BWAMS_HIP(hipEventRecord(b->ev[i], st));
+    }
+    BWAMS_HIP(hipGetLastError());
+    // the SMEM count sizes the sort: one small read-back
+    BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    const int64_t n = (int64_t)b->h_ctr->n_smem_total;
+    b->n_smem = n;
+    if (n > b->max_smem) {
+        set_last_error("SMEM pool overflow: need " + std::to_string(n) + " slots");
+        b->seed_done = true;
+        return BWAMS_ERR_CAPACITY;
+    }
+    if (n > 0) {
+        launch_make_keys(b->d_pool, n, b->d_keys, b->d_vals, st);
+        size_t tb = b->tmp_bytes;
+        // key = rid << 32 | m << 16 | n: only the bits in use are sorted
+        int rid_bits = 1;
+        while (((int64_t)1 << rid_bits) < b->nseq) rid_bits++;
+        BWAMS_HIP(rocprim::radix_sort_pairs(b->d_tmp, tb, b->d_keys, b->d_keys2, b->d_vals, b->d_vals2, (size_t)n,
+                                            0, 32 + rid_bits, st));
+        launch_gather_sorted(b->d_pool, b->d_vals2, n, b->d_sorted, with_sa ? b->d_sa_cnt : nullptr,
+                             opt->max_occ, st);
+    }
+    BWAMS_HIP(hipEventRecord(b->ev[4], st));
+    if (with_sa && n > 0) {
+        size_t tb = b->tmp_bytes;
+        BWAMS_HIP(hipMemsetAsync(b->d_sa_cnt + n, 0, 8, st));
+        BWAMS_HIP(rocprim::exclusive_scan(b->d_tmp, tb, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)n + 1,
+                                          rocprim::plus<int64_t>(), st));
+        launch_sa_lookup(b->idx->fmi, b->d_sorted, n, b->d_sa_off, b->d_sa_coord, b->max_sa, opt->max_occ,
+                         b->d_ctr, b->cu_count, st);
+    }
+    BWAMS_HIP(hipEventRecord(b->ev[5], st));
+    BWAMS_HIP(hipGetLastError());
+    b->seed_done = true;
+    return BWAMS_OK;
+}
+
+int bwams_seed_counts(bwams_batch_t *b, int64_t *n_smem, int64_t *n_sa) {
+    if (!b || !b->seed_done) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, b->stream));
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+    b->n_sa = b->with_sa ? (int64_t)b->h_ctr->n_sa_lookups : 0;
+    if (n_smem) *n_smem = b->n_smem;
+    if (n_sa) *n_sa = b->n_sa;
+    if (b->n_smem > b->max_smem) return BWAMS_ERR_CAPACITY;
+    if (b->n_sa > b->max_sa) {
+        set_last_error("SA coordinate buffer overflow: need " + std::to_string(b->n_sa));
+        return BWAMS_ERR_CAPACITY;
+    }
+    return BWAMS_OK;
+}
+
+int bwams_seed_fetch(bwams_batch_t *b, bwams_smem_t *smem_out, int64_t smem_cap, int64_t *sa_coord,
+                     int64_t sa_cap, int64_t *sa_off) {
+    if (!b || !b->seed_done) return BWAMS_ERR_ARG;
+    int64_t ns = 0, na = 0;
+    int rc = bwams_seed_counts(b, &ns, &na);
+    if (rc) return rc;
+    if (ns > smem_cap || (sa_coord && na > sa_cap)) {
+        set_last_error("bwams_seed_fetch: caller buffers too small");
+        return BWAMS_ERR_CAPACITY;
+    }
+    if (smem_out && ns)
+        BWAMS_HIP(hipMemcpyAsync(smem_out, b->d_sorted, (size_t)ns * sizeof(bwams_smem_t), hipMemcpyDeviceToHost,
+                                 b->stream));
+    if (sa_coord && sa_off && b->with_sa) {
+        if (ns) {
+            BWAMS_HIP(hipMemcpyAsync(sa_off, b->d_sa_off, (size_t)(ns + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+            if (na)
+                BWAMS_HIP(hipMemcpyAsync(sa_coord, b->d_sa_coord, (size_t)na * 8, hipMemcpyDeviceToHost, b->stream));
+        } else {
+            sa_off[0] = 0;
+        }
+    }
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+    return BWAMS_OK;
+}
+
+int bwams_seed_fmi(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, const uint8_t *skip, int64_t nseq,
+                   const bwams_seed_opt_t *opt, bwams_smem_t *smem_out, int64_t smem_cap, int64_t *n_smem,
+                   int64_t *sa_coord, int64_t sa_cap, int64_t *sa_off, int64_t *n_sa) {
+    int rc = bwams_seed_upload(b, enc, cum, skip, nseq);
+    if (rc) return rc;
+    const int with_sa = sa_coord && sa_off;
+    rc = bwams_seed_run(b, opt, with_sa);
+    if (rc) {
+        if (n_smem) *n_smem = b->n_smem;
+        return rc;
+    }
+    rc = bwams_seed_counts(b, n_smem, n_sa);
+    if (rc) return rc;
+    return bwams_seed_fetch(b, smem_out, smem_cap, sa_coord, sa_cap, sa_off);
+}
+
+/* -------------------------------------------------------------- extension -- */
+
+int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref,
+                     int64_t ref_bytes, const uint8_t *qer, int64_t qer_bytes) {
+    if (!b || n < 0 || (n && (!pairs || !ref || !qer))) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    int qmax = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const bwams_seqpair_t &p = pairs[i];
+        if (p.len1 < 0 || p.len2 < 0 || p.idr < 0 || p.idq < 0 || (int64_t)p.idr + p.len1 > ref_bytes ||
+            (int64_t)p.idq + p.len2 > qer_bytes) {
+            set_last_error("bwams_bsw_upload: pair " + std::to_string(i) + " points outside the sequence buffers");
+            return BWAMS_ERR_ARG;
+        }
+        if (p.len2 > qmax) qmax = p.len2;
+    }
+    if (bsw_lds_bytes(qmax) > 160 * 1024) {
+        set_last_error("bwams_bsw_upload: query longer than the LDS-resident kernel supports");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    auto grow = [](void **p, int64_t *cap, int64_t need, size_t elem) -> hipError_t {
+        if (need <= *cap) return hipSuccess;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        *cap = need + need / 4 + 1024;
+        return hipMalloc(p, (size_t)*cap * elem);
+    };
+    BWAMS_HIP(grow((void **)&b->d_pairs, &b->cap_pairs, n, sizeof(bwams_seqpair_t)));
+    BWAMS_HIP(grow((void **)&b->d_ref, &b->cap_ref, ref_bytes + 64, 1));
+    BWAMS_HIP(grow((void **)&b->d_qer, &b->cap_qer, qer_bytes + 64, 1));
+    if (n) {
+        BWAMS_HIP(hipMemcpyAsync(b->d_pairs, pairs, (size_t)n * sizeof(bwams_seqpair_t), hipMemcpyHostToDevice, b->stream));
+        BWAMS_HIP(hipMemcpyAsync(b->d_ref, ref, (size_t)ref_bytes, hipMemcpyHostToDevice, b->stream));
+        BWAMS_HIP(hipMemcpyAsync(b->d_qer, qer, (size_t)qer_bytes, hipMemcpyHostToDevice, b->stream));
+        BWAMS_HIP(hipStreamSynchronize(b->stream));
+    }
+    b->n_pairs = n;
+    b->max_qlen = qmax;
+    return BWAMS_OK;
+}
+
+int bwams_bsw_run(bwams_batch_t *b, int32_t w, const bwams_sw_opt_t *o) {
+    if (!b || !o) return BWAMS_ERR_ARG;
+    if (o->e_ins <= 0 || o->e_del <= 0) {
+        set_last_error("bwams_bsw_run: gap extension penalties must be positive");
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    SwParams prm;
+    prm.o_del = o->o_del; prm.e_del = o->e_del; prm.o_ins = o->o_ins; prm.e_ins = o->e_ins;
+    prm.zdrop = o->zdrop; prm.end_bonus = o->end_bonus;
+    int mx = 0;
+    for (int i = 0; i < 25; ++i) {
+        prm.mat[i] = o->mat[i];
+        mx = mx > o->mat[i] ? mx : o->mat[i];
+    }
+    prm.max_sc = mx;
+    BWAMS_HIP(hipEventRecord(b->ev[6], b->stream));
+    launch_bsw(b->d_pairs, b->n_pairs, b->d_ref, b->d_qer, w, prm, b->max_qlen, b->d_ctr, b->cu_count, b->stream);
+    BWAMS_HIP(hipEventRecord(b->ev[7], b->stream));
+    BWAMS_HIP(hipGetLastError());
+    return BWAMS_OK;
+}
+
+int bwams_bsw_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n) {
+    if (!b || n != b->n_pairs) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    if (n) BWAMS_HIP(hipMemcpyAsync(pairs, b->d_pairs, (size_t)n * sizeof(bwams_seqpair_t), hipMemcpyDeviceToHost, b->stream));
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+    return BWAMS_OK;
+}
+
+int bwams_bsw_extend(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, int64_t ref_bytes,
+                     const uint8_t *qer, int64_t qer_bytes, int32_t w, const bwams_sw_opt_t *opt) {
+    int rc = bwams_bsw_upload(b, pairs, n, ref, ref_bytes, qer, qer_bytes);
+    if (rc) return rc;
+    rc = bwams_bsw_run(b, w, opt);
+    if (rc) return rc;
+    return bwams_bsw_fetch(b, pairs, n);
+}
+
+/* ---------------------------------------------------------------- stats ---- */
+
+int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out) {
+    if (!b || !out) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, b->stream));
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+    bwams_stats_t s;
+    memset(&s, 0, sizeof s);
+    const DevCounters &c = *b->h_ctr;
+    s.n_ext = (int64_t)c.n_ext;
+    s.n_ext_blocks = (int64_t)c.n_ext_blocks;
+    s.n_sa_lookups = (int64_t)c.n_sa_lookups;
+    s.n_lf_steps = (int64_t)c.n_lf_steps;
+    s.n_smem[0] = (int64_t)c.n_after_r1;
+    s.n_smem[1] = (int64_t)(c.n_after_r2 - c.n_after_r1);
+    s.n_smem[2] = (int64_t)(c.n_smem_total - c.n_after_r2);
+    s.bsw_cells = (int64_t)c.bsw_cells;
+    auto el = [&](int a, int bb, float *dst) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b->ev[a], b->ev[bb]) == hipSuccess) *dst = ms;
+    };
+    if (b->seed_done) {
+        el(0, 1, &s.ms_smem_r1);
+        el(1, 2, &s.ms_smem_r2);
+        el(2, 3, &s.ms_smem_r3);
+        el(3, 4, &s.ms_sort);
+        el(4, 5, &s.ms_sal);
+        el(0, 5, &s.ms_seed_total);
+    }
+    el(6, 7, &s.ms_bsw);
+    (void)hipGetLastError();
+    *out = s;
+    return BWAMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+// bsw_extend.hip — banded Smith-Waterman seed extension for gfx950 (MI355X).
+//
+// Reference semantics: BandedPairWiseSW::scalarBandedSWA
+// (/root/reference/src/bandedSWA.cpp:116-237), i.e. ksw_extend2: affine-gap
+// extension from (0,0) with initial score h0, a band that is clipped to |i-j| <= w
+// and shrinks to the non-zero part of the previous row, z-drop exit, and the six
+// outputs score / qle / tle / gtle / gscore / max_off.
+//
+// Mapping (DESIGN.md §"BSW kernel"): one extension task per WAVEFRONT, one query
+// column per lane (column j belongs to lane j & 63, chunk j >> 6), rows walked in
+// order.  A row is fully parallel across its columns because in this recurrence
+// the horizontal gap F is opened from M (the diagonal move), never from H:
+//     F(i,j+1) = max(F(i,j) - e_ins, max(M(i,j) - o_ins - e_ins, 0))
+// so F is a max-plus prefix scan of values known from the previous row, done with
+// wavefront shuffles; E and M are column-local.  The row-wise band bookkeeping of
+// the scalar code (row maximum and its last column, first/last non-zero column,
+// z-drop) becomes wave reductions and ballots, and every decision is taken on
+// complete rows exactly as the scalar loop does — an anti-diagonal sweep cannot do
+// that, because the band of row i depends on all of row i-1.  Arithmetic is int32
+// (scores are < 2^15 for the reference's int16 class; no saturation is relied on).
+#include "common.h"
+
+namespace bwams {
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int NEG = -(1 << 28);
+
+__device__ __forceinline__ int wave_incl_prefix_max(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v = max(v, t);
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
+    bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,
+    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qmax, DevCounters *ctr) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
+    int2 *eh = reinterpret_cast<int2 *>(lds + wave * per_wave);
+    uint8_t *qs = reinterpret_cast<uint8_t *>(eh + (qmax + 1));
+
+    const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    unsigned long long cells = 0;
+
+    while (true) {
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(&ctr->work_head, 1ull);
+        const int64_t pid = (int64_t)(((unsigned long long)__shfl((uint32_t)(t >> 32), 0) << 32) |
+                                      (unsigned long long)__shfl((uint32_t)t, 0));
+        if (pid >= n) break;
+
+        const bwams_seqpair_t sp = pairs[pid];
+        const int qlen = sp.len2, tlen = sp.len1, h0 = sp.h0;
+        const uint8_t *tq = qer + sp.idq;
+        const uint8_t *tr = ref + sp.idr;
+
+        // row -1 of the DP and the query, each column on its owner lane
+        for (int j = lane; j <= qlen; j += 64) {
+            int h = h0;
+            if (j >= 1) {
+                h = h0 - oe_ins - (j - 1) * e_ins;
+                h = h > 0 ? h : 0;
+            }
+            eh[j] = make_int2(h, 0);
+            if (j < qlen) qs[j] = tq[j];
+        }
+
+        // clamp the band to the longest gap the score can pay for (bandedSWA.cpp:147-156)
+        int w = w0;
+        {
+            int max_ins = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_ins) / e_ins + 1.);
+            max_ins = max_ins > 1 ? max_ins : 1;
+            w = w < max_ins ? w : max_ins;
+            int max_del = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_del) / e_del + 1.);
+            max_del = max_del > 1 ? max_del : 1;
+            w = w < max_del ? w : max_del;
+        }
+
+        int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+        int beg = 0, end = qlen;
+
+        int tb_next = tlen > 0 ? tr[0] : 4;
+        for (int i = 0; i < tlen; ++i) {
+            const int tb = tb_next;
+            if (i + 1 < tlen) tb_next = tr[i + 1];           // overlap the next row's load with this row
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            int h1 = 0;
+            if (beg == 0) {
+                h1 = h0 - (o_del + e_del * (i + 1));
+                if (h1 < 0) h1 = 0;
+            }
+            const int sc0 = prm.mat[tb * 5 + 0], sc1 = prm.mat[tb * 5 + 1], sc2 = prm.mat[tb * 5 + 2],
+                      sc3 = prm.mat[tb * 5 + 3], sc4 = prm.mat[tb * 5 + 4];
+
+            int m = 0, mj = -1;
+            int first_nz = 1 << 30, last_nz = -1;
+            int f_carry = 0, hl_carry = h1, h_last = h1;
+            if (beg < end) {
+                cells += (unsigned long long)(end - beg);
+                const int c_lo = beg >> 6, c_hi = (end - 1) >> 6;
+                for (int c = c_lo; c <= c_hi; ++c) {
+                    const int jb = c << 6;
+                    const int j = jb + lane;
+                    const bool act = j >= beg && j < end;
+                    const int c0 = jb > beg ? jb : beg;          // column the carries refer to
+                    int2 cell = make_int2(0, 0);
+                    int qj = 4;
+                    if (act) {
+                        cell = eh[j];
+                        qj = qs[j];
+                    }
+                    const int S = qj == 0 ? sc0 : qj == 1 ? sc1 : qj == 2 ? sc2 : qj == 3 ? sc3 : sc4;
+                    const int M = (act && cell.x) ? cell.x + S : 0;
+                    const int e = cell.y;
+                    int tj = M - oe_ins;
+                    tj = tj > 0 ? tj : 0;
+                    const int g = act ? tj + j * e_ins : NEG;
+                    const int P = wave_incl_prefix_max(g, lane);
+                    int Pex = __shfl_up(P, 1);
+                    if (lane == 0) Pex = NEG;
+                    int F = f_carry - (j - c0) * e_ins;
+                    const int F2 = Pex - (j - 1) * e_ins;
+                    F = F > F2 ? F : F2;
+                    int h = M > e ? M : e;
+                    h = h > F ? h : F;
+                    int e2 = M - oe_del;
+                    e2 = e2 > 0 ? e2 : 0;
+                    const int e1 = e - e_del;
+                    e2 = e2 > e1 ? e2 : e1;
+                    int hl = __shfl_up(h, 1);
+                    if (lane == 0 || j == beg) hl = hl_carry;
+                    if (act) eh[j] = make_int2(hl, e2);
+
+                    // row maximum and the last column that attains it
+                    const int hm = act ? h : -1;
+                    const int cm = wave_max(hm);
+                    if (cm >= m) {
+                        const unsigned long long eq = __ballot(act && h == cm);
+                        m = cm;
+                        mj = jb + 63 - __clzll((long long)eq);
+                    }
+                    // first / last column whose stored (h, e) is non-zero
+                    const unsigned long long nz = __ballot(act && (hl != 0 || e2 != 0));
+                    if (nz) {
+                        const int lo = jb + __ffsll((long long)nz) - 1;
+                        const int hi = jb + 63 - __clzll((long long)nz);
+                        first_nz = first_nz < lo ? first_nz : lo;
+                        last_nz = hi;
+                    }
+                    // carries into the next chunk / the row's last H
+                    int fn = F - e_ins;
+                    fn = fn > tj ? fn : tj;
+                    const int last_lane = (end - 1 < jb + 63 ? end - 1 : jb + 63) - jb;
+                    f_carry = __shfl(fn, 63);
+                    hl_carry = __shfl(h, 63);
+                    h_last = __shfl(h, last_lane);
+                }
+            }
+            const int j_exit = beg < end ? end : beg;
+            const int h1f = beg < end ? h_last : h1;
+            if ((end & 63) == lane) eh[end] = make_int2(h1f, 0);
+            if (j_exit == qlen) {
+                max_ie = gscore > h1f ? max_ie : i;
+                gscore = gscore > h1f ? gscore : h1f;
+            }
+            if (m == 0) break;
+            if (m > mx) {
+                mx = m; max_i = i; max_j = mj;
+                int d = mj - i;
+                d = d < 0 ? -d : d;
+                max_off = max_off > d ? max_off : d;
+            } else if (prm.zdrop > 0) {
+                if (i - max_i > mj - max_j) {
+                    if (mx - m - ((i - max_i) - (mj - max_j)) * e_del > prm.zdrop) break;
+                } else {
+                    if (mx - m - ((mj - max_j) - (i - max_i)) * e_ins > prm.zdrop) break;
+                }
+            }
+            // next row's band: skip leading zeros, cut trailing zeros (bandedSWA.cpp:217-221)
+            const int nbeg = first_nz < end ? first_nz : end;
+            int jj;
+            if (h1f != 0) jj = end;
+            else if (last_nz >= nbeg) jj = last_nz;
+            else jj = nbeg - 1;
+            beg = nbeg;
+            end = jj + 2 < qlen ? jj + 2 : qlen;
+        }
+
+        if (lane == 0) {
+            bwams_seqpair_t *o = &pairs[pid];
+            o->score = mx;
+            o->qle = max_j + 1;
+            o->tle = max_i + 1;
+            o->gtle = max_ie + 1;
+            o->gscore = gscore;
+            o->max_off = max_off;
+        }
+    }
+    if (lane == 0 && cells) atomicAdd(&ctr->bsw_cells, cells);
+}
+
+__global__ void bsw_reset_kernel(DevCounters *ctr) {
+    ctr->work_head = 0;
+    ctr->bsw_cells = 0;
+}
+
+}  // namespace
+
+void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w,
+                const SwParams &prm, int qmax, DevCounters *ctr, int cu_count, hipStream_t st) {
+    bsw_reset_kernel<<<1, 1, 0, st>>>(ctr);
+    if (n <= 0) return;
+    const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
+    const size_t lds = per_wave * kWavesPerBlock;
+    int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t maxb = (int64_t)cu_count * 8;
+    if (blocks > maxb) blocks = maxb;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    bsw_kernel<<<(unsigned)blocks, kWavesPerBlock * 64, lds, st>>>(pairs, n, ref, qer, w, prm, qmax, ctr);
+}
+
+size_t bsw_lds_bytes(int qmax) {
+    const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
+    return per_wave * kWavesPerBlock;
+}
+
+}  // namespace bwams

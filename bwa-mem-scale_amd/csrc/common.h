@@ -1,0 +1,123 @@
+// common.h — internal declarations shared by the HIP translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/bwams.h"
+
+namespace bwams {
+
+void set_last_error(const std::string &s);
+
+#define BWAMS_HIP(call)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            char buf_[512];                                                              \
+            snprintf(buf_, sizeof buf_, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,    \
+                     hipGetErrorString(e_));                                             \
+            bwams::set_last_error(buf_);                                                 \
+            return (e_ == hipErrorOutOfMemory) ? BWAMS_ERR_NOMEM : BWAMS_ERR_DEVICE;     \
+        }                                                                                \
+    } while (0)
+
+// FM-index as the kernels see it (passed by value in the kernarg segment).
+// cp points at the reference's CP_OCC array unchanged: block b occupies four
+// 16-byte pieces  [cnt0 cnt1] [cnt2 cnt3] [hot0 hot1] [hot2 hot3].
+struct DevFmi {
+    const uint4 *cp;
+    const int8_t *sa_ms;
+    const uint32_t *sa_ls;
+    const uint8_t *ref;        // .0123 or nullptr
+    int64_t count[5];
+    int64_t sentinel;
+    int64_t ref_seq_len;
+};
+
+// device-side counters of one seed run
+struct DevCounters {
+    unsigned long long n_ext, n_ext_blocks, n_sa_lookups, n_lf_steps;
+    unsigned long long n_smem_total;     // append cursor of the SMEM pool
+    unsigned long long n_after_r1, n_after_r2;
+    unsigned long long work_head;        // dynamic work queue cursor (reset per kernel)
+    unsigned long long n_work2;          // round-2 work items
+    unsigned long long overflow;         // SMEM pool overflow flag / needed size
+    unsigned long long bsw_cells;
+    unsigned long long pad_[5];
+};
+
+// banded-SW parameters in kernel form (max_sc = max entry of mat)
+struct SwParams {
+    int o_del, e_del, o_ins, e_ins, zdrop, end_bonus, max_sc;
+    int8_t mat[25];
+};
+
+struct Round2Work {
+    uint32_t rid;
+    int32_t x;
+    int32_t min_intv;
+};
+
+void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w,
+                const SwParams &prm, int qmax, DevCounters *ctr, int cu_count, hipStream_t st);
+size_t bsw_lds_bytes(int qmax);
+
+}  // namespace bwams
+
+struct bwams_index {
+    int device = 0;
+    bwams::DevFmi fmi{};
+    bool owns = true;
+    int64_t bytes = 0;
+    int64_t n_blk = 0, n_sa = 0;
+    void *d_cp = nullptr, *d_ms = nullptr, *d_ls = nullptr, *d_ref = nullptr;
+};
+
+struct bwams_batch {
+    bwams_index *idx = nullptr;
+    hipStream_t stream = nullptr;
+    int64_t max_reads = 0, max_bases = 0, max_smem = 0, max_sa = 0;
+    int cu_count = 0;
+
+    // reads
+    uint8_t *d_enc = nullptr;
+    int64_t *d_cum = nullptr;
+    uint8_t *d_skip = nullptr;
+    bool has_skip = false;
+    int64_t nseq = 0, nbases = 0;
+    int max_read_len = 0;
+
+    // seeding buffers
+    bwams_smem_t *d_pool = nullptr;      // unsorted SMEM pool (append order)
+    bwams_smem_t *d_sorted = nullptr;    // (rid, m, n) order
+    uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
+    uint32_t *d_vals = nullptr, *d_vals2 = nullptr;
+    bwams::Round2Work *d_work2 = nullptr;
+    int64_t *d_sa_off = nullptr;         // max_smem + 1
+    int64_t *d_sa_cnt = nullptr;         // max_smem + 1
+    int64_t *d_sa_coord = nullptr;
+    void *d_tmp = nullptr;               // rocPRIM temporary storage
+    size_t tmp_bytes = 0;
+    bwams::DevCounters *d_ctr = nullptr;
+    bwams::DevCounters *h_ctr = nullptr;  // pinned host mirror
+    // per-lane scratch of the SMEM search (previous-interval lists)
+    int64_t *d_prev_k = nullptr, *d_prev_l = nullptr, *d_prev_s = nullptr;
+    int32_t *d_prev_n = nullptr;
+    int64_t prev_threads = 0;
+    int prev_cap = 0;
+
+    int64_t n_smem = 0, n_sa = 0;
+    bool seed_done = false, with_sa = false;
+
+    // extension buffers
+    bwams_seqpair_t *d_pairs = nullptr;
+    uint8_t *d_ref = nullptr, *d_qer = nullptr;
+    int64_t cap_pairs = 0, cap_ref = 0, cap_qer = 0, n_pairs = 0;
+    int max_qlen = 0;
+
+    hipEvent_t ev[10] = {};
+    bwams_stats_t stats{};
+};

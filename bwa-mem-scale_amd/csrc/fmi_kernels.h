@@ -1,0 +1,43 @@
+// fmi_kernels.h — launch wrappers of the FM-index kernels (fmi_seed.hip, fmi_sal.hip).
+#pragma once
+#include "common.h"
+
+namespace bwams {
+
+struct SeedLaunch {
+    DevFmi fmi;
+    const uint8_t *enc;
+    const int64_t *cum;
+    const uint8_t *skip;          // may be nullptr
+    int64_t nseq;
+    int min_seed_len;
+    bwams_smem_t *pool;
+    int64_t pool_cap;
+    DevCounters *ctr;
+    int64_t *prev_k, *prev_l, *prev_s;
+    int32_t *prev_n;
+    int prev_cap;                 // entries per lane
+    int64_t prev_threads;         // lanes the scratch was sized for
+};
+
+// grid sizing shared by batch_create (scratch) and the launches
+int seed_block_threads();
+int64_t seed_max_threads(int cu_count);
+
+// round 1: every pivot of every read (getSMEMsAllPosOneThread)
+void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st);
+// round 2: build the work list from round-1 SMEMs, then one pivot per item (getSMEMsOnePosOneThread)
+void launch_smem_round2(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
+                        int split_width, int cu_count, hipStream_t st);
+// round 3: forward-only seeds (bwtSeedStrategyAllPosOneThread)
+void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st);
+
+// sort keys / gather / SA lookup
+void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, hipStream_t st);
+void launch_gather_sorted(const bwams_smem_t *pool, const uint32_t *order, int64_t n, bwams_smem_t *sorted,
+                          int64_t *sa_cnt, int max_occ, hipStream_t st);
+void launch_sa_lookup(const DevFmi &f, const bwams_smem_t *sorted, int64_t n_smem, const int64_t *sa_off,
+                      int64_t *coord, int64_t coord_cap, int max_occ, DevCounters *ctr, int cu_count,
+                      hipStream_t st);
+
+}  // namespace bwams

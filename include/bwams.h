@@ -1,0 +1,158 @@
+/*
+ * bwams.h — C-ABI of the MI355X-native BWA-MEM seed-and-extend hot path.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  Each entry point names
+ * the reference interface it replaces (file:line under /root/reference) — these
+ * are exactly the call sites a reference maintainer re-binds.
+ *
+ * Conventions
+ *   - every function returns 0 (BWAMS_OK) or a negative error code; the library
+ *     never exits the process and never falls back to a CPU path.  A missing or
+ *     unusable GPU is BWAMS_ERR_DEVICE.
+ *   - the caller owns all host buffers; the library owns device memory.
+ *   - output order is input order (SMEMs sorted by (rid, m, n) as
+ *     mem_collect_smem leaves them; extension results written back in place).
+ *   - a handle is bound to one GPU and one HIP stream; calls on one handle are
+ *     serialised by the caller (the reference has one mem_process_seqs call in
+ *     flight per pipeline slot, src/fastmap.cpp:475-491).  Use one handle per
+ *     host thread / per GPU.
+ */
+#ifndef BWAMS_H
+#define BWAMS_H
+
+#include <stdint.h>
+#include "bwams_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BWAMS_OK               0
+#define BWAMS_ERR_DEVICE      -1   /* no usable gfx950 device / HIP runtime error */
+#define BWAMS_ERR_IO          -2   /* index file missing or malformed */
+#define BWAMS_ERR_ARG         -3   /* invalid argument */
+#define BWAMS_ERR_CAPACITY    -4   /* an output buffer is too small; *n_* holds the need */
+#define BWAMS_ERR_NOMEM       -5
+#define BWAMS_ERR_UNSUPPORTED -6
+
+typedef struct bwams_index bwams_index_t;   /* FM-index resident in one GPU's HBM */
+typedef struct bwams_batch bwams_batch_t;   /* stream + device work buffers for one chunk of reads */
+
+const char *bwams_strerror(int code);
+/* Text of the last HIP / IO error on this thread. */
+const char *bwams_last_error(void);
+int bwams_device_count(int *n);
+
+/* ---------------------------------------------------------------- index ---- */
+
+/* Host-side description of an FM-index, as FMI_search holds it after
+ * load_index (src/FMI_search.cpp:1251-1370): count[] already has the +1. */
+typedef struct bwams_fmi_desc {
+    int64_t ref_seq_len;               /* 2*l_pac + 1 */
+    int64_t count[5];
+    const bwams_cp_occ_t *cp_occ;      /* (ref_seq_len >> 6) + 1 blocks */
+    const int8_t  *sa_ms_byte;         /* (ref_seq_len >> 3) + 1 */
+    const uint32_t *sa_ls_word;        /* (ref_seq_len >> 3) + 1 */
+    int64_t sentinel_index;
+    const uint8_t *ref_0123;           /* 2*l_pac bytes or NULL (load_ref_string, src/fastmap.cpp:813) */
+} bwams_fmi_desc_t;
+
+/* Replaces FMI_search::load_index (src/FMI_search.cpp:1251) + load_ref_string
+ * (src/fastmap.cpp:813): reads <prefix>.bwt.2bit.64 (and <prefix>.0123 when
+ * present) and uploads them to GPU `device`. */
+int bwams_index_open(const char *prefix, int device, bwams_index_t **out);
+
+/* Same, from arrays already in host memory (e.g. the reference's own loaded
+ * FMI_search members or its /dev/shm segments, src/bwa_shm.cpp). */
+int bwams_index_from_host(const bwams_fmi_desc_t *desc, int device, bwams_index_t **out);
+
+/* Same, adopting arrays that already live in this GPU's memory (not copied, not
+ * freed by close).  Lets an on-device index builder hand over without PCIe. */
+int bwams_index_from_device(const bwams_fmi_desc_t *desc_with_device_pointers, int device,
+                            bwams_index_t **out);
+
+int bwams_index_close(bwams_index_t *idx);
+int64_t bwams_index_bytes(const bwams_index_t *idx);
+
+/* ---------------------------------------------------------------- batch ---- */
+
+/* Work buffers sized for up to max_reads reads / max_bases bases per call.
+ * max_smem / max_sa bound the SMEM and SA-coordinate outputs (0 = library
+ * default: 24 SMEMs and 64 coordinates per read on average). */
+int bwams_batch_create(bwams_index_t *idx, int64_t max_reads, int64_t max_bases,
+                       int64_t max_smem, int64_t max_sa, bwams_batch_t **out);
+int bwams_batch_destroy(bwams_batch_t *b);
+
+/* -------------------------------------------------------------- seeding ---- */
+
+/* One-call seeding on host buffers.  Replaces, for a whole chunk,
+ *   mem_collect_smem            (src/bwamem.cpp:648-786; called at :1321) and
+ *   get_sa_entries_prefetch     (src/FMI_search.cpp:2261; called at src/bwamem.cpp:861).
+ *
+ *   enc_qdb   concatenated reads, one base code per byte (0..3, >=4 = N)
+ *   cum_len   nseq+1 offsets into enc_qdb (query_cum_len_ar, widened to 64 bit)
+ *   skip      optional nseq flags; non-zero = read resolved by the exact-match
+ *             filter, not seeded (seq_[l].perfect.exist, src/bwamem.cpp:674-689)
+ *   smem_out  SMEMs of all reads ordered by (rid, m, n); smem_cap slots
+ *   sa_coord  reference coordinates of each SMEM's sampled occurrences, in SMEM
+ *             order; SMEM i owns sa_coord[sa_off[i] .. sa_off[i+1])
+ *   sa_off    n_smem+1 entries (so at least smem_cap+1 slots)
+ * sa_coord/sa_off may be NULL to skip the SA step. */
+int bwams_seed_fmi(bwams_batch_t *b,
+                   const uint8_t *enc_qdb, const int64_t *cum_len, const uint8_t *skip,
+                   int64_t nseq, const bwams_seed_opt_t *opt,
+                   bwams_smem_t *smem_out, int64_t smem_cap, int64_t *n_smem,
+                   int64_t *sa_coord, int64_t sa_cap, int64_t *sa_off, int64_t *n_sa);
+
+/* The same in three steps, so that reads stay resident in HBM across calls and
+ * uploads/downloads can overlap other work: upload -> run (asynchronous on the
+ * batch's stream) -> fetch (synchronises). */
+int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc_qdb, const int64_t *cum_len,
+                      const uint8_t *skip, int64_t nseq);
+int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa);
+int bwams_seed_counts(bwams_batch_t *b, int64_t *n_smem, int64_t *n_sa);   /* synchronises */
+int bwams_seed_fetch(bwams_batch_t *b, bwams_smem_t *smem_out, int64_t smem_cap,
+                     int64_t *sa_coord, int64_t sa_cap, int64_t *sa_off);
+
+/* ------------------------------------------------------------ extension ---- */
+
+/* Banded Smith-Waterman seed extension over n tasks.  Replaces the six call
+ * sites BandedPairWiseSW::{scalarBandedSWAWrapper,getScores16,getScores8}
+ * (src/bwamem.cpp:3229,3297,3366,3445,3510,3581): fills score, tle, gtle, qle,
+ * gscore, max_off of every pair in place with the values of scalarBandedSWA
+ * (src/bandedSWA.cpp:116-237).  ref/qer are the flat seqBufRef/seqBufQer byte
+ * buffers of ref_bytes/qer_bytes bytes. */
+int bwams_bsw_extend(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n,
+                     const uint8_t *ref, int64_t ref_bytes,
+                     const uint8_t *qer, int64_t qer_bytes,
+                     int32_t w, const bwams_sw_opt_t *opt);
+
+/* Resident form: upload once, run (async), fetch. */
+int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n,
+                     const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer, int64_t qer_bytes);
+int bwams_bsw_run(bwams_batch_t *b, int32_t w, const bwams_sw_opt_t *opt);
+int bwams_bsw_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n);
+
+/* ------------------------------------------------------------- counters ---- */
+
+/* Event counts of the last seed run on this batch (the same events the oracle
+ * counts) and per-kernel device times from HIP events recorded
+ * on the batch's stream.  Synchronises. */
+typedef struct bwams_stats {
+    int64_t n_ext;            /* backwardExt evaluations */
+    int64_t n_ext_blocks;     /* CP_OCC blocks they touch: 1 when k and k+s share a block, else 2 */
+    int64_t n_sa_lookups;
+    int64_t n_lf_steps;
+    int64_t n_smem[3];        /* SMEMs from round 1, 2, 3 */
+    int64_t bsw_cells;        /* DP cells evaluated by the last bsw run */
+    float   ms_smem_r1, ms_smem_r2, ms_smem_r3, ms_sort, ms_sal, ms_seed_total;
+    float   ms_bsw;
+} bwams_stats_t;
+int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
+
+int bwams_batch_sync(bwams_batch_t *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BWAMS_H */

@@ -1,0 +1,169 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs.  Integer work: every comparison is bit-exact."""
+import numpy as np
+import pytest
+
+from bwams import capi, fmindex, simulate
+from oracle import loader
+from util import assert_pairs_equal, make_pairs, toy, toy_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_toy():
+    capi.lib()
+    g, idx = toy(200000, seed=13)
+    ix = capi.Index.from_host(idx, 0)
+    yield g, idx, ix
+    ix.close()
+
+
+def _seed_both(idx, ix, reads, opt=None, skip=None, oracle_counters=None):
+    enc, cum = simulate.flatten_reads(reads)
+    o = loader.OracleFMI(idx)
+    oopt = loader.default_seed_opt()
+    gopt = capi.default_seed_opt()
+    if opt:
+        for k, v in opt.items():
+            setattr(oopt, k, v)
+            setattr(gopt, k, v)
+    want = o.collect_smem(enc, cum, oopt, skip=skip, counters=oracle_counters)
+    wcoord, woff = o.sa_lookup(want, oopt.max_occ, counters=oracle_counters)
+    b = capi.Batch(ix, max(len(cum) - 1, 1), max(int(cum[-1]), 1), max_smem=len(want) + 4096,
+                   max_sa=len(wcoord) + 4096)
+    got, coord, off = b.seed(enc, cum, gopt, skip=skip)
+    st = b.stats()
+    b.close()
+    return want, wcoord, woff, got, coord, off, st
+
+
+def test_smem_and_sa_match_oracle(gpu_toy):
+    g, idx, ix = gpu_toy
+    reads, _, _ = simulate.make_reads(g, 4000, seed=5)
+    ctr = loader.Counters()
+    want, wcoord, woff, got, coord, off, st = _seed_both(idx, ix, reads, oracle_counters=ctr)
+    assert len(got) == len(want)
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(off, woff)
+    assert np.array_equal(coord, wcoord)
+    # the kernel performs exactly the extension / LF events the reference algorithm does
+    assert st.n_ext == ctr.n_ext and st.n_ext_blocks == ctr.n_ext_blocks
+    assert st.n_lf_steps == ctr.n_lf_steps and st.n_sa_lookups == ctr.n_sa_lookups
+    assert list(st.n_smem) == list(ctr.n_smem)
+
+
+@pytest.mark.parametrize("opt", [
+    {"min_seed_len": 10}, {"max_mem_intv": 0}, {"split_width": 50, "split_factor": 1.0},
+    {"max_occ": 3}, {"min_seed_len": 30, "max_mem_intv": 5},
+])
+def test_seed_options(gpu_toy, opt):
+    g, idx, ix = gpu_toy
+    reads, _, _ = simulate.make_reads(g, 1500, seed=8)
+    want, wcoord, woff, got, coord, off, _ = _seed_both(idx, ix, reads, opt)
+    assert np.array_equal(got, want) or all(np.array_equal(got[f], want[f]) for f in ("rid", "m", "n", "k", "l", "s"))
+    assert np.array_equal(off, woff) and np.array_equal(coord, wcoord)
+
+
+def test_ragged_and_degenerate_reads(gpu_toy):
+    g, idx, ix = gpu_toy
+    rng = np.random.default_rng(3)
+    reads = []
+    for L in [0, 1, 5, 18, 19, 20, 37, 151, 250, 400, 1000]:
+        st = int(rng.integers(0, len(g) - 1100))
+        r = g[st:st + L].copy()
+        reads.append(r)
+    reads.append(np.full(60, 4, np.uint8))                    # all N
+    r = g[5000:5150].copy(); r[[0, 30, 31, 149]] = 4; reads.append(r)   # N at the ends and inside
+    r = g[7000:7150].copy(); r[75] = (r[75] + 1) & 3; reads.append(r)   # one mismatch
+    reads.append(simulate.revcomp(g[9000:9150]))              # reverse strand
+    reads.append(np.zeros(100, np.uint8))                     # poly-A: huge intervals
+    want, wcoord, woff, got, coord, off, _ = _seed_both(idx, ix, reads)
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(off, woff) and np.array_equal(coord, wcoord)
+
+
+def test_skip_flags_and_empty_batch(gpu_toy):
+    g, idx, ix = gpu_toy
+    reads, _, _ = simulate.make_reads(g, 600, seed=21)
+    skip = (np.arange(600) % 3 == 0).astype(np.uint8)
+    want, wcoord, woff, got, coord, off, _ = _seed_both(idx, ix, reads, skip=skip)
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(coord, wcoord)
+    assert not np.any(skip[got["rid"]])
+    b = capi.Batch(ix, 8, 1200)
+    sm, coord, off = b.seed(np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    assert len(sm) == 0 and len(coord) == 0 and list(off) == [0]
+    b.close()
+
+
+def test_capacity_error_is_reported_not_truncated(gpu_toy):
+    g, idx, ix = gpu_toy
+    reads, _, _ = simulate.make_reads(g, 500, seed=2)
+    enc, cum = simulate.flatten_reads(reads)
+    b = capi.Batch(ix, 500, int(cum[-1]), max_smem=100, max_sa=100)
+    with pytest.raises(capi.BwamsError) as e:
+        b.seed(enc, cum)
+    assert e.value.code == -4
+    b.close()
+
+
+def test_index_file_path(gpu_toy, tmp_path):
+    g, idx, ix = gpu_toy
+    fmindex.write_index(str(tmp_path / "t"), idx)
+    ix2 = capi.Index.open(str(tmp_path / "t"), 0)
+    assert ix2.nbytes == ix.nbytes
+    reads, _, _ = simulate.make_reads(g, 300, seed=4)
+    want, wcoord, woff, got, coord, off, _ = _seed_both(idx, ix2, reads)
+    assert np.array_equal(got["k"], want["k"]) and np.array_equal(coord, wcoord)
+    ix2.close()
+
+
+@pytest.mark.parametrize("w", [100, 200, 5])
+@pytest.mark.parametrize("end_bonus,zdrop", [(5, 100), (0, 0), (5, 15)])
+def test_bsw_matches_oracle(gpu_toy, w, end_bonus, zdrop):
+    _, _, ix = gpu_toy
+    pairs, ref, qer = make_pairs(3000, seed=w * 7 + end_bonus + zdrop)
+    oopt = loader.default_sw_opt(end_bonus); oopt.zdrop = zdrop
+    gopt = capi.default_sw_opt(end_bonus); gopt.zdrop = zdrop
+    want, cells = loader.bsw_pairs(pairs, ref, qer, w, oopt)
+    b = capi.Batch(ix, 8, 1200)
+    got = b.bsw(pairs, ref, qer, w, gopt)
+    st = b.stats()
+    b.close()
+    assert_pairs_equal(got, want, f"w={w}")
+    assert st.bsw_cells == cells
+    # inputs are untouched
+    for f in ("idr", "idq", "id", "len1", "len2", "h0", "seqid", "regid"):
+        assert np.array_equal(got[f], pairs[f])
+
+
+def test_bsw_long_queries_and_edges(gpu_toy):
+    _, _, ix = gpu_toy
+    pairs, ref, qer = make_pairs(400, seed=77, max_q=700, max_extra_t=300, h0_max=600)
+    pairs["len1"][::17] = 0                                   # empty targets
+    want, _ = loader.bsw_pairs(pairs, ref, qer, 100)
+    b = capi.Batch(ix, 8, 1200)
+    got = b.bsw(pairs, ref, qer, 100)
+    assert_pairs_equal(got, want, "long")
+    # no pairs at all
+    empty = b.bsw(pairs[:0], ref, qer, 100)
+    assert len(empty) == 0
+    b.close()
+
+
+def test_bsw_scoring_matrix_variants(gpu_toy):
+    _, _, ix = gpu_toy
+    pairs, ref, qer = make_pairs(800, seed=5)
+    for (a, bb, od, ed, oi, ei) in [(2, 3, 5, 2, 4, 1), (1, 1, 1, 1, 1, 1), (3, 7, 10, 3, 8, 2)]:
+        oopt = loader.default_sw_opt(5, a, bb); gopt = capi.default_sw_opt(5, a, bb)
+        for o in (oopt, gopt):
+            o.o_del, o.e_del, o.o_ins, o.e_ins = od, ed, oi, ei
+        want, _ = loader.bsw_pairs(pairs, ref, qer, 100, oopt)
+        b = capi.Batch(ix, 8, 1200)
+        got = b.bsw(pairs, ref, qer, 100, gopt)
+        b.close()
+        assert_pairs_equal(got, want, f"mat {a},{bb}")

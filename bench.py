@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MI355X seed-and-extend hot path.
+
+One "step" = one pass of the hot path over one resident batch of synthetic reads:
+  FM-index seeding (SMEM rounds 1-3 -> (rid,m,n) sort -> SA lookup) + banded-SW
+  extension of the seeds' left/right tasks, all on the GPU through the C-ABI,
+with reads, index and extension tasks already resident in HBM when the clock starts.
+Workload = BASELINE.json configs[1] (1M x 150 bp single-end, FM-index only, 1 GPU);
+GRCh38 is not available offline, so the index is built (on the GPU) over a seeded
+synthetic genome whose size is stated in the output.  With --gpus N every rank
+holds a replica of the index and its own 1M-read shard (weak scaling, no collective
+on the data path).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the definitions of
+roofline.achieved (algorithmic bytes) and cpu_baseline.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "bwa-mem-scale_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(idx_host_arrays, reads, n_sample, threads):
+    """Time the oracle (CPU restatement, kind="port") on a bounded sample of the same reads:
+    seeding + SA lookup + extension of the same task construction.  The oracle is the checker;
+    it is timed here only as the reported CPU column."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from bwams import pairs as pairs_mod, simulate
+    from oracle import loader
+
+    o = loader.OracleFMI(idx_host_arrays)
+    sample = reads[:n_sample]
+    chunks = np.array_split(np.arange(len(sample)), threads)
+
+    def work(ix):
+        enc, cum = simulate.flatten_reads(sample[ix])
+        sm = o.collect_smem(enc, cum)
+        coord, off = o.sa_lookup(sm, 500)
+        prs, rb, qb = pairs_mod.pairs_from_seeds(sample[ix], sm, coord, off, idx_host_arrays.ref_0123)
+        loader.bsw_pairs(prs, rb, qb, 100)
+        return len(prs)
+
+    # one timed region around everything (pair construction is host glue on both sides and is small)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, chunks))
+    dt = time.perf_counter() - t0
+    return len(sample) / dt / 1e6, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BWAMS_GENOME_MBP", "512")))
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=60_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from bwams import capi, fmindex, pairs as pairs_mod, simulate
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists in the product path)")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    if not os.path.exists(capi.LIB_PATH):
+        if rank == 0:
+            capi.build()
+        if world > 1:
+            dist.barrier()
+    capi.lib()
+
+    # ---------------- inputs (untimed) ----------------
+    t0 = time.time()
+    G = int(args.genome_mbp * 1e6)
+    genome = simulate.make_genome(G, seed=2024)
+    log(f"genome {G/1e6:.0f} Mbp generated in {time.time()-t0:.1f}s")
+    t0 = time.time()
+    idx_dev = fmindex.build_fmindex(genome, device=dev, keep_ref=True)
+    torch.cuda.synchronize()
+    log(f"FM-index built on GPU in {time.time()-t0:.1f}s: text {idx_dev.ref_seq_len/1e9:.2f} G rows, "
+        f"CP_OCC {idx_dev.cp_occ.numel()*8/2**30:.2f} GiB")
+    ix = capi.Index.from_device(idx_dev, local)
+    torch.cuda.empty_cache()
+
+    R = args.reads
+    t0 = time.time()
+    reads, _, _ = simulate.make_reads(genome, R, seed=12345 + rank)
+    enc, cum = simulate.flatten_reads(reads)
+    log(f"{R} reads generated in {time.time()-t0:.1f}s")
+
+    batch = capi.Batch(ix, R, R * reads.shape[1], max_smem=32 * R, max_sa=128 * R)
+    batch.seed_upload(enc, cum)
+    # setup pass: seeds -> extension tasks (host glue, untimed), tasks uploaded once
+    batch.seed_run(with_sa=True)
+    sm, coord, off = batch.seed_fetch()
+    ref_host = np.concatenate([genome, (3 - genome[::-1]).astype(np.uint8)])
+    prs, rbuf, qbuf = pairs_mod.pairs_from_seeds(reads, sm, coord, off, ref_host)
+    batch.bsw_upload(prs, rbuf, qbuf)
+    log(f"setup: {len(sm)} SMEMs, {len(coord)} SA coords, {len(prs)} extension tasks")
+
+    seed_opt = capi.default_seed_opt()
+    sw_opt = capi.default_sw_opt()
+
+    def step():
+        batch.seed_run(seed_opt, with_sa=True)
+        batch.bsw_run(100, sw_opt)
+
+    for _ in range(args.warmup):
+        step()
+    batch.sync()
+
+    # ---------------- timed region ----------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    per_step = []
+    for _ in range(args.steps):
+        step()
+        st = batch.stats()                 # synchronises the batch stream; part of the timed region
+        per_step.append(st)
+    batch.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------- report ----------------
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = R * world * args.steps / elapsed / 1e6
+        st = per_step[-1]
+        r1_ms = float(np.mean([s.ms_smem_r1 for s in per_step]))
+        # algorithmic bytes of the round-1 search kernel per launch:
+        # 64 B per CP_OCC block an extension touches + reads in (1 B/base) + SMEMs out (40 B)
+        r1_bytes = 64 * st.n_blk_round[0] + int(cum[-1]) + 40 * st.n_smem[0]
+        achieved = r1_bytes / (r1_ms * 1e-3) / 1e9
+        all_bytes = (64 * st.n_ext_blocks + int(cum[-1]) * 3 + 40 * sum(st.n_smem) +
+                     64 * st.n_lf_steps + 13 * st.n_sa_lookups)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("genome_mbp") == args.genome_mbp and tj.get("reads") == R:
+                    traffic = tj.get("smem_round1_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mreads/sec aligned, 150bp SE (FM-index seeding + banded-SW extension on GPU)",
+            "value": round(value, 4),
+            "unit": "Mreads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64 intervals / int32 DP",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{R} synthetic 150bp SE reads per GPU vs synthetic {args.genome_mbp:.0f} Mbp genome "
+                            f"(GRCh38 unavailable offline), FM-index only (no ERT/FMA/EMF); step = SMEM r1-r3 + sort "
+                            f"+ SA lookup + banded-SW of one-seed-per-read left/right tasks; chaining not in step",
+                "genome_mbp": args.genome_mbp,
+                "index_bytes": ix.nbytes,
+                "reads_per_gpu": R,
+                "bsw_tasks": int(len(prs)),
+                "parallelism": f"reads sharded x{world}, index replicated",
+            },
+            "stage_ms": {
+                "smem_round1": round(r1_ms, 3),
+                "smem_round2": round(float(np.mean([s.ms_smem_r2 for s in per_step])), 3),
+                "smem_round3": round(float(np.mean([s.ms_smem_r3 for s in per_step])), 3),
+                "sort": round(float(np.mean([s.ms_sort for s in per_step])), 3),
+                "sa_lookup": round(float(np.mean([s.ms_sal for s in per_step])), 3),
+                "seed_total": round(float(np.mean([s.ms_seed_total for s in per_step])), 3),
+                "bsw": round(float(np.mean([s.ms_bsw for s in per_step])), 3),
+            },
+            "events_per_read": {
+                "backward_ext": round(st.n_ext / R, 2),
+                "backward_ext_by_round": [round(x / R, 2) for x in st.n_ext_round],
+                "cp_occ_blocks_by_round": [round(x / R, 2) for x in st.n_blk_round],
+                "cp_occ_blocks": round(st.n_ext_blocks / R, 2),
+                "smems": round(sum(st.n_smem) / R, 2),
+                "sa_lookups": round(st.n_sa_lookups / R, 2),
+                "lf_steps": round(st.n_lf_steps / R, 2),
+                "bsw_cells": round(st.bsw_cells / R, 1),
+                "algorithmic_bytes": round(all_bytes / R, 1),
+            },
+            "roofline": {
+                "kernel": "smem_search_kernel<ALL_POS> (SMEM round 1)",
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "bytes_per_launch": int(r1_bytes),
+                "launch_ms": round(r1_ms, 3),
+            },
+        }
+        if not args.no_cpu_baseline:
+            log("timing the CPU oracle on a sample (cpu_baseline)...")
+            threads = min(16, os.cpu_count() or 1)
+            n_s = min(args.cpu_sample, R)
+            # host copy of the index for the oracle
+            host = fmindex.FMIndex(
+                idx_dev.ref_seq_len, idx_dev.count,
+                idx_dev.cp_occ.cpu().numpy().view(np.uint64),
+                idx_dev.sa_ms_byte.cpu().numpy(), idx_dev.sa_ls_word.cpu().numpy().view(np.uint32),
+                idx_dev.sentinel_index, ref_host)
+            v, dt = cpu_baseline(host, reads, n_s, threads)
+            out["cpu_baseline"] = {
+                "value": round(v, 5), "unit": "Mreads/s", "cores": threads, "kind": "port",
+                "sample": f"first {n_s} reads of the same batch, same index; oracle seeding+SA+extension, "
+                          f"{dt:.1f}s wall on {threads} threads",
+            }
+        print(json.dumps(out), flush=True)
+    batch.close()
+    ix.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,7 @@ class FmiDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_ext", C.c_int64), ("n_ext_blocks", C.c_int64), ("n_sa_lookups", C.c_int64),
                 ("n_lf_steps", C.c_int64), ("n_smem", C.c_int64 * 3), ("bsw_cells", C.c_int64),
+                ("n_ext_round", C.c_int64 * 3), ("n_blk_round", C.c_int64 * 3),
                 ("ms_smem_r1", C.c_float), ("ms_smem_r2", C.c_float), ("ms_smem_r3", C.c_float),
                 ("ms_sort", C.c_float), ("ms_sal", C.c_float), ("ms_seed_total", C.c_float),
                 ("ms_bsw", C.c_float)]

@@ -374,20 +374,26 @@ int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
     a.prev_threads = b->prev_threads;
     const int split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
 
+    // events: 0 start | 8,9 round-1 kernel | 10,11 round-2 kernel | 12,13 round-3 kernel | 3 rounds done
     BWAMS_HIP(hipMemsetAsync(b->d_ctr, 0, sizeof(DevCounters), st));
     BWAMS_HIP(hipEventRecord(b->ev[0], st));
-    if (b->nseq > 0) {
-        launch_smem_round1(a, b->cu_count, st);
-        BWAMS_HIP(hipEventRecord(b->ev[1], st));
-        launch_smem_round2(a, b->d_work2, b->max_smem, split_len, opt->split_width, b->cu_count, st);
-        BWAMS_HIP(hipEventRecord(b->ev[2], st));
-        SeedLaunch a3 = a;
-        a3.min_seed_len = opt->min_seed_len + 1;
-        if (opt->max_mem_intv > 0) launch_smem_round3(a3, opt->max_mem_intv, b->cu_count, st);
-        BWAMS_HIP(hipEventRecord(b->ev[3], st));
-    } else {
-        for (int i = 1; i <= 3; ++i) BWAMS_HIP(hipEventRecord(b->ev[i], st));
-    }
+    launch_mark(b->d_ctr, 0, st);
+    BWAMS_HIP(hipEventRecord(b->ev[8], st));
+    if (b->nseq > 0) launch_smem_round1(a, b->cu_count, st);
+    BWAMS_HIP(hipEventRecord(b->ev[9], st));
+    launch_mark(b->d_ctr, 1, st);
+    if (b->nseq > 0) launch_round2_work(a, b->d_work2, b->max_smem, split_len, opt->split_width, b->cu_count, st);
+    BWAMS_HIP(hipEventRecord(b->ev[10], st));
+    if (b->nseq > 0) launch_smem_round2(a, b->d_work2, b->cu_count, st);
+    BWAMS_HIP(hipEventRecord(b->ev[11], st));
+    launch_mark(b->d_ctr, 2, st);
+    SeedLaunch a3 = a;
+    a3.min_seed_len = opt->min_seed_len + 1;
+    BWAMS_HIP(hipEventRecord(b->ev[12], st));
+    if (b->nseq > 0 && opt->max_mem_intv > 0) launch_smem_round3(a3, opt->max_mem_intv, b->cu_count, st);
+    BWAMS_HIP(hipEventRecord(b->ev[13], st));
+    launch_mark(b->d_ctr, 3, st);
+    BWAMS_HIP(hipEventRecord(b->ev[3], st));
     BWAMS_HIP(hipGetLastError());
     // the SMEM count sizes the sort: one small read-back
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
@@ -582,14 +588,18 @@ int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out) {
     s.n_smem[1] = (int64_t)(c.n_after_r2 - c.n_after_r1);
     s.n_smem[2] = (int64_t)(c.n_smem_total - c.n_after_r2);
     s.bsw_cells = (int64_t)c.bsw_cells;
+    for (int i = 0; i < 3; ++i) {
+        s.n_ext_round[i] = (int64_t)(c.ext_after[i] - (i ? c.ext_after[i - 1] : 0));
+        s.n_blk_round[i] = (int64_t)(c.blk_after[i] - (i ? c.blk_after[i - 1] : 0));
+    }
     auto el = [&](int a, int bb, float *dst) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev[a], b->ev[bb]) == hipSuccess) *dst = ms;
     };
     if (b->seed_done) {
-        el(0, 1, &s.ms_smem_r1);
-        el(1, 2, &s.ms_smem_r2);
-        el(2, 3, &s.ms_smem_r3);
+        el(8, 9, &s.ms_smem_r1);
+        el(10, 11, &s.ms_smem_r2);
+        el(12, 13, &s.ms_smem_r3);
         el(3, 4, &s.ms_sort);
         el(4, 5, &s.ms_sal);
         el(0, 5, &s.ms_seed_total);

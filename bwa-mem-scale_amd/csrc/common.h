@@ -46,7 +46,7 @@ struct DevCounters {
     unsigned long long n_work2;          // round-2 work items
     unsigned long long overflow;         // SMEM pool overflow flag / needed size
     unsigned long long bsw_cells;
-    unsigned long long pad_[5];
+    unsigned long long ext_after[3], blk_after[3];   // n_ext / n_ext_blocks when round 1, 2, 3 ended
 };
 
 // banded-SW parameters in kernel form (max_sc = max entry of mat)
@@ -118,6 +118,6 @@ struct bwams_batch {
     int64_t cap_pairs = 0, cap_ref = 0, cap_qer = 0, n_pairs = 0;
     int max_qlen = 0;
 
-    hipEvent_t ev[10] = {};
+    hipEvent_t ev[16] = {};
     bwams_stats_t stats{};
 };

@@ -24,11 +24,14 @@ struct SeedLaunch {
 int seed_block_threads();
 int64_t seed_max_threads(int cu_count);
 
+// between rounds: snapshot counters (which = 1, 2, 3 after that round; 0 = start) and reset the work cursor
+void launch_mark(DevCounters *ctr, int which, hipStream_t st);
 // round 1: every pivot of every read (getSMEMsAllPosOneThread)
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st);
 // round 2: build the work list from round-1 SMEMs, then one pivot per item (getSMEMsOnePosOneThread)
-void launch_smem_round2(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
+void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
                         int split_width, int cu_count, hipStream_t st);
+void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st);
 // round 3: forward-only seeds (bwtSeedStrategyAllPosOneThread)
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st);
 

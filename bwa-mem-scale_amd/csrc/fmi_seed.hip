@@ -351,6 +351,10 @@ __global__ void round2_work_kernel(const bwams_smem_t *pool, DevCounters *ctr, R
 __global__ void mark_kernel(DevCounters *ctr, int which) {
     if (which == 1) ctr->n_after_r1 = ctr->n_smem_total;
     if (which == 2) ctr->n_after_r2 = ctr->n_smem_total;
+    if (which >= 1 && which <= 3) {
+        ctr->ext_after[which - 1] = ctr->n_ext;
+        ctr->blk_after[which - 1] = ctr->n_ext_blocks;
+    }
     ctr->work_head = 0;
 }
 
@@ -461,23 +465,24 @@ int grid_for(int64_t n_items, int cu_count) {
 int seed_block_threads() { return kBlock; }
 int64_t seed_max_threads(int cu_count) { return (int64_t)cu_count * kBlocksPerCU * kBlock; }
 
+void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
+
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st) {
-    mark_kernel<<<1, 1, 0, st>>>(a.ctr, 0);
     smem_search_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, 0, st>>>(a, nullptr);
-    mark_kernel<<<1, 1, 0, st>>>(a.ctr, 1);
 }
 
-void launch_smem_round2(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
+void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
                         int split_width, int cu_count, hipStream_t st) {
     round2_work_kernel<<<cu_count * 4, 256, 0, st>>>(a.pool, a.ctr, work, work_cap, split_len, split_width);
+}
+
+void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     // the number of items is only known on the device: launch the persistent grid at chip size
     smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, 0, st>>>(a, work);
-    mark_kernel<<<1, 1, 0, st>>>(a.ctr, 2);
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {
     seed_strategy_kernel<<<grid_for(a.nseq, cu_count), kBlock, 0, st>>>(a, max_intv);
-    mark_kernel<<<1, 1, 0, st>>>(a.ctr, 3);
 }
 
 void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, hipStream_t st) {

@@ -137,7 +137,8 @@ int bwams_bsw_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n);
 
 /* Event counts of the last seed run on this batch (the same events the oracle
  * counts) and per-kernel device times from HIP events recorded
- * on the batch's stream.  Synchronises. */
+ * on the batch's stream (ms_smem_r1/r2/r3 bracket the search kernel of that round
+ * alone).  Synchronises. */
 typedef struct bwams_stats {
     int64_t n_ext;            /* backwardExt evaluations */
     int64_t n_ext_blocks;     /* CP_OCC blocks they touch: 1 when k and k+s share a block, else 2 */
@@ -145,6 +146,8 @@ typedef struct bwams_stats {
     int64_t n_lf_steps;
     int64_t n_smem[3];        /* SMEMs from round 1, 2, 3 */
     int64_t bsw_cells;        /* DP cells evaluated by the last bsw run */
+    int64_t n_ext_round[3];   /* n_ext split by round */
+    int64_t n_blk_round[3];   /* n_ext_blocks split by round */
     float   ms_smem_r1, ms_smem_r2, ms_smem_r3, ms_sort, ms_sal, ms_seed_total;
     float   ms_bsw;
 } bwams_stats_t;

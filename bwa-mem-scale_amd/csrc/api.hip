@@ -82,6 +82,10 @@ static int index_finish(bwams_index *ix, const bwams_fmi_desc_t *d) {
     ix->fmi.sa_ms = reinterpret_cast<const int8_t *>(ix->d_ms);
     ix->fmi.sa_ls = reinterpret_cast<const uint32_t *>(ix->d_ls);
     ix->fmi.ref = reinterpret_cast<const uint8_t *>(ix->d_ref);
+    if (d->ref_seq_len >= ((int64_t)1 << 36)) {
+        set_last_error("text longer than 2^36 rows is not supported by the 36-bit interval packing");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
     for (int i = 0; i < 5; ++i) ix->fmi.count[i] = d->count[i];
     ix->fmi.sentinel = d->sentinel_index;
     ix->fmi.ref_seq_len = d->ref_seq_len;
@@ -113,7 +117,8 @@ int bwams_index_from_host(const bwams_fmi_desc_t *d, int device, bwams_index_t *
         BWAMS_HIP(hipMemcpy(ix->d_ref, d->ref_0123, b_ref, hipMemcpyHostToDevice));
     }
     ix->bytes = (int64_t)(b_cp + b_ms + b_ls + b_ref);
-    index_finish(ix, d);
+    int frc = index_finish(ix, d);
+    if (frc) { bwams_index_close(ix); return frc; }
     *out = ix;
     return BWAMS_OK;
 }
@@ -135,7 +140,8 @@ int bwams_index_from_device(const bwams_fmi_desc_t *d, int device, bwams_index_t
     ix->d_ls = const_cast<uint32_t *>(d->sa_ls_word);
     ix->d_ref = const_cast<uint8_t *>(d->ref_0123);
     ix->bytes = ix->n_blk * 64 + ix->n_sa * 5 + (d->ref_0123 ? d->ref_seq_len - 1 : 0);
-    index_finish(ix, d);
+    int frc = index_finish(ix, d);
+    if (frc) { bwams_index_close(ix); return frc; }
     *out = ix;
     return BWAMS_OK;
 }
@@ -245,13 +251,16 @@ int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, 
     BWAMS_HIP(hipMalloc(&b->d_enc, (size_t)max_bases + 64));
     BWAMS_HIP(hipMalloc(&b->d_cum, (size_t)(max_reads + 1) * 8));
     BWAMS_HIP(hipMalloc(&b->d_skip, (size_t)max_reads));
-    BWAMS_HIP(hipMalloc(&b->d_pool, (size_t)b->max_smem * sizeof(bwams_smem_t)));
+    // the pool is handed out in per-wave chunks: room for every wave's partly filled last chunk
+    // of each of the three rounds on top of the max_smem real records
+    b->pool_cap = b->max_smem + 3 * seed_pool_slack(b->cu_count);
+    BWAMS_HIP(hipMalloc(&b->d_pool, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
     BWAMS_HIP(hipMalloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
-    BWAMS_HIP(hipMalloc(&b->d_keys, (size_t)b->max_smem * 8));
-    BWAMS_HIP(hipMalloc(&b->d_keys2, (size_t)b->max_smem * 8));
-    BWAMS_HIP(hipMalloc(&b->d_vals, (size_t)b->max_smem * 4));
-    BWAMS_HIP(hipMalloc(&b->d_vals2, (size_t)b->max_smem * 4));
-    BWAMS_HIP(hipMalloc(&b->d_work2, (size_t)b->max_smem * sizeof(Round2Work)));
+    BWAMS_HIP(hipMalloc(&b->d_keys, (size_t)b->pool_cap * 8));
+    BWAMS_HIP(hipMalloc(&b->d_keys2, (size_t)b->pool_cap * 8));
+    BWAMS_HIP(hipMalloc(&b->d_vals, (size_t)b->pool_cap * 4));
+    BWAMS_HIP(hipMalloc(&b->d_vals2, (size_t)b->pool_cap * 4));
+    BWAMS_HIP(hipMalloc(&b->d_work2, (size_t)b->pool_cap * sizeof(Round2Work)));
     BWAMS_HIP(hipMalloc(&b->d_sa_off, (size_t)(b->max_smem + 1) * 8));
     BWAMS_HIP(hipMalloc(&b->d_sa_cnt, (size_t)(b->max_smem + 1) * 8));
     BWAMS_HIP(hipMalloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
@@ -276,8 +285,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev_k,
-                    b->d_prev_l, b->d_prev_s, b->d_prev_n, b->d_pairs, b->d_ref, b->d_qer};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_pairs, b->d_ref, b->d_qer};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -330,19 +338,29 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
     // the source buffers belong to the caller: do not return before they are consumed
     BWAMS_HIP(hipStreamSynchronize(b->stream));
 
+    // packed form of the reads: 16 bases per code word + 32 bases per N-mask word, padded to 4 words
+    {
+        const int cw = (mx + 15) / 16, mw = (mx + 31) / 32;
+        int W = ((cw + mw + 3) / 4) * 4;
+        if (W < 4) W = 4;
+        b->read_w = W;
+        b->read_cw = cw;
+        const int64_t need = (int64_t)W * (nseq > 0 ? nseq : 1);
+        if (need > b->packed_cap) {
+            if (b->d_packed) (void)hipFree(b->d_packed);
+            b->d_packed = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_packed, (size_t)need * 4));
+            b->packed_cap = need;
+        }
+    }
     // per-lane scratch for the previous-interval lists: (longest read + 1) entries per lane
     const int cap = mx + 1;
     const int64_t threads = seed_max_threads(b->cu_count);
     if (cap > b->prev_cap || threads > b->prev_threads) {
-        for (void *p : {(void *)b->d_prev_k, (void *)b->d_prev_l, (void *)b->d_prev_s, (void *)b->d_prev_n})
-            if (p) (void)hipFree(p);
-        b->d_prev_k = b->d_prev_l = b->d_prev_s = nullptr;
-        b->d_prev_n = nullptr;
+        if (b->d_prev) (void)hipFree(b->d_prev);
+        b->d_prev = nullptr;
         const size_t n = (size_t)cap * (size_t)threads;
-        BWAMS_HIP(hipMalloc(&b->d_prev_k, n * 8));
-        BWAMS_HIP(hipMalloc(&b->d_prev_l, n * 8));
-        BWAMS_HIP(hipMalloc(&b->d_prev_s, n * 8));
-        BWAMS_HIP(hipMalloc(&b->d_prev_n, n * 4));
+        BWAMS_HIP(hipMalloc(&b->d_prev, n * 16));
         b->prev_cap = cap;
         b->prev_threads = threads;
     }
@@ -362,14 +380,16 @@ int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
     a.cum = b->d_cum;
     a.skip = b->has_skip ? b->d_skip : nullptr;
     a.nseq = b->nseq;
+    a.packed = b->d_packed;
+    a.read_w = b->read_w;
+    a.read_cw = b->read_cw;
+    a.reads_in_lds = b->read_w <= 40;      // 40 words x 256 lanes x 4 B = 40 KB per workgroup
+    { const char *dbg = getenv("BWAMS_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
     a.min_seed_len = opt->min_seed_len;
     a.pool = b->d_pool;
-    a.pool_cap = b->max_smem;
+    a.pool_cap = b->pool_cap;
     a.ctr = b->d_ctr;
-    a.prev_k = b->d_prev_k;
-    a.prev_l = b->d_prev_l;
-    a.prev_s = b->d_prev_s;
-    a.prev_n = b->d_prev_n;
+    a.prev = b->d_prev;
     a.prev_cap = b->prev_cap;
     a.prev_threads = b->prev_threads;
     const int split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
@@ -377,12 +397,13 @@ int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
     // events: 0 start | 8,9 round-1 kernel | 10,11 round-2 kernel | 12,13 round-3 kernel | 3 rounds done
     BWAMS_HIP(hipMemsetAsync(b->d_ctr, 0, sizeof(DevCounters), st));
     BWAMS_HIP(hipEventRecord(b->ev[0], st));
+    launch_pack_reads(b->d_enc, b->d_cum, b->nseq, b->read_w, b->read_cw, b->d_packed, st);
     launch_mark(b->d_ctr, 0, st);
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
     if (b->nseq > 0) launch_smem_round1(a, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[9], st));
     launch_mark(b->d_ctr, 1, st);
-    if (b->nseq > 0) launch_round2_work(a, b->d_work2, b->max_smem, split_len, opt->split_width, b->cu_count, st);
+    if (b->nseq > 0) launch_round2_work(a, b->d_work2, b->pool_cap, split_len, opt->split_width, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[10], st));
     if (b->nseq > 0) launch_smem_round2(a, b->d_work2, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[11], st));
@@ -398,27 +419,48 @@ int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
     // the SMEM count sizes the sort: one small read-back
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
-    const int64_t n = (int64_t)b->h_ctr->n_smem_total;
+    const int64_t n_slots = (int64_t)b->h_ctr->n_smem_total;      // pool slots handed out (holes included)
+    const int64_t n = (int64_t)b->h_ctr->n_smem_valid;           // real SMEMs
     b->n_smem = n;
-    if (n > b->max_smem) {
+    if (n > b->max_smem || n_slots > b->pool_cap) {
         set_last_error("SMEM pool overflow: need " + std::to_string(n) + " slots");
         b->seed_done = true;
         return BWAMS_ERR_CAPACITY;
     }
-    if (n > 0) {
-        launch_make_keys(b->d_pool, n, b->d_keys, b->d_vals, st);
-        size_t tb = b->tmp_bytes;
-        // key = rid << 32 | m << 16 | n: only the bits in use are sorted
+    if (n_slots > 0) {
+        // key = rid << 32 | m << 16 | n; chunk holes carry rid = nseq and sort behind every read
+        launch_make_keys(b->d_pool, n_slots, b->d_keys, b->d_vals, (uint32_t)b->nseq, st);
         int rid_bits = 1;
-        while (((int64_t)1 << rid_bits) < b->nseq) rid_bits++;
-        BWAMS_HIP(rocprim::radix_sort_pairs(b->d_tmp, tb, b->d_keys, b->d_keys2, b->d_vals, b->d_vals2, (size_t)n,
-                                            0, 32 + rid_bits, st));
+        while (((int64_t)1 << rid_bits) <= b->nseq) rid_bits++;
+        size_t tb = 0;      // the temporary size depends on the size / bit range: ask for this call
+        BWAMS_HIP(rocprim::radix_sort_pairs(nullptr, tb, b->d_keys, b->d_keys2, b->d_vals, b->d_vals2,
+                                            (size_t)n_slots, 0, 32 + rid_bits, st));
+        if (tb > b->tmp_bytes) {
+            BWAMS_HIP(hipStreamSynchronize(st));
+            (void)hipFree(b->d_tmp);
+            b->d_tmp = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            b->tmp_bytes = tb;
+        }
+        tb = b->tmp_bytes;
+        BWAMS_HIP(rocprim::radix_sort_pairs(b->d_tmp, tb, b->d_keys, b->d_keys2, b->d_vals, b->d_vals2,
+                                            (size_t)n_slots, 0, 32 + rid_bits, st));
         launch_gather_sorted(b->d_pool, b->d_vals2, n, b->d_sorted, with_sa ? b->d_sa_cnt : nullptr,
                              opt->max_occ, st);
     }
     BWAMS_HIP(hipEventRecord(b->ev[4], st));
     if (with_sa && n > 0) {
-        size_t tb = b->tmp_bytes;
+        size_t tb = 0;
+        BWAMS_HIP(rocprim::exclusive_scan(nullptr, tb, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)n + 1,
+                                          rocprim::plus<int64_t>(), st));
+        if (tb > b->tmp_bytes) {
+            BWAMS_HIP(hipStreamSynchronize(st));
+            (void)hipFree(b->d_tmp);
+            b->d_tmp = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            b->tmp_bytes = tb;
+        }
+        tb = b->tmp_bytes;
         BWAMS_HIP(hipMemsetAsync(b->d_sa_cnt + n, 0, 8, st));
         BWAMS_HIP(rocprim::exclusive_scan(b->d_tmp, tb, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)n + 1,
                                           rocprim::plus<int64_t>(), st));
@@ -584,9 +626,9 @@ int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out) {
     s.n_ext_blocks = (int64_t)c.n_ext_blocks;
     s.n_sa_lookups = (int64_t)c.n_sa_lookups;
     s.n_lf_steps = (int64_t)c.n_lf_steps;
-    s.n_smem[0] = (int64_t)c.n_after_r1;
-    s.n_smem[1] = (int64_t)(c.n_after_r2 - c.n_after_r1);
-    s.n_smem[2] = (int64_t)(c.n_smem_total - c.n_after_r2);
+    s.n_smem[0] = (int64_t)c.valid_after[0];
+    s.n_smem[1] = (int64_t)(c.valid_after[1] - c.valid_after[0]);
+    s.n_smem[2] = (int64_t)(c.valid_after[2] - c.valid_after[1]);
     s.bsw_cells = (int64_t)c.bsw_cells;
     for (int i = 0; i < 3; ++i) {
         s.n_ext_round[i] = (int64_t)(c.ext_after[i] - (i ? c.ext_after[i - 1] : 0));

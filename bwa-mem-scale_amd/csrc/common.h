@@ -40,7 +40,9 @@ struct DevFmi {
 // device-side counters of one seed run
 struct DevCounters {
     unsigned long long n_ext, n_ext_blocks, n_sa_lookups, n_lf_steps;
-    unsigned long long n_smem_total;     // append cursor of the SMEM pool
+    unsigned long long n_smem_total;     // append cursor of the SMEM pool (slots handed out, holes included)
+    unsigned long long n_smem_valid;     // real SMEMs written
+    unsigned long long valid_after[3];   // n_smem_valid when round 1, 2, 3 ended
     unsigned long long n_after_r1, n_after_r2;
     unsigned long long work_head;        // dynamic work queue cursor (reset per kernel)
     unsigned long long n_work2;          // round-2 work items
@@ -80,6 +82,7 @@ struct bwams_batch {
     bwams_index *idx = nullptr;
     hipStream_t stream = nullptr;
     int64_t max_reads = 0, max_bases = 0, max_smem = 0, max_sa = 0;
+    int64_t pool_cap = 0;                // max_smem + chunk slack
     int cu_count = 0;
 
     // reads
@@ -89,6 +92,9 @@ struct bwams_batch {
     bool has_skip = false;
     int64_t nseq = 0, nbases = 0;
     int max_read_len = 0;
+    uint32_t *d_packed = nullptr;        // packed reads (2-bit codes + N mask)
+    int64_t packed_cap = 0;              // words
+    int read_w = 0, read_cw = 0;
 
     // seeding buffers
     bwams_smem_t *d_pool = nullptr;      // unsorted SMEM pool (append order)
@@ -104,8 +110,7 @@ struct bwams_batch {
     bwams::DevCounters *d_ctr = nullptr;
     bwams::DevCounters *h_ctr = nullptr;  // pinned host mirror
     // per-lane scratch of the SMEM search (previous-interval lists)
-    int64_t *d_prev_k = nullptr, *d_prev_l = nullptr, *d_prev_s = nullptr;
-    int32_t *d_prev_n = nullptr;
+    uint4 *d_prev = nullptr;
     int64_t prev_threads = 0;
     int prev_cap = 0;
 

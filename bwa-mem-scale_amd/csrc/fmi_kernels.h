@@ -9,13 +9,16 @@ struct SeedLaunch {
     const uint8_t *enc;
     const int64_t *cum;
     const uint8_t *skip;          // may be nullptr
+    const uint32_t *packed;       // reads packed by launch_pack_reads: read_w words per read
+    int read_w, read_cw;          // words per read (multiple of 4) / code words
+    int reads_in_lds;             // 1: each lane keeps its current read in LDS
+    int debug;                    // diagnostic ablations (env BWAMS_DEBUG); 0 in production
     int64_t nseq;
     int min_seed_len;
     bwams_smem_t *pool;
     int64_t pool_cap;
     DevCounters *ctr;
-    int64_t *prev_k, *prev_l, *prev_s;
-    int32_t *prev_n;
+    uint4 *prev;                  // per-lane previous-interval lists: prev_cap entries x 16 B, lane-contiguous
     int prev_cap;                 // entries per lane
     int64_t prev_threads;         // lanes the scratch was sized for
 };
@@ -23,7 +26,11 @@ struct SeedLaunch {
 // grid sizing shared by batch_create (scratch) and the launches
 int seed_block_threads();
 int64_t seed_max_threads(int cu_count);
+int64_t seed_pool_slack(int cu_count);   // pool slots one kernel can leave unused in partly filled chunks
 
+// enc_qdb bytes -> 2-bit codes + N mask, W words per read
+void launch_pack_reads(const uint8_t *enc, const int64_t *cum, int64_t nseq, int W, int cw, uint32_t *packed,
+                       hipStream_t st);
 // between rounds: snapshot counters (which = 1, 2, 3 after that round; 0 = start) and reset the work cursor
 void launch_mark(DevCounters *ctr, int which, hipStream_t st);
 // round 1: every pivot of every read (getSMEMsAllPosOneThread)
@@ -36,7 +43,8 @@ void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_coun
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st);
 
 // sort keys / gather / SA lookup
-void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, hipStream_t st);
+void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, uint32_t hole_key_rid,
+                      hipStream_t st);
 void launch_gather_sorted(const bwams_smem_t *pool, const uint32_t *order, int64_t n, bwams_smem_t *sorted,
                           int64_t *sa_cnt, int max_occ, hipStream_t st);
 void launch_sa_lookup(const DevFmi &f, const bwams_smem_t *sorted, int64_t n_smem, const int64_t *sa_off,

@@ -34,38 +34,94 @@ struct Occ4 {
     int64_t v[4];
 };
 
-// Both ends of an interval.  When k and k+s fall into one block the block is read once.
-__device__ __forceinline__ void occ4_pair(const uint4 *__restrict__ cp, int64_t sp, int64_t ep,
-                                          Occ4 &osp, Occ4 &oep) {
-    const uint4 *p = cp + ((sp >> 6) << 2);
-    uint4 c01 = p[0], c23 = p[1], h01 = p[2], h23 = p[3];
-    {
-        const int y = (int)(sp & 63);
-        const uint64_t mask = y ? (~0ull << (64 - y)) : 0ull;
-        osp.v[0] = (int64_t)mk64(c01.x, c01.y) + __popcll(mk64(h01.x, h01.y) & mask);
-        osp.v[1] = (int64_t)mk64(c01.z, c01.w) + __popcll(mk64(h01.z, h01.w) & mask);
-        osp.v[2] = (int64_t)mk64(c23.x, c23.y) + __popcll(mk64(h23.x, h23.y) & mask);
-        osp.v[3] = (int64_t)mk64(c23.z, c23.w) + __popcll(mk64(h23.z, h23.w) & mask);
-    }
-    if ((ep >> 6) != (sp >> 6)) {
-        const uint4 *q = cp + ((ep >> 6) << 2);
-        c01 = q[0]; c23 = q[1]; h01 = q[2]; h23 = q[3];
-    }
-    {
-        const int y = (int)(ep & 63);
-        const uint64_t mask = y ? (~0ull << (64 - y)) : 0ull;
-        oep.v[0] = (int64_t)mk64(c01.x, c01.y) + __popcll(mk64(h01.x, h01.y) & mask);
-        oep.v[1] = (int64_t)mk64(c01.z, c01.w) + __popcll(mk64(h01.z, h01.w) & mask);
-        oep.v[2] = (int64_t)mk64(c23.x, c23.y) + __popcll(mk64(h23.x, h23.y) & mask);
-        oep.v[3] = (int64_t)mk64(c23.z, c23.w) + __popcll(mk64(h23.z, h23.w) & mask);
-    }
+// ---- quad-cooperative block fetch --------------------------------------------------
+// A lane that reads its own 64-byte block with four 16-byte loads costs four L2 requests
+// per block; the memory system then tops out at ~28 G blocks/s (tools/ubench_gather, mode 0).
+// Instead the four lanes of a quad fetch four blocks together: in load j every lane of the
+// quad reads the 16-byte piece (lane & 3) of quad member j's block, so one wave instruction
+// is 16 fully used 64-byte requests; a 4x4 register transpose inside the quad (DPP
+// quad_perm, no LDS) then hands every lane the whole block it asked for.  This shape
+// reaches the random-line ceiling of HBM (~50 G blocks/s, mode 1 of the same benchmark).
+template <int CTRL>
+__device__ __forceinline__ uint32_t qdpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int J>
+__device__ __forceinline__ int64_t quad_bcast64(int64_t v) {
+    const uint32_t lo = qdpp<J * 0x55>((uint32_t)v), hi = qdpp<J * 0x55>((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)mk64(lo, hi);
 }
 
-// backwardExt of the interval (k, l, s) by base a.
-__device__ __forceinline__ void backward_ext(const DevFmi &f, int64_t k, int64_t l, int64_t s, int a,
-                                             int64_t &nk, int64_t &nl, int64_t &ns) {
+// In place 4x4 transpose across the quad: on entry lane q holds m[j] = element (q, j);
+// on exit lane q holds m[j] = element (j, q).
+__device__ __forceinline__ void quad_transpose(uint32_t &m0, uint32_t &m1, uint32_t &m2, uint32_t &m3, int q) {
+    const bool hi2 = (q & 2) != 0, hi1 = (q & 1) != 0;
+    // exchange 2x2 blocks with lane ^ 2
+    uint32_t t0 = hi2 ? m0 : m2, t1 = hi2 ? m1 : m3;
+    t0 = qdpp<0x4E>(t0);           // quad_perm [2,3,0,1]
+    t1 = qdpp<0x4E>(t1);
+    if (hi2) { m0 = t0; m1 = t1; } else { m2 = t0; m3 = t1; }
+    // exchange inside the 2x2 blocks with lane ^ 1
+    t0 = hi1 ? m0 : m1;
+    t1 = hi1 ? m2 : m3;
+    t0 = qdpp<0xB1>(t0);           // quad_perm [1,0,3,2]
+    t1 = qdpp<0xB1>(t1);
+    if (hi1) { m0 = t0; m2 = t1; } else { m1 = t0; m3 = t1; }
+}
+
+__device__ __forceinline__ void quad_transpose4(uint4 &a0, uint4 &a1, uint4 &a2, uint4 &a3, int q) {
+    quad_transpose(a0.x, a1.x, a2.x, a3.x, q);
+    quad_transpose(a0.y, a1.y, a2.y, a3.y, q);
+    quad_transpose(a0.z, a1.z, a2.z, a3.z, q);
+    quad_transpose(a0.w, a1.w, a2.w, a3.w, q);
+}
+
+__device__ __forceinline__ void occ_from_block(const uint4 &c01, const uint4 &c23, const uint4 &h01,
+                                               const uint4 &h23, int64_t pos, Occ4 &o) {
+    const int y = (int)(pos & 63);
+    const uint64_t mask = y ? (~0ull << (64 - y)) : 0ull;
+    o.v[0] = (int64_t)mk64(c01.x, c01.y) + __popcll(mk64(h01.x, h01.y) & mask);
+    o.v[1] = (int64_t)mk64(c01.z, c01.w) + __popcll(mk64(h01.z, h01.w) & mask);
+    o.v[2] = (int64_t)mk64(c23.x, c23.y) + __popcll(mk64(h23.x, h23.y) & mask);
+    o.v[3] = (int64_t)mk64(c23.z, c23.w) + __popcll(mk64(h23.z, h23.w) & mask);
+}
+
+// backwardExt for every lane of the wave at once.  MUST be called by all 64 lanes
+// (wave-uniform control flow); lanes without work pass need = false.
+__device__ __forceinline__ void backward_ext_coop(const DevFmi &f, bool need, int64_t k, int64_t l, int64_t s,
+                                                  int a, int64_t &nk, int64_t &nl, int64_t &ns) {
+    const int q = (int)(threadIdx.x & 3);
+    const int64_t sp = need ? k : 0, ep = need ? k + s : 0;
+    const bool two = need && ((sp >> 6) != (ep >> 6));
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    uint4 A0 = zero, A1 = zero, A2 = zero, A3 = zero;
+    {
+        const int64_t b0 = quad_bcast64<0>(sp) >> 6, b1 = quad_bcast64<1>(sp) >> 6;
+        const int64_t b2 = quad_bcast64<2>(sp) >> 6, b3 = quad_bcast64<3>(sp) >> 6;
+        const uint32_t n = need ? 1u : 0u;
+        if (qdpp<0x00>(n)) A0 = f.cp[(b0 << 2) + q];
+        if (qdpp<0x55>(n)) A1 = f.cp[(b1 << 2) + q];
+        if (qdpp<0xAA>(n)) A2 = f.cp[(b2 << 2) + q];
+        if (qdpp<0xFF>(n)) A3 = f.cp[(b3 << 2) + q];
+    }
+    uint4 B0 = zero, B1 = zero, B2 = zero, B3 = zero;
+    const bool any_two = __any(two);
+    if (any_two) {
+        const int64_t b0 = quad_bcast64<0>(ep) >> 6, b1 = quad_bcast64<1>(ep) >> 6;
+        const int64_t b2 = quad_bcast64<2>(ep) >> 6, b3 = quad_bcast64<3>(ep) >> 6;
+        const uint32_t n = two ? 1u : 0u;
+        if (qdpp<0x00>(n)) B0 = f.cp[(b0 << 2) + q];
+        if (qdpp<0x55>(n)) B1 = f.cp[(b1 << 2) + q];
+        if (qdpp<0xAA>(n)) B2 = f.cp[(b2 << 2) + q];
+        if (qdpp<0xFF>(n)) B3 = f.cp[(b3 << 2) + q];
+    }
+    // after the transpose A0..A3 are pieces 0..3 of this lane's own block
+    quad_transpose4(A0, A1, A2, A3, q);
+    if (any_two) quad_transpose4(B0, B1, B2, B3, q);
+    if (!two) { B0 = A0; B1 = A1; B2 = A2; B3 = A3; }
     Occ4 osp, oep;
-    occ4_pair(f.cp, k, k + s, osp, oep);
+    occ_from_block(A0, A1, A2, A3, sp, osp);
+    occ_from_block(B0, B1, B2, B3, ep, oep);
     const int64_t s0 = oep.v[0] - osp.v[0], s1 = oep.v[1] - osp.v[1];
     const int64_t s2 = oep.v[2] - osp.v[2], s3 = oep.v[3] - osp.v[3];
     const int64_t l3 = l + ((k <= f.sentinel && k + s > f.sentinel) ? 1 : 0);
@@ -95,15 +151,63 @@ __device__ __forceinline__ unsigned long long take_ticket(unsigned long long *he
     return base;
 }
 
-__device__ __forceinline__ void emit_smem(const SeedLaunch &a, uint32_t rid, uint32_t m, uint32_t n,
-                                          int64_t k, int64_t l, int64_t s) {
-    const unsigned long long pos = atomicAdd(&a.ctr->n_smem_total, 1ull);
-    if ((int64_t)pos < a.pool_cap) {
-        bwams_smem_t r;
-        r.rid = rid; r.m = m; r.n = n; r.pad_ = 0;
-        r.k = k; r.l = l; r.s = s;
-        a.pool[pos] = r;
+// ---- SMEM output: per-wave chunks ----------------------------------------------------
+// One global cursor bumped per emitted SMEM serialises the whole chip on a single address
+// (measured: 2/3 of the round-3 kernel).  Instead a wave reserves chunks of kChunk pool
+// slots with ONE atomic and fills them with ballot-ranked stores; the unused tail of an
+// abandoned chunk is stamped with rid = kHoleRid, which sorts behind every real read and
+// is dropped after the sort.  The number of real SMEMs is added once per wave at exit.
+constexpr int kChunk = 64;
+constexpr uint32_t kHoleRid = 0xffffffffu;
+
+struct WaveOut {
+    long long base;      // first slot of the current chunk (wave-uniform), -1 = none
+    int used;            // slots used in it (wave-uniform)
+    unsigned long long emitted;   // this lane's emitted count (summed at exit)
+};
+
+__device__ __forceinline__ void wave_close_chunk(const SeedLaunch &a, WaveOut &w) {
+    const int lane = (int)(threadIdx.x & 63);
+    if (w.base >= 0) {
+        const long long slot = w.base + w.used + lane;
+        if (w.used + lane < kChunk && slot < a.pool_cap) a.pool[slot].rid = kHoleRid;
     }
+    w.base = -1;
+    w.used = 0;
+}
+
+// MUST be called by all 64 lanes at a wave-uniform point.
+__device__ __forceinline__ void wave_emit(const SeedLaunch &a, WaveOut &w, bool flag, uint32_t rid, uint32_t m,
+                                          uint32_t n, int64_t k, int64_t l, int64_t s) {
+    if (a.debug & 1) flag = false;             // diagnostic ablation only (BWAMS_DEBUG=1)
+    const unsigned long long mask = __ballot(flag);
+    if (!mask) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int cnt = __popcll(mask);
+    if (w.base < 0 || w.used + cnt > kChunk) {
+        wave_close_chunk(a, w);
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&a.ctr->n_smem_total, (unsigned long long)kChunk);
+        w.base = (long long)mk64(__shfl((uint32_t)b, 0), __shfl((uint32_t)(b >> 32), 0));
+    }
+    if (flag) {
+        const long long slot = w.base + w.used + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < a.pool_cap) {
+            bwams_smem_t r;
+            r.rid = rid; r.m = m; r.n = n; r.pad_ = 0;
+            r.k = k; r.l = l; r.s = s;
+            a.pool[slot] = r;
+        }
+        w.emitted++;
+    }
+    w.used += cnt;
+}
+
+__device__ __forceinline__ void wave_emit_finish(const SeedLaunch &a, WaveOut &w) {
+    wave_close_chunk(a, w);
+    unsigned long long e = w.emitted;
+    for (int o = 32; o > 0; o >>= 1) e += mk64(__shfl_down((uint32_t)e, o), __shfl_down((uint32_t)(e >> 32), o));
+    if ((threadIdx.x & 63) == 0 && e) atomicAdd(&a.ctr->n_smem_valid, e);
 }
 
 __device__ __forceinline__ void flush_counters(DevCounters *ctr, unsigned long long n_ext,
@@ -118,6 +222,85 @@ __device__ __forceinline__ void flush_counters(DevCounters *ctr, unsigned long l
     }
 }
 
+// Previous-interval list of one lane: `cap` entries of 16 bytes, contiguous per lane so that
+// consecutive entries share cache lines and pages (a lane-interleaved layout costs four
+// scattered requests per access and thrashes the TLB: profiles/r01_notes.md).  One entry is
+// one 16-byte request:  x = k[31:0]  y = l[31:0]  z = s[31:0]
+//                       w = n[15:0] | k[35:32] << 16 | l[35:32] << 20 | s[35:32] << 24
+// (36-bit rows: texts up to 2^36 = 68 G rows; GRCh38 has 6.4 G.)
+__device__ __forceinline__ void prev_store(uint4 *__restrict__ base, int e, int64_t k, int64_t l, int64_t s, int n) {
+    const uint32_t w = (uint32_t)(n & 0xffff) | (((uint32_t)((uint64_t)k >> 32) & 0xf) << 16) |
+                       (((uint32_t)((uint64_t)l >> 32) & 0xf) << 20) | (((uint32_t)((uint64_t)s >> 32) & 0xf) << 24);
+    base[e] = make_uint4((uint32_t)k, (uint32_t)l, (uint32_t)s, w);
+}
+__device__ __forceinline__ void prev_load(const uint4 *__restrict__ base, int e, int64_t &k, int64_t &l, int64_t &s, int &n) {
+    const uint4 a = base[e];
+    k = (int64_t)mk64(a.x, (a.w >> 16) & 0xf);
+    l = (int64_t)mk64(a.y, (a.w >> 20) & 0xf);
+    s = (int64_t)mk64(a.z, (a.w >> 24) & 0xf);
+    n = (int)(a.w & 0xffff);
+}
+
+// ---- reads: packed once per batch, then resident in LDS ---------------------------------
+// pack_reads_kernel turns the byte-per-base enc_qdb into `W` 32-bit words per read (W a
+// multiple of 4): words [0, cw) hold 2-bit codes (16 bases per word, base j at bits 2*(j&15)),
+// words [cw, cw+mw) hold the N mask (1 bit per base).  A lane that takes a read copies its W
+// words into its own LDS column (word w of thread t at lds[w * 256 + t]: conflict-free for
+// any per-lane w) and from then on every base fetch is an LDS read instead of a
+// divergent global byte load (which costs one L2 request per lane and iteration).
+struct ReadView {
+    const uint32_t *lds_col;   // this thread's LDS column (nullptr -> read packed words from global)
+    const uint32_t *gl;        // packed words of the current read in global memory
+    int cw;
+};
+__device__ __forceinline__ uint32_t read_word(const ReadView &r, int w) {
+    return r.lds_col ? r.lds_col[w * kBlock] : r.gl[w];
+}
+__device__ __forceinline__ int base_at(const ReadView &r, int j) {
+    const uint32_t code = (read_word(r, j >> 4) >> ((j & 15) * 2)) & 3u;
+    const uint32_t isn = (read_word(r, r.cw + (j >> 5)) >> (j & 31)) & 1u;
+    return isn ? 4 : (int)code;
+}
+// copy the packed read `rid` into the LDS column (or just point at it)
+__device__ __forceinline__ void read_take(ReadView &r, uint32_t *lds_col_w, const uint32_t *packed, int W,
+                                          uint32_t rid) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(packed + (int64_t)rid * W);
+    r.gl = packed + (int64_t)rid * W;
+    if (lds_col_w) {
+        for (int w4 = 0; w4 < (W >> 2); ++w4) {
+            const uint4 v = src[w4];
+            lds_col_w[(4 * w4 + 0) * kBlock] = v.x;
+            lds_col_w[(4 * w4 + 1) * kBlock] = v.y;
+            lds_col_w[(4 * w4 + 2) * kBlock] = v.z;
+            lds_col_w[(4 * w4 + 3) * kBlock] = v.w;
+        }
+    }
+}
+
+__global__ void pack_reads_kernel(const uint8_t *__restrict__ enc, const int64_t *__restrict__ cum, int64_t nseq,
+                                  int W, int cw, uint32_t *__restrict__ packed) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nseq * W) return;
+    const int64_t rid = g / W;
+    const int w = (int)(g - rid * W);
+    const int64_t off = cum[rid];
+    const int len = (int)(cum[rid + 1] - off);
+    uint32_t v = 0;
+    if (w < cw) {
+        for (int b = 0; b < 16; ++b) {
+            const int j = w * 16 + b;
+            if (j < len) v |= (uint32_t)(enc[off + j] & 3u) << (2 * b);
+        }
+    } else {
+        const int mwi = w - cw;
+        for (int b = 0; b < 32; ++b) {
+            const int j = mwi * 32 + b;
+            if (j < len && enc[off + j] >= 4) v |= 1u << b;
+        }
+    }
+    packed[g] = v;
+}
+
 enum : int { PH_FETCH = 0, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BWD, PH_BWD_END, PH_EXIT };
 
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
@@ -126,8 +309,14 @@ template <bool ALL_POS>
 __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
     const DevFmi &f = a.fmi;
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t nt = a.prev_threads;
     const int cap = a.prev_cap;
+    uint4 *const prev = a.prev + slot * (int64_t)cap;
+    extern __shared__ uint32_t lds_reads[];
+    uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
+    ReadView rv;
+    rv.lds_col = lds_col;
+    rv.gl = a.packed;
+    rv.cw = a.read_cw;
     const int64_t n_work = ALL_POS ? a.nseq : (int64_t)a.ctr->n_work2;
 
     int phase = PH_FETCH;
@@ -142,19 +331,29 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
     bool first = true;
     int bwd_a = 0;
     unsigned long long n_ext = 0, n_blk = 0;
+    WaveOut wo;
+    wo.base = -1; wo.used = 0; wo.emitted = 0;
 
     while (true) {
+        // at most one SMEM per lane and iteration; written at the wave-uniform point below
+        bool em = false;
+        uint32_t em_m = 0, em_n = 0;
+        int64_t em_k = 0, em_l = 0, em_s = 0;
         // ---- leave a finished pivot -------------------------------------------------
         if (phase == PH_BWD_END) {
             if (num_prev != 0) {
-                const int64_t e = (int64_t)base * nt + slot;
-                const int pn = a.prev_n[e];
-                if (pn - cur_m + 1 >= a.min_seed_len)
-                    emit_smem(a, rid, (uint32_t)cur_m, (uint32_t)pn, a.prev_k[e], a.prev_l[e], a.prev_s[e]);
+                int64_t qk, ql, qs;
+                int qn;
+                prev_load(prev, base, qk, ql, qs, qn);
+                if (qn - cur_m + 1 >= a.min_seed_len) {
+                    em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)qn; em_k = qk; em_l = ql; em_s = qs;
+                }
             }
             x = next_x;
             phase = ALL_POS ? PH_PIVOT : PH_FETCH;
         }
+        wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
+        em = false;
         // ---- take the next work item ------------------------------------------------
         {
             const bool want = phase == PH_FETCH;
@@ -177,6 +376,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
                     len = (int)(a.cum[rid + 1] - qoff);
                     phase = PH_PIVOT;
                     if (ALL_POS && a.skip && a.skip[rid]) phase = PH_FETCH;
+                    else read_take(rv, lds_col, a.packed, a.read_w, rid);
                 }
             }
         }
@@ -187,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             if (x >= len) {
                 phase = PH_FETCH;
             } else {
-                const int c = a.enc[qoff + x];
+                const int c = base_at(rv, x);
                 if (c >= 4) {
                     x = x + 1;                          // query_pos = next_x = x + 1
                     if (!ALL_POS) phase = PH_FETCH;
@@ -214,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
         if (phase == PH_FWD) {
             phase = PH_FWD_END;
             if (j < len) {
-                const int c = a.enc[qoff + j];
+                const int c = base_at(rv, j);
                 next_x = j + 1;
                 if (c < 4) {
                     phase = PH_FWD;
@@ -226,8 +426,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
         }
         if (phase == PH_FWD_END) {
             if (cs >= min_intv) {
-                const int64_t e = (int64_t)(cap - 1 - num_prev) * nt + slot;
-                a.prev_k[e] = ck; a.prev_l[e] = cl; a.prev_s[e] = cs; a.prev_n[e] = cn;
+                prev_store(prev, cap - 1 - num_prev, ck, cl, cs, cn);
                 num_prev++;
             }
             base = cap - num_prev;                      // entry p lives at base + p, longest first
@@ -242,15 +441,14 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             if (p == 0) {
                 go = false;
                 if (num_prev != 0 && j >= 0) {
-                    bwd_a = a.enc[qoff + j];
+                    bwd_a = base_at(rv, j);
                     go = bwd_a < 4;
                 }
             }
             if (!go) {
                 phase = PH_BWD_END;
             } else {
-                const int64_t e = (int64_t)(base + p) * nt + slot;
-                pk = a.prev_k[e]; pl = a.prev_l[e]; ps = a.prev_s[e]; pn = a.prev_n[e];
+                prev_load(prev, base + p, pk, pl, ps, pn);
                 do_ext = true;
                 ek = pk; el = pl; es = ps; ea = bwd_a;
             }
@@ -258,8 +456,8 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
 
         // ---- the one extension of this iteration -------------------------------------
         int64_t nk = 0, nl = 0, ns = 0;
+        backward_ext_coop(f, do_ext, ek, el, es, ea, nk, nl, ns);
         if (do_ext) {
-            backward_ext(f, ek, el, es, ea, nk, nl, ns);
             n_ext++;
             n_blk += ((ek >> 6) == ((ek + es) >> 6)) ? 1 : 2;
         }
@@ -268,8 +466,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
         if (do_ext && phase == PH_FWD) {
             // the extended interval is (k, l) = (nl, nk) after swapping strands back
             if (ns != cs) {
-                const int64_t e = (int64_t)(cap - 1 - num_prev) * nt + slot;
-                a.prev_k[e] = ck; a.prev_l[e] = cl; a.prev_s[e] = cs; a.prev_n[e] = cn;
+                prev_store(prev, cap - 1 - num_prev, ck, cl, cs, cn);
                 num_prev++;
             }
             if (ns < min_intv) {
@@ -282,8 +479,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             }
             if (phase == PH_FWD_END) {
                 if (cs >= min_intv) {
-                    const int64_t e = (int64_t)(cap - 1 - num_prev) * nt + slot;
-                    a.prev_k[e] = ck; a.prev_l[e] = cl; a.prev_s[e] = cs; a.prev_n[e] = cn;
+                    prev_store(prev, cap - 1 - num_prev, ck, cl, cs, cn);
                     num_prev++;
                 }
                 base = cap - num_prev;
@@ -296,7 +492,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             bool keep = false;
             if (first) {
                 if (ns < min_intv && (pn - cur_m + 1) >= a.min_seed_len) {
-                    emit_smem(a, rid, (uint32_t)cur_m, (uint32_t)pn, pk, pl, ps);
+                    em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)pn; em_k = pk; em_l = pl; em_s = ps;
                     first = false;
                 } else if (ns >= min_intv && ns != (int64_t)curr_s) {
                     keep = true;
@@ -307,8 +503,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             }
             if (keep) {
                 curr_s = (int32_t)ns;
-                const int64_t e = (int64_t)(base + num_curr) * nt + slot;
-                a.prev_k[e] = nk; a.prev_l[e] = nl; a.prev_s[e] = ns; a.prev_n[e] = pn;
+                prev_store(prev, base + num_curr, nk, nl, ns, pn);
                 num_curr++;
             }
             p++;
@@ -323,7 +518,9 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
                 }
             }
         }
+        wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
     }
+    wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
 
@@ -334,6 +531,7 @@ __global__ void round2_work_kernel(const bwams_smem_t *pool, DevCounters *ctr, R
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1;
          i += (int64_t)gridDim.x * blockDim.x) {
         const bwams_smem_t s = pool[i];
+        if (s.rid == kHoleRid) continue;
         const int start = (int)s.m, end = (int)s.n + 1;
         if (end - start < split_len || s.s > split_width) continue;
         const unsigned long long pos = atomicAdd(&ctr->n_work2, 1ull);
@@ -349,8 +547,9 @@ __global__ void round2_work_kernel(const bwams_smem_t *pool, DevCounters *ctr, R
 
 // bookkeeping between rounds (single thread): snapshot the pool cursor, reset the queue
 __global__ void mark_kernel(DevCounters *ctr, int which) {
-    if (which == 1) ctr->n_after_r1 = ctr->n_smem_total;
-    if (which == 2) ctr->n_after_r2 = ctr->n_smem_total;
+    if (which == 1) { ctr->n_after_r1 = ctr->n_smem_total; ctr->valid_after[0] = ctr->n_smem_valid; }
+    if (which == 2) { ctr->n_after_r2 = ctr->n_smem_total; ctr->valid_after[1] = ctr->n_smem_valid; }
+    if (which == 3) ctr->valid_after[2] = ctr->n_smem_valid;
     if (which >= 1 && which <= 3) {
         ctr->ext_after[which - 1] = ctr->n_ext;
         ctr->blk_after[which - 1] = ctr->n_ext_blocks;
@@ -361,12 +560,20 @@ __global__ void mark_kernel(DevCounters *ctr, int which) {
 // Round 3: forward-only seeds.
 __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int max_intv) {
     const DevFmi &f = a.fmi;
+    extern __shared__ uint32_t lds_reads[];
+    uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
+    ReadView rv;
+    rv.lds_col = lds_col;
+    rv.gl = a.packed;
+    rv.cw = a.read_cw;
     int phase = PH_FETCH;
     uint32_t rid = 0;
     int64_t qoff = 0;
     int len = 0, x = 0, next_x = 0, j = 0;
     int64_t ck = 0, cl = 0, cs = 0;
     unsigned long long n_ext = 0, n_blk = 0;
+    WaveOut wo;
+    wo.base = -1; wo.used = 0; wo.emitted = 0;
 
     while (true) {
         {
@@ -382,6 +589,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
                     x = 0;
                     phase = PH_PIVOT;
                     if (a.skip && a.skip[rid]) phase = PH_FETCH;
+                    else read_take(rv, lds_col, a.packed, a.read_w, rid);
                 }
             }
         }
@@ -391,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
             if (x >= len) {
                 phase = PH_FETCH;
             } else {
-                const int c = a.enc[qoff + x];
+                const int c = base_at(rv, x);
                 next_x = x + 1;
                 if (c >= 4) {
                     x = next_x;
@@ -404,23 +612,18 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
                 }
             }
         }
+        bool do_ext = false, em = false;
+        uint32_t em_m = 0, em_n = 0;
+        int ea = 0;
         if (phase == PH_FWD) {
             bool stop = true;
             if (j < len) {
-                const int c = a.enc[qoff + j];
+                const int c = base_at(rv, j);
                 next_x = j + 1;
                 if (c < 4) {
-                    int64_t nk, nl, ns;
-                    backward_ext(f, cl, ck, cs, 3 - c, nk, nl, ns);
-                    n_ext++;
-                    n_blk += ((cl >> 6) == ((cl + cs) >> 6)) ? 1 : 2;
-                    ck = nl; cl = nk; cs = ns;
+                    do_ext = true;
+                    ea = 3 - c;
                     stop = false;
-                    if (cs < max_intv && (j - x + 1) >= a.min_seed_len) {
-                        if (cs > 0) emit_smem(a, rid, (uint32_t)x, (uint32_t)j, ck, cl, cs);
-                        stop = true;
-                    }
-                    j++;
                 }
             }
             if (stop) {
@@ -428,16 +631,35 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
                 phase = PH_PIVOT;
             }
         }
+        int64_t nk = 0, nl = 0, ns = 0;
+        backward_ext_coop(f, do_ext, cl, ck, cs, ea, nk, nl, ns);
+        if (do_ext) {
+            n_ext++;
+            n_blk += ((cl >> 6) == ((cl + cs) >> 6)) ? 1 : 2;
+            ck = nl; cl = nk; cs = ns;
+            if (cs < max_intv && (j - x + 1) >= a.min_seed_len) {
+                em = cs > 0;
+                em_m = (uint32_t)x;
+                em_n = (uint32_t)j;
+                x = next_x;
+                phase = PH_PIVOT;
+            }
+            j++;
+        }
+        wave_emit(a, wo, em, rid, em_m, em_n, ck, cl, cs);
     }
+    wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
 
 // (rid, m, n) sort key of each pooled SMEM
-__global__ void make_keys_kernel(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals) {
+__global__ void make_keys_kernel(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals,
+                                 uint32_t hole_key_rid) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const bwams_smem_t s = pool[i];
-        keys[i] = ((uint64_t)s.rid << 32) | ((uint64_t)(s.m & 0xffff) << 16) | (uint64_t)(s.n & 0xffff);
+        const uint32_t rid = s.rid == kHoleRid ? hole_key_rid : s.rid;     // holes behind every read
+        keys[i] = ((uint64_t)rid << 32) | ((uint64_t)(s.m & 0xffff) << 16) | (uint64_t)(s.n & 0xffff);
         vals[i] = (uint32_t)i;
     }
 }
@@ -462,13 +684,23 @@ int grid_for(int64_t n_items, int cu_count) {
 
 }  // namespace
 
+static size_t lds_bytes(const SeedLaunch &a) { return a.reads_in_lds ? (size_t)a.read_w * kBlock * 4 : 0; }
+
+void launch_pack_reads(const uint8_t *enc, const int64_t *cum, int64_t nseq, int W, int cw, uint32_t *packed,
+                       hipStream_t st) {
+    const int64_t n = nseq * W;
+    if (n <= 0) return;
+    pack_reads_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(enc, cum, nseq, W, cw, packed);
+}
+
 int seed_block_threads() { return kBlock; }
 int64_t seed_max_threads(int cu_count) { return (int64_t)cu_count * kBlocksPerCU * kBlock; }
+int64_t seed_pool_slack(int cu_count) { return seed_max_threads(cu_count) / 64 * kChunk; }
 
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
 
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st) {
-    smem_search_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, 0, st>>>(a, nullptr);
+    smem_search_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, nullptr);
 }
 
 void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
@@ -478,16 +710,17 @@ void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap,
 
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     // the number of items is only known on the device: launch the persistent grid at chip size
-    smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, 0, st>>>(a, work);
+    smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, work);
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {
-    seed_strategy_kernel<<<grid_for(a.nseq, cu_count), kBlock, 0, st>>>(a, max_intv);
+    seed_strategy_kernel<<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
 }
 
-void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, hipStream_t st) {
+void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, uint32_t hole_key_rid,
+                      hipStream_t st) {
     if (n <= 0) return;
-    make_keys_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pool, n, keys, vals);
+    make_keys_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pool, n, keys, vals, hole_key_rid);
 }
 
 void launch_gather_sorted(const bwams_smem_t *pool, const uint32_t *order, int64_t n, bwams_smem_t *sorted,

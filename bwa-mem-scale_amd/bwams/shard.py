@@ -1,0 +1,54 @@
+"""Static sharding of a chunk of reads over the GPUs of one node.
+
+Reads have no cross-read dependency in seeding and extension, so rank r of N takes
+a contiguous slice of the chunk; the index is replicated.  No collective is on the
+data path: ranks only exchange their per-rank result counts so that rank 0 can place
+the gathered per-read results in read order (the reference emits SAM in input order).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n_reads: int, world: int, multiple_of: int = 1) -> np.ndarray:
+    """world+1 offsets; every shard size is a multiple of `multiple_of` (2 for paired-end)
+    except possibly the last; sizes differ by at most one unit."""
+    units = (n_reads + multiple_of - 1) // multiple_of
+    base, extra = divmod(units, world)
+    sizes = np.array([(base + (1 if r < extra else 0)) * multiple_of for r in range(world)], dtype=np.int64)
+    b = np.zeros(world + 1, dtype=np.int64)
+    np.cumsum(sizes, out=b[1:])
+    b[-1] = n_reads
+    return np.minimum(b, n_reads)
+
+
+def shard_reads(enc: np.ndarray, cum: np.ndarray, rank: int, world: int, multiple_of: int = 1):
+    """(enc_shard, cum_shard rebased to 0, first_read) for this rank."""
+    b = shard_bounds(len(cum) - 1, world, multiple_of)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    c = cum[lo:hi + 1] - cum[lo]
+    return enc[cum[lo]:cum[hi]], c.astype(np.int64), lo
+
+
+def gather_smems(local_smems: np.ndarray, first_read: int, dist=None):
+    """Concatenate per-rank SMEM arrays in read order on every rank.
+
+    rid is rebased from shard-local to chunk-global.  `dist` is torch.distributed (any
+    backend) or None for a single process."""
+    sm = local_smems.copy()
+    sm["rid"] += np.uint32(first_read)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return sm
+    import torch
+    world = dist.get_world_size()
+    raw = torch.from_numpy(sm.view(np.uint8).reshape(-1).copy())
+    n = torch.tensor([raw.numel()], dtype=torch.int64)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    mx = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros(mx, dtype=torch.uint8)
+    pad[:raw.numel()] = raw
+    bufs = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    parts = [bufs[r][:int(sizes[r].item())].numpy().view(sm.dtype) for r in range(world)]
+    return np.concatenate(parts)

@@ -4,7 +4,7 @@
 # kernel-trace/stats and each PMC group run as separate passes (never combined).
 set -e
 TAG=${1:-r01}
-GMBP=${2:-512}
+GMBP=${2:-1000}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -1,0 +1,64 @@
+"""Committed golden vectors (tests/golden, made by tests/make_golden.py): the oracle must
+still reproduce them on CPU, and the HIP path must reproduce them on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from bwams import fmindex, simulate
+from oracle import loader
+from util import OUT_FIELDS
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _seed_case():
+    z = np.load(os.path.join(G, "seed_toy.npz"))
+    idx = fmindex.build_fmindex(z["genome"])
+    assert np.array_equal(idx.count, z["count"]) and idx.sentinel_index == int(z["sentinel"])
+    return z, idx
+
+
+def _check_seeds(z, sm, coord, off):
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        assert np.array_equal(sm[f], z["smem_" + f]), f
+    assert np.array_equal(coord, z["sa_coord"]) and np.array_equal(off, z["sa_off"])
+
+
+def test_oracle_reproduces_seed_golden():
+    z, idx = _seed_case()
+    enc, cum = simulate.flatten_reads(z["reads"])
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum)
+    coord, off = o.sa_lookup(sm, 500)
+    _check_seeds(z, sm, coord, off)
+
+
+def test_oracle_reproduces_bsw_golden_and_reference_was_consulted():
+    z = np.load(os.path.join(G, "bsw_tasks.npz"))
+    assert bool(z["checked_against_reference"][0]), "regenerate with oracle/_ref present"
+    pairs = np.ascontiguousarray(z["pairs"]).view(loader.SEQPAIR_DTYPE).reshape(-1)
+    for w, key in ((100, "out_w100"), (200, "out_w200")):
+        ours, _ = loader.bsw_pairs(pairs, z["ref"], z["qer"], w)
+        assert np.array_equal(np.stack([ours[f] for f in OUT_FIELDS], axis=1), z[key])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden():
+    from bwams import capi
+    z, idx = _seed_case()
+    enc, cum = simulate.flatten_reads(z["reads"])
+    ix = capi.Index.from_host(idx, 0)
+    b = capi.Batch(ix, len(z["reads"]), int(cum[-1]))
+    sm, coord, off = b.seed(enc, cum)
+    _check_seeds(z, sm, coord, off)
+    st = b.stats()
+    c = z["counters"]
+    assert [st.n_ext, st.n_ext_blocks, st.n_sa_lookups, st.n_lf_steps] + list(st.n_smem) == list(c)
+    zb = np.load(os.path.join(G, "bsw_tasks.npz"))
+    pairs = np.ascontiguousarray(zb["pairs"]).view(capi.SEQPAIR_DTYPE).reshape(-1)
+    for w, key in ((100, "out_w100"), (200, "out_w200")):
+        got = b.bsw(pairs, zb["ref"], zb["qer"], w)
+        assert np.array_equal(np.stack([got[f] for f in OUT_FIELDS], axis=1), zb[key])
+    b.close()
+    ix.close()

@@ -25,6 +25,7 @@ namespace bwams {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+constexpr int kTaskChunk = 8;      // tasks a wave reserves per atomic (one word serves ~90 M tickets/s)
 constexpr int NEG = -(1 << 28);
 
 __device__ __forceinline__ int wave_incl_prefix_max(int v, int lane) {
@@ -44,7 +45,7 @@ __device__ __forceinline__ int wave_max(int v) {
 
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,
-    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qmax, DevCounters *ctr) {
+    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qmax, int qlo, DevCounters *ctr) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
@@ -55,15 +56,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     unsigned long long cells = 0;
 
+    int64_t pid = 0, pid_end = 0;          // this wave's reserved task range
     while (true) {
-        unsigned long long t = 0;
-        if (lane == 0) t = atomicAdd(&ctr->work_head, 1ull);
-        const int64_t pid = (int64_t)(((unsigned long long)__shfl((uint32_t)(t >> 32), 0) << 32) |
-                                      (unsigned long long)__shfl((uint32_t)t, 0));
-        if (pid >= n) break;
+        if (pid >= pid_end) {
+            unsigned long long t = 0;
+            if (lane == 0) t = atomicAdd(&ctr->work_head, (unsigned long long)kTaskChunk);
+            pid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
+                            (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t));
+            pid_end = pid + kTaskChunk < n ? pid + kTaskChunk : n;
+            if (pid >= n) break;
+        }
+        const int64_t cur = pid++;
 
-        const bwams_seqpair_t sp = pairs[pid];
+        const bwams_seqpair_t sp = pairs[cur];
         const int qlen = sp.len2, tlen = sp.len1, h0 = sp.h0;
+        if (qlen <= qlo) continue;                        // handled by a register-resident variant
         const uint8_t *tq = qer + sp.idq;
         const uint8_t *tr = ref + sp.idr;
 
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
         }
 
         if (lane == 0) {
-            bwams_seqpair_t *o = &pairs[pid];
+            bwams_seqpair_t *o = &pairs[cur];
             o->score = mx;
             o->qle = max_j + 1;
             o->tle = max_i + 1;
@@ -213,6 +220,200 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     }
     if (lane == 0 && cells) atomicAdd(&ctr->bsw_cells, cells);
 }
+
+// ---- register-resident variant -----------------------------------------------------------
+// Same algorithm as bsw_kernel, for queries of at most 64 * NCH bases: each column's (h, e)
+// lives in registers of its owner lane, cross-lane traffic is DPP only (row_shr / row_bcast /
+// wave_shr: no LDS, no ds_bpermute), the target row is broadcast with v_readlane from a
+// 64-row register slab that is prefetched one slab ahead.
+template <int CTRL, int RM, int BM>
+__device__ __forceinline__ int dppi(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, BM, false);
+}
+// inclusive prefix max over the 64 lanes (6 DPP steps)
+__device__ __forceinline__ int scan_max(int v) {
+    // lanes without a valid source keep `old` = their own value, so no identity constant is needed
+    v = max(v, dppi<0x111, 0xF, 0xF>(v, v));     // row_shr:1
+    v = max(v, dppi<0x112, 0xF, 0xF>(v, v));     // row_shr:2
+    v = max(v, dppi<0x114, 0xF, 0xF>(v, v));     // row_shr:4
+    v = max(v, dppi<0x118, 0xF, 0xF>(v, v));     // row_shr:8
+    v = max(v, dppi<0x142, 0xA, 0xF>(v, v));     // row_bcast:15 into rows 1 and 3
+    v = max(v, dppi<0x143, 0xC, 0xF>(v, v));     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int lane_shr1(int v, int fill) { return dppi<0x138, 0xF, 0xF>(fill, v); }   // wave_shr:1
+
+template <int NCH>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
+    bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,
+    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qlo, DevCounters *ctr) {
+    const int lane = threadIdx.x & 63;
+    const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    unsigned long long cells = 0;
+
+    int64_t pid = 0, pid_end = 0;          // this wave's reserved task range
+    while (true) {
+        if (pid >= pid_end) {
+            unsigned long long t = 0;
+            if (lane == 0) t = atomicAdd(&ctr->work_head, (unsigned long long)kTaskChunk);
+            pid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
+                            (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t));
+            pid_end = pid + kTaskChunk < n ? pid + kTaskChunk : n;
+            if (pid >= n) break;
+        }
+        const int64_t cur = pid++;
+        const int qlen = __builtin_amdgcn_readfirstlane(pairs[cur].len2);
+        if (qlen <= qlo || qlen > 64 * NCH) continue;           // another variant's task
+        const int tlen = __builtin_amdgcn_readfirstlane(pairs[cur].len1);
+        const int h0 = __builtin_amdgcn_readfirstlane(pairs[cur].h0);
+        const uint8_t *tq = qer + __builtin_amdgcn_readfirstlane(pairs[cur].idq);
+        const uint8_t *tr = ref + __builtin_amdgcn_readfirstlane(pairs[cur].idr);
+
+        int H[NCH], E[NCH], JE[NCH], P0[NCH], P1[NCH], P2[NCH], P3[NCH], P4[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int j = c * 64 + lane;
+            int h = 0;
+            if (j == 0) h = h0;
+            else if (j <= qlen) { h = h0 - oe_ins - (j - 1) * e_ins; h = h > 0 ? h : 0; }
+            H[c] = h;
+            E[c] = 0;
+            JE[c] = j * e_ins;
+            const int qj = j < qlen ? tq[j] : 4;
+            P0[c] = prm.mat[0 * 5 + qj]; P1[c] = prm.mat[1 * 5 + qj]; P2[c] = prm.mat[2 * 5 + qj];
+            P3[c] = prm.mat[3 * 5 + qj]; P4[c] = prm.mat[4 * 5 + qj];
+        }
+        int w = w0;
+        {
+            int max_ins = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_ins) / e_ins + 1.);
+            max_ins = max_ins > 1 ? max_ins : 1;
+            w = w < max_ins ? w : max_ins;
+            int max_del = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_del) / e_del + 1.);
+            max_del = max_del > 1 ? max_del : 1;
+            w = w < max_del ? w : max_del;
+        }
+        int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+        int beg = 0, end = qlen;
+        bool done = false;
+        int tslab_next = lane < tlen ? tr[lane] : 4;
+        for (int rb = 0; rb < tlen && !done; rb += 64) {
+            const int tslab = tslab_next;
+            if (rb + 64 < tlen) tslab_next = (rb + 64 + lane < tlen) ? tr[rb + 64 + lane] : 4;
+            const int rlim = tlen - rb < 64 ? tlen - rb : 64;
+            for (int ri = 0; ri < rlim; ++ri) {
+                const int i = rb + ri;
+                const int tb = __builtin_amdgcn_readlane(tslab, ri);
+                if (beg < i - w) beg = i - w;
+                if (end > i + w + 1) end = i + w + 1;
+                if (end > qlen) end = qlen;
+                int h1 = 0;
+                if (beg == 0) {
+                    h1 = h0 - (o_del + e_del * (i + 1));
+                    if (h1 < 0) h1 = 0;
+                }
+                int m = 0, mj = -1;
+                int first_nz = 1 << 30, last_nz = -1;
+                int f_carry = 0, hl_carry = h1, h_last = h1;
+                if (beg < end) {
+                    cells += (unsigned long long)(end - beg);
+                    const int c_lo = beg >> 6, c_hi = (end - 1) >> 6;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        if (c < c_lo || c > c_hi) continue;
+                        const int jb = c << 6;
+                        const int j = jb + lane;
+                        const bool act = j >= beg && j < end;
+                        const int c0 = jb > beg ? jb : beg;
+                        const int S = tb == 0 ? P0[c] : tb == 1 ? P1[c] : tb == 2 ? P2[c] : tb == 3 ? P3[c] : P4[c];
+                        const int hd = H[c], e = E[c];
+                        const int M = (act && hd) ? hd + S : 0;
+                        int tj = M - oe_ins;
+                        tj = tj > 0 ? tj : 0;
+                        const int g = act ? tj + JE[c] : NEG;
+                        const int Pm = scan_max(g);
+                        const int Pex = lane_shr1(Pm, NEG);
+                        int F = f_carry - (j - c0) * e_ins;
+                        const int F2 = Pex - (JE[c] - e_ins);
+                        F = F > F2 ? F : F2;
+                        int h = M > e ? M : e;
+                        h = h > F ? h : F;
+                        int e2 = M - oe_del;
+                        e2 = e2 > 0 ? e2 : 0;
+                        const int e1 = e - e_del;
+                        e2 = e2 > e1 ? e2 : e1;
+                        int hl = lane_shr1(h, hl_carry);
+                        if (j == beg) hl = hl_carry;
+                        if (act) { H[c] = hl; E[c] = e2; }
+                        // row maximum and the last column attaining it
+                        const int hm = act ? h : -1;
+                        const int cm = __builtin_amdgcn_readlane(scan_max(hm), 63);
+                        if (cm >= m) {
+                            const unsigned long long eq = __ballot(act && h == cm);
+                            m = cm;
+                            mj = jb + 63 - __clzll((long long)eq);
+                        }
+                        const unsigned long long nz = __ballot(act && (hl != 0 || e2 != 0));
+                        if (nz) {
+                            const int lo = jb + __ffsll((long long)nz) - 1;
+                            const int hi = jb + 63 - __clzll((long long)nz);
+                            first_nz = first_nz < lo ? first_nz : lo;
+                            last_nz = hi;
+                        }
+                        int fn = F - e_ins;
+                        fn = fn > tj ? fn : tj;
+                        const int last_lane = (end - 1 < jb + 63 ? end - 1 : jb + 63) - jb;
+                        f_carry = __builtin_amdgcn_readlane(fn, 63);
+                        hl_carry = __builtin_amdgcn_readlane(h, 63);
+                        h_last = __builtin_amdgcn_readlane(h, last_lane);
+                    }
+                }
+                const int j_exit = beg < end ? end : beg;
+                const int h1f = beg < end ? h_last : h1;
+                // eh[end] = {h1f, 0}: column `end` is a real cell only while end < 64 * NCH
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if ((end >> 6) == c && (end & 63) == lane) { H[c] = h1f; E[c] = 0; }
+                if (j_exit == qlen) {
+                    max_ie = gscore > h1f ? max_ie : i;
+                    gscore = gscore > h1f ? gscore : h1f;
+                }
+                if (m == 0) { done = true; break; }
+                if (m > mx) {
+                    mx = m; max_i = i; max_j = mj;
+                    int d = mj - i;
+                    d = d < 0 ? -d : d;
+                    max_off = max_off > d ? max_off : d;
+                } else if (prm.zdrop > 0) {
+                    if (i - max_i > mj - max_j) {
+                        if (mx - m - ((i - max_i) - (mj - max_j)) * e_del > prm.zdrop) { done = true; break; }
+                    } else {
+                        if (mx - m - ((mj - max_j) - (i - max_i)) * e_ins > prm.zdrop) { done = true; break; }
+                    }
+                }
+                const int nbeg = first_nz < end ? first_nz : end;
+                int jj;
+                if (h1f != 0) jj = end;
+                else if (last_nz >= nbeg) jj = last_nz;
+                else jj = nbeg - 1;
+                beg = nbeg;
+                end = jj + 2 < qlen ? jj + 2 : qlen;
+            }
+        }
+        if (lane == 0) {
+            bwams_seqpair_t *o = &pairs[cur];
+            o->score = mx;
+            o->qle = max_j + 1;
+            o->tle = max_i + 1;
+            o->gtle = max_ie + 1;
+            o->gscore = gscore;
+            o->max_off = max_off;
+        }
+    }
+    if (lane == 0 && cells) atomicAdd(&ctr->bsw_cells, cells);
+}
+
+__global__ void bsw_head_reset_kernel(DevCounters *ctr) { ctr->work_head = 0; }
 
 __global__ void bsw_reset_kernel(DevCounters *ctr) {
     ctr->work_head = 0;
@@ -225,15 +426,26 @@ void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uin
                 const SwParams &prm, int qmax, DevCounters *ctr, int cu_count, hipStream_t st) {
     bsw_reset_kernel<<<1, 1, 0, st>>>(ctr);
     if (n <= 0) return;
-    const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
-    const size_t lds = per_wave * kWavesPerBlock;
     int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t maxb = (int64_t)cu_count * 8;
     if (blocks > maxb) blocks = maxb;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    bsw_kernel<<<(unsigned)blocks, kWavesPerBlock * 64, lds, st>>>(pairs, n, ref, qer, w, prm, qmax, ctr);
+    // queries of 1..64 and 65..128 bases: register-resident variants; longer: LDS-resident kernel
+    bsw_kernel_reg<1><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(pairs, n, ref, qer, w, prm, -1, ctr);
+    int qlo = 64;
+    if (qmax > 64) {
+        bsw_head_reset_kernel<<<1, 1, 0, st>>>(ctr);
+        bsw_kernel_reg<2><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(pairs, n, ref, qer, w, prm, 64, ctr);
+        qlo = 128;
+    }
+    if (qmax > 128) {
+        bsw_head_reset_kernel<<<1, 1, 0, st>>>(ctr);
+        const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
+        const size_t lds = per_wave * kWavesPerBlock;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        bsw_kernel<<<(unsigned)blocks, kWavesPerBlock * 64, lds, st>>>(pairs, n, ref, qer, w, prm, qmax, qlo, ctr);
+    }
 }
 
 size_t bsw_lds_bytes(int qmax) {

@@ -293,6 +293,24 @@ __device__ __forceinline__ void read_take(ReadView &r, uint32_t *lds_col_w, cons
     }
 }
 
+// Deferred form for W == 16 (reads of up to 160 bases): the four 16-byte loads are issued when the
+// lane takes the read and land in LDS only after this iteration's extension, so their latency
+// overlaps the index fetches of the other lanes instead of stalling the whole wave.
+struct PendingRead {
+    uint4 v0, v1, v2, v3;
+};
+__device__ __forceinline__ void read_issue(ReadView &r, PendingRead &pr, const uint32_t *packed, uint32_t rid) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(packed + (int64_t)rid * 16);
+    r.gl = packed + (int64_t)rid * 16;
+    pr.v0 = src[0]; pr.v1 = src[1]; pr.v2 = src[2]; pr.v3 = src[3];
+}
+__device__ __forceinline__ void read_land(uint32_t *c, const PendingRead &pr) {
+    c[0 * kBlock] = pr.v0.x;  c[1 * kBlock] = pr.v0.y;  c[2 * kBlock] = pr.v0.z;  c[3 * kBlock] = pr.v0.w;
+    c[4 * kBlock] = pr.v1.x;  c[5 * kBlock] = pr.v1.y;  c[6 * kBlock] = pr.v1.z;  c[7 * kBlock] = pr.v1.w;
+    c[8 * kBlock] = pr.v2.x;  c[9 * kBlock] = pr.v2.y;  c[10 * kBlock] = pr.v2.z; c[11 * kBlock] = pr.v2.w;
+    c[12 * kBlock] = pr.v3.x; c[13 * kBlock] = pr.v3.y; c[14 * kBlock] = pr.v3.z; c[15 * kBlock] = pr.v3.w;
+}
+
 __global__ void pack_reads_kernel(const uint8_t *__restrict__ enc, const int64_t *__restrict__ cum, int64_t nseq,
                                   int W, int cw, uint32_t *__restrict__ packed) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,7 +335,7 @@ __global__ void pack_reads_kernel(const uint8_t *__restrict__ enc, const int64_t
     packed[g] = v;
 }
 
-enum : int { PH_FETCH = 0, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BWD, PH_BWD_END, PH_EXIT };
+enum : int { PH_FETCH = 0, PH_LOAD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BWD, PH_BWD_END, PH_EXIT };
 
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
 // !ALL_POS: work item = (read, pivot, min_intv), one pivot (round 2).
@@ -351,6 +369,9 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0;
+    const bool defer_reads = a.reads_in_lds && a.read_w == 16;
+    PendingRead pend;
+    pend.v0 = pend.v1 = pend.v2 = pend.v3 = make_uint4(0, 0, 0, 0);
 
     while (true) {
         // at most one SMEM per lane and iteration; written at the wave-uniform point below
@@ -393,6 +414,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
                     len = (int)(a.cum[rid + 1] - qoff);
                     phase = PH_PIVOT;
                     if (ALL_POS && a.skip && a.skip[rid]) phase = PH_FETCH;
+                    else if (defer_reads) { read_issue(rv, pend, a.packed, rid); phase = PH_LOAD; }
                     else read_take(rv, lds_col, a.packed, a.read_w, rid);
                 }
             }
@@ -535,6 +557,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
                 }
             }
         }
+        if (phase == PH_LOAD) { read_land(lds_col, pend); phase = PH_PIVOT; }
         wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
     }
     wave_emit_finish(a, wo);
@@ -593,6 +616,9 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0;
+    const bool defer_reads = a.reads_in_lds && a.read_w == 16;
+    PendingRead pend;
+    pend.v0 = pend.v1 = pend.v2 = pend.v3 = make_uint4(0, 0, 0, 0);
 
     while (true) {
         {
@@ -607,6 +633,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
                     x = 0;
                     phase = PH_PIVOT;
                     if (a.skip && a.skip[rid]) phase = PH_FETCH;
+                    else if (defer_reads) { read_issue(rv, pend, a.packed, rid); phase = PH_LOAD; }
                     else read_take(rv, lds_col, a.packed, a.read_w, rid);
                 }
             }
@@ -664,6 +691,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
             }
             j++;
         }
+        if (phase == PH_LOAD) { read_land(lds_col, pend); phase = PH_PIVOT; }
         wave_emit(a, wo, em, rid, em_m, em_n, ck, cl, cs);
     }
     wave_emit_finish(a, wo);

@@ -108,6 +108,11 @@ void orc_bsw_pairs(const bwams_sw_opt_t *o, bwams_seqpair_t *pairs,
                    const uint8_t *ref, const uint8_t *qer, int64_t n,
                    int32_t w, int64_t *cells);
 
+/* ksw_align2 (src/ksw.cpp:347-381) over ksw_u8 / ksw_i16: local SW of mate rescue.
+ * out[7] = score, te, qe, score2, te2, tb, qb. */
+void orc_ksw_align2(const bwams_sw_opt_t *o, int qlen, const uint8_t *query, int tlen,
+                    const uint8_t *target, int xtra, int *out);
+
 #ifdef __cplusplus
 }
 #endif

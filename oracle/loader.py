@@ -80,7 +80,7 @@ _lib = None
 
 def build() -> str:
     out = os.path.join(HERE, "_build", "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "bwams_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "bwams_oracle.h")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "_build/liboracle.so"])
     return out
@@ -105,8 +105,35 @@ def lib():
         L.orc_bsw_scalar.argtypes = [vp, C.c_int, vp, C.c_int, vp, i32, C.c_int] + [vp] * 6
         L.orc_bsw_pairs.restype = None
         L.orc_bsw_pairs.argtypes = [vp, vp, vp, vp, i64, i32, vp]
+        L.orc_ksw_align2.restype = None
+        L.orc_ksw_align2.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
         _lib = L
     return _lib
+
+
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+
+
+def ksw_align2(query, target, xtra: int, opt: SwOpt | None = None):
+    """Restated ksw_align2: (score, te, qe, score2, te2, tb, qb)."""
+    opt = opt or default_sw_opt()
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    t = np.ascontiguousarray(target, dtype=np.uint8)
+    out = (C.c_int * 7)()
+    lib().orc_ksw_align2(C.byref(opt), len(q), _p(q), len(t), _p(t), xtra, out)
+    return tuple(out)
+
+
+def ref_ksw_align2(L, query, target, xtra: int, opt: SwOpt | None = None):
+    """The reference's ksw_align2 from oracle/_ref (it reverses its inputs in place and back)."""
+    opt = opt or default_sw_opt()
+    q = np.ascontiguousarray(query, dtype=np.uint8).copy()
+    t = np.ascontiguousarray(target, dtype=np.uint8).copy()
+    out = (C.c_int * 7)()
+    L.ref_ksw_align2.restype = None
+    L.ref_ksw_align2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.ref_ksw_align2(C.byref(opt), len(q), _p(q), len(t), _p(t), xtra, out)
+    return tuple(out)
 
 
 def _p(a):

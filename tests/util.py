@@ -91,3 +91,44 @@ def assert_pairs_equal(a, b, what=""):
     for f in OUT_FIELDS:
         bad = np.flatnonzero(a[f] != b[f])
         assert bad.size == 0, f"{what}: field {f} differs at {bad[:5]}: {a[f][bad[:5]]} vs {b[f][bad[:5]]}; pair={a[bad[0]]}"
+
+
+def make_local_cases(n: int, seed: int = 9, qmax: int = 151, tmax: int = 900):
+    """(query, target) pairs shaped like mate rescue: a (mutated, possibly truncated) copy of the
+    query somewhere in a longer random window, sometimes twice (second-best hit), sometimes not at all."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        ql = int(rng.integers(20, qmax + 1))
+        q = rng.integers(0, 4, size=ql, dtype=np.uint8)
+        tl = int(rng.integers(ql, tmax))
+        t = rng.integers(0, 4, size=tl, dtype=np.uint8)
+
+        def mutated():
+            rate = float(rng.choice([0.0, 0.02, 0.06, 0.15]))
+            o = []
+            for b in q:
+                u = rng.random()
+                if u < rate * 0.6:
+                    o.append((b + rng.integers(1, 4)) & 3)
+                elif u < rate * 0.8:
+                    continue
+                elif u < rate:
+                    o.extend([b, rng.integers(0, 4)])
+                else:
+                    o.append(b)
+            a = int(rng.integers(0, max(1, len(o) // 3)))
+            z = int(rng.integers(0, max(1, len(o) // 3)))
+            return np.array(o[a: len(o) - z], dtype=np.uint8)
+        k = int(rng.choice([0, 1, 1, 1, 2, 3]))
+        for _c in range(k):
+            c = mutated()
+            if len(c) and len(c) < tl:
+                st = int(rng.integers(0, tl - len(c) + 1))
+                t[st: st + len(c)] = c
+        if rng.random() < 0.1:
+            t[rng.integers(0, tl, size=3)] = 4
+        if rng.random() < 0.1:
+            q[rng.integers(0, ql, size=2)] = 4
+        out.append((q, t))
+    return out

@@ -28,7 +28,7 @@ SYMBOLS = [
     "bwams_index_bytes", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
-    "bwams_batch_stats", "bwams_batch_sync",
+    "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
 ]
 
 
@@ -61,7 +61,7 @@ class Stats(C.Structure):
                 ("n_ext_round", C.c_int64 * 3), ("n_blk_round", C.c_int64 * 3),
                 ("ms_smem_r1", C.c_float), ("ms_smem_r2", C.c_float), ("ms_smem_r3", C.c_float),
                 ("ms_sort", C.c_float), ("ms_sal", C.c_float), ("ms_seed_total", C.c_float),
-                ("ms_bsw", C.c_float)]
+                ("ms_bsw", C.c_float), ("ms_ksw", C.c_float)]
 
 
 def default_seed_opt() -> SeedOpt:
@@ -126,6 +126,7 @@ def lib():
         L.bwams_bsw_upload.argtypes = [vp, vp, i64, vp, i64, vp, i64]
         L.bwams_bsw_run.argtypes = [vp, i32, vp]
         L.bwams_bsw_fetch.argtypes = [vp, vp, i64]
+        L.bwams_ksw_align.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
         L.bwams_batch_stats.argtypes = [vp, vp]
         L.bwams_batch_sync.argtypes = [vp]
         _lib = L
@@ -266,6 +267,17 @@ class Batch:
         p = np.zeros(self._n_pairs, dtype=SEQPAIR_DTYPE)
         _chk(lib().bwams_bsw_fetch(self.h, _p(p), len(p)), "bwams_bsw_fetch")
         return p
+
+    def ksw_align(self, pairs, ref, qer, opt: SwOpt | None = None):
+        """Mate-rescue local SW: int32[n, 7] = score, te, qe, score2, te2, tb, qb (pairs[i].h0 = xtra)."""
+        opt = opt or default_sw_opt()
+        p = np.ascontiguousarray(pairs)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        qer = np.ascontiguousarray(qer, dtype=np.uint8)
+        out = np.zeros((len(p), 7), dtype=np.int32)
+        _chk(lib().bwams_ksw_align(self.h, _p(p), len(p), _p(ref), len(ref), _p(qer), len(qer), C.byref(opt), _p(out)),
+             "bwams_ksw_align")
+        return out
 
     def stats(self) -> Stats:
         s = Stats()

@@ -285,7 +285,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_pairs, b->d_ref, b->d_qer};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_ksw_out, b->d_pairs, b->d_ref, b->d_qer};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -537,7 +537,7 @@ int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, 
                      int64_t ref_bytes, const uint8_t *qer, int64_t qer_bytes) {
     if (!b || n < 0 || (n && (!pairs || !ref || !qer))) return BWAMS_ERR_ARG;
     BWAMS_HIP(hipSetDevice(b->idx->device));
-    int qmax = 1;
+    int qmax = 1, tmax = 1;
     for (int64_t i = 0; i < n; ++i) {
         const bwams_seqpair_t &p = pairs[i];
         if (p.len1 < 0 || p.len2 < 0 || p.idr < 0 || p.idq < 0 || (int64_t)p.idr + p.len1 > ref_bytes ||
@@ -546,6 +546,7 @@ int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, 
             return BWAMS_ERR_ARG;
         }
         if (p.len2 > qmax) qmax = p.len2;
+        if (p.len1 > tmax) tmax = p.len1;
     }
     if (bsw_lds_bytes(qmax) > 160 * 1024) {
         set_last_error("bwams_bsw_upload: query longer than the LDS-resident kernel supports");
@@ -569,6 +570,7 @@ int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, 
     }
     b->n_pairs = n;
     b->max_qlen = qmax;
+    b->max_tlen = tmax;
     return BWAMS_OK;
 }
 
@@ -612,6 +614,50 @@ int bwams_bsw_extend(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n, const 
     return bwams_bsw_fetch(b, pairs, n);
 }
 
+/* ------------------------------------------------------------ mate rescue ---- */
+
+int bwams_ksw_align(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, int64_t ref_bytes,
+                    const uint8_t *qer, int64_t qer_bytes, const bwams_sw_opt_t *o, bwams_kswr_t *out) {
+    if (!b || !o || (n && !out)) return BWAMS_ERR_ARG;
+    int mx = -128, mn = 127;
+    for (int i = 0; i < 25; ++i) {
+        mx = mx > o->mat[i] ? mx : o->mat[i];
+        mn = mn < o->mat[i] ? mn : o->mat[i];
+    }
+    if (mx <= 0 || o->e_ins <= 0 || o->e_del <= 0 ||
+        (o->o_ins + o->e_ins) + (o->o_del + o->e_del) <= mx - mn) {
+        set_last_error("bwams_ksw_align: needs max(mat) > 0 and oe_ins + oe_del > max(mat) - min(mat) "
+                       "(an insertion directly followed by a deletion must not beat a mismatch)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    int rc = bwams_bsw_upload(b, pairs, n, ref, ref_bytes, qer, qer_bytes);
+    if (rc) return rc;
+    if (b->max_qlen > 512 || b->max_tlen > 32767) {
+        set_last_error("bwams_ksw_align: query longer than 512 or target longer than 32767 "
+                       "(the reference's kswv bounds are 512 / 2048, src/kswv.h:54-55)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    if (n > b->cap_ksw) {
+        if (b->d_ksw_out) (void)hipFree(b->d_ksw_out);
+        b->d_ksw_out = nullptr;
+        b->cap_ksw = n + n / 4 + 256;
+        BWAMS_HIP(hipMalloc(&b->d_ksw_out, (size_t)b->cap_ksw * sizeof(bwams_kswr_t)));
+    }
+    SwParams prm;
+    prm.o_del = o->o_del; prm.e_del = o->e_del; prm.o_ins = o->o_ins; prm.e_ins = o->e_ins;
+    prm.zdrop = o->zdrop; prm.end_bonus = o->end_bonus; prm.max_sc = mx;
+    for (int i = 0; i < 25; ++i) prm.mat[i] = o->mat[i];
+    BWAMS_HIP(hipEventRecord(b->ev[14], b->stream));
+    launch_ksw(b->d_pairs, n, b->d_ref, b->d_qer, prm, ((b->max_qlen + 15) / 16) * 16, b->max_tlen, b->d_ksw_out,
+               b->d_ctr, b->cu_count, b->stream);
+    BWAMS_HIP(hipEventRecord(b->ev[15], b->stream));
+    BWAMS_HIP(hipGetLastError());
+    if (n) BWAMS_HIP(hipMemcpyAsync(out, b->d_ksw_out, (size_t)n * sizeof(bwams_kswr_t), hipMemcpyDeviceToHost, b->stream));
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+    return BWAMS_OK;
+}
+
 /* ---------------------------------------------------------------- stats ---- */
 
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out) {
@@ -647,6 +693,7 @@ int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out) {
         el(0, 5, &s.ms_seed_total);
     }
     el(6, 7, &s.ms_bsw);
+    el(14, 15, &s.ms_ksw);
     (void)hipGetLastError();
     *out = s;
     return BWAMS_OK;

@@ -19,6 +19,7 @@
 // that, because the band of row i depends on all of row i-1.  Arithmetic is int32
 // (scores are < 2^15 for the reference's int16 class; no saturation is relied on).
 #include "common.h"
+#include "wave_ops.h"
 
 namespace bwams {
 
@@ -26,7 +27,6 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kTaskChunk = 8;      // tasks a wave reserves per atomic (one word serves ~90 M tickets/s)
-constexpr int NEG = -(1 << 28);
 
 __device__ __forceinline__ int wave_incl_prefix_max(int v, int lane) {
 #pragma unroll
@@ -226,23 +226,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
 // lives in registers of its owner lane, cross-lane traffic is DPP only (row_shr / row_bcast /
 // wave_shr: no LDS, no ds_bpermute), the target row is broadcast with v_readlane from a
 // 64-row register slab that is prefetched one slab ahead.
-template <int CTRL, int RM, int BM>
-__device__ __forceinline__ int dppi(int old, int v) {
-    return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, BM, false);
-}
-// inclusive prefix max over the 64 lanes (6 DPP steps)
-__device__ __forceinline__ int scan_max(int v) {
-    // lanes without a valid source keep `old` = their own value, so no identity constant is needed
-    v = max(v, dppi<0x111, 0xF, 0xF>(v, v));     // row_shr:1
-    v = max(v, dppi<0x112, 0xF, 0xF>(v, v));     // row_shr:2
-    v = max(v, dppi<0x114, 0xF, 0xF>(v, v));     // row_shr:4
-    v = max(v, dppi<0x118, 0xF, 0xF>(v, v));     // row_shr:8
-    v = max(v, dppi<0x142, 0xA, 0xF>(v, v));     // row_bcast:15 into rows 1 and 3
-    v = max(v, dppi<0x143, 0xC, 0xF>(v, v));     // row_bcast:31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ int lane_shr1(int v, int fill) { return dppi<0x138, 0xF, 0xF>(fill, v); }   // wave_shr:1
-
 template <int NCH>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
     bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,

@@ -66,6 +66,8 @@ struct Round2Work {
 void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w,
                 const SwParams &prm, int qmax, DevCounters *ctr, int cu_count, hipStream_t st);
 size_t bsw_lds_bytes(int qmax);
+void launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
+                int pmax, int tmax, void *out, DevCounters *ctr, int cu_count, hipStream_t st);
 
 }  // namespace bwams
 
@@ -121,7 +123,9 @@ struct bwams_batch {
     bwams_seqpair_t *d_pairs = nullptr;
     uint8_t *d_ref = nullptr, *d_qer = nullptr;
     int64_t cap_pairs = 0, cap_ref = 0, cap_qer = 0, n_pairs = 0;
-    int max_qlen = 0;
+    int max_qlen = 0, max_tlen = 0;
+    void *d_ksw_out = nullptr;
+    int64_t cap_ksw = 0;
 
     hipEvent_t ev[16] = {};
     bwams_stats_t stats{};

@@ -133,6 +133,19 @@ int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n,
 int bwams_bsw_run(bwams_batch_t *b, int32_t w, const bwams_sw_opt_t *opt);
 int bwams_bsw_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n);
 
+/* ----------------------------------------------------------- mate rescue ---- */
+
+/* Local Smith-Waterman of mate rescue over n tasks: out[i] = ksw_align2(len2, qer + idq,
+ * len1, ref + idr, 5, mat, o_del, e_del, o_ins, e_ins, xtra = pairs[i].h0, 0)
+ * (src/ksw.cpp:347-381).  Replaces the body of mem_sam_pe_batch
+ * (src/bwamem_pair.cpp:880-979: kswv::getScores8/16 phase 0, host-side reversal, phase 1)
+ * and the scalar call in mem_matesw (src/bwamem_pair.cpp:217).  The sequence buffers are
+ * not modified.  Needs oe_ins + oe_del > max(mat) - min(mat) (true for every bwa-mem
+ * scoring scheme), queries <= 512 and targets <= 32767 bases. */
+int bwams_ksw_align(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n,
+                    const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer, int64_t qer_bytes,
+                    const bwams_sw_opt_t *opt, bwams_kswr_t *out);
+
 /* ------------------------------------------------------------- counters ---- */
 
 /* Event counts of the last seed run on this batch (the same events the oracle
@@ -150,6 +163,7 @@ typedef struct bwams_stats {
     int64_t n_blk_round[3];   /* n_ext_blocks split by round */
     float   ms_smem_r1, ms_smem_r2, ms_smem_r3, ms_sort, ms_sal, ms_seed_total;
     float   ms_bsw;
+    float   ms_ksw;
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 

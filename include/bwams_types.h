@@ -70,6 +70,15 @@ typedef struct bwams_sw_opt {
     int8_t  pad_[3];
 } bwams_sw_opt_t;
 
+/* Result of the local Smith-Waterman of mate rescue: the reference's kswr_t
+ * (src/ksw.h:43-48).  Unset values are -1. */
+typedef struct bwams_kswr {
+    int32_t score;          /* best score */
+    int32_t te, qe;         /* target / query end (inclusive) */
+    int32_t score2, te2;    /* second best score and its target end */
+    int32_t tb, qb;         /* target / query start */
+} bwams_kswr_t;
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,3 +167,63 @@ def test_bsw_scoring_matrix_variants(gpu_toy):
         got = b.bsw(pairs, ref, qer, 100, gopt)
         b.close()
         assert_pairs_equal(got, want, f"mat {a},{bb}")
+
+
+def _local_tasks(cases, xtra):
+    from oracle.loader import SEQPAIR_DTYPE
+    pairs = np.zeros(len(cases), dtype=SEQPAIR_DTYPE)
+    ro = qo = 0
+    refs, qers = [], []
+    for i, (q, t) in enumerate(cases):
+        pairs[i]["idr"], pairs[i]["idq"], pairs[i]["id"] = ro, qo, i
+        pairs[i]["len1"], pairs[i]["len2"], pairs[i]["h0"] = len(t), len(q), xtra
+        pairs[i]["regid"] = i
+        refs.append(t); qers.append(q)
+        ro += len(t); qo += len(q)
+    return pairs, np.concatenate(refs), np.concatenate(qers)
+
+
+@pytest.mark.parametrize("flags", [
+    loader.KSW_XSUBO | loader.KSW_XSTART | loader.KSW_XBYTE | 19,     # mem_matesw, 150-bp mates
+    loader.KSW_XSUBO | loader.KSW_XSTART | 19,                         # 16-bit kernel
+    loader.KSW_XBYTE, 0, loader.KSW_XSUBO | 40,
+])
+def test_ksw_local_matches_oracle(gpu_toy, flags):
+    from util import make_local_cases
+    _, _, ix = gpu_toy
+    cases = make_local_cases(400, seed=flags % 977)
+    pairs, ref, qer = _local_tasks(cases, flags)
+    ref0, qer0 = ref.copy(), qer.copy()
+    b = capi.Batch(ix, 8, 1200)
+    got = b.ksw_align(pairs, ref, qer)
+    b.close()
+    want = np.array([loader.ksw_align2(q, t, flags) for q, t in cases], dtype=np.int32)
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, (bad[:5], got[bad[:3]], want[bad[:3]])
+    assert np.array_equal(ref, ref0) and np.array_equal(qer, qer0)        # inputs are not reversed in place
+
+
+def test_ksw_local_long_queries_scoring_and_limits(gpu_toy):
+    from util import make_local_cases
+    _, _, ix = gpu_toy
+    flags = loader.KSW_XSUBO | loader.KSW_XSTART | 25
+    cases = make_local_cases(120, seed=5, qmax=500, tmax=2000)
+    cases.append((np.random.default_rng(1).integers(0, 4, 300, dtype=np.uint8),) * 2)   # byte-kernel overflow -> 255
+    oopt = loader.default_sw_opt(5, 2, 3); gopt = capi.default_sw_opt(5, 2, 3)
+    for o in (oopt, gopt):
+        o.o_del, o.e_del, o.o_ins, o.e_ins = 5, 2, 4, 1
+    for fl in (flags, flags | loader.KSW_XBYTE):
+        pairs, ref, qer = _local_tasks(cases, fl)
+        b = capi.Batch(ix, 8, 1200)
+        got = b.ksw_align(pairs, ref, qer, gopt)
+        want = np.array([loader.ksw_align2(q, t, fl, oopt) for q, t in cases], dtype=np.int32)
+        assert np.array_equal(got, want), np.flatnonzero((got != want).any(axis=1))[:5]
+        b.close()
+    # unsupported scoring (insertion+deletion cheaper than a mismatch) is refused, not approximated
+    bad = capi.default_sw_opt(5, 1, 30)
+    b = capi.Batch(ix, 8, 1200)
+    with pytest.raises(capi.BwamsError) as e:
+        b.ksw_align(pairs[:2], ref, qer, bad)
+    assert e.value.code == -6
+    assert len(b.ksw_align(pairs[:0], ref, qer)) == 0
+    b.close()

@@ -29,6 +29,7 @@ SYMBOLS = [
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
+    "bwams_tasks_from_seeds", "bwams_tasks_fetch",
 ]
 
 
@@ -61,7 +62,7 @@ class Stats(C.Structure):
                 ("n_ext_round", C.c_int64 * 3), ("n_blk_round", C.c_int64 * 3),
                 ("ms_smem_r1", C.c_float), ("ms_smem_r2", C.c_float), ("ms_smem_r3", C.c_float),
                 ("ms_sort", C.c_float), ("ms_sal", C.c_float), ("ms_seed_total", C.c_float),
-                ("ms_bsw", C.c_float), ("ms_ksw", C.c_float)]
+                ("ms_bsw", C.c_float), ("ms_ksw", C.c_float), ("ms_tasks", C.c_float)]
 
 
 def default_seed_opt() -> SeedOpt:
@@ -127,6 +128,8 @@ def lib():
         L.bwams_bsw_run.argtypes = [vp, i32, vp]
         L.bwams_bsw_fetch.argtypes = [vp, vp, i64]
         L.bwams_ksw_align.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
+        L.bwams_tasks_from_seeds.argtypes = [vp, vp, i32, i32, i32, vp]
+        L.bwams_tasks_fetch.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
         L.bwams_batch_stats.argtypes = [vp, vp]
         L.bwams_batch_sync.argtypes = [vp]
         _lib = L
@@ -267,6 +270,23 @@ class Batch:
         p = np.zeros(self._n_pairs, dtype=SEQPAIR_DTYPE)
         _chk(lib().bwams_bsw_fetch(self.h, _p(p), len(p)), "bwams_bsw_fetch")
         return p
+
+    def tasks_from_seeds(self, opt: SwOpt | None = None, a: int = 1, w: int = 100, max_occ: int = 500) -> int:
+        opt = opt or default_sw_opt()
+        n = C.c_int64(0)
+        _chk(lib().bwams_tasks_from_seeds(self.h, C.byref(opt), a, w, max_occ, C.byref(n)), "bwams_tasks_from_seeds")
+        self._n_pairs = n.value
+        return n.value
+
+    def tasks_fetch(self):
+        rb, qb = C.c_int64(0), C.c_int64(0)
+        lib().bwams_tasks_fetch(self.h, None, 0, None, 0, None, 0, C.byref(rb), C.byref(qb))      # sizes
+        p = np.zeros(self._n_pairs, dtype=SEQPAIR_DTYPE)
+        ref = np.zeros(max(rb.value, 1), dtype=np.uint8)
+        qer = np.zeros(max(qb.value, 1), dtype=np.uint8)
+        _chk(lib().bwams_tasks_fetch(self.h, _p(p), len(p), _p(ref), len(ref), _p(qer), len(qer), C.byref(rb), C.byref(qb)),
+             "bwams_tasks_fetch")
+        return p, ref[:rb.value], qer[:qb.value]
 
     def ksw_align(self, pairs, ref, qer, opt: SwOpt | None = None):
         """Mate-rescue local SW: int32[n, 7] = score, te, qe, score2, te2, tb, qb (pairs[i].h0 = xtra)."""

@@ -66,6 +66,13 @@ struct Round2Work {
 void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w,
                 const SwParams &prm, int qmax, DevCounters *ctr, int cu_count, hipStream_t st);
 size_t bsw_lds_bytes(int qmax);
+size_t task_plan_bytes(int64_t nseq);
+void launch_task_plan(const bwams_smem_t *sm, int64_t n_smem, const int64_t *sa_off, const int64_t *sa_coord,
+                      const int64_t *cum, int64_t nseq, int64_t l_pac, int max_occ, int a, int o_gap, int e_gap, int w,
+                      void *plan, int32_t *cnt, int64_t *wide, hipStream_t st);
+void launch_task_build(const void *plan, const int32_t *cnt, const int64_t *offs, const uint8_t *enc, const int64_t *cum,
+                       const uint8_t *ref0123, int64_t nseq, int a, bwams_seqpair_t *pairs, uint8_t *refbuf,
+                       uint8_t *qerbuf, int cu_count, hipStream_t st);
 void launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
                 int pmax, int tmax, void *out, DevCounters *ctr, int cu_count, hipStream_t st);
 
@@ -124,6 +131,11 @@ struct bwams_batch {
     uint8_t *d_ref = nullptr, *d_qer = nullptr;
     int64_t cap_pairs = 0, cap_ref = 0, cap_qer = 0, n_pairs = 0;
     int max_qlen = 0, max_tlen = 0;
+    void *d_plan = nullptr;
+    int32_t *d_tcnt = nullptr;
+    int64_t *d_twide = nullptr, *d_toffs = nullptr;
+    int64_t cap_plan = 0;
+    int64_t task_ref_bytes = 0, task_qer_bytes = 0;
     void *d_ksw_out = nullptr;
     int64_t cap_ksw = 0;
 

@@ -133,6 +133,20 @@ int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n,
 int bwams_bsw_run(bwams_batch_t *b, int32_t w, const bwams_sw_opt_t *opt);
 int bwams_bsw_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n);
 
+/* ------------------------------------------------------ tasks from seeds ---- */
+
+/* INTERIM (until the chaining rows a9/a14/a16 of SURVEY.md §8 are built): turns the seeds of
+ * the last bwams_seed_run(with_sa = 1) into extension tasks on the device, treating the longest
+ * seed with s <= max_occ of each read as a one-seed chain and laying out its left and right
+ * task as mem_chain2aln_across_reads_V2 does for such a chain (src/bwamem.cpp:2880-3188).
+ * The tasks replace the batch's resident task list (as bwams_bsw_upload would); follow with
+ * bwams_bsw_run / bwams_bsw_fetch.  Needs an index opened with its .0123 reference.
+ * a = match score, w = band width used for the window, opt supplies o_del / e_del. */
+int bwams_tasks_from_seeds(bwams_batch_t *b, const bwams_sw_opt_t *opt, int32_t a, int32_t w, int32_t max_occ,
+                           int64_t *n_tasks);
+int bwams_tasks_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref, int64_t ref_cap,
+                      uint8_t *qer, int64_t qer_cap, int64_t *ref_bytes, int64_t *qer_bytes);
+
 /* ----------------------------------------------------------- mate rescue ---- */
 
 /* Local Smith-Waterman of mate rescue over n tasks: out[i] = ksw_align2(len2, qer + idq,
@@ -164,6 +178,7 @@ typedef struct bwams_stats {
     float   ms_smem_r1, ms_smem_r2, ms_smem_r3, ms_sort, ms_sal, ms_seed_total;
     float   ms_bsw;
     float   ms_ksw;
+    float   ms_tasks;
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 

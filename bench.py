@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fma", action="store_true", help="build and use the FMA tables (all_smem.11 / last_smem.13)")
     ap.add_argument("--pcie", action="store_true", help="also time the one-call host-buffer form (PCIe inclusive)")
     args = ap.parse_args()
 
@@ -116,6 +117,10 @@ def main():
         f"CP_OCC {idx_dev.cp_occ.numel()*8/2**30:.2f} GiB")
     ix = capi.Index.from_device(idx_dev, local)
     torch.cuda.empty_cache()
+    if args.fma:
+        t0 = time.time()
+        ix.build_fma(11, 13)
+        log(f"FMA tables built on GPU in {time.time()-t0:.1f}s (512 MiB + 1 GiB)")
 
     R = args.reads
     t0 = time.time()
@@ -197,7 +202,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{R} synthetic 150bp SE reads per GPU vs synthetic {args.genome_mbp:.0f} Mbp genome "
-                            f"(GRCh38 unavailable offline), FM-index only (no ERT/FMA/EMF); step = pack reads, SMEM r1-r3, sort, "
+                            f"(GRCh38 unavailable offline), FM-index{' + FMA tables' if args.fma else ' only (no ERT/FMA/EMF)'}; step = pack reads, SMEM r1-r3, sort, "
                             f"SA lookup, task construction from the longest seed of each read (interim: the reference's "
                             f"chaining is not built yet), banded-SW w=100 of those tasks; everything on the GPU",
                 "genome_mbp": args.genome_mbp,

@@ -30,6 +30,7 @@ SYMBOLS = [
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
     "bwams_tasks_from_seeds", "bwams_tasks_fetch",
+    "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
 ]
 
 
@@ -114,6 +115,9 @@ def lib():
         L.bwams_index_from_host.argtypes = [vp, C.c_int, vp]
         L.bwams_index_from_device.argtypes = [vp, C.c_int, vp]
         L.bwams_index_close.argtypes = [vp]
+        L.bwams_index_build_fma.argtypes = [vp, C.c_int, C.c_int]
+        L.bwams_index_set_fma.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+        L.bwams_index_fetch_fma.argtypes = [vp, vp, vp]
         L.bwams_index_bytes.restype = i64
         L.bwams_index_bytes.argtypes = [vp]
         L.bwams_batch_create.argtypes = [vp, i64, i64, i64, i64, vp]
@@ -183,6 +187,25 @@ class Index:
         h = C.c_void_p()
         _chk(lib().bwams_index_from_device(C.byref(d), device, C.byref(h)), "bwams_index_from_device")
         return cls(h, keep=idx)
+
+    def build_fma(self, all_bp: int = 11, last_bp: int = 13):
+        _chk(lib().bwams_index_build_fma(self.h, all_bp, last_bp), "bwams_index_build_fma")
+        self._fma = (all_bp, last_bp)
+
+    def set_fma(self, all_tab, all_bp, last_tab, last_bp):
+        if all_tab is None:
+            _chk(lib().bwams_index_set_fma(self.h, None, 0, None, 0), "bwams_index_set_fma")
+            return
+        a = np.ascontiguousarray(all_tab); l = np.ascontiguousarray(last_tab)
+        _chk(lib().bwams_index_set_fma(self.h, _p(a), all_bp, _p(l), last_bp), "bwams_index_set_fma")
+        self._fma = (all_bp, last_bp)
+
+    def fetch_fma(self):
+        all_bp, last_bp = self._fma
+        a = np.zeros((4 ** all_bp, 32), dtype=np.uint32)
+        l = np.zeros((4 ** last_bp, 4), dtype=np.uint32)
+        _chk(lib().bwams_index_fetch_fma(self.h, _p(a), _p(l)), "bwams_index_fetch_fma")
+        return a, l
 
     @property
     def nbytes(self) -> int:

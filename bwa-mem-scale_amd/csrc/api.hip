@@ -212,6 +212,23 @@ int bwams_index_open(const char *prefix, int device, bwams_index_t **out) {
     int rc = bwams_index_from_host(&d, device, out);
     if (rm) munmap((void *)rm, rsz);
     munmap((void *)m, fsz);
+    if (rc) return rc;
+    // optional FMA tables written by `bwa-mem2.scale smem-table` (src/FMI_search.cpp:228-277)
+    {
+        std::string pa = std::string(prefix) + ".all_smem.11", pl = std::string(prefix) + ".last_smem.13";
+        int fa = open(pa.c_str(), O_RDONLY), fl = open(pl.c_str(), O_RDONLY);
+        struct stat sa, sl;
+        if (fa >= 0 && fl >= 0 && fstat(fa, &sa) == 0 && fstat(fl, &sl) == 0 &&
+            (size_t)sa.st_size == ((size_t)1 << 22) * 128 && (size_t)sl.st_size == ((size_t)1 << 26) * 16) {
+            void *ma = mmap(nullptr, (size_t)sa.st_size, PROT_READ, MAP_PRIVATE, fa, 0);
+            void *ml = mmap(nullptr, (size_t)sl.st_size, PROT_READ, MAP_PRIVATE, fl, 0);
+            if (ma != MAP_FAILED && ml != MAP_FAILED) rc = bwams_index_set_fma(*out, ma, 11, ml, 13);
+            if (ma != MAP_FAILED) munmap(ma, (size_t)sa.st_size);
+            if (ml != MAP_FAILED) munmap(ml, (size_t)sl.st_size);
+        }
+        if (fa >= 0) close(fa);
+        if (fl >= 0) close(fl);
+    }
     return rc;
 }
 
@@ -224,11 +241,76 @@ int bwams_index_close(bwams_index_t *ix) {
         (void)hipFree(ix->d_ls);
         if (ix->d_ref) (void)hipFree(ix->d_ref);
     }
+    if (ix->d_all || ix->d_last) {
+        (void)hipSetDevice(ix->device);
+        if (ix->d_all) (void)hipFree(ix->d_all);
+        if (ix->d_last) (void)hipFree(ix->d_last);
+    }
     delete ix;
     return BWAMS_OK;
 }
 
 int64_t bwams_index_bytes(const bwams_index_t *ix) { return ix ? ix->bytes : 0; }
+
+/* ------------------------------------------------------------------- FMA ---- */
+
+static int fma_alloc(bwams_index *ix, int all_bp, int last_bp) {
+    if (all_bp < 2 || all_bp > 11 || last_bp < 2 || last_bp > 13) {
+        set_last_error("FMA depths must be 2..11 (all_smem) and 2..13 (last_smem)");
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(ix->device));
+    if (ix->d_all) (void)hipFree(ix->d_all);
+    if (ix->d_last) (void)hipFree(ix->d_last);
+    ix->d_all = ix->d_last = nullptr;
+    ix->fmi.all_smem = nullptr;
+    ix->fmi.last_smem = nullptr;
+    BWAMS_HIP(hipMalloc(&ix->d_all, ((size_t)1 << (2 * all_bp)) * 128));
+    BWAMS_HIP(hipMalloc(&ix->d_last, ((size_t)1 << (2 * last_bp)) * 16));
+    return BWAMS_OK;
+}
+
+static void fma_attach(bwams_index *ix, int all_bp, int last_bp) {
+    ix->fmi.all_smem = reinterpret_cast<const uint32_t *>(ix->d_all);
+    ix->fmi.last_smem = reinterpret_cast<const uint4 *>(ix->d_last);
+    ix->fmi.all_bp = all_bp;
+    ix->fmi.last_bp = last_bp;
+}
+
+int bwams_index_build_fma(bwams_index_t *ix, int all_bp, int last_bp) {
+    if (!ix) return BWAMS_ERR_ARG;
+    int rc = fma_alloc(ix, all_bp, last_bp);
+    if (rc) return rc;
+    launch_build_fma(ix->fmi, all_bp, reinterpret_cast<uint32_t *>(ix->d_all), last_bp,
+                     reinterpret_cast<uint4 *>(ix->d_last), nullptr);
+    BWAMS_HIP(hipGetLastError());
+    BWAMS_HIP(hipDeviceSynchronize());
+    fma_attach(ix, all_bp, last_bp);
+    return BWAMS_OK;
+}
+
+int bwams_index_set_fma(bwams_index_t *ix, const void *all_smem, int all_bp, const void *last_smem, int last_bp) {
+    if (!ix) return BWAMS_ERR_ARG;
+    if (!all_smem || !last_smem) {                         // detach: FM-index only
+        ix->fmi.all_smem = nullptr;
+        ix->fmi.last_smem = nullptr;
+        return BWAMS_OK;
+    }
+    int rc = fma_alloc(ix, all_bp, last_bp);
+    if (rc) return rc;
+    BWAMS_HIP(hipMemcpy(ix->d_all, all_smem, ((size_t)1 << (2 * all_bp)) * 128, hipMemcpyHostToDevice));
+    BWAMS_HIP(hipMemcpy(ix->d_last, last_smem, ((size_t)1 << (2 * last_bp)) * 16, hipMemcpyHostToDevice));
+    fma_attach(ix, all_bp, last_bp);
+    return BWAMS_OK;
+}
+
+int bwams_index_fetch_fma(bwams_index_t *ix, void *all_smem, void *last_smem) {
+    if (!ix || !ix->d_all || !ix->d_last) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(ix->device));
+    if (all_smem) BWAMS_HIP(hipMemcpy(all_smem, ix->d_all, ((size_t)1 << (2 * ix->fmi.all_bp)) * 128, hipMemcpyDeviceToHost));
+    if (last_smem) BWAMS_HIP(hipMemcpy(last_smem, ix->d_last, ((size_t)1 << (2 * ix->fmi.last_bp)) * 16, hipMemcpyDeviceToHost));
+    return BWAMS_OK;
+}
 
 /* ------------------------------------------------------------------ batch -- */
 

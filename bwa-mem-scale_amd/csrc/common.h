@@ -32,6 +32,10 @@ struct DevFmi {
     const int8_t *sa_ms;
     const uint32_t *sa_ls;
     const uint8_t *ref;        // .0123 or nullptr
+    // FMA direct-lookup tables (reference layouts, src/FMI_search.h:101-135) or nullptr
+    const uint32_t *all_smem;  // 4^all_bp entries x 32 words: last_avail, 10 x {k32, l32, s32}, pad
+    const uint4 *last_smem;    // 4^last_bp entries x 16 B: bp | kms<<8 | lms<<16 | sms<<24, kls, lls, sls
+    int32_t all_bp, last_bp;
     int64_t count[5];
     int64_t sentinel;
     int64_t ref_seq_len;
@@ -85,6 +89,7 @@ struct bwams_index {
     int64_t bytes = 0;
     int64_t n_blk = 0, n_sa = 0;
     void *d_cp = nullptr, *d_ms = nullptr, *d_ls = nullptr, *d_ref = nullptr;
+    void *d_all = nullptr, *d_last = nullptr;    // FMA tables (owned)
 };
 
 struct bwams_batch {

@@ -42,6 +42,9 @@ void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_coun
 // round 3: forward-only seeds (bwtSeedStrategyAllPosOneThread)
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st);
 
+// FMA table builders (__build_all_smem_table / __build_last_smem_table): one lane per table entry
+void launch_build_fma(const DevFmi &f, int all_bp, uint32_t *all_tab, int last_bp, uint4 *last_tab, hipStream_t st);
+
 // sort keys / gather / SA lookup
 void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, uint32_t hole_key_rid,
                       hipStream_t st);

@@ -257,6 +257,68 @@ __device__ __forceinline__ void prev_load(const uint4 *__restrict__ base, int e,
     n = (int)(a.w & 0xffff);
 }
 
+// ---- FMA table builders --------------------------------------------------------------------
+// One lane per table entry walks its k-mer with plain per-lane block reads (an offline step).
+__device__ __forceinline__ void backward_ext_lane(const DevFmi &f, int64_t k, int64_t l, int64_t s, int a,
+                                                  int64_t &nk, int64_t &nl, int64_t &ns) {
+    const int64_t sp = k, ep = k + s;
+    const uint4 *p = f.cp + ((sp >> 6) << 2);
+    const uint4 *q = f.cp + ((ep >> 6) << 2);
+    Occ4 osp, oep;
+    occ_from_block(p[0], p[1], p[2], p[3], sp, osp);
+    occ_from_block(q[0], q[1], q[2], q[3], ep, oep);
+    const int64_t s0 = oep.v[0] - osp.v[0], s1 = oep.v[1] - osp.v[1];
+    const int64_t s2 = oep.v[2] - osp.v[2], s3 = oep.v[3] - osp.v[3];
+    const int64_t l3 = l + ((k <= f.sentinel && k + s > f.sentinel) ? 1 : 0);
+    const int64_t l2 = l3 + s3, l1 = l2 + s2, l0 = l1 + s1;
+    nk = (a == 0 ? f.count[0] + osp.v[0] : a == 1 ? f.count[1] + osp.v[1]
+          : a == 2 ? f.count[2] + osp.v[2] : f.count[3] + osp.v[3]);
+    ns = a == 0 ? s0 : a == 1 ? s1 : a == 2 ? s2 : s3;
+    nl = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
+}
+
+__global__ void build_all_smem_kernel(DevFmi f, int bp, uint32_t *tab) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((int64_t)1 << (2 * bp))) return;
+    uint32_t *ent = tab + idx * 32;
+    for (int w = 0; w < 32; ++w) ent[w] = 0;
+    int a = (int)((idx >> (2 * (bp - 1))) & 3);
+    int64_t k = cnt_at(f, a), l = cnt_at(f, 3 - a), s = cnt_at(f, a + 1) - k;
+    uint32_t last_avail = 0;
+    for (int i = 1; i < bp; ++i) {
+        a = (int)((idx >> (2 * (bp - 1 - i))) & 3);
+        int64_t nk, nl, ns;
+        backward_ext_lane(f, l, k, s, 3 - a, nk, nl, ns);      // forward = backward on the other strand
+        const int64_t fk = nl, fl = nk;
+        ent[1 + 3 * (i - 1)] = (uint32_t)(fk - k);
+        ent[2 + 3 * (i - 1)] = (uint32_t)(fl - cnt_at(f, 3 - a));
+        ent[3 + 3 * (i - 1)] = (uint32_t)ns;
+        if (ns > 0) last_avail = (uint32_t)i; else break;
+        k = fk; l = fl; s = ns;
+    }
+    ent[0] = last_avail;
+}
+
+__global__ void build_last_smem_kernel(DevFmi f, int bp, uint4 *tab) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((int64_t)1 << (2 * bp))) return;
+    int a = (int)((idx >> (2 * (bp - 1))) & 3);
+    int64_t k = cnt_at(f, a), l = cnt_at(f, 3 - a), s = cnt_at(f, a + 1) - k;
+    int i;
+    for (i = 1; i < bp; ++i) {
+        a = (int)((idx >> (2 * (bp - 1 - i))) & 3);
+        int64_t nk, nl, ns;
+        backward_ext_lane(f, l, k, s, 3 - a, nk, nl, ns);
+        if (ns == 0) break;
+        k = nl; l = nk; s = ns;
+    }
+    uint4 e;
+    e.x = (uint32_t)i | (((uint32_t)((uint64_t)k >> 32) & 0xff) << 8) | (((uint32_t)((uint64_t)l >> 32) & 0xff) << 16) |
+          (((uint32_t)((uint64_t)s >> 32) & 0xff) << 24);
+    e.y = (uint32_t)k; e.z = (uint32_t)l; e.w = (uint32_t)s;
+    tab[idx] = e;
+}
+
 // ---- reads: packed once per batch, then resident in LDS ---------------------------------
 // pack_reads_kernel turns the byte-per-base enc_qdb into `W` 32-bit words per read (W a
 // multiple of 4): words [0, cw) hold 2-bit codes (16 bases per word, base j at bits 2*(j&15)),
@@ -335,7 +397,7 @@ __global__ void pack_reads_kernel(const uint8_t *__restrict__ enc, const int64_t
     packed[g] = v;
 }
 
-enum : int { PH_FETCH = 0, PH_LOAD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BWD, PH_BWD_END, PH_EXIT };
+enum : int { PH_FETCH = 0, PH_LOAD, PH_HOLD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BWD, PH_BWD_END, PH_EXIT };
 
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
 // !ALL_POS: work item = (read, pivot, min_intv), one pivot (round 2).
@@ -439,6 +501,41 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
                     next_x = x + 1;
                     num_prev = 0;
                     phase = PH_FWD;
+                    if (f.all_smem && len - x >= f.all_bp) {
+                        // FMA: the first forward steps come from one all_smem entry (FMI_search.cpp:1414-1463)
+                        const int bp = f.all_bp;
+                        uint32_t tix = 0;
+                        int kk = 0;
+                        for (; kk < bp; ++kk) {
+                            const int bb = base_at(rv, x + kk);
+                            if (bb >= 4) break;
+                            tix |= (uint32_t)bb << ((bp - 1 - kk) * 2);
+                        }
+                        const uint32_t *ent = f.all_smem + (int64_t)tix * 32;
+                        const int last_avail = (int)ent[0];
+                        const int last_idx = (kk > last_avail ? last_avail : kk) - 1;
+                        for (int t = 0; t < last_idx; ++t, ++j) {
+                            const int bb = base_at(rv, j);
+                            next_x = j + 1;
+                            const int64_t tk = ck + ent[1 + 3 * t];
+                            const int64_t tl = cnt_at(f, 3 - bb) + ent[2 + 3 * t];
+                            const int64_t ts = ent[3 + 3 * t];
+                            if (ts != cs) {
+                                prev_store(prev, cap - 1 - num_prev, ck, cl, cs, cn);
+                                num_prev++;
+                            }
+                            if (ts < min_intv) {
+                                next_x = j;
+                                j = len;                       // no further forward steps
+                                break;
+                            }
+                            ck = tk; cl = tl; cs = ts; cn = j;
+                        }
+                        if (kk < bp) {                         // an N inside the window (reference quirk kept)
+                            next_x = j + 1;
+                            j = len;
+                        }
+                    }
                 }
             }
         }
@@ -640,6 +737,9 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
         }
         if (__all(phase == PH_EXIT)) break;
 
+        bool em = false;
+        uint32_t em_m = 0, em_n = 0;
+        int64_t em_k = 0, em_l = 0, em_s = 0;
         if (phase == PH_PIVOT) {
             if (x >= len) {
                 phase = PH_FETCH;
@@ -654,11 +754,35 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
                     cs = cnt_at(f, c + 1) - ck;
                     j = x + 1;
                     phase = PH_FWD;
+                    if (f.last_smem && len - x >= f.last_bp) {
+                        // FMA: jump over the longest non-empty prefix of the next last_bp bases (FMI_search.cpp:1705-1750)
+                        const int bp = f.last_bp;
+                        uint32_t tix = 0;
+                        int with_n = 0;
+                        for (int kk = 0; kk < bp; ++kk) {
+                            const int bb = base_at(rv, x + kk);
+                            tix |= (uint32_t)(bb & 3) << ((bp - 1 - kk) * 2);
+                            with_n += bb >> 2;
+                        }
+                        if (with_n == 0) {
+                            const uint4 e = f.last_smem[tix];
+                            const int ebp = (int)(e.x & 0xff);
+                            j = x + ebp;
+                            next_x = j;
+                            ck = (int64_t)(((uint64_t)(uint32_t)(int32_t)(int8_t)((e.x >> 8) & 0xff) << 32) | e.y);
+                            cl = (int64_t)(((uint64_t)(uint32_t)(int32_t)(int8_t)((e.x >> 16) & 0xff) << 32) | e.z);
+                            cs = (int64_t)(((uint64_t)(uint32_t)(int32_t)(int8_t)((e.x >> 24) & 0xff) << 32) | e.w);
+                            if (cs < max_intv && ebp >= a.min_seed_len && cs > 0) {
+                                // emitted WITHOUT ending the pivot (reference quirk); extension resumes next iteration
+                                em = true; em_m = (uint32_t)x; em_n = (uint32_t)(j - 1); em_k = ck; em_l = cl; em_s = cs;
+                            }
+                            phase = PH_HOLD;
+                        }
+                    }
                 }
             }
         }
-        bool do_ext = false, em = false;
-        uint32_t em_m = 0, em_n = 0;
+        bool do_ext = false;
         int ea = 0;
         if (phase == PH_FWD) {
             bool stop = true;
@@ -686,13 +810,15 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
                 em = cs > 0;
                 em_m = (uint32_t)x;
                 em_n = (uint32_t)j;
+                em_k = ck; em_l = cl; em_s = cs;
                 x = next_x;
                 phase = PH_PIVOT;
             }
             j++;
         }
         if (phase == PH_LOAD) { read_land(lds_col, pend); phase = PH_PIVOT; }
-        wave_emit(a, wo, em, rid, em_m, em_n, ck, cl, cs);
+        if (phase == PH_HOLD) phase = PH_FWD;
+        wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
     }
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
@@ -737,6 +863,12 @@ void launch_pack_reads(const uint8_t *enc, const int64_t *cum, int64_t nseq, int
     const int64_t n = nseq * W;
     if (n <= 0) return;
     pack_reads_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(enc, cum, nseq, W, cw, packed);
+}
+
+void launch_build_fma(const DevFmi &f, int all_bp, uint32_t *all_tab, int last_bp, uint4 *last_tab, hipStream_t st) {
+    const int64_t na = (int64_t)1 << (2 * all_bp), nl = (int64_t)1 << (2 * last_bp);
+    build_all_smem_kernel<<<(unsigned)((na + 255) / 256), 256, 0, st>>>(f, all_bp, all_tab);
+    build_last_smem_kernel<<<(unsigned)((nl + 255) / 256), 256, 0, st>>>(f, last_bp, last_tab);
 }
 
 int seed_block_threads() { return kBlock; }

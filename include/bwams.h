@@ -71,6 +71,16 @@ int bwams_index_from_host(const bwams_fmi_desc_t *desc, int device, bwams_index_
 int bwams_index_from_device(const bwams_fmi_desc_t *desc_with_device_pointers, int device,
                             bwams_index_t **out);
 
+/* FMA direct-lookup tables (all_smem_t / last_smem_t, src/FMI_search.h:101-135; used at
+ * src/FMI_search.cpp:1414-1463 and :1705-1750).  build = `bwa-mem2.scale smem-table` on the GPU
+ * (one lane per table entry); set = upload tables read from <prefix>.all_smem.11 / .last_smem.13
+ * (NULL, NULL detaches them); fetch = download (to write those files).  The reference's depths
+ * are all_bp = 11 and last_bp = 13; smaller depths are accepted for testing.  bwams_index_open
+ * loads the two files when they exist next to the index. */
+int bwams_index_build_fma(bwams_index_t *idx, int all_bp, int last_bp);
+int bwams_index_set_fma(bwams_index_t *idx, const void *all_smem, int all_bp, const void *last_smem, int last_bp);
+int bwams_index_fetch_fma(bwams_index_t *idx, void *all_smem, void *last_smem);
+
 int bwams_index_close(bwams_index_t *idx);
 int64_t bwams_index_bytes(const bwams_index_t *idx);
 

@@ -37,7 +37,17 @@ typedef struct orc_fmi {
     const int8_t  *sa_ms_byte;        /* (ref_seq_len >> 3) + 1 */
     const uint32_t *sa_ls_word;       /* (ref_seq_len >> 3) + 1 */
     int64_t sentinel_index;
+    /* FMA direct-lookup tables (src/FMI_search.h:101-135); NULL = FM-index only.
+     * all_bp / last_bp are ALL_SMEM_MAX_BP (11) / LAST_SMEM_MAX_BP (13) in the reference;
+     * smaller depths exist only so that tests can build tables quickly. */
+    const void *all_smem;             /* 4^all_bp entries of 128 B (all_smem_t) */
+    const void *last_smem;            /* 4^last_bp entries of 16 B (last_smem_t) */
+    int32_t all_bp, last_bp;
 } orc_fmi_t;
+
+/* FMA table builders (src/FMI_search.cpp:78-227). */
+void orc_build_all_smem(const orc_fmi_t *f, int bp, void *table);
+void orc_build_last_smem(const orc_fmi_t *f, int bp, void *table);
 
 /* Event counters used to derive the algorithmic byte count of a workload
  * (SURVEY.md §8d): one CP_OCC block is 64 B. */

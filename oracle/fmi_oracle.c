@@ -11,6 +11,10 @@
  *   getSMEMsAllPosOneThread          /root/reference/src/FMI_search.cpp:1608-1660
  *   bwtSeedStrategyAllPosOneThread   /root/reference/src/FMI_search.cpp:1662-1816
  *   mem_collect_smem                 /root/reference/src/bwamem.cpp:648-786
+ *   __build_all_smem_table           /root/reference/src/FMI_search.cpp:78-120
+ *   __build_last_smem_table          /root/reference/src/FMI_search.cpp:155-194
+ *   all_smem use in round 1/2        /root/reference/src/FMI_search.cpp:1414-1463
+ *   last_smem use in round 3         /root/reference/src/FMI_search.cpp:1705-1750
  *   call_one_step                    /root/reference/src/FMI_search.cpp:2206-2259
  *   get_sa_entries_prefetch          /root/reference/src/FMI_search.cpp:2261-2379
  */
@@ -72,6 +76,68 @@ static void forward_ext(const orc_fmi_t *f, const bwams_smem_t *in, int a,
     out->l = r.k;
 }
 
+/* all_smem_t / last_smem_t exactly as the reference packs them (src/FMI_search.h:108-133) */
+typedef struct __attribute__((packed)) {
+    uint32_t last_avail;
+    struct { uint32_t k32, l32, s32; } list[10];
+    uint8_t pad_[4];
+} all_smem_rec;
+typedef struct __attribute__((packed)) {
+    uint8_t bp;
+    int8_t kms, lms, sms;
+    uint32_t kls, lls, sls;
+} last_smem_rec;
+_Static_assert(sizeof(all_smem_rec) == 128 && sizeof(last_smem_rec) == 16, "FMA record sizes");
+
+void orc_build_all_smem(const orc_fmi_t *f, int bp, void *table)
+{
+    all_smem_rec *t = (all_smem_rec *)table;
+    const int64_t n = (int64_t)1 << (2 * bp);
+    for (int64_t idx = 0; idx < n; ++idx) {
+        all_smem_rec *ent = &t[idx];
+        memset(ent, 0, sizeof *ent);
+        int a = (int)((idx >> (2 * (bp - 1))) & 3);
+        bwams_smem_t sm;
+        memset(&sm, 0, sizeof sm);
+        sm.k = f->count[a]; sm.l = f->count[3 - a]; sm.s = f->count[a + 1] - f->count[a];
+        for (int i = 1; i < bp; ++i) {
+            a = (int)((idx >> (2 * (bp - 1 - i))) & 3);
+            bwams_smem_t nw;
+            forward_ext(f, &sm, a, &nw, NULL);
+            ent->list[i - 1].l32 = (uint32_t)(nw.l - f->count[3 - a]);
+            ent->list[i - 1].k32 = (uint32_t)(nw.k - sm.k);
+            ent->list[i - 1].s32 = (uint32_t)nw.s;
+            if (nw.s > 0) ent->last_avail = (uint32_t)i; else break;
+            sm = nw;
+        }
+    }
+}
+
+void orc_build_last_smem(const orc_fmi_t *f, int bp, void *table)
+{
+    last_smem_rec *t = (last_smem_rec *)table;
+    const int64_t n = (int64_t)1 << (2 * bp);
+    for (int64_t idx = 0; idx < n; ++idx) {
+        int a = (int)((idx >> (2 * (bp - 1))) & 3);
+        bwams_smem_t sm;
+        memset(&sm, 0, sizeof sm);
+        sm.k = f->count[a]; sm.l = f->count[3 - a]; sm.s = f->count[a + 1] - f->count[a];
+        int i;
+        for (i = 1; i < bp; ++i) {
+            a = (int)((idx >> (2 * (bp - 1 - i))) & 3);
+            bwams_smem_t nw;
+            forward_ext(f, &sm, a, &nw, NULL);
+            if (nw.s == 0) break;
+            sm = nw;
+        }
+        last_smem_rec *ent = &t[idx];
+        ent->bp = (uint8_t)i;
+        ent->kms = (int8_t)(sm.k >> 32); ent->kls = (uint32_t)(sm.k & 0xffffffff);
+        ent->lms = (int8_t)(sm.l >> 32); ent->lls = (uint32_t)(sm.l & 0xffffffff);
+        ent->sms = (int8_t)(sm.s >> 32); ent->sls = (uint32_t)(sm.s & 0xffffffff);
+    }
+}
+
 int64_t orc_smem_one_pos(const orc_fmi_t *f, const uint8_t *enc_qdb,
                          int16_t *query_pos, const int32_t *min_intv,
                          const int32_t *rid, int32_t num_reads,
@@ -106,8 +172,44 @@ int64_t orc_smem_one_pos(const orc_fmi_t *f, const uint8_t *enc_qdb,
             int num_prev = 0;
             int j;
 
+            /* FMA: the first forward steps come from the all_smem table (FMI_search.cpp:1414-1463) */
+            j = x + 1;
+            if (f->all_smem && readlength - x >= f->all_bp) {
+                const int bp = f->all_bp;
+                uint64_t idx = 0;
+                int kk;
+                for (kk = 0; kk < bp; ++kk) {
+                    if (q[x + kk] >= 4) break;
+                    idx |= (uint64_t)q[x + kk] << ((bp - 1 - kk) * 2);
+                }
+                const all_smem_rec *ent = &((const all_smem_rec *)f->all_smem)[idx];
+                const int with_n = kk < bp;
+                const int last_idx = (kk > (int)ent->last_avail ? (int)ent->last_avail : kk) - 1;
+                int t;
+                for (t = 0; t < last_idx; ++j, ++t) {
+                    a = q[j];
+                    next_x = j + 1;
+                    bwams_smem_t nw = cur;
+                    nw.k = cur.k + ent->list[t].k32;
+                    nw.l = f->count[3 - a] + ent->list[t].l32;
+                    nw.s = ent->list[t].s32;
+                    nw.n = (uint32_t)j;
+                    prev[num_prev] = cur;
+                    if (nw.s != cur.s) num_prev++;
+                    if (nw.s < min_intv[i]) {
+                        next_x = j;
+                        j = readlength;       /* skips the loop below */
+                        break;
+                    }
+                    cur = nw;
+                }
+                if (with_n) {
+                    next_x = j + 1;           /* reference quirk: also after the early exit above */
+                    j = readlength;
+                }
+            }
             /* forward phase: collect the intervals whose size changes */
-            for (j = x + 1; j < readlength; ++j) {
+            for (; j < readlength; ++j) {
                 a = q[j];
                 next_x = j + 1;
                 if (a >= 4) break;
@@ -227,7 +329,31 @@ int64_t orc_seed_strategy(const orc_fmi_t *f, const uint8_t *enc_qdb,
                 cur.k = f->count[a];
                 cur.l = f->count[3 - a];
                 cur.s = f->count[a + 1] - f->count[a];
-                for (int j = x + 1; j < readlength; ++j) {
+                int j = x + 1;
+                /* FMA: jump over the longest non-empty prefix of the next last_bp bases
+                 * (FMI_search.cpp:1705-1750); an emitted seed does NOT end the pivot here */
+                if (f->last_smem && readlength - x >= f->last_bp) {
+                    const int bp = f->last_bp;
+                    uint64_t idx = 0;
+                    int with_n = 0;
+                    for (int kk = 0; kk < bp; ++kk) {
+                        idx |= (uint64_t)q[x + kk] << ((bp - 1 - kk) * 2);
+                        with_n += q[x + kk] >> 2;
+                    }
+                    if (with_n == 0) {
+                        const last_smem_rec *ent = &((const last_smem_rec *)f->last_smem)[idx];
+                        j = x + ent->bp;
+                        next_x = j;
+                        cur.k = ((int64_t)ent->kms << 32) | (int64_t)ent->kls;
+                        cur.l = ((int64_t)ent->lms << 32) | (int64_t)ent->lls;
+                        cur.s = ((int64_t)ent->sms << 32) | (int64_t)ent->sls;
+                        cur.n = (uint32_t)(j - 1);
+                        if (cur.s < max_intv && (cur.n - cur.m + 1) >= (uint32_t)min_seed_len) {
+                            if (cur.s > 0) out[n_out++] = cur;
+                        }
+                    }
+                }
+                for (; j < readlength; ++j) {
                     next_x = j + 1;
                     a = q[j];
                     if (a >= 4) break;

@@ -44,7 +44,8 @@ class SwOpt(C.Structure):
 class OrcFmi(C.Structure):
     _fields_ = [("ref_seq_len", C.c_int64), ("count", C.c_int64 * 5),
                 ("cp_occ", C.c_void_p), ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p),
-                ("sentinel_index", C.c_int64)]
+                ("sentinel_index", C.c_int64),
+                ("all_smem", C.c_void_p), ("last_smem", C.c_void_p), ("all_bp", C.c_int32), ("last_bp", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -149,7 +150,28 @@ class OracleFMI:
         self.ls = np.ascontiguousarray(idx.sa_ls_word)
         self.f = OrcFmi(int(idx.ref_seq_len), (C.c_int64 * 5)(*[int(x) for x in idx.count]),
                         self.cp.ctypes.data, self.ms.ctypes.data, self.ls.ctypes.data,
-                        int(idx.sentinel_index))
+                        int(idx.sentinel_index), None, None, 0, 0)
+        self.all_tab = self.last_tab = None
+
+    def build_fma(self, all_bp: int = 11, last_bp: int = 13):
+        """Build and attach the FMA tables (all_smem: 128 B x 4^all_bp, last_smem: 16 B x 4^last_bp)."""
+        L = lib()
+        L.orc_build_all_smem.restype = None
+        L.orc_build_all_smem.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_build_last_smem.restype = None
+        L.orc_build_last_smem.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.all_tab = np.zeros((4 ** all_bp, 32), dtype=np.uint32)
+        self.last_tab = np.zeros((4 ** last_bp, 4), dtype=np.uint32)
+        L.orc_build_all_smem(C.byref(self.f), all_bp, _p(self.all_tab))
+        L.orc_build_last_smem(C.byref(self.f), last_bp, _p(self.last_tab))
+        self.f.all_smem = self.all_tab.ctypes.data
+        self.f.last_smem = self.last_tab.ctypes.data
+        self.f.all_bp, self.f.last_bp = all_bp, last_bp
+        return self.all_tab, self.last_tab
+
+    def drop_fma(self):
+        self.f.all_smem = None
+        self.f.last_smem = None
 
     def occ(self, pos: int, c: int) -> int:
         return lib().orc_fmi_occ(C.byref(self.f), pos, c)

@@ -252,3 +252,53 @@ def test_device_task_construction_equals_numpy_rule(gpu_toy):
     want, _ = loader.bsw_pairs(want_p, want_r, want_q, 100)
     assert_pairs_equal(res, want, "resident pipeline")
     b.close()
+
+
+def test_fma_tables_and_seeding_with_fma(gpu_toy):
+    """FMA (all_smem / last_smem): device-built tables == oracle-built tables; seeding with the tables
+    == the oracle with the same tables (N reads included: the with_N quirk is reproduced); and at the
+    reference's depths (11 / 13) the tables are pure accelerators on N-free reads."""
+    g, idx, _ = gpu_toy
+    ix = capi.Index.from_host(idx, 0)
+    o = loader.OracleFMI(idx)
+    want_all, want_last = o.build_fma(7, 8)
+    ix.build_fma(7, 8)
+    got_all, got_last = ix.fetch_fma()
+    assert np.array_equal(got_last, want_last)
+    assert np.array_equal(got_all, want_all)
+    reads, _, _ = simulate.make_reads(g, 2500, seed=41)
+    reads[::50, 3] = 4                                  # N inside the first table window of some reads
+    enc, cum = simulate.flatten_reads(reads)
+    for msl in (19, 5):                                 # 5: seeds are emitted at table time (no-break quirk)
+        oopt = loader.default_seed_opt(); gopt = capi.default_seed_opt()
+        oopt.min_seed_len = gopt.min_seed_len = msl
+        ctr = loader.Counters()
+        want = o.collect_smem(enc, cum, oopt, counters=ctr)
+        b = capi.Batch(ix, len(reads), int(cum[-1]), max_smem=len(want) + 4096)
+        got, _, _ = b.seed(enc, cum, gopt, with_sa=False)
+        st = b.stats()
+        b.close()
+        for f in ("rid", "m", "n", "k", "l", "s"):
+            assert np.array_equal(got[f], want[f]), (msl, f)
+        assert st.n_ext == ctr.n_ext and list(st.n_smem) == list(ctr.n_smem)
+    # tables uploaded from the host (the file path of bwams_index_open) behave the same
+    ix.set_fma(want_all, 7, want_last, 8)
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    got2, _, _ = b.seed(enc, cum, with_sa=False)
+    o2 = loader.default_seed_opt()
+    assert np.array_equal(got2["k"], o.collect_smem(enc, cum, o2)["k"])
+    # reference depths: built on the device, identical SMEMs with and without on N-free reads
+    clean = reads[(reads < 4).all(axis=1)]
+    ence, cume = simulate.flatten_reads(clean)
+    ix.build_fma(11, 13)
+    with_fma, _, _ = b.seed(ence, cume, with_sa=False)
+    n_fma = b.stats().n_ext
+    ix.set_fma(None, 0, None, 0)
+    without, _, _ = b.seed(ence, cume, with_sa=False)
+    n_plain = b.stats().n_ext
+    assert np.array_equal(with_fma, without) and n_fma < n_plain
+    o.drop_fma()
+    plain = o.collect_smem(ence, cume)
+    assert np.array_equal(without["k"], plain["k"]) and np.array_equal(without["n"], plain["n"])
+    b.close()
+    ix.close()

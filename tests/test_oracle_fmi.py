@@ -171,3 +171,40 @@ def test_file_roundtrip(tmp_path):
     import os
     L = idx.ref_seq_len
     assert os.path.getsize(tmp_path / "toy.bwt.2bit.64") == 8 + 40 + ((L >> 6) + 1) * 64 + ((L >> 3) + 1) * 5 + 8
+
+
+def test_fma_tables_are_pure_accelerators():
+    """all_smem / last_smem replace the first forward steps with table lookups: with the
+    reference's parameter relation (min_seed_len + 1 > last_bp) and reads without N the SMEM
+    output is identical and only the number of extensions drops (FMA on vs off
+    gave byte-identical SAM)."""
+    g, idx = toy(30000, seed=17)
+    reads, _, _ = simulate.make_reads(g, 400, seed=23)
+    reads = reads[(reads < 4).all(axis=1)]
+    enc, cum = simulate.flatten_reads(reads)
+    o = loader.OracleFMI(idx)
+    c0 = loader.Counters()
+    plain = o.collect_smem(enc, cum, counters=c0)
+    all_tab, last_tab = o.build_fma(7, 8)
+    c1 = loader.Counters()
+    fma = o.collect_smem(enc, cum, counters=c1)
+    assert np.array_equal(plain, fma)
+    assert c1.n_ext < c0.n_ext and list(c1.n_smem) == list(c0.n_smem)
+    # table entries against direct extension: entry for a k-mer that occurs holds its interval
+    mer = reads[0][:8]
+    i8 = int(sum(int(b) << (2 * (7 - t)) for t, b in enumerate(mer)))
+    ent = last_tab[i8]
+    bp = int(ent[0] & 0xff)
+    k, l, s = int(idx.count[mer[0]]), int(idx.count[3 - mer[0]]), int(idx.count[mer[0] + 1] - idx.count[mer[0]])
+    for b in mer[1:bp]:
+        l2, k2, s2 = o.backward_ext(l, k, s, 3 - int(b))      # forward = backward on the other strand
+        k, l, s = k2, l2, s2
+    assert (int(ent[1]), int(ent[2]), int(ent[3])) == (k & 0xffffffff, l & 0xffffffff, s & 0xffffffff)
+    # reads with N: the reference's with_N quirk may shorten a match; rounds still agree in count of reads seeded
+    reads_n, _, _ = simulate.make_reads(g, 300, seed=29)
+    encn, cumn = simulate.flatten_reads(reads_n)
+    a = o.collect_smem(encn, cumn)
+    o.drop_fma()
+    b = o.collect_smem(encn, cumn)
+    clean = (reads_n < 4).all(axis=1)
+    assert np.array_equal(a[clean[a["rid"]]], b[clean[b["rid"]]])

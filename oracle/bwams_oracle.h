@@ -118,6 +118,22 @@ void orc_bsw_pairs(const bwams_sw_opt_t *o, bwams_seqpair_t *pairs,
                    const uint8_t *ref, const uint8_t *qer, int64_t n,
                    int32_t w, int64_t *cells);
 
+/* Exact-match filter (EMF): the mapped perfect table (src/perfect.h:93-213) */
+typedef struct { uint32_t flags, location, left, right; } orc_seed_entry_t;
+typedef struct orc_emf {
+    int32_t seed_len;
+    uint32_t num_loc_entry, num_seed_entry, seq_len;
+    const uint32_t *loc_table;
+    const orc_seed_entry_t *seed_table;
+    const uint8_t *ref;                /* .0123 */
+} orc_emf_t;
+int64_t orc_emf_hash(uint32_t num_seed_entry, const uint8_t *s, int len, int fw);
+int orc_emf_seedcmp(const uint8_t *a, int afl, const uint8_t *b, int bfl, int len);
+int orc_emf_compare_fw_rc(const uint8_t *seed, int len);
+int orc_emf_match_further(const orc_emf_t *t, uint32_t loc, const uint8_t *seed, int is_rev, int len);
+/* find_perfect_match_entry (src/perfect_map.cpp:638-659): returns the FIND_PERFECT_* code */
+int orc_emf_probe(const orc_emf_t *t, const uint8_t *seed, int len, uint32_t *flags, uint32_t *location);
+
 /* ksw_align2 (src/ksw.cpp:347-381) over ksw_u8 / ksw_i16: local SW of mate rescue.
  * out[7] = score, te, qe, score2, te2, tb, qb. */
 void orc_ksw_align2(const bwams_sw_opt_t *o, int qlen, const uint8_t *query, int tlen,

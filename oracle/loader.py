@@ -81,7 +81,7 @@ _lib = None
 
 def build() -> str:
     out = os.path.join(HERE, "_build", "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "bwams_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "emf_oracle.c", "bwams_oracle.h")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "_build/liboracle.so"])
     return out
@@ -135,6 +135,37 @@ def ref_ksw_align2(L, query, target, xtra: int, opt: SwOpt | None = None):
     L.ref_ksw_align2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.ref_ksw_align2(C.byref(opt), len(q), _p(q), len(t), _p(t), xtra, out)
     return tuple(out)
+
+
+class OrcEmf(C.Structure):
+    _fields_ = [("seed_len", C.c_int32), ("num_loc_entry", C.c_uint32), ("num_seed_entry", C.c_uint32),
+                ("seq_len", C.c_uint32), ("loc_table", C.c_void_p), ("seed_table", C.c_void_p), ("ref", C.c_void_p)]
+
+
+class OracleEMF:
+    """EMF table (bwams.emf.EmfTable) + .0123 reference, probed by the restated find_perfect_match_entry."""
+
+    def __init__(self, table, ref_0123):
+        self.loc = np.ascontiguousarray(table.loc_table, dtype=np.uint32)
+        self.seeds = np.ascontiguousarray(table.seed_table, dtype=np.uint32)
+        self.ref = np.ascontiguousarray(ref_0123, dtype=np.uint8)
+        self.t = OrcEmf(table.seed_len, len(self.loc), len(self.seeds), table.seq_len,
+                        self.loc.ctypes.data, self.seeds.ctypes.data, self.ref.ctypes.data)
+        L = lib()
+        L.orc_emf_probe.restype = C.c_int
+        L.orc_emf_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+
+    def probe(self, read):
+        r = np.ascontiguousarray(read, dtype=np.uint8)
+        fl, loc = C.c_uint32(0), C.c_uint32(0)
+        code = lib().orc_emf_probe(C.byref(self.t), _p(r), len(r), C.byref(fl), C.byref(loc))
+        return code, fl.value, loc.value
+
+    def probe_many(self, reads):
+        out = np.zeros((len(reads), 3), dtype=np.int64)
+        for i, r in enumerate(reads):
+            out[i] = self.probe(r)
+        return out
 
 
 def _p(a):

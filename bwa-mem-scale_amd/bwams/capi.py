@@ -31,6 +31,7 @@ SYMBOLS = [
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
     "bwams_tasks_from_seeds", "bwams_tasks_fetch",
     "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
+    "bwams_emf_open", "bwams_emf_from_host", "bwams_emf_close", "bwams_emf_probe",
 ]
 
 
@@ -134,6 +135,10 @@ def lib():
         L.bwams_ksw_align.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
         L.bwams_tasks_from_seeds.argtypes = [vp, vp, i32, i32, i32, vp]
         L.bwams_tasks_fetch.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
+        L.bwams_emf_open.argtypes = [vp, C.c_char_p, vp]
+        L.bwams_emf_from_host.argtypes = [vp, i32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp]
+        L.bwams_emf_close.argtypes = [vp]
+        L.bwams_emf_probe.argtypes = [vp, vp, vp, vp, i64, vp, vp]
         L.bwams_batch_stats.argtypes = [vp, vp]
         L.bwams_batch_sync.argtypes = [vp]
         _lib = L
@@ -214,6 +219,26 @@ class Index:
     def close(self):
         if self.h:
             lib().bwams_index_close(self.h)
+            self.h = None
+
+
+class Emf:
+    """EMF table resident in HBM (bwams.emf.EmfTable or a <prefix>.perfect.<L> file)."""
+
+    def __init__(self, index: Index, table=None, path: str | None = None):
+        self.index = index
+        self.h = C.c_void_p()
+        if path is not None:
+            _chk(lib().bwams_emf_open(index.h, path.encode(), C.byref(self.h)), "bwams_emf_open")
+        else:
+            loc = np.ascontiguousarray(table.loc_table, dtype=np.uint32)
+            seeds = np.ascontiguousarray(table.seed_table, dtype=np.uint32)
+            _chk(lib().bwams_emf_from_host(index.h, table.seed_len, table.seq_len, _p(loc), len(loc), _p(seeds),
+                                           len(seeds), C.byref(self.h)), "bwams_emf_from_host")
+
+    def close(self):
+        if self.h:
+            lib().bwams_emf_close(self.h)
             self.h = None
 
 
@@ -321,6 +346,16 @@ class Batch:
         _chk(lib().bwams_ksw_align(self.h, _p(p), len(p), _p(ref), len(ref), _p(qer), len(qer), C.byref(opt), _p(out)),
              "bwams_ksw_align")
         return out
+
+    def emf_probe(self, emf: Emf, enc, cum):
+        """(perfect uint32[n, 2] = flags, location; code uint8[n])."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        cum = np.ascontiguousarray(cum, dtype=np.int64)
+        n = len(cum) - 1
+        out = np.zeros((max(n, 1), 2), dtype=np.uint32)
+        code = np.zeros(max(n, 1), dtype=np.uint8)
+        _chk(lib().bwams_emf_probe(self.h, emf.h, _p(enc), _p(cum), n, _p(out), _p(code)), "bwams_emf_probe")
+        return out[:n], code[:n]
 
     def stats(self) -> Stats:
         s = Stats()

@@ -367,7 +367,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_ksw_out, b->d_plan, b->d_tcnt, b->d_twide, b->d_toffs, b->d_pairs, b->d_ref, b->d_qer};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_plan, b->d_tcnt, b->d_twide, b->d_toffs, b->d_pairs, b->d_ref, b->d_qer};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -694,6 +694,108 @@ int bwams_bsw_extend(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n, const 
     rc = bwams_bsw_run(b, w, opt);
     if (rc) return rc;
     return bwams_bsw_fetch(b, pairs, n);
+}
+
+/* -------------------------------------------------------------------- EMF ---- */
+
+int bwams_emf_from_host(bwams_index_t *ix, int32_t seed_len, uint32_t seq_len, const uint32_t *loc_table,
+                        uint32_t num_loc_entry, const bwams_seed_entry_t *seed_table, uint32_t num_seed_entry,
+                        bwams_emf_t **out) {
+    if (!ix || !out || !seed_table || !num_seed_entry || seed_len <= 0 || (num_loc_entry && !loc_table)) return BWAMS_ERR_ARG;
+    if (!ix->d_ref) {
+        set_last_error("bwams_emf_from_host: the index was opened without its .0123 reference");
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(ix->device));
+    bwams_emf *e = new bwams_emf();
+    e->idx = ix;
+    const size_t bs = (size_t)num_seed_entry * 16, bl = (size_t)(num_loc_entry ? num_loc_entry : 1) * 4;
+    BWAMS_HIP(hipMalloc(&e->d_seeds, bs));
+    BWAMS_HIP(hipMalloc(&e->d_loc, bl));
+    BWAMS_HIP(hipMemcpy(e->d_seeds, seed_table, bs, hipMemcpyHostToDevice));
+    if (num_loc_entry) BWAMS_HIP(hipMemcpy(e->d_loc, loc_table, (size_t)num_loc_entry * 4, hipMemcpyHostToDevice));
+    e->t.seed_table = reinterpret_cast<const uint4 *>(e->d_seeds);
+    e->t.loc_table = reinterpret_cast<const uint32_t *>(e->d_loc);
+    e->t.ref = ix->fmi.ref;
+    e->t.num_seed_entry = num_seed_entry;
+    e->t.num_loc_entry = num_loc_entry;
+    e->t.seq_len = seq_len;
+    e->t.seed_len = seed_len;
+    e->bytes = (int64_t)(bs + bl);
+    *out = e;
+    return BWAMS_OK;
+}
+
+int bwams_emf_open(bwams_index_t *ix, const char *path, bwams_emf_t **out) {
+    if (!ix || !path || !out) return BWAMS_ERR_ARG;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        set_last_error(std::string("cannot open ") + path);
+        return BWAMS_ERR_IO;
+    }
+    struct stat st;
+    fstat(fd, &st);
+    const size_t fsz = (size_t)st.st_size;
+    const uint8_t *m = fsz >= 64 ? (const uint8_t *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0) : (const uint8_t *)MAP_FAILED;
+    close(fd);
+    if (m == MAP_FAILED) {
+        set_last_error(std::string(path) + ": cannot map");
+        return BWAMS_ERR_IO;
+    }
+    // perfect_table_t header (src/perfect.h:188-213)
+    int32_t seed_len; uint32_t n_loc, n_seed, seq_len;
+    memcpy(&seed_len, m, 4); memcpy(&n_loc, m + 4, 4); memcpy(&n_seed, m + 8, 4); memcpy(&seq_len, m + 40, 4);
+    int rc;
+    if (fsz != 64 + (size_t)n_loc * 4 + (size_t)n_seed * 16) {
+        set_last_error(std::string(path) + ": size does not match its header");
+        rc = BWAMS_ERR_IO;
+    } else {
+        rc = bwams_emf_from_host(ix, seed_len, seq_len, reinterpret_cast<const uint32_t *>(m + 64), n_loc,
+                                 reinterpret_cast<const bwams_seed_entry_t *>(m + 64 + (size_t)n_loc * 4), n_seed, out);
+    }
+    munmap((void *)m, fsz);
+    return rc;
+}
+
+int bwams_emf_close(bwams_emf_t *e) {
+    if (!e) return BWAMS_OK;
+    (void)hipSetDevice(e->idx->device);
+    if (e->d_seeds) (void)hipFree(e->d_seeds);
+    if (e->d_loc) (void)hipFree(e->d_loc);
+    delete e;
+    return BWAMS_OK;
+}
+
+int bwams_emf_probe(bwams_batch_t *b, bwams_emf_t *e, const uint8_t *enc, const int64_t *cum, int64_t nseq,
+                    bwams_perfect_t *out, uint8_t *code) {
+    if (!b || !e || !cum || nseq < 0 || (nseq && (!enc || !out || !code))) return BWAMS_ERR_ARG;
+    if (e->idx != b->idx) {
+        set_last_error("bwams_emf_probe: table and batch belong to different indexes");
+        return BWAMS_ERR_ARG;
+    }
+    const int64_t nb = cum[nseq] - cum[0];
+    if (cum[0] != 0 || nseq > b->max_reads || nb > b->max_bases) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    if (nseq > b->cap_emf) {
+        if (b->d_emf_out) (void)hipFree(b->d_emf_out);
+        if (b->d_emf_code) (void)hipFree(b->d_emf_code);
+        b->d_emf_out = nullptr; b->d_emf_code = nullptr;
+        b->cap_emf = nseq + nseq / 8 + 256;
+        BWAMS_HIP(hipMalloc(&b->d_emf_out, (size_t)b->cap_emf * 8));
+        BWAMS_HIP(hipMalloc(&b->d_emf_code, (size_t)b->cap_emf));
+    }
+    hipStream_t st = b->stream;
+    if (nb) BWAMS_HIP(hipMemcpyAsync(b->d_enc, enc, (size_t)nb, hipMemcpyHostToDevice, st));
+    BWAMS_HIP(hipMemcpyAsync(b->d_cum, cum, (size_t)(nseq + 1) * 8, hipMemcpyHostToDevice, st));
+    launch_emf_probe(e->t, b->d_enc, b->d_cum, nseq, b->d_emf_out, b->d_emf_code, st);
+    BWAMS_HIP(hipGetLastError());
+    if (nseq) {
+        BWAMS_HIP(hipMemcpyAsync(out, b->d_emf_out, (size_t)nseq * 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipMemcpyAsync(code, b->d_emf_code, (size_t)nseq, hipMemcpyDeviceToHost, st));
+    }
+    BWAMS_HIP(hipStreamSynchronize(st));
+    b->seed_done = false;            // the resident reads were replaced
+    return BWAMS_OK;
 }
 
 /* ------------------------------------------------------- tasks from seeds ---- */

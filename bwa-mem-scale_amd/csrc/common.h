@@ -41,6 +41,15 @@ struct DevFmi {
     int64_t ref_seq_len;
 };
 
+// EMF table as the probe kernel sees it
+struct DevEmf {
+    const uint4 *seed_table;     // {flags, location, left, right}
+    const uint32_t *loc_table;
+    const uint8_t *ref;          // .0123
+    uint32_t num_seed_entry, num_loc_entry, seq_len;
+    int32_t seed_len;
+};
+
 // device-side counters of one seed run
 struct DevCounters {
     unsigned long long n_ext, n_ext_blocks, n_sa_lookups, n_lf_steps;
@@ -77,6 +86,8 @@ void launch_task_plan(const bwams_smem_t *sm, int64_t n_smem, const int64_t *sa_
 void launch_task_build(const void *plan, const int32_t *cnt, const int64_t *offs, const uint8_t *enc, const int64_t *cum,
                        const uint8_t *ref0123, int64_t nseq, int a, bwams_seqpair_t *pairs, uint8_t *refbuf,
                        uint8_t *qerbuf, int cu_count, hipStream_t st);
+void launch_emf_probe(const DevEmf &t, const uint8_t *enc, const int64_t *cum, int64_t nseq, uint32_t *out,
+                      uint8_t *code, hipStream_t st);
 void launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
                 int pmax, int tmax, void *out, DevCounters *ctr, int cu_count, hipStream_t st);
 
@@ -90,6 +101,13 @@ struct bwams_index {
     int64_t n_blk = 0, n_sa = 0;
     void *d_cp = nullptr, *d_ms = nullptr, *d_ls = nullptr, *d_ref = nullptr;
     void *d_all = nullptr, *d_last = nullptr;    // FMA tables (owned)
+};
+
+struct bwams_emf {
+    bwams_index *idx = nullptr;
+    bwams::DevEmf t{};
+    void *d_seeds = nullptr, *d_loc = nullptr;
+    int64_t bytes = 0;
 };
 
 struct bwams_batch {
@@ -141,6 +159,9 @@ struct bwams_batch {
     int64_t *d_twide = nullptr, *d_toffs = nullptr;
     int64_t cap_plan = 0;
     int64_t task_ref_bytes = 0, task_qer_bytes = 0;
+    uint32_t *d_emf_out = nullptr;
+    uint8_t *d_emf_code = nullptr;
+    int64_t cap_emf = 0;
     void *d_ksw_out = nullptr;
     int64_t cap_ksw = 0;
 

@@ -37,6 +37,7 @@ extern "C" {
 
 typedef struct bwams_index bwams_index_t;   /* FM-index resident in one GPU's HBM */
 typedef struct bwams_batch bwams_batch_t;   /* stream + device work buffers for one chunk of reads */
+typedef struct bwams_emf bwams_emf_t;       /* exact-match filter table resident in HBM */
 
 const char *bwams_strerror(int code);
 /* Text of the last HIP / IO error on this thread. */
@@ -142,6 +143,25 @@ int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n,
                      const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer, int64_t qer_bytes);
 int bwams_bsw_run(bwams_batch_t *b, int32_t w, const bwams_sw_opt_t *opt);
 int bwams_bsw_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t n);
+
+/* ------------------------------------------------------------------- EMF ---- */
+
+/* Exact-match filter.  open/from_host replace load_perfect_table (src/perfect_map.cpp:344):
+ * <prefix>.perfect.<L> = 64-byte header, u32 loc_table[], seed_entry_t seed_table[]
+ * (src/perfect.h:188-213, :772-822).  The index must hold its .0123 reference. */
+int bwams_emf_open(bwams_index_t *idx, const char *path, bwams_emf_t **out);
+int bwams_emf_from_host(bwams_index_t *idx, int32_t seed_len, uint32_t seq_len, const uint32_t *loc_table,
+                        uint32_t num_loc_entry, const bwams_seed_entry_t *seed_table, uint32_t num_seed_entry,
+                        bwams_emf_t **out);
+int bwams_emf_close(bwams_emf_t *emf);
+
+/* Replaces the kernel-0 loop of mem_kernel1_core (src/bwamem.cpp:1245-1272): for every read
+ * out[i] = seqs[i].perfect and code[i] = the return value of find_perfect_match_entry
+ * (src/perfect_map.cpp:638-659; 0 no table / read shorter than L, 1 read has N, 2 not matched,
+ * 3 forward match, 4 reverse-complement match, 5 seed matched but not the whole read).
+ * `code[i] == 3 || code[i] == 4` is the `skip` flag bwams_seed_fmi takes. */
+int bwams_emf_probe(bwams_batch_t *b, bwams_emf_t *emf, const uint8_t *enc_qdb, const int64_t *cum_len,
+                    int64_t nseq, bwams_perfect_t *out, uint8_t *code);
 
 /* ------------------------------------------------------ tasks from seeds ---- */
 

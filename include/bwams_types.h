@@ -70,6 +70,16 @@ typedef struct bwams_sw_opt {
     int8_t  pad_[3];
 } bwams_sw_opt_t;
 
+/* EMF seed table entry and probe result: the reference's seed_entry_t (src/perfect.h:93-108)
+ * and bseq1_perfect_t (src/perfect.h:153-160: flags bit0 valid, bit1 reverse-complement match,
+ * bits 2.. index of the multi-location list). */
+typedef struct bwams_seed_entry {
+    uint32_t flags, location, left, right;
+} bwams_seed_entry_t;
+typedef struct bwams_perfect {
+    uint32_t flags, location;
+} bwams_perfect_t;
+
 /* Result of the local Smith-Waterman of mate rescue: the reference's kswr_t
  * (src/ksw.h:43-48).  Unset values are -1. */
 typedef struct bwams_kswr {

@@ -302,3 +302,52 @@ def test_fma_tables_and_seeding_with_fma(gpu_toy):
     assert np.array_equal(without["k"], plain["k"]) and np.array_equal(without["n"], plain["n"])
     b.close()
     ix.close()
+
+
+@pytest.mark.parametrize("L", [150, 50])
+def test_emf_probe_matches_oracle(gpu_toy, L, tmp_path):
+    """Exact-match filter: the HIP probe == the restated find_perfect_match_entry on the same table,
+    for reads of exactly L bases and longer ones (tail verification + multi-location lists), both
+    strands, mismatches, N; and the resulting skip flags drive seeding as in the reference."""
+    from bwams import emf
+    g0, idx0, _ = gpu_toy
+    g = g0[:60000].copy()
+    g[5000:5400] = g[1000:1400]                              # exact repeats -> multi-location entries
+    g[9000:9400] = (3 - g[1000:1400][::-1])                  # and a reverse-complement copy
+    idx = fmindex.build_fmindex(g)
+    ix = capi.Index.from_host(idx, 0)
+    tab = emf.build_emf(g, L)
+    emf.write_emf(str(tmp_path / "g.perfect"), tab)
+    e = capi.Emf(ix, path=str(tmp_path / "g.perfect"))
+    o = loader.OracleEMF(tab, idx.ref_0123)
+    rng = np.random.default_rng(L)
+    reads = []
+    for it in range(3000):
+        ln = L if it % 4 else int(rng.integers(L + 1, L + 60))
+        st = int(rng.integers(0, len(g) - ln)) if it % 7 else int(rng.integers(1000, 1400 - min(ln, 350)) if ln < 350 else 0)
+        rd = g[st: st + ln].copy()
+        k = it % 6
+        if k == 1:
+            rd = (3 - rd[::-1]).astype(np.uint8)
+        elif k == 2:
+            rd[rng.integers(0, ln)] ^= 1
+        elif k == 3 and it % 12 == 3:
+            rd[rng.integers(0, ln)] = 4
+        elif k == 4:
+            rd[rng.integers(L - 1, ln)] ^= 2                  # breaks the tail (or the last seed base)
+        reads.append(rd)
+    reads.append(g[0:L - 1].copy())                           # shorter than the table's L -> code 0
+    enc, cum = simulate.flatten_reads(reads)
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    perfect, code = b.emf_probe(e, enc, cum)
+    want = o.probe_many(reads)
+    assert np.array_equal(code, want[:, 0].astype(np.uint8)), np.flatnonzero(code != want[:, 0])[:5]
+    hit = (code == 3) | (code == 4)
+    assert np.array_equal(perfect[hit, 0], want[hit, 1].astype(np.uint32))
+    assert np.array_equal(perfect[hit, 1], want[hit, 2].astype(np.uint32))
+    assert hit.sum() > 800 and (perfect[hit, 0] >> 2).astype(bool).sum() > 20 and set(code) >= {0, 1, 2, 3, 4}
+    # the hits are exactly what seeding skips (bwamem.cpp:674-689)
+    skip = hit.astype(np.uint8)
+    sm, _, _ = b.seed(enc, cum, skip=skip, with_sa=False)
+    assert not np.any(skip[sm["rid"]])
+    b.close(); e.close(); ix.close()

@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fma", action="store_true", help="build and use the FMA tables (all_smem.11 / last_smem.13)")
+    ap.add_argument("--emf", action="store_true", help="build the exact-match filter table (L=150) on the GPU and probe it first")
     ap.add_argument("--pcie", action="store_true", help="also time the one-call host-buffer form (PCIe inclusive)")
     args = ap.parse_args()
 
@@ -122,6 +123,16 @@ def main():
         ix.build_fma(11, 13)
         log(f"FMA tables built on GPU in {time.time()-t0:.1f}s (512 MiB + 1 GiB)")
 
+    emf_h = None
+    if args.emf:
+        from bwams import emf as emf_mod
+        t0 = time.time()
+        emf_tab = emf_mod.build_emf_torch(genome, 150, dev)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        emf_h = capi.Emf(ix, device_table=emf_tab)
+        log(f"EMF table built on GPU in {time.time()-t0:.1f}s: {emf_tab.seed_table.shape[0]/1e6:.0f} M entries "
+            f"({emf_tab.seed_table.numel()*4/2**30:.1f} GiB), {emf_tab.num_seed_used/1e6:.0f} M seeds")
     R = args.reads
     t0 = time.time()
     reads, _, _ = simulate.make_reads(genome, R, seed=12345 + rank)
@@ -136,7 +147,9 @@ def main():
     sw_opt = capi.default_sw_opt()
 
     def step():
-        # reads -> seeds -> (interim one-seed chains) extension tasks -> banded SW, all on the device
+        # reads -> [EMF] -> seeds -> (interim one-seed chains) extension tasks -> banded SW, all on the device
+        if emf_h is not None:
+            batch.emf_run(emf_h)
         batch.seed_run(seed_opt, with_sa=True)
         batch.tasks_from_seeds(sw_opt, 1, 100, seed_opt.max_occ)
         batch.bsw_run(100, sw_opt)
@@ -202,7 +215,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{R} synthetic 150bp SE reads per GPU vs synthetic {args.genome_mbp:.0f} Mbp genome "
-                            f"(GRCh38 unavailable offline), FM-index{' + FMA tables' if args.fma else ' only (no ERT/FMA/EMF)'}; step = pack reads, SMEM r1-r3, sort, "
+                            f"(GRCh38 unavailable offline), FM-index{' + FMA tables' if args.fma else ''}{' + EMF (L=150)' if args.emf else ''}"
+                            f"{'' if (args.fma or args.emf) else ' only (no ERT/FMA/EMF)'}; step = {'EMF probe, ' if args.emf else ''}pack reads, SMEM r1-r3, sort, "
                             f"SA lookup, task construction from the longest seed of each read (interim: the reference's "
                             f"chaining is not built yet), banded-SW w=100 of those tasks; everything on the GPU",
                 "genome_mbp": args.genome_mbp,
@@ -218,6 +232,7 @@ def main():
                 "sort": round(float(np.mean([s.ms_sort for s in per_step])), 3),
                 "sa_lookup": round(float(np.mean([s.ms_sal for s in per_step])), 3),
                 "seed_total": round(float(np.mean([s.ms_seed_total for s in per_step])), 3),
+                "emf": round(float(np.mean([s.ms_emf for s in per_step])), 3),
                 "tasks": round(float(np.mean([s.ms_tasks for s in per_step])), 3),
                 "bsw": round(float(np.mean([s.ms_bsw for s in per_step])), 3),
             },
@@ -244,6 +259,14 @@ def main():
                 "launch_ms": round(r1_ms, 3),
             },
         }
+        if emf_h is not None:
+            _, codes = batch.emf_fetch(R)
+            emf_ms = float(np.mean([s.ms_emf for s in per_step]))
+            emf_bytes = 16 * st.emf_nodes + st.emf_cmp_bytes + int(cum[-1])
+            out["emf"] = {"resolved_fraction": round(float(((codes == 3) | (codes == 4)).mean()), 4),
+                          "launch_ms": round(emf_ms, 3), "nodes_per_read": round(st.emf_nodes / R, 3),
+                          "algorithmic_bytes": int(emf_bytes),
+                          "achieved_GBps": round(emf_bytes / (emf_ms * 1e-3) / 1e9, 1) if emf_ms > 0 else None}
         if args.pcie:
             # host buffers in, host buffers out (bwams_seed_fmi + bwams_bsw_extend): never `value`
             t0 = time.perf_counter()

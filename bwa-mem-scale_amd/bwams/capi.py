@@ -32,6 +32,7 @@ SYMBOLS = [
     "bwams_tasks_from_seeds", "bwams_tasks_fetch",
     "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
     "bwams_emf_open", "bwams_emf_from_host", "bwams_emf_close", "bwams_emf_probe",
+    "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
 ]
 
 
@@ -64,7 +65,8 @@ class Stats(C.Structure):
                 ("n_ext_round", C.c_int64 * 3), ("n_blk_round", C.c_int64 * 3),
                 ("ms_smem_r1", C.c_float), ("ms_smem_r2", C.c_float), ("ms_smem_r3", C.c_float),
                 ("ms_sort", C.c_float), ("ms_sal", C.c_float), ("ms_seed_total", C.c_float),
-                ("ms_bsw", C.c_float), ("ms_ksw", C.c_float), ("ms_tasks", C.c_float)]
+                ("ms_bsw", C.c_float), ("ms_ksw", C.c_float), ("ms_tasks", C.c_float), ("ms_emf", C.c_float),
+                ("emf_nodes", C.c_int64), ("emf_cmp_bytes", C.c_int64)]
 
 
 def default_seed_opt() -> SeedOpt:
@@ -138,6 +140,9 @@ def lib():
         L.bwams_emf_open.argtypes = [vp, C.c_char_p, vp]
         L.bwams_emf_from_host.argtypes = [vp, i32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp]
         L.bwams_emf_close.argtypes = [vp]
+        L.bwams_emf_from_device.argtypes = [vp, i32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp]
+        L.bwams_emf_run.argtypes = [vp, vp]
+        L.bwams_emf_fetch.argtypes = [vp, vp, vp]
         L.bwams_emf_probe.argtypes = [vp, vp, vp, vp, i64, vp, vp]
         L.bwams_batch_stats.argtypes = [vp, vp]
         L.bwams_batch_sync.argtypes = [vp]
@@ -225,10 +230,16 @@ class Index:
 class Emf:
     """EMF table resident in HBM (bwams.emf.EmfTable or a <prefix>.perfect.<L> file)."""
 
-    def __init__(self, index: Index, table=None, path: str | None = None):
+    def __init__(self, index: Index, table=None, path: str | None = None, device_table=None):
         self.index = index
         self.h = C.c_void_p()
-        if path is not None:
+        self._keep = device_table
+        if device_table is not None:          # EmfTable of torch tensors on the index's GPU
+            t = device_table
+            _chk(lib().bwams_emf_from_device(index.h, t.seed_len, t.seq_len, t.loc_table.data_ptr(), t.loc_table.numel(),
+                                             t.seed_table.data_ptr(), t.seed_table.shape[0], C.byref(self.h)),
+                 "bwams_emf_from_device")
+        elif path is not None:
             _chk(lib().bwams_emf_open(index.h, path.encode(), C.byref(self.h)), "bwams_emf_open")
         else:
             loc = np.ascontiguousarray(table.loc_table, dtype=np.uint32)
@@ -355,6 +366,15 @@ class Batch:
         out = np.zeros((max(n, 1), 2), dtype=np.uint32)
         code = np.zeros(max(n, 1), dtype=np.uint8)
         _chk(lib().bwams_emf_probe(self.h, emf.h, _p(enc), _p(cum), n, _p(out), _p(code)), "bwams_emf_probe")
+        return out[:n], code[:n]
+
+    def emf_run(self, emf: Emf):
+        _chk(lib().bwams_emf_run(self.h, emf.h), "bwams_emf_run")
+
+    def emf_fetch(self, n: int):
+        out = np.zeros((max(n, 1), 2), dtype=np.uint32)
+        code = np.zeros(max(n, 1), dtype=np.uint8)
+        _chk(lib().bwams_emf_fetch(self.h, _p(out), _p(code)), "bwams_emf_fetch")
         return out[:n], code[:n]
 
     def stats(self) -> Stats:

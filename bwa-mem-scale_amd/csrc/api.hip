@@ -329,6 +329,7 @@ int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, 
     b->cu_count = prop.multiProcessorCount;
     BWAMS_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     for (auto &e : b->ev) BWAMS_HIP(hipEventCreate(&e));
+    for (auto &e : b->ev_emf) BWAMS_HIP(hipEventCreate(&e));
 
     BWAMS_HIP(hipMalloc(&b->d_enc, (size_t)max_bases + 64));
     BWAMS_HIP(hipMalloc(&b->d_cum, (size_t)(max_reads + 1) * 8));
@@ -372,6 +373,8 @@ int bwams_batch_destroy(bwams_batch_t *b) {
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
     for (auto &e : b->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ev_emf)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(b->stream);
     delete b;
@@ -757,8 +760,68 @@ int bwams_emf_open(bwams_index_t *ix, const char *path, bwams_emf_t **out) {
     return rc;
 }
 
+int bwams_emf_from_device(bwams_index_t *ix, int32_t seed_len, uint32_t seq_len, const uint32_t *loc_table_dev,
+                          uint32_t num_loc_entry, const bwams_seed_entry_t *seed_table_dev, uint32_t num_seed_entry,
+                          bwams_emf_t **out) {
+    if (!ix || !out || !seed_table_dev || !num_seed_entry || seed_len <= 0 || !ix->d_ref) return BWAMS_ERR_ARG;
+    bwams_emf *e = new bwams_emf();
+    e->idx = ix;
+    e->owns = false;
+    e->t.seed_table = reinterpret_cast<const uint4 *>(seed_table_dev);
+    e->t.loc_table = loc_table_dev;
+    e->t.ref = ix->fmi.ref;
+    e->t.num_seed_entry = num_seed_entry;
+    e->t.num_loc_entry = num_loc_entry;
+    e->t.seq_len = seq_len;
+    e->t.seed_len = seed_len;
+    e->bytes = (int64_t)num_seed_entry * 16 + (int64_t)num_loc_entry * 4;
+    *out = e;
+    return BWAMS_OK;
+}
+
+/* Resident form: probe the reads uploaded by bwams_seed_upload and set the batch's skip flags on the
+ * device, so that the following bwams_seed_run leaves the matched reads out. */
+int bwams_emf_run(bwams_batch_t *b, bwams_emf_t *e) {
+    if (!b || !e || e->idx != b->idx) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    const int64_t nseq = b->nseq;
+    if (nseq > b->cap_emf) {
+        if (b->d_emf_out) (void)hipFree(b->d_emf_out);
+        if (b->d_emf_code) (void)hipFree(b->d_emf_code);
+        b->d_emf_out = nullptr; b->d_emf_code = nullptr;
+        b->cap_emf = nseq + nseq / 8 + 256;
+        BWAMS_HIP(hipMalloc(&b->d_emf_out, (size_t)b->cap_emf * 8));
+        BWAMS_HIP(hipMalloc(&b->d_emf_code, (size_t)b->cap_emf));
+    }
+    hipStream_t st = b->stream;
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->emf_nodes, 0, 16, st));
+    BWAMS_HIP(hipEventRecord(b->ev_emf[0], st));
+    launch_emf_probe(e->t, b->d_enc, b->d_cum, nseq, b->d_emf_out, b->d_emf_code, b->d_skip, b->d_ctr, st);
+    BWAMS_HIP(hipEventRecord(b->ev_emf[1], st));
+    // seed_run clears the counters: keep the probe's own
+    BWAMS_HIP(hipMemcpyAsync(&b->h_ctr->emf_nodes, &b->d_ctr->emf_nodes, 16, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    b->emf_nodes = b->h_ctr->emf_nodes;
+    b->emf_cmp_bytes = b->h_ctr->emf_cmp_bytes;
+    BWAMS_HIP(hipGetLastError());
+    b->has_skip = true;
+    return BWAMS_OK;
+}
+
+int bwams_emf_fetch(bwams_batch_t *b, bwams_perfect_t *out, uint8_t *code) {
+    if (!b || !b->d_emf_out) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    if (b->nseq) {
+        if (out) BWAMS_HIP(hipMemcpyAsync(out, b->d_emf_out, (size_t)b->nseq * 8, hipMemcpyDeviceToHost, b->stream));
+        if (code) BWAMS_HIP(hipMemcpyAsync(code, b->d_emf_code, (size_t)b->nseq, hipMemcpyDeviceToHost, b->stream));
+    }
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+    return BWAMS_OK;
+}
+
 int bwams_emf_close(bwams_emf_t *e) {
     if (!e) return BWAMS_OK;
+    if (!e->owns) { delete e; return BWAMS_OK; }
     (void)hipSetDevice(e->idx->device);
     if (e->d_seeds) (void)hipFree(e->d_seeds);
     if (e->d_loc) (void)hipFree(e->d_loc);
@@ -787,7 +850,7 @@ int bwams_emf_probe(bwams_batch_t *b, bwams_emf_t *e, const uint8_t *enc, const 
     hipStream_t st = b->stream;
     if (nb) BWAMS_HIP(hipMemcpyAsync(b->d_enc, enc, (size_t)nb, hipMemcpyHostToDevice, st));
     BWAMS_HIP(hipMemcpyAsync(b->d_cum, cum, (size_t)(nseq + 1) * 8, hipMemcpyHostToDevice, st));
-    launch_emf_probe(e->t, b->d_enc, b->d_cum, nseq, b->d_emf_out, b->d_emf_code, st);
+    launch_emf_probe(e->t, b->d_enc, b->d_cum, nseq, b->d_emf_out, b->d_emf_code, nullptr, nullptr, st);
     BWAMS_HIP(hipGetLastError());
     if (nseq) {
         BWAMS_HIP(hipMemcpyAsync(out, b->d_emf_out, (size_t)nseq * 8, hipMemcpyDeviceToHost, st));
@@ -975,6 +1038,12 @@ int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out) {
     el(6, 7, &s.ms_bsw);
     el(14, 15, &s.ms_ksw);
     el(1, 2, &s.ms_tasks);
+    {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b->ev_emf[0], b->ev_emf[1]) == hipSuccess) s.ms_emf = ms;
+    }
+    s.emf_nodes = (int64_t)b->emf_nodes;
+    s.emf_cmp_bytes = (int64_t)b->emf_cmp_bytes;
     (void)hipGetLastError();
     *out = s;
     return BWAMS_OK;

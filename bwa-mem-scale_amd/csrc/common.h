@@ -61,7 +61,8 @@ struct DevCounters {
     unsigned long long n_work2;          // round-2 work items
     unsigned long long overflow;         // SMEM pool overflow flag / needed size
     unsigned long long bsw_cells;
-    unsigned long long ext_after[3], blk_after[3];   // n_ext / n_ext_blocks when round 1, 2, 3 ended
+    unsigned long long ext_after[3], blk_after[3];
+    unsigned long long emf_nodes, emf_cmp_bytes;     // EMF probe: entries visited, reference bytes compared   // n_ext / n_ext_blocks when round 1, 2, 3 ended
 };
 
 // banded-SW parameters in kernel form (max_sc = max entry of mat)
@@ -87,7 +88,7 @@ void launch_task_build(const void *plan, const int32_t *cnt, const int64_t *offs
                        const uint8_t *ref0123, int64_t nseq, int a, bwams_seqpair_t *pairs, uint8_t *refbuf,
                        uint8_t *qerbuf, int cu_count, hipStream_t st);
 void launch_emf_probe(const DevEmf &t, const uint8_t *enc, const int64_t *cum, int64_t nseq, uint32_t *out,
-                      uint8_t *code, hipStream_t st);
+                      uint8_t *code, uint8_t *skip, DevCounters *ctr, hipStream_t st);
 void launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
                 int pmax, int tmax, void *out, DevCounters *ctr, int cu_count, hipStream_t st);
 
@@ -106,6 +107,7 @@ struct bwams_index {
 struct bwams_emf {
     bwams_index *idx = nullptr;
     bwams::DevEmf t{};
+    bool owns = true;
     void *d_seeds = nullptr, *d_loc = nullptr;
     int64_t bytes = 0;
 };
@@ -166,5 +168,7 @@ struct bwams_batch {
     int64_t cap_ksw = 0;
 
     hipEvent_t ev[16] = {};
+    hipEvent_t ev_emf[2] = {};
+    unsigned long long emf_nodes = 0, emf_cmp_bytes = 0;
     bwams_stats_t stats{};
 };

@@ -54,9 +54,11 @@ __device__ __forceinline__ bool match_further(const DevEmf &t, uint32_t loc, con
 __global__ __launch_bounds__(256) void emf_probe_kernel(DevEmf t, const uint8_t *__restrict__ enc,
                                                         const int64_t *__restrict__ cum, int64_t nseq,
                                                         uint32_t *__restrict__ out /* flags, location */,
-                                                        uint8_t *__restrict__ code_out) {
+                                                        uint8_t *__restrict__ code_out, uint8_t *__restrict__ skip,
+                                                        DevCounters *ctr) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nseq) return;
+    unsigned long long n_nodes = 0, n_cmp_bytes = 0;
+    if (r < nseq) {
     const uint8_t *seed = enc + cum[r];
     const int len = (int)(cum[r + 1] - cum[r]);
     uint32_t flags = 0, location = 0;
@@ -91,6 +93,8 @@ __global__ __launch_bounds__(256) void emf_probe_kernel(DevEmf t, const uint8_t 
                 while (true) {
                     const bool efl = (ent.x & 1u) != 0;
                     const int cmp = seedcmp(t.ref + ent.y, efl, seed, fw_less, L);
+                    n_nodes++;
+                    n_cmp_bytes += (unsigned long long)L;
                     if (cmp == 0) {
                         bool is_rev = efl != fw_less;
                         if (len == L) {
@@ -136,14 +140,25 @@ __global__ __launch_bounds__(256) void emf_probe_kernel(DevEmf t, const uint8_t 
     out[2 * r] = flags;
     out[2 * r + 1] = location;
     code_out[r] = (uint8_t)code;
+    if (skip) skip[r] = (code == 3 || code == 4) ? 1 : 0;
+    }
+    // algorithmic bytes of this launch: 16 B per entry visited + L B per compare
+    for (int o = 32; o > 0; o >>= 1) {
+        n_nodes += ((unsigned long long)__shfl_down((uint32_t)n_nodes, o)) | ((unsigned long long)__shfl_down((uint32_t)(n_nodes >> 32), o) << 32);
+        n_cmp_bytes += ((unsigned long long)__shfl_down((uint32_t)n_cmp_bytes, o)) | ((unsigned long long)__shfl_down((uint32_t)(n_cmp_bytes >> 32), o) << 32);
+    }
+    if (ctr && (threadIdx.x & 63) == 0 && n_nodes) {
+        atomicAdd(&ctr->emf_nodes, n_nodes);
+        atomicAdd(&ctr->emf_cmp_bytes, n_cmp_bytes);
+    }
 }
 
 }  // namespace
 
 void launch_emf_probe(const DevEmf &t, const uint8_t *enc, const int64_t *cum, int64_t nseq, uint32_t *out,
-                      uint8_t *code, hipStream_t st) {
+                      uint8_t *code, uint8_t *skip, DevCounters *ctr, hipStream_t st) {
     if (nseq <= 0) return;
-    emf_probe_kernel<<<(unsigned)((nseq + 255) / 256), 256, 0, st>>>(t, enc, cum, nseq, out, code);
+    emf_probe_kernel<<<(unsigned)((nseq + 255) / 256), 256, 0, st>>>(t, enc, cum, nseq, out, code, skip, ctr);
 }
 
 }  // namespace bwams

@@ -153,6 +153,10 @@ int bwams_emf_open(bwams_index_t *idx, const char *path, bwams_emf_t **out);
 int bwams_emf_from_host(bwams_index_t *idx, int32_t seed_len, uint32_t seq_len, const uint32_t *loc_table,
                         uint32_t num_loc_entry, const bwams_seed_entry_t *seed_table, uint32_t num_seed_entry,
                         bwams_emf_t **out);
+/* adopt a table that already lives in this GPU's memory (not copied, not freed) */
+int bwams_emf_from_device(bwams_index_t *idx, int32_t seed_len, uint32_t seq_len, const uint32_t *loc_table_dev,
+                          uint32_t num_loc_entry, const bwams_seed_entry_t *seed_table_dev, uint32_t num_seed_entry,
+                          bwams_emf_t **out);
 int bwams_emf_close(bwams_emf_t *emf);
 
 /* Replaces the kernel-0 loop of mem_kernel1_core (src/bwamem.cpp:1245-1272): for every read
@@ -162,6 +166,11 @@ int bwams_emf_close(bwams_emf_t *emf);
  * `code[i] == 3 || code[i] == 4` is the `skip` flag bwams_seed_fmi takes. */
 int bwams_emf_probe(bwams_batch_t *b, bwams_emf_t *emf, const uint8_t *enc_qdb, const int64_t *cum_len,
                     int64_t nseq, bwams_perfect_t *out, uint8_t *code);
+
+/* Resident form: probe the reads uploaded by bwams_seed_upload and set the skip flags on the device,
+ * so that the next bwams_seed_run leaves the matched reads out; fetch returns the probe results. */
+int bwams_emf_run(bwams_batch_t *b, bwams_emf_t *emf);
+int bwams_emf_fetch(bwams_batch_t *b, bwams_perfect_t *out, uint8_t *code);
 
 /* ------------------------------------------------------ tasks from seeds ---- */
 
@@ -209,6 +218,9 @@ typedef struct bwams_stats {
     float   ms_bsw;
     float   ms_ksw;
     float   ms_tasks;
+    float   ms_emf;
+    int64_t emf_nodes;        /* EMF probe: seed entries visited */
+    int64_t emf_cmp_bytes;    /* EMF probe: reference bytes compared */
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 

@@ -351,3 +351,38 @@ def test_emf_probe_matches_oracle(gpu_toy, L, tmp_path):
     sm, _, _ = b.seed(enc, cum, skip=skip, with_sa=False)
     assert not np.any(skip[sm["rid"]])
     b.close(); e.close(); ix.close()
+
+
+def test_emf_resident_run_with_gpu_built_table(gpu_toy):
+    """Table built on the GPU (torch builder) and adopted without a host copy; the resident probe sets the
+    skip flags that the following seed run honours; results == the oracle on the same table."""
+    import torch
+    from bwams import emf
+    g0, _, _ = gpu_toy
+    g = g0[:80000].copy()
+    idx = fmindex.build_fmindex(g)
+    ix = capi.Index.from_host(idx, 0)
+    t = emf.build_emf_torch(g, 150, "cuda:0")
+    e = capi.Emf(ix, device_table=t)
+    host_tab = emf.EmfTable(t.seed_len, t.seq_len, t.loc_table.cpu().numpy().view(np.uint32),
+                            t.seed_table.cpu().numpy().view(np.uint32), t.num_seed_used, t.num_seed_key)
+    o = loader.OracleEMF(host_tab, idx.ref_0123)
+    reads, _, _ = simulate.make_reads(g, 4000, seed=51)
+    enc, cum = simulate.flatten_reads(reads)
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.emf_run(e)
+    perfect, code = b.emf_fetch(len(reads))
+    want = o.probe_many(list(reads))
+    assert np.array_equal(code, want[:, 0].astype(np.uint8))
+    hit = (code == 3) | (code == 4)
+    assert np.array_equal(perfect[hit], want[hit, 1:].astype(np.uint32)) and 0.2 < hit.mean() < 0.8
+    b.seed_run(with_sa=True)
+    sm, coord, off = b.seed_fetch()
+    assert not np.any(hit[sm["rid"]])
+    oo = loader.OracleFMI(idx)
+    want_sm = oo.collect_smem(enc, cum, skip=hit.astype(np.uint8))
+    assert np.array_equal(sm["k"], want_sm["k"]) and np.array_equal(sm["rid"], want_sm["rid"])
+    st = b.stats()
+    assert st.emf_nodes >= hit.sum() and st.emf_cmp_bytes == st.emf_nodes * 150
+    b.close(); e.close(); ix.close()

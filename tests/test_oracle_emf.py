@@ -124,3 +124,39 @@ def test_builder_and_probe_against_brute_force(L, tmp_path):
         if flags >> 2:
             n_multi += 1
     assert n_hit > 200 and n_multi > 10
+
+
+def test_torch_builder_against_brute_force():
+    """The bench-scale builder (torch; here on the CPU device) yields a valid table: every probe result
+    agrees with exhaustive search, and its hit/miss decisions equal the numpy builder's."""
+    L = 70
+    g = simulate.make_genome(9000, seed=81, repeat_frac=0.3, repeat_len=160, n_families=2, repeat_div=0.005)
+    g[300:420] = (3 - g[300:420][::-1])
+    t = emf.build_emf_torch(g, L, "cpu")
+    tab = emf.EmfTable(t.seed_len, t.seq_len, t.loc_table.numpy().view(np.uint32), t.seed_table.numpy().view(np.uint32),
+                       t.num_seed_used, t.num_seed_key)
+    ref_tab = emf.build_emf(g, L)
+    assert tab.num_seed_used == ref_tab.num_seed_used and tab.num_seed_key == ref_tab.num_seed_key
+    ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    o, o2 = loader.OracleEMF(tab, ref), loader.OracleEMF(ref_tab, ref)
+    rng = np.random.default_rng(4)
+    hits = 0
+    for it in range(500):
+        ln = L if it % 3 else int(rng.integers(L + 1, L + 30))
+        st = int(rng.integers(0, len(g) - ln))
+        rd = g[st: st + ln].copy()
+        if it % 4 == 1:
+            rd = (3 - rd[::-1]).astype(np.uint8)
+        elif it % 4 == 2:
+            rd[rng.integers(0, ln)] ^= 1
+        code, flags, loc = o.probe(rd)
+        code2, _, _ = o2.probe(rd)
+        assert (code in (3, 4)) == (code2 in (3, 4)), (it, code, code2)
+        truth = _brute_locations(g, rd)
+        if code in (3, 4):
+            is_rc = 1 if flags & 2 else 0
+            assert (loc if not is_rc else loc - (ln - L), is_rc) in truth
+            hits += 1
+        else:
+            assert not truth
+    assert hits > 200

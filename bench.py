@@ -278,7 +278,7 @@ def main():
             dt = (time.perf_counter() - t0) / 2
             out["pcie_inclusive"] = {"value": round(R / dt / 1e6, 4), "unit": "Mreads/s", "ms_per_batch": round(dt * 1e3, 2),
                                      "note": "pageable host buffers, upload + run + download per call, includes numpy copies"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on a sample (cpu_baseline)...")
             threads = min(16, os.cpu_count() or 1)
             n_s = min(args.cpu_sample, R)

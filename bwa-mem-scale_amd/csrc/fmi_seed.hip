@@ -244,17 +244,44 @@ __device__ __forceinline__ void flush_counters(DevCounters *ctr, unsigned long l
 // one 16-byte request:  x = k[31:0]  y = l[31:0]  z = s[31:0]
 //                       w = n[15:0] | k[35:32] << 16 | l[35:32] << 20 | s[35:32] << 24
 // (36-bit rows: texts up to 2^36 = 68 G rows; GRCh38 has 6.4 G.)
-__device__ __forceinline__ void prev_store(uint4 *__restrict__ base, int e, int64_t k, int64_t l, int64_t s, int n) {
+__device__ __forceinline__ uint4 prev_pack(int64_t k, int64_t l, int64_t s, int n) {
     const uint32_t w = (uint32_t)(n & 0xffff) | (((uint32_t)((uint64_t)k >> 32) & 0xf) << 16) |
                        (((uint32_t)((uint64_t)l >> 32) & 0xf) << 20) | (((uint32_t)((uint64_t)s >> 32) & 0xf) << 24);
-    base[e] = make_uint4((uint32_t)k, (uint32_t)l, (uint32_t)s, w);
+    return make_uint4((uint32_t)k, (uint32_t)l, (uint32_t)s, w);
 }
-__device__ __forceinline__ void prev_load(const uint4 *__restrict__ base, int e, int64_t &k, int64_t &l, int64_t &s, int &n) {
-    const uint4 a = base[e];
+__device__ __forceinline__ void prev_unpack(const uint4 a, int64_t &k, int64_t &l, int64_t &s, int &n) {
     k = (int64_t)mk64(a.x, (a.w >> 16) & 0xf);
     l = (int64_t)mk64(a.y, (a.w >> 20) & 0xf);
     s = (int64_t)mk64(a.z, (a.w >> 24) & 0xf);
     n = (int)(a.w & 0xffff);
+}
+
+// The list with its head in LDS.  Entries are pushed at decreasing physical indices during the
+// forward phase (ph = cap-1, cap-2, ...); the backward phase addresses them logically
+// (p = physical - base, base = cap - num_prev, p = 0 is the last one pushed).  The kPrevLds most
+// recently pushed entries — logical indices [0, kPrevLds) — live in an LDS ring (slot = physical
+// index mod kPrevLds, column of the owning lane); older ones are spilled to the HBM list when the
+// ring wraps.  The backward phase compacts towards logical 0, so once a list has shrunk below
+// kPrevLds entries it never touches HBM again.  (A third of the round-1 kernel's HBM traffic was
+// this list: profiles/r01_notes.md.)
+constexpr int kPrevLds = 8;
+struct PrevList {
+    uint4 *glob;          // this lane's HBM list
+    uint4 *ring;          // this lane's LDS column: ring[slot * kBlock]
+};
+__device__ __forceinline__ void prev_push(const PrevList &pl, int ph, int num_prev, int64_t k, int64_t l, int64_t s, int n) {
+    uint4 *slot = pl.ring + (ph & (kPrevLds - 1)) * kBlock;
+    if (num_prev >= kPrevLds) pl.glob[ph + kPrevLds] = *slot;      // the entry pushed kPrevLds pushes ago leaves the ring
+    *slot = prev_pack(k, l, s, n);
+}
+__device__ __forceinline__ void prev_get(const PrevList &pl, int base, int p, int64_t &k, int64_t &l, int64_t &s, int &n) {
+    const uint4 a = p < kPrevLds ? pl.ring[((base + p) & (kPrevLds - 1)) * kBlock] : pl.glob[base + p];
+    prev_unpack(a, k, l, s, n);
+}
+__device__ __forceinline__ void prev_put(const PrevList &pl, int base, int p, int64_t k, int64_t l, int64_t s, int n) {
+    const uint4 a = prev_pack(k, l, s, n);
+    if (p < kPrevLds) pl.ring[((base + p) & (kPrevLds - 1)) * kBlock] = a;
+    else pl.glob[base + p] = a;
 }
 
 // ---- FMA table builders --------------------------------------------------------------------
@@ -406,9 +433,11 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
     const DevFmi &f = a.fmi;
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int cap = a.prev_cap;
-    uint4 *const prev = a.prev + slot * (int64_t)cap;
     extern __shared__ uint32_t lds_reads[];
     uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
+    PrevList prev;
+    prev.glob = a.prev + slot * (int64_t)cap;
+    prev.ring = reinterpret_cast<uint4 *>(lds_reads + (a.reads_in_lds ? a.read_w * kBlock : 0)) + threadIdx.x;
     ReadView rv;
     rv.lds_col = lds_col;
     rv.gl = a.packed;
@@ -431,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0;
-    const bool defer_reads = a.reads_in_lds && a.read_w == 16;
+    const bool defer_reads = false && a.reads_in_lds && a.read_w == 16;   // measured: no gain, costs 16 VGPRs (3 instead of 4 waves/SIMD)
     PendingRead pend;
     pend.v0 = pend.v1 = pend.v2 = pend.v3 = make_uint4(0, 0, 0, 0);
 
@@ -445,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             if (num_prev != 0) {
                 int64_t qk, ql, qs;
                 int qn;
-                prev_load(prev, base, qk, ql, qs, qn);
+                prev_get(prev, base, 0, qk, ql, qs, qn);
                 if (qn - cur_m + 1 >= a.min_seed_len) {
                     em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)qn; em_k = qk; em_l = ql; em_s = qs;
                 }
@@ -521,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
                             const int64_t tl = cnt_at(f, 3 - bb) + ent[2 + 3 * t];
                             const int64_t ts = ent[3 + 3 * t];
                             if (ts != cs) {
-                                prev_store(prev, cap - 1 - num_prev, ck, cl, cs, cn);
+                                prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
                                 num_prev++;
                             }
                             if (ts < min_intv) {
@@ -562,7 +591,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
         }
         if (phase == PH_FWD_END) {
             if (cs >= min_intv) {
-                prev_store(prev, cap - 1 - num_prev, ck, cl, cs, cn);
+                prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
                 num_prev++;
             }
             base = cap - num_prev;                      // entry p lives at base + p, longest first
@@ -584,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             if (!go) {
                 phase = PH_BWD_END;
             } else {
-                prev_load(prev, base + p, pk, pl, ps, pn);
+                prev_get(prev, base, p, pk, pl, ps, pn);
                 do_ext = true;
                 ek = pk; el = pl; es = ps; ea = bwd_a;
             }
@@ -602,7 +631,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
         if (do_ext && phase == PH_FWD) {
             // the extended interval is (k, l) = (nl, nk) after swapping strands back
             if (ns != cs) {
-                prev_store(prev, cap - 1 - num_prev, ck, cl, cs, cn);
+                prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
                 num_prev++;
             }
             if (ns < min_intv) {
@@ -615,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             }
             if (phase == PH_FWD_END) {
                 if (cs >= min_intv) {
-                    prev_store(prev, cap - 1 - num_prev, ck, cl, cs, cn);
+                    prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
                     num_prev++;
                 }
                 base = cap - num_prev;
@@ -639,7 +668,7 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
             }
             if (keep) {
                 curr_s = (int32_t)ns;
-                prev_store(prev, base + num_curr, nk, nl, ns, pn);
+                prev_put(prev, base, num_curr, nk, nl, ns, pn);
                 num_curr++;
             }
             p++;
@@ -713,7 +742,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0;
-    const bool defer_reads = a.reads_in_lds && a.read_w == 16;
+    const bool defer_reads = false && a.reads_in_lds && a.read_w == 16;   // measured: no gain, costs 16 VGPRs (3 instead of 4 waves/SIMD)
     PendingRead pend;
     pend.v0 = pend.v1 = pend.v2 = pend.v3 = make_uint4(0, 0, 0, 0);
 
@@ -857,6 +886,7 @@ int grid_for(int64_t n_items, int cu_count) {
 }  // namespace
 
 static size_t lds_bytes(const SeedLaunch &a) { return a.reads_in_lds ? (size_t)a.read_w * kBlock * 4 : 0; }
+static size_t lds_bytes_search(const SeedLaunch &a) { return lds_bytes(a) + (size_t)kPrevLds * kBlock * 16; }
 
 void launch_pack_reads(const uint8_t *enc, const int64_t *cum, int64_t nseq, int W, int cw, uint32_t *packed,
                        hipStream_t st) {
@@ -878,7 +908,7 @@ int64_t seed_pool_slack(int cu_count) { return seed_max_threads(cu_count) / 64 *
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
 
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st) {
-    smem_search_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, nullptr);
+    smem_search_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
 }
 
 void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
@@ -888,7 +918,7 @@ void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap,
 
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     // the number of items is only known on the device: launch the persistent grid at chip size
-    smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, work);
+    smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {

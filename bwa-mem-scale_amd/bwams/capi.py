@@ -264,16 +264,27 @@ class Batch:
         self.max_sa = max_sa if max_sa > 0 else 64 * max_reads + 1024
 
     def seed(self, enc, cum, opt: SeedOpt | None = None, skip=None, with_sa: bool = True):
-        """One-call seeding on host buffers: (smems, sa_coord, sa_off)."""
+        """Seeding on host buffers: (smems, sa_coord, sa_off).  Upload, run, then download into arrays of
+        exactly the produced size (the one-call C entry point needs caller buffers of capacity size)."""
+        opt = opt or default_seed_opt()
+        self.seed_upload(enc, cum, skip)
+        self.seed_run(opt, with_sa)
+        sm, coord, off = self.seed_fetch()
+        if with_sa:
+            return sm, coord, off
+        return sm, None, None
+
+    def seed_onecall(self, enc, cum, opt: SeedOpt | None = None, skip=None, with_sa: bool = True):
+        """bwams_seed_fmi with capacity-sized caller buffers (what a reference-side caller does)."""
         opt = opt or default_seed_opt()
         enc = np.ascontiguousarray(enc, dtype=np.uint8)
         cum = np.ascontiguousarray(cum, dtype=np.int64)
         sk = np.ascontiguousarray(skip, dtype=np.uint8) if skip is not None else None
         nseq = len(cum) - 1
-        sm = np.zeros(self.max_smem, dtype=SMEM_DTYPE)
+        sm = np.empty(self.max_smem, dtype=SMEM_DTYPE)
         ns, na = C.c_int64(0), C.c_int64(0)
-        coord = np.zeros(self.max_sa, dtype=np.int64) if with_sa else None
-        off = np.zeros(self.max_smem + 1, dtype=np.int64) if with_sa else None
+        coord = np.empty(self.max_sa, dtype=np.int64) if with_sa else None
+        off = np.empty(self.max_smem + 1, dtype=np.int64) if with_sa else None
         _chk(lib().bwams_seed_fmi(self.h, _p(enc), _p(cum), _p(sk), nseq, C.byref(opt), _p(sm), self.max_smem,
                                   C.byref(ns), _p(coord), self.max_sa, _p(off), C.byref(na)), "bwams_seed_fmi")
         n = ns.value

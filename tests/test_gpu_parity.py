@@ -106,7 +106,7 @@ def test_capacity_error_is_reported_not_truncated(gpu_toy):
     enc, cum = simulate.flatten_reads(reads)
     b = capi.Batch(ix, 500, int(cum[-1]), max_smem=100, max_sa=100)
     with pytest.raises(capi.BwamsError) as e:
-        b.seed(enc, cum)
+        b.seed_onecall(enc, cum)
     assert e.value.code == -4
     b.close()
 
@@ -119,6 +119,12 @@ def test_index_file_path(gpu_toy, tmp_path):
     reads, _, _ = simulate.make_reads(g, 300, seed=4)
     want, wcoord, woff, got, coord, off, _ = _seed_both(idx, ix2, reads)
     assert np.array_equal(got["k"], want["k"]) and np.array_equal(coord, wcoord)
+    # the one-call entry point (caller buffers of capacity size) returns the same
+    enc, cum = simulate.flatten_reads(reads)
+    b = capi.Batch(ix2, len(reads), int(cum[-1]))
+    sm1, c1, o1 = b.seed_onecall(enc, cum)
+    assert np.array_equal(sm1["k"], want["k"]) and np.array_equal(c1, wcoord) and np.array_equal(o1, woff)
+    b.close()
     ix2.close()
 
 

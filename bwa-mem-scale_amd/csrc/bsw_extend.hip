@@ -297,58 +297,70 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
                 }
                 int m = 0, mj = -1;
                 int first_nz = 1 << 30, last_nz = -1;
-                int f_carry = 0, hl_carry = h1, h_last = h1;
+                int h_last = h1;
                 if (beg < end) {
                     cells += (unsigned long long)(end - beg);
                     const int c_lo = beg >> 6, c_hi = (end - 1) >> 6;
+                    // phase A — per chunk, independent of the other chunks: diagonal move, gap-open
+                    // source and its prefix maximum (the scans of different chunks overlap in the pipeline)
+                    int Mv[NCH], Tj[NCH], Pm[NCH];
+                    bool Act[NCH];
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
+                        Mv[c] = 0; Tj[c] = 0; Pm[c] = NEG; Act[c] = false;
                         if (c < c_lo || c > c_hi) continue;
-                        const int jb = c << 6;
-                        const int j = jb + lane;
+                        const int j = (c << 6) + lane;
                         const bool act = j >= beg && j < end;
-                        const int c0 = jb > beg ? jb : beg;
                         const int S = tb == 0 ? P0[c] : tb == 1 ? P1[c] : tb == 2 ? P2[c] : tb == 3 ? P3[c] : P4[c];
-                        const int hd = H[c], e = E[c];
+                        const int hd = H[c];
                         const int M = (act && hd) ? hd + S : 0;
                         int tj = M - oe_ins;
                         tj = tj > 0 ? tj : 0;
-                        const int g = act ? tj + JE[c] : NEG;
-                        const int Pm = scan_max(g);
-                        const int Pex = lane_shr1(Pm, NEG);
-                        int F = f_carry - (j - c0) * e_ins;
-                        const int F2 = Pex - (JE[c] - e_ins);
-                        F = F > F2 ? F : F2;
-                        int h = M > e ? M : e;
+                        Mv[c] = M; Tj[c] = tj; Act[c] = act;
+                        Pm[c] = scan_max(act ? tj + JE[c] : NEG);
+                    }
+                    // phase B — stitch the chunks: F from all columns to the left, H, E, shifted H
+                    int carry_src = NEG, carry_h = 0, hmax_lane = -1;
+                    int Hc[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        Hc[c] = 0;
+                        if (c < c_lo || c > c_hi) continue;
+                        const int j = (c << 6) + lane;
+                        int Pex = lane_shr1(Pm[c], carry_src);
+                        Pex = Pex > carry_src ? Pex : carry_src;
+                        int F = Pex - (JE[c] - e_ins);
+                        F = F > 0 ? F : 0;                                  // F(beg) = 0, F >= 0 everywhere
+                        const int e = E[c];
+                        int h = Mv[c] > e ? Mv[c] : e;
                         h = h > F ? h : F;
-                        int e2 = M - oe_del;
+                        int e2 = Mv[c] - oe_del;
                         e2 = e2 > 0 ? e2 : 0;
                         const int e1 = e - e_del;
                         e2 = e2 > e1 ? e2 : e1;
-                        int hl = lane_shr1(h, hl_carry);
-                        if (j == beg) hl = hl_carry;
-                        if (act) { H[c] = hl; E[c] = e2; }
-                        // row maximum and the last column attaining it
-                        const int hm = act ? h : -1;
-                        const int cm = __builtin_amdgcn_readlane(scan_max(hm), 63);
-                        if (cm >= m) {
-                            const unsigned long long eq = __ballot(act && h == cm);
-                            m = cm;
-                            mj = jb + 63 - __clzll((long long)eq);
-                        }
-                        const unsigned long long nz = __ballot(act && (hl != 0 || e2 != 0));
+                        int hl = lane_shr1(h, carry_h);
+                        if (j == beg) hl = h1;
+                        if (Act[c]) { H[c] = hl; E[c] = e2; }
+                        Hc[c] = h;
+                        hmax_lane = max(hmax_lane, Act[c] ? h : -1);
+                        const unsigned long long nz = __ballot(Act[c] && (hl != 0 || e2 != 0));
                         if (nz) {
-                            const int lo = jb + __ffsll((long long)nz) - 1;
-                            const int hi = jb + 63 - __clzll((long long)nz);
+                            const int lo = (c << 6) + __ffsll((long long)nz) - 1;
                             first_nz = first_nz < lo ? first_nz : lo;
-                            last_nz = hi;
+                            last_nz = (c << 6) + 63 - __clzll((long long)nz);
                         }
-                        int fn = F - e_ins;
-                        fn = fn > tj ? fn : tj;
-                        const int last_lane = (end - 1 < jb + 63 ? end - 1 : jb + 63) - jb;
-                        f_carry = __builtin_amdgcn_readlane(fn, 63);
-                        hl_carry = __builtin_amdgcn_readlane(h, 63);
-                        h_last = __builtin_amdgcn_readlane(h, last_lane);
+                        carry_h = __builtin_amdgcn_readlane(h, 63);
+                        const int cs = __builtin_amdgcn_readlane(Pm[c], 63);
+                        carry_src = carry_src > cs ? carry_src : cs;
+                        if (c == c_hi) h_last = __builtin_amdgcn_readlane(h, (end - 1) & 63);
+                    }
+                    // row maximum over all chunks (one scan) and the last column attaining it
+                    m = __builtin_amdgcn_readlane(scan_max(hmax_lane), 63);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        if (c < c_lo || c > c_hi) continue;
+                        const unsigned long long eq = __ballot(Act[c] && Hc[c] == m);
+                        if (eq) mj = (c << 6) + 63 - __clzll((long long)eq);
                     }
                 }
                 const int j_exit = beg < end ? end : beg;

@@ -60,4 +60,32 @@ np.savez_compressed(
     out_w200=np.stack([res[200][0][f] for f in OUT_FIELDS], axis=1),
     cells=np.array([res[100][1], res[200][1]]),
     checked_against_reference=np.array([REF is not None]))
+# ---- mate-rescue local SW: 120 cases x 2 kernels (byte / 16-bit), checked against the reference object ----
+from util import make_local_cases  # noqa: E402
+cases = make_local_cases(120, seed=404)
+flags = [loader.KSW_XSUBO | loader.KSW_XSTART | loader.KSW_XBYTE | 19, loader.KSW_XSUBO | loader.KSW_XSTART | 19]
+outs = []
+for fl in flags:
+    o_ = np.array([loader.ksw_align2(q, t, fl) for q, t in cases], dtype=np.int32)
+    if REF is not None:
+        r_ = np.array([loader.ref_ksw_align2(REF, q, t, fl) for q, t in cases], dtype=np.int32)
+        assert np.array_equal(o_, r_), fl
+    outs.append(o_)
+np.savez_compressed(
+    os.path.join(OUT, "ksw_cases.npz"),
+    qlen=np.array([len(q) for q, _ in cases]), tlen=np.array([len(t) for _, t in cases]),
+    qer=np.concatenate([q for q, _ in cases]), ref=np.concatenate([t for _, t in cases]),
+    flags=np.array(flags), out=np.stack(outs), checked_against_reference=np.array([REF is not None]))
+
+# ---- EMF: table + probes on the seeding genome ----
+from bwams import emf  # noqa: E402
+tab = emf.build_emf(g, 150)
+oe = loader.OracleEMF(tab, idx.ref_0123)
+probe_reads = list(reads) + [g[100:250].copy(), (3 - g[400:550][::-1]).astype(np.uint8), g[1000:1180].copy()]
+pe = oe.probe_many(probe_reads)
+np.savez_compressed(
+    os.path.join(OUT, "emf_toy.npz"),
+    loc_table=tab.loc_table, seed_table=tab.seed_table, seed_len=np.int32(tab.seed_len), seq_len=np.int64(tab.seq_len),
+    read_len=np.array([len(r) for r in probe_reads]), reads=np.concatenate(probe_reads), expect=pe)
+
 print("golden vectors written to", OUT, "| reference cross-check:", REF is not None)

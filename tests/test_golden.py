@@ -43,6 +43,36 @@ def test_oracle_reproduces_bsw_golden_and_reference_was_consulted():
         assert np.array_equal(np.stack([ours[f] for f in OUT_FIELDS], axis=1), z[key])
 
 
+def _ksw_case():
+    z = np.load(os.path.join(G, "ksw_cases.npz"))
+    qo = np.r_[0, np.cumsum(z["qlen"])]
+    to = np.r_[0, np.cumsum(z["tlen"])]
+    cases = [(z["qer"][qo[i]:qo[i + 1]], z["ref"][to[i]:to[i + 1]]) for i in range(len(z["qlen"]))]
+    return z, cases, qo, to
+
+
+def _emf_case():
+    from bwams import emf
+    z = np.load(os.path.join(G, "emf_toy.npz"))
+    tab = emf.EmfTable(int(z["seed_len"]), int(z["seq_len"]), z["loc_table"], z["seed_table"])
+    ro = np.r_[0, np.cumsum(z["read_len"])]
+    reads = [z["reads"][ro[i]:ro[i + 1]] for i in range(len(z["read_len"]))]
+    return z, tab, reads
+
+
+def test_oracle_reproduces_ksw_and_emf_golden():
+    z, cases, _, _ = _ksw_case()
+    assert bool(z["checked_against_reference"][0]), "regenerate with oracle/_ref present"
+    for k, fl in enumerate(z["flags"]):
+        got = np.array([loader.ksw_align2(q, t, int(fl)) for q, t in cases], dtype=np.int32)
+        assert np.array_equal(got, z["out"][k])
+    ze, tab, reads = _emf_case()
+    zs, idx = _seed_case()
+    o = loader.OracleEMF(tab, idx.ref_0123)
+    assert np.array_equal(o.probe_many(reads), ze["expect"])
+    assert set(ze["expect"][:, 0]) >= {2, 3, 4}
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_golden():
     from bwams import capi
@@ -60,5 +90,20 @@ def test_gpu_reproduces_golden():
     for w, key in ((100, "out_w100"), (200, "out_w200")):
         got = b.bsw(pairs, zb["ref"], zb["qer"], w)
         assert np.array_equal(np.stack([got[f] for f in OUT_FIELDS], axis=1), zb[key])
+    # mate-rescue local SW
+    zk, cases, qo, to = _ksw_case()
+    for k, fl in enumerate(zk["flags"]):
+        kp = np.zeros(len(cases), dtype=capi.SEQPAIR_DTYPE)
+        kp["idr"], kp["idq"], kp["len1"], kp["len2"], kp["h0"] = to[:-1], qo[:-1], zk["tlen"], zk["qlen"], int(fl)
+        assert np.array_equal(b.ksw_align(kp, zk["ref"], zk["qer"]), zk["out"][k])
+    # EMF probe
+    ze, tab, reads = _emf_case()
+    e = capi.Emf(ix, table=tab)
+    rl = ze["read_len"]
+    perfect, code = b.emf_probe(e, ze["reads"], np.r_[0, np.cumsum(rl)].astype(np.int64))
+    assert np.array_equal(code, ze["expect"][:, 0].astype(np.uint8))
+    hit = (code == 3) | (code == 4)
+    assert np.array_equal(perfect[hit], ze["expect"][hit, 1:].astype(np.uint32))
+    e.close()
     b.close()
     ix.close()

@@ -80,6 +80,14 @@ prescribes ("128-B requests tallied at 64 B"), and all four shapes saturate at t
 Round-1 search kernel per launch: algorithmic bytes {alg/1e9:.2f} GB; corrected traffic = 2 x {fetch/1e9:.2f} + {write/1e9:.2f}
 = **{(2*fetch+write)/1e9:.1f} GB** = {(2*fetch+write)/alg:.2f}x algorithmic.
 
+## Smith-Waterman kernels alone, against the real reference objects on the host cores
+
+`python tools/bench_sw.py` (profiles/{rnd}_sw_kernels.jsonl): the CPU column is `BandedPairWiseSW::getScores16` (AVX512) and
+`ksw_align2` (SSE2) of `oracle/_ref` — the reference's own code compiled from its tree — on the same tasks, 16 threads.
+
+```
+{open(f"profiles/{rnd}_sw_kernels.jsonl").read() if __import__("os").path.exists(f"profiles/{rnd}_sw_kernels.jsonl") else ""}```
+
 ## bench.py line of the same build
 
 ```json

@@ -79,7 +79,7 @@ def test_gpu_reproduces_golden():
     z, idx = _seed_case()
     enc, cum = simulate.flatten_reads(z["reads"])
     ix = capi.Index.from_host(idx, 0)
-    b = capi.Batch(ix, len(z["reads"]), int(cum[-1]))
+    b = capi.Batch(ix, len(z["reads"]) + 64, int(cum[-1]) + 16384)
     sm, coord, off = b.seed(enc, cum)
     _check_seeds(z, sm, coord, off)
     st = b.stats()

@@ -89,6 +89,78 @@ typedef struct bwams_kswr {
     int32_t tb, qb;         /* target / query start */
 } bwams_kswr_t;
 
+/* ---- chaining and chain-to-alignment (mem_chain_seeds .. mem_chain2aln_across_reads_V2) ---- */
+
+/* One reference sequence: the fields of bntann1_t (src/bntseq.h) the hot path reads. */
+typedef struct bwams_contig {
+    int64_t offset;         /* start on the forward strand */
+    int32_t len;
+    int32_t is_alt;
+} bwams_contig_t;
+
+/* The subset of mem_opt_t (src/bwamem.h:89-124) read by chaining, chain filtering, task
+ * construction and the post-extension bookkeeping.  Defaults: src/bwamem.cpp:135-171. */
+typedef struct bwams_mem_opt {
+    int32_t a;                          /* match score, default 1 */
+    int32_t o_del, e_del, o_ins, e_ins; /* 6, 1, 6, 1 */
+    int32_t pen_clip5, pen_clip3;       /* 5, 5 */
+    int32_t w;                          /* band width, 100 */
+    int32_t zdrop;                      /* 100 */
+    int32_t min_seed_len;               /* 19 */
+    int32_t min_chain_weight;           /* 0 */
+    int32_t max_chain_extend;           /* 1<<30 */
+    int32_t max_occ;                    /* 500 */
+    int32_t max_chain_gap;              /* 10000 */
+    float   mask_level;                 /* 0.50 */
+    float   drop_ratio;                 /* 0.50 */
+    int8_t  mat[25];
+    int8_t  pad_[3];
+} bwams_mem_opt_t;
+
+/* mem_seed_t (src/bwamem.h:129-140), 32 B, same field offsets. */
+typedef struct bwams_chain_seed {
+    int64_t rbeg;
+    int32_t qbeg, len, score;
+    int8_t  done;
+    int8_t  pad0_[3];
+    int32_t aln;            /* index of this seed's region within its read's region list */
+    int32_t pad1_;
+} bwams_chain_seed_t;
+
+/* mem_chain_t (src/bwamem.h:142-149), 48 B, same field offsets; the seeds pointer is replaced
+ * by the index of the chain's first seed in the flat seed array (seeds of a chain are contiguous,
+ * in the order mem_chain_seeds appended them). */
+typedef struct bwams_chain {
+    int32_t  seqid, cseed;
+    int32_t  n, m, first, rid;
+    uint32_t w_kept_alt;    /* w: bits 0-28, kept: bits 29-30, is_alt: bit 31 */
+    float    frac_rep;
+    int64_t  pos;
+    int64_t  seed_off;
+} bwams_chain_t;
+#define BWAMS_CHAIN_W(c)      ((c).w_kept_alt & 0x1fffffffu)
+#define BWAMS_CHAIN_KEPT(c)   (((c).w_kept_alt >> 29) & 3u)
+#define BWAMS_CHAIN_IS_ALT(c) ((c).w_kept_alt >> 31)
+
+/* mem_alnreg_t (src/bwamem.h:153-174), 112 B, same field offsets; the chain pointer is replaced
+ * by the index of the chain in the flat chain array.  Fields the extension stage does not set
+ * are zero, as after the reference's memset. */
+typedef struct bwams_alnreg {
+    int64_t  rb, re;
+    int32_t  qb, qe;
+    int32_t  rid;
+    int32_t  pad0_;
+    int64_t  chain;
+    int32_t  score, truesc, sub, alt_sc, csub, sub_n;
+    int32_t  w, seedcov, secondary, secondary_all, seedlen0;
+    int32_t  n_comp_is_alt;
+    float    frac_rep;
+    int32_t  pad1_;
+    uint64_t hash;
+    int32_t  flg;
+    int32_t  pad2_;
+} bwams_alnreg_t;
+
 #ifdef __cplusplus
 }
 #endif

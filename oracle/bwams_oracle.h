@@ -139,6 +139,40 @@ int orc_emf_probe(const orc_emf_t *t, const uint8_t *seed, int len, uint32_t *fl
 void orc_ksw_align2(const bwams_sw_opt_t *o, int qlen, const uint8_t *query, int tlen,
                     const uint8_t *target, int xtra, int *out);
 
+/* ---- chaining, chain filtering, chain -> alignment regions (chain_oracle.c) ----
+ * Driver logic PARITY UNPINNED (bwamem.cpp is not buildable here); the B-tree and the
+ * introsort it relies on are PINNED against the reference's kbtree.h / ksort.h
+ * (oracle/_ref/libref_chain.so, tests/test_oracle_chain.py). */
+typedef struct orc_bns {            /* the fields of bntseq_t the path reads */
+    int64_t l_pac;
+    int32_t n_seqs;
+    const bwams_contig_t *contigs;
+} orc_bns_t;
+
+/* test hooks for the pinned pieces */
+int64_t orc_kbt_script(int64_t n, const int64_t *pos, const uint8_t *do_put, int32_t *lower, int32_t *order);
+void orc_flt_sort(int64_t n, const uint32_t *w, int32_t *order);
+
+int orc_chain_flt(const bwams_mem_opt_t *opt, int n_chn, bwams_chain_t *a, const bwams_chain_seed_t *seeds);
+int64_t orc_chain_seeds(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const bwams_smem_t *smem, int64_t num_smem,
+                        const int64_t *sa_coord, const int64_t *sa_off, const int64_t *cum_len, int32_t nseq, int do_flt,
+                        bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds, int64_t seed_cap,
+                        int64_t *chain_off, int64_t *n_seeds_out);
+
+typedef struct orc_task_dump {      /* the extension task lists as mem_chain2aln_across_reads_V2 builds them */
+    int32_t build_only;             /* in: stop after building (regions hold the pre-extension state) */
+    int32_t pad_;
+    int64_t n_left, n_right;
+    bwams_seqpair_t *left, *right;
+    uint8_t *left_ref, *left_qer, *right_ref, *right_qer;
+    int64_t left_ref_bytes, left_qer_bytes, right_ref_bytes, right_qer_bytes;
+} orc_task_dump_t;
+int64_t orc_chain2aln(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_t *ref_string, const uint8_t *enc_qdb,
+                      const int64_t *cum_len, int32_t nseq, const bwams_chain_t *chains, const int64_t *chain_off,
+                      bwams_chain_seed_t *seeds, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off,
+                      orc_task_dump_t *dump);
+void orc_task_dump_free(orc_task_dump_t *d);
+
 #ifdef __cplusplus
 }
 #endif

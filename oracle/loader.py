@@ -81,7 +81,8 @@ _lib = None
 
 def build() -> str:
     out = os.path.join(HERE, "_build", "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "emf_oracle.c", "bwams_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "emf_oracle.c", "chain_oracle.c",
+                                            "bwams_oracle.h", "../include/bwams_types.h")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "_build/liboracle.so"])
     return out
@@ -108,6 +109,16 @@ def lib():
         L.orc_bsw_pairs.argtypes = [vp, vp, vp, vp, i64, i32, vp]
         L.orc_ksw_align2.restype = None
         L.orc_ksw_align2.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
+        L.orc_kbt_script.restype = i64
+        L.orc_kbt_script.argtypes = [i64, vp, vp, vp, vp]
+        L.orc_flt_sort.restype = None
+        L.orc_flt_sort.argtypes = [i64, vp, vp]
+        L.orc_chain_seeds.restype = i64
+        L.orc_chain_seeds.argtypes = [vp, vp, vp, i64, vp, vp, vp, i32, C.c_int, vp, i64, vp, i64, vp, vp]
+        L.orc_chain2aln.restype = i64
+        L.orc_chain2aln.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, vp, vp]
+        L.orc_task_dump_free.restype = None
+        L.orc_task_dump_free.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -297,3 +308,154 @@ def ref_bsw(L, which: str, pairs, ref, qer, w: int, opt: SwOpt | None = None):
     getattr(L, {"scalar": "ref_bsw_scalar", "vec16": "ref_bsw_vec16", "vec8": "ref_bsw_vec8"}[which])(
         C.byref(opt), _p(p), _p(r), _p(q), n, w)
     return p[:n].copy()
+
+
+# ---------------------------------------------------------------------------
+# chaining / chain filter / chain -> alignment regions (chain_oracle.c)
+# ---------------------------------------------------------------------------
+CONTIG_DTYPE = np.dtype([("offset", "<i8"), ("len", "<i4"), ("is_alt", "<i4")])
+CHAIN_SEED_DTYPE = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("score", "<i4"), ("done", "i1"),
+                             ("pad0_", "i1", 3), ("aln", "<i4"), ("pad1_", "<i4")])
+CHAIN_DTYPE = np.dtype([("seqid", "<i4"), ("cseed", "<i4"), ("n", "<i4"), ("m", "<i4"), ("first", "<i4"), ("rid", "<i4"),
+                        ("w_kept_alt", "<u4"), ("frac_rep", "<f4"), ("pos", "<i8"), ("seed_off", "<i8")])
+ALNREG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("pad0_", "<i4"),
+                         ("chain", "<i8"), ("score", "<i4"), ("truesc", "<i4"), ("sub", "<i4"), ("alt_sc", "<i4"),
+                         ("csub", "<i4"), ("sub_n", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"),
+                         ("secondary_all", "<i4"), ("seedlen0", "<i4"), ("n_comp_is_alt", "<i4"), ("frac_rep", "<f4"),
+                         ("pad1_", "<i4"), ("hash", "<u8"), ("flg", "<i4"), ("pad2_", "<i4")])
+assert CONTIG_DTYPE.itemsize == 16 and CHAIN_SEED_DTYPE.itemsize == 32 and CHAIN_DTYPE.itemsize == 48
+assert ALNREG_DTYPE.itemsize == 112
+
+
+class MemOpt(C.Structure):
+    _fields_ = [("a", C.c_int32), ("o_del", C.c_int32), ("e_del", C.c_int32), ("o_ins", C.c_int32), ("e_ins", C.c_int32),
+                ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
+                ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
+                ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
+                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3)]
+
+
+def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
+    """mem_opt_init defaults (src/bwamem.cpp:135-171)."""
+    o = MemOpt(a, 6, 1, 6, 1, 5, 5, 100, 100, 19, 0, 1 << 30, 500, 10000, 0.5, 0.5)
+    for i, v in enumerate(fill_scmat(a, b)):
+        o.mat[i] = v
+    return o
+
+
+class OrcBns(C.Structure):
+    _fields_ = [("l_pac", C.c_int64), ("n_seqs", C.c_int32), ("contigs", C.c_void_p)]
+
+
+class TaskDump(C.Structure):
+    _fields_ = [("build_only", C.c_int32), ("pad_", C.c_int32), ("n_left", C.c_int64), ("n_right", C.c_int64),
+                ("left", C.c_void_p), ("right", C.c_void_p), ("left_ref", C.c_void_p), ("left_qer", C.c_void_p),
+                ("right_ref", C.c_void_p), ("right_qer", C.c_void_p), ("left_ref_bytes", C.c_int64),
+                ("left_qer_bytes", C.c_int64), ("right_ref_bytes", C.c_int64), ("right_qer_bytes", C.c_int64)]
+
+
+def single_contig(l_pac: int):
+    c = np.zeros(1, CONTIG_DTYPE)
+    c["len"] = l_pac
+    return c
+
+
+def _bns(l_pac, contigs):
+    contigs = np.ascontiguousarray(contigs, dtype=CONTIG_DTYPE)
+    return OrcBns(int(l_pac), len(contigs), contigs.ctypes.data), contigs
+
+
+def kbt_script(pos, do_put, L=None):
+    """(lower ids, traversal order) of the restated B-tree — or of the reference's kbtree.h when L is ref_chain_lib()."""
+    pos = np.ascontiguousarray(pos, np.int64)
+    do_put = np.ascontiguousarray(do_put, np.uint8)
+    lower = np.zeros(len(pos), np.int32)
+    order = np.zeros(len(pos), np.int32)
+    fn = L.ref_kbt_script if L is not None else lib().orc_kbt_script
+    m = fn(len(pos), _p(pos), _p(do_put), _p(lower), _p(order))
+    return lower, order[:m].copy()
+
+
+def flt_sort(w, L=None):
+    w = np.ascontiguousarray(w, np.uint32)
+    order = np.zeros(len(w), np.int32)
+    fn = L.ref_flt_sort if L is not None else lib().orc_flt_sort
+    fn(len(w), _p(w), _p(order))
+    return order
+
+
+def ref_chain_lib():
+    path = os.path.join(HERE, "_ref", "libref_chain.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.ref_kbt_script.restype = C.c_int64
+    L.ref_kbt_script.argtypes = [C.c_int64] + [C.c_void_p] * 4
+    L.ref_flt_sort.restype = None
+    L.ref_flt_sort.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
+    return L
+
+
+def chain_seeds(smems, sa_coord, sa_off, cum, l_pac, contigs=None, opt: MemOpt | None = None, do_flt: bool = True):
+    """Restated mem_chain_seeds (+ mem_chain_flt when do_flt) -> (chains, seeds, chain_off)."""
+    opt = opt or default_mem_opt()
+    bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
+    smems = np.ascontiguousarray(smems, dtype=SMEM_DTYPE)
+    sa_coord = np.ascontiguousarray(sa_coord, np.int64)
+    sa_off = np.ascontiguousarray(sa_off, np.int64)
+    cum = np.ascontiguousarray(cum, np.int64)
+    nseq = len(cum) - 1
+    cap = max(1, len(sa_coord))
+    chains = np.zeros(cap, CHAIN_DTYPE)
+    seeds = np.zeros(cap, CHAIN_SEED_DTYPE)
+    chain_off = np.zeros(nseq + 1, np.int64)
+    n_seeds = C.c_int64(0)
+    n = lib().orc_chain_seeds(C.byref(opt), C.byref(bns), _p(smems), len(smems), _p(sa_coord), _p(sa_off), _p(cum), nseq,
+                              int(do_flt), _p(chains), cap, _p(seeds), cap, _p(chain_off), C.byref(n_seeds))
+    assert n >= 0, n
+    # compact the seed array to the kept chains, in chain order
+    chains = chains[:n].copy()
+    out = np.zeros(int(chains["n"].sum()), CHAIN_SEED_DTYPE)
+    o = 0
+    for c in chains:
+        k = int(c["n"])
+        out[o:o + k] = seeds[c["seed_off"]:c["seed_off"] + k]
+        c["seed_off"] = o
+        o += k
+    return chains, out, chain_off
+
+
+def chain2aln(chains, seeds, chain_off, enc, cum, ref_string, l_pac, contigs=None, opt: MemOpt | None = None,
+              build_only: bool = False, want_tasks: bool = False):
+    """Restated mem_chain2aln_across_reads_V2 -> (regs, reg_off, seeds with .aln[, tasks])."""
+    opt = opt or default_mem_opt()
+    bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
+    chains = np.ascontiguousarray(chains, dtype=CHAIN_DTYPE)
+    seeds = np.ascontiguousarray(seeds, dtype=CHAIN_SEED_DTYPE).copy()
+    chain_off = np.ascontiguousarray(chain_off, np.int64)
+    cum = np.ascontiguousarray(cum, np.int64)
+    enc = np.ascontiguousarray(enc, np.uint8)
+    ref_string = np.ascontiguousarray(ref_string, np.uint8)
+    nseq = len(cum) - 1
+    cap = max(1, len(seeds))
+    regs = np.zeros(cap, ALNREG_DTYPE)
+    reg_off = np.zeros(nseq + 1, np.int64)
+    dump = TaskDump()
+    dump.build_only = int(build_only)
+    use_dump = build_only or want_tasks
+    n = lib().orc_chain2aln(C.byref(opt), C.byref(bns), _p(ref_string), _p(enc), _p(cum), nseq, _p(chains), _p(chain_off),
+                            _p(seeds), _p(regs), cap, _p(reg_off), C.byref(dump) if use_dump else None)
+    assert n >= 0, n
+    res = [regs[:n].copy(), reg_off, seeds]
+    if use_dump:
+        def arr(ptr, count, dt):
+            if not count:
+                return np.zeros(0, dt)
+            buf = (C.c_uint8 * (count * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).copy()
+        res.append({
+            "left": arr(dump.left, dump.n_left, SEQPAIR_DTYPE), "right": arr(dump.right, dump.n_right, SEQPAIR_DTYPE),
+            "left_ref": arr(dump.left_ref, dump.left_ref_bytes, np.uint8), "left_qer": arr(dump.left_qer, dump.left_qer_bytes, np.uint8),
+            "right_ref": arr(dump.right_ref, dump.right_ref_bytes, np.uint8), "right_qer": arr(dump.right_qer, dump.right_qer_bytes, np.uint8)})
+        lib().orc_task_dump_free(C.byref(dump))
+    return tuple(res)

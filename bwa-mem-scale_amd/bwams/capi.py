@@ -33,7 +33,23 @@ SYMBOLS = [
     "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
     "bwams_emf_open", "bwams_emf_from_host", "bwams_emf_close", "bwams_emf_probe",
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
+    "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
+    "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
 ]
+
+# records of include/bwams_types.h (layouts of bntann1_t's subset, mem_seed_t, mem_chain_t, mem_alnreg_t)
+CONTIG_DTYPE = np.dtype([("offset", "<i8"), ("len", "<i4"), ("is_alt", "<i4")])
+CHAIN_SEED_DTYPE = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("score", "<i4"), ("done", "i1"),
+                             ("pad0_", "i1", 3), ("aln", "<i4"), ("pad1_", "<i4")])
+CHAIN_DTYPE = np.dtype([("seqid", "<i4"), ("cseed", "<i4"), ("n", "<i4"), ("m", "<i4"), ("first", "<i4"), ("rid", "<i4"),
+                        ("w_kept_alt", "<u4"), ("frac_rep", "<f4"), ("pos", "<i8"), ("seed_off", "<i8")])
+ALNREG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("pad0_", "<i4"),
+                         ("chain", "<i8"), ("score", "<i4"), ("truesc", "<i4"), ("sub", "<i4"), ("alt_sc", "<i4"),
+                         ("csub", "<i4"), ("sub_n", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"),
+                         ("secondary_all", "<i4"), ("seedlen0", "<i4"), ("n_comp_is_alt", "<i4"), ("frac_rep", "<f4"),
+                         ("pad1_", "<i4"), ("hash", "<u8"), ("flg", "<i4"), ("pad2_", "<i4")])
+assert CONTIG_DTYPE.itemsize == 16 and CHAIN_SEED_DTYPE.itemsize == 32 and CHAIN_DTYPE.itemsize == 48
+assert ALNREG_DTYPE.itemsize == 112
 
 
 class BwamsError(RuntimeError):
@@ -53,6 +69,15 @@ class SwOpt(C.Structure):
                 ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3)]
 
 
+class MemOpt(C.Structure):
+    """bwams_mem_opt_t: the subset of mem_opt_t read by chaining and chain-to-alignment."""
+    _fields_ = [("a", C.c_int32), ("o_del", C.c_int32), ("e_del", C.c_int32), ("o_ins", C.c_int32), ("e_ins", C.c_int32),
+                ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
+                ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
+                ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
+                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3)]
+
+
 class FmiDesc(C.Structure):
     _fields_ = [("ref_seq_len", C.c_int64), ("count", C.c_int64 * 5),
                 ("cp_occ", C.c_void_p), ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p),
@@ -66,7 +91,11 @@ class Stats(C.Structure):
                 ("ms_smem_r1", C.c_float), ("ms_smem_r2", C.c_float), ("ms_smem_r3", C.c_float),
                 ("ms_sort", C.c_float), ("ms_sal", C.c_float), ("ms_seed_total", C.c_float),
                 ("ms_bsw", C.c_float), ("ms_ksw", C.c_float), ("ms_tasks", C.c_float), ("ms_emf", C.c_float),
-                ("emf_nodes", C.c_int64), ("emf_cmp_bytes", C.c_int64)]
+                ("emf_nodes", C.c_int64), ("emf_cmp_bytes", C.c_int64),
+                ("n_chains", C.c_int64), ("n_chain_seeds", C.c_int64), ("n_left", C.c_int64), ("n_right", C.c_int64),
+                ("n_retry_left", C.c_int64), ("n_retry_right", C.c_int64),
+                ("ms_chain", C.c_float), ("ms_ext_plan", C.c_float), ("ms_ext_left", C.c_float),
+                ("ms_ext_right", C.c_float), ("ms_ext_purge", C.c_float), ("ms_ext_total", C.c_float)]
 
 
 def default_seed_opt() -> SeedOpt:
@@ -86,6 +115,15 @@ def default_sw_opt(end_bonus: int = 5, a: int = 1, b: int = 4) -> SwOpt:
     for j in range(5):
         o.mat[k] = -1
         k += 1
+    return o
+
+
+def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
+    """mem_opt_init defaults (/root/reference/src/bwamem.cpp:135-171)."""
+    o = MemOpt(a, 6, 1, 6, 1, 5, 5, 100, 100, 19, 0, 1 << 30, 500, 10000, 0.5, 0.5)
+    sw = default_sw_opt(5, a, b)
+    for i in range(25):
+        o.mat[i] = sw.mat[i]
     return o
 
 
@@ -127,6 +165,14 @@ def lib():
         L.bwams_batch_destroy.argtypes = [vp]
         L.bwams_seed_fmi.argtypes = [vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, vp, vp]
         L.bwams_seed_upload.argtypes = [vp, vp, vp, vp, i64]
+        L.bwams_index_set_contigs.argtypes = [vp, vp, i32]
+        L.bwams_chain_run.argtypes = [vp, vp, vp, vp]
+        L.bwams_chain_fetch.argtypes = [vp, vp, i64, vp, i64, vp]
+        L.bwams_chain_upload.argtypes = [vp, vp, i64, vp, i64, vp]
+        L.bwams_extend_build.argtypes = [vp, vp, vp, vp]
+        L.bwams_extend_run.argtypes = [vp, vp, vp]
+        L.bwams_extend_fetch.argtypes = [vp, vp, i64, vp, vp]
+        L.bwams_extend_tasks_fetch.argtypes = [vp, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp]
         L.bwams_seed_run.argtypes = [vp, vp, C.c_int]
         L.bwams_seed_counts.argtypes = [vp, vp, vp]
         L.bwams_seed_fetch.argtypes = [vp, vp, i64, vp, i64, vp]
@@ -217,6 +263,10 @@ class Index:
         _chk(lib().bwams_index_fetch_fma(self.h, _p(a), _p(l)), "bwams_index_fetch_fma")
         return a, l
 
+    def set_contigs(self, contigs):
+        c = np.ascontiguousarray(contigs, dtype=CONTIG_DTYPE)
+        _chk(lib().bwams_index_set_contigs(self.h, _p(c), len(c)), "bwams_index_set_contigs")
+
     @property
     def nbytes(self) -> int:
         return lib().bwams_index_bytes(self.h)
@@ -298,6 +348,7 @@ class Batch:
         cum = np.ascontiguousarray(cum, dtype=np.int64)
         sk = np.ascontiguousarray(skip, dtype=np.uint8) if skip is not None else None
         _chk(lib().bwams_seed_upload(self.h, _p(enc), _p(cum), _p(sk), len(cum) - 1), "bwams_seed_upload")
+        self._nseq = len(cum) - 1
 
     def seed_run(self, opt: SeedOpt | None = None, with_sa: bool = True):
         opt = opt or default_seed_opt()
@@ -357,6 +408,64 @@ class Batch:
         _chk(lib().bwams_tasks_fetch(self.h, _p(p), len(p), _p(ref), len(ref), _p(qer), len(qer), C.byref(rb), C.byref(qb)),
              "bwams_tasks_fetch")
         return p, ref[:rb.value], qer[:qb.value]
+
+    # ---- chaining / chain-to-alignment ----
+    def chain_run(self, opt: MemOpt | None = None):
+        """mem_chain_seeds + mem_chain_flt over the resident seeds -> (n_chains, n_seeds)."""
+        opt = opt or default_mem_opt()
+        nc, ns = C.c_int64(0), C.c_int64(0)
+        _chk(lib().bwams_chain_run(self.h, C.byref(opt), C.byref(nc), C.byref(ns)), "bwams_chain_run")
+        self._n_chain = (nc.value, ns.value)
+        return self._n_chain
+
+    def chain_fetch(self):
+        nc, ns = self._n_chain
+        chains = np.zeros(nc, CHAIN_DTYPE)
+        seeds = np.zeros(ns, CHAIN_SEED_DTYPE)
+        off = np.zeros(self._nseq + 1, np.int64)
+        _chk(lib().bwams_chain_fetch(self.h, _p(chains), nc, _p(seeds), ns, _p(off)), "bwams_chain_fetch")
+        return chains, seeds, off
+
+    def chain_upload(self, chains, seeds, chain_off):
+        chains = np.ascontiguousarray(chains, dtype=CHAIN_DTYPE)
+        seeds = np.ascontiguousarray(seeds, dtype=CHAIN_SEED_DTYPE)
+        chain_off = np.ascontiguousarray(chain_off, np.int64)
+        _chk(lib().bwams_chain_upload(self.h, _p(chains), len(chains), _p(seeds), len(seeds), _p(chain_off)),
+             "bwams_chain_upload")
+        self._n_chain = (len(chains), len(seeds))
+
+    def extend_build(self, opt: MemOpt | None = None):
+        opt = opt or default_mem_opt()
+        nl, nr = C.c_int64(0), C.c_int64(0)
+        _chk(lib().bwams_extend_build(self.h, C.byref(opt), C.byref(nl), C.byref(nr)), "bwams_extend_build")
+        return nl.value, nr.value
+
+    def extend_run(self, opt: MemOpt | None = None) -> int:
+        opt = opt or default_mem_opt()
+        n = C.c_int64(0)
+        _chk(lib().bwams_extend_run(self.h, C.byref(opt), C.byref(n)), "bwams_extend_run")
+        return n.value
+
+    def extend_fetch(self):
+        """-> (regs, reg_off, seed_aln)"""
+        n = self._n_chain[1]
+        regs = np.zeros(n, ALNREG_DTYPE)
+        off = np.zeros(self._nseq + 1, np.int64)
+        aln = np.zeros(n, np.int32)
+        _chk(lib().bwams_extend_fetch(self.h, _p(regs), n, _p(off), _p(aln)), "bwams_extend_fetch")
+        return regs, off, aln
+
+    def extend_tasks_fetch(self, side: int):
+        n, rb, qb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        rc = lib().bwams_extend_tasks_fetch(self.h, side, None, 0, None, 0, None, 0, C.byref(n), C.byref(rb), C.byref(qb))
+        if rc not in (0, -4):
+            _chk(rc, "bwams_extend_tasks_fetch")
+        pairs = np.zeros(n.value, SEQPAIR_DTYPE)
+        ref = np.zeros(rb.value, np.uint8)
+        qer = np.zeros(qb.value, np.uint8)
+        _chk(lib().bwams_extend_tasks_fetch(self.h, side, _p(pairs), n.value, _p(ref), rb.value, _p(qer), qb.value,
+                                            C.byref(n), C.byref(rb), C.byref(qb)), "bwams_extend_tasks_fetch")
+        return pairs, ref, qer
 
     def ksw_align(self, pairs, ref, qer, opt: SwOpt | None = None):
         """Mate-rescue local SW: int32[n, 7] = score, te, qe, score2, te2, tb, qb (pairs[i].h0 = xtra)."""

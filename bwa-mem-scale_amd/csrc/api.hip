@@ -42,6 +42,8 @@ static int check_device(int device) {
     return BWAMS_OK;
 }
 
+void chain_state_stats(const ChainState *s, bwams_stats_t *out);   // api_chain.hip
+
 }  // namespace bwams
 
 using namespace bwams;
@@ -241,6 +243,10 @@ int bwams_index_close(bwams_index_t *ix) {
         (void)hipFree(ix->d_ls);
         if (ix->d_ref) (void)hipFree(ix->d_ref);
     }
+    if (ix->d_contigs) {
+        (void)hipSetDevice(ix->device);
+        (void)hipFree(ix->d_contigs);
+    }
     if (ix->d_all || ix->d_last) {
         (void)hipSetDevice(ix->device);
         if (ix->d_all) (void)hipFree(ix->d_all);
@@ -372,6 +378,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
+    if (b->chain) chain_state_free(b->chain);
     for (auto &e : b->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev_emf)
@@ -1044,6 +1051,7 @@ int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out) {
     }
     s.emf_nodes = (int64_t)b->emf_nodes;
     s.emf_cmp_bytes = (int64_t)b->emf_cmp_bytes;
+    chain_state_stats(b->chain, &s);
     (void)hipGetLastError();
     *out = s;
     return BWAMS_OK;

@@ -1,0 +1,508 @@
+// api_chain.hip — C-ABI entry points of the chaining and chain-to-alignment stages
+// (include/bwams.h): launch sequences over chain.hip, ext_aln.hip and bsw_extend.hip on the
+// batch's stream.  No CPU fallback: every entry point runs HIP kernels or returns an error.
+#include <cstring>
+#include <string>
+
+#include <rocprim/rocprim.hpp>
+
+#include "chain_kernels.h"
+
+namespace bwams {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess) cap = 0;
+        return e;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ChainState {
+    // chaining scratch (per SA hit)
+    DevBuf s_next, s_ql, c_last, c_n, c_rid, flt, f_first, f_kept, f_sel, f_be, nodes;
+    // per read
+    DevBuf n_kept, n_kept_seeds, read_base, frac, wide, chain_off, seed_off;
+    // results
+    DevBuf chains, seeds;
+    int64_t n_chains = 0, n_seeds = 0, nseq = 0;
+    bool chain_done = false;
+    // extension
+    DevBuf regs, srt, rmax, cnt, ewide, eoffs;
+    DevBuf lpairs, lref, lqer, rpairs, rref, rqer, retry;
+    int64_t n_left = 0, n_right = 0, lref_b = 0, lqer_b = 0, rref_b = 0, rqer_b = 0;
+    int64_t n_retry_left = 0, n_retry_right = 0;
+    bool built = false, ext_done = false;
+    bwams_mem_opt_t opt{};
+    hipEvent_t ev[10] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 purge
+    bool ev_ok = false;
+};
+
+void chain_state_free(ChainState *s) {
+    if (!s) return;
+    DevBuf *all[] = {&s->s_next, &s->s_ql, &s->c_last, &s->c_n, &s->c_rid, &s->flt, &s->f_first, &s->f_kept, &s->f_sel,
+                     &s->f_be, &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->read_base, &s->frac, &s->wide,
+                     &s->chain_off, &s->seed_off, &s->chains, &s->seeds, &s->regs, &s->srt, &s->rmax, &s->cnt,
+                     &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
+    for (DevBuf *d : all)
+        if (d->p) (void)hipFree(d->p);
+    if (s->ev_ok)
+        for (auto &e : s->ev) (void)hipEventDestroy(e);
+    delete s;
+}
+
+namespace {
+
+__global__ void widen2_kernel(const int32_t *a, const int32_t *b, int64_t n, int64_t *wide) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 2 * (n + 1)) return;
+    const int64_t row = g / (n + 1), i = g - row * (n + 1);
+    wide[g] = i < n ? (int64_t)(row ? b[i] : a[i]) : 0;
+}
+
+int scan_rows(bwams_batch *b, const int64_t *in, int64_t *out, int rows, int64_t n1) {
+    for (int r = 0; r < rows; ++r) {
+        size_t tb = 0;
+        BWAMS_HIP(rocprim::exclusive_scan(nullptr, tb, in + r * n1, out + r * n1, (int64_t)0, (size_t)n1,
+                                          rocprim::plus<int64_t>(), b->stream));
+        if (tb > b->tmp_bytes) {
+            BWAMS_HIP(hipStreamSynchronize(b->stream));
+            if (b->d_tmp) (void)hipFree(b->d_tmp);
+            b->d_tmp = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            b->tmp_bytes = tb;
+        }
+        tb = b->tmp_bytes;
+        BWAMS_HIP(rocprim::exclusive_scan(b->d_tmp, tb, in + r * n1, out + r * n1, (int64_t)0, (size_t)n1,
+                                          rocprim::plus<int64_t>(), b->stream));
+    }
+    return BWAMS_OK;
+}
+
+int get_state(bwams_batch *b, ChainState **out) {
+    if (!b->chain) {
+        b->chain = new ChainState();
+        for (auto &e : b->chain->ev) BWAMS_HIP(hipEventCreate(&e));
+        b->chain->ev_ok = true;
+    }
+    *out = b->chain;
+    return BWAMS_OK;
+}
+
+int check_opt(const bwams_mem_opt_t *o, const char *who) {
+    if (!o || o->e_del <= 0 || o->e_ins <= 0 || o->max_occ <= 0 || o->w < 0) {
+        set_last_error(std::string(who) + ": null options, non-positive gap extension penalty or max_occ");
+        return BWAMS_ERR_ARG;
+    }
+    return BWAMS_OK;
+}
+
+int dev_bns(bwams_index *ix, DevBns *out) {
+    const int64_t l_pac = (ix->fmi.ref_seq_len - 1) / 2;
+    if (!ix->d_contigs) {                       // default: one sequence spanning the whole text
+        bwams_contig_t c;
+        c.offset = 0; c.len = (int32_t)l_pac; c.is_alt = 0;
+        if (l_pac > 0x7fffffffLL) {
+            set_last_error("the index holds more than 2^31 bases: call bwams_index_set_contigs with the real sequences");
+            return BWAMS_ERR_ARG;
+        }
+        BWAMS_HIP(hipMalloc(&ix->d_contigs, sizeof c));
+        BWAMS_HIP(hipMemcpy(ix->d_contigs, &c, sizeof c, hipMemcpyHostToDevice));
+        ix->n_seqs = 1;
+    }
+    out->contigs = reinterpret_cast<const bwams_contig_t *>(ix->d_contigs);
+    out->n_seqs = ix->n_seqs;
+    out->l_pac = l_pac;
+    return BWAMS_OK;
+}
+
+void sw_params(const bwams_mem_opt_t &o, int end_bonus, SwParams *prm) {
+    prm->o_del = o.o_del; prm->e_del = o.e_del; prm->o_ins = o.o_ins; prm->e_ins = o.e_ins;
+    prm->zdrop = o.zdrop; prm->end_bonus = end_bonus;
+    int mx = 0;
+    for (int i = 0; i < 25; ++i) {
+        prm->mat[i] = o.mat[i];
+        mx = mx > o.mat[i] ? mx : o.mat[i];
+    }
+    prm->max_sc = mx;
+}
+
+}  // namespace
+}  // namespace bwams
+
+using namespace bwams;
+
+extern "C" {
+
+int bwams_index_set_contigs(bwams_index_t *ix, const bwams_contig_t *contigs, int32_t n_seqs) {
+    if (!ix || !contigs || n_seqs <= 0) return BWAMS_ERR_ARG;
+    const int64_t l_pac = (ix->fmi.ref_seq_len - 1) / 2;
+    int64_t at = 0;
+    for (int32_t i = 0; i < n_seqs; ++i) {
+        if (contigs[i].offset != at || contigs[i].len <= 0) {
+            set_last_error("bwams_index_set_contigs: sequences must tile [0, l_pac) in order");
+            return BWAMS_ERR_ARG;
+        }
+        at += contigs[i].len;
+    }
+    if (at != l_pac) {
+        set_last_error("bwams_index_set_contigs: sequence lengths do not add up to l_pac");
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(ix->device));
+    if (ix->d_contigs) (void)hipFree(ix->d_contigs);
+    ix->d_contigs = nullptr;
+    BWAMS_HIP(hipMalloc(&ix->d_contigs, (size_t)n_seqs * sizeof(bwams_contig_t)));
+    BWAMS_HIP(hipMemcpy(ix->d_contigs, contigs, (size_t)n_seqs * sizeof(bwams_contig_t), hipMemcpyHostToDevice));
+    ix->n_seqs = n_seqs;
+    return BWAMS_OK;
+}
+
+int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_chains, int64_t *n_seeds) {
+    if (!b || !b->seed_done || !b->with_sa) {
+        set_last_error("bwams_chain_run: run bwams_seed_run(with_sa = 1) first");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_chain_run");
+    if (rc) return rc;
+    if ((rc = bwams_seed_counts(b, nullptr, nullptr))) return rc;     // sizes of the seed stage (and its overflow check)
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    ChainState *s;
+    if ((rc = get_state(b, &s))) return rc;
+    s->chain_done = s->built = s->ext_done = false;
+    hipStream_t st = b->stream;
+    const int64_t nseq = b->nseq, n_sa = b->n_sa, n1 = nseq + 1;
+    const size_t ns = (size_t)(n_sa > 0 ? n_sa : 1);
+    BWAMS_HIP(s->s_next.ensure(ns * 4));  BWAMS_HIP(s->s_ql.ensure(ns * 8));
+    BWAMS_HIP(s->c_last.ensure(ns * 4));  BWAMS_HIP(s->c_n.ensure(ns * 4));   BWAMS_HIP(s->c_rid.ensure(ns * 4));
+    BWAMS_HIP(s->flt.ensure(ns * 8));     BWAMS_HIP(s->f_first.ensure(ns * 4)); BWAMS_HIP(s->f_kept.ensure(ns * 4));
+    BWAMS_HIP(s->f_sel.ensure(ns * 4));   BWAMS_HIP(s->f_be.ensure(ns * 8));
+    BWAMS_HIP(s->nodes.ensure(chain_node_bytes(n_sa, nseq)));
+    BWAMS_HIP(s->n_kept.ensure((size_t)n1 * 4));      BWAMS_HIP(s->n_kept_seeds.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->read_base.ensure((size_t)n1 * 8));   BWAMS_HIP(s->frac.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->wide.ensure((size_t)n1 * 16));       BWAMS_HIP(s->chain_off.ensure((size_t)n1 * 16));
+
+    ChainArgs A;
+    A.smem = b->d_sorted; A.n_smem = b->n_smem; A.sa_off = b->d_sa_off; A.sa_coord = b->d_sa_coord;
+    A.cum = b->d_cum; A.nseq = nseq;
+    if ((rc = dev_bns(b->idx, &A.bns))) return rc;
+    A.opt = *opt;
+    A.s_next = s->s_next.as<int32_t>(); A.s_ql = s->s_ql.as<int2>();
+    A.c_last = s->c_last.as<int32_t>(); A.c_n = s->c_n.as<int32_t>(); A.c_rid = s->c_rid.as<int32_t>();
+    A.flt = s->flt.as<uint2>(); A.f_first = s->f_first.as<int32_t>(); A.f_kept = s->f_kept.as<int32_t>();
+    A.f_sel = s->f_sel.as<int32_t>(); A.f_be = s->f_be.as<int2>(); A.nodes = s->nodes.p;
+    A.n_kept = s->n_kept.as<int32_t>(); A.n_kept_seeds = s->n_kept_seeds.as<int32_t>();
+    A.read_base = s->read_base.as<int64_t>(); A.frac_rep = s->frac.as<float>();
+    A.ctr = b->d_ctr;
+
+    BWAMS_HIP(hipEventRecord(s->ev[0], st));
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 2 * sizeof(unsigned long long), st));
+    // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
+    // one SMEM produce no chain at all
+    if (b->n_smem <= 1 || n_sa == 0) {
+        BWAMS_HIP(hipMemsetAsync(s->n_kept.p, 0, (size_t)n1 * 4, st));
+        BWAMS_HIP(hipMemsetAsync(s->n_kept_seeds.p, 0, (size_t)n1 * 4, st));
+    } else {
+        launch_chain(A, st);
+    }
+    int64_t tot[2] = {0, 0};
+    if (nseq > 0) {
+        const int64_t g = 2 * n1;
+        widen2_kernel<<<(unsigned)((g + 255) / 256), 256, 0, st>>>(A.n_kept, A.n_kept_seeds, nseq, s->wide.as<int64_t>());
+        if ((rc = scan_rows(b, s->wide.as<int64_t>(), s->chain_off.as<int64_t>(), 2, n1))) return rc;
+        BWAMS_HIP(hipMemcpyAsync(&tot[0], s->chain_off.as<int64_t>() + nseq, 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipMemcpyAsync(&tot[1], s->chain_off.as<int64_t>() + n1 + nseq, 8, hipMemcpyDeviceToHost, st));
+    }
+    BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    if (b->h_ctr->chain_overflow) {
+        set_last_error("bwams_chain_run: internal B-tree node region exhausted");
+        return BWAMS_ERR_CAPACITY;
+    }
+    if (b->h_ctr->chain_longread) {
+        set_last_error("bwams_chain_run: a read is long enough for mem_flt_chained_seeds to re-score seeds "
+                       "(5.5 ln L <= 0.05 L); that branch is not built");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    s->n_chains = tot[0]; s->n_seeds = tot[1]; s->nseq = nseq;
+    BWAMS_HIP(s->chains.ensure((size_t)(tot[0] + 1) * sizeof(bwams_chain_t)));
+    BWAMS_HIP(s->seeds.ensure((size_t)(tot[1] + 1) * sizeof(bwams_chain_seed_t)));
+    if (tot[0] > 0)
+        launch_chain_emit(A, s->chain_off.as<int64_t>(), s->chain_off.as<int64_t>() + n1, s->chains.as<bwams_chain_t>(),
+                          s->seeds.as<bwams_chain_seed_t>(), st);
+    BWAMS_HIP(hipEventRecord(s->ev[1], st));
+    BWAMS_HIP(hipGetLastError());
+    s->chain_done = true;
+    s->opt = *opt;
+    if (n_chains) *n_chains = tot[0];
+    if (n_seeds) *n_seeds = tot[1];
+    return BWAMS_OK;
+}
+
+int bwams_chain_fetch(bwams_batch_t *b, bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds,
+                      int64_t seed_cap, int64_t *chain_off) {
+    if (!b || !b->chain || !b->chain->chain_done) {
+        set_last_error("bwams_chain_fetch: no chains on the device");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    if (s->n_chains > chain_cap || s->n_seeds > seed_cap) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    if (s->n_chains) BWAMS_HIP(hipMemcpyAsync(chains, s->chains.p, (size_t)s->n_chains * sizeof(bwams_chain_t), hipMemcpyDeviceToHost, st));
+    if (s->n_seeds) BWAMS_HIP(hipMemcpyAsync(seeds, s->seeds.p, (size_t)s->n_seeds * sizeof(bwams_chain_seed_t), hipMemcpyDeviceToHost, st));
+    if (chain_off) BWAMS_HIP(hipMemcpyAsync(chain_off, s->chain_off.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    return BWAMS_OK;
+}
+
+int bwams_chain_upload(bwams_batch_t *b, const bwams_chain_t *chains, int64_t n_chains, const bwams_chain_seed_t *seeds,
+                       int64_t n_seeds, const int64_t *chain_off) {
+    if (!b || !chain_off || n_chains < 0 || n_seeds < 0 || (n_chains && (!chains || !seeds))) return BWAMS_ERR_ARG;
+    if (b->nseq <= 0) {
+        set_last_error("bwams_chain_upload: upload the reads first (bwams_seed_upload)");
+        return BWAMS_ERR_ARG;
+    }
+    const int64_t nseq = b->nseq, n1 = nseq + 1;
+    if (chain_off[0] != 0 || chain_off[nseq] != n_chains) return BWAMS_ERR_ARG;
+    // seeds must be laid out chain after chain, chains read after read (what bwams_chain_fetch returns)
+    int64_t at = 0;
+    std::string bad;
+    int64_t *soff = new int64_t[(size_t)n1];
+    for (int64_t r = 0; r < nseq && bad.empty(); ++r) {
+        soff[r] = at;
+        if (chain_off[r + 1] < chain_off[r]) bad = "chain_off must be non-decreasing";
+        for (int64_t j = chain_off[r]; j < chain_off[r + 1] && bad.empty(); ++j) {
+            if (chains[j].seqid != r) bad = "chain.seqid does not match chain_off";
+            else if (chains[j].seed_off != at || chains[j].n < 0) bad = "chain.seed_off must enumerate the seed array in order";
+            at += chains[j].n;
+        }
+    }
+    soff[nseq] = at;
+    if (bad.empty() && at != n_seeds) bad = "seed counts do not add up";
+    if (!bad.empty()) {
+        delete[] soff;
+        set_last_error("bwams_chain_upload: " + bad);
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    ChainState *s;
+    int rc = get_state(b, &s);
+    if (rc) { delete[] soff; return rc; }
+    s->chain_done = s->built = s->ext_done = false;
+    hipStream_t st = b->stream;
+    BWAMS_HIP(s->chain_off.ensure((size_t)n1 * 16));
+    BWAMS_HIP(s->chains.ensure((size_t)(n_chains + 1) * sizeof(bwams_chain_t)));
+    BWAMS_HIP(s->seeds.ensure((size_t)(n_seeds + 1) * sizeof(bwams_chain_seed_t)));
+    BWAMS_HIP(hipMemcpyAsync(s->chain_off.p, chain_off, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
+    BWAMS_HIP(hipMemcpyAsync(s->chain_off.as<int64_t>() + n1, soff, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
+    if (n_chains) BWAMS_HIP(hipMemcpyAsync(s->chains.p, chains, (size_t)n_chains * sizeof(bwams_chain_t), hipMemcpyHostToDevice, st));
+    if (n_seeds) BWAMS_HIP(hipMemcpyAsync(s->seeds.p, seeds, (size_t)n_seeds * sizeof(bwams_chain_seed_t), hipMemcpyHostToDevice, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    delete[] soff;
+    s->n_chains = n_chains; s->n_seeds = n_seeds; s->nseq = nseq;
+    s->chain_done = true;
+    return BWAMS_OK;
+}
+
+/* ------------------------------------------------------ chain -> alignment regions ---- */
+
+static int ext_args(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, ExtArgs *A) {
+    const int64_t n1 = s->nseq + 1;
+    A->chains = s->chains.as<bwams_chain_t>(); A->n_chains = s->n_chains;
+    A->seeds = s->seeds.as<bwams_chain_seed_t>(); A->n_seeds = s->n_seeds;
+    A->chain_off = s->chain_off.as<int64_t>(); A->seed_off = s->chain_off.as<int64_t>() + n1;
+    A->enc = b->d_enc; A->cum = b->d_cum; A->nseq = s->nseq;
+    A->ref = b->idx->fmi.ref;
+    int rc = dev_bns(b->idx, &A->bns);
+    if (rc) return rc;
+    A->opt = *opt;
+    A->regs = s->regs.as<bwams_alnreg_t>(); A->srt = s->srt.as<uint32_t>(); A->rmax = s->rmax.as<int64_t>();
+    A->cnt = s->cnt.as<int32_t>(); A->ctr = b->d_ctr;
+    return BWAMS_OK;
+}
+
+int bwams_extend_build(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_left, int64_t *n_right) {
+    if (!b || !b->chain || !b->chain->chain_done) {
+        set_last_error("bwams_extend_build: run bwams_chain_run (or bwams_chain_upload) first");
+        return BWAMS_ERR_ARG;
+    }
+    if (!b->idx->d_ref) {
+        set_last_error("bwams_extend_build: the index was opened without its .0123 reference");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_extend_build");
+    if (rc) return rc;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    ChainState *s = b->chain;
+    s->built = s->ext_done = false;
+    hipStream_t st = b->stream;
+    const int64_t N = s->n_seeds, N1 = N + 1;
+    BWAMS_HIP(s->regs.ensure((size_t)N1 * sizeof(bwams_alnreg_t)));
+    BWAMS_HIP(s->srt.ensure((size_t)N1 * 4));
+    BWAMS_HIP(s->rmax.ensure((size_t)(s->n_chains + 1) * 16));
+    BWAMS_HIP(s->cnt.ensure((size_t)N1 * 6 * 4));
+    BWAMS_HIP(s->ewide.ensure((size_t)N1 * 6 * 8));
+    BWAMS_HIP(s->eoffs.ensure((size_t)N1 * 6 * 8));
+    ExtArgs A;
+    if ((rc = ext_args(b, s, opt, &A))) return rc;
+    BWAMS_HIP(hipEventRecord(s->ev[2], st));
+    launch_ext_plan(A, s->ewide.as<int64_t>(), st);
+    if ((rc = scan_rows(b, s->ewide.as<int64_t>(), s->eoffs.as<int64_t>(), 6, N1))) return rc;
+    int64_t tot[6];
+    for (int r = 0; r < 6; ++r)
+        BWAMS_HIP(hipMemcpyAsync(&tot[r], s->eoffs.as<int64_t>() + r * N1 + N, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    for (int r : {1, 2, 4, 5})
+        if (tot[r] >= ((int64_t)1 << 31)) {
+            set_last_error("bwams_extend_build: task buffers exceed the 31-bit offsets of SeqPair; use smaller chunks");
+            return BWAMS_ERR_CAPACITY;
+        }
+    s->n_left = tot[0]; s->lqer_b = tot[1]; s->lref_b = tot[2];
+    s->n_right = tot[3]; s->rqer_b = tot[4]; s->rref_b = tot[5];
+    BWAMS_HIP(s->lpairs.ensure((size_t)(tot[0] + 1) * sizeof(bwams_seqpair_t)));
+    BWAMS_HIP(s->rpairs.ensure((size_t)(tot[3] + 1) * sizeof(bwams_seqpair_t)));
+    const int64_t mx = tot[0] > tot[3] ? tot[0] : tot[3];
+    BWAMS_HIP(s->retry.ensure((size_t)(mx + 1) * sizeof(bwams_seqpair_t)));
+    BWAMS_HIP(s->lqer.ensure((size_t)tot[1] + 64)); BWAMS_HIP(s->lref.ensure((size_t)tot[2] + 64));
+    BWAMS_HIP(s->rqer.ensure((size_t)tot[4] + 64)); BWAMS_HIP(s->rref.ensure((size_t)tot[5] + 64));
+    launch_ext_build(A, s->eoffs.as<int64_t>(), s->lpairs.as<bwams_seqpair_t>(), s->lref.as<uint8_t>(), s->lqer.as<uint8_t>(),
+                     s->rpairs.as<bwams_seqpair_t>(), s->rref.as<uint8_t>(), s->rqer.as<uint8_t>(), b->cu_count, st);
+    BWAMS_HIP(hipEventRecord(s->ev[3], st));
+    BWAMS_HIP(hipGetLastError());
+    s->built = true;
+    s->opt = *opt;
+    if (n_left) *n_left = tot[0];
+    if (n_right) *n_right = tot[3];
+    return BWAMS_OK;
+}
+
+// one side: extend at w, settle, re-run the unsettled tasks at 2w (MAX_BAND_TRY = 2, bwamem.cpp:79)
+static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, int64_t *n_retry_out) {
+    hipStream_t st = b->stream;
+    bwams_seqpair_t *pairs = right ? s->rpairs.as<bwams_seqpair_t>() : s->lpairs.as<bwams_seqpair_t>();
+    const uint8_t *ref = right ? s->rref.as<uint8_t>() : s->lref.as<uint8_t>();
+    const uint8_t *qer = right ? s->rqer.as<uint8_t>() : s->lqer.as<uint8_t>();
+    const int64_t n = right ? s->n_right : s->n_left;
+    SwParams prm;
+    sw_params(A.opt, right ? A.opt.pen_clip3 : A.opt.pen_clip5, &prm);
+    const int qmax = b->max_read_len > 1 ? b->max_read_len : 1;
+    *n_retry_out = 0;
+    if (n == 0) return BWAMS_OK;
+    unsigned long long *d_nretry = &b->d_ctr->n_retry;
+    BWAMS_HIP(hipMemsetAsync(d_nretry, 0, sizeof(unsigned long long), st));
+    launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st);
+    launch_ext_post(A, right, pairs, n, A.opt.w, 0, s->retry.as<bwams_seqpair_t>(), d_nretry, st);
+    unsigned long long nr = 0;
+    BWAMS_HIP(hipMemcpyAsync(&nr, d_nretry, sizeof nr, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    if (nr) {
+        launch_bsw(s->retry.as<bwams_seqpair_t>(), (int64_t)nr, ref, qer, A.opt.w << 1, prm, qmax, b->d_ctr, b->cu_count, st);
+        launch_ext_post(A, right, s->retry.as<bwams_seqpair_t>(), (int64_t)nr, A.opt.w << 1, 1, nullptr, d_nretry, st);
+    }
+    *n_retry_out = (int64_t)nr;
+    return BWAMS_OK;
+}
+
+int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_regs) {
+    if (!b || !b->chain || !b->chain->chain_done) {
+        set_last_error("bwams_extend_run: run bwams_chain_run (or bwams_chain_upload) first");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    int rc;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    if (!s->built || memcmp(&s->opt, opt, sizeof *opt) != 0) {
+        if ((rc = bwams_extend_build(b, opt, nullptr, nullptr))) return rc;
+    }
+    ExtArgs A;
+    if ((rc = ext_args(b, s, opt, &A))) return rc;
+    BWAMS_HIP(hipEventRecord(s->ev[4], st));
+    if ((rc = run_side(b, s, A, 0, &s->n_retry_left))) return rc;
+    BWAMS_HIP(hipEventRecord(s->ev[5], st));
+    BWAMS_HIP(hipEventRecord(s->ev[6], st));
+    launch_ext_right_h0(A, s->rpairs.as<bwams_seqpair_t>(), s->n_right, st);
+    if ((rc = run_side(b, s, A, 1, &s->n_retry_right))) return rc;
+    BWAMS_HIP(hipEventRecord(s->ev[7], st));
+    BWAMS_HIP(hipEventRecord(s->ev[8], st));
+    if (s->n_seeds) launch_ext_purge(A, st);
+    BWAMS_HIP(hipEventRecord(s->ev[9], st));
+    BWAMS_HIP(hipGetLastError());
+    s->ext_done = true;
+    s->built = false;             // the task records now hold results; a second run rebuilds them
+    if (n_regs) *n_regs = s->n_seeds;
+    return BWAMS_OK;
+}
+
+int bwams_extend_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, int32_t *seed_aln) {
+    if (!b || !b->chain || !(b->chain->ext_done || b->chain->built)) {
+        set_last_error("bwams_extend_fetch: no regions on the device");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    if (s->n_seeds > reg_cap) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    if (s->n_seeds) BWAMS_HIP(hipMemcpyAsync(regs, s->regs.p, (size_t)s->n_seeds * sizeof(bwams_alnreg_t), hipMemcpyDeviceToHost, st));
+    if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->chain_off.as<int64_t>() + (s->nseq + 1), (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (seed_aln && s->n_seeds)
+        BWAMS_HIP(hipMemcpy2DAsync(seed_aln, 4, reinterpret_cast<const char *>(s->seeds.p) + offsetof(bwams_chain_seed_t, aln),
+                                   sizeof(bwams_chain_seed_t), 4, (size_t)s->n_seeds, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    return BWAMS_OK;
+}
+
+int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref,
+                             int64_t ref_cap, uint8_t *qer, int64_t qer_cap, int64_t *n_pairs, int64_t *ref_bytes,
+                             int64_t *qer_bytes) {
+    if (!b || !b->chain || !(b->chain->built || b->chain->ext_done) || (side != 0 && side != 1)) {
+        set_last_error("bwams_extend_tasks_fetch: no task lists on the device");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    const int64_t n = side ? s->n_right : s->n_left, rb = side ? s->rref_b : s->lref_b, qb = side ? s->rqer_b : s->lqer_b;
+    if (n_pairs) *n_pairs = n;
+    if (ref_bytes) *ref_bytes = rb;
+    if (qer_bytes) *qer_bytes = qb;
+    if (n > pair_cap || rb > ref_cap || qb > qer_cap) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    if (n) BWAMS_HIP(hipMemcpyAsync(pairs, side ? s->rpairs.p : s->lpairs.p, (size_t)n * sizeof(bwams_seqpair_t), hipMemcpyDeviceToHost, st));
+    if (rb) BWAMS_HIP(hipMemcpyAsync(ref, side ? s->rref.p : s->lref.p, (size_t)rb, hipMemcpyDeviceToHost, st));
+    if (qb) BWAMS_HIP(hipMemcpyAsync(qer, side ? s->rqer.p : s->lqer.p, (size_t)qb, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    return BWAMS_OK;
+}
+
+}  // extern "C"
+
+namespace bwams {
+// timing and counts of the chain / extension stages for bwams_batch_stats (api.hip)
+void chain_state_stats(const ChainState *s, bwams_stats_t *out) {
+    if (!s) return;
+    out->n_chains = s->n_chains; out->n_chain_seeds = s->n_seeds;
+    out->n_left = s->n_left; out->n_right = s->n_right;
+    out->n_retry_left = s->n_retry_left; out->n_retry_right = s->n_retry_right;
+    auto el = [&](int a, int b, float *dst) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s->ev[a], s->ev[b]) == hipSuccess) *dst = ms;
+    };
+    el(0, 1, &out->ms_chain);
+    el(2, 3, &out->ms_ext_plan);
+    if (s->ext_done) {
+        el(4, 5, &out->ms_ext_left);
+        el(6, 7, &out->ms_ext_right);
+        el(8, 9, &out->ms_ext_purge);
+        el(4, 9, &out->ms_ext_total);
+    }
+    (void)hipGetLastError();
+}
+}  // namespace bwams

@@ -1,0 +1,78 @@
+// chain_kernels.h — device-side argument blocks and launchers of the chaining and
+// chain-to-alignment stages (chain.hip, ext_aln.hip).
+#pragma once
+
+#include "common.h"
+
+namespace bwams {
+
+// bntseq_t as the kernels see it
+struct DevBns {
+    const bwams_contig_t *contigs;
+    int32_t n_seqs;
+    int64_t l_pac;
+};
+
+// Scratch of the chaining kernel.  Every array except `nodes` and the per-read ones is indexed
+// like sa_coord (one slot per SA hit = per seed); a read owns the slice of its SMEMs' hits.
+struct ChainArgs {
+    const bwams_smem_t *smem;      // (rid, m, n)-sorted
+    int64_t n_smem;
+    const int64_t *sa_off;         // n_smem + 1
+    const int64_t *sa_coord;
+    const int64_t *cum;            // nseq + 1
+    int64_t nseq;
+    DevBns bns;
+    bwams_mem_opt_t opt;
+    // per seed
+    int32_t *s_next;               // next seed of the same chain, -1 = last
+    int2 *s_ql;                    // {qbeg, len}
+    // per chain (slot of its first seed)
+    int32_t *c_last, *c_n, *c_rid;
+    // filter work arrays (slot i of a read = i-th chain in sorted order)
+    uint2 *flt;                    // {w | kept << 29 | is_alt << 31, chain id}
+    int32_t *f_first, *f_kept, *f_sel;
+    int2 *f_be;                    // {chn_beg, chn_end}
+    void *nodes;                   // B-tree nodes
+    // per read
+    int32_t *n_kept, *n_kept_seeds;
+    int64_t *read_base;
+    float *frac_rep;
+    DevCounters *ctr;
+};
+
+size_t chain_node_bytes(int64_t n_sa, int64_t nseq);
+void launch_chain(const ChainArgs &A, hipStream_t st);
+void launch_chain_emit(const ChainArgs &A, const int64_t *chain_off, const int64_t *seed_off, bwams_chain_t *chains,
+                       bwams_chain_seed_t *seeds, hipStream_t st);
+
+// ---- chain -> alignment regions (ext_aln.hip) ----
+struct ExtArgs {
+    const bwams_chain_t *chains;
+    int64_t n_chains;
+    bwams_chain_seed_t *seeds;     // .aln is written
+    int64_t n_seeds;               // == number of regions
+    const int64_t *chain_off;      // nseq + 1
+    const int64_t *seed_off;       // nseq + 1: first seed (= first region) of each read
+    const uint8_t *enc;
+    const int64_t *cum;
+    int64_t nseq;
+    const uint8_t *ref;            // 2 * l_pac bases
+    DevBns bns;
+    bwams_mem_opt_t opt;
+    bwams_alnreg_t *regs;
+    uint32_t *srt;                 // per region slot: the seed's index within its chain, visit order reversed (srtg)
+    int64_t *rmax;                 // 2 per chain
+    int32_t *cnt;                  // 6 x n_seeds: has_left, lq, lr, has_right, rq, rr
+    DevCounters *ctr;
+};
+void launch_ext_plan(const ExtArgs &A, int64_t *wide, hipStream_t st);
+void launch_ext_build(const ExtArgs &A, const int64_t *offs, bwams_seqpair_t *left, uint8_t *lref, uint8_t *lqer,
+                      bwams_seqpair_t *right, uint8_t *rref, uint8_t *rqer, int cu_count, hipStream_t st);
+// after one extension attempt at band width w: settle finished tasks, queue the others for the next width
+void launch_ext_post(const ExtArgs &A, int right, const bwams_seqpair_t *pairs, int64_t n, int w, int last_try,
+                     bwams_seqpair_t *retry, unsigned long long *n_retry, hipStream_t st);
+void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hipStream_t st);
+void launch_ext_purge(const ExtArgs &A, hipStream_t st);
+
+}  // namespace bwams

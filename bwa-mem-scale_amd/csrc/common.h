@@ -63,7 +63,13 @@ struct DevCounters {
     unsigned long long bsw_cells;
     unsigned long long ext_after[3], blk_after[3];
     unsigned long long emf_nodes, emf_cmp_bytes;     // EMF probe: entries visited, reference bytes compared   // n_ext / n_ext_blocks when round 1, 2, 3 ended
+    unsigned long long chain_overflow;   // chaining: B-tree node region exhausted (never expected)
+    unsigned long long chain_longread;   // chaining: reads long enough for mem_flt_chained_seeds to re-score seeds
+    unsigned long long n_retry;          // extension: tasks queued for the next band width
 };
+
+struct ChainState;                       // chain / extension buffers of a batch (api_chain.hip)
+void chain_state_free(ChainState *s);
 
 // banded-SW parameters in kernel form (max_sc = max entry of mat)
 struct SwParams {
@@ -102,6 +108,8 @@ struct bwams_index {
     int64_t n_blk = 0, n_sa = 0;
     void *d_cp = nullptr, *d_ms = nullptr, *d_ls = nullptr, *d_ref = nullptr;
     void *d_all = nullptr, *d_last = nullptr;    // FMA tables (owned)
+    void *d_contigs = nullptr;                   // bwams_contig_t[n_seqs] (owned); null = one sequence [0, l_pac)
+    int32_t n_seqs = 0;
 };
 
 struct bwams_emf {
@@ -166,6 +174,8 @@ struct bwams_batch {
     int64_t cap_emf = 0;
     void *d_ksw_out = nullptr;
     int64_t cap_ksw = 0;
+
+    bwams::ChainState *chain = nullptr;
 
     hipEvent_t ev[16] = {};
     hipEvent_t ev_emf[2] = {};

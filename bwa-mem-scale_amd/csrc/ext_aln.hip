@@ -1,0 +1,322 @@
+// ext_aln.hip — from filtered chains to alignment regions, on the device.
+//
+// Replaces mem_chain2aln_across_reads_V2 (/root/reference/src/bwamem.cpp:2773-3760) for a whole
+// chunk: per chain the reference window (cal_max_gap :94-104, strand and contig clip
+// :2896-2925, bns_fetch_seq_v2 bntseq.cpp:484-520), per seed one region and up to two extension
+// tasks in the reference's SeqPair layout (:2953-3188), the post-extension bookkeeping with the
+// band-retry rule (:3240-3274 and its five copies), and the purge of seeds already covered by an
+// earlier region (:3648-3755).  The banded Smith-Waterman itself is bsw_extend.hip.
+//
+// Regions share the index space of the flat seed array: region p of a read is the p-th seed
+// visited (chain by chain, seeds by descending score then index), as in the reference's av->a.
+#include "common.h"
+#include "chain_kernels.h"
+
+namespace bwams {
+namespace {
+
+constexpr int H0_ = -99;         // macro.h:56
+
+__device__ __forceinline__ int cal_max_gap(const bwams_mem_opt_t &o, int qlen) {
+    const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+    const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+    int l = l_del > l_ins ? l_del : l_ins;
+    l = l > 1 ? l : 1;
+    return l < (o.w << 1) ? l : (o.w << 1);
+}
+
+__device__ __forceinline__ int pos2rid(const DevBns &b, int64_t pos_f) {
+    int left = 0, mid = 0, right = b.n_seqs;
+    if (pos_f >= b.l_pac) return -1;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= b.contigs[mid].offset) {
+            if (mid == b.n_seqs - 1) break;
+            if (pos_f < b.contigs[mid + 1].offset) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+
+__device__ __forceinline__ int seedcov(const bwams_alnreg_t &a, const bwams_chain_t &c, const bwams_chain_seed_t *seeds) {
+    int cov = 0;
+    for (int i = 0; i < c.n; ++i) {
+        const bwams_chain_seed_t *t = &seeds[c.seed_off + i];
+        if (t->qbeg >= a.qb && t->qbeg + t->len <= a.qe && t->rbeg >= a.rb && t->rbeg + t->len <= a.re) cov += t->len;
+    }
+    return cov;
+}
+
+// lane per chain: window, seed order, regions, task sizes
+__global__ void ext_plan_kernel(ExtArgs A) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= A.n_chains) return;
+    const bwams_chain_t c = A.chains[j];
+    const int r = c.seqid;
+    const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
+    const int64_t l_pac = A.bns.l_pac;
+    bwams_chain_seed_t *cs = A.seeds + c.seed_off;
+    if (c.n == 0) return;
+
+    int64_t r0 = l_pac << 1, r1 = 0;
+    for (int i = 0; i < c.n; ++i) {
+        const int64_t rb = cs[i].rbeg;
+        const int qb = cs[i].qbeg, ln = cs[i].len;
+        const int64_t b = rb - (qb + cal_max_gap(A.opt, qb));
+        const int64_t e = rb + ln + ((l_query - qb - ln) + cal_max_gap(A.opt, l_query - qb - ln));
+        r0 = r0 < b ? r0 : b;
+        r1 = r1 > e ? r1 : e;
+    }
+    r0 = r0 > 0 ? r0 : 0;
+    r1 = r1 < (l_pac << 1) ? r1 : (l_pac << 1);
+    const int64_t rbeg0 = cs[0].rbeg;
+    if (r0 < l_pac && l_pac < r1) {
+        if (rbeg0 < l_pac) r1 = l_pac;
+        else r0 = l_pac;
+    }
+    {   // bns_fetch_seq_v2: clip to the reference sequence holding the first seed
+        const bool is_rev = rbeg0 >= l_pac;
+        const int rid = pos2rid(A.bns, is_rev ? (l_pac << 1) - 1 - rbeg0 : rbeg0);
+        int64_t far_beg = A.bns.contigs[rid].offset, far_end = far_beg + A.bns.contigs[rid].len;
+        if (is_rev) { const int64_t t0 = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t0; }
+        r0 = r0 > far_beg ? r0 : far_beg;
+        r1 = r1 < far_end ? r1 : far_end;
+    }
+    A.rmax[2 * j] = r0; A.rmax[2 * j + 1] = r1;
+
+    // srt: seed indices by ascending (score, index) — ks_introsort_64 over distinct keys
+    uint32_t *srt = A.srt + c.seed_off;
+    for (int i = 0; i < c.n; ++i) {
+        const int sc = cs[i].score;
+        int p = i;
+        while (p > 0 && cs[srt[p - 1]].score > sc) { srt[p] = srt[p - 1]; --p; }
+        srt[p] = (uint32_t)i;
+    }
+
+    const int64_t reg0 = A.seed_off[r];
+    const int64_t N = A.n_seeds;
+    for (int k = c.n - 1; k >= 0; --k) {
+        const int64_t p = c.seed_off + (c.n - 1 - k);
+        bwams_chain_seed_t *s = &cs[srt[k]];
+        s->aln = (int32_t)(p - reg0);
+        bwams_alnreg_t a;
+        a.rb = a.re = H0_; a.qb = a.qe = H0_;
+        a.rid = c.rid; a.pad0_ = 0;
+        a.chain = j;
+        a.score = a.truesc = -1;
+        a.sub = a.alt_sc = a.csub = a.sub_n = 0;
+        a.w = A.opt.w; a.seedcov = 0; a.secondary = a.secondary_all = 0;
+        a.seedlen0 = s->len; a.n_comp_is_alt = 0;
+        a.frac_rep = c.frac_rep; a.pad1_ = 0; a.hash = 0; a.flg = 0; a.pad2_ = 0;
+        int nl = 0, lq = 0, lr = 0, nr = 0, rq = 0, rr = 0;
+        if (s->qbeg) {
+            nl = 1; lq = s->qbeg; lr = (int)(s->rbeg - r0);
+            a.qb = s->qbeg; a.rb = s->rbeg;
+        } else {
+            a.score = a.truesc = s->len * A.opt.a; a.qb = 0; a.rb = s->rbeg;
+        }
+        if (s->qbeg + s->len != l_query) {
+            const int64_t qe = s->qbeg + s->len;
+            const int64_t re = s->rbeg + s->len - r0;
+            nr = 1; rq = (int)(l_query - qe); rr = (int)(r1 - r0 - re);
+            a.qe = (int32_t)qe; a.re = r0 + re;
+        } else {
+            a.qe = l_query; a.re = s->rbeg + s->len;
+            a.seedcov = seedcov(a, c, A.seeds);       // rb, qb are always set at this point
+        }
+        A.regs[p] = a;
+        A.cnt[0 * N + p] = nl; A.cnt[1 * N + p] = lq; A.cnt[2 * N + p] = lr;
+        A.cnt[3 * N + p] = nr; A.cnt[4 * N + p] = rq; A.cnt[5 * N + p] = rr;
+    }
+}
+
+__global__ void ext_widen_kernel(const int32_t *cnt, int64_t n, int64_t *wide) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 6 * (n + 1)) return;
+    const int64_t row = g / (n + 1), i = g - row * (n + 1);
+    wide[g] = i < n ? (int64_t)cnt[row * n + i] : 0;
+}
+
+// wave per region: SeqPair records and sequence copies
+__global__ __launch_bounds__(256) void ext_build_kernel(ExtArgs A, const int64_t *__restrict__ offs, bwams_seqpair_t *left,
+                                                        uint8_t *lref, uint8_t *lqer, bwams_seqpair_t *right, uint8_t *rref,
+                                                        uint8_t *rqer) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t N = A.n_seeds, n1 = N + 1;
+    for (int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < N; p += stride) {
+        const int nl = A.cnt[0 * N + p], nr = A.cnt[3 * N + p];
+        if (!nl && !nr) continue;
+        const int64_t j = A.regs[p].chain;
+        const bwams_chain_t c = A.chains[j];
+        const int k = c.n - 1 - (int)(p - c.seed_off);
+        const bwams_chain_seed_t s = A.seeds[c.seed_off + A.srt[c.seed_off + k]];
+        const int r = c.seqid;
+        const int64_t qoff = A.cum[r];
+        const int l_query = (int)(A.cum[r + 1] - qoff);
+        const int64_t r0 = A.rmax[2 * j];
+        if (nl) {
+            const int64_t ti = offs[0 * n1 + p], qo = offs[1 * n1 + p], ro = offs[2 * n1 + p];
+            const int ql = s.qbeg, rl = (int)(s.rbeg - r0);
+            for (int t = lane; t < ql; t += 64) lqer[qo + t] = A.enc[qoff + s.qbeg - 1 - t];
+            for (int t = lane; t < rl; t += 64) lref[ro + t] = A.ref[s.rbeg - 1 - t];
+            if (lane == 0) {
+                bwams_seqpair_t sp;
+                sp.idr = (int32_t)ro; sp.idq = (int32_t)qo; sp.id = (int32_t)ti;
+                sp.len1 = rl; sp.len2 = ql; sp.h0 = s.len * A.opt.a; sp.seqid = r; sp.regid = s.aln;
+                sp.score = sp.tle = sp.gtle = sp.qle = sp.gscore = sp.max_off = 0;
+                left[ti] = sp;
+            }
+        }
+        if (nr) {
+            const int64_t ti = offs[3 * n1 + p], qo = offs[4 * n1 + p], ro = offs[5 * n1 + p];
+            const int qe = s.qbeg + s.len;
+            const int ql = l_query - qe, rl = A.cnt[5 * N + p];
+            const int64_t rs = s.rbeg + s.len;
+            for (int t = lane; t < ql; t += 64) rqer[qo + t] = A.enc[qoff + qe + t];
+            for (int t = lane; t < rl; t += 64) rref[ro + t] = A.ref[rs + t];
+            if (lane == 0) {
+                bwams_seqpair_t sp;
+                sp.idr = (int32_t)ro; sp.idq = (int32_t)qo; sp.id = (int32_t)ti;
+                sp.len1 = rl; sp.len2 = ql; sp.h0 = H0_; sp.seqid = r; sp.regid = s.aln;
+                sp.score = sp.tle = sp.gtle = sp.qle = sp.gscore = sp.max_off = 0;
+                right[ti] = sp;
+            }
+        }
+    }
+}
+
+// lane per task, after one extension attempt
+__global__ void ext_post_kernel(ExtArgs A, int right, const bwams_seqpair_t *__restrict__ pairs, int64_t n, int w, int last_try,
+                                bwams_seqpair_t *retry, unsigned long long *n_retry) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n) return;
+    const bwams_seqpair_t sp = pairs[l];
+    bwams_alnreg_t *ap = &A.regs[A.seed_off[sp.seqid] + sp.regid];
+    bwams_alnreg_t a = *ap;
+    const int prev = a.score;
+    a.score = sp.score;
+    if (a.score == prev || sp.max_off < (w >> 1) + (w >> 2) || last_try) {
+        if (!right) {
+            if (sp.gscore <= 0 || sp.gscore <= a.score - A.opt.pen_clip5) {
+                a.qb -= sp.qle; a.rb -= sp.tle;
+                a.truesc = a.score;
+            } else {
+                a.qb = 0; a.rb -= sp.gtle;
+                a.truesc = sp.gscore;
+            }
+        } else {
+            if (sp.gscore <= 0 || sp.gscore <= a.score - A.opt.pen_clip3) {
+                a.qe += sp.qle; a.re += sp.tle;
+                a.truesc += a.score - sp.h0;
+            } else {
+                a.qe = (int32_t)(A.cum[sp.seqid + 1] - A.cum[sp.seqid]); a.re += sp.gtle;
+                a.truesc += sp.gscore - sp.h0;
+            }
+        }
+        a.w = a.w > w ? a.w : w;
+        if (a.rb != H0_ && a.qb != H0_ && a.qe != H0_ && a.re != H0_) a.seedcov = seedcov(a, A.chains[a.chain], A.seeds);
+        *ap = a;
+    } else {
+        ap->score = a.score;
+        const unsigned long long slot = atomicAdd(n_retry, 1ull);
+        retry[slot] = sp;
+    }
+}
+
+// the right extension starts from the score the left one reached (bwamem.cpp:3425-3430)
+__global__ void ext_right_h0_kernel(ExtArgs A, bwams_seqpair_t *right, int64_t n) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n) return;
+    right[l].h0 = A.regs[A.seed_off[right[l].seqid] + right[l].regid].score;
+}
+
+// lane per read: drop seeds (and their regions) that an earlier region already explains
+__global__ __launch_bounds__(64) void ext_purge_kernel(ExtArgs A) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.nseq) return;
+    const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
+    const int64_t reg0 = A.seed_off[r];
+    bwams_alnreg_t *av = A.regs + reg0;
+    const int64_t av_n = A.seed_off[r + 1] - reg0;
+    int lim = 0;
+    for (int64_t j = A.chain_off[r]; j < A.chain_off[r + 1]; ++j) {
+        const bwams_chain_t c = A.chains[j];
+        const bwams_chain_seed_t *cs = A.seeds + c.seed_off;
+        uint32_t *srt2 = A.srt + c.seed_off;
+        for (int k = c.n - 1; k >= 0; --k) {
+            const bwams_chain_seed_t s = cs[srt2[k]];
+            int64_t i;
+            int v = 0;
+            for (i = 0; i < av_n && v < lim; ++i) {
+                const bwams_alnreg_t *p = &av[i];
+                const int64_t prb = p->rb, pre = p->re;
+                const int pqb = p->qb, pqe = p->qe;
+                if (pqb == -1 && pqe == -1) continue;
+                if (s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) { v++; continue; }
+                if ((double)(s.len - p->seedlen0) > .1 * (double)l_query) { v++; continue; }
+                const int pw = p->w;
+                int qd = s.qbeg - pqb;
+                int64_t rd = s.rbeg - prb;
+                int max_gap = cal_max_gap(A.opt, (int)(qd < rd ? qd : rd));
+                int w = max_gap < pw ? max_gap : pw;
+                if (qd - rd < w && rd - qd < w) break;
+                qd = pqe - (s.qbeg + s.len); rd = pre - (s.rbeg + s.len);
+                max_gap = cal_max_gap(A.opt, (int)(qd < rd ? qd : rd));
+                w = max_gap < pw ? max_gap : pw;
+                if (qd - rd < w && rd - qd < w) break;
+                v++;
+            }
+            if (v < lim) {
+                for (v = k + 1; v < c.n; ++v) {
+                    if (srt2[v] == 0xffffffffu) continue;
+                    const bwams_chain_seed_t t = cs[srt2[v]];
+                    if ((double)t.len < (double)s.len * .95) continue;
+                    if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= (s.len >> 2) && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+                    if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= (s.len >> 2) && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+                }
+                if (v == c.n) {
+                    av[s.aln].qb = -1; av[s.aln].qe = -1;
+                    srt2[k] = 0xffffffffu;
+                    continue;
+                }
+            }
+            lim++;
+        }
+    }
+}
+
+}  // namespace
+
+void launch_ext_plan(const ExtArgs &A, int64_t *wide, hipStream_t st) {
+    if (A.n_chains > 0) ext_plan_kernel<<<(unsigned)((A.n_chains + 63) / 64), 64, 0, st>>>(A);
+    const int64_t g = 6 * (A.n_seeds + 1);
+    ext_widen_kernel<<<(unsigned)((g + 255) / 256), 256, 0, st>>>(A.cnt, A.n_seeds, wide);
+}
+
+void launch_ext_build(const ExtArgs &A, const int64_t *offs, bwams_seqpair_t *left, uint8_t *lref, uint8_t *lqer,
+                      bwams_seqpair_t *right, uint8_t *rref, uint8_t *rqer, int cu_count, hipStream_t st) {
+    if (A.n_seeds <= 0) return;
+    int64_t blocks = (A.n_seeds + 3) / 4;
+    if (blocks > (int64_t)cu_count * 16) blocks = (int64_t)cu_count * 16;
+    ext_build_kernel<<<(unsigned)blocks, 256, 0, st>>>(A, offs, left, lref, lqer, right, rref, rqer);
+}
+
+void launch_ext_post(const ExtArgs &A, int right, const bwams_seqpair_t *pairs, int64_t n, int w, int last_try,
+                     bwams_seqpair_t *retry, unsigned long long *n_retry, hipStream_t st) {
+    if (n <= 0) return;
+    ext_post_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(A, right, pairs, n, w, last_try, retry, n_retry);
+}
+
+void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hipStream_t st) {
+    if (n <= 0) return;
+    ext_right_h0_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(A, right, n);
+}
+
+void launch_ext_purge(const ExtArgs &A, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    ext_purge_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
+}
+
+}  // namespace bwams

@@ -221,8 +221,47 @@ typedef struct bwams_stats {
     float   ms_emf;
     int64_t emf_nodes;        /* EMF probe: seed entries visited */
     int64_t emf_cmp_bytes;    /* EMF probe: reference bytes compared */
+    /* chaining / chain-to-alignment (last bwams_chain_run / bwams_extend_run) */
+    int64_t n_chains, n_chain_seeds;
+    int64_t n_left, n_right;              /* extension tasks built */
+    int64_t n_retry_left, n_retry_right;  /* tasks re-run at twice the band width */
+    float   ms_chain, ms_ext_plan, ms_ext_left, ms_ext_right, ms_ext_purge, ms_ext_total;
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
+
+/* ------------------------------------------------------------------------- *
+ * Chaining and chain-to-alignment: replace, for a whole chunk,
+ *   mem_chain_seeds + mem_chain_flt (+ the short-read early-out of mem_flt_chained_seeds),
+ *     called from mem_kernel1_core, src/bwamem.cpp:1341-1372
+ *   mem_chain2aln_across_reads_V2, src/bwamem.cpp:2773-3760, called from mem_kernel2_core
+ * ------------------------------------------------------------------------- */
+
+/* The reference sequences of the index (bntseq_t::anns: offset, len, is_alt), needed by
+ * bns_intv2rid / bns_fetch_seq_v2.  Without this call the index is one sequence [0, l_pac). */
+int bwams_index_set_contigs(bwams_index_t *idx, const bwams_contig_t *contigs, int32_t n_seqs);
+
+/* Chain the seeds the last bwams_seed_run(with_sa = 1) left on the device and filter the chains.
+ * Results stay resident; counts are returned.  BWAMS_ERR_UNSUPPORTED when a read is long enough
+ * (5.5 ln L <= 0.05 L, L >= ~1100) for mem_flt_chained_seeds to re-score seeds with ksw_align2. */
+int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_chains, int64_t *n_seeds);
+/* chains grouped by read (chain_off[nseq + 1]) in mem_chain_flt's output order; the seeds of
+ * chain c are seeds[c.seed_off .. + c.n) in the order mem_chain_seeds appended them. */
+int bwams_chain_fetch(bwams_batch_t *b, bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds,
+                      int64_t seed_cap, int64_t *chain_off);
+/* Host-input variant for a caller that keeps chaining on the host: upload chain_ar. */
+int bwams_chain_upload(bwams_batch_t *b, const bwams_chain_t *chains, int64_t n_chains, const bwams_chain_seed_t *seeds,
+                       int64_t n_seeds, const int64_t *chain_off);
+
+/* Build the extension tasks of the resident chains (phase 1 of mem_chain2aln_across_reads_V2);
+ * bwams_extend_run then extends left (band w, retry at 2w), right (h0 = left score), settles the
+ * regions and purges covered seeds.  One region per seed, grouped by read (reg_off[nseq + 1]). */
+int bwams_extend_build(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_left, int64_t *n_right);
+int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_regs);
+int bwams_extend_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, int32_t *seed_aln);
+/* the task lists as built (side 0 = left, 1 = right), for inspection */
+int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref,
+                             int64_t ref_cap, uint8_t *qer, int64_t qer_cap, int64_t *n_pairs, int64_t *ref_bytes,
+                             int64_t *qer_bytes);
 
 int bwams_batch_sync(bwams_batch_t *b);
 

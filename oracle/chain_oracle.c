@@ -479,7 +479,8 @@ int64_t orc_chain_seeds(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const 
                 const wchain_t *c = &wc[order[i]];
                 bwams_chain_t *o = &chains[n_chains++];
                 memset(o, 0, sizeof *o);
-                o->seqid = l; o->n = c->n; o->m = c->n; o->rid = c->rid;
+                o->seqid = l; o->n = c->n; o->rid = c->rid;
+                for (o->m = 1; o->m < o->n; o->m <<= 1) {}      /* SEEDS_PER_CHAIN = 1, doubled on demand (bwamem.cpp:398-412) */
                 o->w_kept_alt = (uint32_t)c->is_alt << 31;
                 o->frac_rep = (float)l_rep / l_seq;
                 o->pos = c->pos;

@@ -1,0 +1,257 @@
+"""GPU parity for chaining, chain filtering and chain-to-alignment: the HIP path through the
+C-ABI against the CPU oracle on the same seeded inputs.  Integer work (plus frac_rep, one float
+division): every comparison is bit-exact."""
+import numpy as np
+import pytest
+
+from bwams import capi, fmindex, simulate
+from oracle import loader
+from util import toy
+
+pytestmark = pytest.mark.gpu
+
+CHAIN_FIELDS = ("seqid", "n", "m", "first", "rid", "w_kept_alt", "frac_rep", "pos", "seed_off")
+SEED_FIELDS = ("rbeg", "qbeg", "len", "score")
+REG_FIELDS = ("rb", "re", "qb", "qe", "rid", "chain", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w",
+              "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp_is_alt", "frac_rep", "hash", "flg")
+PAIR_IN = ("idr", "idq", "len1", "len2", "h0", "seqid", "regid")
+
+
+def _mem_opts(**kw):
+    o, g = loader.default_mem_opt(), capi.default_mem_opt()
+    for k, v in kw.items():
+        setattr(o, k, v)
+        setattr(g, k, v)
+    if "a" in kw:
+        for i, v in enumerate(loader.fill_scmat(kw["a"], 4)):
+            o.mat[i] = v
+            g.mat[i] = v
+    return o, g
+
+
+@pytest.fixture(scope="module")
+def rep_toy():
+    """A genome with several repeat families so that reads carry many chains (> 9: deep B-trees)."""
+    capi.lib()
+    g = simulate.make_genome(120000, seed=31, repeat_frac=0.45, repeat_len=260, n_families=4)
+    idx = fmindex.build_fmindex(g)
+    ix = capi.Index.from_host(idx, 0)
+    yield g, idx, ix
+    ix.close()
+
+
+def _reads(g, n, seed, extra=()):
+    reads, _, _ = simulate.make_reads(g, n, seed=seed)
+    reads = list(reads) + list(extra)
+    return reads
+
+
+def _run(idx, ix, g, reads, contigs=None, seed_kw=None, **mem_kw):
+    enc, cum = simulate.flatten_reads(reads)
+    oopt, gopt = _mem_opts(**mem_kw)
+    so, sg = loader.default_seed_opt(), capi.default_seed_opt()
+    so.max_occ = sg.max_occ = oopt.max_occ
+    so.min_seed_len = sg.min_seed_len = oopt.min_seed_len
+    for k, v in (seed_kw or {}).items():
+        setattr(so, k, v)
+        setattr(sg, k, v)
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum, so)
+    coord, off = o.sa_lookup(sm, so.max_occ)
+    l_pac = len(g)
+    ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    want = {}
+    want["chains"], want["seeds"], want["chain_off"] = loader.chain_seeds(sm, coord, off, cum, l_pac, contigs=contigs, opt=oopt)
+    b = capi.Batch(ix, max(len(cum) - 1, 1), max(int(cum[-1]), 1), max_smem=len(sm) + 4096, max_sa=len(coord) + 4096)
+    if contigs is not None:
+        ix.set_contigs(contigs)
+    else:
+        c = np.zeros(1, capi.CONTIG_DTYPE)
+        c["len"] = l_pac
+        ix.set_contigs(c)
+    b.seed_upload(enc, cum)
+    b.seed_run(sg, with_sa=True)
+    b.chain_run(gopt)
+    got = {}
+    got["chains"], got["seeds"], got["chain_off"] = b.chain_fetch()
+    ctx = dict(enc=enc, cum=cum, ref=ref, l_pac=l_pac, oopt=oopt, gopt=gopt, contigs=contigs, sm=sm, coord=coord, off=off)
+    return b, want, got, ctx
+
+
+def _assert_chains(want, got):
+    assert np.array_equal(got["chain_off"], want["chain_off"])
+    assert len(got["chains"]) == len(want["chains"]) and len(got["seeds"]) == len(want["seeds"])
+    for f in CHAIN_FIELDS:
+        assert np.array_equal(got["chains"][f], want["chains"][f]), f
+    for f in SEED_FIELDS:
+        assert np.array_equal(got["seeds"][f], want["seeds"][f]), f
+
+
+def test_chains_match_oracle(rep_toy):
+    g, idx, ix = rep_toy
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 3000, 7))
+    _assert_chains(want, got)
+    per_read = np.diff(want["chain_off"])
+    assert per_read.max() > 9 and len(want["chains"]) > 3000          # deep trees and the filter both exercised
+    kept = (want["chains"]["w_kept_alt"] >> 29) & 3
+    assert set(np.unique(kept)) >= {1, 2, 3}
+    b.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(w=20, max_chain_gap=80), dict(mask_level=0.2, drop_ratio=0.9), dict(max_occ=4), dict(min_chain_weight=40),
+    dict(max_chain_extend=2), dict(min_seed_len=12), dict(min_chain_weight=1000),
+])
+def test_chain_options(rep_toy, kw):
+    g, idx, ix = rep_toy
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 1200, 9), **kw)
+    _assert_chains(want, got)
+    b.close()
+
+
+def test_chain_duplicate_positions_and_ties(rep_toy):
+    """Reads built from tandem copies of one segment: the same reference position is hit from
+    query offsets further apart than the band, which makes chains with EQUAL positions (B-tree
+    duplicate keys) and equal weights (introsort tie order)."""
+    g, idx, ix = rep_toy
+    rng = np.random.default_rng(5)
+    extra = []
+    for _ in range(300):
+        st = int(rng.integers(0, len(g) - 400))
+        unit = g[st:st + int(rng.integers(25, 60))]
+        gap = rng.integers(0, 4, size=int(rng.integers(101, 160)), dtype=np.uint8)
+        r = np.concatenate([unit, gap, unit, gap[:int(rng.integers(0, 50))], unit])[:400]
+        extra.append(simulate.revcomp(r) if rng.random() < 0.5 else r)
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 200, 3, extra), w=10)
+    _assert_chains(want, got)
+    # the case did occur: some read has two chains with the same position
+    dup = 0
+    for r in range(len(want["chain_off"]) - 1):
+        p = want["chains"]["pos"][want["chain_off"][r]:want["chain_off"][r + 1]]
+        dup += len(p) != len(np.unique(p))
+    assert dup > 0
+    b.close()
+
+
+def test_chain_contigs_and_alt(rep_toy):
+    g, idx, ix = rep_toy
+    l_pac = len(g)
+    contigs = np.zeros(4, capi.CONTIG_DTYPE)
+    contigs["offset"] = [0, 30000, 30150, 90000]
+    contigs["len"] = [30000, 150, 59850, l_pac - 90000]
+    contigs["is_alt"] = [0, 0, 1, 0]
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 2500, 17), contigs=contigs)
+    _assert_chains(want, got)
+    assert (want["chains"]["w_kept_alt"] >> 31).sum() > 0
+    # and the extension windows are clipped to the contig of the chain
+    b.extend_run(ctx["gopt"])
+    regs, reg_off, aln = b.extend_fetch()
+    wregs, wreg_off, wseeds = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
+                                               ctx["ref"], l_pac, contigs=contigs, opt=ctx["oopt"])
+    assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
+    for f in REG_FIELDS:
+        assert np.array_equal(regs[f], wregs[f]), f
+    b.close()
+    c = np.zeros(1, capi.CONTIG_DTYPE)
+    c["len"] = l_pac
+    ix.set_contigs(c)
+
+
+def test_single_smem_chunk_yields_no_chain(rep_toy):
+    """mem_chain_seeds' loop guard skips a work item that holds exactly one SMEM (bwamem.cpp:819)."""
+    g, idx, ix = rep_toy
+    reads = [g[5000:5019].copy()]                 # one 19-mer -> at most one SMEM
+    b, want, got, ctx = _run(idx, ix, g, reads)
+    assert len(ctx["sm"]) == 1
+    _assert_chains(want, got)
+    assert len(got["chains"]) == 0
+    b.close()
+
+
+def test_extension_tasks_match_oracle(rep_toy):
+    g, idx, ix = rep_toy
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 2000, 23))
+    nl, nr = b.extend_build(ctx["gopt"])
+    wregs, wreg_off, wseeds, tasks = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"],
+                                                      ctx["cum"], ctx["ref"], ctx["l_pac"], opt=ctx["oopt"], build_only=True)
+    assert nl == len(tasks["left"]) and nr == len(tasks["right"])
+    regs, reg_off, aln = b.extend_fetch()
+    assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
+    for f in REG_FIELDS:
+        assert np.array_equal(regs[f], wregs[f]), f
+    for side, name in ((0, "left"), (1, "right")):
+        pairs, ref, qer = b.extend_tasks_fetch(side)
+        for f in PAIR_IN:
+            assert np.array_equal(pairs[f], tasks[name][f]), (name, f)
+        assert np.array_equal(ref, tasks[name + "_ref"]) and np.array_equal(qer, tasks[name + "_qer"])
+    b.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(w=12, zdrop=30), dict(pen_clip5=0, pen_clip3=11), dict(e_del=2, e_ins=3, o_del=4),
+                                dict(a=2)])
+def test_regions_match_oracle(rep_toy, kw):
+    g, idx, ix = rep_toy
+    extra = []
+    rng = np.random.default_rng(41)
+    for _ in range(200):                          # reads with long indels: band retries and clipping decisions
+        st = int(rng.integers(0, len(g) - 600))
+        a = g[st:st + 70]
+        gap = int(rng.integers(5, 60))
+        if rng.random() < 0.5:
+            r = np.concatenate([a, g[st + 70 + gap:st + 150 + gap]])
+        else:
+            r = np.concatenate([a, rng.integers(0, 4, size=gap, dtype=np.uint8), g[st + 70:st + 150]])
+        extra.append(r)
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 1500, 29, extra), **kw)
+    n = b.extend_run(ctx["gopt"])
+    regs, reg_off, aln = b.extend_fetch()
+    wregs, wreg_off, wseeds = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
+                                               ctx["ref"], ctx["l_pac"], opt=ctx["oopt"])
+    assert n == len(wregs) and np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
+    for f in REG_FIELDS:
+        assert np.array_equal(regs[f], wregs[f]), f
+    st = b.stats()
+    assert st.n_chains == len(want["chains"]) and st.n_left + st.n_right > 0
+    if kw.get("w") == 12:
+        assert st.n_retry_left + st.n_retry_right > 0 and (wregs["w"] == 24).sum() > 0     # the band-retry path ran
+    if not kw:
+        purged = (regs["qb"] == -1) & (regs["qe"] == -1)
+        assert purged.sum() > 0 and (~purged).sum() > 0
+    b.close()
+
+
+def test_chain_upload_then_extend(rep_toy):
+    """A caller that chains on the host hands chain_ar over and gets the same regions."""
+    g, idx, ix = rep_toy
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 800, 37))
+    b.extend_run(ctx["gopt"])
+    regs1, off1, aln1 = b.extend_fetch()
+    b.close()
+    enc, cum = ctx["enc"], ctx["cum"]
+    b2 = capi.Batch(ix, len(cum) - 1, int(cum[-1]))
+    b2.seed_upload(enc, cum)
+    b2.chain_upload(want["chains"], want["seeds"], want["chain_off"])
+    b2.extend_run(ctx["gopt"])
+    regs2, off2, aln2 = b2.extend_fetch()
+    assert np.array_equal(off1, off2) and np.array_equal(aln1, aln2)
+    for f in REG_FIELDS:
+        assert np.array_equal(regs1[f], regs2[f]), f
+    bad = want["chains"].copy()
+    if len(bad):
+        bad["seed_off"][0] += 1
+        with pytest.raises(capi.BwamsError):
+            b2.chain_upload(bad, want["seeds"], want["chain_off"])
+    b2.close()
+
+
+def test_long_read_branch_is_refused(rep_toy):
+    g, idx, ix = rep_toy
+    reads = [g[1000:2300].copy()]
+    enc, cum = simulate.flatten_reads(reads)
+    b = capi.Batch(ix, 1, int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.seed_run(capi.default_seed_opt(), with_sa=True)
+    with pytest.raises(capi.BwamsError) as e:
+        b.chain_run(capi.default_mem_opt())
+    assert e.value.code == -6
+    b.close()

@@ -2,9 +2,10 @@
 """bench.py — throughput of the MI355X seed-and-extend hot path.
 
 One "step" = one pass of the hot path over one resident batch of synthetic reads:
-  FM-index seeding (SMEM rounds 1-3 -> (rid,m,n) sort -> SA lookup) + banded-SW
-  extension of the seeds' left/right tasks, all on the GPU through the C-ABI,
-with reads, index and extension tasks already resident in HBM when the clock starts.
+  FM-index seeding (SMEM rounds 1-3 -> (rid,m,n) sort -> SA lookup) -> seed chaining and
+  chain filtering -> extension tasks of every seed of every kept chain -> banded-SW left
+  and right extension with the band-retry rule -> region bookkeeping and purge,
+all on the GPU through the C-ABI, with reads and index resident in HBM when the clock starts.
 Workload = BASELINE.json configs[1] (1M x 150 bp single-end, FM-index only, 1 GPU);
 GRCh38 is not available offline, so the index is built (on the GPU) over a seeded
 synthetic genome whose size is stated in the output.  With --gpus N every rank
@@ -39,14 +40,15 @@ def log(*a):
 
 def cpu_baseline(idx_host_arrays, reads, n_sample, threads):
     """Time the oracle (CPU restatement, kind="port") on a bounded sample of the same reads:
-    seeding + SA lookup + extension of the same task construction.  The oracle is the checker;
-    it is timed here only as the reported CPU column."""
+    seeding + SA lookup + chaining + chain-to-alignment (the same stages as the GPU step).  The
+    oracle is the checker; it is timed here only as the reported CPU column."""
     from concurrent.futures import ThreadPoolExecutor
 
-    from bwams import pairs as pairs_mod, simulate
+    from bwams import simulate
     from oracle import loader
 
     o = loader.OracleFMI(idx_host_arrays)
+    l_pac = (idx_host_arrays.ref_seq_len - 1) // 2
     sample = reads[:n_sample]
     chunks = np.array_split(np.arange(len(sample)), threads)
 
@@ -57,12 +59,12 @@ def cpu_baseline(idx_host_arrays, reads, n_sample, threads):
             enc, cum = simulate.flatten_reads(sub)
             sm = o.collect_smem(enc, cum)
             coord, off = o.sa_lookup(sm, 500)
-            prs, rb, qb = pairs_mod.pairs_from_seeds(sub, sm, coord, off, idx_host_arrays.ref_0123)
-            loader.bsw_pairs(prs, rb, qb, 100)
-            n += len(prs)
+            ch, sd, choff = loader.chain_seeds(sm, coord, off, cum, l_pac)
+            regs, _, _ = loader.chain2aln(ch, sd, choff, enc, cum, idx_host_arrays.ref_0123, l_pac)
+            n += len(regs)
         return n
 
-    # one timed region around everything (pair construction is host glue on both sides and is small)
+    # one timed region around everything
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
         list(ex.map(work, chunks))
@@ -87,7 +89,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from bwams import capi, fmindex, pairs as pairs_mod, simulate
+    from bwams import capi, fmindex, simulate
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,20 +146,19 @@ def main():
     ref_host = np.concatenate([genome, (3 - genome[::-1]).astype(np.uint8)])
 
     seed_opt = capi.default_seed_opt()
-    sw_opt = capi.default_sw_opt()
+    mem_opt = capi.default_mem_opt()
 
     def step():
-        # reads -> [EMF] -> seeds -> (interim one-seed chains) extension tasks -> banded SW, all on the device
+        # reads -> [EMF] -> seeds -> chains -> extension tasks -> banded SW (left, right, retries) -> regions
         if emf_h is not None:
             batch.emf_run(emf_h)
         batch.seed_run(seed_opt, with_sa=True)
-        batch.tasks_from_seeds(sw_opt, 1, 100, seed_opt.max_occ)
-        batch.bsw_run(100, sw_opt)
+        batch.chain_run(mem_opt)
+        batch.extend_run(mem_opt)
 
     for _ in range(args.warmup):
         step()
     batch.sync()
-    n_tasks = batch._n_pairs
 
     # ---------------- timed region ----------------
     if world > 1:
@@ -217,12 +218,13 @@ def main():
                 "workload": f"{R} synthetic 150bp SE reads per GPU vs synthetic {args.genome_mbp:.0f} Mbp genome "
                             f"(GRCh38 unavailable offline), FM-index{' + FMA tables' if args.fma else ''}{' + EMF (L=150)' if args.emf else ''}"
                             f"{'' if (args.fma or args.emf) else ' only (no ERT/FMA/EMF)'}; step = {'EMF probe, ' if args.emf else ''}pack reads, SMEM r1-r3, sort, "
-                            f"SA lookup, task construction from the longest seed of each read (interim: the reference's "
-                            f"chaining is not built yet), banded-SW w=100 of those tasks; everything on the GPU",
+                            f"SA lookup, chaining + chain filter, extension tasks of all seeds of the kept chains, "
+                            f"banded-SW left then right (w=100, retry at 200), region bookkeeping + purge; everything on the GPU",
                 "genome_mbp": args.genome_mbp,
                 "index_bytes": ix.nbytes,
                 "reads_per_gpu": R,
-                "bsw_tasks": int(n_tasks),
+                "chains": int(st.n_chains), "regions": int(st.n_chain_seeds),
+                "bsw_tasks": int(st.n_left + st.n_right), "bsw_retries": int(st.n_retry_left + st.n_retry_right),
                 "parallelism": f"reads sharded x{world}, index replicated",
             },
             "stage_ms": {
@@ -233,8 +235,11 @@ def main():
                 "sa_lookup": round(float(np.mean([s.ms_sal for s in per_step])), 3),
                 "seed_total": round(float(np.mean([s.ms_seed_total for s in per_step])), 3),
                 "emf": round(float(np.mean([s.ms_emf for s in per_step])), 3),
-                "tasks": round(float(np.mean([s.ms_tasks for s in per_step])), 3),
-                "bsw": round(float(np.mean([s.ms_bsw for s in per_step])), 3),
+                "chain": round(float(np.mean([s.ms_chain for s in per_step])), 3),
+                "ext_tasks": round(float(np.mean([s.ms_ext_plan for s in per_step])), 3),
+                "ext_left": round(float(np.mean([s.ms_ext_left for s in per_step])), 3),
+                "ext_right": round(float(np.mean([s.ms_ext_right for s in per_step])), 3),
+                "ext_purge": round(float(np.mean([s.ms_ext_purge for s in per_step])), 3),
             },
             "events_per_read": {
                 "backward_ext": round(st.n_ext / R, 2),
@@ -270,14 +275,15 @@ def main():
         if args.pcie:
             # host buffers in, host buffers out (bwams_seed_fmi + bwams_bsw_extend): never `value`
             t0 = time.perf_counter()
-            sm, coord, off = batch.seed_fetch()
-            prs, rbuf, qbuf = pairs_mod.pairs_from_seeds(reads, sm, coord, off, ref_host)
             for _ in range(2):
-                batch.seed(enc, cum, seed_opt)
-                batch.bsw(prs, rbuf, qbuf, 100, sw_opt)
+                batch.seed(enc, cum, seed_opt)              # upload reads, run, download SMEMs + SA coordinates
+                batch.chain_run(mem_opt)
+                batch.chain_fetch()                         # download chains
+                batch.extend_run(mem_opt)
+                batch.extend_fetch()                        # download regions
             dt = (time.perf_counter() - t0) / 2
             out["pcie_inclusive"] = {"value": round(R / dt / 1e6, 4), "unit": "Mreads/s", "ms_per_batch": round(dt * 1e3, 2),
-                                     "note": "pageable host buffers, upload + run + download per call, includes numpy copies"}
+                                     "note": "pageable host buffers: reads up; SMEMs, SA coordinates, chains and regions down; includes numpy copies"}
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on a sample (cpu_baseline)...")
             threads = min(16, os.cpu_count() or 1)
@@ -291,7 +297,7 @@ def main():
             v, dt = cpu_baseline(host, reads, n_s, threads)
             out["cpu_baseline"] = {
                 "value": round(v, 5), "unit": "Mreads/s", "cores": threads, "kind": "port",
-                "sample": f"first {n_s} reads of the same batch, same index; oracle seeding+SA+extension, "
+                "sample": f"first {n_s} reads of the same batch, same index; oracle seeding+SA+chaining+chain2aln, "
                           f"{dt:.1f}s wall on {threads} threads",
             }
         print(json.dumps(out), flush=True)

@@ -27,9 +27,9 @@ struct DevBuf {
 
 struct ChainState {
     // chaining scratch (per SA hit)
-    DevBuf s_next, s_ql, c_last, c_n, c_rid, flt, f_first, f_kept, f_sel, f_be, nodes;
+    DevBuf s_next, s_ql, crec, flt, f_rec, f_first, f_kept, f_sel, nodes;
     // per read
-    DevBuf n_kept, n_kept_seeds, read_base, frac, wide, chain_off, seed_off;
+    DevBuf n_kept, n_kept_seeds, n_chn, heavy, read_base, frac, wide, chain_off;
     // results
     DevBuf chains, seeds;
     int64_t n_chains = 0, n_seeds = 0, nseq = 0;
@@ -47,9 +47,9 @@ struct ChainState {
 
 void chain_state_free(ChainState *s) {
     if (!s) return;
-    DevBuf *all[] = {&s->s_next, &s->s_ql, &s->c_last, &s->c_n, &s->c_rid, &s->flt, &s->f_first, &s->f_kept, &s->f_sel,
-                     &s->f_be, &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->read_base, &s->frac, &s->wide,
-                     &s->chain_off, &s->seed_off, &s->chains, &s->seeds, &s->regs, &s->srt, &s->rmax, &s->cnt,
+    DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
+                     &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->read_base, &s->frac, &s->wide,
+                     &s->chain_off, &s->chains, &s->seeds, &s->regs, &s->srt, &s->rmax, &s->cnt,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -181,9 +181,10 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     const int64_t nseq = b->nseq, n_sa = b->n_sa, n1 = nseq + 1;
     const size_t ns = (size_t)(n_sa > 0 ? n_sa : 1);
     BWAMS_HIP(s->s_next.ensure(ns * 4));  BWAMS_HIP(s->s_ql.ensure(ns * 8));
-    BWAMS_HIP(s->c_last.ensure(ns * 4));  BWAMS_HIP(s->c_n.ensure(ns * 4));   BWAMS_HIP(s->c_rid.ensure(ns * 4));
-    BWAMS_HIP(s->flt.ensure(ns * 8));     BWAMS_HIP(s->f_first.ensure(ns * 4)); BWAMS_HIP(s->f_kept.ensure(ns * 4));
-    BWAMS_HIP(s->f_sel.ensure(ns * 4));   BWAMS_HIP(s->f_be.ensure(ns * 8));
+    BWAMS_HIP(s->crec.ensure(chain_rec_bytes(n_sa)));
+    BWAMS_HIP(s->flt.ensure(ns * 8));     BWAMS_HIP(s->f_rec.ensure(ns * 16));
+    BWAMS_HIP(s->f_first.ensure(ns * 4)); BWAMS_HIP(s->f_kept.ensure(ns * 4)); BWAMS_HIP(s->f_sel.ensure(ns * 4));
+    BWAMS_HIP(s->n_chn.ensure((size_t)n1 * 4));       BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->nodes.ensure(chain_node_bytes(n_sa, nseq)));
     BWAMS_HIP(s->n_kept.ensure((size_t)n1 * 4));      BWAMS_HIP(s->n_kept_seeds.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->read_base.ensure((size_t)n1 * 8));   BWAMS_HIP(s->frac.ensure((size_t)n1 * 4));
@@ -195,22 +196,23 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     if ((rc = dev_bns(b->idx, &A.bns))) return rc;
     A.opt = *opt;
     A.s_next = s->s_next.as<int32_t>(); A.s_ql = s->s_ql.as<int2>();
-    A.c_last = s->c_last.as<int32_t>(); A.c_n = s->c_n.as<int32_t>(); A.c_rid = s->c_rid.as<int32_t>();
-    A.flt = s->flt.as<uint2>(); A.f_first = s->f_first.as<int32_t>(); A.f_kept = s->f_kept.as<int32_t>();
-    A.f_sel = s->f_sel.as<int32_t>(); A.f_be = s->f_be.as<int2>(); A.nodes = s->nodes.p;
+    A.crec = s->crec.p;
+    A.flt = s->flt.as<uint2>(); A.f_rec = s->f_rec.as<uint4>(); A.f_first = s->f_first.as<int32_t>();
+    A.f_kept = s->f_kept.as<int32_t>(); A.f_sel = s->f_sel.as<int32_t>(); A.nodes = s->nodes.p;
     A.n_kept = s->n_kept.as<int32_t>(); A.n_kept_seeds = s->n_kept_seeds.as<int32_t>();
+    A.n_chn = s->n_chn.as<int32_t>(); A.heavy = s->heavy.as<int32_t>();
     A.read_base = s->read_base.as<int64_t>(); A.frac_rep = s->frac.as<float>();
     A.ctr = b->d_ctr;
 
     BWAMS_HIP(hipEventRecord(s->ev[0], st));
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 2 * sizeof(unsigned long long), st));
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 3 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all
     if (b->n_smem <= 1 || n_sa == 0) {
         BWAMS_HIP(hipMemsetAsync(s->n_kept.p, 0, (size_t)n1 * 4, st));
         BWAMS_HIP(hipMemsetAsync(s->n_kept_seeds.p, 0, (size_t)n1 * 4, st));
     } else {
-        launch_chain(A, st);
+        launch_chain(A, b->cu_count, st);
     }
     int64_t tot[2] = {0, 0};
     if (nseq > 0) {
@@ -433,7 +435,7 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
     if ((rc = run_side(b, s, A, 1, &s->n_retry_right))) return rc;
     BWAMS_HIP(hipEventRecord(s->ev[7], st));
     BWAMS_HIP(hipEventRecord(s->ev[8], st));
-    if (s->n_seeds) launch_ext_purge(A, st);
+    if (s->n_seeds) launch_ext_purge(A, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(s->ev[9], st));
     BWAMS_HIP(hipGetLastError());
     s->ext_done = true;

@@ -424,7 +424,7 @@ void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uin
     int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t maxb = (int64_t)cu_count * 8;
     if (blocks > maxb) blocks = maxb;
-    // queries of 1..64 and 65..128 bases: register-resident variants; longer: LDS-resident kernel
+    // queries of 1..64, 65..128 and 129..192 bases: register-resident variants; longer: LDS-resident kernel
     bsw_kernel_reg<1><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(pairs, n, ref, qer, w, prm, -1, ctr);
     int qlo = 64;
     if (qmax > 64) {
@@ -433,6 +433,11 @@ void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uin
         qlo = 128;
     }
     if (qmax > 128) {
+        bsw_head_reset_kernel<<<1, 1, 0, st>>>(ctr);
+        bsw_kernel_reg<3><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(pairs, n, ref, qer, w, prm, 128, ctr);
+        qlo = 192;
+    }
+    if (qmax > 192) {
         bsw_head_reset_kernel<<<1, 1, 0, st>>>(ctr);
         const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
         const size_t lds = per_wave * kWavesPerBlock;

@@ -6,11 +6,18 @@
 // and the short-read early-out of mem_flt_chained_seeds (bwamem.cpp:491-526), consuming the
 // SMEMs and SA coordinates that the seeding stage left in HBM.
 //
-// The work is inherently sequential per read (each seed is tested against the chain found by
-// an ordered lookup, then the chains of the read are sorted and filtered pairwise), and reads
-// are independent: one lane per read, all state in HBM scratch indexed by the read's slice of
-// the SA-coordinate array.  A seed IS an SA hit, so every per-seed array shares the index space
-// of sa_coord; a chain is named by its first seed.
+// The work is sequential per read (each seed is tested against the chain found by an ordered
+// lookup; then the read's chains are sorted and filtered pairwise) and reads are independent.
+//   chain_kernel        one lane per read: chaining, chain weights; for reads with few chains
+//                       also the sort and the filter.
+//   chain_heavy_kernel  one wave per read with many chains: the sort runs on lane 0 over an LDS
+//                       copy, the quadratic pairwise filter runs 64 kept chains at a time.
+// All state lives in HBM scratch indexed by the read's slice of the SA-coordinate array: a seed
+// IS an SA hit, so every per-seed array shares the index space of sa_coord, and a chain is named
+// by its first seed.  The latency of dependent loads is what a lane pays for, so the hot records
+// are laid out to be fetched whole: a B-tree node carries its keys' positions (160 B, ten 16-byte
+// loads in flight at once, searched in registers), and a chain record carries everything
+// test_and_merge and mem_chain_weight read (64 B; the weight is maintained incrementally).
 //
 // Two generic pieces decide tie cases and are therefore kept behaviour-identical to klib:
 //   * the ordered map is a B-tree of order t = 5 (what kb_init(chn, 512 + 8) gives for the
@@ -26,16 +33,33 @@ namespace {
 
 constexpr int KB_T = 5;
 constexpr int KB_MAXK = 2 * KB_T - 1;
+constexpr int kLightChains = 16;     // reads with more chains than this go to chain_heavy_kernel
+constexpr int kLdsChains = 1024;     // chains the heavy kernel keeps in LDS (44 B each)
 
-struct Node {                  // 80 B
+struct alignas(16) Node {            // 160 B
     int32_t n, internal;
-    int32_t key[KB_MAXK];      // chain ids (relative seed index of the chain's first seed)
-    int32_t ptr[KB_MAXK + 1];  // node ids relative to the read's node region
+    int64_t pos[KB_MAXK];            // reference position of each key's chain (the sort key)
+    int32_t key[KB_MAXK];            // chain ids (relative index of the chain's first seed)
+    int32_t ptr[KB_MAXK + 1];        // node ids relative to the read's node region
+    int32_t pad_;
 };
+static_assert(sizeof(Node) == 160, "node layout");
 
-__device__ __forceinline__ int pos2rid(const DevBns &b, int64_t pos_f) {
-    int left = 0, mid = 0, right = b.n_seqs;
+struct alignas(16) ChainRec {        // 64 B, slot of the chain's first seed
+    int64_t last_rbeg, endr;         // last seed's rbeg; running `end` of the reference-side weight
+    int32_t first_qbeg, last_qbeg, last_len, rid;
+    int32_t n, last_idx, wq, wr;     // seeds, last seed, query-/reference-side weights so far
+    int32_t endq, pad_[3];
+};
+static_assert(sizeof(ChainRec) == 64, "chain record layout");
+
+// bns_pos2rid / bns_intv2rid (bntseq.cpp:397-421) with a one-entry cache of the last sequence found
+struct RidCache { int64_t lo, hi; int rid; };
+
+__device__ __forceinline__ int pos2rid(const DevBns &b, int64_t pos_f, RidCache &rc) {
     if (pos_f >= b.l_pac) return -1;
+    if (pos_f >= rc.lo && pos_f < rc.hi) return rc.rid;
+    int left = 0, mid = 0, right = b.n_seqs;
     while (left < right) {
         mid = (left + right) >> 1;
         if (pos_f >= b.contigs[mid].offset) {
@@ -44,23 +68,22 @@ __device__ __forceinline__ int pos2rid(const DevBns &b, int64_t pos_f) {
             left = mid + 1;
         } else right = mid;
     }
+    const int64_t off = b.contigs[mid].offset;
+    if (pos_f >= off) { rc.lo = off; rc.hi = mid == b.n_seqs - 1 ? b.l_pac : b.contigs[mid + 1].offset; rc.rid = mid; }
     return mid;
 }
 __device__ __forceinline__ int64_t depos(const DevBns &b, int64_t pos) {
     return pos >= b.l_pac ? (b.l_pac << 1) - 1 - pos : pos;
 }
-__device__ __forceinline__ int intv2rid(const DevBns &b, int64_t rb, int64_t re) {
+__device__ __forceinline__ int intv2rid(const DevBns &b, int64_t rb, int64_t re, RidCache &rc) {
     if (rb < b.l_pac && re > b.l_pac) return -2;
-    const int rid_b = pos2rid(b, depos(b, rb));
-    const int rid_e = rb < re ? pos2rid(b, depos(b, re - 1)) : rid_b;
+    const int rid_b = pos2rid(b, depos(b, rb), rc);
+    const int rid_e = rb < re ? pos2rid(b, depos(b, re - 1), rc) : rid_b;
     return rid_b == rid_e ? rid_b : -1;
 }
 
-__device__ __forceinline__ int kb_cmp(int64_t a, int64_t b) { return (b < a) - (a < b); }
-
 // per-read view of the scratch
 struct ReadCtx {
-    const int64_t *pos;     // sa_coord + base: pos[id] is the key of chain id
     Node *nodes;
     int32_t n_nodes, cap_nodes, root;
     int32_t n_keys;
@@ -74,50 +97,71 @@ __device__ __forceinline__ int32_t new_node(ReadCtx &c) {
     return c.n_nodes++;
 }
 
-__device__ int getp_aux(const ReadCtx &c, const Node *x, int64_t k, int *r) {
-    int begin = 0, end = x->n;
-    if (x->n == 0) return -1;
-    while (begin < end) {
-        const int mid = (begin + end) >> 1;
-        if (kb_cmp(c.pos[x->key[mid]], k) < 0) begin = mid + 1;
-        else end = mid;
-    }
-    if (begin == x->n) { *r = 1; return x->n - 1; }
-    if ((*r = kb_cmp(k, c.pos[x->key[begin]])) < 0) --begin;
-    return begin;
+// __kb_getp_aux (kbtree.h:124-139) on a register copy of the node: keys are sorted, so the lower
+// bound is the number of keys below k, and "found" means some key equals k
+__device__ __forceinline__ int node_search(const Node &x, int64_t k, bool &eq) {
+    int cnt = 0;
+    bool e = false;
+#pragma unroll
+    for (int t = 0; t < KB_MAXK; ++t)
+        if (t < x.n) { cnt += x.pos[t] < k ? 1 : 0; e |= x.pos[t] == k; }
+    eq = e;
+    return e ? cnt : cnt - 1;
+}
+__device__ __forceinline__ int32_t sel_key(const Node &x, int i) {
+    int32_t v = x.key[0];
+#pragma unroll
+    for (int t = 1; t < KB_MAXK; ++t) v = i == t ? x.key[t] : v;
+    return v;
+}
+__device__ __forceinline__ int64_t sel_pos(const Node &x, int i) {
+    int64_t v = x.pos[0];
+#pragma unroll
+    for (int t = 1; t < KB_MAXK; ++t) v = i == t ? x.pos[t] : v;
+    return v;
+}
+__device__ __forceinline__ int32_t sel_ptr(const Node &x, int i) {
+    int32_t v = x.ptr[0];
+#pragma unroll
+    for (int t = 1; t <= KB_MAXK; ++t) v = i == t ? x.ptr[t] : v;
+    return v;
 }
 
-__device__ int32_t kbt_lower(const ReadCtx &c, int64_t k) {
-    int r = 0;
+// kb_intervalp (kbtree.h:159-176): the chain with the closest position <= k, or -1
+__device__ int32_t kbt_lower(const ReadCtx &c, int64_t k, int64_t &lower_pos) {
     int32_t lower = -1, xi = c.root;
     for (;;) {
-        const Node *x = &c.nodes[xi];
-        const int i = getp_aux(c, x, k, &r);
-        if (i >= 0 && r == 0) return x->key[i];
-        if (i >= 0) lower = x->key[i];
-        if (!x->internal) return lower;
-        xi = x->ptr[i + 1];
+        const Node x = c.nodes[xi];
+        bool eq;
+        const int i = node_search(x, k, eq);
+        if (i >= 0) { lower = sel_key(x, i); lower_pos = sel_pos(x, i); }
+        if (i >= 0 && eq) return lower;
+        if (!x.internal) return lower;
+        xi = sel_ptr(x, i + 1);
     }
 }
 
+// __kb_split (kbtree.h:183-199), in memory (one call per ~5 insertions)
 __device__ void kbt_split(ReadCtx &c, int32_t xi, int i, int32_t yi) {
     const int32_t zi = new_node(c);
     if (c.overflow) return;
     Node *x = &c.nodes[xi], *y = &c.nodes[yi], *z = &c.nodes[zi];
     z->internal = y->internal;
     z->n = KB_T - 1;
-    for (int t = 0; t < KB_T - 1; ++t) z->key[t] = y->key[KB_T + t];
+    for (int t = 0; t < KB_T - 1; ++t) { z->key[t] = y->key[KB_T + t]; z->pos[t] = y->pos[KB_T + t]; }
     if (y->internal) for (int t = 0; t < KB_T; ++t) z->ptr[t] = y->ptr[KB_T + t];
     y->n = KB_T - 1;
-    for (int t = x->n; t > i; --t) x->ptr[t + 1] = x->ptr[t];
+    const int xn = x->n;
+    for (int t = xn; t > i; --t) x->ptr[t + 1] = x->ptr[t];
     x->ptr[i + 1] = zi;
-    for (int t = x->n - 1; t >= i; --t) x->key[t + 1] = x->key[t];
+    for (int t = xn - 1; t >= i; --t) { x->key[t + 1] = x->key[t]; x->pos[t + 1] = x->pos[t]; }
     x->key[i] = y->key[KB_T - 1];
-    ++x->n;
+    x->pos[i] = y->pos[KB_T - 1];
+    x->n = xn + 1;
 }
 
-__device__ void kbt_put(ReadCtx &c, int32_t id) {
-    const int64_t k = c.pos[id];
+// __kb_putp_aux / kb_putp (kbtree.h:200-233)
+__device__ void kbt_put(ReadCtx &c, int32_t id, int64_t k) {
     ++c.n_keys;
     int32_t xi = c.root;
     if (c.nodes[xi].n == KB_MAXK) {
@@ -130,22 +174,29 @@ __device__ void kbt_put(ReadCtx &c, int32_t id) {
         xi = s;
     }
     for (;;) {
-        Node *x = &c.nodes[xi];
-        int r;
-        if (!x->internal) {
-            const int i = getp_aux(c, x, k, &r);
-            for (int t = x->n - 1; t > i; --t) x->key[t + 1] = x->key[t];
-            x->key[i + 1] = id;
-            ++x->n;
+        Node x = c.nodes[xi];
+        bool eq;
+        if (!x.internal) {
+            const int i = node_search(x, k, eq);          // insert after slot i
+#pragma unroll
+            for (int t = KB_MAXK - 1; t >= 1; --t)
+                if (t > i + 1 && t <= x.n) { x.key[t] = x.key[t - 1]; x.pos[t] = x.pos[t - 1]; }
+#pragma unroll
+            for (int t = 0; t < KB_MAXK; ++t)
+                if (t == i + 1) { x.key[t] = id; x.pos[t] = k; }
+            ++x.n;
+            c.nodes[xi] = x;
             return;
         }
-        int i = getp_aux(c, x, k, &r) + 1;
-        if (c.nodes[x->ptr[i]].n == KB_MAXK) {
-            kbt_split(c, xi, i, x->ptr[i]);
+        int i = node_search(x, k, eq) + 1;
+        int32_t ci = sel_ptr(x, i);
+        if (c.nodes[ci].n == KB_MAXK) {
+            const int64_t median = c.nodes[ci].pos[KB_T - 1];
+            kbt_split(c, xi, i, ci);
             if (c.overflow) return;
-            if (kb_cmp(k, c.pos[x->key[i]]) > 0) ++i;
+            if (k > median) ci = c.nodes[xi].ptr[i + 1];      // chain_cmp(*k, x->key[i]) > 0: ++i
         }
-        xi = x->ptr[i];
+        xi = ci;
     }
 }
 
@@ -236,6 +287,84 @@ __device__ void flt_introsort(uint2 *a, int n) {
     }
 }
 
+// ---- the pairwise filter of mem_chain_flt, sequential form --------------------------------------
+// fl[0..n_chn) sorted; rec[i] = {chn_beg, chn_end, w | is_alt << 31, first}.  Leaves kept[] set.
+__device__ void filter_seq(const bwams_mem_opt_t &opt, int n_chn, uint4 *rec, int32_t *kept, int32_t *sel) {
+    int n_sel = 0;
+    kept[0] = 3;
+    sel[n_sel++] = 0;
+    for (int i = 1; i < n_chn; ++i) {
+        bool large_ovlp = false;
+        const uint4 ri = rec[i];
+        const int bi = (int)ri.x, ei = (int)ri.y, wi = (int)(ri.z & 0x7fffffffu);
+        const bool alt_i = (ri.z >> 31) != 0;
+        int k;
+        for (k = 0; k < n_sel; ++k) {
+            const int j = sel[k];
+            const uint4 rj = rec[j];
+            const int bj = (int)rj.x, ej = (int)rj.y;
+            const int b_max = bj > bi ? bj : bi;
+            const int e_min = ej < ei ? ej : ei;
+            const bool alt_j = (rj.z >> 31) != 0;
+            if (e_min > b_max && (!alt_j || alt_i)) {
+                const int li = ei - bi, lj = ej - bj;
+                const int min_l = li < lj ? li : lj;
+                if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level && min_l < opt.max_chain_gap) {
+                    large_ovlp = true;
+                    if ((int)rj.w < 0) rec[j].w = (uint32_t)i;
+                    const int wj = (int)(rj.z & 0x7fffffffu);
+                    if ((float)wi < (float)wj * opt.drop_ratio && wj - wi >= (opt.min_seed_len << 1)) break;
+                }
+            }
+        }
+        if (k == n_sel) {
+            sel[n_sel++] = i;
+            kept[i] = large_ovlp ? 2 : 3;
+        }
+    }
+    for (int i = 0; i < n_sel; ++i) {
+        const int f = (int)rec[sel[i]].w;
+        if (f >= 0) kept[f] = 1;
+    }
+}
+
+// max_chain_extend, compaction, per-read totals (bwamem.cpp:618-640); sequential
+__device__ void finish_read(const ChainArgs &A, int64_t r, int64_t base, int n_chn, int L) {
+    uint2 *fl = A.flt + base;
+    uint4 *rec = A.f_rec + base;
+    int32_t *kept = A.f_kept + base, *first = A.f_first + base;
+    const ChainRec *crec = reinterpret_cast<const ChainRec *>(A.crec) + base;
+    int i, k;
+    for (i = k = 0; i < n_chn; ++i) {
+        if (kept[i] == 0 || kept[i] == 3) continue;
+        if (++k >= A.opt.max_chain_extend) break;
+    }
+    for (; i < n_chn; ++i)
+        if (kept[i] < 3) kept[i] = 0;
+    int n_seeds = 0;
+    for (i = k = 0; i < n_chn; ++i) {
+        if (kept[i] == 0) continue;
+        const uint2 f = fl[i];
+        const uint32_t alt = rec[i].z & 0x80000000u;
+        fl[k] = make_uint2(f.x | ((unsigned)kept[i] << 29) | alt, f.y);
+        first[k] = (int32_t)rec[i].w;
+        n_seeds += crec[f.y].n;
+        ++k;
+    }
+    A.n_kept[r] = k;
+    A.n_kept_seeds[r] = n_seeds;
+    // mem_flt_chained_seeds re-scores seeds only for long reads (min_l <= 0.05 * l_query)
+    if (k) {
+        const double min_l = A.opt.min_chain_weight ? (double)(1.1f * (float)A.opt.min_chain_weight) : (double)5.5f * log((double)L);
+        if (!(min_l > (double)(0.05f * (float)L))) atomicAdd(&A.ctr->chain_longread, 1ull);
+    }
+}
+
+__device__ __forceinline__ uint4 make_rec(const ChainArgs &A, const ChainRec &c, uint32_t w) {
+    const uint32_t alt = A.bns.contigs[c.rid].is_alt != 0 ? 0x80000000u : 0u;
+    return make_uint4((uint32_t)c.first_qbeg, (uint32_t)(c.last_qbeg + c.last_len), w | alt, 0xffffffffu);
+}
+
 // ---- the chaining kernel: one lane per read --------------------------------------------------
 __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,6 +372,7 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
     A.n_kept[r] = 0;
     A.n_kept_seeds[r] = 0;
     A.read_base[r] = 0;
+    A.n_chn[r] = 0;
     const bwams_smem_t *sm = A.smem;
     // slice of this read in the (rid, m, n)-sorted SMEM array
     int64_t lo = 0, hi = A.n_smem;
@@ -269,46 +399,53 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
     const int32_t cnt = (int32_t)(A.sa_off[end] - base);
     A.read_base[r] = base;
     if (cnt == 0) return;
+    const int64_t *pos = A.sa_coord + base;
     int32_t *s_next = A.s_next + base;
     int2 *s_ql = A.s_ql + base;
-    int32_t *c_last = A.c_last + base, *c_n = A.c_n + base, *c_rid = A.c_rid + base;
+    ChainRec *crec = reinterpret_cast<ChainRec *>(A.crec) + base;
 
     ReadCtx c;
-    c.pos = A.sa_coord + base;
     const int64_t nbase = (base >> 1) + 2 * r;
     c.nodes = reinterpret_cast<Node *>(A.nodes) + nbase;
     c.cap_nodes = (int32_t)((((base + cnt) >> 1) + 2 * (r + 1)) - nbase);
     c.n_nodes = 0; c.n_keys = 0; c.overflow = false;
     c.root = new_node(c);
+    RidCache rc;
+    rc.lo = 0; rc.hi = -1; rc.rid = 0;
 
     const int64_t l_pac = A.bns.l_pac;
     for (int64_t i = beg; i < end; ++i) {
         const int qbeg = (int)sm[i].m, slen = (int)sm[i].n + 1 - (int)sm[i].m;
         const int32_t g0 = (int32_t)(A.sa_off[i] - base), g1 = (int32_t)(A.sa_off[i + 1] - base);
         for (int32_t g = g0; g < g1; ++g) {
-            const int64_t rbeg = c.pos[g];
-            const int rid = intv2rid(A.bns, rbeg, rbeg + slen);
+            const int64_t rbeg = pos[g];
+            const int rid = intv2rid(A.bns, rbeg, rbeg + slen, rc);
             if (rid < 0) continue;
             bool to_add = true;
             if (c.n_keys) {
-                const int32_t lower = kbt_lower(c, rbeg);
+                int64_t fr = 0;
+                const int32_t lower = kbt_lower(c, rbeg, fr);
                 if (lower >= 0) {                                        // test_and_merge
-                    const int32_t li = c_last[lower];
-                    const int2 lq = s_ql[li], fq = s_ql[lower];
-                    const int64_t lr = c.pos[li], fr = c.pos[lower];
-                    const int64_t qend = lq.x + lq.y, rend = lr + lq.y;
-                    if (rid != c_rid[lower]) to_add = true;
-                    else if (qbeg >= fq.x && qbeg + slen <= qend && rbeg >= fr && rbeg + slen <= rend) to_add = false;   // contained
+                    ChainRec ch = crec[lower];
+                    const int64_t lr = ch.last_rbeg;
+                    const int64_t qend = ch.last_qbeg + ch.last_len, rend = lr + ch.last_len;
+                    if (rid != ch.rid) to_add = true;
+                    else if (qbeg >= ch.first_qbeg && qbeg + slen <= qend && rbeg >= fr && rbeg + slen <= rend) to_add = false;   // contained
                     else if ((lr < l_pac || fr < l_pac) && rbeg >= l_pac) to_add = true;
                     else {
-                        const int64_t x = qbeg - lq.x, y = rbeg - lr;
-                        if (y >= 0 && x - y <= A.opt.w && y - x <= A.opt.w && x - lq.y < A.opt.max_chain_gap &&
-                            y - lq.y < A.opt.max_chain_gap) {
+                        const int64_t x = qbeg - ch.last_qbeg, y = rbeg - lr;
+                        if (y >= 0 && x - y <= A.opt.w && y - x <= A.opt.w && x - ch.last_len < A.opt.max_chain_gap &&
+                            y - ch.last_len < A.opt.max_chain_gap) {
                             s_ql[g] = make_int2(qbeg, slen);
                             s_next[g] = -1;
-                            s_next[li] = g;
-                            c_last[lower] = g;
-                            c_n[lower] += 1;
+                            s_next[ch.last_idx] = g;
+                            // mem_chain_weight's two running sums, one seed further
+                            if (qbeg >= ch.endq) ch.wq += slen; else if (qbeg + slen > ch.endq) ch.wq += qbeg + slen - ch.endq;
+                            ch.endq = ch.endq > qbeg + slen ? ch.endq : qbeg + slen;
+                            if (rbeg >= ch.endr) ch.wr += slen; else if (rbeg + slen > ch.endr) ch.wr += (int)(rbeg + slen - ch.endr);
+                            ch.endr = ch.endr > rbeg + slen ? ch.endr : rbeg + slen;
+                            ch.last_rbeg = rbeg; ch.last_qbeg = qbeg; ch.last_len = slen; ch.last_idx = g; ch.n += 1;
+                            crec[lower] = ch;
                             to_add = false;
                         }
                     }
@@ -317,8 +454,13 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
             if (to_add) {
                 s_ql[g] = make_int2(qbeg, slen);
                 s_next[g] = -1;
-                c_last[g] = g; c_n[g] = 1; c_rid[g] = rid;
-                kbt_put(c, g);
+                ChainRec ch;
+                ch.last_rbeg = rbeg; ch.endr = rbeg + slen;
+                ch.first_qbeg = qbeg; ch.last_qbeg = qbeg; ch.last_len = slen; ch.rid = rid;
+                ch.n = 1; ch.last_idx = g; ch.wq = slen; ch.wr = slen;
+                ch.endq = qbeg + slen; ch.pad_[0] = ch.pad_[1] = ch.pad_[2] = 0;
+                crec[g] = ch;
+                kbt_put(c, g, rbeg);
                 if (c.overflow) { atomicAdd(&A.ctr->chain_overflow, 1ull); return; }
             }
         }
@@ -326,100 +468,134 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
     if (c.n_keys == 0) return;
 
     // chains in B-tree order, their weights, the weight floor
-    int32_t *ord = A.f_first + base;            // reused below as `first`
+    int32_t *ord = A.f_first + base;
     const int32_t n_trav = kbt_traverse(c, ord);
     uint2 *fl = A.flt + base;
     int n_chn = 0;
     for (int32_t t = 0; t < n_trav; ++t) {
         const int32_t id = ord[t];
-        int64_t endq = 0, endr = 0;
-        int wq = 0, wr = 0;
-        for (int32_t g = id; g >= 0; g = s_next[g]) {
-            const int2 q = s_ql[g];
-            const int64_t rb = c.pos[g];
-            if (q.x >= endq) wq += q.y; else if (q.x + q.y > endq) wq += (int)(q.x + q.y - endq);
-            endq = endq > q.x + q.y ? endq : q.x + q.y;
-            if (rb >= endr) wr += q.y; else if (rb + q.y > endr) wr += (int)(rb + q.y - endr);
-            endr = endr > rb + q.y ? endr : rb + q.y;
-        }
-        int w = wr < wq ? wr : wq;
+        const ChainRec ch = crec[id];
+        int w = ch.wr < ch.wq ? ch.wr : ch.wq;
         w = w < (1 << 30) ? w : (1 << 30) - 1;
         if (t == 0) fl[0] = make_uint2((unsigned)w, (unsigned)id);      // a_[0] stays in place when everything is dropped
         if (w < A.opt.min_chain_weight) continue;
         fl[n_chn++] = make_uint2((unsigned)w, (unsigned)id);
     }
     if (n_chn == 0) n_chn = 1;                  // the reference keeps a_[0] in that case (bwamem.cpp:549-572)
-    flt_introsort(fl, n_chn);
-
-    // pairwise filter
-    int32_t *first = A.f_first + base;
-    int32_t *kept = A.f_kept + base;
-    int32_t *sel = A.f_sel + base;
-    int2 *be = A.f_be + base;
-    for (int i = 0; i < n_chn; ++i) {
-        const int32_t id = (int32_t)fl[i].y;
-        const int2 lq = s_ql[c_last[id]];
-        be[i] = make_int2(s_ql[id].x, lq.x + lq.y);
-        first[i] = -1; kept[i] = 0;
+    A.n_chn[r] = n_chn;
+    if (n_chn > kLightChains) {                 // sort + filter by a whole wave (chain_heavy_kernel)
+        const unsigned long long slot = atomicAdd(&A.ctr->n_heavy, 1ull);
+        A.heavy[slot] = (int32_t)r;
+        return;
     }
-    int n_sel = 0;
-    kept[0] = 3;
-    sel[n_sel++] = 0;
-    for (int i = 1; i < n_chn; ++i) {
-        bool large_ovlp = false;
-        const int2 bi = be[i];
-        const int wi = (int)fl[i].x;
-        const bool alt_i = A.bns.contigs[c_rid[fl[i].y]].is_alt != 0;
-        int k;
-        for (k = 0; k < n_sel; ++k) {
-            const int j = sel[k];
-            const int2 bj = be[j];
-            const int b_max = bj.x > bi.x ? bj.x : bi.x;
-            const int e_min = bj.y < bi.y ? bj.y : bi.y;
-            const bool alt_j = A.bns.contigs[c_rid[fl[j].y]].is_alt != 0;
-            if (e_min > b_max && (!alt_j || alt_i)) {
-                const int li = bi.y - bi.x, lj = bj.y - bj.x;
-                const int min_l = li < lj ? li : lj;
-                if ((float)(e_min - b_max) >= (float)min_l * A.opt.mask_level && min_l < A.opt.max_chain_gap) {
-                    large_ovlp = true;
-                    if (first[j] < 0) first[j] = i;
-                    const int wj = (int)fl[j].x;
-                    if ((float)wi < (float)wj * A.opt.drop_ratio && wj - wi >= (A.opt.min_seed_len << 1)) break;
+    flt_introsort(fl, n_chn);
+    uint4 *rec = A.f_rec + base;
+    int32_t *kept = A.f_kept + base;
+    for (int i = 0; i < n_chn; ++i) {
+        rec[i] = make_rec(A, crec[fl[i].y], fl[i].x);
+        kept[i] = 0;
+    }
+    filter_seq(A.opt, n_chn, rec, kept, A.f_sel + base);
+    finish_read(A, r, base, n_chn, L);
+}
+
+// ---- reads with many chains: one wave per read ---------------------------------------------------
+__global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsigned long long *n_heavy_p) {
+    __shared__ uint2 l_fl[kLdsChains];
+    __shared__ uint4 l_rec[kLdsChains];        // by sorted position: {beg, end, w | alt, first}
+    __shared__ uint4 l_sel[kLdsChains];        // the kept ("selected") chains, in selection order: {beg, end, w | alt, position}
+    const int lane = threadIdx.x;
+    const int64_t n_heavy = (int64_t)*n_heavy_p;
+    for (int64_t hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
+        const int64_t r = A.heavy[hi];
+        const int64_t base = A.read_base[r];
+        const int n_chn = A.n_chn[r];
+        const int L = (int)(A.cum[r + 1] - A.cum[r]);
+        uint2 *fl = A.flt + base;
+        uint4 *rec = A.f_rec + base;
+        int32_t *kept = A.f_kept + base;
+        const ChainRec *crec = reinterpret_cast<const ChainRec *>(A.crec) + base;
+        if (n_chn > kLdsChains) {              // beyond the LDS budget: the sequential form, on lane 0
+            if (lane == 0) {
+                flt_introsort(fl, n_chn);
+                for (int i = 0; i < n_chn; ++i) { rec[i] = make_rec(A, crec[fl[i].y], fl[i].x); kept[i] = 0; }
+                filter_seq(A.opt, n_chn, rec, kept, A.f_sel + base);
+                finish_read(A, r, base, n_chn, L);
+            }
+            continue;
+        }
+        __syncthreads();
+        for (int i = lane; i < n_chn; i += 64) l_fl[i] = fl[i];
+        __syncthreads();
+        if (lane == 0) flt_introsort(l_fl, n_chn);           // ksort's order is inherently sequential
+        __syncthreads();
+        for (int i = lane; i < n_chn; i += 64) {
+            const uint2 f = l_fl[i];
+            fl[i] = f;
+            l_rec[i] = make_rec(A, crec[f.y], f.x);
+            kept[i] = 0;
+        }
+        __syncthreads();
+        // pairwise filter: chain i against the chains selected so far, 64 at a time.  The sequential
+        // loop visits them in selection order and stops at the first one that drops chain i; every
+        // selected chain visited up to there with a large overlap records i as its first shadowed hit.
+        int n_sel = 1;
+        if (lane == 0) { const uint4 r0 = l_rec[0]; l_sel[0] = make_uint4(r0.x, r0.y, r0.z, 0u); kept[0] = 3; }
+        __syncthreads();
+        for (int i = 1; i < n_chn; ++i) {
+            const uint4 ri = l_rec[i];
+            const int bi = (int)ri.x, ei = (int)ri.y, wi = (int)(ri.z & 0x7fffffffu);
+            const bool alt_i = (ri.z >> 31) != 0;
+            bool large_ovlp = false, dropped = false;
+            for (int kb = 0; kb < n_sel && !dropped; kb += 64) {
+                const int k = kb + lane;
+                bool lg = false, br = false;
+                uint4 rj = make_uint4(0, 0, 0, 0);
+                if (k < n_sel) {
+                    rj = l_sel[k];
+                    const int bj = (int)rj.x, ej = (int)rj.y;
+                    const int b_max = bj > bi ? bj : bi;
+                    const int e_min = ej < ei ? ej : ei;
+                    const bool alt_j = (rj.z >> 31) != 0;
+                    if (e_min > b_max && (!alt_j || alt_i)) {
+                        const int li = ei - bi, lj = ej - bj;
+                        const int min_l = li < lj ? li : lj;
+                        if ((float)(e_min - b_max) >= (float)min_l * A.opt.mask_level && min_l < A.opt.max_chain_gap) {
+                            lg = true;
+                            const int wj = (int)(rj.z & 0x7fffffffu);
+                            br = (float)wi < (float)wj * A.opt.drop_ratio && wj - wi >= (A.opt.min_seed_len << 1);
+                        }
+                    }
+                }
+                const unsigned long long m_br = __ballot(br);
+                unsigned long long m_lg = __ballot(lg);
+                if (m_br) {
+                    const int first_br = __ffsll((long long)m_br) - 1;
+                    m_lg &= first_br == 63 ? ~0ull : ((2ull << first_br) - 1ull);
+                    dropped = true;
+                }
+                if (m_lg) large_ovlp = true;
+                if (lg && ((m_lg >> lane) & 1ull)) {         // `first` of selected chain j = rj.w (its sorted position)
+                    uint4 *pj = &l_rec[rj.w];
+                    if ((int)pj->w < 0) pj->w = (uint32_t)i;
                 }
             }
+            if (!dropped) {
+                if (lane == 0) { l_sel[n_sel] = make_uint4(ri.x, ri.y, ri.z, (uint32_t)i); kept[i] = large_ovlp ? 2 : 3; }
+                ++n_sel;
+            }
+            __syncthreads();
         }
-        if (k == n_sel) {
-            sel[n_sel++] = i;
-            kept[i] = large_ovlp ? 2 : 3;
+        for (int k = lane; k < n_sel; k += 64) {
+            const int f = (int)l_rec[l_sel[k].w].w;
+            if (f >= 0) kept[f] = 1;
         }
-    }
-    for (int i = 0; i < n_sel; ++i) {
-        const int f = first[sel[i]];
-        if (f >= 0) kept[f] = 1;
-    }
-    int i, k;
-    for (i = k = 0; i < n_chn; ++i) {
-        if (kept[i] == 0 || kept[i] == 3) continue;
-        if (++k >= A.opt.max_chain_extend) break;
-    }
-    for (; i < n_chn; ++i)
-        if (kept[i] < 3) kept[i] = 0;
-    int n_seeds = 0;
-    for (i = k = 0; i < n_chn; ++i) {
-        if (kept[i] == 0) continue;
-        const uint2 f = fl[i];
-        const bool alt = A.bns.contigs[c_rid[f.y]].is_alt != 0;
-        fl[k] = make_uint2(f.x | ((unsigned)kept[i] << 29) | (alt ? 0x80000000u : 0u), f.y);
-        first[k] = first[i];
-        n_seeds += c_n[f.y];
-        ++k;
-    }
-    A.n_kept[r] = k;
-    A.n_kept_seeds[r] = n_seeds;
-    // mem_flt_chained_seeds re-scores seeds only for long reads (min_l <= 0.05 * l_query)
-    if (k) {
-        const double min_l = A.opt.min_chain_weight ? (double)(1.1f * (float)A.opt.min_chain_weight) : (double)5.5f * log((double)L);
-        if (!(min_l > (double)(0.05f * (float)L))) atomicAdd(&A.ctr->chain_longread, 1ull);
+        __syncthreads();
+        for (int i = lane; i < n_chn; i += 64) rec[i] = l_rec[i];
+        __threadfence_block();
+        __syncthreads();
+        if (lane == 0) finish_read(A, r, base, n_chn, L);
+        __syncthreads();
     }
 }
 
@@ -436,11 +612,12 @@ __global__ void chain_emit_kernel(ChainArgs A, const int64_t *__restrict__ chain
     const int32_t *s_next = A.s_next + base;
     const int2 *s_ql = A.s_ql + base;
     const int64_t *pos = A.sa_coord + base;
+    const ChainRec *crec = reinterpret_cast<const ChainRec *>(A.crec) + base;
     int64_t so = seed_off[r];
     const float frac = A.frac_rep[r];
     for (int j = 0; j < nk; ++j) {
         const int32_t id = (int32_t)fl[j].y;
-        const int n = A.c_n[base + id];
+        const int n = crec[id].n;
         bwams_chain_t c;
         c.seqid = (int32_t)r; c.cseed = 0;
         c.n = n;
@@ -448,7 +625,7 @@ __global__ void chain_emit_kernel(ChainArgs A, const int64_t *__restrict__ chain
         while (m < n) m <<= 1;                   // SEEDS_PER_CHAIN = 1, doubled on demand (bwamem.cpp:398-412)
         c.m = m;
         c.first = first[j];
-        c.rid = A.c_rid[base + id];
+        c.rid = crec[id].rid;
         c.w_kept_alt = fl[j].x;
         c.frac_rep = frac;
         c.pos = pos[id];
@@ -468,10 +645,12 @@ __global__ void chain_emit_kernel(ChainArgs A, const int64_t *__restrict__ chain
 }  // namespace
 
 size_t chain_node_bytes(int64_t n_sa, int64_t nseq) { return (size_t)((n_sa >> 1) + 2 * nseq + 4) * sizeof(Node); }
+size_t chain_rec_bytes(int64_t n_sa) { return (size_t)(n_sa > 0 ? n_sa : 1) * sizeof(ChainRec); }
 
-void launch_chain(const ChainArgs &A, hipStream_t st) {
+void launch_chain(const ChainArgs &A, int cu_count, hipStream_t st) {
     if (A.nseq <= 0) return;
     chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, 0, st>>>(A, &A.ctr->n_heavy);
 }
 void launch_chain_emit(const ChainArgs &A, const int64_t *chain_off, const int64_t *seed_off, bwams_chain_t *chains,
                        bwams_chain_seed_t *seeds, hipStream_t st) {

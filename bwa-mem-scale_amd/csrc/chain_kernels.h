@@ -27,22 +27,23 @@ struct ChainArgs {
     // per seed
     int32_t *s_next;               // next seed of the same chain, -1 = last
     int2 *s_ql;                    // {qbeg, len}
-    // per chain (slot of its first seed)
-    int32_t *c_last, *c_n, *c_rid;
+    void *crec;                    // per chain (slot of its first seed): 64-byte chain record
     // filter work arrays (slot i of a read = i-th chain in sorted order)
     uint2 *flt;                    // {w | kept << 29 | is_alt << 31, chain id}
+    uint4 *f_rec;                  // {chn_beg, chn_end, w | is_alt << 31, first}
     int32_t *f_first, *f_kept, *f_sel;
-    int2 *f_be;                    // {chn_beg, chn_end}
     void *nodes;                   // B-tree nodes
     // per read
-    int32_t *n_kept, *n_kept_seeds;
+    int32_t *n_kept, *n_kept_seeds, *n_chn;
+    int32_t *heavy;                // reads handed to the wave-per-read kernel (ctr->n_heavy of them)
     int64_t *read_base;
     float *frac_rep;
     DevCounters *ctr;
 };
 
 size_t chain_node_bytes(int64_t n_sa, int64_t nseq);
-void launch_chain(const ChainArgs &A, hipStream_t st);
+size_t chain_rec_bytes(int64_t n_sa);
+void launch_chain(const ChainArgs &A, int cu_count, hipStream_t st);
 void launch_chain_emit(const ChainArgs &A, const int64_t *chain_off, const int64_t *seed_off, bwams_chain_t *chains,
                        bwams_chain_seed_t *seeds, hipStream_t st);
 
@@ -73,6 +74,6 @@ void launch_ext_build(const ExtArgs &A, const int64_t *offs, bwams_seqpair_t *le
 void launch_ext_post(const ExtArgs &A, int right, const bwams_seqpair_t *pairs, int64_t n, int w, int last_try,
                      bwams_seqpair_t *retry, unsigned long long *n_retry, hipStream_t st);
 void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hipStream_t st);
-void launch_ext_purge(const ExtArgs &A, hipStream_t st);
+void launch_ext_purge(const ExtArgs &A, int cu_count, hipStream_t st);
 
 }  // namespace bwams

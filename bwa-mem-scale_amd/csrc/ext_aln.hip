@@ -232,14 +232,53 @@ __global__ void ext_right_h0_kernel(ExtArgs A, bwams_seqpair_t *right, int64_t n
     right[l].h0 = A.regs[A.seed_off[right[l].seqid] + right[l].regid].score;
 }
 
-// lane per read: drop seeds (and their regions) that an earlier region already explains
+// ---- purge: drop seeds (and their regions) that an earlier region already explains ----------
+// (bwamem.cpp:3648-3755).  Sequential per read; the scan over the read's regions is quadratic, so
+// reads with few regions take one lane each and the others one wave each (the scan over regions
+// then runs 64 at a time, with ballots standing in for the loop's counters and its break).
+constexpr int kLightRegs = 32;
+
+// does region p "explain" seed s?  0: p is purged (skipped), 1: no (v++), 2: yes (break)
+__device__ __forceinline__ int purge_class(const bwams_mem_opt_t &opt, const bwams_chain_seed_t &s, int l_query, int64_t prb,
+                                           int64_t pre, int pqb, int pqe, int pseedlen0, int pw) {
+    if (pqb == -1 && pqe == -1) return 0;
+    if (s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) return 1;
+    if ((double)(s.len - pseedlen0) > .1 * (double)l_query) return 1;
+    int qd = s.qbeg - pqb;
+    int64_t rd = s.rbeg - prb;
+    int max_gap = cal_max_gap(opt, (int)(qd < rd ? qd : rd));
+    int w = max_gap < pw ? max_gap : pw;
+    if (qd - rd < w && rd - qd < w) return 2;
+    qd = pqe - (s.qbeg + s.len); rd = pre - (s.rbeg + s.len);
+    max_gap = cal_max_gap(opt, (int)(qd < rd ? qd : rd));
+    w = max_gap < pw ? max_gap : pw;
+    if (qd - rd < w && rd - qd < w) return 2;
+    return 1;
+}
+
+// is there a longer-or-similar seed later in the visiting order that overlaps s off-diagonal?
+__device__ __forceinline__ bool purge_keep_anyway(const bwams_chain_seed_t &s, const bwams_chain_seed_t *cs, const uint32_t *srt2,
+                                                  int k, int n) {
+    int v;
+    for (v = k + 1; v < n; ++v) {
+        const uint32_t sv = __hip_atomic_load(&srt2[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sv == 0xffffffffu) continue;
+        const bwams_chain_seed_t t = cs[sv];
+        if ((double)t.len < (double)s.len * .95) continue;
+        if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= (s.len >> 2) && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+        if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= (s.len >> 2) && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+    }
+    return v != n;
+}
+
 __global__ __launch_bounds__(64) void ext_purge_kernel(ExtArgs A) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= A.nseq) return;
-    const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
     const int64_t reg0 = A.seed_off[r];
-    bwams_alnreg_t *av = A.regs + reg0;
     const int64_t av_n = A.seed_off[r + 1] - reg0;
+    if (av_n > kLightRegs || av_n == 0) return;
+    const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
+    bwams_alnreg_t *av = A.regs + reg0;
     int lim = 0;
     for (int64_t j = A.chain_off[r]; j < A.chain_off[r + 1]; ++j) {
         const bwams_chain_t c = A.chains[j];
@@ -251,38 +290,71 @@ __global__ __launch_bounds__(64) void ext_purge_kernel(ExtArgs A) {
             int v = 0;
             for (i = 0; i < av_n && v < lim; ++i) {
                 const bwams_alnreg_t *p = &av[i];
-                const int64_t prb = p->rb, pre = p->re;
-                const int pqb = p->qb, pqe = p->qe;
-                if (pqb == -1 && pqe == -1) continue;
-                if (s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) { v++; continue; }
-                if ((double)(s.len - p->seedlen0) > .1 * (double)l_query) { v++; continue; }
-                const int pw = p->w;
-                int qd = s.qbeg - pqb;
-                int64_t rd = s.rbeg - prb;
-                int max_gap = cal_max_gap(A.opt, (int)(qd < rd ? qd : rd));
-                int w = max_gap < pw ? max_gap : pw;
-                if (qd - rd < w && rd - qd < w) break;
-                qd = pqe - (s.qbeg + s.len); rd = pre - (s.rbeg + s.len);
-                max_gap = cal_max_gap(A.opt, (int)(qd < rd ? qd : rd));
-                w = max_gap < pw ? max_gap : pw;
-                if (qd - rd < w && rd - qd < w) break;
-                v++;
+                const int cls = purge_class(A.opt, s, l_query, p->rb, p->re, p->qb, p->qe, p->seedlen0, p->w);
+                if (cls == 2) break;
+                v += cls;
             }
-            if (v < lim) {
-                for (v = k + 1; v < c.n; ++v) {
-                    if (srt2[v] == 0xffffffffu) continue;
-                    const bwams_chain_seed_t t = cs[srt2[v]];
-                    if ((double)t.len < (double)s.len * .95) continue;
-                    if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= (s.len >> 2) && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
-                    if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= (s.len >> 2) && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
-                }
-                if (v == c.n) {
-                    av[s.aln].qb = -1; av[s.aln].qe = -1;
-                    srt2[k] = 0xffffffffu;
-                    continue;
-                }
+            if (v < lim && !purge_keep_anyway(s, cs, srt2, k, c.n)) {
+                av[s.aln].qb = -1; av[s.aln].qe = -1;
+                srt2[k] = 0xffffffffu;
+                continue;
             }
             lim++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ext_purge_wave_kernel(ExtArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < A.nseq; r += stride) {
+        const int64_t reg0 = A.seed_off[r];
+        const int64_t av_n = A.seed_off[r + 1] - reg0;
+        if (av_n <= kLightRegs) continue;
+        const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
+        bwams_alnreg_t *av = A.regs + reg0;
+        int lim = 0;
+        for (int64_t j = A.chain_off[r]; j < A.chain_off[r + 1]; ++j) {
+            const bwams_chain_t c = A.chains[j];
+            const bwams_chain_seed_t *cs = A.seeds + c.seed_off;
+            uint32_t *srt2 = A.srt + c.seed_off;
+            for (int k = c.n - 1; k >= 0; --k) {
+                const uint32_t sk = __hip_atomic_load(&srt2[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bwams_chain_seed_t s = cs[sk];
+                int v = 0;
+                bool brk = false;
+                for (int64_t base = 0; base < av_n && v < lim; base += 64) {
+                    const int64_t i = base + lane;
+                    int cls = 0;
+                    if (i < av_n) {
+                        bwams_alnreg_t *p = &av[i];
+                        // qb/qe are rewritten by this wave while it runs: read them past the vector L1
+                        const unsigned long long qq = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&p->qb),
+                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        cls = purge_class(A.opt, s, l_query, p->rb, p->re, (int)(uint32_t)qq, (int)(uint32_t)(qq >> 32),
+                                          p->seedlen0, p->w);
+                    }
+                    const unsigned long long m_v = __ballot(cls == 1), m_b = __ballot(cls == 2);
+                    if (m_b) {
+                        const int pb = __ffsll((long long)m_b) - 1;
+                        const int v_at = v + __popcll(m_v & ((1ull << pb) - 1ull));
+                        if (v_at < lim) { v = v_at; brk = true; break; }
+                    }
+                    v += __popcll(m_v);
+                    if (v > lim) v = lim;                 // the sequential loop stops counting at lim
+                }
+                (void)brk;
+                if (v < lim && !purge_keep_anyway(s, cs, srt2, k, c.n)) {
+                    if (lane == 0) {
+                        const unsigned long long gone = 0xffffffffffffffffull;     // qb = qe = -1
+                        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&av[s.aln].qb), gone, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&srt2[k], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    continue;
+                }
+                lim++;
+            }
         }
     }
 }
@@ -314,9 +386,12 @@ void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hi
     ext_right_h0_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(A, right, n);
 }
 
-void launch_ext_purge(const ExtArgs &A, hipStream_t st) {
+void launch_ext_purge(const ExtArgs &A, int cu_count, hipStream_t st) {
     if (A.nseq <= 0) return;
     ext_purge_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
+    int64_t blocks = (A.nseq + 3) / 4;
+    if (blocks > (int64_t)cu_count * 8) blocks = (int64_t)cu_count * 8;
+    ext_purge_wave_kernel<<<(unsigned)blocks, 256, 0, st>>>(A);
 }
 
 }  // namespace bwams

@@ -29,7 +29,7 @@ struct ChainState {
     // chaining scratch (per SA hit)
     DevBuf s_next, s_ql, crec, flt, f_rec, f_first, f_kept, f_sel, nodes;
     // per read
-    DevBuf n_kept, n_kept_seeds, n_chn, heavy, read_base, frac, wide, chain_off;
+    DevBuf n_kept, n_kept_seeds, n_chn, heavy, read_base, frac, wide, chain_off, slice, okeys, okeys2, ovals, ovals2;
     // results
     DevBuf chains, seeds;
     int64_t n_chains = 0, n_seeds = 0, nseq = 0;
@@ -48,7 +48,7 @@ struct ChainState {
 void chain_state_free(ChainState *s) {
     if (!s) return;
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
-                     &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->read_base, &s->frac, &s->wide,
+                     &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
                      &s->chain_off, &s->chains, &s->seeds, &s->regs, &s->srt, &s->rmax, &s->cnt,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
@@ -173,6 +173,10 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     int rc = check_opt(opt, "bwams_chain_run");
     if (rc) return rc;
     if ((rc = bwams_seed_counts(b, nullptr, nullptr))) return rc;     // sizes of the seed stage (and its overflow check)
+    if (b->max_read_len >= 32768) {
+        set_last_error("bwams_chain_run: reads of 32768 bases or more are not supported (16-bit query coordinates)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
     BWAMS_HIP(hipSetDevice(b->idx->device));
     ChainState *s;
     if ((rc = get_state(b, &s))) return rc;
@@ -185,6 +189,9 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     BWAMS_HIP(s->flt.ensure(ns * 8));     BWAMS_HIP(s->f_rec.ensure(ns * 16));
     BWAMS_HIP(s->f_first.ensure(ns * 4)); BWAMS_HIP(s->f_kept.ensure(ns * 4)); BWAMS_HIP(s->f_sel.ensure(ns * 4));
     BWAMS_HIP(s->n_chn.ensure((size_t)n1 * 4));       BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->slice.ensure((size_t)n1 * 16));
+    BWAMS_HIP(s->okeys.ensure((size_t)n1 * 4));       BWAMS_HIP(s->okeys2.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->ovals.ensure((size_t)n1 * 4));       BWAMS_HIP(s->ovals2.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->nodes.ensure(chain_node_bytes(n_sa, nseq)));
     BWAMS_HIP(s->n_kept.ensure((size_t)n1 * 4));      BWAMS_HIP(s->n_kept_seeds.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->read_base.ensure((size_t)n1 * 8));   BWAMS_HIP(s->frac.ensure((size_t)n1 * 4));
@@ -201,18 +208,34 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     A.f_kept = s->f_kept.as<int32_t>(); A.f_sel = s->f_sel.as<int32_t>(); A.nodes = s->nodes.p;
     A.n_kept = s->n_kept.as<int32_t>(); A.n_kept_seeds = s->n_kept_seeds.as<int32_t>();
     A.n_chn = s->n_chn.as<int32_t>(); A.heavy = s->heavy.as<int32_t>();
+    A.slice = s->slice.as<int64_t>(); A.order = s->ovals2.as<uint32_t>();
     A.read_base = s->read_base.as<int64_t>(); A.frac_rep = s->frac.as<float>();
     A.ctr = b->d_ctr;
 
     BWAMS_HIP(hipEventRecord(s->ev[0], st));
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 3 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 11 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[4], chain_ticket[4]
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all
     if (b->n_smem <= 1 || n_sa == 0) {
         BWAMS_HIP(hipMemsetAsync(s->n_kept.p, 0, (size_t)n1 * 4, st));
         BWAMS_HIP(hipMemsetAsync(s->n_kept_seeds.p, 0, (size_t)n1 * 4, st));
     } else {
-        launch_chain(A, b->cu_count, st);
+        // reads of similar seed count share a wave: sort read ids by descending count
+        launch_chain_count(A, s->okeys.as<uint32_t>(), s->ovals.as<uint32_t>(), st);
+        size_t tb = 0;
+        BWAMS_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, s->okeys.as<uint32_t>(), s->okeys2.as<uint32_t>(),
+                                                 s->ovals.as<uint32_t>(), s->ovals2.as<uint32_t>(), (size_t)nseq, 0, 32, st));
+        if (tb > b->tmp_bytes) {
+            BWAMS_HIP(hipStreamSynchronize(st));
+            if (b->d_tmp) (void)hipFree(b->d_tmp);
+            b->d_tmp = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            b->tmp_bytes = tb;
+        }
+        tb = b->tmp_bytes;
+        BWAMS_HIP(rocprim::radix_sort_pairs_desc(b->d_tmp, tb, s->okeys.as<uint32_t>(), s->okeys2.as<uint32_t>(),
+                                                 s->ovals.as<uint32_t>(), s->ovals2.as<uint32_t>(), (size_t)nseq, 0, 32, st));
+        launch_chain(A, s->okeys.as<uint32_t>(), b->cu_count, st);
     }
     int64_t tot[2] = {0, 0};
     if (nseq > 0) {

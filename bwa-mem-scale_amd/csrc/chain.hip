@@ -8,8 +8,10 @@
 //
 // The work is sequential per read (each seed is tested against the chain found by an ordered
 // lookup; then the read's chains are sorted and filtered pairwise) and reads are independent.
-//   chain_kernel        one lane per read: chaining, chain weights; for reads with few chains
-//                       also the sort and the filter.
+//   chain_kernel        one lane per read with few seeds: chaining, chain weights; for reads with
+//                       few chains also the sort and the filter.
+//   chain_wave_kernel   one wave per read with many seeds, heaviest reads first: the same code run
+//                       in lockstep by 64 lanes (uniform loads = one request; lane 0 stores).
 //   chain_heavy_kernel  one wave per read with many chains: the sort runs on lane 0 over an LDS
 //                       copy, the quadratic pairwise filter runs 64 kept chains at a time.
 // All state lives in HBM scratch indexed by the read's slice of the SA-coordinate array: a seed
@@ -33,25 +35,33 @@ namespace {
 
 constexpr int KB_T = 5;
 constexpr int KB_MAXK = 2 * KB_T - 1;
+constexpr int kLaneSeeds = 32;       // reads with more seeds than this are chained by a whole wave (chain_wave_kernel)
 constexpr int kLightChains = 16;     // reads with more chains than this go to chain_heavy_kernel
-constexpr int kLdsChains = 1024;     // chains the heavy kernel keeps in LDS (44 B each)
-
-struct alignas(16) Node {            // 160 B
-    int32_t n, internal;
+constexpr int kLdsChains = 1024;     // chains the heavy kernel keeps in LDS (40 B each)
+struct alignas(16) Node {            // 144 B = nine 16-byte loads
+    int16_t n, internal;
+    int16_t ptr[KB_MAXK + 1];        // node ids relative to the read's node region
     int64_t pos[KB_MAXK];            // reference position of each key's chain (the sort key)
-    int32_t key[KB_MAXK];            // chain ids (relative index of the chain's first seed)
-    int32_t ptr[KB_MAXK + 1];        // node ids relative to the read's node region
-    int32_t pad_;
+    int32_t key[KB_MAXK];            // chain ids (creation order within the read)
+    int32_t pad_[3];
 };
-static_assert(sizeof(Node) == 160, "node layout");
+static_assert(sizeof(Node) == 144, "node layout");
 
-struct alignas(16) ChainRec {        // 64 B, slot of the chain's first seed
+struct alignas(16) ChainRec {        // 48 B, one per chain in creation order
     int64_t last_rbeg, endr;         // last seed's rbeg; running `end` of the reference-side weight
-    int32_t first_qbeg, last_qbeg, last_len, rid;
-    int32_t n, last_idx, wq, wr;     // seeds, last seed, query-/reference-side weights so far
-    int32_t endq, pad_[3];
+    int16_t first_qbeg, last_qbeg, last_len, endq;   // query coordinates (reads are shorter than 32768)
+    int32_t rid, n;                  // reference sequence, seeds
+    int32_t first_idx, last_idx;     // first / last seed (index relative to the read's first SA hit)
+    int32_t wq, wr;                  // query-/reference-side weights so far
 };
-static_assert(sizeof(ChainRec) == 64, "chain record layout");
+static_assert(sizeof(ChainRec) == 48, "chain record layout");
+
+// LDS bytes a wave needs to chain a read of at most K seeds: K chain records + the B-tree's nodes
+// (every node but the root holds >= t - 1 = 4 keys: at most 5K/16 + 3 nodes)
+__host__ __device__ constexpr int lds_nodes(int K) { return (K * 5) / 16 + 3; }
+__host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * sizeof(ChainRec) + (size_t)lds_nodes(K) * sizeof(Node); }
+constexpr int kClassS = 128, kClassM = 512, kClassL = 1700;      // seeds per read: 12 KB, 48 KB, 159 KB of LDS
+static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
 
 // bns_pos2rid / bns_intv2rid (bntseq.cpp:397-421) with a one-entry cache of the last sequence found
 struct RidCache { int64_t lo, hi; int rid; };
@@ -85,21 +95,40 @@ __device__ __forceinline__ int intv2rid(const DevBns &b, int64_t rb, int64_t re,
 // per-read view of the scratch
 struct ReadCtx {
     Node *nodes;
+    ChainRec *crec;
     int32_t n_nodes, cap_nodes, root;
     int32_t n_keys;
     bool overflow;
+    bool wr;                 // this lane performs the stores (lane-per-read: always; wave-per-read: lane 0)
 };
 
 __device__ __forceinline__ int32_t new_node(ReadCtx &c) {
     if (c.n_nodes >= c.cap_nodes) { c.overflow = true; return 0; }
-    Node *x = &c.nodes[c.n_nodes];
-    x->n = 0; x->internal = 0;
+    if (c.n_nodes >= 32767) { c.overflow = true; return 0; }
+    if (c.wr) { Node *x = &c.nodes[c.n_nodes]; x->n = 0; x->internal = 0; }
     return c.n_nodes++;
+}
+
+// Register copy of a node.  Filled field by field (independent loads, all in flight at once) rather
+// than by a struct copy: a byte-wise copy of the mixed 16/32/64-bit layout is not promoted to
+// registers by the compiler and would bounce through scratch memory.
+struct NodeR {
+    int32_t n, internal;
+    int64_t pos[KB_MAXK];
+    int32_t key[KB_MAXK];
+    int32_t ptr[KB_MAXK + 1];
+};
+__device__ __forceinline__ void load_node(const Node *p, NodeR &x, bool want_ptr) {
+    x.n = p->n; x.internal = p->internal;
+#pragma unroll
+    for (int t = 0; t < KB_MAXK; ++t) { x.pos[t] = p->pos[t]; x.key[t] = p->key[t]; }
+#pragma unroll
+    for (int t = 0; t <= KB_MAXK; ++t) x.ptr[t] = want_ptr ? (int32_t)p->ptr[t] : 0;
 }
 
 // __kb_getp_aux (kbtree.h:124-139) on a register copy of the node: keys are sorted, so the lower
 // bound is the number of keys below k, and "found" means some key equals k
-__device__ __forceinline__ int node_search(const Node &x, int64_t k, bool &eq) {
+__device__ __forceinline__ int node_search(const NodeR &x, int64_t k, bool &eq) {
     int cnt = 0;
     bool e = false;
 #pragma unroll
@@ -108,19 +137,19 @@ __device__ __forceinline__ int node_search(const Node &x, int64_t k, bool &eq) {
     eq = e;
     return e ? cnt : cnt - 1;
 }
-__device__ __forceinline__ int32_t sel_key(const Node &x, int i) {
+__device__ __forceinline__ int32_t sel_key(const NodeR &x, int i) {
     int32_t v = x.key[0];
 #pragma unroll
     for (int t = 1; t < KB_MAXK; ++t) v = i == t ? x.key[t] : v;
     return v;
 }
-__device__ __forceinline__ int64_t sel_pos(const Node &x, int i) {
+__device__ __forceinline__ int64_t sel_pos(const NodeR &x, int i) {
     int64_t v = x.pos[0];
 #pragma unroll
     for (int t = 1; t < KB_MAXK; ++t) v = i == t ? x.pos[t] : v;
     return v;
 }
-__device__ __forceinline__ int32_t sel_ptr(const Node &x, int i) {
+__device__ __forceinline__ int32_t sel_ptr(const NodeR &x, int i) {
     int32_t v = x.ptr[0];
 #pragma unroll
     for (int t = 1; t <= KB_MAXK; ++t) v = i == t ? x.ptr[t] : v;
@@ -128,10 +157,11 @@ __device__ __forceinline__ int32_t sel_ptr(const Node &x, int i) {
 }
 
 // kb_intervalp (kbtree.h:159-176): the chain with the closest position <= k, or -1
-__device__ int32_t kbt_lower(const ReadCtx &c, int64_t k, int64_t &lower_pos) {
+__device__ __forceinline__ int32_t kbt_lower(const ReadCtx &c, int64_t k, int64_t &lower_pos) {
     int32_t lower = -1, xi = c.root;
     for (;;) {
-        const Node x = c.nodes[xi];
+        NodeR x;
+        load_node(&c.nodes[xi], x, true);
         bool eq;
         const int i = node_search(x, k, eq);
         if (i >= 0) { lower = sel_key(x, i); lower_pos = sel_pos(x, i); }
@@ -142,9 +172,9 @@ __device__ int32_t kbt_lower(const ReadCtx &c, int64_t k, int64_t &lower_pos) {
 }
 
 // __kb_split (kbtree.h:183-199), in memory (one call per ~5 insertions)
-__device__ void kbt_split(ReadCtx &c, int32_t xi, int i, int32_t yi) {
+__device__ __forceinline__ void kbt_split(ReadCtx &c, int32_t xi, int i, int32_t yi) {
     const int32_t zi = new_node(c);
-    if (c.overflow) return;
+    if (c.overflow || !c.wr) return;
     Node *x = &c.nodes[xi], *y = &c.nodes[yi], *z = &c.nodes[zi];
     z->internal = y->internal;
     z->n = KB_T - 1;
@@ -153,39 +183,42 @@ __device__ void kbt_split(ReadCtx &c, int32_t xi, int i, int32_t yi) {
     y->n = KB_T - 1;
     const int xn = x->n;
     for (int t = xn; t > i; --t) x->ptr[t + 1] = x->ptr[t];
-    x->ptr[i + 1] = zi;
+    x->ptr[i + 1] = (int16_t)zi;
     for (int t = xn - 1; t >= i; --t) { x->key[t + 1] = x->key[t]; x->pos[t + 1] = x->pos[t]; }
     x->key[i] = y->key[KB_T - 1];
     x->pos[i] = y->pos[KB_T - 1];
-    x->n = xn + 1;
+    x->n = (int16_t)(xn + 1);
 }
 
 // __kb_putp_aux / kb_putp (kbtree.h:200-233)
-__device__ void kbt_put(ReadCtx &c, int32_t id, int64_t k) {
+__device__ __forceinline__ void kbt_put(ReadCtx &c, int32_t id, int64_t k) {
     ++c.n_keys;
     int32_t xi = c.root;
     if (c.nodes[xi].n == KB_MAXK) {
         const int32_t s = new_node(c);
         if (c.overflow) return;
-        c.nodes[s].internal = 1; c.nodes[s].n = 0; c.nodes[s].ptr[0] = xi;
+        if (c.wr) { c.nodes[s].internal = 1; c.nodes[s].n = 0; c.nodes[s].ptr[0] = (int16_t)xi; }
         c.root = s;
         kbt_split(c, s, 0, xi);
         if (c.overflow) return;
         xi = s;
     }
     for (;;) {
-        Node x = c.nodes[xi];
+        Node *px = &c.nodes[xi];
+        NodeR x;
+        load_node(px, x, true);
         bool eq;
         if (!x.internal) {
             const int i = node_search(x, k, eq);          // insert after slot i
+            if (c.wr) {
 #pragma unroll
-            for (int t = KB_MAXK - 1; t >= 1; --t)
-                if (t > i + 1 && t <= x.n) { x.key[t] = x.key[t - 1]; x.pos[t] = x.pos[t - 1]; }
+                for (int t = KB_MAXK - 1; t >= 1; --t)
+                    if (t > i + 1 && t <= x.n) { px->key[t] = x.key[t - 1]; px->pos[t] = x.pos[t - 1]; }
 #pragma unroll
-            for (int t = 0; t < KB_MAXK; ++t)
-                if (t == i + 1) { x.key[t] = id; x.pos[t] = k; }
-            ++x.n;
-            c.nodes[xi] = x;
+                for (int t = 0; t < KB_MAXK; ++t)
+                    if (t == i + 1) { px->key[t] = id; px->pos[t] = k; }
+                px->n = (int16_t)(x.n + 1);
+            }
             return;
         }
         int i = node_search(x, k, eq) + 1;
@@ -202,7 +235,7 @@ __device__ void kbt_put(ReadCtx &c, int32_t id, int64_t k) {
 
 // in-order traversal (__kb_traverse, kbtree.h:345-368) with an explicit stack; si = children already
 // descended (height <= 16 covers 5^16 keys)
-__device__ int32_t kbt_traverse(const ReadCtx &c, int32_t *out) {
+__device__ __forceinline__ int32_t kbt_traverse(const ReadCtx &c, int32_t *out) {
     int32_t sx[16];
     int32_t si[16];
     int sp = 0, n = 0;
@@ -210,12 +243,12 @@ __device__ int32_t kbt_traverse(const ReadCtx &c, int32_t *out) {
     while (sp >= 0) {
         const Node *x = &c.nodes[sx[sp]];
         if (!x->internal) {
-            for (int t = 0; t < x->n; ++t) out[n++] = x->key[t];
+            for (int t = 0; t < x->n; ++t) { if (c.wr) out[n] = x->key[t]; ++n; }
             --sp;
             continue;
         }
         const int i = si[sp];
-        if (i > 0 && i - 1 < x->n) out[n++] = x->key[i - 1];
+        if (i > 0 && i - 1 < x->n) { if (c.wr) out[n] = x->key[i - 1]; ++n; }
         if (i <= x->n && sp < 15) {
             si[sp] = i + 1;
             ++sp;
@@ -366,21 +399,50 @@ __device__ __forceinline__ uint4 make_rec(const ChainArgs &A, const ChainRec &c,
 }
 
 // ---- the chaining kernel: one lane per read --------------------------------------------------
-__global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
+// lane per read: the read's slice of the sorted SMEM array and its seed count (the sort key that
+// groups reads of similar cost into the same wave)
+__global__ void chain_count_kernel(ChainArgs A, uint32_t *keys, uint32_t *vals) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= A.nseq) return;
-    A.n_kept[r] = 0;
-    A.n_kept_seeds[r] = 0;
-    A.read_base[r] = 0;
-    A.n_chn[r] = 0;
     const bwams_smem_t *sm = A.smem;
-    // slice of this read in the (rid, m, n)-sorted SMEM array
     int64_t lo = 0, hi = A.n_smem;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)sm[mid].rid < r) lo = mid + 1; else hi = mid; }
     const int64_t beg = lo;
     hi = A.n_smem;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)sm[mid].rid <= r) lo = mid + 1; else hi = mid; }
     const int64_t end = lo;
+    A.slice[2 * r] = beg; A.slice[2 * r + 1] = end;
+    const int64_t cnt = beg < end ? A.sa_off[end] - A.sa_off[beg] : 0;
+    keys[r] = (uint32_t)(cnt < 0xffffffffll ? cnt : 0xffffffffll);
+    vals[r] = (uint32_t)r;
+    // class boundaries in the descending order: [0, c[0]) > L, [c[0], c[1]) > M, [c[1], c[2]) > S, [c[2], c[3]) > lane tier
+    if (cnt > kLaneSeeds) {
+        atomicAdd(&A.ctr->chain_class[3], 1ull);
+        if (cnt > kClassS) atomicAdd(&A.ctr->chain_class[2], 1ull);
+        if (cnt > kClassM) atomicAdd(&A.ctr->chain_class[1], 1ull);
+        if (cnt > kClassL) atomicAdd(&A.ctr->chain_class[0], 1ull);
+    }
+}
+
+// Chain one read.  `nl` lanes run this function in lockstep on the same read: 1 (a lane per read) or
+// 64 (a wave per read: every load is wave-uniform, i.e. one request; lane 0 performs the stores).
+// nodes / crec_w: where the B-tree and the chain records live while chaining — the read's HBM scratch,
+// or LDS (then the records are copied out to crec_g at the end; the tree is not needed afterwards).
+// LDS = true: nodes / crec_w point into LDS and every access through them must stay a ds_* instruction
+// (a flat access would wait on vmcnt, i.e. on the round trip of every global store issued before it),
+// so the pointers are never mixed with HBM pointers in this instantiation.
+template <bool LDS>
+__device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int lane, int nl, Node *nodes, int32_t cap_nodes,
+                                           ChainRec *crec_w, int32_t cap_chains) {
+    const bool wr = lane == 0;
+    if (wr) {
+        A.n_kept[r] = 0;
+        A.n_kept_seeds[r] = 0;
+        A.read_base[r] = 0;
+        A.n_chn[r] = 0;
+    }
+    const bwams_smem_t *sm = A.smem;
+    const int64_t beg = A.slice[2 * r], end = A.slice[2 * r + 1];
     const int L = (int)(A.cum[r + 1] - A.cum[r]);
     if (beg == end || L < A.opt.min_seed_len) return;
 
@@ -393,32 +455,49 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
         else e = e > se ? e : se;
     }
     l_rep += e - b;
-    A.frac_rep[r] = (float)l_rep / (float)L;
+    if (wr) A.frac_rep[r] = (float)l_rep / (float)L;
 
     const int64_t base = A.sa_off[beg];
     const int32_t cnt = (int32_t)(A.sa_off[end] - base);
-    A.read_base[r] = base;
+    if (wr) A.read_base[r] = base;
     if (cnt == 0) return;
     const int64_t *pos = A.sa_coord + base;
     int32_t *s_next = A.s_next + base;
     int2 *s_ql = A.s_ql + base;
-    ChainRec *crec = reinterpret_cast<ChainRec *>(A.crec) + base;
-
+    ChainRec *crec_g = reinterpret_cast<ChainRec *>(A.crec) + base;
+    ChainRec *crec;
     ReadCtx c;
-    const int64_t nbase = (base >> 1) + 2 * r;
-    c.nodes = reinterpret_cast<Node *>(A.nodes) + nbase;
-    c.cap_nodes = (int32_t)((((base + cnt) >> 1) + 2 * (r + 1)) - nbase);
-    c.n_nodes = 0; c.n_keys = 0; c.overflow = false;
+    if constexpr (LDS) {
+        crec = crec_w;
+        c.nodes = nodes; c.cap_nodes = cap_nodes;
+    } else {
+        crec = crec_g;
+        const int64_t nbase = (base >> 1) + 2 * r;
+        c.nodes = reinterpret_cast<Node *>(A.nodes) + nbase;
+        c.cap_nodes = (int32_t)((((base + cnt) >> 1) + 2 * (r + 1)) - nbase);
+    }
+    c.crec = crec;
+    c.n_nodes = 0; c.n_keys = 0; c.overflow = false; c.wr = wr;
     c.root = new_node(c);
     RidCache rc;
     rc.lo = 0; rc.hi = -1; rc.rid = 0;
+    if (LDS && cnt > cap_chains) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return; }
 
     const int64_t l_pac = A.bns.l_pac;
     for (int64_t i = beg; i < end; ++i) {
         const int qbeg = (int)sm[i].m, slen = (int)sm[i].n + 1 - (int)sm[i].m;
         const int32_t g0 = (int32_t)(A.sa_off[i] - base), g1 = (int32_t)(A.sa_off[i + 1] - base);
+        int64_t pos64 = 0;                       // wave mode: the positions of 64 seeds, one per lane
         for (int32_t g = g0; g < g1; ++g) {
-            const int64_t rbeg = pos[g];
+            int64_t rbeg;
+            if (nl == 64) {
+                // one load per 64 seeds: a load per seed would wait (vmcnt) for the round trip of the
+                // stores the previous seed issued
+                const int j = (g - g0) & 63;
+                if (j == 0) pos64 = g + lane < g1 ? pos[g + lane] : 0;
+                rbeg = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(pos64 >> 32), j) << 32) |
+                                 (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pos64, j));
+            } else rbeg = pos[g];
             const int rid = intv2rid(A.bns, rbeg, rbeg + slen, rc);
             if (rid < 0) continue;
             bool to_add = true;
@@ -436,32 +515,33 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
                         const int64_t x = qbeg - ch.last_qbeg, y = rbeg - lr;
                         if (y >= 0 && x - y <= A.opt.w && y - x <= A.opt.w && x - ch.last_len < A.opt.max_chain_gap &&
                             y - ch.last_len < A.opt.max_chain_gap) {
-                            s_ql[g] = make_int2(qbeg, slen);
-                            s_next[g] = -1;
-                            s_next[ch.last_idx] = g;
+                            if (wr) {
+                                s_ql[g] = make_int2(qbeg, slen);
+                                s_next[g] = -1;
+                                s_next[ch.last_idx] = g;
+                            }
                             // mem_chain_weight's two running sums, one seed further
                             if (qbeg >= ch.endq) ch.wq += slen; else if (qbeg + slen > ch.endq) ch.wq += qbeg + slen - ch.endq;
-                            ch.endq = ch.endq > qbeg + slen ? ch.endq : qbeg + slen;
+                            ch.endq = (int16_t)(ch.endq > qbeg + slen ? ch.endq : qbeg + slen);
                             if (rbeg >= ch.endr) ch.wr += slen; else if (rbeg + slen > ch.endr) ch.wr += (int)(rbeg + slen - ch.endr);
                             ch.endr = ch.endr > rbeg + slen ? ch.endr : rbeg + slen;
-                            ch.last_rbeg = rbeg; ch.last_qbeg = qbeg; ch.last_len = slen; ch.last_idx = g; ch.n += 1;
-                            crec[lower] = ch;
+                            ch.last_rbeg = rbeg; ch.last_qbeg = (int16_t)qbeg; ch.last_len = (int16_t)slen; ch.last_idx = g; ch.n += 1;
+                            if (wr) crec[lower] = ch;
                             to_add = false;
                         }
                     }
                 }
             }
             if (to_add) {
-                s_ql[g] = make_int2(qbeg, slen);
-                s_next[g] = -1;
+                if (wr) { s_ql[g] = make_int2(qbeg, slen); s_next[g] = -1; }
                 ChainRec ch;
                 ch.last_rbeg = rbeg; ch.endr = rbeg + slen;
-                ch.first_qbeg = qbeg; ch.last_qbeg = qbeg; ch.last_len = slen; ch.rid = rid;
-                ch.n = 1; ch.last_idx = g; ch.wq = slen; ch.wr = slen;
-                ch.endq = qbeg + slen; ch.pad_[0] = ch.pad_[1] = ch.pad_[2] = 0;
-                crec[g] = ch;
-                kbt_put(c, g, rbeg);
-                if (c.overflow) { atomicAdd(&A.ctr->chain_overflow, 1ull); return; }
+                ch.first_qbeg = (int16_t)qbeg; ch.last_qbeg = (int16_t)qbeg; ch.last_len = (int16_t)slen; ch.endq = (int16_t)(qbeg + slen);
+                ch.rid = rid; ch.n = 1; ch.first_idx = g; ch.last_idx = g; ch.wq = slen; ch.wr = slen;
+                const int32_t cid = c.n_keys;                            // chains are numbered in creation order
+                if (wr) crec[cid] = ch;
+                kbt_put(c, cid, rbeg);
+                if (c.overflow) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return; }
             }
         }
     }
@@ -477,11 +557,15 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
         const ChainRec ch = crec[id];
         int w = ch.wr < ch.wq ? ch.wr : ch.wq;
         w = w < (1 << 30) ? w : (1 << 30) - 1;
-        if (t == 0) fl[0] = make_uint2((unsigned)w, (unsigned)id);      // a_[0] stays in place when everything is dropped
+        if (t == 0 && wr) fl[0] = make_uint2((unsigned)w, (unsigned)id);      // a_[0] stays in place when everything is dropped
         if (w < A.opt.min_chain_weight) continue;
-        fl[n_chn++] = make_uint2((unsigned)w, (unsigned)id);
+        if (wr) fl[n_chn] = make_uint2((unsigned)w, (unsigned)id);
+        ++n_chn;
     }
     if (n_chn == 0) n_chn = 1;                  // the reference keeps a_[0] in that case (bwamem.cpp:549-572)
+    if constexpr (LDS)                          // chain records out of LDS, for the filter and the emit stages
+        for (int32_t k = lane; k < c.n_keys; k += nl) crec_g[k] = crec_w[k];
+    if (!wr) return;
     A.n_chn[r] = n_chn;
     if (n_chn > kLightChains) {                 // sort + filter by a whole wave (chain_heavy_kernel)
         const unsigned long long slot = atomicAdd(&A.ctr->n_heavy, 1ull);
@@ -496,7 +580,39 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A) {
         kept[i] = 0;
     }
     filter_seq(A.opt, n_chn, rec, kept, A.f_sel + base);
+    if constexpr (LDS) __threadfence_block();   // crec_g was written by the other lanes just above
     finish_read(A, r, base, n_chn, L);
+}
+
+// reads with few seeds: one lane per read, state in HBM scratch
+__global__ __launch_bounds__(64) void chain_kernel(ChainArgs A, const uint32_t *__restrict__ n_seeds) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.nseq) return;
+    if (n_seeds[r] > (uint32_t)kLaneSeeds) return;          // a wave kernel's
+    chain_read<false>(A, r, 0, 1, nullptr, 0, nullptr, 0);
+}
+
+// reads with many seeds: one wave (= one block) per read, B-tree and chain records in LDS.  The reads
+// order[lo .. hi) (sorted by descending seed count, so a size class is a range) are handed out by ticket.
+// K = 0: no LDS (reads too large for a CU's LDS): state in HBM scratch.
+__global__ __launch_bounds__(64) void chain_wave_kernel(ChainArgs A, const unsigned long long *lo_p, const unsigned long long *hi_p,
+                                                        unsigned long long *ticket, int K) {
+    extern __shared__ __align__(16) unsigned char l_mem[];
+    const int lane = threadIdx.x;
+    const int64_t lo = lo_p ? (int64_t)*lo_p : 0, hi = (int64_t)*hi_p;
+    ChainRec *l_crec = reinterpret_cast<ChainRec *>(l_mem);
+    Node *l_nodes = reinterpret_cast<Node *>(l_mem + (size_t)K * sizeof(ChainRec));
+    for (;;) {
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(ticket, 1ull);
+        t = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
+            (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t);
+        if (lo + (int64_t)t >= hi) break;
+        const int64_t r = (int64_t)A.order[lo + (int64_t)t];
+        if (K) chain_read<true>(A, r, lane, 64, l_nodes, lds_nodes(K), l_crec, K);
+        else chain_read<false>(A, r, lane, 64, nullptr, 0, nullptr, 0);
+        __syncthreads();
+    }
 }
 
 // ---- reads with many chains: one wave per read ---------------------------------------------------
@@ -616,8 +732,9 @@ __global__ void chain_emit_kernel(ChainArgs A, const int64_t *__restrict__ chain
     int64_t so = seed_off[r];
     const float frac = A.frac_rep[r];
     for (int j = 0; j < nk; ++j) {
-        const int32_t id = (int32_t)fl[j].y;
-        const int n = crec[id].n;
+        const ChainRec ch = crec[fl[j].y];
+        const int32_t id = ch.first_idx;          // the chain's first seed
+        const int n = ch.n;
         bwams_chain_t c;
         c.seqid = (int32_t)r; c.cseed = 0;
         c.n = n;
@@ -625,7 +742,7 @@ __global__ void chain_emit_kernel(ChainArgs A, const int64_t *__restrict__ chain
         while (m < n) m <<= 1;                   // SEEDS_PER_CHAIN = 1, doubled on demand (bwamem.cpp:398-412)
         c.m = m;
         c.first = first[j];
-        c.rid = crec[id].rid;
+        c.rid = ch.rid;
         c.w_kept_alt = fl[j].x;
         c.frac_rep = frac;
         c.pos = pos[id];
@@ -647,9 +764,25 @@ __global__ void chain_emit_kernel(ChainArgs A, const int64_t *__restrict__ chain
 size_t chain_node_bytes(int64_t n_sa, int64_t nseq) { return (size_t)((n_sa >> 1) + 2 * nseq + 4) * sizeof(Node); }
 size_t chain_rec_bytes(int64_t n_sa) { return (size_t)(n_sa > 0 ? n_sa : 1) * sizeof(ChainRec); }
 
-void launch_chain(const ChainArgs &A, int cu_count, hipStream_t st) {
+void launch_chain_count(const ChainArgs &A, uint32_t *keys, uint32_t *vals, hipStream_t st) {
     if (A.nseq <= 0) return;
-    chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
+    chain_count_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A, keys, vals);
+}
+void launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    unsigned long long *cls = A.ctr->chain_class, *tk = A.ctr->chain_ticket;
+    // heaviest first: reads beyond the LDS budget (HBM state), then the three LDS size classes, then the lane tier
+    chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, 0, st>>>(A, nullptr, cls + 0, tk + 0, 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes(kClassL));
+        attr_set = true;
+    }
+    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), st>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
+    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassM), st>>>(A, cls + 1, cls + 2, tk + 2, kClassM);
+    chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), st>>>(A, cls + 2, cls + 3, tk + 3, kClassS);
+    chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A, n_seeds);
     chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, 0, st>>>(A, &A.ctr->n_heavy);
 }
 void launch_chain_emit(const ChainArgs &A, const int64_t *chain_off, const int64_t *seed_off, bwams_chain_t *chains,

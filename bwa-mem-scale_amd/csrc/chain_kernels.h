@@ -37,13 +37,16 @@ struct ChainArgs {
     int32_t *n_kept, *n_kept_seeds, *n_chn;
     int32_t *heavy;                // reads handed to the wave-per-read kernel (ctr->n_heavy of them)
     int64_t *read_base;
+    int64_t *slice;                // 2 per read: its [beg, end) in smem
+    const uint32_t *order;         // read ids by descending seed count
     float *frac_rep;
     DevCounters *ctr;
 };
 
 size_t chain_node_bytes(int64_t n_sa, int64_t nseq);
 size_t chain_rec_bytes(int64_t n_sa);
-void launch_chain(const ChainArgs &A, int cu_count, hipStream_t st);
+void launch_chain_count(const ChainArgs &A, uint32_t *keys, uint32_t *vals, hipStream_t st);
+void launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipStream_t st);
 void launch_chain_emit(const ChainArgs &A, const int64_t *chain_off, const int64_t *seed_off, bwams_chain_t *chains,
                        bwams_chain_seed_t *seeds, hipStream_t st);
 

@@ -65,7 +65,9 @@ struct DevCounters {
     unsigned long long emf_nodes, emf_cmp_bytes;     // EMF probe: entries visited, reference bytes compared   // n_ext / n_ext_blocks when round 1, 2, 3 ended
     unsigned long long chain_overflow;   // chaining: B-tree node region exhausted (never expected)
     unsigned long long chain_longread;   // chaining: reads long enough for mem_flt_chained_seeds to re-score seeds
-    unsigned long long n_heavy;          // chaining: reads handed to the wave-per-read kernel
+    unsigned long long n_heavy;          // chaining: reads handed to the wave-per-read filter kernel
+    unsigned long long chain_class[4];   // chaining: reads with more seeds than the L, M, S and lane-tier limits
+    unsigned long long chain_ticket[4];  // chaining: work cursors of the wave kernels
     unsigned long long n_retry;          // extension: tasks queued for the next band width
 };
 

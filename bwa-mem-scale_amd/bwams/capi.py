@@ -75,7 +75,7 @@ class MemOpt(C.Structure):
                 ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
                 ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
                 ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
-                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3)]
+                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32)]
 
 
 class FmiDesc(C.Structure):
@@ -95,7 +95,8 @@ class Stats(C.Structure):
                 ("n_chains", C.c_int64), ("n_chain_seeds", C.c_int64), ("n_left", C.c_int64), ("n_right", C.c_int64),
                 ("n_retry_left", C.c_int64), ("n_retry_right", C.c_int64),
                 ("ms_chain", C.c_float), ("ms_ext_plan", C.c_float), ("ms_ext_left", C.c_float),
-                ("ms_ext_right", C.c_float), ("ms_ext_purge", C.c_float), ("ms_ext_total", C.c_float)]
+                ("ms_ext_right", C.c_float), ("ms_ext_purge", C.c_float), ("ms_ext_total", C.c_float),
+                ("n_ext_rounds", C.c_int64)]
 
 
 def default_seed_opt() -> SeedOpt:

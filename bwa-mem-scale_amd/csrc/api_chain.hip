@@ -1,6 +1,7 @@
 // api_chain.hip — C-ABI entry points of the chaining and chain-to-alignment stages
 // (include/bwams.h): launch sequences over chain.hip, ext_aln.hip and bsw_extend.hip on the
 // batch's stream.  No CPU fallback: every entry point runs HIP kernels or returns an error.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -35,13 +36,13 @@ struct ChainState {
     int64_t n_chains = 0, n_seeds = 0, nseq = 0;
     bool chain_done = false;
     // extension
-    DevBuf regs, srt, rmax, cnt, ewide, eoffs;
+    DevBuf regs, srt, rmax, cnt, ewide, eoffs, state, kreg, cur, lim;
     DevBuf lpairs, lref, lqer, rpairs, rref, rqer, retry;
     int64_t n_left = 0, n_right = 0, lref_b = 0, lqer_b = 0, rref_b = 0, rqer_b = 0;
-    int64_t n_retry_left = 0, n_retry_right = 0;
+    int64_t n_retry_left = 0, n_retry_right = 0, n_rounds = 0;
     bool built = false, ext_done = false;
     bwams_mem_opt_t opt{};
-    hipEvent_t ev[10] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 purge
+    hipEvent_t ev[12] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 selection (first round each), 10-11 all rounds
     bool ev_ok = false;
 };
 
@@ -49,7 +50,7 @@ void chain_state_free(ChainState *s) {
     if (!s) return;
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
                      &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
-                     &s->chain_off, &s->chains, &s->seeds, &s->regs, &s->srt, &s->rmax, &s->cnt,
+                     &s->chain_off, &s->chains, &s->seeds, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -351,6 +352,58 @@ static int ext_args(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, E
     A->opt = *opt;
     A->regs = s->regs.as<bwams_alnreg_t>(); A->srt = s->srt.as<uint32_t>(); A->rmax = s->rmax.as<int64_t>();
     A->cnt = s->cnt.as<int32_t>(); A->ctr = b->d_ctr;
+    A->state = s->state.as<int32_t>(); A->kreg = s->kreg.p;
+    A->cur = s->cur.as<int32_t>(); A->lim = s->lim.as<int32_t>();
+    return BWAMS_OK;
+}
+
+// allocate the per-seed arrays and run the plan kernel (windows, seed order, regions, task sizes)
+static int ext_plan(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, int extend_all, ExtArgs *A) {
+    const int64_t N1 = s->n_seeds + 1, n1 = s->nseq + 1;
+    BWAMS_HIP(s->regs.ensure((size_t)N1 * sizeof(bwams_alnreg_t)));
+    BWAMS_HIP(s->srt.ensure((size_t)N1 * 4));
+    BWAMS_HIP(s->rmax.ensure((size_t)(s->n_chains + 1) * 16));
+    BWAMS_HIP(s->cnt.ensure((size_t)N1 * 6 * 4));
+    BWAMS_HIP(s->ewide.ensure((size_t)N1 * 6 * 8));
+    BWAMS_HIP(s->eoffs.ensure((size_t)N1 * 6 * 8));
+    BWAMS_HIP(s->state.ensure((size_t)N1 * 4));
+    BWAMS_HIP(s->kreg.ensure((size_t)N1 * 32));
+    BWAMS_HIP(s->cur.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->lim.ensure((size_t)n1 * 4));
+    int rc = ext_args(b, s, opt, A);
+    if (rc) return rc;
+    BWAMS_HIP(hipMemsetAsync(s->cur.p, 0, (size_t)n1 * 4, b->stream));
+    BWAMS_HIP(hipMemsetAsync(s->lim.p, 0, (size_t)n1 * 4, b->stream));
+    launch_ext_plan(*A, extend_all, b->stream);
+    return BWAMS_OK;
+}
+
+// build the task lists of the seeds requested this round
+static int ext_build_round(bwams_batch *b, ChainState *s, const ExtArgs &A, int64_t tot[6]) {
+    hipStream_t st = b->stream;
+    const int64_t N = s->n_seeds, N1 = N + 1;
+    launch_ext_widen(A, s->ewide.as<int64_t>(), st);
+    int rc = scan_rows(b, s->ewide.as<int64_t>(), s->eoffs.as<int64_t>(), 6, N1);
+    if (rc) return rc;
+    for (int r = 0; r < 6; ++r)
+        BWAMS_HIP(hipMemcpyAsync(&tot[r], s->eoffs.as<int64_t>() + r * N1 + N, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    for (int r : {1, 2, 4, 5})
+        if (tot[r] >= ((int64_t)1 << 31)) {
+            set_last_error("extension task buffers exceed the 31-bit offsets of SeqPair; use smaller chunks");
+            return BWAMS_ERR_CAPACITY;
+        }
+    s->n_left = tot[0]; s->lqer_b = tot[1]; s->lref_b = tot[2];
+    s->n_right = tot[3]; s->rqer_b = tot[4]; s->rref_b = tot[5];
+    BWAMS_HIP(s->lpairs.ensure((size_t)(tot[0] + 1) * sizeof(bwams_seqpair_t)));
+    BWAMS_HIP(s->rpairs.ensure((size_t)(tot[3] + 1) * sizeof(bwams_seqpair_t)));
+    const int64_t mx = tot[0] > tot[3] ? tot[0] : tot[3];
+    BWAMS_HIP(s->retry.ensure((size_t)(mx + 1) * sizeof(bwams_seqpair_t)));
+    BWAMS_HIP(s->lqer.ensure((size_t)tot[1] + 64)); BWAMS_HIP(s->lref.ensure((size_t)tot[2] + 64));
+    BWAMS_HIP(s->rqer.ensure((size_t)tot[4] + 64)); BWAMS_HIP(s->rref.ensure((size_t)tot[5] + 64));
+    if (tot[0] + tot[3] > 0)
+        launch_ext_build(A, s->eoffs.as<int64_t>(), s->lpairs.as<bwams_seqpair_t>(), s->lref.as<uint8_t>(), s->lqer.as<uint8_t>(),
+                         s->rpairs.as<bwams_seqpair_t>(), s->rref.as<uint8_t>(), s->rqer.as<uint8_t>(), b->cu_count, st);
     return BWAMS_OK;
 }
 
@@ -369,37 +422,11 @@ int bwams_extend_build(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_
     ChainState *s = b->chain;
     s->built = s->ext_done = false;
     hipStream_t st = b->stream;
-    const int64_t N = s->n_seeds, N1 = N + 1;
-    BWAMS_HIP(s->regs.ensure((size_t)N1 * sizeof(bwams_alnreg_t)));
-    BWAMS_HIP(s->srt.ensure((size_t)N1 * 4));
-    BWAMS_HIP(s->rmax.ensure((size_t)(s->n_chains + 1) * 16));
-    BWAMS_HIP(s->cnt.ensure((size_t)N1 * 6 * 4));
-    BWAMS_HIP(s->ewide.ensure((size_t)N1 * 6 * 8));
-    BWAMS_HIP(s->eoffs.ensure((size_t)N1 * 6 * 8));
     ExtArgs A;
-    if ((rc = ext_args(b, s, opt, &A))) return rc;
     BWAMS_HIP(hipEventRecord(s->ev[2], st));
-    launch_ext_plan(A, s->ewide.as<int64_t>(), st);
-    if ((rc = scan_rows(b, s->ewide.as<int64_t>(), s->eoffs.as<int64_t>(), 6, N1))) return rc;
+    if ((rc = ext_plan(b, s, opt, 1, &A))) return rc;           // every seed, as the reference builds them
     int64_t tot[6];
-    for (int r = 0; r < 6; ++r)
-        BWAMS_HIP(hipMemcpyAsync(&tot[r], s->eoffs.as<int64_t>() + r * N1 + N, 8, hipMemcpyDeviceToHost, st));
-    BWAMS_HIP(hipStreamSynchronize(st));
-    for (int r : {1, 2, 4, 5})
-        if (tot[r] >= ((int64_t)1 << 31)) {
-            set_last_error("bwams_extend_build: task buffers exceed the 31-bit offsets of SeqPair; use smaller chunks");
-            return BWAMS_ERR_CAPACITY;
-        }
-    s->n_left = tot[0]; s->lqer_b = tot[1]; s->lref_b = tot[2];
-    s->n_right = tot[3]; s->rqer_b = tot[4]; s->rref_b = tot[5];
-    BWAMS_HIP(s->lpairs.ensure((size_t)(tot[0] + 1) * sizeof(bwams_seqpair_t)));
-    BWAMS_HIP(s->rpairs.ensure((size_t)(tot[3] + 1) * sizeof(bwams_seqpair_t)));
-    const int64_t mx = tot[0] > tot[3] ? tot[0] : tot[3];
-    BWAMS_HIP(s->retry.ensure((size_t)(mx + 1) * sizeof(bwams_seqpair_t)));
-    BWAMS_HIP(s->lqer.ensure((size_t)tot[1] + 64)); BWAMS_HIP(s->lref.ensure((size_t)tot[2] + 64));
-    BWAMS_HIP(s->rqer.ensure((size_t)tot[4] + 64)); BWAMS_HIP(s->rref.ensure((size_t)tot[5] + 64));
-    launch_ext_build(A, s->eoffs.as<int64_t>(), s->lpairs.as<bwams_seqpair_t>(), s->lref.as<uint8_t>(), s->lqer.as<uint8_t>(),
-                     s->rpairs.as<bwams_seqpair_t>(), s->rref.as<uint8_t>(), s->rqer.as<uint8_t>(), b->cu_count, st);
+    if ((rc = ext_build_round(b, s, A, tot))) return rc;
     BWAMS_HIP(hipEventRecord(s->ev[3], st));
     BWAMS_HIP(hipGetLastError());
     s->built = true;
@@ -419,7 +446,6 @@ static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, 
     SwParams prm;
     sw_params(A.opt, right ? A.opt.pen_clip3 : A.opt.pen_clip5, &prm);
     const int qmax = b->max_read_len > 1 ? b->max_read_len : 1;
-    *n_retry_out = 0;
     if (n == 0) return BWAMS_OK;
     unsigned long long *d_nretry = &b->d_ctr->n_retry;
     BWAMS_HIP(hipMemsetAsync(d_nretry, 0, sizeof(unsigned long long), st));
@@ -432,37 +458,62 @@ static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, 
         launch_bsw(s->retry.as<bwams_seqpair_t>(), (int64_t)nr, ref, qer, A.opt.w << 1, prm, qmax, b->d_ctr, b->cu_count, st);
         launch_ext_post(A, right, s->retry.as<bwams_seqpair_t>(), (int64_t)nr, A.opt.w << 1, 1, nullptr, d_nretry, st);
     }
-    *n_retry_out = (int64_t)nr;
+    *n_retry_out += (int64_t)nr;
     return BWAMS_OK;
 }
 
+// Rounds of (build the requested tasks, extend left, extend right, select).  Round 0 extends the first
+// seed visited of every chain; a later round extends the seeds the selection found it must keep but
+// that had not been extended yet.  After kMaxRounds everything still undecided is extended at once.
 int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_regs) {
     if (!b || !b->chain || !b->chain->chain_done) {
         set_last_error("bwams_extend_run: run bwams_chain_run (or bwams_chain_upload) first");
         return BWAMS_ERR_ARG;
     }
+    if (!b->idx->d_ref) {
+        set_last_error("bwams_extend_run: the index was opened without its .0123 reference");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_extend_run");
+    if (rc) return rc;
+    int kMaxRounds = 6;
+    if (const char *e = getenv("BWAMS_EXT_MAX_ROUNDS")) kMaxRounds = atoi(e) > 0 ? atoi(e) : 1;    // test knob: force the extend-the-rest fallback
     ChainState *s = b->chain;
-    int rc;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
-    if (!s->built || memcmp(&s->opt, opt, sizeof *opt) != 0) {
-        if ((rc = bwams_extend_build(b, opt, nullptr, nullptr))) return rc;
-    }
+    s->built = s->ext_done = false;
     ExtArgs A;
-    if ((rc = ext_args(b, s, opt, &A))) return rc;
-    BWAMS_HIP(hipEventRecord(s->ev[4], st));
-    if ((rc = run_side(b, s, A, 0, &s->n_retry_left))) return rc;
-    BWAMS_HIP(hipEventRecord(s->ev[5], st));
-    BWAMS_HIP(hipEventRecord(s->ev[6], st));
-    launch_ext_right_h0(A, s->rpairs.as<bwams_seqpair_t>(), s->n_right, st);
-    if ((rc = run_side(b, s, A, 1, &s->n_retry_right))) return rc;
-    BWAMS_HIP(hipEventRecord(s->ev[7], st));
-    BWAMS_HIP(hipEventRecord(s->ev[8], st));
-    if (s->n_seeds) launch_ext_purge(A, b->cu_count, st);
-    BWAMS_HIP(hipEventRecord(s->ev[9], st));
+    BWAMS_HIP(hipEventRecord(s->ev[10], st));
+    BWAMS_HIP(hipEventRecord(s->ev[2], st));
+    if ((rc = ext_plan(b, s, opt, opt->extend_all != 0, &A))) return rc;
+    int64_t tot_left = 0, tot_right = 0;
+    s->n_retry_left = s->n_retry_right = 0;
+    int round = 0;
+    for (;; ++round) {
+        int64_t tot[6];
+        if ((rc = ext_build_round(b, s, A, tot))) return rc;
+        if (round == 0) { BWAMS_HIP(hipEventRecord(s->ev[3], st)); BWAMS_HIP(hipEventRecord(s->ev[4], st)); }
+        tot_left += tot[0]; tot_right += tot[3];
+        if ((rc = run_side(b, s, A, 0, &s->n_retry_left))) return rc;
+        if (round == 0) { BWAMS_HIP(hipEventRecord(s->ev[5], st)); BWAMS_HIP(hipEventRecord(s->ev[6], st)); }
+        launch_ext_right_h0(A, s->rpairs.as<bwams_seqpair_t>(), s->n_right, st);
+        if ((rc = run_side(b, s, A, 1, &s->n_retry_right))) return rc;
+        if (round == 0) { BWAMS_HIP(hipEventRecord(s->ev[7], st)); BWAMS_HIP(hipEventRecord(s->ev[8], st)); }
+        BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_req, 0, sizeof(unsigned long long), st));
+        if (s->n_seeds) launch_ext_select(A, b->cu_count, st);
+        if (round == 0) BWAMS_HIP(hipEventRecord(s->ev[9], st));
+        unsigned long long n_req = 0;
+        BWAMS_HIP(hipMemcpyAsync(&n_req, &b->d_ctr->n_req, sizeof n_req, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        if (n_req == 0) break;
+        if (round + 1 >= kMaxRounds) launch_ext_request_rest(A, st);
+    }
+    BWAMS_HIP(hipEventRecord(s->ev[11], st));
     BWAMS_HIP(hipGetLastError());
+    s->n_rounds = round + 1;
+    s->n_left = tot_left; s->n_right = tot_right;
     s->ext_done = true;
-    s->built = false;             // the task records now hold results; a second run rebuilds them
+    s->opt = *opt;
     if (n_regs) *n_regs = s->n_seeds;
     return BWAMS_OK;
 }
@@ -526,7 +577,8 @@ void chain_state_stats(const ChainState *s, bwams_stats_t *out) {
         el(4, 5, &out->ms_ext_left);
         el(6, 7, &out->ms_ext_right);
         el(8, 9, &out->ms_ext_purge);
-        el(4, 9, &out->ms_ext_total);
+        el(10, 11, &out->ms_ext_total);
+        out->n_ext_rounds = s->n_rounds;
     }
     (void)hipGetLastError();
 }

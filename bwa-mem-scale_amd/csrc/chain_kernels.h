@@ -68,15 +68,20 @@ struct ExtArgs {
     uint32_t *srt;                 // per region slot: the seed's index within its chain, visit order reversed (srtg)
     int64_t *rmax;                 // 2 per chain
     int32_t *cnt;                  // 6 x n_seeds: has_left, lq, lr, has_right, rq, rr
+    int32_t *state;                // per seed: kept / purged / requested / extended (extension rounds)
+    void *kreg;                    // per read (at its first region's slot): the regions kept so far, 32 B each
+    int32_t *cur, *lim;            // per read: seeds decided so far, regions kept so far
     DevCounters *ctr;
 };
-void launch_ext_plan(const ExtArgs &A, int64_t *wide, hipStream_t st);
+void launch_ext_plan(const ExtArgs &A, int extend_all, hipStream_t st);
+void launch_ext_widen(const ExtArgs &A, int64_t *wide, hipStream_t st);
 void launch_ext_build(const ExtArgs &A, const int64_t *offs, bwams_seqpair_t *left, uint8_t *lref, uint8_t *lqer,
                       bwams_seqpair_t *right, uint8_t *rref, uint8_t *rqer, int cu_count, hipStream_t st);
 // after one extension attempt at band width w: settle finished tasks, queue the others for the next width
 void launch_ext_post(const ExtArgs &A, int right, const bwams_seqpair_t *pairs, int64_t n, int w, int last_try,
                      bwams_seqpair_t *retry, unsigned long long *n_retry, hipStream_t st);
 void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hipStream_t st);
-void launch_ext_purge(const ExtArgs &A, int cu_count, hipStream_t st);
+void launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st);
+void launch_ext_request_rest(const ExtArgs &A, hipStream_t st);
 
 }  // namespace bwams

@@ -69,6 +69,7 @@ struct DevCounters {
     unsigned long long chain_class[4];   // chaining: reads with more seeds than the L, M, S and lane-tier limits
     unsigned long long chain_ticket[4];  // chaining: work cursors of the wave kernels
     unsigned long long n_retry;          // extension: tasks queued for the next band width
+    unsigned long long n_req;            // extension: seeds requested by the last selection
 };
 
 struct ChainState;                       // chain / extension buffers of a batch (api_chain.hip)

@@ -16,6 +16,8 @@ namespace bwams {
 namespace {
 
 constexpr int H0_ = -99;         // macro.h:56
+// per-seed state of the extension rounds
+constexpr int kExtKept = 1, kExtPurged = 2, kExtReq = 4, kExtDone = 8;
 
 __device__ __forceinline__ int cal_max_gap(const bwams_mem_opt_t &o, int qlen) {
     const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
@@ -49,7 +51,7 @@ __device__ __forceinline__ int seedcov(const bwams_alnreg_t &a, const bwams_chai
 }
 
 // lane per chain: window, seed order, regions, task sizes
-__global__ void ext_plan_kernel(ExtArgs A) {
+__global__ void ext_plan_kernel(ExtArgs A, int extend_all) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= A.n_chains) return;
     const bwams_chain_t c = A.chains[j];
@@ -128,14 +130,21 @@ __global__ void ext_plan_kernel(ExtArgs A) {
         A.regs[p] = a;
         A.cnt[0 * N + p] = nl; A.cnt[1 * N + p] = lq; A.cnt[2 * N + p] = lr;
         A.cnt[3 * N + p] = nr; A.cnt[4 * N + p] = rq; A.cnt[5 * N + p] = rr;
+        // the first round extends the first seed visited of every chain (every seed when extend_all):
+        // those are the seeds most likely to survive the containment test
+        int st = 0;
+        if (!nl && !nr) st = kExtDone;                       // nothing to extend
+        else if (extend_all || k == c.n - 1) st = kExtReq;
+        A.state[p] = st;
     }
 }
 
-__global__ void ext_widen_kernel(const int32_t *cnt, int64_t n, int64_t *wide) {
+// task sizes of the seeds requested this round, widened for the scans
+__global__ void ext_widen_kernel(const int32_t *cnt, const int32_t *state, int64_t n, int64_t *wide) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= 6 * (n + 1)) return;
     const int64_t row = g / (n + 1), i = g - row * (n + 1);
-    wide[g] = i < n ? (int64_t)cnt[row * n + i] : 0;
+    wide[g] = (i < n && (state[i] & kExtReq)) ? (int64_t)cnt[row * n + i] : 0;
 }
 
 // wave per region: SeqPair records and sequence copies
@@ -146,8 +155,10 @@ __global__ __launch_bounds__(256) void ext_build_kernel(ExtArgs A, const int64_t
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t N = A.n_seeds, n1 = N + 1;
     for (int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < N; p += stride) {
+        const int st = A.state[p];
+        if (!(st & kExtReq)) continue;
         const int nl = A.cnt[0 * N + p], nr = A.cnt[3 * N + p];
-        if (!nl && !nr) continue;
+        if (lane == 0) A.state[p] = (st & ~kExtReq) | kExtDone;      // extended by the time the next selection runs
         const int64_t j = A.regs[p].chain;
         const bwams_chain_t c = A.chains[j];
         const int k = c.n - 1 - (int)(p - c.seed_off);
@@ -271,100 +282,136 @@ __device__ __forceinline__ bool purge_keep_anyway(const bwams_chain_seed_t &s, c
     return v != n;
 }
 
-__global__ __launch_bounds__(64) void ext_purge_kernel(ExtArgs A) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= A.nseq) return;
-    const int64_t reg0 = A.seed_off[r];
-    const int64_t av_n = A.seed_off[r + 1] - reg0;
-    if (av_n > kLightRegs || av_n == 0) return;
-    const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
-    bwams_alnreg_t *av = A.regs + reg0;
-    int lim = 0;
-    for (int64_t j = A.chain_off[r]; j < A.chain_off[r + 1]; ++j) {
-        const bwams_chain_t c = A.chains[j];
-        const bwams_chain_seed_t *cs = A.seeds + c.seed_off;
-        uint32_t *srt2 = A.srt + c.seed_off;
-        for (int k = c.n - 1; k >= 0; --k) {
-            const bwams_chain_seed_t s = cs[srt2[k]];
-            int64_t i;
-            int v = 0;
-            for (i = 0; i < av_n && v < lim; ++i) {
-                const bwams_alnreg_t *p = &av[i];
-                const int cls = purge_class(A.opt, s, l_query, p->rb, p->re, p->qb, p->qe, p->seedlen0, p->w);
-                if (cls == 2) break;
-                v += cls;
-            }
-            if (v < lim && !purge_keep_anyway(s, cs, srt2, k, c.n)) {
-                av[s.aln].qb = -1; av[s.aln].qe = -1;
-                srt2[k] = 0xffffffffu;
-                continue;
-            }
-            lim++;
-        }
-    }
+// Selection (one round): walk the read's seeds in visiting order from where the last round stopped.
+// A seed explained by a region kept so far — and not rescued by the overlap test — is purged without
+// ever being extended; the reference extends it first and throws the result away (the purged region
+// is dropped by mem_kernel2_core, bwamem.cpp:1446-1456), and its test reads nothing but regions kept
+// EARLIER (its scan stops after `lim` unpurged regions, which are exactly those).  A seed that must
+// be kept needs its own extension: if that is not done yet it is requested and the read waits for
+// the next round.
+struct KReg { int64_t rb, re; int32_t qb, qe, seedlen0, w; };      // what the test reads of a kept region
+
+__device__ __forceinline__ void select_seed_of_slot(const ExtArgs &A, int64_t p, bwams_chain_t &c, int &k, bwams_chain_seed_t &s) {
+    c = A.chains[A.regs[p].chain];
+    k = c.n - 1 - (int)(p - c.seed_off);
+    const uint32_t sk = __hip_atomic_load(&A.srt[c.seed_off + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = A.seeds[c.seed_off + sk];
 }
 
-__global__ __launch_bounds__(256) void ext_purge_wave_kernel(ExtArgs A) {
+__global__ __launch_bounds__(64) void ext_select_kernel(ExtArgs A) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool req = false;
+    if (r < A.nseq) {
+        const int64_t reg0 = A.seed_off[r];
+        const int av_n = (int)(A.seed_off[r + 1] - reg0);
+        int t = A.cur[r];
+        if (av_n <= kLightRegs && t < av_n) {
+            const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
+            KReg *kreg = reinterpret_cast<KReg *>(A.kreg) + reg0;
+            int lim = A.lim[r];
+            for (; t < av_n; ++t) {
+                const int64_t p = reg0 + t;
+                bwams_chain_t c;
+                bwams_chain_seed_t s;
+                int k;
+                select_seed_of_slot(A, p, c, k, s);
+                bool brk = false;
+                for (int i = 0; i < lim && !brk; ++i) {
+                    const KReg q = kreg[i];
+                    brk = purge_class(A.opt, s, l_query, q.rb, q.re, q.qb, q.qe, q.seedlen0, q.w) == 2;
+                }
+                const int st = A.state[p];
+                if (brk && !purge_keep_anyway(s, A.seeds + c.seed_off, A.srt + c.seed_off, k, c.n)) {
+                    A.regs[p].qb = -1; A.regs[p].qe = -1;
+                    A.srt[c.seed_off + k] = 0xffffffffu;
+                    A.state[p] = st | kExtPurged;
+                    continue;
+                }
+                if (!(st & kExtDone)) { A.state[p] = st | kExtReq; req = true; break; }
+                const bwams_alnreg_t *a = &A.regs[p];
+                KReg q;
+                q.rb = a->rb; q.re = a->re; q.qb = a->qb; q.qe = a->qe; q.seedlen0 = a->seedlen0; q.w = a->w;
+                kreg[lim++] = q;
+                A.state[p] = st | kExtKept;
+            }
+            A.cur[r] = t;
+            A.lim[r] = lim;
+        }
+    }
+    const unsigned long long m = __ballot(req);
+    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&A.ctr->n_req, (unsigned long long)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void ext_select_wave_kernel(ExtArgs A) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < A.nseq; r += stride) {
         const int64_t reg0 = A.seed_off[r];
-        const int64_t av_n = A.seed_off[r + 1] - reg0;
-        if (av_n <= kLightRegs) continue;
+        const int av_n = (int)(A.seed_off[r + 1] - reg0);
+        int t = A.cur[r];
+        if (av_n <= kLightRegs || t >= av_n) continue;
         const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
-        bwams_alnreg_t *av = A.regs + reg0;
-        int lim = 0;
-        for (int64_t j = A.chain_off[r]; j < A.chain_off[r + 1]; ++j) {
-            const bwams_chain_t c = A.chains[j];
-            const bwams_chain_seed_t *cs = A.seeds + c.seed_off;
-            uint32_t *srt2 = A.srt + c.seed_off;
-            for (int k = c.n - 1; k >= 0; --k) {
-                const uint32_t sk = __hip_atomic_load(&srt2[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bwams_chain_seed_t s = cs[sk];
-                int v = 0;
-                bool brk = false;
-                for (int64_t base = 0; base < av_n && v < lim; base += 64) {
-                    const int64_t i = base + lane;
-                    int cls = 0;
-                    if (i < av_n) {
-                        bwams_alnreg_t *p = &av[i];
-                        // qb/qe are rewritten by this wave while it runs: read them past the vector L1
-                        const unsigned long long qq = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&p->qb),
-                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        cls = purge_class(A.opt, s, l_query, p->rb, p->re, (int)(uint32_t)qq, (int)(uint32_t)(qq >> 32),
-                                          p->seedlen0, p->w);
-                    }
-                    const unsigned long long m_v = __ballot(cls == 1), m_b = __ballot(cls == 2);
-                    if (m_b) {
-                        const int pb = __ffsll((long long)m_b) - 1;
-                        const int v_at = v + __popcll(m_v & ((1ull << pb) - 1ull));
-                        if (v_at < lim) { v = v_at; brk = true; break; }
-                    }
-                    v += __popcll(m_v);
-                    if (v > lim) v = lim;                 // the sequential loop stops counting at lim
+        KReg *kreg = reinterpret_cast<KReg *>(A.kreg) + reg0;
+        int lim = A.lim[r];
+        for (; t < av_n; ++t) {
+            const int64_t p = reg0 + t;
+            bwams_chain_t c;
+            bwams_chain_seed_t s;
+            int k;
+            select_seed_of_slot(A, p, c, k, s);
+            bool brk = false;
+            for (int base = 0; base < lim && !brk; base += 64) {          // the kept regions, 64 at a time
+                const int i = base + lane;
+                int cls = 0;
+                if (i < lim) {
+                    const KReg q = kreg[i];
+                    cls = purge_class(A.opt, s, l_query, q.rb, q.re, q.qb, q.qe, q.seedlen0, q.w);
                 }
-                (void)brk;
-                if (v < lim && !purge_keep_anyway(s, cs, srt2, k, c.n)) {
-                    if (lane == 0) {
-                        const unsigned long long gone = 0xffffffffffffffffull;     // qb = qe = -1
-                        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&av[s.aln].qb), gone, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&srt2[k], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    continue;
-                }
-                lim++;
+                brk = __ballot(cls == 2) != 0;
             }
+            const int st = A.state[p];
+            if (brk && !purge_keep_anyway(s, A.seeds + c.seed_off, A.srt + c.seed_off, k, c.n)) {
+                if (lane == 0) {
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&A.regs[p].qb), 0xffffffffffffffffull,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // qb = qe = -1
+                    __hip_atomic_store(&A.srt[c.seed_off + k], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    A.state[p] = st | kExtPurged;
+                }
+                continue;
+            }
+            if (!(st & kExtDone)) {
+                if (lane == 0) { A.state[p] = st | kExtReq; atomicAdd(&A.ctr->n_req, 1ull); }
+                break;
+            }
+            if (lane == 0) {
+                const bwams_alnreg_t *a = &A.regs[p];
+                KReg q;
+                q.rb = a->rb; q.re = a->re; q.qb = a->qb; q.qe = a->qe; q.seedlen0 = a->seedlen0; q.w = a->w;
+                kreg[lim] = q;
+                A.state[p] = st | kExtKept;
+            }
+            ++lim;
         }
+        if (lane == 0) { A.cur[r] = t; A.lim[r] = lim; }
     }
+}
+
+// after too many rounds: request every seed that is still undecided and unextended
+__global__ void ext_request_rest_kernel(ExtArgs A) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n_seeds) return;
+    const int st = A.state[p];
+    if (!(st & (kExtKept | kExtPurged | kExtDone | kExtReq))) A.state[p] = st | kExtReq;
 }
 
 }  // namespace
 
-void launch_ext_plan(const ExtArgs &A, int64_t *wide, hipStream_t st) {
-    if (A.n_chains > 0) ext_plan_kernel<<<(unsigned)((A.n_chains + 63) / 64), 64, 0, st>>>(A);
+void launch_ext_plan(const ExtArgs &A, int extend_all, hipStream_t st) {
+    if (A.n_chains > 0) ext_plan_kernel<<<(unsigned)((A.n_chains + 63) / 64), 64, 0, st>>>(A, extend_all);
+}
+void launch_ext_widen(const ExtArgs &A, int64_t *wide, hipStream_t st) {
     const int64_t g = 6 * (A.n_seeds + 1);
-    ext_widen_kernel<<<(unsigned)((g + 255) / 256), 256, 0, st>>>(A.cnt, A.n_seeds, wide);
+    ext_widen_kernel<<<(unsigned)((g + 255) / 256), 256, 0, st>>>(A.cnt, A.state, A.n_seeds, wide);
 }
 
 void launch_ext_build(const ExtArgs &A, const int64_t *offs, bwams_seqpair_t *left, uint8_t *lref, uint8_t *lqer,
@@ -386,12 +433,16 @@ void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hi
     ext_right_h0_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(A, right, n);
 }
 
-void launch_ext_purge(const ExtArgs &A, int cu_count, hipStream_t st) {
+void launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st) {
     if (A.nseq <= 0) return;
-    ext_purge_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
+    ext_select_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
     int64_t blocks = (A.nseq + 3) / 4;
     if (blocks > (int64_t)cu_count * 8) blocks = (int64_t)cu_count * 8;
-    ext_purge_wave_kernel<<<(unsigned)blocks, 256, 0, st>>>(A);
+    ext_select_wave_kernel<<<(unsigned)blocks, 256, 0, st>>>(A);
+}
+void launch_ext_request_rest(const ExtArgs &A, hipStream_t st) {
+    if (A.n_seeds <= 0) return;
+    ext_request_rest_kernel<<<(unsigned)((A.n_seeds + 255) / 256), 256, 0, st>>>(A);
 }
 
 }  // namespace bwams

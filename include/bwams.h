@@ -225,7 +225,8 @@ typedef struct bwams_stats {
     int64_t n_chains, n_chain_seeds;
     int64_t n_left, n_right;              /* extension tasks built */
     int64_t n_retry_left, n_retry_right;  /* tasks re-run at twice the band width */
-    float   ms_chain, ms_ext_plan, ms_ext_left, ms_ext_right, ms_ext_purge, ms_ext_total;
+    float   ms_chain, ms_ext_plan, ms_ext_left, ms_ext_right, ms_ext_purge, ms_ext_total;   /* left/right/purge: first round */
+    int64_t n_ext_rounds;                 /* extension rounds of the last bwams_extend_run */
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 

@@ -115,6 +115,12 @@ typedef struct bwams_mem_opt {
     float   drop_ratio;                 /* 0.50 */
     int8_t  mat[25];
     int8_t  pad_[3];
+    /* Not a mem_opt_t field.  0 (default): a seed that an earlier kept region already explains is
+     * purged WITHOUT being extended — the reference extends it first and discards the result
+     * (mem_kernel2_core drops purged regions, src/bwamem.cpp:1446-1456), so every kept region and
+     * every purge decision is unchanged; only the contents of purged regions differ.
+     * 1: extend every seed, purged regions hold the reference's dead values too. */
+    int32_t extend_all;
 } bwams_mem_opt_t;
 
 /* mem_seed_t (src/bwamem.h:129-140), 32 B, same field offsets. */

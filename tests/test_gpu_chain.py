@@ -78,6 +78,17 @@ def _run(idx, ix, g, reads, contigs=None, seed_kw=None, **mem_kw):
     return b, want, got, ctx
 
 
+def _assert_regs(regs, wregs, exact_dead: bool):
+    """Kept regions and the purge decisions are always identical; the contents of purged regions (which
+    the reference computes and then drops, bwamem.cpp:1446-1456) only with extend_all = 1."""
+    assert len(regs) == len(wregs)
+    purged = (wregs["qb"] == -1) & (wregs["qe"] == -1)
+    assert np.array_equal((regs["qb"] == -1) & (regs["qe"] == -1), purged)
+    keep = slice(None) if exact_dead else ~purged
+    for f in REG_FIELDS:
+        assert np.array_equal(regs[f][keep], wregs[f][keep]), f
+
+
 def _assert_chains(want, got):
     assert np.array_equal(got["chain_off"], want["chain_off"])
     assert len(got["chains"]) == len(want["chains"]) and len(got["seeds"]) == len(want["seeds"])
@@ -149,8 +160,7 @@ def test_chain_contigs_and_alt(rep_toy):
     wregs, wreg_off, wseeds = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
                                                ctx["ref"], l_pac, contigs=contigs, opt=ctx["oopt"])
     assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
-    for f in REG_FIELDS:
-        assert np.array_equal(regs[f], wregs[f]), f
+    _assert_regs(regs, wregs, False)
     b.close()
     c = np.zeros(1, capi.CONTIG_DTYPE)
     c["len"] = l_pac
@@ -187,8 +197,8 @@ def test_extension_tasks_match_oracle(rep_toy):
     b.close()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(w=12, zdrop=30), dict(pen_clip5=0, pen_clip3=11), dict(e_del=2, e_ins=3, o_del=4),
-                                dict(a=2)])
+@pytest.mark.parametrize("kw", [dict(), dict(extend_all=1), dict(w=12, zdrop=30), dict(w=12, zdrop=30, extend_all=1),
+                                dict(pen_clip5=0, pen_clip3=11), dict(e_del=2, e_ins=3, o_del=4), dict(a=2), dict(a=2, extend_all=1)])
 def test_regions_match_oracle(rep_toy, kw):
     g, idx, ix = rep_toy
     extra = []
@@ -205,18 +215,39 @@ def test_regions_match_oracle(rep_toy, kw):
     b, want, got, ctx = _run(idx, ix, g, _reads(g, 1500, 29, extra), **kw)
     n = b.extend_run(ctx["gopt"])
     regs, reg_off, aln = b.extend_fetch()
-    wregs, wreg_off, wseeds = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
-                                               ctx["ref"], ctx["l_pac"], opt=ctx["oopt"])
+    wregs, wreg_off, wseeds, tasks_all = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
+                                                          ctx["ref"], ctx["l_pac"], opt=ctx["oopt"], want_tasks=True)
     assert n == len(wregs) and np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
-    for f in REG_FIELDS:
-        assert np.array_equal(regs[f], wregs[f]), f
+    _assert_regs(regs, wregs, bool(kw.get("extend_all")))
     st = b.stats()
     assert st.n_chains == len(want["chains"]) and st.n_left + st.n_right > 0
+    if kw.get("extend_all"):
+        assert st.n_ext_rounds == 1 and st.n_left + st.n_right == len(tasks_all["left"]) + len(tasks_all["right"])
+    else:                                            # dead extensions are skipped, in a handful of rounds
+        assert 1 < st.n_ext_rounds <= 8 and st.n_left + st.n_right < len(tasks_all["left"]) + len(tasks_all["right"])
     if kw.get("w") == 12:
         assert st.n_retry_left + st.n_retry_right > 0 and (wregs["w"] == 24).sum() > 0     # the band-retry path ran
     if not kw:
         purged = (regs["qb"] == -1) & (regs["qe"] == -1)
         assert purged.sum() > 0 and (~purged).sum() > 0
+    b.close()
+
+
+def test_round_cap_extends_the_rest(rep_toy, monkeypatch):
+    """After the round cap everything still undecided is extended at once; regions are the same."""
+    g, idx, ix = rep_toy
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 1500, 77), max_occ=60)
+    wregs, wreg_off, wseeds = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
+                                               ctx["ref"], ctx["l_pac"], opt=ctx["oopt"])
+    rounds = []
+    for cap in ("6", "1"):
+        monkeypatch.setenv("BWAMS_EXT_MAX_ROUNDS", cap)
+        b.extend_run(ctx["gopt"])
+        regs, reg_off, aln = b.extend_fetch()
+        assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
+        _assert_regs(regs, wregs, False)
+        rounds.append(b.stats().n_ext_rounds)
+    assert rounds[0] > 2 and rounds[1] == 2          # natural convergence vs. round 0 + "the rest"
     b.close()
 
 
@@ -234,8 +265,7 @@ def test_chain_upload_then_extend(rep_toy):
     b2.extend_run(ctx["gopt"])
     regs2, off2, aln2 = b2.extend_fetch()
     assert np.array_equal(off1, off2) and np.array_equal(aln1, aln2)
-    for f in REG_FIELDS:
-        assert np.array_equal(regs1[f], regs2[f]), f
+    _assert_regs(regs2, regs1, False)
     bad = want["chains"].copy()
     if len(bad):
         bad["seed_off"][0] += 1

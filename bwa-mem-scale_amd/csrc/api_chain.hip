@@ -44,6 +44,8 @@ struct ChainState {
     bwams_mem_opt_t opt{};
     hipEvent_t ev[12] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 selection (first round each), 10-11 all rounds
     bool ev_ok = false;
+    hipStream_t aux[5] = {};      // the chaining tiers run concurrently
+    hipEvent_t fork = nullptr, join[5] = {};
 };
 
 void chain_state_free(ChainState *s) {
@@ -54,8 +56,12 @@ void chain_state_free(ChainState *s) {
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
-    if (s->ev_ok)
+    if (s->ev_ok) {
         for (auto &e : s->ev) (void)hipEventDestroy(e);
+        for (auto &e : s->join) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(s->fork);
+        for (auto &q : s->aux) (void)hipStreamDestroy(q);
+    }
     delete s;
 }
 
@@ -91,6 +97,9 @@ int get_state(bwams_batch *b, ChainState **out) {
     if (!b->chain) {
         b->chain = new ChainState();
         for (auto &e : b->chain->ev) BWAMS_HIP(hipEventCreate(&e));
+        for (auto &e : b->chain->join) BWAMS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        BWAMS_HIP(hipEventCreateWithFlags(&b->chain->fork, hipEventDisableTiming));
+        for (auto &q : b->chain->aux) BWAMS_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
         b->chain->ev_ok = true;
     }
     *out = b->chain;
@@ -214,7 +223,7 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     A.ctr = b->d_ctr;
 
     BWAMS_HIP(hipEventRecord(s->ev[0], st));
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 11 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[4], chain_ticket[4]
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 13 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[5], chain_ticket[5]
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all
     if (b->n_smem <= 1 || n_sa == 0) {
@@ -236,7 +245,10 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
         tb = b->tmp_bytes;
         BWAMS_HIP(rocprim::radix_sort_pairs_desc(b->d_tmp, tb, s->okeys.as<uint32_t>(), s->okeys2.as<uint32_t>(),
                                                  s->ovals.as<uint32_t>(), s->ovals2.as<uint32_t>(), (size_t)nseq, 0, 32, st));
-        launch_chain(A, s->okeys.as<uint32_t>(), b->cu_count, st);
+        if (launch_chain(A, s->okeys.as<uint32_t>(), b->cu_count, st, s->aux, s->fork, s->join)) {
+            set_last_error("bwams_chain_run: stream fork/join failed");
+            return BWAMS_ERR_DEVICE;
+        }
     }
     int64_t tot[2] = {0, 0};
     if (nseq > 0) {

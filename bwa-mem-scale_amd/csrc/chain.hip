@@ -37,7 +37,7 @@ constexpr int KB_T = 5;
 constexpr int KB_MAXK = 2 * KB_T - 1;
 constexpr int kLaneSeeds = 32;       // reads with more seeds than this are chained by a whole wave (chain_wave_kernel)
 constexpr int kLightChains = 16;     // reads with more chains than this go to chain_heavy_kernel
-constexpr int kLdsChains = 1024;     // chains the heavy kernel keeps in LDS (40 B each)
+constexpr int kLdsChains = 960;      // chains the heavy kernel keeps in LDS (41 B each: four blocks per CU)
 struct alignas(16) Node {            // 144 B = nine 16-byte loads
     int16_t n, internal;
     int16_t ptr[KB_MAXK + 1];        // node ids relative to the read's node region
@@ -60,7 +60,7 @@ static_assert(sizeof(ChainRec) == 48, "chain record layout");
 // (every node but the root holds >= t - 1 = 4 keys: at most 5K/16 + 3 nodes)
 __host__ __device__ constexpr int lds_nodes(int K) { return (K * 5) / 16 + 3; }
 __host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * sizeof(ChainRec) + (size_t)lds_nodes(K) * sizeof(Node); }
-constexpr int kClassS = 128, kClassM = 512, kClassL = 1700;      // seeds per read: 12 KB, 48 KB, 159 KB of LDS
+constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL = 1700;      // seeds per read: 12, 24, 48, 159 KB of LDS
 static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
 
 // bns_pos2rid / bns_intv2rid (bntseq.cpp:397-421) with a one-entry cache of the last sequence found
@@ -233,6 +233,67 @@ __device__ __forceinline__ void kbt_put(ReadCtx &c, int32_t id, int64_t k) {
     }
 }
 
+// ---- the same B-tree operations, run by a whole wave on one tree (nodes in LDS) -----------------
+// Lane t < 9 owns key slot t of the node being visited: the binary search of __kb_getp_aux becomes
+// two ballots, the shift of a leaf insertion one read and one write per lane.  Every lane returns
+// the same values.
+__device__ __forceinline__ int wnode_search(const Node *p, int n, int64_t k, int lane, bool &eq) {
+    const int64_t my = lane < KB_MAXK ? p->pos[lane] : 0;
+    const unsigned long long m_lt = __ballot(lane < n && my < k);
+    const unsigned long long m_eq = __ballot(lane < n && my == k);
+    eq = m_eq != 0;
+    const int cnt = __popcll(m_lt);
+    return eq ? cnt : cnt - 1;
+}
+__device__ __forceinline__ int32_t wkbt_lower(const ReadCtx &c, int64_t k, int lane, int64_t &lower_pos) {
+    int32_t lower = -1, xi = c.root;
+    for (;;) {
+        const Node *p = &c.nodes[xi];
+        const int n = p->n, internal = p->internal;
+        bool eq;
+        const int i = wnode_search(p, n, k, lane, eq);
+        if (i >= 0) { lower = p->key[i]; lower_pos = p->pos[i]; }
+        if ((i >= 0 && eq) || !internal) return lower;
+        xi = p->ptr[i + 1];
+    }
+}
+__device__ __forceinline__ void wkbt_put(ReadCtx &c, int32_t id, int64_t k, int lane) {
+    ++c.n_keys;
+    int32_t xi = c.root;
+    if (c.nodes[xi].n == KB_MAXK) {
+        const int32_t s = new_node(c);
+        if (c.overflow) return;
+        if (c.wr) { c.nodes[s].internal = 1; c.nodes[s].n = 0; c.nodes[s].ptr[0] = (int16_t)xi; }
+        c.root = s;
+        kbt_split(c, s, 0, xi);
+        if (c.overflow) return;
+        xi = s;
+    }
+    for (;;) {
+        Node *p = &c.nodes[xi];
+        const int n = p->n, internal = p->internal;
+        bool eq;
+        const int i = wnode_search(p, n, k, lane, eq);
+        if (!internal) {                                   // insert after slot i: slots i+1 .. n-1 move up by one
+            const bool mv = lane > i && lane < n;
+            const int64_t mp = mv ? p->pos[lane] : 0;
+            const int32_t mk = mv ? p->key[lane] : 0;
+            if (mv) { p->pos[lane + 1] = mp; p->key[lane + 1] = mk; }
+            if (c.wr) { p->pos[i + 1] = k; p->key[i + 1] = id; p->n = (int16_t)(n + 1); }
+            return;
+        }
+        int ii = i + 1;
+        int32_t ci = p->ptr[ii];
+        if (c.nodes[ci].n == KB_MAXK) {
+            const int64_t median = c.nodes[ci].pos[KB_T - 1];
+            kbt_split(c, xi, ii, ci);
+            if (c.overflow) return;
+            if (k > median) ci = c.nodes[xi].ptr[ii + 1];
+        }
+        xi = ci;
+    }
+}
+
 // in-order traversal (__kb_traverse, kbtree.h:345-368) with an explicit stack; si = children already
 // descended (height <= 16 covers 5^16 keys)
 __device__ __forceinline__ int32_t kbt_traverse(const ReadCtx &c, int32_t *out) {
@@ -262,11 +323,11 @@ __device__ __forceinline__ int32_t kbt_traverse(const ReadCtx &c, int32_t *out) 
 __device__ __forceinline__ bool flt_lt(uint2 a, uint2 b) { return a.x > b.x; }
 __device__ __forceinline__ void swp(uint2 *a, int i, int j) { const uint2 t = a[i]; a[i] = a[j]; a[j] = t; }
 
-__device__ void flt_insertsort(uint2 *a, int s, int t) {
+__device__ __forceinline__ void flt_insertsort(uint2 *a, int s, int t) {
     for (int i = s + 1; i < t; ++i)
         for (int j = i; j > s && flt_lt(a[j], a[j - 1]); --j) swp(a, j, j - 1);
 }
-__device__ void flt_combsort(uint2 *a, int n) {
+__device__ __forceinline__ void flt_combsort(uint2 *a, int n) {
     const double shrink = 1.2473309501039786540366528676643;
     bool do_swap;
     unsigned long long gap = (unsigned long long)n;
@@ -283,7 +344,7 @@ __device__ void flt_combsort(uint2 *a, int n) {
     } while (do_swap || gap > 2);
     if (gap != 1) flt_insertsort(a, 0, n);
 }
-__device__ void flt_introsort(uint2 *a, int n) {
+__device__ __forceinline__ void flt_introsort(uint2 *a, int n) {
     if (n < 1) return;
     if (n == 2) { if (flt_lt(a[1], a[0])) swp(a, 0, 1); return; }
     int d;
@@ -415,10 +476,12 @@ __global__ void chain_count_kernel(ChainArgs A, uint32_t *keys, uint32_t *vals) 
     const int64_t cnt = beg < end ? A.sa_off[end] - A.sa_off[beg] : 0;
     keys[r] = (uint32_t)(cnt < 0xffffffffll ? cnt : 0xffffffffll);
     vals[r] = (uint32_t)r;
-    // class boundaries in the descending order: [0, c[0]) > L, [c[0], c[1]) > M, [c[1], c[2]) > S, [c[2], c[3]) > lane tier
+    // class boundaries in the descending order: [0, c[0]) > L, [c[0], c[1]) > M, [c[1], c[2]) > M1, [c[2], c[3]) > S,
+    // [c[3], c[4]) > lane tier
     if (cnt > kLaneSeeds) {
-        atomicAdd(&A.ctr->chain_class[3], 1ull);
-        if (cnt > kClassS) atomicAdd(&A.ctr->chain_class[2], 1ull);
+        atomicAdd(&A.ctr->chain_class[4], 1ull);
+        if (cnt > kClassS) atomicAdd(&A.ctr->chain_class[3], 1ull);
+        if (cnt > kClassM1) atomicAdd(&A.ctr->chain_class[2], 1ull);
         if (cnt > kClassM) atomicAdd(&A.ctr->chain_class[1], 1ull);
         if (cnt > kClassL) atomicAdd(&A.ctr->chain_class[0], 1ull);
     }
@@ -503,7 +566,9 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
             bool to_add = true;
             if (c.n_keys) {
                 int64_t fr = 0;
-                const int32_t lower = kbt_lower(c, rbeg, fr);
+                int32_t lower;
+                if constexpr (LDS) lower = wkbt_lower(c, rbeg, lane, fr);
+                else lower = kbt_lower(c, rbeg, fr);
                 if (lower >= 0) {                                        // test_and_merge
                     ChainRec ch = crec[lower];
                     const int64_t lr = ch.last_rbeg;
@@ -540,7 +605,8 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
                 ch.rid = rid; ch.n = 1; ch.first_idx = g; ch.last_idx = g; ch.wq = slen; ch.wr = slen;
                 const int32_t cid = c.n_keys;                            // chains are numbered in creation order
                 if (wr) crec[cid] = ch;
-                kbt_put(c, cid, rbeg);
+                if constexpr (LDS) wkbt_put(c, cid, rbeg, lane);
+                else kbt_put(c, cid, rbeg);
                 if (c.overflow) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return; }
             }
         }
@@ -620,6 +686,7 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
     __shared__ uint2 l_fl[kLdsChains];
     __shared__ uint4 l_rec[kLdsChains];        // by sorted position: {beg, end, w | alt, first}
     __shared__ uint4 l_sel[kLdsChains];        // the kept ("selected") chains, in selection order: {beg, end, w | alt, position}
+    __shared__ uint8_t l_kept[kLdsChains];
     const int lane = threadIdx.x;
     const int64_t n_heavy = (int64_t)*n_heavy_p;
     for (int64_t hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
@@ -647,16 +714,15 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
         __syncthreads();
         for (int i = lane; i < n_chn; i += 64) {
             const uint2 f = l_fl[i];
-            fl[i] = f;
             l_rec[i] = make_rec(A, crec[f.y], f.x);
-            kept[i] = 0;
+            l_kept[i] = 0;
         }
         __syncthreads();
         // pairwise filter: chain i against the chains selected so far, 64 at a time.  The sequential
         // loop visits them in selection order and stops at the first one that drops chain i; every
         // selected chain visited up to there with a large overlap records i as its first shadowed hit.
         int n_sel = 1;
-        if (lane == 0) { const uint4 r0 = l_rec[0]; l_sel[0] = make_uint4(r0.x, r0.y, r0.z, 0u); kept[0] = 3; }
+        if (lane == 0) { const uint4 r0 = l_rec[0]; l_sel[0] = make_uint4(r0.x, r0.y, r0.z, 0u); l_kept[0] = 3; }
         __syncthreads();
         for (int i = 1; i < n_chn; ++i) {
             const uint4 ri = l_rec[i];
@@ -697,20 +763,55 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
                 }
             }
             if (!dropped) {
-                if (lane == 0) { l_sel[n_sel] = make_uint4(ri.x, ri.y, ri.z, (uint32_t)i); kept[i] = large_ovlp ? 2 : 3; }
+                if (lane == 0) { l_sel[n_sel] = make_uint4(ri.x, ri.y, ri.z, (uint32_t)i); l_kept[i] = large_ovlp ? 2 : 3; }
                 ++n_sel;
             }
             __syncthreads();
         }
         for (int k = lane; k < n_sel; k += 64) {
             const int f = (int)l_rec[l_sel[k].w].w;
-            if (f >= 0) kept[f] = 1;
+            if (f >= 0) l_kept[f] = 1;
         }
         __syncthreads();
-        for (int i = lane; i < n_chn; i += 64) rec[i] = l_rec[i];
-        __threadfence_block();
-        __syncthreads();
-        if (lane == 0) finish_read(A, r, base, n_chn, L);
+        // max_chain_extend (bwamem.cpp:618-625) can only bite when it is smaller than the chain count
+        if (A.opt.max_chain_extend <= n_chn) {
+            if (lane == 0) {
+                int i, k;
+                for (i = k = 0; i < n_chn; ++i) {
+                    if (l_kept[i] == 0 || l_kept[i] == 3) continue;
+                    if (++k >= A.opt.max_chain_extend) break;
+                }
+                for (; i < n_chn; ++i)
+                    if (l_kept[i] < 3) l_kept[i] = 0;
+            }
+            __syncthreads();
+        }
+        // compaction of the kept chains and the read's totals, 64 chains at a time
+        int32_t *first = A.f_first + base;
+        int n_out = 0, n_seeds = 0;
+        for (int ib = 0; ib < n_chn; ib += 64) {
+            const int i = ib + lane;
+            const int kp = i < n_chn ? (int)l_kept[i] : 0;
+            const unsigned long long m = __ballot(kp != 0);
+            if (kp) {
+                const int o = n_out + __popcll(m & ((1ull << lane) - 1ull));
+                const uint2 f = l_fl[i];
+                const uint4 rc4 = l_rec[i];
+                fl[o] = make_uint2(f.x | ((unsigned)kp << 29) | (rc4.z & 0x80000000u), f.y);
+                first[o] = (int32_t)rc4.w;
+                n_seeds += crec[f.y].n;
+            }
+            n_out += __popcll(m);
+        }
+        for (int d = 32; d >= 1; d >>= 1) n_seeds += __shfl_xor(n_seeds, d);
+        if (lane == 0) {
+            A.n_kept[r] = n_out;
+            A.n_kept_seeds[r] = n_seeds;
+            if (n_out) {
+                const double min_l = A.opt.min_chain_weight ? (double)(1.1f * (float)A.opt.min_chain_weight) : (double)5.5f * log((double)L);
+                if (!(min_l > (double)(0.05f * (float)L))) atomicAdd(&A.ctr->chain_longread, 1ull);
+            }
+        }
         __syncthreads();
     }
 }
@@ -768,22 +869,34 @@ void launch_chain_count(const ChainArgs &A, uint32_t *keys, uint32_t *vals, hipS
     if (A.nseq <= 0) return;
     chain_count_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A, keys, vals);
 }
-void launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipStream_t st) {
-    if (A.nseq <= 0) return;
+// The tiers are independent of each other: they run concurrently on the auxiliary streams (forked from
+// and joined back into the batch's stream), the filter of the many-chain reads after all of them.
+int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipStream_t st, hipStream_t *aux,
+                 hipEvent_t fork, hipEvent_t *join) {
+    if (A.nseq <= 0) return 0;
     unsigned long long *cls = A.ctr->chain_class, *tk = A.ctr->chain_ticket;
-    // heaviest first: reads beyond the LDS budget (HBM state), then the three LDS size classes, then the lane tier
-    chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, 0, st>>>(A, nullptr, cls + 0, tk + 0, 0);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds_bytes(kClassL));
         attr_set = true;
     }
-    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), st>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
-    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassM), st>>>(A, cls + 1, cls + 2, tk + 2, kClassM);
-    chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), st>>>(A, cls + 2, cls + 3, tk + 3, kClassS);
-    chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A, n_seeds);
+    if (hipEventRecord(fork, st) != hipSuccess) return -1;
+    for (int i = 0; i < 5; ++i)
+        if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
+    // heaviest first: reads beyond the LDS budget (HBM state) and class L, then M, M1, S, then the lane tier
+    chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, 0, aux[0]>>>(A, nullptr, cls + 0, tk + 0, 0);
+    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[0]>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
+    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 1, cls + 2, tk + 2, kClassM);
+    chain_wave_kernel<<<(unsigned)(cu_count * 6), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 2, cls + 3, tk + 3, kClassM1);
+    chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 3, cls + 4, tk + 4, kClassS);
+    chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[4]>>>(A, n_seeds);
+    for (int i = 0; i < 5; ++i) {
+        if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
+        if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;
+    }
     chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, 0, st>>>(A, &A.ctr->n_heavy);
+    return 0;
 }
 void launch_chain_emit(const ChainArgs &A, const int64_t *chain_off, const int64_t *seed_off, bwams_chain_t *chains,
                        bwams_chain_seed_t *seeds, hipStream_t st) {

@@ -46,7 +46,8 @@ struct ChainArgs {
 size_t chain_node_bytes(int64_t n_sa, int64_t nseq);
 size_t chain_rec_bytes(int64_t n_sa);
 void launch_chain_count(const ChainArgs &A, uint32_t *keys, uint32_t *vals, hipStream_t st);
-void launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipStream_t st);
+int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipStream_t st, hipStream_t *aux,
+                 hipEvent_t fork, hipEvent_t *join);
 void launch_chain_emit(const ChainArgs &A, const int64_t *chain_off, const int64_t *seed_off, bwams_chain_t *chains,
                        bwams_chain_seed_t *seeds, hipStream_t st);
 

@@ -88,4 +88,35 @@ np.savez_compressed(
     loc_table=tab.loc_table, seed_table=tab.seed_table, seed_len=np.int32(tab.seed_len), seq_len=np.int64(tab.seq_len),
     read_len=np.array([len(r) for r in probe_reads]), reads=np.concatenate(probe_reads), expect=pe)
 
+# ---- chaining + chain-to-alignment on the seeding case (plus reads with tandem units: equal chain positions) ----
+CHAIN_REF = loader.ref_chain_lib()
+rng = np.random.default_rng(505)
+extra = []
+for _ in range(40):
+    st_ = int(rng.integers(0, len(g) - 400))
+    unit = g[st_:st_ + int(rng.integers(25, 60))]
+    gap = rng.integers(0, 4, size=int(rng.integers(101, 140)), dtype=np.uint8)
+    extra.append(np.concatenate([unit, gap, unit, gap[:20], unit])[:300])
+creads = list(reads) + extra
+cenc, ccum = simulate.flatten_reads(creads)
+csm = o.collect_smem(cenc, ccum)
+ccoord, coff = o.sa_lookup(csm, 500)
+mopt = loader.default_mem_opt()
+ch, sd, choff = loader.chain_seeds(csm, ccoord, coff, ccum, len(g), opt=mopt)
+regs, reg_off, sd2 = loader.chain2aln(ch, sd, choff, cenc, ccum, idx.ref_0123, len(g), opt=mopt)
+if CHAIN_REF is not None:       # the two klib pieces the chaining relies on, against the reference's own headers
+    for n_ in (5, 40, 700):
+        pp = rng.integers(0, 30, size=n_).astype(np.int64)
+        put = np.ones(n_, np.uint8)
+        a_, b_ = loader.kbt_script(pp, put), loader.kbt_script(pp, put, CHAIN_REF)
+        assert np.array_equal(a_[0], b_[0]) and np.array_equal(a_[1], b_[1])
+        ww = rng.integers(0, 6, size=n_).astype(np.uint32)
+        assert np.array_equal(loader.flt_sort(ww), loader.flt_sort(ww, CHAIN_REF))
+np.savez_compressed(
+    os.path.join(OUT, "chain_toy.npz"),
+    read_len=np.array([len(r) for r in creads]), reads=cenc,
+    chains=ch.view(np.uint8).reshape(len(ch), -1), seeds=sd2.view(np.uint8).reshape(len(sd2), -1), chain_off=choff,
+    regs=regs.view(np.uint8).reshape(len(regs), -1), reg_off=reg_off,
+    klib_checked_against_reference=np.array([CHAIN_REF is not None]))
+
 print("golden vectors written to", OUT, "| reference cross-check:", REF is not None)

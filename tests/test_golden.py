@@ -73,6 +73,72 @@ def test_oracle_reproduces_ksw_and_emf_golden():
     assert set(ze["expect"][:, 0]) >= {2, 3, 4}
 
 
+def _chain_case():
+    z = np.load(os.path.join(G, "chain_toy.npz"))
+    cum = np.r_[0, np.cumsum(z["read_len"])].astype(np.int64)
+    chains = np.ascontiguousarray(z["chains"]).view(loader.CHAIN_DTYPE).reshape(-1)
+    seeds = np.ascontiguousarray(z["seeds"]).view(loader.CHAIN_SEED_DTYPE).reshape(-1)
+    regs = np.ascontiguousarray(z["regs"]).view(loader.ALNREG_DTYPE).reshape(-1)
+    return z, cum, chains, seeds, regs
+
+
+CHAIN_F = ("seqid", "n", "m", "first", "rid", "w_kept_alt", "frac_rep", "pos", "seed_off")
+SEED_F = ("rbeg", "qbeg", "len", "score", "aln")
+REG_F = ("rb", "re", "qb", "qe", "rid", "chain", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep")
+
+
+def test_oracle_reproduces_chain_golden():
+    z, cum, chains, seeds, regs = _chain_case()
+    assert bool(z["klib_checked_against_reference"][0]), "regenerate with oracle/_ref present"
+    zs, idx = _seed_case()
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(z["reads"], cum)
+    coord, off = o.sa_lookup(sm, 500)
+    ch, sd, choff = loader.chain_seeds(sm, coord, off, cum, len(zs["genome"]))
+    rg, roff, sd2 = loader.chain2aln(ch, sd, choff, z["reads"], cum, idx.ref_0123, len(zs["genome"]))
+    assert np.array_equal(choff, z["chain_off"]) and np.array_equal(roff, z["reg_off"])
+    for f in CHAIN_F:
+        assert np.array_equal(ch[f], chains[f]), f
+    for f in SEED_F:
+        assert np.array_equal(sd2[f], seeds[f]), f
+    for f in REG_F:
+        assert np.array_equal(rg[f], regs[f]), f
+    per_read = np.diff(choff)
+    dup = sum(len(np.unique(ch["pos"][a:b])) != b - a for a, b in zip(choff[:-1], choff[1:]))
+    assert per_read.max() >= 3 and dup > 0            # the fixture holds duplicate chain positions
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_chain_golden():
+    from bwams import capi
+    z, cum, chains, seeds, regs = _chain_case()
+    zs, idx = _seed_case()
+    ix = capi.Index.from_host(idx, 0)
+    b = capi.Batch(ix, len(cum) + 64, int(cum[-1]) + 16384)
+    b.seed_upload(z["reads"], cum)
+    b.seed_run(capi.default_seed_opt(), with_sa=True)
+    for extend_all in (1, 0):
+        opt = capi.default_mem_opt()
+        opt.extend_all = extend_all
+        b.chain_run(opt)
+        ch, sd, choff = b.chain_fetch()
+        b.extend_run(opt)
+        rg, roff, aln = b.extend_fetch()
+        assert np.array_equal(choff, z["chain_off"]) and np.array_equal(roff, z["reg_off"])
+        for f in CHAIN_F:
+            assert np.array_equal(ch[f], chains[f]), f
+        for f in SEED_F[:-1]:
+            assert np.array_equal(sd[f], seeds[f]), f
+        assert np.array_equal(aln, seeds["aln"])
+        purged = (regs["qb"] == -1) & (regs["qe"] == -1)
+        assert np.array_equal((rg["qb"] == -1) & (rg["qe"] == -1), purged)
+        keep = slice(None) if extend_all else ~purged
+        for f in REG_F:
+            assert np.array_equal(rg[f][keep], regs[f][keep]), (extend_all, f)
+    b.close()
+    ix.close()
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_golden():
     from bwams import capi

@@ -461,13 +461,13 @@ static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, 
     if (n == 0) return BWAMS_OK;
     unsigned long long *d_nretry = &b->d_ctr->n_retry;
     BWAMS_HIP(hipMemsetAsync(d_nretry, 0, sizeof(unsigned long long), st));
-    launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st);
+    if (launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st, s->aux, s->fork, s->join)) return BWAMS_ERR_DEVICE;
     launch_ext_post(A, right, pairs, n, A.opt.w, 0, s->retry.as<bwams_seqpair_t>(), d_nretry, st);
     unsigned long long nr = 0;
     BWAMS_HIP(hipMemcpyAsync(&nr, d_nretry, sizeof nr, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     if (nr) {
-        launch_bsw(s->retry.as<bwams_seqpair_t>(), (int64_t)nr, ref, qer, A.opt.w << 1, prm, qmax, b->d_ctr, b->cu_count, st);
+        if (launch_bsw(s->retry.as<bwams_seqpair_t>(), (int64_t)nr, ref, qer, A.opt.w << 1, prm, qmax, b->d_ctr, b->cu_count, st, s->aux, s->fork, s->join)) return BWAMS_ERR_DEVICE;
         launch_ext_post(A, right, s->retry.as<bwams_seqpair_t>(), (int64_t)nr, A.opt.w << 1, 1, nullptr, d_nretry, st);
     }
     *n_retry_out += (int64_t)nr;

@@ -45,7 +45,7 @@ __device__ __forceinline__ int wave_max(int v) {
 
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,
-    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qmax, int qlo, DevCounters *ctr) {
+    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qmax, int qlo, DevCounters *ctr, unsigned long long *head) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     while (true) {
         if (pid >= pid_end) {
             unsigned long long t = 0;
-            if (lane == 0) t = atomicAdd(&ctr->work_head, (unsigned long long)kTaskChunk);
+            if (lane == 0) t = atomicAdd(head, (unsigned long long)kTaskChunk);
             pid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
                             (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t));
             pid_end = pid + kTaskChunk < n ? pid + kTaskChunk : n;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
 template <int NCH>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
     bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,
-    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qlo, DevCounters *ctr) {
+    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qlo, DevCounters *ctr, unsigned long long *head) {
     const int lane = threadIdx.x & 63;
     const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
     while (true) {
         if (pid >= pid_end) {
             unsigned long long t = 0;
-            if (lane == 0) t = atomicAdd(&ctr->work_head, (unsigned long long)kTaskChunk);
+            if (lane == 0) t = atomicAdd(head, (unsigned long long)kTaskChunk);
             pid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
                             (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t));
             pid_end = pid + kTaskChunk < n ? pid + kTaskChunk : n;
@@ -408,44 +408,50 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
     if (lane == 0 && cells) atomicAdd(&ctr->bsw_cells, cells);
 }
 
-__global__ void bsw_head_reset_kernel(DevCounters *ctr) { ctr->work_head = 0; }
-
 __global__ void bsw_reset_kernel(DevCounters *ctr) {
-    ctr->work_head = 0;
+    for (int i = 0; i < 4; ++i) ctr->bsw_head[i] = 0;
     ctr->bsw_cells = 0;
 }
 
 }  // namespace
 
-void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w,
-                const SwParams &prm, int qmax, DevCounters *ctr, int cu_count, hipStream_t st) {
+// One kernel per query-length class (register-resident for 1..64, 65..128, 129..192 bases, LDS-resident
+// beyond), each with its own ticket counter.  With auxiliary streams the classes run concurrently, so
+// the tail of one overlaps the body of the next.
+int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w, const SwParams &prm, int qmax,
+               DevCounters *ctr, int cu_count, hipStream_t st, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join) {
     bsw_reset_kernel<<<1, 1, 0, st>>>(ctr);
-    if (n <= 0) return;
+    if (n <= 0) return 0;
     int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t maxb = (int64_t)cu_count * 8;
     if (blocks > maxb) blocks = maxb;
-    // queries of 1..64, 65..128 and 129..192 bases: register-resident variants; longer: LDS-resident kernel
-    bsw_kernel_reg<1><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(pairs, n, ref, qer, w, prm, -1, ctr);
-    int qlo = 64;
-    if (qmax > 64) {
-        bsw_head_reset_kernel<<<1, 1, 0, st>>>(ctr);
-        bsw_kernel_reg<2><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(pairs, n, ref, qer, w, prm, 64, ctr);
-        qlo = 128;
+    const int n_class = qmax > 192 ? 4 : qmax > 128 ? 3 : qmax > 64 ? 2 : 1;
+    hipStream_t q[4] = {st, st, st, st};
+    if (aux && n_class > 1) {
+        if (hipEventRecord(fork, st) != hipSuccess) return -1;
+        for (int c = 1; c < n_class; ++c) {
+            q[c] = aux[c - 1];
+            if (hipStreamWaitEvent(q[c], fork, 0) != hipSuccess) return -1;
+        }
     }
-    if (qmax > 128) {
-        bsw_head_reset_kernel<<<1, 1, 0, st>>>(ctr);
-        bsw_kernel_reg<3><<<(unsigned)blocks, kWavesPerBlock * 64, 0, st>>>(pairs, n, ref, qer, w, prm, 128, ctr);
-        qlo = 192;
-    }
-    if (qmax > 192) {
-        bsw_head_reset_kernel<<<1, 1, 0, st>>>(ctr);
+    // the longest queries first: their tasks are the most expensive
+    if (n_class > 3) {
         const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
         const size_t lds = per_wave * kWavesPerBlock;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        bsw_kernel<<<(unsigned)blocks, kWavesPerBlock * 64, lds, st>>>(pairs, n, ref, qer, w, prm, qmax, qlo, ctr);
+        bsw_kernel<<<(unsigned)blocks, kWavesPerBlock * 64, lds, q[3]>>>(pairs, n, ref, qer, w, prm, qmax, 192, ctr, &ctr->bsw_head[3]);
     }
+    if (n_class > 2) bsw_kernel_reg<3><<<(unsigned)blocks, kWavesPerBlock * 64, 0, q[2]>>>(pairs, n, ref, qer, w, prm, 128, ctr, &ctr->bsw_head[2]);
+    if (n_class > 1) bsw_kernel_reg<2><<<(unsigned)blocks, kWavesPerBlock * 64, 0, q[1]>>>(pairs, n, ref, qer, w, prm, 64, ctr, &ctr->bsw_head[1]);
+    bsw_kernel_reg<1><<<(unsigned)blocks, kWavesPerBlock * 64, 0, q[0]>>>(pairs, n, ref, qer, w, prm, -1, ctr, &ctr->bsw_head[0]);
+    if (aux && n_class > 1)
+        for (int c = 1; c < n_class; ++c) {
+            if (hipEventRecord(join[c - 1], q[c]) != hipSuccess) return -1;
+            if (hipStreamWaitEvent(st, join[c - 1], 0) != hipSuccess) return -1;
+        }
+    return 0;
 }
 
 size_t bsw_lds_bytes(int qmax) {

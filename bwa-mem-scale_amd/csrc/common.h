@@ -61,6 +61,7 @@ struct DevCounters {
     unsigned long long n_work2;          // round-2 work items
     unsigned long long overflow;         // SMEM pool overflow flag / needed size
     unsigned long long bsw_cells;
+    unsigned long long bsw_head[4];      // ticket counters of the banded-SW class kernels
     unsigned long long ext_after[3], blk_after[3];
     unsigned long long emf_nodes, emf_cmp_bytes;     // EMF probe: entries visited, reference bytes compared   // n_ext / n_ext_blocks when round 1, 2, 3 ended
     unsigned long long chain_overflow;   // chaining: B-tree node region exhausted (never expected)
@@ -87,8 +88,9 @@ struct Round2Work {
     int32_t min_intv;
 };
 
-void launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w,
-                const SwParams &prm, int qmax, DevCounters *ctr, int cu_count, hipStream_t st);
+int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w, const SwParams &prm, int qmax,
+               DevCounters *ctr, int cu_count, hipStream_t st, hipStream_t *aux = nullptr, hipEvent_t fork = nullptr,
+               hipEvent_t *join = nullptr);
 size_t bsw_lds_bytes(int qmax);
 size_t task_plan_bytes(int64_t nseq);
 void launch_task_plan(const bwams_smem_t *sm, int64_t n_smem, const int64_t *sa_off, const int64_t *sa_coord,

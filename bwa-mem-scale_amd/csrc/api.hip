@@ -682,6 +682,7 @@ int bwams_bsw_run(bwams_batch_t *b, int32_t w, const bwams_sw_opt_t *o) {
         mx = mx > o->mat[i] ? mx : o->mat[i];
     }
     prm.max_sc = mx;
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->bsw_cells, 0, sizeof(unsigned long long), b->stream));
     BWAMS_HIP(hipEventRecord(b->ev[6], b->stream));
     launch_bsw(b->d_pairs, b->n_pairs, b->d_ref, b->d_qer, w, prm, b->max_qlen, b->d_ctr, b->cu_count, b->stream);
     BWAMS_HIP(hipEventRecord(b->ev[7], b->stream));

@@ -496,6 +496,7 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
     s->built = s->ext_done = false;
     ExtArgs A;
     BWAMS_HIP(hipEventRecord(s->ev[10], st));
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->bsw_cells, 0, sizeof(unsigned long long), st));      // DP cells of this run, all rounds
     BWAMS_HIP(hipEventRecord(s->ev[2], st));
     if ((rc = ext_plan(b, s, opt, opt->extend_all != 0, &A))) return rc;
     int64_t tot_left = 0, tot_right = 0;

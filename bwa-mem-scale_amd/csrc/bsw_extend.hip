@@ -409,8 +409,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
 }
 
 __global__ void bsw_reset_kernel(DevCounters *ctr) {
-    for (int i = 0; i < 4; ++i) ctr->bsw_head[i] = 0;
-    ctr->bsw_cells = 0;
+    for (int i = 0; i < 4; ++i) ctr->bsw_head[i] = 0;      // bsw_cells accumulates until the caller clears it
 }
 
 }  // namespace

@@ -1,10 +1,10 @@
-// seed_tasks.hip — extension tasks from seeds, on the device (interim glue).
+// seed_tasks.hip — extension tasks straight from seeds, on the device (bwams_tasks_from_seeds).
 //
-// The reference builds its extension tasks on the host from chains
-// (mem_chain_seeds -> mem_chain_flt -> mem_chain2aln_across_reads_V2,
-// /root/reference/src/bwamem.cpp:789-959, :528-646, :2849-3191).  Chaining is not built yet
-// (DESIGN.md §0, rows a9/a14/a16); until it is, this file keeps the resident pipeline whole
-// by treating the longest non-repetitive seed of each read as a one-seed chain and laying out
+// The reference builds its extension tasks from chains (mem_chain_seeds -> mem_chain_flt ->
+// mem_chain2aln_across_reads_V2, /root/reference/src/bwamem.cpp:789-959, :528-646, :2849-3191);
+// that path is chain.hip + ext_aln.hip.  This older entry point, kept in the ABI as a cheap
+// seeds-only probe of the extension stage, treats
+// the longest non-repetitive seed of each read as a one-seed chain and lays out
 // its left and right tasks exactly as the reference does for such a chain: window from
 // cal_max_gap (bwamem.cpp:94-104, :2880-2905), strand clipping (:2906-2910), left = reversed
 // query prefix vs reversed reference window with h0 = seed_len * a (:2953-3060), right = query

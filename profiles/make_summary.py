@@ -20,7 +20,14 @@ def short(k):
                       ("smem_search_kernel<false>", "smem_search_kernel<false> (SMEM round 2)"),
                       ("seed_strategy", "seed_strategy_kernel (SMEM round 3)"), ("sa_lookup", "sa_lookup_kernel"),
                       ("bsw_kernel_reg<1>", "bsw_kernel_reg<1> (queries <= 64)"),
-                      ("bsw_kernel_reg<2>", "bsw_kernel_reg<2> (queries 65..128)"), ("bsw_kernel", "bsw_kernel (LDS, queries > 128)"),
+                      ("bsw_kernel_reg<2>", "bsw_kernel_reg<2> (queries 65..128)"),
+                      ("bsw_kernel_reg<3>", "bsw_kernel_reg<3> (queries 129..192)"), ("bsw_kernel", "bsw_kernel (LDS, queries > 192)"),
+                      ("chain_count", "chain_count_kernel"), ("chain_wave", "chain_wave_kernel (wave per read, LDS state; 5 size classes)"),
+                      ("chain_heavy", "chain_heavy_kernel (sort + filter of many-chain reads)"),
+                      ("chain_emit", "chain_emit_kernel"), ("chain_kernel", "chain_kernel (lane per read)"),
+                      ("ext_plan", "ext_plan_kernel"), ("ext_build", "ext_build_kernel (task construction)"),
+                      ("ext_post", "ext_post_kernel"), ("ext_select_wave", "ext_select_wave_kernel (selection / purge, wave per read)"),
+                      ("ext_select", "ext_select_kernel (selection / purge, lane per read)"),
                       ("pack_reads", "pack_reads_kernel"), ("round2_work", "round2_work_kernel"),
                       ("make_keys", "make_keys_kernel"), ("gather_sorted", "gather_sorted_kernel"),
                       ("plan_kernel", "plan_kernel (task construction)"), ("build_kernel", "build_kernel (task construction)"),
@@ -55,11 +62,13 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
     f.write("Collected by `bash profiles/run_profiles.sh <tag> 1000`: `rocprofv3 --kernel-trace --stats -- python3 bench.py "
             "--genome-mbp 1000 --steps 2 --warmup 1 --no-cpu-baseline` plus one `--pmc` pass per counter group (never combined "
             f"with tracing); summarised by `profiles/make_summary.py`.  Raw: `profiles/{rnd}_kernel_stats.csv`.\n\n")
-    f.write("## Kernel time (library kernels; torch / rocPRIM kernels of the untimed index build omitted)\n\n| kernel | calls | avg ms |\n|---|---|---|\n")
+    f.write("## Kernel time (library kernels; torch / rocPRIM kernels of the untimed index build omitted)\n\n"
+            "3 steps per run (1 warm-up + 2 timed); kernels that run once per extension round or per query-length class have "
+            "several calls per step, so the per-step column is total / 3.\n\n| kernel | calls | avg ms | ms per step |\n|---|---|---|---|\n")
     for r in rows:
         s = short(r["Name"])
         if s:
-            f.write(f"| {s} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} |\n")
+            f.write(f"| {s} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['TotalDurationNs'])/3e6:.2f} |\n")
     f.write(f"\n`roofline.launch_ms` measured live by `bench.py` with HIP events in the run below: {bench['roofline']['launch_ms']} ms "
             "(the rocprofv3 average above covers warm-up + timed launches of the profiled run).\n\n")
     f.write("## PMC per launch (uncorrected counter values; average over the launches of one run)\n\n"

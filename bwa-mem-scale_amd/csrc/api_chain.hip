@@ -223,7 +223,7 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     A.ctr = b->d_ctr;
 
     BWAMS_HIP(hipEventRecord(s->ev[0], st));
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 13 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[5], chain_ticket[5]
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 16 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[6], chain_ticket[6], heavy_ticket
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all
     if (b->n_smem <= 1 || n_sa == 0) {

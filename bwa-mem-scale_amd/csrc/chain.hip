@@ -60,7 +60,7 @@ static_assert(sizeof(ChainRec) == 48, "chain record layout");
 // (every node but the root holds >= t - 1 = 4 keys: at most 5K/16 + 3 nodes)
 __host__ __device__ constexpr int lds_nodes(int K) { return (K * 5) / 16 + 3; }
 __host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * sizeof(ChainRec) + (size_t)lds_nodes(K) * sizeof(Node); }
-constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL = 1700;      // seeds per read: 12, 24, 48, 159 KB of LDS
+constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL1 = 850, kClassL = 1700;      // seeds per read: 12, 24, 48, 79, 159 KB of LDS
 static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
 
 // bns_pos2rid / bns_intv2rid (bntseq.cpp:397-421) with a one-entry cache of the last sequence found
@@ -245,17 +245,35 @@ __device__ __forceinline__ int wnode_search(const Node *p, int n, int64_t k, int
     const int cnt = __popcll(m_lt);
     return eq ? cnt : cnt - 1;
 }
-__device__ __forceinline__ int32_t wkbt_lower(const ReadCtx &c, int64_t k, int lane, int64_t &lower_pos) {
+// The lookup also remembers where an insertion of the same key would land: kb_putp descends through the
+// same children (slot getp_aux + 1), so when the lookup reached a leaf and met no full node on the way
+// (kb_putp would split nothing), the insertion is a plain leaf insert at the remembered slot.
+struct WPath { int32_t leaf; int16_t slot, n; bool ok; };
+__device__ __forceinline__ int32_t wkbt_lower(const ReadCtx &c, int64_t k, int lane, int64_t &lower_pos, WPath &path) {
     int32_t lower = -1, xi = c.root;
+    bool any_full = false;
     for (;;) {
         const Node *p = &c.nodes[xi];
         const int n = p->n, internal = p->internal;
+        any_full |= n == KB_MAXK;
         bool eq;
         const int i = wnode_search(p, n, k, lane, eq);
         if (i >= 0) { lower = p->key[i]; lower_pos = p->pos[i]; }
-        if ((i >= 0 && eq) || !internal) return lower;
+        if (!internal) {
+            path.leaf = xi; path.slot = (int16_t)i; path.n = (int16_t)n; path.ok = !any_full;
+            return lower;
+        }
+        if (i >= 0 && eq) { path.ok = false; return lower; }       // found in an internal node: no leaf reached
         xi = p->ptr[i + 1];
     }
+}
+// leaf insertion after slot i (the tail of __kb_putp_aux): slots i+1 .. n-1 move up by one
+__device__ __forceinline__ void wleaf_insert(ReadCtx &c, Node *p, int i, int n, int32_t id, int64_t k, int lane) {
+    const bool mv = lane > i && lane < n;
+    const int64_t mp = mv ? p->pos[lane] : 0;
+    const int32_t mk = mv ? p->key[lane] : 0;
+    if (mv) { p->pos[lane + 1] = mp; p->key[lane + 1] = mk; }
+    if (c.wr) { p->pos[i + 1] = k; p->key[i + 1] = id; p->n = (int16_t)(n + 1); }
 }
 __device__ __forceinline__ void wkbt_put(ReadCtx &c, int32_t id, int64_t k, int lane) {
     ++c.n_keys;
@@ -274,14 +292,7 @@ __device__ __forceinline__ void wkbt_put(ReadCtx &c, int32_t id, int64_t k, int 
         const int n = p->n, internal = p->internal;
         bool eq;
         const int i = wnode_search(p, n, k, lane, eq);
-        if (!internal) {                                   // insert after slot i: slots i+1 .. n-1 move up by one
-            const bool mv = lane > i && lane < n;
-            const int64_t mp = mv ? p->pos[lane] : 0;
-            const int32_t mk = mv ? p->key[lane] : 0;
-            if (mv) { p->pos[lane + 1] = mp; p->key[lane + 1] = mk; }
-            if (c.wr) { p->pos[i + 1] = k; p->key[i + 1] = id; p->n = (int16_t)(n + 1); }
-            return;
-        }
+        if (!internal) { wleaf_insert(c, p, i, n, id, k, lane); return; }
         int ii = i + 1;
         int32_t ci = p->ptr[ii];
         if (c.nodes[ci].n == KB_MAXK) {
@@ -476,13 +487,14 @@ __global__ void chain_count_kernel(ChainArgs A, uint32_t *keys, uint32_t *vals) 
     const int64_t cnt = beg < end ? A.sa_off[end] - A.sa_off[beg] : 0;
     keys[r] = (uint32_t)(cnt < 0xffffffffll ? cnt : 0xffffffffll);
     vals[r] = (uint32_t)r;
-    // class boundaries in the descending order: [0, c[0]) > L, [c[0], c[1]) > M, [c[1], c[2]) > M1, [c[2], c[3]) > S,
-    // [c[3], c[4]) > lane tier
+    // class boundaries in the descending order: [0, c[0]) > L, [c[0], c[1]) > L1, [c[1], c[2]) > M, [c[2], c[3]) > M1,
+    // [c[3], c[4]) > S, [c[4], c[5]) > lane tier
     if (cnt > kLaneSeeds) {
-        atomicAdd(&A.ctr->chain_class[4], 1ull);
-        if (cnt > kClassS) atomicAdd(&A.ctr->chain_class[3], 1ull);
-        if (cnt > kClassM1) atomicAdd(&A.ctr->chain_class[2], 1ull);
-        if (cnt > kClassM) atomicAdd(&A.ctr->chain_class[1], 1ull);
+        atomicAdd(&A.ctr->chain_class[5], 1ull);
+        if (cnt > kClassS) atomicAdd(&A.ctr->chain_class[4], 1ull);
+        if (cnt > kClassM1) atomicAdd(&A.ctr->chain_class[3], 1ull);
+        if (cnt > kClassM) atomicAdd(&A.ctr->chain_class[2], 1ull);
+        if (cnt > kClassL1) atomicAdd(&A.ctr->chain_class[1], 1ull);
         if (cnt > kClassL) atomicAdd(&A.ctr->chain_class[0], 1ull);
     }
 }
@@ -564,10 +576,12 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
             const int rid = intv2rid(A.bns, rbeg, rbeg + slen, rc);
             if (rid < 0) continue;
             bool to_add = true;
+            WPath path;
+            path.ok = false;
             if (c.n_keys) {
                 int64_t fr = 0;
                 int32_t lower;
-                if constexpr (LDS) lower = wkbt_lower(c, rbeg, lane, fr);
+                if constexpr (LDS) lower = wkbt_lower(c, rbeg, lane, fr, path);
                 else lower = kbt_lower(c, rbeg, fr);
                 if (lower >= 0) {                                        // test_and_merge
                     ChainRec ch = crec[lower];
@@ -605,8 +619,10 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
                 ch.rid = rid; ch.n = 1; ch.first_idx = g; ch.last_idx = g; ch.wq = slen; ch.wr = slen;
                 const int32_t cid = c.n_keys;                            // chains are numbered in creation order
                 if (wr) crec[cid] = ch;
-                if constexpr (LDS) wkbt_put(c, cid, rbeg, lane);
-                else kbt_put(c, cid, rbeg);
+                if constexpr (LDS) {
+                    if (path.ok) { ++c.n_keys; wleaf_insert(c, &c.nodes[path.leaf], path.slot, path.n, cid, rbeg, lane); }
+                    else wkbt_put(c, cid, rbeg, lane);
+                } else kbt_put(c, cid, rbeg);
                 if (c.overflow) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return; }
             }
         }
@@ -689,7 +705,12 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
     __shared__ uint8_t l_kept[kLdsChains];
     const int lane = threadIdx.x;
     const int64_t n_heavy = (int64_t)*n_heavy_p;
-    for (int64_t hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
+    for (;;) {
+        unsigned long long tk = 0;
+        if (lane == 0) tk = atomicAdd(&A.ctr->heavy_ticket, 1ull);
+        const int64_t hi = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tk >> 32)) << 32) |
+                                     (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)tk));
+        if (hi >= n_heavy) break;
         const int64_t r = A.heavy[hi];
         const int64_t base = A.read_base[r];
         const int n_chn = A.n_chn[r];
@@ -884,12 +905,13 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     if (hipEventRecord(fork, st) != hipSuccess) return -1;
     for (int i = 0; i < 5; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
-    // heaviest first: reads beyond the LDS budget (HBM state) and class L, then M, M1, S, then the lane tier
+    // heaviest first: reads beyond the LDS budget (HBM state) and classes L, L1, then M, M1, S, then the lane tier
     chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, 0, aux[0]>>>(A, nullptr, cls + 0, tk + 0, 0);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[0]>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
-    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 1, cls + 2, tk + 2, kClassM);
-    chain_wave_kernel<<<(unsigned)(cu_count * 6), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 2, cls + 3, tk + 3, kClassM1);
-    chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 3, cls + 4, tk + 4, kClassS);
+    chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, lds_bytes(kClassL1), aux[0]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
+    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
+    chain_wave_kernel<<<(unsigned)(cu_count * 6), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
+    chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 4, cls + 5, tk + 5, kClassS);
     chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[4]>>>(A, n_seeds);
     for (int i = 0; i < 5; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;

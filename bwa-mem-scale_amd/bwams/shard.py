@@ -52,3 +52,39 @@ def gather_smems(local_smems: np.ndarray, first_read: int, dist=None):
     dist.all_gather(bufs, pad)
     parts = [bufs[r][:int(sizes[r].item())].numpy().view(sm.dtype) for r in range(world)]
     return np.concatenate(parts)
+
+
+def _all_gather_bytes(arr: np.ndarray, dist):
+    """Per-rank list of the ranks' arrays (same dtype), via two all_gathers of padded byte buffers."""
+    import torch
+    world = dist.get_world_size()
+    raw = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy())
+    n = torch.tensor([raw.numel()], dtype=torch.int64)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    mx = max(1, int(max(int(s.item()) for s in sizes)))
+    pad = torch.zeros(mx, dtype=torch.uint8)
+    pad[:raw.numel()] = raw
+    bufs = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return [bufs[r][:int(sizes[r].item())].numpy().view(arr.dtype) for r in range(world)]
+
+
+def gather_regions(regs: np.ndarray, reg_off: np.ndarray, n_chains: int, dist=None):
+    """Concatenate per-rank alignment regions (bwams_alnreg_t records grouped by read, reg_off[n_local + 1])
+    in read order on every rank: -> (regs, reg_off over the whole chunk).  The chain index of a region is
+    rebased by the number of chains of the preceding ranks, like rid in gather_smems."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return regs.copy(), reg_off.copy()
+    parts = _all_gather_bytes(regs, dist)
+    offs = _all_gather_bytes(np.ascontiguousarray(reg_off, np.int64), dist)
+    nch = _all_gather_bytes(np.array([n_chains], np.int64), dist)
+    out, out_off, base_reg, base_chain = [], [np.zeros(1, np.int64)], 0, 0
+    for r, (p, o) in enumerate(zip(parts, offs)):
+        p = p.copy()
+        p["chain"] += base_chain
+        out.append(p)
+        out_off.append(o[1:] + base_reg)
+        base_reg += len(p)
+        base_chain += int(nch[r][0])
+    return np.concatenate(out), np.concatenate(out_off)

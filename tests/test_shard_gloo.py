@@ -38,8 +38,17 @@ def _worker(rank, world, port, out_dir):
     e, c, first = shard.shard_reads(enc, cum, rank, world)
     local = loader.OracleFMI(idx).collect_smem(e, c)
     allsm = shard.gather_smems(local, first, dist)
+    # the rest of the path on the shard: SA lookup, chaining, chain-to-alignment; regions gathered in read order
+    o = loader.OracleFMI(idx)
+    coord, off = o.sa_lookup(local)
+    ch, sd, choff = loader.chain_seeds(local, coord, off, c, len(g))
+    ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, e, c, ref, len(g))
+    allregs, all_off = shard.gather_regions(regs, reg_off, len(ch), dist)
     if rank == 0:
         np.save(os.path.join(out_dir, "gathered.npy"), allsm)
+        np.save(os.path.join(out_dir, "regs.npy"), allregs)
+        np.save(os.path.join(out_dir, "reg_off.npy"), all_off)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,3 +65,12 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path):
     assert len(got) == len(want)
     for f in ("rid", "m", "n", "k", "l", "s"):
         assert np.array_equal(got[f], want[f]), f
+    o = loader.OracleFMI(idx)
+    coord, off = o.sa_lookup(want)
+    ch, sd, choff = loader.chain_seeds(want, coord, off, cum, len(g))
+    ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    wregs, wreg_off, _ = loader.chain2aln(ch, sd, choff, enc, cum, ref, len(g))
+    gregs, goff = np.load(tmp_path / "regs.npy"), np.load(tmp_path / "reg_off.npy")
+    assert np.array_equal(goff, wreg_off) and len(gregs) == len(wregs) > 0
+    for f in ("rb", "re", "qb", "qe", "rid", "chain", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
+        assert np.array_equal(gregs[f], wregs[f]), f

@@ -320,6 +320,28 @@ int bwams_index_fetch_fma(bwams_index_t *ix, void *all_smem, void *last_smem) {
 
 /* ------------------------------------------------------------------ batch -- */
 
+// (re)allocate every buffer whose size follows max_smem; the batch grows them when a chunk needs more
+static int alloc_smem_buffers(bwams_batch *b, int64_t max_smem) {
+    void **ptrs[] = {(void **)&b->d_pool, (void **)&b->d_sorted, (void **)&b->d_keys, (void **)&b->d_keys2, (void **)&b->d_vals,
+                     (void **)&b->d_vals2, (void **)&b->d_work2, (void **)&b->d_sa_off, (void **)&b->d_sa_cnt};
+    for (void **p : ptrs)
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    b->max_smem = max_smem;
+    // the pool is handed out in per-wave chunks: room for every wave's partly filled last chunk
+    // of each of the three rounds on top of the max_smem real records
+    b->pool_cap = b->max_smem + 3 * seed_pool_slack(b->cu_count);
+    BWAMS_HIP(hipMalloc(&b->d_pool, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
+    BWAMS_HIP(hipMalloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
+    BWAMS_HIP(hipMalloc(&b->d_keys, (size_t)b->pool_cap * 8));
+    BWAMS_HIP(hipMalloc(&b->d_keys2, (size_t)b->pool_cap * 8));
+    BWAMS_HIP(hipMalloc(&b->d_vals, (size_t)b->pool_cap * 4));
+    BWAMS_HIP(hipMalloc(&b->d_vals2, (size_t)b->pool_cap * 4));
+    BWAMS_HIP(hipMalloc(&b->d_work2, (size_t)b->pool_cap * sizeof(Round2Work)));
+    BWAMS_HIP(hipMalloc(&b->d_sa_off, (size_t)(b->max_smem + 1) * 8));
+    BWAMS_HIP(hipMalloc(&b->d_sa_cnt, (size_t)(b->max_smem + 1) * 8));
+    return BWAMS_OK;
+}
+
 int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, int64_t max_smem,
                        int64_t max_sa, bwams_batch_t **out) {
     if (!ix || !out || max_reads <= 0 || max_bases <= 0) return BWAMS_ERR_ARG;
@@ -340,18 +362,8 @@ int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, 
     BWAMS_HIP(hipMalloc(&b->d_enc, (size_t)max_bases + 64));
     BWAMS_HIP(hipMalloc(&b->d_cum, (size_t)(max_reads + 1) * 8));
     BWAMS_HIP(hipMalloc(&b->d_skip, (size_t)max_reads));
-    // the pool is handed out in per-wave chunks: room for every wave's partly filled last chunk
-    // of each of the three rounds on top of the max_smem real records
-    b->pool_cap = b->max_smem + 3 * seed_pool_slack(b->cu_count);
-    BWAMS_HIP(hipMalloc(&b->d_pool, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
-    BWAMS_HIP(hipMalloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
-    BWAMS_HIP(hipMalloc(&b->d_keys, (size_t)b->pool_cap * 8));
-    BWAMS_HIP(hipMalloc(&b->d_keys2, (size_t)b->pool_cap * 8));
-    BWAMS_HIP(hipMalloc(&b->d_vals, (size_t)b->pool_cap * 4));
-    BWAMS_HIP(hipMalloc(&b->d_vals2, (size_t)b->pool_cap * 4));
-    BWAMS_HIP(hipMalloc(&b->d_work2, (size_t)b->pool_cap * sizeof(Round2Work)));
-    BWAMS_HIP(hipMalloc(&b->d_sa_off, (size_t)(b->max_smem + 1) * 8));
-    BWAMS_HIP(hipMalloc(&b->d_sa_cnt, (size_t)(b->max_smem + 1) * 8));
+    int arc = alloc_smem_buffers(b, b->max_smem);
+    if (arc) { bwams_batch_destroy(b); return arc; }
     BWAMS_HIP(hipMalloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
     BWAMS_HIP(hipMalloc(&b->d_ctr, sizeof(DevCounters)));
     BWAMS_HIP(hipHostMalloc(&b->h_ctr, sizeof(DevCounters)));
@@ -459,7 +471,26 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
     return BWAMS_OK;
 }
 
+static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa);
+
+// The SMEM and SA buffers grow on demand: the kernels keep counting when a buffer is full, so one
+// overflowing pass tells the size the chunk needs and the stage is simply run again.
 int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
+    if (!b || !opt) return BWAMS_ERR_ARG;
+    b->last_seed_opt = *opt;
+    int rc = seed_run_once(b, opt, with_sa);
+    if (rc == BWAMS_ERR_CAPACITY && b->n_smem > b->max_smem) {
+        BWAMS_HIP(hipStreamSynchronize(b->stream));
+        const int64_t need = b->n_smem + b->n_smem / 4 + 1024;
+        if ((rc = alloc_smem_buffers(b, need))) return rc;
+        b->tmp_bytes = 0;                           // rocPRIM scratch is re-queried per call
+        if (b->d_tmp) { (void)hipFree(b->d_tmp); b->d_tmp = nullptr; }
+        rc = seed_run_once(b, opt, with_sa);
+    }
+    return rc;
+}
+
+static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
     if (!b || !opt) return BWAMS_ERR_ARG;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
@@ -575,8 +606,23 @@ int bwams_seed_counts(bwams_batch_t *b, int64_t *n_smem, int64_t *n_sa) {
     if (n_sa) *n_sa = b->n_sa;
     if (b->n_smem > b->max_smem) return BWAMS_ERR_CAPACITY;
     if (b->n_sa > b->max_sa) {
-        set_last_error("SA coordinate buffer overflow: need " + std::to_string(b->n_sa));
-        return BWAMS_ERR_CAPACITY;
+        // the lookup kernel counted every coordinate but stored only max_sa of them: grow and run it again
+        (void)hipFree(b->d_sa_coord);
+        b->d_sa_coord = nullptr;
+        b->max_sa = b->n_sa + b->n_sa / 8 + 1024;
+        BWAMS_HIP(hipMalloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
+        BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_sa_lookups, 0, 2 * sizeof(unsigned long long), b->stream));   // + n_lf_steps
+        launch_sa_lookup(b->idx->fmi, b->d_sorted, b->n_smem, b->d_sa_off, b->d_sa_coord, b->max_sa, b->last_seed_opt.max_occ,
+                         b->d_ctr, b->cu_count, b->stream);
+        BWAMS_HIP(hipEventRecord(b->ev[5], b->stream));
+        BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, b->stream));
+        BWAMS_HIP(hipStreamSynchronize(b->stream));
+        b->n_sa = (int64_t)b->h_ctr->n_sa_lookups;
+        if (n_sa) *n_sa = b->n_sa;
+        if (b->n_sa > b->max_sa) {
+            set_last_error("SA coordinate buffer overflow: need " + std::to_string(b->n_sa));
+            return BWAMS_ERR_CAPACITY;
+        }
     }
     return BWAMS_OK;
 }

@@ -165,6 +165,7 @@ struct bwams_batch {
 
     int64_t n_smem = 0, n_sa = 0;
     bool seed_done = false, with_sa = false;
+    bwams_seed_opt_t last_seed_opt{};    // of the last bwams_seed_run (a grown SA buffer re-runs the lookup)
 
     // extension buffers
     bwams_seqpair_t *d_pairs = nullptr;

@@ -88,8 +88,11 @@ int64_t bwams_index_bytes(const bwams_index_t *idx);
 /* ---------------------------------------------------------------- batch ---- */
 
 /* Work buffers sized for up to max_reads reads / max_bases bases per call.
- * max_smem / max_sa bound the SMEM and SA-coordinate outputs (0 = library
- * default: 24 SMEMs and 64 coordinates per read on average). */
+ * max_smem / max_sa are the initial sizes of the SMEM and SA-coordinate buffers (0 = library
+ * default: 24 SMEMs and 64 coordinates per read on average).  They are not limits: a chunk that
+ * needs more makes the stage run a second time on grown buffers (the kernels keep counting when
+ * a buffer is full).  The host buffers of bwams_seed_fmi / bwams_seed_fetch are the caller's and
+ * still yield BWAMS_ERR_CAPACITY when too small. */
 int bwams_batch_create(bwams_index_t *idx, int64_t max_reads, int64_t max_bases,
                        int64_t max_smem, int64_t max_sa, bwams_batch_t **out);
 int bwams_batch_destroy(bwams_batch_t *b);

@@ -111,6 +111,31 @@ def test_capacity_error_is_reported_not_truncated(gpu_toy):
     b.close()
 
 
+def test_resident_buffers_grow_on_demand(gpu_toy):
+    """The resident path sizes its SMEM / SA buffers from an overflowing pass and runs the stage again; the
+    results (and the event counters) are those of a batch that was large enough from the start."""
+    g, idx, ix = gpu_toy
+    reads, _, _ = simulate.make_reads(g, 2000, seed=12)
+    enc, cum = simulate.flatten_reads(reads)
+    o = loader.OracleFMI(idx)
+    ctr = loader.Counters()
+    want = o.collect_smem(enc, cum, counters=ctr)
+    wcoord, woff = o.sa_lookup(want, 500, counters=ctr)
+    b = capi.Batch(ix, len(reads), int(cum[-1]), max_smem=64, max_sa=64)
+    got, coord, off = b.seed(enc, cum)
+    assert len(got) == len(want) > 64
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(off, woff) and np.array_equal(coord, wcoord)
+    st = b.stats()
+    assert st.n_sa_lookups == ctr.n_sa_lookups and st.n_lf_steps == ctr.n_lf_steps and list(st.n_smem) == list(ctr.n_smem)
+    # and the stages behind it run on the grown buffers
+    nc, ns = b.chain_run()
+    wch, wsd, wchoff = loader.chain_seeds(want, wcoord, woff, cum, len(g))
+    assert nc == len(wch) and ns == len(wsd)
+    b.close()
+
+
 def test_index_file_path(gpu_toy, tmp_path):
     g, idx, ix = gpu_toy
     fmindex.write_index(str(tmp_path / "t"), idx)

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 
 #include <rocprim/rocprim.hpp>
 
@@ -32,7 +33,8 @@ struct ChainState {
     // per read
     DevBuf n_kept, n_kept_seeds, n_chn, heavy, read_base, frac, wide, chain_off, slice, okeys, okeys2, ovals, ovals2;
     // results
-    DevBuf chains, seeds;
+    DevBuf chains, seeds, seeds2;
+    DevBuf sw_qb, sw_rb, sw_read, sw_newn, sw_res;      // mem_flt_chained_seeds (long reads)
     int64_t n_chains = 0, n_seeds = 0, nseq = 0;
     bool chain_done = false;
     // extension
@@ -52,7 +54,7 @@ void chain_state_free(ChainState *s) {
     if (!s) return;
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
                      &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
-                     &s->chain_off, &s->chains, &s->seeds, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -175,6 +177,70 @@ int bwams_index_set_contigs(bwams_index_t *ix, const bwams_contig_t *contigs, in
     return BWAMS_OK;
 }
 
+// mem_flt_chained_seeds for the chunk's long reads (seed_sw.hip): re-score short seeds with the local-SW
+// kernel, drop the weak ones, re-pack the seed array
+static int flt_chained_seeds(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, const DevBns &bns) {
+    if (!b->idx->d_ref) {
+        set_last_error("bwams_chain_run: reads of ~1100 bases and more need the .0123 reference (mem_flt_chained_seeds)");
+        return BWAMS_ERR_ARG;
+    }
+    int mx = -128, mn = 127;
+    for (int i = 0; i < 25; ++i) { mx = mx > opt->mat[i] ? mx : opt->mat[i]; mn = mn < opt->mat[i] ? mn : opt->mat[i]; }
+    if (mx <= 0 || (opt->o_ins + opt->e_ins) + (opt->o_del + opt->e_del) <= mx - mn) {
+        set_last_error("bwams_chain_run: the local SW of mem_flt_chained_seeds needs max(mat) > 0 and oe_ins + oe_del > max(mat) - min(mat)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = b->stream;
+    const int64_t N = s->n_seeds, N1 = N + 1, C = s->n_chains, n1 = s->nseq + 1;
+    BWAMS_HIP(s->cnt.ensure((size_t)N1 * 6 * 4));
+    BWAMS_HIP(s->ewide.ensure((size_t)(N1 > C + 1 ? N1 : C + 1) * 6 * 8));
+    BWAMS_HIP(s->eoffs.ensure((size_t)(N1 > C + 1 ? N1 : C + 1) * 6 * 8));
+    BWAMS_HIP(s->sw_qb.ensure((size_t)N1 * 4)); BWAMS_HIP(s->sw_rb.ensure((size_t)N1 * 8));
+    BWAMS_HIP(s->sw_read.ensure((size_t)N1 * 4)); BWAMS_HIP(s->sw_newn.ensure((size_t)(C + 1) * 4));
+    BWAMS_HIP(s->seeds2.ensure((size_t)N1 * sizeof(bwams_chain_seed_t)));
+    SeedSwArgs W;
+    W.chains = s->chains.as<bwams_chain_t>(); W.n_chains = C;
+    W.seeds = s->seeds.as<bwams_chain_seed_t>(); W.n_seeds = N;
+    W.enc = b->d_enc; W.cum = b->d_cum; W.nseq = s->nseq; W.ref = b->idx->fmi.ref; W.bns = bns; W.opt = *opt;
+    W.cnt = s->cnt.as<int32_t>(); W.win_qb = s->sw_qb.as<int32_t>(); W.win_rb = s->sw_rb.as<int64_t>();
+    W.seed_read = s->sw_read.as<int32_t>();
+    launch_seedsw_plan(W, s->ewide.as<int64_t>(), st);
+    int rc = scan_rows(b, s->ewide.as<int64_t>(), s->eoffs.as<int64_t>(), 3, N1);
+    if (rc) return rc;
+    int64_t tot[3];
+    for (int r = 0; r < 3; ++r)
+        BWAMS_HIP(hipMemcpyAsync(&tot[r], s->eoffs.as<int64_t>() + r * N1 + N, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    if (tot[1] >= ((int64_t)1 << 31) || tot[2] >= ((int64_t)1 << 31)) {
+        set_last_error("bwams_chain_run: seed re-scoring buffers exceed the 31-bit offsets of SeqPair; use smaller chunks");
+        return BWAMS_ERR_CAPACITY;
+    }
+    BWAMS_HIP(s->lpairs.ensure((size_t)(tot[0] + 1) * sizeof(bwams_seqpair_t)));
+    BWAMS_HIP(s->lqer.ensure((size_t)tot[1] + 64)); BWAMS_HIP(s->lref.ensure((size_t)tot[2] + 64));
+    BWAMS_HIP(s->sw_res.ensure((size_t)(tot[0] + 1) * sizeof(bwams_kswr_t)));
+    if (tot[0] > 0) {
+        launch_seedsw_build(W, s->eoffs.as<int64_t>(), s->lpairs.as<bwams_seqpair_t>(), s->lref.as<uint8_t>(), s->lqer.as<uint8_t>(),
+                            b->cu_count, st);
+        SwParams prm;
+        sw_params(*opt, 0, &prm);
+        launch_ksw(s->lpairs.as<bwams_seqpair_t>(), tot[0], s->lref.as<uint8_t>(), s->lqer.as<uint8_t>(), prm, 208, 200,
+                   s->sw_res.p, b->d_ctr, b->cu_count, st);
+    }
+    // keep / drop, new chain lengths, packed offsets (eoffs row 0 still holds the task index of each seed)
+    int64_t *cw = s->ewide.as<int64_t>();                // reused: C + 1 entries
+    int64_t *coff = s->eoffs.as<int64_t>() + 3 * N1;     // behind the three rows in use
+    launch_seedsw_apply(W, s->eoffs.as<int64_t>(), s->sw_res.as<bwams_kswr_t>(), s->sw_newn.as<int32_t>(), cw, st);
+    if ((rc = scan_rows(b, cw, coff, 1, C + 1))) return rc;
+    int64_t new_total = 0;
+    BWAMS_HIP(hipMemcpyAsync(&new_total, coff + C, 8, hipMemcpyDeviceToHost, st));
+    launch_seedsw_repack(W, s->sw_newn.as<int32_t>(), coff, s->seeds2.as<bwams_chain_seed_t>(), s->chain_off.as<int64_t>(),
+                         s->chain_off.as<int64_t>() + n1, st);
+    BWAMS_HIP(hipStreamSynchronize(st));
+    std::swap(s->seeds, s->seeds2);
+    s->n_seeds = new_total;
+    return BWAMS_OK;
+}
+
 int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_chains, int64_t *n_seeds) {
     if (!b || !b->seed_done || !b->with_sa) {
         set_last_error("bwams_chain_run: run bwams_seed_run(with_sa = 1) first");
@@ -264,23 +330,20 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
         set_last_error("bwams_chain_run: internal B-tree node region exhausted");
         return BWAMS_ERR_CAPACITY;
     }
-    if (b->h_ctr->chain_longread) {
-        set_last_error("bwams_chain_run: a read is long enough for mem_flt_chained_seeds to re-score seeds "
-                       "(5.5 ln L <= 0.05 L); that branch is not built");
-        return BWAMS_ERR_UNSUPPORTED;
-    }
+    const bool has_long = b->h_ctr->chain_longread != 0;
     s->n_chains = tot[0]; s->n_seeds = tot[1]; s->nseq = nseq;
     BWAMS_HIP(s->chains.ensure((size_t)(tot[0] + 1) * sizeof(bwams_chain_t)));
     BWAMS_HIP(s->seeds.ensure((size_t)(tot[1] + 1) * sizeof(bwams_chain_seed_t)));
     if (tot[0] > 0)
         launch_chain_emit(A, s->chain_off.as<int64_t>(), s->chain_off.as<int64_t>() + n1, s->chains.as<bwams_chain_t>(),
                           s->seeds.as<bwams_chain_seed_t>(), st);
+    if (has_long && tot[0] > 0 && (rc = flt_chained_seeds(b, s, opt, A.bns))) return rc;
     BWAMS_HIP(hipEventRecord(s->ev[1], st));
     BWAMS_HIP(hipGetLastError());
     s->chain_done = true;
     s->opt = *opt;
-    if (n_chains) *n_chains = tot[0];
-    if (n_seeds) *n_seeds = tot[1];
+    if (n_chains) *n_chains = s->n_chains;
+    if (n_seeds) *n_seeds = s->n_seeds;
     return BWAMS_OK;
 }
 

@@ -3,8 +3,9 @@
 // Replaces, for a whole chunk of reads, the reference's
 //   mem_chain_seeds   /root/reference/src/bwamem.cpp:789-959  (+ test_and_merge :379-421)
 //   mem_chain_flt     bwamem.cpp:528-646  (+ mem_chain_weight :451-470)
-// and the short-read early-out of mem_flt_chained_seeds (bwamem.cpp:491-526), consuming the
-// SMEMs and SA coordinates that the seeding stage left in HBM.
+// consuming the SMEMs and SA coordinates that the seeding stage left in HBM.  mem_flt_chained_seeds
+// (bwamem.cpp:491-526) acts only on reads of ~1100 bases and more: this file flags such reads, the
+// re-scoring itself is seed_sw.hip.
 //
 // The work is sequential per read (each seed is tested against the chain found by an ordered
 // lookup; then the read's chains are sorted and filtered pairwise) and reads are independent.

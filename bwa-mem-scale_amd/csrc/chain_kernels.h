@@ -85,4 +85,29 @@ void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hi
 void launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st);
 void launch_ext_request_rest(const ExtArgs &A, hipStream_t st);
 
+// ---- mem_flt_chained_seeds for long reads (seed_sw.hip) ----
+struct SeedSwArgs {
+    bwams_chain_t *chains;
+    int64_t n_chains;
+    bwams_chain_seed_t *seeds;
+    int64_t n_seeds;
+    const uint8_t *enc;
+    const int64_t *cum;
+    int64_t nseq;
+    const uint8_t *ref;
+    DevBns bns;
+    bwams_mem_opt_t opt;
+    int32_t *cnt;                  // 3 x n_seeds: runs the SW, query window length, reference window length
+    int32_t *win_qb;               // per seed: start of the query window
+    int64_t *win_rb;               // per seed: start of the reference window
+    int32_t *seed_read;            // per seed: its read
+};
+void launch_seedsw_plan(const SeedSwArgs &A, int64_t *wide, hipStream_t st);
+void launch_seedsw_build(const SeedSwArgs &A, const int64_t *offs, bwams_seqpair_t *pairs, uint8_t *ref, uint8_t *qer,
+                         int cu_count, hipStream_t st);
+void launch_seedsw_apply(const SeedSwArgs &A, const int64_t *offs, const bwams_kswr_t *res, int32_t *new_n, int64_t *wide,
+                         hipStream_t st);
+void launch_seedsw_repack(const SeedSwArgs &A, const int32_t *new_n, const int64_t *new_off, bwams_chain_seed_t *out,
+                          const int64_t *chain_off, int64_t *seed_off, hipStream_t st);
+
 }  // namespace bwams

@@ -245,8 +245,9 @@ int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 int bwams_index_set_contigs(bwams_index_t *idx, const bwams_contig_t *contigs, int32_t n_seqs);
 
 /* Chain the seeds the last bwams_seed_run(with_sa = 1) left on the device and filter the chains.
- * Results stay resident; counts are returned.  BWAMS_ERR_UNSUPPORTED when a read is long enough
- * (5.5 ln L <= 0.05 L, L >= ~1100) for mem_flt_chained_seeds to re-score seeds with ksw_align2. */
+ * Results stay resident; counts are returned.  For reads long enough (5.5 ln L <= 0.05 L, L >= ~1100)
+ * mem_flt_chained_seeds' re-scoring of short seeds (mem_seed_sw -> ksw_align2) runs as well; that step
+ * needs the index's .0123 reference and, like bwams_ksw_align, oe_ins + oe_del > max(mat) - min(mat). */
 int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_chains, int64_t *n_seeds);
 /* chains grouped by read (chain_off[nseq + 1]) in mem_chain_flt's output order; the seeds of
  * chain c are seeds[c.seed_off .. + c.n) in the order mem_chain_seeds appended them. */

@@ -157,7 +157,7 @@ int orc_chain_flt(const bwams_mem_opt_t *opt, int n_chn, bwams_chain_t *a, const
 int64_t orc_chain_seeds(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const bwams_smem_t *smem, int64_t num_smem,
                         const int64_t *sa_coord, const int64_t *sa_off, const int64_t *cum_len, int32_t nseq, int do_flt,
                         bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds, int64_t seed_cap,
-                        int64_t *chain_off, int64_t *n_seeds_out);
+                        int64_t *chain_off, int64_t *n_seeds_out, const uint8_t *ref_string, const uint8_t *enc_qdb);
 
 typedef struct orc_task_dump {      /* the extension task lists as mem_chain2aln_across_reads_V2 builds them */
     int32_t build_only;             /* in: stop after building (regions hold the pre-extension state) */

@@ -10,7 +10,8 @@
  *   mem_chain_weight                bwamem.cpp:451-470   (chain_weight)
  *   mem_chain_flt                   bwamem.cpp:528-646   (orc_chain_flt)
  *   ks_introsort / ks_combsort      ksort.h              (flt_introsort, flt_combsort)
- *   mem_flt_chained_seeds           bwamem.cpp:491-526   (the short-read early-out only)
+ *   mem_flt_chained_seeds, mem_seed_sw   bwamem.cpp:425-449, :491-526   (flt_chained_seeds, seed_sw)
+ *   bns_fetch_seq                   bntseq.cpp:545-574   (the contig clip inside seed_sw)
  *   cal_max_gap                     bwamem.cpp:94-104    (cal_max_gap)
  *   mem_chain2aln_across_reads_V2   bwamem.cpp:2773-3760 (orc_chain2aln)
  *   bns_fetch_seq_v2                bntseq.cpp:484-520   (the contig clip of rmax)
@@ -394,15 +395,79 @@ int orc_chain_flt(const bwams_mem_opt_t *opt, int n_chn, bwams_chain_t *a, const
     return k;
 }
 
+/* mem_seed_sw (bwamem.cpp:425-449): local SW score of a short seed in a +-50 window, or -1 */
+#define MEM_SHORT_EXT 50
+#define MEM_SHORT_LEN 200
+static int seed_sw(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_t *ref_string, int l_query,
+                   const uint8_t *query, const bwams_chain_seed_t *s)
+{
+    const int64_t l_pac = bns->l_pac;
+    int qb, qe;
+    int64_t rb, re, mid;
+    if (s->len >= MEM_SHORT_LEN) return -1;
+    qb = s->qbeg; qe = s->qbeg + s->len;
+    rb = s->rbeg; re = s->rbeg + s->len;
+    mid = (rb + re) >> 1;
+    qb -= MEM_SHORT_EXT; qb = qb > 0 ? qb : 0;
+    qe += MEM_SHORT_EXT; qe = qe < l_query ? qe : l_query;
+    rb -= MEM_SHORT_EXT; rb = rb > 0 ? rb : 0;
+    re += MEM_SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
+    if (rb < l_pac && l_pac < re) {
+        if (mid < l_pac) re = l_pac;
+        else rb = l_pac;
+    }
+    if (qe - qb >= MEM_SHORT_LEN || re - rb >= MEM_SHORT_LEN) return -1;
+    {   /* bns_fetch_seq: clip to the reference sequence holding mid */
+        int is_rev;
+        const int rid = pos2rid(bns, depos(bns, mid, &is_rev));
+        int64_t far_beg = bns->contigs[rid].offset, far_end = far_beg + bns->contigs[rid].len;
+        if (is_rev) { const int64_t t0 = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t0; }
+        rb = rb > far_beg ? rb : far_beg;
+        re = re < far_end ? re : far_end;
+    }
+    bwams_sw_opt_t sw;
+    sw.o_del = opt->o_del; sw.e_del = opt->e_del; sw.o_ins = opt->o_ins; sw.e_ins = opt->e_ins;
+    sw.zdrop = opt->zdrop; sw.end_bonus = 0;
+    memcpy(sw.mat, opt->mat, 25);
+    int out[7];
+    orc_ksw_align2(&sw, qe - qb, query + qb, (int)(re - rb), ref_string + rb, 0x80000 /* KSW_XSTART */, out);
+    return out[0];
+}
+
+/* mem_flt_chained_seeds (bwamem.cpp:491-526) for one read's kept chains: drops the seeds whose local
+ * score is below min_HSP_score and compacts each chain's seed list in place (c->n shrinks). */
+static void flt_chained_seeds(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_t *ref_string, int l_query,
+                              const uint8_t *query, int n_chn, bwams_chain_t *a, bwams_chain_seed_t *seeds)
+{
+    const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log(l_query);
+    const int min_HSP_score = (int)(opt->a * min_l + .499);
+    if (min_l > 0.05f * l_query) return;
+    for (int i = 0; i < n_chn; ++i) {
+        bwams_chain_t *c = &a[i];
+        bwams_chain_seed_t *cs = seeds + c->seed_off;
+        int j, k;
+        for (j = k = 0; j < c->n; ++j) {
+            bwams_chain_seed_t *s = &cs[j];
+            s->score = seed_sw(opt, bns, ref_string, l_query, query, s);
+            if (s->score < 0 || s->score >= min_HSP_score) {
+                s->score = s->score < 0 ? s->len * opt->a : s->score;
+                cs[k++] = *s;
+            }
+        }
+        c->n = k;
+    }
+}
+
 /* mem_chain_seeds for a batch (one work item), followed — when do_flt — by the per-read
- * mem_chain_flt and the short-read early-out of mem_flt_chained_seeds (bwamem.cpp:1354-1372).
+ * mem_chain_flt and mem_flt_chained_seeds (bwamem.cpp:1354-1372; the latter needs ref_string and enc_qdb
+ * and only acts on reads of ~1100 bases and more).
  * Output: flat chains grouped by read (chain_off[nseq+1]); the seeds of chain c are
  * seeds[c.seed_off .. +c.n).  Returns the number of chains, -1 on overflow, -2 when a read is
  * long enough for mem_flt_chained_seeds to re-score seeds (not restated). */
 int64_t orc_chain_seeds(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const bwams_smem_t *smem, int64_t num_smem,
                         const int64_t *sa_coord, const int64_t *sa_off, const int64_t *cum_len, int32_t nseq, int do_flt,
                         bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds, int64_t seed_cap,
-                        int64_t *chain_off, int64_t *n_seeds_out)
+                        int64_t *chain_off, int64_t *n_seeds_out, const uint8_t *ref_string, const uint8_t *enc_qdb)
 {
     const int64_t l_pac = bns->l_pac;
     int64_t smem_ptr = 0, pos = 0, n_chains = 0, n_seeds = 0;
@@ -497,9 +562,11 @@ int64_t orc_chain_seeds(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const 
         if (do_flt) {
             const int kept = orc_chain_flt(opt, (int)(n_chains - first_chain), chains + first_chain, seeds);
             n_chains = first_chain + kept;
-            /* mem_flt_chained_seeds (bwamem.cpp:491-526): only its early-out is restated */
             const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log(l_seq);
-            if (!(min_l > 0.05f * l_seq) && kept) return -2;
+            if (!(min_l > 0.05f * l_seq) && kept && do_flt != 2) {          /* do_flt == 2: stop after mem_chain_flt (test hook) */
+                if (!ref_string || !enc_qdb) return -2;
+                flt_chained_seeds(opt, bns, ref_string, l_seq, enc_qdb + cum_len[l], kept, chains + first_chain, seeds);
+            }
         }
         chain_off[l + 1] = n_chains - first_chain;
     }

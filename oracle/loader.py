@@ -114,7 +114,7 @@ def lib():
         L.orc_flt_sort.restype = None
         L.orc_flt_sort.argtypes = [i64, vp, vp]
         L.orc_chain_seeds.restype = i64
-        L.orc_chain_seeds.argtypes = [vp, vp, vp, i64, vp, vp, vp, i32, C.c_int, vp, i64, vp, i64, vp, vp]
+        L.orc_chain_seeds.argtypes = [vp, vp, vp, i64, vp, vp, vp, i32, C.c_int, vp, i64, vp, i64, vp, vp, vp, vp]
         L.orc_chain2aln.restype = i64
         L.orc_chain2aln.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, vp, vp]
         L.orc_task_dump_free.restype = None
@@ -396,8 +396,10 @@ def ref_chain_lib():
     return L
 
 
-def chain_seeds(smems, sa_coord, sa_off, cum, l_pac, contigs=None, opt: MemOpt | None = None, do_flt: bool = True):
-    """Restated mem_chain_seeds (+ mem_chain_flt when do_flt) -> (chains, seeds, chain_off)."""
+def chain_seeds(smems, sa_coord, sa_off, cum, l_pac, contigs=None, opt: MemOpt | None = None, do_flt: bool | int = True,
+                ref_string=None, enc=None):
+    """Restated mem_chain_seeds (+ mem_chain_flt and mem_flt_chained_seeds when do_flt) -> (chains, seeds, chain_off).
+    ref_string / enc are only needed when a read is long enough (~1100 bases) for mem_flt_chained_seeds to act."""
     opt = opt or default_mem_opt()
     bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
     smems = np.ascontiguousarray(smems, dtype=SMEM_DTYPE)
@@ -411,7 +413,9 @@ def chain_seeds(smems, sa_coord, sa_off, cum, l_pac, contigs=None, opt: MemOpt |
     chain_off = np.zeros(nseq + 1, np.int64)
     n_seeds = C.c_int64(0)
     n = lib().orc_chain_seeds(C.byref(opt), C.byref(bns), _p(smems), len(smems), _p(sa_coord), _p(sa_off), _p(cum), nseq,
-                              int(do_flt), _p(chains), cap, _p(seeds), cap, _p(chain_off), C.byref(n_seeds))
+                              int(do_flt), _p(chains), cap, _p(seeds), cap, _p(chain_off), C.byref(n_seeds),
+                              _p(np.ascontiguousarray(ref_string, np.uint8)) if ref_string is not None else None,
+                              _p(np.ascontiguousarray(enc, np.uint8)) if enc is not None else None)
     assert n >= 0, n
     # compact the seed array to the kept chains, in chain order
     chains = chains[:n].copy()

@@ -61,7 +61,8 @@ def _run(idx, ix, g, reads, contigs=None, seed_kw=None, **mem_kw):
     l_pac = len(g)
     ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
     want = {}
-    want["chains"], want["seeds"], want["chain_off"] = loader.chain_seeds(sm, coord, off, cum, l_pac, contigs=contigs, opt=oopt)
+    want["chains"], want["seeds"], want["chain_off"] = loader.chain_seeds(sm, coord, off, cum, l_pac, contigs=contigs, opt=oopt,
+                                                                          ref_string=ref, enc=enc)
     b = capi.Batch(ix, max(len(cum) - 1, 1), max(int(cum[-1]), 1), max_smem=len(sm) + 4096, max_sa=len(coord) + 4096)
     if contigs is not None:
         ix.set_contigs(contigs)
@@ -274,14 +275,37 @@ def test_chain_upload_then_extend(rep_toy):
     b2.close()
 
 
-def test_long_read_branch_is_refused(rep_toy):
+def test_long_reads_rescore_short_seeds(rep_toy):
+    """Reads of ~1100 bases and more: mem_flt_chained_seeds re-scores every seed shorter than 200 bases with a
+    local SW in a +-50 window and drops the weak ones; chains, seeds (with their new scores) and regions
+    equal the oracle's."""
     g, idx, ix = rep_toy
-    reads = [g[1000:2300].copy()]
-    enc, cum = simulate.flatten_reads(reads)
-    b = capi.Batch(ix, 1, int(cum[-1]))
-    b.seed_upload(enc, cum)
-    b.seed_run(capi.default_seed_opt(), with_sa=True)
-    with pytest.raises(capi.BwamsError) as e:
-        b.chain_run(capi.default_mem_opt())
-    assert e.value.code == -6
+    rng = np.random.default_rng(91)
+    reads = []
+    for i in range(60):
+        L = int(rng.integers(1110, 2200))
+        st = int(rng.integers(0, len(g) - L - 1))
+        r = g[st:st + L].copy()
+        nmut = int(rng.integers(5, 60))
+        pos = rng.integers(0, L, size=nmut)
+        r[pos] = (r[pos] + rng.integers(1, 4, size=nmut)) & 3
+        if i % 3 == 0:                                   # a chimeric tail: short seeds with poor surroundings
+            r[L - 300:] = rng.integers(0, 4, size=300)
+            k = int(rng.integers(L - 280, L - 60))
+            r[k:k + 30] = g[st + k:st + k + 30]
+        reads.append(simulate.revcomp(r) if i % 2 else r)
+    reads += list(simulate.make_reads(g, 200, seed=5)[0])             # short reads in the same chunk are untouched
+    b, want, got, ctx = _run(idx, ix, g, reads)
+    _assert_chains(want, got)
+    long_chain = np.diff(ctx["cum"])[want["chains"]["seqid"]] >= 1110
+    sc, ln = want["seeds"]["score"], want["seeds"]["len"]
+    assert (sc != ln).sum() > 0                                          # some seeds carry an SW score
+    raw_c, raw_s, _ = loader.chain_seeds(ctx["sm"], ctx["coord"], ctx["off"], ctx["cum"], ctx["l_pac"], opt=ctx["oopt"], do_flt=False)
+    assert long_chain.any() and len(want["seeds"]) < int(raw_s["len"].shape[0])
+    b.extend_run(ctx["gopt"])
+    regs, reg_off, aln = b.extend_fetch()
+    wregs, wreg_off, wseeds = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
+                                               ctx["ref"], ctx["l_pac"], opt=ctx["oopt"])
+    assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
+    _assert_regs(regs, wregs, False)
     b.close()

@@ -314,7 +314,64 @@ def test_single_smem_work_item_quirk():
     assert len(ch) >= 1
 
 
+def test_long_reads_seed_rescoring_from_definition():
+    """mem_flt_chained_seeds: for reads with 5.5 ln L <= 0.05 L every kept chain's seeds shorter than 200 bases
+    are re-scored by ksw_align2 (pinned, tests/test_oracle_ksw.py) in a +-50 window; recomputed here in Python
+    from the chains as mem_chain_flt leaves them and compared with the oracle's output."""
+    assert 5.5 * math.log(150) > 0.05 * 150 and 5.5 * math.log(1200) <= 0.05 * 1200
+    from bwams import simulate
+    g, idx = util.toy(30000)
+    rng = np.random.default_rng(17)
+    reads = []
+    for i in range(12):
+        L = int(rng.integers(1110, 1600))
+        st = int(rng.integers(0, len(g) - L - 1))
+        r = g[st:st + L].copy()
+        pos = rng.integers(0, L, size=25)
+        r[pos] = (r[pos] + rng.integers(1, 4, size=25)) & 3
+        r[L - 250:] = rng.integers(0, 4, size=250)
+        k = int(rng.integers(L - 230, L - 60))
+        r[k:k + 28] = g[st + k:st + k + 28]
+        reads.append(simulate.revcomp(r) if i % 2 else r)
+    enc, cum = simulate.flatten_reads(reads)
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum)
+    coord, off = o.sa_lookup(sm)
+    l_pac = len(g)
+    ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    opt = loader.default_mem_opt()
+    got_c, got_s, got_off = loader.chain_seeds(sm, coord, off, cum, l_pac, ref_string=ref, enc=enc)
+    pre_c, pre_s, pre_off = loader.chain_seeds(sm, coord, off, cum, l_pac, do_flt=2)
+    assert np.array_equal(got_off, pre_off) and len(got_c) == len(pre_c)
+    n_sw = n_drop = 0
+    for c_pre, c_got in zip(pre_c, got_c):
+        r = int(c_pre["seqid"])
+        L = int(cum[r + 1] - cum[r])
+        q = enc[cum[r]:cum[r + 1]]
+        min_hsp = int(opt.a * (np.float32(5.5) * math.log(L)) + .499)
+        keep = []
+        for s in pre_s[c_pre["seed_off"]:c_pre["seed_off"] + c_pre["n"]]:
+            score = -1
+            if s["len"] < 200:
+                qb, qe = max(int(s["qbeg"]) - 50, 0), min(int(s["qbeg"] + s["len"]) + 50, L)
+                rb, re = max(int(s["rbeg"]) - 50, 0), min(int(s["rbeg"] + s["len"]) + 50, 2 * l_pac)
+                mid = (int(s["rbeg"]) + int(s["rbeg"] + s["len"])) >> 1
+                if rb < l_pac < re:
+                    if mid < l_pac:
+                        re = l_pac
+                    else:
+                        rb = l_pac
+                if qe - qb < 200 and re - rb < 200:
+                    score = loader.ksw_align2(q[qb:qe], ref[rb:re], loader.KSW_XSTART)[0]
+                    n_sw += 1
+            if score < 0 or score >= min_hsp:
+                keep.append((int(s["rbeg"]), int(s["qbeg"]), int(s["len"]), int(s["len"]) * opt.a if score < 0 else score))
+            else:
+                n_drop += 1
+        gs = got_s[c_got["seed_off"]:c_got["seed_off"] + c_got["n"]]
+        assert [(int(x["rbeg"]), int(x["qbeg"]), int(x["len"]), int(x["score"])) for x in gs] == keep
+    assert n_sw > 50 and n_drop > 5
+
+
 def test_long_read_threshold_reported():
-    """mem_flt_chained_seeds re-scores seeds only when 5.5*ln(L) <= 0.05*L (L >= ~1100); the oracle
-    restates the early-out and reports the other branch as not restated."""
     assert 5.5 * math.log(150) > 0.05 * 150 and 5.5 * math.log(1200) <= 0.05 * 1200

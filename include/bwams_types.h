@@ -121,6 +121,7 @@ typedef struct bwams_mem_opt {
      * every purge decision is unchanged; only the contents of purged regions differ.
      * 1: extend every seed, purged regions hold the reference's dead values too. */
     int32_t extend_all;
+    float   mask_level_redun;           /* mem_opt_t again: 0.95, read by mem_sort_dedup_patch */
 } bwams_mem_opt_t;
 
 /* mem_seed_t (src/bwamem.h:129-140), 32 B, same field offsets. */

@@ -81,7 +81,7 @@ _lib = None
 
 def build() -> str:
     out = os.path.join(HERE, "_build", "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "emf_oracle.c", "chain_oracle.c",
+    srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "emf_oracle.c", "chain_oracle.c", "dedup_oracle.c",
                                             "bwams_oracle.h", "../include/bwams_types.h")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "_build/liboracle.so"])
@@ -119,6 +119,12 @@ def lib():
         L.orc_chain2aln.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, vp, vp]
         L.orc_task_dump_free.restype = None
         L.orc_task_dump_free.argtypes = [vp]
+        L.orc_ksw_global2_score.restype = C.c_int
+        L.orc_ksw_global2_score.argtypes = [C.c_int, vp, C.c_int, vp, vp] + [C.c_int] * 5
+        L.orc_ars_sort.restype = None
+        L.orc_ars_sort.argtypes = [i64, C.c_int, vp, vp, vp, vp]
+        L.orc_regs_finish.restype = i64
+        L.orc_regs_finish.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -289,6 +295,8 @@ def ref_lib(isa: str | None = None):
             for fn in ("ref_bsw_scalar", "ref_bsw_vec16", "ref_bsw_vec8"):
                 getattr(L, fn).restype = None
                 getattr(L, fn).argtypes = [vp, vp, vp, vp, C.c_int, C.c_int]
+            L.ref_ksw_global2.restype = C.c_int
+            L.ref_ksw_global2.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int]
             L.ref_ksw_extend2.restype = C.c_int
             L.ref_ksw_extend2.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int] + [vp] * 5
             L.isa = i
@@ -332,12 +340,13 @@ class MemOpt(C.Structure):
                 ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
                 ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
                 ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
-                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32)]
+                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float)]
 
 
 def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
     """mem_opt_init defaults (src/bwamem.cpp:135-171)."""
     o = MemOpt(a, 6, 1, 6, 1, 5, 5, 100, 100, 19, 0, 1 << 30, 500, 10000, 0.5, 0.5)
+    o.mask_level_redun = 0.95
     for i, v in enumerate(fill_scmat(a, b)):
         o.mat[i] = v
     return o
@@ -393,6 +402,8 @@ def ref_chain_lib():
     L.ref_kbt_script.argtypes = [C.c_int64] + [C.c_void_p] * 4
     L.ref_flt_sort.restype = None
     L.ref_flt_sort.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
+    L.ref_ars_sort.restype = None
+    L.ref_ars_sort.argtypes = [C.c_int64, C.c_int] + [C.c_void_p] * 4
     return L
 
 
@@ -463,3 +474,42 @@ def chain2aln(chains, seeds, chain_off, enc, cum, ref_string, l_pac, contigs=Non
             "right_ref": arr(dump.right_ref, dump.right_ref_bytes, np.uint8), "right_qer": arr(dump.right_qer, dump.right_qer_bytes, np.uint8)})
         lib().orc_task_dump_free(C.byref(dump))
     return tuple(res)
+
+
+# ---------------------------------------------------------------------------
+# the tail of mem_kernel2_core (dedup_oracle.c)
+# ---------------------------------------------------------------------------
+def ksw_global2_score(query, target, w: int, opt: SwOpt | None = None, L=None):
+    """Score of the banded global alignment (ksw_global2 without backtrack); L = ref_lib() runs the reference's."""
+    opt = opt or default_sw_opt()
+    q = np.ascontiguousarray(query, np.uint8)
+    t = np.ascontiguousarray(target, np.uint8)
+    if L is not None:
+        return L.ref_ksw_global2(C.byref(opt), len(q), _p(q), len(t), _p(t), w)
+    return lib().orc_ksw_global2_score(len(q), _p(q), len(t), _p(t), C.cast(opt.mat, C.c_void_p), opt.o_del, opt.e_del,
+                                       opt.o_ins, opt.e_ins, w)
+
+
+def ars_sort(which: int, k0, k1=None, k2=None, L=None):
+    """Order of ks_introsort(mem_ars2) (which = 0, key re) / ks_introsort(mem_ars) (which = 1, keys score, rb, qb)."""
+    k0 = np.ascontiguousarray(k0, np.int64)
+    k1 = np.ascontiguousarray(k1 if k1 is not None else np.zeros(len(k0)), np.int64)
+    k2 = np.ascontiguousarray(k2 if k2 is not None else np.zeros(len(k0)), np.int64)
+    order = np.zeros(len(k0), np.int32)
+    (L.ref_ars_sort if L is not None else lib().orc_ars_sort)(len(k0), which, _p(k0), _p(k1), _p(k2), _p(order))
+    return order
+
+
+def regs_finish(regs, reg_off, enc, cum, ref_string, l_pac, contigs=None, opt: MemOpt | None = None):
+    """Restated tail of mem_kernel2_core: drop purged regions, mem_sort_dedup_patch, ALT mark -> (regs, reg_off)."""
+    opt = opt or default_mem_opt()
+    bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE).copy()
+    reg_off = np.ascontiguousarray(reg_off, np.int64)
+    cum = np.ascontiguousarray(cum, np.int64)
+    enc = np.ascontiguousarray(enc, np.uint8)
+    ref_string = np.ascontiguousarray(ref_string, np.uint8)
+    out_off = np.zeros(len(cum), np.int64)
+    n = lib().orc_regs_finish(C.byref(opt), C.byref(bns), _p(ref_string), _p(enc), _p(cum), len(cum) - 1, _p(regs), _p(reg_off),
+                              _p(out_off))
+    return regs[:n].copy(), out_off

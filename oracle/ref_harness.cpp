@@ -75,4 +75,10 @@ void ref_ksw_align2(const ref_sw_opt *o, int qlen, uint8_t *query, int tlen,
     out[4] = r.te2; out[5] = r.tb; out[6] = r.qb;
 }
 
+/* ksw_global2 (ksw.cpp:558), score only (n_cigar = cigar = NULL), as mem_patch_reg -> bwa_gen_cigar2 calls it. */
+int ref_ksw_global2(const ref_sw_opt *o, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int w)
+{
+    return ksw_global2(qlen, query, tlen, target, 5, o->mat, o->o_del, o->e_del, o->o_ins, o->e_ins, w, 0, 0);
+}
+
 } /* extern "C" */

@@ -26,7 +26,28 @@ KBTREE_INIT(chn, key48_t, chain_cmp)
 #define flt_lt(a, b) ((a).w > (b).w)
 KSORT_INIT(mem_flt, key48_t, flt_lt)
 
+// the two sorts of mem_sort_dedup_patch (bwamem.cpp:176-180) over the fields their comparators read
+typedef struct { int64_t re, rb; int32_t score, qb, id; } reg5_t;
+#define alnreg_slt2(a, b) ((a).re < (b).re)
+KSORT_INIT(mem_ars2, reg5_t, alnreg_slt2)
+#define alnreg_slt(a, b) ((a).score > (b).score || ((a).score == (b).score && ((a).rb < (b).rb || ((a).rb == (b).rb && (a).qb < (b).qb))))
+KSORT_INIT(mem_ars, reg5_t, alnreg_slt)
+
 extern "C" {
+
+// which = 0: ks_introsort(mem_ars2) on k0 = re; which = 1: ks_introsort(mem_ars) on (k0, k1, k2) = (score, rb, qb)
+void ref_ars_sort(int64_t n, int which, const int64_t *k0, const int64_t *k1, const int64_t *k2, int32_t *order)
+{
+    reg5_t *a = (reg5_t *)calloc(n ? n : 1, sizeof(reg5_t));
+    for (int64_t i = 0; i < n; ++i) {
+        a[i].id = (int32_t)i;
+        if (which) { a[i].score = (int32_t)k0[i]; a[i].rb = k1[i]; a[i].qb = (int32_t)k2[i]; }
+        else a[i].re = k0[i];
+    }
+    if (which) ks_introsort(mem_ars, n, a); else ks_introsort(mem_ars2, n, a);
+    for (int64_t i = 0; i < n; ++i) order[i] = a[i].id;
+    free(a);
+}
 
 // for every i: look up the closest key <= pos[i] (when the tree is not empty), then insert i if do_put[i]
 int64_t ref_kbt_script(int64_t n, const int64_t *pos, const uint8_t *do_put, int32_t *lower, int32_t *order)

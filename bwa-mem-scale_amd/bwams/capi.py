@@ -35,6 +35,7 @@ SYMBOLS = [
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
+    "bwams_dedup_run", "bwams_dedup_fetch",
 ]
 
 # records of include/bwams_types.h (layouts of bntann1_t's subset, mem_seed_t, mem_chain_t, mem_alnreg_t)
@@ -96,7 +97,7 @@ class Stats(C.Structure):
                 ("n_retry_left", C.c_int64), ("n_retry_right", C.c_int64),
                 ("ms_chain", C.c_float), ("ms_ext_plan", C.c_float), ("ms_ext_left", C.c_float),
                 ("ms_ext_right", C.c_float), ("ms_ext_purge", C.c_float), ("ms_ext_total", C.c_float),
-                ("n_ext_rounds", C.c_int64)]
+                ("n_ext_rounds", C.c_int64), ("n_final_regs", C.c_int64), ("ms_dedup", C.c_float), ("pad_", C.c_float)]
 
 
 def default_seed_opt() -> SeedOpt:
@@ -175,6 +176,8 @@ def lib():
         L.bwams_extend_run.argtypes = [vp, vp, vp]
         L.bwams_extend_fetch.argtypes = [vp, vp, i64, vp, vp]
         L.bwams_extend_tasks_fetch.argtypes = [vp, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp]
+        L.bwams_dedup_run.argtypes = [vp, vp, vp]
+        L.bwams_dedup_fetch.argtypes = [vp, vp, i64, vp]
         L.bwams_seed_run.argtypes = [vp, vp, C.c_int]
         L.bwams_seed_counts.argtypes = [vp, vp, vp]
         L.bwams_seed_fetch.argtypes = [vp, vp, i64, vp, i64, vp]
@@ -456,6 +459,20 @@ class Batch:
         aln = np.zeros(n, np.int32)
         _chk(lib().bwams_extend_fetch(self.h, _p(regs), n, _p(off), _p(aln)), "bwams_extend_fetch")
         return regs, off, aln
+
+    def dedup_run(self, opt: MemOpt | None = None) -> int:
+        """The tail of mem_kernel2_core (mem_sort_dedup_patch ...) over the regions of extend_run."""
+        opt = opt or default_mem_opt()
+        n = C.c_int64(0)
+        _chk(lib().bwams_dedup_run(self.h, C.byref(opt), C.byref(n)), "bwams_dedup_run")
+        self._n_final = n.value
+        return n.value
+
+    def dedup_fetch(self):
+        regs = np.zeros(self._n_final, ALNREG_DTYPE)
+        off = np.zeros(self._nseq + 1, np.int64)
+        _chk(lib().bwams_dedup_fetch(self.h, _p(regs), self._n_final, _p(off)), "bwams_dedup_fetch")
+        return regs, off
 
     def extend_tasks_fetch(self, side: int):
         n, rb, qb = C.c_int64(0), C.c_int64(0), C.c_int64(0)

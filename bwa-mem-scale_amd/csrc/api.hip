@@ -730,7 +730,10 @@ int bwams_bsw_run(bwams_batch_t *b, int32_t w, const bwams_sw_opt_t *o) {
     prm.max_sc = mx;
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->bsw_cells, 0, sizeof(unsigned long long), b->stream));
     BWAMS_HIP(hipEventRecord(b->ev[6], b->stream));
-    launch_bsw(b->d_pairs, b->n_pairs, b->d_ref, b->d_qer, w, prm, b->max_qlen, b->d_ctr, b->cu_count, b->stream);
+    if (launch_bsw(b->d_pairs, b->n_pairs, b->d_ref, b->d_qer, w, prm, b->max_qlen, b->d_ctr, b->cu_count, b->stream)) {
+        set_last_error("bwams_bsw_run: a query longer than ~18000 bases does not fit the LDS kernel");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
     BWAMS_HIP(hipEventRecord(b->ev[7], b->stream));
     BWAMS_HIP(hipGetLastError());
     return BWAMS_OK;

@@ -35,6 +35,9 @@ struct ChainState {
     // results
     DevBuf chains, seeds, seeds2;
     DevBuf sw_qb, sw_rb, sw_read, sw_newn, sw_res;      // mem_flt_chained_seeds (long reads)
+    DevBuf dd_regs, dd_ord, dd_srt, dd_eh, dd_nout, dd_wide, dd_off, dd_out;   // mem_sort_dedup_patch
+    int64_t n_final = 0;
+    bool dedup_done = false;
     int64_t n_chains = 0, n_seeds = 0, nseq = 0;
     bool chain_done = false;
     // extension
@@ -44,7 +47,7 @@ struct ChainState {
     int64_t n_retry_left = 0, n_retry_right = 0, n_rounds = 0;
     bool built = false, ext_done = false;
     bwams_mem_opt_t opt{};
-    hipEvent_t ev[12] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 selection (first round each), 10-11 all rounds
+    hipEvent_t ev[14] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 selection (first round each), 10-11 all rounds
     bool ev_ok = false;
     hipStream_t aux[5] = {};      // the chaining tiers run concurrently
     hipEvent_t fork = nullptr, join[5] = {};
@@ -54,7 +57,8 @@ void chain_state_free(ChainState *s) {
     if (!s) return;
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
                      &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
-                     &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
+                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -524,7 +528,10 @@ static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, 
     if (n == 0) return BWAMS_OK;
     unsigned long long *d_nretry = &b->d_ctr->n_retry;
     BWAMS_HIP(hipMemsetAsync(d_nretry, 0, sizeof(unsigned long long), st));
-    if (launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st, s->aux, s->fork, s->join)) return BWAMS_ERR_DEVICE;
+    if (int lrc = launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st, s->aux, s->fork, s->join)) {
+        set_last_error(lrc == -2 ? "banded SW: a query longer than ~18000 bases does not fit the LDS kernel" : "banded SW: stream fork/join failed");
+        return lrc == -2 ? BWAMS_ERR_UNSUPPORTED : BWAMS_ERR_DEVICE;
+    }
     launch_ext_post(A, right, pairs, n, A.opt.w, 0, s->retry.as<bwams_seqpair_t>(), d_nretry, st);
     unsigned long long nr = 0;
     BWAMS_HIP(hipMemcpyAsync(&nr, d_nretry, sizeof nr, hipMemcpyDeviceToHost, st));
@@ -612,6 +619,77 @@ int bwams_extend_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, 
     return BWAMS_OK;
 }
 
+/* ---------------------------------------------- the tail of mem_kernel2_core ---- */
+
+int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_regs) {
+    if (!b || !b->chain || !b->chain->ext_done) {
+        set_last_error("bwams_dedup_run: run bwams_extend_run first");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_dedup_run");
+    if (rc) return rc;
+    ChainState *s = b->chain;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    s->dedup_done = false;
+    const int64_t N = s->n_seeds, n1 = s->nseq + 1;
+    const int64_t L = b->max_read_len > 1 ? b->max_read_len : 1;
+    // strips for the global alignment: as many lanes as 1 GiB of (h, e) rows allows, at most 64 Ki
+    int64_t n_lanes = ((int64_t)1 << 30) / ((L + 2) * 8);
+    n_lanes = n_lanes > 65536 ? 65536 : n_lanes < 64 ? 64 : n_lanes;
+    const int64_t n_waves = (int64_t)b->cu_count * 4;
+    BWAMS_HIP(s->dd_regs.ensure((size_t)(N + 1) * sizeof(bwams_alnreg_t)));
+    BWAMS_HIP(s->dd_out.ensure((size_t)(N + 1) * sizeof(bwams_alnreg_t)));
+    BWAMS_HIP(s->dd_ord.ensure((size_t)(N + 1) * 4));
+    BWAMS_HIP(s->dd_srt.ensure(dedup_sortrec_bytes(N)));
+    BWAMS_HIP(s->dd_eh.ensure((size_t)(n_lanes + n_waves) * (size_t)(L + 2) * 8));
+    BWAMS_HIP(s->dd_nout.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->dd_wide.ensure((size_t)n1 * 16));
+    BWAMS_HIP(s->dd_off.ensure((size_t)n1 * 8));
+    DedupArgs D;
+    D.regs = s->dd_regs.as<bwams_alnreg_t>();
+    D.seed_off = s->chain_off.as<int64_t>() + n1;
+    D.enc = b->d_enc; D.cum = b->d_cum; D.nseq = s->nseq; D.ref = b->idx->fmi.ref;
+    if ((rc = dev_bns(b->idx, &D.bns))) return rc;
+    D.opt = *opt;
+    D.ord = s->dd_ord.as<int32_t>(); D.srt = s->dd_srt.p; D.eh = s->dd_eh.as<int2>(); D.eh_lanes = n_lanes;
+    D.max_read_len = (int32_t)L; D.n_out = s->dd_nout.as<int32_t>();
+    BWAMS_HIP(hipEventRecord(s->ev[12], st));
+    // work on a copy: bwams_extend_fetch stays valid
+    if (N) BWAMS_HIP(hipMemcpyAsync(D.regs, s->regs.p, (size_t)N * sizeof(bwams_alnreg_t), hipMemcpyDeviceToDevice, st));
+    BWAMS_HIP(hipMemsetAsync(D.n_out, 0, (size_t)n1 * 4, st));
+    launch_dedup(D, n_lanes, n_waves, st);
+    int64_t total = 0;
+    if (s->nseq > 0) {
+        widen2_kernel<<<(unsigned)((2 * n1 + 255) / 256), 256, 0, st>>>(D.n_out, D.n_out, s->nseq, s->dd_wide.as<int64_t>());
+        if ((rc = scan_rows(b, s->dd_wide.as<int64_t>(), s->dd_off.as<int64_t>(), 1, n1))) return rc;
+        launch_dedup_gather(D, s->dd_off.as<int64_t>(), s->dd_out.as<bwams_alnreg_t>(), st);
+        BWAMS_HIP(hipMemcpyAsync(&total, s->dd_off.as<int64_t>() + s->nseq, 8, hipMemcpyDeviceToHost, st));
+    }
+    BWAMS_HIP(hipEventRecord(s->ev[13], st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(hipGetLastError());
+    s->n_final = total;
+    s->dedup_done = true;
+    if (n_regs) *n_regs = total;
+    return BWAMS_OK;
+}
+
+int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off) {
+    if (!b || !b->chain || !b->chain->dedup_done) {
+        set_last_error("bwams_dedup_fetch: run bwams_dedup_run first");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    if (s->n_final > reg_cap) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    if (s->n_final) BWAMS_HIP(hipMemcpyAsync(regs, s->dd_out.p, (size_t)s->n_final * sizeof(bwams_alnreg_t), hipMemcpyDeviceToHost, st));
+    if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->dd_off.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    return BWAMS_OK;
+}
+
 int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref,
                              int64_t ref_cap, uint8_t *qer, int64_t qer_cap, int64_t *n_pairs, int64_t *ref_bytes,
                              int64_t *qer_bytes) {
@@ -656,6 +734,7 @@ void chain_state_stats(const ChainState *s, bwams_stats_t *out) {
         el(10, 11, &out->ms_ext_total);
         out->n_ext_rounds = s->n_rounds;
     }
+    if (s->dedup_done) { el(12, 13, &out->ms_dedup); out->n_final_regs = s->n_final; }
     (void)hipGetLastError();
 }
 }  // namespace bwams

@@ -435,12 +435,18 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
     }
     // the longest queries first: their tasks are the most expensive
     if (n_class > 3) {
+        // (h, e) row + query of one task per wave in LDS: fewer waves per block for very long queries
         const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
-        const size_t lds = per_wave * kWavesPerBlock;
+        int waves = (int)((size_t)160 * 1024 / per_wave);
+        if (waves < 1) return -2;                  // a query of more than ~18 k bases does not fit a CU's LDS
+        waves = waves < kWavesPerBlock ? waves : kWavesPerBlock;
+        const size_t lds = per_wave * (size_t)waves;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        bsw_kernel<<<(unsigned)blocks, kWavesPerBlock * 64, lds, q[3]>>>(pairs, n, ref, qer, w, prm, qmax, 192, ctr, &ctr->bsw_head[3]);
+        int64_t lblocks = (n + waves - 1) / waves;
+        if (lblocks > maxb) lblocks = maxb;
+        bsw_kernel<<<(unsigned)lblocks, waves * 64, lds, q[3]>>>(pairs, n, ref, qer, w, prm, qmax, 192, ctr, &ctr->bsw_head[3]);
     }
     if (n_class > 2) bsw_kernel_reg<3><<<(unsigned)blocks, kWavesPerBlock * 64, 0, q[2]>>>(pairs, n, ref, qer, w, prm, 128, ctr, &ctr->bsw_head[2]);
     if (n_class > 1) bsw_kernel_reg<2><<<(unsigned)blocks, kWavesPerBlock * 64, 0, q[1]>>>(pairs, n, ref, qer, w, prm, 64, ctr, &ctr->bsw_head[1]);

@@ -110,4 +110,25 @@ void launch_seedsw_apply(const SeedSwArgs &A, const int64_t *offs, const bwams_k
 void launch_seedsw_repack(const SeedSwArgs &A, const int32_t *new_n, const int64_t *new_off, bwams_chain_seed_t *out,
                           const int64_t *chain_off, int64_t *seed_off, hipStream_t st);
 
+// ---- the tail of mem_kernel2_core: mem_sort_dedup_patch (dedup.hip) ----
+struct DedupArgs {
+    bwams_alnreg_t *regs;          // a working copy of the extension's regions (modified in place)
+    const int64_t *seed_off;       // nseq + 1: a read's slots
+    const uint8_t *enc;
+    const int64_t *cum;
+    int64_t nseq;
+    const uint8_t *ref;
+    DevBns bns;
+    bwams_mem_opt_t opt;
+    int32_t *ord;                  // per slot: the read's surviving regions in their current order
+    void *srt;                     // per slot: 24-byte sort records (reads that do not use LDS)
+    int2 *eh;                      // (h, e) rows of the global alignment: max_read_len + 2 cells per lane
+    int64_t eh_lanes;              // strips [0, eh_lanes) belong to dedup_kernel's lanes, the following ones to the wave kernel
+    int32_t max_read_len;
+    int32_t *n_out;                // per read: regions left
+};
+size_t dedup_sortrec_bytes(int64_t n);
+void launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st);
+void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
+
 }  // namespace bwams

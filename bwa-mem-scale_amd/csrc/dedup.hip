@@ -1,0 +1,284 @@
+// dedup.hip — the tail of mem_kernel2_core on the device (/root/reference/src/bwamem.cpp:1446-1481):
+// purged regions dropped, mem_sort_dedup_patch (:314-375) with mem_patch_reg (:199-250) and the score-only
+// global alignment it calls (bwa_gen_cigar2 -> ksw_global2, bwa.cpp:380-428, ksw.cpp:558-649), the ALT mark.
+//
+// Sequential per read (sort by end, pairwise redundancy / patch tests against the regions just upstream, sort
+// by score, drop identical hits), a handful of regions per read: one lane per read for reads with few regions,
+// one wavefront per read (sort records in LDS, lane 0 drives) for the others.  Both sorts are ksort.h's
+// introsort — unstable, so reproduced operation by operation (see chain.hip) on 24-byte sort records.
+// The banded global alignment of a patch candidate runs in the lane (row-by-row, (h, e) row in a per-lane
+// HBM strip): rare, and a few hundred microseconds for 150-base reads.
+#include "common.h"
+#include "chain_kernels.h"
+
+namespace bwams {
+namespace {
+
+constexpr int kLightN = 32;          // regions per read handled by a single lane
+constexpr int kLdsN = 1024;          // sort records a wavefront keeps in LDS
+constexpr int MINUS_INF = -0x40000000;
+
+struct SortRec { int64_t k; int32_t s, q, idx; int32_t pad_; };      // ars2: k = re; ars: k = rb, s = score, q = qb
+
+struct LtEnd   { __device__ __forceinline__ bool operator()(const SortRec &a, const SortRec &b) const { return a.k < b.k; } };
+struct LtScore { __device__ __forceinline__ bool operator()(const SortRec &a, const SortRec &b) const {
+    return a.s > b.s || (a.s == b.s && (a.k < b.k || (a.k == b.k && a.q < b.q))); } };
+
+template <class LT> __device__ __forceinline__ void r_insertsort(SortRec *a, int s, int t, LT lt) {
+    for (int i = s + 1; i < t; ++i)
+        for (int j = i; j > s && lt(a[j], a[j - 1]); --j) { const SortRec x = a[j]; a[j] = a[j - 1]; a[j - 1] = x; }
+}
+template <class LT> __device__ __forceinline__ void r_combsort(SortRec *a, int n, LT lt) {
+    const double shrink = 1.2473309501039786540366528676643;
+    bool do_swap;
+    unsigned long long gap = (unsigned long long)n;
+    do {
+        if (gap > 2) {
+            gap = (unsigned long long)((double)gap / shrink);
+            if (gap == 9 || gap == 10) gap = 11;
+        }
+        do_swap = false;
+        for (long long i = 0; i < (long long)n - (long long)gap; ++i) {
+            const long long j = i + (long long)gap;
+            if (lt(a[j], a[i])) { const SortRec x = a[i]; a[i] = a[j]; a[j] = x; do_swap = true; }
+        }
+    } while (do_swap || gap > 2);
+    if (gap != 1) r_insertsort(a, 0, n, lt);
+}
+template <class LT> __device__ __forceinline__ void r_introsort(SortRec *a, int n, LT lt) {
+    if (n < 1) return;
+    if (n == 2) { if (lt(a[1], a[0])) { const SortRec x = a[0]; a[0] = a[1]; a[1] = x; } return; }
+    int d;
+    for (d = 2; (1ul << d) < (unsigned long)n; ++d);
+    int stk_l[40], stk_r[40], stk_d[40], top = 0;
+    int s = 0, t = n - 1;
+    d <<= 1;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) { r_combsort(a + s, t - s + 1, lt); t = s; continue; }
+            int i = s, j = t, k = i + ((j - i) >> 1) + 1;
+            if (lt(a[k], a[i])) { if (lt(a[k], a[j])) k = j; }
+            else k = lt(a[j], a[i]) ? i : j;
+            const SortRec rp = a[k];
+            if (k != t) { a[k] = a[t]; a[t] = rp; }
+            for (;;) {
+                do ++i; while (lt(a[i], rp));
+                do --j; while (i <= j && lt(rp, a[j]));
+                if (j <= i) break;
+                const SortRec x = a[i]; a[i] = a[j]; a[j] = x;
+            }
+            { const SortRec x = a[i]; a[i] = a[t]; a[t] = x; }
+            if (i - s > t - i) {
+                if (i - s > 16) { stk_l[top] = s; stk_r[top] = i - 1; stk_d[top] = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { stk_l[top] = i + 1; stk_r[top] = t; stk_d[top] = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+        } else {
+            if (top == 0) { r_insertsort(a, 0, n, lt); return; }
+            --top; s = stk_l[top]; t = stk_r[top]; d = stk_d[top];
+        }
+    }
+}
+
+// ksw_global2 without backtrack; query[j] = qseq[qs * j], target[i] = tseq[ts * i] (ts = qs = -1 on the reverse strand,
+// where bwa_gen_cigar2 reverses both sequences); eh: qlen + 1 cells of this lane's strip
+__device__ int global_score(const bwams_mem_opt_t &o, int qlen, const uint8_t *qseq, int qs, int tlen, const uint8_t *tseq, int ts,
+                            int w, int2 *eh) {
+    const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+    eh[0] = make_int2(0, MINUS_INF);
+    int j;
+    for (j = 1; j <= qlen && j <= w; ++j) eh[j] = make_int2(-(o.o_ins + o.e_ins * j), MINUS_INF);
+    for (; j <= qlen; ++j) eh[j] = make_int2(MINUS_INF, MINUS_INF);
+    for (int i = 0; i < tlen; ++i) {
+        int f = MINUS_INF;
+        const int8_t *mrow = &o.mat[tseq[(int64_t)ts * i] * 5];
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        int h1 = beg == 0 ? -(o.o_del + o.e_del * (i + 1)) : MINUS_INF;
+        for (j = beg; j < end; ++j) {
+            const int2 p = eh[j];
+            int m = p.x, e = p.y;
+            m += mrow[qseq[(int64_t)qs * j]];
+            int h = m >= e ? m : e;
+            h = h >= f ? h : f;
+            int t = m - oe_del;
+            e -= o.e_del;
+            e = e > t ? e : t;
+            eh[j] = make_int2(h1, e);
+            h1 = h;
+            t = m - oe_ins;
+            f -= o.e_ins;
+            f = f > t ? f : t;
+        }
+        eh[end] = make_int2(h1, MINUS_INF);
+    }
+    return eh[qlen].x;
+}
+
+// mem_patch_reg (bwamem.cpp:199-250): score of the merged alignment, or 0
+__device__ int patch_reg(const DedupArgs &A, const uint8_t *query, const bwams_alnreg_t &a, const bwams_alnreg_t &b, int *w_out, int2 *eh) {
+    const bwams_mem_opt_t &opt = A.opt;
+    const int64_t l_pac = A.bns.l_pac;
+    if (a.rb < l_pac && b.rb >= l_pac) return 0;
+    if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+    int w = (int)((a.re - b.rb) - (a.qe - b.qb));
+    w = w > 0 ? w : -w;
+    double r = (double)(a.re - b.rb) / (double)(b.re - a.rb) - (double)(a.qe - b.qb) / (double)(b.qe - a.qb);
+    r = r > 0. ? r : -r;
+    if (a.re < b.rb || a.qe < b.qb) {
+        if (w > (opt.w << 1) || r >= (double)0.05f) return 0;
+    } else if (w > (opt.w << 2) || r >= (double)(0.05f * 2)) return 0;
+    w += a.w + b.w;
+    w = w < (opt.w << 2) ? w : (opt.w << 2);
+    // bwa_gen_cigar2 (score only)
+    const int l_query = b.qe - a.qb;
+    const int64_t rb = a.rb, re = b.re;
+    int score = 0;
+    if (!(l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac))) {
+        const int64_t rlen = re - rb;
+        const bool rev = rb >= l_pac;
+        const uint8_t *qseq = rev ? query + a.qb + l_query - 1 : query + a.qb;
+        const uint8_t *tseq = rev ? A.ref + rb + rlen - 1 : A.ref + rb;
+        const int st = rev ? -1 : 1;
+        if (l_query == rlen && w == 0) {
+            for (int i = 0; i < l_query; ++i) score += opt.mat[tseq[(int64_t)st * i] * 5 + qseq[(int64_t)st * i]];
+        } else {
+            int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+            int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+            int max_gap = max_ins > max_del ? max_ins : max_del;
+            max_gap = max_gap > 1 ? max_gap : 1;
+            const int dl = (int)(rlen - l_query) < 0 ? -(int)(rlen - l_query) : (int)(rlen - l_query);
+            int ww = (max_gap + dl + 1) >> 1;
+            ww = ww < w ? ww : w;
+            const int min_w = dl + 3;
+            ww = ww > min_w ? ww : min_w;
+            score = global_score(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh);
+        }
+    }
+    const int q_s = (int)((double)(b.qe - a.qb) / (double)((b.qe - b.qb) + (a.qe - a.qb)) * (double)(b.score + a.score) + .499);
+    const int r_s = (int)((double)(b.re - a.rb) / (double)((b.re - b.rb) + (a.re - a.rb)) * (double)(b.score + a.score) + .499);
+    if ((double)score / (double)(q_s > r_s ? q_s : r_s) < (double)0.90f) return 0;
+    *w_out = w;
+    return score;
+}
+
+// The whole per-read procedure, run by one lane.  srt: room for the read's sort records (HBM strip or LDS).
+__device__ int dedup_read(const DedupArgs &A, int64_t r, SortRec *srt, int2 *eh) {
+    const int64_t reg0 = A.seed_off[r];
+    const int av_n = (int)(A.seed_off[r + 1] - reg0);
+    bwams_alnreg_t *a = A.regs + reg0;
+    int32_t *ord = A.ord + reg0;
+    const uint8_t *query = A.enc + A.cum[r];
+    int n = 0;
+    for (int i = 0; i < av_n; ++i)                         // bwamem.cpp:1446-1456
+        if (a[i].qe > a[i].qb) ord[n++] = i;
+    if (n > 1) {
+        for (int i = 0; i < n; ++i) { SortRec x; x.k = a[ord[i]].re; x.s = 0; x.q = 0; x.idx = ord[i]; x.pad_ = 0; srt[i] = x; }
+        r_introsort(srt, n, LtEnd());
+        for (int i = 0; i < n; ++i) { ord[i] = srt[i].idx; a[ord[i]].n_comp_is_alt = 1; }
+        for (int i = 1; i < n; ++i) {
+            bwams_alnreg_t *p = &a[ord[i]];
+            const bwams_alnreg_t *pr = &a[ord[i - 1]];
+            if (p->rid != pr->rid || p->rb >= pr->re + A.opt.max_chain_gap) continue;
+            for (int j = i - 1; j >= 0; --j) {
+                bwams_alnreg_t *q = &a[ord[j]];
+                if (!(p->rid == q->rid && p->rb < q->re + A.opt.max_chain_gap)) break;
+                if (q->qe == q->qb) continue;
+                const int64_t or_ = q->re - p->rb;
+                const int64_t oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+                const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+                const int64_t mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+                int score, w;
+                if ((float)or_ > A.opt.mask_level_redun * (float)mr && (float)oq > A.opt.mask_level_redun * (float)mq) {
+                    if (p->score < q->score) { p->qe = p->qb; break; }
+                    else q->qe = q->qb;
+                } else if (q->rb < p->rb && (score = patch_reg(A, query, *q, *p, &w, eh)) > 0) {
+                    p->n_comp_is_alt = (p->n_comp_is_alt + q->n_comp_is_alt + 1) & 0x3fffffff;
+                    p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+                    p->sub = p->sub > q->sub ? p->sub : q->sub;
+                    p->csub = p->csub > q->csub ? p->csub : q->csub;
+                    p->qb = q->qb; p->rb = q->rb;
+                    p->truesc = p->score = score;
+                    p->w = w;
+                    q->qb = q->qe;
+                }
+            }
+        }
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+            if (a[ord[i]].qe > a[ord[i]].qb) ord[m++] = ord[i];
+        n = m;
+        for (int i = 0; i < n; ++i) {
+            const bwams_alnreg_t *p = &a[ord[i]];
+            SortRec x; x.k = p->rb; x.s = p->score; x.q = p->qb; x.idx = ord[i]; x.pad_ = 0;
+            srt[i] = x;
+        }
+        r_introsort(srt, n, LtScore());
+        for (int i = 0; i < n; ++i) ord[i] = srt[i].idx;
+        for (int i = 1; i < n; ++i) {
+            bwams_alnreg_t *p = &a[ord[i]];
+            const bwams_alnreg_t *pr = &a[ord[i - 1]];
+            if (p->score == pr->score && p->rb == pr->rb && p->qb == pr->qb) p->qe = p->qb;
+        }
+        m = n ? 1 : 0;
+        for (int i = 1; i < n; ++i)
+            if (a[ord[i]].qe > a[ord[i]].qb) ord[m++] = ord[i];
+        n = m;
+    }
+    for (int i = 0; i < n; ++i) {                          // bwamem.cpp:1470-1481
+        bwams_alnreg_t *p = &a[ord[i]];
+        if (p->rid >= 0 && A.bns.contigs[p->rid].is_alt) p->n_comp_is_alt = (p->n_comp_is_alt & 0x3fffffff) | (1 << 30);
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(64) void dedup_kernel(DedupArgs A, int64_t n_lanes) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_lanes) return;
+    int2 *eh = A.eh + g * (int64_t)(A.max_read_len + 2);
+    for (int64_t r = g; r < A.nseq; r += n_lanes) {
+        const int64_t reg0 = A.seed_off[r];
+        const int av_n = (int)(A.seed_off[r + 1] - reg0);
+        if (av_n > kLightN) continue;
+        A.n_out[r] = av_n ? dedup_read(A, r, reinterpret_cast<SortRec *>(A.srt) + reg0, eh) : 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_waves) {
+    __shared__ SortRec l_srt[kLdsN];
+    const int lane = threadIdx.x;
+    int2 *eh = A.eh + (A.eh_lanes + blockIdx.x) * (int64_t)(A.max_read_len + 2);
+    for (int64_t r = blockIdx.x; r < A.nseq; r += n_waves) {
+        const int64_t reg0 = A.seed_off[r];
+        const int av_n = (int)(A.seed_off[r + 1] - reg0);
+        if (av_n <= kLightN) continue;
+        if (lane == 0) A.n_out[r] = dedup_read(A, r, av_n <= kLdsN ? l_srt : reinterpret_cast<SortRec *>(A.srt) + reg0, eh);
+    }
+}
+
+// lane per read: the surviving regions, in their final order
+__global__ void dedup_gather_kernel(DedupArgs A, const int64_t *__restrict__ out_off, bwams_alnreg_t *out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.nseq) return;
+    const int64_t reg0 = A.seed_off[r];
+    const int n = A.n_out[r];
+    for (int i = 0; i < n; ++i) out[out_off[r] + i] = A.regs[reg0 + A.ord[reg0 + i]];
+}
+
+}  // namespace
+
+size_t dedup_sortrec_bytes(int64_t n) { return (size_t)(n + 1) * sizeof(SortRec); }
+
+void launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    dedup_kernel<<<(unsigned)((n_lanes + 63) / 64), 64, 0, st>>>(A, n_lanes);
+    dedup_wave_kernel<<<(unsigned)n_waves, 64, 0, st>>>(A, n_waves);
+}
+void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    dedup_gather_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A, out_off, out);
+}
+
+}  // namespace bwams

@@ -230,6 +230,9 @@ typedef struct bwams_stats {
     int64_t n_retry_left, n_retry_right;  /* tasks re-run at twice the band width */
     float   ms_chain, ms_ext_plan, ms_ext_left, ms_ext_right, ms_ext_purge, ms_ext_total;   /* left/right/purge: first round */
     int64_t n_ext_rounds;                 /* extension rounds of the last bwams_extend_run */
+    int64_t n_final_regs;                 /* regions left by the last bwams_dedup_run */
+    float   ms_dedup;
+    float   pad_;
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 
@@ -263,6 +266,12 @@ int bwams_chain_upload(bwams_batch_t *b, const bwams_chain_t *chains, int64_t n_
 int bwams_extend_build(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_left, int64_t *n_right);
 int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_regs);
 int bwams_extend_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, int32_t *seed_aln);
+/* The tail of mem_kernel2_core (src/bwamem.cpp:1446-1481) on the regions of bwams_extend_run: purged regions
+ * dropped, mem_sort_dedup_patch (redundant hits removed, colinear neighbours merged by mem_patch_reg's global
+ * alignment, identical hits removed; result ordered by score, rb, qb), the ALT mark.  Needs mask_level_redun in
+ * the options.  The extension's regions stay available to bwams_extend_fetch. */
+int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_regs);
+int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off);
 /* the task lists as built (side 0 = left, 1 = right), for inspection */
 int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref,
                              int64_t ref_cap, uint8_t *qer, int64_t qer_cap, int64_t *n_pairs, int64_t *ref_bytes,

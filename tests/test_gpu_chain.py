@@ -309,3 +309,68 @@ def test_long_reads_rescore_short_seeds(rep_toy):
     assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
     _assert_regs(regs, wregs, False)
     b.close()
+
+
+FINAL_FIELDS = REG_FIELDS
+
+
+def _assert_final(b, ctx, want, contigs=None):
+    wregs, wreg_off, _ = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
+                                          ctx["ref"], ctx["l_pac"], contigs=contigs, opt=ctx["oopt"])
+    wfin, wfin_off = loader.regs_finish(wregs, wreg_off, ctx["enc"], ctx["cum"], ctx["ref"], ctx["l_pac"], contigs=contigs,
+                                        opt=ctx["oopt"])
+    b.extend_run(ctx["gopt"])
+    n = b.dedup_run(ctx["gopt"])
+    fin, fin_off = b.dedup_fetch()
+    assert n == len(wfin) and np.array_equal(fin_off, wfin_off)
+    for f in FINAL_FIELDS:
+        assert np.array_equal(fin[f], wfin[f]), f
+    return wfin, wregs
+
+
+def test_final_regions_match_oracle(rep_toy):
+    """mem_sort_dedup_patch on the device: redundant and identical hits removed, order by (score, rb, qb)."""
+    g, idx, ix = rep_toy
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 3000, 61))
+    wfin, wregs = _assert_final(b, ctx, want)
+    alive = ~((wregs["qb"] == -1) & (wregs["qe"] == -1))
+    assert 0 < len(wfin) <= alive.sum()
+    assert b.stats().n_final_regs == len(wfin)
+    # the extension's own regions are still there
+    regs, reg_off, aln = b.extend_fetch()
+    assert len(regs) == len(wregs)
+    b.close()
+
+
+@pytest.mark.parametrize("kw", [dict(mask_level_redun=0.5), dict(max_chain_gap=300), dict(w=30), dict(max_occ=50)])
+def test_final_regions_options(rep_toy, kw):
+    g, idx, ix = rep_toy
+    b, want, got, ctx = _run(idx, ix, g, _reads(g, 1500, 63), **kw)
+    _assert_final(b, ctx, want)
+    b.close()
+
+
+def test_final_regions_patch_split_alignments(rep_toy):
+    """Long reads with a deletion wider than the chaining band but within twice the band: two chains, two regions,
+    merged into one by mem_patch_reg's global alignment (score-only ksw_global2, both strands); ALT contigs marked."""
+    g, idx, ix = rep_toy
+    rng = np.random.default_rng(71)
+    reads = []
+    for i in range(40):
+        st = int(rng.integers(0, len(g) - 6000))
+        gap = int(rng.integers(120, 200))
+        r = np.concatenate([g[st:st + 2500], g[st + 2500 + gap:st + 5200 + gap]])
+        pos = rng.integers(0, len(r), size=20)
+        r[pos] = (r[pos] + 1) & 3
+        reads.append(simulate.revcomp(r) if i % 2 else r)
+    reads += list(simulate.make_reads(g, 300, seed=6)[0])
+    contigs = np.zeros(2, capi.CONTIG_DTYPE)
+    contigs["offset"], contigs["len"], contigs["is_alt"] = [0, 70000], [70000, len(g) - 70000], [0, 1]
+    b, want, got, ctx = _run(idx, ix, g, reads, contigs=contigs)
+    wfin, wregs = _assert_final(b, ctx, want, contigs=contigs)
+    merged = (wfin["n_comp_is_alt"] & 0x3fffffff) > 1
+    assert merged.sum() >= 10 and (wfin["n_comp_is_alt"] >> 30).sum() > 0
+    b.close()
+    c = np.zeros(1, capi.CONTIG_DTYPE)
+    c["len"] = len(g)
+    ix.set_contigs(c)

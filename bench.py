@@ -5,7 +5,7 @@ One "step" = one pass of the hot path over one resident batch of synthetic reads
   FM-index seeding (SMEM rounds 1-3 -> (rid,m,n) sort -> SA lookup) -> seed chaining and
   chain filtering -> extension tasks of the kept chains' seeds -> banded-SW left and right
   extension with the band-retry rule -> region bookkeeping and purge (in rounds: a seed the
-  reference would extend and then discard is not extended),
+  reference would extend and then discard is not extended) -> mem_sort_dedup_patch,
 all on the GPU through the C-ABI, with reads and index resident in HBM when the clock starts.
 Workload = BASELINE.json configs[1] (1M x 150 bp single-end, FM-index only, 1 GPU);
 GRCh38 is not available offline, so the index is built (on the GPU) over a seeded
@@ -61,8 +61,9 @@ def cpu_baseline(idx_host_arrays, reads, n_sample, threads):
             sm = o.collect_smem(enc, cum)
             coord, off = o.sa_lookup(sm, 500)
             ch, sd, choff = loader.chain_seeds(sm, coord, off, cum, l_pac)
-            regs, _, _ = loader.chain2aln(ch, sd, choff, enc, cum, idx_host_arrays.ref_0123, l_pac)
-            n += len(regs)
+            regs, reg_off, _ = loader.chain2aln(ch, sd, choff, enc, cum, idx_host_arrays.ref_0123, l_pac)
+            fin, _ = loader.regs_finish(regs, reg_off, enc, cum, idx_host_arrays.ref_0123, l_pac)
+            n += len(fin)
         return n
 
     # one timed region around everything
@@ -156,6 +157,7 @@ def main():
         batch.seed_run(seed_opt, with_sa=True)
         batch.chain_run(mem_opt)
         batch.extend_run(mem_opt)
+        batch.dedup_run(mem_opt)
 
     for _ in range(args.warmup):
         step()
@@ -221,13 +223,13 @@ def main():
                             f"{'' if (args.fma or args.emf) else ' only (no ERT/FMA/EMF)'}; step = {'EMF probe, ' if args.emf else ''}pack reads, SMEM r1-r3, sort, "
                             f"SA lookup, chaining + chain filter, extension tasks of the seeds of the kept chains, "
                             f"banded-SW left then right (w=100, retry at 200), region bookkeeping + purge (seeds the reference would extend "
-                            f"and then discard are not extended); everything on the GPU",
+                            f"and then discard are not extended), mem_sort_dedup_patch; everything on the GPU",
                 "genome_mbp": args.genome_mbp,
                 "index_bytes": ix.nbytes,
                 "reads_per_gpu": R,
                 "chains": int(st.n_chains), "regions": int(st.n_chain_seeds),
                 "bsw_tasks": int(st.n_left + st.n_right), "bsw_retries": int(st.n_retry_left + st.n_retry_right),
-                "ext_rounds": int(st.n_ext_rounds),
+                "ext_rounds": int(st.n_ext_rounds), "final_regions": int(st.n_final_regs),
                 "parallelism": f"reads sharded x{world}, index replicated",
             },
             "stage_ms": {
@@ -244,6 +246,7 @@ def main():
                 "ext_right": round(float(np.mean([s.ms_ext_right for s in per_step])), 3),
                 "ext_select": round(float(np.mean([s.ms_ext_purge for s in per_step])), 3),
                 "ext_total": round(float(np.mean([s.ms_ext_total for s in per_step])), 3),
+                "dedup": round(float(np.mean([s.ms_dedup for s in per_step])), 3),
                 "note": "ext_tasks/left/right/select are the first extension round; ext_total covers all rounds",
             },
             "events_per_read": {
@@ -292,10 +295,11 @@ def main():
                 batch.chain_run(mem_opt)
                 batch.chain_fetch()                         # download chains
                 batch.extend_run(mem_opt)
-                batch.extend_fetch()                        # download regions
+                batch.dedup_run(mem_opt)
+                batch.dedup_fetch()                         # download the final regions
             dt = (time.perf_counter() - t0) / 2
             out["pcie_inclusive"] = {"value": round(R / dt / 1e6, 4), "unit": "Mreads/s", "ms_per_batch": round(dt * 1e3, 2),
-                                     "note": "pageable host buffers: reads up; SMEMs, SA coordinates, chains and regions down; includes numpy copies"}
+                                     "note": "pageable host buffers: reads up; SMEMs, SA coordinates, chains and final regions down; includes numpy copies"}
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on a sample (cpu_baseline)...")
             threads = min(16, os.cpu_count() or 1)
@@ -309,7 +313,7 @@ def main():
             v, dt = cpu_baseline(host, reads, n_s, threads)
             out["cpu_baseline"] = {
                 "value": round(v, 5), "unit": "Mreads/s", "cores": threads, "kind": "port",
-                "sample": f"first {n_s} reads of the same batch, same index; oracle seeding+SA+chaining+chain2aln, "
+                "sample": f"first {n_s} reads of the same batch, same index; oracle seeding+SA+chaining+chain2aln+dedup, "
                           f"{dt:.1f}s wall on {threads} threads",
             }
         print(json.dumps(out), flush=True)

@@ -1,8 +1,10 @@
 // api_chain.hip — C-ABI entry points of the chaining and chain-to-alignment stages
 // (include/bwams.h): launch sequences over chain.hip, ext_aln.hip and bsw_extend.hip on the
 // batch's stream.  No CPU fallback: every entry point runs HIP kernels or returns an error.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <utility>
 
@@ -654,6 +656,10 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     D.opt = *opt;
     D.ord = s->dd_ord.as<int32_t>(); D.srt = s->dd_srt.p; D.eh = s->dd_eh.as<int2>(); D.eh_lanes = n_lanes;
     D.max_read_len = (int32_t)L; D.n_out = s->dd_nout.as<int32_t>();
+    BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
+    { const char *e = getenv("BWAMS_DEDUP_SEQ"); D.force_seq = e ? atoi(e) : 0; }
+    D.heavy = s->heavy.as<int32_t>(); D.n_heavy_ctr = &b->d_ctr->dedup_heavy; D.ticket = &b->d_ctr->dedup_ticket;
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->dedup_heavy, 0, 2 * sizeof(unsigned long long), st));
     BWAMS_HIP(hipEventRecord(s->ev[12], st));
     // work on a copy: bwams_extend_fetch stays valid
     if (N) BWAMS_HIP(hipMemcpyAsync(D.regs, s->regs.p, (size_t)N * sizeof(bwams_alnreg_t), hipMemcpyDeviceToDevice, st));

@@ -126,6 +126,9 @@ struct DedupArgs {
     int64_t eh_lanes;              // strips [0, eh_lanes) belong to dedup_kernel's lanes, the following ones to the wave kernel
     int32_t max_read_len;
     int32_t *n_out;                // per read: regions left
+    int32_t *heavy;                // reads with many regions (listed by dedup_kernel, processed by dedup_wave_kernel)
+    unsigned long long *n_heavy_ctr, *ticket;
+    int32_t force_seq;             // debug: lane 0 runs the one-lane form for every read
 };
 size_t dedup_sortrec_bytes(int64_t n);
 void launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st);

@@ -82,6 +82,14 @@ template <class LT> __device__ __forceinline__ void r_introsort(SortRec *a, int 
     }
 }
 
+// The sorts are called through this non-inlined wrapper: the pointer stays generic (LDS or HBM, flat accesses).
+// Instantiated directly on a __shared__ array the inlined introsort spun forever on gfx950 (ROCm 7.2) for a
+// six-record input that the same code sorts correctly through a generic pointer; see profiles/r01_notes.md.
+__device__ __noinline__ void sort_records(SortRec *a, int n, int by_score) {
+    if (by_score) r_introsort(a, n, LtScore());
+    else r_introsort(a, n, LtEnd());
+}
+
 // ksw_global2 without backtrack; query[j] = qseq[qs * j], target[i] = tseq[ts * i] (ts = qs = -1 on the reverse strand,
 // where bwa_gen_cigar2 reverses both sequences); eh: qlen + 1 cells of this lane's strip
 __device__ int global_score(const bwams_mem_opt_t &o, int qlen, const uint8_t *qseq, int qs, int tlen, const uint8_t *tseq, int ts,
@@ -176,7 +184,7 @@ __device__ int dedup_read(const DedupArgs &A, int64_t r, SortRec *srt, int2 *eh)
         if (a[i].qe > a[i].qb) ord[n++] = i;
     if (n > 1) {
         for (int i = 0; i < n; ++i) { SortRec x; x.k = a[ord[i]].re; x.s = 0; x.q = 0; x.idx = ord[i]; x.pad_ = 0; srt[i] = x; }
-        r_introsort(srt, n, LtEnd());
+        sort_records(srt, n, 0);
         for (int i = 0; i < n; ++i) { ord[i] = srt[i].idx; a[ord[i]].n_comp_is_alt = 1; }
         for (int i = 1; i < n; ++i) {
             bwams_alnreg_t *p = &a[ord[i]];
@@ -215,7 +223,7 @@ __device__ int dedup_read(const DedupArgs &A, int64_t r, SortRec *srt, int2 *eh)
             SortRec x; x.k = p->rb; x.s = p->score; x.q = p->qb; x.idx = ord[i]; x.pad_ = 0;
             srt[i] = x;
         }
-        r_introsort(srt, n, LtScore());
+        sort_records(srt, n, 1);
         for (int i = 0; i < n; ++i) ord[i] = srt[i].idx;
         for (int i = 1; i < n; ++i) {
             bwams_alnreg_t *p = &a[ord[i]];
@@ -241,20 +249,162 @@ __global__ __launch_bounds__(64) void dedup_kernel(DedupArgs A, int64_t n_lanes)
     for (int64_t r = g; r < A.nseq; r += n_lanes) {
         const int64_t reg0 = A.seed_off[r];
         const int av_n = (int)(A.seed_off[r + 1] - reg0);
-        if (av_n > kLightN) continue;
+        if (av_n > kLightN) {                                  // a wavefront's (dedup_wave_kernel)
+            A.heavy[atomicAdd(A.n_heavy_ctr, 1ull)] = (int32_t)r;
+            continue;
+        }
         A.n_out[r] = av_n ? dedup_read(A, r, reinterpret_cast<SortRec *>(A.srt) + reg0, eh) : 0;
     }
 }
 
+// One wavefront per read with many regions.  The loops that are plain maps or compactions run across the
+// lanes; the two sorts run on lane 0 over LDS records; the pairwise pass (sequential by nature) runs on
+// lane 0 but rejects the common case — the region just upstream is on another sequence or further than
+// max_chain_gap away — from LDS copies of (rid, rb, re), which that pass never changes for regions it has
+// not reached yet.
+// Fields that lane 0 rewrites during the pairwise pass are re-read by the other lanes afterwards: those loads go
+// past the vector L1 (which may still hold the line from the first pass) with agent-scope atomic loads.
+__device__ __forceinline__ void load_qbqe(const bwams_alnreg_t *p, int &qb, int &qe) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&p->qb), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    qb = (int)(uint32_t)v; qe = (int)(uint32_t)(v >> 32);
+}
+// slots of the regions with qe > qb, in order; ord lives in LDS
+__device__ __forceinline__ int wave_compact_alive(const bwams_alnreg_t *a, int32_t *ord, int n_in, bool first, int lane) {
+    int n = 0;
+    for (int ib = 0; ib < n_in; ib += 64) {
+        const int i = ib + lane;
+        int slot = 0;
+        bool alive = false;
+        if (i < n_in) {
+            slot = first ? i : ord[i];
+            int qb, qe;
+            load_qbqe(&a[slot], qb, qe);
+            alive = qe > qb;
+        }
+        const unsigned long long m = __ballot(alive);
+        if (alive) ord[n + __popcll(m & ((1ull << lane) - 1ull))] = slot;     // n + rank <= i: never ahead of a pending read
+        n += __popcll(m);
+    }
+    return n;
+}
+
 __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_waves) {
     __shared__ SortRec l_srt[kLdsN];
+    __shared__ int64_t l_rb[kLdsN];
+    __shared__ int32_t l_ord[kLdsN];
     const int lane = threadIdx.x;
     int2 *eh = A.eh + (A.eh_lanes + blockIdx.x) * (int64_t)(A.max_read_len + 2);
-    for (int64_t r = blockIdx.x; r < A.nseq; r += n_waves) {
+    const int64_t n_heavy = (int64_t)*A.n_heavy_ctr;
+    for (;;) {
+        unsigned long long tk = 0;
+        if (lane == 0) tk = atomicAdd(A.ticket, 1ull);
+        const int64_t t = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tk >> 32)) << 32) |
+                                    (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)tk));
+        if (t >= n_heavy) break;
+        const int64_t r = A.heavy[t];
         const int64_t reg0 = A.seed_off[r];
         const int av_n = (int)(A.seed_off[r + 1] - reg0);
-        if (av_n <= kLightN) continue;
-        if (lane == 0) A.n_out[r] = dedup_read(A, r, av_n <= kLdsN ? l_srt : reinterpret_cast<SortRec *>(A.srt) + reg0, eh);
+        bwams_alnreg_t *a = A.regs + reg0;
+        int32_t *ord = A.ord + reg0;
+        const uint8_t *query = A.enc + A.cum[r];
+        __syncthreads();
+        if (av_n > kLdsN || A.force_seq) {                              // beyond the LDS budget: the one-lane form
+            if (lane == 0) A.n_out[r] = dedup_read(A, r, reinterpret_cast<SortRec *>(A.srt) + reg0, eh);
+            continue;
+        }
+        int n = wave_compact_alive(a, l_ord, av_n, true, lane);         // bwamem.cpp:1446-1456
+        __syncthreads();
+        if (n > 1) {
+            for (int i = lane; i < n; i += 64) {
+                const bwams_alnreg_t *p = &a[l_ord[i]];
+                SortRec x; x.k = p->re; x.s = p->rid; x.q = 0; x.idx = l_ord[i]; x.pad_ = 0;
+                l_srt[i] = x;
+            }
+            __syncthreads();
+            if (lane == 0) sort_records(l_srt, n, 0);
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const int slot = l_srt[i].idx;
+                l_ord[i] = slot;
+                l_rb[i] = a[slot].rb;
+                a[slot].n_comp_is_alt = 1;
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (lane == 0) {
+                for (int i = 1; i < n; ++i) {
+                    if (l_srt[i].s != l_srt[i - 1].s || l_rb[i] >= l_srt[i - 1].k + A.opt.max_chain_gap) continue;
+                    bwams_alnreg_t *p = &a[l_ord[i]];
+                    for (int j = i - 1; j >= 0; --j) {
+                        if (!(l_srt[i].s == l_srt[j].s && p->rb < l_srt[j].k + A.opt.max_chain_gap)) break;
+                        bwams_alnreg_t *q = &a[l_ord[j]];
+                        if (q->qe == q->qb) continue;
+                        const int64_t or_ = q->re - p->rb;
+                        const int64_t oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+                        const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+                        const int64_t mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+                        int score, w;
+                        if ((float)or_ > A.opt.mask_level_redun * (float)mr && (float)oq > A.opt.mask_level_redun * (float)mq) {
+                            if (p->score < q->score) { p->qe = p->qb; break; }
+                            else q->qe = q->qb;
+                        } else if (q->rb < p->rb && (score = patch_reg(A, query, *q, *p, &w, eh)) > 0) {
+                            p->n_comp_is_alt = (p->n_comp_is_alt + q->n_comp_is_alt + 1) & 0x3fffffff;
+                            p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+                            p->sub = p->sub > q->sub ? p->sub : q->sub;
+                            p->csub = p->csub > q->csub ? p->csub : q->csub;
+                            p->qb = q->qb; p->rb = q->rb;
+                            p->truesc = p->score = score;
+                            p->w = w;
+                            q->qb = q->qe;
+                        }
+                    }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            n = wave_compact_alive(a, l_ord, n, false, lane);
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const bwams_alnreg_t *p = &a[l_ord[i]];
+                SortRec x;
+                x.k = (int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(&p->rb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x.s = __hip_atomic_load(&p->score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int qb, qe;
+                load_qbqe(p, qb, qe);
+                x.q = qb; x.idx = l_ord[i]; x.pad_ = 0;
+                l_srt[i] = x;
+            }
+            __syncthreads();
+            if (lane == 0) sort_records(l_srt, n, 1);
+            __syncthreads();
+            // identical hits: same (score, rb, qb) as the predecessor in sorted order
+            int m = 0;
+            for (int ib = 0; ib < n; ib += 64) {
+                const int i = ib + lane;
+                bool keep = false;
+                int slot = 0;
+                if (i < n) {
+                    const SortRec x = l_srt[i];
+                    slot = x.idx;
+                    keep = i == 0 || !(x.s == l_srt[i - 1].s && x.k == l_srt[i - 1].k && x.q == l_srt[i - 1].q);
+                    if (!keep) a[slot].qe = a[slot].qb;
+                }
+                const unsigned long long mk = __ballot(keep);
+                if (keep) l_ord[m + __popcll(mk & ((1ull << lane) - 1ull))] = slot;
+                m += __popcll(mk);
+            }
+            n = m;
+            __threadfence_block();
+            __syncthreads();
+        }
+        for (int i = lane; i < n; i += 64) {                            // bwamem.cpp:1470-1481; final order out to HBM
+            bwams_alnreg_t *p = &a[l_ord[i]];
+            ord[i] = l_ord[i];
+            const int nc = __hip_atomic_load(&p->n_comp_is_alt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p->rid >= 0 && A.bns.contigs[p->rid].is_alt) p->n_comp_is_alt = (nc & 0x3fffffff) | (1 << 30);
+        }
+        if (lane == 0) A.n_out[r] = n;
     }
 }
 

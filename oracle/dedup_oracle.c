@@ -69,6 +69,7 @@ int orc_ksw_global2_score(int qlen, const uint8_t *query, int tlen, const uint8_
 
 /* bwa_gen_cigar2 with n_cigar = NM = 0: the score of the global alignment of query[0, l_query) against
  * ref_string[rb, re); both are reversed on the reverse strand (bwa.cpp:394-399) */
+int64_t orc_dedup_dp_calls = 0, orc_dedup_dp_cells = 0;      /* test / diagnostic counters */
 static int gen_score(const bwams_mem_opt_t *opt, int w_, int64_t l_pac, const uint8_t *ref_string, int l_query,
                      const uint8_t *query, int64_t rb, int64_t re, int *score)
 {
@@ -95,6 +96,7 @@ static int gen_score(const bwams_mem_opt_t *opt, int w_, int64_t l_pac, const ui
         w = w < w_ ? w : w_;
         min_w = abs((int)(rlen - l_query)) + 3;
         w = w > min_w ? w : min_w;
+        orc_dedup_dp_calls++; orc_dedup_dp_cells += (int64_t)rlen * (2 * w + 1 < l_query ? 2 * w + 1 : l_query);
         *score = orc_ksw_global2_score(l_query, q, (int)rlen, r, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w);
     }
     free(q); free(r);

@@ -37,7 +37,7 @@ struct ChainState {
     // results
     DevBuf chains, seeds, seeds2;
     DevBuf sw_qb, sw_rb, sw_read, sw_newn, sw_res;      // mem_flt_chained_seeds (long reads)
-    DevBuf dd_regs, dd_ord, dd_srt, dd_eh, dd_nout, dd_wide, dd_off, dd_out;   // mem_sort_dedup_patch
+    DevBuf dd_regs, dd_ord, dd_srt, dd_eh, dd_nout, dd_wide, dd_off, dd_out, dd_light;   // mem_sort_dedup_patch
     int64_t n_final = 0;
     bool dedup_done = false;
     int64_t n_chains = 0, n_seeds = 0, nseq = 0;
@@ -60,7 +60,7 @@ void chain_state_free(ChainState *s) {
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
                      &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
-                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -658,8 +658,10 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     D.max_read_len = (int32_t)L; D.n_out = s->dd_nout.as<int32_t>();
     BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
     { const char *e = getenv("BWAMS_DEDUP_SEQ"); D.force_seq = e ? atoi(e) : 0; }
-    D.heavy = s->heavy.as<int32_t>(); D.n_heavy_ctr = &b->d_ctr->dedup_heavy; D.ticket = &b->d_ctr->dedup_ticket;
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->dedup_heavy, 0, 2 * sizeof(unsigned long long), st));
+    BWAMS_HIP(s->dd_light.ensure((size_t)n1 * 4));
+    D.heavy = s->heavy.as<int32_t>(); D.light = s->dd_light.as<int32_t>();
+    D.n_heavy_ctr = &b->d_ctr->dedup_heavy; D.ticket = &b->d_ctr->dedup_ticket; D.n_light_ctr = &b->d_ctr->dedup_light;
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->dedup_heavy, 0, 3 * sizeof(unsigned long long), st));
     BWAMS_HIP(hipEventRecord(s->ev[12], st));
     // work on a copy: bwams_extend_fetch stays valid
     if (N) BWAMS_HIP(hipMemcpyAsync(D.regs, s->regs.p, (size_t)N * sizeof(bwams_alnreg_t), hipMemcpyDeviceToDevice, st));

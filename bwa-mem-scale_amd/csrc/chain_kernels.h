@@ -126,8 +126,8 @@ struct DedupArgs {
     int64_t eh_lanes;              // strips [0, eh_lanes) belong to dedup_kernel's lanes, the following ones to the wave kernel
     int32_t max_read_len;
     int32_t *n_out;                // per read: regions left
-    int32_t *heavy;                // reads with many regions (listed by dedup_kernel, processed by dedup_wave_kernel)
-    unsigned long long *n_heavy_ctr, *ticket;
+    int32_t *heavy, *light;        // reads with many / few regions that need the full procedure (listed by the triage kernel)
+    unsigned long long *n_heavy_ctr, *n_light_ctr, *ticket;
     int32_t force_seq;             // debug: lane 0 runs the one-lane form for every read
 };
 size_t dedup_sortrec_bytes(int64_t n);

@@ -105,20 +105,34 @@ __device__ int global_score(const bwams_mem_opt_t &o, int qlen, const uint8_t *q
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         int h1 = beg == 0 ? -(o.o_del + o.e_del * (i + 1)) : MINUS_INF;
-        for (j = beg; j < end; ++j) {
-            const int2 p = eh[j];
-            int m = p.x, e = p.y;
-            m += mrow[qseq[(int64_t)qs * j]];
-            int h = m >= e ? m : e;
-            h = h >= f ? h : f;
-            int t = m - oe_del;
-            e -= o.e_del;
-            e = e > t ? e : t;
-            eh[j] = make_int2(h1, e);
-            h1 = h;
-            t = m - oe_ins;
-            f -= o.e_ins;
-            f = f > t ? f : t;
+        // eight cells at a time: the row lives in HBM and a lane waits a full round trip per load, so the
+        // loads of a block are issued together
+        for (j = beg; j < end; j += 8) {
+            int2 blk[8];
+            int sc[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int jj = j + t < end ? j + t : end - 1;
+                blk[t] = eh[jj];
+                sc[t] = mrow[qseq[(int64_t)qs * jj]];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (j + t < end) {
+                    int m = blk[t].x, e = blk[t].y;
+                    m += sc[t];
+                    int h = m >= e ? m : e;
+                    h = h >= f ? h : f;
+                    int tt = m - oe_del;
+                    e -= o.e_del;
+                    e = e > tt ? e : tt;
+                    eh[j + t] = make_int2(h1, e);
+                    h1 = h;
+                    tt = m - oe_ins;
+                    f -= o.e_ins;
+                    f = f > tt ? f : tt;
+                }
+            }
         }
         eh[end] = make_int2(h1, MINUS_INF);
     }
@@ -242,18 +256,38 @@ __device__ int dedup_read(const DedupArgs &A, int64_t r, SortRec *srt, int2 *eh)
     return n;
 }
 
+// lane per read: reads left with at most one region are finished here; the others are listed for the
+// lane tier (few regions) or the wave tier (many)
+__global__ void dedup_triage_kernel(DedupArgs A) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.nseq) return;
+    const int64_t reg0 = A.seed_off[r];
+    const int av_n = (int)(A.seed_off[r + 1] - reg0);
+    bwams_alnreg_t *a = A.regs + reg0;
+    int n = 0, last = 0;
+    for (int i = 0; i < av_n; ++i)
+        if (a[i].qe > a[i].qb) { last = i; ++n; }
+    if (n <= 1) {                                  // mem_sort_dedup_patch returns at once (n_comp stays 0)
+        if (n == 1) {
+            A.ord[reg0] = last;
+            if (a[last].rid >= 0 && A.bns.contigs[a[last].rid].is_alt) a[last].n_comp_is_alt = (a[last].n_comp_is_alt & 0x3fffffff) | (1 << 30);
+        }
+        A.n_out[r] = n;
+        return;
+    }
+    if (av_n > kLightN) A.heavy[atomicAdd(A.n_heavy_ctr, 1ull)] = (int32_t)r;
+    else A.light[atomicAdd(A.n_light_ctr, 1ull)] = (int32_t)r;
+}
+
+// lane tier: one lane per listed read (each lane owns a strip for the global alignment)
 __global__ __launch_bounds__(64) void dedup_kernel(DedupArgs A, int64_t n_lanes) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_lanes) return;
     int2 *eh = A.eh + g * (int64_t)(A.max_read_len + 2);
-    for (int64_t r = g; r < A.nseq; r += n_lanes) {
-        const int64_t reg0 = A.seed_off[r];
-        const int av_n = (int)(A.seed_off[r + 1] - reg0);
-        if (av_n > kLightN) {                                  // a wavefront's (dedup_wave_kernel)
-            A.heavy[atomicAdd(A.n_heavy_ctr, 1ull)] = (int32_t)r;
-            continue;
-        }
-        A.n_out[r] = av_n ? dedup_read(A, r, reinterpret_cast<SortRec *>(A.srt) + reg0, eh) : 0;
+    const int64_t n_light = (int64_t)*A.n_light_ctr;
+    for (int64_t t = g; t < n_light; t += n_lanes) {
+        const int64_t r = A.light[t];
+        A.n_out[r] = dedup_read(A, r, reinterpret_cast<SortRec *>(A.srt) + A.seed_off[r], eh);
     }
 }
 
@@ -423,6 +457,7 @@ size_t dedup_sortrec_bytes(int64_t n) { return (size_t)(n + 1) * sizeof(SortRec)
 
 void launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st) {
     if (A.nseq <= 0) return;
+    dedup_triage_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A);
     dedup_kernel<<<(unsigned)((n_lanes + 63) / 64), 64, 0, st>>>(A, n_lanes);
     dedup_wave_kernel<<<(unsigned)n_waves, 64, 0, st>>>(A, n_waves);
 }

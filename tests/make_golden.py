@@ -104,6 +104,14 @@ ccoord, coff = o.sa_lookup(csm, 500)
 mopt = loader.default_mem_opt()
 ch, sd, choff = loader.chain_seeds(csm, ccoord, coff, ccum, len(g), opt=mopt)
 regs, reg_off, sd2 = loader.chain2aln(ch, sd, choff, cenc, ccum, idx.ref_0123, len(g), opt=mopt)
+fin, fin_off = loader.regs_finish(regs, reg_off, cenc, ccum, idx.ref_0123, len(g), opt=mopt)
+SWREF = loader.ref_lib()
+if SWREF is not None:           # the global alignment mem_patch_reg relies on, against the reference's ksw.cpp object
+    for _ in range(50):
+        q_ = rng.integers(0, 4, size=int(rng.integers(5, 200)), dtype=np.uint8)
+        t_ = np.concatenate([q_[:len(q_) // 2], rng.integers(0, 4, size=int(rng.integers(0, 9)), dtype=np.uint8), q_[len(q_) // 2:]])
+        w_ = int(rng.integers(1, 60))
+        assert loader.ksw_global2_score(q_, t_, w_) == loader.ksw_global2_score(q_, t_, w_, L=SWREF)
 if CHAIN_REF is not None:       # the two klib pieces the chaining relies on, against the reference's own headers
     for n_ in (5, 40, 700):
         pp = rng.integers(0, 30, size=n_).astype(np.int64)
@@ -117,6 +125,7 @@ np.savez_compressed(
     read_len=np.array([len(r) for r in creads]), reads=cenc,
     chains=ch.view(np.uint8).reshape(len(ch), -1), seeds=sd2.view(np.uint8).reshape(len(sd2), -1), chain_off=choff,
     regs=regs.view(np.uint8).reshape(len(regs), -1), reg_off=reg_off,
-    klib_checked_against_reference=np.array([CHAIN_REF is not None]))
+    final=fin.view(np.uint8).reshape(len(fin), -1), final_off=fin_off,
+    klib_checked_against_reference=np.array([CHAIN_REF is not None and SWREF is not None]))
 
 print("golden vectors written to", OUT, "| reference cross-check:", REF is not None)

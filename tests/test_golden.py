@@ -82,6 +82,14 @@ def _chain_case():
     return z, cum, chains, seeds, regs
 
 
+def _final_case(z):
+    return np.ascontiguousarray(z["final"]).view(loader.ALNREG_DTYPE).reshape(-1), z["final_off"]
+
+
+FINAL_F = ("rb", "re", "qb", "qe", "rid", "chain", "score", "truesc", "sub", "csub", "w", "seedcov", "seedlen0", "n_comp_is_alt",
+           "frac_rep")
+
+
 CHAIN_F = ("seqid", "n", "m", "first", "rid", "w_kept_alt", "frac_rep", "pos", "seed_off")
 SEED_F = ("rbeg", "qbeg", "len", "score", "aln")
 REG_F = ("rb", "re", "qb", "qe", "rid", "chain", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep")
@@ -103,6 +111,11 @@ def test_oracle_reproduces_chain_golden():
         assert np.array_equal(sd2[f], seeds[f]), f
     for f in REG_F:
         assert np.array_equal(rg[f], regs[f]), f
+    fin, fin_off = _final_case(z)
+    gf, gfo = loader.regs_finish(rg, roff, z["reads"], cum, idx.ref_0123, len(zs["genome"]))
+    assert np.array_equal(gfo, fin_off)
+    for f in FINAL_F:
+        assert np.array_equal(gf[f], fin[f]), f
     per_read = np.diff(choff)
     dup = sum(len(np.unique(ch["pos"][a:b])) != b - a for a, b in zip(choff[:-1], choff[1:]))
     assert per_read.max() >= 3 and dup > 0            # the fixture holds duplicate chain positions
@@ -135,6 +148,12 @@ def test_gpu_reproduces_chain_golden():
         keep = slice(None) if extend_all else ~purged
         for f in REG_F:
             assert np.array_equal(rg[f][keep], regs[f][keep]), (extend_all, f)
+        fin, fin_off = _final_case(z)
+        assert b.dedup_run(opt) == len(fin)
+        gf, gfo = b.dedup_fetch()
+        assert np.array_equal(gfo, fin_off)
+        for f in FINAL_F:
+            assert np.array_equal(gf[f], fin[f]), (extend_all, f)
     b.close()
     ix.close()
 

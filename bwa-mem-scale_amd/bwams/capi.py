@@ -35,8 +35,9 @@ SYMBOLS = [
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
-    "bwams_dedup_run", "bwams_dedup_fetch",
+    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_pestat",
 ]
+PESTAT_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4"), ("avg", "<f8"), ("std", "<f8")])
 
 # records of include/bwams_types.h (layouts of bntann1_t's subset, mem_seed_t, mem_chain_t, mem_alnreg_t)
 CONTIG_DTYPE = np.dtype([("offset", "<i8"), ("len", "<i4"), ("is_alt", "<i4")])
@@ -76,7 +77,7 @@ class MemOpt(C.Structure):
                 ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
                 ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
                 ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
-                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float)]
+                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float), ("max_ins", C.c_int32)]
 
 
 class FmiDesc(C.Structure):
@@ -124,6 +125,7 @@ def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
     """mem_opt_init defaults (/root/reference/src/bwamem.cpp:135-171)."""
     o = MemOpt(a, 6, 1, 6, 1, 5, 5, 100, 100, 19, 0, 1 << 30, 500, 10000, 0.5, 0.5)
     o.mask_level_redun = 0.95
+    o.max_ins = 10000
     sw = default_sw_opt(5, a, b)
     for i in range(25):
         o.mat[i] = sw.mat[i]
@@ -178,6 +180,7 @@ def lib():
         L.bwams_extend_tasks_fetch.argtypes = [vp, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp]
         L.bwams_dedup_run.argtypes = [vp, vp, vp]
         L.bwams_dedup_fetch.argtypes = [vp, vp, i64, vp]
+        L.bwams_pestat.argtypes = [vp, vp, vp]
         L.bwams_seed_run.argtypes = [vp, vp, C.c_int]
         L.bwams_seed_counts.argtypes = [vp, vp, vp]
         L.bwams_seed_fetch.argtypes = [vp, vp, i64, vp, i64, vp]
@@ -473,6 +476,13 @@ class Batch:
         off = np.zeros(self._nseq + 1, np.int64)
         _chk(lib().bwams_dedup_fetch(self.h, _p(regs), self._n_final, _p(off)), "bwams_dedup_fetch")
         return regs, off
+
+    def pestat(self, opt: MemOpt | None = None):
+        """mem_pestat over the final regions (reads 2i, 2i+1 = pair i) -> 4 records FF, FR, RF, RR."""
+        opt = opt or default_mem_opt()
+        pes = np.zeros(4, PESTAT_DTYPE)
+        _chk(lib().bwams_pestat(self.h, C.byref(opt), _p(pes)), "bwams_pestat")
+        return pes
 
     def extend_tasks_fetch(self, side: int):
         n, rb, qb = C.c_int64(0), C.c_int64(0), C.c_int64(0)

@@ -1,12 +1,14 @@
 // api_chain.hip — C-ABI entry points of the chaining and chain-to-alignment stages
 // (include/bwams.h): launch sequences over chain.hip, ext_aln.hip and bsw_extend.hip on the
 // batch's stream.  No CPU fallback: every entry point runs HIP kernels or returns an error.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -38,6 +40,7 @@ struct ChainState {
     DevBuf chains, seeds, seeds2;
     DevBuf sw_qb, sw_rb, sw_read, sw_newn, sw_res;      // mem_flt_chained_seeds (long reads)
     DevBuf dd_regs, dd_ord, dd_srt, dd_eh, dd_nout, dd_wide, dd_off, dd_out, dd_light;   // mem_sort_dedup_patch
+    DevBuf pe_keys, pe_keys2;                           // mem_pestat
     int64_t n_final = 0;
     bool dedup_done = false;
     int64_t n_chains = 0, n_seeds = 0, nseq = 0;
@@ -60,7 +63,7 @@ void chain_state_free(ChainState *s) {
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
                      &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
-                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -695,6 +698,89 @@ int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, i
     if (s->n_final) BWAMS_HIP(hipMemcpyAsync(regs, s->dd_out.p, (size_t)s->n_final * sizeof(bwams_alnreg_t), hipMemcpyDeviceToHost, st));
     if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->dd_off.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
+    return BWAMS_OK;
+}
+
+/* ------------------------------------------------------------------ mem_pestat ---- */
+
+int bwams_pestat(bwams_batch_t *b, const bwams_mem_opt_t *opt, bwams_pestat_t pes[4]) {
+    if (!b || !b->chain || !b->chain->dedup_done || !pes) {
+        set_last_error("bwams_pestat: run bwams_dedup_run first");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_pestat");
+    if (rc) return rc;
+    ChainState *s = b->chain;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    const int64_t n_pairs = s->nseq >> 1;
+    const int64_t l_pac = (b->idx->fmi.ref_seq_len - 1) / 2;
+    memset(pes, 0, 4 * sizeof(bwams_pestat_t));
+    std::vector<unsigned long long> keys((size_t)(n_pairs > 0 ? n_pairs : 1));
+    if (n_pairs > 0) {
+        BWAMS_HIP(s->pe_keys.ensure((size_t)n_pairs * 8));
+        BWAMS_HIP(s->pe_keys2.ensure((size_t)n_pairs * 8));
+        launch_pestat(s->dd_out.as<bwams_alnreg_t>(), s->dd_off.as<int64_t>(), n_pairs, l_pac, *opt,
+                      s->pe_keys.as<unsigned long long>(), st);
+        size_t tb = 0;
+        BWAMS_HIP(rocprim::radix_sort_keys(nullptr, tb, s->pe_keys.as<unsigned long long>(), s->pe_keys2.as<unsigned long long>(),
+                                           (size_t)n_pairs, 0, 64, st));
+        if (tb > b->tmp_bytes) {
+            BWAMS_HIP(hipStreamSynchronize(st));
+            if (b->d_tmp) (void)hipFree(b->d_tmp);
+            b->d_tmp = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            b->tmp_bytes = tb;
+        }
+        tb = b->tmp_bytes;
+        BWAMS_HIP(rocprim::radix_sort_keys(b->d_tmp, tb, s->pe_keys.as<unsigned long long>(), s->pe_keys2.as<unsigned long long>(),
+                                           (size_t)n_pairs, 0, 64, st));
+        BWAMS_HIP(hipMemcpyAsync(keys.data(), s->pe_keys2.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+    }
+    // the reference's arithmetic over each orientation's sorted insert sizes (bwamem_pair.cpp:111-155), as written
+    size_t beg[5] = {0, 0, 0, 0, 0};
+    {
+        size_t k = 0;
+        for (int d = 0; d < 4; ++d) {
+            beg[d] = k;
+            while (k < (size_t)n_pairs && keys[k] != ~0ull && (int)(keys[k] >> 60) == d) ++k;
+        }
+        beg[4] = k;
+    }
+    const unsigned long long mask = (1ull << 60) - 1ull;
+    int max = 0;
+    for (int d = 0; d < 4; ++d) {
+        bwams_pestat_t *r = &pes[d];
+        const unsigned long long *q = keys.data() + beg[d];
+        const size_t qn = beg[d + 1] - beg[d];
+        max = max > (int)qn ? max : (int)qn;
+        if (qn < 10) { r->failed = 1; continue; }
+        const int p25 = (int)(q[(int)(.25 * qn + .499)] & mask);
+        const int p75 = (int)(q[(int)(.75 * qn + .499)] & mask);
+        r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
+        if (r->low < 1) r->low = 1;
+        r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+        int x = 0;
+        size_t k;
+        for (k = 0, r->avg = 0; k < qn; ++k) {
+            const uint64_t v = q[k] & mask;
+            if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) r->avg += v, ++x;
+        }
+        r->avg /= x;
+        for (k = 0, r->std = 0; k < qn; ++k) {
+            const uint64_t v = q[k] & mask;
+            if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) r->std += (v - r->avg) * (v - r->avg);
+        }
+        r->std = sqrt(r->std / x);
+        r->low = (int)(p25 - 3.0 * (p75 - p25) + .499);
+        r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+        if (r->low > r->avg - 4.0 * r->std) r->low = (int)(r->avg - 4.0 * r->std + .499);
+        if (r->high < r->avg + 4.0 * r->std) r->high = (int)(r->avg + 4.0 * r->std + .499);
+        if (r->low < 1) r->low = 1;
+    }
+    for (int d = 0; d < 4; ++d)
+        if (pes[d].failed == 0 && (double)(beg[d + 1] - beg[d]) < max * 0.05) pes[d].failed = 1;
     return BWAMS_OK;
 }
 

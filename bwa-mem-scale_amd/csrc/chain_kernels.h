@@ -132,6 +132,8 @@ struct DedupArgs {
 };
 size_t dedup_sortrec_bytes(int64_t n);
 void launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st);
+void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n_pairs, int64_t l_pac, const bwams_mem_opt_t &opt,
+                   unsigned long long *keys, hipStream_t st);
 void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
 
 }  // namespace bwams

@@ -451,7 +451,49 @@ __global__ void dedup_gather_kernel(DedupArgs A, const int64_t *__restrict__ out
     for (int i = 0; i < n; ++i) out[out_off[r] + i] = A.regs[reg0 + A.ord[reg0 + i]];
 }
 
+// ---- mem_pestat, the per-pair part (bwamem_pair.cpp:66-108): lane per pair -> key = dir << 60 | insert size, or ~0 ----
+__device__ __forceinline__ int cal_sub(const bwams_mem_opt_t &opt, int n, const bwams_alnreg_t *a) {
+    int j;
+    for (j = 1; j < n; ++j) {
+        const int b_max = a[j].qb > a[0].qb ? a[j].qb : a[0].qb;
+        const int e_min = a[j].qe < a[0].qe ? a[j].qe : a[0].qe;
+        if (e_min > b_max) {
+            const int lj = a[j].qe - a[j].qb, l0 = a[0].qe - a[0].qb;
+            const int min_l = lj < l0 ? lj : l0;
+            if ((float)(e_min - b_max) >= (float)min_l * opt.mask_level) break;
+        }
+    }
+    return j < n ? a[j].score : opt.min_seed_len * opt.a;
+}
+__global__ void pestat_kernel(const bwams_alnreg_t *__restrict__ regs, const int64_t *__restrict__ reg_off, int64_t n_pairs,
+                              int64_t l_pac, bwams_mem_opt_t opt, unsigned long long *keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    unsigned long long key = ~0ull;
+    const int64_t o0 = reg_off[2 * i], o1 = reg_off[2 * i + 1], o2 = reg_off[2 * i + 2];
+    const int n0 = (int)(o1 - o0), n1 = (int)(o2 - o1);
+    if (n0 && n1) {
+        const bwams_alnreg_t *r0 = regs + o0, *r1 = regs + o1;
+        if (!((double)cal_sub(opt, n0, r0) > 0.8 * (double)r0[0].score) && !((double)cal_sub(opt, n1, r1) > 0.8 * (double)r1[0].score) &&
+            r0[0].rid == r1[0].rid) {
+            const int64_t b1 = r0[0].rb, b2 = r1[0].rb;
+            const int s1 = b1 >= l_pac, s2 = b2 >= l_pac;
+            const int64_t p2 = s1 == s2 ? b2 : (l_pac << 1) - 1 - b2;
+            const int64_t is = p2 > b1 ? p2 - b1 : b1 - p2;
+            const int dir = (s1 == s2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+            if (is && is <= opt.max_ins) key = ((unsigned long long)dir << 60) | (unsigned long long)is;
+        }
+    }
+    keys[i] = key;
+}
+
 }  // namespace
+
+void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n_pairs, int64_t l_pac, const bwams_mem_opt_t &opt,
+                   unsigned long long *keys, hipStream_t st) {
+    if (n_pairs <= 0) return;
+    pestat_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, st>>>(regs, reg_off, n_pairs, l_pac, opt, keys);
+}
 
 size_t dedup_sortrec_bytes(int64_t n) { return (size_t)(n + 1) * sizeof(SortRec); }
 

@@ -272,6 +272,11 @@ int bwams_extend_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, 
  * the options.  The extension's regions stay available to bwams_extend_fetch. */
 int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_regs);
 int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off);
+/* mem_pestat (src/bwamem_pair.cpp:89-156; called at src/bwamem.cpp:1888) over the final regions of
+ * bwams_dedup_run: reads 2i and 2i+1 are the two ends of pair i.  pes[4] = orientations FF, FR, RF, RR.
+ * The per-pair work (cal_sub, mem_infer_dir) and the sort run on the device; the percentile / mean / std
+ * arithmetic over the sorted insert sizes is the reference's sequential double-precision loop, on the host. */
+int bwams_pestat(bwams_batch_t *b, const bwams_mem_opt_t *opt, bwams_pestat_t pes[4]);
 /* the task lists as built (side 0 = left, 1 = right), for inspection */
 int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref,
                              int64_t ref_cap, uint8_t *qer, int64_t qer_cap, int64_t *n_pairs, int64_t *ref_bytes,

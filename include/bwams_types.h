@@ -122,7 +122,16 @@ typedef struct bwams_mem_opt {
      * 1: extend every seed, purged regions hold the reference's dead values too. */
     int32_t extend_all;
     float   mask_level_redun;           /* mem_opt_t again: 0.95, read by mem_sort_dedup_patch */
+    int32_t max_ins;                    /* 10000, read by mem_pestat */
 } bwams_mem_opt_t;
+
+/* mem_pestat_t (src/bwamem.h:178-182), same layout. */
+typedef struct bwams_pestat {
+    int32_t low, high;      /* bounds within which a pair counts as properly paired */
+    int32_t failed;         /* non-zero: orientation not supported by enough data */
+    int32_t pad_;
+    double  avg, std;
+} bwams_pestat_t;
 
 /* mem_seed_t (src/bwamem.h:129-140), 32 B, same field offsets. */
 typedef struct bwams_chain_seed {

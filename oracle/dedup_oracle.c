@@ -297,3 +297,90 @@ int64_t orc_regs_finish(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const 
     out_off[nseq] = n_out;
     return n_out;
 }
+
+/* ---- mem_pestat (bwamem_pair.cpp:57-156): insert-size statistics of a chunk of read pairs ---- */
+#include <math.h>
+#define MIN_RATIO     0.8
+#define MIN_DIR_CNT   10
+#define MIN_DIR_RATIO 0.05
+#define OUTLIER_BOUND 2.0
+#define MAPPING_BOUND 3.0
+#define MAX_STDDEV    4.0
+
+static int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)
+{
+    int64_t p2;
+    int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
+    p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+    *dist = p2 > b1 ? p2 - b1 : b1 - p2;
+    return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+static int cal_sub(const bwams_mem_opt_t *opt, int n, const bwams_alnreg_t *a)
+{
+    int j;
+    for (j = 1; j < n; ++j) {
+        int b_max = a[j].qb > a[0].qb ? a[j].qb : a[0].qb;
+        int e_min = a[j].qe < a[0].qe ? a[j].qe : a[0].qe;
+        if (e_min > b_max) {
+            int min_l = a[j].qe - a[j].qb < a[0].qe - a[0].qb ? a[j].qe - a[j].qb : a[0].qe - a[0].qb;
+            if (e_min - b_max >= min_l * opt->mask_level) break;
+        }
+    }
+    return j < n ? a[j].score : opt->min_seed_len * opt->a;
+}
+static int cmp_u64(const void *a, const void *b)
+{
+    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return (x > y) - (x < y);
+}
+void orc_pestat(const bwams_mem_opt_t *opt, int64_t l_pac, int n, const bwams_alnreg_t *regs, const int64_t *reg_off,
+                bwams_pestat_t pes[4])
+{
+    int i, d, max;
+    uint64_t *isz[4];
+    size_t cnt[4] = {0, 0, 0, 0};
+    memset(pes, 0, 4 * sizeof(bwams_pestat_t));
+    for (d = 0; d < 4; ++d) isz[d] = (uint64_t *)malloc(((size_t)(n >> 1) + 1) * 8);
+    for (i = 0; i < n >> 1; ++i) {
+        const bwams_alnreg_t *r0 = regs + reg_off[i << 1], *r1 = regs + reg_off[i << 1 | 1];
+        const int n0 = (int)(reg_off[(i << 1) + 1] - reg_off[i << 1]), n1 = (int)(reg_off[(i << 1 | 1) + 1] - reg_off[i << 1 | 1]);
+        int64_t is;
+        if (n0 == 0 || n1 == 0) continue;
+        if (cal_sub(opt, n0, r0) > MIN_RATIO * r0[0].score) continue;
+        if (cal_sub(opt, n1, r1) > MIN_RATIO * r1[0].score) continue;
+        if (r0[0].rid != r1[0].rid) continue;
+        const int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+        if (is && is <= opt->max_ins) isz[dir][cnt[dir]++] = (uint64_t)is;
+    }
+    for (d = 0; d < 4; ++d) {
+        bwams_pestat_t *r = &pes[d];
+        uint64_t *q = isz[d];
+        const size_t qn = cnt[d];
+        int p25, p50, p75, x;
+        size_t k;
+        if (qn < MIN_DIR_CNT) { r->failed = 1; continue; }
+        qsort(q, qn, 8, cmp_u64);                      /* ks_introsort_64: the sorted values are what matters */
+        p25 = (int)q[(int)(.25 * qn + .499)];
+        p50 = (int)q[(int)(.50 * qn + .499)];
+        p75 = (int)q[(int)(.75 * qn + .499)];
+        (void)p50;
+        r->low = (int)(p25 - OUTLIER_BOUND * (p75 - p25) + .499);
+        if (r->low < 1) r->low = 1;
+        r->high = (int)(p75 + OUTLIER_BOUND * (p75 - p25) + .499);
+        for (k = 0, x = 0, r->avg = 0; k < qn; ++k)
+            if (q[k] >= (uint64_t)r->low && q[k] <= (uint64_t)r->high) r->avg += q[k], ++x;
+        r->avg /= x;
+        for (k = 0, r->std = 0; k < qn; ++k)
+            if (q[k] >= (uint64_t)r->low && q[k] <= (uint64_t)r->high) r->std += (q[k] - r->avg) * (q[k] - r->avg);
+        r->std = sqrt(r->std / x);
+        r->low = (int)(p25 - MAPPING_BOUND * (p75 - p25) + .499);
+        r->high = (int)(p75 + MAPPING_BOUND * (p75 - p25) + .499);
+        if (r->low > r->avg - MAX_STDDEV * r->std) r->low = (int)(r->avg - MAX_STDDEV * r->std + .499);
+        if (r->high < r->avg + MAX_STDDEV * r->std) r->high = (int)(r->avg + MAX_STDDEV * r->std + .499);
+        if (r->low < 1) r->low = 1;
+    }
+    for (d = 0, max = 0; d < 4; ++d) max = max > (int)cnt[d] ? max : (int)cnt[d];
+    for (d = 0; d < 4; ++d)
+        if (pes[d].failed == 0 && cnt[d] < max * MIN_DIR_RATIO) pes[d].failed = 1;
+    for (d = 0; d < 4; ++d) free(isz[d]);
+}

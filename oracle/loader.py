@@ -123,6 +123,8 @@ def lib():
         L.orc_ksw_global2_score.argtypes = [C.c_int, vp, C.c_int, vp, vp] + [C.c_int] * 5
         L.orc_ars_sort.restype = None
         L.orc_ars_sort.argtypes = [i64, C.c_int, vp, vp, vp, vp]
+        L.orc_pestat.restype = None
+        L.orc_pestat.argtypes = [vp, i64, C.c_int, vp, vp, vp]
         L.orc_regs_finish.restype = i64
         L.orc_regs_finish.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
         _lib = L
@@ -340,13 +342,14 @@ class MemOpt(C.Structure):
                 ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
                 ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
                 ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
-                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float)]
+                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float), ("max_ins", C.c_int32)]
 
 
 def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
     """mem_opt_init defaults (src/bwamem.cpp:135-171)."""
     o = MemOpt(a, 6, 1, 6, 1, 5, 5, 100, 100, 19, 0, 1 << 30, 500, 10000, 0.5, 0.5)
     o.mask_level_redun = 0.95
+    o.max_ins = 10000
     for i, v in enumerate(fill_scmat(a, b)):
         o.mat[i] = v
     return o
@@ -513,3 +516,17 @@ def regs_finish(regs, reg_off, enc, cum, ref_string, l_pac, contigs=None, opt: M
     n = lib().orc_regs_finish(C.byref(opt), C.byref(bns), _p(ref_string), _p(enc), _p(cum), len(cum) - 1, _p(regs), _p(reg_off),
                               _p(out_off))
     return regs[:n].copy(), out_off
+
+
+PESTAT_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4"), ("avg", "<f8"), ("std", "<f8")])
+assert PESTAT_DTYPE.itemsize == 32
+
+
+def pestat(regs, reg_off, l_pac, opt: MemOpt | None = None):
+    """Restated mem_pestat over final regions (reads 2i, 2i+1 = pair i) -> 4 records (FF, FR, RF, RR)."""
+    opt = opt or default_mem_opt()
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE)
+    reg_off = np.ascontiguousarray(reg_off, np.int64)
+    pes = np.zeros(4, PESTAT_DTYPE)
+    lib().orc_pestat(C.byref(opt), int(l_pac), len(reg_off) - 1, _p(regs), _p(reg_off), _p(pes))
+    return pes

@@ -374,3 +374,37 @@ def test_final_regions_patch_split_alignments(rep_toy):
     c = np.zeros(1, capi.CONTIG_DTYPE)
     c["len"] = len(g)
     ix.set_contigs(c)
+
+
+def test_pestat_matches_oracle(rep_toy):
+    """mem_pestat over the final regions of paired reads: per-pair selection and the sort on the device, the
+    reference's percentile / mean / std arithmetic on the host — every field bit-equal to the oracle's."""
+    g, idx, ix = rep_toy
+    rng = np.random.default_rng(123)
+    reads = []
+    for i in range(3000):
+        ins = int(max(160, rng.normal(420, 45)))
+        st = int(rng.integers(0, len(g) - ins - 1))
+        frag = g[st:st + ins]
+        r1, r2 = frag[:150].copy(), simulate.revcomp(frag[-150:])
+        for r in (r1, r2):
+            pos = rng.integers(0, 150, size=int(rng.integers(0, 4)))
+            r[pos] = (r[pos] + 1) & 3
+        if i % 7 == 0:                                 # some pairs in the other orientations / unpaired
+            r2 = simulate.revcomp(r2)
+        if i % 2:
+            r1, r2 = simulate.revcomp(r1), simulate.revcomp(r2)
+        reads += [r1, r2]
+    for kw in (dict(), dict(max_ins=430), dict(mask_level=0.9)):
+        b, want, got, ctx = _run(idx, ix, g, reads, **kw)
+        wfin, _ = _assert_final(b, ctx, want)
+        wregs, wreg_off, _ = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
+                                              ctx["ref"], ctx["l_pac"], opt=ctx["oopt"])
+        wfin, wfin_off = loader.regs_finish(wregs, wreg_off, ctx["enc"], ctx["cum"], ctx["ref"], ctx["l_pac"], opt=ctx["oopt"])
+        wpes = loader.pestat(wfin, wfin_off, ctx["l_pac"], opt=ctx["oopt"])
+        pes = b.pestat(ctx["gopt"])
+        for f in ("low", "high", "failed", "avg", "std"):
+            assert np.array_equal(pes[f], wpes[f]), (kw, f, pes, wpes)
+        if not kw:
+            assert wpes["failed"][1] == 0 and 380 < wpes["avg"][1] < 460 and (wpes["failed"] == 0).sum() >= 2
+        b.close()

@@ -119,3 +119,48 @@ def test_whole_path_invariants():
             key = list(zip(-a["score"], a["rb"], a["qb"]))
             assert key == sorted(key) and len(set(key)) == len(key)
         assert np.all(a["qe"] > a["qb"])
+
+
+def test_pestat_from_definition():
+    """mem_pestat: orientation / insert size per pair (mem_infer_dir), the 'unique pair' selection, percentile bounds,
+    mean and std — recomputed in numpy for constructed final regions."""
+    l_pac = 1_000_000
+    rng = np.random.default_rng(2)
+    regs, off = [], [0]
+    ins_fr = []
+    for i in range(400):
+        p = int(rng.integers(1000, l_pac - 2000))
+        ins = int(rng.normal(350, 30))
+        a = _reg(p, p + 150, 0, 150, 150)                                         # read 1 forward at p
+        rb2 = 2 * l_pac - 1 - (p + ins)                                           # read 2 on the reverse strand, 5' end at p + ins
+        b = _reg(rb2, rb2 + 150, 0, 150, 150)
+        regs += [a, b]
+        off += [off[-1] + 1, off[-1] + 2]
+        ins_fr.append(ins)
+        if i % 50 == 0:                                                           # a pair with a strong second hit: not unique
+            regs.insert(len(regs) - 1, _reg(p + 5000, p + 5150, 0, 150, 140))
+            off[-2] += 1; off[-1] += 1
+            ins_fr.pop()
+    regs = np.concatenate(regs)
+    pes = loader.pestat(regs, np.array(off), l_pac)
+    assert list(pes["failed"]) == [1, 0, 1, 1]
+    q = np.sort(np.array(ins_fr, dtype=np.uint64))
+    n = len(q)
+    p25, p75 = int(q[int(.25 * n + .499)]), int(q[int(.75 * n + .499)])
+    low, high = max(1, int(p25 - 2.0 * (p75 - p25) + .499)), int(p75 + 2.0 * (p75 - p25) + .499)
+    sel = q[(q >= low) & (q <= high)].astype(np.float64)
+    avg = 0.0
+    for v in sel:
+        avg += v
+    avg /= len(sel)
+    sd = 0.0
+    for v in sel:
+        sd += (v - avg) * (v - avg)
+    sd = (sd / len(sel)) ** 0.5
+    assert pes["avg"][1] == avg and pes["std"][1] == sd
+    lo2, hi2 = int(p25 - 3.0 * (p75 - p25) + .499), int(p75 + 3.0 * (p75 - p25) + .499)
+    if lo2 > avg - 4.0 * sd:
+        lo2 = int(avg - 4.0 * sd + .499)
+    if hi2 < avg + 4.0 * sd:
+        hi2 = int(avg + 4.0 * sd + .499)
+    assert (pes["low"][1], pes["high"][1]) == (max(1, lo2), hi2)

@@ -28,6 +28,9 @@ def short(k):
                       ("ext_plan", "ext_plan_kernel"), ("ext_build", "ext_build_kernel (task construction)"),
                       ("ext_post", "ext_post_kernel"), ("ext_select_wave", "ext_select_wave_kernel (selection / purge, wave per read)"),
                       ("ext_select", "ext_select_kernel (selection / purge, lane per read)"),
+                      ("dedup_triage", "dedup_triage_kernel"), ("dedup_wave", "dedup_wave_kernel (mem_sort_dedup_patch, wave per read)"),
+                      ("dedup_gather", "dedup_gather_kernel"), ("dedup_kernel", "dedup_kernel (mem_sort_dedup_patch, lane per read)"),
+                      ("seedsw_", "seedsw kernels (long reads only)"),
                       ("pack_reads", "pack_reads_kernel"), ("round2_work", "round2_work_kernel"),
                       ("make_keys", "make_keys_kernel"), ("gather_sorted", "gather_sorted_kernel"),
                       ("plan_kernel", "plan_kernel (task construction)"), ("build_kernel", "build_kernel (task construction)"),

@@ -35,7 +35,7 @@ SYMBOLS = [
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
-    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_pestat",
+    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_pestat", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
 ]
 PESTAT_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4"), ("avg", "<f8"), ("std", "<f8")])
 
@@ -181,6 +181,8 @@ def lib():
         L.bwams_dedup_run.argtypes = [vp, vp, vp]
         L.bwams_dedup_fetch.argtypes = [vp, vp, i64, vp]
         L.bwams_pestat.argtypes = [vp, vp, vp]
+        L.bwams_emf_regs_run.argtypes = [vp, vp, vp, vp]
+        L.bwams_emf_regs_fetch.argtypes = [vp, vp, i64, vp, vp]
         L.bwams_seed_run.argtypes = [vp, vp, C.c_int]
         L.bwams_seed_counts.argtypes = [vp, vp, vp]
         L.bwams_seed_fetch.argtypes = [vp, vp, i64, vp, i64, vp]
@@ -476,6 +478,17 @@ class Batch:
         off = np.zeros(self._nseq + 1, np.int64)
         _chk(lib().bwams_dedup_fetch(self.h, _p(regs), self._n_final, _p(off)), "bwams_dedup_fetch")
         return regs, off
+
+    def emf_regs(self, emf: "Emf", opt: MemOpt | None = None):
+        """mem_perfect2reg for the reads the last emf_run resolved -> (regs, reg_off, first_is_rev)."""
+        opt = opt or default_mem_opt()
+        n = C.c_int64(0)
+        _chk(lib().bwams_emf_regs_run(self.h, emf.h, C.byref(opt), C.byref(n)), "bwams_emf_regs_run")
+        regs = np.zeros(n.value, ALNREG_DTYPE)
+        off = np.zeros(self._nseq + 1, np.int64)
+        rev = np.zeros(self._nseq, np.uint8)
+        _chk(lib().bwams_emf_regs_fetch(self.h, _p(regs), n.value, _p(off), _p(rev)), "bwams_emf_regs_fetch")
+        return regs, off, rev
 
     def pestat(self, opt: MemOpt | None = None):
         """mem_pestat over the final regions (reads 2i, 2i+1 = pair i) -> 4 records FF, FR, RF, RR."""

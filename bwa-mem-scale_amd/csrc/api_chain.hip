@@ -41,6 +41,9 @@ struct ChainState {
     DevBuf sw_qb, sw_rb, sw_read, sw_newn, sw_res;      // mem_flt_chained_seeds (long reads)
     DevBuf dd_regs, dd_ord, dd_srt, dd_eh, dd_nout, dd_wide, dd_off, dd_out, dd_light;   // mem_sort_dedup_patch
     DevBuf pe_keys, pe_keys2;                           // mem_pestat
+    DevBuf er_wide, er_off, er_scr, er_n, er_rev, er_out, er_ooff;   // mem_perfect2reg
+    int64_t er_total = 0, er_nseq = 0;
+    bool er_done = false;
     int64_t n_final = 0;
     bool dedup_done = false;
     int64_t n_chains = 0, n_seeds = 0, nseq = 0;
@@ -63,7 +66,7 @@ void chain_state_free(ChainState *s) {
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
                      &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
-                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -697,6 +700,65 @@ int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, i
     hipStream_t st = b->stream;
     if (s->n_final) BWAMS_HIP(hipMemcpyAsync(regs, s->dd_out.p, (size_t)s->n_final * sizeof(bwams_alnreg_t), hipMemcpyDeviceToHost, st));
     if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->dd_off.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    return BWAMS_OK;
+}
+
+/* ------------------------------------------------------------ mem_perfect2reg ---- */
+
+int bwams_emf_regs_run(bwams_batch_t *b, bwams_emf_t *e, const bwams_mem_opt_t *opt, int64_t *n_regs) {
+    if (!b || !e || !b->d_emf_out || !b->d_emf_code) {
+        set_last_error("bwams_emf_regs_run: run bwams_emf_run first");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_emf_regs_run");
+    if (rc) return rc;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    ChainState *s;
+    if ((rc = get_state(b, &s))) return rc;
+    s->er_done = false;
+    hipStream_t st = b->stream;
+    const int64_t nseq = b->nseq, n1 = nseq + 1;
+    BWAMS_HIP(s->er_wide.ensure((size_t)n1 * 8)); BWAMS_HIP(s->er_off.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->er_ooff.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->er_n.ensure((size_t)n1 * 4)); BWAMS_HIP(s->er_rev.ensure((size_t)n1));
+    EmfRegArgs A;
+    A.t = e->t; A.perfect = b->d_emf_out; A.code = b->d_emf_code; A.enc = b->d_enc; A.cum = b->d_cum; A.nseq = nseq;
+    if ((rc = dev_bns(b->idx, &A.bns))) return rc;
+    A.opt = *opt;
+    A.scratch = nullptr;
+    launch_emfregs_count(A, s->er_wide.as<int64_t>(), st);
+    if ((rc = scan_rows(b, s->er_wide.as<int64_t>(), s->er_off.as<int64_t>(), 1, n1))) return rc;
+    int64_t n_scr = 0, total = 0;
+    BWAMS_HIP(hipMemcpyAsync(&n_scr, s->er_off.as<int64_t>() + nseq, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(s->er_scr.ensure(emfregs_scratch_bytes(n_scr)));
+    A.scratch = s->er_scr.p;
+    launch_emfregs_fill(A, s->er_off.as<int64_t>(), s->er_n.as<int32_t>(), s->er_rev.as<uint8_t>(), s->er_wide.as<int64_t>(), st);
+    if ((rc = scan_rows(b, s->er_wide.as<int64_t>(), s->er_ooff.as<int64_t>(), 1, n1))) return rc;
+    BWAMS_HIP(hipMemcpyAsync(&total, s->er_ooff.as<int64_t>() + nseq, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(s->er_out.ensure((size_t)(total + 1) * sizeof(bwams_alnreg_t)));
+    launch_emfregs_emit(A, s->er_off.as<int64_t>(), s->er_n.as<int32_t>(), s->er_ooff.as<int64_t>(), s->er_out.as<bwams_alnreg_t>(), st);
+    BWAMS_HIP(hipGetLastError());
+    s->er_total = total; s->er_nseq = nseq;
+    s->er_done = true;
+    if (n_regs) *n_regs = total;
+    return BWAMS_OK;
+}
+
+int bwams_emf_regs_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, uint8_t *first_is_rev) {
+    if (!b || !b->chain || !b->chain->er_done) {
+        set_last_error("bwams_emf_regs_fetch: run bwams_emf_regs_run first");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    if (s->er_total > reg_cap) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    if (s->er_total) BWAMS_HIP(hipMemcpyAsync(regs, s->er_out.p, (size_t)s->er_total * sizeof(bwams_alnreg_t), hipMemcpyDeviceToHost, st));
+    if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->er_ooff.p, (size_t)(s->er_nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (first_is_rev && s->er_nseq) BWAMS_HIP(hipMemcpyAsync(first_is_rev, s->er_rev.p, (size_t)s->er_nseq, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     return BWAMS_OK;
 }

@@ -136,4 +136,23 @@ void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n
                    unsigned long long *keys, hipStream_t st);
 void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
 
+// ---- regions of the reads the exact-match filter resolved (emf_regs.hip) ----
+struct EmfRegArgs {
+    DevEmf t;
+    const uint32_t *perfect;       // 2 per read: flags, location (bseq1_perfect_t)
+    const uint8_t *code;           // FIND_PERFECT_* per read
+    const uint8_t *enc;
+    const int64_t *cum;
+    int64_t nseq;
+    DevBns bns;
+    bwams_mem_opt_t opt;
+    void *scratch;                 // mem_aln_perfect_t-like records, a slice per read
+};
+size_t emfregs_scratch_bytes(int64_t n);
+void launch_emfregs_count(const EmfRegArgs &A, int64_t *wide, hipStream_t st);
+void launch_emfregs_fill(const EmfRegArgs &A, const int64_t *scr_off, int32_t *n_final, uint8_t *first_is_rev, int64_t *wide,
+                         hipStream_t st);
+void launch_emfregs_emit(const EmfRegArgs &A, const int64_t *scr_off, const int32_t *n_final, const int64_t *out_off,
+                         bwams_alnreg_t *out, hipStream_t st);
+
 }  // namespace bwams

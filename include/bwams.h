@@ -272,6 +272,12 @@ int bwams_extend_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, 
  * the options.  The extension's regions stay available to bwams_extend_fetch. */
 int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_regs);
 int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off);
+/* mem_perfect2reg with get_perfect_locations and perfect_dedup_patch (src/perfect_map.cpp:659-869), for every read
+ * the last bwams_emf_run resolved (code FW_MATCHED / RC_MATCHED): all its exact locations as full-length regions
+ * (grouped by read, reg_off[nseq + 1]); first_is_rev[r] = mem_perfect2reg's return value (strand of the first one). */
+int bwams_emf_regs_run(bwams_batch_t *b, bwams_emf_t *emf, const bwams_mem_opt_t *opt, int64_t *n_regs);
+int bwams_emf_regs_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, uint8_t *first_is_rev);
+
 /* mem_pestat (src/bwamem_pair.cpp:89-156; called at src/bwamem.cpp:1888) over the final regions of
  * bwams_dedup_run: reads 2i and 2i+1 are the two ends of pair i.  pes[4] = orientations FF, FR, RF, RR.
  * The per-pair work (cal_sub, mem_infer_dir) and the sort run on the device; the percentile / mean / std

@@ -134,6 +134,12 @@ int orc_emf_match_further(const orc_emf_t *t, uint32_t loc, const uint8_t *seed,
 /* find_perfect_match_entry (src/perfect_map.cpp:638-659): returns the FIND_PERFECT_* code */
 int orc_emf_probe(const orc_emf_t *t, const uint8_t *seed, int len, uint32_t *flags, uint32_t *location);
 
+/* mem_perfect2reg with get_perfect_locations and perfect_dedup_patch (src/perfect_map.cpp:659-869): the regions of a
+ * read that the EMF resolved (flags / location = its bseq1_perfect_t).  Returns the count (-1: cap too small). */
+struct orc_bns;
+int orc_perfect2reg(const bwams_mem_opt_t *opt, const orc_emf_t *t, const struct orc_bns *bns, const uint8_t *seq, int l_seq,
+                    uint32_t flags, uint32_t location, bwams_alnreg_t *out, int cap, int *first_is_rev);
+
 /* ksw_align2 (src/ksw.cpp:347-381) over ksw_u8 / ksw_i16: local SW of mate rescue.
  * out[7] = score, te, qe, score2, te2, tb, qb. */
 void orc_ksw_align2(const bwams_sw_opt_t *o, int qlen, const uint8_t *query, int tlen,

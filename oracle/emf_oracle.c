@@ -154,3 +154,109 @@ int orc_emf_probe(const orc_emf_t *t, const uint8_t *seed, int len, uint32_t *fl
     }
     return 2;                                           /* FIND_PERFECT_NOT_MATCHED */
 }
+
+/* ---- EMF result consumers: get_perfect_locations, perfect_dedup_patch, mem_perfect2reg
+ *      (perfect_map.cpp:659-869): every location of an exactly matching read as a mem_alnreg_t.
+ *      PARITY UNPINNED (perfect_map.cpp is not buildable here); the primitives it calls are pinned. ---- */
+typedef struct { int64_t loc, pos; int rid, is_rev, is_alt; } aln_perfect_t;
+
+static int emf_pos2rid(const orc_bns_t *b, int64_t pos_f)
+{
+    int left = 0, mid = 0, right = b->n_seqs;
+    if (pos_f >= b->l_pac) return -1;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= b->contigs[mid].offset) {
+            if (mid == b->n_seqs - 1) break;
+            if (pos_f < b->contigs[mid + 1].offset) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+static void init_aln(aln_perfect_t *a, int64_t pos, int len, int is_rev, const orc_bns_t *bns, int seed_len)
+{
+    a->loc = pos;
+    a->rid = emf_pos2rid(bns, pos);
+    if (len != seed_len && is_rev) pos = pos - (len - seed_len);
+    a->pos = pos - bns->contigs[a->rid].offset;
+    a->is_rev = is_rev;
+    a->is_alt = bns->contigs[a->rid].is_alt != 0;
+}
+static int init_multi(aln_perfect_t *av, int n, uint32_t num_loc, const uint32_t *locs, const uint8_t *seq, int l_seq, int is_rev,
+                      uint32_t matched_loc, const orc_bns_t *bns, const orc_emf_t *t)
+{
+    for (uint32_t i = 0; i < num_loc; ++i) {
+        const uint32_t loc = locs[is_rev ? num_loc - 1 - i : i];        /* keeps the vector sorted by rb */
+        if (loc == matched_loc) continue;
+        if (t->seed_len == l_seq || orc_emf_match_further(t, loc, seq, is_rev, l_seq))
+            init_aln(&av[n++], (int64_t)loc, l_seq, is_rev, bns, t->seed_len);
+    }
+    return n;
+}
+int orc_perfect2reg(const bwams_mem_opt_t *opt, const orc_emf_t *t, const orc_bns_t *bns, const uint8_t *seq, int l_seq,
+                    uint32_t flags, uint32_t location, bwams_alnreg_t *out, int cap, int *first_is_rev)
+{
+    const int rc_matched = (flags & FLAG_RC) != 0;
+    const uint32_t multi = flags >> 2;
+    const uint32_t *lt = t->loc_table;
+    int m = 1;
+    if (multi) {
+        const uint32_t first = lt[multi];
+        m = (first & 0x80000000u) ? 1 + (int)lt[first & 0x7fffffffu] + (int)lt[(first & 0x7fffffffu) + 1]
+                                  : 1 + (int)((first >> 16) & 0xffff) + (int)(first & 0xffff);
+    }
+    aln_perfect_t *av = (aln_perfect_t *)calloc((size_t)m, sizeof *av);
+    int n = 0;
+    if (!multi) init_aln(&av[n++], (int64_t)location, l_seq, rc_matched ? 1 : 0, bns, t->seed_len);
+    else {
+        const int many = (lt[multi] & 0x80000000u) != 0;
+        const uint32_t st = many ? (lt[multi] & 0x7fffffffu) : multi;
+        uint32_t nfw, nrc;
+        const uint32_t *lfw, *lrc;
+        if (!many) { nfw = (lt[st] >> 16) & 0xffff; nrc = lt[st] & 0xffff; lfw = &lt[st + 1]; lrc = &lt[st + 1 + nfw]; }
+        else { nfw = lt[st]; nrc = lt[st + 1]; lfw = &lt[st + 2]; lrc = &lt[st + 2 + nfw]; }
+        if (!rc_matched) {
+            init_aln(&av[n++], (int64_t)location, l_seq, 0, bns, t->seed_len);
+            n = init_multi(av, n, nfw, lfw, seq, l_seq, 0, location, bns, t);
+            n = init_multi(av, n, nrc, lrc, seq, l_seq, 1, location, bns, t);
+        } else {
+            n = init_multi(av, n, nrc, lrc, seq, l_seq, 0, location, bns, t);
+            init_aln(&av[n++], (int64_t)location, l_seq, 1, bns, t->seed_len);
+            n = init_multi(av, n, nfw, lfw, seq, l_seq, 1, location, bns, t);
+        }
+    }
+    /* perfect_dedup_patch (perfect_map.cpp:781-815) */
+    if (n > 1) {
+        int i, j, k;
+        for (i = 1; i < n; ++i) {
+            aln_perfect_t *p = &av[i];
+            if (p->rid != av[i - 1].rid || p->is_rev != av[i - 1].is_rev || p->pos >= av[i - 1].pos + l_seq + opt->max_chain_gap) continue;
+            for (j = i - 1; j >= 0 && p->rid == av[j].rid && p->is_rev == av[j].is_rev && p->pos < av[j].pos + l_seq + opt->max_chain_gap; --j) {
+                aln_perfect_t *q = &av[j];
+                if (q->rid < 0) continue;
+                if (q->pos + l_seq - p->pos > opt->mask_level_redun * l_seq) q->rid = -1;
+            }
+        }
+        for (i = 0, k = 0; i < n; ++i)
+            if (av[i].rid >= 0) { if (k != i) av[k++] = av[i]; else ++k; }
+        n = k;
+    }
+    if (first_is_rev) *first_is_rev = av[0].is_rev;
+    if (n > cap) { free(av); return -1; }
+    for (int i = 0; i < n; ++i) {                         /* mem_perfect2reg (perfect_map.cpp:817-867) */
+        const aln_perfect_t *p = &av[i];
+        bwams_alnreg_t *r = &out[i];
+        memset(r, 0, sizeof *r);
+        if (!p->is_rev) { r->rb = p->loc; r->re = p->loc + l_seq; }
+        else { r->rb = (bns->l_pac << 1) - (p->loc + l_seq); r->re = (bns->l_pac << 1) - p->loc; }
+        r->qb = 0; r->qe = l_seq;
+        r->rid = p->rid;
+        r->score = r->truesc = l_seq * opt->a;
+        r->w = opt->w;
+        r->seedlen0 = l_seq;
+        r->n_comp_is_alt = 1 | (p->is_alt << 30);
+    }
+    free(av);
+    return n;
+}

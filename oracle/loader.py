@@ -186,6 +186,20 @@ class OracleEMF:
             out[i] = self.probe(r)
         return out
 
+    def perfect2reg(self, read, flags: int, location: int, l_pac: int, contigs=None, opt=None, cap: int = 1 << 16):
+        """Restated mem_perfect2reg for one resolved read -> (regs, first_is_rev)."""
+        L = lib()
+        L.orc_perfect2reg.restype = C.c_int
+        L.orc_perfect2reg.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+        opt = opt or default_mem_opt()
+        bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
+        r = np.ascontiguousarray(read, dtype=np.uint8)
+        out = np.zeros(cap, ALNREG_DTYPE)
+        rev = C.c_int(0)
+        n = L.orc_perfect2reg(C.byref(opt), C.byref(self.t), C.byref(bns), _p(r), len(r), flags, location, _p(out), cap, C.byref(rev))
+        assert n >= 0
+        return out[:n].copy(), rev.value
+
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None

@@ -417,3 +417,75 @@ def test_emf_resident_run_with_gpu_built_table(gpu_toy):
     st = b.stats()
     assert st.emf_nodes >= hit.sum() and st.emf_cmp_bytes == st.emf_nodes * 150
     b.close(); e.close(); ix.close()
+
+
+@pytest.mark.parametrize("L", [150, 64])
+def test_emf_regions_match_oracle(gpu_toy, L, tmp_path):
+    """mem_perfect2reg: every exact location of an EMF-resolved read (multi-location lists on both strands, tails
+    verified for reads longer than L, overlapping locations of a tandem repeat collapsed) as a full-length region."""
+    from bwams import emf
+    g0, idx0, _ = gpu_toy
+    g = g0[:60000].copy()
+    g[5000:5400] = g[1000:1400]                              # exact repeats -> multi-location entries
+    g[9000:9400] = (3 - g[1000:1400][::-1])                  # a reverse-complement copy
+    g[30000:30400] = g[1000:1400]
+    g[20000:20700] = np.tile(np.array([0, 1, 0, 2, 1], np.uint8), 140)      # tandem repeat: locations 5 bases apart
+    idx = fmindex.build_fmindex(g)
+    ix = capi.Index.from_host(idx, 0)
+    contigs = np.zeros(3, capi.CONTIG_DTYPE)
+    contigs["offset"], contigs["len"], contigs["is_alt"] = [0, 8000, 25000], [8000, 17000, len(g) - 25000], [0, 0, 1]
+    ix.set_contigs(contigs)
+    tab = emf.build_emf(g, L)
+    e = capi.Emf(ix, table=tab)
+    o = loader.OracleEMF(tab, idx.ref_0123)
+    rng = np.random.default_rng(L + 1)
+    reads = []
+    for it in range(1500):
+        ln = L if it % 3 else int(rng.integers(L + 1, L + 50))
+        where = it % 5
+        if where == 0:
+            st = int(rng.integers(1000, 1400 - ln)) if ln < 400 else 1000
+        elif where == 1:
+            st = int(rng.integers(20000, 20700 - ln))
+        else:
+            st = int(rng.integers(0, len(g) - ln))
+        rd = g[st:st + ln].copy()
+        if it % 2:
+            rd = simulate.revcomp(rd)
+        if it % 11 == 0:
+            rd[rng.integers(0, ln)] ^= 1
+        reads.append(rd)
+    enc, cum = simulate.flatten_reads(reads)
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.emf_run(e)
+    perfect, code = b.emf_fetch(len(reads))
+    regs, off, rev = b.emf_regs(e)
+    n_multi = n_collapsed = 0
+    for r, rd in enumerate(reads):
+        got = regs[off[r]:off[r + 1]]
+        if code[r] not in (3, 4):
+            assert len(got) == 0
+            continue
+        want, wrev = o.perfect2reg(rd, int(perfect[r, 0]), int(perfect[r, 1]), len(g), contigs=contigs)
+        assert len(got) == len(want) and rev[r] == wrev, r
+        for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedlen0", "n_comp_is_alt", "sub", "csub", "seedcov"):
+            assert np.array_equal(got[f], want[f]), (r, f)
+        n_multi += len(want) > 1
+        if perfect[r, 0] >> 2:
+            first = int(tab.loc_table[perfect[r, 0] >> 2])
+            n_loc = 1 + ((first >> 16) & 0xffff) + (first & 0xffff) if not first & 0x80000000 else None
+            if n_loc is not None and len(want) < n_loc:
+                n_collapsed += 1
+        # every region is an exact occurrence of the read — except that for a reverse-strand hit of a read longer than
+        # L the reference places the region from the seed's location, not from the read's (mem_perfect2reg uses
+        # mem_aln_perfect_t::loc, which init_mem_aln_perfect leaves unadjusted): restated as is
+        ref = idx.ref_0123
+        for a in want:
+            if len(rd) == L or a["rb"] < len(g):
+                assert np.array_equal(ref[a["rb"]:a["re"]], rd)
+    assert n_multi > 100 and n_collapsed > 20
+    b.close(); e.close()
+    c = np.zeros(1, capi.CONTIG_DTYPE)
+    c["len"] = len(g)
+    ix.close()

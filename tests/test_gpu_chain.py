@@ -408,3 +408,51 @@ def test_pestat_matches_oracle(rep_toy):
         if not kw:
             assert wpes["failed"][1] == 0 and 380 < wpes["avg"][1] < 460 and (wpes["failed"] == 0).sum() >= 2
         b.close()
+
+
+def test_degenerate_inputs_through_the_whole_path(rep_toy):
+    """Empty chunk, reads without seeds (all N, too short, random), a single read, an odd read count for mem_pestat."""
+    g, idx, ix = rep_toy
+    rng = np.random.default_rng(8)
+    cases = [
+        [],
+        [np.full(100, 4, np.uint8)],
+        [g[100:110].copy()],
+        [rng.integers(0, 4, size=150, dtype=np.uint8)],
+        [g[2000:2150].copy()],
+        [np.full(60, 4, np.uint8), g[3000:3150].copy(), g[10:25].copy(), rng.integers(0, 4, size=80, dtype=np.uint8),
+         simulate.revcomp(g[7000:7200]), np.zeros(150, np.uint8), g[500:519].copy()],
+    ]
+    for reads in cases:
+        if reads:
+            enc, cum = simulate.flatten_reads(reads)
+        else:
+            enc, cum = np.zeros(0, np.uint8), np.zeros(1, np.int64)
+        o = loader.OracleFMI(idx)
+        sm = o.collect_smem(enc, cum) if reads else np.zeros(0, loader.SMEM_DTYPE)
+        coord, off = o.sa_lookup(sm) if len(sm) else (np.zeros(0, np.int64), np.zeros(1, np.int64))
+        l_pac = len(g)
+        ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+        oopt, gopt = _mem_opts()
+        wch, wsd, wchoff = loader.chain_seeds(sm, coord, off, cum, l_pac, opt=oopt, ref_string=ref, enc=enc)
+        wregs, wreg_off, wsd2 = loader.chain2aln(wch, wsd, wchoff, enc, cum, ref, l_pac, opt=oopt)
+        wfin, wfin_off = loader.regs_finish(wregs, wreg_off, enc, cum, ref, l_pac, opt=oopt)
+        b = capi.Batch(ix, max(len(reads), 1), max(int(cum[-1]), 1))
+        b.seed_upload(enc, cum)
+        b.seed_run(capi.default_seed_opt(), with_sa=True)
+        nc, ns = b.chain_run(gopt)
+        ch, sd, choff = b.chain_fetch()
+        assert nc == len(wch) and ns == len(wsd) and np.array_equal(choff, wchoff)
+        n = b.extend_run(gopt)
+        regs, reg_off, aln = b.extend_fetch()
+        assert n == len(wregs) and np.array_equal(reg_off, wreg_off)
+        _assert_regs(regs, wregs, False)
+        assert b.dedup_run(gopt) == len(wfin)
+        fin, fin_off = b.dedup_fetch()
+        assert np.array_equal(fin_off, wfin_off)
+        for f in FINAL_FIELDS:
+            assert np.array_equal(fin[f], wfin[f]), f
+        pes, wpes = b.pestat(gopt), loader.pestat(wfin, wfin_off, l_pac, opt=oopt)
+        for f in ("low", "high", "failed", "avg", "std"):
+            assert np.array_equal(pes[f], wpes[f]), f
+        b.close()

@@ -335,6 +335,8 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
         if ((rc = scan_rows(b, s->wide.as<int64_t>(), s->chain_off.as<int64_t>(), 2, n1))) return rc;
         BWAMS_HIP(hipMemcpyAsync(&tot[0], s->chain_off.as<int64_t>() + nseq, 8, hipMemcpyDeviceToHost, st));
         BWAMS_HIP(hipMemcpyAsync(&tot[1], s->chain_off.as<int64_t>() + n1 + nseq, 8, hipMemcpyDeviceToHost, st));
+    } else {
+        BWAMS_HIP(hipMemsetAsync(s->chain_off.p, 0, (size_t)n1 * 16, st));       // no reads: both offset rows are {0}
     }
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
@@ -441,6 +443,7 @@ static int ext_args(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, E
     A->cnt = s->cnt.as<int32_t>(); A->ctr = b->d_ctr;
     A->state = s->state.as<int32_t>(); A->kreg = s->kreg.p;
     A->cur = s->cur.as<int32_t>(); A->lim = s->lim.as<int32_t>();
+    A->sel_heavy = s->heavy.as<int32_t>(); A->n_sel_heavy = &b->d_ctr->sel_heavy; A->sel_ticket = &b->d_ctr->sel_ticket;
     return BWAMS_OK;
 }
 
@@ -457,8 +460,11 @@ static int ext_plan(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, i
     BWAMS_HIP(s->kreg.ensure((size_t)N1 * 32));
     BWAMS_HIP(s->cur.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->lim.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
     int rc = ext_args(b, s, opt, A);
     if (rc) return rc;
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->sel_heavy, 0, 2 * sizeof(unsigned long long), b->stream));
+    launch_ext_heavy_list(*A, b->stream);
     BWAMS_HIP(hipMemsetAsync(s->cur.p, 0, (size_t)n1 * 4, b->stream));
     BWAMS_HIP(hipMemsetAsync(s->lim.p, 0, (size_t)n1 * 4, b->stream));
     launch_ext_plan(*A, extend_all, b->stream);
@@ -591,6 +597,7 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
         if ((rc = run_side(b, s, A, 1, &s->n_retry_right))) return rc;
         if (round == 0) { BWAMS_HIP(hipEventRecord(s->ev[7], st)); BWAMS_HIP(hipEventRecord(s->ev[8], st)); }
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_req, 0, sizeof(unsigned long long), st));
+        BWAMS_HIP(hipMemsetAsync(&b->d_ctr->sel_ticket, 0, sizeof(unsigned long long), st));
         if (s->n_seeds) launch_ext_select(A, b->cu_count, st);
         if (round == 0) BWAMS_HIP(hipEventRecord(s->ev[9], st));
         unsigned long long n_req = 0;
@@ -672,7 +679,10 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     // work on a copy: bwams_extend_fetch stays valid
     if (N) BWAMS_HIP(hipMemcpyAsync(D.regs, s->regs.p, (size_t)N * sizeof(bwams_alnreg_t), hipMemcpyDeviceToDevice, st));
     BWAMS_HIP(hipMemsetAsync(D.n_out, 0, (size_t)n1 * 4, st));
-    launch_dedup(D, n_lanes, n_waves, st);
+    if (launch_dedup(D, n_lanes, n_waves, st, s->aux[0], s->fork, s->join[0])) {
+        set_last_error("bwams_dedup_run: stream fork/join failed");
+        return BWAMS_ERR_DEVICE;
+    }
     int64_t total = 0;
     if (s->nseq > 0) {
         widen2_kernel<<<(unsigned)((2 * n1 + 255) / 256), 256, 0, st>>>(D.n_out, D.n_out, s->nseq, s->dd_wide.as<int64_t>());

@@ -30,6 +30,7 @@
 //     final insertion sort, comb-sort depth fallback), which is not stable.
 #include "common.h"
 #include "chain_kernels.h"
+#include "wave_ops.h"
 
 namespace bwams {
 namespace {
@@ -686,10 +687,7 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(ChainArgs A, const unsig
     ChainRec *l_crec = reinterpret_cast<ChainRec *>(l_mem);
     Node *l_nodes = reinterpret_cast<Node *>(l_mem + (size_t)K * sizeof(ChainRec));
     for (;;) {
-        unsigned long long t = 0;
-        if (lane == 0) t = atomicAdd(ticket, 1ull);
-        t = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
-            (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t);
+        const unsigned long long t = wave_ticket(ticket, 1ull);
         if (lo + (int64_t)t >= hi) break;
         const int64_t r = (int64_t)A.order[lo + (int64_t)t];
         if (K) chain_read<true>(A, r, lane, 64, l_nodes, lds_nodes(K), l_crec, K);
@@ -707,10 +705,7 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
     const int lane = threadIdx.x;
     const int64_t n_heavy = (int64_t)*n_heavy_p;
     for (;;) {
-        unsigned long long tk = 0;
-        if (lane == 0) tk = atomicAdd(&A.ctr->heavy_ticket, 1ull);
-        const int64_t hi = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tk >> 32)) << 32) |
-                                     (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)tk));
+        const int64_t hi = (int64_t)wave_ticket(&A.ctr->heavy_ticket, 1ull);
         if (hi >= n_heavy) break;
         const int64_t r = A.heavy[hi];
         const int64_t base = A.read_base[r];

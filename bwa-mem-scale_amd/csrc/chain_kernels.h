@@ -72,6 +72,8 @@ struct ExtArgs {
     int32_t *state;                // per seed: kept / purged / requested / extended (extension rounds)
     void *kreg;                    // per read (at its first region's slot): the regions kept so far, 32 B each
     int32_t *cur, *lim;            // per read: seeds decided so far, regions kept so far
+    int32_t *sel_heavy;            // reads with many regions (the selection's wave tier)
+    unsigned long long *n_sel_heavy, *sel_ticket;
     DevCounters *ctr;
 };
 void launch_ext_plan(const ExtArgs &A, int extend_all, hipStream_t st);
@@ -82,6 +84,7 @@ void launch_ext_build(const ExtArgs &A, const int64_t *offs, bwams_seqpair_t *le
 void launch_ext_post(const ExtArgs &A, int right, const bwams_seqpair_t *pairs, int64_t n, int w, int last_try,
                      bwams_seqpair_t *retry, unsigned long long *n_retry, hipStream_t st);
 void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hipStream_t st);
+void launch_ext_heavy_list(const ExtArgs &A, hipStream_t st);
 void launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st);
 void launch_ext_request_rest(const ExtArgs &A, hipStream_t st);
 
@@ -131,7 +134,8 @@ struct DedupArgs {
     int32_t force_seq;             // debug: lane 0 runs the one-lane form for every read
 };
 size_t dedup_sortrec_bytes(int64_t n);
-void launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st);
+int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st, hipStream_t aux, hipEvent_t fork,
+                 hipEvent_t join);
 void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n_pairs, int64_t l_pac, const bwams_mem_opt_t &opt,
                    unsigned long long *keys, hipStream_t st);
 void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);

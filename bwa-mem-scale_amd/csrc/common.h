@@ -72,6 +72,7 @@ struct DevCounters {
     unsigned long long heavy_ticket;     // chaining: work cursor of chain_heavy_kernel
     unsigned long long n_retry;          // extension: tasks queued for the next band width
     unsigned long long n_req;            // extension: seeds requested by the last selection
+    unsigned long long sel_heavy, sel_ticket;       // extension: reads of the selection's wave tier, its work cursor
     unsigned long long dedup_heavy, dedup_ticket, dedup_light;   // dedup: reads for the wave tier, its work cursor, reads for the lane tier
 };
 

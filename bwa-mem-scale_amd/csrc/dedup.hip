@@ -10,6 +10,7 @@
 // HBM strip): rare, and a few hundred microseconds for 150-base reads.
 #include "common.h"
 #include "chain_kernels.h"
+#include "wave_ops.h"
 
 namespace bwams {
 namespace {
@@ -331,10 +332,7 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
     int2 *eh = A.eh + (A.eh_lanes + blockIdx.x) * (int64_t)(A.max_read_len + 2);
     const int64_t n_heavy = (int64_t)*A.n_heavy_ctr;
     for (;;) {
-        unsigned long long tk = 0;
-        if (lane == 0) tk = atomicAdd(A.ticket, 1ull);
-        const int64_t t = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tk >> 32)) << 32) |
-                                    (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)tk));
+        const int64_t t = (int64_t)wave_ticket(A.ticket, 1ull);
         if (t >= n_heavy) break;
         const int64_t r = A.heavy[t];
         const int64_t reg0 = A.seed_off[r];
@@ -497,11 +495,16 @@ void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n
 
 size_t dedup_sortrec_bytes(int64_t n) { return (size_t)(n + 1) * sizeof(SortRec); }
 
-void launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st) {
-    if (A.nseq <= 0) return;
+// triage, then the lane tier and the wave tier side by side (they work on disjoint reads)
+int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st, hipStream_t aux, hipEvent_t fork,
+                 hipEvent_t join) {
+    if (A.nseq <= 0) return 0;
     dedup_triage_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A);
-    dedup_kernel<<<(unsigned)((n_lanes + 63) / 64), 64, 0, st>>>(A, n_lanes);
+    if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(aux, fork, 0) != hipSuccess) return -1;
     dedup_wave_kernel<<<(unsigned)n_waves, 64, 0, st>>>(A, n_waves);
+    dedup_kernel<<<(unsigned)((n_lanes + 63) / 64), 64, 0, aux>>>(A, n_lanes);
+    if (hipEventRecord(join, aux) != hipSuccess || hipStreamWaitEvent(st, join, 0) != hipSuccess) return -1;
+    return 0;
 }
 void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st) {
     if (A.nseq <= 0) return;

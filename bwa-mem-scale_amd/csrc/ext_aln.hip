@@ -11,6 +11,7 @@
 // visited (chain by chain, seeds by descending score then index), as in the reference's av->a.
 #include "common.h"
 #include "chain_kernels.h"
+#include "wave_ops.h"
 
 namespace bwams {
 namespace {
@@ -342,10 +343,20 @@ __global__ __launch_bounds__(64) void ext_select_kernel(ExtArgs A) {
     if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&A.ctr->n_req, (unsigned long long)__popcll(m));
 }
 
+// lane per read, once per run: the reads the wave tier of the selection handles
+__global__ void ext_heavy_list_kernel(ExtArgs A) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.nseq) return;
+    if (A.seed_off[r + 1] - A.seed_off[r] > kLightRegs) A.sel_heavy[atomicAdd(A.n_sel_heavy, 1ull)] = (int32_t)r;
+}
+
 __global__ __launch_bounds__(256) void ext_select_wave_kernel(ExtArgs A) {
     const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < A.nseq; r += stride) {
+    const int64_t n_heavy = (int64_t)*A.n_sel_heavy;
+    for (;;) {
+        const int64_t ti = (int64_t)wave_ticket(A.sel_ticket, 1ull);
+        if (ti >= n_heavy) break;
+        const int64_t r = A.sel_heavy[ti];
         const int64_t reg0 = A.seed_off[r];
         const int av_n = (int)(A.seed_off[r + 1] - reg0);
         int t = A.cur[r];
@@ -433,12 +444,14 @@ void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hi
     ext_right_h0_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(A, right, n);
 }
 
+void launch_ext_heavy_list(const ExtArgs &A, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    ext_heavy_list_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A);
+}
 void launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st) {
     if (A.nseq <= 0) return;
     ext_select_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
-    int64_t blocks = (A.nseq + 3) / 4;
-    if (blocks > (int64_t)cu_count * 8) blocks = (int64_t)cu_count * 8;
-    ext_select_wave_kernel<<<(unsigned)blocks, 256, 0, st>>>(A);
+    ext_select_wave_kernel<<<(unsigned)(cu_count * 2), 256, 0, st>>>(A);
 }
 void launch_ext_request_rest(const ExtArgs &A, hipStream_t st) {
     if (A.n_seeds <= 0) return;

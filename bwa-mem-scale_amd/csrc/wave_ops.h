@@ -24,4 +24,16 @@ __device__ __forceinline__ int scan_max(int v) {
 __device__ __forceinline__ int lane_shr1(int v, int fill) { return dppi<0x138, 0xF, 0xF>(fill, v); }   // wave_shr:1
 
 
+// One value per wave from a global cursor: lane 0 advances it by `step`, every lane gets the old value.
+// Deliberately out of line.  Inlined into a `for (;;)` with a `continue`, the lane-0 branch around the
+// atomic was threaded through the loop's back edge (the other lanes "know" their ticket is the constant
+// 0), which split the wave: lanes 1..63 re-ran the loop body with ticket 0 while lane 0 fetched the next
+// one.  A call keeps the branch and the broadcast together.
+__device__ __noinline__ inline unsigned long long wave_ticket(unsigned long long *cursor, unsigned long long step) {
+    unsigned long long t = 0;
+    if ((threadIdx.x & 63) == 0) t = atomicAdd(cursor, step);
+    return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
+           (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t);
+}
+
 }  // namespace bwams

@@ -77,7 +77,8 @@ class MemOpt(C.Structure):
                 ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
                 ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
                 ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
-                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float), ("max_ins", C.c_int32)]
+                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float), ("max_ins", C.c_int32),
+                ("b", C.c_int32), ("pen_unpaired", C.c_int32), ("max_matesw", C.c_int32)]
 
 
 class FmiDesc(C.Structure):
@@ -126,6 +127,7 @@ def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
     o = MemOpt(a, 6, 1, 6, 1, 5, 5, 100, 100, 19, 0, 1 << 30, 500, 10000, 0.5, 0.5)
     o.mask_level_redun = 0.95
     o.max_ins = 10000
+    o.b, o.pen_unpaired, o.max_matesw = b, 17, 50
     sw = default_sw_opt(5, a, b)
     for i in range(25):
         o.mat[i] = sw.mat[i]

@@ -108,6 +108,40 @@ def make_reads(genome: np.ndarray, n_reads: int, seed: int = 12345,
     return reads, truth.astype(np.int64), is_rev
 
 
+
+def make_read_pairs(genome: np.ndarray, n_pairs: int, seed: int = 777, read_len: int = READ_LEN,
+                    insert_mean: float = 400.0, insert_sd: float = 40.0, damaged_frac: float = 0.15,
+                    discordant_frac: float = 0.05):
+    """Paired-end reads (FR library): list of 2 * n_pairs arrays, ends of pair p at 2p and 2p + 1.
+
+    A ``damaged_frac`` of the pairs carry one end with ~12 % substitutions (too few exact seeds to be found by
+    seeding: the case mate rescue exists for); a ``discordant_frac`` have their second end drawn from an
+    unrelated position.  Half of the pairs are flipped as a whole (fragment from the reverse strand)."""
+    rng = np.random.default_rng(seed)
+    n = genome.shape[0]
+    out = []
+    for _ in range(n_pairs):
+        isz = int(max(read_len + 20, rng.normal(insert_mean, insert_sd)))
+        p = int(rng.integers(0, n - isz - 1))
+        frag = genome[p:p + isz]
+        if rng.random() < 0.5:
+            frag = revcomp(frag)
+        e1 = frag[:read_len].copy()
+        e2 = revcomp(frag[-read_len:]).copy()
+        if rng.random() < discordant_frac:
+            q = int(rng.integers(0, n - read_len - 1))
+            e2 = genome[q:q + read_len].copy()
+        for e in (e1, e2):                                   # sequencing errors
+            m = rng.random(read_len) < 0.01
+            e[m] = (e[m] + 1 + rng.integers(0, 3, size=int(m.sum()))) & 3
+        if rng.random() < damaged_frac:
+            e = e2 if rng.random() < 0.5 else e1
+            m = rng.random(read_len) < 0.12
+            e[m] = (e[m] + 1 + rng.integers(0, 3, size=int(m.sum()))) & 3
+        out.append(e1.astype(np.uint8))
+        out.append(e2.astype(np.uint8))
+    return out
+
 def flatten_reads(reads) -> tuple[np.ndarray, np.ndarray]:
     """(enc_qdb bytes, cum_len int64[n+1]) from a 2-D array or a list of 1-D arrays.
 

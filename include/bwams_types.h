@@ -123,6 +123,9 @@ typedef struct bwams_mem_opt {
     int32_t extend_all;
     float   mask_level_redun;           /* mem_opt_t again: 0.95, read by mem_sort_dedup_patch */
     int32_t max_ins;                    /* 10000, read by mem_pestat */
+    int32_t b;                          /* mismatch penalty, 4: mem_mark_primary_se and mem_pair read a + b */
+    int32_t pen_unpaired;               /* 17: anchors of mate rescue score >= best - pen_unpaired */
+    int32_t max_matesw;                 /* 50: anchors per end that mate rescue tries */
 } bwams_mem_opt_t;
 
 /* mem_pestat_t (src/bwamem.h:178-182), same layout. */
@@ -132,6 +135,17 @@ typedef struct bwams_pestat {
     int32_t pad_;
     double  avg, std;
 } bwams_pestat_t;
+
+/* The pairing decision for one read pair: what mem_sam_pe_batch_post (src/bwamem_pair.cpp:981-1098) has in hand
+ * after mate rescue, mem_mark_primary_se of both ends and mem_pair (:366-427).  z[] / sub / n_sub are those of
+ * mem_pair and are meaningful only when score > 0 (otherwise the reference leaves them unset; here 0 / -1). */
+typedef struct bwams_pair {
+    int32_t score;          /* mem_pair's return value o; 0: no proper pair (or an end without a primary hit) */
+    int32_t sub, n_sub;     /* second best pairing score, pairings within max(a+b, o_del+e_del, o_ins+e_ins) of it */
+    int32_t z[2];           /* index of the paired region in each end's list, -1 when unset */
+    int32_t n_pri[2];       /* mem_mark_primary_se's return value of each end (regions on the primary assembly) */
+    int32_t n_matesw;       /* mem_matesw's return values summed: rescue alignments this pair consumed */
+} bwams_pair_t;
 
 /* mem_seed_t (src/bwamem.h:129-140), 32 B, same field offsets. */
 typedef struct bwams_chain_seed {

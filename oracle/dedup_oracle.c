@@ -108,6 +108,7 @@ static int patch_reg(const bwams_mem_opt_t *opt, int64_t l_pac, const uint8_t *r
 {
     int w, score = 0, q_s, r_s;
     double r;
+    if (ref_string == 0 || query == 0) return 0;             /* bwamem.cpp:206: mate rescue passes bns = pac = query = 0 */
     if (a->rb < l_pac && b->rb >= l_pac) return 0;
     if (a->qb >= b->qb || a->qe >= b->qe || a->re >= b->re) return 0;
     w = (int)((a->re - b->rb) - (a->qe - b->qb));
@@ -273,6 +274,13 @@ static int sort_dedup_patch(const bwams_mem_opt_t *opt, int64_t l_pac, const uin
         if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
     free(ord);
     return m;
+}
+
+/* mem_sort_dedup_patch for callers outside this file (pair_oracle.c: query = ref_string = NULL, no patching) */
+int orc_sort_dedup_patch(const bwams_mem_opt_t *opt, int64_t l_pac, const uint8_t *ref_string, const uint8_t *query, int n,
+                         bwams_alnreg_t *a)
+{
+    return sort_dedup_patch(opt, l_pac, ref_string, query, n, a);
 }
 
 /* The tail of mem_kernel2_core for a work item: regs (grouped by read, reg_off[nseq+1]) are compacted in

@@ -356,7 +356,8 @@ class MemOpt(C.Structure):
                 ("pen_clip5", C.c_int32), ("pen_clip3", C.c_int32), ("w", C.c_int32), ("zdrop", C.c_int32),
                 ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
                 ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
-                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float), ("max_ins", C.c_int32)]
+                ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float), ("max_ins", C.c_int32),
+                ("b", C.c_int32), ("pen_unpaired", C.c_int32), ("max_matesw", C.c_int32)]
 
 
 def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
@@ -364,6 +365,7 @@ def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
     o = MemOpt(a, 6, 1, 6, 1, 5, 5, 100, 100, 19, 0, 1 << 30, 500, 10000, 0.5, 0.5)
     o.mask_level_redun = 0.95
     o.max_ins = 10000
+    o.b, o.pen_unpaired, o.max_matesw = b, 17, 50
     for i, v in enumerate(fill_scmat(a, b)):
         o.mat[i] = v
     return o
@@ -544,3 +546,42 @@ def pestat(regs, reg_off, l_pac, opt: MemOpt | None = None):
     pes = np.zeros(4, PESTAT_DTYPE)
     lib().orc_pestat(C.byref(opt), int(l_pac), len(reg_off) - 1, _p(regs), _p(reg_off), _p(pes))
     return pes
+
+
+PAIR_DTYPE = np.dtype([("score", "<i4"), ("sub", "<i4"), ("n_sub", "<i4"), ("z", "<i4", (2,)), ("n_pri", "<i4", (2,)),
+                       ("n_matesw", "<i4")])
+assert PAIR_DTYPE.itemsize == 32
+
+
+def pair_pe(regs, reg_off, enc, cum, ref_string, l_pac, pes, contigs=None, opt: MemOpt | None = None, id_base: int = 0,
+            no_rescue: bool = False):
+    """Restated PE tail up to the pairing decision: mate rescue, mem_mark_primary_se, mem_pair
+    -> (regs, reg_off, pairs).  Reads 2p, 2p + 1 are the ends of pair p."""
+    opt = opt or default_mem_opt()
+    bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE)
+    reg_off = np.ascontiguousarray(reg_off, np.int64)
+    cum = np.ascontiguousarray(cum, np.int64)
+    enc = np.ascontiguousarray(enc, np.uint8)
+    ref_string = np.ascontiguousarray(ref_string, np.uint8)
+    pes = np.ascontiguousarray(pes, PESTAT_DTYPE)
+    nseq = len(cum) - 1
+    assert nseq % 2 == 0 and len(reg_off) == nseq + 1
+    cap = len(regs) + 4 * min(opt.max_matesw, max(1, len(regs))) * nseq + 16
+    out = np.zeros(cap, ALNREG_DTYPE)
+    out_off = np.zeros(nseq + 1, np.int64)
+    pairs = np.zeros(nseq // 2, PAIR_DTYPE)
+    L = lib()
+    L.orc_pair_pe.restype = C.c_int64
+    n = L.orc_pair_pe(C.byref(opt), C.byref(bns), _p(ref_string), _p(enc), _p(cum), nseq // 2, _p(regs), _p(reg_off), _p(pes),
+                      C.c_int64(id_base), int(no_rescue), _p(out), C.c_int64(cap), _p(out_off), _p(pairs))
+    assert n >= 0, "orc_pair_pe: output capacity"
+    return out[:n].copy(), out_off, pairs
+
+
+def mark_primary_se(regs, id_: int, opt: MemOpt | None = None):
+    """Restated mem_mark_primary_se on one read's regions -> (regs, n_pri)."""
+    opt = opt or default_mem_opt()
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE).copy()
+    n_pri = lib().orc_mark_primary_se(C.byref(opt), len(regs), _p(regs), C.c_int64(id_))
+    return regs, n_pri

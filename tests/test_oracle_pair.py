@@ -1,0 +1,87 @@
+"""The paired-end tail up to the pairing decision (mate rescue, mem_mark_primary_se, mem_pair): the oracle's driver
+logic on simulated FR pairs, checked through what the domain guarantees (a rescued mate lands where its fragment
+says, proper pairs pair, orientation statistics select FR) and on constructed cases."""
+import numpy as np
+
+from bwams import simulate
+from oracle import loader
+from tests import util
+
+
+def _chunk(n_pairs=400, seed=5, **kw):
+    g, idx = util.toy(60000, seed=3)
+    reads = simulate.make_read_pairs(g, n_pairs, seed=seed, **kw)
+    return g, idx, reads, util.oracle_pe_pipeline(g, idx, reads)
+
+
+def test_rescue_pairs_the_damaged_ends():
+    g, idx, reads, c = _chunk()
+    pes = c["pes"]
+    assert pes["failed"].tolist() == [1, 0, 1, 1]                      # an FR library
+    assert 300 < pes["avg"][1] < 500
+    out, out_off, pairs = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], pes)
+    n0, n1 = np.diff(c["reg_off"]), np.diff(out_off)
+    assert pairs["n_matesw"].sum() > 20 and (n1 > n0).sum() > 10          # rescue ran and added regions
+    # without rescue fewer pairs are proper
+    _, _, pairs_nr = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], pes, no_rescue=True)
+    assert (pairs["score"] > 0).sum() > (pairs_nr["score"] > 0).sum()
+    assert pairs_nr["n_matesw"].sum() == 0
+    # a proper pair: z picks regions whose distance lies within the FR bounds
+    l_pac = c["l_pac"]
+    ok = 0
+    for p in np.flatnonzero(pairs["score"] > 0):
+        a = out[out_off[2 * p] + pairs["z"][p, 0]]
+        b = out[out_off[2 * p + 1] + pairs["z"][p, 1]]
+        fa = a["rb"] if a["rb"] < l_pac else 2 * l_pac - 1 - a["rb"]
+        fb = b["rb"] if b["rb"] < l_pac else 2 * l_pac - 1 - b["rb"]
+        assert (a["rb"] >= l_pac) != (b["rb"] >= l_pac)                      # opposite strands
+        assert pes["low"][1] <= abs(int(fa) - int(fb)) <= pes["high"][1] + 1
+        assert pairs["score"][p] <= a["score"] + b["score"]
+        ok += 1
+    assert ok > 300
+    # every list is what mem_mark_primary_se leaves: score-descending among non-ALT, hashes set, the first is primary
+    for r in range(len(out_off) - 1):
+        a = out[out_off[r]:out_off[r + 1]]
+        if len(a):
+            assert a["secondary"][0] == -1 and np.all(np.diff(a["score"]) <= 0) and np.all(a["hash"] != 0)
+    assert np.array_equal(pairs["n_pri"].ravel(), n1)                      # no ALT sequences here
+
+
+def test_mark_primary_se_constructed():
+    opt = loader.default_mem_opt()
+    regs = np.zeros(4, loader.ALNREG_DTYPE)
+    # two hits covering the same query span (the weaker becomes secondary of the stronger), one elsewhere, one ALT
+    regs["qb"], regs["qe"] = [0, 5, 100, 0], [100, 100, 150, 100]
+    regs["score"] = [95, 100, 50, 97]
+    regs["rb"] = [1000, 5000, 9000, 20000]
+    regs["re"] = regs["rb"] + (regs["qe"] - regs["qb"])
+    regs["n_comp_is_alt"] = [1, 1, 1, 1 | (1 << 30)]
+    out, n_pri = loader.mark_primary_se(regs, 7, opt)
+    assert n_pri == 3
+    # non-ALT first in score order, the ALT hit last
+    assert out["score"].tolist() == [100, 95, 50, 97]
+    assert out["secondary"].tolist() == [-1, 0, -1, 0x7fffffff]
+    assert out["sub"].tolist() == [95, 0, 0, 0]                          # reset, then set by the second pass (primary assembly only)
+    assert out["alt_sc"].tolist() == [0, 0, 0, 0] and out["secondary_all"].tolist() == [-1, 0, -1, 0]
+    # sub_n is not reset between the passes: the 95 counts in both (100 - 95 <= 7), the ALT 97 in neither
+    # (a non-ALT hit does not count an ALT competitor)
+    assert out["sub_n"].tolist() == [2, 0, 0, 0]
+
+
+def test_pair_scores_follow_the_insert_size_model():
+    g, idx, reads, c = _chunk(200, seed=9, damaged_frac=0.0, discordant_frac=0.0)
+    pes = c["pes"].copy()
+    out, out_off, pairs = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], pes)
+    good = pairs["score"] > 0
+    assert good.mean() > 0.9
+    # the pairing score is the sum of the two scores minus the insert-size penalty: recompute it
+    import math
+    for p in np.flatnonzero(good)[:100]:
+        a = out[out_off[2 * p] + pairs["z"][p, 0]]
+        b = out[out_off[2 * p + 1] + pairs["z"][p, 1]]
+        l_pac = c["l_pac"]
+        fa = int(a["rb"]) if a["rb"] < l_pac else 2 * l_pac - 1 - int(a["rb"])
+        fb = int(b["rb"]) if b["rb"] < l_pac else 2 * l_pac - 1 - int(b["rb"])
+        ns = (abs(fa - fb) - pes["avg"][1]) / pes["std"][1]
+        q = int(int(a["score"]) + int(b["score"]) + .721 * math.log(2. * math.erfc(abs(ns) * math.sqrt(.5))) + .499)
+        assert pairs["score"][p] == max(q, 0)

@@ -132,3 +132,22 @@ def make_local_cases(n: int, seed: int = 9, qmax: int = 151, tmax: int = 900):
             q[rng.integers(0, ql, size=2)] = 4
         out.append((q, t))
     return out
+
+
+def oracle_pe_pipeline(g, idx, reads, contigs=None, opt=None):
+    """Run the CPU oracle from reads to final regions (+ insert-size statistics) for a chunk of read pairs.
+    Returns a dict with enc, cum, ref, regs, reg_off, pes."""
+    from bwams import simulate
+    from oracle import loader
+    enc, cum = simulate.flatten_reads(reads)
+    opt = opt or loader.default_mem_opt()
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum)
+    coord, off = o.sa_lookup(sm)
+    l_pac = len(g)
+    ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    ch, sd, choff = loader.chain_seeds(sm, coord, off, cum, l_pac, contigs=contigs, opt=opt, ref_string=ref, enc=enc)
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, enc, cum, ref, l_pac, contigs=contigs, opt=opt)
+    fin, fin_off = loader.regs_finish(regs, reg_off, enc, cum, ref, l_pac, contigs=contigs, opt=opt)
+    pes = loader.pestat(fin, fin_off, l_pac, opt=opt)
+    return dict(enc=enc, cum=cum, ref=ref, l_pac=l_pac, regs=fin, reg_off=fin_off, pes=pes, opt=opt, sm=sm, coord=coord, off=off)

@@ -35,8 +35,11 @@ SYMBOLS = [
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
-    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_pestat", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
+    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_pestat", "bwams_pair_run", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
 ]
+PAIR_DTYPE = np.dtype([("score", "<i4"), ("sub", "<i4"), ("n_sub", "<i4"), ("z", "<i4", (2,)), ("n_pri", "<i4", (2,)),
+                       ("n_matesw", "<i4")])
+assert PAIR_DTYPE.itemsize == 32
 PESTAT_DTYPE = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad_", "<i4"), ("avg", "<f8"), ("std", "<f8")])
 
 # records of include/bwams_types.h (layouts of bntann1_t's subset, mem_seed_t, mem_chain_t, mem_alnreg_t)
@@ -99,7 +102,8 @@ class Stats(C.Structure):
                 ("n_retry_left", C.c_int64), ("n_retry_right", C.c_int64),
                 ("ms_chain", C.c_float), ("ms_ext_plan", C.c_float), ("ms_ext_left", C.c_float),
                 ("ms_ext_right", C.c_float), ("ms_ext_purge", C.c_float), ("ms_ext_total", C.c_float),
-                ("n_ext_rounds", C.c_int64), ("n_final_regs", C.c_int64), ("ms_dedup", C.c_float), ("pad_", C.c_float)]
+                ("n_ext_rounds", C.c_int64), ("n_final_regs", C.c_int64), ("ms_dedup", C.c_float), ("ms_pair", C.c_float),
+                ("n_pair_tasks", C.c_int64), ("n_pair_redone", C.c_int64), ("n_pair_regs", C.c_int64)]
 
 
 def default_seed_opt() -> SeedOpt:
@@ -183,6 +187,8 @@ def lib():
         L.bwams_dedup_run.argtypes = [vp, vp, vp]
         L.bwams_dedup_fetch.argtypes = [vp, vp, i64, vp]
         L.bwams_pestat.argtypes = [vp, vp, vp]
+        L.bwams_pair_run.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp]
+        L.bwams_pair_fetch.argtypes = [vp, vp, C.c_int64, vp, vp]
         L.bwams_emf_regs_run.argtypes = [vp, vp, vp, vp]
         L.bwams_emf_regs_fetch.argtypes = [vp, vp, i64, vp, vp]
         L.bwams_seed_run.argtypes = [vp, vp, C.c_int]
@@ -498,6 +504,24 @@ class Batch:
         pes = np.zeros(4, PESTAT_DTYPE)
         _chk(lib().bwams_pestat(self.h, C.byref(opt), _p(pes)), "bwams_pestat")
         return pes
+
+    def pair_run(self, pes, opt: MemOpt | None = None, id_base: int = 0, no_rescue: bool = False):
+        """Mate rescue + mem_mark_primary_se + mem_pair over the final regions (reads 2p, 2p+1 = pair p)
+        -> (regions, rescue alignments)."""
+        opt = opt or default_mem_opt()
+        pes = np.ascontiguousarray(pes, PESTAT_DTYPE)
+        n, nt = C.c_int64(0), C.c_int64(0)
+        _chk(lib().bwams_pair_run(self.h, C.byref(opt), _p(pes), id_base, int(no_rescue), C.byref(n), C.byref(nt)), "bwams_pair_run")
+        self._n_pair_regs = n.value
+        return n.value, nt.value
+
+    def pair_fetch(self):
+        """-> (regs, reg_off, pairs) as mem_sam_pe_batch_post holds them before its MAPQ / SAM part."""
+        regs = np.zeros(self._n_pair_regs, ALNREG_DTYPE)
+        off = np.zeros(self._nseq + 1, np.int64)
+        pairs = np.zeros(self._nseq // 2, PAIR_DTYPE)
+        _chk(lib().bwams_pair_fetch(self.h, _p(regs), len(regs), _p(off), _p(pairs)), "bwams_pair_fetch")
+        return regs, off, pairs
 
     def extend_tasks_fetch(self, side: int):
         n, rb, qb = C.c_int64(0), C.c_int64(0), C.c_int64(0)

@@ -41,6 +41,11 @@ struct ChainState {
     DevBuf sw_qb, sw_rb, sw_read, sw_newn, sw_res;      // mem_flt_chained_seeds (long reads)
     DevBuf dd_regs, dd_ord, dd_srt, dd_eh, dd_nout, dd_wide, dd_off, dd_out, dd_light;   // mem_sort_dedup_patch
     DevBuf pe_keys, pe_keys2;                           // mem_pestat
+    // mate rescue + mem_mark_primary_se + mem_pair
+    DevBuf pr_na, pr_wide, pr_offs, pr_anchor, pr_slot, pr_task, pr_trb, pr_tl1, pr_twide, pr_toffs, pr_pairs, pr_tref, pr_tqer,
+           pr_aln, pr_pool, pr_ord, pr_srt, pr_z, pr_nfin, pr_npri, pr_nsw, pr_full, pr_owide, pr_ooff, pr_out, pr_res;
+    int64_t pr_total = 0, pr_tasks = 0, pr_redone = 0;
+    bool pair_done = false;
     DevBuf er_wide, er_off, er_scr, er_n, er_rev, er_out, er_ooff;   // mem_perfect2reg
     int64_t er_total = 0, er_nseq = 0;
     bool er_done = false;
@@ -55,7 +60,7 @@ struct ChainState {
     int64_t n_retry_left = 0, n_retry_right = 0, n_rounds = 0;
     bool built = false, ext_done = false;
     bwams_mem_opt_t opt{};
-    hipEvent_t ev[14] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 selection (first round each), 10-11 all rounds
+    hipEvent_t ev[16] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 selection (first round each), 10-11 all rounds
     bool ev_ok = false;
     hipStream_t aux[5] = {};      // the chaining tiers run concurrently
     hipEvent_t fork = nullptr, join[5] = {};
@@ -66,7 +71,9 @@ void chain_state_free(ChainState *s) {
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
                      &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
-                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->pr_na, &s->pr_wide, &s->pr_offs, &s->pr_anchor, &s->pr_slot, &s->pr_task, &s->pr_trb, &s->pr_tl1, &s->pr_twide, &s->pr_toffs,
+                     &s->pr_pairs, &s->pr_tref, &s->pr_tqer, &s->pr_aln, &s->pr_pool, &s->pr_ord, &s->pr_srt, &s->pr_z, &s->pr_nfin, &s->pr_npri, &s->pr_nsw, &s->pr_full, &s->pr_owide,
+                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -268,7 +275,7 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     BWAMS_HIP(hipSetDevice(b->idx->device));
     ChainState *s;
     if ((rc = get_state(b, &s))) return rc;
-    s->chain_done = s->built = s->ext_done = false;
+    s->chain_done = s->built = s->ext_done = s->dedup_done = s->pair_done = false;
     hipStream_t st = b->stream;
     const int64_t nseq = b->nseq, n_sa = b->n_sa, n1 = nseq + 1;
     const size_t ns = (size_t)(n_sa > 0 ? n_sa : 1);
@@ -411,7 +418,7 @@ int bwams_chain_upload(bwams_batch_t *b, const bwams_chain_t *chains, int64_t n_
     ChainState *s;
     int rc = get_state(b, &s);
     if (rc) { delete[] soff; return rc; }
-    s->chain_done = s->built = s->ext_done = false;
+    s->chain_done = s->built = s->ext_done = s->dedup_done = s->pair_done = false;
     hipStream_t st = b->stream;
     BWAMS_HIP(s->chain_off.ensure((size_t)n1 * 16));
     BWAMS_HIP(s->chains.ensure((size_t)(n_chains + 1) * sizeof(bwams_chain_t)));
@@ -513,7 +520,7 @@ int bwams_extend_build(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_
     if (rc) return rc;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     ChainState *s = b->chain;
-    s->built = s->ext_done = false;
+    s->built = s->ext_done = s->dedup_done = s->pair_done = false;
     hipStream_t st = b->stream;
     ExtArgs A;
     BWAMS_HIP(hipEventRecord(s->ev[2], st));
@@ -577,7 +584,7 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
     ChainState *s = b->chain;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
-    s->built = s->ext_done = false;
+    s->built = s->ext_done = s->dedup_done = s->pair_done = false;
     ExtArgs A;
     BWAMS_HIP(hipEventRecord(s->ev[10], st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->bsw_cells, 0, sizeof(unsigned long long), st));      // DP cells of this run, all rounds
@@ -646,7 +653,7 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     ChainState *s = b->chain;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
-    s->dedup_done = false;
+    s->dedup_done = s->pair_done = false;
     const int64_t N = s->n_seeds, n1 = s->nseq + 1;
     const int64_t L = b->max_read_len > 1 ? b->max_read_len : 1;
     // strips for the global alignment: as many lanes as 1 GiB of (h, e) rows allows, at most 64 Ki
@@ -710,6 +717,149 @@ int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, i
     hipStream_t st = b->stream;
     if (s->n_final) BWAMS_HIP(hipMemcpyAsync(regs, s->dd_out.p, (size_t)s->n_final * sizeof(bwams_alnreg_t), hipMemcpyDeviceToHost, st));
     if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->dd_off.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    return BWAMS_OK;
+}
+
+/* ------------------------------------------------- mate rescue, mem_mark_primary_se, mem_pair ---- */
+
+int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t no_rescue,
+                   int64_t *n_regs, int64_t *n_tasks) {
+    if (!b || !b->chain || !b->chain->dedup_done) {
+        set_last_error("bwams_pair_run: run bwams_dedup_run first");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_pair_run");
+    if (rc) return rc;
+    ChainState *s = b->chain;
+    if (!pes || (s->nseq & 1)) {
+        set_last_error("bwams_pair_run: needs the insert-size statistics and an even number of reads (ends of pair p at 2p, 2p + 1)");
+        return BWAMS_ERR_ARG;
+    }
+    int tmax = 1;
+    for (int k = 0; k < 4; ++k)
+        if (!pes[k].failed && pes[k].high - pes[k].low + b->max_read_len > tmax) tmax = pes[k].high - pes[k].low + b->max_read_len;
+    if (!no_rescue && (b->max_read_len > 512 || tmax > 32767)) {
+        set_last_error("bwams_pair_run: mate rescue needs reads of at most 512 bases and windows (high - low + read length) of at most 32767");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    s->pair_done = false;
+    const int64_t nseq = s->nseq, n1 = nseq + 1;
+    BWAMS_HIP(s->pr_na.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->pr_wide.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->pr_offs.ensure((size_t)n1 * 16));
+    BWAMS_HIP(s->pr_nfin.ensure((size_t)n1 * 4)); BWAMS_HIP(s->pr_npri.ensure((size_t)n1 * 4)); BWAMS_HIP(s->pr_nsw.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->pr_full.ensure((size_t)n1));
+    BWAMS_HIP(s->pr_owide.ensure((size_t)n1 * 8)); BWAMS_HIP(s->pr_ooff.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->pr_res.ensure((size_t)(nseq / 2 + 1) * sizeof(bwams_pair_t)));
+    PairArgs A;
+    A.regs = s->dd_out.as<bwams_alnreg_t>(); A.reg_off = s->dd_off.as<int64_t>();
+    A.enc = b->d_enc; A.cum = b->d_cum; A.nseq = nseq; A.ref = b->idx->fmi.ref;
+    if ((rc = dev_bns(b->idx, &A.bns))) return rc;
+    A.opt = *opt;
+    for (int k = 0; k < 4; ++k) A.pes[k] = pes[k];
+    A.id_base = id_base; A.no_rescue = no_rescue ? 1 : 0; A.pass = 0;
+    A.drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") ? 1 : 0; A.pad_ = 0;      // test knob: exercise the second pass
+    A.na = s->pr_na.as<int32_t>();
+    int64_t *aoff = s->pr_offs.as<int64_t>(), *ooff = aoff + n1;
+    A.aoff = aoff; A.ooff = ooff;
+    A.n_fin = s->pr_nfin.as<int32_t>(); A.n_pri = s->pr_npri.as<int32_t>(); A.n_sw = s->pr_nsw.as<int32_t>();
+    A.full = s->pr_full.as<uint8_t>(); A.ctr = b->d_ctr;
+    A.anchor = nullptr; A.slot_read = nullptr; A.n_slots = 0; A.task = nullptr; A.trb = nullptr; A.tl1 = nullptr; A.aln = nullptr;
+    A.pool = nullptr; A.ord = nullptr; A.zbuf = nullptr; A.srt = nullptr;
+    BWAMS_HIP(hipEventRecord(s->ev[14], st));
+    BWAMS_HIP(hipMemsetAsync(A.full, 0, (size_t)n1, st));
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_full, 0, 2 * sizeof(unsigned long long), st));
+    // anchors per read, pool capacities
+    launch_pair_count(A, s->pr_wide.as<int64_t>(), st);
+    if ((rc = scan_rows(b, s->pr_wide.as<int64_t>(), aoff, 1, n1))) return rc;
+    launch_pair_cap(A, s->pr_wide.as<int64_t>(), st);
+    if ((rc = scan_rows(b, s->pr_wide.as<int64_t>(), ooff, 1, n1))) return rc;
+    int64_t n_slots = 0, n_pool = 0;
+    BWAMS_HIP(hipMemcpyAsync(&n_slots, aoff + nseq, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipMemcpyAsync(&n_pool, ooff + nseq, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    A.n_slots = n_slots;
+    const int64_t E1 = 4 * n_slots + 1;
+    BWAMS_HIP(s->pr_anchor.ensure((size_t)(n_slots + 1) * 4)); BWAMS_HIP(s->pr_slot.ensure((size_t)(n_slots + 1) * 4));
+    BWAMS_HIP(s->pr_task.ensure((size_t)E1 * 4)); BWAMS_HIP(s->pr_trb.ensure((size_t)E1 * 8)); BWAMS_HIP(s->pr_tl1.ensure((size_t)E1 * 4));
+    BWAMS_HIP(s->pr_twide.ensure((size_t)E1 * 24)); BWAMS_HIP(s->pr_toffs.ensure((size_t)E1 * 24));
+    BWAMS_HIP(s->pr_pool.ensure((size_t)(n_pool + 1) * sizeof(bwams_alnreg_t)));
+    BWAMS_HIP(s->pr_ord.ensure((size_t)(n_pool + 1) * 4)); BWAMS_HIP(s->pr_z.ensure((size_t)(n_pool + 1) * 4));
+    BWAMS_HIP(s->pr_srt.ensure((size_t)(n_pool + 1) * 24));
+    A.anchor = s->pr_anchor.as<int32_t>(); A.slot_read = s->pr_slot.as<int32_t>();
+    A.task = s->pr_task.as<int32_t>(); A.trb = s->pr_trb.as<int64_t>(); A.tl1 = s->pr_tl1.as<int32_t>();
+    A.pool = s->pr_pool.as<bwams_alnreg_t>(); A.ord = s->pr_ord.as<int32_t>(); A.zbuf = s->pr_z.as<int32_t>(); A.srt = s->pr_srt.p;
+    launch_pair_slots(A, st);
+    SwParams prm;
+    sw_params(*opt, 0, &prm);
+    s->pr_tasks = 0; s->pr_redone = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        A.pass = pass;
+        int64_t tot[3] = {0, 0, 0};
+        launch_pair_plan(A, s->pr_twide.as<int64_t>(), st);
+        if ((rc = scan_rows(b, s->pr_twide.as<int64_t>(), s->pr_toffs.as<int64_t>(), 3, E1))) return rc;
+        for (int r = 0; r < 3; ++r)
+            BWAMS_HIP(hipMemcpyAsync(&tot[r], s->pr_toffs.as<int64_t>() + r * E1 + (E1 - 1), 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        if (tot[1] >= ((int64_t)1 << 31) || tot[2] >= ((int64_t)1 << 31)) {
+            set_last_error("bwams_pair_run: rescue windows exceed the 31-bit offsets of SeqPair; use smaller chunks");
+            return BWAMS_ERR_CAPACITY;
+        }
+        BWAMS_HIP(s->pr_pairs.ensure((size_t)(tot[0] + 1) * sizeof(bwams_seqpair_t)));
+        BWAMS_HIP(s->pr_tref.ensure((size_t)tot[1] + 64)); BWAMS_HIP(s->pr_tqer.ensure((size_t)tot[2] + 64));
+        BWAMS_HIP(s->pr_aln.ensure((size_t)(tot[0] + 1) * 28));
+        A.aln = s->pr_aln.as<int32_t>();
+        launch_pair_build(A, s->pr_toffs.as<int64_t>(), s->pr_pairs.as<bwams_seqpair_t>(), s->pr_tref.as<uint8_t>(), s->pr_tqer.as<uint8_t>(),
+                          b->cu_count, st);
+        if (tot[0] > 0)
+            launch_ksw(s->pr_pairs.as<bwams_seqpair_t>(), tot[0], s->pr_tref.as<uint8_t>(), s->pr_tqer.as<uint8_t>(), prm,
+                       ((b->max_read_len + 15) / 16) * 16, tmax, s->pr_aln.p, b->d_ctr, b->cu_count, st);
+        launch_pair_post(A, st);
+        s->pr_tasks += tot[0];
+        unsigned long long flags[2] = {0, 0};
+        BWAMS_HIP(hipMemcpyAsync(flags, &b->d_ctr->pair_full, sizeof flags, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        if (flags[1]) {
+            set_last_error("bwams_pair_run: internal error, a rescue alignment was missing in the second pass");
+            return BWAMS_ERR_DEVICE;
+        }
+        if (pass == 0) s->pr_redone = (int64_t)flags[0];
+        if (pass == 1 || flags[0] == 0) break;
+    }
+    // regions in final order, then mem_pair
+    launch_pair_widen(A, s->pr_owide.as<int64_t>(), st);
+    if ((rc = scan_rows(b, s->pr_owide.as<int64_t>(), s->pr_ooff.as<int64_t>(), 1, n1))) return rc;
+    int64_t total = 0;
+    BWAMS_HIP(hipMemcpyAsync(&total, s->pr_ooff.as<int64_t>() + nseq, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(s->pr_out.ensure((size_t)(total + 1) * sizeof(bwams_alnreg_t)));
+    launch_pair_gather(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), st);
+    launch_pair_pair(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), s->pr_res.as<bwams_pair_t>(), st);
+    BWAMS_HIP(hipEventRecord(s->ev[15], st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(hipGetLastError());
+    s->pr_total = total;
+    s->pair_done = true;
+    if (n_regs) *n_regs = total;
+    if (n_tasks) *n_tasks = s->pr_tasks;
+    return BWAMS_OK;
+}
+
+int bwams_pair_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, bwams_pair_t *pairs) {
+    if (!b || !b->chain || !b->chain->pair_done) {
+        set_last_error("bwams_pair_fetch: run bwams_pair_run first");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    if (s->pr_total > reg_cap) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    if (regs && s->pr_total) BWAMS_HIP(hipMemcpyAsync(regs, s->pr_out.p, (size_t)s->pr_total * sizeof(bwams_alnreg_t), hipMemcpyDeviceToHost, st));
+    if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->pr_ooff.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (pairs && s->nseq > 1) BWAMS_HIP(hipMemcpyAsync(pairs, s->pr_res.p, (size_t)(s->nseq / 2) * sizeof(bwams_pair_t), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     return BWAMS_OK;
 }
@@ -901,6 +1051,10 @@ void chain_state_stats(const ChainState *s, bwams_stats_t *out) {
         out->n_ext_rounds = s->n_rounds;
     }
     if (s->dedup_done) { el(12, 13, &out->ms_dedup); out->n_final_regs = s->n_final; }
+    if (s->pair_done) {
+        el(14, 15, &out->ms_pair);
+        out->n_pair_tasks = s->pr_tasks; out->n_pair_redone = s->pr_redone; out->n_pair_regs = s->pr_total;
+    }
     (void)hipGetLastError();
 }
 }  // namespace bwams

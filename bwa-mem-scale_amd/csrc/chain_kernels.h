@@ -159,4 +159,44 @@ void launch_emfregs_fill(const EmfRegArgs &A, const int64_t *scr_off, int32_t *n
 void launch_emfregs_emit(const EmfRegArgs &A, const int64_t *scr_off, const int32_t *n_final, const int64_t *out_off,
                          bwams_alnreg_t *out, hipStream_t st);
 
+// ---- paired-end tail: mate rescue, mem_mark_primary_se, mem_pair (pair.hip) ----
+struct PairArgs {
+    const bwams_alnreg_t *regs;    // final regions after de-duplication, grouped by read
+    const int64_t *reg_off;
+    const uint8_t *enc;
+    const int64_t *cum;
+    int64_t nseq;                  // even: reads 2p, 2p + 1 are the ends of pair p
+    const uint8_t *ref;
+    DevBns bns;
+    bwams_mem_opt_t opt;
+    bwams_pestat_t pes[4];
+    int64_t id_base;               // n_processed >> 1 of the chunk (mem_mark_primary_se / mem_pair hash their ids)
+    int32_t no_rescue, pass;
+    int32_t drop_plan, pad_;       // test knob: the first pass plans nothing, so every rescue goes through the second
+    int32_t *na;                   // per read: anchors it provides
+    const int64_t *aoff, *ooff;    // per read: first anchor slot, first pool slot
+    int32_t *anchor, *slot_read;   // per anchor slot: region index within its read, the read
+    int64_t n_slots;
+    int32_t *task;                 // per slot x 4 orientations: rescue alignment index or -1
+    int64_t *trb;                  // window start
+    int32_t *tl1;                  // window length or -1
+    const int32_t *aln;            // 7 per task (kswr_t)
+    bwams_alnreg_t *pool;          // per read: its regions, then room for the rescued ones
+    int32_t *ord, *zbuf;           // per pool slot
+    void *srt;                     // per pool slot: a 24-byte sort record
+    int32_t *n_fin, *n_pri, *n_sw; // per read
+    uint8_t *full;                 // per read: redo with every orientation planned
+    DevCounters *ctr;
+};
+void launch_pair_count(const PairArgs &A, int64_t *wide, hipStream_t st);
+void launch_pair_cap(const PairArgs &A, int64_t *wide, hipStream_t st);
+void launch_pair_slots(const PairArgs &A, hipStream_t st);
+void launch_pair_plan(const PairArgs &A, int64_t *wide, hipStream_t st);
+void launch_pair_build(const PairArgs &A, const int64_t *offs, bwams_seqpair_t *pairs, uint8_t *tref, uint8_t *tqer, int cu_count,
+                       hipStream_t st);
+void launch_pair_post(const PairArgs &A, hipStream_t st);
+void launch_pair_widen(const PairArgs &A, int64_t *wide, hipStream_t st);
+void launch_pair_gather(const PairArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
+void launch_pair_pair(const PairArgs &A, const int64_t *out_off, const bwams_alnreg_t *out, bwams_pair_t *res, hipStream_t st);
+
 }  // namespace bwams

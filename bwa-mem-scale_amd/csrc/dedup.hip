@@ -11,6 +11,7 @@
 #include "common.h"
 #include "chain_kernels.h"
 #include "wave_ops.h"
+#include "region_sort.h"
 
 namespace bwams {
 namespace {
@@ -18,78 +19,6 @@ namespace {
 constexpr int kLightN = 32;          // regions per read handled by a single lane
 constexpr int kLdsN = 1024;          // sort records a wavefront keeps in LDS
 constexpr int MINUS_INF = -0x40000000;
-
-struct SortRec { int64_t k; int32_t s, q, idx; int32_t pad_; };      // ars2: k = re; ars: k = rb, s = score, q = qb
-
-struct LtEnd   { __device__ __forceinline__ bool operator()(const SortRec &a, const SortRec &b) const { return a.k < b.k; } };
-struct LtScore { __device__ __forceinline__ bool operator()(const SortRec &a, const SortRec &b) const {
-    return a.s > b.s || (a.s == b.s && (a.k < b.k || (a.k == b.k && a.q < b.q))); } };
-
-template <class LT> __device__ __forceinline__ void r_insertsort(SortRec *a, int s, int t, LT lt) {
-    for (int i = s + 1; i < t; ++i)
-        for (int j = i; j > s && lt(a[j], a[j - 1]); --j) { const SortRec x = a[j]; a[j] = a[j - 1]; a[j - 1] = x; }
-}
-template <class LT> __device__ __forceinline__ void r_combsort(SortRec *a, int n, LT lt) {
-    const double shrink = 1.2473309501039786540366528676643;
-    bool do_swap;
-    unsigned long long gap = (unsigned long long)n;
-    do {
-        if (gap > 2) {
-            gap = (unsigned long long)((double)gap / shrink);
-            if (gap == 9 || gap == 10) gap = 11;
-        }
-        do_swap = false;
-        for (long long i = 0; i < (long long)n - (long long)gap; ++i) {
-            const long long j = i + (long long)gap;
-            if (lt(a[j], a[i])) { const SortRec x = a[i]; a[i] = a[j]; a[j] = x; do_swap = true; }
-        }
-    } while (do_swap || gap > 2);
-    if (gap != 1) r_insertsort(a, 0, n, lt);
-}
-template <class LT> __device__ __forceinline__ void r_introsort(SortRec *a, int n, LT lt) {
-    if (n < 1) return;
-    if (n == 2) { if (lt(a[1], a[0])) { const SortRec x = a[0]; a[0] = a[1]; a[1] = x; } return; }
-    int d;
-    for (d = 2; (1ul << d) < (unsigned long)n; ++d);
-    int stk_l[40], stk_r[40], stk_d[40], top = 0;
-    int s = 0, t = n - 1;
-    d <<= 1;
-    for (;;) {
-        if (s < t) {
-            if (--d == 0) { r_combsort(a + s, t - s + 1, lt); t = s; continue; }
-            int i = s, j = t, k = i + ((j - i) >> 1) + 1;
-            if (lt(a[k], a[i])) { if (lt(a[k], a[j])) k = j; }
-            else k = lt(a[j], a[i]) ? i : j;
-            const SortRec rp = a[k];
-            if (k != t) { a[k] = a[t]; a[t] = rp; }
-            for (;;) {
-                do ++i; while (lt(a[i], rp));
-                do --j; while (i <= j && lt(rp, a[j]));
-                if (j <= i) break;
-                const SortRec x = a[i]; a[i] = a[j]; a[j] = x;
-            }
-            { const SortRec x = a[i]; a[i] = a[t]; a[t] = x; }
-            if (i - s > t - i) {
-                if (i - s > 16) { stk_l[top] = s; stk_r[top] = i - 1; stk_d[top] = d; ++top; }
-                s = t - i > 16 ? i + 1 : t;
-            } else {
-                if (t - i > 16) { stk_l[top] = i + 1; stk_r[top] = t; stk_d[top] = d; ++top; }
-                t = i - s > 16 ? i - 1 : s;
-            }
-        } else {
-            if (top == 0) { r_insertsort(a, 0, n, lt); return; }
-            --top; s = stk_l[top]; t = stk_r[top]; d = stk_d[top];
-        }
-    }
-}
-
-// The sorts are called through this non-inlined wrapper: the pointer stays generic (LDS or HBM, flat accesses).
-// Instantiated directly on a __shared__ array the inlined introsort spun forever on gfx950 (ROCm 7.2) for a
-// six-record input that the same code sorts correctly through a generic pointer; see profiles/r01_notes.md.
-__device__ __noinline__ void sort_records(SortRec *a, int n, int by_score) {
-    if (by_score) r_introsort(a, n, LtScore());
-    else r_introsort(a, n, LtEnd());
-}
 
 // ksw_global2 without backtrack; query[j] = qseq[qs * j], target[i] = tseq[ts * i] (ts = qs = -1 on the reverse strand,
 // where bwa_gen_cigar2 reverses both sequences); eh: qlen + 1 cells of this lane's strip

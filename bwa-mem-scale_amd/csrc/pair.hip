@@ -1,0 +1,521 @@
+// pair.hip — the paired-end tail of worker_sam up to the pairing decision, on the device
+// (/root/reference/src/bwamem_pair.cpp): mate rescue (mem_sam_pe_batch_pre :838-870 -> mem_matesw_batch_pre
+// :1193-1355, the batched ksw_align2 of mem_sam_pe_batch :880-979, mem_sam_pe_batch_post :981-1042 ->
+// mem_matesw_batch_post :1497-1601), mem_mark_primary_se (bwamem.cpp:1905-1980) of both ends and mem_pair (:366-427).
+//
+// Structure.  The anchors of an end are a snapshot of its regions taken before any rescue and the region list they
+// rescue INTO is the mate's, so the two ends of a pair are independent: the unit of sequential work is "one read's
+// region list, visited by its mate's anchors in order".
+//   plan    lane per anchor: which of the four orientations still lack a consistent hit in the mate's list as it
+//           is now, and their rescue windows (bns_fetch_seq's clip to the anchor's sequence and strand)
+//   build   wave per window: the SeqPair and its two byte strings (the mate reverse-complemented for FR / RF)
+//   align   ksw_local.hip (both passes of ksw_align2)
+//   post    lane per read: the reference's sequential procedure — re-test the orientations against the list as it
+//           has become, insert each rescued region by score, mem_sort_dedup_patch (bns = pac = query = 0: no
+//           patching) after every alignment consumed; then mem_mark_primary_se
+//   gather  regions in final order;  pair: lane per pair, mem_pair
+// The reference's _post can want an alignment that _pre did not batch (a region that made an orientation
+// "consistent" was removed by a later de-duplication); it then calls ksw_align2 on the spot (index == -1).  Here
+// such a read is flagged, and a second pass plans every non-failed orientation for it and redoes it from scratch.
+//
+// The region lists are index arrays (`ord`) over a per-read pool: originals first, rescued regions appended.
+#include "common.h"
+#include "chain_kernels.h"
+#include "region_sort.h"
+
+namespace bwams {
+namespace {
+
+constexpr int KSW_XBYTE = 0x10000, KSW_XSUBO = 0x40000, KSW_XSTART = 0x80000;
+
+__device__ __forceinline__ uint64_t hash_64(uint64_t key) {          // utils.h:117-128
+    key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
+    key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
+    return key;
+}
+__device__ __forceinline__ int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) {      // bwamem_pair.cpp:57-65
+    const int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
+    const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+    *dist = p2 > b1 ? p2 - b1 : b1 - p2;
+    return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+__device__ __forceinline__ int pos2rid(const DevBns &b, int64_t pos_f) {                             // bntseq.cpp:397-413
+    if (pos_f >= b.l_pac) return -1;
+    int left = 0, mid = 0, right = b.n_seqs;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= b.contigs[mid].offset) {
+            if (mid == b.n_seqs - 1) break;
+            if (pos_f < b.contigs[mid + 1].offset) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+__device__ __forceinline__ int is_alt(const bwams_alnreg_t &r) { return (r.n_comp_is_alt >> 30) & 3; }
+
+// the rescue window of anchor a for orientation r4 (mem_matesw: window arithmetic + bns_fetch_seq's clip)
+__device__ bool rescue_window(const PairArgs &A, const bwams_alnreg_t &a, int r4, int l_ms, int64_t *rb_out, int64_t *re_out) {
+    const int64_t l_pac = A.bns.l_pac;
+    const bool is_rev = (r4 >> 1) != (r4 & 1), is_larger = !(r4 >> 1);
+    const int64_t low = A.pes[r4].low, high = A.pes[r4].high;
+    int64_t rb, re;
+    if (!is_rev) {
+        rb = is_larger ? a.rb + low : a.rb - high;
+        re = (is_larger ? a.rb + high : a.rb - low) + l_ms;
+    } else {
+        rb = (is_larger ? a.rb + low : a.rb - high) - l_ms;
+        re = is_larger ? a.rb + high : a.rb - low;
+    }
+    if (rb < 0) rb = 0;
+    if (re > l_pac << 1) re = l_pac << 1;
+    if (!(rb < re)) return false;
+    const int64_t mid = (rb + re) >> 1;
+    const bool mrev = mid >= l_pac;
+    const int rid = pos2rid(A.bns, mrev ? (l_pac << 1) - 1 - mid : mid);
+    int64_t far_beg = A.bns.contigs[rid].offset, far_end = far_beg + A.bns.contigs[rid].len;
+    if (mrev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+    rb = rb > far_beg ? rb : far_beg;
+    re = re < far_end ? re : far_end;
+    *rb_out = rb; *re_out = re;
+    return a.rid == rid && re - rb >= A.opt.min_seed_len;
+}
+
+// ---- anchors ---------------------------------------------------------------------------------------------------
+// lane per read: how many anchors it provides (regions scoring within pen_unpaired of its best, at most max_matesw)
+__global__ void pair_count_kernel(PairArgs A, int64_t *wide) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > A.nseq) return;
+    int na = 0;
+    if (r < A.nseq && !A.no_rescue) {
+        const int64_t r0 = A.reg_off[r];
+        const int n = (int)(A.reg_off[r + 1] - r0);
+        for (int j = 0; j < n && na < A.opt.max_matesw; ++j)
+            if (A.regs[r0 + j].score >= A.regs[r0].score - A.opt.pen_unpaired) ++na;
+    }
+    if (r < A.nseq) A.na[r] = na;
+    wide[r] = na;                                            // row 0: anchor slots
+}
+// lane per read: capacity of its pool = its regions + 4 per anchor of its mate
+__global__ void pair_cap_kernel(PairArgs A, int64_t *wide) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > A.nseq) return;
+    wide[r] = r < A.nseq ? (A.reg_off[r + 1] - A.reg_off[r]) + 4 * (int64_t)A.na[r ^ 1] : 0;
+}
+__global__ void pair_slots_kernel(PairArgs A) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.nseq) return;
+    const int64_t r0 = A.reg_off[r], s0 = A.aoff[r];
+    const int n = (int)(A.reg_off[r + 1] - r0), na = A.na[r];
+    int k = 0;
+    for (int j = 0; j < n && k < na; ++j)
+        if (A.regs[r0 + j].score >= A.regs[r0].score - A.opt.pen_unpaired) {
+            A.anchor[s0 + k] = j;
+            A.slot_read[s0 + k] = (int32_t)r;
+            ++k;
+        }
+}
+
+// ---- plan: lane per anchor --------------------------------------------------------------------------------------
+__global__ void pair_plan_kernel(PairArgs A, int64_t *wide) {          // wide: 3 rows of 4 * n_slots + 1
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N1 = 4 * A.n_slots + 1;
+    if (s == 0) { wide[N1 - 1] = 0; wide[2 * N1 - 1] = 0; wide[3 * N1 - 1] = 0; }
+    if (s >= A.n_slots) return;
+    const int64_t r = A.slot_read[s], m = r ^ 1;
+    const bwams_alnreg_t a = A.regs[A.reg_off[r] + A.anchor[s]];
+    const int l_ms = (int)(A.cum[m + 1] - A.cum[m]);
+    bool skip[4];
+    for (int k = 0; k < 4; ++k) skip[k] = A.pes[k].failed != 0;
+    bool active = !(A.pass == 0 && A.drop_plan);
+    if (A.pass == 0) {                                       // the mate's list before any rescue
+        const int64_t m0 = A.reg_off[m];
+        const int mn = (int)(A.reg_off[m + 1] - m0);
+        for (int i = 0; i < mn; ++i) {
+            int64_t dist;
+            const int d = infer_dir(A.bns.l_pac, a.rb, A.regs[m0 + i].rb, &dist);
+            if (dist >= A.pes[d].low && dist <= A.pes[d].high) skip[d] = true;
+        }
+    } else active = A.full[m] != 0;                          // second pass: only the flagged reads, every orientation
+    for (int k = 0; k < 4; ++k) {
+        int64_t rb = 0, re = 0;
+        const bool on = active && !skip[k] && rescue_window(A, a, k, l_ms, &rb, &re);
+        const int64_t e = 4 * s + k;
+        A.trb[e] = rb;
+        A.tl1[e] = on ? (int32_t)(re - rb) : -1;
+        wide[e] = on ? 1 : 0;
+        wide[N1 + e] = on ? re - rb : 0;
+        wide[2 * N1 + e] = on ? l_ms : 0;
+    }
+}
+
+// ---- build: wave per window ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_build_kernel(PairArgs A, const int64_t *offs, bwams_seqpair_t *pairs, uint8_t *tref,
+                                                         uint8_t *tqer) {
+    const int lane = threadIdx.x & 63;
+    const int64_t N1 = 4 * A.n_slots + 1;
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t e = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < 4 * A.n_slots; e += stride) {
+        const int l1 = A.tl1[e];
+        if (lane == 0) A.task[e] = l1 >= 0 ? (int32_t)offs[e] : -1;
+        if (l1 < 0) continue;
+        const int64_t s = e >> 2;
+        const int k = (int)(e & 3);
+        const int64_t m = (int64_t)A.slot_read[s] ^ 1;
+        const int l_ms = (int)(A.cum[m + 1] - A.cum[m]);
+        const int64_t t = offs[e], ro = offs[N1 + e], qo = offs[2 * N1 + e], rb = A.trb[e];
+        const bool is_rev = (k >> 1) != (k & 1);
+        const uint8_t *ms = A.enc + A.cum[m];
+        for (int i = lane; i < l1; i += 64) tref[ro + i] = A.ref[rb + i];
+        for (int i = lane; i < l_ms; i += 64) {
+            const uint8_t c = is_rev ? ms[l_ms - 1 - i] : ms[i];
+            tqer[qo + i] = is_rev ? (c < 4 ? 3 - c : 4) : c;
+        }
+        if (lane == 0) {
+            bwams_seqpair_t p;
+            p.idr = (int32_t)ro; p.idq = (int32_t)qo; p.id = (int32_t)e; p.len1 = l1; p.len2 = l_ms;
+            p.h0 = KSW_XSUBO | KSW_XSTART | (l_ms * A.opt.a < 250 ? KSW_XBYTE : 0) | (A.opt.min_seed_len * A.opt.a);
+            p.seqid = (int32_t)m; p.regid = (int32_t)t;
+            p.score = p.tle = p.gtle = p.qle = p.gscore = p.max_off = -1;
+            pairs[t] = p;
+        }
+    }
+}
+
+// ---- post: lane per read ------------------------------------------------------------------------------------------
+// mem_sort_dedup_patch(opt, 0, 0, 0, n, a) on the list ord[0, n) over pool
+__device__ int list_sort_dedup(const PairArgs &A, bwams_alnreg_t *pool, int32_t *ord, int n, SortRec *srt) {
+    if (n <= 1) return n;
+    for (int i = 0; i < n; ++i) { SortRec x; x.k = pool[ord[i]].re; x.s = 0; x.q = 0; x.idx = ord[i]; x.pad_ = 0; srt[i] = x; }
+    sort_records(srt, n, 0);
+    for (int i = 0; i < n; ++i) {
+        ord[i] = srt[i].idx;
+        pool[ord[i]].n_comp_is_alt = (pool[ord[i]].n_comp_is_alt & ~0x3fffffff) | 1;
+    }
+    for (int i = 1; i < n; ++i) {
+        bwams_alnreg_t *p = &pool[ord[i]];
+        const bwams_alnreg_t *pr = &pool[ord[i - 1]];
+        if (p->rid != pr->rid || p->rb >= pr->re + A.opt.max_chain_gap) continue;
+        for (int j = i - 1; j >= 0; --j) {
+            bwams_alnreg_t *q = &pool[ord[j]];
+            if (!(p->rid == q->rid && p->rb < q->re + A.opt.max_chain_gap)) break;
+            if (q->qe == q->qb) continue;
+            const int64_t or_ = q->re - p->rb;
+            const int64_t oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+            const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+            const int64_t mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+            if ((float)or_ > A.opt.mask_level_redun * (float)mr && (float)oq > A.opt.mask_level_redun * (float)mq) {
+                if (p->score < q->score) { p->qe = p->qb; break; }
+                else q->qe = q->qb;
+            }                                                    // mem_patch_reg returns 0 without a query (bwamem.cpp:206)
+        }
+    }
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (pool[ord[i]].qe > pool[ord[i]].qb) ord[m++] = ord[i];
+    n = m;
+    for (int i = 0; i < n; ++i) {
+        const bwams_alnreg_t *p = &pool[ord[i]];
+        SortRec x; x.k = p->rb; x.s = p->score; x.q = p->qb; x.idx = ord[i]; x.pad_ = 0;
+        srt[i] = x;
+    }
+    sort_records(srt, n, 1);
+    for (int i = 0; i < n; ++i) ord[i] = srt[i].idx;
+    for (int i = 1; i < n; ++i) {
+        bwams_alnreg_t *p = &pool[ord[i]];
+        const bwams_alnreg_t *pr = &pool[ord[i - 1]];
+        if (p->score == pr->score && p->rb == pr->rb && p->qb == pr->qb) p->qe = p->qb;
+    }
+    m = n ? 1 : 0;
+    for (int i = 1; i < n; ++i)
+        if (pool[ord[i]].qe > pool[ord[i]].qb) ord[m++] = ord[i];
+    return m;
+}
+
+// mem_mark_primary_se_core on the list
+__device__ void list_mark_core(const PairArgs &A, bwams_alnreg_t *pool, const int32_t *ord, int n, int32_t *z) {
+    int tmp = A.opt.a + A.opt.b;
+    tmp = A.opt.o_del + A.opt.e_del > tmp ? A.opt.o_del + A.opt.e_del : tmp;
+    tmp = A.opt.o_ins + A.opt.e_ins > tmp ? A.opt.o_ins + A.opt.e_ins : tmp;
+    int zn = 0;
+    z[zn++] = 0;
+    for (int i = 1; i < n; ++i) {
+        bwams_alnreg_t *ai = &pool[ord[i]];
+        int k;
+        for (k = 0; k < zn; ++k) {
+            bwams_alnreg_t *aj = &pool[ord[z[k]]];
+            const int b_max = aj->qb > ai->qb ? aj->qb : ai->qb;
+            const int e_min = aj->qe < ai->qe ? aj->qe : ai->qe;
+            if (e_min > b_max) {
+                const int min_l = ai->qe - ai->qb < aj->qe - aj->qb ? ai->qe - ai->qb : aj->qe - aj->qb;
+                if ((float)(e_min - b_max) >= (float)min_l * A.opt.mask_level) {
+                    if (aj->sub == 0) aj->sub = ai->score;
+                    if (aj->score - ai->score <= tmp && (is_alt(*aj) || !is_alt(*ai))) ++aj->sub_n;
+                    break;
+                }
+            }
+        }
+        if (k == zn) z[zn++] = i;
+        else ai->secondary = z[k];
+    }
+}
+// mem_mark_primary_se on the list; returns n_pri.  The two sorts compare (score, is_alt, hash) keys that cannot tie
+// (hash_64 is a bijection on id + i), so their result does not depend on the sorting algorithm.
+__device__ int list_mark_primary(const PairArgs &A, bwams_alnreg_t *pool, int32_t *ord, int n, int64_t id, SortRec *srt, int32_t *z) {
+    if (n == 0) return 0;
+    int n_pri = 0;
+    for (int i = 0; i < n; ++i) {
+        bwams_alnreg_t *p = &pool[ord[i]];
+        p->sub = p->alt_sc = 0; p->secondary = p->secondary_all = -1; p->hash = hash_64((uint64_t)(id + i));
+        if (!is_alt(*p)) ++n_pri;
+    }
+    for (int i = 0; i < n; ++i) {
+        const bwams_alnreg_t *p = &pool[ord[i]];
+        SortRec x; x.k = (int64_t)p->hash; x.s = p->score; x.q = is_alt(*p); x.idx = ord[i]; x.pad_ = 0;
+        srt[i] = x;
+    }
+    sort_records(srt, n, 2);
+    for (int i = 0; i < n; ++i) ord[i] = srt[i].idx;
+    list_mark_core(A, pool, ord, n, z);
+    for (int i = 0; i < n; ++i) {
+        bwams_alnreg_t *p = &pool[ord[i]];
+        p->secondary_all = i;
+        if (!is_alt(*p) && p->secondary >= 0 && is_alt(pool[ord[p->secondary]])) p->alt_sc = pool[ord[p->secondary]].score;
+    }
+    if (n_pri < n) {
+        if (n_pri > 0) {
+            for (int i = 0; i < n; ++i) {
+                const bwams_alnreg_t *p = &pool[ord[i]];
+                SortRec x; x.k = (int64_t)p->hash; x.s = p->score; x.q = is_alt(*p); x.idx = ord[i]; x.pad_ = 0;
+                srt[i] = x;
+            }
+            sort_records(srt, n, 3);
+            for (int i = 0; i < n; ++i) ord[i] = srt[i].idx;
+        }
+        for (int i = 0; i < n; ++i) z[pool[ord[i]].secondary_all] = i;
+        for (int i = 0; i < n; ++i) {
+            bwams_alnreg_t *p = &pool[ord[i]];
+            if (p->secondary >= 0) {
+                p->secondary_all = z[p->secondary];
+                if (is_alt(*p)) p->secondary = 0x7fffffff;
+            } else p->secondary_all = -1;
+        }
+        if (n_pri > 0) {
+            for (int i = 0; i < n_pri; ++i) { pool[ord[i]].sub = 0; pool[ord[i]].secondary = -1; }
+            list_mark_core(A, pool, ord, n_pri, z);
+        }
+    } else {
+        for (int i = 0; i < n; ++i) pool[ord[i]].secondary_all = pool[ord[i]].secondary;
+    }
+    return n_pri;
+}
+
+__global__ __launch_bounds__(64) void pair_post_kernel(PairArgs A) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= A.nseq) return;
+    if (A.pass == 1 && !A.full[m]) return;                   // second pass: only the flagged reads
+    const int64_t l_pac = A.bns.l_pac;
+    const int64_t o0 = A.ooff[m];
+    bwams_alnreg_t *pool = A.pool + o0;
+    int32_t *ord = A.ord + o0, *z = A.zbuf + o0;
+    SortRec *srt = reinterpret_cast<SortRec *>(A.srt) + o0;
+    const int64_t m0 = A.reg_off[m];
+    int n = (int)(A.reg_off[m + 1] - m0), n_pool = n;
+    for (int i = 0; i < n; ++i) { bwams_alnreg_t x = A.regs[m0 + i]; x.flg = 0; pool[i] = x; ord[i] = i; }
+    const int64_t r = m ^ 1;                                 // the mate provides the anchors
+    const int l_ms = (int)(A.cum[m + 1] - A.cum[m]);
+    const int na = A.na[r];
+    int n_sw = 0;
+    bool need_full = false;
+    for (int j = 0; j < na && !need_full; ++j) {
+        const int64_t s = A.aoff[r] + j;
+        const bwams_alnreg_t a = A.regs[A.reg_off[r] + A.anchor[s]];
+        bool skip[4];
+        for (int k = 0; k < 4; ++k) skip[k] = A.pes[k].failed != 0;
+        for (int i = 0; i < n; ++i) {
+            int64_t dist;
+            const int d = infer_dir(l_pac, a.rb, pool[ord[i]].rb, &dist);
+            if (dist >= A.pes[d].low && dist <= A.pes[d].high) skip[d] = true;
+        }
+        if (skip[0] && skip[1] && skip[2] && skip[3]) continue;
+        int cnt = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (skip[k]) continue;
+            int64_t rb, re;
+            if (rescue_window(A, a, k, l_ms, &rb, &re)) {
+                const int t = A.task[4 * s + k];
+                if (t < 0) { need_full = true; break; }      // the reference aligns on the spot: second pass
+                const int32_t *al = A.aln + (int64_t)t * 7;  // score, te, qe, score2, te2, tb, qb
+                const int score = al[0], te = al[1], qe = al[2], score2 = al[3], tb = al[5], qb = al[6];
+                if (score >= A.opt.min_seed_len && qb >= 0) {
+                    const bool is_rev = (k >> 1) != (k & 1);
+                    bwams_alnreg_t b;
+                    memset(&b, 0, sizeof b);
+                    b.rid = a.rid;
+                    b.n_comp_is_alt = (int32_t)((uint32_t)is_alt(a) << 30);
+                    b.qb = is_rev ? l_ms - (qe + 1) : qb;
+                    b.qe = is_rev ? l_ms - qb : qe + 1;
+                    b.rb = is_rev ? (l_pac << 1) - (rb + te + 1) : rb + tb;
+                    b.re = is_rev ? (l_pac << 1) - (rb + tb) : rb + te + 1;
+                    b.score = score;
+                    b.csub = score2;
+                    b.secondary = -1;
+                    b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+                    pool[n_pool] = b;
+                    int i;
+                    for (i = 0; i < n; ++i)
+                        if (pool[ord[i]].score < b.score) break;
+                    for (int q = n; q > i; --q) ord[q] = ord[q - 1];
+                    ord[i] = n_pool;
+                    ++n; ++n_pool;
+                }
+                ++cnt;
+            }
+            if (cnt) n = list_sort_dedup(A, pool, ord, n, srt);
+        }
+        n_sw += cnt;
+    }
+    if (need_full) {
+        if (A.pass == 0) { A.full[m] = 1; atomicAdd(&A.ctr->pair_full, 1ull); }
+        else atomicAdd(&A.ctr->pair_fail, 1ull);             // cannot happen: every valid window was planned
+        A.n_fin[m] = 0; A.n_pri[m] = 0; A.n_sw[m] = 0;
+        return;
+    }
+    const int64_t id = ((A.id_base + (m >> 1)) << 1) | (m & 1);
+    A.n_pri[m] = list_mark_primary(A, pool, ord, n, id, srt, z);
+    A.n_fin[m] = n;
+    A.n_sw[m] = n_sw;
+}
+
+__global__ void pair_widen_kernel(PairArgs A, int64_t *wide) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > A.nseq) return;
+    wide[r] = r < A.nseq ? A.n_fin[r] : 0;
+}
+__global__ void pair_gather_kernel(PairArgs A, const int64_t *out_off, bwams_alnreg_t *out) {
+    const int64_t r = blockIdx.x;
+    const int64_t o0 = A.ooff[r], d0 = out_off[r];
+    const int n = A.n_fin[r];
+    const uint4 *src = reinterpret_cast<const uint4 *>(A.pool);
+    uint4 *dst = reinterpret_cast<uint4 *>(out);
+    for (int i = threadIdx.x; i < n * 7; i += blockDim.x) {       // 112 B = 7 x 16 B
+        const int e = i / 7, w = i - e * 7;
+        dst[(d0 + e) * 7 + w] = src[(o0 + A.ord[o0 + e]) * 7 + w];
+    }
+}
+
+// ---- mem_pair: lane per pair ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pair_pair_kernel(PairArgs A, const int64_t *out_off, const bwams_alnreg_t *out, bwams_pair_t *res) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (A.nseq >> 1)) return;
+    const int64_t l_pac = A.bns.l_pac;
+    bwams_pair_t R;
+    R.score = R.sub = R.n_sub = 0;
+    R.z[0] = R.z[1] = -1;
+    R.n_pri[0] = A.n_pri[2 * p]; R.n_pri[1] = A.n_pri[2 * p + 1];
+    R.n_matesw = A.n_sw[2 * p] + A.n_sw[2 * p + 1];
+    if (R.n_pri[0] && R.n_pri[1]) {
+        // v: x = rid << 32 | forward position within the sequence; y = score << 32 | i << 2 | strand << 1 | end.
+        // As a sort record: k = x, (s, q) = the two halves of y.  y holds a unique (i, end): no ties.
+        SortRec *v = reinterpret_cast<SortRec *>(A.srt) + A.ooff[2 * p];        // the two ends' strips are adjacent
+        int vn = 0;
+        for (int e = 0; e < 2; ++e)
+            for (int i = 0; i < R.n_pri[e]; ++i) {
+                const bwams_alnreg_t *g = &out[out_off[2 * p + e] + i];
+                int64_t x = g->rb < l_pac ? g->rb : (l_pac << 1) - 1 - g->rb;
+                x = (int64_t)((uint64_t)g->rid << 32 | (uint64_t)(x - A.bns.contigs[g->rid].offset));
+                SortRec t; t.k = x; t.s = g->score; t.q = i << 2 | (g->rb >= l_pac) << 1 | e; t.idx = 0; t.pad_ = 0;
+                v[vn++] = t;
+            }
+        sort_records(v, vn, 4);
+        int tmp = A.opt.a + A.opt.b;
+        tmp = tmp > A.opt.o_del + A.opt.e_del ? tmp : A.opt.o_del + A.opt.e_del;
+        tmp = tmp > A.opt.o_ins + A.opt.e_ins ? tmp : A.opt.o_ins + A.opt.e_ins;
+        const int id = (int)(A.id_base + p);
+        // u is never stored: its order is total ((q, hash) then (k, i)), so its last two elements are a running
+        // top-2 and n_sub a second sweep
+        uint64_t b1x = 0, b1y = 0, b2x = 0, b2y = 0;
+        long long un = 0;
+        int sub = 0;
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            int y[4] = {-1, -1, -1, -1};
+            long long cnt = 0;
+            for (int i = 0; i < vn; ++i) {
+                for (int r = 0; r < 2; ++r) {
+                    const int dir = r << 1 | (v[i].q >> 1 & 1);
+                    if (A.pes[dir].failed) continue;
+                    const int which = r << 1 | ((v[i].q & 1) ^ 1);
+                    if (y[which] < 0) continue;
+                    for (int k = y[which]; k >= 0; --k) {
+                        if ((v[k].q & 3) != which) continue;
+                        const int64_t dist = v[i].k - v[k].k;
+                        if (dist > A.pes[dir].high) break;
+                        if (dist < A.pes[dir].low) continue;
+                        const double ns = ((double)dist - A.pes[dir].avg) / A.pes[dir].std;
+                        int q = (int)((double)((int64_t)v[i].s + (int64_t)v[k].s) + .721 * log(2. * erfc(fabs(ns) * 0.70710678118654752440)) * A.opt.a + .499);
+                        if (q < 0) q = 0;
+                        if (sweep == 0) {
+                            const uint64_t uy = (uint64_t)k << 32 | (uint64_t)i;
+                            const uint64_t ux = (uint64_t)q << 32 | (hash_64(uy ^ (uint64_t)(int64_t)(id << 8)) & 0xffffffffu);
+                            if (un == 0 || ux > b1x || (ux == b1x && uy > b1y)) { b2x = b1x; b2y = b1y; b1x = ux; b1y = uy; }
+                            else if (un == 1 || ux > b2x || (ux == b2x && uy > b2y)) { b2x = ux; b2y = uy; }
+                            ++un;
+                        } else if (sub - q <= tmp) ++cnt;
+                    }
+                }
+                y[v[i].q & 3] = i;
+            }
+            if (sweep == 0) {
+                if (un == 0) break;
+                sub = un > 1 ? (int)(b2x >> 32) : 0;
+                if (un == 1) break;
+            } else R.n_sub = (int)(cnt - 1);                 // every element but the best one (whose q >= sub)
+        }
+        if (un) {
+            const int i = (int)(uint32_t)b1y, k = (int)(b1y >> 32);
+            R.z[v[i].q & 1] = v[i].q >> 2;
+            R.z[v[k].q & 1] = v[k].q >> 2;
+            R.score = (int)(b1x >> 32);
+            R.sub = sub;
+        }
+    }
+    res[p] = R;
+}
+
+}  // namespace
+
+static unsigned blocks_of(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+void launch_pair_count(const PairArgs &A, int64_t *wide, hipStream_t st) {
+    pair_count_kernel<<<blocks_of(A.nseq + 1, 256), 256, 0, st>>>(A, wide);
+}
+void launch_pair_cap(const PairArgs &A, int64_t *wide, hipStream_t st) {
+    pair_cap_kernel<<<blocks_of(A.nseq + 1, 256), 256, 0, st>>>(A, wide);
+}
+void launch_pair_slots(const PairArgs &A, hipStream_t st) {
+    if (A.nseq > 0) pair_slots_kernel<<<blocks_of(A.nseq, 256), 256, 0, st>>>(A);
+}
+void launch_pair_plan(const PairArgs &A, int64_t *wide, hipStream_t st) {
+    pair_plan_kernel<<<blocks_of(A.n_slots > 0 ? A.n_slots : 1, 64), 64, 0, st>>>(A, wide);
+}
+void launch_pair_build(const PairArgs &A, const int64_t *offs, bwams_seqpair_t *pairs, uint8_t *tref, uint8_t *tqer, int cu_count,
+                       hipStream_t st) {
+    if (A.n_slots <= 0) return;
+    int64_t blocks = A.n_slots;                              // 4 entries per slot, 4 waves per block
+    if (blocks > (int64_t)cu_count * 16) blocks = (int64_t)cu_count * 16;
+    pair_build_kernel<<<(unsigned)blocks, 256, 0, st>>>(A, offs, pairs, tref, tqer);
+}
+void launch_pair_post(const PairArgs &A, hipStream_t st) {
+    if (A.nseq > 0) pair_post_kernel<<<blocks_of(A.nseq, 64), 64, 0, st>>>(A);
+}
+void launch_pair_widen(const PairArgs &A, int64_t *wide, hipStream_t st) {
+    pair_widen_kernel<<<blocks_of(A.nseq + 1, 256), 256, 0, st>>>(A, wide);
+}
+void launch_pair_gather(const PairArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st) {
+    if (A.nseq > 0) pair_gather_kernel<<<(unsigned)A.nseq, 64, 0, st>>>(A, out_off, out);
+}
+void launch_pair_pair(const PairArgs &A, const int64_t *out_off, const bwams_alnreg_t *out, bwams_pair_t *res, hipStream_t st) {
+    if (A.nseq > 1) pair_pair_kernel<<<blocks_of(A.nseq >> 1, 64), 64, 0, st>>>(A, out_off, out, res);
+}
+
+}  // namespace bwams

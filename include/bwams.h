@@ -232,7 +232,10 @@ typedef struct bwams_stats {
     int64_t n_ext_rounds;                 /* extension rounds of the last bwams_extend_run */
     int64_t n_final_regs;                 /* regions left by the last bwams_dedup_run */
     float   ms_dedup;
-    float   pad_;
+    float   ms_pair;                      /* last bwams_pair_run, all of it */
+    int64_t n_pair_tasks;                 /* rescue alignments (ksw_align2 calls) of the last bwams_pair_run */
+    int64_t n_pair_redone;                /* reads whose rescue was redone with every orientation planned */
+    int64_t n_pair_regs;                  /* regions after rescue */
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 
@@ -283,6 +286,22 @@ int bwams_emf_regs_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap
  * The per-pair work (cal_sub, mem_infer_dir) and the sort run on the device; the percentile / mean / std
  * arithmetic over the sorted insert sizes is the reference's sequential double-precision loop, on the host. */
 int bwams_pestat(bwams_batch_t *b, const bwams_mem_opt_t *opt, bwams_pestat_t pes[4]);
+/* The paired-end tail of worker_sam up to the pairing decision, for the chunk whose final regions bwams_dedup_run
+ * left on the device (reads 2p and 2p + 1 = the ends of pair p):
+ *   - mate rescue: mem_sam_pe_batch_pre -> mem_matesw_batch_pre (src/bwamem_pair.cpp:838-870, :1193-1355: anchors
+ *     scoring within pen_unpaired of an end's best hit, at most max_matesw; one window per orientation that is not
+ *     failed and has no consistent hit yet), the batched ksw_align2 of mem_sam_pe_batch (:880-979), and
+ *     mem_sam_pe_batch_post -> mem_matesw_batch_post (:981-1042, :1497-1601: insertion by score and
+ *     mem_sort_dedup_patch(opt, 0, 0, 0, ..) after each alignment) — the non-ERT form;
+ *   - mem_mark_primary_se (src/bwamem.cpp:1905-1980) of both ends with ids (id_base + p) << 1 | end;
+ *   - mem_pair (src/bwamem_pair.cpp:366-427) when both ends have a primary hit.
+ * pes[4] is mem_pestat's result (bwams_pestat) or the caller's (-I); id_base = n_processed >> 1 of the chunk.
+ * no_rescue != 0 = MEM_F_NO_RESCUE.  bwams_pair_fetch returns the regions per read as mem_sam_pe_batch_post holds them
+ * before its MAPQ / SAM part (grouped by read, reg_off[nseq + 1]) and one bwams_pair_t per pair.
+ * The insert-size term of mem_pair is double arithmetic through log / erfc of the device math library. */
+int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t no_rescue,
+                   int64_t *n_regs, int64_t *n_tasks);
+int bwams_pair_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, bwams_pair_t *pairs);
 /* the task lists as built (side 0 = left, 1 = right), for inspection */
 int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref,
                              int64_t ref_cap, uint8_t *qer, int64_t qer_cap, int64_t *n_pairs, int64_t *ref_bytes,

@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--fma", action="store_true", help="build and use the FMA tables (all_smem.11 / last_smem.13)")
     ap.add_argument("--emf", action="store_true", help="build the exact-match filter table (L=150) on the GPU and probe it first")
     ap.add_argument("--pcie", action="store_true", help="also time the one-call host-buffer form (PCIe inclusive)")
+    ap.add_argument("--no-pe", action="store_true", help="skip the paired-end leg (mate rescue + pairing; reported beside, never `value`)")
     args = ap.parse_args()
 
     import torch
@@ -300,6 +301,40 @@ def main():
             dt = (time.perf_counter() - t0) / 2
             out["pcie_inclusive"] = {"value": round(R / dt / 1e6, 4), "unit": "Mreads/s", "ms_per_batch": round(dt * 1e3, 2),
                                      "note": "pageable host buffers: reads up; SMEMs, SA coordinates, chains and final regions down; includes numpy copies"}
+        if not args.no_pe and world == 1:
+            # paired-end leg (BASELINE config 5's path on one GPU): the same step on R/2 FR pairs, then mem_pestat,
+            # mate rescue, mem_mark_primary_se and mem_pair.  Reported beside the headline, never `value`.
+            t0 = time.time()
+            pr = simulate.make_read_pairs_bulk(genome, R // 2, seed=4242)
+            penc, pcum = simulate.flatten_reads(pr)
+            log(f"{R // 2} read pairs generated in {time.time()-t0:.1f}s")
+            batch.seed_upload(penc, pcum)
+
+            def pe_step():
+                step()
+                pes_ = batch.pestat(mem_opt)
+                n_, nt_ = batch.pair_run(pes_, mem_opt)
+                return pes_, n_, nt_
+
+            pe_step()
+            batch.sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                pes_, n_pe, nt_pe = pe_step()
+            batch.sync()
+            dt = (time.perf_counter() - t0) / 2
+            pst = batch.stats()
+            _, _, prs = batch.pair_fetch()
+            out["paired_end"] = {
+                "value": round(2 * (R // 2) / dt / 1e6, 4), "unit": "Mreads/s", "ms_per_batch": round(dt * 1e3, 2),
+                "pairs": R // 2, "ms_pestat_plus_pair": round(dt * 1e3 - float(pst.ms_seed_total + pst.ms_chain + pst.ms_ext_total + pst.ms_dedup), 2),
+                "ms_pair_run": round(float(pst.ms_pair), 3), "rescue_alignments": int(nt_pe), "reads_redone": int(pst.n_pair_redone),
+                "regions_after_rescue": int(n_pe), "proper_pairs": round(float((prs["score"] > 0).mean()), 4),
+                "orientations_failed": [int(x) for x in pes_["failed"]], "insert_avg_std": [round(float(pes_["avg"][1]), 2), round(float(pes_["std"][1]), 2)],
+                "note": "2x150bp FR pairs (insert 400 +- 40, 5 % with a damaged end, 2 % discordant): SE step + mem_pestat + mate rescue "
+                        "(ksw_align2 on the GPU) + mem_mark_primary_se + mem_pair; regions and pairing decisions stay on the device",
+            }
+            batch.seed_upload(enc, cum)
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on a sample (cpu_baseline)...")
             threads = min(16, os.cpu_count() or 1)

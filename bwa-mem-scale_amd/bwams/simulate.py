@@ -142,6 +142,41 @@ def make_read_pairs(genome: np.ndarray, n_pairs: int, seed: int = 777, read_len:
         out.append(e2.astype(np.uint8))
     return out
 
+
+def make_read_pairs_bulk(genome: np.ndarray, n_pairs: int, seed: int = 777, read_len: int = READ_LEN,
+                         insert_mean: float = 400.0, insert_sd: float = 40.0, damaged_frac: float = 0.05,
+                         discordant_frac: float = 0.02) -> np.ndarray:
+    """Vectorised form of make_read_pairs for large batches: uint8[2 * n_pairs, read_len], ends of pair p in rows
+    2p and 2p + 1 (FR library, 1 % substitutions, a damaged_frac with one end at ~12 % substitutions, a
+    discordant_frac with the second end from an unrelated position)."""
+    rng = np.random.default_rng(seed)
+    n = genome.shape[0]
+    isz = np.maximum(read_len + 20, rng.normal(insert_mean, insert_sd, size=n_pairs)).astype(np.int64)
+    pos = (rng.random(n_pairs) * (n - isz - 1)).astype(np.int64)
+    col = np.arange(read_len)[None, :]
+    out = np.empty((2 * n_pairs, read_len), dtype=np.uint8)
+    slab = 1 << 17
+    for a in range(0, n_pairs, slab):
+        b = min(a + slab, n_pairs)
+        left = genome[(pos[a:b, None] + col)]
+        right = genome[(pos[a:b, None] + isz[a:b, None] - read_len + col)]
+        flip = rng.random(b - a) < 0.5
+        e1 = np.where(flip[:, None], revcomp(right), left)
+        e2 = np.where(flip[:, None], left, revcomp(right))
+        disc = rng.random(b - a) < discordant_frac
+        if disc.any():
+            q = rng.integers(0, n - read_len - 1, size=int(disc.sum()))
+            e2[disc] = genome[q[:, None] + col]
+        dmg = rng.random(b - a) < damaged_frac
+        which = rng.random(b - a) < 0.5
+        for e, sel in ((e1, dmg & which), (e2, dmg & ~which)):
+            rate = np.where(sel, 0.12, 0.01)[:, None]
+            m = rng.random(e.shape) < rate
+            e[m] = (e[m] + 1 + rng.integers(0, 3, size=int(m.sum()))) & 3
+        out[2 * a:2 * b:2] = e1
+        out[2 * a + 1:2 * b:2] = e2
+    return out
+
 def flatten_reads(reads) -> tuple[np.ndarray, np.ndarray]:
     """(enc_qdb bytes, cum_len int64[n+1]) from a 2-D array or a list of 1-D arrays.
 

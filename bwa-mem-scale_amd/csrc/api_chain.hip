@@ -768,7 +768,7 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     A.n_fin = s->pr_nfin.as<int32_t>(); A.n_pri = s->pr_npri.as<int32_t>(); A.n_sw = s->pr_nsw.as<int32_t>();
     A.full = s->pr_full.as<uint8_t>(); A.ctr = b->d_ctr;
     A.anchor = nullptr; A.slot_read = nullptr; A.n_slots = 0; A.task = nullptr; A.trb = nullptr; A.tl1 = nullptr; A.aln = nullptr;
-    A.pool = nullptr; A.ord = nullptr; A.zbuf = nullptr; A.srt = nullptr;
+    A.pool = nullptr; A.ord = nullptr; A.zbuf = nullptr; A.srt = nullptr; A.heavy = nullptr;
     BWAMS_HIP(hipEventRecord(s->ev[14], st));
     BWAMS_HIP(hipMemsetAsync(A.full, 0, (size_t)n1, st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_full, 0, 2 * sizeof(unsigned long long), st));
@@ -793,6 +793,8 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     A.task = s->pr_task.as<int32_t>(); A.trb = s->pr_trb.as<int64_t>(); A.tl1 = s->pr_tl1.as<int32_t>();
     A.pool = s->pr_pool.as<bwams_alnreg_t>(); A.ord = s->pr_ord.as<int32_t>(); A.zbuf = s->pr_z.as<int32_t>(); A.srt = s->pr_srt.p;
     launch_pair_slots(A, st);
+    BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
+    A.heavy = s->heavy.as<int32_t>();
     SwParams prm;
     sw_params(*opt, 0, &prm);
     s->pr_tasks = 0; s->pr_redone = 0;
@@ -817,7 +819,8 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
         if (tot[0] > 0)
             launch_ksw(s->pr_pairs.as<bwams_seqpair_t>(), tot[0], s->pr_tref.as<uint8_t>(), s->pr_tqer.as<uint8_t>(), prm,
                        ((b->max_read_len + 15) / 16) * 16, tmax, s->pr_aln.p, b->d_ctr, b->cu_count, st);
-        launch_pair_post(A, st);
+        BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_heavy, 0, 2 * sizeof(unsigned long long), st));
+        launch_pair_post(A, b->cu_count, st);
         s->pr_tasks += tot[0];
         unsigned long long flags[2] = {0, 0};
         BWAMS_HIP(hipMemcpyAsync(flags, &b->d_ctr->pair_full, sizeof flags, hipMemcpyDeviceToHost, st));
@@ -829,7 +832,9 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
         if (pass == 0) s->pr_redone = (int64_t)flags[0];
         if (pass == 1 || flags[0] == 0) break;
     }
-    // regions in final order, then mem_pair
+    // mem_mark_primary_se of every read, regions in final order, then mem_pair
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_heavy, 0, 2 * sizeof(unsigned long long), st));
+    launch_pair_mark(A, b->cu_count, st);
     launch_pair_widen(A, s->pr_owide.as<int64_t>(), st);
     if ((rc = scan_rows(b, s->pr_owide.as<int64_t>(), s->pr_ooff.as<int64_t>(), 1, n1))) return rc;
     int64_t total = 0;

@@ -186,6 +186,7 @@ struct PairArgs {
     void *srt;                     // per pool slot: a 24-byte sort record
     int32_t *n_fin, *n_pri, *n_sw; // per read
     uint8_t *full;                 // per read: redo with every orientation planned
+    int32_t *heavy;                // reads whose list mem_mark_primary_se handles with a wavefront
     DevCounters *ctr;
 };
 void launch_pair_count(const PairArgs &A, int64_t *wide, hipStream_t st);
@@ -194,7 +195,8 @@ void launch_pair_slots(const PairArgs &A, hipStream_t st);
 void launch_pair_plan(const PairArgs &A, int64_t *wide, hipStream_t st);
 void launch_pair_build(const PairArgs &A, const int64_t *offs, bwams_seqpair_t *pairs, uint8_t *tref, uint8_t *tqer, int cu_count,
                        hipStream_t st);
-void launch_pair_post(const PairArgs &A, hipStream_t st);
+void launch_pair_post(const PairArgs &A, int cu_count, hipStream_t st);
+void launch_pair_mark(const PairArgs &A, int cu_count, hipStream_t st);
 void launch_pair_widen(const PairArgs &A, int64_t *wide, hipStream_t st);
 void launch_pair_gather(const PairArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
 void launch_pair_pair(const PairArgs &A, const int64_t *out_off, const bwams_alnreg_t *out, bwams_pair_t *res, hipStream_t st);

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "chain_kernels.h"
 #include "region_sort.h"
+#include "wave_ops.h"
 
 namespace bwams {
 namespace {
@@ -310,14 +311,12 @@ __device__ int list_mark_primary(const PairArgs &A, bwams_alnreg_t *pool, int32_
     return n_pri;
 }
 
-__global__ __launch_bounds__(64) void pair_post_kernel(PairArgs A) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= A.nseq) return;
-    if (A.pass == 1 && !A.full[m]) return;                   // second pass: only the flagged reads
+// the whole rescue of read m's list by one lane, lists and sort records in HBM
+__device__ void post_read_seq(const PairArgs &A, int64_t m) {
     const int64_t l_pac = A.bns.l_pac;
     const int64_t o0 = A.ooff[m];
     bwams_alnreg_t *pool = A.pool + o0;
-    int32_t *ord = A.ord + o0, *z = A.zbuf + o0;
+    int32_t *ord = A.ord + o0;
     SortRec *srt = reinterpret_cast<SortRec *>(A.srt) + o0;
     const int64_t m0 = A.reg_off[m];
     int n = (int)(A.reg_off[m + 1] - m0), n_pool = n;
@@ -381,10 +380,404 @@ __global__ __launch_bounds__(64) void pair_post_kernel(PairArgs A) {
         A.n_fin[m] = 0; A.n_pri[m] = 0; A.n_sw[m] = 0;
         return;
     }
-    const int64_t id = ((A.id_base + (m >> 1)) << 1) | (m & 1);
-    A.n_pri[m] = list_mark_primary(A, pool, ord, n, id, srt, z);
     A.n_fin[m] = n;
     A.n_sw[m] = n_sw;
+}
+
+constexpr int kPostLight = 16;       // pool slots (regions + room for rescued ones) a single lane handles
+constexpr int kPostLds = 1024;       // pool slots a wavefront keeps in LDS
+
+__global__ __launch_bounds__(64) void pair_post_kernel(PairArgs A) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= A.nseq) return;
+    if (A.pass == 1 && !A.full[m]) return;                   // second pass: only the flagged reads
+    if (A.ooff[m + 1] - A.ooff[m] > kPostLight) { A.heavy[atomicAdd(&A.ctr->pair_heavy, 1ull)] = (int32_t)m; return; }
+    post_read_seq(A, m);
+}
+
+// Long lists: a wavefront per read.  What the procedure reads of a region (rid, rb, re, qb, qe, score) lives in LDS,
+// indexed by pool slot; the list is an LDS index array.  The loops over the list run across the lanes (orientation
+// tests by ballot, insertion point and shift, compactions, the identical-hit pass); the two sorts of
+// mem_sort_dedup_patch are rank sorts — every lane counts, from LDS, the records that sort before its own — which
+// give ksort.h's order whenever no two keys are equal; if a key repeats (identical hits) lane 0 runs the
+// operation-exact introsort instead.  Only the pairwise redundancy pass is sequential (lane 0, LDS).  The pool in
+// HBM is written once per region (the copy, a rescued region, the final n_comp); lanes exchange data through LDS only.
+__global__ __launch_bounds__(64) void pair_post_wave_kernel(PairArgs A) {
+    __shared__ int64_t l_rb[kPostLds], l_re[kPostLds], l_k64[kPostLds];
+    __shared__ int32_t l_qb[kPostLds], l_qe[kPostLds], l_sc[kPostLds], l_rid[kPostLds], l_ncia[kPostLds];
+    __shared__ int32_t l_ord[kPostLds], l_tmp[kPostLds], l_ks[kPostLds], l_kq[kPostLds];
+    const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int64_t n_heavy = (int64_t)A.ctr->pair_heavy;
+    const int64_t l_pac = A.bns.l_pac;
+    const int gap = A.opt.max_chain_gap;
+    for (;;) {
+        const int64_t tk = (int64_t)wave_ticket(&A.ctr->pair_ticket, 1ull);
+        if (tk >= n_heavy) break;
+        const int64_t m = A.heavy[tk];
+        const int64_t o0 = A.ooff[m];
+        __syncthreads();
+        if (A.ooff[m + 1] - o0 > kPostLds) {                 // beyond the LDS arrays: one lane, through HBM
+            if (lane == 0) post_read_seq(A, m);
+            continue;
+        }
+        bwams_alnreg_t *pool = A.pool + o0;
+        SortRec *srt = reinterpret_cast<SortRec *>(A.srt) + o0;
+        const int64_t m0 = A.reg_off[m];
+        int n = (int)(A.reg_off[m + 1] - m0), n_pool = n;
+        {   // copy the read's regions into its pool (flg = 0) and their keys into LDS
+            const uint4 *src = reinterpret_cast<const uint4 *>(A.regs + m0);
+            uint4 *dst = reinterpret_cast<uint4 *>(pool);
+            for (int i = lane; i < n * 7; i += 64) {
+                uint4 v = src[i];
+                if (i % 7 == 6) v.z = 0;                     // flg (bytes 104..107)
+                dst[i] = v;
+            }
+            for (int i = lane; i < n; i += 64) {
+                const bwams_alnreg_t *p = A.regs + m0 + i;
+                l_rb[i] = p->rb; l_re[i] = p->re; l_qb[i] = p->qb; l_qe[i] = p->qe; l_sc[i] = p->score; l_rid[i] = p->rid;
+                l_ncia[i] = p->n_comp_is_alt;
+                l_ord[i] = i;
+            }
+        }
+        __syncthreads();
+        const int64_t r = m ^ 1;
+        const int l_ms = (int)(A.cum[m + 1] - A.cum[m]);
+        const int na = A.na[r];
+        int n_sw = 0;
+        bool need_full = false;
+
+        // a sort of the list by rank; by_score = 0: key re, 1: (score desc, rb, qb)
+        auto sort_list = [&](int by_score) {
+            for (int i = lane; i < n; i += 64) {
+                const int sl = l_ord[i];
+                l_k64[i] = by_score ? l_rb[sl] : l_re[sl];
+                l_ks[i] = by_score ? l_sc[sl] : 0;
+                l_kq[i] = by_score ? l_qb[sl] : 0;
+            }
+            __syncthreads();
+            bool tie = false;
+            for (int ib = 0; ib < n; ib += 64) {
+                const int i = ib + lane;
+                int rank = 0, eq = 0;
+                if (i < n) {
+                    const int64_t k = l_k64[i];
+                    const int ks = l_ks[i], kq = l_kq[i];
+                    for (int j = 0; j < n; ++j) {
+                        const int64_t kj = l_k64[j];
+                        const int sj = l_ks[j], qj = l_kq[j];
+                        const bool lt = sj > ks || (sj == ks && (kj < k || (kj == k && qj < kq)));
+                        rank += lt ? 1 : 0;
+                        eq += (sj == ks && kj == k && qj == kq) ? 1 : 0;
+                    }
+                    l_tmp[rank] = l_ord[i];                  // ranks collide only when keys repeat (then the fallback runs)
+                }
+                tie = tie || (__ballot(i < n && eq > 1) != 0);
+            }
+            __syncthreads();
+            if (!tie) {
+                for (int i = lane; i < n; i += 64) l_ord[i] = l_tmp[i];
+            } else {                                         // equal keys: ksort.h's introsort decides their order
+                if (lane == 0) {
+                    for (int i = 0; i < n; ++i) {
+                        SortRec x; x.k = l_k64[i]; x.s = l_ks[i]; x.q = l_kq[i]; x.idx = l_ord[i]; x.pad_ = 0;
+                        srt[i] = x;
+                    }
+                    sort_records(srt, n, by_score);
+                    for (int i = 0; i < n; ++i) l_ord[i] = srt[i].idx;
+                }
+            }
+            __syncthreads();
+        };
+        auto compact = [&]() {                               // keep the regions with qe > qb, in order
+            int nn = 0;
+            for (int ib = 0; ib < n; ib += 64) {
+                const int i = ib + lane;
+                int sl = 0;
+                bool alive = false;
+                if (i < n) { sl = l_ord[i]; alive = l_qe[sl] > l_qb[sl]; }
+                const unsigned long long mk = __ballot(alive);
+                if (alive) l_ord[nn + __popcll(mk & below)] = sl;          // nn + rank <= i: never ahead of a pending read
+                nn += __popcll(mk);
+            }
+            __syncthreads();
+            n = nn;
+        };
+
+        for (int j = 0; j < na && !need_full; ++j) {
+            const int64_t s = A.aoff[r] + j;
+            const bwams_alnreg_t *ap = A.regs + A.reg_off[r] + A.anchor[s];
+            const int64_t a_rb = ap->rb;
+            bool skip[4];
+            for (int k = 0; k < 4; ++k) skip[k] = A.pes[k].failed != 0;
+            for (int ib = 0; ib < n; ib += 64) {
+                const int i = ib + lane;
+                int d = -1;
+                if (i < n) {
+                    int64_t dist;
+                    const int dd = infer_dir(l_pac, a_rb, l_rb[l_ord[i]], &dist);
+                    if (dist >= A.pes[dd].low && dist <= A.pes[dd].high) d = dd;
+                }
+                for (int k = 0; k < 4; ++k) skip[k] = skip[k] || (__ballot(d == k) != 0);
+            }
+            if (skip[0] && skip[1] && skip[2] && skip[3]) continue;
+            const bwams_alnreg_t a = *ap;
+            int cnt = 0;
+            for (int k = 0; k < 4; ++k) {
+                if (skip[k]) continue;
+                int64_t rb, re;
+                if (rescue_window(A, a, k, l_ms, &rb, &re)) {
+                    const int t = A.task[4 * s + k];
+                    if (t < 0) { need_full = true; break; }
+                    const int32_t *al = A.aln + (int64_t)t * 7;
+                    const int score = al[0], te = al[1], qe = al[2], score2 = al[3], tb = al[5], qb = al[6];
+                    if (score >= A.opt.min_seed_len && qb >= 0) {
+                        const bool is_rev = (k >> 1) != (k & 1);
+                        const int sl = n_pool;
+                        const int b_qb = is_rev ? l_ms - (qe + 1) : qb, b_qe = is_rev ? l_ms - qb : qe + 1;
+                        const int64_t b_rb = is_rev ? (l_pac << 1) - (rb + te + 1) : rb + tb;
+                        const int64_t b_re = is_rev ? (l_pac << 1) - (rb + tb) : rb + te + 1;
+                        if (lane == 0) {
+                            bwams_alnreg_t b;
+                            memset(&b, 0, sizeof b);
+                            b.rid = a.rid;
+                            b.n_comp_is_alt = (int32_t)((uint32_t)is_alt(a) << 30);
+                            b.qb = b_qb; b.qe = b_qe; b.rb = b_rb; b.re = b_re;
+                            b.score = score;
+                            b.csub = score2;
+                            b.secondary = -1;
+                            b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+                            pool[sl] = b;
+                            l_rb[sl] = b_rb; l_re[sl] = b_re; l_qb[sl] = b_qb; l_qe[sl] = b_qe; l_sc[sl] = score; l_rid[sl] = a.rid;
+                            l_ncia[sl] = b.n_comp_is_alt;
+                        }
+                        // insertion point: the first region scoring less than b
+                        int at = n;
+                        for (int ib = 0; ib < n && at == n; ib += 64) {
+                            const int i = ib + lane;
+                            const unsigned long long mk = __ballot(i < n && l_sc[l_ord[i]] < score);
+                            if (mk) at = ib + __ffsll((long long)mk) - 1;
+                        }
+                        for (int ib = ((n - at) / 64) * 64; ib >= 0; ib -= 64) {     // shift up, highest chunk first
+                            const int q = at + 1 + ib + lane;                        // q in (at, n]
+                            int v = 0;
+                            if (q <= n) v = l_ord[q - 1];
+                            __syncthreads();
+                            if (q <= n) l_ord[q] = v;
+                            __syncthreads();
+                        }
+                        if (lane == 0) l_ord[at] = sl;
+                        ++n; ++n_pool;
+                        __syncthreads();
+                    }
+                    ++cnt;
+                }
+                if (cnt && n > 1) {                          // mem_sort_dedup_patch(opt, 0, 0, 0, n, a)
+                    sort_list(0);
+                    for (int i = lane; i < n; i += 64) l_ncia[l_ord[i]] = (l_ncia[l_ord[i]] & ~0x3fffffff) | 1;
+                    if (lane == 0) {
+                        for (int i = 1; i < n; ++i) {
+                            const int p = l_ord[i], pr = l_ord[i - 1];
+                            if (l_rid[p] != l_rid[pr] || l_rb[p] >= l_re[pr] + gap) continue;
+                            for (int jj = i - 1; jj >= 0; --jj) {
+                                const int q = l_ord[jj];
+                                if (!(l_rid[p] == l_rid[q] && l_rb[p] < l_re[q] + gap)) break;
+                                if (l_qe[q] == l_qb[q]) continue;
+                                const int64_t or_ = l_re[q] - l_rb[p];
+                                const int64_t oq = l_qb[q] < l_qb[p] ? l_qe[q] - l_qb[p] : l_qe[p] - l_qb[q];
+                                const int64_t mr = l_re[q] - l_rb[q] < l_re[p] - l_rb[p] ? l_re[q] - l_rb[q] : l_re[p] - l_rb[p];
+                                const int64_t mq = l_qe[q] - l_qb[q] < l_qe[p] - l_qb[p] ? l_qe[q] - l_qb[q] : l_qe[p] - l_qb[p];
+                                if ((float)or_ > A.opt.mask_level_redun * (float)mr && (float)oq > A.opt.mask_level_redun * (float)mq) {
+                                    if (l_sc[p] < l_sc[q]) { l_qe[p] = l_qb[p]; break; }
+                                    else l_qe[q] = l_qb[q];
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    compact();
+                    sort_list(1);
+                    for (int ib = 0; ib < n; ib += 64) {                             // identical hits
+                        const int i = ib + lane;
+                        if (i >= 1 && i < n) {
+                            const int p = l_ord[i], pr = l_ord[i - 1];
+                            if (l_sc[p] == l_sc[pr] && l_rb[p] == l_rb[pr] && l_qb[p] == l_qb[pr]) l_qe[p] = l_qb[p];
+                        }
+                    }
+                    __syncthreads();
+                    compact();
+                }
+            }
+            n_sw += cnt;
+        }
+        if (need_full) {
+            if (lane == 0) {
+                if (A.pass == 0) { A.full[m] = 1; atomicAdd(&A.ctr->pair_full, 1ull); }
+                else atomicAdd(&A.ctr->pair_fail, 1ull);
+                A.n_fin[m] = 0; A.n_pri[m] = 0; A.n_sw[m] = 0;
+            }
+            continue;
+        }
+        for (int i = lane; i < n; i += 64) {
+            const int sl = l_ord[i];
+            A.ord[o0 + i] = sl;
+            pool[sl].n_comp_is_alt = l_ncia[sl];
+        }
+        if (lane == 0) { A.n_fin[m] = n; A.n_sw[m] = n_sw; }
+    }
+}
+
+// ---- mem_mark_primary_se: lane per read for short lists, wavefront per read for long ones -------------------------
+constexpr int kMarkLight = 24;       // regions a single lane handles
+constexpr int kMarkLds = 1024;       // regions a wavefront keeps in LDS
+
+__global__ __launch_bounds__(64) void pair_mark_kernel(PairArgs A) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= A.nseq) return;
+    const int n = A.n_fin[m];
+    if (n > kMarkLight) { A.heavy[atomicAdd(&A.ctr->pair_heavy, 1ull)] = (int32_t)m; return; }
+    const int64_t o0 = A.ooff[m];
+    const int64_t id = ((A.id_base + (m >> 1)) << 1) | (m & 1);
+    A.n_pri[m] = list_mark_primary(A, A.pool + o0, A.ord + o0, n, id, reinterpret_cast<SortRec *>(A.srt) + o0, A.zbuf + o0);
+}
+
+// The list is long: its two sorts dominate when one lane runs them through HBM.  Both compare keys that cannot tie,
+// so each element's final position is the number of elements that sort before it — counted by the 64 lanes from LDS.
+// Only mem_mark_primary_se_core's scan stays sequential (lane 0, over LDS copies of qb / qe / score / is_alt); every
+// field is written back to the pool by the lane that owns the element, so lanes never exchange data through HBM.
+__global__ __launch_bounds__(64) void pair_mark_wave_kernel(PairArgs A) {
+    __shared__ int32_t l_slot[kMarkLds], l_sc[kMarkLds], l_alt[kMarkLds], l_qb[kMarkLds], l_qe[kMarkLds];
+    __shared__ uint64_t l_hash[kMarkLds];
+    __shared__ int32_t l_at[kMarkLds];         // sorted position -> original index
+    __shared__ int32_t l_sub[kMarkLds], l_subn[kMarkLds], l_sec[kMarkLds], l_secall[kMarkLds], l_altsc[kMarkLds];   // by sorted position
+    __shared__ int32_t l_pos2[kMarkLds], l_at2[kMarkLds], l_z[kMarkLds];
+    const int lane = threadIdx.x;
+    const int64_t n_heavy = (int64_t)A.ctr->pair_heavy;
+    int tmp = A.opt.a + A.opt.b;
+    tmp = A.opt.o_del + A.opt.e_del > tmp ? A.opt.o_del + A.opt.e_del : tmp;
+    tmp = A.opt.o_ins + A.opt.e_ins > tmp ? A.opt.o_ins + A.opt.e_ins : tmp;
+    for (;;) {
+        const int64_t t = (int64_t)wave_ticket(&A.ctr->pair_ticket, 1ull);
+        if (t >= n_heavy) break;
+        const int64_t m = A.heavy[t];
+        const int n = A.n_fin[m];
+        const int64_t o0 = A.ooff[m];
+        bwams_alnreg_t *pool = A.pool + o0;
+        int32_t *ord = A.ord + o0;
+        const int64_t id = ((A.id_base + (m >> 1)) << 1) | (m & 1);
+        __syncthreads();
+        if (n > kMarkLds) {                                  // beyond the LDS arrays: one lane, through HBM
+            if (lane == 0) A.n_pri[m] = list_mark_primary(A, pool, ord, n, id, reinterpret_cast<SortRec *>(A.srt) + o0, A.zbuf + o0);
+            continue;
+        }
+        int n_pri = 0;
+        for (int ib = 0; ib < n; ib += 64) {
+            const int i = ib + lane;
+            bool pri = false;
+            if (i < n) {
+                const int slot = ord[i];
+                const bwams_alnreg_t *p = &pool[slot];
+                l_slot[i] = slot; l_sc[i] = p->score; l_alt[i] = is_alt(*p); l_qb[i] = p->qb; l_qe[i] = p->qe;
+                l_hash[i] = hash_64((uint64_t)(id + i));
+                pri = !is_alt(*p);
+            }
+            n_pri += __popcll(__ballot(pri));
+        }
+        __syncthreads();
+        // order 1: score descending, is_alt ascending, hash ascending
+        for (int i = lane; i < n; i += 64) {
+            const int sc = l_sc[i], al = l_alt[i];
+            const uint64_t h = l_hash[i];
+            int r = 0;
+            for (int j = 0; j < n; ++j) {
+                const int sj = l_sc[j], aj = l_alt[j];
+                r += (sj > sc || (sj == sc && (aj < al || (aj == al && l_hash[j] < h)))) ? 1 : 0;
+            }
+            l_at[r] = i;
+            l_sub[i] = 0; l_subn[i] = 0; l_sec[i] = -1; l_altsc[i] = 0;
+        }
+        __syncthreads();
+        // mem_mark_primary_se_core over the sorted list (sequential: each element looks at the primaries found so far)
+        auto core = [&](const int32_t *at, int cnt) {
+            int zn = 0;
+            l_z[zn++] = 0;
+            for (int i = 1; i < cnt; ++i) {
+                const int oi = at[i];
+                int k;
+                for (k = 0; k < zn; ++k) {
+                    const int j = l_z[k], oj = at[j];
+                    const int b_max = l_qb[oj] > l_qb[oi] ? l_qb[oj] : l_qb[oi];
+                    const int e_min = l_qe[oj] < l_qe[oi] ? l_qe[oj] : l_qe[oi];
+                    if (e_min > b_max) {
+                        const int li = l_qe[oi] - l_qb[oi], lj = l_qe[oj] - l_qb[oj];
+                        const int min_l = li < lj ? li : lj;
+                        if ((float)(e_min - b_max) >= (float)min_l * A.opt.mask_level) {
+                            if (l_sub[oj] == 0) l_sub[oj] = l_sc[oi];
+                            if (l_sc[oj] - l_sc[oi] <= tmp && (l_alt[oj] || !l_alt[oi])) ++l_subn[oj];
+                            break;
+                        }
+                    }
+                }
+                if (k == zn) l_z[zn++] = i;
+                else l_sec[oi] = l_z[k];
+            }
+        };
+        // l_sub / l_subn / l_sec / l_altsc / l_secall / l_pos2 are indexed by ORIGINAL index from here on
+        if (lane == 0) core(l_at, n);
+        __syncthreads();
+        for (int r = lane; r < n; r += 64) {                 // rank in the first round, alt_sc
+            const int oi = l_at[r];
+            l_secall[oi] = r;
+            const int sec = l_sec[oi];
+            if (!l_alt[oi] && sec >= 0 && l_alt[l_at[sec]]) l_altsc[oi] = l_sc[l_at[sec]];
+        }
+        __syncthreads();
+        const int32_t *fin_at = l_at;
+        if (n_pri < n) {
+            if (n_pri > 0) {
+                // order 2 (is_alt ascending, score descending, hash ascending) = a stable partition of order 1 by is_alt
+                for (int r = lane; r < n; r += 64) {
+                    const int al = l_alt[l_at[r]];
+                    int c = 0;
+                    for (int j = 0; j < n; ++j) {
+                        const int aj = l_alt[l_at[j]];
+                        c += (aj < al || (aj == al && j < r)) ? 1 : 0;
+                    }
+                    l_pos2[r] = c;
+                    l_at2[c] = l_at[r];
+                }
+                fin_at = l_at2;
+            } else {
+                for (int r = lane; r < n; r += 64) l_pos2[r] = r;
+            }
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {             // i: original index
+                if (l_sec[i] >= 0) {
+                    l_secall[i] = l_pos2[l_sec[i]];          // z[a[i].secondary], where z maps first-round rank -> position now
+                    if (l_alt[i]) l_sec[i] = 0x7fffffff;
+                } else l_secall[i] = -1;
+            }
+            __syncthreads();
+            if (n_pri > 0) {
+                for (int r = lane; r < n_pri; r += 64) { l_sub[fin_at[r]] = 0; l_sec[fin_at[r]] = -1; }
+                __syncthreads();
+                if (lane == 0) core(fin_at, n_pri);
+                __syncthreads();
+            }
+        } else {
+            for (int i = lane; i < n; i += 64) l_secall[i] = l_sec[i];
+            __syncthreads();
+        }
+        for (int f = lane; f < n; f += 64) {                 // write back, final order
+            const int oi = fin_at[f];
+            const int slot = l_slot[oi];
+            bwams_alnreg_t *p = &pool[slot];
+            p->sub = l_sub[oi]; p->alt_sc = l_altsc[oi]; p->secondary = l_sec[oi]; p->secondary_all = l_secall[oi];
+            p->hash = l_hash[oi]; p->sub_n += l_subn[oi];
+            ord[f] = slot;
+        }
+        if (lane == 0) A.n_pri[m] = n_pri;
+    }
 }
 
 __global__ void pair_widen_kernel(PairArgs A, int64_t *wide) {
@@ -505,8 +898,15 @@ void launch_pair_build(const PairArgs &A, const int64_t *offs, bwams_seqpair_t *
     if (blocks > (int64_t)cu_count * 16) blocks = (int64_t)cu_count * 16;
     pair_build_kernel<<<(unsigned)blocks, 256, 0, st>>>(A, offs, pairs, tref, tqer);
 }
-void launch_pair_post(const PairArgs &A, hipStream_t st) {
-    if (A.nseq > 0) pair_post_kernel<<<blocks_of(A.nseq, 64), 64, 0, st>>>(A);
+void launch_pair_post(const PairArgs &A, int cu_count, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    pair_post_kernel<<<blocks_of(A.nseq, 64), 64, 0, st>>>(A);
+    pair_post_wave_kernel<<<(unsigned)(cu_count * 2), 64, 0, st>>>(A);
+}
+void launch_pair_mark(const PairArgs &A, int cu_count, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    pair_mark_kernel<<<blocks_of(A.nseq, 64), 64, 0, st>>>(A);
+    pair_mark_wave_kernel<<<(unsigned)(cu_count * 3), 64, 0, st>>>(A);
 }
 void launch_pair_widen(const PairArgs &A, int64_t *wide, hipStream_t st) {
     pair_widen_kernel<<<blocks_of(A.nseq + 1, 256), 256, 0, st>>>(A, wide);

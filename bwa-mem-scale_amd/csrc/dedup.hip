@@ -254,7 +254,7 @@ __device__ __forceinline__ int wave_compact_alive(const bwams_alnreg_t *a, int32
 }
 
 __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_waves) {
-    __shared__ SortRec l_srt[kLdsN];
+    __shared__ SortRec l_srt[kLdsN], l_srt2[kLdsN];
     __shared__ int64_t l_rb[kLdsN];
     __shared__ int32_t l_ord[kLdsN];
     const int lane = threadIdx.x;
@@ -283,8 +283,7 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
                 l_srt[i] = x;
             }
             __syncthreads();
-            if (lane == 0) sort_records(l_srt, n, 0);
-            __syncthreads();
+            wave_sort_records(l_srt, l_srt2, n, 0, lane);
             for (int i = lane; i < n; i += 64) {
                 const int slot = l_srt[i].idx;
                 l_ord[i] = slot;
@@ -337,8 +336,7 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
                 l_srt[i] = x;
             }
             __syncthreads();
-            if (lane == 0) sort_records(l_srt, n, 1);
-            __syncthreads();
+            wave_sort_records(l_srt, l_srt2, n, 1, lane);
             // identical hits: same (score, rb, qb) as the predecessor in sorted order
             int m = 0;
             for (int ib = 0; ib < n; ib += 64) {

@@ -95,5 +95,39 @@ __device__ __noinline__ void sort_records(SortRec *a, int n, int by_score) {
     }
 }
 
+// The same sorts for a one-wavefront block with the records in LDS: every lane counts the records that sort before
+// its own (a rank sort: O(n^2 / 64) LDS reads, no dependent chain), which is the unique sorted order — and hence
+// ksort.h's — whenever no two records compare equal.  A lane-wide ballot checks that; if some do, lane 0 runs the
+// operation-exact introsort on the untouched input instead.  All 64 lanes call this; a and tmp hold n records each.
+template <class LT> __device__ __forceinline__ bool wave_rank_pass(const SortRec *a, SortRec *tmp, int n, int lane, LT lt) {
+    bool tie = false;
+    for (int ib = 0; ib < n; ib += 64) {
+        const int i = ib + lane;
+        int eq = 0;
+        if (i < n) {
+            const SortRec x = a[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const SortRec y = a[j];
+                const bool l = lt(y, x);
+                rank += l ? 1 : 0;
+                eq += (!l && !lt(x, y)) ? 1 : 0;
+            }
+            tmp[rank] = x;                                   // collisions only with equal records (then tmp is not used)
+        }
+        tie = tie || (__ballot(eq > 1) != 0);
+    }
+    return tie;
+}
+__device__ __forceinline__ void wave_sort_records(SortRec *a, SortRec *tmp, int n, int by_score, int lane) {
+    if (n < 2) return;
+    const bool tie = by_score ? wave_rank_pass(a, tmp, n, lane, LtScore()) : wave_rank_pass(a, tmp, n, lane, LtEnd());
+    __syncthreads();
+    if (!tie) {
+        for (int i = lane; i < n; i += 64) a[i] = tmp[i];
+    } else if (lane == 0) sort_records(a, n, by_score);
+    __syncthreads();
+}
+
 }  // namespace
 }  // namespace bwams

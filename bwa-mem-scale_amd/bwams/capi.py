@@ -35,7 +35,7 @@ SYMBOLS = [
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
-    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_pestat", "bwams_pair_run", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
+    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_pestat", "bwams_pestat_keys", "bwams_pestat_from_keys", "bwams_pair_run", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
 ]
 PAIR_DTYPE = np.dtype([("score", "<i4"), ("sub", "<i4"), ("n_sub", "<i4"), ("z", "<i4", (2,)), ("n_pri", "<i4", (2,)),
                        ("n_matesw", "<i4")])
@@ -104,6 +104,14 @@ class Stats(C.Structure):
                 ("ms_ext_right", C.c_float), ("ms_ext_purge", C.c_float), ("ms_ext_total", C.c_float),
                 ("n_ext_rounds", C.c_int64), ("n_final_regs", C.c_int64), ("ms_dedup", C.c_float), ("ms_pair", C.c_float),
                 ("n_pair_tasks", C.c_int64), ("n_pair_redone", C.c_int64), ("n_pair_regs", C.c_int64)]
+
+
+def pestat_from_keys(keys) -> np.ndarray:
+    """mem_pestat's arithmetic over the insert-size keys of a whole chunk (host only; keys in any order)."""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    pes = np.zeros(4, PESTAT_DTYPE)
+    _chk(lib().bwams_pestat_from_keys(_p(keys), len(keys), _p(pes)), "bwams_pestat_from_keys")
+    return pes
 
 
 def default_seed_opt() -> SeedOpt:
@@ -187,6 +195,8 @@ def lib():
         L.bwams_dedup_run.argtypes = [vp, vp, vp]
         L.bwams_dedup_fetch.argtypes = [vp, vp, i64, vp]
         L.bwams_pestat.argtypes = [vp, vp, vp]
+        L.bwams_pestat_keys.argtypes = [vp, vp, vp, C.c_int64, vp]
+        L.bwams_pestat_from_keys.argtypes = [vp, C.c_int64, vp]
         L.bwams_pair_run.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp]
         L.bwams_pair_fetch.argtypes = [vp, vp, C.c_int64, vp, vp]
         L.bwams_emf_regs_run.argtypes = [vp, vp, vp, vp]
@@ -504,6 +514,14 @@ class Batch:
         pes = np.zeros(4, PESTAT_DTYPE)
         _chk(lib().bwams_pestat(self.h, C.byref(opt), _p(pes)), "bwams_pestat")
         return pes
+
+    def pestat_keys(self, opt: MemOpt | None = None) -> np.ndarray:
+        """One key per qualifying pair of this batch (orientation << 60 | insert size), sorted."""
+        opt = opt or default_mem_opt()
+        keys = np.zeros(max(self._nseq // 2, 1), np.uint64)
+        n = C.c_int64(0)
+        _chk(lib().bwams_pestat_keys(self.h, C.byref(opt), _p(keys), len(keys), C.byref(n)), "bwams_pestat_keys")
+        return keys[:n.value].copy()
 
     def pair_run(self, pes, opt: MemOpt | None = None, id_base: int = 0, no_rescue: bool = False):
         """Mate rescue + mem_mark_primary_se + mem_pair over the final regions (reads 2p, 2p+1 = pair p)

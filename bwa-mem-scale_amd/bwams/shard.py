@@ -88,3 +88,30 @@ def gather_regions(regs: np.ndarray, reg_off: np.ndarray, n_chains: int, dist=No
         base_reg += len(p)
         base_chain += int(nch[r][0])
     return np.concatenate(out), np.concatenate(out_off)
+
+
+def pestat_sharded(local_keys: np.ndarray, dist=None) -> np.ndarray:
+    """mem_pestat for a chunk whose pairs are sharded: the one exchange step of the paired-end path.  Every rank
+    contributes the insert-size keys of its qualifying pairs (capi.Batch.pestat_keys), the keys are all-gathered
+    (8 bytes per pair) and every rank runs the reference's arithmetic on the union — bit-identical to the unsharded
+    statistics, which depend only on the multiset of (orientation, insert size)."""
+    from . import capi
+    keys = np.ascontiguousarray(local_keys, np.uint64)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        keys = np.concatenate(_all_gather_bytes(keys, dist))
+    return capi.pestat_from_keys(keys)
+
+
+def gather_pairs(regs: np.ndarray, reg_off: np.ndarray, pairs: np.ndarray, dist=None):
+    """Concatenate per-rank results of the paired-end tail in read order on every rank:
+    -> (regs, reg_off over the whole chunk, pairs)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return regs.copy(), reg_off.copy(), pairs.copy()
+    parts = _all_gather_bytes(regs, dist)
+    offs = _all_gather_bytes(np.ascontiguousarray(reg_off, np.int64), dist)
+    prs = _all_gather_bytes(pairs, dist)
+    out_off, base = [np.zeros(1, np.int64)], 0
+    for p, o in zip(parts, offs):
+        out_off.append(o[1:] + base)
+        base += len(p)
+    return np.concatenate(parts), np.concatenate(out_off), np.concatenate(prs)

@@ -12,6 +12,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include "chain_kernels.h"
 
 namespace bwams {
@@ -930,48 +931,47 @@ int bwams_emf_regs_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap
 
 /* ------------------------------------------------------------------ mem_pestat ---- */
 
-int bwams_pestat(bwams_batch_t *b, const bwams_mem_opt_t *opt, bwams_pestat_t pes[4]) {
-    if (!b || !b->chain || !b->chain->dedup_done || !pes) {
-        set_last_error("bwams_pestat: run bwams_dedup_run first");
-        return BWAMS_ERR_ARG;
-    }
-    int rc = check_opt(opt, "bwams_pestat");
-    if (rc) return rc;
-    ChainState *s = b->chain;
-    BWAMS_HIP(hipSetDevice(b->idx->device));
+// the insert-size keys of the qualifying pairs, sorted: orientation << 60 | insert size
+static int pestat_keys(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, std::vector<unsigned long long> *keys) {
     hipStream_t st = b->stream;
     const int64_t n_pairs = s->nseq >> 1;
     const int64_t l_pac = (b->idx->fmi.ref_seq_len - 1) / 2;
-    memset(pes, 0, 4 * sizeof(bwams_pestat_t));
-    std::vector<unsigned long long> keys((size_t)(n_pairs > 0 ? n_pairs : 1));
-    if (n_pairs > 0) {
-        BWAMS_HIP(s->pe_keys.ensure((size_t)n_pairs * 8));
-        BWAMS_HIP(s->pe_keys2.ensure((size_t)n_pairs * 8));
-        launch_pestat(s->dd_out.as<bwams_alnreg_t>(), s->dd_off.as<int64_t>(), n_pairs, l_pac, *opt,
-                      s->pe_keys.as<unsigned long long>(), st);
-        size_t tb = 0;
-        BWAMS_HIP(rocprim::radix_sort_keys(nullptr, tb, s->pe_keys.as<unsigned long long>(), s->pe_keys2.as<unsigned long long>(),
-                                           (size_t)n_pairs, 0, 64, st));
-        if (tb > b->tmp_bytes) {
-            BWAMS_HIP(hipStreamSynchronize(st));
-            if (b->d_tmp) (void)hipFree(b->d_tmp);
-            b->d_tmp = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
-            b->tmp_bytes = tb;
-        }
-        tb = b->tmp_bytes;
-        BWAMS_HIP(rocprim::radix_sort_keys(b->d_tmp, tb, s->pe_keys.as<unsigned long long>(), s->pe_keys2.as<unsigned long long>(),
-                                           (size_t)n_pairs, 0, 64, st));
-        BWAMS_HIP(hipMemcpyAsync(keys.data(), s->pe_keys2.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st));
+    keys->assign((size_t)(n_pairs > 0 ? n_pairs : 0), ~0ull);
+    if (n_pairs <= 0) return BWAMS_OK;
+    BWAMS_HIP(s->pe_keys.ensure((size_t)n_pairs * 8));
+    BWAMS_HIP(s->pe_keys2.ensure((size_t)n_pairs * 8));
+    launch_pestat(s->dd_out.as<bwams_alnreg_t>(), s->dd_off.as<int64_t>(), n_pairs, l_pac, *opt,
+                  s->pe_keys.as<unsigned long long>(), st);
+    size_t tb = 0;
+    BWAMS_HIP(rocprim::radix_sort_keys(nullptr, tb, s->pe_keys.as<unsigned long long>(), s->pe_keys2.as<unsigned long long>(),
+                                       (size_t)n_pairs, 0, 64, st));
+    if (tb > b->tmp_bytes) {
         BWAMS_HIP(hipStreamSynchronize(st));
+        if (b->d_tmp) (void)hipFree(b->d_tmp);
+        b->d_tmp = nullptr;
+        BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+        b->tmp_bytes = tb;
     }
-    // the reference's arithmetic over each orientation's sorted insert sizes (bwamem_pair.cpp:111-155), as written
+    tb = b->tmp_bytes;
+    BWAMS_HIP(rocprim::radix_sort_keys(b->d_tmp, tb, s->pe_keys.as<unsigned long long>(), s->pe_keys2.as<unsigned long long>(),
+                                       (size_t)n_pairs, 0, 64, st));
+    BWAMS_HIP(hipMemcpyAsync(keys->data(), s->pe_keys2.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    size_t k = keys->size();
+    while (k > 0 && (*keys)[k - 1] == ~0ull) --k;           // pairs that do not qualify sort last
+    keys->resize(k);
+    return BWAMS_OK;
+}
+
+// the reference's arithmetic over each orientation's sorted insert sizes (bwamem_pair.cpp:111-155), as written
+static void pestat_from_sorted(const unsigned long long *keys, size_t n, bwams_pestat_t pes[4]) {
+    memset(pes, 0, 4 * sizeof(bwams_pestat_t));
     size_t beg[5] = {0, 0, 0, 0, 0};
     {
         size_t k = 0;
         for (int d = 0; d < 4; ++d) {
             beg[d] = k;
-            while (k < (size_t)n_pairs && keys[k] != ~0ull && (int)(keys[k] >> 60) == d) ++k;
+            while (k < n && (int)(keys[k] >> 60) == d) ++k;
         }
         beg[4] = k;
     }
@@ -979,7 +979,7 @@ int bwams_pestat(bwams_batch_t *b, const bwams_mem_opt_t *opt, bwams_pestat_t pe
     int max = 0;
     for (int d = 0; d < 4; ++d) {
         bwams_pestat_t *r = &pes[d];
-        const unsigned long long *q = keys.data() + beg[d];
+        const unsigned long long *q = keys + beg[d];
         const size_t qn = beg[d + 1] - beg[d];
         max = max > (int)qn ? max : (int)qn;
         if (qn < 10) { r->failed = 1; continue; }
@@ -1008,6 +1008,43 @@ int bwams_pestat(bwams_batch_t *b, const bwams_mem_opt_t *opt, bwams_pestat_t pe
     }
     for (int d = 0; d < 4; ++d)
         if (pes[d].failed == 0 && (double)(beg[d + 1] - beg[d]) < max * 0.05) pes[d].failed = 1;
+}
+
+int bwams_pestat(bwams_batch_t *b, const bwams_mem_opt_t *opt, bwams_pestat_t pes[4]) {
+    if (!b || !b->chain || !b->chain->dedup_done || !pes) {
+        set_last_error("bwams_pestat: run bwams_dedup_run first");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_pestat");
+    if (rc) return rc;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    std::vector<unsigned long long> keys;
+    if ((rc = pestat_keys(b, b->chain, opt, &keys))) return rc;
+    pestat_from_sorted(keys.data(), keys.size(), pes);
+    return BWAMS_OK;
+}
+
+int bwams_pestat_keys(bwams_batch_t *b, const bwams_mem_opt_t *opt, uint64_t *keys_out, int64_t cap, int64_t *n_keys) {
+    if (!b || !b->chain || !b->chain->dedup_done || !n_keys) {
+        set_last_error("bwams_pestat_keys: run bwams_dedup_run first");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_pestat_keys");
+    if (rc) return rc;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    std::vector<unsigned long long> keys;
+    if ((rc = pestat_keys(b, b->chain, opt, &keys))) return rc;
+    *n_keys = (int64_t)keys.size();
+    if ((int64_t)keys.size() > cap) return BWAMS_ERR_CAPACITY;
+    if (!keys.empty()) memcpy(keys_out, keys.data(), keys.size() * 8);
+    return BWAMS_OK;
+}
+
+int bwams_pestat_from_keys(const uint64_t *keys_in, int64_t n, bwams_pestat_t pes[4]) {
+    if (n < 0 || (n && !keys_in) || !pes) return BWAMS_ERR_ARG;
+    std::vector<unsigned long long> keys(keys_in, keys_in + n);
+    std::sort(keys.begin(), keys.end());
+    pestat_from_sorted(keys.data(), keys.size(), pes);
     return BWAMS_OK;
 }
 

@@ -286,6 +286,13 @@ int bwams_emf_regs_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap
  * The per-pair work (cal_sub, mem_infer_dir) and the sort run on the device; the percentile / mean / std
  * arithmetic over the sorted insert sizes is the reference's sequential double-precision loop, on the host. */
 int bwams_pestat(bwams_batch_t *b, const bwams_mem_opt_t *opt, bwams_pestat_t pes[4]);
+/* The same in two halves, for a chunk whose pairs are sharded over several batches / GPUs: mem_pestat is a statistic
+ * of the WHOLE chunk, the one step of the path where shards exchange data.  bwams_pestat_keys returns one key per
+ * qualifying pair of this batch (orientation << 60 | insert size; n_keys <= nseq / 2, BWAMS_ERR_CAPACITY if cap is
+ * smaller); the caller concatenates the keys of all shards (an all-gather) and every shard calls
+ * bwams_pestat_from_keys (host only, any order of keys) on the union: bit-identical to the unsharded result. */
+int bwams_pestat_keys(bwams_batch_t *b, const bwams_mem_opt_t *opt, uint64_t *keys, int64_t cap, int64_t *n_keys);
+int bwams_pestat_from_keys(const uint64_t *keys, int64_t n, bwams_pestat_t pes[4]);
 /* The paired-end tail of worker_sam up to the pairing decision, for the chunk whose final regions bwams_dedup_run
  * left on the device (reads 2p and 2p + 1 = the ends of pair p):
  *   - mate rescue: mem_sam_pe_batch_pre -> mem_matesw_batch_pre (src/bwamem_pair.cpp:838-870, :1193-1355: anchors

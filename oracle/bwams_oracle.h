@@ -187,6 +187,8 @@ void orc_ars_sort(int64_t n, int which, const int64_t *k0, const int64_t *k1, co
 /* mem_pestat (bwamem_pair.cpp:89-156) over the final regions; reads 2i, 2i+1 = pair i.  PARITY UNPINNED. */
 void orc_pestat(const bwams_mem_opt_t *opt, int64_t l_pac, int n, const bwams_alnreg_t *regs, const int64_t *reg_off,
                 bwams_pestat_t pes[4]);
+int64_t orc_pestat_keys(const bwams_mem_opt_t *opt, int64_t l_pac, int n, const bwams_alnreg_t *regs, const int64_t *reg_off,
+                        uint64_t *keys);
 int64_t orc_regs_finish(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_t *ref_string, const uint8_t *enc_qdb,
                         const int64_t *cum_len, int32_t nseq, bwams_alnreg_t *regs, const int64_t *reg_off, int64_t *out_off);
 

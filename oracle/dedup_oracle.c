@@ -341,6 +341,25 @@ static int cmp_u64(const void *a, const void *b)
     const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
     return (x > y) - (x < y);
 }
+/* the (orientation << 60 | insert size) key of every qualifying pair, in pair order; returns the count */
+int64_t orc_pestat_keys(const bwams_mem_opt_t *opt, int64_t l_pac, int n, const bwams_alnreg_t *regs, const int64_t *reg_off,
+                        uint64_t *keys)
+{
+    int64_t m = 0;
+    for (int i = 0; i < n >> 1; ++i) {
+        const bwams_alnreg_t *r0 = regs + reg_off[i << 1], *r1 = regs + reg_off[i << 1 | 1];
+        const int n0 = (int)(reg_off[(i << 1) + 1] - reg_off[i << 1]), n1 = (int)(reg_off[(i << 1 | 1) + 1] - reg_off[i << 1 | 1]);
+        int64_t is;
+        if (n0 == 0 || n1 == 0) continue;
+        if (cal_sub(opt, n0, r0) > MIN_RATIO * r0[0].score) continue;
+        if (cal_sub(opt, n1, r1) > MIN_RATIO * r1[0].score) continue;
+        if (r0[0].rid != r1[0].rid) continue;
+        const int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+        if (is && is <= opt->max_ins) keys[m++] = (uint64_t)dir << 60 | (uint64_t)is;
+    }
+    return m;
+}
+
 void orc_pestat(const bwams_mem_opt_t *opt, int64_t l_pac, int n, const bwams_alnreg_t *regs, const int64_t *reg_off,
                 bwams_pestat_t pes[4])
 {

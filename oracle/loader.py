@@ -585,3 +585,15 @@ def mark_primary_se(regs, id_: int, opt: MemOpt | None = None):
     regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE).copy()
     n_pri = lib().orc_mark_primary_se(C.byref(opt), len(regs), _p(regs), C.c_int64(id_))
     return regs, n_pri
+
+
+def pestat_keys(regs, reg_off, l_pac, opt: MemOpt | None = None):
+    """The insert-size keys (orientation << 60 | insert size) of the qualifying pairs, in pair order."""
+    opt = opt or default_mem_opt()
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE)
+    reg_off = np.ascontiguousarray(reg_off, np.int64)
+    keys = np.zeros(max((len(reg_off) - 1) // 2, 1), np.uint64)
+    L = lib()
+    L.orc_pestat_keys.restype = C.c_int64
+    n = L.orc_pestat_keys(C.byref(opt), C.c_int64(int(l_pac)), len(reg_off) - 1, _p(regs), _p(reg_off), _p(keys))
+    return keys[:n].copy()

@@ -128,4 +128,26 @@ np.savez_compressed(
     final=fin.view(np.uint8).reshape(len(fin), -1), final_off=fin_off,
     klib_checked_against_reference=np.array([CHAIN_REF is not None and SWREF is not None]))
 
+# ---- paired-end tail on the seeding genome: 120 FR pairs (damaged / discordant ends included) ----
+preads = simulate.make_read_pairs(g, 120, seed=606, insert_mean=330.0, insert_sd=30.0, damaged_frac=0.25, discordant_frac=0.1)
+penc, pcum = simulate.flatten_reads(preads)
+psm = o.collect_smem(penc, pcum)
+pcoord, poff = o.sa_lookup(psm, 500)
+pch, psd, pchoff = loader.chain_seeds(psm, pcoord, poff, pcum, len(g), opt=mopt)
+pregs, preg_off, _ = loader.chain2aln(pch, psd, pchoff, penc, pcum, idx.ref_0123, len(g), opt=mopt)
+pfin, pfin_off = loader.regs_finish(pregs, preg_off, penc, pcum, idx.ref_0123, len(g), opt=mopt)
+ppes = loader.pestat(pfin, pfin_off, len(g), opt=mopt)
+pout, pout_off, ppairs = loader.pair_pe(pfin, pfin_off, penc, pcum, idx.ref_0123, len(g), ppes, opt=mopt, id_base=1000)
+if SWREF is not None:           # the local alignment mate rescue relies on, against the reference's ksw.cpp object
+    xtra = loader.KSW_XSUBO | loader.KSW_XSTART | loader.KSW_XBYTE | 19
+    for p_ in range(0, 40, 2):
+        q_, t_ = preads[p_ + 1], g[max(0, 40 * p_):40 * p_ + 600]
+        assert np.array_equal(loader.ksw_align2(q_, t_, xtra), loader.ref_ksw_align2(SWREF, q_, t_, xtra))
+np.savez_compressed(
+    os.path.join(OUT, "pair_toy.npz"),
+    read_len=np.array([len(r) for r in preads]), reads=penc, pes=ppes.view(np.uint8).reshape(4, -1), id_base=np.int64(1000),
+    final=pfin.view(np.uint8).reshape(len(pfin), -1), final_off=pfin_off,
+    out=pout.view(np.uint8).reshape(len(pout), -1), out_off=pout_off, pairs=ppairs.view(np.uint8).reshape(len(ppairs), -1),
+    ksw_checked_against_reference=np.array([SWREF is not None]))
+
 print("golden vectors written to", OUT, "| reference cross-check:", REF is not None)

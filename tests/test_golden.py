@@ -158,6 +158,57 @@ def test_gpu_reproduces_chain_golden():
     ix.close()
 
 
+PAIR_REG_F = ("rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary",
+              "secondary_all", "n_comp_is_alt", "hash")
+
+
+def _pair_case():
+    z = np.load(os.path.join(G, "pair_toy.npz"))
+    cum = np.concatenate([[0], np.cumsum(z["read_len"])]).astype(np.int64)
+    pes = np.ascontiguousarray(z["pes"]).view(loader.PESTAT_DTYPE).ravel()
+    fin = np.ascontiguousarray(z["final"]).view(loader.ALNREG_DTYPE).ravel()
+    out = np.ascontiguousarray(z["out"]).view(loader.ALNREG_DTYPE).ravel()
+    pairs = np.ascontiguousarray(z["pairs"]).view(loader.PAIR_DTYPE).ravel()
+    return z, cum, pes, fin, out, pairs
+
+
+def test_oracle_reproduces_pair_golden():
+    z, cum, pes, fin, out, pairs = _pair_case()
+    zs, idx = _seed_case()
+    l_pac = len(zs["genome"])
+    assert np.array_equal(loader.pestat(fin, z["final_off"], l_pac), pes)
+    got, got_off, got_pairs = loader.pair_pe(fin, z["final_off"], z["reads"], cum, idx.ref_0123, l_pac, pes, id_base=int(z["id_base"]))
+    assert np.array_equal(got_off, z["out_off"]) and np.array_equal(got_pairs, pairs)
+    for f in PAIR_REG_F:
+        assert np.array_equal(got[f], out[f]), f
+    assert pairs["n_matesw"].sum() > 10 and (pairs["score"] > 0).sum() > 80      # the fixture holds rescues and proper pairs
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_pair_golden():
+    from bwams import capi
+    z, cum, pes, fin, out, pairs = _pair_case()
+    zs, idx = _seed_case()
+    ix = capi.Index.from_host(idx, 0)
+    b = capi.Batch(ix, len(cum) - 1, int(cum[-1]))
+    opt = capi.default_mem_opt()
+    b.seed_upload(z["reads"], cum)
+    b.seed_run(capi.default_seed_opt(), with_sa=True)
+    b.chain_run(opt)
+    b.extend_run(opt)
+    assert b.dedup_run(opt) == len(fin)
+    assert np.array_equal(b.pestat(opt), pes)
+    n, _ = b.pair_run(pes, opt, id_base=int(z["id_base"]))
+    got, got_off, got_pairs = b.pair_fetch()
+    assert n == len(out) and np.array_equal(got_off, z["out_off"])
+    for f in ("score", "sub", "n_sub", "z", "n_pri", "n_matesw"):
+        assert np.array_equal(got_pairs[f], pairs[f]), f
+    for f in PAIR_REG_F:
+        assert np.array_equal(got[f], out[f]), f
+    b.close()
+    ix.close()
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_golden():
     from bwams import capi

@@ -48,6 +48,9 @@ def _compare(g, ix, reads, pes=None, contigs=None, id_base=0, no_rescue=False, *
     if pes is None:
         pes = b.pestat(gopt)
         assert np.array_equal(pes, loader.pestat(fin, fin_off, l_pac, opt=oopt))
+        keys = b.pestat_keys(gopt)                       # the two halves a sharded chunk uses
+        assert np.array_equal(keys, np.sort(loader.pestat_keys(fin, fin_off, l_pac, opt=oopt)))
+        assert np.array_equal(capi.pestat_from_keys(keys[::-1]), pes)
     want_regs, want_off, want_pairs = loader.pair_pe(fin, fin_off, enc, cum, ref, l_pac, pes, contigs=contigs, opt=oopt,
                                                      id_base=id_base, no_rescue=no_rescue)
     n, n_tasks = b.pair_run(pes, gopt, id_base=id_base, no_rescue=no_rescue)

@@ -74,3 +74,61 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path):
     assert np.array_equal(goff, wreg_off) and len(gregs) == len(wregs) > 0
     for f in ("rb", "re", "qb", "qe", "rid", "chain", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
         assert np.array_equal(gregs[f], wregs[f]), f
+
+
+def _pe_chunk():
+    g, idx = toy(40000, seed=5)
+    reads = simulate.make_read_pairs(g, 160, seed=21, damaged_frac=0.25, discordant_frac=0.1)
+    return g, idx, reads
+
+
+def _pe_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "bwa-mem-scale_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import loader
+    from util import oracle_pe_pipeline
+    g, idx, reads = _pe_chunk()
+    enc, cum = simulate.flatten_reads(reads)
+    # shards hold whole pairs; the CPU oracle stands in for the GPU stages on each shard
+    bounds = shard.shard_bounds(len(reads), world, 2)
+    mine = reads[bounds[rank]:bounds[rank + 1]]
+    c = oracle_pe_pipeline(g, idx, mine)
+    # the exchange step: insert-size statistics of the WHOLE chunk from every shard's keys
+    pes = shard.pestat_sharded(loader.pestat_keys(c["regs"], c["reg_off"], c["l_pac"]), dist)
+    out, off, prs = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], pes,
+                                   id_base=int(bounds[rank]) // 2)
+    allregs, alloff, allprs = shard.gather_pairs(out, off, prs, dist)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "pes.npy"), pes)
+        np.save(os.path.join(out_dir, "pe_regs.npy"), allregs)
+        np.save(os.path.join(out_dir, "pe_off.npy"), alloff)
+        np.save(os.path.join(out_dir, "pe_pairs.npy"), allprs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_paired_end_equals_single_process(tmp_path):
+    """Pairs sharded over two ranks: the all-gathered insert-size keys give the whole chunk's statistics, and the
+    gathered regions / pairing decisions equal the single-process ones."""
+    from oracle import loader
+    from util import oracle_pe_pipeline
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_pe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g, idx, reads = _pe_chunk()
+    c = oracle_pe_pipeline(g, idx, reads)
+    assert np.array_equal(np.load(tmp_path / "pes.npy"), c["pes"])
+    # and the host-only half of the product's mem_pestat agrees with the oracle on the same keys
+    from bwams import capi
+    assert np.array_equal(capi.pestat_from_keys(loader.pestat_keys(c["regs"], c["reg_off"], c["l_pac"])), c["pes"])
+    want, want_off, want_prs = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], c["pes"])
+    got, got_off, got_prs = np.load(tmp_path / "pe_regs.npy"), np.load(tmp_path / "pe_off.npy"), np.load(tmp_path / "pe_pairs.npy")
+    assert np.array_equal(got_off, want_off) and np.array_equal(got_prs, want_prs)
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "sub", "sub_n", "csub", "secondary", "secondary_all", "hash", "n_comp_is_alt"):
+        assert np.array_equal(got[f], want[f]), f
+    assert want_prs["n_matesw"].sum() > 5 and c["pes"]["failed"].tolist() == [1, 0, 1, 1]

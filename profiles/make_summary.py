@@ -31,6 +31,14 @@ def short(k):
                       ("dedup_triage", "dedup_triage_kernel"), ("dedup_wave", "dedup_wave_kernel (mem_sort_dedup_patch, wave per read)"),
                       ("dedup_gather", "dedup_gather_kernel"), ("dedup_kernel", "dedup_kernel (mem_sort_dedup_patch, lane per read)"),
                       ("seedsw_", "seedsw kernels (long reads only)"),
+                      ("pair_post_wave", "pair_post_wave_kernel (mate rescue into long region lists, wave per read)"),
+                      ("pair_post", "pair_post_kernel (mate rescue, lane per read)"),
+                      ("pair_mark_wave", "pair_mark_wave_kernel (mem_mark_primary_se, wave per read)"),
+                      ("pair_mark", "pair_mark_kernel (mem_mark_primary_se, lane per read)"),
+                      ("pair_pair", "pair_pair_kernel (mem_pair)"), ("pair_plan", "pair_plan_kernel (rescue windows)"),
+                      ("pair_build", "pair_build_kernel (rescue tasks)"), ("pair_gather", "pair_gather_kernel"),
+                      ("pair_count", "pair_count_kernel"), ("pestat", "pestat_kernel"),
+                      ("ext_heavy_list", "ext_heavy_list_kernel"),
                       ("pack_reads", "pack_reads_kernel"), ("round2_work", "round2_work_kernel"),
                       ("make_keys", "make_keys_kernel"), ("gather_sorted", "gather_sorted_kernel"),
                       ("plan_kernel", "plan_kernel (task construction)"), ("build_kernel", "build_kernel (task construction)"),
@@ -40,12 +48,20 @@ def short(k):
     return None
 
 
-ks = glob.glob(src + "/trace/*/*_kernel_stats.csv")[0]
+import os
+
+
+def newest(pattern):
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] 
+
+
+ks = newest(src + "/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(ks, f"profiles/{rnd}_kernel_stats.csv")
 rows = list(csv.DictReader(open(ks)))
 P = {}
 for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
-    fs = glob.glob(f"{src}/{p}/*/*_counter_collection.csv")
+    fs = newest(f"{src}/{p}/*/*_counter_collection.csv")
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -72,6 +88,15 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
         s = short(r["Name"])
         if s:
             f.write(f"| {s} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['TotalDurationNs'])/3e6:.2f} |\n")
+    pe = newest(src + "/trace_pe/*/*_kernel_stats.csv")
+    if pe and "paired_end" in bench:
+        shutil.copy(pe[0], f"profiles/{rnd}_pe_kernel_stats.csv")
+        f.write("\n### Paired-end leg (`bench.py`'s `paired_end` object: 500 k pairs; 3 calls = 1 warm-up + 2 timed batches)\n\n"
+                "| kernel | calls | avg ms |\n|---|---|---|\n")
+        for r in csv.DictReader(open(pe[0])):
+            s_ = short(r["Name"])
+            if s_ and ("pair_" in s_ or "ksw" in s_ or "pestat" in s_):
+                f.write(f"| {s_} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} |\n")
     f.write(f"\n`roofline.launch_ms` measured live by `bench.py` with HIP events in the run below: {bench['roofline']['launch_ms']} ms "
             "(the rocprofv3 average above covers warm-up + timed launches of the profiled run).\n\n")
     f.write("## PMC per launch (uncorrected counter values; average over the launches of one run)\n\n"

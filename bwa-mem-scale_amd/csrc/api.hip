@@ -1032,8 +1032,8 @@ int bwams_ksw_align(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, c
     }
     int rc = bwams_bsw_upload(b, pairs, n, ref, ref_bytes, qer, qer_bytes);
     if (rc) return rc;
-    if (b->max_qlen > 512 || b->max_tlen > 32767) {
-        set_last_error("bwams_ksw_align: query longer than 512 or target longer than 32767 "
+    if (b->max_qlen > 512 || b->max_tlen > kKswMaxTarget) {
+        set_last_error("bwams_ksw_align: query longer than 512 or target longer than 20000 "
                        "(the reference's kswv bounds are 512 / 2048, src/kswv.h:54-55)");
         return BWAMS_ERR_UNSUPPORTED;
     }
@@ -1049,8 +1049,11 @@ int bwams_ksw_align(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, c
     prm.zdrop = o->zdrop; prm.end_bonus = o->end_bonus; prm.max_sc = mx;
     for (int i = 0; i < 25; ++i) prm.mat[i] = o->mat[i];
     BWAMS_HIP(hipEventRecord(b->ev[14], b->stream));
-    launch_ksw(b->d_pairs, n, b->d_ref, b->d_qer, prm, ((b->max_qlen + 15) / 16) * 16, b->max_tlen, b->d_ksw_out,
-               b->d_ctr, b->cu_count, b->stream);
+    if (launch_ksw(b->d_pairs, n, b->d_ref, b->d_qer, prm, ((b->max_qlen + 15) / 16) * 16, b->max_tlen, b->d_ksw_out,
+                   b->d_ctr, b->cu_count, b->stream)) {
+        set_last_error("bwams_ksw_align: target too long for the LDS of one block");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
     BWAMS_HIP(hipEventRecord(b->ev[15], b->stream));
     BWAMS_HIP(hipGetLastError());
     if (n) BWAMS_HIP(hipMemcpyAsync(out, b->d_ksw_out, (size_t)n * sizeof(bwams_kswr_t), hipMemcpyDeviceToHost, b->stream));

@@ -243,8 +243,8 @@ static int flt_chained_seeds(bwams_batch *b, ChainState *s, const bwams_mem_opt_
                             b->cu_count, st);
         SwParams prm;
         sw_params(*opt, 0, &prm);
-        launch_ksw(s->lpairs.as<bwams_seqpair_t>(), tot[0], s->lref.as<uint8_t>(), s->lqer.as<uint8_t>(), prm, 208, 200,
-                   s->sw_res.p, b->d_ctr, b->cu_count, st);
+        (void)launch_ksw(s->lpairs.as<bwams_seqpair_t>(), tot[0], s->lref.as<uint8_t>(), s->lqer.as<uint8_t>(), prm, 208, 200,
+                         s->sw_res.p, b->d_ctr, b->cu_count, st);
     }
     // keep / drop, new chain lengths, packed offsets (eoffs row 0 still holds the task index of each seed)
     int64_t *cw = s->ewide.as<int64_t>();                // reused: C + 1 entries
@@ -740,8 +740,8 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     int tmax = 1;
     for (int k = 0; k < 4; ++k)
         if (!pes[k].failed && pes[k].high - pes[k].low + b->max_read_len > tmax) tmax = pes[k].high - pes[k].low + b->max_read_len;
-    if (!no_rescue && (b->max_read_len > 512 || tmax > 32767)) {
-        set_last_error("bwams_pair_run: mate rescue needs reads of at most 512 bases and windows (high - low + read length) of at most 32767");
+    if (!no_rescue && (b->max_read_len > 512 || tmax > kKswMaxTarget)) {
+        set_last_error("bwams_pair_run: mate rescue needs reads of at most 512 bases and windows (high - low + read length) of at most 20000");
         return BWAMS_ERR_UNSUPPORTED;
     }
     BWAMS_HIP(hipSetDevice(b->idx->device));
@@ -817,9 +817,11 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
         A.aln = s->pr_aln.as<int32_t>();
         launch_pair_build(A, s->pr_toffs.as<int64_t>(), s->pr_pairs.as<bwams_seqpair_t>(), s->pr_tref.as<uint8_t>(), s->pr_tqer.as<uint8_t>(),
                           b->cu_count, st);
-        if (tot[0] > 0)
-            launch_ksw(s->pr_pairs.as<bwams_seqpair_t>(), tot[0], s->pr_tref.as<uint8_t>(), s->pr_tqer.as<uint8_t>(), prm,
-                       ((b->max_read_len + 15) / 16) * 16, tmax, s->pr_aln.p, b->d_ctr, b->cu_count, st);
+        if (tot[0] > 0 && launch_ksw(s->pr_pairs.as<bwams_seqpair_t>(), tot[0], s->pr_tref.as<uint8_t>(), s->pr_tqer.as<uint8_t>(), prm,
+                                     ((b->max_read_len + 15) / 16) * 16, tmax, s->pr_aln.p, b->d_ctr, b->cu_count, st)) {
+            set_last_error("bwams_pair_run: rescue window too long for the local-SW kernel");
+            return BWAMS_ERR_UNSUPPORTED;
+        }
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_heavy, 0, 2 * sizeof(unsigned long long), st));
         launch_pair_post(A, b->cu_count, st);
         s->pr_tasks += tot[0];

@@ -106,7 +106,8 @@ void launch_task_build(const void *plan, const int32_t *cnt, const int64_t *offs
                        uint8_t *qerbuf, int cu_count, hipStream_t st);
 void launch_emf_probe(const DevEmf &t, const uint8_t *enc, const int64_t *cum, int64_t nseq, uint32_t *out,
                       uint8_t *code, uint8_t *skip, DevCounters *ctr, hipStream_t st);
-void launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
+constexpr int kKswMaxTarget = 20000;     // longest local-SW target: its row-maxima list must fit the LDS of a 4-wave block
+int launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
                 int pmax, int tmax, void *out, DevCounters *ctr, int cu_count, hipStream_t st);
 
 }  // namespace bwams

@@ -216,13 +216,19 @@ __global__ void ksw_reset_kernel(DevCounters *ctr) { ctr->work_head = 0; }
 
 }  // namespace
 
-// out: n records of 7 int32 (kswr_t layout)
-void launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
-                int pmax, int tmax, void *out, DevCounters *ctr, int cu_count, hipStream_t st) {
-    if (n <= 0) return;
+// out: n records of 7 int32 (kswr_t layout).  Returns 0, or -2 when the row-maxima lists of a block (tmax / 2 + 2
+// entries per wave) do not fit one CU's LDS: targets up to kKswMaxTarget bases.
+int launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
+               int pmax, int tmax, void *out, DevCounters *ctr, int cu_count, hipStream_t st) {
+    if (n <= 0) return 0;
     int bcap = tmax / 2 + 2;                               // runs of row maxima are separated by at least one row
     if (bcap < 64) bcap = 64;
     const size_t lds = (size_t)kKswWaves * bcap * 4;
+    if (lds > 160 * 1024) return -2;
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ksw_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     int64_t blocks = (n + kKswWaves - 1) / kKswWaves;
     const int64_t maxb = (int64_t)cu_count * 8;
     if (blocks > maxb) blocks = maxb;
@@ -233,6 +239,7 @@ void launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, con
         ksw_reset_kernel<<<1, 1, 0, st>>>(ctr);
         ksw_kernel<8><<<(unsigned)blocks, kKswWaves * 64, lds, st>>>(pairs, n, ref, qer, prm, 192, bcap, o, ctr);
     }
+    return 0;
 }
 
 }  // namespace bwams

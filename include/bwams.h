@@ -197,7 +197,7 @@ int bwams_tasks_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t pair_cap
  * (src/bwamem_pair.cpp:880-979: kswv::getScores8/16 phase 0, host-side reversal, phase 1)
  * and the scalar call in mem_matesw (src/bwamem_pair.cpp:217).  The sequence buffers are
  * not modified.  Needs oe_ins + oe_del > max(mat) - min(mat) (true for every bwa-mem
- * scoring scheme), queries <= 512 and targets <= 32767 bases. */
+ * scoring scheme), queries <= 512 and targets <= 20000 bases (the row-maxima list of a target must fit one CU's LDS). */
 int bwams_ksw_align(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n,
                     const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer, int64_t qer_bytes,
                     const bwams_sw_opt_t *opt, bwams_kswr_t *out);

@@ -258,6 +258,23 @@ def test_ksw_local_long_queries_scoring_and_limits(gpu_toy):
     assert e.value.code == -6
     assert len(b.ksw_align(pairs[:0], ref, qer)) == 0
     b.close()
+    # a long rescue window (15 kb target: the row-maxima lists need more than the default 64 KB of dynamic LDS) and one
+    # beyond the supported length (refused, not truncated)
+    rng = np.random.default_rng(77)
+    t_long = rng.integers(0, 4, 15000, dtype=np.uint8)
+    q_long = t_long[9000:9150].copy()
+    q_long[[10, 70]] ^= 1
+    lp, lref, lqer = _local_tasks([(q_long, t_long), (q_long[:100], t_long[:400])], flags)
+    b = capi.Batch(ix, 8, 1200)
+    got = b.ksw_align(lp, lref, lqer)
+    want = np.array([loader.ksw_align2(q_long, t_long, flags), loader.ksw_align2(q_long[:100], t_long[:400], flags)], dtype=np.int32)
+    assert np.array_equal(got, want) and got[0, 0] >= 140
+    too_long = rng.integers(0, 4, 20001, dtype=np.uint8)
+    tp, tref, tqer = _local_tasks([(q_long, too_long)], flags)
+    with pytest.raises(capi.BwamsError) as e:
+        b.ksw_align(tp, tref, tqer)
+    assert e.value.code == -6
+    b.close()
 
 
 def test_device_task_construction_equals_numpy_rule(gpu_toy):

@@ -91,3 +91,74 @@ def test_million_reads_properties_and_sampled_parity(big):
         for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "n_comp_is_alt", "frac_rep"):
             assert np.array_equal(a[f], w[f]), (r, f)
     b.close()
+
+
+def test_half_million_pairs_properties_and_sampled_parity(big):
+    """The paired-end tail at full size (500 k pairs = 1 M reads): properties, idempotence, and — a pair's result
+    depends only on its own two region lists, the statistics and its id — the oracle on a random sample of pairs."""
+    g, host, ix, _, _, _ = big
+    n_pairs = N_READS // 2
+    pr = simulate.make_read_pairs_bulk(g, n_pairs, seed=31)
+    enc, cum = simulate.flatten_reads(pr)
+    b = capi.Batch(ix, N_READS, int(cum[-1]))
+    b.seed_upload(enc, cum)
+    opt = capi.default_mem_opt()
+    n, fin, off = _run(b, opt)
+    pes = b.pestat(opt)
+    l_pac = len(g)
+    assert pes["failed"].tolist() == [1, 0, 1, 1] and abs(pes["avg"][1] - 400) < 5 and abs(pes["std"][1] - 40) < 3
+    assert np.array_equal(capi.pestat_from_keys(b.pestat_keys(opt)), pes)
+    ID0 = 7_000_000
+    n_out, n_sw = b.pair_run(pes, opt, id_base=ID0)
+    out, ooff, pairs = b.pair_fetch()
+    st = b.stats()
+    # --- properties at full size
+    per0, per1 = np.diff(off), np.diff(ooff)
+    assert ooff[-1] == n_out == len(out) and np.all(per1 >= 0) and n_sw == st.n_pair_tasks > 10_000
+    assert np.all(pairs["n_pri"].ravel() == per1)                              # one sequence, no ALT: every region is primary-assembly
+    assert (pairs["score"] > 0).mean() > 0.95
+    assert (per1 > per0).sum() > 2_000                                         # rescue added regions
+    rid_of = np.repeat(np.arange(N_READS), per1)
+    pos_in = np.arange(len(out)) - np.repeat(ooff[:-1], per1)
+    # mem_mark_primary_se: hash_64(id + position before its sort) is a bijection -> all hashes distinct within a read,
+    # the list is sorted by (score desc, hash asc), secondary points at an earlier, overlapping, non-secondary region
+    same = rid_of[1:] == rid_of[:-1]
+    s0, s1 = out["score"][:-1], out["score"][1:]
+    h0, h1 = out["hash"][:-1], out["hash"][1:]
+    assert np.all(((s0 > s1) | ((s0 == s1) & (h0 < h1)))[same])
+    sec = out["secondary"]
+    has = sec >= 0
+    assert np.all(sec[has] < pos_in[has]) and np.all(out["secondary"][(np.repeat(ooff[:-1], per1) + np.where(has, sec, 0))[has]] < 0)
+    assert np.all(out["secondary_all"] == out["secondary"])                     # no ALT hits: the second round is skipped
+    # mem_pair: the chosen regions are on opposite strands, within the bounds, and the score is at most the sum
+    good = np.flatnonzero(pairs["score"] > 0)
+    a = out[ooff[2 * good] + pairs["z"][good, 0]]
+    c = out[ooff[2 * good + 1] + pairs["z"][good, 1]]
+    fa = np.where(a["rb"] < l_pac, a["rb"], 2 * l_pac - 1 - a["rb"])
+    fc = np.where(c["rb"] < l_pac, c["rb"], 2 * l_pac - 1 - c["rb"])
+    assert np.all((a["rb"] >= l_pac) != (c["rb"] >= l_pac))
+    d = np.abs(fa - fc)
+    assert np.all((d >= pes["low"][1]) & (d <= pes["high"][1]))
+    assert np.all(pairs["score"][good] <= a["score"] + c["score"]) and np.all(pairs["sub"][good] <= pairs["score"][good])
+    # --- idempotence
+    n_out2, _ = b.pair_run(pes, opt, id_base=ID0)
+    out2, ooff2, pairs2 = b.pair_fetch()
+    assert n_out2 == n_out and np.array_equal(ooff2, ooff) and np.array_equal(pairs2, pairs) and np.array_equal(out2["hash"], out["hash"])
+    # --- the oracle on a random sample of pairs, fed the very regions the device started from
+    rng = np.random.default_rng(6)
+    resc = np.flatnonzero(pairs["n_matesw"] > 0)
+    pick = np.unique(np.concatenate([rng.choice(n_pairs, size=1500, replace=False), rng.choice(resc, size=500, replace=False)]))
+    ref = host.ref_0123
+    for p in pick:
+        r0 = 2 * p
+        sub_off = np.array([0, per0[r0], per0[r0] + per0[r0 + 1]], np.int64)
+        sub_regs = fin[off[r0]:off[r0 + 2]]
+        sub_cum = (cum[r0:r0 + 3] - cum[r0]).astype(np.int64)
+        sub_enc = enc[cum[r0]:cum[r0 + 2]]
+        w, woff, wp = loader.pair_pe(sub_regs, sub_off, sub_enc, sub_cum, ref, l_pac, pes, id_base=ID0 + int(p))
+        assert np.array_equal(wp[0], pairs[p]), p
+        got = out[ooff[r0]:ooff[r0 + 2]]
+        assert np.array_equal(woff, ooff[r0:r0 + 3] - ooff[r0]), p
+        for f in ("rb", "re", "qb", "qe", "score", "sub", "sub_n", "csub", "secondary", "hash", "n_comp_is_alt", "seedcov"):
+            assert np.array_equal(got[f], w[f]), (p, f)
+    b.close()

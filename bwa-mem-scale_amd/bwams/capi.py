@@ -35,8 +35,13 @@ SYMBOLS = [
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
-    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_pestat", "bwams_pestat_keys", "bwams_pestat_from_keys", "bwams_pair_run", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
+    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_chain_run_ert", "bwams_pestat", "bwams_pestat_keys", "bwams_pestat_from_keys", "bwams_pair_run", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
 ]
+ERT_MEM_DTYPE = np.dtype([("forward", "u1"), ("pad_", "u1", (3,)), ("start", "<i4"), ("end", "<i4"), ("rc_start", "<i4"),
+                          ("rc_end", "<i4"), ("skip_ref_fetch", "<i4"), ("fetch_leaves", "<i4"), ("hitbeg", "<i4"),
+                          ("hitcount", "<i4"), ("end_correction", "<i4"), ("is_multi_hit", "<i4"), ("c_pivot", "<i4"),
+                          ("p_pivot", "<i4"), ("pp_pivot", "<i4")])
+assert ERT_MEM_DTYPE.itemsize == 56
 PAIR_DTYPE = np.dtype([("score", "<i4"), ("sub", "<i4"), ("n_sub", "<i4"), ("z", "<i4", (2,)), ("n_pri", "<i4", (2,)),
                        ("n_matesw", "<i4")])
 assert PAIR_DTYPE.itemsize == 32
@@ -195,6 +200,7 @@ def lib():
         L.bwams_dedup_run.argtypes = [vp, vp, vp]
         L.bwams_dedup_fetch.argtypes = [vp, vp, i64, vp]
         L.bwams_pestat.argtypes = [vp, vp, vp]
+        L.bwams_chain_run_ert.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         L.bwams_pestat_keys.argtypes = [vp, vp, vp, C.c_int64, vp]
         L.bwams_pestat_from_keys.argtypes = [vp, C.c_int64, vp]
         L.bwams_pair_run.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp]
@@ -514,6 +520,20 @@ class Batch:
         pes = np.zeros(4, PESTAT_DTYPE)
         _chk(lib().bwams_pestat(self.h, C.byref(opt), _p(pes)), "bwams_pestat")
         return pes
+
+    def chain_run_ert(self, mems, mem_off, hits, hit_off, opt: MemOpt | None = None):
+        """ERT mode: chain the MEMs / hits of the reference's ERT walk (reads uploaded with seed_upload)
+        -> (chains, chain seeds)."""
+        opt = opt or default_mem_opt()
+        mems = np.ascontiguousarray(mems, ERT_MEM_DTYPE)
+        mem_off = np.ascontiguousarray(mem_off, np.int64)
+        hits = np.ascontiguousarray(hits, np.uint64)
+        hit_off = np.ascontiguousarray(hit_off, np.int64)
+        nc, ns = C.c_int64(0), C.c_int64(0)
+        _chk(lib().bwams_chain_run_ert(self.h, C.byref(opt), _p(mems), _p(mem_off), _p(hits), _p(hit_off), C.byref(nc), C.byref(ns)),
+             "bwams_chain_run_ert")
+        self._n_chain = (nc.value, ns.value)
+        return self._n_chain
 
     def pestat_keys(self, opt: MemOpt | None = None) -> np.ndarray:
         """One key per qualifying pair of this batch (orientation << 60 | insert size), sorted."""

@@ -45,6 +45,7 @@ struct ChainState {
     // mate rescue + mem_mark_primary_se + mem_pair
     DevBuf pr_na, pr_wide, pr_offs, pr_anchor, pr_slot, pr_task, pr_trb, pr_tl1, pr_twide, pr_toffs, pr_pairs, pr_tref, pr_tqer,
            pr_aln, pr_pool, pr_ord, pr_srt, pr_z, pr_nfin, pr_npri, pr_nsw, pr_full, pr_owide, pr_ooff, pr_out, pr_res;
+    DevBuf et_mems, et_moff, et_hits, et_hoff, et_smem, et_cnt, et_off, et_coord, et_srt;      // ERT mode input translation
     int64_t pr_total = 0, pr_tasks = 0, pr_redone = 0;
     bool pair_done = false;
     DevBuf er_wide, er_off, er_scr, er_n, er_rev, er_out, er_ooff;   // mem_perfect2reg
@@ -74,7 +75,7 @@ void chain_state_free(ChainState *s) {
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
                      &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->pr_na, &s->pr_wide, &s->pr_offs, &s->pr_anchor, &s->pr_slot, &s->pr_task, &s->pr_trb, &s->pr_tl1, &s->pr_twide, &s->pr_toffs,
                      &s->pr_pairs, &s->pr_tref, &s->pr_tqer, &s->pr_aln, &s->pr_pool, &s->pr_ord, &s->pr_srt, &s->pr_z, &s->pr_nfin, &s->pr_npri, &s->pr_nsw, &s->pr_full, &s->pr_owide,
-                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -261,6 +262,17 @@ static int flt_chained_seeds(bwams_batch *b, ChainState *s, const bwams_mem_opt_
     return BWAMS_OK;
 }
 
+// the seeds of a chunk as the chaining kernels read them: SMEM-like records in (rid, m, n) order and, per record,
+// the reference positions to chain (already strided to at most max_occ)
+struct SeedView {
+    const bwams_smem_t *smem;
+    int64_t n_smem;
+    const int64_t *sa_off, *sa_coord;
+    int64_t n_sa;
+    bool one_smem_quirk;        // mem_chain_seeds' `pos < num_smem - 1` (bwamem.cpp:819); mem_chain_new has no such guard
+};
+static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedView &sv, int64_t *n_chains, int64_t *n_seeds);
+
 int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_chains, int64_t *n_seeds) {
     if (!b || !b->seed_done || !b->with_sa) {
         set_last_error("bwams_chain_run: run bwams_seed_run(with_sa = 1) first");
@@ -269,6 +281,69 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     int rc = check_opt(opt, "bwams_chain_run");
     if (rc) return rc;
     if ((rc = bwams_seed_counts(b, nullptr, nullptr))) return rc;     // sizes of the seed stage (and its overflow check)
+    SeedView sv;
+    sv.smem = b->d_sorted; sv.n_smem = b->n_smem; sv.sa_off = b->d_sa_off; sv.sa_coord = b->d_sa_coord; sv.n_sa = b->n_sa;
+    sv.one_smem_quirk = true;
+    return chain_common(b, opt, sv, n_chains, n_seeds);
+}
+
+int bwams_chain_run_ert(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_ert_mem_t *mems, const int64_t *mem_off,
+                        const uint64_t *hits, const int64_t *hit_off, int64_t *n_chains, int64_t *n_seeds) {
+    if (!b || b->nseq <= 0 || !mem_off || !hit_off) {
+        set_last_error("bwams_chain_run_ert: upload the reads first (bwams_seed_upload) and pass the MEM / hit offsets");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_chain_run_ert");
+    if (rc) return rc;
+    const int64_t nseq = b->nseq, n1 = nseq + 1;
+    const int64_t n_mems = mem_off[nseq], n_hits = hit_off[nseq];
+    if (mem_off[0] != 0 || hit_off[0] != 0 || n_mems < 0 || n_hits < 0 || (n_mems && !mems) || (n_hits && !hits)) return BWAMS_ERR_ARG;
+    for (int64_t r = 0; r < nseq; ++r) {
+        if (mem_off[r + 1] < mem_off[r] || hit_off[r + 1] < hit_off[r]) { set_last_error("bwams_chain_run_ert: offsets must be non-decreasing"); return BWAMS_ERR_ARG; }
+        const int64_t nh = hit_off[r + 1] - hit_off[r];
+        for (int64_t i = mem_off[r]; i < mem_off[r + 1]; ++i) {
+            const bwams_ert_mem_t &m = mems[i];
+            if (m.start < 0 || m.end <= m.start || m.hitcount < 0 || m.hitbeg < 0 || (int64_t)m.hitbeg + m.hitcount > nh) {
+                set_last_error("bwams_chain_run_ert: a MEM with an empty span or a hit slice outside its read's hit array");
+                return BWAMS_ERR_ARG;
+            }
+        }
+    }
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    ChainState *s;
+    if ((rc = get_state(b, &s))) return rc;
+    hipStream_t st = b->stream;
+    BWAMS_HIP(s->et_mems.ensure((size_t)(n_mems + 1) * sizeof(bwams_ert_mem_t)));
+    BWAMS_HIP(s->et_moff.ensure((size_t)n1 * 8)); BWAMS_HIP(s->et_hoff.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->et_hits.ensure((size_t)(n_hits + 1) * 8));
+    BWAMS_HIP(s->et_smem.ensure((size_t)(n_mems + 1) * sizeof(bwams_smem_t)));
+    BWAMS_HIP(s->et_cnt.ensure((size_t)(n_mems + 1) * 8)); BWAMS_HIP(s->et_off.ensure((size_t)(n_mems + 1) * 8));
+    BWAMS_HIP(s->et_srt.ensure((size_t)(n_mems + 1) * 24));
+    if (n_mems) BWAMS_HIP(hipMemcpyAsync(s->et_mems.p, mems, (size_t)n_mems * sizeof(bwams_ert_mem_t), hipMemcpyHostToDevice, st));
+    if (n_hits) BWAMS_HIP(hipMemcpyAsync(s->et_hits.p, hits, (size_t)n_hits * 8, hipMemcpyHostToDevice, st));
+    BWAMS_HIP(hipMemcpyAsync(s->et_moff.p, mem_off, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
+    BWAMS_HIP(hipMemcpyAsync(s->et_hoff.p, hit_off, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
+    ErtArgs E;
+    E.mems = s->et_mems.as<bwams_ert_mem_t>(); E.mem_off = s->et_moff.as<int64_t>();
+    E.hits = s->et_hits.as<uint64_t>(); E.hit_off = s->et_hoff.as<int64_t>();
+    E.nseq = nseq; E.n_mems = n_mems; E.l_pac = (b->idx->fmi.ref_seq_len - 1) / 2;
+    E.max_occ = opt->max_occ; E.pad_ = 0;
+    E.smem_out = s->et_smem.as<bwams_smem_t>(); E.cnt = s->et_cnt.as<int64_t>(); E.srt = s->et_srt.p;
+    launch_ert_sort(E, st);
+    if ((rc = scan_rows(b, s->et_cnt.as<int64_t>(), s->et_off.as<int64_t>(), 1, n_mems + 1))) return rc;
+    int64_t n_sa = 0;
+    BWAMS_HIP(hipMemcpyAsync(&n_sa, s->et_off.as<int64_t>() + n_mems, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(s->et_coord.ensure((size_t)(n_sa + 1) * 8));
+    launch_ert_pick(E, s->et_off.as<int64_t>(), s->et_coord.as<int64_t>(), st);
+    SeedView sv;
+    sv.smem = s->et_smem.as<bwams_smem_t>(); sv.n_smem = n_mems; sv.sa_off = s->et_off.as<int64_t>();
+    sv.sa_coord = s->et_coord.as<int64_t>(); sv.n_sa = n_sa; sv.one_smem_quirk = false;
+    return chain_common(b, opt, sv, n_chains, n_seeds);
+}
+
+static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedView &sv, int64_t *n_chains, int64_t *n_seeds) {
+    int rc;
     if (b->max_read_len >= 32768) {
         set_last_error("bwams_chain_run: reads of 32768 bases or more are not supported (16-bit query coordinates)");
         return BWAMS_ERR_UNSUPPORTED;
@@ -278,7 +353,7 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     if ((rc = get_state(b, &s))) return rc;
     s->chain_done = s->built = s->ext_done = s->dedup_done = s->pair_done = false;
     hipStream_t st = b->stream;
-    const int64_t nseq = b->nseq, n_sa = b->n_sa, n1 = nseq + 1;
+    const int64_t nseq = b->nseq, n_sa = sv.n_sa, n1 = nseq + 1;
     const size_t ns = (size_t)(n_sa > 0 ? n_sa : 1);
     BWAMS_HIP(s->s_next.ensure(ns * 4));  BWAMS_HIP(s->s_ql.ensure(ns * 8));
     BWAMS_HIP(s->crec.ensure(chain_rec_bytes(n_sa)));
@@ -294,7 +369,7 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     BWAMS_HIP(s->wide.ensure((size_t)n1 * 16));       BWAMS_HIP(s->chain_off.ensure((size_t)n1 * 16));
 
     ChainArgs A;
-    A.smem = b->d_sorted; A.n_smem = b->n_smem; A.sa_off = b->d_sa_off; A.sa_coord = b->d_sa_coord;
+    A.smem = sv.smem; A.n_smem = sv.n_smem; A.sa_off = sv.sa_off; A.sa_coord = sv.sa_coord;
     A.cum = b->d_cum; A.nseq = nseq;
     if ((rc = dev_bns(b->idx, &A.bns))) return rc;
     A.opt = *opt;
@@ -312,7 +387,7 @@ int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_cha
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 16 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[6], chain_ticket[6], heavy_ticket
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all
-    if (b->n_smem <= 1 || n_sa == 0) {
+    if ((sv.one_smem_quirk ? sv.n_smem <= 1 : sv.n_smem <= 0) || n_sa == 0) {
         BWAMS_HIP(hipMemsetAsync(s->n_kept.p, 0, (size_t)n1 * 4, st));
         BWAMS_HIP(hipMemsetAsync(s->n_kept_seeds.p, 0, (size_t)n1 * 4, st));
     } else {

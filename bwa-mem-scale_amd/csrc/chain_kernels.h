@@ -201,4 +201,19 @@ void launch_pair_widen(const PairArgs &A, int64_t *wide, hipStream_t st);
 void launch_pair_gather(const PairArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
 void launch_pair_pair(const PairArgs &A, const int64_t *out_off, const bwams_alnreg_t *out, bwams_pair_t *res, hipStream_t st);
 
+// ---- ERT mode: MEMs + hits of the reference's ERT walk -> the chaining kernels' input (ert_chain.hip) ----
+struct ErtArgs {
+    const bwams_ert_mem_t *mems;   // all reads, grouped by read
+    const int64_t *mem_off;        // nseq + 1
+    const uint64_t *hits;
+    const int64_t *hit_off;        // nseq + 1 (mem.hitbeg is relative to the read's slice)
+    int64_t nseq, n_mems, l_pac;
+    int32_t max_occ, pad_;
+    bwams_smem_t *smem_out;        // one record per MEM, sorted within the read
+    int64_t *cnt;                  // n_mems + 1: positions each record contributes
+    void *srt;                     // n_mems sort records
+};
+void launch_ert_sort(const ErtArgs &A, hipStream_t st);
+void launch_ert_pick(const ErtArgs &A, const int64_t *sa_off, int64_t *coord, hipStream_t st);
+
 }  // namespace bwams

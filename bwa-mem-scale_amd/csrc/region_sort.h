@@ -24,6 +24,10 @@ struct LtHash2 { __device__ __forceinline__ bool operator()(const SortRec &a, co
 struct LtXY    { __device__ __forceinline__ bool operator()(const SortRec &a, const SortRec &b) const {
     return a.k < b.k || (a.k == b.k && (a.s < b.s || (a.s == b.s && a.q < b.q))); } };
 
+// smem_lt_2 (bwamem.cpp:73): MEMs of the ERT walk by (start, end); k = start, s = end
+struct LtStartEnd { __device__ __forceinline__ bool operator()(const SortRec &a, const SortRec &b) const {
+    return a.k == b.k ? a.s < b.s : a.k < b.k; } };
+
 template <class LT> __device__ __forceinline__ void r_insertsort(SortRec *a, int s, int t, LT lt) {
     for (int i = s + 1; i < t; ++i)
         for (int j = i; j > s && lt(a[j], a[j - 1]); --j) { const SortRec x = a[j]; a[j] = a[j - 1]; a[j - 1] = x; }
@@ -91,7 +95,8 @@ __device__ __noinline__ void sort_records(SortRec *a, int n, int by_score) {
     case 1: r_introsort(a, n, LtScore()); break;
     case 2: r_introsort(a, n, LtHash()); break;
     case 3: r_introsort(a, n, LtHash2()); break;
-    default: r_introsort(a, n, LtXY()); break;
+    case 4: r_introsort(a, n, LtXY()); break;
+    default: r_introsort(a, n, LtStartEnd()); break;
     }
 }
 

@@ -255,6 +255,15 @@ int bwams_index_set_contigs(bwams_index_t *idx, const bwams_contig_t *contigs, i
  * mem_flt_chained_seeds' re-scoring of short seeds (mem_seed_sw -> ksw_align2) runs as well; that step
  * needs the index's .0123 reference and, like bwams_ksw_align, oe_ins + oe_del > max(mat) - min(mat). */
 int bwams_chain_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_chains, int64_t *n_seeds);
+/* ERT mode: the same stage fed by the reference's ERT walk instead of the FM-index seeding.  Replaces, in
+ * mem_kernel1_core_ert (src/bwamem.cpp:1193-1203), ks_introsort(mem_smem_sort_lt) + mem_chain_new (:961-1050) +
+ * mem_chain_flt + mem_flt_chained_seeds for the whole chunk; the walk itself (get_seeds / reseed / last,
+ * src/ertseeding.cpp) is not built here and stays on the host.  mems: the walk's mem_t records as it leaves them
+ * (unsorted), grouped by read (mem_off[nseq + 1]); hits: the reads' hit arrays back to back (hit_off[nseq + 1];
+ * mem.hitbeg is relative to its read's slice).  The reads must have been uploaded (bwams_seed_upload).  Results as
+ * for bwams_chain_run: bwams_chain_fetch, bwams_extend_run, ... */
+int bwams_chain_run_ert(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_ert_mem_t *mems, const int64_t *mem_off,
+                        const uint64_t *hits, const int64_t *hit_off, int64_t *n_chains, int64_t *n_seeds);
 /* chains grouped by read (chain_off[nseq + 1]) in mem_chain_flt's output order; the seeds of
  * chain c are seeds[c.seed_off .. + c.n) in the order mem_chain_seeds appended them. */
 int bwams_chain_fetch(bwams_batch_t *b, bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds,

@@ -147,6 +147,21 @@ typedef struct bwams_pair {
     int32_t n_matesw;       /* mem_matesw's return values summed: rescue alignments this pair consumed */
 } bwams_pair_t;
 
+/* mem_t (src/ertseeding.h:62-78), 56 B, same field offsets: one maximal exact match found by the reference's ERT walk
+ * and the slice [hitbeg, hitbeg + hitcount) of the read's hit array that belongs to it. */
+typedef struct bwams_ert_mem {
+    uint8_t forward;        /* found by forward search (hits are reference coordinates as they are) */
+    uint8_t pad_[3];
+    int32_t start, end;     /* [start, end) in the read */
+    int32_t rc_start, rc_end;
+    int32_t skip_ref_fetch;
+    int32_t fetch_leaves;   /* hits were gathered from the leaves: coordinates as they are, like forward */
+    int32_t hitbeg, hitcount;
+    int32_t end_correction; /* backward search: bases by which the match ran past its start position */
+    int32_t is_multi_hit;
+    int32_t c_pivot, p_pivot, pp_pivot;     /* pivot_t */
+} bwams_ert_mem_t;
+
 /* mem_seed_t (src/bwamem.h:129-140), 32 B, same field offsets. */
 typedef struct bwams_chain_seed {
     int64_t rbeg;

@@ -165,6 +165,13 @@ int64_t orc_chain_seeds(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const 
                         bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds, int64_t seed_cap,
                         int64_t *chain_off, int64_t *n_seeds_out, const uint8_t *ref_string, const uint8_t *enc_qdb);
 
+/* ERT mode (a13): ks_introsort(mem_smem_sort_lt) + mem_chain_new + mem_chain_flt + mem_flt_chained_seeds over the
+ * MEMs / hits an ERT walk produced (bwamem.cpp:961-1050, :1193-1203).  Same pinning status as orc_chain_seeds. */
+int64_t orc_chain_new_ert(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const bwams_ert_mem_t *mems, const int64_t *mem_off,
+                          const uint64_t *hits, const int64_t *hit_off, const int64_t *cum_len, int32_t nseq, int do_flt,
+                          bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds, int64_t seed_cap,
+                          int64_t *chain_off, int64_t *n_seeds_out, const uint8_t *ref_string, const uint8_t *enc_qdb);
+
 typedef struct orc_task_dump {      /* the extension task lists as mem_chain2aln_across_reads_V2 builds them */
     int32_t build_only;             /* in: stop after building (regions hold the pre-extension state) */
     int32_t pad_;

@@ -576,6 +576,125 @@ int64_t orc_chain_seeds(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const 
 }
 
 /* ------------------------------------------------------------------ chain -> alignment regions */
+/* ---- ERT mode: the tail of mem_kernel1_core_ert (bwamem.cpp:1193-1203) for a chunk whose MEMs and hits the
+ * reference's ERT walk (get_seeds / reseed / last, ertseeding.cpp) produced: ks_introsort(mem_smem_sort_lt),
+ * mem_chain_new (:961-1050), mem_chain_flt, mem_flt_chained_seeds.  mems of read l: [mem_off[l], mem_off[l+1]);
+ * its hit array starts at hits + hit_off[l] (mem.hitbeg is relative to it). ---- */
+typedef int (*orc_lt_fn)(const void *ctx, int a, int b);
+void orc_idx_introsort(size_t n, int *a, orc_lt_fn lt, const void *ctx);
+static int ert_mem_lt(const void *ctx, int a, int b)              /* smem_lt_2, bwamem.cpp:73 */
+{
+    const bwams_ert_mem_t *m = (const bwams_ert_mem_t *)ctx;
+    return m[a].start == m[b].start ? m[a].end < m[b].end : m[a].start < m[b].start;
+}
+int64_t orc_chain_new_ert(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const bwams_ert_mem_t *mems, const int64_t *mem_off,
+                          const uint64_t *hits, const int64_t *hit_off, const int64_t *cum_len, int32_t nseq, int do_flt,
+                          bwams_chain_t *chains, int64_t chain_cap, bwams_chain_seed_t *seeds, int64_t seed_cap,
+                          int64_t *chain_off, int64_t *n_seeds_out, const uint8_t *ref_string, const uint8_t *enc_qdb)
+{
+    const int64_t l_pac = bns->l_pac;
+    int64_t n_chains = 0, n_seeds = 0;
+    chain_off[0] = 0;
+    for (int l = 0; l < nseq; ++l) {
+        const int len = (int)(cum_len[l + 1] - cum_len[l]);
+        const int nm = (int)(mem_off[l + 1] - mem_off[l]);
+        const int64_t first_chain = n_chains;
+        chain_off[l + 1] = n_chains;
+        if (nm == 0) continue;                                     /* (an EMF-resolved read has no MEMs either) */
+        const bwams_ert_mem_t *mm = mems + mem_off[l];
+        const uint64_t *hh = hits + hit_off[l];
+        int *ord = (int *)malloc((size_t)nm * sizeof(int));
+        for (int i = 0; i < nm; ++i) ord[i] = i;
+        orc_idx_introsort((size_t)nm, ord, ert_mem_lt, mm);        /* bwamem.cpp:1193 */
+        if (len < opt->min_seed_len) { free(ord); continue; }      /* mem_chain_new returns at once (:978) */
+        int i, b = 0, e = 0, l_rep = 0;
+        int64_t max_c = 1;
+        for (i = 0; i < nm; ++i) {                                 /* frac_rep (:980-987) */
+            const bwams_ert_mem_t *p = &mm[ord[i]];
+            const int sb = p->start, se = p->end;
+            max_c += p->hitcount < opt->max_occ ? p->hitcount : opt->max_occ;
+            if (p->hitcount <= opt->max_occ) continue;
+            if (sb > e) l_rep += e - b, b = sb, e = se;
+            else e = e > se ? e : se;
+        }
+        l_rep += e - b;
+        wchain_t *wc = (wchain_t *)calloc((size_t)max_c, sizeof(wchain_t));
+        int64_t *wpos = (int64_t *)malloc((size_t)max_c * sizeof(int64_t));
+        int32_t n_wc = 0;
+        orc_kbt_t tree;
+        orc_kbt_init(&tree, wpos);
+        for (i = 0; i < nm; ++i) {
+            const bwams_ert_mem_t *p = &mm[ord[i]];
+            const int slen = p->end - p->start;
+            const int step = p->hitcount > opt->max_occ ? p->hitcount / opt->max_occ : 1;
+            int64_t k;
+            int count;
+            for (k = count = 0; k < p->hitcount && count < opt->max_occ; k += step, ++count) {
+                bwams_chain_seed_t s;
+                memset(&s, 0, sizeof s);
+                if (p->forward || p->fetch_leaves) s.rbeg = (int64_t)hh[p->hitbeg + k];
+                else s.rbeg = (l_pac << 1) - ((int64_t)hh[p->hitbeg + k] + slen - p->end_correction);
+                s.qbeg = p->start;
+                s.len = p->end - p->start;
+                s.score = s.len;
+                const int rid = intv2rid(bns, s.rbeg, s.rbeg + s.len);
+                if (rid < 0) continue;
+                int to_add = 0;
+                if (tree.n_keys) {
+                    const int32_t lower = orc_kbt_lower(&tree, s.rbeg);
+                    if (lower < 0 || !test_and_merge(opt, l_pac, &wc[lower], &s, rid)) to_add = 1;
+                } else to_add = 1;
+                if (to_add) {
+                    wchain_t *c = &wc[n_wc];
+                    c->n = 1; c->m = 4;
+                    c->seeds = (bwams_chain_seed_t *)malloc((size_t)c->m * sizeof(bwams_chain_seed_t));
+                    c->seeds[0] = s;
+                    c->rid = rid;
+                    c->is_alt = !!bns->contigs[rid].is_alt;
+                    c->pos = wpos[n_wc] = s.rbeg;
+                    orc_kbt_put(&tree, n_wc++);
+                }
+            }
+        }
+        free(ord);
+        int32_t *order = (int32_t *)malloc((size_t)(n_wc ? n_wc : 1) * sizeof(int32_t));
+        const int64_t n_trav = n_wc ? orc_kbt_traverse(&tree, order) : 0;
+        int64_t need_seeds = 0;
+        for (int64_t t = 0; t < n_trav; ++t) need_seeds += wc[order[t]].n;
+        const int overflow = n_chains + n_trav > chain_cap || n_seeds + need_seeds > seed_cap;
+        if (!overflow)
+            for (int64_t t = 0; t < n_trav; ++t) {
+                const wchain_t *c = &wc[order[t]];
+                bwams_chain_t *o = &chains[n_chains++];
+                memset(o, 0, sizeof *o);
+                o->seqid = l; o->n = c->n; o->rid = c->rid;
+                for (o->m = 1; o->m < o->n; o->m <<= 1) {}
+                o->w_kept_alt = (uint32_t)c->is_alt << 31;
+                o->frac_rep = (float)l_rep / len;
+                o->pos = c->pos;
+                o->seed_off = n_seeds;
+                memcpy(seeds + n_seeds, c->seeds, (size_t)c->n * sizeof(bwams_chain_seed_t));
+                n_seeds += c->n;
+            }
+        for (int32_t t = 0; t < n_wc; ++t) free(wc[t].seeds);
+        free(order); free(wc); free(wpos);
+        orc_kbt_free(&tree);
+        if (overflow) return -1;
+        if (do_flt && n_chains > first_chain) {
+            const int kept = orc_chain_flt(opt, (int)(n_chains - first_chain), chains + first_chain, seeds);
+            n_chains = first_chain + kept;
+            const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log(len);
+            if (!(min_l > 0.05f * len) && kept) {
+                if (!ref_string || !enc_qdb) return -2;
+                flt_chained_seeds(opt, bns, ref_string, len, enc_qdb + cum_len[l], kept, chains + first_chain, seeds);
+            }
+        }
+        chain_off[l + 1] = n_chains;
+    }
+    if (n_seeds_out) *n_seeds_out = n_seeds;
+    return n_chains;
+}
+
 static int cal_max_gap(const bwams_mem_opt_t *opt, int qlen)
 {
     int l_del = (int)((double)(qlen * opt->a - opt->o_del) / opt->e_del + 1.);

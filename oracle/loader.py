@@ -597,3 +597,45 @@ def pestat_keys(regs, reg_off, l_pac, opt: MemOpt | None = None):
     L.orc_pestat_keys.restype = C.c_int64
     n = L.orc_pestat_keys(C.byref(opt), C.c_int64(int(l_pac)), len(reg_off) - 1, _p(regs), _p(reg_off), _p(keys))
     return keys[:n].copy()
+
+
+ERT_MEM_DTYPE = np.dtype([("forward", "u1"), ("pad_", "u1", (3,)), ("start", "<i4"), ("end", "<i4"), ("rc_start", "<i4"),
+                          ("rc_end", "<i4"), ("skip_ref_fetch", "<i4"), ("fetch_leaves", "<i4"), ("hitbeg", "<i4"),
+                          ("hitcount", "<i4"), ("end_correction", "<i4"), ("is_multi_hit", "<i4"), ("c_pivot", "<i4"),
+                          ("p_pivot", "<i4"), ("pp_pivot", "<i4")])
+assert ERT_MEM_DTYPE.itemsize == 56
+
+
+def chain_new_ert(mems, mem_off, hits, hit_off, cum, l_pac, contigs=None, opt: MemOpt | None = None, do_flt: bool = True,
+                  ref_string=None, enc=None):
+    """Restated tail of mem_kernel1_core_ert: introsort of the MEMs, mem_chain_new, mem_chain_flt,
+    mem_flt_chained_seeds -> (chains, seeds, chain_off)."""
+    opt = opt or default_mem_opt()
+    bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
+    mems = np.ascontiguousarray(mems, dtype=ERT_MEM_DTYPE)
+    mem_off = np.ascontiguousarray(mem_off, np.int64)
+    hits = np.ascontiguousarray(hits, np.uint64)
+    hit_off = np.ascontiguousarray(hit_off, np.int64)
+    cum = np.ascontiguousarray(cum, np.int64)
+    nseq = len(cum) - 1
+    cap = max(1, int(np.minimum(mems["hitcount"], opt.max_occ).sum()))
+    chains = np.zeros(cap, CHAIN_DTYPE)
+    seeds = np.zeros(cap, CHAIN_SEED_DTYPE)
+    chain_off = np.zeros(nseq + 1, np.int64)
+    n_seeds = C.c_int64(0)
+    L = lib()
+    L.orc_chain_new_ert.restype = C.c_int64
+    n = L.orc_chain_new_ert(C.byref(opt), C.byref(bns), _p(mems), _p(mem_off), _p(hits), _p(hit_off), _p(cum), nseq, int(do_flt),
+                            _p(chains), C.c_int64(cap), _p(seeds), C.c_int64(cap), _p(chain_off), C.byref(n_seeds),
+                            _p(np.ascontiguousarray(ref_string, np.uint8)) if ref_string is not None else None,
+                            _p(np.ascontiguousarray(enc, np.uint8)) if enc is not None else None)
+    assert n >= 0, n
+    chains = chains[:n].copy()
+    out = np.zeros(int(chains["n"].sum()), CHAIN_SEED_DTYPE)
+    o = 0
+    for c in chains:
+        k = int(c["n"])
+        out[o:o + k] = seeds[c["seed_off"]:c["seed_off"] + k]
+        c["seed_off"] = o
+        o += k
+    return chains, out, chain_off

@@ -456,3 +456,49 @@ def test_degenerate_inputs_through_the_whole_path(rep_toy):
         for f in ("low", "high", "failed", "avg", "std"):
             assert np.array_equal(pes[f], wpes[f]), f
         b.close()
+
+
+def test_ert_mode_chaining_matches_oracle(rep_toy):
+    """bwams_chain_run_ert: the MEMs / hits an ERT walk would leave (FM-index SMEMs dressed up as such: every hit,
+    some stored the way backward search stores them, MEMs shuffled and some duplicated) through the device sort,
+    mem_chain_new, the chain filter and on to the final regions — against the oracle's ERT tail, and, the inputs being
+    equivalent, against the FM-index path too."""
+    from util import ert_mems_from_smems
+    g, idx, ix = rep_toy
+    reads = _reads(g, 2000, 23, extra=[g[100:118].copy(), np.full(90, 4, np.uint8)])
+    enc, cum = simulate.flatten_reads(reads)
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum)
+    all_coord, all_off = o.sa_lookup(sm, 1 << 30)
+    l_pac = len(g)
+    ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    for trial, (mo, dup) in enumerate(((500, 0.1), (5, 0.0))):
+        oopt, gopt = _mem_opts(max_occ=mo)
+        mems, mem_off, hits, hit_off = ert_mems_from_smems(sm, all_coord, all_off, len(reads), l_pac, seed=trial, dup_frac=dup)
+        want = loader.chain_new_ert(mems, mem_off, hits, hit_off, cum, l_pac, opt=oopt)
+        b = capi.Batch(ix, len(reads), int(cum[-1]))
+        b.seed_upload(enc, cum)
+        nc, ns = b.chain_run_ert(mems, mem_off, hits, hit_off, gopt)
+        got = dict(zip(("chains", "seeds", "chain_off"), b.chain_fetch()))
+        assert nc == len(want[0]) and ns == len(want[1])
+        _assert_chains(dict(chains=want[0], seeds=want[1], chain_off=want[2]), got)
+        if dup == 0.0:                                        # equivalent inputs: the FM-index path's chains
+            coord, off = o.sa_lookup(sm, mo)
+            fm = loader.chain_seeds(sm, coord, off, cum, l_pac, opt=oopt)
+            assert np.array_equal(fm[2], want[2]) and np.array_equal(fm[0]["pos"], want[0]["pos"])
+            assert (mems["hitcount"] > mo).sum() > 20
+        # the rest of the path runs on these chains like on any others
+        b.extend_run(gopt)
+        regs, reg_off, aln = b.extend_fetch()
+        wregs, wreg_off, wseeds = loader.chain2aln(want[0], want[1], want[2], enc, cum, ref, l_pac, opt=oopt)
+        assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
+        _assert_regs(regs, wregs, False)
+        b.close()
+    # malformed input is refused
+    bad = mems.copy()
+    bad["hitbeg"][0] = 1 << 20
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    b.seed_upload(enc, cum)
+    with pytest.raises(capi.BwamsError):
+        b.chain_run_ert(bad, mem_off, hits, hit_off)
+    b.close()

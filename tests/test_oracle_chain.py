@@ -375,3 +375,43 @@ def test_long_reads_seed_rescoring_from_definition():
 
 def test_long_read_threshold_reported():
     assert 5.5 * math.log(150) > 0.05 * 150 and 5.5 * math.log(1200) <= 0.05 * 1200
+
+
+def test_ert_mode_chaining_equals_fm_index_chaining_on_equivalent_seeds():
+    """mem_chain_new (ERT mode) and mem_chain_seeds run the same procedure on differently represented seeds: fed the
+    FM-index SMEMs dressed up as an ERT walk's output (all hits, some stored the way backward search stores them,
+    shuffled, a few duplicated), the restated ERT tail must produce the chains of the FM-index path."""
+    from bwams import fmindex, simulate
+    g = simulate.make_genome(50000, seed=9, repeat_frac=0.4, repeat_len=220, n_families=3)
+    idx = fmindex.build_fmindex(g)
+    reads, _, _ = simulate.make_reads(g, 400, seed=10)
+    enc, cum = simulate.flatten_reads(reads)
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum)
+    coord, off = o.sa_lookup(sm)                                    # what the FM-index path chains (strided, <= max_occ)
+    all_coord, all_off = o.sa_lookup(sm, 1 << 30)                   # every occurrence
+    l_pac = len(g)
+    want = loader.chain_seeds(sm, coord, off, cum, l_pac)
+    mems, mem_off, hits, hit_off = util.ert_mems_from_smems(sm, all_coord, all_off, len(reads), l_pac, seed=3, dup_frac=0.0)
+    got = loader.chain_new_ert(mems, mem_off, hits, hit_off, cum, l_pac)
+    assert np.array_equal(got[2], want[2])
+    for f in ("seqid", "n", "m", "first", "rid", "w_kept_alt", "frac_rep", "pos", "seed_off"):
+        assert np.array_equal(got[0][f], want[0][f]), f
+    for f in ("rbeg", "qbeg", "len", "score"):
+        assert np.array_equal(got[1][f], want[1][f]), f
+    assert (mems["forward"] == 0).sum() > 100 and len(want[0]) > 400
+    # a small max_occ: the strided pick over the hit array must land on the rows get_sa_entries picks
+    opt8 = loader.default_mem_opt()
+    opt8.max_occ = 3
+    coord8, off8 = o.sa_lookup(sm, 3)
+    want8 = loader.chain_seeds(sm, coord8, off8, cum, l_pac, opt=opt8)
+    got8 = loader.chain_new_ert(mems, mem_off, hits, hit_off, cum, l_pac, opt=opt8)
+    assert (mems["hitcount"] > 3).sum() > 20 and np.array_equal(got8[2], want8[2])
+    for f in ("n", "rid", "w_kept_alt", "frac_rep", "pos"):
+        assert np.array_equal(got8[0][f], want8[0][f]), f
+    assert np.array_equal(got8[1]["rbeg"], want8[1]["rbeg"])
+    # duplicated MEMs change nothing but the weights of the chains they fall into (contained seeds are dropped)
+    mems2, mem_off2, hits2, hit_off2 = util.ert_mems_from_smems(sm, all_coord, all_off, len(reads), l_pac, seed=4, dup_frac=0.2)
+    got2 = loader.chain_new_ert(mems2, mem_off2, hits2, hit_off2, cum, l_pac, do_flt=False)
+    want2 = loader.chain_seeds(sm, coord, off, cum, l_pac, do_flt=False)
+    assert np.array_equal(got2[2], want2[2]) and np.array_equal(got2[0]["pos"], want2[0]["pos"]) and np.array_equal(got2[0]["n"], want2[0]["n"])

@@ -151,3 +151,52 @@ def oracle_pe_pipeline(g, idx, reads, contigs=None, opt=None):
     fin, fin_off = loader.regs_finish(regs, reg_off, enc, cum, ref, l_pac, contigs=contigs, opt=opt)
     pes = loader.pestat(fin, fin_off, l_pac, opt=opt)
     return dict(enc=enc, cum=cum, ref=ref, l_pac=l_pac, regs=fin, reg_off=fin_off, pes=pes, opt=opt, sm=sm, coord=coord, off=off)
+
+
+
+def ert_mems_from_smems(sm, all_coord, all_off, nseq, l_pac, seed=0, shuffle=True, backward_frac=0.4, dup_frac=0.05):
+    """Dress FM-index SMEMs up as the output of the reference's ERT walk (mem_t records + per-read hit arrays).
+
+    all_coord / all_off hold EVERY occurrence of each SMEM (SA lookup with max_occ = infinity), in BWT-row order, so
+    that mem_chain_new's strided pick (hits[hitbeg + k], k = 0, step, ..) sees the rows get_sa_entries would.  A
+    backward_frac of the MEMs are marked "found by backward search": their hits are stored as the walk stores them
+    (position of the reverse-complemented match, off by end_correction) and mem_chain_new maps them back.  MEMs are
+    shuffled within a read (the reference sorts them) and a few are duplicated (ties for the unstable sort)."""
+    from oracle import loader
+    rng = np.random.default_rng(seed)
+    mems, hits, mem_off, hit_off = [], [], [0], [0]
+    order = np.argsort(sm["rid"], kind="stable")
+    by_read = [[] for _ in range(nseq)]
+    for i in order:
+        by_read[int(sm["rid"][i])].append(int(i))
+    for r in range(nseq):
+        idxs = list(by_read[r])
+        idxs += [i for i in idxs if rng.random() < dup_frac]
+        if shuffle:
+            rng.shuffle(idxs)
+        hb = 0
+        for i in idxs:
+            pos = all_coord[all_off[i]:all_off[i + 1]].astype(np.int64)
+            m = np.zeros(1, loader.ERT_MEM_DTYPE)[0]
+            m["start"], m["end"] = int(sm["m"][i]), int(sm["n"][i]) + 1
+            slen = int(m["end"]) - int(m["start"])
+            m["hitbeg"], m["hitcount"] = hb, len(pos)
+            kind = rng.random()
+            if kind < backward_frac:
+                m["forward"], m["fetch_leaves"] = 0, 0
+                m["end_correction"] = int(rng.integers(0, 4))
+                stored = 2 * l_pac - pos - slen + int(m["end_correction"])
+            elif kind < backward_frac + 0.2:
+                m["forward"], m["fetch_leaves"] = 0, 1
+                stored = pos
+            else:
+                m["forward"] = 1
+                stored = pos
+            hits.append(stored.astype(np.uint64))
+            hb += len(pos)
+            mems.append(m)
+        mem_off.append(len(mems))
+        hit_off.append(hit_off[-1] + hb)
+    mems = np.array(mems, dtype=loader.ERT_MEM_DTYPE) if mems else np.zeros(0, loader.ERT_MEM_DTYPE)
+    hits = np.concatenate(hits) if hits else np.zeros(0, np.uint64)
+    return mems, np.array(mem_off, np.int64), hits, np.array(hit_off, np.int64)

@@ -799,8 +799,9 @@ int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, i
 
 /* ------------------------------------------------- mate rescue, mem_mark_primary_se, mem_pair ---- */
 
-int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t no_rescue,
+int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t flags,
                    int64_t *n_regs, int64_t *n_tasks) {
+    const int no_rescue = flags & BWAMS_PAIR_NO_RESCUE, use_ert = (flags & BWAMS_PAIR_USE_ERT) != 0;
     if (!b || !b->chain || !b->chain->dedup_done) {
         set_last_error("bwams_pair_run: run bwams_dedup_run first");
         return BWAMS_ERR_ARG;
@@ -837,7 +838,8 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     A.opt = *opt;
     for (int k = 0; k < 4; ++k) A.pes[k] = pes[k];
     A.id_base = id_base; A.no_rescue = no_rescue ? 1 : 0; A.pass = 0;
-    A.drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") ? 1 : 0; A.pad_ = 0;      // test knob: exercise the second pass
+    A.drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") ? 1 : 0;                 // test knob: exercise the second pass
+    A.use_ert = use_ert ? 1 : 0;
     A.na = s->pr_na.as<int32_t>();
     int64_t *aoff = s->pr_offs.as<int64_t>(), *ooff = aoff + n1;
     A.aoff = aoff; A.ooff = ooff;

@@ -172,7 +172,8 @@ struct PairArgs {
     bwams_pestat_t pes[4];
     int64_t id_base;               // n_processed >> 1 of the chunk (mem_mark_primary_se / mem_pair hash their ids)
     int32_t no_rescue, pass;
-    int32_t drop_plan, pad_;       // test knob: the first pass plans nothing, so every rescue goes through the second
+    int32_t drop_plan;             // test knob: the first pass plans nothing, so every rescue goes through the second
+    int32_t use_ert;               // mem_sam_pe_batch_post's useErt branch: mem_matesw_batch_post_ert
     int32_t *na;                   // per read: anchors it provides
     const int64_t *aoff, *ooff;    // per read: first anchor slot, first pool slot
     int32_t *anchor, *slot_read;   // per anchor slot: region index within its read, the read

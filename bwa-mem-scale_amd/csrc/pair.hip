@@ -184,15 +184,22 @@ __global__ __launch_bounds__(256) void pair_build_kernel(PairArgs A, const int64
 }
 
 // ---- post: lane per read ------------------------------------------------------------------------------------------
-// mem_sort_dedup_patch(opt, 0, 0, 0, n, a) on the list ord[0, n) over pool
-__device__ int list_sort_dedup(const PairArgs &A, bwams_alnreg_t *pool, int32_t *ord, int n, SortRec *srt) {
-    if (n <= 1) return n;
-    for (int i = 0; i < n; ++i) { SortRec x; x.k = pool[ord[i]].re; x.s = 0; x.q = 0; x.idx = ord[i]; x.pad_ = 0; srt[i] = x; }
-    sort_records(srt, n, 0);
+// sort_alnreg_re (by_score = 0) / sort_alnreg_score (1) on the list ord[0, n) over pool: ksort.h's introsort
+__device__ void list_sort(const bwams_alnreg_t *pool, int32_t *ord, int n, SortRec *srt, int by_score) {
+    if (n < 2) return;
     for (int i = 0; i < n; ++i) {
-        ord[i] = srt[i].idx;
-        pool[ord[i]].n_comp_is_alt = (pool[ord[i]].n_comp_is_alt & ~0x3fffffff) | 1;
+        const bwams_alnreg_t *p = &pool[ord[i]];
+        SortRec x; x.idx = ord[i]; x.pad_ = 0;
+        if (by_score) { x.k = p->rb; x.s = p->score; x.q = p->qb; } else { x.k = p->re; x.s = 0; x.q = 0; }
+        srt[i] = x;
     }
+    sort_records(srt, n, by_score);
+    for (int i = 0; i < n; ++i) ord[i] = srt[i].idx;
+}
+// the pairwise redundancy pass of mem_(sort_)dedup_patch over the list as it stands, then the compaction; without a
+// query mem_patch_reg returns 0 (bwamem.cpp:206), so nothing is merged
+__device__ int list_pairwise(const PairArgs &A, bwams_alnreg_t *pool, int32_t *ord, int n) {
+    for (int i = 0; i < n; ++i) pool[ord[i]].n_comp_is_alt = (pool[ord[i]].n_comp_is_alt & ~0x3fffffff) | 1;
     for (int i = 1; i < n; ++i) {
         bwams_alnreg_t *p = &pool[ord[i]];
         const bwams_alnreg_t *pr = &pool[ord[i - 1]];
@@ -208,29 +215,34 @@ __device__ int list_sort_dedup(const PairArgs &A, bwams_alnreg_t *pool, int32_t 
             if ((float)or_ > A.opt.mask_level_redun * (float)mr && (float)oq > A.opt.mask_level_redun * (float)mq) {
                 if (p->score < q->score) { p->qe = p->qb; break; }
                 else q->qe = q->qb;
-            }                                                    // mem_patch_reg returns 0 without a query (bwamem.cpp:206)
+            }
         }
     }
     int m = 0;
     for (int i = 0; i < n; ++i)
         if (pool[ord[i]].qe > pool[ord[i]].qb) ord[m++] = ord[i];
-    n = m;
-    for (int i = 0; i < n; ++i) {
-        const bwams_alnreg_t *p = &pool[ord[i]];
-        SortRec x; x.k = p->rb; x.s = p->score; x.q = p->qb; x.idx = ord[i]; x.pad_ = 0;
-        srt[i] = x;
-    }
-    sort_records(srt, n, 1);
-    for (int i = 0; i < n; ++i) ord[i] = srt[i].idx;
+    return m;
+}
+// mem_sort_dedup_patch(opt, 0, 0, 0, n, a) on the list
+__device__ int list_sort_dedup(const PairArgs &A, bwams_alnreg_t *pool, int32_t *ord, int n, SortRec *srt) {
+    if (n <= 1) return n;
+    list_sort(pool, ord, n, srt, 0);
+    n = list_pairwise(A, pool, ord, n);
+    list_sort(pool, ord, n, srt, 1);
     for (int i = 1; i < n; ++i) {
         bwams_alnreg_t *p = &pool[ord[i]];
         const bwams_alnreg_t *pr = &pool[ord[i - 1]];
         if (p->score == pr->score && p->rb == pr->rb && p->qb == pr->qb) p->qe = p->qb;
     }
-    m = n ? 1 : 0;
+    int m = n ? 1 : 0;
     for (int i = 1; i < n; ++i)
         if (pool[ord[i]].qe > pool[ord[i]].qb) ord[m++] = ord[i];
     return m;
+}
+// mem_dedup_patch(opt, 0, 0, 0, n, a) (bwamem.cpp:262-312): no sorting, no identical-hit pass
+__device__ int list_dedup(const PairArgs &A, bwams_alnreg_t *pool, int32_t *ord, int n) {
+    if (n <= 1) return n;
+    return list_pairwise(A, pool, ord, n);
 }
 
 // mem_mark_primary_se_core on the list
@@ -324,8 +336,11 @@ __device__ void post_read_seq(const PairArgs &A, int64_t m) {
     const int64_t r = m ^ 1;                                 // the mate provides the anchors
     const int l_ms = (int)(A.cum[m + 1] - A.cum[m]);
     const int na = A.na[r];
-    int n_sw = 0;
+    int n_sw = 0, last_cnt = 0;
     bool need_full = false;
+    // useErt (mem_sam_pe_batch_post, bwamem_pair.cpp:1017-1041): the list is sorted by end first and kept so by
+    // mem_matesw_batch_post_ert; afterwards mem_sort_dedup_patch if the LAST anchor consumed an alignment, else a score sort
+    if (A.use_ert && !A.no_rescue) list_sort(pool, ord, n, srt, 0);
     for (int j = 0; j < na && !need_full; ++j) {
         const int64_t s = A.aoff[r] + j;
         const bwams_alnreg_t a = A.regs[A.reg_off[r] + A.anchor[s]];
@@ -336,6 +351,7 @@ __device__ void post_read_seq(const PairArgs &A, int64_t m) {
             const int d = infer_dir(l_pac, a.rb, pool[ord[i]].rb, &dist);
             if (dist >= A.pes[d].low && dist <= A.pes[d].high) skip[d] = true;
         }
+        last_cnt = 0;
         if (skip[0] && skip[1] && skip[2] && skip[3]) continue;
         int cnt = 0;
         for (int k = 0; k < 4; ++k) {
@@ -362,17 +378,38 @@ __device__ void post_read_seq(const PairArgs &A, int64_t m) {
                     b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
                     pool[n_pool] = b;
                     int i;
-                    for (i = 0; i < n; ++i)
-                        if (pool[ord[i]].score < b.score) break;
-                    for (int q = n; q > i; --q) ord[q] = ord[q - 1];
-                    ord[i] = n_pool;
+                    if (!A.use_ert) {
+                        for (i = 0; i < n; ++i)
+                            if (pool[ord[i]].score < b.score) break;
+                        for (int q = n; q > i; --q) ord[q] = ord[q - 1];
+                        ord[i] = n_pool;
+                    } else {                                  // mem_matesw_batch_post_ert: by end position
+                        bool resort = false;
+                        for (i = 0; i < n; ++i) {
+                            if (pool[ord[i]].re == b.re) { resort = true; break; }
+                            if (pool[ord[i]].re > b.re) break;
+                        }
+                        if (resort) {                         // "let the scores decide", then sort by end again
+                            list_sort(pool, ord, n, srt, 1);
+                            for (i = 0; i < n; ++i)
+                                if (pool[ord[i]].score < b.score) break;
+                        }
+                        for (int q = n; q > i; --q) ord[q] = ord[q - 1];
+                        ord[i] = n_pool;
+                        if (resort) list_sort(pool, ord, n + 1, srt, 0);
+                    }
                     ++n; ++n_pool;
                 }
                 ++cnt;
             }
-            if (cnt) n = list_sort_dedup(A, pool, ord, n, srt);
+            if (cnt) n = A.use_ert ? list_dedup(A, pool, ord, n) : list_sort_dedup(A, pool, ord, n, srt);
         }
         n_sw += cnt;
+        last_cnt = cnt;
+    }
+    if (A.use_ert && !A.no_rescue && !need_full) {
+        if (last_cnt) n = list_sort_dedup(A, pool, ord, n, srt);
+        else list_sort(pool, ord, n, srt, 1);
     }
     if (need_full) {
         if (A.pass == 0) { A.full[m] = 1; atomicAdd(&A.ctr->pair_full, 1ull); }
@@ -391,7 +428,8 @@ __global__ __launch_bounds__(64) void pair_post_kernel(PairArgs A) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= A.nseq) return;
     if (A.pass == 1 && !A.full[m]) return;                   // second pass: only the flagged reads
-    if (A.ooff[m + 1] - A.ooff[m] > kPostLight) { A.heavy[atomicAdd(&A.ctr->pair_heavy, 1ull)] = (int32_t)m; return; }
+    // (the ERT variant of the procedure exists in its one-lane form only)
+    if (!A.use_ert && A.ooff[m + 1] - A.ooff[m] > kPostLight) { A.heavy[atomicAdd(&A.ctr->pair_heavy, 1ull)] = (int32_t)m; return; }
     post_read_seq(A, m);
 }
 

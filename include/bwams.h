@@ -308,14 +308,18 @@ int bwams_pestat_from_keys(const uint64_t *keys, int64_t n, bwams_pestat_t pes[4
  *     scoring within pen_unpaired of an end's best hit, at most max_matesw; one window per orientation that is not
  *     failed and has no consistent hit yet), the batched ksw_align2 of mem_sam_pe_batch (:880-979), and
  *     mem_sam_pe_batch_post -> mem_matesw_batch_post (:981-1042, :1497-1601: insertion by score and
- *     mem_sort_dedup_patch(opt, 0, 0, 0, ..) after each alignment) — the non-ERT form;
+ *     mem_sort_dedup_patch(opt, 0, 0, 0, ..) after each alignment), or its useErt form (BWAMS_PAIR_USE_ERT);
  *   - mem_mark_primary_se (src/bwamem.cpp:1905-1980) of both ends with ids (id_base + p) << 1 | end;
  *   - mem_pair (src/bwamem_pair.cpp:366-427) when both ends have a primary hit.
  * pes[4] is mem_pestat's result (bwams_pestat) or the caller's (-I); id_base = n_processed >> 1 of the chunk.
- * no_rescue != 0 = MEM_F_NO_RESCUE.  bwams_pair_fetch returns the regions per read as mem_sam_pe_batch_post holds them
+ * flags: BWAMS_PAIR_* below.  bwams_pair_fetch returns the regions per read as mem_sam_pe_batch_post holds them
  * before its MAPQ / SAM part (grouped by read, reg_off[nseq + 1]) and one bwams_pair_t per pair.
  * The insert-size term of mem_pair is double arithmetic through log / erfc of the device math library. */
-int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t no_rescue,
+#define BWAMS_PAIR_NO_RESCUE 1   /* MEM_F_NO_RESCUE */
+#define BWAMS_PAIR_USE_ERT   2   /* mem_sam_pe_batch_post's useErt branch (ERT-mode runs): the mate's list is sorted by end
+                                  * position, rescue goes through mem_matesw_batch_post_ert (insertion by end, mem_dedup_patch),
+                                  * and one mem_sort_dedup_patch or score sort closes each end (src/bwamem_pair.cpp:1017-1041) */
+int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t flags,
                    int64_t *n_regs, int64_t *n_tasks);
 int bwams_pair_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, bwams_pair_t *pairs);
 /* the task lists as built (side 0 = left, 1 = right), for inspection */

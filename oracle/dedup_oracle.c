@@ -276,6 +276,56 @@ static int sort_dedup_patch(const bwams_mem_opt_t *opt, int64_t l_pac, const uin
     return m;
 }
 
+/* mem_dedup_patch (bwamem.cpp:262-312): the pairwise pass of mem_sort_dedup_patch on the list as it stands (the
+ * caller keeps it sorted by end), no sorting, no identical-hit pass */
+int orc_dedup_patch(const bwams_mem_opt_t *opt, int64_t l_pac, const uint8_t *ref_string, const uint8_t *query, int n,
+                    bwams_alnreg_t *a)
+{
+    int m, i, j;
+    if (n <= 1) return n;
+    for (i = 0; i < n; ++i) SET_N_COMP(a[i], 1);
+    for (i = 1; i < n; ++i) {
+        bwams_alnreg_t *p = &a[i];
+        if (p->rid != a[i - 1].rid || p->rb >= a[i - 1].re + opt->max_chain_gap) continue;
+        for (j = i - 1; j >= 0 && p->rid == a[j].rid && p->rb < a[j].re + opt->max_chain_gap; --j) {
+            bwams_alnreg_t *q = &a[j];
+            int64_t or_, oq, mr, mq;
+            int score, w;
+            if (q->qe == q->qb) continue;
+            or_ = q->re - p->rb;
+            oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+            mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+            mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+            if (or_ > opt->mask_level_redun * mr && oq > opt->mask_level_redun * mq) {
+                if (p->score < q->score) { p->qe = p->qb; break; }
+                else q->qe = q->qb;
+            } else if (q->rb < p->rb && (score = patch_reg(opt, l_pac, ref_string, query, q, p, &w)) > 0) {
+                SET_N_COMP(*p, N_COMP(*p) + N_COMP(*q) + 1);
+                p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+                p->sub = p->sub > q->sub ? p->sub : q->sub;
+                p->csub = p->csub > q->csub ? p->csub : q->csub;
+                p->qb = q->qb; p->rb = q->rb;
+                p->truesc = p->score = score;
+                p->w = w;
+                q->qb = q->qe;
+            }
+        }
+    }
+    for (i = 0, m = 0; i < n; ++i)
+        if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+    return m;
+}
+/* sort_alnreg_re / sort_alnreg_score (bwamem.cpp:188-194) */
+void orc_sort_alnreg(int n, bwams_alnreg_t *a, int by_score)
+{
+    if (n < 2) return;
+    int *ord = (int *)malloc((size_t)n * sizeof(int));
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    orc_idx_introsort((size_t)n, ord, by_score ? ars_lt : ars2_lt, a);
+    permute(a, n, ord);
+    free(ord);
+}
+
 /* mem_sort_dedup_patch for callers outside this file (pair_oracle.c: query = ref_string = NULL, no patching) */
 int orc_sort_dedup_patch(const bwams_mem_opt_t *opt, int64_t l_pac, const uint8_t *ref_string, const uint8_t *query, int n,
                          bwams_alnreg_t *a)

@@ -554,7 +554,7 @@ assert PAIR_DTYPE.itemsize == 32
 
 
 def pair_pe(regs, reg_off, enc, cum, ref_string, l_pac, pes, contigs=None, opt: MemOpt | None = None, id_base: int = 0,
-            no_rescue: bool = False):
+            no_rescue: bool = False, use_ert: bool = False):
     """Restated PE tail up to the pairing decision: mate rescue, mem_mark_primary_se, mem_pair
     -> (regs, reg_off, pairs).  Reads 2p, 2p + 1 are the ends of pair p."""
     opt = opt or default_mem_opt()
@@ -574,7 +574,7 @@ def pair_pe(regs, reg_off, enc, cum, ref_string, l_pac, pes, contigs=None, opt: 
     L = lib()
     L.orc_pair_pe.restype = C.c_int64
     n = L.orc_pair_pe(C.byref(opt), C.byref(bns), _p(ref_string), _p(enc), _p(cum), nseq // 2, _p(regs), _p(reg_off), _p(pes),
-                      C.c_int64(id_base), int(no_rescue), _p(out), C.c_int64(cap), _p(out_off), _p(pairs))
+                      C.c_int64(id_base), int(no_rescue) | (int(use_ert) << 1), _p(out), C.c_int64(cap), _p(out_off), _p(pairs))
     assert n >= 0, "orc_pair_pe: output capacity"
     return out[:n].copy(), out_off, pairs
 

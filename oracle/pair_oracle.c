@@ -80,11 +80,19 @@ static int fetch_window(const orc_bns_t *bns, int64_t *beg, int64_t mid, int64_t
     return rid;
 }
 
+int orc_dedup_patch(const bwams_mem_opt_t *opt, int64_t l_pac, const uint8_t *ref_string, const uint8_t *query, int n,
+                    bwams_alnreg_t *a);
+void orc_sort_alnreg(int n, bwams_alnreg_t *a, int by_score);
+
 int64_t orc_pair_sw_calls = 0;       /* diagnostic: ksw_align2 calls made by the rescue */
 
 /* mem_matesw_orig: rescue the mate ms of anchor a into the mate's region list ma (n regions, room for 4 more) */
+/* ert != 0: mem_matesw_batch_post_ert (bwamem_pair.cpp:1357-1495) — the list is kept sorted by END position: the
+ * rescued region goes in front of the first region ending later; if one ends exactly where it does the list is
+ * re-sorted by score, the region inserted by score, and everything sorted by end again; then mem_dedup_patch (no
+ * sorting) instead of mem_sort_dedup_patch. */
 static int matesw(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_t *ref_string, const bwams_pestat_t pes[4],
-                  const bwams_alnreg_t *a, int l_ms, const uint8_t *ms, bwams_alnreg_t *ma, int *ma_n)
+                  const bwams_alnreg_t *a, int l_ms, const uint8_t *ms, bwams_alnreg_t *ma, int *ma_n, int ert)
 {
     const int64_t l_pac = bns->l_pac;
     int i, r, skip[4], n = 0, rid = -1;
@@ -141,15 +149,36 @@ static int matesw(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_
                 b.secondary = -1;
                 b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
                 ++*ma_n;
-                for (i = 0; i < *ma_n - 1; ++i)
-                    if (ma[i].score < b.score) break;
-                tmp = i;
-                for (i = *ma_n - 1; i > tmp; --i) ma[i] = ma[i - 1];
-                ma[i] = b;
+                if (!ert) {
+                    for (i = 0; i < *ma_n - 1; ++i)
+                        if (ma[i].score < b.score) break;
+                    tmp = i;
+                    for (i = *ma_n - 1; i > tmp; --i) ma[i] = ma[i - 1];
+                    ma[i] = b;
+                } else {
+                    int resort = 0;
+                    for (i = 0; i < *ma_n - 1; ++i) {
+                        if (ma[i].re == b.re) { resort = 1; break; }
+                        if (ma[i].re > b.re) break;
+                    }
+                    if (resort) {
+                        orc_sort_alnreg(*ma_n - 1, ma, 1);
+                        for (i = 0; i < *ma_n - 1; ++i)
+                            if (ma[i].score < b.score) break;
+                        tmp = i;
+                        for (i = *ma_n - 1; i > tmp; --i) ma[i] = ma[i - 1];
+                        ma[i] = b;
+                        orc_sort_alnreg(*ma_n, ma, 0);
+                    } else {
+                        tmp = i;
+                        for (i = *ma_n - 1; i > tmp; --i) ma[i] = ma[i - 1];
+                        ma[i] = b;
+                    }
+                }
             }
             ++n;
         }
-        if (n) *ma_n = orc_sort_dedup_patch(opt, l_pac, 0, 0, *ma_n, ma);
+        if (n) *ma_n = ert ? orc_dedup_patch(opt, l_pac, 0, 0, *ma_n, ma) : orc_sort_dedup_patch(opt, l_pac, 0, 0, *ma_n, ma);
     }
     free(rev);
     return n;
@@ -304,9 +333,10 @@ static int pair(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const bwams_pe
  * regions per read afterwards.  id_base = n_processed >> 1 of the chunk.  Returns the region count, -1 on overflow. */
 int64_t orc_pair_pe(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_t *ref_string, const uint8_t *enc_qdb,
                     const int64_t *cum_len, int32_t n_pairs, const bwams_alnreg_t *regs, const int64_t *reg_off,
-                    const bwams_pestat_t pes[4], int64_t id_base, int no_rescue, bwams_alnreg_t *out, int64_t out_cap,
+                    const bwams_pestat_t pes[4], int64_t id_base, int flags, bwams_alnreg_t *out, int64_t out_cap,
                     int64_t *out_off, bwams_pair_t *pairs)
 {
+    const int no_rescue = flags & 1, use_ert = (flags >> 1) & 1;       /* MEM_F_NO_RESCUE; useErt */
     int64_t n_out = 0;
     for (int p = 0; p < n_pairs; ++p) {
         int n[2], nb[2], i, j;
@@ -331,12 +361,20 @@ int64_t orc_pair_pe(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint
         if (!no_rescue) {
             for (i = 0; i < 2; ++i)
                 for (j = 0; j < n[i]; ++j) a[i][j].flg = 0;           /* bwamem_pair.cpp:1011-1014 */
-            for (i = 0; i < 2; ++i)
+            for (i = 0; i < 2; ++i) {
+                int val = 0;
+                if (use_ert) orc_sort_alnreg(n[!i], a[!i], 0);                   /* bwamem_pair.cpp:1017-1018 */
                 for (j = 0; j < nb[i] && j < opt->max_matesw; ++j) {
                     const int64_t m = 2 * (int64_t)p + !i;
-                    pr->n_matesw += matesw(opt, bns, ref_string, pes, &b[i][j], (int)(cum_len[m + 1] - cum_len[m]),
-                                           enc_qdb + cum_len[m], a[!i], &n[!i]);
+                    val = matesw(opt, bns, ref_string, pes, &b[i][j], (int)(cum_len[m + 1] - cum_len[m]),
+                                 enc_qdb + cum_len[m], a[!i], &n[!i], use_ert);
+                    pr->n_matesw += val;
                 }
+                if (use_ert) {                                                    /* :1033-1041: the LAST anchor's return value decides */
+                    if (val) n[!i] = orc_sort_dedup_patch(opt, bns->l_pac, 0, 0, n[!i], a[!i]);
+                    else orc_sort_alnreg(n[!i], a[!i], 1);
+                }
+            }
         }
         const int64_t id = id_base + p;
         pr->n_pri[0] = orc_mark_primary_se(opt, n[0], a[0], id << 1 | 0);

@@ -34,7 +34,7 @@ def _gpu_final(ix, reads, gopt, contigs=None):
     return b, enc, cum
 
 
-def _compare(g, ix, reads, pes=None, contigs=None, id_base=0, no_rescue=False, **kw):
+def _compare(g, ix, reads, pes=None, contigs=None, id_base=0, no_rescue=False, use_ert=False, **kw):
     oopt, gopt = loader.default_mem_opt(), capi.default_mem_opt()
     for k, v in kw.items():
         setattr(oopt, k, v)
@@ -52,8 +52,8 @@ def _compare(g, ix, reads, pes=None, contigs=None, id_base=0, no_rescue=False, *
         assert np.array_equal(keys, np.sort(loader.pestat_keys(fin, fin_off, l_pac, opt=oopt)))
         assert np.array_equal(capi.pestat_from_keys(keys[::-1]), pes)
     want_regs, want_off, want_pairs = loader.pair_pe(fin, fin_off, enc, cum, ref, l_pac, pes, contigs=contigs, opt=oopt,
-                                                     id_base=id_base, no_rescue=no_rescue)
-    n, n_tasks = b.pair_run(pes, gopt, id_base=id_base, no_rescue=no_rescue)
+                                                     id_base=id_base, no_rescue=no_rescue, use_ert=use_ert)
+    n, n_tasks = b.pair_run(pes, gopt, id_base=id_base, no_rescue=no_rescue, use_ert=use_ert)
     regs, off, pairs = b.pair_fetch()
     assert n == len(want_regs) and np.array_equal(off, want_off)
     for f in ("score", "sub", "n_sub", "z", "n_pri", "n_matesw"):
@@ -142,3 +142,17 @@ def test_pair_with_alt_contigs(pe_toy):
         c = np.zeros(1, capi.CONTIG_DTYPE)
         c["len"] = l_pac
         ix.set_contigs(c)
+
+
+def test_pair_ert_variant(pe_toy):
+    """useErt: mem_matesw_batch_post_ert (list kept sorted by end, mem_dedup_patch, closing sort) — inferred statistics,
+    and caller-given ones with every orientation allowed (several alignments per anchor, end-position ties)."""
+    g, idx, ix = pe_toy
+    reads = simulate.make_read_pairs(g, 900, seed=12, damaged_frac=0.35, discordant_frac=0.15)
+    r = _compare(g, ix, reads, use_ert=True)
+    assert r["pairs"]["n_matesw"].sum() > 100
+    pes = np.zeros(4, capi.PESTAT_DTYPE)
+    pes["low"], pes["high"], pes["avg"], pes["std"] = 150, 700, 400.0, 45.0
+    r = _compare(g, ix, reads[:800], pes=pes, use_ert=True, id_base=77)
+    assert r["n_tasks"] > 500
+    _compare(g, ix, reads[:400], use_ert=True, no_rescue=True)

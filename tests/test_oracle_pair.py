@@ -85,3 +85,25 @@ def test_pair_scores_follow_the_insert_size_model():
         ns = (abs(fa - fb) - pes["avg"][1]) / pes["std"][1]
         q = int(int(a["score"]) + int(b["score"]) + .721 * math.log(2. * math.erfc(abs(ns) * math.sqrt(.5))) + .499)
         assert pairs["score"][p] == max(q, 0)
+
+
+def test_ert_variant_of_mate_rescue():
+    """useErt routes mate rescue through mem_matesw_batch_post_ert (list kept sorted by end, mem_dedup_patch after each
+    alignment, one mem_sort_dedup_patch or score sort at the end).  Without a rescue the detour through the end-sorted
+    order changes nothing (the final score sort is total once identical hits are gone); with one, the surviving regions
+    are the same set in almost every pair (the reference's own runs differ in 1 pair of 5000, SURVEY §8c addendum)."""
+    g, idx, reads, c = _chunk(400, seed=5)
+    args = (c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], c["pes"])
+    out0, off0, pr0 = loader.pair_pe(*args)
+    out1, off1, pr1 = loader.pair_pe(*args, use_ert=True)
+    assert np.array_equal(pr0["n_matesw"], pr1["n_matesw"]) and pr1["n_matesw"].sum() > 20
+    same = 0
+    for p in range(len(pr0)):
+        a0, a1 = out0[off0[2 * p]:off0[2 * p + 2]], out1[off1[2 * p]:off1[2 * p + 2]]
+        if pr0["n_matesw"][p] == 0:
+            assert np.array_equal(a0, a1) and np.array_equal(pr0[p], pr1[p]), p
+        k0 = sorted(zip(a0["rb"].tolist(), a0["re"].tolist(), a0["qb"].tolist(), a0["qe"].tolist(), a0["score"].tolist()))
+        k1 = sorted(zip(a1["rb"].tolist(), a1["re"].tolist(), a1["qb"].tolist(), a1["qe"].tolist(), a1["score"].tolist()))
+        same += k0 == k1
+    assert same >= len(pr0) - 4
+    assert (pr1["score"] > 0).sum() >= (pr0["score"] > 0).sum() - 2

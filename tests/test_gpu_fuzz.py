@@ -1,0 +1,116 @@
+"""Differential test over random configurations: genome shape, read lengths and error rates, scoring and heuristic
+options — the whole path (seeding .. de-duplication, then the paired-end tail) on the GPU against the oracle, bit for
+bit.  Small inputs, many configurations: what the fixed-option parity tests cannot reach."""
+import os
+
+import numpy as np
+import pytest
+
+from bwams import capi, fmindex, simulate
+from oracle import loader
+
+pytestmark = pytest.mark.gpu
+
+REG_F = ("rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary",
+         "secondary_all", "seedlen0", "n_comp_is_alt", "frac_rep", "hash")
+
+
+def _config(seed):
+    rng = np.random.default_rng(seed)
+    a = int(rng.choice([1, 1, 2, 3]))
+    b = int(rng.choice([2, 4, 4, 6]))
+    kw = dict(
+        a=a, o_del=int(rng.choice([4, 6, 8])), e_del=int(rng.choice([1, 2])), o_ins=int(rng.choice([4, 6, 7])),
+        e_ins=int(rng.choice([1, 2])), pen_clip5=int(rng.choice([0, 5, 9])), pen_clip3=int(rng.choice([0, 5, 7])),
+        w=int(rng.choice([8, 30, 100])), zdrop=int(rng.choice([20, 100, 300])),
+        min_seed_len=int(rng.choice([15, 19, 19, 25])), min_chain_weight=int(rng.choice([0, 0, 30])),
+        max_occ=int(rng.choice([20, 100, 500])), max_chain_gap=int(rng.choice([200, 10000])),
+        mask_level=float(rng.choice([0.3, 0.5, 0.7])), drop_ratio=float(rng.choice([0.3, 0.5, 0.8])),
+        mask_level_redun=float(rng.choice([0.8, 0.95])), pen_unpaired=int(rng.choice([5, 17, 40])),
+        max_matesw=int(rng.choice([2, 10, 50])), max_ins=int(rng.choice([600, 10000])),
+    )
+    shape = dict(genome=int(rng.choice([20000, 60000, 150000])), repeat_frac=float(rng.choice([0.05, 0.3, 0.5])),
+                 repeat_len=int(rng.choice([60, 250, 700])), n_families=int(rng.choice([1, 3, 6])),
+                 read_len=int(rng.choice([60, 100, 151, 250])), n_pairs=int(rng.choice([150, 300])),
+                 insert=float(rng.choice([260.0, 420.0])), damaged=float(rng.choice([0.1, 0.4])),
+                 n_contigs=int(rng.choice([1, 1, 3])))
+    return kw, b, shape
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("BWAMS_FUZZ_N", "48")))))
+def test_random_configuration(seed):
+    kw, bmis, sh = _config(1000 + seed)
+    capi.lib()
+    L = sh["read_len"]
+    g = simulate.make_genome(sh["genome"], seed=seed, repeat_frac=sh["repeat_frac"], repeat_len=sh["repeat_len"],
+                             n_families=sh["n_families"])
+    idx = fmindex.build_fmindex(g)
+    ix = capi.Index.from_host(idx, 0)
+    l_pac = len(g)
+    contigs = None
+    if sh["n_contigs"] == 3:
+        contigs = np.zeros(3, capi.CONTIG_DTYPE)
+        c1, c2 = l_pac // 3, 2 * l_pac // 3
+        contigs["offset"] = [0, c1, c2]
+        contigs["len"] = [c1, c2 - c1, l_pac - c2]
+        contigs["is_alt"] = [0, 1, 0]
+        ix.set_contigs(contigs)
+    reads = simulate.make_read_pairs(g, sh["n_pairs"], seed=seed + 50, read_len=L, insert_mean=max(sh["insert"], L + 40.0),
+                                     insert_sd=25.0, damaged_frac=sh["damaged"], discordant_frac=0.08)
+    rng = np.random.default_rng(seed)
+    for r in reads[::17]:                                      # a few Ns
+        r[rng.integers(0, L)] = 4
+    enc, cum = simulate.flatten_reads(reads)
+    oopt, gopt = loader.default_mem_opt(kw["a"], bmis), capi.default_mem_opt(kw["a"], bmis)
+    for k, v in kw.items():
+        setattr(oopt, k, v)
+        setattr(gopt, k, v)
+    so, sg = loader.default_seed_opt(), capi.default_seed_opt()
+    so.max_occ = sg.max_occ = kw["max_occ"]
+    so.min_seed_len = sg.min_seed_len = kw["min_seed_len"]
+    ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    # oracle
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum, so)
+    coord, off = o.sa_lookup(sm, so.max_occ)
+    wch, wsd, wchoff = loader.chain_seeds(sm, coord, off, cum, l_pac, contigs=contigs, opt=oopt, ref_string=ref, enc=enc)
+    wregs, wreg_off, _ = loader.chain2aln(wch, wsd, wchoff, enc, cum, ref, l_pac, contigs=contigs, opt=oopt)
+    wfin, wfin_off = loader.regs_finish(wregs, wreg_off, enc, cum, ref, l_pac, contigs=contigs, opt=oopt)
+    wpes = loader.pestat(wfin, wfin_off, l_pac, opt=oopt)
+    # device
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.seed_run(sg, with_sa=True)
+    gsm, gcoord, goff = b.seed_fetch()
+    assert len(gsm) == len(sm) and np.array_equal(gcoord, coord) and np.array_equal(goff, off)
+    b.chain_run(gopt)
+    ch, sd, choff = b.chain_fetch()
+    assert np.array_equal(choff, wchoff)
+    for f in ("n", "rid", "w_kept_alt", "frac_rep", "pos", "first"):
+        assert np.array_equal(ch[f], wch[f]), f
+    b.extend_run(gopt)
+    regs, reg_off, _ = b.extend_fetch()
+    assert np.array_equal(reg_off, wreg_off)
+    purged = (wregs["qb"] == -1) & (wregs["qe"] == -1)
+    assert np.array_equal((regs["qb"] == -1) & (regs["qe"] == -1), purged)
+    for f in ("rb", "re", "qb", "qe", "score", "truesc", "w", "seedcov"):
+        assert np.array_equal(regs[f][~purged], wregs[f][~purged]), f
+    assert b.dedup_run(gopt) == len(wfin)
+    fin, fin_off = b.dedup_fetch()
+    assert np.array_equal(fin_off, wfin_off)
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "n_comp_is_alt", "sub", "csub"):
+        assert np.array_equal(fin[f], wfin[f]), f
+    pes = b.pestat(gopt)
+    assert np.array_equal(pes, wpes)
+    if L <= 512 and all(p["failed"] or p["high"] - p["low"] + L <= 20000 for p in pes):
+        for use_ert in (False, True):
+            wout, wout_off, wpairs = loader.pair_pe(wfin, wfin_off, enc, cum, ref, l_pac, wpes, contigs=contigs, opt=oopt,
+                                                    id_base=seed * 1000, use_ert=use_ert)
+            n, _ = b.pair_run(pes, gopt, id_base=seed * 1000, use_ert=use_ert)
+            out, out_off, pairs = b.pair_fetch()
+            assert n == len(wout) and np.array_equal(out_off, wout_off), use_ert
+            assert np.array_equal(pairs, wpairs), use_ert
+            for f in REG_F:
+                assert np.array_equal(out[f], wout[f]), (use_ert, f)
+    b.close()
+    ix.close()

@@ -68,6 +68,9 @@ def test_random_configuration(seed):
     so, sg = loader.default_seed_opt(), capi.default_seed_opt()
     so.max_occ = sg.max_occ = kw["max_occ"]
     so.min_seed_len = sg.min_seed_len = kw["min_seed_len"]
+    so.split_factor = sg.split_factor = float(rng.choice([1.2, 1.5, 2.0]))
+    so.split_width = sg.split_width = int(rng.choice([2, 10, 40]))
+    so.max_mem_intv = sg.max_mem_intv = int(rng.choice([0, 20, 50]))
     ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
     # oracle
     o = loader.OracleFMI(idx)
@@ -112,5 +115,17 @@ def test_random_configuration(seed):
             assert np.array_equal(pairs, wpairs), use_ert
             for f in REG_F:
                 assert np.array_equal(out[f], wout[f]), (use_ert, f)
+    # ERT mode's way into chaining, fed the same seeds dressed up as an ERT walk's output
+    from util import ert_mems_from_smems
+    all_coord, all_off = o.sa_lookup(sm, 1 << 30)
+    mems, mem_off, hits, hit_off = ert_mems_from_smems(sm, all_coord, all_off, len(reads), l_pac, seed=seed, dup_frac=0.05)
+    wech = loader.chain_new_ert(mems, mem_off, hits, hit_off, cum, l_pac, contigs=contigs, opt=oopt, ref_string=ref, enc=enc)
+    b.chain_run_ert(mems, mem_off, hits, hit_off, gopt)
+    ech, esd, echoff = b.chain_fetch()
+    assert np.array_equal(echoff, wech[2])
+    for f in ("n", "rid", "w_kept_alt", "frac_rep", "pos", "first"):
+        assert np.array_equal(ech[f], wech[0][f]), f
+    for f in ("rbeg", "qbeg", "len", "score"):
+        assert np.array_equal(esd[f], wech[1][f]), f
     b.close()
     ix.close()

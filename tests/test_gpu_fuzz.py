@@ -31,7 +31,9 @@ def _config(seed):
     )
     shape = dict(genome=int(rng.choice([20000, 60000, 150000])), repeat_frac=float(rng.choice([0.05, 0.3, 0.5])),
                  repeat_len=int(rng.choice([60, 250, 700])), n_families=int(rng.choice([1, 3, 6])),
-                 read_len=int(rng.choice([60, 100, 151, 250])), n_pairs=int(rng.choice([150, 300])),
+                 read_len=int(rng.choice([60, 100, 151, 250, 250, 1300])), n_pairs=int(rng.choice([150, 300])),
+                 fma=(int(rng.integers(4, 9)), int(rng.integers(5, 10))) if rng.random() < 0.35 else None,
+                 extend_all=int(rng.random() < 0.3),
                  insert=float(rng.choice([260.0, 420.0])), damaged=float(rng.choice([0.1, 0.4])),
                  n_contigs=int(rng.choice([1, 1, 3])))
     return kw, b, shape
@@ -55,6 +57,8 @@ def test_random_configuration(seed):
         contigs["len"] = [c1, c2 - c1, l_pac - c2]
         contigs["is_alt"] = [0, 1, 0]
         ix.set_contigs(contigs)
+    if L > 1000:
+        sh["n_pairs"] = 40                                     # long reads: mem_flt_chained_seeds re-scores short seeds
     reads = simulate.make_read_pairs(g, sh["n_pairs"], seed=seed + 50, read_len=L, insert_mean=max(sh["insert"], L + 40.0),
                                      insert_sd=25.0, damaged_frac=sh["damaged"], discordant_frac=0.08)
     rng = np.random.default_rng(seed)
@@ -72,8 +76,12 @@ def test_random_configuration(seed):
     so.split_width = sg.split_width = int(rng.choice([2, 10, 40]))
     so.max_mem_intv = sg.max_mem_intv = int(rng.choice([0, 20, 50]))
     ref = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    oopt.extend_all = gopt.extend_all = sh["extend_all"]
     # oracle
     o = loader.OracleFMI(idx)
+    if sh["fma"]:                                              # FMA tables at random (shallow) depths, built on both sides
+        o.build_fma(*sh["fma"])
+        ix.build_fma(*sh["fma"])
     sm = o.collect_smem(enc, cum, so)
     coord, off = o.sa_lookup(sm, so.max_occ)
     wch, wsd, wchoff = loader.chain_seeds(sm, coord, off, cum, l_pac, contigs=contigs, opt=oopt, ref_string=ref, enc=enc)
@@ -96,8 +104,9 @@ def test_random_configuration(seed):
     assert np.array_equal(reg_off, wreg_off)
     purged = (wregs["qb"] == -1) & (wregs["qe"] == -1)
     assert np.array_equal((regs["qb"] == -1) & (regs["qe"] == -1), purged)
+    keep = slice(None) if sh["extend_all"] else ~purged
     for f in ("rb", "re", "qb", "qe", "score", "truesc", "w", "seedcov"):
-        assert np.array_equal(regs[f][~purged], wregs[f][~purged]), f
+        assert np.array_equal(regs[f][keep], wregs[f][keep]), f
     assert b.dedup_run(gopt) == len(wfin)
     fin, fin_off = b.dedup_fetch()
     assert np.array_equal(fin_off, wfin_off)

@@ -119,7 +119,7 @@ Round-1 search kernel per launch: algorithmic bytes {alg/1e9:.2f} GB; corrected 
 
 ## Smith-Waterman kernels alone, against the real reference objects on the host cores
 
-`python tools/bench_sw.py` (profiles/{rnd}_sw_kernels.jsonl): the CPU column is `BandedPairWiseSW::getScores16` (AVX512) and
+`python tests/bench_sw_kernels.py` (profiles/{rnd}_sw_kernels.jsonl): the CPU column is `BandedPairWiseSW::getScores16` (AVX512) and
 `ksw_align2` (SSE2) of `oracle/_ref` — the reference's own code compiled from its tree — on the same tasks, 16 threads.
 
 ```

@@ -3,7 +3,7 @@
 (oracle/_ref: bandedSWA.cpp / ksw.cpp compiled from the reference tree) timed beside them on the
 host cores as cpu_baseline kind "reference".  Prints one JSON line per kernel.
 
-    python tools/bench_sw.py [--tasks 400000]
+    python tests/bench_sw_kernels.py [--tasks 400000]
 """
 import argparse
 import json

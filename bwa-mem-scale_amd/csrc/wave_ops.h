@@ -10,15 +10,25 @@ template <int CTRL, int RM, int BM>
 __device__ __forceinline__ int dppi(int old, int v) {
     return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, BM, false);
 }
-// inclusive prefix max over the 64 lanes (6 DPP steps)
+// inclusive prefix max over the 64 lanes: six v_max_i32 with a DPP-permuted first operand, in place.  Written as
+// assembly because the compiler expands `max(v, update_dpp(v, v, ..))` into v_mov + v_mov_dpp + v_max (three VALU
+// instructions and a wait state per step) instead of the fused form; lanes without a valid source (or outside
+// row_mask) are not written, i.e. keep their own value, so no identity constant is needed.  A VALU write followed
+// by a DPP read of the same register needs two wait states: the s_nop 1 in front of every step.
 __device__ __forceinline__ int scan_max(int v) {
-    // lanes without a valid source keep `old` = their own value, so no identity constant is needed
-    v = max(v, dppi<0x111, 0xF, 0xF>(v, v));     // row_shr:1
-    v = max(v, dppi<0x112, 0xF, 0xF>(v, v));     // row_shr:2
-    v = max(v, dppi<0x114, 0xF, 0xF>(v, v));     // row_shr:4
-    v = max(v, dppi<0x118, 0xF, 0xF>(v, v));     // row_shr:8
-    v = max(v, dppi<0x142, 0xA, 0xF>(v, v));     // row_bcast:15 into rows 1 and 3
-    v = max(v, dppi<0x143, 0xC, 0xF>(v, v));     // row_bcast:31 into rows 2 and 3
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
     return v;
 }
 __device__ __forceinline__ int lane_shr1(int v, int fill) { return dppi<0x138, 0xF, 0xF>(fill, v); }   // wave_shr:1

@@ -253,7 +253,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
         const uint8_t *tq = qer + __builtin_amdgcn_readfirstlane(pairs[cur].idq);
         const uint8_t *tr = ref + __builtin_amdgcn_readfirstlane(pairs[cur].idr);
 
-        int H[NCH], E[NCH], JE[NCH], P0[NCH], P1[NCH], P2[NCH], P3[NCH], P4[NCH];
+        // query profile: the scores of column j against target bases 0..3 packed as four int8 (one v_bfe_i32 per cell
+        // instead of a select tree), against N separately
+        int H[NCH], E[NCH], JE[NCH], PK[NCH], P4[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int j = c * 64 + lane;
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
             E[c] = 0;
             JE[c] = j * e_ins;
             const int qj = j < qlen ? tq[j] : 4;
-            P0[c] = prm.mat[0 * 5 + qj]; P1[c] = prm.mat[1 * 5 + qj]; P2[c] = prm.mat[2 * 5 + qj];
-            P3[c] = prm.mat[3 * 5 + qj]; P4[c] = prm.mat[4 * 5 + qj];
+            PK[c] = (int)(((uint32_t)(uint8_t)prm.mat[0 * 5 + qj]) | ((uint32_t)(uint8_t)prm.mat[1 * 5 + qj] << 8) |
+                          ((uint32_t)(uint8_t)prm.mat[2 * 5 + qj] << 16) | ((uint32_t)(uint8_t)prm.mat[3 * 5 + qj] << 24));
+            P4[c] = prm.mat[4 * 5 + qj];
         }
         int w = w0;
         {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
                         if (c < c_lo || c > c_hi) continue;
                         const int j = (c << 6) + lane;
                         const bool act = j >= beg && j < end;
-                        const int S = tb == 0 ? P0[c] : tb == 1 ? P1[c] : tb == 2 ? P2[c] : tb == 3 ? P3[c] : P4[c];
+                        const int S = tb < 4 ? __builtin_amdgcn_sbfe(PK[c], (unsigned)(tb << 3), 8u) : P4[c];
                         const int hd = H[c];
                         const int M = (act && hd) ? hd + S : 0;
                         int tj = M - oe_ins;

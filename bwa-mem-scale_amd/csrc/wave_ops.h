@@ -16,7 +16,7 @@ __device__ __forceinline__ int dppi(int old, int v) {
 // row_mask) are not written, i.e. keep their own value, so no identity constant is needed.  A VALU write followed
 // by a DPP read of the same register needs two wait states: the s_nop 1 in front of every step.
 __device__ __forceinline__ int scan_max(int v) {
-    asm("s_nop 1\n\t"
+    asm("s_nop 4\n\t"         // also covers "VALU writes EXEC, then a DPP instruction" (5 wait states): the compiler cannot see into the asm
         "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"

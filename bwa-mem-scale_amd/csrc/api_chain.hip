@@ -36,7 +36,7 @@ struct ChainState {
     // chaining scratch (per SA hit)
     DevBuf s_next, s_ql, crec, flt, f_rec, f_first, f_kept, f_sel, nodes;
     // per read
-    DevBuf n_kept, n_kept_seeds, n_chn, heavy, read_base, frac, wide, chain_off, slice, okeys, okeys2, ovals, ovals2;
+    DevBuf n_kept, n_kept_seeds, n_chn, heavy, redo, read_base, frac, wide, chain_off, slice, okeys, okeys2, ovals, ovals2;
     // results
     DevBuf chains, seeds, seeds2;
     DevBuf sw_qb, sw_rb, sw_read, sw_newn, sw_res;      // mem_flt_chained_seeds (long reads)
@@ -71,7 +71,7 @@ struct ChainState {
 void chain_state_free(ChainState *s) {
     if (!s) return;
     DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
-                     &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
+                     &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->redo, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
                      &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->pr_na, &s->pr_wide, &s->pr_offs, &s->pr_anchor, &s->pr_slot, &s->pr_task, &s->pr_trb, &s->pr_tl1, &s->pr_twide, &s->pr_toffs,
                      &s->pr_pairs, &s->pr_tref, &s->pr_tqer, &s->pr_aln, &s->pr_pool, &s->pr_ord, &s->pr_srt, &s->pr_z, &s->pr_nfin, &s->pr_npri, &s->pr_nsw, &s->pr_full, &s->pr_owide,
@@ -360,6 +360,7 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
     BWAMS_HIP(s->flt.ensure(ns * 8));     BWAMS_HIP(s->f_rec.ensure(ns * 16));
     BWAMS_HIP(s->f_first.ensure(ns * 4)); BWAMS_HIP(s->f_kept.ensure(ns * 4)); BWAMS_HIP(s->f_sel.ensure(ns * 4));
     BWAMS_HIP(s->n_chn.ensure((size_t)n1 * 4));       BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->redo.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->slice.ensure((size_t)n1 * 16));
     BWAMS_HIP(s->okeys.ensure((size_t)n1 * 4));       BWAMS_HIP(s->okeys2.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->ovals.ensure((size_t)n1 * 4));       BWAMS_HIP(s->ovals2.ensure((size_t)n1 * 4));
@@ -378,12 +379,13 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
     A.flt = s->flt.as<uint2>(); A.f_rec = s->f_rec.as<uint4>(); A.f_first = s->f_first.as<int32_t>();
     A.f_kept = s->f_kept.as<int32_t>(); A.f_sel = s->f_sel.as<int32_t>(); A.nodes = s->nodes.p;
     A.n_kept = s->n_kept.as<int32_t>(); A.n_kept_seeds = s->n_kept_seeds.as<int32_t>();
-    A.n_chn = s->n_chn.as<int32_t>(); A.heavy = s->heavy.as<int32_t>();
+    A.n_chn = s->n_chn.as<int32_t>(); A.heavy = s->heavy.as<int32_t>(); A.redo = s->redo.as<int32_t>();
     A.slice = s->slice.as<int64_t>(); A.order = s->ovals2.as<uint32_t>();
     A.read_base = s->read_base.as<int64_t>(); A.frac_rep = s->frac.as<float>();
     A.ctr = b->d_ctr;
 
     BWAMS_HIP(hipEventRecord(s->ev[0], st));
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_redo, 0, 2 * sizeof(unsigned long long), st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 16 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[6], chain_ticket[6], heavy_ticket
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all

@@ -61,8 +61,9 @@ static_assert(sizeof(ChainRec) == 48, "chain record layout");
 // LDS bytes a wave needs to chain a read of at most K seeds: K chain records + the B-tree's nodes
 // (every node but the root holds >= t - 1 = 4 keys: at most 5K/16 + 3 nodes)
 __host__ __device__ constexpr int lds_nodes(int K) { return (K * 5) / 16 + 3; }
-__host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * sizeof(ChainRec) + (size_t)lds_nodes(K) * sizeof(Node); }
-constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL1 = 850, kClassL = 1700;      // seeds per read: 12, 24, 48, 79, 159 KB of LDS
+// (the wave tiers keep an ordered array of (position, chain id) instead: 12 B per chain)
+__host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * (sizeof(ChainRec) + 12) + 64; }
+constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL1 = 850, kClassL = 1700;      // seeds per read: 7.7, 15, 31, 51, 102 KB of LDS
 static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
 
 // bns_pos2rid / bns_intv2rid (bntseq.cpp:397-421) with a one-entry cache of the last sequence found
@@ -508,8 +509,39 @@ __global__ void chain_count_kernel(ChainArgs A, uint32_t *keys, uint32_t *vals) 
 // LDS = true: nodes / crec_w point into LDS and every access through them must stay a ds_* instruction
 // (a flat access would wait on vmcnt, i.e. on the round trip of every global store issued before it),
 // so the pointers are never mixed with HBM pointers in this instantiation.
-template <bool LDS>
-__device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int lane, int nl, Node *nodes, int32_t cap_nodes,
+// ---- an ordered array instead of the B-tree (wave tiers) ---------------------------------------------------------
+// While every chain position of a read is distinct, kbtree answers kb_intervalp with THE greatest key <= k and
+// traverses in key order whatever its shape: a sorted array in LDS gives the same answers with two ballots per
+// lookup (which 64-key chunk, which key in it) and a lane-parallel shift per insertion, in 12 B per chain instead of
+// the nodes' ~45.  Equal positions are where the tree's shape starts to matter (which of the equal keys a lookup
+// meets, where a duplicate lands): inserting a position that is already present makes the attempt give up, and the
+// read is chained again with the B-tree (chain_redo_kernel).
+__device__ __forceinline__ int sarr_lower(const int64_t *key, int n, int64_t k, int lane, bool &eq) {
+    const int nch = (n + 63) >> 6;
+    const unsigned long long mc = __ballot(lane < nch && key[lane << 6] <= k);      // chunks whose first key is <= k
+    if (!mc) { eq = false; return -1; }
+    const int c = __popcll(mc) - 1;
+    const int i = (c << 6) + lane;
+    const int64_t my = i < n ? key[i] : 0;
+    const unsigned long long mk = __ballot(i < n && my <= k);
+    const int idx = (c << 6) + __popcll(mk) - 1;
+    eq = __ballot(i < n && my == k) != 0;
+    return idx;
+}
+__device__ __forceinline__ void sarr_insert(int64_t *key, int32_t *cid, int n, int at, int64_t k, int32_t id, int lane) {
+    for (int base = ((n - at) >> 6) << 6; base >= 0; base -= 64) {                  // move [at, n) up by one, top chunk first
+        const int i = at + base + lane;
+        const bool mv = i < n;
+        const int64_t kk = mv ? key[i] : 0;
+        const int32_t cc = mv ? cid[i] : 0;
+        if (mv) { key[i + 1] = kk; cid[i + 1] = cc; }
+    }
+    if (lane == 0) { key[at] = k; cid[at] = id; }
+}
+
+// CONT = 0: kbtree (exact for any input); CONT = 1: sorted array, returns false when the read needs the B-tree
+template <bool LDS, int CONT = 0>
+__device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int lane, int nl, Node *nodes, int32_t cap_nodes,
                                            ChainRec *crec_w, int32_t cap_chains) {
     const bool wr = lane == 0;
     if (wr) {
@@ -521,7 +553,7 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
     const bwams_smem_t *sm = A.smem;
     const int64_t beg = A.slice[2 * r], end = A.slice[2 * r + 1];
     const int L = (int)(A.cum[r + 1] - A.cum[r]);
-    if (beg == end || L < A.opt.min_seed_len) return;
+    if (beg == end || L < A.opt.min_seed_len) return true;
 
     // frac_rep: query span covered by over-frequent SMEMs
     int b = 0, e = 0, l_rep = 0;
@@ -537,7 +569,7 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
     const int64_t base = A.sa_off[beg];
     const int32_t cnt = (int32_t)(A.sa_off[end] - base);
     if (wr) A.read_base[r] = base;
-    if (cnt == 0) return;
+    if (cnt == 0) return true;
     const int64_t *pos = A.sa_coord + base;
     int32_t *s_next = A.s_next + base;
     int2 *s_ql = A.s_ql + base;
@@ -555,10 +587,15 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
     }
     c.crec = crec;
     c.n_nodes = 0; c.n_keys = 0; c.overflow = false; c.wr = wr;
-    c.root = new_node(c);
+    int64_t *s_key = nullptr;            // CONT = 1: the ordered array lives where the nodes would
+    int32_t *s_cid = nullptr;
+    if constexpr (CONT == 1) {
+        s_key = reinterpret_cast<int64_t *>(nodes);
+        s_cid = reinterpret_cast<int32_t *>(s_key + cap_chains);
+    } else c.root = new_node(c);
     RidCache rc;
     rc.lo = 0; rc.hi = -1; rc.rid = 0;
-    if (LDS && cnt > cap_chains) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return; }
+    if (LDS && cnt > cap_chains) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return true; }
 
     const int64_t l_pac = A.bns.l_pac;
     for (int64_t i = beg; i < end; ++i) {
@@ -583,7 +620,13 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
             if (c.n_keys) {
                 int64_t fr = 0;
                 int32_t lower;
-                if constexpr (LDS) lower = wkbt_lower(c, rbeg, lane, fr, path);
+                if constexpr (CONT == 1) {
+                    bool eq;
+                    const int idx = sarr_lower(s_key, c.n_keys, rbeg, lane, eq);
+                    lower = -1;
+                    if (idx >= 0) { lower = s_cid[idx]; fr = s_key[idx]; }
+                    path.slot = (int16_t)0; path.leaf = idx; path.ok = !eq;          // leaf: where the key would go - 1; ok: not present yet
+                } else if constexpr (LDS) lower = wkbt_lower(c, rbeg, lane, fr, path);
                 else lower = kbt_lower(c, rbeg, fr);
                 if (lower >= 0) {                                        // test_and_merge
                     ChainRec ch = crec[lower];
@@ -621,19 +664,28 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
                 ch.rid = rid; ch.n = 1; ch.first_idx = g; ch.last_idx = g; ch.wq = slen; ch.wr = slen;
                 const int32_t cid = c.n_keys;                            // chains are numbered in creation order
                 if (wr) crec[cid] = ch;
-                if constexpr (LDS) {
+                if constexpr (CONT == 1) {
+                    if (c.n_keys && !path.ok) return false;                          // a second chain at this position: the B-tree decides
+                    sarr_insert(s_key, s_cid, c.n_keys, c.n_keys ? path.leaf + 1 : 0, rbeg, cid, lane);
+                    ++c.n_keys;
+                } else if constexpr (LDS) {
                     if (path.ok) { ++c.n_keys; wleaf_insert(c, &c.nodes[path.leaf], path.slot, path.n, cid, rbeg, lane); }
                     else wkbt_put(c, cid, rbeg, lane);
                 } else kbt_put(c, cid, rbeg);
-                if (c.overflow) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return; }
+                if (c.overflow) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return true; }
             }
         }
     }
-    if (c.n_keys == 0) return;
+    if (c.n_keys == 0) return true;
 
     // chains in B-tree order, their weights, the weight floor
     int32_t *ord = A.f_first + base;
-    const int32_t n_trav = kbt_traverse(c, ord);
+    int32_t n_trav;
+    if constexpr (CONT == 1) {
+        n_trav = c.n_keys;
+        for (int32_t t = lane; t < n_trav; t += nl) ord[t] = s_cid[t];
+        __threadfence_block();                                                       // ord is read back by every lane below
+    } else n_trav = kbt_traverse(c, ord);
     uint2 *fl = A.flt + base;
     int n_chn = 0;
     for (int32_t t = 0; t < n_trav; ++t) {
@@ -649,12 +701,12 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
     if (n_chn == 0) n_chn = 1;                  // the reference keeps a_[0] in that case (bwamem.cpp:549-572)
     if constexpr (LDS)                          // chain records out of LDS, for the filter and the emit stages
         for (int32_t k = lane; k < c.n_keys; k += nl) crec_g[k] = crec_w[k];
-    if (!wr) return;
+    if (!wr) return true;
     A.n_chn[r] = n_chn;
     if (n_chn > kLightChains) {                 // sort + filter by a whole wave (chain_heavy_kernel)
         const unsigned long long slot = atomicAdd(&A.ctr->n_heavy, 1ull);
         A.heavy[slot] = (int32_t)r;
-        return;
+        return true;
     }
     flt_introsort(fl, n_chn);
     uint4 *rec = A.f_rec + base;
@@ -666,6 +718,7 @@ __device__ __forceinline__ void chain_read(const ChainArgs &A, int64_t r, int la
     filter_seq(A.opt, n_chn, rec, kept, A.f_sel + base);
     if constexpr (LDS) __threadfence_block();   // crec_g was written by the other lanes just above
     finish_read(A, r, base, n_chn, L);
+    return true;
 }
 
 // reads with few seeds: one lane per read, state in HBM scratch
@@ -690,9 +743,22 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(ChainArgs A, const unsig
         const unsigned long long t = wave_ticket(ticket, 1ull);
         if (lo + (int64_t)t >= hi) break;
         const int64_t r = (int64_t)A.order[lo + (int64_t)t];
-        if (K) chain_read<true>(A, r, lane, 64, l_nodes, lds_nodes(K), l_crec, K);
-        else chain_read<false>(A, r, lane, 64, nullptr, 0, nullptr, 0);
+        if (K) {
+            if (!chain_read<true, 1>(A, r, lane, 64, l_nodes, 0, l_crec, K) && lane == 0)
+                A.redo[atomicAdd(&A.ctr->chain_redo, 1ull)] = (int32_t)r;
+        } else chain_read<false>(A, r, lane, 64, nullptr, 0, nullptr, 0);
         __syncthreads();
+    }
+}
+
+// reads whose chain positions repeat: again, with the B-tree (state in HBM scratch, wave per read)
+__global__ __launch_bounds__(64) void chain_redo_kernel(ChainArgs A) {
+    const int lane = threadIdx.x;
+    const int64_t n = (int64_t)A.ctr->chain_redo;
+    for (;;) {
+        const int64_t t = (int64_t)wave_ticket(&A.ctr->chain_redo_ticket, 1ull);
+        if (t >= n) break;
+        chain_read<false>(A, A.redo[t], lane, 64, nullptr, 0, nullptr, 0);
     }
 }
 
@@ -913,6 +979,7 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;
     }
+    chain_redo_kernel<<<(unsigned)(cu_count * 2), 64, 0, st>>>(A);
     chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, 0, st>>>(A, &A.ctr->n_heavy);
     return 0;
 }

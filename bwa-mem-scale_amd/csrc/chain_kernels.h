@@ -40,6 +40,7 @@ struct ChainArgs {
     int64_t *slice;                // 2 per read: its [beg, end) in smem
     const uint32_t *order;         // read ids by descending seed count
     float *frac_rep;
+    int32_t *redo;                 // reads to chain again with the B-tree (a chain position repeated)
     DevCounters *ctr;
 };
 

@@ -53,7 +53,7 @@ struct ChainState {
     bool er_done = false;
     int64_t n_final = 0;
     bool dedup_done = false;
-    int64_t n_chains = 0, n_seeds = 0, nseq = 0;
+    int64_t n_chains = 0, n_seeds = 0, nseq = 0, n_chain_redo = 0;
     bool chain_done = false;
     // extension
     DevBuf regs, srt, rmax, cnt, ewide, eoffs, state, kreg, cur, lim;
@@ -430,6 +430,7 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
         return BWAMS_ERR_CAPACITY;
     }
     const bool has_long = b->h_ctr->chain_longread != 0;
+    s->n_chain_redo = (int64_t)b->h_ctr->chain_redo;
     s->n_chains = tot[0]; s->n_seeds = tot[1]; s->nseq = nseq;
     BWAMS_HIP(s->chains.ensure((size_t)(tot[0] + 1) * sizeof(bwams_chain_t)));
     BWAMS_HIP(s->seeds.ensure((size_t)(tot[1] + 1) * sizeof(bwams_chain_seed_t)));
@@ -1157,7 +1158,7 @@ namespace bwams {
 // timing and counts of the chain / extension stages for bwams_batch_stats (api.hip)
 void chain_state_stats(const ChainState *s, bwams_stats_t *out) {
     if (!s) return;
-    out->n_chains = s->n_chains; out->n_chain_seeds = s->n_seeds;
+    out->n_chains = s->n_chains; out->n_chain_seeds = s->n_seeds; out->n_chain_redo = s->n_chain_redo;
     out->n_left = s->n_left; out->n_right = s->n_right;
     out->n_retry_left = s->n_retry_left; out->n_retry_right = s->n_retry_right;
     auto el = [&](int a, int b, float *dst) {

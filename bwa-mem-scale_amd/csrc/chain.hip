@@ -12,7 +12,9 @@
 //   chain_kernel        one lane per read with few seeds: chaining, chain weights; for reads with
 //                       few chains also the sort and the filter.
 //   chain_wave_kernel   one wave per read with many seeds, heaviest reads first: the same code run
-//                       in lockstep by 64 lanes (uniform loads = one request; lane 0 stores).
+//                       in lockstep by 64 lanes (uniform loads = one request; lane 0 stores), the
+//                       chain records and an ordered array of chain positions in LDS; a read in
+//                       which a chain position repeats goes to chain_redo_kernel (B-tree, HBM).
 //   chain_heavy_kernel  one wave per read with many chains: the sort runs on lane 0 over an LDS
 //                       copy, the quadratic pairwise filter runs 64 kept chains at a time.
 // All state lives in HBM scratch indexed by the read's slice of the SA-coordinate array: a seed
@@ -25,7 +27,9 @@
 // Two generic pieces decide tie cases and are therefore kept behaviour-identical to klib:
 //   * the ordered map is a B-tree of order t = 5 (what kb_init(chn, 512 + 8) gives for the
 //     48-byte mem_chain_t, kbtree.h:64) with kbtree.h's search, split and insert rules, so that
-//     equal positions resolve to the same chain and the in-order traversal is the same;
+//     equal positions resolve to the same chain and the in-order traversal is the same; while
+//     all positions of a read are distinct the tree's shape cannot matter, and the wave tiers
+//     use a plain sorted array until one repeats;
 //   * chains are sorted by weight with ksort.h's introsort (median-of-3, 16-element cut-off,
 //     final insertion sort, comb-sort depth fallback), which is not stable.
 #include "common.h"
@@ -58,10 +62,8 @@ struct alignas(16) ChainRec {        // 48 B, one per chain in creation order
 };
 static_assert(sizeof(ChainRec) == 48, "chain record layout");
 
-// LDS bytes a wave needs to chain a read of at most K seeds: K chain records + the B-tree's nodes
-// (every node but the root holds >= t - 1 = 4 keys: at most 5K/16 + 3 nodes)
-__host__ __device__ constexpr int lds_nodes(int K) { return (K * 5) / 16 + 3; }
-// (the wave tiers keep an ordered array of (position, chain id) instead: 12 B per chain)
+// LDS bytes a wave needs to chain a read of at most K seeds: K chain records + the ordered array of
+// (position, chain id), 12 B per chain
 __host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * (sizeof(ChainRec) + 12) + 64; }
 constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL1 = 850, kClassL = 1700;      // seeds per read: 7.7, 15, 31, 51, 102 KB of LDS
 static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
@@ -236,77 +238,7 @@ __device__ __forceinline__ void kbt_put(ReadCtx &c, int32_t id, int64_t k) {
     }
 }
 
-// ---- the same B-tree operations, run by a whole wave on one tree (nodes in LDS) -----------------
-// Lane t < 9 owns key slot t of the node being visited: the binary search of __kb_getp_aux becomes
-// two ballots, the shift of a leaf insertion one read and one write per lane.  Every lane returns
-// the same values.
-__device__ __forceinline__ int wnode_search(const Node *p, int n, int64_t k, int lane, bool &eq) {
-    const int64_t my = lane < KB_MAXK ? p->pos[lane] : 0;
-    const unsigned long long m_lt = __ballot(lane < n && my < k);
-    const unsigned long long m_eq = __ballot(lane < n && my == k);
-    eq = m_eq != 0;
-    const int cnt = __popcll(m_lt);
-    return eq ? cnt : cnt - 1;
-}
-// The lookup also remembers where an insertion of the same key would land: kb_putp descends through the
-// same children (slot getp_aux + 1), so when the lookup reached a leaf and met no full node on the way
-// (kb_putp would split nothing), the insertion is a plain leaf insert at the remembered slot.
-struct WPath { int32_t leaf; int16_t slot, n; bool ok; };
-__device__ __forceinline__ int32_t wkbt_lower(const ReadCtx &c, int64_t k, int lane, int64_t &lower_pos, WPath &path) {
-    int32_t lower = -1, xi = c.root;
-    bool any_full = false;
-    for (;;) {
-        const Node *p = &c.nodes[xi];
-        const int n = p->n, internal = p->internal;
-        any_full |= n == KB_MAXK;
-        bool eq;
-        const int i = wnode_search(p, n, k, lane, eq);
-        if (i >= 0) { lower = p->key[i]; lower_pos = p->pos[i]; }
-        if (!internal) {
-            path.leaf = xi; path.slot = (int16_t)i; path.n = (int16_t)n; path.ok = !any_full;
-            return lower;
-        }
-        if (i >= 0 && eq) { path.ok = false; return lower; }       // found in an internal node: no leaf reached
-        xi = p->ptr[i + 1];
-    }
-}
-// leaf insertion after slot i (the tail of __kb_putp_aux): slots i+1 .. n-1 move up by one
-__device__ __forceinline__ void wleaf_insert(ReadCtx &c, Node *p, int i, int n, int32_t id, int64_t k, int lane) {
-    const bool mv = lane > i && lane < n;
-    const int64_t mp = mv ? p->pos[lane] : 0;
-    const int32_t mk = mv ? p->key[lane] : 0;
-    if (mv) { p->pos[lane + 1] = mp; p->key[lane + 1] = mk; }
-    if (c.wr) { p->pos[i + 1] = k; p->key[i + 1] = id; p->n = (int16_t)(n + 1); }
-}
-__device__ __forceinline__ void wkbt_put(ReadCtx &c, int32_t id, int64_t k, int lane) {
-    ++c.n_keys;
-    int32_t xi = c.root;
-    if (c.nodes[xi].n == KB_MAXK) {
-        const int32_t s = new_node(c);
-        if (c.overflow) return;
-        if (c.wr) { c.nodes[s].internal = 1; c.nodes[s].n = 0; c.nodes[s].ptr[0] = (int16_t)xi; }
-        c.root = s;
-        kbt_split(c, s, 0, xi);
-        if (c.overflow) return;
-        xi = s;
-    }
-    for (;;) {
-        Node *p = &c.nodes[xi];
-        const int n = p->n, internal = p->internal;
-        bool eq;
-        const int i = wnode_search(p, n, k, lane, eq);
-        if (!internal) { wleaf_insert(c, p, i, n, id, k, lane); return; }
-        int ii = i + 1;
-        int32_t ci = p->ptr[ii];
-        if (c.nodes[ci].n == KB_MAXK) {
-            const int64_t median = c.nodes[ci].pos[KB_T - 1];
-            kbt_split(c, xi, ii, ci);
-            if (c.overflow) return;
-            if (k > median) ci = c.nodes[xi].ptr[ii + 1];
-        }
-        xi = ci;
-    }
-}
+struct WPath { int32_t leaf; int16_t slot, n; bool ok; };     // what a lookup remembers for the insertion that may follow
 
 // in-order traversal (__kb_traverse, kbtree.h:345-368) with an explicit stack; si = children already
 // descended (height <= 16 covers 5^16 keys)
@@ -626,8 +558,7 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
                     lower = -1;
                     if (idx >= 0) { lower = s_cid[idx]; fr = s_key[idx]; }
                     path.slot = (int16_t)0; path.leaf = idx; path.ok = !eq;          // leaf: where the key would go - 1; ok: not present yet
-                } else if constexpr (LDS) lower = wkbt_lower(c, rbeg, lane, fr, path);
-                else lower = kbt_lower(c, rbeg, fr);
+                } else lower = kbt_lower(c, rbeg, fr);
                 if (lower >= 0) {                                        // test_and_merge
                     ChainRec ch = crec[lower];
                     const int64_t lr = ch.last_rbeg;
@@ -668,9 +599,6 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
                     if (c.n_keys && !path.ok) return false;                          // a second chain at this position: the B-tree decides
                     sarr_insert(s_key, s_cid, c.n_keys, c.n_keys ? path.leaf + 1 : 0, rbeg, cid, lane);
                     ++c.n_keys;
-                } else if constexpr (LDS) {
-                    if (path.ok) { ++c.n_keys; wleaf_insert(c, &c.nodes[path.leaf], path.slot, path.n, cid, rbeg, lane); }
-                    else wkbt_put(c, cid, rbeg, lane);
                 } else kbt_put(c, cid, rbeg);
                 if (c.overflow) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return true; }
             }
@@ -970,9 +898,9 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     // heaviest first: reads beyond the LDS budget (HBM state) and classes L, L1, then M, M1, S, then the lane tier
     chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, 0, aux[0]>>>(A, nullptr, cls + 0, tk + 0, 0);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[0]>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
-    chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, lds_bytes(kClassL1), aux[0]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
-    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
-    chain_wave_kernel<<<(unsigned)(cu_count * 6), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
+    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassL1), aux[0]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
+    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
+    chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
     chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 4, cls + 5, tk + 5, kClassS);
     chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[4]>>>(A, n_seeds);
     for (int i = 0; i < 5; ++i) {

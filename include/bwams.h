@@ -236,6 +236,8 @@ typedef struct bwams_stats {
     int64_t n_pair_tasks;                 /* rescue alignments (ksw_align2 calls) of the last bwams_pair_run */
     int64_t n_pair_redone;                /* reads whose rescue was redone with every orientation planned */
     int64_t n_pair_regs;                  /* regions after rescue */
+    int64_t n_chain_redo;                 /* reads of the last chaining run in which a chain position repeated: chained again
+                                           * with the exact B-tree instead of the ordered array */
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 

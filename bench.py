@@ -206,7 +206,10 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mreads/sec aligned, 150bp SE (FM-index seeding + banded-SW extension on GPU)",
+            # BASELINE.json: "Mreads/sec aligned, GRCh38 150bp SE, at 1/2/4/8 MI355X; % HBM roofline" — same metric; GRCh38 is
+            # not available offline, so the genome is synthetic (config.workload) and the roofline share is `roofline.frac`
+            "metric": f"Mreads/sec aligned, 150bp SE (synthetic {args.genome_mbp:.0f} Mbp genome in place of GRCh38), at {world} MI355X; "
+                      "% HBM roofline in roofline.frac",
             "value": round(value, 4),
             "unit": "Mreads/s",
             "n_gpus": world,

@@ -29,7 +29,6 @@ SYMBOLS = [
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
-    "bwams_tasks_from_seeds", "bwams_tasks_fetch",
     "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
     "bwams_emf_open", "bwams_emf_from_host", "bwams_emf_close", "bwams_emf_probe",
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
@@ -215,8 +214,6 @@ def lib():
         L.bwams_bsw_run.argtypes = [vp, i32, vp]
         L.bwams_bsw_fetch.argtypes = [vp, vp, i64]
         L.bwams_ksw_align.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
-        L.bwams_tasks_from_seeds.argtypes = [vp, vp, i32, i32, i32, vp]
-        L.bwams_tasks_fetch.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp]
         L.bwams_emf_open.argtypes = [vp, C.c_char_p, vp]
         L.bwams_emf_from_host.argtypes = [vp, i32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp]
         L.bwams_emf_close.argtypes = [vp]
@@ -426,24 +423,6 @@ class Batch:
         _chk(lib().bwams_bsw_fetch(self.h, _p(p), len(p)), "bwams_bsw_fetch")
         return p
 
-    def tasks_from_seeds(self, opt: SwOpt | None = None, a: int = 1, w: int = 100, max_occ: int = 500) -> int:
-        opt = opt or default_sw_opt()
-        n = C.c_int64(0)
-        _chk(lib().bwams_tasks_from_seeds(self.h, C.byref(opt), a, w, max_occ, C.byref(n)), "bwams_tasks_from_seeds")
-        self._n_pairs = n.value
-        return n.value
-
-    def tasks_fetch(self):
-        rb, qb = C.c_int64(0), C.c_int64(0)
-        lib().bwams_tasks_fetch(self.h, None, 0, None, 0, None, 0, C.byref(rb), C.byref(qb))      # sizes
-        p = np.zeros(self._n_pairs, dtype=SEQPAIR_DTYPE)
-        ref = np.zeros(max(rb.value, 1), dtype=np.uint8)
-        qer = np.zeros(max(qb.value, 1), dtype=np.uint8)
-        _chk(lib().bwams_tasks_fetch(self.h, _p(p), len(p), _p(ref), len(ref), _p(qer), len(qer), C.byref(rb), C.byref(qb)),
-             "bwams_tasks_fetch")
-        return p, ref[:rb.value], qer[:qb.value]
-
-    # ---- chaining / chain-to-alignment ----
     def chain_run(self, opt: MemOpt | None = None):
         """mem_chain_seeds + mem_chain_flt over the resident seeds -> (n_chains, n_seeds)."""
         opt = opt or default_mem_opt()

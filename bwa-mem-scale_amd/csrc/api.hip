@@ -386,7 +386,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_plan, b->d_tcnt, b->d_twide, b->d_toffs, b->d_pairs, b->d_ref, b->d_qer};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_pairs, b->d_ref, b->d_qer};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -915,102 +915,6 @@ int bwams_emf_probe(bwams_batch_t *b, bwams_emf_t *e, const uint8_t *enc, const 
     }
     BWAMS_HIP(hipStreamSynchronize(st));
     b->seed_done = false;            // the resident reads were replaced
-    return BWAMS_OK;
-}
-
-/* ------------------------------------------------------- tasks from seeds ---- */
-
-int bwams_tasks_from_seeds(bwams_batch_t *b, const bwams_sw_opt_t *o, int32_t a, int32_t w, int32_t max_occ,
-                           int64_t *n_tasks) {
-    if (!b || !o || !b->seed_done || !b->with_sa) {
-        set_last_error("bwams_tasks_from_seeds: run bwams_seed_run(with_sa = 1) first");
-        return BWAMS_ERR_ARG;
-    }
-    if (!b->idx->d_ref) {
-        set_last_error("bwams_tasks_from_seeds: the index was opened without its .0123 reference");
-        return BWAMS_ERR_ARG;
-    }
-    BWAMS_HIP(hipSetDevice(b->idx->device));
-    hipStream_t st = b->stream;
-    const int64_t nseq = b->nseq;
-    if (nseq > b->cap_plan) {
-        for (void *p : {(void *)b->d_plan, (void *)b->d_tcnt, (void *)b->d_twide, (void *)b->d_toffs})
-            if (p) (void)hipFree(p);
-        b->d_plan = nullptr; b->d_tcnt = nullptr; b->d_twide = b->d_toffs = nullptr;
-        b->cap_plan = nseq;
-        BWAMS_HIP(hipMalloc(&b->d_plan, task_plan_bytes(nseq)));
-        BWAMS_HIP(hipMalloc(&b->d_tcnt, (size_t)nseq * 6 * 4));
-        BWAMS_HIP(hipMalloc(&b->d_twide, (size_t)(nseq + 1) * 6 * 8));
-        BWAMS_HIP(hipMalloc(&b->d_toffs, (size_t)(nseq + 1) * 6 * 8));
-    }
-    BWAMS_HIP(hipEventRecord(b->ev[1], st));
-    int64_t tot[6] = {0, 0, 0, 0, 0, 0};
-    if (nseq > 0) {
-        const int64_t l_pac = (b->idx->fmi.ref_seq_len - 1) / 2;
-        launch_task_plan(b->d_sorted, b->n_smem, b->d_sa_off, b->d_sa_coord, b->d_cum, nseq, l_pac, max_occ, a,
-                         o->o_del, o->e_del, w, b->d_plan, b->d_tcnt, b->d_twide, st);
-        for (int r = 0; r < 6; ++r) {
-            size_t tb = 0;
-            BWAMS_HIP(rocprim::exclusive_scan(nullptr, tb, b->d_twide + r * (nseq + 1), b->d_toffs + r * (nseq + 1),
-                                              (int64_t)0, (size_t)nseq + 1, rocprim::plus<int64_t>(), st));
-            if (tb > b->tmp_bytes) {
-                BWAMS_HIP(hipStreamSynchronize(st));
-                (void)hipFree(b->d_tmp);
-                b->d_tmp = nullptr;
-                BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
-                b->tmp_bytes = tb;
-            }
-            tb = b->tmp_bytes;
-            BWAMS_HIP(rocprim::exclusive_scan(b->d_tmp, tb, b->d_twide + r * (nseq + 1), b->d_toffs + r * (nseq + 1),
-                                              (int64_t)0, (size_t)nseq + 1, rocprim::plus<int64_t>(), st));
-        }
-        // totals size the task buffers: one small read-back
-        for (int r = 0; r < 6; ++r)
-            BWAMS_HIP(hipMemcpyAsync(&tot[r], b->d_toffs + r * (nseq + 1) + nseq, 8, hipMemcpyDeviceToHost, st));
-        BWAMS_HIP(hipStreamSynchronize(st));
-    }
-    const int64_t n = tot[0] + tot[3], qb = tot[1] + tot[4], rb = tot[2] + tot[5];
-    if (rb >= ((int64_t)1 << 31) || qb >= ((int64_t)1 << 31)) {
-        set_last_error("bwams_tasks_from_seeds: task buffers exceed the 31-bit offsets of SeqPair; use smaller chunks");
-        return BWAMS_ERR_CAPACITY;
-    }
-    auto grow = [](void **p, int64_t *cap, int64_t need, size_t elem) -> hipError_t {
-        if (need <= *cap) return hipSuccess;
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-        *cap = need + need / 8 + 1024;
-        return hipMalloc(p, (size_t)*cap * elem);
-    };
-    BWAMS_HIP(grow((void **)&b->d_pairs, &b->cap_pairs, n, sizeof(bwams_seqpair_t)));
-    BWAMS_HIP(grow((void **)&b->d_ref, &b->cap_ref, rb + 64, 1));
-    BWAMS_HIP(grow((void **)&b->d_qer, &b->cap_qer, qb + 64, 1));
-    if (nseq > 0)
-        launch_task_build(b->d_plan, b->d_tcnt, b->d_toffs, b->d_enc, b->d_cum, b->idx->fmi.ref, nseq, a, b->d_pairs,
-                          b->d_ref, b->d_qer, b->cu_count, st);
-    BWAMS_HIP(hipEventRecord(b->ev[2], st));
-    BWAMS_HIP(hipGetLastError());
-    b->n_pairs = n;
-    b->max_qlen = b->max_read_len > 1 ? b->max_read_len : 1;
-    b->max_tlen = b->max_read_len + 2 * w + 8;
-    b->task_ref_bytes = rb;
-    b->task_qer_bytes = qb;
-    if (n_tasks) *n_tasks = n;
-    return BWAMS_OK;
-}
-
-int bwams_tasks_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref, int64_t ref_cap,
-                      uint8_t *qer, int64_t qer_cap, int64_t *ref_bytes, int64_t *qer_bytes) {
-    if (!b) return BWAMS_ERR_ARG;
-    if (ref_bytes) *ref_bytes = b->task_ref_bytes;
-    if (qer_bytes) *qer_bytes = b->task_qer_bytes;
-    if (b->n_pairs > pair_cap || b->task_ref_bytes > ref_cap || b->task_qer_bytes > qer_cap) return BWAMS_ERR_CAPACITY;
-    BWAMS_HIP(hipSetDevice(b->idx->device));
-    if (b->n_pairs) {
-        BWAMS_HIP(hipMemcpyAsync(pairs, b->d_pairs, (size_t)b->n_pairs * sizeof(bwams_seqpair_t), hipMemcpyDeviceToHost, b->stream));
-        BWAMS_HIP(hipMemcpyAsync(ref, b->d_ref, (size_t)b->task_ref_bytes, hipMemcpyDeviceToHost, b->stream));
-        BWAMS_HIP(hipMemcpyAsync(qer, b->d_qer, (size_t)b->task_qer_bytes, hipMemcpyDeviceToHost, b->stream));
-    }
-    BWAMS_HIP(hipStreamSynchronize(b->stream));
     return BWAMS_OK;
 }
 

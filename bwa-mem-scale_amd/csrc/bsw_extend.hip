@@ -59,10 +59,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     int64_t pid = 0, pid_end = 0;          // this wave's reserved task range
     while (true) {
         if (pid >= pid_end) {
-            unsigned long long t = 0;
-            if (lane == 0) t = atomicAdd(head, (unsigned long long)kTaskChunk);
-            pid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
-                            (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t));
+            pid = (int64_t)wave_ticket(head, (unsigned long long)kTaskChunk);   // out of line: see wave_ops.h
             pid_end = pid + kTaskChunk < n ? pid + kTaskChunk : n;
             if (pid >= n) break;
         }
@@ -238,10 +235,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
     int64_t pid = 0, pid_end = 0;          // this wave's reserved task range
     while (true) {
         if (pid >= pid_end) {
-            unsigned long long t = 0;
-            if (lane == 0) t = atomicAdd(head, (unsigned long long)kTaskChunk);
-            pid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) |
-                            (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)t));
+            pid = (int64_t)wave_ticket(head, (unsigned long long)kTaskChunk);   // out of line: see wave_ops.h
             pid_end = pid + kTaskChunk < n ? pid + kTaskChunk : n;
             if (pid >= n) break;
         }

@@ -98,13 +98,6 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
                DevCounters *ctr, int cu_count, hipStream_t st, hipStream_t *aux = nullptr, hipEvent_t fork = nullptr,
                hipEvent_t *join = nullptr);
 size_t bsw_lds_bytes(int qmax);
-size_t task_plan_bytes(int64_t nseq);
-void launch_task_plan(const bwams_smem_t *sm, int64_t n_smem, const int64_t *sa_off, const int64_t *sa_coord,
-                      const int64_t *cum, int64_t nseq, int64_t l_pac, int max_occ, int a, int o_gap, int e_gap, int w,
-                      void *plan, int32_t *cnt, int64_t *wide, hipStream_t st);
-void launch_task_build(const void *plan, const int32_t *cnt, const int64_t *offs, const uint8_t *enc, const int64_t *cum,
-                       const uint8_t *ref0123, int64_t nseq, int a, bwams_seqpair_t *pairs, uint8_t *refbuf,
-                       uint8_t *qerbuf, int cu_count, hipStream_t st);
 void launch_emf_probe(const DevEmf &t, const uint8_t *enc, const int64_t *cum, int64_t nseq, uint32_t *out,
                       uint8_t *code, uint8_t *skip, DevCounters *ctr, hipStream_t st);
 constexpr int kKswMaxTarget = 20000;     // longest local-SW target: its row-maxima list must fit the LDS of a 4-wave block
@@ -178,11 +171,6 @@ struct bwams_batch {
     uint8_t *d_ref = nullptr, *d_qer = nullptr;
     int64_t cap_pairs = 0, cap_ref = 0, cap_qer = 0, n_pairs = 0;
     int max_qlen = 0, max_tlen = 0;
-    void *d_plan = nullptr;
-    int32_t *d_tcnt = nullptr;
-    int64_t *d_twide = nullptr, *d_toffs = nullptr;
-    int64_t cap_plan = 0;
-    int64_t task_ref_bytes = 0, task_qer_bytes = 0;
     uint32_t *d_emf_out = nullptr;
     uint8_t *d_emf_code = nullptr;
     int64_t cap_emf = 0;

@@ -16,8 +16,9 @@
 //   in, so divergent phases still share one memory round trip.  Lanes pull the next
 //   read from a global cursor when they finish (no tail of idle lanes), the grid is
 //   persistent and sized to the chip, and the per-lane list of "previous" intervals
-//   lives in a lane-interleaved HBM scratch that stays L2-resident.
+//   keeps its 8 newest entries in an LDS ring, the rest in a lane-contiguous HBM list.
 #include "fmi_kernels.h"
+#include "wave_ops.h"
 
 namespace bwams {
 
@@ -152,9 +153,7 @@ __device__ __forceinline__ bool take_ticket(unsigned long long *head, WaveTicket
     if (!m) return false;
     const int lane = (int)(threadIdx.x & 63);
     if (wt.left == 0) {
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(head, (unsigned long long)kTicketChunk);
-        wt.next = mk64(__builtin_amdgcn_readfirstlane((uint32_t)b), __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)));
+        wt.next = wave_ticket(head, (unsigned long long)kTicketChunk);   // out of line: see wave_ops.h
         wt.left = kTicketChunk;
     }
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -202,9 +201,7 @@ __device__ __forceinline__ void wave_emit(const SeedLaunch &a, WaveOut &w, bool 
     const int cnt = __popcll(mask);
     if (w.base < 0 || w.used + cnt > kChunk) {
         wave_close_chunk(a, w);
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(&a.ctr->n_smem_total, (unsigned long long)kChunk);
-        w.base = (long long)mk64(__shfl((uint32_t)b, 0), __shfl((uint32_t)(b >> 32), 0));
+        w.base = (long long)wave_ticket(&a.ctr->n_smem_total, (unsigned long long)kChunk);   // out of line: see wave_ops.h
     }
     if (flag) {
         const long long slot = w.base + w.used + __popcll(mask & ((1ull << lane) - 1ull));
@@ -382,24 +379,6 @@ __device__ __forceinline__ void read_take(ReadView &r, uint32_t *lds_col_w, cons
     }
 }
 
-// Deferred form for W == 16 (reads of up to 160 bases): the four 16-byte loads are issued when the
-// lane takes the read and land in LDS only after this iteration's extension, so their latency
-// overlaps the index fetches of the other lanes instead of stalling the whole wave.
-struct PendingRead {
-    uint4 v0, v1, v2, v3;
-};
-__device__ __forceinline__ void read_issue(ReadView &r, PendingRead &pr, const uint32_t *packed, uint32_t rid) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(packed + (int64_t)rid * 16);
-    r.gl = packed + (int64_t)rid * 16;
-    pr.v0 = src[0]; pr.v1 = src[1]; pr.v2 = src[2]; pr.v3 = src[3];
-}
-__device__ __forceinline__ void read_land(uint32_t *c, const PendingRead &pr) {
-    c[0 * kBlock] = pr.v0.x;  c[1 * kBlock] = pr.v0.y;  c[2 * kBlock] = pr.v0.z;  c[3 * kBlock] = pr.v0.w;
-    c[4 * kBlock] = pr.v1.x;  c[5 * kBlock] = pr.v1.y;  c[6 * kBlock] = pr.v1.z;  c[7 * kBlock] = pr.v1.w;
-    c[8 * kBlock] = pr.v2.x;  c[9 * kBlock] = pr.v2.y;  c[10 * kBlock] = pr.v2.z; c[11 * kBlock] = pr.v2.w;
-    c[12 * kBlock] = pr.v3.x; c[13 * kBlock] = pr.v3.y; c[14 * kBlock] = pr.v3.z; c[15 * kBlock] = pr.v3.w;
-}
-
 __global__ void pack_reads_kernel(const uint8_t *__restrict__ enc, const int64_t *__restrict__ cum, int64_t nseq,
                                   int W, int cw, uint32_t *__restrict__ packed) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -460,9 +439,6 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0;
-    const bool defer_reads = false && a.reads_in_lds && a.read_w == 16;   // measured: no gain, costs 16 VGPRs (3 instead of 4 waves/SIMD)
-    PendingRead pend;
-    pend.v0 = pend.v1 = pend.v2 = pend.v3 = make_uint4(0, 0, 0, 0);
 
     while (true) {
         // at most one SMEM per lane and iteration; written at the wave-uniform point below
@@ -505,7 +481,6 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
                     len = (int)(a.cum[rid + 1] - qoff);
                     phase = PH_PIVOT;
                     if (ALL_POS && a.skip && a.skip[rid]) phase = PH_FETCH;
-                    else if (defer_reads) { read_issue(rv, pend, a.packed, rid); phase = PH_LOAD; }
                     else read_take(rv, lds_col, a.packed, a.read_w, rid);
                 }
             }
@@ -683,7 +658,6 @@ __global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const
                 }
             }
         }
-        if (phase == PH_LOAD) { read_land(lds_col, pend); phase = PH_PIVOT; }
         wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
     }
     wave_emit_finish(a, wo);
@@ -742,9 +716,6 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0;
-    const bool defer_reads = false && a.reads_in_lds && a.read_w == 16;   // measured: no gain, costs 16 VGPRs (3 instead of 4 waves/SIMD)
-    PendingRead pend;
-    pend.v0 = pend.v1 = pend.v2 = pend.v3 = make_uint4(0, 0, 0, 0);
 
     while (true) {
         {
@@ -759,7 +730,6 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
                     x = 0;
                     phase = PH_PIVOT;
                     if (a.skip && a.skip[rid]) phase = PH_FETCH;
-                    else if (defer_reads) { read_issue(rv, pend, a.packed, rid); phase = PH_LOAD; }
                     else read_take(rv, lds_col, a.packed, a.read_w, rid);
                 }
             }
@@ -845,7 +815,6 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
             }
             j++;
         }
-        if (phase == PH_LOAD) { read_land(lds_col, pend); phase = PH_PIVOT; }
         if (phase == PH_HOLD) phase = PH_FWD;
         wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
     }

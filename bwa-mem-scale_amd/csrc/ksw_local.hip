@@ -185,9 +185,7 @@ __global__ __launch_bounds__(kKswWaves * 64) void ksw_kernel(const bwams_seqpair
     int64_t pid = 0, pid_end = 0;
     while (true) {
         if (pid >= pid_end) {
-            unsigned long long t = 0;
-            if (lane == 0) t = atomicAdd(&ctr->work_head, 4ull);
-            pid = (int64_t)(((unsigned long long)uni((int)(t >> 32)) << 32) | (unsigned long long)(uint32_t)uni((int)t));
+            pid = (int64_t)wave_ticket(&ctr->work_head, 4ull);   // out of line: see wave_ops.h
             pid_end = pid + 4 < n ? pid + 4 : n;
             if (pid >= n) break;
         }

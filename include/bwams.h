@@ -175,20 +175,6 @@ int bwams_emf_probe(bwams_batch_t *b, bwams_emf_t *emf, const uint8_t *enc_qdb, 
 int bwams_emf_run(bwams_batch_t *b, bwams_emf_t *emf);
 int bwams_emf_fetch(bwams_batch_t *b, bwams_perfect_t *out, uint8_t *code);
 
-/* ------------------------------------------------------ tasks from seeds ---- */
-
-/* INTERIM (until the chaining rows a9/a14/a16 of SURVEY.md §8 are built): turns the seeds of
- * the last bwams_seed_run(with_sa = 1) into extension tasks on the device, treating the longest
- * seed with s <= max_occ of each read as a one-seed chain and laying out its left and right
- * task as mem_chain2aln_across_reads_V2 does for such a chain (src/bwamem.cpp:2880-3188).
- * The tasks replace the batch's resident task list (as bwams_bsw_upload would); follow with
- * bwams_bsw_run / bwams_bsw_fetch.  Needs an index opened with its .0123 reference.
- * a = match score, w = band width used for the window, opt supplies o_del / e_del. */
-int bwams_tasks_from_seeds(bwams_batch_t *b, const bwams_sw_opt_t *opt, int32_t a, int32_t w, int32_t max_occ,
-                           int64_t *n_tasks);
-int bwams_tasks_fetch(bwams_batch_t *b, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref, int64_t ref_cap,
-                      uint8_t *qer, int64_t qer_cap, int64_t *ref_bytes, int64_t *qer_bytes);
-
 /* ----------------------------------------------------------- mate rescue ---- */
 
 /* Local Smith-Waterman of mate rescue over n tasks: out[i] = ksw_align2(len2, qer + idq,

@@ -277,31 +277,6 @@ def test_ksw_local_long_queries_scoring_and_limits(gpu_toy):
     b.close()
 
 
-def test_device_task_construction_equals_numpy_rule(gpu_toy):
-    """bwams_tasks_from_seeds (interim one-seed chains, device) == bwams/pairs.py (same rule, numpy),
-    and extending those tasks on the GPU == the oracle on the same tasks."""
-    from bwams import pairs as pairs_mod
-    g, idx, ix = gpu_toy
-    reads, _, _ = simulate.make_reads(g, 3000, seed=31)
-    enc, cum = simulate.flatten_reads(reads)
-    b = capi.Batch(ix, len(reads), int(cum[-1]))
-    b.seed_upload(enc, cum)
-    b.seed_run(with_sa=True)
-    sm, coord, off = b.seed_fetch()
-    want_p, want_r, want_q = pairs_mod.pairs_from_seeds(reads, sm, coord, off, idx.ref_0123)
-    n = b.tasks_from_seeds()
-    got_p, got_r, got_q = b.tasks_fetch()
-    assert n == len(want_p) and len(got_p) == len(want_p)
-    for f in ("idr", "idq", "id", "len1", "len2", "h0", "seqid", "regid"):
-        assert np.array_equal(got_p[f], want_p[f]), f
-    assert np.array_equal(got_r, want_r) and np.array_equal(got_q, want_q)
-    b.bsw_run(100)
-    res = b.bsw_fetch()
-    want, _ = loader.bsw_pairs(want_p, want_r, want_q, 100)
-    assert_pairs_equal(res, want, "resident pipeline")
-    b.close()
-
-
 def test_fma_tables_and_seeding_with_fma(gpu_toy):
     """FMA (all_smem / last_smem): device-built tables == oracle-built tables; seeding with the tables
     == the oracle with the same tables (N reads included: the with_N quirk is reproduced); and at the

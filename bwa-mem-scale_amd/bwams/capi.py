@@ -25,7 +25,7 @@ SEQPAIR_DTYPE = np.dtype([(n, "<i4") for n in
 SYMBOLS = [
     "bwams_strerror", "bwams_last_error", "bwams_device_count",
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
-    "bwams_index_bytes", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
@@ -110,6 +110,11 @@ class Stats(C.Structure):
                 ("n_pair_tasks", C.c_int64), ("n_pair_redone", C.c_int64), ("n_pair_regs", C.c_int64), ("n_chain_redo", C.c_int64)]
 
 
+class BuildStats(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("chunks", C.c_int32), ("rounds", C.c_int32), ("unresolved_after_first", C.c_int64),
+                ("ms_first_pass", C.c_float), ("ms_outputs", C.c_float)]
+
+
 def pestat_from_keys(keys) -> np.ndarray:
     """mem_pestat's arithmetic over the insert-size keys of a whole chunk (host only; keys in any order)."""
     keys = np.ascontiguousarray(keys, np.uint64)
@@ -179,6 +184,9 @@ def lib():
         L.bwams_index_from_host.argtypes = [vp, C.c_int, vp]
         L.bwams_index_from_device.argtypes = [vp, C.c_int, vp]
         L.bwams_index_close.argtypes = [vp]
+        L.bwams_index_build.argtypes = [vp, i64, C.c_int, C.c_int, C.c_int, i64, vp, vp]
+        L.bwams_index_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.bwams_index_save.argtypes = [vp, C.c_char_p]
         L.bwams_index_build_fma.argtypes = [vp, C.c_int, C.c_int]
         L.bwams_index_set_fma.argtypes = [vp, vp, C.c_int, vp, C.c_int]
         L.bwams_index_fetch_fma.argtypes = [vp, vp, vp]
@@ -274,6 +282,39 @@ class Index:
         h = C.c_void_p()
         _chk(lib().bwams_index_from_device(C.byref(d), device, C.byref(h)), "bwams_index_from_device")
         return cls(h, keep=idx)
+
+    @classmethod
+    def build(cls, genome, device: int = 0, keep_ref: bool = True, chunk_rows: int = 0) -> "Index":
+        """FM-index of fw || revcomp(fw) built on the GPU (bwams_index_build).  genome: numpy uint8 codes 0..3, or a torch
+        uint8 tensor already on `device`."""
+        h = C.c_void_p()
+        st = BuildStats()
+        if isinstance(genome, np.ndarray):
+            g = np.ascontiguousarray(genome, dtype=np.uint8)
+            _chk(lib().bwams_index_build(_p(g), len(g), 0, device, int(keep_ref), chunk_rows, C.byref(st), C.byref(h)), "bwams_index_build")
+        else:
+            g = genome.contiguous()
+            _chk(lib().bwams_index_build(g.data_ptr(), g.numel(), 1, device, int(keep_ref), chunk_rows, C.byref(st), C.byref(h)),
+                 "bwams_index_build")
+        ix = cls(h)
+        ix.build_stats = st
+        return ix
+
+    def fetch(self, with_ref: bool = True):
+        """The resident arrays as a bwams.fmindex.FMIndex of numpy arrays (for the file writer / the CPU oracle)."""
+        from bwams import fmindex
+        d = FmiDesc()
+        _chk(lib().bwams_index_fetch(self.h, None, None, None, None, C.byref(d)), "bwams_index_fetch")
+        L = int(d.ref_seq_len)
+        cp = np.empty(((L >> 6) + 1, 8), dtype=np.uint64)
+        ms = np.empty((L >> 3) + 1, dtype=np.int8)
+        ls = np.empty((L >> 3) + 1, dtype=np.uint32)
+        ref = np.empty(L - 1, dtype=np.uint8) if with_ref else None
+        _chk(lib().bwams_index_fetch(self.h, _p(cp), _p(ms), _p(ls), _p(ref), C.byref(d)), "bwams_index_fetch")
+        return fmindex.FMIndex(L, np.array(list(d.count), dtype=np.int64), cp, ms, ls, int(d.sentinel_index), ref)
+
+    def save(self, prefix: str):
+        _chk(lib().bwams_index_save(self.h, prefix.encode()), "bwams_index_save")
 
     def build_fma(self, all_bp: int = 11, last_bp: int = 13):
         _chk(lib().bwams_index_build_fma(self.h, all_bp, last_bp), "bwams_index_build_fma")

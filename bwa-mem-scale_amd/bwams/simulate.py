@@ -45,6 +45,25 @@ def make_genome(n_bases: int, seed: int = 2024, repeat_frac: float = 0.10,
     return g
 
 
+def chromosomes(n_bases: int, n_seq: int = 24) -> np.ndarray:
+    """Cut a synthetic genome into `n_seq` sequences whose lengths fall off like the human chromosomes' (longest about
+    five times the shortest): bntann1_t's `len` is 32 bits (src/bntseq.h), so a genome beyond 2^31 bases must be several
+    sequences, as GRCh38 is.  Returns records with the fields of bwams_contig_t (offset, len, is_alt)."""
+    w = np.linspace(5.0, 1.0, n_seq)
+    lens = np.floor(w / w.sum() * n_bases).astype(np.int64)
+    lens[0] += n_bases - int(lens.sum())
+    assert lens.max() < 2 ** 31
+    out = np.zeros(n_seq, dtype=np.dtype([("offset", "<i8"), ("len", "<i4"), ("is_alt", "<i4")]))
+    out["offset"][1:] = np.cumsum(lens)[:-1]
+    out["len"] = lens
+    return out
+
+
+def contig_bounds(contigs) -> np.ndarray:
+    """Ascending start offsets plus the total length, the form make_reads / make_read_pairs_bulk take."""
+    return np.concatenate([contigs["offset"], [contigs["offset"][-1] + contigs["len"][-1]]]).astype(np.int64)
+
+
 def revcomp(x: np.ndarray) -> np.ndarray:
     """Reverse complement of a code array; N (4) stays N."""
     r = x[..., ::-1]
@@ -145,7 +164,7 @@ def make_read_pairs(genome: np.ndarray, n_pairs: int, seed: int = 777, read_len:
 
 def make_read_pairs_bulk(genome: np.ndarray, n_pairs: int, seed: int = 777, read_len: int = READ_LEN,
                          insert_mean: float = 400.0, insert_sd: float = 40.0, damaged_frac: float = 0.05,
-                         discordant_frac: float = 0.02) -> np.ndarray:
+                         discordant_frac: float = 0.02, contig_bounds: np.ndarray | None = None) -> np.ndarray:
     """Vectorised form of make_read_pairs for large batches: uint8[2 * n_pairs, read_len], ends of pair p in rows
     2p and 2p + 1 (FR library, 1 % substitutions, a damaged_frac with one end at ~12 % substitutions, a
     discordant_frac with the second end from an unrelated position)."""
@@ -153,6 +172,10 @@ def make_read_pairs_bulk(genome: np.ndarray, n_pairs: int, seed: int = 777, read
     n = genome.shape[0]
     isz = np.maximum(read_len + 20, rng.normal(insert_mean, insert_sd, size=n_pairs)).astype(np.int64)
     pos = (rng.random(n_pairs) * (n - isz - 1)).astype(np.int64)
+    if contig_bounds is not None:                            # a fragment that would straddle two sequences starts at the later one
+        cb = np.asarray(contig_bounds, dtype=np.int64)
+        c = np.searchsorted(cb, pos + isz, side="right") - 1
+        pos = np.where(pos < cb[c], cb[c], pos)
     col = np.arange(read_len)[None, :]
     out = np.empty((2 * n_pairs, read_len), dtype=np.uint8)
     slab = 1 << 17

@@ -43,6 +43,8 @@ static int check_device(int device) {
 }
 
 void chain_state_stats(const ChainState *s, bwams_stats_t *out);   // api_chain.hip
+int fmi_build_device(bwams_index *ix, const uint8_t *d_fw, int64_t l_pac, int keep_ref, int64_t chunk_rows, int verbose,
+                     bwams_build_stats_t *bs);                   // fmi_build.hip
 
 }  // namespace bwams
 
@@ -231,6 +233,96 @@ int bwams_index_open(const char *prefix, int device, bwams_index_t **out) {
         if (fa >= 0) close(fa);
         if (fl >= 0) close(fl);
     }
+    return rc;
+}
+
+int bwams_index_build(const uint8_t *fw, int64_t l_pac, int fw_on_device, int device, int keep_ref, int64_t chunk_rows,
+                      bwams_build_stats_t *stats, bwams_index_t **out) {
+    if (!fw || !out || l_pac <= 0) {
+        set_last_error("bwams_index_build: null or empty sequence");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    BWAMS_HIP(hipSetDevice(device));
+    void *staged = nullptr;
+    if (!fw_on_device) {
+        BWAMS_HIP(hipMalloc(&staged, (size_t)l_pac));
+        hipError_t e = hipMemcpy(staged, fw, (size_t)l_pac, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(staged); BWAMS_HIP(e); }
+    }
+    bwams_index *ix = new bwams_index();
+    ix->device = device;
+    const char *vb = getenv("BWAMS_VERBOSE");
+    rc = fmi_build_device(ix, staged ? (const uint8_t *)staged : fw, l_pac, keep_ref, chunk_rows, vb && *vb && *vb != '0', stats);
+    if (staged) (void)hipFree(staged);
+    if (rc) { bwams_index_close(ix); return rc; }
+    *out = ix;
+    return BWAMS_OK;
+}
+
+int bwams_index_fetch(bwams_index_t *ix, bwams_cp_occ_t *cp_occ, int8_t *sa_ms_byte, uint32_t *sa_ls_word, uint8_t *ref_0123,
+                      bwams_fmi_desc_t *d) {
+    if (!ix) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(ix->device));
+    if (cp_occ) BWAMS_HIP(hipMemcpy(cp_occ, ix->d_cp, (size_t)ix->n_blk * 64, hipMemcpyDeviceToHost));
+    if (sa_ms_byte) BWAMS_HIP(hipMemcpy(sa_ms_byte, ix->d_ms, (size_t)ix->n_sa, hipMemcpyDeviceToHost));
+    if (sa_ls_word) BWAMS_HIP(hipMemcpy(sa_ls_word, ix->d_ls, (size_t)ix->n_sa * 4, hipMemcpyDeviceToHost));
+    if (ref_0123) {
+        if (!ix->d_ref) {
+            set_last_error("bwams_index_fetch: the index holds no .0123 text");
+            return BWAMS_ERR_ARG;
+        }
+        BWAMS_HIP(hipMemcpy(ref_0123, ix->d_ref, (size_t)(ix->fmi.ref_seq_len - 1), hipMemcpyDeviceToHost));
+    }
+    if (d) {
+        memset(d, 0, sizeof *d);
+        d->ref_seq_len = ix->fmi.ref_seq_len;
+        for (int i = 0; i < 5; ++i) d->count[i] = ix->fmi.count[i];
+        d->sentinel_index = ix->fmi.sentinel;
+    }
+    return BWAMS_OK;
+}
+
+int bwams_index_save(bwams_index_t *ix, const char *prefix) {
+    if (!ix || !prefix) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(ix->device));
+    const size_t kSlab = (size_t)256 << 20;
+    std::vector<uint8_t> slab(kSlab);
+    auto stream_out = [&](FILE *f, const void *dev, size_t bytes) -> int {
+        for (size_t o = 0; o < bytes; o += kSlab) {
+            const size_t n = std::min(kSlab, bytes - o);
+            BWAMS_HIP(hipMemcpy(slab.data(), (const uint8_t *)dev + o, n, hipMemcpyDeviceToHost));
+            if (fwrite(slab.data(), 1, n, f) != n) return BWAMS_ERR_IO;
+        }
+        return BWAMS_OK;
+    };
+    std::string path = std::string(prefix) + ".bwt.2bit.64";
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) {
+        set_last_error("cannot create " + path);
+        return BWAMS_ERR_IO;
+    }
+    int64_t hdr[6];
+    hdr[0] = ix->fmi.ref_seq_len;
+    for (int i = 0; i < 5; ++i) hdr[1 + i] = ix->fmi.count[i] - 1;          // the file holds them without the loader's +1
+    int rc = fwrite(hdr, 8, 6, f) == 6 ? BWAMS_OK : BWAMS_ERR_IO;
+    if (!rc) rc = stream_out(f, ix->d_cp, (size_t)ix->n_blk * 64);
+    if (!rc) rc = stream_out(f, ix->d_ms, (size_t)ix->n_sa);
+    if (!rc) rc = stream_out(f, ix->d_ls, (size_t)ix->n_sa * 4);
+    const int64_t sent = ix->fmi.sentinel;
+    if (!rc && fwrite(&sent, 8, 1, f) != 1) rc = BWAMS_ERR_IO;
+    if (fclose(f) != 0 && !rc) rc = BWAMS_ERR_IO;
+    if (!rc && ix->d_ref) {
+        path = std::string(prefix) + ".0123";
+        f = fopen(path.c_str(), "wb");
+        if (!f) rc = BWAMS_ERR_IO;
+        else {
+            rc = stream_out(f, ix->d_ref, (size_t)(ix->fmi.ref_seq_len - 1));
+            if (fclose(f) != 0 && !rc) rc = BWAMS_ERR_IO;
+        }
+    }
+    if (rc == BWAMS_ERR_IO) set_last_error("write failed: " + path);
     return rc;
 }
 

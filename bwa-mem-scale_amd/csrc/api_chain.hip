@@ -775,6 +775,8 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
         if ((rc = scan_rows(b, s->dd_wide.as<int64_t>(), s->dd_off.as<int64_t>(), 1, n1))) return rc;
         launch_dedup_gather(D, s->dd_off.as<int64_t>(), s->dd_out.as<bwams_alnreg_t>(), st);
         BWAMS_HIP(hipMemcpyAsync(&total, s->dd_off.as<int64_t>() + s->nseq, 8, hipMemcpyDeviceToHost, st));
+    } else {
+        BWAMS_HIP(hipMemsetAsync(s->dd_off.p, 0, 8, st));          // an empty chunk: reg_off = {0}
     }
     BWAMS_HIP(hipEventRecord(s->ev[13], st));
     BWAMS_HIP(hipStreamSynchronize(st));

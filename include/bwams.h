@@ -82,6 +82,29 @@ int bwams_index_build_fma(bwams_index_t *idx, int all_bp, int last_bp);
 int bwams_index_set_fma(bwams_index_t *idx, const void *all_smem, int all_bp, const void *last_smem, int last_bp);
 int bwams_index_fetch_fma(bwams_index_t *idx, void *all_smem, void *last_smem);
 
+/* FM-index construction on the GPU.  Replaces `bwa-mem2.scale index`'s FMI_search::build_index +
+ * build_fm_index (src/FMI_search.cpp:774-849, :611-771; driver src/main.cpp -> bwa_index, src/bwtindex.cpp):
+ * text = fw || revcomp(fw), suffix array (prefix doubling on the device instead of host SA-IS), BWT,
+ * CP_OCC, SA samples.  The arrays equal the reference's byte for byte (they are functions of the suffix
+ * array).  fw: l_pac base codes 0..3, one per byte (N already replaced, as bns_fasta2bntseq does), in host
+ * memory or — fw_on_device != 0 — in this GPU's memory.  Texts up to 2^36 rows (GRCh38: 6.4 G rows, ~150 GB
+ * of HBM while building).  chunk_rows bounds the rows sorted at once (0 = 2^30).  stats may be NULL. */
+typedef struct bwams_build_stats {
+    int64_t rows;                      /* 2*l_pac + 1 */
+    int32_t chunks, rounds;            /* key-space chunks of the first pass; doubling rounds after it */
+    int64_t unresolved_after_first;    /* rows still tied after the 29-base pass */
+    float ms_first_pass, ms_outputs;   /* device time of the first pass / of BWT + CP_OCC + SA samples */
+} bwams_build_stats_t;
+int bwams_index_build(const uint8_t *fw, int64_t l_pac, int fw_on_device, int device, int keep_ref,
+                      int64_t chunk_rows, bwams_build_stats_t *stats, bwams_index_t **out);
+/* The resident arrays back to the host (any pointer may be NULL), e.g. to write the reference's files
+ * or to hand them to a CPU reader.  desc receives the scalars (count[] with the loader's +1). */
+int bwams_index_fetch(bwams_index_t *idx, bwams_cp_occ_t *cp_occ, int8_t *sa_ms_byte, uint32_t *sa_ls_word,
+                      uint8_t *ref_0123, bwams_fmi_desc_t *desc);
+/* Writes <prefix>.bwt.2bit.64 (and <prefix>.0123 when the index holds the text) in the reference's format
+ * (src/FMI_search.cpp:629-763, :796-829), streaming from HBM. */
+int bwams_index_save(bwams_index_t *idx, const char *prefix);
+
 int bwams_index_close(bwams_index_t *idx);
 int64_t bwams_index_bytes(const bwams_index_t *idx);
 

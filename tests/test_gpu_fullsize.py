@@ -10,23 +10,29 @@ from oracle import loader
 pytestmark = pytest.mark.gpu
 
 N_READS = 1_000_000
-GENOME = 48_000_000
+# two index sizes: 48 Mbp (quick) and GRCh38's own l_pac = 3 209 286 105 (src/bwa_shm.cpp:1386: 6 418 572 211 rows, beyond
+# 2^32), where every 64-bit row path of the kernels (36-bit interval packing, sa_ms_byte != 0, coordinates >= 2^32 in
+# chaining, extension and pairing) is live.  Both indexes are built on the GPU (bwams_index_build).
+GENOMES = {"48Mbp": 48_000_000, "GRCh38_size_6.4G_rows": 3_209_286_105}
 
 
-@pytest.fixture(scope="module")
-def big():
-    import torch
+@pytest.fixture(scope="module", params=list(GENOMES.keys()))
+def big(request):
     capi.lib()
-    g = simulate.make_genome(GENOME, seed=77)
-    idx_dev = fmindex.build_fmindex(g, device="cuda:0", keep_ref=True)
-    torch.cuda.synchronize()
-    ix = capi.Index.from_device(idx_dev, 0)
-    reads, _, _ = simulate.make_reads(g, N_READS, seed=99)
+    n = GENOMES[request.param]
+    g = simulate.make_genome(n, seed=77)
+    ix = capi.Index.build(g, 0)
+    contigs = simulate.chromosomes(n) if n >= 2 ** 31 else None      # bntann1_t.len is 32 bits: several sequences, as GRCh38
+    if contigs is not None:
+        ix.set_contigs(contigs)
+    host = ix.fetch()
+    assert host.ref_seq_len == 2 * n + 1
+    if n > 2_000_000_000:
+        assert host.ref_seq_len > 2 ** 32 and int(host.sa_ms_byte.max()) >= 1
+    assert np.array_equal(host.ref_0123[:n], g)
+    reads, _, _ = simulate.make_reads(g, N_READS, seed=99, contig_bounds=None if contigs is None else simulate.contig_bounds(contigs))
     enc, cum = simulate.flatten_reads(reads)
-    host = fmindex.FMIndex(idx_dev.ref_seq_len, idx_dev.count, idx_dev.cp_occ.cpu().numpy().view(np.uint64),
-                           idx_dev.sa_ms_byte.cpu().numpy(), idx_dev.sa_ls_word.cpu().numpy().view(np.uint32),
-                           idx_dev.sentinel_index, np.concatenate([g, (3 - g[::-1]).astype(np.uint8)]))
-    yield g, host, ix, reads, enc, cum
+    yield g, host, ix, reads, enc, cum, contigs
     ix.close()
 
 
@@ -40,13 +46,23 @@ def _run(b, opt):
 
 
 def test_million_reads_properties_and_sampled_parity(big):
-    g, host, ix, reads, enc, cum = big
+    g, host, ix, reads, enc, cum, contigs = big
     b = capi.Batch(ix, N_READS, int(cum[-1]))
     b.seed_upload(enc, cum)
     opt = capi.default_mem_opt()
     n, fin, off = _run(b, opt)
     sm, coord, sa_off = b.seed_fetch()
     # --- properties at full size
+    # every SA coordinate spells its seed (rows, SA samples and LF steps are right wherever they lie in the index)
+    rs = np.random.default_rng(3).choice(len(sm), size=min(len(sm), 200_000), replace=False)
+    rs = rs[(sa_off[rs + 1] > sa_off[rs])]
+    c0 = coord[sa_off[rs]]
+    ln = (sm["n"][rs] - sm["m"][rs] + 1).astype(np.int64)
+    assert np.all(c0 + ln <= len(host.ref_0123))
+    for t in range(0, 19):                                                   # min_seed_len bases of every sampled seed
+        assert np.array_equal(host.ref_0123[c0 + t], reads[sm["rid"][rs], sm["m"][rs] + t])
+    if host.ref_seq_len > 2 ** 32:
+        assert int(sm["k"].max()) >= 2 ** 32 and int(coord.max()) >= 2 ** 32 and int(fin["rb"].max()) >= 2 ** 32
     key = (sm["rid"].astype(np.int64) << 32) | (sm["m"].astype(np.int64) << 16) | sm["n"].astype(np.int64)
     assert np.all(np.diff(key) >= 0)                                         # mem_collect_smem's (rid, m, n) order
     assert off[0] == 0 and off[-1] == n == len(fin) and np.all(np.diff(off) >= 0)
@@ -82,9 +98,9 @@ def test_million_reads_properties_and_sampled_parity(big):
     osm = o.collect_smem(sub_enc, sub_cum)
     ocoord, ooff = o.sa_lookup(osm)
     l_pac = len(g)
-    ch, sd, choff = loader.chain_seeds(osm, ocoord, ooff, sub_cum, l_pac)
-    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, sub_enc, sub_cum, host.ref_0123, l_pac)
-    wfin, wfin_off = loader.regs_finish(regs, reg_off, sub_enc, sub_cum, host.ref_0123, l_pac)
+    ch, sd, choff = loader.chain_seeds(osm, ocoord, ooff, sub_cum, l_pac, contigs=contigs)
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, sub_enc, sub_cum, host.ref_0123, l_pac, contigs=contigs)
+    wfin, wfin_off = loader.regs_finish(regs, reg_off, sub_enc, sub_cum, host.ref_0123, l_pac, contigs=contigs)
     for k, r in enumerate(pick):
         a, w = fin[off[r]:off[r + 1]], wfin[wfin_off[k]:wfin_off[k + 1]]
         assert len(a) == len(w), r
@@ -96,9 +112,9 @@ def test_million_reads_properties_and_sampled_parity(big):
 def test_half_million_pairs_properties_and_sampled_parity(big):
     """The paired-end tail at full size (500 k pairs = 1 M reads): properties, idempotence, and — a pair's result
     depends only on its own two region lists, the statistics and its id — the oracle on a random sample of pairs."""
-    g, host, ix, _, _, _ = big
+    g, host, ix, _, _, _, contigs = big
     n_pairs = N_READS // 2
-    pr = simulate.make_read_pairs_bulk(g, n_pairs, seed=31)
+    pr = simulate.make_read_pairs_bulk(g, n_pairs, seed=31, contig_bounds=None if contigs is None else simulate.contig_bounds(contigs))
     enc, cum = simulate.flatten_reads(pr)
     b = capi.Batch(ix, N_READS, int(cum[-1]))
     b.seed_upload(enc, cum)
@@ -155,7 +171,7 @@ def test_half_million_pairs_properties_and_sampled_parity(big):
         sub_regs = fin[off[r0]:off[r0 + 2]]
         sub_cum = (cum[r0:r0 + 3] - cum[r0]).astype(np.int64)
         sub_enc = enc[cum[r0]:cum[r0 + 2]]
-        w, woff, wp = loader.pair_pe(sub_regs, sub_off, sub_enc, sub_cum, ref, l_pac, pes, id_base=ID0 + int(p))
+        w, woff, wp = loader.pair_pe(sub_regs, sub_off, sub_enc, sub_cum, ref, l_pac, pes, contigs=contigs, id_base=ID0 + int(p))
         assert np.array_equal(wp[0], pairs[p]), p
         got = out[ooff[r0]:ooff[r0 + 2]]
         assert np.array_equal(woff, ooff[r0:r0 + 3] - ooff[r0]), p

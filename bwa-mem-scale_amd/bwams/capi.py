@@ -422,6 +422,13 @@ class Batch:
         _chk(lib().bwams_seed_upload(self.h, _p(enc), _p(cum), _p(sk), len(cum) - 1), "bwams_seed_upload")
         self._nseq = len(cum) - 1
 
+    def seed_upload_device(self, enc_ptr: int, cum, skip=None):
+        """Same, with the read bytes already in this GPU's memory (enc_ptr = device address of the chunk's first base)."""
+        cum = np.ascontiguousarray(cum, dtype=np.int64)
+        sk = np.ascontiguousarray(skip, dtype=np.uint8) if skip is not None else None
+        _chk(lib().bwams_seed_upload(self.h, C.c_void_p(enc_ptr), _p(cum), _p(sk), len(cum) - 1), "bwams_seed_upload")
+        self._nseq = len(cum) - 1
+
     def seed_run(self, opt: SeedOpt | None = None, with_sa: bool = True):
         opt = opt or default_seed_opt()
         _chk(lib().bwams_seed_run(self.h, C.byref(opt), 1 if with_sa else 0), "bwams_seed_run")

@@ -39,35 +39,25 @@ def gather_smems(local_smems: np.ndarray, first_read: int, dist=None):
     sm["rid"] += np.uint32(first_read)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return sm
-    import torch
-    world = dist.get_world_size()
-    raw = torch.from_numpy(sm.view(np.uint8).reshape(-1).copy())
-    n = torch.tensor([raw.numel()], dtype=torch.int64)
-    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    mx = int(max(int(s.item()) for s in sizes))
-    pad = torch.zeros(mx, dtype=torch.uint8)
-    pad[:raw.numel()] = raw
-    bufs = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    parts = [bufs[r][:int(sizes[r].item())].numpy().view(sm.dtype) for r in range(world)]
-    return np.concatenate(parts)
+    return np.concatenate(_all_gather_bytes(sm, dist))
 
 
 def _all_gather_bytes(arr: np.ndarray, dist):
     """Per-rank list of the ranks' arrays (same dtype), via two all_gathers of padded byte buffers."""
     import torch
     world = dist.get_world_size()
-    raw = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy())
-    n = torch.tensor([raw.numel()], dtype=torch.int64)
-    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    # RCCL ("nccl") moves device buffers, gloo host buffers
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    raw = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()).to(dev)
+    n = torch.tensor([raw.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, n)
     mx = max(1, int(max(int(s.item()) for s in sizes)))
-    pad = torch.zeros(mx, dtype=torch.uint8)
+    pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
     pad[:raw.numel()] = raw
-    bufs = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)]
+    bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(bufs, pad)
-    return [bufs[r][:int(sizes[r].item())].numpy().view(arr.dtype) for r in range(world)]
+    return [bufs[r][:int(sizes[r].item())].cpu().numpy().view(arr.dtype) for r in range(world)]
 
 
 def gather_regions(regs: np.ndarray, reg_off: np.ndarray, n_chains: int, dist=None):

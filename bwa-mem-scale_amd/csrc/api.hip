@@ -528,7 +528,8 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
     b->max_read_len = mx;
     b->has_skip = skip != nullptr;
     b->seed_done = false;
-    if (nb) BWAMS_HIP(hipMemcpyAsync(b->d_enc, enc, (size_t)nb, hipMemcpyHostToDevice, b->stream));
+    // enc may already live in this GPU's memory (a caller that keeps several chunks resident): the copy kind is inferred
+    if (nb) BWAMS_HIP(hipMemcpyAsync(b->d_enc, enc, (size_t)nb, hipMemcpyDefault, b->stream));
     BWAMS_HIP(hipMemcpyAsync(b->d_cum, cum, (size_t)(nseq + 1) * 8, hipMemcpyHostToDevice, b->stream));
     if (skip && nseq) BWAMS_HIP(hipMemcpyAsync(b->d_skip, skip, (size_t)nseq, hipMemcpyHostToDevice, b->stream));
     // the source buffers belong to the caller: do not return before they are consumed

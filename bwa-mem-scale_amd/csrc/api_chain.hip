@@ -386,7 +386,7 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
 
     BWAMS_HIP(hipEventRecord(s->ev[0], st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_redo, 0, 2 * sizeof(unsigned long long), st));
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 16 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[6], chain_ticket[6], heavy_ticket
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 19 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[6], chain_ticket[6], heavy_ticket, heavy_tickets[3]
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all
     if ((sv.one_smem_quirk ? sv.n_smem <= 1 : sv.n_smem <= 0) || n_sa == 0) {
@@ -425,6 +425,15 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
     }
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
+    {
+        static const char *vb = getenv("BWAMS_VERBOSE");
+        if (vb && *vb && *vb != '0') {
+            const unsigned long long *d = b->h_ctr->dbg;
+            fprintf(stderr, "[bwams_chain_run] filter wave tier: reads by chains <=32 %llu <=64 %llu <=128 %llu <=256 %llu <=512 %llu <=960 %llu more %llu; "
+                            "Mcycles: sequential(HBM) %.1f sort %.1f filter %.1f; chains %llu selected %llu\n",
+                    d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7] / 1e6, d[8] / 1e6, d[9] / 1e6, d[11], d[10]);
+        }
+    }
     if (b->h_ctr->chain_overflow) {
         set_last_error("bwams_chain_run: internal B-tree node region exhausted");
         return BWAMS_ERR_CAPACITY;

@@ -43,7 +43,6 @@ constexpr int KB_T = 5;
 constexpr int KB_MAXK = 2 * KB_T - 1;
 constexpr int kLaneSeeds = 32;       // reads with more seeds than this are chained by a whole wave (chain_wave_kernel)
 constexpr int kLightChains = 16;     // reads with more chains than this go to chain_heavy_kernel
-constexpr int kLdsChains = 960;      // chains the heavy kernel keeps in LDS (41 B each: four blocks per CU)
 struct alignas(16) Node {            // 144 B = nine 16-byte loads
     int16_t n, internal;
     int16_t ptr[KB_MAXK + 1];        // node ids relative to the read's node region
@@ -691,30 +690,49 @@ __global__ __launch_bounds__(64) void chain_redo_kernel(ChainArgs A) {
 }
 
 // ---- reads with many chains: one wave per read ---------------------------------------------------
-__global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsigned long long *n_heavy_p) {
-    __shared__ uint2 l_fl[kLdsChains];
-    __shared__ uint4 l_rec[kLdsChains];        // by sorted position: {beg, end, w | alt, first}
-    __shared__ uint4 l_sel[kLdsChains];        // the kept ("selected") chains, in selection order: {beg, end, w | alt, position}
-    __shared__ uint8_t l_kept[kLdsChains];
+// Size classes (chains per read): each class is its own launch with the LDS its largest read needs — 41 B per chain —
+// so that the many reads with a few dozen chains run 12 waves to a CU instead of sharing the footprint of the rare read
+// with thousands (reads in repeat families reach max_occ hits per SMEM: on a GRCh38-size index a read can carry > 2000
+// chains, and the quadratic filter of such a read on one lane through HBM took 40 ms).  Every launch walks the whole
+// list of many-chain reads with its own ticket counter and skips the other classes' reads.
+constexpr int kHeavyCap[3] = {256, 960, 3840};         // 10.5 / 39 / 157 KB of LDS
+__host__ __device__ constexpr size_t heavy_lds_bytes(int cap) { return (size_t)cap * 41 + 64; }
+static_assert(heavy_lds_bytes(kHeavyCap[2]) <= 160 * 1024, "the largest class must fit one CU's LDS");
+
+__global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsigned long long *n_heavy_p, int cap_lo, int cap,
+                                                         unsigned long long *ticket) {
+    extern __shared__ __align__(16) unsigned char l_heavy[];
+    uint4 *l_rec = reinterpret_cast<uint4 *>(l_heavy);                   // by sorted position: {beg, end, w | alt, first}
+    uint4 *l_sel = l_rec + cap;                // the kept ("selected") chains, in selection order: {beg, end, w | alt, position}
+    uint2 *l_fl = reinterpret_cast<uint2 *>(l_sel + cap);
+    uint8_t *l_kept = reinterpret_cast<uint8_t *>(l_fl + cap);
+    const int kLdsChains = cap;
     const int lane = threadIdx.x;
     const int64_t n_heavy = (int64_t)*n_heavy_p;
     for (;;) {
-        const int64_t hi = (int64_t)wave_ticket(&A.ctr->heavy_ticket, 1ull);
+        const int64_t hi = (int64_t)wave_ticket(ticket, 1ull);
         if (hi >= n_heavy) break;
         const int64_t r = A.heavy[hi];
         const int64_t base = A.read_base[r];
         const int n_chn = A.n_chn[r];
+        if (n_chn <= cap_lo || (n_chn > cap && cap != kHeavyCap[2])) continue;          // another class's read
         const int L = (int)(A.cum[r + 1] - A.cum[r]);
         uint2 *fl = A.flt + base;
         uint4 *rec = A.f_rec + base;
         int32_t *kept = A.f_kept + base;
         const ChainRec *crec = reinterpret_cast<const ChainRec *>(A.crec) + base;
+        const unsigned long long t_0 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            const int bk = n_chn <= 32 ? 0 : n_chn <= 64 ? 1 : n_chn <= 128 ? 2 : n_chn <= 256 ? 3 : n_chn <= 512 ? 4 : n_chn <= 960 ? 5 : 6;
+            atomicAdd(&A.ctr->dbg[bk], 1ull);
+        }
         if (n_chn > kLdsChains) {              // beyond the LDS budget: the sequential form, on lane 0
             if (lane == 0) {
                 flt_introsort(fl, n_chn);
                 for (int i = 0; i < n_chn; ++i) { rec[i] = make_rec(A, crec[fl[i].y], fl[i].x); kept[i] = 0; }
                 filter_seq(A.opt, n_chn, rec, kept, A.f_sel + base);
                 finish_read(A, r, base, n_chn, L);
+                atomicAdd(&A.ctr->dbg[7], __builtin_amdgcn_s_memtime() - t_0);
             }
             continue;
         }
@@ -723,6 +741,7 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
         __syncthreads();
         if (lane == 0) flt_introsort(l_fl, n_chn);           // ksort's order is inherently sequential
         __syncthreads();
+        const unsigned long long t_1 = __builtin_amdgcn_s_memtime();
         for (int i = lane; i < n_chn; i += 64) {
             const uint2 f = l_fl[i];
             l_rec[i] = make_rec(A, crec[f.y], f.x);
@@ -784,6 +803,13 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
             if (f >= 0) l_kept[f] = 1;
         }
         __syncthreads();
+        if (lane == 0) {
+            const unsigned long long t_2 = __builtin_amdgcn_s_memtime();
+            atomicAdd(&A.ctr->dbg[8], t_1 - t_0);
+            atomicAdd(&A.ctr->dbg[9], t_2 - t_1);
+            atomicAdd(&A.ctr->dbg[10], (unsigned long long)n_sel);
+            atomicAdd(&A.ctr->dbg[11], (unsigned long long)n_chn);
+        }
         // max_chain_extend (bwamem.cpp:618-625) can only bite when it is smaller than the chain count
         if (A.opt.max_chain_extend <= n_chn) {
             if (lane == 0) {
@@ -908,7 +934,24 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;
     }
     chain_redo_kernel<<<(unsigned)(cu_count * 2), 64, 0, st>>>(A);
-    chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, 0, st>>>(A, &A.ctr->n_heavy);
+    // the filter of the many-chain reads: three size classes, concurrently, the class of the longest reads first
+    static bool heavy_attr = false;
+    if (!heavy_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)heavy_lds_bytes(kHeavyCap[2]));
+        heavy_attr = true;
+    }
+    if (hipEventRecord(fork, st) != hipSuccess) return -1;
+    for (int i = 0; i < 2; ++i)
+        if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
+    unsigned long long *htk = A.ctr->heavy_tickets;
+    chain_heavy_kernel<<<(unsigned)cu_count, 64, heavy_lds_bytes(kHeavyCap[2]), aux[0]>>>(A, &A.ctr->n_heavy, kHeavyCap[1], kHeavyCap[2], htk + 2);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, heavy_lds_bytes(kHeavyCap[1]), aux[1]>>>(A, &A.ctr->n_heavy, kHeavyCap[0], kHeavyCap[1], htk + 1);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 12), 64, heavy_lds_bytes(kHeavyCap[0]), st>>>(A, &A.ctr->n_heavy, 0, kHeavyCap[0], htk + 0);
+    for (int i = 0; i < 2; ++i) {
+        if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
+        if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;
+    }
     return 0;
 }
 void launch_chain_emit(const ChainArgs &A, const int64_t *chain_off, const int64_t *seed_off, bwams_chain_t *chains,

@@ -69,13 +69,15 @@ struct DevCounters {
     unsigned long long n_heavy;          // chaining: reads handed to the wave-per-read filter kernel
     unsigned long long chain_class[6];   // chaining: reads with more seeds than the L, L1, M, M1, S and lane-tier limits
     unsigned long long chain_ticket[6];  // chaining: work cursors of the wave kernels
-    unsigned long long heavy_ticket;     // chaining: work cursor of chain_heavy_kernel
+    unsigned long long heavy_ticket;     // (unused)
+    unsigned long long heavy_tickets[3]; // chaining: work cursors of chain_heavy_kernel's size classes
     unsigned long long n_retry;          // extension: tasks queued for the next band width
     unsigned long long n_req;            // extension: seeds requested by the last selection
     unsigned long long sel_heavy, sel_ticket;       // extension: reads of the selection's wave tier, its work cursor
     unsigned long long dedup_heavy, dedup_ticket, dedup_light;   // dedup: reads for the wave tier, its work cursor, reads for the lane tier
     unsigned long long chain_redo, chain_redo_ticket;   // chaining: reads the ordered-array attempt gave up on, work cursor
     unsigned long long pair_heavy, pair_ticket;   // mem_mark_primary_se: reads of the wave tier, its work cursor
+    unsigned long long dbg[16];          // diagnostics printed under BWAMS_VERBOSE (chain_heavy_kernel: size histogram, cycles)
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };
 

@@ -144,6 +144,7 @@ int bwams_seed_fmi(bwams_batch_t *b,
 /* The same in three steps, so that reads stay resident in HBM across calls and
  * uploads/downloads can overlap other work: upload -> run (asynchronous on the
  * batch's stream) -> fetch (synchronises). */
+/* (enc_qdb may be a host pointer or a pointer into this GPU's memory; cum_len and skip are host arrays.) */
 int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc_qdb, const int64_t *cum_len,
                       const uint8_t *skip, int64_t nseq);
 int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa);

@@ -43,6 +43,16 @@ static int check_device(int device) {
 }
 
 void chain_state_stats(const ChainState *s, bwams_stats_t *out);   // api_chain.hip
+
+int bsw_list_ensure(bwams_batch *b, int64_t n_tasks) {
+    if (n_tasks <= b->cap_bsw_list) return BWAMS_OK;
+    BWAMS_HIP(hipStreamSynchronize(b->stream));
+    if (b->d_bsw_list) (void)hipFree(b->d_bsw_list);
+    b->d_bsw_list = nullptr;
+    b->cap_bsw_list = n_tasks + n_tasks / 4 + 1024;
+    BWAMS_HIP(hipMalloc(&b->d_bsw_list, bsw_list_bytes(b->cap_bsw_list)));
+    return BWAMS_OK;
+}
 int fmi_build_device(bwams_index *ix, const uint8_t *d_fw, int64_t l_pac, int keep_ref, int64_t chunk_rows, int verbose,
                      bwams_build_stats_t *bs);                   // fmi_build.hip
 
@@ -478,7 +488,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_pairs, b->d_ref, b->d_qer};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -822,8 +832,9 @@ int bwams_bsw_run(bwams_batch_t *b, int32_t w, const bwams_sw_opt_t *o) {
     }
     prm.max_sc = mx;
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->bsw_cells, 0, sizeof(unsigned long long), b->stream));
+    if (int lrc = bsw_list_ensure(b, b->n_pairs)) return lrc;
     BWAMS_HIP(hipEventRecord(b->ev[6], b->stream));
-    if (launch_bsw(b->d_pairs, b->n_pairs, b->d_ref, b->d_qer, w, prm, b->max_qlen, b->d_ctr, b->cu_count, b->stream)) {
+    if (launch_bsw(b->d_pairs, b->n_pairs, b->d_ref, b->d_qer, w, prm, b->max_qlen, b->d_ctr, b->cu_count, b->stream, b->d_bsw_list)) {
         set_last_error("bwams_bsw_run: a query longer than ~18000 bases does not fit the LDS kernel");
         return BWAMS_ERR_UNSUPPORTED;
     }

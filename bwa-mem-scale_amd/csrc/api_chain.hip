@@ -637,7 +637,8 @@ static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, 
     if (n == 0) return BWAMS_OK;
     unsigned long long *d_nretry = &b->d_ctr->n_retry;
     BWAMS_HIP(hipMemsetAsync(d_nretry, 0, sizeof(unsigned long long), st));
-    if (int lrc = launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st, s->aux, s->fork, s->join)) {
+    if (int erc = bsw_list_ensure(b, n)) return erc;
+    if (int lrc = launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st, b->d_bsw_list, s->aux, s->fork, s->join)) {
         set_last_error(lrc == -2 ? "banded SW: a query longer than ~18000 bases does not fit the LDS kernel" : "banded SW: stream fork/join failed");
         return lrc == -2 ? BWAMS_ERR_UNSUPPORTED : BWAMS_ERR_DEVICE;
     }
@@ -646,7 +647,7 @@ static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, 
     BWAMS_HIP(hipMemcpyAsync(&nr, d_nretry, sizeof nr, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     if (nr) {
-        if (launch_bsw(s->retry.as<bwams_seqpair_t>(), (int64_t)nr, ref, qer, A.opt.w << 1, prm, qmax, b->d_ctr, b->cu_count, st, s->aux, s->fork, s->join)) return BWAMS_ERR_DEVICE;
+        if (launch_bsw(s->retry.as<bwams_seqpair_t>(), (int64_t)nr, ref, qer, A.opt.w << 1, prm, qmax, b->d_ctr, b->cu_count, st, b->d_bsw_list, s->aux, s->fork, s->join)) return BWAMS_ERR_DEVICE;
         launch_ext_post(A, right, s->retry.as<bwams_seqpair_t>(), (int64_t)nr, A.opt.w << 1, 1, nullptr, d_nretry, st);
     }
     *n_retry_out += (int64_t)nr;

@@ -45,8 +45,10 @@ __device__ __forceinline__ int wave_max(int v) {
 
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,
-    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qmax, int qlo, DevCounters *ctr, unsigned long long *head) {
+    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qmax, int qlo, DevCounters *ctr, unsigned long long *head,
+    const int32_t *__restrict__ list, const unsigned long long *n_list) {
     extern __shared__ __align__(16) unsigned char lds[];
+    n = (int64_t)*n_list;                              // this kernel walks the list of tasks left to the one-task-per-wave kernels
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
     int2 *eh = reinterpret_cast<int2 *>(lds + wave * per_wave);
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
             pid_end = pid + kTaskChunk < n ? pid + kTaskChunk : n;
             if (pid >= n) break;
         }
-        const int64_t cur = pid++;
+        const int64_t cur = list[pid++];
 
         const bwams_seqpair_t sp = pairs[cur];
         const int qlen = sp.len2, tlen = sp.len1, h0 = sp.h0;
@@ -218,171 +220,261 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     if (lane == 0 && cells) atomicAdd(&ctr->bsw_cells, cells);
 }
 
-// ---- register-resident variant -----------------------------------------------------------
-// Same algorithm as bsw_kernel, for queries of at most 64 * NCH bases: each column's (h, e)
-// lives in registers of its owner lane, cross-lane traffic is DPP only (row_shr / row_bcast /
-// wave_shr: no LDS, no ds_bpermute), the target row is broadcast with v_readlane from a
-// 64-row register slab that is prefetched one slab ahead.
-template <int NCH>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
-    bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,
-    const uint8_t *__restrict__ qer, int w0, SwParams prm, int qlo, DevCounters *ctr, unsigned long long *head) {
-    const int lane = threadIdx.x & 63;
+// ---- four tasks per wavefront ---------------------------------------------------------------
+// bsw_kernel above spends one wavefront on one task, with the row's band bookkeeping (beg, end, row maximum and its
+// column, z-drop, ...) in scalar registers: measured, a row of <= 128 cells cost ~110 vector but ~250 scalar
+// instructions, and the one scalar unit of a CU serves four SIMDs (profiles/r01_notes.md 26-28) — the scalar pipe,
+// not the vector one, bounded the one-task-per-wave kernels.  In bsw_qwin_kernel a task owns one DPP ROW (16 lanes), so
+//   * four tasks share a wavefront and every cross-lane step is a row-local DPP operation (row_shr scans for the
+//     max-plus prefix of F and the H shift, row_ror butterflies for the four per-row reductions);
+//   * the bookkeeping lives in vector registers, replicated over the task's 16 lanes: no scalar work per row at all;
+//   * a quarter that finishes its task takes the next one from the wave's reservation while the others carry on.
+// Tasks are binned by query length first (bsw_classify_kernel) — the class fixes the LDS per task — one launch per
+// class, concurrently.  Results are bit-identical to scalarBandedSWA: the recurrences and every per-row decision are
+// those of bsw_kernel above.
+constexpr int kQuadCpl[5] = {2, 4, 6, 9, 12};                 // a class holds queries of <= 16 * kQuadCpl - 1 bases (16 * kQuadCpl columns of LDS)
+constexpr int kNumBswClass = 6;                              // five quad classes + the rest (one task per wave, LDS)
+constexpr int kQuadChunk = 16;                               // tasks a wave reserves per atomic
+
+__host__ __device__ __forceinline__ int bsw_class_of(int qlen, int h0, int max_sc) {
+    // the row maximum and its column travel as one key (h << 8 | j): needs h < 2^22 and j < 256
+    const long long top = (long long)h0 + (long long)qlen * max_sc;       // no score of the task can exceed it
+    if (qlen > 16 * kQuadCpl[4] - 1 || top >= (1 << 22) || h0 < 0) return 5;
+    return qlen <= 16 * kQuadCpl[0] - 1 ? 0 : qlen <= 16 * kQuadCpl[1] - 1 ? 1 : qlen <= 16 * kQuadCpl[2] - 1 ? 2
+           : qlen <= 16 * kQuadCpl[3] - 1 ? 3 : 4;
+}
+
+// list[c * n + k] = k-th task of class c (any order: results go back by task index)
+__global__ void bsw_classify_kernel(const bwams_seqpair_t *__restrict__ pairs, int64_t n, int max_sc, int32_t *__restrict__ list,
+                                    unsigned long long *cnt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cls = t < n ? bsw_class_of(pairs[t].len2, pairs[t].h0, max_sc) : -1;
+#pragma unroll
+    for (int c = 0; c < kNumBswClass; ++c) {
+        // every lane of the class adds its own 1: no lane-leader branch (the pattern of wave_ops.h's wave_ticket note);
+        // the order inside a class list is immaterial
+        if (cls == c) list[(int64_t)c * n + (int64_t)atomicAdd(&cnt[c], 1ull)] = (int32_t)t;
+    }
+}
+
+// row-local (16-lane) DPP helpers.  A VALU write followed by a DPP read of the same register needs two wait states.
+__device__ __forceinline__ int row_scan_max(int v) {            // inclusive prefix max over the lanes of a DPP row
+    asm("s_nop 4\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int row_all_max(int v) {             // maximum over the 16 lanes of a DPP row, in every lane
+    asm("s_nop 4\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int row_shr1(int v, int fill) { return dppi<0x111, 0xF, 0xF>(fill, v); }   // lane g gets lane g - 1's v; lane 0 the fill
+
+// ---- four tasks per wavefront, row state in LDS, a 48-column register window that follows the band -------------
+// A kernel whose cost follows the query length computes mostly dead columns: the band of a typical extension is
+// narrow: ~23 live columns per row on the bench workload, because it shrinks to the non-zero span of the previous row.
+// Here the row state eh[] of a task lives in LDS (8 B per column: H | E + the query base), and each row loads just the
+// live columns [beg, end) into a window of kWin = 3 columns per lane (48 per task), computes them (F as a prefix
+// maximum: a lane's own columns sequentially, then four DPP steps over the lanes), and stores them back; a band wider than 48 columns takes further passes with the prefix maximum and
+// the last H carried over.  Columns outside the band keep their stale values in LDS, as scalarBandedSWA's eh[] does.
+constexpr int kWin = 3;
+
+__global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
+    bwams_seqpair_t *__restrict__ pairs, const int32_t *__restrict__ list, const unsigned long long *n_list_p,
+    const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, int w0, SwParams prm, DevCounters *ctr, unsigned long long *head,
+    int cols) {
+    extern __shared__ uint2 qwin_lds[];                            // [wave][quarter][cols]: {H, E | query base << 28}
+    const int lane = threadIdx.x & 63, g = lane & 15, q = lane >> 4;
+    uint2 *const row_eh = qwin_lds + (size_t)(((threadIdx.x >> 6) * 4 + q) * cols);
     const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int pk[5], pn[5];                                              // score rows of the matrix, one per target base
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        pk[t] = (int)(((uint32_t)(uint8_t)prm.mat[t * 5 + 0]) | ((uint32_t)(uint8_t)prm.mat[t * 5 + 1] << 8) |
+                      ((uint32_t)(uint8_t)prm.mat[t * 5 + 2] << 16) | ((uint32_t)(uint8_t)prm.mat[t * 5 + 3] << 24));
+        pn[t] = prm.mat[t * 5 + 4];
+    }
+    const int64_t n_list = (int64_t)*n_list_p;
+    const unsigned long long kLeaders = 0x0001000100010001ull;
+    int64_t pid = 0, pid_end = 0;
+    bool exhausted = false;
+    bool alive = false;
+    int cur = 0, qlen = 0, tlen = 0, h0 = 0, w = 0, i = 0, beg = 0, end = 0;
+    int mx = 0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, tb_next = 4;
+    const uint8_t *tr = ref;
     unsigned long long cells = 0;
 
-    int64_t pid = 0, pid_end = 0;          // this wave's reserved task range
-    while (true) {
-        if (pid >= pid_end) {
-            pid = (int64_t)wave_ticket(head, (unsigned long long)kTaskChunk);   // out of line: see wave_ops.h
-            pid_end = pid + kTaskChunk < n ? pid + kTaskChunk : n;
-            if (pid >= n) break;
+    for (;;) {
+        const unsigned long long need_m = __ballot(!alive);
+        if (need_m) {
+            if (pid >= pid_end && !exhausted) {
+                pid = (int64_t)wave_ticket(head, (unsigned long long)kQuadChunk);
+                pid_end = pid + kQuadChunk < n_list ? pid + kQuadChunk : n_list;
+                if (pid >= n_list) { exhausted = true; pid_end = pid; }
+            }
+            const int avail = (int)(pid_end - pid);
+            const int nq = __popcll(need_m & kLeaders);
+            const int rank = __popcll(need_m & kLeaders & ((1ull << (q * 16)) - 1ull));
+            if (!alive && rank < avail) {
+                cur = list[pid + rank];
+                const bwams_seqpair_t sp = pairs[cur];
+                qlen = sp.len2; tlen = sp.len1; h0 = sp.h0;
+                const uint8_t *tq = qer + sp.idq;
+                tr = ref + sp.idr;
+                for (int c = g; c <= qlen; c += 16) {             // row -1 of the DP and the query, 16 columns at a time
+                    int h = h0;
+                    if (c >= 1) { h = h0 - oe_ins - (c - 1) * e_ins; h = h > 0 ? h : 0; }
+                    uint32_t qb = c < qlen ? (uint32_t)tq[c] : 4u;
+                    qb = qb > 4u ? 4u : qb;
+                    row_eh[c] = make_uint2((uint32_t)h, qb << 28);
+                }
+                w = w0;
+                {
+                    int max_ins = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_ins) / e_ins + 1.);
+                    max_ins = max_ins > 1 ? max_ins : 1;
+                    w = w < max_ins ? w : max_ins;
+                    int max_del = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_del) / e_del + 1.);
+                    max_del = max_del > 1 ? max_del : 1;
+                    w = w < max_del ? w : max_del;
+                }
+                mx = h0; max_i = -1; max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+                beg = 0; end = qlen; i = 0;
+                alive = tlen > 0;
+                if (!alive && g == 0) {
+                    bwams_seqpair_t *o = &pairs[cur];
+                    o->score = mx; o->qle = 0; o->tle = 0; o->gtle = 0; o->gscore = -1; o->max_off = 0;
+                }
+                tb_next = alive ? (int)tr[0] : 4;
+            }
+            pid += nq < avail ? nq : avail;
+            if (exhausted && !__any(alive)) break;
         }
-        const int64_t cur = pid++;
-        const int qlen = __builtin_amdgcn_readfirstlane(pairs[cur].len2);
-        if (qlen <= qlo || qlen > 64 * NCH) continue;           // another variant's task
-        const int tlen = __builtin_amdgcn_readfirstlane(pairs[cur].len1);
-        const int h0 = __builtin_amdgcn_readfirstlane(pairs[cur].h0);
-        const uint8_t *tq = qer + __builtin_amdgcn_readfirstlane(pairs[cur].idq);
-        const uint8_t *tr = ref + __builtin_amdgcn_readfirstlane(pairs[cur].idr);
 
-        // query profile: the scores of column j against target bases 0..3 packed as four int8 (one v_bfe_i32 per cell
-        // instead of a select tree), against N separately
-        int H[NCH], E[NCH], JE[NCH], PK[NCH], P4[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int j = c * 64 + lane;
-            int h = 0;
-            if (j == 0) h = h0;
-            else if (j <= qlen) { h = h0 - oe_ins - (j - 1) * e_ins; h = h > 0 ? h : 0; }
-            H[c] = h;
-            E[c] = 0;
-            JE[c] = j * e_ins;
-            const int qj = j < qlen ? tq[j] : 4;
-            PK[c] = (int)(((uint32_t)(uint8_t)prm.mat[0 * 5 + qj]) | ((uint32_t)(uint8_t)prm.mat[1 * 5 + qj] << 8) |
-                          ((uint32_t)(uint8_t)prm.mat[2 * 5 + qj] << 16) | ((uint32_t)(uint8_t)prm.mat[3 * 5 + qj] << 24));
-            P4[c] = prm.mat[4 * 5 + qj];
+        // ---- one row of every live task
+        int tb = tb_next;
+        tb = tb > 4 ? 4 : tb;
+        if (alive && i + 1 < tlen) tb_next = tr[i + 1];
+        const int pkt = tb == 0 ? pk[0] : tb == 1 ? pk[1] : tb == 2 ? pk[2] : tb == 3 ? pk[3] : pk[4];
+        const int pnt = tb == 0 ? pn[0] : tb == 1 ? pn[1] : tb == 2 ? pn[2] : tb == 3 ? pn[3] : pn[4];
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        int h1 = 0;
+        if (beg == 0) {
+            h1 = h0 - (o_del + e_del * (i + 1));
+            h1 = h1 < 0 ? 0 : h1;
         }
-        int w = w0;
-        {
-            int max_ins = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_ins) / e_ins + 1.);
-            max_ins = max_ins > 1 ? max_ins : 1;
-            w = w < max_ins ? w : max_ins;
-            int max_del = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_del) / e_del + 1.);
-            max_del = max_del > 1 ? max_del : 1;
-            w = w < max_del ? w : max_del;
+        const bool row = alive && beg < end;
+        int key = -1, first_nz = 1 << 20, last_nz = -1, hlast = -1;
+        int c_max = NEG, c_h = h1;                                  // carried into a further pass: prefix maximum, last H
+        for (int base = beg; __any(row && base < end); base += 16 * kWin) {
+            const bool in = row && base < end;
+            const int jb = base + g * kWin;
+            int Mv[kWin], Pl[kWin], Ev[kWin];
+            uint32_t Qb[kWin];
+            int run = NEG;
+#pragma unroll
+            for (int c = 0; c < kWin; ++c) {
+                const int j = jb + c;
+                const bool act = in && j < end;
+                uint2 wd = make_uint2(0u, 0u);
+                if (act) wd = row_eh[j];
+                const int hd = (int)wd.x, e = (int)(wd.y & 0x0fffffffu);
+                const uint32_t qb = wd.y >> 28;
+                const int S = qb < 4u ? __builtin_amdgcn_sbfe(pkt, qb << 3, 8u) : pnt;
+                const int M = (act && hd) ? hd + S : 0;
+                int tj = M - oe_ins;
+                tj = tj > 0 ? tj : 0;
+                const int x = act ? tj + j * e_ins : NEG;
+                run = run > x ? run : x;
+                Mv[c] = M; Pl[c] = run; Ev[c] = e; Qb[c] = qb;
+            }
+            const int scan = row_scan_max(run);
+            int Lex = row_shr1(scan, NEG);
+            Lex = Lex > c_max ? Lex : c_max;
+            int Hh[kWin], E2[kWin];
+#pragma unroll
+            for (int c = 0; c < kWin; ++c) {
+                const int j = jb + c;
+                int Pex = c ? Pl[c - 1] : NEG;
+                Pex = Pex > Lex ? Pex : Lex;
+                int F = Pex - (j - 1) * e_ins;
+                F = F > 0 ? F : 0;
+                const int e = Ev[c];
+                int h = Mv[c] > e ? Mv[c] : e;
+                h = h > F ? h : F;
+                int e2 = Mv[c] - oe_del;
+                e2 = e2 > 0 ? e2 : 0;
+                const int e1 = e - e_del;
+                e2 = e2 > e1 ? e2 : e1;
+                Hh[c] = h; E2[c] = e2;
+            }
+            const int h_in = row_shr1(Hh[kWin - 1], c_h);
+#pragma unroll
+            for (int c = 0; c < kWin; ++c) {
+                const int j = jb + c;
+                const bool act = in && j < end;
+                int hl = c ? Hh[c - 1] : h_in;
+                if (j == beg) hl = h1;
+                if (act) {
+                    row_eh[j] = make_uint2((uint32_t)hl, (uint32_t)E2[c] | (Qb[c] << 28));
+                    const int k = (Hh[c] << 8) | j;
+                    key = key > k ? key : k;
+                    if (hl != 0 || E2[c] != 0) { first_nz = first_nz < j ? first_nz : j; last_nz = j; }
+                    if (j == end - 1) hlast = Hh[c];
+                }
+            }
+            if (__any(row && base + 16 * kWin < end)) {            // a further pass: carry the prefix maximum and the last column's H
+                const int pm = row_all_max(scan);
+                c_max = c_max > pm ? c_max : pm;
+                c_h = row_all_max(g == 15 ? Hh[kWin - 1] : -1);
+            }
         }
-        int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
-        int beg = 0, end = qlen;
-        bool done = false;
-        int tslab_next = lane < tlen ? tr[lane] : 4;
-        for (int rb = 0; rb < tlen && !done; rb += 64) {
-            const int tslab = tslab_next;
-            if (rb + 64 < tlen) tslab_next = (rb + 64 + lane < tlen) ? tr[rb + 64 + lane] : 4;
-            const int rlim = tlen - rb < 64 ? tlen - rb : 64;
-            for (int ri = 0; ri < rlim; ++ri) {
-                const int i = rb + ri;
-                const int tb = __builtin_amdgcn_readlane(tslab, ri);
-                if (beg < i - w) beg = i - w;
-                if (end > i + w + 1) end = i + w + 1;
-                if (end > qlen) end = qlen;
-                int h1 = 0;
-                if (beg == 0) {
-                    h1 = h0 - (o_del + e_del * (i + 1));
-                    if (h1 < 0) h1 = 0;
-                }
-                int m = 0, mj = -1;
-                int first_nz = 1 << 30, last_nz = -1;
-                int h_last = h1;
-                if (beg < end) {
-                    cells += (unsigned long long)(end - beg);
-                    const int c_lo = beg >> 6, c_hi = (end - 1) >> 6;
-                    // phase A — per chunk, independent of the other chunks: diagonal move, gap-open
-                    // source and its prefix maximum (the scans of different chunks overlap in the pipeline)
-                    int Mv[NCH], Tj[NCH], Pm[NCH];
-                    bool Act[NCH];
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        Mv[c] = 0; Tj[c] = 0; Pm[c] = NEG; Act[c] = false;
-                        if (c < c_lo || c > c_hi) continue;
-                        const int j = (c << 6) + lane;
-                        const bool act = j >= beg && j < end;
-                        const int S = tb < 4 ? __builtin_amdgcn_sbfe(PK[c], (unsigned)(tb << 3), 8u) : P4[c];
-                        const int hd = H[c];
-                        const int M = (act && hd) ? hd + S : 0;
-                        int tj = M - oe_ins;
-                        tj = tj > 0 ? tj : 0;
-                        Mv[c] = M; Tj[c] = tj; Act[c] = act;
-                        Pm[c] = scan_max(act ? tj + JE[c] : NEG);
-                    }
-                    // phase B — stitch the chunks: F from all columns to the left, H, E, shifted H
-                    int carry_src = NEG, carry_h = 0, hmax_lane = -1;
-                    int Hc[NCH];
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        Hc[c] = 0;
-                        if (c < c_lo || c > c_hi) continue;
-                        const int j = (c << 6) + lane;
-                        int Pex = lane_shr1(Pm[c], carry_src);
-                        Pex = Pex > carry_src ? Pex : carry_src;
-                        int F = Pex - (JE[c] - e_ins);
-                        F = F > 0 ? F : 0;                                  // F(beg) = 0, F >= 0 everywhere
-                        const int e = E[c];
-                        int h = Mv[c] > e ? Mv[c] : e;
-                        h = h > F ? h : F;
-                        int e2 = Mv[c] - oe_del;
-                        e2 = e2 > 0 ? e2 : 0;
-                        const int e1 = e - e_del;
-                        e2 = e2 > e1 ? e2 : e1;
-                        int hl = lane_shr1(h, carry_h);
-                        if (j == beg) hl = h1;
-                        if (Act[c]) { H[c] = hl; E[c] = e2; }
-                        Hc[c] = h;
-                        hmax_lane = max(hmax_lane, Act[c] ? h : -1);
-                        const unsigned long long nz = __ballot(Act[c] && (hl != 0 || e2 != 0));
-                        if (nz) {
-                            const int lo = (c << 6) + __ffsll((long long)nz) - 1;
-                            first_nz = first_nz < lo ? first_nz : lo;
-                            last_nz = (c << 6) + 63 - __clzll((long long)nz);
-                        }
-                        carry_h = __builtin_amdgcn_readlane(h, 63);
-                        const int cs = __builtin_amdgcn_readlane(Pm[c], 63);
-                        carry_src = carry_src > cs ? carry_src : cs;
-                        if (c == c_hi) h_last = __builtin_amdgcn_readlane(h, (end - 1) & 63);
-                    }
-                    // row maximum over all chunks (one scan) and the last column attaining it
-                    m = __builtin_amdgcn_readlane(scan_max(hmax_lane), 63);
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        if (c < c_lo || c > c_hi) continue;
-                        const unsigned long long eq = __ballot(Act[c] && Hc[c] == m);
-                        if (eq) mj = (c << 6) + 63 - __clzll((long long)eq);
-                    }
-                }
-                const int j_exit = beg < end ? end : beg;
-                const int h1f = beg < end ? h_last : h1;
-                // eh[end] = {h1f, 0}: column `end` is a real cell only while end < 64 * NCH
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-                    if ((end >> 6) == c && (end & 63) == lane) { H[c] = h1f; E[c] = 0; }
-                if (j_exit == qlen) {
-                    max_ie = gscore > h1f ? max_ie : i;
-                    gscore = gscore > h1f ? gscore : h1f;
-                }
-                if (m == 0) { done = true; break; }
+        key = row_all_max(key);
+        first_nz = -row_all_max(-first_nz);
+        last_nz = row_all_max(last_nz);
+        hlast = row_all_max(hlast);
+        const int m = row ? key >> 8 : 0, mj = row ? key & 0xff : -1;
+        const int h1f = row ? hlast : h1;
+        if (alive) {
+            if (g == 0) {                                           // eh[end] = {h1f, 0}
+                const uint2 we = row_eh[end];
+                row_eh[end] = make_uint2((uint32_t)h1f, we.y & 0xf0000000u);
+            }
+            if (row) cells += (unsigned long long)(g == 0 ? end - beg : 0);
+            const int j_exit = row ? end : beg;
+            if (j_exit == qlen) {
+                max_ie = gscore > h1f ? max_ie : i;
+                gscore = gscore > h1f ? gscore : h1f;
+            }
+            bool fin = m == 0;
+            if (!fin) {
                 if (m > mx) {
                     mx = m; max_i = i; max_j = mj;
                     int d = mj - i;
                     d = d < 0 ? -d : d;
                     max_off = max_off > d ? max_off : d;
                 } else if (prm.zdrop > 0) {
-                    if (i - max_i > mj - max_j) {
-                        if (mx - m - ((i - max_i) - (mj - max_j)) * e_del > prm.zdrop) { done = true; break; }
-                    } else {
-                        if (mx - m - ((mj - max_j) - (i - max_i)) * e_ins > prm.zdrop) { done = true; break; }
-                    }
+                    if (i - max_i > mj - max_j) fin = mx - m - ((i - max_i) - (mj - max_j)) * e_del > prm.zdrop;
+                    else fin = mx - m - ((mj - max_j) - (i - max_i)) * e_ins > prm.zdrop;
                 }
+            }
+            if (!fin) {
                 const int nbeg = first_nz < end ? first_nz : end;
                 int jj;
                 if (h1f != 0) jj = end;
@@ -390,49 +482,54 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel_reg(
                 else jj = nbeg - 1;
                 beg = nbeg;
                 end = jj + 2 < qlen ? jj + 2 : qlen;
+                ++i;
+                fin = i >= tlen;
+            }
+            if (fin) {
+                if (g == 0) {
+                    bwams_seqpair_t *o = &pairs[cur];
+                    o->score = mx; o->qle = max_j + 1; o->tle = max_i + 1; o->gtle = max_ie + 1; o->gscore = gscore; o->max_off = max_off;
+                }
+                alive = false;
             }
         }
-        if (lane == 0) {
-            bwams_seqpair_t *o = &pairs[cur];
-            o->score = mx;
-            o->qle = max_j + 1;
-            o->tle = max_i + 1;
-            o->gtle = max_ie + 1;
-            o->gscore = gscore;
-            o->max_off = max_off;
-        }
     }
+    for (int o = 32; o > 0; o >>= 1) cells += ((unsigned long long)__shfl_down((unsigned)(cells >> 32), o) << 32) | (unsigned)__shfl_down((unsigned)cells, o);
     if (lane == 0 && cells) atomicAdd(&ctr->bsw_cells, cells);
 }
 
+
 __global__ void bsw_reset_kernel(DevCounters *ctr) {
     for (int i = 0; i < 4; ++i) ctr->bsw_head[i] = 0;      // bsw_cells accumulates until the caller clears it
+    for (int i = 0; i < kNumBswClass; ++i) ctr->bsw_cls_cnt[i] = ctr->bsw_cls_head[i] = 0;
 }
 
 }  // namespace
 
-// One kernel per query-length class (register-resident for 1..64, 65..128, 129..192 bases, LDS-resident
-// beyond), each with its own ticket counter.  With auxiliary streams the classes run concurrently, so
-// the tail of one overlaps the body of the next.
+// Tasks are binned (bsw_classify_kernel) by query length into five four-tasks-per-wave launches and, for what is left
+// (queries beyond 191 bases, scores beyond 2^22), the one-task-per-wave LDS kernel.  Every launch has its own ticket counter; with auxiliary
+// streams they run concurrently, the classes of the longest queries first.  `list` holds kNumBswClass * n task indices.
 int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w, const SwParams &prm, int qmax,
-               DevCounters *ctr, int cu_count, hipStream_t st, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join) {
+               DevCounters *ctr, int cu_count, hipStream_t st, int32_t *list, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join) {
     bsw_reset_kernel<<<1, 1, 0, st>>>(ctr);
     if (n <= 0) return 0;
+    bsw_classify_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pairs, n, prm.max_sc, list, ctr->bsw_cls_cnt);
     int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t maxb = (int64_t)cu_count * 8;
     if (blocks > maxb) blocks = maxb;
-    const int n_class = qmax > 192 ? 4 : qmax > 128 ? 3 : qmax > 64 ? 2 : 1;
     hipStream_t q[4] = {st, st, st, st};
-    if (aux && n_class > 1) {
+    const int n_aux = aux ? 3 : 0;
+    if (n_aux) {
         if (hipEventRecord(fork, st) != hipSuccess) return -1;
-        for (int c = 1; c < n_class; ++c) {
-            q[c] = aux[c - 1];
-            if (hipStreamWaitEvent(q[c], fork, 0) != hipSuccess) return -1;
+        for (int c = 0; c < n_aux; ++c) {
+            q[c + 1] = aux[c];
+            if (hipStreamWaitEvent(q[c + 1], fork, 0) != hipSuccess) return -1;
         }
     }
-    // the longest queries first: their tasks are the most expensive
-    if (n_class > 3) {
-        // (h, e) row + query of one task per wave in LDS: fewer waves per block for very long queries
+    const unsigned B = (unsigned)blocks, T = kWavesPerBlock * 64;
+    unsigned long long *cnt = ctr->bsw_cls_cnt, *hd = ctr->bsw_cls_head;
+    {
+        // what neither packed form can take: (h, e) row + query of one task per wave in LDS, fewer waves per block for very long queries
         const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
         int waves = (int)((size_t)160 * 1024 / per_wave);
         if (waves < 1) return -2;                  // a query of more than ~18 k bases does not fit a CU's LDS
@@ -443,18 +540,21 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int64_t lblocks = (n + waves - 1) / waves;
         if (lblocks > maxb) lblocks = maxb;
-        bsw_kernel<<<(unsigned)lblocks, waves * 64, lds, q[3]>>>(pairs, n, ref, qer, w, prm, qmax, 192, ctr, &ctr->bsw_head[3]);
+        bsw_kernel<<<(unsigned)lblocks, waves * 64, lds, q[3]>>>(pairs, n, ref, qer, w, prm, qmax, -1, ctr, &ctr->bsw_head[3], list + 5 * n, cnt + 5);
     }
-    if (n_class > 2) bsw_kernel_reg<3><<<(unsigned)blocks, kWavesPerBlock * 64, 0, q[2]>>>(pairs, n, ref, qer, w, prm, 128, ctr, &ctr->bsw_head[2]);
-    if (n_class > 1) bsw_kernel_reg<2><<<(unsigned)blocks, kWavesPerBlock * 64, 0, q[1]>>>(pairs, n, ref, qer, w, prm, 64, ctr, &ctr->bsw_head[1]);
-    bsw_kernel_reg<1><<<(unsigned)blocks, kWavesPerBlock * 64, 0, q[0]>>>(pairs, n, ref, qer, w, prm, -1, ctr, &ctr->bsw_head[0]);
-    if (aux && n_class > 1)
-        for (int c = 1; c < n_class; ++c) {
-            if (hipEventRecord(join[c - 1], q[c]) != hipSuccess) return -1;
-            if (hipStreamWaitEvent(st, join[c - 1], 0) != hipSuccess) return -1;
+    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 192 * 8, q[2]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
+    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 144 * 8, q[1]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
+    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 96 * 8, q[0]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
+    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 64 * 8, q[2]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
+    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 32 * 8, q[1]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
+    if (n_aux)
+        for (int c = 0; c < n_aux; ++c) {
+            if (hipEventRecord(join[c], q[c + 1]) != hipSuccess) return -1;
+            if (hipStreamWaitEvent(st, join[c], 0) != hipSuccess) return -1;
         }
     return 0;
 }
+size_t bsw_list_bytes(int64_t n) { return (size_t)kNumBswClass * (size_t)(n > 0 ? n : 1) * sizeof(int32_t); }
 
 size_t bsw_lds_bytes(int qmax) {
     const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;

@@ -61,7 +61,8 @@ struct DevCounters {
     unsigned long long n_work2;          // round-2 work items
     unsigned long long overflow;         // SMEM pool overflow flag / needed size
     unsigned long long bsw_cells;
-    unsigned long long bsw_head[4];      // ticket counters of the banded-SW class kernels
+    unsigned long long bsw_head[4];      // ticket counters of the one-task-per-wave banded-SW kernels
+    unsigned long long bsw_cls_cnt[6], bsw_cls_head[6];   // banded SW: tasks per query-length class, ticket counters of the class launches
     unsigned long long ext_after[3], blk_after[3];
     unsigned long long emf_nodes, emf_cmp_bytes;     // EMF probe: entries visited, reference bytes compared   // n_ext / n_ext_blocks when round 1, 2, 3 ended
     unsigned long long chain_overflow;   // chaining: B-tree node region exhausted (never expected)
@@ -97,8 +98,9 @@ struct Round2Work {
 };
 
 int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w, const SwParams &prm, int qmax,
-               DevCounters *ctr, int cu_count, hipStream_t st, hipStream_t *aux = nullptr, hipEvent_t fork = nullptr,
+               DevCounters *ctr, int cu_count, hipStream_t st, int32_t *list, hipStream_t *aux = nullptr, hipEvent_t fork = nullptr,
                hipEvent_t *join = nullptr);
+size_t bsw_list_bytes(int64_t n_tasks);          // scratch `list` of launch_bsw
 size_t bsw_lds_bytes(int qmax);
 void launch_emf_probe(const DevEmf &t, const uint8_t *enc, const int64_t *cum, int64_t nseq, uint32_t *out,
                       uint8_t *code, uint8_t *skip, DevCounters *ctr, hipStream_t st);
@@ -119,6 +121,10 @@ struct bwams_index {
     void *d_contigs = nullptr;                   // bwams_contig_t[n_seqs] (owned); null = one sequence [0, l_pac)
     int32_t n_seqs = 0;
 };
+
+namespace bwams {
+int bsw_list_ensure(bwams_batch *b, int64_t n_tasks);   // grows b->d_bsw_list (synchronises the stream when it must reallocate)
+}
 
 struct bwams_emf {
     bwams_index *idx = nullptr;
@@ -178,6 +184,8 @@ struct bwams_batch {
     int64_t cap_emf = 0;
     void *d_ksw_out = nullptr;
     int64_t cap_ksw = 0;
+    int32_t *d_bsw_list = nullptr;       // task lists of the banded-SW length classes (launch_bsw)
+    int64_t cap_bsw_list = 0;            // tasks it is sized for
 
     bwams::ChainState *chain = nullptr;
 

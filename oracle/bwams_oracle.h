@@ -156,6 +156,8 @@ typedef struct orc_bns {            /* the fields of bntseq_t the path reads */
 } orc_bns_t;
 
 /* test hooks for the pinned pieces */
+uint64_t orc_hash_64(uint64_t key);
+int64_t orc_depos(int64_t l_pac, int64_t pos, int *is_rev);
 int64_t orc_kbt_script(int64_t n, const int64_t *pos, const uint8_t *do_put, int32_t *lower, int32_t *order);
 void orc_flt_sort(int64_t n, const uint32_t *w, int32_t *order);
 

@@ -971,3 +971,7 @@ void orc_task_dump_free(orc_task_dump_t *d)
     free(d->left); free(d->right); free(d->left_ref); free(d->left_qer); free(d->right_ref); free(d->right_qer);
     memset(d, 0, sizeof *d);
 }
+
+/* exported for the pin against bns_depos (bntseq.h:88-91) */
+int64_t orc_depos(int64_t l_pac, int64_t pos, int *is_rev) { orc_bns_t b; b.l_pac = l_pac; b.n_seqs = 0; b.contigs = 0; return depos(&b, pos, is_rev); }
+

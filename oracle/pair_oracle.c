@@ -395,3 +395,7 @@ int64_t orc_pair_pe(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint
     out_off[2 * (int64_t)n_pairs] = n_out;
     return n_out;
 }
+
+/* exported for the pins of tests/test_oracle_pair.py against the reference headers (utils.h:117-128, bntseq.h:88-91) */
+uint64_t orc_hash_64(uint64_t key) { return hash_64(key); }
+

@@ -14,6 +14,20 @@
 #include "bandedSWA.h"   /* /root/reference/src, via -I */
 #include "ksw.h"
 
+#include <stddef.h>
+#include "../include/bwams_types.h"
+/* the records that cross the C-ABI are the reference's own, byte for byte (bandedSWA.h:90-99, ksw.h:43-48) */
+#define SAME_FIELD(T, U, f) static_assert(offsetof(T, f) == offsetof(U, f) && sizeof(((T *)0)->f) == sizeof(((U *)0)->f), #f)
+static_assert(sizeof(SeqPair) == sizeof(bwams_seqpair_t) && sizeof(SeqPair) == 56, "SeqPair");
+SAME_FIELD(SeqPair, bwams_seqpair_t, idr); SAME_FIELD(SeqPair, bwams_seqpair_t, idq); SAME_FIELD(SeqPair, bwams_seqpair_t, id);
+SAME_FIELD(SeqPair, bwams_seqpair_t, len1); SAME_FIELD(SeqPair, bwams_seqpair_t, len2); SAME_FIELD(SeqPair, bwams_seqpair_t, h0);
+SAME_FIELD(SeqPair, bwams_seqpair_t, seqid); SAME_FIELD(SeqPair, bwams_seqpair_t, regid); SAME_FIELD(SeqPair, bwams_seqpair_t, score);
+SAME_FIELD(SeqPair, bwams_seqpair_t, tle); SAME_FIELD(SeqPair, bwams_seqpair_t, gtle); SAME_FIELD(SeqPair, bwams_seqpair_t, qle);
+SAME_FIELD(SeqPair, bwams_seqpair_t, gscore); SAME_FIELD(SeqPair, bwams_seqpair_t, max_off);
+static_assert(sizeof(kswr_t) == sizeof(bwams_kswr_t) && sizeof(kswr_t) == 28, "kswr_t");
+SAME_FIELD(kswr_t, bwams_kswr_t, score); SAME_FIELD(kswr_t, bwams_kswr_t, te); SAME_FIELD(kswr_t, bwams_kswr_t, qe);
+SAME_FIELD(kswr_t, bwams_kswr_t, score2); SAME_FIELD(kswr_t, bwams_kswr_t, te2); SAME_FIELD(kswr_t, bwams_kswr_t, tb); SAME_FIELD(kswr_t, bwams_kswr_t, qb);
+
 extern "C" {
 
 struct ref_sw_opt {

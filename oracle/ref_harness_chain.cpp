@@ -9,8 +9,11 @@
 #include <assert.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "kbtree.h"
 #include "ksort.h"
+#include "utils.h"      /* hash_64 */
+#include "bntseq.h"     /* bns_depos */
 
 typedef struct {
     int32_t id, pad0[5];
@@ -78,6 +81,16 @@ void ref_flt_sort(int64_t n, const uint32_t *w, int32_t *order)
     ks_introsort(mem_flt, n, a);
     for (int64_t i = 0; i < n; ++i) order[i] = a[i].id;
     free(a);
+}
+
+/* hash_64 (utils.h:117-128) and bns_depos (bntseq.h:88-91): header-only inlines */
+uint64_t ref_hash_64(uint64_t key) { return hash_64(key); }
+int64_t ref_bns_depos(int64_t l_pac, int64_t pos, int *is_rev)
+{
+    bntseq_t b;
+    memset(&b, 0, sizeof b);
+    b.l_pac = l_pac;
+    return bns_depos(&b, pos, is_rev);
 }
 
 }  // extern "C"

@@ -107,3 +107,25 @@ def test_ert_variant_of_mate_rescue():
         same += k0 == k1
     assert same >= len(pr0) - 4
     assert (pr1["score"] > 0).sum() >= (pr0["score"] > 0).sum() - 2
+
+
+def test_hash_64_and_bns_depos_equal_the_reference_headers():
+    """hash_64 (utils.h:117-128) and bns_depos (bntseq.h:88-91) are header-only inlines: the reference's own, compiled into
+    oracle/_ref/libref_chain.so, against the restatements the pairing / chaining oracles use."""
+    import ctypes as C
+    R = loader.ref_chain_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    L = loader.lib()
+    R.ref_hash_64.restype = L.orc_hash_64.restype = C.c_uint64
+    R.ref_hash_64.argtypes = L.orc_hash_64.argtypes = [C.c_uint64]
+    R.ref_bns_depos.restype = L.orc_depos.restype = C.c_int64
+    R.ref_bns_depos.argtypes = L.orc_depos.argtypes = [C.c_int64, C.c_int64, C.c_void_p]
+    rng = np.random.default_rng(12)
+    keys = list(rng.integers(0, 2 ** 63, size=5000, dtype=np.uint64)) + [0, 1, 2 ** 64 - 1, 2 ** 32, 7_000_000]
+    for k in keys:
+        assert R.ref_hash_64(int(k)) == L.orc_hash_64(int(k))
+    l_pac = 3_209_286_105
+    for pos in list(rng.integers(0, 2 * l_pac, size=3000)) + [0, l_pac - 1, l_pac, 2 * l_pac - 1]:
+        a, b = C.c_int(-1), C.c_int(-1)
+        assert R.ref_bns_depos(l_pac, int(pos), C.byref(a)) == L.orc_depos(l_pac, int(pos), C.byref(b)) and a.value == b.value

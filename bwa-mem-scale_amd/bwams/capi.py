@@ -25,7 +25,7 @@ SEQPAIR_DTYPE = np.dtype([(n, "<i4") for n in
 SYMBOLS = [
     "bwams_strerror", "bwams_last_error", "bwams_device_count",
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
-    "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
@@ -57,6 +57,10 @@ ALNREG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i
                          ("csub", "<i4"), ("sub_n", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"),
                          ("secondary_all", "<i4"), ("seedlen0", "<i4"), ("n_comp_is_alt", "<i4"), ("frac_rep", "<f4"),
                          ("pad1_", "<i4"), ("hash", "<u8"), ("flg", "<i4"), ("pad2_", "<i4")])
+ALN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("flag", "<i4"), ("is_rev", "<i4"), ("is_alt", "<i4"), ("mapq", "<i4"),
+                      ("NM", "<i4"), ("n_cigar", "<i4"), ("md_len", "<i4"), ("cigar_off", "<i8"), ("md_off", "<i8"),
+                      ("score", "<i4"), ("sub", "<i4"), ("alt_sc", "<i4"), ("pad_", "<i4")])
+assert ALN_DTYPE.itemsize == 72
 assert CONTIG_DTYPE.itemsize == 16 and CHAIN_SEED_DTYPE.itemsize == 32 and CHAIN_DTYPE.itemsize == 48
 assert ALNREG_DTYPE.itemsize == 112
 
@@ -85,7 +89,7 @@ class MemOpt(C.Structure):
                 ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
                 ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
                 ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float), ("max_ins", C.c_int32),
-                ("b", C.c_int32), ("pen_unpaired", C.c_int32), ("max_matesw", C.c_int32)]
+                ("b", C.c_int32), ("pen_unpaired", C.c_int32), ("max_matesw", C.c_int32), ("mapq_coef_len", C.c_int32)]
 
 
 class FmiDesc(C.Structure):
@@ -149,6 +153,7 @@ def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
     o.mask_level_redun = 0.95
     o.max_ins = 10000
     o.b, o.pen_unpaired, o.max_matesw = b, 17, 50
+    o.mapq_coef_len = 50
     sw = default_sw_opt(5, a, b)
     for i in range(25):
         o.mat[i] = sw.mat[i]
@@ -187,6 +192,8 @@ def lib():
         L.bwams_index_build.argtypes = [vp, i64, C.c_int, C.c_int, C.c_int, i64, vp, vp]
         L.bwams_index_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
         L.bwams_index_save.argtypes = [vp, C.c_char_p]
+        L.bwams_reg2aln_run.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.bwams_reg2aln_fetch.argtypes = [vp, vp, i64, vp, i64, vp, i64]
         L.bwams_index_build_fma.argtypes = [vp, C.c_int, C.c_int]
         L.bwams_index_set_fma.argtypes = [vp, vp, C.c_int, vp, C.c_int]
         L.bwams_index_fetch_fma.argtypes = [vp, vp, vp]
@@ -561,6 +568,17 @@ class Batch:
              "bwams_chain_run_ert")
         self._n_chain = (nc.value, ns.value)
         return self._n_chain
+
+    def reg2aln(self, opt: MemOpt | None = None, source: int = 0):
+        """mem_reg2aln over the final regions (source 0: after dedup_run; 1: after pair_run): (records, CIGAR pool, MD pool)."""
+        opt = opt or default_mem_opt()
+        n, nc, nm = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _chk(lib().bwams_reg2aln_run(self.h, C.byref(opt), source, C.byref(n), C.byref(nc), C.byref(nm)), "bwams_reg2aln_run")
+        aln = np.zeros(max(n.value, 1), ALN_DTYPE)
+        cig = np.zeros(max(nc.value, 1), np.uint32)
+        md = np.zeros(max(nm.value, 1), np.uint8)
+        _chk(lib().bwams_reg2aln_fetch(self.h, _p(aln), len(aln), _p(cig), len(cig), _p(md), len(md)), "bwams_reg2aln_fetch")
+        return aln[:n.value], cig[:nc.value], md[:nm.value]
 
     def pestat_keys(self, opt: MemOpt | None = None) -> np.ndarray:
         """One key per qualifying pair of this batch (orientation << 60 | insert size), sorted."""

@@ -51,6 +51,10 @@ struct ChainState {
     DevBuf er_wide, er_off, er_scr, er_n, er_rev, er_out, er_ooff;   // mem_perfect2reg
     int64_t er_total = 0, er_nseq = 0;
     bool er_done = false;
+    DevBuf al_need, al_cls, al_off, al_scr, al_list, al_rec, al_wide, al_offs, al_cig, al_md, al_cnt;   // mem_reg2aln
+    int64_t al_n = 0, al_ncig = 0, al_nmd = 0;
+    int al_source = 0;
+    bool al_done = false;
     int64_t n_final = 0;
     bool dedup_done = false;
     int64_t n_chains = 0, n_seeds = 0, nseq = 0, n_chain_redo = 0;
@@ -75,7 +79,7 @@ void chain_state_free(ChainState *s) {
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
                      &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->pr_na, &s->pr_wide, &s->pr_offs, &s->pr_anchor, &s->pr_slot, &s->pr_task, &s->pr_trb, &s->pr_tl1, &s->pr_twide, &s->pr_toffs,
                      &s->pr_pairs, &s->pr_tref, &s->pr_tqer, &s->pr_aln, &s->pr_pool, &s->pr_ord, &s->pr_srt, &s->pr_z, &s->pr_nfin, &s->pr_npri, &s->pr_nsw, &s->pr_full, &s->pr_owide,
-                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->al_need, &s->al_cls, &s->al_off, &s->al_scr, &s->al_list, &s->al_rec, &s->al_wide, &s->al_offs, &s->al_cig, &s->al_md, &s->al_cnt, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -961,6 +965,124 @@ int bwams_pair_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, in
     if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->pr_ooff.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
     if (pairs && s->nseq > 1) BWAMS_HIP(hipMemcpyAsync(pairs, s->pr_res.p, (size_t)(s->nseq / 2) * sizeof(bwams_pair_t), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
+    return BWAMS_OK;
+}
+
+/* ------------------------------------------------------------- mem_reg2aln ---- */
+
+// mem_approx_mapq_se (bwamem.cpp:1983-2008) on the host: a dozen double operations per region, with the C library's log
+static int approx_mapq_se(const bwams_mem_opt_t *opt, const bwams_alnreg_t *a) {
+    int mapq, l, sub = a->sub ? a->sub : opt->min_seed_len * opt->a;
+    double identity;
+    const int coef_len = opt->mapq_coef_len;
+    const double coef_fac = coef_len > 0 ? log((double)coef_len) : 0.;
+    sub = a->csub > sub ? a->csub : sub;
+    if (sub >= a->score) return 0;
+    l = a->qe - a->qb > a->re - a->rb ? a->qe - a->qb : (int)(a->re - a->rb);
+    identity = 1. - (double)(l * opt->a - a->score) / (opt->a + opt->b) / l;
+    if (a->score == 0) mapq = 0;
+    else if (coef_len > 0) {
+        double tmp = l < coef_len ? 1. : coef_fac / log(l);
+        tmp *= identity * identity;
+        mapq = (int)(6.02 * (a->score - sub) / opt->a * tmp * tmp + .499);
+    } else {
+        mapq = (int)(30.0 * (1. - (double)sub / a->score) * log(a->seedcov) + .499);
+        mapq = identity < 0.95 ? (int)(mapq * identity * identity + .499) : mapq;
+    }
+    if (a->sub_n > 0) mapq -= (int)(4.343 * log(a->sub_n + 1) + .499);
+    if (mapq > 60) mapq = 60;
+    if (mapq < 0) mapq = 0;
+    mapq = (int)(mapq * (1. - a->frac_rep) + .499);
+    return mapq;
+}
+
+int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t source, int64_t *n_aln, int64_t *n_cigar_ops,
+                      int64_t *md_bytes) {
+    if (!b || !b->chain || (source == 0 && !b->chain->dedup_done) || (source == 1 && !b->chain->pair_done) || source < 0 || source > 1) {
+        set_last_error("bwams_reg2aln_run: run bwams_dedup_run (source 0) or bwams_pair_run (source 1) first");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_reg2aln_run");
+    if (rc) return rc;
+    if (!b->idx->d_ref) {
+        set_last_error("bwams_reg2aln_run: the index was opened without its .0123 reference");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    s->al_done = false;
+    const int64_t n = source ? s->pr_total : s->n_final;
+    RegAlnArgs A;
+    memset(&A, 0, sizeof A);
+    A.regs = source ? s->pr_out.as<bwams_alnreg_t>() : s->dd_out.as<bwams_alnreg_t>();
+    A.reg_off = source ? s->pr_ooff.as<int64_t>() : s->dd_off.as<int64_t>();
+    A.n_regs = n; A.nseq = s->nseq;
+    A.enc = b->d_enc; A.cum = b->d_cum; A.ref = b->idx->fmi.ref;
+    if ((rc = dev_bns(b->idx, &A.bns))) return rc;
+    A.opt = *opt;
+    const int64_t n1 = n + 1;
+    BWAMS_HIP(s->al_need.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->al_cls.ensure((size_t)n1 * 4));
+    BWAMS_HIP(s->al_off.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->al_list.ensure((size_t)n1 * 3 * 4));
+    BWAMS_HIP(s->al_rec.ensure((size_t)n1 * sizeof(bwams_aln_t)));
+    BWAMS_HIP(s->al_wide.ensure((size_t)(2 * n1) * 8));
+    BWAMS_HIP(s->al_offs.ensure((size_t)(2 * n1) * 8));
+    BWAMS_HIP(s->al_cnt.ensure(64));
+    A.need = s->al_need.as<int64_t>(); A.cls = s->al_cls.as<int32_t>(); A.scr_off = s->al_off.as<int64_t>();
+    A.list = s->al_list.as<int32_t>(); A.n_list = s->al_cnt.as<unsigned long long>(); A.rec = s->al_rec.as<bwams_aln_t>();
+    int64_t tot[2] = {0, 0};
+    if (n > 0) {
+        BWAMS_HIP(hipMemsetAsync(s->al_cnt.p, 0, 64, st));
+        BWAMS_HIP(hipMemsetAsync(s->al_need.as<int64_t>() + n, 0, 8, st));
+        launch_aln_plan(A, st);
+        if ((rc = scan_rows(b, A.need, s->al_off.as<int64_t>(), 1, n1))) return rc;
+        int64_t scr_bytes = 0;
+        BWAMS_HIP(hipMemcpyAsync(&scr_bytes, s->al_off.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        BWAMS_HIP(s->al_scr.ensure((size_t)scr_bytes + 64));
+        A.scr = s->al_scr.as<uint8_t>();
+        launch_aln_run(A, b->cu_count, st);
+        launch_aln_sizes(A, s->al_wide.as<int64_t>(), st);
+        if ((rc = scan_rows(b, s->al_wide.as<int64_t>(), s->al_offs.as<int64_t>(), 2, n1))) return rc;
+        BWAMS_HIP(hipMemcpyAsync(&tot[0], s->al_offs.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipMemcpyAsync(&tot[1], s->al_offs.as<int64_t>() + n1 + n, 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        BWAMS_HIP(s->al_cig.ensure((size_t)(tot[0] + 1) * 4));
+        BWAMS_HIP(s->al_md.ensure((size_t)tot[1] + 16));
+        launch_aln_gather(A, s->al_offs.as<int64_t>(), s->al_cig.as<uint32_t>(), s->al_md.as<char>(), st);
+        BWAMS_HIP(hipStreamSynchronize(st));
+        BWAMS_HIP(hipGetLastError());
+    }
+    s->al_n = n; s->al_ncig = tot[0]; s->al_nmd = tot[1]; s->al_source = source; s->al_done = true;
+    s->opt = *opt;
+    if (n_aln) *n_aln = n;
+    if (n_cigar_ops) *n_cigar_ops = tot[0];
+    if (md_bytes) *md_bytes = tot[1];
+    return BWAMS_OK;
+}
+
+int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uint32_t *cigar, int64_t cigar_cap, char *md, int64_t md_cap) {
+    if (!b || !b->chain || !b->chain->al_done) {
+        set_last_error("bwams_reg2aln_fetch: run bwams_reg2aln_run first");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    if (s->al_n > aln_cap || s->al_ncig > cigar_cap || s->al_nmd > md_cap) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    std::vector<bwams_alnreg_t> regs((size_t)s->al_n);
+    if (s->al_n) {
+        BWAMS_HIP(hipMemcpyAsync(aln, s->al_rec.p, (size_t)s->al_n * sizeof(bwams_aln_t), hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipMemcpyAsync(regs.data(), s->al_source ? s->pr_out.p : s->dd_out.p, (size_t)s->al_n * sizeof(bwams_alnreg_t),
+                                 hipMemcpyDeviceToHost, st));
+        if (s->al_ncig) BWAMS_HIP(hipMemcpyAsync(cigar, s->al_cig.p, (size_t)s->al_ncig * 4, hipMemcpyDeviceToHost, st));
+        if (s->al_nmd) BWAMS_HIP(hipMemcpyAsync(md, s->al_md.p, (size_t)s->al_nmd, hipMemcpyDeviceToHost, st));
+    }
+    BWAMS_HIP(hipStreamSynchronize(st));
+    for (int64_t k = 0; k < s->al_n; ++k)
+        if (aln[k].rid >= 0) aln[k].mapq = regs[(size_t)k].secondary < 0 ? approx_mapq_se(&s->opt, &regs[(size_t)k]) : 0;
     return BWAMS_OK;
 }
 

@@ -218,4 +218,27 @@ struct ErtArgs {
 void launch_ert_sort(const ErtArgs &A, hipStream_t st);
 void launch_ert_pick(const ErtArgs &A, const int64_t *sa_off, int64_t *coord, hipStream_t st);
 
+// ---- SAM-side alignment: mem_reg2aln -> bwa_gen_cigar2 -> ksw_global2 with traceback (reg2aln.hip) ----
+struct RegAlnArgs {
+    const bwams_alnreg_t *regs;    // final regions, grouped by read
+    const int64_t *reg_off;        // nseq + 1
+    int64_t n_regs, nseq;
+    const uint8_t *enc;
+    const int64_t *cum;
+    const uint8_t *ref;            // .0123
+    DevBns bns;
+    bwams_mem_opt_t opt;
+    int64_t *need;                 // per region: bytes of scratch
+    int32_t *cls;                  // per region: -2 rejected, -1 no DP, 0 / 1 LDS ring class, 2 HBM row
+    const int64_t *scr_off;        // per region: offset into scr
+    uint8_t *scr;
+    int32_t *list;                 // 3 * n_regs: regions that need DP, by class
+    unsigned long long *n_list;    // 3 counters
+    bwams_aln_t *rec;
+};
+void launch_aln_plan(const RegAlnArgs &A, hipStream_t st);
+void launch_aln_run(const RegAlnArgs &A, int cu_count, hipStream_t st);
+void launch_aln_sizes(const RegAlnArgs &A, int64_t *wide, hipStream_t st);
+void launch_aln_gather(const RegAlnArgs &A, const int64_t *offs, uint32_t *cig, char *md, hipStream_t st);
+
 }  // namespace bwams

@@ -199,6 +199,19 @@ int bwams_emf_probe(bwams_batch_t *b, bwams_emf_t *emf, const uint8_t *enc_qdb, 
 int bwams_emf_run(bwams_batch_t *b, bwams_emf_t *emf);
 int bwams_emf_fetch(bwams_batch_t *b, bwams_perfect_t *out, uint8_t *code);
 
+/* ------------------------------------------------- alignments for SAM (f3) ---- */
+
+/* CIGAR, NM, MD, position and mapping quality of every final region of the chunk.  Replaces, per region, mem_reg2aln
+ * (src/bwamem.cpp:2533-2628; called from mem_reg2sam, :2318, and mem_sam_pe, src/bwamem_pair.cpp) with what it calls:
+ * bwa_gen_cigar2 (src/bwa.cpp:380-467) -> ksw_global2 with traceback (src/ksw.cpp:558-668), and mem_approx_mapq_se
+ * (src/bwamem.cpp:1983-2008).  source 0: the regions bwams_dedup_run left (single-end), 1: those of bwams_pair_run.
+ * fetch returns one bwams_aln_t per region in region order, the CIGAR pool (uint32 opLen << 4 | op) and the MD pool
+ * (NUL-terminated strings); the XA string and the SAM text stay on the host. */
+int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t source, int64_t *n_aln, int64_t *n_cigar_ops,
+                      int64_t *md_bytes);
+int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uint32_t *cigar, int64_t cigar_cap, char *md,
+                        int64_t md_cap);
+
 /* ----------------------------------------------------------- mate rescue ---- */
 
 /* Local Smith-Waterman of mate rescue over n tasks: out[i] = ksw_align2(len2, qer + idq,

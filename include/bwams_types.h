@@ -126,6 +126,7 @@ typedef struct bwams_mem_opt {
     int32_t b;                          /* mismatch penalty, 4: mem_mark_primary_se and mem_pair read a + b */
     int32_t pen_unpaired;               /* 17: anchors of mate rescue score >= best - pen_unpaired */
     int32_t max_matesw;                 /* 50: anchors per end that mate rescue tries */
+    int32_t mapq_coef_len;              /* mapQ_coef_len, 50 (mapQ_coef_fac = log(mapQ_coef_len)): read by mem_approx_mapq_se */
 } bwams_mem_opt_t;
 
 /* mem_pestat_t (src/bwamem.h:178-182), same layout. */
@@ -205,6 +206,19 @@ typedef struct bwams_alnreg {
     int32_t  flg;
     int32_t  pad2_;
 } bwams_alnreg_t;
+
+/* mem_aln_t (src/bwamem.h:184-194) as mem_reg2aln fills it, with the bit fields widened and the CIGAR / MD pointer replaced
+ * by offsets into the flat CIGAR (uint32 opLen << 4 | op, op: MIDSH = 01234) and MD (NUL-terminated strings) pools. */
+typedef struct bwams_aln {
+    int64_t  pos;            /* forward-strand 5'-end position within the sequence */
+    int32_t  rid;            /* sequence index; < 0 for the unmapped record */
+    int32_t  flag;           /* 0x4 unmapped, 0x100 secondary */
+    int32_t  is_rev, is_alt, mapq, NM;
+    int32_t  n_cigar, md_len;        /* md_len counts the terminating NUL */
+    int64_t  cigar_off, md_off;
+    int32_t  score, sub, alt_sc;
+    int32_t  pad_;
+} bwams_aln_t;
 
 #ifdef __cplusplus
 }

@@ -156,6 +156,12 @@ typedef struct orc_bns {            /* the fields of bntseq_t the path reads */
 } orc_bns_t;
 
 /* test hooks for the pinned pieces */
+/* SAM-side alignment (aln_oracle.c): ksw_global2 with traceback (pinned), mem_approx_mapq_se, mem_reg2aln (unpinned) */
+int orc_ksw_global2_cigar(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del,
+                          int e_del, int o_ins, int e_ins, int w, int *n_cigar, uint32_t *cigar);
+int orc_approx_mapq_se(const bwams_mem_opt_t *opt, const bwams_alnreg_t *a);
+int orc_reg2aln(const bwams_mem_opt_t *opt, const struct orc_bns *bns, const uint8_t *ref_string, int l_query, const uint8_t *query,
+                const bwams_alnreg_t *ar, bwams_aln_t *a, uint32_t *cigar, char *md);
 uint64_t orc_hash_64(uint64_t key);
 int64_t orc_depos(int64_t l_pac, int64_t pos, int *is_rev);
 int64_t orc_kbt_script(int64_t n, const int64_t *pos, const uint8_t *do_put, int32_t *lower, int32_t *order);

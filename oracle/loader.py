@@ -357,7 +357,7 @@ class MemOpt(C.Structure):
                 ("min_seed_len", C.c_int32), ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32),
                 ("max_occ", C.c_int32), ("max_chain_gap", C.c_int32), ("mask_level", C.c_float),
                 ("drop_ratio", C.c_float), ("mat", C.c_int8 * 25), ("pad_", C.c_int8 * 3), ("extend_all", C.c_int32), ("mask_level_redun", C.c_float), ("max_ins", C.c_int32),
-                ("b", C.c_int32), ("pen_unpaired", C.c_int32), ("max_matesw", C.c_int32)]
+                ("b", C.c_int32), ("pen_unpaired", C.c_int32), ("max_matesw", C.c_int32), ("mapq_coef_len", C.c_int32)]
 
 
 def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
@@ -366,6 +366,7 @@ def default_mem_opt(a: int = 1, b: int = 4) -> MemOpt:
     o.mask_level_redun = 0.95
     o.max_ins = 10000
     o.b, o.pen_unpaired, o.max_matesw = b, 17, 50
+    o.mapq_coef_len = 50
     for i, v in enumerate(fill_scmat(a, b)):
         o.mat[i] = v
     return o
@@ -507,6 +508,58 @@ def ksw_global2_score(query, target, w: int, opt: SwOpt | None = None, L=None):
         return L.ref_ksw_global2(C.byref(opt), len(q), _p(q), len(t), _p(t), w)
     return lib().orc_ksw_global2_score(len(q), _p(q), len(t), _p(t), C.cast(opt.mat, C.c_void_p), opt.o_del, opt.e_del,
                                        opt.o_ins, opt.e_ins, w)
+
+
+ALN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("flag", "<i4"), ("is_rev", "<i4"), ("is_alt", "<i4"), ("mapq", "<i4"),
+                      ("NM", "<i4"), ("n_cigar", "<i4"), ("md_len", "<i4"), ("cigar_off", "<i8"), ("md_off", "<i8"),
+                      ("score", "<i4"), ("sub", "<i4"), ("alt_sc", "<i4"), ("pad_", "<i4")])
+assert ALN_DTYPE.itemsize == 72
+
+
+def ksw_global2_cigar(query, target, w: int, opt: SwOpt | None = None, L=None):
+    """(score, cigar uint32[]) of ksw_global2 with traceback; L = a reference library from ref_lib() to run the real one."""
+    opt = opt or default_sw_opt()
+    q = np.ascontiguousarray(query, np.uint8)
+    t = np.ascontiguousarray(target, np.uint8)
+    cig = np.zeros(len(q) + len(t) + 4, np.uint32)
+    n = C.c_int(0)
+    if L is None:
+        f = lib().orc_ksw_global2_cigar
+        f.restype = C.c_int
+        sc = f(len(q), _p(q), len(t), _p(t), C.byref(opt, SwOpt.mat.offset), opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, w,
+               C.byref(n), _p(cig))
+    else:
+        L.ref_ksw_global2_cigar.restype = C.c_int
+        L.ref_ksw_global2_cigar.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        sc = L.ref_ksw_global2_cigar(C.byref(opt), len(q), _p(q), len(t), _p(t), w, C.byref(n), _p(cig), len(cig))
+    return sc, cig[:n.value].copy()
+
+
+def reg2aln(regs, reg_off, enc, cum, ref_string, l_pac, contigs=None, opt: MemOpt | None = None):
+    """mem_reg2aln over every region (regions grouped by read): (aln records, cigar pool, md pool as bytes)."""
+    opt = opt or default_mem_opt()
+    bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE)
+    enc = np.ascontiguousarray(enc, np.uint8)
+    ref_string = np.ascontiguousarray(ref_string, np.uint8)
+    out = np.zeros(len(regs), ALN_DTYPE)
+    cigs, mds = [], []
+    co = mo = 0
+    f = lib().orc_reg2aln
+    f.restype = C.c_int
+    for r in range(len(reg_off) - 1):
+        q = enc[cum[r]:cum[r + 1]]
+        for k in range(int(reg_off[r]), int(reg_off[r + 1])):
+            ar = regs[k:k + 1]
+            span = max(int(ar["re"][0] - ar["rb"][0]), 0)
+            cig = np.zeros(len(q) + span + 8, np.uint32)
+            md = np.zeros(3 * span + 32, np.uint8)
+            f(C.byref(opt), C.byref(bns), _p(ref_string), len(q), _p(q), _p(ar), _p(out[k:k + 1]), _p(cig), _p(md))
+            out[k]["cigar_off"], out[k]["md_off"] = co, mo
+            cigs.append(cig[:out[k]["n_cigar"]]); mds.append(md[:out[k]["md_len"]])
+            co += int(out[k]["n_cigar"]); mo += int(out[k]["md_len"])
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)      # noqa: E731
+    return out, cat(cigs, np.uint32), cat(mds, np.uint8)
 
 
 def ars_sort(which: int, k0, k1=None, k2=None, L=None):

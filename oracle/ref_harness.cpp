@@ -95,4 +95,17 @@ int ref_ksw_global2(const ref_sw_opt *o, int qlen, const uint8_t *query, int tle
     return ksw_global2(qlen, query, tlen, target, 5, o->mat, o->o_del, o->e_del, o->o_ins, o->e_ins, w, 0, 0);
 }
 
+/* ksw_global2 with traceback: the CIGAR is copied out (cap entries) and the reference's buffer freed. */
+int ref_ksw_global2_cigar(const ref_sw_opt *o, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int w,
+                          int *n_cigar, uint32_t *cigar_out, int cap)
+{
+    uint32_t *cigar = 0;
+    int n = 0;
+    const int sc = ksw_global2(qlen, query, tlen, target, 5, o->mat, o->o_del, o->e_del, o->o_ins, o->e_ins, w, &n, &cigar);
+    for (int i = 0; i < n && i < cap; ++i) cigar_out[i] = cigar[i];
+    *n_cigar = n;
+    free(cigar);
+    return sc;
+}
+
 } /* extern "C" */

@@ -120,15 +120,18 @@ int bwams_index_from_host(const bwams_fmi_desc_t *d, int device, bwams_index_t *
     ix->n_sa = (d->ref_seq_len >> 3) + 1;
     const size_t b_cp = (size_t)ix->n_blk * 64, b_ms = (size_t)ix->n_sa, b_ls = (size_t)ix->n_sa * 4;
     const size_t b_ref = d->ref_0123 ? (size_t)(d->ref_seq_len - 1) : 0;
-    BWAMS_HIP(hipMalloc(&ix->d_cp, b_cp));
-    BWAMS_HIP(hipMalloc(&ix->d_ms, b_ms));
-    BWAMS_HIP(hipMalloc(&ix->d_ls, b_ls));
-    BWAMS_HIP(hipMemcpy(ix->d_cp, d->cp_occ, b_cp, hipMemcpyHostToDevice));
-    BWAMS_HIP(hipMemcpy(ix->d_ms, d->sa_ms_byte, b_ms, hipMemcpyHostToDevice));
-    BWAMS_HIP(hipMemcpy(ix->d_ls, d->sa_ls_word, b_ls, hipMemcpyHostToDevice));
-    if (b_ref) {
-        BWAMS_HIP(hipMalloc(&ix->d_ref, b_ref));
-        BWAMS_HIP(hipMemcpy(ix->d_ref, d->ref_0123, b_ref, hipMemcpyHostToDevice));
+    // a failed allocation or copy must not strand the multi-GB buffers already made: close the handle on the way out
+    auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes);
+        return e != hipSuccess ? e : hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t ue = up(&ix->d_cp, d->cp_occ, b_cp);
+    if (ue == hipSuccess) ue = up(&ix->d_ms, d->sa_ms_byte, b_ms);
+    if (ue == hipSuccess) ue = up(&ix->d_ls, d->sa_ls_word, b_ls);
+    if (ue == hipSuccess && b_ref) ue = up(&ix->d_ref, d->ref_0123, b_ref);
+    if (ue != hipSuccess) {
+        bwams_index_close(ix);
+        BWAMS_HIP(ue);
     }
     ix->bytes = (int64_t)(b_cp + b_ms + b_ls + b_ref);
     int frc = index_finish(ix, d);

@@ -326,6 +326,113 @@ __device__ __forceinline__ void flt_introsort(uint2 *a, int n) {
     }
 }
 
+// ---- the same introsort, run by a whole wavefront over an LDS array -----------------------------------------
+// ksort.h's introsort is not stable, so ties (equal weights are common) come out in an order that only the same
+// sequence of operations reproduces — but that sequence need not be EXECUTED sequentially:
+//   * Hoare's partition is a function of two flag vectors over the untouched range — "stops the upward scan"
+//     (!lt(a[x], pivot)) and "stops the downward scan" (!lt(pivot, a[x])): its k-th swap exchanges the k-th upward stopper
+//     with the k-th downward stopper for as long as the former lies left of the latter (positions already swapped are never
+//     scanned again), and the pivot lands on the next upward stopper or on the last swapped downward position, whichever
+//     comes first.  The stoppers are listed with ballots, the swaps are independent;
+//   * the final insertion sort over the whole array is a STABLE sort, whose result is unique: a rank sort gives it.
+// The control flow between partitions (median of three, explicit stack, depth budget, comb-sort fallback on lane 0) is
+// ksort's own.  tmp: 2 * n uint16 (the stopper lists), stk: 3 * 40 ints, both LDS.  All 64 lanes call this.
+__device__ void wave_flt_introsort(uint2 *a, int n, uint16_t *tmp, int *stk, int lane) {
+    if (n < 2) return;
+    if (n == 2) {
+        if (lane == 0 && flt_lt(a[1], a[0])) swp(a, 0, 1);
+        __syncthreads();
+        return;
+    }
+    uint16_t *ls = tmp, *rs = tmp + n;
+    int d;
+    for (d = 2; (1ul << d) < (unsigned long)n; ++d);
+    int top = 0, s = 0, t = n - 1;
+    d <<= 1;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) {
+                if (lane == 0) flt_combsort(a + s, t - s + 1);
+                __syncthreads();
+                t = s;
+                continue;
+            }
+            int i = s, j = t, k = i + ((j - i) >> 1) + 1;
+            {
+                const uint2 ak = a[k], ai = a[i], aj = a[j];
+                if (flt_lt(ak, ai)) { if (flt_lt(ak, aj)) k = j; }
+                else k = flt_lt(aj, ai) ? i : j;
+            }
+            const uint2 rp = a[k];
+            __syncthreads();
+            if (lane == 0 && k != t) { a[k] = a[t]; a[t] = rp; }
+            __syncthreads();
+            int NL = 0, NR = 0;
+            for (int x0 = s + 1; x0 <= t; x0 += 64) {
+                const int x = x0 + lane;
+                const bool f = x <= t && !flt_lt(a[x], rp);
+                const unsigned long long m = __ballot(f);
+                if (f) ls[NL + __popcll(m & below)] = (uint16_t)x;
+                NL += __popcll(m);
+            }
+            for (int x0 = t - 1; x0 >= s + 1; x0 -= 64) {
+                const int x = x0 - lane;
+                const bool f = x >= s + 1 && !flt_lt(rp, a[x]);
+                const unsigned long long m = __ballot(f);
+                if (f) rs[NR + __popcll(m & below)] = (uint16_t)x;
+                NR += __popcll(m);
+            }
+            __syncthreads();
+            const int np = NL < NR ? NL : NR;
+            int m_sw = 0;
+            for (int k0 = 0; k0 < np; k0 += 64) {
+                const int kk = k0 + lane;
+                m_sw += __popcll(__ballot(kk < np && ls[kk] < rs[kk]));
+            }
+            for (int k0 = 0; k0 < m_sw; k0 += 64) {
+                const int kk = k0 + lane;
+                if (kk < m_sw) swp(a, ls[kk], rs[kk]);
+            }
+            int i_f = ls[m_sw];
+            if (m_sw >= 1 && (int)rs[m_sw - 1] < i_f) i_f = rs[m_sw - 1];
+            __syncthreads();
+            if (lane == 0) swp(a, i_f, t);
+            __syncthreads();
+            i = i_f;
+            if (i - s > t - i) {
+                if (i - s > 16) { stk[3 * top] = s; stk[3 * top + 1] = i - 1; stk[3 * top + 2] = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { stk[3 * top] = i + 1; stk[3 * top + 1] = t; stk[3 * top + 2] = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+            __syncthreads();                         // the stack entries were written by every lane (same values)
+        } else {
+            if (top == 0) break;
+            --top; s = stk[3 * top]; t = stk[3 * top + 1]; d = stk[3 * top + 2];
+        }
+    }
+    // the closing insertion sort = THE stable sort of what the partitions left.  (Not a local clean-up: ksort's median of
+    // three never examines a[s], which may lie beyond the pivot and then travels a long way in the insertion sort.)  A rank
+    // sort: every lane counts, from uniform LDS reads, the elements that sort before its own.
+    __syncthreads();
+    uint2 *out = reinterpret_cast<uint2 *>(tmp);          // n * 8 bytes: the stopper lists are dead by now
+    for (int x0 = 0; x0 < n; x0 += 64) {
+        const int x = x0 + lane;
+        const uint2 v = x < n ? a[x] : make_uint2(0u, 0u);
+        int pos = 0;
+        for (int y = 0; y < n; ++y) {
+            const uint32_t wy = a[y].x;
+            pos += (wy > v.x || (wy == v.x && y < x)) ? 1 : 0;
+        }
+        if (x < n) out[pos] = v;
+    }
+    __syncthreads();
+    for (int x = lane; x < n; x += 64) a[x] = out[x];
+    __syncthreads();
+}
+
 // ---- the pairwise filter of mem_chain_flt, sequential form --------------------------------------
 // fl[0..n_chn) sorted; rec[i] = {chn_beg, chn_end, w | is_alt << 31, first}.  Leaves kept[] set.
 __device__ void filter_seq(const bwams_mem_opt_t &opt, int n_chn, uint4 *rec, int32_t *kept, int32_t *sel) {
@@ -739,8 +846,9 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
         __syncthreads();
         for (int i = lane; i < n_chn; i += 64) l_fl[i] = fl[i];
         __syncthreads();
-        if (lane == 0) flt_introsort(l_fl, n_chn);           // ksort's order is inherently sequential
-        __syncthreads();
+        // ksort's introsort, operation for operation, by the whole wave; l_sel is free until the filter: it lends the sort
+        // its stopper lists / output copy (8 B per chain) and, behind them, the partition stack
+        wave_flt_introsort(l_fl, n_chn, reinterpret_cast<uint16_t *>(l_sel), reinterpret_cast<int *>(reinterpret_cast<char *>(l_sel) + (size_t)n_chn * 8), lane);
         const unsigned long long t_1 = __builtin_amdgcn_s_memtime();
         for (int i = lane; i < n_chn; i += 64) {
             const uint2 f = l_fl[i];
@@ -922,9 +1030,11 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     for (int i = 0; i < 5; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
     // heaviest first: reads beyond the LDS budget (HBM state) and classes L, L1, then M, M1, S, then the lane tier
-    chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, 0, aux[0]>>>(A, nullptr, cls + 0, tk + 0, 0);
-    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[0]>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
-    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassL1), aux[0]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
+    // (the reads beyond a CU's LDS keep their state in HBM: every step is a dependent L2 / HBM access, so they get many
+    // waves — no LDS limits them; at GRCh38 size, with max_occ hits per repeat SMEM, they were the stage's long pole on two)
+    chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, 0, aux[0]>>>(A, nullptr, cls + 0, tk + 0, 0);
+    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[1]>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
+    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassL1), aux[2]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
     chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
     chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
     chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 4, cls + 5, tk + 5, kClassS);

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG, "_build", "libbwams.so")
+LIB_PATH = os.environ.get("BWAMS_LIB") or os.path.join(PKG, "_build", "libbwams.so")     # BWAMS_LIB: A/B runs of another build
 
 SMEM_DTYPE = np.dtype([("rid", "<u4"), ("m", "<u4"), ("n", "<u4"), ("pad_", "<u4"),
                        ("k", "<i8"), ("l", "<i8"), ("s", "<i8")])

@@ -220,19 +220,24 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     if (lane == 0 && cells) atomicAdd(&ctr->bsw_cells, cells);
 }
 
-// ---- four tasks per wavefront ---------------------------------------------------------------
+// ---- eight tasks per wavefront -------------------------------------------------------------
 // bsw_kernel above spends one wavefront on one task, with the row's band bookkeeping (beg, end, row maximum and its
 // column, z-drop, ...) in scalar registers: measured, a row of <= 128 cells cost ~110 vector but ~250 scalar
 // instructions, and the one scalar unit of a CU serves four SIMDs (profiles/r01_notes.md 26-28) — the scalar pipe,
-// not the vector one, bounded the one-task-per-wave kernels.  In bsw_qwin_kernel a task owns one DPP ROW (16 lanes), so
-//   * four tasks share a wavefront and every cross-lane step is a row-local DPP operation (row_shr scans for the
-//     max-plus prefix of F and the H shift, row_ror butterflies for the four per-row reductions);
-//   * the bookkeeping lives in vector registers, replicated over the task's 16 lanes: no scalar work per row at all;
-//   * a quarter that finishes its task takes the next one from the wave's reservation while the others carry on.
+// not the vector one, bounded the one-task-per-wave kernels.  In bsw_qwin_kernel a task owns kBswLpt = 8 lanes (half a
+// DPP row), so
+//   * eight tasks share a wavefront and every cross-lane step stays inside a DPP row (quad_perm scans + one ds_swizzle for
+//     the max-plus prefix of F, row_shr for the H shift, quad_perm / row_half_mirror butterflies for the four per-row
+//     reductions);
+//   * the bookkeeping lives in vector registers, replicated over the task's lanes: no scalar work per row at all;
+//   * a task slot that finishes takes the next task from the wave's reservation while the others carry on.
 // Tasks are binned by query length first (bsw_classify_kernel) — the class fixes the LDS per task — one launch per
 // class, concurrently.  Results are bit-identical to scalarBandedSWA: the recurrences and every per-row decision are
-// those of bsw_kernel above.
+// those of bsw_kernel above.  Measured on the bench workload (5.9 M tasks, 13.4 G cells per step): one task per wave
+// 89 ms; 16 lanes x all columns in registers 83; 16 x 3-column window 80; 8 x 4 66; 8 x 3 71; 8 x 6 72; 4 x 8 73 (LDS
+// and registers cost occupancy); one task per LANE with its row in LDS 170 (the row caps a CU at four waves).
 constexpr int kQuadCpl[5] = {2, 4, 6, 9, 12};                 // a class holds queries of <= 16 * kQuadCpl - 1 bases (16 * kQuadCpl columns of LDS)
+constexpr int kBswLpt = 8, kBswWin = 4;                       // lanes per task, window columns per lane (bsw_qwin_kernel)
 constexpr int kNumBswClass = 6;                              // five quad classes + the rest (one task per wave, LDS)
 constexpr int kQuadChunk = 16;                               // tasks a wave reserves per atomic
 
@@ -284,22 +289,55 @@ __device__ __forceinline__ int row_all_max(int v) {             // maximum over 
 }
 __device__ __forceinline__ int row_shr1(int v, int fill) { return dppi<0x111, 0xF, 0xF>(fill, v); }   // lane g gets lane g - 1's v; lane 0 the fill
 
-// ---- four tasks per wavefront, row state in LDS, a 48-column register window that follows the band -------------
+// ---- row state in LDS, a register window that follows the band ----------------------------------------------------
 // A kernel whose cost follows the query length computes mostly dead columns: the band of a typical extension is
 // narrow: ~23 live columns per row on the bench workload, because it shrinks to the non-zero span of the previous row.
 // Here the row state eh[] of a task lives in LDS (8 B per column: H | E + the query base), and each row loads just the
-// live columns [beg, end) into a window of kWin = 3 columns per lane (48 per task), computes them (F as a prefix
-// maximum: a lane's own columns sequentially, then four DPP steps over the lanes), and stores them back; a band wider than 48 columns takes further passes with the prefix maximum and
+// live columns [beg, end) into a window of kWin columns per lane (LPT * kWin per task: 32 as launched), computes them (F as a prefix
+// maximum: a lane's own columns sequentially, then four DPP steps over the lanes), and stores them back; a band wider than the window takes further passes with the prefix maximum and
 // the last H carried over.  Columns outside the band keep their stale values in LDS, as scalarBandedSWA's eh[] does.
-constexpr int kWin = 3;
+// cross-lane steps over a task's LPT lanes (16 = one DPP row, 8 = half a row)
+template <int LPT> __device__ __forceinline__ int grp_scan_max(int v, int g);
+template <> __device__ __forceinline__ __attribute__((unused)) int grp_scan_max<16>(int v, int) { return row_scan_max(v); }
+template <> __device__ __forceinline__ __attribute__((unused)) int grp_scan_max<8>(int v, int g) {
+    // inclusive scan inside each quad (two quad_perm steps), then lanes 4..7 take the first quad's total (lane 3 of the
+    // half row, fetched with ds_swizzle: source = (lane & 0b11000) | 0b00011)
+    asm("s_nop 4\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    const int t = __builtin_amdgcn_ds_swizzle(v, 0x78);
+    return (g & 4) ? (v > t ? v : t) : v;
+}
+template <int LPT> __device__ __forceinline__ int grp_all_max(int v);
+template <> __device__ __forceinline__ __attribute__((unused)) int grp_all_max<16>(int v) { return row_all_max(v); }
+template <> __device__ __forceinline__ __attribute__((unused)) int grp_all_max<8>(int v) {
+    asm("s_nop 4\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+// lane g of the group gets lane g - 1's v, lane 0 the fill
+template <int LPT> __device__ __forceinline__ int grp_shr1(int v, int fill, int g) {
+    const int t = row_shr1(v, fill);
+    return (LPT < 16 && g == 0) ? fill : t;
+}
 
+
+template <int LPT, int kWin>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
     bwams_seqpair_t *__restrict__ pairs, const int32_t *__restrict__ list, const unsigned long long *n_list_p,
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, int w0, SwParams prm, DevCounters *ctr, unsigned long long *head,
     int cols) {
-    extern __shared__ uint2 qwin_lds[];                            // [wave][quarter][cols]: {H, E | query base << 28}
-    const int lane = threadIdx.x & 63, g = lane & 15, q = lane >> 4;
-    uint2 *const row_eh = qwin_lds + (size_t)(((threadIdx.x >> 6) * 4 + q) * cols);
+    extern __shared__ uint2 qwin_lds[];                            // [wave][task slot][cols]: {H, E | query base << 28}
+    constexpr int TPW = 64 / LPT;                                  // tasks per wavefront
+    const int lane = threadIdx.x & 63, g = lane & (LPT - 1), q = lane / LPT;
+    uint2 *const row_eh = qwin_lds + (size_t)(((threadIdx.x >> 6) * TPW + q) * cols);
     const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     int pk[5], pn[5];                                              // score rows of the matrix, one per target base
@@ -310,7 +348,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
         pn[t] = prm.mat[t * 5 + 4];
     }
     const int64_t n_list = (int64_t)*n_list_p;
-    const unsigned long long kLeaders = 0x0001000100010001ull;
+    const unsigned long long kLeaders = LPT == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;   // lane 0 of every task slot
     int64_t pid = 0, pid_end = 0;
     bool exhausted = false;
     bool alive = false;
@@ -329,14 +367,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
             }
             const int avail = (int)(pid_end - pid);
             const int nq = __popcll(need_m & kLeaders);
-            const int rank = __popcll(need_m & kLeaders & ((1ull << (q * 16)) - 1ull));
+            const int rank = __popcll(need_m & kLeaders & ((1ull << (q * LPT)) - 1ull));
             if (!alive && rank < avail) {
                 cur = list[pid + rank];
                 const bwams_seqpair_t sp = pairs[cur];
                 qlen = sp.len2; tlen = sp.len1; h0 = sp.h0;
                 const uint8_t *tq = qer + sp.idq;
                 tr = ref + sp.idr;
-                for (int c = g; c <= qlen; c += 16) {             // row -1 of the DP and the query, 16 columns at a time
+                for (int c = g; c <= qlen; c += LPT) {            // row -1 of the DP and the query, LPT columns at a time
                     int h = h0;
                     if (c >= 1) { h = h0 - oe_ins - (c - 1) * e_ins; h = h > 0 ? h : 0; }
                     uint32_t qb = c < qlen ? (uint32_t)tq[c] : 4u;
@@ -382,7 +420,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
         const bool row = alive && beg < end;
         int key = -1, first_nz = 1 << 20, last_nz = -1, hlast = -1;
         int c_max = NEG, c_h = h1;                                  // carried into a further pass: prefix maximum, last H
-        for (int base = beg; __any(row && base < end); base += 16 * kWin) {
+        for (int base = beg; __any(row && base < end); base += LPT * kWin) {
             const bool in = row && base < end;
             const int jb = base + g * kWin;
             int Mv[kWin], Pl[kWin], Ev[kWin];
@@ -404,8 +442,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
                 run = run > x ? run : x;
                 Mv[c] = M; Pl[c] = run; Ev[c] = e; Qb[c] = qb;
             }
-            const int scan = row_scan_max(run);
-            int Lex = row_shr1(scan, NEG);
+            const int scan = grp_scan_max<LPT>(run, g);
+            int Lex = grp_shr1<LPT>(scan, NEG, g);
             Lex = Lex > c_max ? Lex : c_max;
             int Hh[kWin], E2[kWin];
 #pragma unroll
@@ -424,7 +462,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
                 e2 = e2 > e1 ? e2 : e1;
                 Hh[c] = h; E2[c] = e2;
             }
-            const int h_in = row_shr1(Hh[kWin - 1], c_h);
+            const int h_in = grp_shr1<LPT>(Hh[kWin - 1], c_h, g);
 #pragma unroll
             for (int c = 0; c < kWin; ++c) {
                 const int j = jb + c;
@@ -439,16 +477,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
                     if (j == end - 1) hlast = Hh[c];
                 }
             }
-            if (__any(row && base + 16 * kWin < end)) {            // a further pass: carry the prefix maximum and the last column's H
-                const int pm = row_all_max(scan);
+            if (__any(row && base + LPT * kWin < end)) {            // a further pass: carry the prefix maximum and the last column's H
+                const int pm = grp_all_max<LPT>(scan);
                 c_max = c_max > pm ? c_max : pm;
-                c_h = row_all_max(g == 15 ? Hh[kWin - 1] : -1);
+                c_h = grp_all_max<LPT>(g == LPT - 1 ? Hh[kWin - 1] : -1);
             }
         }
-        key = row_all_max(key);
-        first_nz = -row_all_max(-first_nz);
-        last_nz = row_all_max(last_nz);
-        hlast = row_all_max(hlast);
+        key = grp_all_max<LPT>(key);
+        first_nz = -grp_all_max<LPT>(-first_nz);
+        last_nz = grp_all_max<LPT>(last_nz);
+        hlast = grp_all_max<LPT>(hlast);
         const int m = row ? key >> 8 : 0, mj = row ? key & 0xff : -1;
         const int h1f = row ? hlast : h1;
         if (alive) {
@@ -542,11 +580,17 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
         if (lblocks > maxb) lblocks = maxb;
         bsw_kernel<<<(unsigned)lblocks, waves * 64, lds, q[3]>>>(pairs, n, ref, qer, w, prm, qmax, -1, ctr, &ctr->bsw_head[3], list + 5 * n, cnt + 5);
     }
-    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 192 * 8, q[2]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
-    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 144 * 8, q[1]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
-    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 96 * 8, q[0]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
-    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 64 * 8, q[2]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
-    bsw_qwin_kernel<<<B, T, (size_t)kWavesPerBlock * 4 * 32 * 8, q[1]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
+    static bool qwin_attr = false;
+    if (!qwin_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_qwin_kernel<kBswLpt, kBswWin>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 8));
+        qwin_attr = true;
+    }
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 8, q[2]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 8, q[1]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 96 * 8, q[0]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 64 * 8, q[2]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 32 * 8, q[1]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
     if (n_aux)
         for (int c = 0; c < n_aux; ++c) {
             if (hipEventRecord(join[c], q[c + 1]) != hipSuccess) return -1;

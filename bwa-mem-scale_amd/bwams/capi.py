@@ -588,6 +588,14 @@ class Batch:
         _chk(lib().bwams_pestat_keys(self.h, C.byref(opt), _p(keys), len(keys), C.byref(n)), "bwams_pestat_keys")
         return keys[:n.value].copy()
 
+    def mark_primary_se(self, opt: MemOpt | None = None, id_base: int = 0):
+        """Single-end chunk: mem_mark_primary_se of every read's final regions (then pair_fetch / reg2aln(source=1))."""
+        opt = opt or default_mem_opt()
+        n, nt = C.c_int64(0), C.c_int64(0)
+        _chk(lib().bwams_pair_run(self.h, C.byref(opt), None, id_base, 4, C.byref(n), C.byref(nt)), "bwams_pair_run")
+        self._n_pair_regs = n.value
+        return n.value
+
     def pair_run(self, pes, opt: MemOpt | None = None, id_base: int = 0, no_rescue: bool = False, use_ert: bool = False):
         """Mate rescue + mem_mark_primary_se + mem_pair over the final regions (reads 2p, 2p+1 = pair p)
         -> (regions, rescue alignments)."""

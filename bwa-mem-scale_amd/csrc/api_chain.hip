@@ -47,7 +47,7 @@ struct ChainState {
            pr_aln, pr_pool, pr_ord, pr_srt, pr_z, pr_nfin, pr_npri, pr_nsw, pr_full, pr_owide, pr_ooff, pr_out, pr_res;
     DevBuf et_mems, et_moff, et_hits, et_hoff, et_smem, et_cnt, et_off, et_coord, et_srt;      // ERT mode input translation
     int64_t pr_total = 0, pr_tasks = 0, pr_redone = 0;
-    bool pair_done = false;
+    bool pair_done = false, pr_single = false;
     DevBuf er_wide, er_off, er_scr, er_n, er_rev, er_out, er_ooff;   // mem_perfect2reg
     int64_t er_total = 0, er_nseq = 0;
     bool er_done = false;
@@ -820,7 +820,10 @@ int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, i
 
 int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t flags,
                    int64_t *n_regs, int64_t *n_tasks) {
-    const int no_rescue = flags & BWAMS_PAIR_NO_RESCUE, use_ert = (flags & BWAMS_PAIR_USE_ERT) != 0;
+    const int single_end = (flags & BWAMS_PAIR_SINGLE_END) != 0;
+    const int no_rescue = (flags & BWAMS_PAIR_NO_RESCUE) || single_end, use_ert = (flags & BWAMS_PAIR_USE_ERT) != 0;
+    static const bwams_pestat_t no_pes[4] = {{0, 0, 1, 0, 0., 0.}, {0, 0, 1, 0, 0., 0.}, {0, 0, 1, 0, 0., 0.}, {0, 0, 1, 0, 0., 0.}};
+    if (single_end && !pes) pes = no_pes;
     if (!b || !b->chain || !b->chain->dedup_done) {
         set_last_error("bwams_pair_run: run bwams_dedup_run first");
         return BWAMS_ERR_ARG;
@@ -828,7 +831,7 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     int rc = check_opt(opt, "bwams_pair_run");
     if (rc) return rc;
     ChainState *s = b->chain;
-    if (!pes || (s->nseq & 1)) {
+    if (!pes || (!single_end && (s->nseq & 1))) {
         set_last_error("bwams_pair_run: needs the insert-size statistics and an even number of reads (ends of pair p at 2p, 2p + 1)");
         return BWAMS_ERR_ARG;
     }
@@ -859,6 +862,7 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     A.id_base = id_base; A.no_rescue = no_rescue ? 1 : 0; A.pass = 0;
     A.drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") ? 1 : 0;                 // test knob: exercise the second pass
     A.use_ert = use_ert ? 1 : 0;
+    A.single_end = single_end;
     A.na = s->pr_na.as<int32_t>();
     int64_t *aoff = s->pr_offs.as<int64_t>(), *ooff = aoff + n1;
     A.aoff = aoff; A.ooff = ooff;
@@ -941,11 +945,12 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     BWAMS_HIP(hipStreamSynchronize(st));
     BWAMS_HIP(s->pr_out.ensure((size_t)(total + 1) * sizeof(bwams_alnreg_t)));
     launch_pair_gather(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), st);
-    launch_pair_pair(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), s->pr_res.as<bwams_pair_t>(), st);
+    if (!single_end) launch_pair_pair(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), s->pr_res.as<bwams_pair_t>(), st);
     BWAMS_HIP(hipEventRecord(s->ev[15], st));
     BWAMS_HIP(hipStreamSynchronize(st));
     BWAMS_HIP(hipGetLastError());
     s->pr_total = total;
+    s->pr_single = single_end != 0;
     s->pair_done = true;
     if (n_regs) *n_regs = total;
     if (n_tasks) *n_tasks = s->pr_tasks;
@@ -963,7 +968,7 @@ int bwams_pair_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, in
     hipStream_t st = b->stream;
     if (regs && s->pr_total) BWAMS_HIP(hipMemcpyAsync(regs, s->pr_out.p, (size_t)s->pr_total * sizeof(bwams_alnreg_t), hipMemcpyDeviceToHost, st));
     if (reg_off) BWAMS_HIP(hipMemcpyAsync(reg_off, s->pr_ooff.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
-    if (pairs && s->nseq > 1) BWAMS_HIP(hipMemcpyAsync(pairs, s->pr_res.p, (size_t)(s->nseq / 2) * sizeof(bwams_pair_t), hipMemcpyDeviceToHost, st));
+    if (pairs && s->nseq > 1 && !s->pr_single) BWAMS_HIP(hipMemcpyAsync(pairs, s->pr_res.p, (size_t)(s->nseq / 2) * sizeof(bwams_pair_t), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     return BWAMS_OK;
 }

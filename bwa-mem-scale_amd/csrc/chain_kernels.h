@@ -175,6 +175,7 @@ struct PairArgs {
     int32_t no_rescue, pass;
     int32_t drop_plan;             // test knob: the first pass plans nothing, so every rescue goes through the second
     int32_t use_ert;               // mem_sam_pe_batch_post's useErt branch: mem_matesw_batch_post_ert
+    int32_t single_end;            // mem_reg2sam's form: every read on its own, id = id_base + read, no rescue, no pairing
     int32_t *na;                   // per read: anchors it provides
     const int64_t *aoff, *ooff;    // per read: first anchor slot, first pool slot
     int32_t *anchor, *slot_read;   // per anchor slot: region index within its read, the read

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64) void pair_mark_kernel(PairArgs A) {
     const int n = A.n_fin[m];
     if (n > kMarkLight) { A.heavy[atomicAdd(&A.ctr->pair_heavy, 1ull)] = (int32_t)m; return; }
     const int64_t o0 = A.ooff[m];
-    const int64_t id = ((A.id_base + (m >> 1)) << 1) | (m & 1);
+    const int64_t id = A.single_end ? A.id_base + m : (((A.id_base + (m >> 1)) << 1) | (m & 1));      // mem_reg2sam passes n_processed + i, mem_sam_pe id << 1 | end
     A.n_pri[m] = list_mark_primary(A, A.pool + o0, A.ord + o0, n, id, reinterpret_cast<SortRec *>(A.srt) + o0, A.zbuf + o0);
 }
 
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(64) void pair_mark_wave_kernel(PairArgs A) {
         const int64_t o0 = A.ooff[m];
         bwams_alnreg_t *pool = A.pool + o0;
         int32_t *ord = A.ord + o0;
-        const int64_t id = ((A.id_base + (m >> 1)) << 1) | (m & 1);
+        const int64_t id = A.single_end ? A.id_base + m : (((A.id_base + (m >> 1)) << 1) | (m & 1));      // mem_reg2sam passes n_processed + i, mem_sam_pe id << 1 | end
         __syncthreads();
         if (n > kMarkLds) {                                  // beyond the LDS arrays: one lane, through HBM
             if (lane == 0) A.n_pri[m] = list_mark_primary(A, pool, ord, n, id, reinterpret_cast<SortRec *>(A.srt) + o0, A.zbuf + o0);

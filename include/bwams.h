@@ -341,6 +341,8 @@ int bwams_pestat_from_keys(const uint64_t *keys, int64_t n, bwams_pestat_t pes[4
  * before its MAPQ / SAM part (grouped by read, reg_off[nseq + 1]) and one bwams_pair_t per pair.
  * The insert-size term of mem_pair is double arithmetic through log / erfc of the device math library. */
 #define BWAMS_PAIR_NO_RESCUE 1   /* MEM_F_NO_RESCUE */
+#define BWAMS_PAIR_SINGLE_END 4  /* single-end chunk: just mem_mark_primary_se(opt, n, a, id_base + read) of every read, as mem_reg2sam
+                                    does (src/bwamem.cpp:2318-2330); pes may be NULL, no rescue, no pairing, any number of reads */
 #define BWAMS_PAIR_USE_ERT   2   /* mem_sam_pe_batch_post's useErt branch (ERT-mode runs): the mate's list is sorted by end
                                   * position, rescue goes through mem_matesw_batch_post_ert (insertion by end, mem_dedup_patch),
                                   * and one mem_sort_dedup_patch or score sort closes each end (src/bwamem_pair.cpp:1017-1041) */

@@ -99,3 +99,31 @@ def test_reg2aln_wide_bands_and_long_reads():
         reads.append(simulate.revcomp(a) if rng.random() < 0.5 else a)
     r = _run(g, idx, reads)
     assert r["gapped"] > 200
+
+
+def test_single_end_mark_primary_then_reg2aln():
+    """The single-end SAM side on the device: mem_mark_primary_se(opt, n, a, n_processed + i) of every read (odd read count
+    allowed), then mem_reg2aln with the mapping quality of the marked regions."""
+    g, idx = toy()
+    reads, _, _ = simulate.make_reads(g, 1201, seed=23)
+    oopt, gopt = _opts()
+    ix = capi.Index.from_host(idx, 0)
+    enc, cum = simulate.flatten_reads(reads)
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.seed_run(capi.default_seed_opt(), with_sa=True)
+    b.chain_run(gopt); b.extend_run(gopt); b.dedup_run(gopt)
+    fin, fin_off = b.dedup_fetch()
+    ID0 = 5_000_003
+    n = b.mark_primary_se(gopt, id_base=ID0)
+    regs, off, _ = b.pair_fetch()
+    assert n == len(fin) and np.array_equal(off, fin_off)
+    want = fin.copy()
+    for r in range(len(reads)):
+        w, _n_pri = loader.mark_primary_se(fin[fin_off[r]:fin_off[r + 1]], ID0 + r, oopt)
+        want[fin_off[r]:fin_off[r + 1]] = w
+    for f in ("rb", "re", "qb", "qe", "score", "sub", "sub_n", "alt_sc", "secondary", "secondary_all", "hash", "n_comp_is_alt"):
+        assert np.array_equal(regs[f], want[f]), f
+    assert (regs["secondary"] >= 0).sum() > 20 and (regs["sub"] > 0).sum() > 50
+    _check(b.reg2aln(gopt, 1), loader.reg2aln(want, fin_off, enc, cum, idx.ref_0123, len(g), opt=oopt))
+    b.close(); ix.close()

@@ -283,19 +283,27 @@ def main():
         elapsed = float(t.item())
 
     # ---------------- SAM-side alignment of the last chunk's final regions (reported beside, never `value`) ----------------
+    batch.mark_primary_se(mem_opt, id_base=first)
+    batch.sync()
     t0 = time.perf_counter()
-    aln_, cig_, md_ = batch.reg2aln(mem_opt, 0)
+    batch.mark_primary_se(mem_opt, id_base=first)           # mem_mark_primary_se of every read (mem_reg2sam's first step)
+    batch.sync()
+    mark_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    aln_, cig_, md_ = batch.reg2aln(mem_opt, 1)
     reg2aln_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
     n_aln = capi.C.c_int64(0); n_cig = capi.C.c_int64(0); n_md = capi.C.c_int64(0)
-    capi._chk(capi.lib().bwams_reg2aln_run(batch.h, capi.C.byref(mem_opt), 0, capi.C.byref(n_aln), capi.C.byref(n_cig), capi.C.byref(n_md)), "bwams_reg2aln_run")
+    capi._chk(capi.lib().bwams_reg2aln_run(batch.h, capi.C.byref(mem_opt), 1, capi.C.byref(n_aln), capi.C.byref(n_cig), capi.C.byref(n_md)), "bwams_reg2aln_run")
     reg2aln_run_ms = (time.perf_counter() - t0) * 1e3
     sam_side = {"regions": int(n_aln.value), "cigar_ops": int(n_cig.value), "md_bytes": int(n_md.value),
                 "gapped_fraction": round(float(np.mean([(int(c) & 0xf) in (1, 2) for c in cig_[:200000]])), 4) if len(cig_) else 0.0,
+                "ms_mark_primary_se": round(mark_ms, 2), "mean_mapq": round(float(aln_["mapq"].mean()), 2) if len(aln_) else None,
                 "ms_run": round(reg2aln_run_ms, 2), "ms_run_plus_fetch": round(reg2aln_ms, 2),
                 "Malignments_per_s": round(n_aln.value / (reg2aln_run_ms * 1e-3) / 1e6, 2) if reg2aln_run_ms > 0 else None,
-                "note": "mem_reg2aln (band inference, banded global alignment with traceback, CIGAR / NM / MD, position) on the device for every final "
-                        "region of one chunk; mapping quality on the host side of the library; XA and SAM text are not built"}
+                "note": "single-end SAM side of one chunk on the device: mem_mark_primary_se of every read, then mem_reg2aln (band inference, "
+                        "banded global alignment with traceback, CIGAR / NM / MD, position) of every final region; mapping quality on the host "
+                        "side of the library; XA and SAM text are not built"}
     del aln_, cig_, md_
 
     # ---------------- paired-end leg (every rank: the pestat exchange is a collective) ----------------
@@ -392,7 +400,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int64 intervals / int32 DP",
             "data": "synthetic",
-            "not_included": ["mem_mark_primary_se (single-end)", "mem_reg2aln / ksw_global2 traceback / CIGAR (timed beside: sam_side)", "SAM text", "FASTQ decode and host I/O",
+            "not_included": ["mem_mark_primary_se + mem_reg2aln / ksw_global2 traceback / CIGAR (timed beside: sam_side)", "XA + SAM text", "FASTQ decode and host I/O",
                              "PCIe transfers (see pcie_inclusive with --pcie)"],
             "config": {
                 "workload": f"{total_reads} synthetic 150bp SE reads ({R} per GPU, {n_chunks} resident chunk(s) of <= {CH}) vs a synthetic {G} bp genome "

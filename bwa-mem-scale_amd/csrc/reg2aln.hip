@@ -171,9 +171,22 @@ __global__ void aln_plan_kernel(RegAlnArgs A) {
             wmax = wmax < ((int64_t)A.opt.w << 2) ? wmax : ((int64_t)A.opt.w << 2);
             wmax = wmax > d + 3 ? wmax : d + 3;
             const int64_t n_col = lq < 2 * wmax + 1 ? lq : 2 * wmax + 1;
-            cls = 2 * wmax + 2 <= 32 ? 0 : 2 * wmax + 2 <= 128 ? 1 : 2;
-            need += ((n_col + 3) / 4) * 4 * (int64_t)lr;                 // z: (n_col + 3) / 4 words per row
-            if (cls == 2) need += (int64_t)(lq + 1) * 8;
+            // the class follows the band of the FIRST try (bwa.cpp:414-423); a retry that outgrows the ring — rare: the
+            // global score fell short of the local one — sends the region to the HBM-row launch, which runs last
+            {
+                const int8_t m0 = A.opt.mat[0];
+                const int max_ins = (int)((double)(((lq + 1) >> 1) * m0 - A.opt.o_ins) / A.opt.e_ins + 1.);
+                const int max_del = (int)((double)(((lq + 1) >> 1) * m0 - A.opt.o_del) / A.opt.e_del + 1.);
+                int max_gap = max_ins > max_del ? max_ins : max_del;
+                max_gap = max_gap > 1 ? max_gap : 1;
+                int w1 = (max_gap + d + 1) >> 1;
+                const int w2c = w2 < A.opt.w << 2 ? w2 : A.opt.w << 2;
+                w1 = w1 < w2c ? w1 : w2c;
+                w1 = w1 > d + 3 ? w1 : d + 3;
+                cls = 2 * w1 + 2 <= 32 ? 0 : 2 * w1 + 2 <= 128 ? 1 : 2;
+            }
+            need += ((n_col + 3) / 4) * 4 * (int64_t)lr;                 // z: (n_col + 3) / 4 words per row, for the widest band
+            need += (int64_t)(lq + 1) * 8;                               // the HBM (h, e) row, should the region end up there
         }
     }
     A.need[k] = (need + 15) & ~(int64_t)15;
@@ -325,6 +338,7 @@ __global__ __launch_bounds__(64) void aln_dp_kernel(RegAlnArgs A, int cls) {
         w2 = w2 > tmp ? w2 : tmp;
         if (w2 > A.opt.w) w2 = w2 < ar.w ? w2 : ar.w;
         int it = 0, last_sc = -(1 << 30), score = 0, n_cigar = 0;
+        bool requeue = false;
         do {
             w2 = w2 < A.opt.w << 2 ? w2 : A.opt.w << 2;
             // bwa_gen_cigar2's band (bwa.cpp:414-423); the gap-free shortcut cannot apply to a listed region's first try,
@@ -338,11 +352,16 @@ __global__ __launch_bounds__(64) void aln_dp_kernel(RegAlnArgs A, int cls) {
             int w = (max_gap + d + 1) >> 1;
             w = w < w2 ? w : w2;
             w = w > d + 3 ? w : d + 3;
+            if (RING && 2 * w + 2 > RING) { requeue = true; break; }
             score = global2_cigar<RING>(A, S, w, eh, z, cigar, &n_cigar);
             if (score == last_sc || w2 == A.opt.w << 2) break;
             last_sc = score;
             w2 <<= 1;
         } while (++it < 3 && score < ar.truesc - A.opt.a);
+        if (requeue) {                                   // redone from the start by the HBM-row launch
+            A.list[2 * A.n_regs + (int64_t)atomicAdd(&A.n_list[2], 1ull)] = (int32_t)k;
+            continue;
+        }
         int md_len = 0;
         const int NM = nm_md(S, cigar, n_cigar, md, &md_len);
         finish_record(A, k, ar, l_query, cigar, n_cigar, NM, md_len);

@@ -242,9 +242,9 @@ constexpr int kNumBswClass = 6;                              // five quad classe
 constexpr int kQuadChunk = 16;                               // tasks a wave reserves per atomic
 
 __host__ __device__ __forceinline__ int bsw_class_of(int qlen, int h0, int max_sc) {
-    // the row maximum and its column travel as one key (h << 8 | j): needs h < 2^22 and j < 256
+    // a column's row state is one LDS word (H and E in 14 bits each, the query base on top): needs scores < 2^14
     const long long top = (long long)h0 + (long long)qlen * max_sc;       // no score of the task can exceed it
-    if (qlen > 16 * kQuadCpl[4] - 1 || top >= (1 << 22) || h0 < 0) return 5;
+    if (qlen > 16 * kQuadCpl[4] - 1 || top >= (1 << 14) || h0 < 0) return 5;
     return qlen <= 16 * kQuadCpl[0] - 1 ? 0 : qlen <= 16 * kQuadCpl[1] - 1 ? 1 : qlen <= 16 * kQuadCpl[2] - 1 ? 2
            : qlen <= 16 * kQuadCpl[3] - 1 ? 3 : 4;
 }
@@ -253,12 +253,20 @@ __host__ __device__ __forceinline__ int bsw_class_of(int qlen, int h0, int max_s
 __global__ void bsw_classify_kernel(const bwams_seqpair_t *__restrict__ pairs, int64_t n, int max_sc, int32_t *__restrict__ list,
                                     unsigned long long *cnt) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int cls = t < n ? bsw_class_of(pairs[t].len2, pairs[t].h0, max_sc) : -1;
 #pragma unroll
     for (int c = 0; c < kNumBswClass; ++c) {
-        // every lane of the class adds its own 1: no lane-leader branch (the pattern of wave_ops.h's wave_ticket note);
-        // the order inside a class list is immaterial
-        if (cls == c) list[(int64_t)c * n + (int64_t)atomicAdd(&cnt[c], 1ull)] = (int32_t)t;
+        // one atomic per wave and class (a per-task atomic on six addresses cost 0.6 ms per launch); straight-line code in a
+        // fully unrolled loop: no back edge for the leader's branch to be threaded through (wave_ops.h, wave_ticket)
+        const unsigned long long m = __ballot(cls == c);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&cnt[c], (unsigned long long)__popcll(m));
+            base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)base, leader);
+            if (cls == c) list[(int64_t)c * n + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)t;
+        }
     }
 }
 
@@ -292,7 +300,7 @@ __device__ __forceinline__ int row_shr1(int v, int fill) { return dppi<0x111, 0x
 // ---- row state in LDS, a register window that follows the band ----------------------------------------------------
 // A kernel whose cost follows the query length computes mostly dead columns: the band of a typical extension is
 // narrow: ~23 live columns per row on the bench workload, because it shrinks to the non-zero span of the previous row.
-// Here the row state eh[] of a task lives in LDS (8 B per column: H | E + the query base), and each row loads just the
+// Here the row state eh[] of a task lives in LDS (one word per column: H | E << 14 | the query base << 28), and each row loads just the
 // live columns [beg, end) into a window of kWin columns per lane (LPT * kWin per task: 32 as launched), computes them (F as a prefix
 // maximum: a lane's own columns sequentially, then four DPP steps over the lanes), and stores them back; a band wider than the window takes further passes with the prefix maximum and
 // the last H carried over.  Columns outside the band keep their stale values in LDS, as scalarBandedSWA's eh[] does.
@@ -334,10 +342,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
     bwams_seqpair_t *__restrict__ pairs, const int32_t *__restrict__ list, const unsigned long long *n_list_p,
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, int w0, SwParams prm, DevCounters *ctr, unsigned long long *head,
     int cols) {
-    extern __shared__ uint2 qwin_lds[];                            // [wave][task slot][cols]: {H, E | query base << 28}
+    extern __shared__ uint32_t qwin_lds[];                         // [wave][task slot][cols]: H (14 bits) | E << 14 | query base << 28
     constexpr int TPW = 64 / LPT;                                  // tasks per wavefront
     const int lane = threadIdx.x & 63, g = lane & (LPT - 1), q = lane / LPT;
-    uint2 *const row_eh = qwin_lds + (size_t)(((threadIdx.x >> 6) * TPW + q) * cols);
+    uint32_t *const row_eh = qwin_lds + (size_t)(((threadIdx.x >> 6) * TPW + q) * cols);
     const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     int pk[5], pn[5];                                              // score rows of the matrix, one per target base
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
                     if (c >= 1) { h = h0 - oe_ins - (c - 1) * e_ins; h = h > 0 ? h : 0; }
                     uint32_t qb = c < qlen ? (uint32_t)tq[c] : 4u;
                     qb = qb > 4u ? 4u : qb;
-                    row_eh[c] = make_uint2((uint32_t)h, qb << 28);
+                    row_eh[c] = (uint32_t)h | (qb << 28);
                 }
                 w = w0;
                 {
@@ -430,10 +438,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
             for (int c = 0; c < kWin; ++c) {
                 const int j = jb + c;
                 const bool act = in && j < end;
-                uint2 wd = make_uint2(0u, 0u);
+                uint32_t wd = 0u;
                 if (act) wd = row_eh[j];
-                const int hd = (int)wd.x, e = (int)(wd.y & 0x0fffffffu);
-                const uint32_t qb = wd.y >> 28;
+                const int hd = (int)(wd & 0x3fffu), e = (int)((wd >> 14) & 0x3fffu);
+                const uint32_t qb = wd >> 28;
                 const int S = qb < 4u ? __builtin_amdgcn_sbfe(pkt, qb << 3, 8u) : pnt;
                 const int M = (act && hd) ? hd + S : 0;
                 int tj = M - oe_ins;
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
                 int hl = c ? Hh[c - 1] : h_in;
                 if (j == beg) hl = h1;
                 if (act) {
-                    row_eh[j] = make_uint2((uint32_t)hl, (uint32_t)E2[c] | (Qb[c] << 28));
+                    row_eh[j] = (uint32_t)hl | ((uint32_t)E2[c] << 14) | (Qb[c] << 28);
                     const int k = (Hh[c] << 8) | j;
                     key = key > k ? key : k;
                     if (hl != 0 || E2[c] != 0) { first_nz = first_nz < j ? first_nz : j; last_nz = j; }
@@ -491,8 +499,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
         const int h1f = row ? hlast : h1;
         if (alive) {
             if (g == 0) {                                           // eh[end] = {h1f, 0}
-                const uint2 we = row_eh[end];
-                row_eh[end] = make_uint2((uint32_t)h1f, we.y & 0xf0000000u);
+                row_eh[end] = (uint32_t)h1f | (row_eh[end] & 0xf0000000u);
             }
             if (row) cells += (unsigned long long)(g == 0 ? end - beg : 0);
             const int j_exit = row ? end : beg;
@@ -583,14 +590,14 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
     static bool qwin_attr = false;
     if (!qwin_attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_qwin_kernel<kBswLpt, kBswWin>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 8));
+                                  (int)((size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4));
         qwin_attr = true;
     }
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 8, q[2]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 8, q[1]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 96 * 8, q[0]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 64 * 8, q[2]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 32 * 8, q[1]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4, q[2]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 4, q[1]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 96 * 4, q[0]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 64 * 4, q[2]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 32 * 4, q[1]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
     if (n_aux)
         for (int c = 0; c < n_aux; ++c) {
             if (hipEventRecord(join[c], q[c + 1]) != hipSuccess) return -1;

@@ -19,10 +19,16 @@ def short(k):
     for pat, name in (("smem_search_kernel<true>", "smem_search_kernel<true> (SMEM round 1)"),
                       ("smem_search_kernel<false>", "smem_search_kernel<false> (SMEM round 2)"),
                       ("seed_strategy", "seed_strategy_kernel (SMEM round 3)"), ("sa_lookup", "sa_lookup_kernel"),
-                      ("bsw_kernel_reg<1>", "bsw_kernel_reg<1> (queries <= 64)"),
-                      ("bsw_kernel_reg<2>", "bsw_kernel_reg<2> (queries 65..128)"),
-                      ("bsw_kernel_reg<3>", "bsw_kernel_reg<3> (queries 129..192)"), ("bsw_kernel", "bsw_kernel (LDS, queries > 192)"),
-                      ("chain_count", "chain_count_kernel"), ("chain_wave", "chain_wave_kernel (wave per read, LDS state; 5 size classes)"),
+                      ("bsw_qwin_kernel", "bsw_qwin_kernel (banded SW, 8 tasks per wave; 5 query-length classes)"),
+                      ("bsw_classify", "bsw_classify_kernel"), ("bsw_kernel", "bsw_kernel (one task per wave, LDS: queries > 191)"),
+                      ("aln_dp_kernel", "aln_dp_kernel (mem_reg2aln: banded global alignment + traceback)"),
+                      ("aln_simple", "aln_simple_kernel (mem_reg2aln: gap-free regions)"), ("aln_gather", "aln_gather_kernel"),
+                      ("aln_plan", "aln_plan_kernel"),
+                      ("key_collect", "key_collect_kernel (index build: MSD chunk collection)"),
+                      ("chunk_finish", "chunk_finish_kernel (index build)"), ("bwt_block", "bwt_block_kernel (index build: BWT -> CP_OCC)"),
+                      ("round_keys", "round_keys_kernel (index build: doubling round)"), ("round_finish", "round_finish_kernel (index build)"),
+                      ("key_hist", "key_hist_kernel (index build)"), ("sa_sample", "sa_sample_kernel (index build)"),
+                      ("chain_count", "chain_count_kernel"), ("chain_wave", "chain_wave_kernel (wave per read, LDS state; 6 size classes)"),
                       ("chain_heavy", "chain_heavy_kernel (sort + filter of many-chain reads)"),
                       ("chain_emit", "chain_emit_kernel"), ("chain_kernel", "chain_kernel (lane per read)"),
                       ("ext_plan", "ext_plan_kernel"), ("ext_build", "ext_build_kernel (task construction)"),
@@ -60,6 +66,7 @@ ks = newest(src + "/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(ks, f"profiles/{rnd}_kernel_stats.csv")
 rows = list(csv.DictReader(open(ks)))
 P = {}
+N = {}          # launches per run (3 steps)
 for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     fs = newest(f"{src}/{p}/*/*_counter_collection.csv")
     if not fs:
@@ -72,16 +79,18 @@ for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
         if s:
             for c, x in v.items():
                 P.setdefault(s, {})[c] = sum(x) / len(x)
+                N[s] = len(x)
 
 r1 = P["smem_search_kernel<true> (SMEM round 1)"]
 fetch, write = r1["FETCH_SIZE"] * 1024, r1["WRITE_SIZE"] * 1024
 alg = bench["roofline"]["bytes_per_launch"]
 with open(f"profiles/{rnd}_summary.md", "w") as f:
     f.write(f"# Round {rnd} — rocprofv3 summary (MI355X, gfx950, ROCm 7.2)\n\n")
-    f.write("Collected by `bash profiles/run_profiles.sh <tag> 1000`: `rocprofv3 --kernel-trace --stats -- python3 bench.py "
-            "--genome-mbp 1000 --steps 2 --warmup 1 --no-cpu-baseline` plus one `--pmc` pass per counter group (never combined "
+    f.write("Collected by `bash profiles/run_profiles_r02.sh <tag>` at the metric's configuration (synthetic genome of GRCh38's size, 6.4 G index rows): "
+            "`rocprofv3 --kernel-trace --stats -- python3 bench.py "
+            "--steps 2 --warmup 1 --no-cpu-baseline --no-pe` plus one `--pmc` pass per counter group (never combined "
             f"with tracing); summarised by `profiles/make_summary.py`.  Raw: `profiles/{rnd}_kernel_stats.csv`.\n\n")
-    f.write("## Kernel time (library kernels; torch / rocPRIM kernels of the untimed index build omitted)\n\n"
+    f.write("## Kernel time (library kernels; rocPRIM kernels omitted; the index-build kernels run once, untimed by bench.py)\n\n"
             "3 steps per run (1 warm-up + 2 timed); kernels that run once per extension round or per query-length class have "
             "several calls per step, so the per-step column is total / 3.\n\n| kernel | calls | avg ms | ms per step |\n|---|---|---|---|\n")
     for r in rows:
@@ -100,13 +109,14 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
     f.write(f"\n`roofline.launch_ms` measured live by `bench.py` with HIP events in the run below: {bench['roofline']['launch_ms']} ms "
             "(the rocprofv3 average above covers warm-up + timed launches of the profiled run).\n\n")
     f.write("## PMC per launch (uncorrected counter values; average over the launches of one run)\n\n"
-            "| kernel | FETCH_SIZE (GB) | WRITE_SIZE (GB) | TCC hit / miss (M req) | ACTIVE_INST_ANY / WAVE_CYCLES | VALU wave-insts (G) |\n|---|---|---|---|---|---|\n")
+            "| kernel | launches / 3 steps | FETCH_SIZE (GB) | WRITE_SIZE (GB) | TCC hit / miss (M req) | ACTIVE_INST_ANY / WAVE_CYCLES | WAIT_ANY / WAVE_CYCLES | VALU / SALU wave-insts (G) |\n|---|---|---|---|---|---|---|---|\n")
     for s, c in P.items():
         if "FETCH_SIZE" not in c:
             continue
-        f.write(f"| {s} | {c['FETCH_SIZE']*1024/1e9:.2f} | {c.get('WRITE_SIZE',0)*1024/1e9:.2f} | {c.get('TCC_HIT_sum',0)/1e6:.0f} / "
+        f.write(f"| {s} | {N.get(s, 0)} | {c['FETCH_SIZE']*1024/1e9:.2f} | {c.get('WRITE_SIZE',0)*1024/1e9:.2f} | {c.get('TCC_HIT_sum',0)/1e6:.0f} / "
                 f"{c.get('TCC_MISS_sum',0)/1e6:.0f} | {c.get('SQ_ACTIVE_INST_ANY',0)/max(c.get('SQ_WAVE_CYCLES',1),1):.3f} | "
-                f"{c.get('SQ_INSTS_VALU',0)/1e9:.2f} |\n")
+                f"{c.get('SQ_WAIT_ANY',0)/max(c.get('SQ_WAVE_CYCLES',1),1):.3f} | "
+                f"{c.get('SQ_INSTS_VALU',0)/1e9:.2f} / {c.get('SQ_INSTS_SALU',0)/1e9:.2f} |\n")
     f.write(f"""
 **Calibration of FETCH_SIZE on this access pattern** (`tools/ubench_gather.hip` under `rocprofv3 --pmc FETCH_SIZE` and
 `--pmc TCC_EA0_RDREQ_sum`, known byte counts): a random 16-, 32-, 64- and 128-byte read per lane all report exactly one
@@ -115,7 +125,15 @@ prescribes ("128-B requests tallied at 64 B"), and all four shapes saturate at t
 128-B lines.  Every random request moves one 128-B line: **HBM read bytes = 2 x FETCH_SIZE**; WRITE_SIZE is exact.
 
 Round-1 search kernel per launch: algorithmic bytes {alg/1e9:.2f} GB; corrected traffic = 2 x {fetch/1e9:.2f} + {write/1e9:.2f}
-= **{(2*fetch+write)/1e9:.1f} GB** = {(2*fetch+write)/alg:.2f}x algorithmic.
+= **{(2*fetch+write)/1e9:.1f} GB** = {(2*fetch+write)/alg:.2f}x algorithmic.  At {bench['roofline']['launch_ms']} ms per launch that is
+{(2*fetch+write)/(bench['roofline']['launch_ms']*1e-3)/1e12:.2f} TB/s of HBM traffic ({(2*fetch+write)/(bench['roofline']['launch_ms']*1e-3)/8e12:.2f} of the 8 TB/s peak,
+{(2*fetch+write)/(bench['roofline']['launch_ms']*1e-3)/6.3e12:.2f} of the 6.3 TB/s a streaming copy reaches), against `roofline.frac` = {bench['roofline']['frac']} in algorithmic bytes.
+L2 misses per launch {r1.get('TCC_MISS_sum',0)/1e6:.0f} M = {r1.get('TCC_MISS_sum',0)/(bench['roofline']['launch_ms']*1e-3)/1e9:.1f} G lines/s; `tools/ubench_gather` (mode 1, the kernel's quad-cooperative
+fetch, a 12 GiB table) tops out at 48 G random 64-byte blocks/s = 3.07 TB/s of useful bytes = 0.38 of peak when every block is its own line.
+
+Banded-SW kernels per step: {sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3e9:.1f} G vector and
+{sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3e9:.1f} G scalar wave-instructions (chip issue rates: 1228.8 G VALU/s at one per 2 cycles per SIMD,
+614.4 G SALU/s at one per cycle per CU, 2.4 GHz) in `stage_ms.ext_total` = {bench['stage_ms']['ext_total']} ms.
 
 ## Smith-Waterman kernels alone, against the real reference objects on the host cores
 
@@ -135,6 +153,11 @@ json.dump({"genome_mbp": bench["config"]["genome_mbp"], "reads": bench["config"]
            "smem_round1_hbm_bytes_per_launch": int(2 * fetch + write),
            "smem_round1_fetch_size_bytes": int(fetch), "smem_round1_write_size_bytes": int(write),
            "correction": "HBM read bytes = 2 x FETCH_SIZE (calibrated with tools/ubench_gather: one 128-B line per random request), WRITE_SIZE exact",
-           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/run_profiles.sh"},
+           "smem_round1_measured_frac": round((2 * fetch + write) / (bench["roofline"]["launch_ms"] * 1e-3) / 8e12, 4),
+           "smem_round1_l2_hit_miss": [int(r1.get("TCC_HIT_sum", 0)), int(r1.get("TCC_MISS_sum", 0))],
+           "bsw_valu_insts": int(sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3),
+           "bsw_salu_insts": int(sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3),
+           "commit": os.popen("git rev-parse --short HEAD").read().strip(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_* (separate passes), profiles/run_profiles_r02.sh; bsw_* = wave-instructions per step"},
           open(f"profiles/{rnd}_pmc_summary.json", "w"), indent=1)
 print(open(f"profiles/{rnd}_summary.md").read()[:2500])

@@ -64,6 +64,9 @@ int64_t orc_fmi_occ(const orc_fmi_t *f, int64_t pos, int c);
 void orc_backward_ext(const orc_fmi_t *f, const bwams_smem_t *in, int a,
                       bwams_smem_t *out, orc_counters_t *ctr);
 
+/* forward extension by base a (src/FMI_search.cpp:1475-1485) */
+void orc_forward_ext(const orc_fmi_t *f, const bwams_smem_t *in, int a, bwams_smem_t *out);
+
 /* getSMEMsOnePosOneThread (src/FMI_search.cpp:1372-1606), FM-index only path
  * (no all_smem table).  query_pos[] is in/out; returns SMEMs appended. */
 int64_t orc_smem_one_pos(const orc_fmi_t *f, const uint8_t *enc_qdb,
@@ -214,6 +217,28 @@ int64_t orc_pair_pe(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint
                     const int64_t *cum_len, int32_t n_pairs, const bwams_alnreg_t *regs, const int64_t *reg_off,
                     const bwams_pestat_t pes[4], int64_t id_base, int flags /* 1: no rescue, 2: useErt */, bwams_alnreg_t *out, int64_t out_cap,
                     int64_t *out_off, bwams_pair_t *pairs);
+
+/* ---- ERT index (ert_oracle.c): writer, decoder, seeding.  PARITY UNPINNED (see the file header). ---- */
+typedef struct orc_ert {
+    int32_t kmer, xmer, read_len, hit_threshold;   /* kmerSize 15, xmerSize 4, READ_LEN, HIT_THRESHOLD 256 in the reference */
+    const uint64_t *kmer_table;                    /* 4^kmer entries */
+    const uint8_t *mlt;                            /* <prefix>.mlt_table */
+    int64_t mlt_bytes;
+    const uint8_t *ref;                            /* .0123, both strands */
+    int64_t ref_len;                               /* 2 * l_pac */
+} orc_ert_t;
+/* buildKmerTrees (src/ertindex.cpp:773-943): fills kmer_table (4^kmer entries) and returns the malloc'ed tree bytes */
+uint8_t *orc_ert_build(const orc_fmi_t *f, int kmer, int xmer, int read_len, int hit_threshold, uint64_t *kmer_table,
+                       int64_t *mlt_bytes);
+void orc_ert_free(uint8_t *p);
+/* L[m-1] = longest prefix of read[i..) with at least m occurrences, m = 1..M (M <= 20) */
+void orc_ert_profile(const orc_ert_t *e, const uint8_t *q, int len, int i, int M, uint8_t *L);
+/* occurrences of read[i, i+mlen) in right-context order; returns the count */
+int64_t orc_ert_hits(const orc_ert_t *e, const uint8_t *q, int len, int i, int mlen, int64_t *hits, int64_t cap);
+/* the three seeding rounds + hit sampling of mem_kernel1_core_ert, in the layout of orc_collect_smem + orc_sa_lookup */
+int64_t orc_ert_collect(const orc_ert_t *e, const bwams_seed_opt_t *opt, const uint8_t *enc, const int64_t *cum,
+                        const uint8_t *skip, int32_t nseq, bwams_smem_t *out, int64_t cap, int64_t *sa_coord,
+                        int64_t sa_cap, int64_t *sa_off);
 
 #ifdef __cplusplus
 }

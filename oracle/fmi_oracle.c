@@ -76,6 +76,11 @@ static void forward_ext(const orc_fmi_t *f, const bwams_smem_t *in, int a,
     out->l = r.k;
 }
 
+void orc_forward_ext(const orc_fmi_t *f, const bwams_smem_t *in, int a, bwams_smem_t *out)
+{
+    forward_ext(f, in, a, out, NULL);
+}
+
 /* all_smem_t / last_smem_t exactly as the reference packs them (src/FMI_search.h:108-133) */
 typedef struct __attribute__((packed)) {
     uint32_t last_avail;

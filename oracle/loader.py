@@ -82,6 +82,7 @@ _lib = None
 def build() -> str:
     out = os.path.join(HERE, "_build", "liboracle.so")
     srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "emf_oracle.c", "chain_oracle.c", "dedup_oracle.c",
+                                            "pair_oracle.c", "aln_oracle.c", "ert_oracle.c",
                                             "bwams_oracle.h", "../include/bwams_types.h")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "_build/liboracle.so"])
@@ -272,6 +273,74 @@ class OracleFMI:
                                 C.byref(counters) if counters is not None else None)
         assert t >= 0
         return coord[:t].copy(), off
+
+
+class OrcErt(C.Structure):
+    _fields_ = [("kmer", C.c_int32), ("xmer", C.c_int32), ("read_len", C.c_int32), ("hit_threshold", C.c_int32),
+                ("kmer_table", C.c_void_p), ("mlt", C.c_void_p), ("mlt_bytes", C.c_int64),
+                ("ref", C.c_void_p), ("ref_len", C.c_int64)]
+
+
+class OracleERT:
+    """ERT index built by the restated writer (ert_oracle.c) over an OracleFMI; kmer_table / mlt are numpy arrays in
+    the reference's file layout (<prefix>.kmer_table, <prefix>.mlt_table)."""
+
+    def __init__(self, fmi: "OracleFMI", ref_0123, kmer: int = 15, xmer: int = 4, read_len: int = 151, hit_threshold: int = 256):
+        L = lib()
+        L.orc_ert_build.restype = C.c_void_p
+        L.orc_ert_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_ert_free.restype = None
+        L.orc_ert_free.argtypes = [C.c_void_p]
+        L.orc_ert_profile.restype = None
+        L.orc_ert_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_ert_hits.restype = C.c_int64
+        L.orc_ert_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.orc_ert_collect.restype = C.c_int64
+        L.orc_ert_collect.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        self.fmi = fmi
+        self.kmer_table = np.zeros(4 ** kmer, dtype=np.uint64)
+        nb = C.c_int64(0)
+        ptr = L.orc_ert_build(C.byref(fmi.f), kmer, xmer, read_len, hit_threshold, _p(self.kmer_table), C.byref(nb))
+        self.mlt = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(int(nb.value), 1),)).copy()[:int(nb.value)]
+        L.orc_ert_free(ptr)
+        self.mlt_pad = np.concatenate([self.mlt, np.zeros(16, dtype=np.uint8)])     # 5-/8-byte reads near the end
+        self.ref = np.ascontiguousarray(ref_0123, dtype=np.uint8)
+        self.e = OrcErt(kmer, xmer, read_len, hit_threshold, self.kmer_table.ctypes.data, self.mlt_pad.ctypes.data,
+                        int(nb.value), self.ref.ctypes.data, len(self.ref))
+
+    def profile(self, read, i: int, M: int = 20):
+        q = np.ascontiguousarray(read, dtype=np.uint8)
+        out = np.zeros(M, dtype=np.uint8)
+        lib().orc_ert_profile(C.byref(self.e), _p(q), len(q), i, M, _p(out))
+        return out
+
+    def hits(self, read, i: int, mlen: int, cap: int = 1 << 16):
+        q = np.ascontiguousarray(read, dtype=np.uint8)
+        out = np.zeros(cap, dtype=np.int64)
+        n = lib().orc_ert_hits(C.byref(self.e), _p(q), len(q), i, mlen, _p(out), cap)
+        return out[:min(n, cap)].copy(), n
+
+    def collect(self, enc, cum, opt: SeedOpt | None = None, skip=None):
+        """-> (smems in (rid, m, n) order with k = l = 0, sa_coord, sa_off): what collect_smem + sa_lookup give"""
+        opt = opt or default_seed_opt()
+        nseq = len(cum) - 1
+        cap = 3 * int(cum[-1] - cum[0]) + 64
+        out = np.zeros(cap, dtype=SMEM_DTYPE)
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        cum = np.ascontiguousarray(cum, dtype=np.int64)
+        sk = np.ascontiguousarray(skip, dtype=np.uint8) if skip is not None else None
+        sa_cap = cap * 8 + 1024
+        while True:
+            coord = np.zeros(sa_cap, dtype=np.int64)
+            off = np.zeros(cap + 1, dtype=np.int64)
+            n = lib().orc_ert_collect(C.byref(self.e), C.byref(opt), _p(enc), _p(cum), _p(sk), nseq, _p(out), cap,
+                                      _p(coord), sa_cap, _p(off))
+            if n == -1 and sa_cap < (1 << 30):
+                sa_cap *= 8
+                continue
+            break
+        assert n >= 0, f"orc_ert_collect -> {n}"
+        return out[:n].copy(), coord[:off[n]].copy(), off[:n + 1].copy()
 
 
 def bsw_pairs(pairs, ref, qer, w: int, opt: SwOpt | None = None):

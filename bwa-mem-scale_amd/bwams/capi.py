@@ -27,6 +27,7 @@ SYMBOLS = [
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
+    "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
     "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
@@ -236,6 +237,12 @@ def lib():
         L.bwams_emf_run.argtypes = [vp, vp]
         L.bwams_emf_fetch.argtypes = [vp, vp, vp]
         L.bwams_emf_probe.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+        L.bwams_ert_from_host.argtypes = [vp, vp, i32, i32, i32, vp, i64, vp]
+        L.bwams_ert_open.argtypes = [vp, C.c_char_p, i32, vp]
+        L.bwams_ert_close.argtypes = [vp]
+        L.bwams_ert_bytes.restype = i64
+        L.bwams_ert_bytes.argtypes = [vp]
+        L.bwams_seed_run_ert.argtypes = [vp, vp, vp, C.c_int]
         L.bwams_batch_stats.argtypes = [vp, vp]
         L.bwams_batch_sync.argtypes = [vp]
         _lib = L
@@ -382,6 +389,31 @@ class Emf:
             self.h = None
 
 
+class Ert:
+    """ERT index resident in HBM: the reference's <prefix>.kmer_table / <prefix>.mlt_table, from files or host arrays."""
+
+    def __init__(self, index: Index, kmer_table=None, mlt_table=None, kmer: int = 15, xmer: int = 4, read_len: int = 151,
+                 prefix: str | None = None):
+        self.index = index
+        self.h = C.c_void_p()
+        if prefix is not None:
+            _chk(lib().bwams_ert_open(index.h, prefix.encode(), read_len, C.byref(self.h)), "bwams_ert_open")
+        else:
+            kt = np.ascontiguousarray(kmer_table, dtype=np.uint64)
+            mt = np.ascontiguousarray(mlt_table, dtype=np.uint8)
+            assert len(kt) == 4 ** kmer
+            _chk(lib().bwams_ert_from_host(index.h, _p(kt), kmer, xmer, read_len, _p(mt), len(mt), C.byref(self.h)),
+                 "bwams_ert_from_host")
+
+    def nbytes(self) -> int:
+        return int(lib().bwams_ert_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            lib().bwams_ert_close(self.h)
+            self.h = None
+
+
 class Batch:
     def __init__(self, index: Index, max_reads: int, max_bases: int, max_smem: int = 0, max_sa: int = 0):
         self.index = index
@@ -439,6 +471,11 @@ class Batch:
     def seed_run(self, opt: SeedOpt | None = None, with_sa: bool = True):
         opt = opt or default_seed_opt()
         _chk(lib().bwams_seed_run(self.h, C.byref(opt), 1 if with_sa else 0), "bwams_seed_run")
+
+    def seed_run_ert(self, ert: "Ert", opt: SeedOpt | None = None, with_sa: bool = True):
+        """Seeding over the ERT: same outputs as seed_run (seed_fetch, chain_run follow unchanged)."""
+        opt = opt or default_seed_opt()
+        _chk(lib().bwams_seed_run_ert(self.h, ert.h, C.byref(opt), 1 if with_sa else 0), "bwams_seed_run_ert")
 
     def seed_counts(self):
         ns, na = C.c_int64(0), C.c_int64(0)

@@ -16,6 +16,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "fmi_kernels.h"
+#include "ert_kernels.h"
 
 namespace bwams {
 
@@ -491,7 +492,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -584,6 +585,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
 int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
     if (!b || !opt) return BWAMS_ERR_ARG;
     b->last_seed_opt = *opt;
+    b->seed_ert = nullptr;
     int rc = seed_run_once(b, opt, with_sa);
     if (rc == BWAMS_ERR_CAPACITY && b->n_smem > b->max_smem) {
         BWAMS_HIP(hipStreamSynchronize(b->stream));
@@ -718,6 +720,12 @@ int bwams_seed_counts(bwams_batch_t *b, int64_t *n_smem, int64_t *n_sa) {
         b->max_sa = b->n_sa + b->n_sa / 8 + 1024;
         BWAMS_HIP(hipMalloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_sa_lookups, 0, 2 * sizeof(unsigned long long), b->stream));   // + n_lf_steps
+        if (b->seed_ert) {
+            launch_ert_locate(b->seed_ert->t, b->d_enc, b->d_cum, b->d_sorted, b->n_smem, b->d_sa_cnt, b->last_seed_opt.max_occ,
+                              b->d_ctr, b->stream);
+            launch_ert_gather(b->seed_ert->t, b->d_sorted, b->n_smem, b->d_sa_off, b->d_sa_coord, b->max_sa,
+                              b->last_seed_opt.max_occ, b->d_ctr, b->stream);
+        } else
         launch_sa_lookup(b->idx->fmi, b->d_sorted, b->n_smem, b->d_sa_off, b->d_sa_coord, b->max_sa, b->last_seed_opt.max_occ,
                          b->d_ctr, b->cu_count, b->stream);
         BWAMS_HIP(hipEventRecord(b->ev[5], b->stream));
@@ -773,6 +781,223 @@ int bwams_seed_fmi(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, con
     rc = bwams_seed_counts(b, n_smem, n_sa);
     if (rc) return rc;
     return bwams_seed_fetch(b, smem_out, smem_cap, sa_coord, sa_cap, sa_off);
+}
+
+/* ------------------------------------------------------------ ERT seeding -- */
+
+int bwams_ert_from_host(bwams_index_t *ix, const uint64_t *kmer_table, int32_t kmer_size, int32_t xmer_size,
+                        int32_t read_len, const uint8_t *mlt_table, int64_t mlt_bytes, bwams_ert_t **out) {
+    if (!ix || !out || !kmer_table || (mlt_bytes && !mlt_table) || mlt_bytes < 0) return BWAMS_ERR_ARG;
+    if (kmer_size < 2 || kmer_size > 15 || xmer_size < 1 || xmer_size > 8 || read_len < kmer_size + xmer_size) {
+        set_last_error("bwams_ert_from_host: k-mer size must be in [2, 15], x-mer size in [1, 8]");
+        return BWAMS_ERR_ARG;
+    }
+    if (!ix->d_ref) {
+        set_last_error("bwams_ert_from_host: the index was opened without its .0123 reference");
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(ix->device));
+    bwams_ert *e = new bwams_ert();
+    e->idx = ix;
+    const size_t nk = (size_t)1 << (2 * kmer_size);
+    hipError_t he = hipMalloc(&e->d_kmer, nk * 8);
+    if (he == hipSuccess) he = hipMalloc(&e->d_mlt, (size_t)mlt_bytes + 16);
+    if (he == hipSuccess) he = hipMemcpy(e->d_kmer, kmer_table, nk * 8, hipMemcpyHostToDevice);
+    if (he == hipSuccess && mlt_bytes) he = hipMemcpy(e->d_mlt, mlt_table, (size_t)mlt_bytes, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemset((uint8_t *)e->d_mlt + mlt_bytes, 0, 16);
+    if (he != hipSuccess) {
+        set_last_error(std::string("bwams_ert_from_host: ") + hipGetErrorString(he));
+        bwams_ert_close(e);
+        return he == hipErrorOutOfMemory ? BWAMS_ERR_NOMEM : BWAMS_ERR_DEVICE;
+    }
+    e->t.kmer = (const uint64_t *)e->d_kmer;
+    e->t.mlt = (const uint8_t *)e->d_mlt;
+    e->t.ref = ix->fmi.ref;
+    e->t.ref_len = ix->fmi.ref_seq_len - 1;
+    e->t.K = kmer_size; e->t.X = xmer_size; e->t.read_len = read_len;
+    e->bytes = (int64_t)(nk * 8) + mlt_bytes + 16;
+    *out = e;
+    return BWAMS_OK;
+}
+
+int bwams_ert_open(bwams_index_t *ix, const char *prefix, int32_t read_len, bwams_ert_t **out) {
+    if (!ix || !prefix || !out) return BWAMS_ERR_ARG;
+    if (!ix->d_ref) {
+        set_last_error("bwams_ert_open: the index was opened without its .0123 reference");
+        return BWAMS_ERR_ARG;
+    }
+    const int K = 15, X = 4;                       // kmerSize / xmerSize, src/macro.h:204-206
+    const std::string fk = std::string(prefix) + ".kmer_table", fm = std::string(prefix) + ".mlt_table";
+    FILE *f1 = fopen(fk.c_str(), "rb"), *f2 = fopen(fm.c_str(), "rb");
+    if (!f1 || !f2) {
+        if (f1) fclose(f1);
+        if (f2) fclose(f2);
+        set_last_error("bwams_ert_open: cannot open " + (f1 ? fm : fk));
+        return BWAMS_ERR_IO;
+    }
+    fseek(f2, 0, SEEK_END);
+    const int64_t mlt_bytes = (int64_t)ftell(f2);
+    fseek(f2, 0, SEEK_SET);
+    BWAMS_HIP(hipSetDevice(ix->device));
+    bwams_ert *e = new bwams_ert();
+    e->idx = ix;
+    const size_t nk = (size_t)1 << (2 * K);
+    int rc = BWAMS_OK;
+    const size_t chunk = (size_t)256 << 20;          // streamed through one pinned staging buffer
+    void *stage = nullptr;
+    hipError_t he = hipMalloc(&e->d_kmer, nk * 8);
+    if (he == hipSuccess) he = hipMalloc(&e->d_mlt, (size_t)mlt_bytes + 16);
+    if (he == hipSuccess) he = hipHostMalloc(&stage, chunk);
+    if (he != hipSuccess) rc = he == hipErrorOutOfMemory ? BWAMS_ERR_NOMEM : BWAMS_ERR_DEVICE;
+    auto stream_in = [&](FILE *f, void *dst, size_t total) {
+        size_t done = 0;
+        while (rc == BWAMS_OK && done < total) {
+            const size_t n = total - done < chunk ? total - done : chunk;
+            if (fread(stage, 1, n, f) != n) { rc = BWAMS_ERR_IO; break; }
+            if (hipMemcpy((uint8_t *)dst + done, stage, n, hipMemcpyHostToDevice) != hipSuccess) { rc = BWAMS_ERR_DEVICE; break; }
+            done += n;
+        }
+    };
+    if (rc == BWAMS_OK) stream_in(f1, e->d_kmer, nk * 8);
+    if (rc == BWAMS_OK) stream_in(f2, e->d_mlt, (size_t)mlt_bytes);
+    if (rc == BWAMS_OK && hipMemset((uint8_t *)e->d_mlt + mlt_bytes, 0, 16) != hipSuccess) rc = BWAMS_ERR_DEVICE;
+    fclose(f1); fclose(f2);
+    if (stage) (void)hipHostFree(stage);
+    if (rc != BWAMS_OK) {
+        set_last_error("bwams_ert_open: reading " + fk + " / " + fm + " failed");
+        bwams_ert_close(e);
+        return rc;
+    }
+    e->t.kmer = (const uint64_t *)e->d_kmer;
+    e->t.mlt = (const uint8_t *)e->d_mlt;
+    e->t.ref = ix->fmi.ref;
+    e->t.ref_len = ix->fmi.ref_seq_len - 1;
+    e->t.K = K; e->t.X = X; e->t.read_len = read_len;
+    e->bytes = (int64_t)(nk * 8) + mlt_bytes + 16;
+    *out = e;
+    return BWAMS_OK;
+}
+
+int bwams_ert_close(bwams_ert_t *e) {
+    if (!e) return BWAMS_OK;
+    (void)hipSetDevice(e->idx->device);
+    if (e->d_kmer) (void)hipFree(e->d_kmer);
+    if (e->d_mlt) (void)hipFree(e->d_mlt);
+    delete e;
+    return BWAMS_OK;
+}
+
+int64_t bwams_ert_bytes(const bwams_ert_t *e) { return e ? e->bytes : 0; }
+
+static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t *opt, int with_sa, int M) {
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    b->with_sa = with_sa != 0;
+    b->n_smem = b->n_sa = 0;
+    const int64_t need = (int64_t)(M + 1) * (b->nbases > 0 ? b->nbases : 1);
+    if (need > b->cap_ert_prof) {
+        if (b->d_ert_prof) (void)hipFree(b->d_ert_prof);
+        b->d_ert_prof = nullptr;
+        b->cap_ert_prof = need + need / 8;
+        BWAMS_HIP(hipMalloc(&b->d_ert_prof, (size_t)b->cap_ert_prof));
+    }
+    const uint8_t *skip = b->has_skip ? b->d_skip : nullptr;
+    // events: 0 start | 8,9 match profiles | 10,11 the three rounds | 3,4 sort | 12,13 locate | 4,5 locate + hits
+    BWAMS_HIP(hipMemsetAsync(b->d_ctr, 0, sizeof(DevCounters), st));
+    BWAMS_HIP(hipEventRecord(b->ev[0], st));
+    BWAMS_HIP(hipMemsetAsync(b->d_ert_prof, 0, (size_t)need, st));
+    BWAMS_HIP(hipEventRecord(b->ev[8], st));
+    launch_ert_profile(e->t, b->d_enc, b->d_cum, skip, b->nseq, b->nbases, M, b->d_ert_prof, st);
+    BWAMS_HIP(hipEventRecord(b->ev[9], st));
+    BWAMS_HIP(hipEventRecord(b->ev[10], st));
+    launch_ert_select(b->d_ert_prof, b->d_cum, skip, b->nseq, b->nbases, M, *opt, b->d_pool, b->pool_cap, b->d_ctr, st);
+    BWAMS_HIP(hipEventRecord(b->ev[11], st));
+    BWAMS_HIP(hipEventRecord(b->ev[3], st));
+    BWAMS_HIP(hipGetLastError());
+    BWAMS_HIP(hipMemcpyAsync(&b->d_ctr->n_smem_valid, &b->d_ctr->n_smem_total, 8, hipMemcpyDeviceToDevice, st));
+    BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    const int64_t n = (int64_t)b->h_ctr->n_smem_total;
+    b->n_smem = n;
+    if (n > b->max_smem || n > b->pool_cap) {
+        set_last_error("SMEM pool overflow: need " + std::to_string(n) + " slots");
+        b->seed_done = true;
+        return BWAMS_ERR_CAPACITY;
+    }
+    if (n > 0) {
+        launch_make_keys(b->d_pool, n, b->d_keys, b->d_vals, (uint32_t)b->nseq, st);
+        int rid_bits = 1;
+        while (((int64_t)1 << rid_bits) <= b->nseq) rid_bits++;
+        size_t tb = 0;
+        BWAMS_HIP(rocprim::radix_sort_pairs(nullptr, tb, b->d_keys, b->d_keys2, b->d_vals, b->d_vals2, (size_t)n, 0,
+                                            32 + rid_bits, st));
+        if (tb > b->tmp_bytes) {
+            BWAMS_HIP(hipStreamSynchronize(st));
+            (void)hipFree(b->d_tmp);
+            b->d_tmp = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            b->tmp_bytes = tb;
+        }
+        tb = b->tmp_bytes;
+        BWAMS_HIP(rocprim::radix_sort_pairs(b->d_tmp, tb, b->d_keys, b->d_keys2, b->d_vals, b->d_vals2, (size_t)n, 0,
+                                            32 + rid_bits, st));
+        launch_gather_sorted(b->d_pool, b->d_vals2, n, b->d_sorted, nullptr, opt->max_occ, st);
+    }
+    BWAMS_HIP(hipEventRecord(b->ev[4], st));
+    BWAMS_HIP(hipEventRecord(b->ev[12], st));
+    launch_ert_locate(e->t, b->d_enc, b->d_cum, b->d_sorted, n, with_sa ? b->d_sa_cnt : nullptr, opt->max_occ, b->d_ctr, st);
+    BWAMS_HIP(hipEventRecord(b->ev[13], st));
+    if (with_sa && n > 0) {
+        size_t tb = 0;
+        BWAMS_HIP(rocprim::exclusive_scan(nullptr, tb, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)n + 1,
+                                          rocprim::plus<int64_t>(), st));
+        if (tb > b->tmp_bytes) {
+            BWAMS_HIP(hipStreamSynchronize(st));
+            (void)hipFree(b->d_tmp);
+            b->d_tmp = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            b->tmp_bytes = tb;
+        }
+        tb = b->tmp_bytes;
+        BWAMS_HIP(hipMemsetAsync(b->d_sa_cnt + n, 0, 8, st));
+        BWAMS_HIP(rocprim::exclusive_scan(b->d_tmp, tb, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)n + 1,
+                                          rocprim::plus<int64_t>(), st));
+        launch_ert_gather(e->t, b->d_sorted, n, b->d_sa_off, b->d_sa_coord, b->max_sa, opt->max_occ, b->d_ctr, st);
+    }
+    BWAMS_HIP(hipEventRecord(b->ev[5], st));
+    BWAMS_HIP(hipGetLastError());
+    b->seed_done = true;
+    return BWAMS_OK;
+}
+
+int bwams_seed_run_ert(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t *opt, int with_sa) {
+    if (!b || !e || !opt) return BWAMS_ERR_ARG;
+    if (e->idx != b->idx) {
+        set_last_error("bwams_seed_run_ert: table and batch belong to different indexes");
+        return BWAMS_ERR_ARG;
+    }
+    const int M = opt->split_width + 1 > opt->max_mem_intv ? opt->split_width + 1 : opt->max_mem_intv;
+    if (opt->min_seed_len < e->t.K + e->t.X || M > 20 || M < 1) {
+        set_last_error("bwams_seed_run_ert: needs min_seed_len >= kmer + xmer size, split_width < 20 and max_mem_intv <= 20 "
+                       "(the trees store hit counts below 20 only)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    if (b->max_read_len > 255 || b->max_read_len > e->t.read_len) {
+        set_last_error("bwams_seed_run_ert: a read is longer than the read length the ERT was built for");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    b->last_seed_opt = *opt;
+    b->seed_ert = e;
+    int rc = ert_run_once(b, e, opt, with_sa, M);
+    if (rc == BWAMS_ERR_CAPACITY && b->n_smem > b->max_smem) {
+        BWAMS_HIP(hipStreamSynchronize(b->stream));
+        const int64_t need = b->n_smem + b->n_smem / 4 + 1024;
+        if ((rc = alloc_smem_buffers(b, need))) return rc;
+        b->tmp_bytes = 0;
+        if (b->d_tmp) { (void)hipFree(b->d_tmp); b->d_tmp = nullptr; }
+        rc = ert_run_once(b, e, opt, with_sa, M);
+    }
+    return rc;
 }
 
 /* -------------------------------------------------------------- extension -- */

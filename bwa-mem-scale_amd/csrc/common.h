@@ -50,6 +50,15 @@ struct DevEmf {
     int32_t seed_len;
 };
 
+// ERT index as the kernels see it: the reference's two files, resident (src/ertindex.cpp writes them)
+struct DevErt {
+    const uint64_t *kmer;      // <prefix>.kmer_table: 4^K entries
+    const uint8_t *mlt;        // <prefix>.mlt_table, padded by 16 bytes
+    const uint8_t *ref;        // .0123, both strands
+    int64_t ref_len;           // 2 * l_pac
+    int32_t K, X, read_len;    // kmerSize, xmerSize, READ_LEN of the build (src/macro.h:204-206, :66)
+};
+
 // device-side counters of one seed run
 struct DevCounters {
     unsigned long long n_ext, n_ext_blocks, n_sa_lookups, n_lf_steps;
@@ -126,6 +135,13 @@ namespace bwams {
 int bsw_list_ensure(bwams_batch *b, int64_t n_tasks);   // grows b->d_bsw_list (synchronises the stream when it must reallocate)
 }
 
+struct bwams_ert {
+    bwams_index *idx = nullptr;
+    bwams::DevErt t{};
+    void *d_kmer = nullptr, *d_mlt = nullptr;
+    int64_t bytes = 0;
+};
+
 struct bwams_emf {
     bwams_index *idx = nullptr;
     bwams::DevEmf t{};
@@ -172,6 +188,9 @@ struct bwams_batch {
 
     int64_t n_smem = 0, n_sa = 0;
     bool seed_done = false, with_sa = false;
+    bwams_ert *seed_ert = nullptr;       // the last seed run went over this ERT (nullptr: FM-index)
+    uint8_t *d_ert_prof = nullptr;       // ERT seeding: match-length planes, (M + 1) x nbases bytes
+    int64_t cap_ert_prof = 0;
     bwams_seed_opt_t last_seed_opt{};    // of the last bwams_seed_run (a grown SA buffer re-runs the lookup)
 
     // extension buffers

@@ -1,0 +1,17 @@
+// ert_kernels.h — launch wrappers of the ERT seeding kernels (ert_seed.hip).
+#pragma once
+#include "common.h"
+
+namespace bwams {
+
+// planes of `prof`: (M + 1) x nbases bytes, zeroed by the caller; [0] = N flag, [m] = L_m
+void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum, const uint8_t *skip, int64_t nseq,
+                        int64_t nbases, int M, uint8_t *prof, hipStream_t st);
+void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *skip, int64_t nseq, int64_t nbases, int M,
+                       const bwams_seed_opt_t &opt, bwams_smem_t *pool, int64_t pool_cap, DevCounters *ctr, hipStream_t st);
+void launch_ert_locate(const DevErt &e, const uint8_t *enc, const int64_t *cum, bwams_smem_t *sorted, int64_t n,
+                       int64_t *sa_cnt, int max_occ, DevCounters *ctr, hipStream_t st);
+void launch_ert_gather(const DevErt &e, bwams_smem_t *sorted, int64_t n, const int64_t *sa_off, int64_t *coord,
+                       int64_t coord_cap, int max_occ, DevCounters *ctr, hipStream_t st);
+
+}  // namespace bwams

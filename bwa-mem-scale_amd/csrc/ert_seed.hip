@@ -1,0 +1,481 @@
+// ert_seed.hip — seeding over the ERT index (enumerated radix trees) for gfx950.
+//
+// Replaces the per-read block of mem_kernel1_core_ert (/root/reference/src/bwamem.cpp:1122-1193: get_seeds[_prefix],
+// reseed[_prefix], last, ks_introsort) and the hit sampling of mem_chain_new (:993-1004).  The index bytes are the
+// reference's own (<prefix>.kmer_table, <prefix>.mlt_table as src/ertindex.cpp writes them; entry and node fields
+// as src/ertseeding.cpp:2142-2305, :836-975, :485-497, :521-587 read them).
+//
+// The reference walks a read serially: one forward walk from a pivot marks, in a bit vector (LEP), the end positions
+// where the hit set shrinks, and a backward walk (the same trees, reverse-complemented read) is started from each
+// marked end.  That order is a chain of dependent, divergent pointer chases per read.  On the GPU every start position
+// of every read gets its own lane and one forward walk (about 150 independent walks per read), which records
+//     L_m(i) = the longest prefix of read[i..) that occurs at least m times,  m = 1 .. M (M <= 20),
+// m bounded by what the trees store: child pointers carry the hit count of their subtree while it is below 20
+// (src/ertindex.cpp:455-461), which is all reseeding (min_intv <= split_width + 1) and `last` (max_mem_intv) ask.
+// The three seeding rounds then are arithmetic on those profiles (ert_select_kernel):
+//     round 1  [i, i+L_1(i)) is an SMEM iff L_1(i) >= min_seed_len and it ends behind the match from i-1;
+//     round 2  for an SMEM with <= split_width hits and >= split_len bases: the same test on L_m, m = hits + 1,
+//              for the matches that cover the SMEM's middle;
+//     round 3  from x, the first length >= min_seed_len + 1 with fewer than max_mem_intv hits; continue behind it.
+// The result is what mem_collect_smem gives over the FM-index (the reference's ERT mode is written to reproduce it:
+// src/ertseeding.cpp:2891, :3444-3461), so the seeds go through the same sort and the chaining stage unchanged.
+// Hits come out of the trees in A, C, G, T order = suffix order, as the SA interval would list them.
+#include "fmi_kernels.h"
+#include "ert_kernels.h"
+#include "wave_ops.h"
+
+namespace bwams {
+namespace {
+
+enum { N_EMPTY = 0, N_LEAF = 1, N_UNIFORM = 2, N_DIVERGE = 3 };          // node_type_t, ertindex.h:12
+enum { E_INVALID = 0, E_SINGLE = 1, E_INFREQUENT = 2, E_FREQUENT = 3 };  // macro.h:216-219
+constexpr int kMany = 255;           // 20 hits or more: the trees do not say how many
+constexpr int kStage = 24;           // seeds of one read staged in LDS before the wave appends them together
+
+// n <= 8 bytes at any address, little endian: two aligned 8-byte loads (the table is padded by 16 bytes)
+__device__ __forceinline__ uint64_t ld_le(const uint8_t *p, int n) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint64_t *q = (const uint64_t *)(a & ~(uintptr_t)7);
+    const int sh = (int)(a & 7) * 8;
+    uint64_t v = q[0];
+    if (sh) v = (v >> sh) | (q[1] << (64 - sh));
+    return n == 8 ? v : v & ((1ull << (8 * n)) - 1);
+}
+
+struct Where {
+    int kind;          // 0 nothing, 1 one position, 2 multi-hit list at `at`, 3 subtree at `at`
+    int w;
+    int64_t at, root;
+};
+
+// One forward walk from read position i (oracle: ert_walk).  PROFILE: store L_m into the planes; otherwise stop at
+// stop_len and describe where the hits of read[i, i+stop_len) are.  Returns the matched length.
+template <bool PROFILE>
+__device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len, int i, int M, uint8_t *__restrict__ plane,
+                        int64_t plane_stride, int stop_len, Where *wh) {
+    const int K = e.K, X = e.X;
+    if (i + K > len) return 0;
+    uint64_t key = 0;
+    for (int j = 0; j < K; ++j) {
+        const uint32_t b = q[i + j];
+        if (b > 3) return 0;
+        key |= (uint64_t)b << (2 * j);
+    }
+    const uint64_t ent = e.kmer[key];
+    int code = (int)(ent & 3);
+    if (code == E_INVALID) return 0;
+    const int64_t root = (int64_t)(ent >> 24);
+    const int w = ((ent >> 22) & 3) == 0 ? 4 : (int)((ent >> 22) & 3);
+    int cur = (int)((ent >> 17) & 31);
+    if (cur == 0) cur = kMany;
+    int d = K;
+    int64_t node = -1, leaf_pos = -1, mh_at = -1;
+    const uint8_t *__restrict__ mlt = e.mlt;
+    if (code == E_SINGLE) {
+        leaf_pos = (int64_t)(ld_le(mlt + root + 1, 5) >> 1);
+        cur = 1;
+    } else if (code == E_INFREQUENT) {
+        node = root + 4;
+    } else {
+        if (i + K + X > len) return 0;
+        uint32_t xk = 0;
+        for (int j = 0; j < X; ++j) {
+            const uint32_t b = q[i + K + j];
+            if (b > 3) return 0;
+            xk |= b << (2 * j);
+        }
+        const uint64_t xe = ld_le(mlt + root + 4 + 8 * (int64_t)xk, 8);
+        code = (int)(xe & 3);
+        if (code == E_INVALID) return 0;
+        d = K + X;
+        cur = (int)((xe >> 17) & 31);
+        if (cur == 0) cur = kMany;
+        if (code == E_SINGLE) {
+            leaf_pos = (int64_t)(ld_le(mlt + root + (int64_t)(xe >> 24) + 1, 5) >> 1);
+            cur = 1;
+        } else {
+            node = root + (int64_t)(xe >> 24);
+        }
+    }
+    int64_t mh_base = -1;
+    auto drop_to = [&](int nc) {
+        if (PROFILE) {
+            const int hi = cur < M ? cur : M;
+            for (int m = nc + 1; m <= hi; ++m) plane[(int64_t)m * plane_stride] = (uint8_t)d;
+        }
+        cur = nc;
+    };
+    while (leaf_pos < 0) {
+        if (!PROFILE && d >= stop_len) break;
+        if (i + d >= len) break;
+        const uint32_t b = q[i + d];
+        if (b > 3) break;
+        const int c = 3 - (int)b;
+        const uint64_t head = ld_le(mlt + node, 8);       // code byte and the first 7 bytes behind it
+        const uint32_t cd = (uint32_t)(head & 0xff);
+        const int t = (cd >> (c << 1)) & 3;
+        if (t == N_EMPTY) break;
+        if (t == N_UNIFORM) {
+            const int nbp = (int)((head >> 8) & 0xff);
+            int j = 0;
+            for (; j < nbp; ++j) {
+                if (!PROFILE && d + j >= stop_len) break;
+                if (i + d + j >= len) break;
+                const int bp = (mlt[node + 2 + (j >> 2)] >> ((~j & 3) << 1)) & 3;
+                const uint32_t bb = q[i + d + j];
+                if (bb > 3 || 3 - (int)bb != bp) break;
+            }
+            d += j;
+            node = node + 2 + ((nbp + 3) >> 2);
+            if (j < nbp) break;
+            continue;
+        }
+        // types of the four children: pointers first, then the leaf records, both in A, C, G, T order (c = 3 .. 0)
+        const uint32_t is_div = (cd & (cd >> 1)) & 0x55, is_leaf = (cd & ~(cd >> 1)) & 0x55;
+        const uint32_t above = c == 3 ? 0u : (0xffu << ((c + 1) << 1)) & 0xff;
+        const int n_ptr = __popc(is_div), before_ptr = __popc(is_div & above), before_leaf = __popc(is_leaf & above);
+        if (t == N_LEAF) {
+            const uint64_t rec = ld_le(mlt + node + 1 + n_ptr * w + 5 * before_leaf, 5);
+            int nc = 1;
+            if (rec & 1) {
+                if (mh_base < 0) mh_base = root + (int64_t)ld_le(mlt + root, 4);
+                mh_at = mh_base + (int64_t)(rec >> 1);
+                const uint64_t h = ld_le(mlt + mh_at, 7);
+                nc = (int)(h & 0xffff);
+                leaf_pos = (int64_t)((h >> 16) >> 1);
+                if (nc >= 20) nc = kMany;
+            } else {
+                leaf_pos = (int64_t)(rec >> 1);
+            }
+            drop_to(nc);
+            d += 1;
+        } else {
+            const uint64_t v = ld_le(mlt + node + 1 + before_ptr * w, w);
+            int nc = (int)(v & 63);
+            if (nc == 0) nc = kMany;
+            drop_to(nc);
+            d += 1;
+            node = node + (int64_t)(v >> 6);
+        }
+    }
+    if (leaf_pos >= 0) {
+        // the rest of the suffix is not in the tree: compare with the text (get_seeds_prefix :2940-2965)
+        const int lim = PROFILE ? len - i : (stop_len < len - i ? stop_len : len - i);
+        const uint8_t *__restrict__ rf = e.ref + leaf_pos;
+        const int64_t room = e.ref_len - leaf_pos;
+        while (d < lim && d < room) {
+            const uint32_t bb = q[i + d];
+            if (bb > 3 || rf[d] != bb) break;
+            d++;
+        }
+    }
+    if (PROFILE) {
+        const int hi = cur < M ? cur : M;
+        for (int m = 1; m <= hi; ++m) plane[(int64_t)m * plane_stride] = (uint8_t)d;
+    } else {
+        wh->root = root; wh->w = w;
+        if (leaf_pos >= 0 && mh_at >= 0) { wh->kind = 2; wh->at = mh_at; }
+        else if (leaf_pos >= 0) { wh->kind = 1; wh->at = leaf_pos; }
+        else { wh->kind = 3; wh->at = node; }
+    }
+    return d;
+}
+
+// lane = one base of the batch = one start position of one read.  planes: [0] = the base is N, [m] = L_m.
+__global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_t *__restrict__ enc,
+                                                          const int64_t *__restrict__ cum, const uint8_t *__restrict__ skip,
+                                                          int64_t nseq, int64_t nbases, int M, uint8_t *__restrict__ prof) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t g0 = g - (threadIdx.x & 63);            // the wave's first base: one search per wave
+    int64_t r = 0;
+    if ((threadIdx.x & 63) == 0 && g0 < nbases) {
+        int64_t lo = 0, hi = nseq;                        // last r with cum[r] <= g0
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cum[mid] <= g0) lo = mid; else hi = mid;
+        }
+        r = lo;
+    }
+    r = ((int64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r);
+    if (g >= nbases) return;
+    while (r + 1 < nseq && g >= cum[r + 1]) r++;
+    const int64_t c0 = cum[r];
+    const int len = (int)(cum[r + 1] - c0), i = (int)(g - c0);
+    const uint8_t *q = enc + c0;
+    prof[g] = q[i] > 3;
+    if (skip && skip[r]) return;
+    ert_walk<true>(e, q, len, i, M, prof + g, nbases, 0, nullptr);
+}
+
+struct SelectArgs {
+    const uint8_t *prof;
+    const int64_t *cum;
+    const uint8_t *skip;
+    int64_t nseq, nbases;
+    int M, msl, split_len, split_width, max_intv;
+    bwams_smem_t *pool;
+    int64_t pool_cap;
+    DevCounters *ctr;
+};
+
+// lane = one read: the three rounds over the profiles; seeds are staged per lane and appended once per wave
+__global__ __launch_bounds__(256) void ert_select_kernel(SelectArgs A) {
+    __shared__ uint32_t stage[kStage * 256];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int tid = threadIdx.x;
+    int n_st = 0;
+    int64_t c0 = 0;
+    const bool live = r < A.nseq && !(A.skip && A.skip[r]);
+    auto emit = [&](int st, int ln, int cnt) {
+        const uint32_t rec = (uint32_t)st | ((uint32_t)ln << 8) | ((uint32_t)cnt << 16);
+        if (n_st < kStage) {
+            stage[n_st * 256 + tid] = rec;
+            n_st++;
+        } else {                                           // more seeds than the stage holds: append one by one
+            const unsigned long long slot = atomicAdd(&A.ctr->n_smem_total, 1ull);
+            if ((int64_t)slot < A.pool_cap) {
+                bwams_smem_t o;
+                o.rid = (uint32_t)r; o.m = (uint32_t)st; o.n = (uint32_t)(st + ln - 1); o.pad_ = 0;
+                o.k = 0; o.l = 0; o.s = cnt == kMany ? -1 : cnt;
+                A.pool[slot] = o;
+            }
+        }
+    };
+    if (live) {
+        c0 = A.cum[r];
+        const int len = (int)(A.cum[r + 1] - c0);
+        const uint8_t *P = A.prof + c0;
+        const int64_t S = A.nbases;
+        auto L = [&](int m, int i) -> int { return P[(int64_t)m * S + i]; };
+        auto count_of = [&](int i, int ln) -> int {
+            int c = 0;
+            for (int m = 1; m <= A.M; ++m) {
+                if (L(m, i) >= ln) c = m; else break;
+            }
+            return c >= A.M ? kMany : c;
+        };
+        uint64_t nm0 = 0, nm1 = 0, nm2 = 0, nm3 = 0;       // N positions of the read (reads are at most 255 long)
+        int prev_e = -1;
+        for (int i = 0; i < len; ++i) {
+            const uint64_t isn = P[i];
+            const uint64_t bit = isn << (i & 63);
+            if (i < 64) nm0 |= bit; else if (i < 128) nm1 |= bit; else if (i < 192) nm2 |= bit; else nm3 |= bit;
+            const int l1 = L(1, i), en = i + l1;
+            if (l1 >= A.msl && (i == 0 || en > prev_e)) {
+                const int cnt = count_of(i, l1);
+                emit(i, l1, cnt);
+                if (l1 >= A.split_len && cnt <= A.split_width) {
+                    // reseeding (bwamem.cpp:1165-1181): matches with more hits that cover the middle
+                    const int x = (i + en) >> 1, m = cnt + 1;
+                    for (int a = x; a >= 0; --a) {
+                        const int l = L(m, a);
+                        if (l > 0 && a + l <= x) break;
+                        if (l < A.msl || a + l <= x) continue;
+                        if (a > 0 && a + l <= a - 1 + L(m, a - 1)) continue;
+                        emit(a, l, count_of(a, l));
+                    }
+                }
+            }
+            prev_e = en;
+        }
+        if (A.max_intv > 0) {
+            // `last` (ertseeding.cpp:3425-3511 = bwtSeedStrategyAllPosOneThread)
+            auto first_n = [&](int lo, int hi) -> int {      // first N in [lo, hi), -1 if none
+                for (int wd = lo >> 6; wd <= (hi - 1) >> 6 && wd < 4; ++wd) {
+                    uint64_t mk = wd == 0 ? nm0 : wd == 1 ? nm1 : wd == 2 ? nm2 : nm3;
+                    if (wd == (lo >> 6)) mk &= ~0ull << (lo & 63);
+                    if (wd == ((hi - 1) >> 6) && (hi & 63)) mk &= ~0ull >> (64 - (hi & 63));
+                    if (mk) return wd * 64 + __builtin_ctzll(mk);
+                }
+                return -1;
+            };
+            int x = 0;
+            while (x < len) {
+                if (P[x]) { x++; continue; }
+                int want = L(A.max_intv, x) + 1;
+                if (want < A.msl + 1) want = A.msl + 1;
+                const int hi = x + want < len ? x + want : len;
+                const int nn = hi > x + 1 ? first_n(x + 1, hi) : -1;
+                if (nn >= 0) { x = nn + 1; continue; }
+                if (x + want > len) break;
+                if (L(1, x) >= want) emit(x, want, count_of(x, want));
+                x += want;
+            }
+        }
+    }
+    // append: exclusive prefix of the staged counts over the wave, one ticket per wave
+    int incl = n_st;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    if (total == 0) return;
+    const unsigned long long base = wave_ticket(&A.ctr->n_smem_total, (unsigned long long)total);
+    const int64_t at = (int64_t)base + incl - n_st;
+    for (int j = 0; j < n_st; ++j) {
+        const uint32_t rec = stage[j * 256 + tid];
+        if (at + j < A.pool_cap) {
+            bwams_smem_t o;
+            const int st = rec & 0xff, ln = (rec >> 8) & 0xff, cnt = (rec >> 16) & 0xff;
+            o.rid = (uint32_t)r; o.m = (uint32_t)st; o.n = (uint32_t)(st + ln - 1); o.pad_ = 0;
+            o.k = 0; o.l = 0; o.s = cnt == kMany ? -1 : cnt;
+            A.pool[at + j] = o;
+        }
+    }
+}
+
+// Leaves below a node in A, C, G, T order (getNextByteIdx_dfs).  COUNT: number of hits (subtrees whose pointer
+// carries the count are not entered).  Otherwise: hit t goes to out[t / step] when t % step == 0 and t / step < lim.
+// Returns the number of hits, or -1 when the explicit stack is exhausted (a corrupt index).
+template <bool COUNT>
+__device__ int64_t ert_leaves(const DevErt &e, int64_t node, int64_t mh_base, int w, int64_t step, int64_t lim,
+                              int64_t *__restrict__ out) {
+    constexpr int kStack = 256;
+    uint64_t stk[kStack];                 // node << 3 | next child
+    int sp = 0;
+    int64_t t = 0;
+    int c = 3;
+    const uint8_t *__restrict__ mlt = e.mlt;
+    auto put = [&](int64_t pos) {
+        if (!COUNT) {
+            const int64_t k = t / step;
+            if (k * step == t && k < lim) out[k] = pos;
+        }
+        t++;
+    };
+    for (;;) {
+        if (c < 0) {
+            if (sp == 0) break;
+            const uint64_t top = stk[--sp];
+            node = (int64_t)(top >> 3);
+            c = (int)(top & 7) - 1;
+            continue;
+        }
+        const uint64_t head = ld_le(mlt + node, 2);
+        const uint32_t cd = (uint32_t)(head & 0xff);
+        const int ty = (cd >> (c << 1)) & 3;
+        if (ty == N_EMPTY) { c--; continue; }
+        if (ty == N_UNIFORM) {
+            const int nbp = (int)(head >> 8);
+            node = node + 2 + ((nbp + 3) >> 2);          // a run is the only child of its node: nothing to come back to
+            c = 3;
+            continue;
+        }
+        const uint32_t is_div = (cd & (cd >> 1)) & 0x55, is_leaf = (cd & ~(cd >> 1)) & 0x55;
+        const uint32_t above = c == 3 ? 0u : (0xffu << ((c + 1) << 1)) & 0xff;
+        const int n_ptr = __popc(is_div);
+        if (ty == N_LEAF) {
+            const uint64_t rec = ld_le(mlt + node + 1 + n_ptr * w + 5 * __popc(is_leaf & above), 5);
+            if (rec & 1) {
+                const int64_t at = mh_base + (int64_t)(rec >> 1);
+                const int nc = (int)ld_le(mlt + at, 2);
+                if (COUNT) t += nc;
+                else
+                    for (int k = 0; k < nc; ++k) put((int64_t)(ld_le(mlt + at + 2 + 5 * k, 5) >> 1));
+            } else {
+                put((int64_t)(rec >> 1));
+            }
+            c--;
+            continue;
+        }
+        const uint64_t v = ld_le(mlt + node + 1 + __popc(is_div & above) * w, w);
+        if (COUNT && (v & 63)) { t += (int64_t)(v & 63); c--; continue; }
+        if (sp == kStack) return -1;
+        stk[sp++] = ((uint64_t)node << 3) | (uint64_t)(c + 1);     // resume with the next child
+        node = node + (int64_t)(v >> 6);
+        c = 3;
+    }
+    return t;
+}
+
+// lane = one sorted seed: walk again to its depth, remember where its hits are (k = address, l = kind | w << 8 |
+// root << 16) and count them when the profile could not (20 or more)
+__global__ __launch_bounds__(256) void ert_locate_kernel(DevErt e, const uint8_t *__restrict__ enc,
+                                                         const int64_t *__restrict__ cum, bwams_smem_t *__restrict__ sm,
+                                                         int64_t n, int64_t *__restrict__ sa_cnt, int max_occ,
+                                                         DevCounters *ctr) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    bwams_smem_t s = sm[g];
+    const int64_t c0 = cum[s.rid];
+    const int len = (int)(cum[s.rid + 1] - c0), mlen = (int)(s.n - s.m + 1);
+    Where wh;
+    wh.kind = 0; wh.w = 0; wh.at = 0; wh.root = 0;
+    const int d = ert_walk<false>(e, enc + c0, len, (int)s.m, 0, nullptr, 0, mlen, &wh);
+    int64_t cnt = s.s;
+    if (d < mlen) { wh.kind = 0; cnt = 0; }                 // cannot happen with a consistent index
+    if (cnt < 0) {
+        if (wh.kind == 1) cnt = 1;
+        else if (wh.kind == 2) cnt = (int64_t)ld_le(e.mlt + wh.at, 2);
+        else if (wh.kind == 3) {
+            cnt = ert_leaves<true>(e, wh.at, wh.root + (int64_t)ld_le(e.mlt + wh.root, 4), wh.w, 1, 0, nullptr);
+            if (cnt < 0) { cnt = 0; wh.kind = 0; atomicAdd(&ctr->overflow, 1ull); }
+        }
+    }
+    s.s = cnt;
+    s.k = wh.at;
+    s.l = (int64_t)wh.kind | ((int64_t)wh.w << 8) | (wh.root << 16);
+    sm[g] = s;
+    if (sa_cnt) sa_cnt[g] = cnt < (int64_t)max_occ ? cnt : (int64_t)max_occ;
+}
+
+// lane = one sorted seed: its hits, sampled as mem_chain_new does (step = s / max_occ), into coord[sa_off ..)
+__global__ __launch_bounds__(256) void ert_gather_kernel(DevErt e, bwams_smem_t *__restrict__ sm, int64_t n,
+                                                         const int64_t *__restrict__ sa_off, int64_t *__restrict__ coord,
+                                                         int64_t coord_cap, int max_occ, DevCounters *ctr) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) ctr->n_sa_lookups = (unsigned long long)sa_off[n];
+    if (g >= n) return;
+    bwams_smem_t s = sm[g];
+    const int kind = (int)(s.l & 0xff), w = (int)((s.l >> 8) & 0xff);
+    const int64_t root = s.l >> 16, at = s.k, off = sa_off[g];
+    const int64_t step = s.s > (int64_t)max_occ ? s.s / max_occ : 1;
+    const int64_t lim = s.s < (int64_t)max_occ ? s.s : (int64_t)max_occ;
+    if (off + lim <= coord_cap) {
+        if (kind == 1) {
+            coord[off] = at;
+        } else if (kind == 2) {
+            for (int64_t k = 0; k < lim; ++k) coord[off + k] = (int64_t)(ld_le(e.mlt + at + 2 + 5 * (k * step), 5) >> 1);
+        } else if (kind == 3) {
+            ert_leaves<false>(e, at, root + (int64_t)ld_le(e.mlt + root, 4), w, step, lim, coord + off);
+        }
+    }
+    s.k = 0; s.l = 0;          // the FM-index interval has no meaning here
+    sm[g] = s;
+}
+
+}  // namespace
+
+void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum, const uint8_t *skip, int64_t nseq,
+                        int64_t nbases, int M, uint8_t *prof, hipStream_t st) {
+    if (nbases <= 0) return;
+    ert_profile_kernel<<<(unsigned)((nbases + 255) / 256), 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof);
+}
+
+void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *skip, int64_t nseq, int64_t nbases, int M,
+                       const bwams_seed_opt_t &opt, bwams_smem_t *pool, int64_t pool_cap, DevCounters *ctr, hipStream_t st) {
+    if (nseq <= 0) return;
+    SelectArgs A;
+    A.prof = prof; A.cum = cum; A.skip = skip; A.nseq = nseq; A.nbases = nbases; A.M = M;
+    A.msl = opt.min_seed_len;
+    A.split_len = (int)(opt.min_seed_len * opt.split_factor + .499);
+    A.split_width = opt.split_width;
+    A.max_intv = opt.max_mem_intv;
+    A.pool = pool; A.pool_cap = pool_cap; A.ctr = ctr;
+    ert_select_kernel<<<(unsigned)((nseq + 255) / 256), 256, 0, st>>>(A);
+}
+
+void launch_ert_locate(const DevErt &e, const uint8_t *enc, const int64_t *cum, bwams_smem_t *sorted, int64_t n,
+                       int64_t *sa_cnt, int max_occ, DevCounters *ctr, hipStream_t st) {
+    if (n <= 0) return;
+    ert_locate_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(e, enc, cum, sorted, n, sa_cnt, max_occ, ctr);
+}
+
+void launch_ert_gather(const DevErt &e, bwams_smem_t *sorted, int64_t n, const int64_t *sa_off, int64_t *coord,
+                       int64_t coord_cap, int max_occ, DevCounters *ctr, hipStream_t st) {
+    if (n <= 0) return;
+    ert_gather_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(e, sorted, n, sa_off, coord, coord_cap, max_occ, ctr);
+}
+
+}  // namespace bwams

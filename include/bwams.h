@@ -265,6 +265,32 @@ typedef struct bwams_stats {
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 
 /* ------------------------------------------------------------------------- *
+ * ERT seeding: replaces the per-read block of mem_kernel1_core_ert (src/bwamem.cpp:1122-1193: get_seeds /
+ * get_seeds_prefix, reseed / reseed_prefix, last, ks_introsort) and the hit sampling of mem_chain_new
+ * (src/bwamem.cpp:993-1004), for a whole chunk.
+ * ------------------------------------------------------------------------- */
+typedef struct bwams_ert bwams_ert_t;
+
+/* The two files `bwa-mem2 index -a ert` writes (src/ertindex.cpp:773-943), as host arrays: kmer_table = 4^kmer_size
+ * 8-byte entries, mlt_table = the radix trees.  kmer_size / xmer_size / read_len are the build's kmerSize (15),
+ * xmerSize (4) and READ_LEN (src/macro.h:204-206, :66); other values exist for test-sized indexes.  The index handle
+ * must hold the .0123 reference (leaf expansion reads it).  The tables are copied into HBM. */
+int bwams_ert_from_host(bwams_index_t *idx, const uint64_t *kmer_table, int32_t kmer_size, int32_t xmer_size,
+                        int32_t read_len, const uint8_t *mlt_table, int64_t mlt_bytes, bwams_ert_t **out);
+/* The same from <prefix>.kmer_table and <prefix>.mlt_table (kmerSize 15, xmerSize 4), streamed into HBM. */
+int bwams_ert_open(bwams_index_t *idx, const char *prefix, int32_t read_len, bwams_ert_t **out);
+int bwams_ert_close(bwams_ert_t *ert);
+int64_t bwams_ert_bytes(const bwams_ert_t *ert);
+
+/* bwams_seed_run over the ERT instead of the FM-index: same inputs (bwams_seed_upload), same outputs
+ * (bwams_seed_counts / bwams_seed_fetch, then bwams_chain_run): the SMEMs of the three seeding rounds in
+ * (rid, m, n) order with s = number of hits (k and l are 0: there is no BWT interval), and the sampled hit
+ * positions where the FM path puts the suffix-array coordinates.  BWAMS_ERR_UNSUPPORTED when
+ * min_seed_len < kmer_size + xmer_size, when split_width + 1 or max_mem_intv exceed 20 (the trees store hit counts
+ * below 20 only, src/ertindex.cpp:455-461) or when a read is longer than read_len / 255 bases. */
+int bwams_seed_run_ert(bwams_batch_t *b, bwams_ert_t *ert, const bwams_seed_opt_t *opt, int with_sa);
+
+/* ------------------------------------------------------------------------- *
  * Chaining and chain-to-alignment: replace, for a whole chunk,
  *   mem_chain_seeds + mem_chain_flt (+ the short-read early-out of mem_flt_chained_seeds),
  *     called from mem_kernel1_core, src/bwamem.cpp:1341-1372

@@ -1,0 +1,137 @@
+"""GPU parity of ERT seeding (bwams_seed_run_ert, row a12): the HIP walk over an ERT index in the reference's file
+layout against (1) the CPU restatement of the same walk (oracle/ert_oracle.c) and (2) FM-index seeding, which the
+reference's ERT mode reproduces by design.  Integer work: every comparison is bit-exact.
+
+The index bytes come from the restated writer (oracle/ert_oracle.c = src/ertindex.cpp); the reference's k-mer size
+is a macro (15 -> an 8 GiB table), so most cases use a test-sized k and one case runs the real k = 15 layout."""
+import numpy as np
+import pytest
+
+from bwams import capi, fmindex, simulate
+from oracle import loader
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(n_bases, seed, kmer, xmer, thr, repeat_frac=0.2, read_len=151):
+    g = simulate.make_genome(n_bases, seed=seed, repeat_frac=repeat_frac, repeat_len=200, n_families=3)
+    idx = fmindex.build_fmindex(g)
+    text = fmindex.fw_rc_text(g)
+    o = loader.OracleFMI(idx)
+    e = loader.OracleERT(o, text, kmer=kmer, xmer=xmer, read_len=read_len, hit_threshold=thr)
+    ix = capi.Index.from_host(idx, 0)
+    ert = capi.Ert(ix, e.kmer_table, e.mlt, kmer=kmer, xmer=xmer, read_len=read_len)
+    return g, idx, o, e, ix, ert
+
+
+def _reads(g, n, seed, with_edge=True):
+    reads, _, _ = simulate.make_reads(g, n, seed=seed)
+    reads = [np.array(r, dtype=np.uint8) for r in reads]
+    rng = np.random.default_rng(seed)
+    for r in reads[::7]:
+        r[int(rng.integers(0, len(r)))] = 4
+    if with_edge:
+        reads.append(rng.integers(0, 4, size=150).astype(np.uint8))
+        reads.append(np.array(g[:150], dtype=np.uint8))
+        reads.append(np.array(g[-150:], dtype=np.uint8))
+        reads.append(np.array(g[1000:1020], dtype=np.uint8))          # shorter than a seed would need to be useful
+        reads.append(np.full(80, 4, np.uint8))
+        reads.append(np.zeros(0, np.uint8))
+        reads.append(np.array(g[3000:3019], dtype=np.uint8))          # exactly min_seed_len
+    return simulate.flatten_reads(reads)
+
+
+def _opts(**kw):
+    oo, go = loader.default_seed_opt(), capi.default_seed_opt()
+    for k, v in kw.items():
+        setattr(oo, k, v)
+        setattr(go, k, v)
+    return oo, go
+
+
+def _check(o, e, ix, ert, enc, cum, oo, go, skip=None):
+    want, wcoord, woff = e.collect(enc, cum, oo, skip=skip)
+    b = capi.Batch(ix, max(len(cum) - 1, 1), max(int(cum[-1]), 1), max_smem=64, max_sa=64)   # both buffers must grow
+    b.seed_upload(enc, cum, skip)
+    b.seed_run_ert(ert, go)
+    got, coord, off = b.seed_fetch()
+    # the same batch through the FM-index
+    b.seed_run(go)
+    fm, fcoord, foff = b.seed_fetch()
+    b.close()
+    assert len(got) == len(want)
+    for f in ("rid", "m", "n", "s"):
+        assert np.array_equal(got[f], want[f]), f
+    assert not got["k"].any() and not got["l"].any()
+    assert np.array_equal(off, woff) and np.array_equal(coord, wcoord)
+    assert len(fm) == len(got)
+    for f in ("rid", "m", "n", "s"):
+        assert np.array_equal(got[f], fm[f]), f
+    assert np.array_equal(off, foff)
+    # FM-index coordinates carry the sentinel quirk of get_sa_entries (0 for a handful of rows at the start of the text)
+    assert np.all((coord == fcoord) | ((fcoord == 0) & (coord < 128)))
+    return got
+
+
+@pytest.mark.parametrize("kmer,xmer,thr,n_bases,seed", [(8, 2, 16, 100000, 1), (6, 2, 6, 20000, 2), (10, 4, 256, 300000, 3)])
+def test_ert_seeding_matches_oracle_and_fm(kmer, xmer, thr, n_bases, seed):
+    g, idx, o, e, ix, ert = _make(n_bases, seed, kmer, xmer, thr)
+    enc, cum = _reads(g, 1500, seed)
+    for kw in ({}, {"split_factor": 1.2, "split_width": 12, "max_mem_intv": 15, "max_occ": 7},
+               {"min_seed_len": 25}, {"max_mem_intv": 0}, {"max_occ": 3, "split_width": 18}):
+        oo, go = _opts(**kw)
+        got = _check(o, e, ix, ert, enc, cum, oo, go)
+        assert len(got) > 1000
+    ert.close(); ix.close()
+
+
+def test_ert_skip_flags_and_chain():
+    """EMF-matched reads are left out; the chaining stage runs on ERT seeds exactly as on FM seeds."""
+    g, idx, o, e, ix, ert = _make(150000, 5, 9, 3, 64)
+    enc, cum = _reads(g, 2000, 9, with_edge=False)
+    skip = (np.arange(len(cum) - 1) % 5 == 0).astype(np.uint8)
+    oo, go = _opts()
+    _check(o, e, ix, ert, enc, cum, oo, go, skip=skip)
+    b = capi.Batch(ix, len(cum) - 1, int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.seed_run_ert(ert, go)
+    b.chain_run()
+    ch_e, sd_e, off_e = b.chain_fetch()
+    b.seed_run(go)
+    b.chain_run()
+    ch_f, sd_f, off_f = b.chain_fetch()
+    b.close()
+    assert np.array_equal(off_e, off_f) and len(ch_e) == len(ch_f) and len(sd_e) == len(sd_f)
+    # seeds whose FM coordinate fell to the sentinel quirk are the only admissible difference: none on this genome
+    assert ch_e.tobytes() == ch_f.tobytes() and sd_e.tobytes() == sd_f.tobytes()
+    ert.close(); ix.close()
+
+
+def test_ert_unsupported_options():
+    g, idx, o, e, ix, ert = _make(20000, 7, 8, 2, 16)
+    enc, cum = _reads(g, 50, 1, with_edge=False)
+    b = capi.Batch(ix, len(cum) - 1, int(cum[-1]))
+    b.seed_upload(enc, cum)
+    for kw in ({"min_seed_len": 9}, {"max_mem_intv": 21}, {"split_width": 20}):
+        oo, go = _opts(**kw)
+        with pytest.raises(capi.BwamsError) as ei:
+            b.seed_run_ert(ert, go)
+        assert "hit counts below 20" in str(ei.value)
+    long_reads = [np.array(g[:400], dtype=np.uint8)]
+    enc2, cum2 = simulate.flatten_reads(long_reads)
+    b2 = capi.Batch(ix, 1, 400)
+    b2.seed_upload(enc2, cum2)
+    with pytest.raises(capi.BwamsError):
+        b2.seed_run_ert(ert, capi.default_seed_opt())
+    b.close(); b2.close(); ert.close(); ix.close()
+
+
+def test_ert_real_kmer_size():
+    """The reference's own table geometry: k = 15 (8 GiB k-mer table), x = 4, HIT_THRESHOLD 256."""
+    g, idx, o, e, ix, ert = _make(1_000_000, 11, 15, 4, 256, repeat_frac=0.1)
+    assert len(e.kmer_table) == 1 << 30
+    enc, cum = _reads(g, 3000, 4)
+    oo, go = _opts()
+    got = _check(o, e, ix, ert, enc, cum, oo, go)
+    assert len(got) > 3000
+    ert.close(); ix.close()

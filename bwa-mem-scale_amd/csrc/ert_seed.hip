@@ -382,7 +382,7 @@ __device__ int64_t ert_leaves(const DevErt &e, int64_t node, int64_t mh_base, in
         const uint64_t v = ld_le(mlt + node + 1 + __popc(is_div & above) * w, w);
         if (COUNT && (v & 63)) { t += (int64_t)(v & 63); c--; continue; }
         if (sp == kStack) return -1;
-        stk[sp++] = ((uint64_t)node << 3) | (uint64_t)(c + 1);     // resume with the next child
+        stk[sp++] = ((uint64_t)node << 3) | (uint64_t)c;           // popped as c - 1: resume with the next child
         node = node + (int64_t)(v >> 6);
         c = 3;
     }

@@ -28,6 +28,7 @@ SYMBOLS = [
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
+    "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
     "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
@@ -243,6 +244,10 @@ def lib():
         L.bwams_ert_bytes.restype = i64
         L.bwams_ert_bytes.argtypes = [vp]
         L.bwams_seed_run_ert.argtypes = [vp, vp, vp, C.c_int]
+        L.bwams_ert_build.argtypes = [vp, i32, i32, i32, i32, vp]
+        L.bwams_ert_info.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.bwams_ert_fetch.argtypes = [vp, vp, vp]
+        L.bwams_ert_save.argtypes = [vp, C.c_char_p]
         L.bwams_batch_stats.argtypes = [vp, vp]
         L.bwams_batch_sync.argtypes = [vp]
         _lib = L
@@ -404,6 +409,31 @@ class Ert:
             assert len(kt) == 4 ** kmer
             _chk(lib().bwams_ert_from_host(index.h, _p(kt), kmer, xmer, read_len, _p(mt), len(mt), C.byref(self.h)),
                  "bwams_ert_from_host")
+
+    @classmethod
+    def build(cls, index: Index, kmer: int = 15, xmer: int = 4, read_len: int = 151, hit_threshold: int = 256) -> "Ert":
+        """bwams_ert_build: the tables from the resident FM-index, on the GPU"""
+        self = cls.__new__(cls)
+        self.index = index
+        self.h = C.c_void_p()
+        _chk(lib().bwams_ert_build(index.h, kmer, xmer, read_len, hit_threshold, C.byref(self.h)), "bwams_ert_build")
+        return self
+
+    def info(self):
+        k, x, rl, nb = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        ms = (C.c_float * 3)()
+        _chk(lib().bwams_ert_info(self.h, C.byref(k), C.byref(x), C.byref(rl), C.byref(nb), ms), "bwams_ert_info")
+        return {"kmer": k.value, "xmer": x.value, "read_len": rl.value, "mlt_bytes": nb.value, "build_ms": list(ms)}
+
+    def fetch(self):
+        i = self.info()
+        kt = np.zeros(4 ** i["kmer"], dtype=np.uint64)
+        mt = np.zeros(max(i["mlt_bytes"], 1), dtype=np.uint8)
+        _chk(lib().bwams_ert_fetch(self.h, _p(kt), _p(mt)), "bwams_ert_fetch")
+        return kt, mt[:i["mlt_bytes"]]
+
+    def save(self, prefix: str):
+        _chk(lib().bwams_ert_save(self.h, prefix.encode()), "bwams_ert_save")
 
     def nbytes(self) -> int:
         return int(lib().bwams_ert_bytes(self.h))

@@ -816,6 +816,7 @@ int bwams_ert_from_host(bwams_index_t *ix, const uint64_t *kmer_table, int32_t k
     e->t.ref_len = ix->fmi.ref_seq_len - 1;
     e->t.K = kmer_size; e->t.X = xmer_size; e->t.read_len = read_len;
     e->bytes = (int64_t)(nk * 8) + mlt_bytes + 16;
+    e->mlt_bytes = mlt_bytes;
     *out = e;
     return BWAMS_OK;
 }
@@ -874,8 +875,78 @@ int bwams_ert_open(bwams_index_t *ix, const char *prefix, int32_t read_len, bwam
     e->t.ref_len = ix->fmi.ref_seq_len - 1;
     e->t.K = K; e->t.X = X; e->t.read_len = read_len;
     e->bytes = (int64_t)(nk * 8) + mlt_bytes + 16;
+    e->mlt_bytes = mlt_bytes;
     *out = e;
     return BWAMS_OK;
+}
+
+int bwams_ert_build(bwams_index_t *ix, int32_t kmer_size, int32_t xmer_size, int32_t read_len, int32_t hit_threshold,
+                    bwams_ert_t **out) {
+    if (!ix || !out) return BWAMS_ERR_ARG;
+    if (kmer_size < 2 || kmer_size > 15 || xmer_size < 1 || xmer_size > 8 || read_len < kmer_size + xmer_size || read_len > 255 ||
+        hit_threshold < 1) {
+        set_last_error("bwams_ert_build: k-mer size must be in [2, 15], x-mer size in [1, 8], read length in [k + x, 255]");
+        return BWAMS_ERR_ARG;
+    }
+    if (!ix->d_ref) {
+        set_last_error("bwams_ert_build: the index holds no .0123 reference (leaf expansion reads it)");
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(ix->device));
+    hipDeviceProp_t prop;
+    BWAMS_HIP(hipGetDeviceProperties(&prop, ix->device));
+    bwams_ert *e = new bwams_ert();
+    e->idx = ix;
+    const char *vb = getenv("BWAMS_VERBOSE");
+    const int rc = ert_build_device(e, ix->fmi, kmer_size, xmer_size, read_len, hit_threshold, prop.multiProcessorCount,
+                                    vb && atoi(vb) > 0);
+    if (rc) { bwams_ert_close(e); return rc; }
+    *out = e;
+    return BWAMS_OK;
+}
+
+int bwams_ert_info(const bwams_ert_t *e, int32_t *kmer_size, int32_t *xmer_size, int32_t *read_len, int64_t *mlt_bytes,
+                   float build_ms[3]) {
+    if (!e) return BWAMS_ERR_ARG;
+    if (kmer_size) *kmer_size = e->t.K;
+    if (xmer_size) *xmer_size = e->t.X;
+    if (read_len) *read_len = e->t.read_len;
+    if (mlt_bytes) *mlt_bytes = e->mlt_bytes;
+    if (build_ms) for (int i = 0; i < 3; ++i) build_ms[i] = e->build_ms[i];
+    return BWAMS_OK;
+}
+
+int bwams_ert_fetch(bwams_ert_t *e, uint64_t *kmer_table, uint8_t *mlt_table) {
+    if (!e) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(e->idx->device));
+    if (kmer_table) BWAMS_HIP(hipMemcpy(kmer_table, e->d_kmer, ((size_t)1 << (2 * e->t.K)) * 8, hipMemcpyDeviceToHost));
+    if (mlt_table && e->mlt_bytes) BWAMS_HIP(hipMemcpy(mlt_table, e->d_mlt, (size_t)e->mlt_bytes, hipMemcpyDeviceToHost));
+    return BWAMS_OK;
+}
+
+int bwams_ert_save(bwams_ert_t *e, const char *prefix) {
+    if (!e || !prefix) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(e->idx->device));
+    const size_t chunk = (size_t)256 << 20;
+    void *stage = nullptr;
+    BWAMS_HIP(hipHostMalloc(&stage, chunk));
+    int rc = BWAMS_OK;
+    auto stream_out = [&](const std::string &path, const void *src, size_t total) {
+        FILE *f = fopen(path.c_str(), "wb");
+        if (!f) { rc = BWAMS_ERR_IO; set_last_error("bwams_ert_save: cannot create " + path); return; }
+        size_t done = 0;
+        while (rc == BWAMS_OK && done < total) {
+            const size_t n = total - done < chunk ? total - done : chunk;
+            if (hipMemcpy(stage, (const uint8_t *)src + done, n, hipMemcpyDeviceToHost) != hipSuccess) { rc = BWAMS_ERR_DEVICE; break; }
+            if (fwrite(stage, 1, n, f) != n) { rc = BWAMS_ERR_IO; set_last_error("bwams_ert_save: short write to " + path); break; }
+            done += n;
+        }
+        fclose(f);
+    };
+    stream_out(std::string(prefix) + ".kmer_table", e->d_kmer, ((size_t)1 << (2 * e->t.K)) * 8);
+    if (rc == BWAMS_OK) stream_out(std::string(prefix) + ".mlt_table", e->d_mlt, (size_t)e->mlt_bytes);
+    (void)hipHostFree(stage);
+    return rc;
 }
 
 int bwams_ert_close(bwams_ert_t *e) {

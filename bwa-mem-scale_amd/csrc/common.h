@@ -139,7 +139,8 @@ struct bwams_ert {
     bwams_index *idx = nullptr;
     bwams::DevErt t{};
     void *d_kmer = nullptr, *d_mlt = nullptr;
-    int64_t bytes = 0;
+    int64_t bytes = 0, mlt_bytes = 0;
+    float build_ms[3] = {0, 0, 0};       // bwams_ert_build: sizes, scan + allocation, bytes
 };
 
 struct bwams_emf {

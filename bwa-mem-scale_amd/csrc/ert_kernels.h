@@ -14,4 +14,7 @@ void launch_ert_locate(const DevErt &e, const uint8_t *enc, const int64_t *cum, 
 void launch_ert_gather(const DevErt &e, bwams_smem_t *sorted, int64_t n, const int64_t *sa_off, int64_t *coord,
                        int64_t coord_cap, int max_occ, DevCounters *ctr, hipStream_t st);
 
+// ert_build.hip: the two tables of `bwa-mem2 index -a ert` from the resident FM-index, into buffers owned by *e
+int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, int hit_threshold, int cu_count, int verbose);
+
 }  // namespace bwams

@@ -279,6 +279,17 @@ int bwams_ert_from_host(bwams_index_t *idx, const uint64_t *kmer_table, int32_t 
                         int32_t read_len, const uint8_t *mlt_table, int64_t mlt_bytes, bwams_ert_t **out);
 /* The same from <prefix>.kmer_table and <prefix>.mlt_table (kmerSize 15, xmerSize 4), streamed into HBM. */
 int bwams_ert_open(bwams_index_t *idx, const char *prefix, int32_t read_len, bwams_ert_t **out);
+/* Builds the two tables on the GPU from the resident FM-index (replaces buildKmerTrees, src/ertindex.cpp:773-943):
+ * the same bytes the reference writes for kmerSize = kmer_size, xmerSize = xmer_size, readLength = read_len and
+ * HIT_THRESHOLD = hit_threshold (15, 4, READ_LEN, 256 in src/macro.h).  The index must hold its .0123 reference. */
+int bwams_ert_build(bwams_index_t *idx, int32_t kmer_size, int32_t xmer_size, int32_t read_len, int32_t hit_threshold,
+                    bwams_ert_t **out);
+/* geometry, tree bytes and the build's kernel times (sizes, scan + allocation, bytes; 0 when loaded) */
+int bwams_ert_info(const bwams_ert_t *ert, int32_t *kmer_size, int32_t *xmer_size, int32_t *read_len, int64_t *mlt_bytes,
+                   float build_ms[3]);
+/* copies the tables to the host (either pointer may be NULL) / writes <prefix>.kmer_table and <prefix>.mlt_table */
+int bwams_ert_fetch(bwams_ert_t *ert, uint64_t *kmer_table, uint8_t *mlt_table);
+int bwams_ert_save(bwams_ert_t *ert, const char *prefix);
 int bwams_ert_close(bwams_ert_t *ert);
 int64_t bwams_ert_bytes(const bwams_ert_t *ert);
 

@@ -123,7 +123,7 @@ int bwams_index_from_host(const bwams_fmi_desc_t *d, int device, bwams_index_t *
     const size_t b_ref = d->ref_0123 ? (size_t)(d->ref_seq_len - 1) : 0;
     // a failed allocation or copy must not strand the multi-GB buffers already made: close the handle on the way out
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(dst, bytes);
+        hipError_t e = hipMalloc(dst, bytes + 64);          // slack: kernels read whole aligned words
         return e != hipSuccess ? e : hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     hipError_t ue = up(&ix->d_cp, d->cp_occ, b_cp);
@@ -492,7 +492,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -722,9 +722,9 @@ int bwams_seed_counts(bwams_batch_t *b, int64_t *n_smem, int64_t *n_sa) {
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_sa_lookups, 0, 2 * sizeof(unsigned long long), b->stream));   // + n_lf_steps
         if (b->seed_ert) {
             launch_ert_locate(b->seed_ert->t, b->d_enc, b->d_cum, b->d_sorted, b->n_smem, b->d_sa_cnt, b->last_seed_opt.max_occ,
-                              b->d_ctr, b->stream);
+                              b->d_ctr, b->d_ert_stk, b->ert_stk_frames, b->cu_count, b->stream);
             launch_ert_gather(b->seed_ert->t, b->d_sorted, b->n_smem, b->d_sa_off, b->d_sa_coord, b->max_sa,
-                              b->last_seed_opt.max_occ, b->d_ctr, b->stream);
+                              b->last_seed_opt.max_occ, b->d_ctr, b->d_ert_stk, b->ert_stk_frames, b->cu_count, b->stream);
         } else
         launch_sa_lookup(b->idx->fmi, b->d_sorted, b->n_smem, b->d_sa_off, b->d_sa_coord, b->max_sa, b->last_seed_opt.max_occ,
                          b->d_ctr, b->cu_count, b->stream);
@@ -972,6 +972,13 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
         b->cap_ert_prof = need + need / 8;
         BWAMS_HIP(hipMalloc(&b->d_ert_prof, (size_t)b->cap_ert_prof));
     }
+    const int frames = e->t.read_len + 2;
+    if (frames > b->ert_stk_frames) {
+        if (b->d_ert_stk) (void)hipFree(b->d_ert_stk);
+        b->d_ert_stk = nullptr;
+        BWAMS_HIP(hipMalloc(&b->d_ert_stk, (size_t)ert_walk_threads(b->cu_count) * (size_t)frames * 8));
+        b->ert_stk_frames = frames;
+    }
     const uint8_t *skip = b->has_skip ? b->d_skip : nullptr;
     // events: 0 start | 8,9 match profiles | 10,11 the three rounds | 3,4 sort | 12,13 locate | 4,5 locate + hits
     BWAMS_HIP(hipMemsetAsync(b->d_ctr, 0, sizeof(DevCounters), st));
@@ -1016,7 +1023,8 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
     }
     BWAMS_HIP(hipEventRecord(b->ev[4], st));
     BWAMS_HIP(hipEventRecord(b->ev[12], st));
-    launch_ert_locate(e->t, b->d_enc, b->d_cum, b->d_sorted, n, with_sa ? b->d_sa_cnt : nullptr, opt->max_occ, b->d_ctr, st);
+    launch_ert_locate(e->t, b->d_enc, b->d_cum, b->d_sorted, n, with_sa ? b->d_sa_cnt : nullptr, opt->max_occ, b->d_ctr, b->d_ert_stk,
+                      b->ert_stk_frames, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[13], st));
     if (with_sa && n > 0) {
         size_t tb = 0;
@@ -1033,7 +1041,8 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
         BWAMS_HIP(hipMemsetAsync(b->d_sa_cnt + n, 0, 8, st));
         BWAMS_HIP(rocprim::exclusive_scan(b->d_tmp, tb, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)n + 1,
                                           rocprim::plus<int64_t>(), st));
-        launch_ert_gather(e->t, b->d_sorted, n, b->d_sa_off, b->d_sa_coord, b->max_sa, opt->max_occ, b->d_ctr, st);
+        launch_ert_gather(e->t, b->d_sorted, n, b->d_sa_off, b->d_sa_coord, b->max_sa, opt->max_occ, b->d_ctr, b->d_ert_stk,
+                          b->ert_stk_frames, b->cu_count, st);
     }
     BWAMS_HIP(hipEventRecord(b->ev[5], st));
     BWAMS_HIP(hipGetLastError());

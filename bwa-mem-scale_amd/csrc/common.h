@@ -192,6 +192,8 @@ struct bwams_batch {
     bwams_ert *seed_ert = nullptr;       // the last seed run went over this ERT (nullptr: FM-index)
     uint8_t *d_ert_prof = nullptr;       // ERT seeding: match-length planes, (M + 1) x nbases bytes
     int64_t cap_ert_prof = 0;
+    uint64_t *d_ert_stk = nullptr;       // ERT seeding: stacks of the leaf walks (ert_walk_threads x frames words)
+    int ert_stk_frames = 0;
     bwams_seed_opt_t last_seed_opt{};    // of the last bwams_seed_run (a grown SA buffer re-runs the lookup)
 
     // extension buffers

@@ -42,6 +42,14 @@ __device__ __forceinline__ uint64_t ld_le(const uint8_t *p, int n) {
     return n == 8 ? v : v & ((1ull << (8 * n)) - 1);
 }
 
+// eight base codes (one per byte, first base in the low byte) -> 16 bits, first base lowest
+__device__ __forceinline__ uint64_t squeeze8(uint64_t v) {
+    v &= 0x0303030303030303ull;
+    v = (v | (v >> 6)) & 0x000F000F000F000Full;
+    v = (v | (v >> 12)) & 0x000000FF000000FFull;
+    return (v | (v >> 24)) & 0xFFFFull;
+}
+
 struct Where {
     int kind;          // 0 nothing, 1 one position, 2 multi-hit list at `at`, 3 subtree at `at`
     int w;
@@ -55,12 +63,12 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
                         int64_t plane_stride, int stop_len, Where *wh) {
     const int K = e.K, X = e.X;
     if (i + K > len) return 0;
-    uint64_t key = 0;
-    for (int j = 0; j < K; ++j) {
-        const uint32_t b = q[i + j];
-        if (b > 3) return 0;
-        key |= (uint64_t)b << (2 * j);
-    }
+    // 16 bases as two 8-byte loads (the read buffer is padded); 2-bit codes gathered first base lowest, as getHashKey does
+    const uint64_t b0 = ld_le(q + i, 8), b1 = ld_le(q + i + 8, 8);
+    const uint64_t nmask = K >= 8 ? (K >= 16 ? ~0ull : ((1ull << (8 * (K - 8))) - 1)) : 0ull;
+    const uint64_t n0 = K >= 8 ? ~0ull : ((1ull << (8 * K)) - 1);
+    if (((b0 & n0) | (b1 & nmask)) & 0xFCFCFCFCFCFCFCFCull) return 0;
+    const uint64_t key = (squeeze8(b0) | (squeeze8(b1) << 16)) & ((1ull << (2 * K)) - 1);
     const uint64_t ent = e.kmer[key];
     int code = (int)(ent & 3);
     if (code == E_INVALID) return 0;
@@ -163,9 +171,15 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
         const int lim = PROFILE ? len - i : (stop_len < len - i ? stop_len : len - i);
         const uint8_t *__restrict__ rf = e.ref + leaf_pos;
         const int64_t room = e.ref_len - leaf_pos;
-        while (d < lim && d < room) {
-            const uint32_t bb = q[i + d];
-            if (bb > 3 || rf[d] != bb) break;
+        const int stop = (int64_t)lim < room ? lim : (int)room;
+        bool open = true;
+        while (d + 8 <= stop) {                    // eight bases per step; an N in the read (4) never equals a text base
+            const uint64_t x = ld_le(rf + d, 8) ^ ld_le(q + i + d, 8);
+            if (x) { d += __builtin_ctzll(x) >> 3; open = false; break; }
+            d += 8;
+        }
+        while (open && d < stop) {
+            if (rf[d] != q[i + d]) break;
             d++;
         }
     }
@@ -330,9 +344,8 @@ __global__ __launch_bounds__(256) void ert_select_kernel(SelectArgs A) {
 // Returns the number of hits, or -1 when the explicit stack is exhausted (a corrupt index).
 template <bool COUNT>
 __device__ int64_t ert_leaves(const DevErt &e, int64_t node, int64_t mh_base, int w, int64_t step, int64_t lim,
-                              int64_t *__restrict__ out) {
-    constexpr int kStack = 256;
-    uint64_t stk[kStack];                 // node << 3 | next child
+                              int64_t *__restrict__ out, uint64_t *__restrict__ stk, int64_t stride, int max_frames) {
+    // explicit stack in HBM, frame-major / lane-minor (stk already points at this lane's column): node << 3 | next child
     int sp = 0;
     int64_t t = 0;
     int c = 3;
@@ -347,7 +360,7 @@ __device__ int64_t ert_leaves(const DevErt &e, int64_t node, int64_t mh_base, in
     for (;;) {
         if (c < 0) {
             if (sp == 0) break;
-            const uint64_t top = stk[--sp];
+            const uint64_t top = stk[(int64_t)(--sp) * stride];
             node = (int64_t)(top >> 3);
             c = (int)(top & 7) - 1;
             continue;
@@ -380,9 +393,20 @@ __device__ int64_t ert_leaves(const DevErt &e, int64_t node, int64_t mh_base, in
             continue;
         }
         const uint64_t v = ld_le(mlt + node + 1 + __popc(is_div & above) * w, w);
-        if (COUNT && (v & 63)) { t += (int64_t)(v & 63); c--; continue; }
-        if (sp == kStack) return -1;
-        stk[sp++] = ((uint64_t)node << 3) | (uint64_t)c;           // popped as c - 1: resume with the next child
+        if (v & 63) {
+            // the pointer carries the subtree's hit count (below 20): counting needs no visit, and sampling only when
+            // one of the wanted ranks (multiples of step, fewer than lim of them) falls inside [t, t + count)
+            const int64_t cnt = (int64_t)(v & 63);
+            bool skip = COUNT;
+            if (!COUNT) {
+                const int64_t k = (t + step - 1) / step;
+                skip = k * step >= t + cnt || k >= lim;
+            }
+            if (skip) { t += cnt; c--; continue; }
+        }
+        if (!COUNT && t > (lim - 1) * step) break;       // every wanted rank has been written
+        if (sp == max_frames) return -1;
+        stk[(int64_t)(sp++) * stride] = ((uint64_t)node << 3) | (uint64_t)c;   // popped as c - 1: resume with the next child
         node = node + (int64_t)(v >> 6);
         c = 3;
     }
@@ -394,55 +418,59 @@ __device__ int64_t ert_leaves(const DevErt &e, int64_t node, int64_t mh_base, in
 __global__ __launch_bounds__(256) void ert_locate_kernel(DevErt e, const uint8_t *__restrict__ enc,
                                                          const int64_t *__restrict__ cum, bwams_smem_t *__restrict__ sm,
                                                          int64_t n, int64_t *__restrict__ sa_cnt, int max_occ,
-                                                         DevCounters *ctr) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n) return;
-    bwams_smem_t s = sm[g];
-    const int64_t c0 = cum[s.rid];
-    const int len = (int)(cum[s.rid + 1] - c0), mlen = (int)(s.n - s.m + 1);
-    Where wh;
-    wh.kind = 0; wh.w = 0; wh.at = 0; wh.root = 0;
-    const int d = ert_walk<false>(e, enc + c0, len, (int)s.m, 0, nullptr, 0, mlen, &wh);
-    int64_t cnt = s.s;
-    if (d < mlen) { wh.kind = 0; cnt = 0; }                 // cannot happen with a consistent index
-    if (cnt < 0) {
-        if (wh.kind == 1) cnt = 1;
-        else if (wh.kind == 2) cnt = (int64_t)ld_le(e.mlt + wh.at, 2);
-        else if (wh.kind == 3) {
-            cnt = ert_leaves<true>(e, wh.at, wh.root + (int64_t)ld_le(e.mlt + wh.root, 4), wh.w, 1, 0, nullptr);
-            if (cnt < 0) { cnt = 0; wh.kind = 0; atomicAdd(&ctr->overflow, 1ull); }
+                                                         DevCounters *ctr, uint64_t *__restrict__ stk, int max_frames) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+    for (int64_t g = tid; g < n; g += nt) {
+        bwams_smem_t s = sm[g];
+        const int64_t c0 = cum[s.rid];
+        const int len = (int)(cum[s.rid + 1] - c0), mlen = (int)(s.n - s.m + 1);
+        Where wh;
+        wh.kind = 0; wh.w = 0; wh.at = 0; wh.root = 0;
+        const int d = ert_walk<false>(e, enc + c0, len, (int)s.m, 0, nullptr, 0, mlen, &wh);
+        int64_t cnt = s.s;
+        if (d < mlen) { wh.kind = 0; cnt = 0; }                 // cannot happen with a consistent index
+        if (cnt < 0) {
+            if (wh.kind == 1) cnt = 1;
+            else if (wh.kind == 2) cnt = (int64_t)ld_le(e.mlt + wh.at, 2);
+            else if (wh.kind == 3) {
+                cnt = ert_leaves<true>(e, wh.at, wh.root + (int64_t)ld_le(e.mlt + wh.root, 4), wh.w, 1, 0, nullptr, stk + tid, nt,
+                                       max_frames);
+                if (cnt < 0) { cnt = 0; wh.kind = 0; atomicAdd(&ctr->overflow, 1ull); }
+            }
         }
+        s.s = cnt;
+        s.k = wh.at;
+        s.l = (int64_t)wh.kind | ((int64_t)wh.w << 8) | (wh.root << 16);
+        sm[g] = s;
+        if (sa_cnt) sa_cnt[g] = cnt < (int64_t)max_occ ? cnt : (int64_t)max_occ;
     }
-    s.s = cnt;
-    s.k = wh.at;
-    s.l = (int64_t)wh.kind | ((int64_t)wh.w << 8) | (wh.root << 16);
-    sm[g] = s;
-    if (sa_cnt) sa_cnt[g] = cnt < (int64_t)max_occ ? cnt : (int64_t)max_occ;
 }
 
 // lane = one sorted seed: its hits, sampled as mem_chain_new does (step = s / max_occ), into coord[sa_off ..)
 __global__ __launch_bounds__(256) void ert_gather_kernel(DevErt e, bwams_smem_t *__restrict__ sm, int64_t n,
                                                          const int64_t *__restrict__ sa_off, int64_t *__restrict__ coord,
-                                                         int64_t coord_cap, int max_occ, DevCounters *ctr) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g == 0) ctr->n_sa_lookups = (unsigned long long)sa_off[n];
-    if (g >= n) return;
-    bwams_smem_t s = sm[g];
-    const int kind = (int)(s.l & 0xff), w = (int)((s.l >> 8) & 0xff);
-    const int64_t root = s.l >> 16, at = s.k, off = sa_off[g];
-    const int64_t step = s.s > (int64_t)max_occ ? s.s / max_occ : 1;
-    const int64_t lim = s.s < (int64_t)max_occ ? s.s : (int64_t)max_occ;
-    if (off + lim <= coord_cap) {
-        if (kind == 1) {
-            coord[off] = at;
-        } else if (kind == 2) {
-            for (int64_t k = 0; k < lim; ++k) coord[off + k] = (int64_t)(ld_le(e.mlt + at + 2 + 5 * (k * step), 5) >> 1);
-        } else if (kind == 3) {
-            ert_leaves<false>(e, at, root + (int64_t)ld_le(e.mlt + root, 4), w, step, lim, coord + off);
+                                                         int64_t coord_cap, int max_occ, DevCounters *ctr,
+                                                         uint64_t *__restrict__ stk, int max_frames) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+    if (tid == 0) ctr->n_sa_lookups = (unsigned long long)sa_off[n];
+    for (int64_t g = tid; g < n; g += nt) {
+        bwams_smem_t s = sm[g];
+        const int kind = (int)(s.l & 0xff), w = (int)((s.l >> 8) & 0xff);
+        const int64_t root = s.l >> 16, at = s.k, off = sa_off[g];
+        const int64_t step = s.s > (int64_t)max_occ ? s.s / max_occ : 1;
+        const int64_t lim = s.s < (int64_t)max_occ ? s.s : (int64_t)max_occ;
+        if (off + lim <= coord_cap) {
+            if (kind == 1) {
+                coord[off] = at;
+            } else if (kind == 2) {
+                for (int64_t k = 0; k < lim; ++k) coord[off + k] = (int64_t)(ld_le(e.mlt + at + 2 + 5 * (k * step), 5) >> 1);
+            } else if (kind == 3) {
+                ert_leaves<false>(e, at, root + (int64_t)ld_le(e.mlt + root, 4), w, step, lim, coord + off, stk + tid, nt, max_frames);
+            }
         }
+        s.k = 0; s.l = 0;          // the FM-index interval has no meaning here
+        sm[g] = s;
     }
-    s.k = 0; s.l = 0;          // the FM-index interval has no meaning here
-    sm[g] = s;
 }
 
 }  // namespace
@@ -466,16 +494,24 @@ void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *s
     ert_select_kernel<<<(unsigned)((nseq + 255) / 256), 256, 0, st>>>(A);
 }
 
+int64_t ert_walk_threads(int cu_count) { return (int64_t)cu_count * 8 * 256; }
+
 void launch_ert_locate(const DevErt &e, const uint8_t *enc, const int64_t *cum, bwams_smem_t *sorted, int64_t n,
-                       int64_t *sa_cnt, int max_occ, DevCounters *ctr, hipStream_t st) {
+                       int64_t *sa_cnt, int max_occ, DevCounters *ctr, uint64_t *stk, int max_frames, int cu_count,
+                       hipStream_t st) {
     if (n <= 0) return;
-    ert_locate_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(e, enc, cum, sorted, n, sa_cnt, max_occ, ctr);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)cu_count * 8) blocks = (int64_t)cu_count * 8;
+    ert_locate_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, enc, cum, sorted, n, sa_cnt, max_occ, ctr, stk, max_frames);
 }
 
 void launch_ert_gather(const DevErt &e, bwams_smem_t *sorted, int64_t n, const int64_t *sa_off, int64_t *coord,
-                       int64_t coord_cap, int max_occ, DevCounters *ctr, hipStream_t st) {
+                       int64_t coord_cap, int max_occ, DevCounters *ctr, uint64_t *stk, int max_frames, int cu_count,
+                       hipStream_t st) {
     if (n <= 0) return;
-    ert_gather_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(e, sorted, n, sa_off, coord, coord_cap, max_occ, ctr);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)cu_count * 8) blocks = (int64_t)cu_count * 8;
+    ert_gather_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, sorted, n, sa_off, coord, coord_cap, max_occ, ctr, stk, max_frames);
 }
 
 }  // namespace bwams

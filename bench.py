@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fma", action="store_true", help="build and use the FMA tables (all_smem.11 / last_smem.13)")
     ap.add_argument("--emf", action="store_true", help="build the exact-match filter table (L=150) on the GPU and probe it first")
+    ap.add_argument("--ert", action="store_true", help="build the ERT index (k-mer table + radix trees) on the GPU and seed over it instead of the FM-index")
     ap.add_argument("--pcie", action="store_true", help="also time the one-call host-buffer form (PCIe inclusive)")
     ap.add_argument("--no-pe", action="store_true", help="skip the paired-end leg (mate rescue + pairing; reported beside, never `value`)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: rendezvous (gloo), barriers and the JSON line only")
@@ -206,6 +207,15 @@ def main():
         ix.build_fma(11, 13)
         log(f"FMA tables built on GPU in {time.time()-t0:.1f}s (512 MiB + 1 GiB)")
 
+    ert_h = None
+    ert_info = None
+    if args.ert:
+        t0 = time.time()
+        ert_h = capi.Ert.build(ix)                 # kmerSize 15, xmerSize 4, READ_LEN 151, HIT_THRESHOLD 256 (src/macro.h)
+        ert_info = ert_h.info()
+        log(f"ERT built on GPU in {time.time()-t0:.1f}s: k-mer table 8 GiB + trees {ert_info['mlt_bytes']/2**30:.1f} GiB "
+            f"(kernels: sizes {ert_info['build_ms'][0]/1e3:.1f}s, bytes {ert_info['build_ms'][2]/1e3:.1f}s)")
+
     emf_h = None
     if args.emf:
         from bwams import emf as emf_mod
@@ -248,7 +258,10 @@ def main():
         batch.seed_upload_device(d_reads[c].data_ptr(), cums[c])         # device-to-device copy + 2-bit packing
         if emf_h is not None:
             batch.emf_run(emf_h)
-        batch.seed_run(seed_opt, with_sa=True)
+        if ert_h is not None:
+            batch.seed_run_ert(ert_h, seed_opt, with_sa=True)
+        else:
+            batch.seed_run(seed_opt, with_sa=True)
         batch.chain_run(mem_opt)
         batch.extend_run(mem_opt)
         batch.dedup_run(mem_opt)
@@ -317,7 +330,10 @@ def main():
         batch.seed_upload(penc, pcum)
 
         def pe_step():
-            batch.seed_run(seed_opt, with_sa=True)
+            if ert_h is not None:
+                batch.seed_run_ert(ert_h, seed_opt, with_sa=True)
+            else:
+                batch.seed_run(seed_opt, with_sa=True)
             batch.chain_run(mem_opt)
             batch.extend_run(mem_opt)
             batch.dedup_run(mem_opt)
@@ -378,7 +394,7 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if abs(tj.get("genome_mbp", 0) - args.genome_mbp) < 1 and tj.get("reads") == len(reads_l[-1]) and not (args.fma or args.emf):
+                if abs(tj.get("genome_mbp", 0) - args.genome_mbp) < 1 and tj.get("reads") == len(reads_l[-1]) and not (args.fma or args.emf or args.ert):
                     traffic = tj.get("smem_round1_hbm_bytes_per_launch")
                     pmc = tj
             except Exception:
@@ -406,9 +422,10 @@ def main():
                 "workload": f"{total_reads} synthetic 150bp SE reads ({R} per GPU, {n_chunks} resident chunk(s) of <= {CH}) vs a synthetic {G} bp genome "
                             f"({'= GRCh38 l_pac; ' if abs(G - GRCH38_L_PAC) < 1000 else ''}{2 * G + 1} index rows, "
                             f"{len(contigs) if contigs is not None else 1} sequences; GRCh38 itself unavailable offline), "
-                            f"FM-index{' + FMA tables' if args.fma else ''}{' + EMF (L=150)' if args.emf else ''}"
-                            f"{'' if (args.fma or args.emf) else ' only (no ERT/FMA/EMF)'}; step = per chunk: {'EMF probe, ' if args.emf else ''}pack reads, SMEM r1-r3, sort, "
-                            f"SA lookup, chaining + chain filter, extension tasks of the seeds of the kept chains, "
+                            f"FM-index{' + ERT (seeding runs over the ERT)' if args.ert else ''}{' + FMA tables' if args.fma else ''}{' + EMF (L=150)' if args.emf else ''}"
+                            f"{'' if (args.fma or args.emf or args.ert) else ' only (no ERT/FMA/EMF)'}; step = per chunk: {'EMF probe, ' if args.emf else ''}"
+                            f"{'ERT walk of every read position, the three seeding rounds over the match profiles, sort, hit listing' if args.ert else 'pack reads, SMEM r1-r3, sort, SA lookup'}, "
+                            f"chaining + chain filter, extension tasks of the seeds of the kept chains, "
                             f"banded-SW left then right (w=100, retry at 200), region bookkeeping + purge (seeds the reference would extend "
                             f"and then discard are not extended), mem_sort_dedup_patch; everything on the GPU",
                 "genome_mbp": round(G / 1e6, 3),
@@ -484,6 +501,35 @@ def main():
                 "note": "fraction of the extension stage's wall time that the counted instructions need at the guide's issue rates "
                         "(1 VALU wave-instruction / 2 cycles / SIMD, 1 SALU / cycle / CU, 2.4 GHz); counts from the committed PMC pass",
             }
+        if ert_h is not None:
+            # the ERT walk kernel replaces the SMEM search as the dominant seeding kernel: its algorithmic bytes =
+            # 8 B per k-mer entry + one 32-B sector per tree record decoded + the .0123 bytes compared + the reads in + L_m out
+            w_ms = mean("ms_smem_r1")
+            w_bytes = 8 * st.ert_kmer_lookups + 32 * st.ert_node_reads + st.ert_ref_bytes + n_bases + 2 * n_bases
+            out["stage_ms"].update({"ert_walk": round(w_ms, 3), "ert_rounds": round(mean("ms_smem_r2"), 3),
+                                    "ert_locate": round(mean("ms_smem_r3"), 3), "ert_locate_plus_hits": round(mean("ms_sal"), 3)})
+            for k_ in ("smem_round1", "smem_round2", "smem_round3", "sa_lookup"):
+                out["stage_ms"].pop(k_, None)
+            out["roofline"] = {
+                "kernel": "ert_profile_kernel (one forward ERT walk per read position)",
+                "bound": "hbm", "achieved": round(w_bytes / (w_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(w_bytes), "launch_ms": round(w_ms, 3),
+                "random_accesses_per_s": round((st.ert_kmer_lookups + st.ert_node_reads) / (w_ms * 1e-3) / 1e9, 2),
+                "note": "random 8-B / 32-B reads: the distinct-line ceiling of this part is 48 G lines/s (tools/ubench_gather), i.e. "
+                        "0.38 of the byte peak for 64-B lines; walks per second is the figure to read",
+            }
+            out["ert"] = {
+                "kmer_size": ert_info["kmer"], "xmer_size": ert_info["xmer"], "read_len": ert_info["read_len"],
+                "kmer_table_bytes": 8 * 4 ** ert_info["kmer"], "tree_bytes": ert_info["mlt_bytes"],
+                "build_s": {"sizes": round(ert_info["build_ms"][0] / 1e3, 2), "bytes": round(ert_info["build_ms"][2] / 1e3, 2)},
+                "events_per_read": {"kmer_lookups": round(st.ert_kmer_lookups / CHn, 2), "tree_records": round(st.ert_node_reads / CHn, 2),
+                                    "text_bytes_compared": round(st.ert_ref_bytes / CHn, 1)},
+                "Gwalks_per_s": round(n_bases / (w_ms * 1e-3) / 1e9, 2),
+                "note": "seeds and sampled hit positions are identical to the FM-index path's (tests/test_gpu_ert.py, tools/ert_scale.py)",
+            }
+            for k_ in ("backward_ext", "backward_ext_by_round", "cp_occ_blocks_by_round", "cp_occ_blocks", "lf_steps", "algorithmic_bytes"):
+                out["events_per_read"].pop(k_, None)
         if emf_h is not None:
             _, codes = batch.emf_fetch(CHn)
             emf_ms = mean("ms_emf")

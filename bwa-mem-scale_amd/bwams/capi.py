@@ -113,7 +113,8 @@ class Stats(C.Structure):
                 ("ms_chain", C.c_float), ("ms_ext_plan", C.c_float), ("ms_ext_left", C.c_float),
                 ("ms_ext_right", C.c_float), ("ms_ext_purge", C.c_float), ("ms_ext_total", C.c_float),
                 ("n_ext_rounds", C.c_int64), ("n_final_regs", C.c_int64), ("ms_dedup", C.c_float), ("ms_pair", C.c_float),
-                ("n_pair_tasks", C.c_int64), ("n_pair_redone", C.c_int64), ("n_pair_regs", C.c_int64), ("n_chain_redo", C.c_int64)]
+                ("n_pair_tasks", C.c_int64), ("n_pair_redone", C.c_int64), ("n_pair_regs", C.c_int64), ("n_chain_redo", C.c_int64),
+                ("ert_kmer_lookups", C.c_int64), ("ert_node_reads", C.c_int64), ("ert_ref_bytes", C.c_int64)]
 
 
 class BuildStats(C.Structure):

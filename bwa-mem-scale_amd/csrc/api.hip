@@ -973,11 +973,13 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
         BWAMS_HIP(hipMalloc(&b->d_ert_prof, (size_t)b->cap_ert_prof));
     }
     const int frames = e->t.read_len + 2;
+    const size_t part_bytes = ert_count_bytes();      // partial counters sit behind the stacks
     if (frames > b->ert_stk_frames) {
         if (b->d_ert_stk) (void)hipFree(b->d_ert_stk);
         b->d_ert_stk = nullptr;
-        BWAMS_HIP(hipMalloc(&b->d_ert_stk, (size_t)ert_walk_threads(b->cu_count) * (size_t)frames * 8));
+        BWAMS_HIP(hipMalloc(&b->d_ert_stk, (size_t)ert_walk_threads(b->cu_count) * (size_t)frames * 8 + part_bytes));
         b->ert_stk_frames = frames;
+        BWAMS_HIP(hipMemsetAsync(b->d_ert_stk + (size_t)ert_walk_threads(b->cu_count) * (size_t)frames, 0, part_bytes, b->stream));
     }
     const uint8_t *skip = b->has_skip ? b->d_skip : nullptr;
     // events: 0 start | 8,9 match profiles | 10,11 the three rounds | 3,4 sort | 12,13 locate | 4,5 locate + hits
@@ -985,7 +987,8 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
     BWAMS_HIP(hipEventRecord(b->ev[0], st));
     BWAMS_HIP(hipMemsetAsync(b->d_ert_prof, 0, (size_t)need, st));
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
-    launch_ert_profile(e->t, b->d_enc, b->d_cum, skip, b->nseq, b->nbases, M, b->d_ert_prof, st);
+    launch_ert_profile(e->t, b->d_enc, b->d_cum, skip, b->nseq, b->nbases, M, b->d_ert_prof, b->d_ctr,
+                       (unsigned long long *)(b->d_ert_stk + (size_t)ert_walk_threads(b->cu_count) * (size_t)b->ert_stk_frames), st);
     BWAMS_HIP(hipEventRecord(b->ev[9], st));
     BWAMS_HIP(hipEventRecord(b->ev[10], st));
     launch_ert_select(b->d_ert_prof, b->d_cum, skip, b->nseq, b->nbases, M, *opt, b->d_pool, b->pool_cap, b->d_ctr, st);
@@ -993,6 +996,8 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
     BWAMS_HIP(hipEventRecord(b->ev[3], st));
     BWAMS_HIP(hipGetLastError());
     BWAMS_HIP(hipMemcpyAsync(&b->d_ctr->n_smem_valid, &b->d_ctr->n_smem_total, 8, hipMemcpyDeviceToDevice, st));
+    for (int k = 0; k < 3; ++k)      // the rounds are not separate launches here: all seeds are reported under round 1
+        BWAMS_HIP(hipMemcpyAsync(&b->d_ctr->valid_after[k], &b->d_ctr->n_smem_total, 8, hipMemcpyDeviceToDevice, st));
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     const int64_t n = (int64_t)b->h_ctr->n_smem_total;
@@ -1418,6 +1423,9 @@ int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev_emf[0], b->ev_emf[1]) == hipSuccess) s.ms_emf = ms;
     }
+    s.ert_kmer_lookups = (int64_t)c.ert_kmer;
+    s.ert_node_reads = (int64_t)c.ert_nodes;
+    s.ert_ref_bytes = (int64_t)c.ert_ref;
     s.emf_nodes = (int64_t)b->emf_nodes;
     s.emf_cmp_bytes = (int64_t)b->emf_cmp_bytes;
     chain_state_stats(b->chain, &s);

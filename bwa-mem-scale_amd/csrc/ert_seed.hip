@@ -30,6 +30,7 @@ namespace {
 enum { N_EMPTY = 0, N_LEAF = 1, N_UNIFORM = 2, N_DIVERGE = 3 };          // node_type_t, ertindex.h:12
 enum { E_INVALID = 0, E_SINGLE = 1, E_INFREQUENT = 2, E_FREQUENT = 3 };  // macro.h:216-219
 constexpr int kMany = 255;           // 20 hits or more: the trees do not say how many
+constexpr int kCntSlots = 4096;      // partial event counters of the walk kernel
 constexpr int kStage = 24;           // seeds of one read staged in LDS before the wave appends them together
 
 // n <= 8 bytes at any address, little endian: two aligned 8-byte loads (the table is padded by 16 bytes)
@@ -50,6 +51,8 @@ __device__ __forceinline__ uint64_t squeeze8(uint64_t v) {
     return (v | (v >> 24)) & 0xFFFFull;
 }
 
+struct WalkCnt { uint32_t kmer, nodes, ref; };      // k-mer entries read, tree records decoded, text bytes compared
+
 struct Where {
     int kind;          // 0 nothing, 1 one position, 2 multi-hit list at `at`, 3 subtree at `at`
     int w;
@@ -60,7 +63,7 @@ struct Where {
 // stop_len and describe where the hits of read[i, i+stop_len) are.  Returns the matched length.
 template <bool PROFILE>
 __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len, int i, int M, uint8_t *__restrict__ plane,
-                        int64_t plane_stride, int stop_len, Where *wh) {
+                        int64_t plane_stride, int stop_len, Where *wh, WalkCnt &wc) {
     const int K = e.K, X = e.X;
     if (i + K > len) return 0;
     // 16 bases as two 8-byte loads (the read buffer is padded); 2-bit codes gathered first base lowest, as getHashKey does
@@ -70,6 +73,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
     if (((b0 & n0) | (b1 & nmask)) & 0xFCFCFCFCFCFCFCFCull) return 0;
     const uint64_t key = (squeeze8(b0) | (squeeze8(b1) << 16)) & ((1ull << (2 * K)) - 1);
     const uint64_t ent = e.kmer[key];
+    wc.kmer++;
     int code = (int)(ent & 3);
     if (code == E_INVALID) return 0;
     const int64_t root = (int64_t)(ent >> 24);
@@ -93,6 +97,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
             xk |= b << (2 * j);
         }
         const uint64_t xe = ld_le(mlt + root + 4 + 8 * (int64_t)xk, 8);
+        wc.nodes++;
         code = (int)(xe & 3);
         if (code == E_INVALID) return 0;
         d = K + X;
@@ -120,6 +125,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
         if (b > 3) break;
         const int c = 3 - (int)b;
         const uint64_t head = ld_le(mlt + node, 8);       // code byte and the first 7 bytes behind it
+        wc.nodes++;
         const uint32_t cd = (uint32_t)(head & 0xff);
         const int t = (cd >> (c << 1)) & 3;
         if (t == N_EMPTY) break;
@@ -144,6 +150,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
         const int n_ptr = __popc(is_div), before_ptr = __popc(is_div & above), before_leaf = __popc(is_leaf & above);
         if (t == N_LEAF) {
             const uint64_t rec = ld_le(mlt + node + 1 + n_ptr * w + 5 * before_leaf, 5);
+            wc.nodes++;
             int nc = 1;
             if (rec & 1) {
                 if (mh_base < 0) mh_base = root + (int64_t)ld_le(mlt + root, 4);
@@ -172,6 +179,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
         const uint8_t *__restrict__ rf = e.ref + leaf_pos;
         const int64_t room = e.ref_len - leaf_pos;
         const int stop = (int64_t)lim < room ? lim : (int)room;
+        const int d_from = d;
         bool open = true;
         while (d + 8 <= stop) {                    // eight bases per step; an N in the read (4) never equals a text base
             const uint64_t x = ld_le(rf + d, 8) ^ ld_le(q + i + d, 8);
@@ -182,6 +190,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
             if (rf[d] != q[i + d]) break;
             d++;
         }
+        wc.ref += (uint32_t)(d - d_from + (d < stop));
     }
     if (PROFILE) {
         const int hi = cur < M ? cur : M;
@@ -198,7 +207,8 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
 // lane = one base of the batch = one start position of one read.  planes: [0] = the base is N, [m] = L_m.
 __global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_t *__restrict__ enc,
                                                           const int64_t *__restrict__ cum, const uint8_t *__restrict__ skip,
-                                                          int64_t nseq, int64_t nbases, int M, uint8_t *__restrict__ prof) {
+                                                          int64_t nseq, int64_t nbases, int M, uint8_t *__restrict__ prof,
+                                                          unsigned long long *__restrict__ part) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t g0 = g - (threadIdx.x & 63);            // the wave's first base: one search per wave
     int64_t r = 0;
@@ -211,14 +221,38 @@ __global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_
         r = lo;
     }
     r = ((int64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r);
-    if (g >= nbases) return;
-    while (r + 1 < nseq && g >= cum[r + 1]) r++;
-    const int64_t c0 = cum[r];
-    const int len = (int)(cum[r + 1] - c0), i = (int)(g - c0);
-    const uint8_t *q = enc + c0;
-    prof[g] = q[i] > 3;
-    if (skip && skip[r]) return;
-    ert_walk<true>(e, q, len, i, M, prof + g, nbases, 0, nullptr);
+    WalkCnt wc = {0, 0, 0};
+    if (g < nbases) {
+        while (r + 1 < nseq && g >= cum[r + 1]) r++;
+        const int64_t c0 = cum[r];
+        const int len = (int)(cum[r + 1] - c0), i = (int)(g - c0);
+        const uint8_t *q = enc + c0;
+        prof[g] = q[i] > 3;
+        if (!(skip && skip[r])) ert_walk<true>(e, q, len, i, M, prof + g, nbases, 0, nullptr, wc);
+    }
+    // event counts of the launch (8 B per k-mer entry, a 32-B sector per tree record, the text bytes)
+    uint32_t a = wc.kmer, b = wc.nodes, c = wc.ref;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); }
+    if ((threadIdx.x & 63) == 0) {
+        // 2 M waves: spread the additions over kCntSlots lines, summed by ert_count_kernel afterwards
+        unsigned long long *p = part + 3 * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kCntSlots - 1));
+        if (a) atomicAdd(p, (unsigned long long)a);
+        if (b) atomicAdd(p + 1, (unsigned long long)b);
+        if (c) atomicAdd(p + 2, (unsigned long long)c);
+    }
+}
+
+__global__ void ert_count_kernel(unsigned long long *part, DevCounters *ctr) {
+    __shared__ unsigned long long acc[3];
+    if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kCntSlots; i += blockDim.x)
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long v = part[3 * i + k];
+            if (v) { atomicAdd(&acc[k], v); part[3 * i + k] = 0; }
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) { ctr->ert_kmer = acc[0]; ctr->ert_nodes = acc[1]; ctr->ert_ref = acc[2]; }
 }
 
 struct SelectArgs {
@@ -426,7 +460,8 @@ __global__ __launch_bounds__(256) void ert_locate_kernel(DevErt e, const uint8_t
         const int len = (int)(cum[s.rid + 1] - c0), mlen = (int)(s.n - s.m + 1);
         Where wh;
         wh.kind = 0; wh.w = 0; wh.at = 0; wh.root = 0;
-        const int d = ert_walk<false>(e, enc + c0, len, (int)s.m, 0, nullptr, 0, mlen, &wh);
+        WalkCnt wc = {0, 0, 0};
+        const int d = ert_walk<false>(e, enc + c0, len, (int)s.m, 0, nullptr, 0, mlen, &wh, wc);
         int64_t cnt = s.s;
         if (d < mlen) { wh.kind = 0; cnt = 0; }                 // cannot happen with a consistent index
         if (cnt < 0) {
@@ -476,9 +511,10 @@ __global__ __launch_bounds__(256) void ert_gather_kernel(DevErt e, bwams_smem_t 
 }  // namespace
 
 void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum, const uint8_t *skip, int64_t nseq,
-                        int64_t nbases, int M, uint8_t *prof, hipStream_t st) {
+                        int64_t nbases, int M, uint8_t *prof, DevCounters *ctr, unsigned long long *part, hipStream_t st) {
     if (nbases <= 0) return;
-    ert_profile_kernel<<<(unsigned)((nbases + 255) / 256), 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof);
+    ert_profile_kernel<<<(unsigned)((nbases + 255) / 256), 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof, part);
+    ert_count_kernel<<<1, 256, 0, st>>>(part, ctr);
 }
 
 void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *skip, int64_t nseq, int64_t nbases, int M,
@@ -495,6 +531,7 @@ void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *s
 }
 
 int64_t ert_walk_threads(int cu_count) { return (int64_t)cu_count * 8 * 256; }
+size_t ert_count_bytes() { return (size_t)kCntSlots * 3 * 8; }
 
 void launch_ert_locate(const DevErt &e, const uint8_t *enc, const int64_t *cum, bwams_smem_t *sorted, int64_t n,
                        int64_t *sa_cnt, int max_occ, DevCounters *ctr, uint64_t *stk, int max_frames, int cu_count,

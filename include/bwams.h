@@ -261,6 +261,11 @@ typedef struct bwams_stats {
     int64_t n_pair_regs;                  /* regions after rescue */
     int64_t n_chain_redo;                 /* reads of the last chaining run in which a chain position repeated: chained again
                                            * with the exact B-tree instead of the ordered array */
+    /* last bwams_seed_run_ert: events of the walk kernel (ms_smem_r1 = that kernel, ms_smem_r2 = the three rounds over the
+     * profiles, ms_smem_r3 = locating the seeds' hits, ms_sal = locating + listing the hits) */
+    int64_t ert_kmer_lookups;             /* 8-byte k-mer table entries read */
+    int64_t ert_node_reads;               /* tree records decoded (x-mer entry, node head, leaf record / pointer) */
+    int64_t ert_ref_bytes;                /* .0123 bytes compared by leaf expansion */
 } bwams_stats_t;
 int bwams_batch_stats(bwams_batch_t *b, bwams_stats_t *out);
 

@@ -492,7 +492,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk, b->d_ert_redo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -704,6 +704,15 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     return BWAMS_OK;
 }
 
+static int ert_redo_ensure(bwams_batch_t *b, int64_t n) {
+    if (n <= b->cap_ert_redo) return BWAMS_OK;
+    if (b->d_ert_redo) (void)hipFree(b->d_ert_redo);
+    b->d_ert_redo = nullptr;
+    b->cap_ert_redo = n + n / 4 + 1024;
+    BWAMS_HIP(hipMalloc(&b->d_ert_redo, (size_t)((b->cap_ert_redo + 31) / 32) * 4));
+    return BWAMS_OK;
+}
+
 int bwams_seed_counts(bwams_batch_t *b, int64_t *n_smem, int64_t *n_sa) {
     if (!b || !b->seed_done) return BWAMS_ERR_ARG;
     BWAMS_HIP(hipSetDevice(b->idx->device));
@@ -723,8 +732,11 @@ int bwams_seed_counts(bwams_batch_t *b, int64_t *n_smem, int64_t *n_sa) {
         if (b->seed_ert) {
             launch_ert_locate(b->seed_ert->t, b->d_enc, b->d_cum, b->d_sorted, b->n_smem, b->d_sa_cnt, b->last_seed_opt.max_occ,
                               b->d_ctr, b->d_ert_stk, b->ert_stk_frames, b->cu_count, b->stream);
+            if (int rrc = ert_redo_ensure(b, b->n_smem)) return rrc;
             launch_ert_gather(b->seed_ert->t, b->d_sorted, b->n_smem, b->d_sa_off, b->d_sa_coord, b->max_sa,
-                              b->last_seed_opt.max_occ, b->d_ctr, b->d_ert_stk, b->ert_stk_frames, b->cu_count, b->stream);
+                              b->last_seed_opt.max_occ, b->d_ctr, b->d_ert_stk, b->ert_stk_frames, b->d_ert_redo, b->max_sa,
+                              b->cu_count, b->stream);
+            launch_ert_clear(b->d_sorted, b->n_smem, b->stream);
         } else
         launch_sa_lookup(b->idx->fmi, b->d_sorted, b->n_smem, b->d_sa_off, b->d_sa_coord, b->max_sa, b->last_seed_opt.max_occ,
                          b->d_ctr, b->cu_count, b->stream);
@@ -785,6 +797,19 @@ int bwams_seed_fmi(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, con
 
 /* ------------------------------------------------------------ ERT seeding -- */
 
+// A loaded index starts with an empty hit-count table (filled as big subtrees are counted for the first time); sized
+// from the tree bytes: a four-way node with 20 or more hits below it stands for at least some hundred bytes of trees.
+static int ert_count_table(bwams_ert *e) {
+    int bits = 16;
+    while (bits < 26 && ((int64_t)1 << bits) < e->mlt_bytes / 256) bits++;
+    BWAMS_HIP(hipMalloc(&e->d_cnt, (size_t)16 << bits));
+    BWAMS_HIP(hipMemset(e->d_cnt, 0, (size_t)16 << bits));
+    e->t.cnt_tab = (uint64_t *)e->d_cnt;
+    e->t.cnt_bits = bits;
+    e->bytes += (int64_t)16 << bits;
+    return BWAMS_OK;
+}
+
 int bwams_ert_from_host(bwams_index_t *ix, const uint64_t *kmer_table, int32_t kmer_size, int32_t xmer_size,
                         int32_t read_len, const uint8_t *mlt_table, int64_t mlt_bytes, bwams_ert_t **out) {
     if (!ix || !out || !kmer_table || (mlt_bytes && !mlt_table) || mlt_bytes < 0) return BWAMS_ERR_ARG;
@@ -817,6 +842,7 @@ int bwams_ert_from_host(bwams_index_t *ix, const uint64_t *kmer_table, int32_t k
     e->t.K = kmer_size; e->t.X = xmer_size; e->t.read_len = read_len;
     e->bytes = (int64_t)(nk * 8) + mlt_bytes + 16;
     e->mlt_bytes = mlt_bytes;
+    if (int crc = ert_count_table(e)) { bwams_ert_close(e); return crc; }
     *out = e;
     return BWAMS_OK;
 }
@@ -876,6 +902,7 @@ int bwams_ert_open(bwams_index_t *ix, const char *prefix, int32_t read_len, bwam
     e->t.K = K; e->t.X = X; e->t.read_len = read_len;
     e->bytes = (int64_t)(nk * 8) + mlt_bytes + 16;
     e->mlt_bytes = mlt_bytes;
+    if (int crc = ert_count_table(e)) { bwams_ert_close(e); return crc; }
     *out = e;
     return BWAMS_OK;
 }
@@ -954,6 +981,7 @@ int bwams_ert_close(bwams_ert_t *e) {
     (void)hipSetDevice(e->idx->device);
     if (e->d_kmer) (void)hipFree(e->d_kmer);
     if (e->d_mlt) (void)hipFree(e->d_mlt);
+    if (e->d_cnt) (void)hipFree(e->d_cnt);
     delete e;
     return BWAMS_OK;
 }
@@ -972,7 +1000,7 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
         b->cap_ert_prof = need + need / 8;
         BWAMS_HIP(hipMalloc(&b->d_ert_prof, (size_t)b->cap_ert_prof));
     }
-    const int frames = e->t.read_len + 2;
+    const int frames = 2 * (e->t.read_len + 2);      // the counting walk keeps two words per level
     const size_t part_bytes = ert_count_bytes();      // partial counters sit behind the stacks
     if (frames > b->ert_stk_frames) {
         if (b->d_ert_stk) (void)hipFree(b->d_ert_stk);
@@ -1046,9 +1074,11 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
         BWAMS_HIP(hipMemsetAsync(b->d_sa_cnt + n, 0, 8, st));
         BWAMS_HIP(rocprim::exclusive_scan(b->d_tmp, tb, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)n + 1,
                                           rocprim::plus<int64_t>(), st));
+        if (int rrc = ert_redo_ensure(b, n)) return rrc;
         launch_ert_gather(e->t, b->d_sorted, n, b->d_sa_off, b->d_sa_coord, b->max_sa, opt->max_occ, b->d_ctr, b->d_ert_stk,
-                          b->ert_stk_frames, b->cu_count, st);
+                          b->ert_stk_frames, b->d_ert_redo, b->max_sa, b->cu_count, st);
     }
+    launch_ert_clear(b->d_sorted, n, st);
     BWAMS_HIP(hipEventRecord(b->ev[5], st));
     BWAMS_HIP(hipGetLastError());
     b->seed_done = true;

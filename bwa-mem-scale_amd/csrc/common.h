@@ -57,6 +57,8 @@ struct DevErt {
     const uint8_t *ref;        // .0123, both strands
     int64_t ref_len;           // 2 * l_pac
     int32_t K, X, read_len;    // kmerSize, xmerSize, READ_LEN of the build (src/macro.h:204-206, :66)
+    uint64_t *cnt_tab;         // hit counts of the subtrees with 20 hits or more: {node address + 1, hits} pairs, open addressing
+    int32_t cnt_bits;          // log2 of the number of pairs
 };
 
 // device-side counters of one seed run
@@ -139,8 +141,8 @@ int bsw_list_ensure(bwams_batch *b, int64_t n_tasks);   // grows b->d_bsw_list (
 struct bwams_ert {
     bwams_index *idx = nullptr;
     bwams::DevErt t{};
-    void *d_kmer = nullptr, *d_mlt = nullptr;
-    int64_t bytes = 0, mlt_bytes = 0;
+    void *d_kmer = nullptr, *d_mlt = nullptr, *d_cnt = nullptr;
+    int64_t bytes = 0, mlt_bytes = 0, n_big = 0;
     float build_ms[3] = {0, 0, 0};       // bwams_ert_build: sizes, scan + allocation, bytes
 };
 
@@ -195,6 +197,8 @@ struct bwams_batch {
     int64_t cap_ert_prof = 0;
     uint64_t *d_ert_stk = nullptr;       // ERT seeding: stacks of the leaf walks (ert_walk_threads x frames words)
     int ert_stk_frames = 0;
+    uint32_t *d_ert_redo = nullptr;      // ERT seeding: seeds whose hits the rank descent could not list (bit per seed)
+    int64_t cap_ert_redo = 0;            // seeds it is sized for
     bwams_seed_opt_t last_seed_opt{};    // of the last bwams_seed_run (a grown SA buffer re-runs the lookup)
 
     // extension buffers

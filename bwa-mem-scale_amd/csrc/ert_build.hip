@@ -96,7 +96,8 @@ struct BuildArgs {
     uint64_t *stk;           // 5 words per frame, frame-major, lane-minor
     int64_t n_threads;
     int max_frames;
-    unsigned long long *err; // [0] stack exhausted
+    unsigned long long *err; // [0] stack exhausted, [1] four-way nodes with 20 hits or more (pass B)
+    DevErt cnt;              // pass C: only cnt_tab / cnt_bits are used (the hit-count table of those nodes)
 };
 
 // One k-mer's walk.  EMIT = false: cur[0..2] are the byte cursors under pointer widths 2, 3, 4; EMIT = true: cur[0]
@@ -108,10 +109,11 @@ struct Walk {
     uint8_t *out;
     int w;
     uint32_t cur[3], maxp[3];
-    uint32_t mh, mh_base;
+    uint32_t mh, mh_base, n_big;
+    int64_t blob_off;
     bool failed;
 
-    __device__ Walk(const BuildArgs &a, int64_t t) : A(a), tid(t), out(nullptr), w(2), mh(0), mh_base(0), failed(false) {
+    __device__ Walk(const BuildArgs &a, int64_t t) : A(a), tid(t), out(nullptr), w(2), mh(0), mh_base(0), n_big(0), blob_off(0), failed(false) {
         cur[0] = cur[1] = cur[2] = 0;
         maxp[0] = maxp[1] = maxp[2] = 0;
     }
@@ -203,6 +205,10 @@ struct Walk {
                         else code |= (uint32_t)N_LEAF << (i << 1);
                     }
                     start[0] = cur[0]; start[1] = cur[1]; start[2] = cur[2];
+                    if (ik.s >= 20) {          // its hit count is in no pointer: the seeding kernels look it up by address
+                        if (EMIT) cnt_insert(A.cnt, blob_off + cur[0], ik.s);
+                        else n_big++;
+                    }
                     if (EMIT) put(cur[0], code, 1);
                     adv(1, n_ptr);
                     for (int i = 3; i >= 0; --i) {
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(256) void ert_size_kernel(BuildArgs A) {
                 xmer_table<false>(W, A, ik);
             }
             if (W.failed) atomicAdd(&A.err[0], 1ull);
+            if (W.n_big) atomicAdd(&A.err[1], (unsigned long long)W.n_big);
             const int w = pick_width(W.maxp);
             const uint64_t tree = W.cur[w - 2];
             if (num_hits < 20) lo |= (uint64_t)num_hits << 17;
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(256) void ert_emit_kernel(BuildArgs A) {
         kmer_search(A, idx, ik, lep, num_hits);
         Walk<true> W(A, tid);
         W.out = A.mlt + off;
+        W.blob_off = (int64_t)off;
         if (code == E_SINGLE) {
             W.put(0, 0, 1);
             W.put(1, (uint64_t)sa_true(A.f, ik.k) << 1, 5);
@@ -431,8 +439,8 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
     ERT_HIP(hipMalloc(&d_meta, n_kmers * 8));
     ERT_HIP(hipMalloc(&d_off, n_kmers * 8));
     ERT_HIP(hipMalloc(&d_stk, (size_t)A.n_threads * (size_t)A.max_frames * 40));
-    ERT_HIP(hipMalloc(&d_err, 8));
-    ERT_HIP(hipMemsetAsync(d_err, 0, 8, st));
+    ERT_HIP(hipMalloc(&d_err, 16));
+    ERT_HIP(hipMemsetAsync(d_err, 0, 16, st));
     A.kmer = (uint64_t *)e->d_kmer;
     A.meta = (uint64_t *)d_meta;
     A.off = (const uint64_t *)d_off;
@@ -451,12 +459,12 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
         ERT_HIP(rocprim::exclusive_scan(d_tmp, tb, in, (uint64_t *)d_off, (uint64_t)0, (size_t)n_kmers, rocprim::plus<uint64_t>(), st));
     }
     uint64_t last_off = 0, last_meta = 0;
-    unsigned long long err = 0;
+    unsigned long long err[2] = {0, 0};
     ERT_HIP(hipMemcpyAsync(&last_off, (uint64_t *)d_off + (n_kmers - 1), 8, hipMemcpyDeviceToHost, st));
     ERT_HIP(hipMemcpyAsync(&last_meta, (uint64_t *)d_meta + (n_kmers - 1), 8, hipMemcpyDeviceToHost, st));
-    ERT_HIP(hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, st));
+    ERT_HIP(hipMemcpyAsync(err, d_err, 16, hipMemcpyDeviceToHost, st));
     ERT_HIP(hipStreamSynchronize(st));
-    if (err) {
+    if (err[0]) {
         set_last_error("ert_build: a radix tree is deeper than the read length allows (corrupt index?)");
         cleanup();
         return BWAMS_ERR_UNSUPPORTED;
@@ -465,6 +473,13 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
     ERT_HIP(hipMalloc(&e->d_mlt, (size_t)mlt_bytes + 16));
     ERT_HIP(hipMemsetAsync(e->d_mlt, 0, (size_t)mlt_bytes + 16, st));
     A.mlt = (uint8_t *)e->d_mlt;
+    int bits = 10;
+    while (((uint64_t)1 << bits) < 2 * err[1] + 16) bits++;
+    ERT_HIP(hipMalloc(&e->d_cnt, ((size_t)16) << bits));
+    ERT_HIP(hipMemsetAsync(e->d_cnt, 0, ((size_t)16) << bits, st));
+    memset(&A.cnt, 0, sizeof A.cnt);
+    A.cnt.cnt_tab = (uint64_t *)e->d_cnt;
+    A.cnt.cnt_bits = bits;
     ERT_HIP(hipEventRecord(e2, st));
     hipLaunchKernelGGL(ert_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A);
     ERT_HIP(hipGetLastError());
@@ -475,8 +490,8 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
     (void)hipEventElapsedTime(&msS, e1, e2);
     (void)hipEventElapsedTime(&msC, e2, e3);
     if (verbose)
-        fprintf(stderr, "[bwams] ert_build: %llu k-mers, trees %.3f GB; sizes %.1f ms, scan + alloc %.1f ms, bytes %.1f ms\n",
-                (unsigned long long)n_kmers, mlt_bytes / 1e9, msB, msS, msC);
+        fprintf(stderr, "[bwams] ert_build: %llu k-mers, trees %.3f GB, %llu nodes with 20+ hits (count table 2^%d); sizes %.1f ms, scan + alloc %.1f ms, bytes %.1f ms\n",
+                (unsigned long long)n_kmers, mlt_bytes / 1e9, err[1], bits, msB, msS, msC);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     cleanup();
 #undef ERT_HIP
@@ -485,7 +500,10 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
     e->t.ref = f.ref;
     e->t.ref_len = f.ref_seq_len - 1;
     e->t.K = K; e->t.X = X; e->t.read_len = read_len;
-    e->bytes = (int64_t)(n_kmers * 8) + mlt_bytes + 16;
+    e->t.cnt_tab = (uint64_t *)e->d_cnt;
+    e->t.cnt_bits = bits;
+    e->n_big = (int64_t)err[1];
+    e->bytes = (int64_t)(n_kmers * 8) + mlt_bytes + 16 + ((int64_t)16 << bits);
     e->mlt_bytes = mlt_bytes;
     e->build_ms[0] = msB; e->build_ms[1] = msS; e->build_ms[2] = msC;
     return BWAMS_OK;

@@ -373,6 +373,80 @@ __global__ __launch_bounds__(256) void ert_select_kernel(SelectArgs A) {
     }
 }
 
+// ---- hit counts of the big subtrees -------------------------------------------------------------------------------
+// A child pointer carries its subtree's hit count only below 20 (src/ertindex.cpp:455-461); for the others the reference
+// walks the subtree and counts leaves.  Here those counts live in an open-addressing table in HBM (key = address of the
+// four-way node + 1, value = hits): bwams_ert_build fills it from the FM-index intervals it has at hand, a loaded index
+// fills it as subtrees are counted for the first time.  With every count known a hit of given rank is found by descent.
+// hits of the leaf record `li` (0-based among the node's leaf records) of a four-way node: one position or a list
+__device__ __forceinline__ int64_t leaf_rec(const uint8_t *__restrict__ mlt, int64_t node, int n_ptr, int w, int li, int64_t mh_base,
+                                            int64_t *list_at) {
+    const uint64_t rec = ld_le(mlt + node + 1 + n_ptr * w + 5 * li, 5);
+    if (rec & 1) {
+        *list_at = mh_base + (int64_t)(rec >> 1);
+        return (int64_t)ld_le(mlt + *list_at, 2);
+    }
+    *list_at = -(int64_t)(rec >> 1) - 1;       // a single position, encoded negative
+    return 1;
+}
+
+// the four-way node a pointer target stands for: runs (UNIFORM) in front of it are skipped
+__device__ __forceinline__ int64_t skip_runs(const uint8_t *__restrict__ mlt, int64_t node) {
+    for (;;) {
+        const uint64_t head = ld_le(mlt + node, 2);
+        const uint32_t cd = (uint32_t)(head & 0xff);
+        const uint32_t is_uni = (~cd & (cd >> 1)) & 0x55;
+        if (!is_uni) return node;
+        node = node + 2 + (((int)(head >> 8) + 3) >> 2);
+    }
+}
+
+// Number of hits below `node` (a four-way node).  Post-order walk: counts of big subtrees come from the table when it has
+// them and go into it when they had to be summed.  Returns -1 when the explicit stack is exhausted (a corrupt index).
+__device__ int64_t ert_count(const DevErt &e, int64_t node, int64_t mh_base, int w, uint64_t *__restrict__ stk, int64_t stride,
+                             int max_frames) {
+    const uint8_t *__restrict__ mlt = e.mlt;
+    int sp = 0, c = 3;
+    int64_t acc = 0;
+    for (;;) {
+        if (c < 0) {
+            if (acc >= 20) cnt_insert(e, node, acc);
+            if (sp == 0) return acc;
+            sp -= 2;
+            const uint64_t top = stk[(int64_t)sp * stride];
+            const int64_t pacc = (int64_t)stk[(int64_t)(sp + 1) * stride];
+            node = (int64_t)(top >> 3);
+            c = (int)(top & 7) - 1;
+            acc += pacc;
+            continue;
+        }
+        const uint32_t cd = mlt[node];
+        const int ty = (cd >> (c << 1)) & 3;
+        if (ty == N_EMPTY) { c--; continue; }
+        const uint32_t is_div = (cd & (cd >> 1)) & 0x55, is_leaf = (cd & ~(cd >> 1)) & 0x55;
+        const uint32_t above = c == 3 ? 0u : (0xffu << ((c + 1) << 1)) & 0xff;
+        const int n_ptr = __popc(is_div);
+        if (ty == N_LEAF) {
+            int64_t at;
+            acc += leaf_rec(mlt, node, n_ptr, w, __popc(is_leaf & above), mh_base, &at);
+            c--;
+            continue;
+        }
+        const uint64_t v = ld_le(mlt + node + 1 + __popc(is_div & above) * w, w);
+        if (v & 63) { acc += (int64_t)(v & 63); c--; continue; }
+        const int64_t child = skip_runs(mlt, node + (int64_t)(v >> 6));
+        const int64_t known = cnt_lookup(e, child);
+        if (known >= 0) { acc += known; c--; continue; }
+        if (sp + 2 > max_frames) return -1;
+        stk[(int64_t)sp * stride] = ((uint64_t)node << 3) | (uint64_t)c;
+        stk[(int64_t)(sp + 1) * stride] = (uint64_t)acc;
+        sp += 2;
+        node = child;
+        c = 3;
+        acc = 0;
+    }
+}
+
 // Leaves below a node in A, C, G, T order (getNextByteIdx_dfs).  COUNT: number of hits (subtrees whose pointer
 // carries the count are not entered).  Otherwise: hit t goes to out[t / step] when t % step == 0 and t / step < lim.
 // Returns the number of hits, or -1 when the explicit stack is exhausted (a corrupt index).
@@ -464,12 +538,13 @@ __global__ __launch_bounds__(256) void ert_locate_kernel(DevErt e, const uint8_t
         const int d = ert_walk<false>(e, enc + c0, len, (int)s.m, 0, nullptr, 0, mlen, &wh, wc);
         int64_t cnt = s.s;
         if (d < mlen) { wh.kind = 0; cnt = 0; }                 // cannot happen with a consistent index
+        if (wh.kind == 3) wh.at = skip_runs(e.mlt, wh.at);      // hits are listed from the four-way node behind a run
         if (cnt < 0) {
             if (wh.kind == 1) cnt = 1;
             else if (wh.kind == 2) cnt = (int64_t)ld_le(e.mlt + wh.at, 2);
             else if (wh.kind == 3) {
-                cnt = ert_leaves<true>(e, wh.at, wh.root + (int64_t)ld_le(e.mlt + wh.root, 4), wh.w, 1, 0, nullptr, stk + tid, nt,
-                                       max_frames);
+                cnt = cnt_lookup(e, wh.at);
+                if (cnt < 0) cnt = ert_count(e, wh.at, wh.root + (int64_t)ld_le(e.mlt + wh.root, 4), wh.w, stk + tid, nt, max_frames);
                 if (cnt < 0) { cnt = 0; wh.kind = 0; atomicAdd(&ctr->overflow, 1ull); }
             }
         }
@@ -481,31 +556,94 @@ __global__ __launch_bounds__(256) void ert_locate_kernel(DevErt e, const uint8_t
     }
 }
 
-// lane = one sorted seed: its hits, sampled as mem_chain_new does (step = s / max_occ), into coord[sa_off ..)
-__global__ __launch_bounds__(256) void ert_gather_kernel(DevErt e, bwams_smem_t *__restrict__ sm, int64_t n,
+// lane = one sampled hit: seed g's hits of rank 0, step, 2 step, ... (step = s / max_occ as mem_chain_new samples them,
+// src/bwamem.cpp:993-1004) are found by descent: at a four-way node the children's hit counts (leaf records, pointer
+// bits, the table) say which child holds the wanted rank.  A count the table does not have marks the seed for the
+// serial walk below.
+__global__ __launch_bounds__(256) void ert_hits_kernel(DevErt e, const bwams_smem_t *__restrict__ sm, int64_t n,
+                                                       const int64_t *__restrict__ sa_off, int64_t *__restrict__ coord,
+                                                       int64_t coord_cap, int max_occ, DevCounters *ctr,
+                                                       uint32_t *__restrict__ redo) {
+    const int64_t total = sa_off[n] < coord_cap ? sa_off[n] : coord_cap;
+    const uint8_t *__restrict__ mlt = e.mlt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_sa_lookups = (unsigned long long)sa_off[n];
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        int64_t lo = 0, hi = n;                    // upper_bound(sa_off, g) - 1
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (sa_off[mid] <= g) lo = mid; else hi = mid;
+        }
+        const bwams_smem_t s = sm[lo];
+        const int kind = (int)(s.l & 0xff), w = (int)((s.l >> 8) & 0xff);
+        const int64_t root = s.l >> 16;
+        const int64_t step = s.s > (int64_t)max_occ ? s.s / max_occ : 1;
+        int64_t rho = (g - sa_off[lo]) * step, pos = -1;
+        if (kind == 1) {
+            pos = s.k;
+        } else if (kind == 2) {
+            pos = (int64_t)(ld_le(mlt + s.k + 2 + 5 * rho, 5) >> 1);
+        } else if (kind == 3) {
+            const int64_t mh_base = root + (int64_t)ld_le(mlt + root, 4);
+            int64_t node = s.k;
+            bool fail = false;
+            for (int guard = 0; guard < 1024 && pos < 0 && !fail; ++guard) {
+                const uint32_t cd = mlt[node];
+                const uint32_t is_div = (cd & (cd >> 1)) & 0x55;
+                const int n_ptr = __popc(is_div);
+                int li = 0, pi = 0;
+                int64_t next = -1;
+                for (int c = 3; c >= 0 && pos < 0 && next < 0 && !fail; --c) {
+                    const int ty = (cd >> (c << 1)) & 3;
+                    if (ty == N_EMPTY) continue;
+                    if (ty == N_LEAF) {
+                        int64_t at;
+                        const int64_t nc = leaf_rec(mlt, node, n_ptr, w, li++, mh_base, &at);
+                        if (rho < nc) pos = at < 0 ? -at - 1 : (int64_t)(ld_le(mlt + at + 2 + 5 * rho, 5) >> 1);
+                        else rho -= nc;
+                    } else if (ty == N_DIVERGE) {
+                        const uint64_t v = ld_le(mlt + node + 1 + (pi++) * w, w);
+                        const int64_t child = skip_runs(mlt, node + (int64_t)(v >> 6));
+                        int64_t cnt = (int64_t)(v & 63);
+                        if (cnt == 0) {
+                            cnt = cnt_lookup(e, child);
+                            if (cnt < 0) { fail = true; break; }
+                        }
+                        if (rho < cnt) next = child; else rho -= cnt;
+                    } else {
+                        fail = true;          // a run cannot be met here: s.k and every child are behind their runs
+                    }
+                }
+                if (pos < 0 && next < 0) fail = true;
+                node = next;
+            }
+            if (fail || pos < 0) { atomicOr(&redo[lo >> 5], 1u << (lo & 31)); continue; }
+        }
+        coord[g] = pos;
+    }
+}
+
+// lane = one seed marked by ert_hits_kernel: its hits by the serial leaf walk (the reference's leaf_gather order)
+__global__ __launch_bounds__(256) void ert_gather_kernel(DevErt e, const bwams_smem_t *__restrict__ sm, int64_t n,
                                                          const int64_t *__restrict__ sa_off, int64_t *__restrict__ coord,
-                                                         int64_t coord_cap, int max_occ, DevCounters *ctr,
+                                                         int64_t coord_cap, int max_occ, const uint32_t *__restrict__ redo,
                                                          uint64_t *__restrict__ stk, int max_frames) {
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
-    if (tid == 0) ctr->n_sa_lookups = (unsigned long long)sa_off[n];
     for (int64_t g = tid; g < n; g += nt) {
-        bwams_smem_t s = sm[g];
+        if (!((redo[g >> 5] >> (g & 31)) & 1)) continue;
+        const bwams_smem_t s = sm[g];
         const int kind = (int)(s.l & 0xff), w = (int)((s.l >> 8) & 0xff);
         const int64_t root = s.l >> 16, at = s.k, off = sa_off[g];
         const int64_t step = s.s > (int64_t)max_occ ? s.s / max_occ : 1;
         const int64_t lim = s.s < (int64_t)max_occ ? s.s : (int64_t)max_occ;
-        if (off + lim <= coord_cap) {
-            if (kind == 1) {
-                coord[off] = at;
-            } else if (kind == 2) {
-                for (int64_t k = 0; k < lim; ++k) coord[off + k] = (int64_t)(ld_le(e.mlt + at + 2 + 5 * (k * step), 5) >> 1);
-            } else if (kind == 3) {
-                ert_leaves<false>(e, at, root + (int64_t)ld_le(e.mlt + root, 4), w, step, lim, coord + off, stk + tid, nt, max_frames);
-            }
-        }
-        s.k = 0; s.l = 0;          // the FM-index interval has no meaning here
-        sm[g] = s;
+        if (kind == 3 && off + lim <= coord_cap)
+            ert_leaves<false>(e, at, root + (int64_t)ld_le(e.mlt + root, 4), w, step, lim, coord + off, stk + tid, nt, max_frames);
     }
+}
+
+// the FM-index interval has no meaning for these seeds: k = l = 0 once the hits are listed
+__global__ void ert_clear_kernel(bwams_smem_t *__restrict__ sm, int64_t n) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) { sm[g].k = 0; sm[g].l = 0; }
 }
 
 }  // namespace
@@ -543,12 +681,22 @@ void launch_ert_locate(const DevErt &e, const uint8_t *enc, const int64_t *cum, 
 }
 
 void launch_ert_gather(const DevErt &e, bwams_smem_t *sorted, int64_t n, const int64_t *sa_off, int64_t *coord,
-                       int64_t coord_cap, int max_occ, DevCounters *ctr, uint64_t *stk, int max_frames, int cu_count,
-                       hipStream_t st) {
+                       int64_t coord_cap, int max_occ, DevCounters *ctr, uint64_t *stk, int max_frames, uint32_t *redo,
+                       int64_t n_coord_hint, int cu_count, hipStream_t st) {
     if (n <= 0) return;
-    int64_t blocks = (n + 255) / 256;
+    (void)hipMemsetAsync(redo, 0, (size_t)((n + 31) / 32) * 4, st);
+    int64_t blocks = (n_coord_hint + 255) / 256;
+    if (blocks > (int64_t)cu_count * 16) blocks = (int64_t)cu_count * 16;
+    if (blocks < 1) blocks = 1;
+    ert_hits_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, sorted, n, sa_off, coord, coord_cap, max_occ, ctr, redo);
+    blocks = (n + 255) / 256;
     if (blocks > (int64_t)cu_count * 8) blocks = (int64_t)cu_count * 8;
-    ert_gather_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, sorted, n, sa_off, coord, coord_cap, max_occ, ctr, stk, max_frames);
+    ert_gather_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, sorted, n, sa_off, coord, coord_cap, max_occ, redo, stk, max_frames);
+}
+
+void launch_ert_clear(bwams_smem_t *sorted, int64_t n, hipStream_t st) {
+    if (n <= 0) return;
+    ert_clear_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(sorted, n);
 }
 
 }  // namespace bwams

@@ -38,7 +38,8 @@ static __device__ __forceinline__ void cnt_insert(const DevErt &e, int64_t node,
 
 // planes of `prof`: (M + 1) x nbases bytes, zeroed by the caller; [0] = N flag, [m] = L_m
 void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum, const uint8_t *skip, int64_t nseq,
-                        int64_t nbases, int M, uint8_t *prof, DevCounters *ctr, unsigned long long *part, hipStream_t st);
+                        int64_t nbases, int M, uint8_t *prof, DevCounters *ctr, unsigned long long *part, int cu_count,
+                        hipStream_t st);
 size_t ert_count_bytes();      // `part`: zeroed once; the launch leaves it zeroed
 void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *skip, int64_t nseq, int64_t nbases, int M,
                        const bwams_seed_opt_t &opt, bwams_smem_t *pool, int64_t pool_cap, DevCounters *ctr, hipStream_t st);

@@ -31,15 +31,18 @@ enum { N_EMPTY = 0, N_LEAF = 1, N_UNIFORM = 2, N_DIVERGE = 3 };          // node
 enum { E_INVALID = 0, E_SINGLE = 1, E_INFREQUENT = 2, E_FREQUENT = 3 };  // macro.h:216-219
 constexpr int kMany = 255;           // 20 hits or more: the trees do not say how many
 constexpr int kCntSlots = 4096;      // partial event counters of the walk kernel
+constexpr int kCoopRounds = 6;       // diagonals a wave expands cooperatively before the lanes go on alone
 constexpr int kStage = 24;           // seeds of one read staged in LDS before the wave appends them together
 
-// n <= 8 bytes at any address, little endian: two aligned 8-byte loads (the table is padded by 16 bytes)
+// n <= 8 bytes at any address, little endian: one unaligned 8-byte load (gfx950 global loads need no alignment; the
+// tables, the reads and the text are padded so that the 8 bytes exist)
+__device__ __forceinline__ uint64_t ld8(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
 __device__ __forceinline__ uint64_t ld_le(const uint8_t *p, int n) {
-    const uintptr_t a = (uintptr_t)p;
-    const uint64_t *q = (const uint64_t *)(a & ~(uintptr_t)7);
-    const int sh = (int)(a & 7) * 8;
-    uint64_t v = q[0];
-    if (sh) v = (v >> sh) | (q[1] << (64 - sh));
+    const uint64_t v = ld8(p);
     return n == 8 ? v : v & ((1ull << (8 * n)) - 1);
 }
 
@@ -53,6 +56,8 @@ __device__ __forceinline__ uint64_t squeeze8(uint64_t v) {
 
 struct WalkCnt { uint32_t kmer, nodes, ref; };      // k-mer entries read, tree records decoded, text bytes compared
 
+struct Pend { int64_t leaf_pos; int d, cur; };      // a walk that reached a leaf: text position of the match start, depth, hits
+
 struct Where {
     int kind;          // 0 nothing, 1 one position, 2 multi-hit list at `at`, 3 subtree at `at`
     int w;
@@ -63,7 +68,7 @@ struct Where {
 // stop_len and describe where the hits of read[i, i+stop_len) are.  Returns the matched length.
 template <bool PROFILE>
 __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len, int i, int M, uint8_t *__restrict__ plane,
-                        int64_t plane_stride, int stop_len, Where *wh, WalkCnt &wc) {
+                        int64_t plane_stride, int stop_len, Where *wh, WalkCnt &wc, Pend *pend = nullptr) {
     const int K = e.K, X = e.X;
     if (i + K > len) return 0;
     // 16 bases as two 8-byte loads (the read buffer is padded); 2-bit codes gathered first base lowest, as getHashKey does
@@ -131,13 +136,27 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
         if (t == N_EMPTY) break;
         if (t == N_UNIFORM) {
             const int nbp = (int)((head >> 8) & 0xff);
+            // the run, eight bases per step: the run's bytes hold four bases each, first base in the top bits, as 3 - base;
+            // the read's eight bytes are squeezed to 2-bit codes, first base in the low bits
+            int lim_j = nbp;
+            if (!PROFILE && stop_len - d < lim_j) lim_j = stop_len - d;
+            if (len - i - d < lim_j) lim_j = len - i - d;
             int j = 0;
-            for (; j < nbp; ++j) {
-                if (!PROFILE && d + j >= stop_len) break;
-                if (i + d + j >= len) break;
-                const int bp = (mlt[node + 2 + (j >> 2)] >> ((~j & 3) << 1)) & 3;
-                const uint32_t bb = q[i + d + j];
-                if (bb > 3 || 3 - (int)bb != bp) break;
+            while (j < lim_j) {
+                const uint64_t q8 = ld8(q + i + d + j);
+                const uint32_t rb = j < 24 ? (uint32_t)((head >> (16 + 2 * j)) & 0xffff)      // bytes 2.. of the head word (j is a multiple of 8)
+                                           : (uint32_t)ld_le(mlt + node + 2 + (j >> 2), 2);
+                // reverse the four 2-bit groups of each byte, then complement: codes of eight bases, first base lowest
+                uint32_t r = ((rb & 0x0303u) << 6) | ((rb & 0x0C0Cu) << 2) | ((rb & 0x3030u) >> 2) | ((rb & 0xC0C0u) >> 6);
+                r = ~r & 0xffffu;
+                const uint32_t x = ((uint32_t)squeeze8(q8) ^ r) & 0xffffu;
+                const uint64_t nn = q8 & 0xFCFCFCFCFCFCFCFCull;
+                int ok = x ? (__builtin_ctz(x) >> 1) : 8;
+                const int okn = nn ? (__builtin_ctzll(nn) >> 3) : 8;
+                if (okn < ok) ok = okn;
+                if (ok > lim_j - j) ok = lim_j - j;
+                j += ok;
+                if (ok < 8) break;
             }
             d += j;
             node = node + 2 + ((nbp + 3) >> 2);
@@ -173,6 +192,10 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
             node = node + (int64_t)(v >> 6);
         }
     }
+    if (PROFILE && pend) {              // the caller expands the leaf (wave-cooperatively) and stores the final lengths
+        pend->leaf_pos = leaf_pos; pend->d = d; pend->cur = cur;
+        return d;
+    }
     if (leaf_pos >= 0) {
         // the rest of the suffix is not in the tree: compare with the text (get_seeds_prefix :2940-2965)
         const int lim = PROFILE ? len - i : (stop_len < len - i ? stop_len : len - i);
@@ -205,37 +228,102 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
 }
 
 // lane = one base of the batch = one start position of one read.  planes: [0] = the base is N, [m] = L_m.
+// Persistent waves, 64 consecutive bases per trip: a walk lives for some ten microseconds, and a grid of one short-lived
+// workgroup per 256 bases kept only five waves per CU in flight (workgroup launch rate), where the walk needs dozens
+// of them to cover its chain of dependent HBM reads.
 __global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_t *__restrict__ enc,
                                                           const int64_t *__restrict__ cum, const uint8_t *__restrict__ skip,
                                                           int64_t nseq, int64_t nbases, int M, uint8_t *__restrict__ prof,
                                                           unsigned long long *__restrict__ part) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t g0 = g - (threadIdx.x & 63);            // the wave's first base: one search per wave
-    int64_t r = 0;
-    if ((threadIdx.x & 63) == 0 && g0 < nbases) {
-        int64_t lo = 0, hi = nseq;                        // last r with cum[r] <= g0
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (cum[mid] <= g0) lo = mid; else hi = mid;
-        }
-        r = lo;
-    }
-    r = ((int64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     WalkCnt wc = {0, 0, 0};
-    if (g < nbases) {
-        while (r + 1 < nseq && g >= cum[r + 1]) r++;
-        const int64_t c0 = cum[r];
-        const int len = (int)(cum[r + 1] - c0), i = (int)(g - c0);
-        const uint8_t *q = enc + c0;
-        prof[g] = q[i] > 3;
-        if (!(skip && skip[r])) ert_walk<true>(e, q, len, i, M, prof + g, nbases, 0, nullptr, wc);
+    for (int64_t g0 = wave * 64; g0 < nbases; g0 += n_waves * 64) {
+        int64_t r = 0;
+        if (lane == 0) {
+            // last r with cum[r] <= g0, one search per wave: reads are about equally long, so look next to the proportional
+            // guess first and bisect only what is left
+            int64_t lo = 0, hi = nseq;
+            const int64_t gs = (int64_t)((double)g0 * (double)nseq / (double)nbases);
+            int64_t a = gs - 2 < 0 ? 0 : gs - 2, b = gs + 3 > nseq ? nseq : gs + 3;
+            if (cum[a] <= g0) lo = a; else hi = a;
+            if (hi > b) { if (cum[b] <= g0) lo = b; else hi = b; }
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (cum[mid] <= g0) lo = mid; else hi = mid;
+            }
+            r = lo;
+        }
+        r = ((int64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r);
+        const int64_t g = g0 + lane;
+        Pend pd = {-1, 0, 0};
+        int64_t c0 = 0;
+        int len = 0, i = 0;
+        if (g < nbases) {
+            while (r + 1 < nseq && g >= cum[r + 1]) r++;
+            c0 = cum[r];
+            len = (int)(cum[r + 1] - c0); i = (int)(g - c0);
+            const uint8_t *q = enc + c0;
+            prof[g] = q[i] > 3;
+            if (!(skip && skip[r])) ert_walk<true>(e, q, len, i, M, prof + g, nbases, 0, nullptr, wc, &pd);
+        }
+        // ---- leaf expansion: the rest of the suffix is not in the tree, compare with the text (get_seeds_prefix :2940-2965)
+        bool open = pd.leaf_pos >= 0;
+        int d = pd.d;
+        const int64_t D = pd.leaf_pos - i;                    // text position of read position 0 on this lane's diagonal
+        auto probe = [&]() {                                 // eight bases; an N in the read (4) never equals a text base
+            const int64_t room = e.ref_len - pd.leaf_pos;
+            const int stop = (int64_t)(len - i) < room ? len - i : (int)room;
+            const int n = stop - d;
+            if (n <= 0) { open = false; return; }
+            uint64_t x = ld8(e.ref + pd.leaf_pos + d) ^ ld8(enc + c0 + i + d);
+            if (n < 8) x |= 0xFFull << (8 * n);
+            wc.ref += n < 8 ? n : 8;
+            if (x) { d += __builtin_ctzll(x) >> 3; open = false; } else d += 8;
+        };
+        if (open) probe();
+        // Lanes on a long match mostly share their diagonal (consecutive read positions, one locus): the wave compares that
+        // diagonal once, 64 bases per load, and every lane of the group reads its answer from the mismatch bits.  A lane
+        // for lane compare costs one divergent load per lane and 8 bases, and the address unit serialises those.
+        for (int round = 0; round < kCoopRounds; ++round) {
+            const uint64_t todo = __ballot(open);
+            if (!todo) break;
+            const int leader = __builtin_ctzll(todo);
+            const int64_t Dl = ((int64_t)__builtin_amdgcn_readlane((int)(D >> 32), leader) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)D, leader);
+            const int64_t cl = ((int64_t)__builtin_amdgcn_readlane((int)(c0 >> 32), leader) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)c0, leader);
+            const int lenl = __builtin_amdgcn_readlane(len, leader);
+            uint64_t m0 = ~0ull, m1 = ~0ull, m2 = ~0ull, m3 = ~0ull;
+            const int nch = (lenl + 63) >> 6;
+            for (int k = 0; k < nch && k < 4; ++k) {
+                const int j = 64 * k + lane;
+                const int64_t pos = Dl + j;
+                bool mm = true;
+                if (j < lenl && pos >= 0 && pos < e.ref_len) mm = e.ref[pos] != enc[cl + j];
+                const uint64_t bits = __ballot(mm);
+                if (k == 0) m0 = bits; else if (k == 1) m1 = bits; else if (k == 2) m2 = bits; else m3 = bits;
+            }
+            if (lane == 0) wc.ref += 64 * (nch < 4 ? nch : 4);
+            if (open && D == Dl && c0 == cl) {
+                const int x = i + d;                         // first mismatch at or behind read position x
+                int k = x >> 6;
+                uint64_t m = (k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : m3) & (~0ull << (x & 63));
+                while (m == 0 && k < 3) { k++; m = k == 1 ? m1 : k == 2 ? m2 : m3; }
+                d = (m ? 64 * k + __builtin_ctzll(m) : 256) - i;
+                if (d > len - i) d = len - i;
+                open = false;
+            }
+        }
+        while (open) probe();                                // more diagonals in the wave than rounds: each lane for itself
+        if (pd.leaf_pos >= 0 || pd.cur > 0) {
+            const int hi = pd.cur < M ? pd.cur : M;
+            for (int m = 1; m <= hi; ++m) prof[g + (int64_t)m * nbases] = (uint8_t)d;
+        }
     }
     // event counts of the launch (8 B per k-mer entry, a 32-B sector per tree record, the text bytes)
     uint32_t a = wc.kmer, b = wc.nodes, c = wc.ref;
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); }
-    if ((threadIdx.x & 63) == 0) {
-        // 2 M waves: spread the additions over kCntSlots lines, summed by ert_count_kernel afterwards
-        unsigned long long *p = part + 3 * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kCntSlots - 1));
+    if (lane == 0) {
+        unsigned long long *p = part + 3 * (wave & (kCntSlots - 1));
         if (a) atomicAdd(p, (unsigned long long)a);
         if (b) atomicAdd(p + 1, (unsigned long long)b);
         if (c) atomicAdd(p + 2, (unsigned long long)c);
@@ -649,9 +737,12 @@ __global__ void ert_clear_kernel(bwams_smem_t *__restrict__ sm, int64_t n) {
 }  // namespace
 
 void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum, const uint8_t *skip, int64_t nseq,
-                        int64_t nbases, int M, uint8_t *prof, DevCounters *ctr, unsigned long long *part, hipStream_t st) {
+                        int64_t nbases, int M, uint8_t *prof, DevCounters *ctr, unsigned long long *part, int cu_count,
+                        hipStream_t st) {
     if (nbases <= 0) return;
-    ert_profile_kernel<<<(unsigned)((nbases + 255) / 256), 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof, part);
+    int64_t blocks = (nbases + 255) / 256;
+    if (blocks > (int64_t)cu_count * 8) blocks = (int64_t)cu_count * 8;      // 32 waves per CU
+    ert_profile_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof, part);
     ert_count_kernel<<<1, 256, 0, st>>>(part, ctr);
 }
 

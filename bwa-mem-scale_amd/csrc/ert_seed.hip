@@ -741,7 +741,14 @@ void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum,
                         hipStream_t st) {
     if (nbases <= 0) return;
     int64_t blocks = (nbases + 255) / 256;
-    if (blocks > (int64_t)cu_count * 8) blocks = (int64_t)cu_count * 8;      // 32 waves per CU
+    // persistent waves, many more than fit at once: trips differ a lot in length (repeats), and 32 blocks per CU measured
+    // 16.9 ms against 20.9 ms for one residency (8 per CU) and 17.8 ms for one block per 256 bases (GRCh38 size, 1 M reads)
+    static int per_cu = -1;
+    if (per_cu < 0) {
+        const char *g = getenv("BWAMS_ERT_GRID");      // experiments: blocks per CU, 0 = one block per 256 bases
+        per_cu = g ? atoi(g) : 32;
+    }
+    if (per_cu > 0 && blocks > (int64_t)cu_count * per_cu) blocks = (int64_t)cu_count * per_cu;
     ert_profile_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof, part);
     ert_count_kernel<<<1, 256, 0, st>>>(part, ctr);
 }

@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fma", action="store_true", help="build and use the FMA tables (all_smem.11 / last_smem.13)")
     ap.add_argument("--emf", action="store_true", help="build the exact-match filter table (L=150) on the GPU and probe it first")
+    ap.add_argument("--no-ert-leg", action="store_true", help="skip the beside leg that repeats the steps with seeding over the ERT")
     ap.add_argument("--ert", action="store_true", help="build the ERT index (k-mer table + radix trees) on the GPU and seed over it instead of the FM-index")
     ap.add_argument("--pcie", action="store_true", help="also time the one-call host-buffer form (PCIe inclusive)")
     ap.add_argument("--no-pe", action="store_true", help="skip the paired-end leg (mate rescue + pairing; reported beside, never `value`)")
@@ -155,6 +156,36 @@ def dry_run(args, rank, world):
                           "scaling": args.scaling, "vs_baseline": None, "dry_run": True}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+
+def ert_report(st, mean, CHn, n_bases, ert_info):
+    """stage times, roofline object and index facts of a run whose seeding went over the ERT (st: last chunk's stats)"""
+    # algorithmic bytes of the walk kernel (SURVEY.md 8d): 8 B per k-mer entry + one 32-B sector per tree record decoded + the .0123
+    # bytes compared + the reads in + the L_m bytes out
+    w_ms = mean("ms_smem_r1")
+    w_bytes = 8 * st.ert_kmer_lookups + 32 * st.ert_node_reads + st.ert_ref_bytes + n_bases + 2 * n_bases
+    stage = {"ert_walk": round(w_ms, 3), "ert_rounds": round(mean("ms_smem_r2"), 3), "ert_locate": round(mean("ms_smem_r3"), 3),
+             "ert_locate_plus_hits": round(mean("ms_sal"), 3), "sort": round(mean("ms_sort"), 3), "seed_total": round(mean("ms_seed_total"), 3)}
+    roof = {
+        "kernel": "ert_profile_kernel (one forward ERT walk per read position)",
+        "bound": "hbm", "achieved": round(w_bytes / (w_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+        "bytes_per_launch": int(w_bytes), "launch_ms": round(w_ms, 3),
+        "random_reads_per_s_G": round((st.ert_kmer_lookups + st.ert_node_reads) / (w_ms * 1e-3) / 1e9, 2),
+        "note": "random 8-B / 32-B reads: the distinct-line ceiling of this part is 48 G lines/s (tools/ubench_gather), i.e. 0.38 of the "
+                "byte peak even for whole 64-B lines; random reads per second is the figure to read",
+    }
+    info = {
+        "kmer_size": ert_info["kmer"], "xmer_size": ert_info["xmer"], "read_len": ert_info["read_len"],
+        "kmer_table_bytes": 8 * 4 ** ert_info["kmer"], "tree_bytes": ert_info["mlt_bytes"],
+        "build_s": {"sizes": round(ert_info["build_ms"][0] / 1e3, 2), "bytes": round(ert_info["build_ms"][2] / 1e3, 2)},
+        "events_per_read": {"kmer_lookups": round(st.ert_kmer_lookups / CHn, 2), "tree_records": round(st.ert_node_reads / CHn, 2),
+                            "text_bytes_compared": round(st.ert_ref_bytes / CHn, 1)},
+        "Gwalks_per_s": round(n_bases / (w_ms * 1e-3) / 1e9, 2),
+        "note": "seeds and sampled hit positions are identical to the FM-index path's (tests/test_gpu_ert.py, tools/ert_scale.py)",
+    }
+    return stage, roof, info
 
 
 def main():
@@ -294,6 +325,33 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---------------- the same steps with seeding over the ERT (reported beside, never `value`; N = 1 only) ----------------
+    ert_side = None
+    if not args.ert and not args.no_ert_leg and world == 1 and not (args.fma or args.emf):
+        t0 = time.time()
+        ert_h = capi.Ert.build(ix)
+        ert_info = ert_h.info()
+        log(f"ERT built on GPU in {time.time()-t0:.1f}s: k-mer table 8 GiB + trees {ert_info['mlt_bytes']/2**30:.1f} GiB")
+        step()
+        batch.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pc_e = []
+        for _ in range(args.steps):
+            step(pc_e)
+        batch.sync()
+        torch.cuda.synchronize()
+        el_e = time.perf_counter() - t0
+        mean_e = lambda f: float(np.mean([getattr(s_, f) for s_ in pc_e]))       # noqa: E731
+        stg, roof, einfo = ert_report(pc_e[-1], mean_e, len(reads_l[-1]), int(cums[-1][-1]), ert_info)
+        ert_side = {"value": round(total_reads * args.steps / el_e / 1e6, 4), "unit": "Mreads/s", "ms_per_step": round(el_e / args.steps * 1e3, 3),
+                    "stage_ms": stg, "roofline": roof, "index": einfo,
+                    "final_regions": int(pc_e[-1].n_final_regs),
+                    "note": "configs[2]'s seeding backend on the same reads: the ERT (k-mer table + radix trees, built on the GPU from the "
+                            "resident FM-index) replaces SMEM search + SA lookup; chaining, extension and dedup unchanged; same final regions"}
+        ert_h.close()
+        ert_h = None
 
     # ---------------- SAM-side alignment of the last chunk's final regions (reported beside, never `value`) ----------------
     batch.mark_primary_se(mem_opt, id_base=first)
@@ -501,35 +559,17 @@ def main():
                 "note": "fraction of the extension stage's wall time that the counted instructions need at the guide's issue rates "
                         "(1 VALU wave-instruction / 2 cycles / SIMD, 1 SALU / cycle / CU, 2.4 GHz); counts from the committed PMC pass",
             }
-        if ert_h is not None:
-            # the ERT walk kernel replaces the SMEM search as the dominant seeding kernel: its algorithmic bytes =
-            # 8 B per k-mer entry + one 32-B sector per tree record decoded + the .0123 bytes compared + the reads in + L_m out
-            w_ms = mean("ms_smem_r1")
-            w_bytes = 8 * st.ert_kmer_lookups + 32 * st.ert_node_reads + st.ert_ref_bytes + n_bases + 2 * n_bases
-            out["stage_ms"].update({"ert_walk": round(w_ms, 3), "ert_rounds": round(mean("ms_smem_r2"), 3),
-                                    "ert_locate": round(mean("ms_smem_r3"), 3), "ert_locate_plus_hits": round(mean("ms_sal"), 3)})
+        if args.ert:
+            stg, roof, einfo = ert_report(st, mean, CHn, n_bases, ert_info)
             for k_ in ("smem_round1", "smem_round2", "smem_round3", "sa_lookup"):
                 out["stage_ms"].pop(k_, None)
-            out["roofline"] = {
-                "kernel": "ert_profile_kernel (one forward ERT walk per read position)",
-                "bound": "hbm", "achieved": round(w_bytes / (w_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                "bytes_per_launch": int(w_bytes), "launch_ms": round(w_ms, 3),
-                "random_accesses_per_s": round((st.ert_kmer_lookups + st.ert_node_reads) / (w_ms * 1e-3) / 1e9, 2),
-                "note": "random 8-B / 32-B reads: the distinct-line ceiling of this part is 48 G lines/s (tools/ubench_gather), i.e. "
-                        "0.38 of the byte peak for 64-B lines; walks per second is the figure to read",
-            }
-            out["ert"] = {
-                "kmer_size": ert_info["kmer"], "xmer_size": ert_info["xmer"], "read_len": ert_info["read_len"],
-                "kmer_table_bytes": 8 * 4 ** ert_info["kmer"], "tree_bytes": ert_info["mlt_bytes"],
-                "build_s": {"sizes": round(ert_info["build_ms"][0] / 1e3, 2), "bytes": round(ert_info["build_ms"][2] / 1e3, 2)},
-                "events_per_read": {"kmer_lookups": round(st.ert_kmer_lookups / CHn, 2), "tree_records": round(st.ert_node_reads / CHn, 2),
-                                    "text_bytes_compared": round(st.ert_ref_bytes / CHn, 1)},
-                "Gwalks_per_s": round(n_bases / (w_ms * 1e-3) / 1e9, 2),
-                "note": "seeds and sampled hit positions are identical to the FM-index path's (tests/test_gpu_ert.py, tools/ert_scale.py)",
-            }
+            out["stage_ms"].update(stg)
+            out["roofline"] = roof
+            out["ert"] = einfo
             for k_ in ("backward_ext", "backward_ext_by_round", "cp_occ_blocks_by_round", "cp_occ_blocks", "lf_steps", "algorithmic_bytes"):
                 out["events_per_read"].pop(k_, None)
+        elif ert_side is not None:
+            out["ert_mode"] = ert_side
         if emf_h is not None:
             _, codes = batch.emf_fetch(CHn)
             emf_ms = mean("ms_emf")

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pe"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pe --no-ert-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace done" > $OUT/progress.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pe -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/trace_pe.log 2>&1

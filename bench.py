@@ -159,7 +159,20 @@ def dry_run(args, rank, world):
 
 
 
-def ert_report(st, mean, CHn, n_bases, ert_info):
+def load_pmc_summary(genome_mbp, reads):
+    """counter-measured figures of the same workload from the committed PMC passes (separate rocprofv3 runs cannot be taken
+    inside this one); the file is stamped with the commit and workload it was measured on"""
+    tfile = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    try:
+        tj = json.load(open(tfile))
+        if abs(tj.get("genome_mbp", 0) - genome_mbp) < 1 and tj.get("reads") == reads:
+            return tj
+    except Exception:
+        pass
+    return None
+
+
+def ert_report(st, mean, CHn, n_bases, ert_info, pmc=None):
     """stage times, roofline object and index facts of a run whose seeding went over the ERT (st: last chunk's stats)"""
     # algorithmic bytes of the walk kernel (SURVEY.md 8d): 8 B per k-mer entry + one 32-B sector per tree record decoded + the .0123
     # bytes compared + the reads in + the L_m bytes out
@@ -170,7 +183,8 @@ def ert_report(st, mean, CHn, n_bases, ert_info):
     roof = {
         "kernel": "ert_profile_kernel (one forward ERT walk per read position)",
         "bound": "hbm", "achieved": round(w_bytes / (w_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(w_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "traffic": None if not pmc else pmc.get("ert_walk_hbm_bytes_per_launch"),
         "bytes_per_launch": int(w_bytes), "launch_ms": round(w_ms, 3),
         "random_reads_per_s_G": round((st.ert_kmer_lookups + st.ert_node_reads) / (w_ms * 1e-3) / 1e9, 2),
         "note": "random 8-B / 32-B reads: the distinct-line ceiling of this part is 48 G lines/s (tools/ubench_gather), i.e. 0.38 of the "
@@ -344,7 +358,8 @@ def main():
         torch.cuda.synchronize()
         el_e = time.perf_counter() - t0
         mean_e = lambda f: float(np.mean([getattr(s_, f) for s_ in pc_e]))       # noqa: E731
-        stg, roof, einfo = ert_report(pc_e[-1], mean_e, len(reads_l[-1]), int(cums[-1][-1]), ert_info)
+        stg, roof, einfo = ert_report(pc_e[-1], mean_e, len(reads_l[-1]), int(cums[-1][-1]), ert_info,
+                                      load_pmc_summary(args.genome_mbp, len(reads_l[-1])))
         ert_side = {"value": round(total_reads * args.steps / el_e / 1e6, 4), "unit": "Mreads/s", "ms_per_step": round(el_e / args.steps * 1e3, 3),
                     "stage_ms": stg, "roofline": roof, "index": einfo,
                     "final_regions": int(pc_e[-1].n_final_regs),
@@ -560,7 +575,7 @@ def main():
                         "(1 VALU wave-instruction / 2 cycles / SIMD, 1 SALU / cycle / CU, 2.4 GHz); counts from the committed PMC pass",
             }
         if args.ert:
-            stg, roof, einfo = ert_report(st, mean, CHn, n_bases, ert_info)
+            stg, roof, einfo = ert_report(st, mean, CHn, n_bases, ert_info, load_pmc_summary(args.genome_mbp, CHn))
             for k_ in ("smem_round1", "smem_round2", "smem_round3", "sa_lookup"):
                 out["stage_ms"].pop(k_, None)
             out["stage_ms"].update(stg)

@@ -48,6 +48,14 @@ def short(k):
                       ("pack_reads", "pack_reads_kernel"), ("round2_work", "round2_work_kernel"),
                       ("make_keys", "make_keys_kernel"), ("gather_sorted", "gather_sorted_kernel"),
                       ("plan_kernel", "plan_kernel (task construction)"), ("build_kernel", "build_kernel (task construction)"),
+                      ("ert_profile", "ert_profile_kernel (ERT: one forward walk per read position)"),
+                      ("ert_select", "ert_select_kernel (ERT: the three seeding rounds over the match profiles)"),
+                      ("ert_locate", "ert_locate_kernel (ERT: where a seed's hits are, their number)"),
+                      ("ert_hits", "ert_hits_kernel (ERT: hits by rank descent, lane per sampled hit)"),
+                      ("ert_gather", "ert_gather_kernel (ERT: serial leaf walk, fallback)"),
+                      ("ert_size", "ert_size_kernel (ERT build: sizes and pointer widths)"),
+                      ("ert_emit", "ert_emit_kernel (ERT build: bytes)"),
+                      ("ert_count", "ert_count_kernel"), ("ert_clear", "ert_clear_kernel"),
                       ("emf_probe", "emf_probe_kernel"), ("ksw_kernel", "ksw_kernel")):
         if pat in k:
             return name
@@ -81,6 +89,18 @@ for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
                 P.setdefault(s, {})[c] = sum(x) / len(x)
                 N[s] = len(x)
 
+E = {}          # the ERT walk kernel's counters (passes over bench.py --ert)
+for p in ("pmc_fetch_ert", "pmc_write_ert", "pmc_sq_ert"):
+    fs = newest(f"{src}/{p}/*/*_counter_collection.csv")
+    if not fs:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if "ert_profile_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for c, x in acc.items():
+        E[c] = sum(x) / len(x)
+
 r1 = P["smem_search_kernel<true> (SMEM round 1)"]
 fetch, write = r1["FETCH_SIZE"] * 1024, r1["WRITE_SIZE"] * 1024
 alg = bench["roofline"]["bytes_per_launch"]
@@ -106,6 +126,21 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
             s_ = short(r["Name"])
             if s_ and ("pair_" in s_ or "ksw" in s_ or "pestat" in s_):
                 f.write(f"| {s_} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} |\n")
+    te = newest(src + "/trace_ert/*/*_kernel_stats.csv")
+    if te:
+        shutil.copy(te[0], f"profiles/{rnd}_ert_kernel_stats.csv")
+        f.write("\n### Seeding over the ERT (`bench.py --ert --steps 2 --warmup 1 --no-cpu-baseline --no-pe`; the build kernels run once)\n\n"
+                "| kernel | calls | avg ms |\n|---|---|---|\n")
+        for r in csv.DictReader(open(te[0])):
+            s_ = short(r["Name"])
+            if s_ and "ert_" in s_:
+                f.write(f"| {s_} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} |\n")
+        if E.get("FETCH_SIZE") is not None:
+            ef, ew = E["FETCH_SIZE"] * 1024, E.get("WRITE_SIZE", 0) * 1024
+            f.write(f"\nWalk kernel (`ert_profile_kernel`) per launch: FETCH_SIZE {ef/1e9:.2f} GB, WRITE_SIZE {ew/1e9:.2f} GB -> HBM traffic = 2 x "
+                    f"{ef/1e9:.2f} + {ew/1e9:.2f} = **{(2*ef+ew)/1e9:.1f} GB**; SQ: ACTIVE_INST_ANY / WAVE_CYCLES = "
+                    f"{E.get('SQ_ACTIVE_INST_ANY',0)/max(E.get('SQ_WAVE_CYCLES',1),1):.3f}, WAIT_ANY / WAVE_CYCLES = {E.get('SQ_WAIT_ANY',0)/max(E.get('SQ_WAVE_CYCLES',1),1):.3f}, "
+                    f"{E.get('SQ_INSTS_VALU',0)/1e9:.2f} G VALU + {E.get('SQ_INSTS_SALU',0)/1e9:.2f} G SALU + {E.get('SQ_INSTS_VMEM_RD',0)/1e9:.3f} G VMEM-read wave-instructions.\n")
     f.write(f"\n`roofline.launch_ms` measured live by `bench.py` with HIP events in the run below: {bench['roofline']['launch_ms']} ms "
             "(the rocprofv3 average above covers warm-up + timed launches of the profiled run).\n\n")
     f.write("## PMC per launch (uncorrected counter values; average over the launches of one run)\n\n"
@@ -157,6 +192,8 @@ json.dump({"genome_mbp": bench["config"]["genome_mbp"], "reads": bench["config"]
            "smem_round1_l2_hit_miss": [int(r1.get("TCC_HIT_sum", 0)), int(r1.get("TCC_MISS_sum", 0))],
            "bsw_valu_insts": int(sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3),
            "bsw_salu_insts": int(sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3),
+           "ert_walk_hbm_bytes_per_launch": int(2 * E["FETCH_SIZE"] * 1024 + E.get("WRITE_SIZE", 0) * 1024) if "FETCH_SIZE" in E else None,
+           "ert_walk_valu_salu_vmem_insts": [int(E.get("SQ_INSTS_VALU", 0)), int(E.get("SQ_INSTS_SALU", 0)), int(E.get("SQ_INSTS_VMEM_RD", 0))] if E else None,
            "commit": os.popen("git rev-parse --short HEAD").read().strip(),
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_* (separate passes), profiles/run_profiles_r02.sh; bsw_* = wave-instructions per step"},
           open(f"profiles/{rnd}_pmc_summary.json", "w"), indent=1)

@@ -28,7 +28,7 @@ SYMBOLS = [
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
-    "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save",
+    "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
     "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
@@ -249,6 +249,7 @@ def lib():
         L.bwams_ert_info.argtypes = [vp, vp, vp, vp, vp, vp]
         L.bwams_ert_fetch.argtypes = [vp, vp, vp]
         L.bwams_ert_save.argtypes = [vp, C.c_char_p]
+        L.bwams_debug_sort.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
         L.bwams_batch_stats.argtypes = [vp, vp]
         L.bwams_batch_sync.argtypes = [vp]
         _lib = L
@@ -358,6 +359,13 @@ class Index:
     def set_contigs(self, contigs):
         c = np.ascontiguousarray(contigs, dtype=CONTIG_DTYPE)
         _chk(lib().bwams_index_set_contigs(self.h, _p(c), len(c)), "bwams_index_set_contigs")
+
+    def debug_sort(self, k, s, q, which: int, mode: int = 0):
+        """order of the wave tier's region sort (test hook)"""
+        k = np.ascontiguousarray(k, np.int64); s = np.ascontiguousarray(s, np.int32); q = np.ascontiguousarray(q, np.int32)
+        out = np.zeros(len(k), np.int32)
+        _chk(lib().bwams_debug_sort(self.h, _p(k), _p(s), _p(q), len(k), which, mode, _p(out)), "bwams_debug_sort")
+        return out
 
     @property
     def nbytes(self) -> int:

@@ -1291,6 +1291,20 @@ int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pa
     return BWAMS_OK;
 }
 
+/* Test hook: the region sorts of the de-duplication's wave tier on caller-given keys (order_out[i] = index of the i-th
+ * record after the sort).  which: 0 = mem_ars2 (key k), 1 = mem_ars (s descending, k, q).  mode: 0 = as the kernels run
+ * it, 1 = the operation-exact wave-parallel introsort even without ties, 2 = the sequential introsort on lane 0. */
+int bwams_debug_sort(bwams_index_t *ix, const int64_t *k, const int32_t *s, const int32_t *q, int32_t n, int32_t which,
+                     int32_t mode, int32_t *order_out) {
+    if (!ix || n < 0 || (n && (!k || !s || !q || !order_out))) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(ix->device));
+    if (launch_sort_test(k, s, q, n, which, mode, order_out)) {
+        set_last_error("bwams_debug_sort: n must be at most 1024");
+        return BWAMS_ERR_ARG;
+    }
+    return BWAMS_OK;
+}
+
 }  // extern "C"
 
 namespace bwams {

@@ -140,6 +140,8 @@ int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream
 void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n_pairs, int64_t l_pac, const bwams_mem_opt_t &opt,
                    unsigned long long *keys, hipStream_t st);
 void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
+// test hook (bwams_debug_sort): the wave tier's sort of n <= 1024 records on the current device
+int launch_sort_test(const int64_t *k, const int32_t *s, const int32_t *q, int n, int by_score, int mode, int32_t *order);
 
 // ---- regions of the reads the exact-match filter resolved (emf_regs.hip) ----
 struct EmfRegArgs {

@@ -412,7 +412,41 @@ __global__ void pestat_kernel(const bwams_alnreg_t *__restrict__ regs, const int
     keys[i] = key;
 }
 
+// test hook: one wavefront sorts n records held in LDS, as the wave tier does (mode 0: rank sort with the exact fallback on
+// ties, 1: the operation-exact wave introsort always, 2: lane 0 alone through sort_records)
+__global__ __launch_bounds__(64) void sort_test_kernel(const SortRec *__restrict__ in, int n, int by_score, int mode, int32_t *__restrict__ order) {
+    __shared__ SortRec l_a[kLdsN], l_t[kLdsN];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64) l_a[i] = in[i];
+    __syncthreads();
+    if (mode == 2) {
+        if (lane == 0) sort_records(l_a, n, by_score);
+        __syncthreads();
+    } else {
+        wave_sort_records(l_a, l_t, n, by_score, lane, mode == 1);
+    }
+    for (int i = lane; i < n; i += 64) order[i] = l_a[i].idx;
+}
+
 }  // namespace
+
+int launch_sort_test(const int64_t *k, const int32_t *s_, const int32_t *q, int n, int by_score, int mode, int32_t *order) {
+    if (n < 0 || n > kLdsN) return -1;
+    SortRec *h = (SortRec *)malloc(sizeof(SortRec) * (size_t)(n + 1));
+    for (int i = 0; i < n; ++i) { h[i].k = k[i]; h[i].s = s_[i]; h[i].q = q[i]; h[i].idx = i; h[i].pad_ = 0; }
+    SortRec *d_in = nullptr;
+    int32_t *d_ord = nullptr;
+    int rc = -1;
+    if (hipMalloc(&d_in, sizeof(SortRec) * (size_t)(n + 1)) == hipSuccess && hipMalloc(&d_ord, 4 * (size_t)(n + 1)) == hipSuccess &&
+        hipMemcpy(d_in, h, sizeof(SortRec) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess) {
+        sort_test_kernel<<<1, 64>>>(d_in, n, by_score, mode, d_ord);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(order, d_ord, 4 * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_ord) (void)hipFree(d_ord);
+    free(h);
+    return rc;
+}
 
 void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n_pairs, int64_t l_pac, const bwams_mem_opt_t &opt,
                    unsigned long long *keys, hipStream_t st) {

@@ -100,10 +100,18 @@ __device__ __noinline__ void sort_records(SortRec *a, int n, int by_score) {
     }
 }
 
+// the depth-limit fallback of the wave-parallel form below (sequential, generic pointer like sort_records)
+__device__ __noinline__ void comb_records(SortRec *a, int n, int by_score) {
+    if (by_score) r_combsort(a, n, LtScore()); else r_combsort(a, n, LtEnd());
+}
+
 // The same sorts for a one-wavefront block with the records in LDS: every lane counts the records that sort before
 // its own (a rank sort: O(n^2 / 64) LDS reads, no dependent chain), which is the unique sorted order — and hence
-// ksort.h's — whenever no two records compare equal.  A lane-wide ballot checks that; if some do, lane 0 runs the
-// operation-exact introsort on the untouched input instead.  All 64 lanes call this; a and tmp hold n records each.
+// ksort.h's — whenever no two records compare equal.  A lane-wide ballot checks that; if some do, the wave runs the
+// operation-exact introsort (wave_introsort) on the untouched input instead.  All 64 lanes call this; a and tmp hold n
+// records each.  (Round 1 sent lane 0 alone into the sequential introsort here while 63 lanes waited at the barrier:
+// the configuration in which an inlined LDS instantiation once hung, profiles/r01_notes.md 20.  No lane-0-only sort call
+// on LDS is left in the wave tiers.)
 template <class LT> __device__ __forceinline__ bool wave_rank_pass(const SortRec *a, SortRec *tmp, int n, int lane, LT lt) {
     bool tie = false;
     for (int ib = 0; ib < n; ib += 64) {
@@ -124,14 +132,124 @@ template <class LT> __device__ __forceinline__ bool wave_rank_pass(const SortRec
     }
     return tie;
 }
-__device__ __forceinline__ void wave_sort_records(SortRec *a, SortRec *tmp, int n, int by_score, int lane) {
+// ks_introsort operation by operation, but with the whole wavefront on every step (all 64 lanes call this; a in LDS,
+// tmp = n records of LDS scratch, stk = 120 ints of LDS).  The Hoare partition of a range [s, t] around the pivot rp
+// (moved to a[t]) is determined by two lists: the "up stoppers" (x in s+1..t, ascending, with !lt(a[x], rp)) and the
+// "down stoppers" (x in t-1..s+1, descending, with !lt(rp, a[x])); the scalar loop swaps the k-th up stopper with the
+// k-th down stopper while the former lies below the latter, m swaps in all, and the pivot lands on
+// min(up[m], down[m-1]).  The lists are built with ballots, the swaps are independent.  The closing insertion sort over
+// the whole array is a stable sort of what the partitions left: a rank sort (ksort's median of three never examines
+// a[s], so the element may lie far from its place: a windowed clean-up would be wrong).  The comb-sort fallback of the
+// depth limit stays sequential on lane 0, through the non-inlined generic-pointer routine.
+template <class LT> __device__ void wave_introsort(SortRec *a, int n, SortRec *tmp, int *stk, int lane, LT lt, int by_score) {
     if (n < 2) return;
-    const bool tie = by_score ? wave_rank_pass(a, tmp, n, lane, LtScore()) : wave_rank_pass(a, tmp, n, lane, LtEnd());
+    if (n == 2) {
+        if (lane == 0 && lt(a[1], a[0])) { const SortRec x = a[0]; a[0] = a[1]; a[1] = x; }
+        __syncthreads();
+        return;
+    }
+    uint16_t *ls = reinterpret_cast<uint16_t *>(tmp), *rs = ls + n;          // 4 n bytes of the 24 n
+    int d;
+    for (d = 2; (1ul << d) < (unsigned long)n; ++d);
+    int top = 0, s = 0, t = n - 1;
+    d <<= 1;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) {
+                if (lane == 0) comb_records(a + s, t - s + 1, by_score);
+                __syncthreads();
+                t = s;
+                continue;
+            }
+            int i = s, j = t, k = i + ((j - i) >> 1) + 1;
+            {
+                const SortRec ak = a[k], ai = a[i], aj = a[j];
+                if (lt(ak, ai)) { if (lt(ak, aj)) k = j; }
+                else k = lt(aj, ai) ? i : j;
+            }
+            const SortRec rp = a[k];
+            __syncthreads();
+            if (lane == 0 && k != t) { a[k] = a[t]; a[t] = rp; }
+            __syncthreads();
+            int NL = 0, NR = 0;
+            for (int x0 = s + 1; x0 <= t; x0 += 64) {
+                const int x = x0 + lane;
+                const bool f = x <= t && !lt(a[x], rp);
+                const unsigned long long m = __ballot(f);
+                if (f) ls[NL + __popcll(m & below)] = (uint16_t)x;
+                NL += __popcll(m);
+            }
+            for (int x0 = t - 1; x0 >= s + 1; x0 -= 64) {
+                const int x = x0 - lane;
+                const bool f = x >= s + 1 && !lt(rp, a[x]);
+                const unsigned long long m = __ballot(f);
+                if (f) rs[NR + __popcll(m & below)] = (uint16_t)x;
+                NR += __popcll(m);
+            }
+            __syncthreads();
+            const int np = NL < NR ? NL : NR;
+            int m_sw = 0;
+            for (int k0 = 0; k0 < np; k0 += 64) {
+                const int kk = k0 + lane;
+                m_sw += __popcll(__ballot(kk < np && ls[kk] < rs[kk]));
+            }
+            for (int k0 = 0; k0 < m_sw; k0 += 64) {
+                const int kk = k0 + lane;
+                if (kk < m_sw) { const int p = ls[kk], q = rs[kk]; const SortRec x = a[p]; a[p] = a[q]; a[q] = x; }
+            }
+            int i_f = ls[m_sw];                      // up[m] exists: t itself is an up stopper
+            if (m_sw >= 1 && (int)rs[m_sw - 1] < i_f) i_f = rs[m_sw - 1];
+            __syncthreads();
+            if (lane == 0) { const SortRec x = a[i_f]; a[i_f] = a[t]; a[t] = x; }
+            __syncthreads();
+            i = i_f;
+            if (i - s > t - i) {
+                if (i - s > 16) { stk[3 * top] = s; stk[3 * top + 1] = i - 1; stk[3 * top + 2] = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { stk[3 * top] = i + 1; stk[3 * top + 1] = t; stk[3 * top + 2] = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+            __syncthreads();                         // the stack entries were written by every lane (same values)
+        } else {
+            if (top == 0) break;
+            --top; s = stk[3 * top]; t = stk[3 * top + 1]; d = stk[3 * top + 2];
+        }
+    }
+    __syncthreads();
+    for (int x0 = 0; x0 < n; x0 += 64) {
+        const int x = x0 + lane;
+        if (x < n) {
+            const SortRec v = a[x];
+            int pos = 0;
+            for (int y = 0; y < n; ++y) {
+                const SortRec w = a[y];
+                pos += (lt(w, v) || (!lt(v, w) && y < x)) ? 1 : 0;
+            }
+            tmp[pos] = v;                            // the stopper lists are dead by now
+        }
+    }
+    __syncthreads();
+    for (int x = lane; x < n; x += 64) a[x] = tmp[x];
+    __syncthreads();
+}
+
+// force_exact: take the operation-exact path even when no two keys are equal (tests)
+__device__ __forceinline__ void wave_sort_records(SortRec *a, SortRec *tmp, int n, int by_score, int lane, bool force_exact = false) {
+    __shared__ int l_sort_stk[120];
+    if (n < 2) return;
+    bool tie = true;
+    if (!force_exact) tie = by_score ? wave_rank_pass(a, tmp, n, lane, LtScore()) : wave_rank_pass(a, tmp, n, lane, LtEnd());
     __syncthreads();
     if (!tie) {
         for (int i = lane; i < n; i += 64) a[i] = tmp[i];
-    } else if (lane == 0) sort_records(a, n, by_score);
-    __syncthreads();
+        __syncthreads();
+    } else if (by_score) {
+        wave_introsort(a, n, tmp, l_sort_stk, lane, LtScore(), 1);
+    } else {
+        wave_introsort(a, n, tmp, l_sort_stk, lane, LtEnd(), 0);
+    }
 }
 
 }  // namespace

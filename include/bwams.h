@@ -225,6 +225,14 @@ int bwams_ksw_align(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n,
                     const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer, int64_t qer_bytes,
                     const bwams_sw_opt_t *opt, bwams_kswr_t *out);
 
+/* Test hook (not part of the drop-in surface): the region sorts of mem_sort_dedup_patch as the wave tier of the
+ * de-duplication kernel runs them, on caller-given keys of n <= 1024 records; order_out[i] = index of the i-th record
+ * after the sort.  which: 0 = mem_ars2 (key k = re), 1 = mem_ars (s = score descending, k = rb, q = qb).  mode: 0 = as
+ * the kernels choose (rank sort, operation-exact introsort when keys tie), 1 = the wave-parallel operation-exact
+ * introsort always, 2 = ksort.h's sequential introsort on one lane. */
+int bwams_debug_sort(bwams_index_t *idx, const int64_t *k, const int32_t *s, const int32_t *q, int32_t n, int32_t which,
+                     int32_t mode, int32_t *order_out);
+
 /* ------------------------------------------------------------- counters ---- */
 
 /* Event counts of the last seed run on this batch (the same events the oracle

@@ -752,12 +752,12 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     // strips for the global alignment: as many lanes as 1 GiB of (h, e) rows allows, at most 64 Ki
     int64_t n_lanes = ((int64_t)1 << 30) / ((L + 2) * 8);
     n_lanes = n_lanes > 65536 ? 65536 : n_lanes < 64 ? 64 : n_lanes;
-    const int64_t n_waves = (int64_t)b->cu_count * 4;
+    const int64_t n_waves = (int64_t)b->cu_count * 4, n_waves_small = (int64_t)b->cu_count * 16;
     BWAMS_HIP(s->dd_regs.ensure((size_t)(N + 1) * sizeof(bwams_alnreg_t)));
     BWAMS_HIP(s->dd_out.ensure((size_t)(N + 1) * sizeof(bwams_alnreg_t)));
     BWAMS_HIP(s->dd_ord.ensure((size_t)(N + 1) * 4));
     BWAMS_HIP(s->dd_srt.ensure(dedup_sortrec_bytes(N)));
-    BWAMS_HIP(s->dd_eh.ensure((size_t)(n_lanes + n_waves) * (size_t)(L + 2) * 8));
+    BWAMS_HIP(s->dd_eh.ensure((size_t)(n_lanes + 2 * n_waves + n_waves_small) * (size_t)(L + 2) * 8));
     BWAMS_HIP(s->dd_nout.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->dd_wide.ensure((size_t)n1 * 16));
     BWAMS_HIP(s->dd_off.ensure((size_t)n1 * 8));
@@ -774,12 +774,14 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     BWAMS_HIP(s->dd_light.ensure((size_t)n1 * 4));
     D.heavy = s->heavy.as<int32_t>(); D.light = s->dd_light.as<int32_t>();
     D.n_heavy_ctr = &b->d_ctr->dedup_heavy; D.ticket = &b->d_ctr->dedup_ticket; D.n_light_ctr = &b->d_ctr->dedup_light;
+    D.ticket2 = &b->d_ctr->dedup_ticket2; D.ticket3 = &b->d_ctr->dedup_ticket3;
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->dedup_heavy, 0, 3 * sizeof(unsigned long long), st));
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->dedup_ticket2, 0, 2 * sizeof(unsigned long long), st));
     BWAMS_HIP(hipEventRecord(s->ev[12], st));
     // work on a copy: bwams_extend_fetch stays valid
     if (N) BWAMS_HIP(hipMemcpyAsync(D.regs, s->regs.p, (size_t)N * sizeof(bwams_alnreg_t), hipMemcpyDeviceToDevice, st));
     BWAMS_HIP(hipMemsetAsync(D.n_out, 0, (size_t)n1 * 4, st));
-    if (launch_dedup(D, n_lanes, n_waves, st, s->aux[0], s->fork, s->join[0])) {
+    if (launch_dedup(D, n_lanes, n_waves, n_waves_small, st, s->aux[0], s->aux[1], s->aux[2], s->fork, s->join[0], s->join[1], s->join[2])) {
         set_last_error("bwams_dedup_run: stream fork/join failed");
         return BWAMS_ERR_DEVICE;
     }

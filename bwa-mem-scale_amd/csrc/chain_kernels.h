@@ -133,10 +133,11 @@ struct DedupArgs {
     int32_t *heavy, *light;        // reads with many / few regions that need the full procedure (listed by the triage kernel)
     unsigned long long *n_heavy_ctr, *n_light_ctr, *ticket;
     int32_t force_seq;             // debug: lane 0 runs the one-lane form for every read
+    unsigned long long *ticket2, *ticket3;   // work cursors of the wave tier's smaller instances
 };
 size_t dedup_sortrec_bytes(int64_t n);
-int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st, hipStream_t aux, hipEvent_t fork,
-                 hipEvent_t join);
+int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, int64_t n_waves_small, hipStream_t st, hipStream_t aux,
+                 hipStream_t aux2, hipStream_t aux3, hipEvent_t fork, hipEvent_t join, hipEvent_t join2, hipEvent_t join3);
 void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n_pairs, int64_t l_pac, const bwams_mem_opt_t &opt,
                    unsigned long long *keys, hipStream_t st);
 void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);

@@ -17,7 +17,8 @@ namespace bwams {
 namespace {
 
 constexpr int kLightN = 32;          // regions per read handled by a single lane
-constexpr int kLdsN = 1024;          // sort records a wavefront keeps in LDS
+constexpr int kSmallN = 128, kMidN = 512;      // regions per read of the wave tier's smaller instances
+constexpr int kLdsN = 2048;          // sort records a wavefront keeps in LDS (largest instance of the wave tier)
 constexpr int MINUS_INF = -0x40000000;
 
 // ksw_global2 without backtrack; query[j] = qseq[qs * j], target[i] = tseq[ts * i] (ts = qs = -1 on the reverse strand,
@@ -106,7 +107,7 @@ __device__ int patch_reg(const DedupArgs &A, const uint8_t *query, const bwams_a
             ww = ww < w ? ww : w;
             const int min_w = dl + 3;
             ww = ww > min_w ? ww : min_w;
-            score = global_score(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh);
+            score = A.force_seq == 2 ? 0 : global_score(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh);   // 2: timing experiment only
         }
     }
     const int q_s = (int)((double)(b.qe - a.qb) / (double)((b.qe - b.qb) + (a.qe - a.qb)) * (double)(b.score + a.score) + .499);
@@ -253,24 +254,31 @@ __device__ __forceinline__ int wave_compact_alive(const bwams_alnreg_t *a, int32
     return n;
 }
 
-__global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_waves) {
-    __shared__ SortRec l_srt[kLdsN], l_srt2[kLdsN];
-    __shared__ int64_t l_rb[kLdsN];
-    __shared__ int32_t l_ord[kLdsN];
+// Three instances share the list of heavy reads, each with its own ticket counter and LDS budget (60 B per region):
+// LO < regions <= CAP for (32, 128] (7.7 KB per wave, ~20 waves per CU), (128, 512] (30 KB, five per CU) and
+// (512, 2048] (120 KB, one per CU; 355 reads per million on the bench workload).  One 1024-region instance left two waves
+// per CU for every heavy read, and the four reads beyond it sorted 1100 records through HBM on a single lane: 14.9 ms.
+template <int CAP, int LO>
+__global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_waves, int64_t eh_base, unsigned long long *ticket) {
+    extern __shared__ __align__(16) unsigned char lds_dd[];
+    SortRec *l_srt = reinterpret_cast<SortRec *>(lds_dd), *l_srt2 = l_srt + CAP;
+    int64_t *l_rb = reinterpret_cast<int64_t *>(l_srt2 + CAP);
+    int32_t *l_ord = reinterpret_cast<int32_t *>(l_rb + CAP);
     const int lane = threadIdx.x;
-    int2 *eh = A.eh + (A.eh_lanes + blockIdx.x) * (int64_t)(A.max_read_len + 2);
+    int2 *eh = A.eh + (eh_base + blockIdx.x) * (int64_t)(A.max_read_len + 2);
     const int64_t n_heavy = (int64_t)*A.n_heavy_ctr;
     for (;;) {
-        const int64_t t = (int64_t)wave_ticket(A.ticket, 1ull);
+        const int64_t t = (int64_t)wave_ticket(ticket, 1ull);
         if (t >= n_heavy) break;
         const int64_t r = A.heavy[t];
         const int64_t reg0 = A.seed_off[r];
         const int av_n = (int)(A.seed_off[r + 1] - reg0);
+        if (av_n <= LO || (av_n > CAP && CAP != kLdsN)) continue;       // another instance's read (the largest takes what is beyond, too)
         bwams_alnreg_t *a = A.regs + reg0;
         int32_t *ord = A.ord + reg0;
         const uint8_t *query = A.enc + A.cum[r];
         __syncthreads();
-        if (av_n > kLdsN || A.force_seq) {                              // beyond the LDS budget: the one-lane form
+        if (av_n > kLdsN || A.force_seq == 1) {                              // beyond the LDS budget: the one-lane form
             if (lane == 0) A.n_out[r] = dedup_read(A, r, reinterpret_cast<SortRec *>(A.srt) + reg0, eh);
             continue;
         }
@@ -412,10 +420,11 @@ __global__ void pestat_kernel(const bwams_alnreg_t *__restrict__ regs, const int
     keys[i] = key;
 }
 
+constexpr int kTestN = 1024;
 // test hook: one wavefront sorts n records held in LDS, as the wave tier does (mode 0: rank sort with the exact fallback on
 // ties, 1: the operation-exact wave introsort always, 2: lane 0 alone through sort_records)
 __global__ __launch_bounds__(64) void sort_test_kernel(const SortRec *__restrict__ in, int n, int by_score, int mode, int32_t *__restrict__ order) {
-    __shared__ SortRec l_a[kLdsN], l_t[kLdsN];
+    __shared__ SortRec l_a[kTestN], l_t[kTestN];
     const int lane = threadIdx.x;
     for (int i = lane; i < n; i += 64) l_a[i] = in[i];
     __syncthreads();
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(64) void sort_test_kernel(const SortRec *__restrict
 }  // namespace
 
 int launch_sort_test(const int64_t *k, const int32_t *s_, const int32_t *q, int n, int by_score, int mode, int32_t *order) {
-    if (n < 0 || n > kLdsN) return -1;
+    if (n < 0 || n > kTestN) return -1;
     SortRec *h = (SortRec *)malloc(sizeof(SortRec) * (size_t)(n + 1));
     for (int i = 0; i < n; ++i) { h[i].k = k[i]; h[i].s = s_[i]; h[i].q = q[i]; h[i].idx = i; h[i].pad_ = 0; }
     SortRec *d_in = nullptr;
@@ -457,14 +466,26 @@ void launch_pestat(const bwams_alnreg_t *regs, const int64_t *reg_off, int64_t n
 size_t dedup_sortrec_bytes(int64_t n) { return (size_t)(n + 1) * sizeof(SortRec); }
 
 // triage, then the lane tier and the wave tier side by side (they work on disjoint reads)
-int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, hipStream_t st, hipStream_t aux, hipEvent_t fork,
-                 hipEvent_t join) {
+int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, int64_t n_waves_small, hipStream_t st, hipStream_t aux,
+                 hipStream_t aux2, hipStream_t aux3, hipEvent_t fork, hipEvent_t join, hipEvent_t join2, hipEvent_t join3) {
     if (A.nseq <= 0) return 0;
     dedup_triage_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A);
     if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(aux, fork, 0) != hipSuccess) return -1;
-    dedup_wave_kernel<<<(unsigned)n_waves, 64, 0, st>>>(A, n_waves);
+    // the reads with the most regions first (one wave per CU), the bulk beside them on the auxiliary streams
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dedup_wave_kernel<kLdsN, kMidN>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * kLdsN);
+        attr = true;
+    }
+    dedup_wave_kernel<kLdsN, kMidN><<<(unsigned)n_waves, 64, 60 * kLdsN, st>>>(A, n_waves, A.eh_lanes, A.ticket);
     dedup_kernel<<<(unsigned)((n_lanes + 63) / 64), 64, 0, aux>>>(A, n_lanes);
     if (hipEventRecord(join, aux) != hipSuccess || hipStreamWaitEvent(st, join, 0) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(aux3, fork, 0) != hipSuccess) return -1;
+    dedup_wave_kernel<kMidN, kSmallN><<<(unsigned)n_waves, 64, 60 * kMidN, aux3>>>(A, n_waves, A.eh_lanes + n_waves, A.ticket3);
+    if (hipEventRecord(join3, aux3) != hipSuccess || hipStreamWaitEvent(st, join3, 0) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(aux2, fork, 0) != hipSuccess) return -1;
+    dedup_wave_kernel<kSmallN, kLightN><<<(unsigned)n_waves_small, 64, 60 * kSmallN, aux2>>>(A, n_waves_small, A.eh_lanes + 2 * n_waves, A.ticket2);
+    if (hipEventRecord(join2, aux2) != hipSuccess || hipStreamWaitEvent(st, join2, 0) != hipSuccess) return -1;
     return 0;
 }
 void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st) {

@@ -214,6 +214,9 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
 
+    # the library forks its size classes onto auxiliary streams; HIP's default of four hardware queues makes some of them
+    # share a queue and run one after the other (chaining 44 -> 40 ms with eight)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 

@@ -66,6 +66,9 @@ static_assert(sizeof(ChainRec) == 48, "chain record layout");
 __host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * (sizeof(ChainRec) + 12) + 64; }
 constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL1 = 850, kClassL = 1700;      // seeds per read: 7.7, 15, 31, 51, 102 KB of LDS
 static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
+// class XL: reads beyond class L keep only the ordered array (12 B per chain) in LDS, the chain records in HBM
+constexpr int kClassXL = 8192;
+__host__ __device__ constexpr size_t lds_bytes_xl(int K) { return (size_t)K * 12 + 64; }
 
 // bns_pos2rid / bns_intv2rid (bntseq.cpp:397-421) with a one-entry cache of the last sequence found
 struct RidCache { int64_t lo, hi; int rid; };
@@ -537,6 +540,7 @@ __global__ void chain_count_kernel(ChainArgs A, uint32_t *keys, uint32_t *vals) 
         if (cnt > kClassM) atomicAdd(&A.ctr->chain_class[2], 1ull);
         if (cnt > kClassL1) atomicAdd(&A.ctr->chain_class[1], 1ull);
         if (cnt > kClassL) atomicAdd(&A.ctr->chain_class[0], 1ull);
+        if (cnt > kClassXL) atomicAdd(&A.ctr->chain_class[6], 1ull);      // [0, c[6]) beyond XL, [c[6], c[0]) XL
     }
 }
 
@@ -578,7 +582,7 @@ __device__ __forceinline__ void sarr_insert(int64_t *key, int32_t *cid, int n, i
 }
 
 // CONT = 0: kbtree (exact for any input); CONT = 1: sorted array, returns false when the read needs the B-tree
-template <bool LDS, int CONT = 0>
+template <bool LDS, int CONT = 0, bool CREC_HBM = false>
 __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int lane, int nl, Node *nodes, int32_t cap_nodes,
                                            ChainRec *crec_w, int32_t cap_chains) {
     const bool wr = lane == 0;
@@ -615,7 +619,7 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
     ChainRec *crec;
     ReadCtx c;
     if constexpr (LDS) {
-        crec = crec_w;
+        crec = CREC_HBM ? crec_g : crec_w;
         c.nodes = nodes; c.cap_nodes = cap_nodes;
     } else {
         crec = crec_g;
@@ -733,7 +737,7 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
         ++n_chn;
     }
     if (n_chn == 0) n_chn = 1;                  // the reference keeps a_[0] in that case (bwamem.cpp:549-572)
-    if constexpr (LDS)                          // chain records out of LDS, for the filter and the emit stages
+    if constexpr (LDS && !CREC_HBM)             // chain records out of LDS, for the filter and the emit stages
         for (int32_t k = lane; k < c.n_keys; k += nl) crec_g[k] = crec_w[k];
     if (!wr) return true;
     A.n_chn[r] = n_chn;
@@ -772,12 +776,15 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(ChainArgs A, const unsig
     const int lane = threadIdx.x;
     const int64_t lo = lo_p ? (int64_t)*lo_p : 0, hi = (int64_t)*hi_p;
     ChainRec *l_crec = reinterpret_cast<ChainRec *>(l_mem);
-    Node *l_nodes = reinterpret_cast<Node *>(l_mem + (size_t)K * sizeof(ChainRec));
+    Node *l_nodes = reinterpret_cast<Node *>(l_mem + (size_t)(K > 0 ? K : 0) * sizeof(ChainRec));
     for (;;) {
         const unsigned long long t = wave_ticket(ticket, 1ull);
         if (lo + (int64_t)t >= hi) break;
         const int64_t r = (int64_t)A.order[lo + (int64_t)t];
-        if (K) {
+        if (K < 0) {                 // class XL: ordered array of -K chains in LDS, chain records in HBM
+            if (!chain_read<true, 1, true>(A, r, lane, 64, reinterpret_cast<Node *>(l_mem), 0, nullptr, -K) && lane == 0)
+                A.redo[atomicAdd(&A.ctr->chain_redo, 1ull)] = (int32_t)r;
+        } else if (K) {
             if (!chain_read<true, 1>(A, r, lane, 64, l_nodes, 0, l_crec, K) && lane == 0)
                 A.redo[atomicAdd(&A.ctr->chain_redo, 1ull)] = (int32_t)r;
         } else chain_read<false>(A, r, lane, 64, nullptr, 0, nullptr, 0);
@@ -1032,7 +1039,10 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     // heaviest first: reads beyond the LDS budget (HBM state) and classes L, L1, then M, M1, S, then the lane tier
     // (the reads beyond a CU's LDS keep their state in HBM: every step is a dependent L2 / HBM access, so they get many
     // waves — no LDS limits them; at GRCh38 size, with max_occ hits per repeat SMEM, they were the stage's long pole on two)
-    chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, 0, aux[0]>>>(A, nullptr, cls + 0, tk + 0, 0);
+    // (class XL, round 2: the five reads per million beyond class L — 2915 seeds the longest — took 19.5 ms in the HBM tier and
+    // were the stage's long pole; with the ordered array in LDS only their chain records are in HBM)
+    chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, 0, aux[0]>>>(A, nullptr, cls + 6, tk + 0, 0);
+    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes_xl(kClassXL), aux[0]>>>(A, cls + 6, cls + 0, tk + 6, -kClassXL);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[1]>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
     chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassL1), aux[2]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
     chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);

@@ -67,7 +67,7 @@ __host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * (size
 constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL1 = 850, kClassL = 1700;      // seeds per read: 7.7, 15, 31, 51, 102 KB of LDS
 static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
 // class XL: reads beyond class L keep only the ordered array (12 B per chain) in LDS, the chain records in HBM
-constexpr int kClassXL = 8192;
+constexpr int kClassXL = 4096;       // sarr_lower finds the 64-key chunk with one ballot: at most 64 chunks
 __host__ __device__ constexpr size_t lds_bytes_xl(int K) { return (size_t)K * 12 + 64; }
 
 // bns_pos2rid / bns_intv2rid (bntseq.cpp:397-421) with a one-entry cache of the last sequence found

@@ -562,8 +562,8 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
     int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t maxb = (int64_t)cu_count * 8;
     if (blocks > maxb) blocks = maxb;
-    hipStream_t q[4] = {st, st, st, st};
-    const int n_aux = aux ? 3 : 0;
+    hipStream_t q[5] = {st, st, st, st, st};
+    const int n_aux = aux ? 4 : 0;
     if (n_aux) {
         if (hipEventRecord(fork, st) != hipSuccess) return -1;
         for (int c = 0; c < n_aux; ++c) {
@@ -573,8 +573,23 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
     }
     const unsigned B = (unsigned)blocks, T = kWavesPerBlock * 64;
     unsigned long long *cnt = ctr->bsw_cls_cnt, *hd = ctr->bsw_cls_head;
+    static bool qwin_attr = false;
+    if (!qwin_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_qwin_kernel<kBswLpt, kBswWin>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4));
+        qwin_attr = true;
+    }
+    // every class on a stream of its own, the classes of the longest queries first.  (With two classes per stream and the
+    // one-task-per-wave kernel — usually without a single task, but 2048 blocks that wait for a free CU slot — in front of one
+    // of them, the kernel trace showed two class launches starting 14 ms late.)
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4, q[4]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 4, q[3]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 96 * 4, q[2]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 64 * 4, q[1]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 32 * 4, q[0]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
     {
-        // what neither packed form can take: (h, e) row + query of one task per wave in LDS, fewer waves per block for very long queries
+        // what neither packed form can take: (h, e) row + query of one task per wave in LDS, fewer waves per block for very long queries.
+        // Last on the main stream, persistent waves on a small grid: the class is usually empty.
         const size_t per_wave = (((size_t)(qmax + 1) * 8 + (size_t)qmax + 64 + 15) / 16) * 16;
         int waves = (int)((size_t)160 * 1024 / per_wave);
         if (waves < 1) return -2;                  // a query of more than ~18 k bases does not fit a CU's LDS
@@ -584,20 +599,10 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int64_t lblocks = (n + waves - 1) / waves;
-        if (lblocks > maxb) lblocks = maxb;
-        bsw_kernel<<<(unsigned)lblocks, waves * 64, lds, q[3]>>>(pairs, n, ref, qer, w, prm, qmax, -1, ctr, &ctr->bsw_head[3], list + 5 * n, cnt + 5);
+        const int64_t lcap = qmax > 16 * kQuadCpl[4] - 1 ? maxb : (int64_t)cu_count * 2;     // long queries: this IS the main class
+        if (lblocks > lcap) lblocks = lcap;
+        bsw_kernel<<<(unsigned)lblocks, waves * 64, lds, q[0]>>>(pairs, n, ref, qer, w, prm, qmax, -1, ctr, &ctr->bsw_head[3], list + 5 * n, cnt + 5);
     }
-    static bool qwin_attr = false;
-    if (!qwin_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_qwin_kernel<kBswLpt, kBswWin>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4));
-        qwin_attr = true;
-    }
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4, q[2]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 4, q[1]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 96 * 4, q[0]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 64 * 4, q[2]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 32 * 4, q[1]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
     if (n_aux)
         for (int c = 0; c < n_aux; ++c) {
             if (hipEventRecord(join[c], q[c + 1]) != hipSuccess) return -1;

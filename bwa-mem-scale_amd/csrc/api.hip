@@ -1019,7 +1019,7 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
                        (unsigned long long *)(b->d_ert_stk + (size_t)ert_walk_threads(b->cu_count) * (size_t)b->ert_stk_frames), b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[9], st));
     BWAMS_HIP(hipEventRecord(b->ev[10], st));
-    launch_ert_select(b->d_ert_prof, b->d_cum, skip, b->nseq, b->nbases, M, *opt, b->d_pool, b->pool_cap, b->d_ctr, st);
+    launch_ert_select(b->d_ert_prof, b->d_cum, skip, b->nseq, b->nbases, M, *opt, b->d_pool, b->pool_cap, b->d_ctr, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[11], st));
     BWAMS_HIP(hipEventRecord(b->ev[3], st));
     BWAMS_HIP(hipGetLastError());

@@ -42,7 +42,8 @@ void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum,
                         hipStream_t st);
 size_t ert_count_bytes();      // `part`: zeroed once; the launch leaves it zeroed
 void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *skip, int64_t nseq, int64_t nbases, int M,
-                       const bwams_seed_opt_t &opt, bwams_smem_t *pool, int64_t pool_cap, DevCounters *ctr, hipStream_t st);
+                       const bwams_seed_opt_t &opt, bwams_smem_t *pool, int64_t pool_cap, DevCounters *ctr, int cu_count,
+                       hipStream_t st);
 // the leaf walks keep their stack in `stk`: ert_walk_threads(cu_count) lanes x max_frames words, frame-major
 int64_t ert_walk_threads(int cu_count);
 void launch_ert_locate(const DevErt &e, const uint8_t *enc, const int64_t *cum, bwams_smem_t *sorted, int64_t n,

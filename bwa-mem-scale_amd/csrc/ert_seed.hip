@@ -32,7 +32,6 @@ enum { E_INVALID = 0, E_SINGLE = 1, E_INFREQUENT = 2, E_FREQUENT = 3 };  // macr
 constexpr int kMany = 255;           // 20 hits or more: the trees do not say how many
 constexpr int kCntSlots = 4096;      // partial event counters of the walk kernel
 constexpr int kCoopRounds = 6;       // diagonals a wave expands cooperatively before the lanes go on alone
-constexpr int kStage = 24;           // seeds of one read staged in LDS before the wave appends them together
 
 // n <= 8 bytes at any address, little endian: one unaligned 8-byte load (gfx950 global loads need no alignment; the
 // tables, the reads and the text are padded so that the 8 bytes exist)
@@ -354,71 +353,116 @@ struct SelectArgs {
     DevCounters *ctr;
 };
 
-// lane = one read: the three rounds over the profiles; seeds are staged per lane and appended once per wave
-__global__ __launch_bounds__(256) void ert_select_kernel(SelectArgs A) {
-    __shared__ uint32_t stage[kStage * 256];
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int tid = threadIdx.x;
-    int n_st = 0;
-    int64_t c0 = 0;
-    const bool live = r < A.nseq && !(A.skip && A.skip[r]);
-    auto emit = [&](int st, int ln, int cnt) {
-        const uint32_t rec = (uint32_t)st | ((uint32_t)ln << 8) | ((uint32_t)cnt << 16);
-        if (n_st < kStage) {
-            stage[n_st * 256 + tid] = rec;
-            n_st++;
-        } else {                                           // more seeds than the stage holds: append one by one
-            const unsigned long long slot = atomicAdd(&A.ctr->n_smem_total, 1ull);
-            if ((int64_t)slot < A.pool_cap) {
-                bwams_smem_t o;
-                o.rid = (uint32_t)r; o.m = (uint32_t)st; o.n = (uint32_t)(st + ln - 1); o.pad_ = 0;
-                o.k = 0; o.l = 0; o.s = cnt == kMany ? -1 : cnt;
-                A.pool[slot] = o;
-            }
+// wave = one read at a time, lane = read position (64 positions per chunk, up to four chunks): the profile bytes of a
+// read are consecutive in each plane, so every load of the wave is one or two lines (a lane per read made every load 64
+// lines: 5.2 ms per million reads).  Seeds are staged in LDS per wave and appended to the pool in batches.
+constexpr int kSelStage = 320;        // staged seeds per wave (flushed when fewer than 64 + kSelSlack slots are free)
+constexpr int kSelSlack = 64;
+
+struct SelWave {
+    uint2 *st;                        // {rid, start | len << 8 | hits << 16}
+    int n;
+};
+
+__device__ __forceinline__ void sel_flush(const SelectArgs &A, SelWave &W, int lane) {
+    if (W.n == 0) return;
+    const unsigned long long base = wave_ticket(&A.ctr->n_smem_total, (unsigned long long)W.n);
+    for (int j = lane; j < W.n; j += 64) {
+        const uint2 rec = W.st[j];
+        const int64_t at = (int64_t)base + j;
+        if (at < A.pool_cap) {
+            bwams_smem_t o;
+            const int stt = rec.y & 0xff, ln = (rec.y >> 8) & 0xff, cnt = (rec.y >> 16) & 0xff;
+            o.rid = rec.x; o.m = (uint32_t)stt; o.n = (uint32_t)(stt + ln - 1); o.pad_ = 0;
+            o.k = 0; o.l = 0; o.s = cnt == kMany ? -1 : cnt;
+            A.pool[at] = o;
         }
-    };
-    if (live) {
-        c0 = A.cum[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    W.n = 0;
+}
+// lanes with `want` append one seed each
+__device__ __forceinline__ void sel_emit(const SelectArgs &A, SelWave &W, int lane, bool want, uint32_t rid, int stt, int ln, int cnt) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    if (W.n + __popcll(m) > kSelStage) sel_flush(A, W, lane);
+    if (want) W.st[W.n + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(rid, (uint32_t)stt | ((uint32_t)ln << 8) | ((uint32_t)cnt << 16));
+    W.n += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void ert_select_kernel(SelectArgs A) {
+    __shared__ uint2 stage[4 * kSelStage];
+    const int lane = threadIdx.x & 63;
+    SelWave W;
+    W.st = stage + (threadIdx.x >> 6) * kSelStage;
+    W.n = 0;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const int64_t S = A.nbases;
+    for (int64_t r = wave; r < A.nseq; r += n_waves) {
+        if (A.skip && A.skip[r]) continue;
+        const int64_t c0 = A.cum[r];
         const int len = (int)(A.cum[r + 1] - c0);
+        if (len <= 0) continue;
         const uint8_t *P = A.prof + c0;
-        const int64_t S = A.nbases;
+        const int nch = (len + 63) >> 6;                       // <= 4 (reads are at most 255 long)
         auto L = [&](int m, int i) -> int { return P[(int64_t)m * S + i]; };
+        // hits of read[i, i+ln): the largest m with L_m(i) >= ln (L_m falls with m)
         auto count_of = [&](int i, int ln) -> int {
-            int c = 0;
-            for (int m = 1; m <= A.M; ++m) {
+            int c = 1;
+            for (int m = 2; m <= A.M; ++m) {
                 if (L(m, i) >= ln) c = m; else break;
             }
             return c >= A.M ? kMany : c;
         };
-        uint64_t nm0 = 0, nm1 = 0, nm2 = 0, nm3 = 0;       // N positions of the read (reads are at most 255 long)
-        int prev_e = -1;
-        for (int i = 0; i < len; ++i) {
-            const uint64_t isn = P[i];
-            const uint64_t bit = isn << (i & 63);
-            if (i < 64) nm0 |= bit; else if (i < 128) nm1 |= bit; else if (i < 192) nm2 |= bit; else nm3 |= bit;
-            const int l1 = L(1, i), en = i + l1;
-            if (l1 >= A.msl && (i == 0 || en > prev_e)) {
-                const int cnt = count_of(i, l1);
-                emit(i, l1, cnt);
-                if (l1 >= A.split_len && cnt <= A.split_width) {
-                    // reseeding (bwamem.cpp:1165-1181): matches with more hits that cover the middle
-                    const int x = (i + en) >> 1, m = cnt + 1;
-                    for (int a = x; a >= 0; --a) {
-                        const int l = L(m, a);
-                        if (l > 0 && a + l <= x) break;
-                        if (l < A.msl || a + l <= x) continue;
-                        if (a > 0 && a + l <= a - 1 + L(m, a - 1)) continue;
-                        emit(a, l, count_of(a, l));
-                    }
+        int l1[4], lx[4];
+        unsigned long long nm[4];
+        for (int k = 0; k < 4; ++k) {
+            const int p = 64 * k + lane;
+            const bool v = k < nch && p < len;
+            l1[k] = v ? L(1, p) : 0;
+            lx[k] = v && A.max_intv > 0 ? L(A.max_intv, p) : 0;
+            nm[k] = __ballot(v && P[p] != 0);
+        }
+        // ---- round 1, with reseeding (bwamem.cpp:1165-1181) of the SMEMs that qualify
+        int prev_e_carry = -1;                                // position - 1 + L_1 of the lane in front of this chunk
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                         // unrolled: l1[] stays in registers
+            if (k >= nch) break;
+            const int p = 64 * k + lane;
+            const int e = p + l1[k];
+            int prev_e = __shfl_up(e, 1);
+            if (lane == 0) prev_e = prev_e_carry;
+            prev_e_carry = __shfl(e, 63);
+            const bool smem = p < len && l1[k] >= A.msl && (p == 0 || e > prev_e);
+            int cnt = 0;
+            if (smem) cnt = count_of(p, l1[k]);
+            sel_emit(A, W, lane, smem, (uint32_t)r, p, l1[k], cnt);
+            unsigned long long todo = __ballot(smem && l1[k] >= A.split_len && cnt <= A.split_width);
+            while (todo) {
+                const int ld = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int i0 = 64 * k + ld, en0 = i0 + __shfl(l1[k], ld), m = __shfl(cnt, ld) + 1;
+                const int x = (i0 + en0) >> 1;                 // matches with at least m hits that cover position x
+                int carry = 0;                                 // L_m of the position in front of the chunk
+                for (int kk = 0; kk <= (x >> 6); ++kk) {
+                    const int a = 64 * kk + lane;
+                    const int la = a <= x && a < len ? L(m, a) : 0;
+                    int lp = __shfl_up(la, 1);
+                    if (lane == 0) lp = carry;
+                    carry = __shfl(la, 63);
+                    const bool ok = a <= x && la >= A.msl && a + la > x && (a == 0 || a + la > a - 1 + lp);
+                    int c2 = 0;
+                    if (ok) c2 = count_of(a, la);
+                    sel_emit(A, W, lane, ok, (uint32_t)r, a, la, c2);
                 }
             }
-            prev_e = en;
         }
+        // ---- round 3: `last` (ertseeding.cpp:3425-3511 = bwtSeedStrategyAllPosOneThread); x is wave-uniform
         if (A.max_intv > 0) {
-            // `last` (ertseeding.cpp:3425-3511 = bwtSeedStrategyAllPosOneThread)
             auto first_n = [&](int lo, int hi) -> int {      // first N in [lo, hi), -1 if none
                 for (int wd = lo >> 6; wd <= (hi - 1) >> 6 && wd < 4; ++wd) {
-                    uint64_t mk = wd == 0 ? nm0 : wd == 1 ? nm1 : wd == 2 ? nm2 : nm3;
+                    unsigned long long mk = nm[wd];
                     if (wd == (lo >> 6)) mk &= ~0ull << (lo & 63);
                     if (wd == ((hi - 1) >> 6) && (hi & 63)) mk &= ~0ull >> (64 - (hi & 63));
                     if (mk) return wd * 64 + __builtin_ctzll(mk);
@@ -427,38 +471,30 @@ __global__ __launch_bounds__(256) void ert_select_kernel(SelectArgs A) {
             };
             int x = 0;
             while (x < len) {
-                if (P[x]) { x++; continue; }
-                int want = L(A.max_intv, x) + 1;
+                const int k = x >> 6, j = x & 63;
+                if ((nm[k] >> j) & 1) { x++; continue; }
+                const int lxx = __shfl(k == 0 ? lx[0] : k == 1 ? lx[1] : k == 2 ? lx[2] : lx[3], j);
+                const int l1x = __shfl(k == 0 ? l1[0] : k == 1 ? l1[1] : k == 2 ? l1[2] : l1[3], j);
+                int want = lxx + 1;
                 if (want < A.msl + 1) want = A.msl + 1;
                 const int hi = x + want < len ? x + want : len;
                 const int nn = hi > x + 1 ? first_n(x + 1, hi) : -1;
                 if (nn >= 0) { x = nn + 1; continue; }
                 if (x + want > len) break;
-                if (L(1, x) >= want) emit(x, want, count_of(x, want));
+                if (l1x >= want) {
+                    // hits: lane m holds L_m(x); the number of leading planes that reach `want`
+                    const int lm = lane >= 1 && lane <= A.M ? L(lane, x) : 0;
+                    const unsigned long long ge = __ballot(lane >= 1 && lane <= A.M && lm >= want);
+                    int c = __builtin_ctzll(~(ge >> 1));
+                    c = c >= A.M ? kMany : c;
+                    sel_emit(A, W, lane, lane == 0, (uint32_t)r, x, want, c);
+                }
                 x += want;
             }
         }
+        if (W.n > kSelStage - 64 - kSelSlack) sel_flush(A, W, lane);
     }
-    // append: exclusive prefix of the staged counts over the wave, one ticket per wave
-    int incl = n_st;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if ((tid & 63) >= o) incl += v;
-    }
-    const int total = __shfl(incl, 63);
-    if (total == 0) return;
-    const unsigned long long base = wave_ticket(&A.ctr->n_smem_total, (unsigned long long)total);
-    const int64_t at = (int64_t)base + incl - n_st;
-    for (int j = 0; j < n_st; ++j) {
-        const uint32_t rec = stage[j * 256 + tid];
-        if (at + j < A.pool_cap) {
-            bwams_smem_t o;
-            const int st = rec & 0xff, ln = (rec >> 8) & 0xff, cnt = (rec >> 16) & 0xff;
-            o.rid = (uint32_t)r; o.m = (uint32_t)st; o.n = (uint32_t)(st + ln - 1); o.pad_ = 0;
-            o.k = 0; o.l = 0; o.s = cnt == kMany ? -1 : cnt;
-            A.pool[at + j] = o;
-        }
-    }
+    sel_flush(A, W, lane);
 }
 
 // ---- hit counts of the big subtrees -------------------------------------------------------------------------------
@@ -754,7 +790,8 @@ void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum,
 }
 
 void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *skip, int64_t nseq, int64_t nbases, int M,
-                       const bwams_seed_opt_t &opt, bwams_smem_t *pool, int64_t pool_cap, DevCounters *ctr, hipStream_t st) {
+                       const bwams_seed_opt_t &opt, bwams_smem_t *pool, int64_t pool_cap, DevCounters *ctr, int cu_count,
+                       hipStream_t st) {
     if (nseq <= 0) return;
     SelectArgs A;
     A.prof = prof; A.cum = cum; A.skip = skip; A.nseq = nseq; A.nbases = nbases; A.M = M;
@@ -763,7 +800,9 @@ void launch_ert_select(const uint8_t *prof, const int64_t *cum, const uint8_t *s
     A.split_width = opt.split_width;
     A.max_intv = opt.max_mem_intv;
     A.pool = pool; A.pool_cap = pool_cap; A.ctr = ctr;
-    ert_select_kernel<<<(unsigned)((nseq + 255) / 256), 256, 0, st>>>(A);
+    int64_t blocks = (nseq + 3) / 4;
+    if (blocks > (int64_t)cu_count * 16) blocks = (int64_t)cu_count * 16;
+    ert_select_kernel<<<(unsigned)blocks, 256, 0, st>>>(A);
 }
 
 int64_t ert_walk_threads(int cu_count) { return (int64_t)cu_count * 8 * 256; }

@@ -99,6 +99,33 @@ __device__ __forceinline__ int intv2rid(const DevBns &b, int64_t rb, int64_t re,
     return rid_b == rid_e ? rid_b : -1;
 }
 
+// The same for a wavefront working on one read: lane l keeps the offset of sequence l (or, with more than 64 sequences, of
+// sequence 64 l) in a register, and a position's sequence is a ballot (plus one coalesced load for the second level)
+// instead of a binary search of dependent global loads — seeds of a read in a repeat family jump between sequences, the
+// one-entry cache misses, and those loads were most of the per-seed latency of the wave tiers.
+struct WaveBns { int64_t off; };
+__device__ __forceinline__ WaveBns wave_bns_load(const DevBns &b, int lane) {
+    WaveBns w;
+    const int stride = b.n_seqs <= 64 ? 1 : 64;
+    const int64_t i = (int64_t)lane * stride;
+    w.off = i < b.n_seqs ? b.contigs[i].offset : INT64_MAX;
+    return w;
+}
+__device__ __forceinline__ int pos2rid_w(const DevBns &b, const WaveBns &w, int64_t pos_f, int lane) {
+    if (pos_f >= b.l_pac) return -1;
+    const int c = __popcll(__ballot(w.off <= pos_f)) - 1;          // offset[0] = 0 <= pos_f: c >= 0
+    if (b.n_seqs <= 64) return c;
+    const int i = c * 64 + lane;
+    const int64_t o = i < b.n_seqs ? b.contigs[i].offset : INT64_MAX;
+    return c * 64 + __popcll(__ballot(o <= pos_f)) - 1;
+}
+__device__ __forceinline__ int intv2rid_w(const DevBns &b, const WaveBns &w, int64_t rb, int64_t re, int lane) {
+    if (rb < b.l_pac && re > b.l_pac) return -2;
+    const int rid_b = pos2rid_w(b, w, depos(b, rb), lane);
+    const int rid_e = rb < re ? pos2rid_w(b, w, depos(b, re - 1), lane) : rid_b;
+    return rid_b == rid_e ? rid_b : -1;
+}
+
 // per-read view of the scratch
 struct ReadCtx {
     Node *nodes;
@@ -637,6 +664,9 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
     } else c.root = new_node(c);
     RidCache rc;
     rc.lo = 0; rc.hi = -1; rc.rid = 0;
+    WaveBns wb;
+    wb.off = 0;
+    if (nl == 64 && A.bns.n_seqs <= 4096) wb = wave_bns_load(A.bns, lane);
     if (LDS && cnt > cap_chains) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return true; }
 
     const int64_t l_pac = A.bns.l_pac;
@@ -654,7 +684,8 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
                 rbeg = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(pos64 >> 32), j) << 32) |
                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pos64, j));
             } else rbeg = pos[g];
-            const int rid = intv2rid(A.bns, rbeg, rbeg + slen, rc);
+            const int rid = nl == 64 && A.bns.n_seqs <= 4096 ? intv2rid_w(A.bns, wb, rbeg, rbeg + slen, lane)
+                                                               : intv2rid(A.bns, rbeg, rbeg + slen, rc);
             if (rid < 0) continue;
             bool to_add = true;
             WPath path;

@@ -249,25 +249,34 @@ __host__ __device__ __forceinline__ int bsw_class_of(int qlen, int h0, int max_s
            : qlen <= 16 * kQuadCpl[3] - 1 ? 3 : 4;
 }
 
-// list[c * n + k] = k-th task of class c (any order: results go back by task index)
-__global__ void bsw_classify_kernel(const bwams_seqpair_t *__restrict__ pairs, int64_t n, int max_sc, int32_t *__restrict__ list,
-                                    unsigned long long *cnt) {
+// list[c * n + k] = k-th task of class c (any order: results go back by task index).  Appends are aggregated per block of
+// 1024 tasks: waves count into LDS, one global atomic per class and block (one per class and WAVE was 270 k atomics on six
+// addresses per launch: 1.9 ms of a kernel that reads 160 MB).
+__global__ __launch_bounds__(1024) void bsw_classify_kernel(const bwams_seqpair_t *__restrict__ pairs, int64_t n, int max_sc, int32_t *__restrict__ list,
+                                                            unsigned long long *cnt) {
+    __shared__ unsigned int l_cnt[kNumBswClass];
+    __shared__ unsigned long long l_base[kNumBswClass];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    if (threadIdx.x < kNumBswClass) l_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int cls = t < n ? bsw_class_of(pairs[t].len2, pairs[t].h0, max_sc) : -1;
+    unsigned int my_off = 0;                       // offset of this lane's task inside the block's share of its class
 #pragma unroll
     for (int c = 0; c < kNumBswClass; ++c) {
-        // one atomic per wave and class (a per-task atomic on six addresses cost 0.6 ms per launch); straight-line code in a
-        // fully unrolled loop: no back edge for the leader's branch to be threaded through (wave_ops.h, wave_ticket)
         const unsigned long long m = __ballot(cls == c);
         if (m) {
             const int leader = __ffsll((long long)m) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&cnt[c], (unsigned long long)__popcll(m));
-            base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)base, leader);
-            if (cls == c) list[(int64_t)c * n + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)t;
+            unsigned int wbase = 0;
+            if (lane == leader) wbase = atomicAdd(&l_cnt[c], (unsigned int)__popcll(m));
+            wbase = (unsigned int)__shfl((int)wbase, leader);
+            if (cls == c) my_off = wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
         }
     }
+    __syncthreads();
+    if (threadIdx.x < kNumBswClass && l_cnt[threadIdx.x]) l_base[threadIdx.x] = atomicAdd(&cnt[threadIdx.x], (unsigned long long)l_cnt[threadIdx.x]);
+    __syncthreads();
+    if (cls >= 0) list[(int64_t)cls * n + (int64_t)l_base[cls] + my_off] = (int32_t)t;
 }
 
 // row-local (16-lane) DPP helpers.  A VALU write followed by a DPP read of the same register needs two wait states.
@@ -558,7 +567,7 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
                DevCounters *ctr, int cu_count, hipStream_t st, int32_t *list, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join) {
     bsw_reset_kernel<<<1, 1, 0, st>>>(ctr);
     if (n <= 0) return 0;
-    bsw_classify_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pairs, n, prm.max_sc, list, ctr->bsw_cls_cnt);
+    bsw_classify_kernel<<<(unsigned)((n + 1023) / 1024), 1024, 0, st>>>(pairs, n, prm.max_sc, list, ctr->bsw_cls_cnt);
     int64_t blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t maxb = (int64_t)cu_count * 8;
     if (blocks > maxb) blocks = maxb;

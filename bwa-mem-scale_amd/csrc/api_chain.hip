@@ -434,8 +434,8 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
         if (vb && *vb && *vb != '0') {
             const unsigned long long *d = b->h_ctr->dbg;
             fprintf(stderr, "[bwams_chain_run] filter wave tier: reads by chains <=32 %llu <=64 %llu <=128 %llu <=256 %llu <=512 %llu <=960 %llu more %llu; "
-                            "Mcycles: sequential(HBM) %.1f sort %.1f filter %.1f; chains %llu selected %llu\n",
-                    d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7] / 1e6, d[8] / 1e6, d[9] / 1e6, d[11], d[10]);
+                            "Mcycles: sequential(HBM) %.1f sort %.1f filter %.1f; chains %llu selected %llu; longest read: sort %.2f filter %.2f Mcycles, most chains %llu, most selected %llu\n",
+                    d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7] / 1e6, d[8] / 1e6, d[9] / 1e6, d[11], d[10], d[12] / 1e6, d[13] / 1e6, d[14], d[15]);
         }
     }
     if (b->h_ctr->chain_overflow) {

@@ -905,37 +905,49 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
             const int bi = (int)ri.x, ei = (int)ri.y, wi = (int)(ri.z & 0x7fffffffu);
             const bool alt_i = (ri.z >> 31) != 0;
             bool large_ovlp = false, dropped = false;
-            for (int kb = 0; kb < n_sel && !dropped; kb += 64) {
-                const int k = kb + lane;
-                bool lg = false, br = false;
-                uint4 rj = make_uint4(0, 0, 0, 0);
-                if (k < n_sel) {
-                    rj = l_sel[k];
-                    const int bj = (int)rj.x, ej = (int)rj.y;
-                    const int b_max = bj > bi ? bj : bi;
-                    const int e_min = ej < ei ? ej : ei;
-                    const bool alt_j = (rj.z >> 31) != 0;
-                    if (e_min > b_max && (!alt_j || alt_i)) {
-                        const int li = ei - bi, lj = ej - bj;
-                        const int min_l = li < lj ? li : lj;
-                        if ((float)(e_min - b_max) >= (float)min_l * A.opt.mask_level && min_l < A.opt.max_chain_gap) {
-                            lg = true;
-                            const int wj = (int)(rj.z & 0x7fffffffu);
-                            br = (float)wi < (float)wj * A.opt.drop_ratio && wj - wi >= (A.opt.min_seed_len << 1);
+            // four chunks of 64 selected chains per trip: their LDS loads and tests are independent, only the resolution
+            // (first drop, shadow marks up to it) goes chunk by chunk — a read with thousands of equal-weight chains scans its
+            // whole selection for every chain, and one chunk per trip left that scan waiting on one LDS round trip at a time
+            for (int kb = 0; kb < n_sel && !dropped; kb += 256) {
+                bool lg[4], br[4];
+                uint4 rj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + 64 * u + lane;
+                    lg[u] = false; br[u] = false;
+                    rj[u] = make_uint4(0, 0, 0, 0);
+                    if (k < n_sel) {
+                        rj[u] = l_sel[k];
+                        const int bj = (int)rj[u].x, ej = (int)rj[u].y;
+                        const int b_max = bj > bi ? bj : bi;
+                        const int e_min = ej < ei ? ej : ei;
+                        const bool alt_j = (rj[u].z >> 31) != 0;
+                        if (e_min > b_max && (!alt_j || alt_i)) {
+                            const int li = ei - bi, lj = ej - bj;
+                            const int min_l = li < lj ? li : lj;
+                            if ((float)(e_min - b_max) >= (float)min_l * A.opt.mask_level && min_l < A.opt.max_chain_gap) {
+                                lg[u] = true;
+                                const int wj = (int)(rj[u].z & 0x7fffffffu);
+                                br[u] = (float)wi < (float)wj * A.opt.drop_ratio && wj - wi >= (A.opt.min_seed_len << 1);
+                            }
                         }
                     }
                 }
-                const unsigned long long m_br = __ballot(br);
-                unsigned long long m_lg = __ballot(lg);
-                if (m_br) {
-                    const int first_br = __ffsll((long long)m_br) - 1;
-                    m_lg &= first_br == 63 ? ~0ull : ((2ull << first_br) - 1ull);
-                    dropped = true;
-                }
-                if (m_lg) large_ovlp = true;
-                if (lg && ((m_lg >> lane) & 1ull)) {         // `first` of selected chain j = rj.w (its sorted position)
-                    uint4 *pj = &l_rec[rj.w];
-                    if ((int)pj->w < 0) pj->w = (uint32_t)i;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (dropped || kb + 64 * u >= n_sel) break;
+                    const unsigned long long m_br = __ballot(br[u]);
+                    unsigned long long m_lg = __ballot(lg[u]);
+                    if (m_br) {
+                        const int first_br = __ffsll((long long)m_br) - 1;
+                        m_lg &= first_br == 63 ? ~0ull : ((2ull << first_br) - 1ull);
+                        dropped = true;
+                    }
+                    if (m_lg) large_ovlp = true;
+                    if (lg[u] && ((m_lg >> lane) & 1ull)) {         // `first` of selected chain j = rj.w (its sorted position)
+                        uint4 *pj = &l_rec[rj[u].w];
+                        if ((int)pj->w < 0) pj->w = (uint32_t)i;
+                    }
                 }
             }
             if (!dropped) {
@@ -953,6 +965,10 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
             const unsigned long long t_2 = __builtin_amdgcn_s_memtime();
             atomicAdd(&A.ctr->dbg[8], t_1 - t_0);
             atomicAdd(&A.ctr->dbg[9], t_2 - t_1);
+            atomicMax(&A.ctr->dbg[12], t_1 - t_0);
+            atomicMax(&A.ctr->dbg[13], t_2 - t_1);
+            atomicMax(&A.ctr->dbg[14], (unsigned long long)n_chn);
+            atomicMax(&A.ctr->dbg[15], (unsigned long long)n_sel);
             atomicAdd(&A.ctr->dbg[10], (unsigned long long)n_sel);
             atomicAdd(&A.ctr->dbg[11], (unsigned long long)n_chn);
         }

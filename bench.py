@@ -561,7 +561,7 @@ def main():
         }
         ext_ms = mean("ms_ext_total")
         out["extension"] = {
-            "kernels": "bsw_qwin_kernel (banded SW, four tasks per wavefront: integer VALU issue bound, neither of the contract's two roofs)",
+            "kernels": "bsw_qwin_kernel (banded SW, eight tasks per wavefront: integer VALU issue and LDS latency bound, neither of the contract's two roofs)",
             "tasks": int(st.n_left + st.n_right), "dp_cells": int(st.bsw_cells), "ms_all_rounds": round(ext_ms, 3),
             "Gcells_per_s": round(st.bsw_cells / (ext_ms * 1e-3) / 1e9, 2) if ext_ms > 0 else None,
             "Mtasks_per_s": round((st.n_left + st.n_right) / (ext_ms * 1e-3) / 1e6, 2) if ext_ms > 0 else None,

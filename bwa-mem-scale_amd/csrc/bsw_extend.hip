@@ -560,8 +560,8 @@ __global__ void bsw_reset_kernel(DevCounters *ctr) {
 
 }  // namespace
 
-// Tasks are binned (bsw_classify_kernel) by query length into five four-tasks-per-wave launches and, for what is left
-// (queries beyond 191 bases, scores beyond 2^22), the one-task-per-wave LDS kernel.  Every launch has its own ticket counter; with auxiliary
+// Tasks are binned (bsw_classify_kernel) by query length into five eight-tasks-per-wave launches and, for what is left
+// (queries beyond 191 bases, scores beyond 2^14), the one-task-per-wave LDS kernel.  Every launch has its own ticket counter; with auxiliary
 // streams they run concurrently, the classes of the longest queries first.  `list` holds kNumBswClass * n task indices.
 int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w, const SwParams &prm, int qmax,
                DevCounters *ctr, int cu_count, hipStream_t st, int32_t *list, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join) {

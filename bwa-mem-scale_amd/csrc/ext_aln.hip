@@ -451,7 +451,7 @@ void launch_ext_heavy_list(const ExtArgs &A, hipStream_t st) {
 void launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st) {
     if (A.nseq <= 0) return;
     ext_select_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
-    ext_select_wave_kernel<<<(unsigned)(cu_count * 2), 256, 0, st>>>(A);
+    ext_select_wave_kernel<<<(unsigned)(cu_count * 8), 256, 0, st>>>(A);      // latency-bound (dependent global loads per seed): many waves
 }
 void launch_ext_request_rest(const ExtArgs &A, hipStream_t st) {
     if (A.n_seeds <= 0) return;

@@ -939,6 +939,7 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     }
     // mem_mark_primary_se of every read, regions in final order, then mem_pair
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_heavy, 0, 2 * sizeof(unsigned long long), st));
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_ticket2, 0, sizeof(unsigned long long), st));
     launch_pair_mark(A, b->cu_count, st);
     launch_pair_widen(A, s->pr_owide.as<int64_t>(), st);
     if ((rc = scan_rows(b, s->pr_owide.as<int64_t>(), s->pr_ooff.as<int64_t>(), 1, n1))) return rc;

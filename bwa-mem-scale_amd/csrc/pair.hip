@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64) void pair_post_wave_kernel(PairArgs A) {
 
 // ---- mem_mark_primary_se: lane per read for short lists, wavefront per read for long ones -------------------------
 constexpr int kMarkLight = 24;       // regions a single lane handles
-constexpr int kMarkLds = 1024;       // regions a wavefront keeps in LDS
+constexpr int kMarkLdsMax = 2048, kMarkLdsSmall = 256;       // regions a wavefront keeps in LDS (68 B each): the two instances
 
 __global__ __launch_bounds__(64) void pair_mark_kernel(PairArgs A) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -683,22 +683,31 @@ __global__ __launch_bounds__(64) void pair_mark_kernel(PairArgs A) {
 // so each element's final position is the number of elements that sort before it — counted by the 64 lanes from LDS.
 // Only mem_mark_primary_se_core's scan stays sequential (lane 0, over LDS copies of qb / qe / score / is_alt); every
 // field is written back to the pool by the lane that owns the element, so lanes never exchange data through HBM.
-__global__ __launch_bounds__(64) void pair_mark_wave_kernel(PairArgs A) {
-    __shared__ int32_t l_slot[kMarkLds], l_sc[kMarkLds], l_alt[kMarkLds], l_qb[kMarkLds], l_qe[kMarkLds];
-    __shared__ uint64_t l_hash[kMarkLds];
-    __shared__ int32_t l_at[kMarkLds];         // sorted position -> original index
-    __shared__ int32_t l_sub[kMarkLds], l_subn[kMarkLds], l_sec[kMarkLds], l_secall[kMarkLds], l_altsc[kMarkLds];   // by sorted position
-    __shared__ int32_t l_pos2[kMarkLds], l_at2[kMarkLds], l_z[kMarkLds];
+// Two instances (LO < regions <= CAP: (24, 256] with 17 KB of LDS per wave, (256, 2048] with 139 KB) share the list of
+// long lists, each with its own ticket counter; the largest also takes what is beyond its LDS (one lane, through HBM).
+// One 1024-entry instance kept three waves per CU busy with mostly short lists and sent the longest (> 1024 regions) to
+// a single lane: 11.3 ms for a chunk.
+template <int CAP, int LO>
+__global__ __launch_bounds__(64) void pair_mark_wave_kernel(PairArgs A, unsigned long long *ticket) {
+    extern __shared__ __align__(16) unsigned char lds_mark[];
+    uint64_t *l_hash = reinterpret_cast<uint64_t *>(lds_mark);
+    int32_t *l_slot = reinterpret_cast<int32_t *>(l_hash + CAP);
+    int32_t *l_sc = l_slot + CAP, *l_alt = l_sc + CAP, *l_qb = l_alt + CAP, *l_qe = l_qb + CAP;
+    int32_t *l_at = l_qe + CAP;                // sorted position -> original index
+    int32_t *l_sub = l_at + CAP, *l_subn = l_sub + CAP, *l_sec = l_subn + CAP, *l_secall = l_sec + CAP, *l_altsc = l_secall + CAP;   // by sorted position
+    int32_t *l_pos2 = l_altsc + CAP, *l_at2 = l_pos2 + CAP, *l_z = l_at2 + CAP;
+    constexpr int kMarkLds = CAP;
     const int lane = threadIdx.x;
     const int64_t n_heavy = (int64_t)A.ctr->pair_heavy;
     int tmp = A.opt.a + A.opt.b;
     tmp = A.opt.o_del + A.opt.e_del > tmp ? A.opt.o_del + A.opt.e_del : tmp;
     tmp = A.opt.o_ins + A.opt.e_ins > tmp ? A.opt.o_ins + A.opt.e_ins : tmp;
     for (;;) {
-        const int64_t t = (int64_t)wave_ticket(&A.ctr->pair_ticket, 1ull);
+        const int64_t t = (int64_t)wave_ticket(ticket, 1ull);
         if (t >= n_heavy) break;
         const int64_t m = A.heavy[t];
         const int n = A.n_fin[m];
+        if (n <= LO || (n > CAP && CAP != kMarkLdsMax)) continue;         // the other instance's list
         const int64_t o0 = A.ooff[m];
         bwams_alnreg_t *pool = A.pool + o0;
         int32_t *ord = A.ord + o0;
@@ -944,7 +953,13 @@ void launch_pair_post(const PairArgs &A, int cu_count, hipStream_t st) {
 void launch_pair_mark(const PairArgs &A, int cu_count, hipStream_t st) {
     if (A.nseq <= 0) return;
     pair_mark_kernel<<<blocks_of(A.nseq, 64), 64, 0, st>>>(A);
-    pair_mark_wave_kernel<<<(unsigned)(cu_count * 3), 64, 0, st>>>(A);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pair_mark_wave_kernel<kMarkLdsMax, kMarkLdsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, 68 * kMarkLdsMax);
+        attr = true;
+    }
+    pair_mark_wave_kernel<kMarkLdsMax, kMarkLdsSmall><<<(unsigned)cu_count, 64, 68 * kMarkLdsMax, st>>>(A, &A.ctr->pair_ticket);
+    pair_mark_wave_kernel<kMarkLdsSmall, kMarkLight><<<(unsigned)(cu_count * 8), 64, 68 * kMarkLdsSmall, st>>>(A, &A.ctr->pair_ticket2);
 }
 void launch_pair_widen(const PairArgs &A, int64_t *wide, hipStream_t st) {
     pair_widen_kernel<<<blocks_of(A.nseq + 1, 256), 256, 0, st>>>(A, wide);

@@ -29,6 +29,7 @@ SYMBOLS = [
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
     "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
+    "bwams_emf_build", "bwams_emf_info", "bwams_emf_table_fetch", "bwams_emf_save",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
     "bwams_batch_stats", "bwams_batch_sync", "bwams_ksw_align",
     "bwams_index_build_fma", "bwams_index_set_fma", "bwams_index_fetch_fma",
@@ -250,6 +251,10 @@ def lib():
         L.bwams_ert_fetch.argtypes = [vp, vp, vp]
         L.bwams_ert_save.argtypes = [vp, C.c_char_p]
         L.bwams_debug_sort.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+        L.bwams_emf_build.argtypes = [vp, i32, C.c_double, vp]
+        L.bwams_emf_info.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.bwams_emf_table_fetch.argtypes = [vp, vp, vp]
+        L.bwams_emf_save.argtypes = [vp, C.c_char_p]
         L.bwams_batch_stats.argtypes = [vp, vp]
         L.bwams_batch_sync.argtypes = [vp]
         _lib = L
@@ -396,6 +401,33 @@ class Emf:
             seeds = np.ascontiguousarray(table.seed_table, dtype=np.uint32)
             _chk(lib().bwams_emf_from_host(index.h, table.seed_len, table.seq_len, _p(loc), len(loc), _p(seeds),
                                            len(seeds), C.byref(self.h)), "bwams_emf_from_host")
+
+    @classmethod
+    def build(cls, index: Index, seed_len: int = 150, slack: float = 1.1) -> "Emf":
+        """bwams_emf_build: the table from the resident forward reference, on the GPU"""
+        self = cls.__new__(cls)
+        self.index = index
+        self._keep = None
+        self.h = C.c_void_p()
+        _chk(lib().bwams_emf_build(index.h, seed_len, slack, C.byref(self.h)), "bwams_emf_build")
+        return self
+
+    def info(self):
+        sl, ne, nl = C.c_int32(0), C.c_uint32(0), C.c_uint32(0)
+        nu, nk, ms = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _chk(lib().bwams_emf_info(self.h, C.byref(sl), C.byref(ne), C.byref(nl), C.byref(nu), C.byref(nk), C.byref(ms)), "bwams_emf_info")
+        return {"seed_len": sl.value, "num_seed_entry": ne.value, "num_loc_entry": nl.value, "n_used": nu.value, "n_key": nk.value,
+                "build_ms": ms.value}
+
+    def fetch_table(self):
+        i = self.info()
+        loc = np.zeros(max(i["num_loc_entry"], 1), dtype=np.uint32)
+        seeds = np.zeros((i["num_seed_entry"], 4), dtype=np.uint32)
+        _chk(lib().bwams_emf_table_fetch(self.h, _p(loc), _p(seeds)), "bwams_emf_table_fetch")
+        return loc[:i["num_loc_entry"]], seeds
+
+    def save(self, path: str):
+        _chk(lib().bwams_emf_save(self.h, path.encode()), "bwams_emf_save")
 
     def close(self):
         if self.h:

@@ -1323,6 +1323,87 @@ int bwams_emf_fetch(bwams_batch_t *b, bwams_perfect_t *out, uint8_t *code) {
     return BWAMS_OK;
 }
 
+int bwams_emf_build(bwams_index_t *ix, int32_t seed_len, double slack, bwams_emf_t **out) {
+    if (!ix || !out || seed_len < 16 || seed_len > 255 || !(slack >= 1.0 && slack <= 4.0)) {
+        set_last_error("bwams_emf_build: seed length must be in [16, 255], slack in [1, 4]");
+        return BWAMS_ERR_ARG;
+    }
+    if (!ix->d_ref) {
+        set_last_error("bwams_emf_build: the index holds no .0123 reference");
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(ix->device));
+    hipDeviceProp_t prop;
+    BWAMS_HIP(hipGetDeviceProperties(&prop, ix->device));
+    const int64_t l_pac = (ix->fmi.ref_seq_len - 1) / 2;
+    if (l_pac < seed_len) {
+        set_last_error("bwams_emf_build: the reference is shorter than the seed length");
+        return BWAMS_ERR_ARG;
+    }
+    bwams_emf *e = new bwams_emf();
+    e->idx = ix;
+    const char *vb = getenv("BWAMS_VERBOSE");
+    int64_t st[4] = {0, 0, 0, 0};
+    const int rc = emf_build_device(e, (const uint8_t *)ix->d_ref, l_pac, seed_len, slack, prop.multiProcessorCount, vb && atoi(vb) > 0, st);
+    if (rc) { bwams_emf_close(e); return rc; }
+    e->n_used = st[0]; e->n_key = st[1]; e->n_other = st[2]; e->build_ms = st[3];
+    *out = e;
+    return BWAMS_OK;
+}
+
+int bwams_emf_info(const bwams_emf_t *e, int32_t *seed_len, uint32_t *num_seed_entry, uint32_t *num_loc_entry, int64_t *n_used, int64_t *n_key,
+                   int64_t *build_ms) {
+    if (!e) return BWAMS_ERR_ARG;
+    if (seed_len) *seed_len = e->t.seed_len;
+    if (num_seed_entry) *num_seed_entry = e->t.num_seed_entry;
+    if (num_loc_entry) *num_loc_entry = e->t.num_loc_entry;
+    if (n_used) *n_used = e->n_used;
+    if (n_key) *n_key = e->n_key;
+    if (build_ms) *build_ms = e->build_ms;
+    return BWAMS_OK;
+}
+
+int bwams_emf_table_fetch(bwams_emf_t *e, uint32_t *loc_table, bwams_seed_entry_t *seed_table) {
+    if (!e) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(e->idx->device));
+    if (loc_table && e->t.num_loc_entry) BWAMS_HIP(hipMemcpy(loc_table, e->t.loc_table, (size_t)e->t.num_loc_entry * 4, hipMemcpyDeviceToHost));
+    if (seed_table) BWAMS_HIP(hipMemcpy(seed_table, e->t.seed_table, (size_t)e->t.num_seed_entry * 16, hipMemcpyDeviceToHost));
+    return BWAMS_OK;
+}
+
+/* <path> in the reference's `.perfect.<L>` layout (perfect.h:188-213): 64-byte header, loc_table, seed_table */
+int bwams_emf_save(bwams_emf_t *e, const char *path) {
+    if (!e || !path) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(e->idx->device));
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_last_error(std::string("bwams_emf_save: cannot create ") + path); return BWAMS_ERR_IO; }
+    unsigned char hdr[64];
+    memset(hdr, 0, sizeof hdr);
+    const int32_t sl = e->t.seed_len;
+    const uint32_t a[3] = {e->t.num_loc_entry, e->t.num_seed_entry, e->t.num_seed_entry};
+    const uint32_t b3[3] = {e->t.seq_len, (uint32_t)e->n_used, (uint32_t)e->n_key};
+    memcpy(hdr, &sl, 4); memcpy(hdr + 4, a, 12); memcpy(hdr + 40, b3, 12);
+    int rc = fwrite(hdr, 1, 64, f) == 64 ? BWAMS_OK : BWAMS_ERR_IO;
+    const size_t chunk = (size_t)256 << 20;
+    void *stage = nullptr;
+    if (rc == BWAMS_OK && hipHostMalloc(&stage, chunk) != hipSuccess) rc = BWAMS_ERR_NOMEM;
+    auto stream_out = [&](const void *src, size_t total) {
+        size_t done = 0;
+        while (rc == BWAMS_OK && done < total) {
+            const size_t n = total - done < chunk ? total - done : chunk;
+            if (hipMemcpy(stage, (const uint8_t *)src + done, n, hipMemcpyDeviceToHost) != hipSuccess) { rc = BWAMS_ERR_DEVICE; break; }
+            if (fwrite(stage, 1, n, f) != n) { rc = BWAMS_ERR_IO; break; }
+            done += n;
+        }
+    };
+    if (rc == BWAMS_OK) stream_out(e->t.loc_table, (size_t)e->t.num_loc_entry * 4);
+    if (rc == BWAMS_OK) stream_out(e->t.seed_table, (size_t)e->t.num_seed_entry * 16);
+    if (stage) (void)hipHostFree(stage);
+    fclose(f);
+    if (rc) set_last_error(std::string("bwams_emf_save: writing ") + path + " failed");
+    return rc;
+}
+
 int bwams_emf_close(bwams_emf_t *e) {
     if (!e) return BWAMS_OK;
     if (!e->owns) { delete e; return BWAMS_OK; }

@@ -154,7 +154,13 @@ struct bwams_emf {
     bool owns = true;
     void *d_seeds = nullptr, *d_loc = nullptr;
     int64_t bytes = 0;
+    int64_t n_used = 0, n_key = 0, n_other = 0, build_ms = 0;     // bwams_emf_build: distinct L-mers, buckets used, nodes outside their bucket
 };
+
+namespace bwams {
+int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_len, double slack, int cu_count, int verbose,
+                     int64_t stats[4]);
+}
 
 struct bwams_batch {
     bwams_index *idx = nullptr;

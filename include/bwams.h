@@ -184,6 +184,17 @@ int bwams_emf_from_host(bwams_index_t *idx, int32_t seed_len, uint32_t seq_len, 
 int bwams_emf_from_device(bwams_index_t *idx, int32_t seed_len, uint32_t seq_len, const uint32_t *loc_table_dev,
                           uint32_t num_loc_entry, const bwams_seed_entry_t *seed_table_dev, uint32_t num_seed_entry,
                           bwams_emf_t **out);
+/* Builds the table on the GPU from the resident forward reference (replaces `bwa-mem2.scale perfect-index`,
+ * src/perfect_index.cpp): every L-mer of the forward strand, canonical orientation, one bucket per hash value with its
+ * L-mers in ascending order (root in the bucket's slot, the others in free slots), further locations of repeated L-mers
+ * in loc_table.  num_seed_entry = slack x l_pac (the reference uses 1.1).  The table is the reference's format and is
+ * probed identically; the placement of collision nodes differs from the reference builder's (which is order dependent). */
+int bwams_emf_build(bwams_index_t *idx, int32_t seed_len, double slack, bwams_emf_t **out);
+int bwams_emf_info(const bwams_emf_t *emf, int32_t *seed_len, uint32_t *num_seed_entry, uint32_t *num_loc_entry, int64_t *n_used,
+                   int64_t *n_key, int64_t *build_ms);
+/* the two arrays back to the host (either may be NULL) / the `<prefix>.perfect.<L>` file (src/perfect.h:188-213) */
+int bwams_emf_table_fetch(bwams_emf_t *emf, uint32_t *loc_table, bwams_seed_entry_t *seed_table);
+int bwams_emf_save(bwams_emf_t *emf, const char *path);
 int bwams_emf_close(bwams_emf_t *emf);
 
 /* Replaces the kernel-0 loop of mem_kernel1_core (src/bwamem.cpp:1245-1272): for every read

@@ -148,7 +148,10 @@ __global__ __launch_bounds__(256) void emf_bucket_kernel(BucketArgs A) {
             head = i == 0 || (uint32_t)(A.keys[i - 1] >> 32) != key;
         }
         // distinct L-mers of the run: first position, orientation, members in either orientation
-        uint32_t u_pos[kMaxU], u_hi[kMaxU], u_same[kMaxU], u_other[kMaxU];
+        // per L-mer: a witness window (u_pos, its orientation in u_fw) for the comparisons; per orientation the smallest
+        // position and the number of windows.  The entry's location is the smallest position of all (as the reference's
+        // builder, which meets the windows in text order, stores the first one).
+        uint32_t u_pos[kMaxU], u_hi[kMaxU], u_min[kMaxU][2], u_cnt[kMaxU][2];
         uint64_t u_fw = 0;
         int c = 0;
         int64_t j = i;
@@ -164,9 +167,12 @@ __global__ __launch_bounds__(256) void emf_bucket_kernel(BucketArgs A) {
                 for (int k = 0; k < c && hit < 0; ++k)
                     if (((u_hi[k] ^ hi) >> 1) == 0 && canon_cmp(B, u_pos[k], (u_fw >> k) & 1, p, f) == 0) hit = k;
                 if (hit >= 0) {
-                    if (f == (bool)((u_fw >> hit) & 1)) u_same[hit]++; else u_other[hit]++;
+                    u_cnt[hit][f]++;
+                    if ((uint32_t)p < u_min[hit][f]) u_min[hit][f] = (uint32_t)p;
                 } else if (c < kMaxU) {
-                    u_pos[c] = (uint32_t)p; u_hi[c] = hi; u_same[c] = 0; u_other[c] = 0;
+                    u_pos[c] = (uint32_t)p; u_hi[c] = hi;
+                    u_cnt[c][0] = u_cnt[c][1] = 0; u_min[c][0] = u_min[c][1] = kNoEntry;
+                    u_cnt[c][f] = 1; u_min[c][f] = (uint32_t)p;
                     if (f) u_fw |= 1ull << c;
                     ++c;
                 } else too_many = true;
@@ -178,8 +184,9 @@ __global__ __launch_bounds__(256) void emf_bucket_kernel(BucketArgs A) {
             if (head) {
                 atomicOr(&A.used[key >> 5], 1u << (key & 31));
                 for (int k = 0; k < c; ++k) {
-                    const uint32_t m = u_same[k] + u_other[k];
-                    if (m) words += (u_same[k] < 256 && u_other[k] < 256 ? 1 : 3) + m;
+                    const int f0 = u_min[k][1] < u_min[k][0] ? 1 : 0;
+                    const uint32_t same = u_cnt[k][f0] - 1, other = u_cnt[k][1 - f0];
+                    if (same + other) words += (same < 256 && other < 256 ? 1 : 3) + same + other;
                 }
             }
             const unsigned long long s0 = wave_sum(head && c > 1 ? (unsigned long long)(c - 1) : 0ull), s1 = wave_sum(words),
@@ -219,29 +226,31 @@ __global__ __launch_bounds__(256) void emf_bucket_kernel(BucketArgs A) {
         for (int r = c - 1; r >= 0; --r) {                 // from the tail of the chain: a node's `right` is the next larger L-mer
             const int k = ord[r];
             const uint32_t slot = r == 0 ? key : A.free_list[fbase + (unsigned long long)(r - 1)];
-            uint32_t flags = ((u_fw >> k) & 1 ? 1u : 0u) | (r == 0 ? 0u : 2u);
-            const uint32_t m = u_same[k] + u_other[k];
+            const int f0 = u_min[k][1] < u_min[k][0] ? 1 : 0;             // orientation of the first (smallest) location
+            const uint32_t rep = u_min[k][f0], same = u_cnt[k][f0] - 1, other = u_cnt[k][1 - f0];
+            uint32_t flags = (f0 ? 1u : 0u) | (r == 0 ? 0u : 2u);
+            const uint32_t m = same + other;
             if (m) {
-                const bool shortf = u_same[k] < 256 && u_other[k] < 256;
+                const bool shortf = same < 256 && other < 256;
                 const unsigned long long at = atomicAdd(&A.ctr[1], (unsigned long long)((shortf ? 1 : 3) + m));
                 if (at + (shortf ? 1 : 3) + m <= A.loc_cap) {
                     unsigned long long wpos;
-                    if (shortf) { A.loc[at] = (u_same[k] << 16) | u_other[k]; wpos = at + 1; }
-                    else { A.loc[at] = 0x80000000u | (uint32_t)(at + 1); A.loc[at + 1] = u_same[k]; A.loc[at + 2] = u_other[k]; wpos = at + 3; }
-                    unsigned long long ws = wpos, wo = wpos + u_same[k];
+                    if (shortf) { A.loc[at] = (same << 16) | other; wpos = at + 1; }
+                    else { A.loc[at] = 0x80000000u | (uint32_t)(at + 1); A.loc[at + 1] = same; A.loc[at + 2] = other; wpos = at + 3; }
+                    unsigned long long ws = wpos, wo = wpos + same;
                     const bool kf = (u_fw >> k) & 1;
-                    for (int64_t e = i; e < j; ++e) {       // the run again: members of this L-mer, positions ascending
+                    for (int64_t e = i; e < j; ++e) {       // the run again: the other windows of this L-mer, positions ascending
                         const int64_t p = A.pos[e];
                         const uint32_t hi = (uint32_t)A.keys[e];
-                        if ((uint32_t)p == u_pos[k] || ((hi ^ u_hi[k]) >> 1) != 0) continue;
+                        if ((uint32_t)p == rep || ((hi ^ u_hi[k]) >> 1) != 0) continue;
                         const bool f = hi & 1u;
                         if (canon_cmp(B, u_pos[k], kf, p, f) != 0) continue;
-                        if (f == kf) A.loc[ws++] = (uint32_t)p; else A.loc[wo++] = (uint32_t)p;
+                        if ((int)f == f0) A.loc[ws++] = (uint32_t)p; else A.loc[wo++] = (uint32_t)p;
                     }
                     flags |= (uint32_t)at << 2;
                 } else atomicAdd(&A.ctr[4], 1ull);
             }
-            A.seeds[slot] = make_uint4(flags, u_pos[k], kNoEntry, slot_of_next);
+            A.seeds[slot] = make_uint4(flags, rep, kNoEntry, slot_of_next);
             slot_of_next = slot;
         }
     }

@@ -68,7 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fma", action="store_true", help="build and use the FMA tables (all_smem.11 / last_smem.13)")
-    ap.add_argument("--emf", action="store_true", help="build the exact-match filter table (L=150) on the GPU and probe it first")
+    ap.add_argument("--emf", action="store_true", help="build the exact-match filter table (L=150) on the GPU; reads it resolves skip seeding and get their regions from it")
     ap.add_argument("--no-ert-leg", action="store_true", help="skip the beside leg that repeats the steps with seeding over the ERT")
     ap.add_argument("--ert", action="store_true", help="build the ERT index (k-mer table + radix trees) on the GPU and seed over it instead of the FM-index")
     ap.add_argument("--pcie", action="store_true", help="also time the one-call host-buffer form (PCIe inclusive)")
@@ -255,6 +255,15 @@ def main():
         ix.build_fma(11, 13)
         log(f"FMA tables built on GPU in {time.time()-t0:.1f}s (512 MiB + 1 GiB)")
 
+    emf_h = None
+    emf_info = None
+    if args.emf:
+        t0 = time.time()
+        emf_h = capi.Emf.build(ix, seed_len=150, slack=1.1)       # `perfect-index -l 150`: num_seed_entry = 1.1 x l_pac
+        emf_info = emf_h.info()
+        log(f"EMF table built on GPU in {time.time()-t0:.1f}s: {emf_info['num_seed_entry']/1e6:.0f} M entries "
+            f"({emf_info['num_seed_entry']*16/2**30:.1f} GiB), {emf_info['n_used']/1e6:.0f} M distinct 150-mers in {emf_info['n_key']/1e6:.0f} M buckets")
+
     ert_h = None
     ert_info = None
     if args.ert:
@@ -263,17 +272,6 @@ def main():
         ert_info = ert_h.info()
         log(f"ERT built on GPU in {time.time()-t0:.1f}s: k-mer table 8 GiB + trees {ert_info['mlt_bytes']/2**30:.1f} GiB "
             f"(kernels: sizes {ert_info['build_ms'][0]/1e3:.1f}s, bytes {ert_info['build_ms'][2]/1e3:.1f}s)")
-
-    emf_h = None
-    if args.emf:
-        from bwams import emf as emf_mod
-        t0 = time.time()
-        emf_tab = emf_mod.build_emf_torch(genome, 150, dev)
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        emf_h = capi.Emf(ix, device_table=emf_tab)
-        log(f"EMF table built on GPU in {time.time()-t0:.1f}s: {emf_tab.seed_table.shape[0]/1e6:.0f} M entries "
-            f"({emf_tab.seed_table.numel()*4/2**30:.1f} GiB), {emf_tab.num_seed_used/1e6:.0f} M seeds")
 
     if args.scaling == "weak":
         R = args.reads
@@ -305,7 +303,9 @@ def main():
         # reads (HBM) -> [EMF] -> seeds -> chains -> extension tasks -> banded SW (left, right, retries) -> regions -> dedup
         batch.seed_upload_device(d_reads[c].data_ptr(), cums[c])         # device-to-device copy + 2-bit packing
         if emf_h is not None:
-            batch.emf_run(emf_h)
+            batch.emf_run(emf_h)                                          # probe; the matched reads skip seeding ...
+            n_emf = capi.C.c_int64(0)                                     # ... and get their regions directly (mem_perfect2reg)
+            capi._chk(capi.lib().bwams_emf_regs_run(batch.h, emf_h.h, capi.C.byref(mem_opt), capi.C.byref(n_emf)), "bwams_emf_regs_run")
         if ert_h is not None:
             batch.seed_run_ert(ert_h, seed_opt, with_sa=True)
         else:
@@ -592,7 +592,9 @@ def main():
             _, codes = batch.emf_fetch(CHn)
             emf_ms = mean("ms_emf")
             emf_bytes = 16 * st.emf_nodes + st.emf_cmp_bytes + n_bases
-            out["emf"] = {"resolved_fraction": round(float(((codes == 3) | (codes == 4)).mean()), 4),
+            out["emf"] = {"table_entries": emf_info["num_seed_entry"], "table_bytes": emf_info["num_seed_entry"] * 16,
+                          "distinct_lmers": emf_info["n_used"], "build_s": round(emf_info["build_ms"] / 1e3, 2),
+                          "resolved_fraction": round(float(((codes == 3) | (codes == 4)).mean()), 4),
                           "launch_ms": round(emf_ms, 3), "nodes_per_read": round(st.emf_nodes / CHn, 3),
                           "algorithmic_bytes": int(emf_bytes),
                           "achieved_GBps": round(emf_bytes / (emf_ms * 1e-3) / 1e9, 1) if emf_ms > 0 else None}

@@ -38,7 +38,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 GRCH38_L_PAC = 3_209_286_105   # /root/reference/src/bwa_shm.cpp:1386 (reference_seq_len = 2 * l_pac + 1)
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD, one VALU wave-instruction per 2 cycles per SIMD (more than one wave resident),
 # one SALU instruction per cycle per CU, 2.4 GHz
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
+# integer VALU issue measured on the chip with four waves per SIMD (tools/ubench_valu.hip, gpurun 2026-10-04): v_max_i32, v_cndmask_b32,
+# v_cmp, v_bfe, v_perm, DPP and the v_pk_*_i16 forms 555-570 G wave-instructions/s (4.4 cycles per SIMD), v_add_u32 / v_sub_u32 910 G/s
+# (2.7 cycles); the banded-SW kernel's mix is about one add/sub in four: 1 / (0.75 / 560 + 0.25 / 910)
+VALU_PEAK_GINST = round(1.0 / (0.75 / 560.0 + 0.25 / 910.0), 1)
 SALU_PEAK_GINST = 256 * 2.4
 # the reference itself, timed in the build container: the tree does not travel to the GPU box
 REFERENCE_MEASURED = {
@@ -590,7 +593,7 @@ def main():
         }
         ext_ms = mean("ms_ext_total")
         out["extension"] = {
-            "kernels": "bsw_qwin_kernel (banded SW, eight tasks per wavefront: integer VALU issue and LDS latency bound, neither of the contract's two roofs)",
+            "kernels": "bsw_qwin_kernel (banded SW, eight tasks per wavefront: bound by integer VALU issue, see issue_roof; neither of the contract's two roofs)",
             "tasks": int(st.n_left + st.n_right), "dp_cells": int(st.bsw_cells), "ms_all_rounds": round(ext_ms, 3),
             "Gcells_per_s": round(st.bsw_cells / (ext_ms * 1e-3) / 1e9, 2) if ext_ms > 0 else None,
             "Mtasks_per_s": round((st.n_left + st.n_right) / (ext_ms * 1e-3) / 1e6, 2) if ext_ms > 0 else None,
@@ -603,8 +606,9 @@ def main():
                 "valu_frac": round(v / (VALU_PEAK_GINST * 1e9) / (ext_ms * 1e-3), 4),
                 "salu_frac": round(s_ / (SALU_PEAK_GINST * 1e9) / (ext_ms * 1e-3), 4),
                 "peaks": {"valu_Ginst_s": VALU_PEAK_GINST, "salu_Ginst_s": SALU_PEAK_GINST},
-                "note": "fraction of the extension stage's wall time that the counted instructions need at the guide's issue rates "
-                        "(1 VALU wave-instruction / 2 cycles / SIMD, 1 SALU / cycle / CU, 2.4 GHz); counts from the committed PMC pass",
+                "note": "fraction of the extension stage's wall time that the counted instructions need at the chip's issue rates: "
+                        "integer VALU as measured by tools/ubench_valu.hip (4.4 cycles per wave-instruction per SIMD, add/sub 2.7, "
+                        "blended for the kernel's mix), 1 SALU / cycle / CU at 2.4 GHz; counts from the committed PMC pass",
             }
         if args.ert:
             stg, roof, einfo = ert_report(st, mean, CHn, n_bases, ert_info, load_pmc_summary(args.genome_mbp, CHn))

@@ -167,7 +167,7 @@ L2 misses per launch {r1.get('TCC_MISS_sum',0)/1e6:.0f} M = {r1.get('TCC_MISS_su
 fetch, a 12 GiB table) tops out at 48 G random 64-byte blocks/s = 3.07 TB/s of useful bytes = 0.38 of peak when every block is its own line.
 
 Banded-SW kernels per step: {sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3e9:.1f} G vector and
-{sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3e9:.1f} G scalar wave-instructions (chip issue rates: 1228.8 G VALU/s at one per 2 cycles per SIMD,
+{sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3e9:.1f} G scalar wave-instructions (issue rates: integer VALU 555-570 G/s measured by `tools/ubench_valu.hip` = 4.4 cycles per SIMD, add/sub 910 G/s;
 614.4 G SALU/s at one per cycle per CU, 2.4 GHz) in `stage_ms.ext_total` = {bench['stage_ms']['ext_total']} ms.
 
 ## Smith-Waterman kernels alone, against the real reference objects on the host cores

@@ -220,6 +220,21 @@ typedef struct bwams_aln {
     int32_t  pad_;
 } bwams_aln_t;
 
+/* What mem_reg2sam / mem_gen_alt / mem_aln2sam read beyond bwams_mem_opt_t: fields of mem_opt_t (src/bwamem.h:89-124,
+ * defaults src/bwamem.cpp:135-171) and the read-group id (bwa_rg_id, src/bwa.cpp). */
+#define BWAMS_MEM_F_ALL            0x8
+#define BWAMS_MEM_F_NO_MULTI       0x10
+#define BWAMS_MEM_F_SOFTCLIP       0x200
+#define BWAMS_MEM_F_KEEP_SUPP_MAPQ 0x1000
+typedef struct bwams_sam_opt {
+    int32_t T;                  /* minimum score to output, 30 */
+    int32_t flag;               /* BWAMS_MEM_F_* (the reference's MEM_F_* values) */
+    float   XA_drop_ratio;      /* 0.80 */
+    int32_t max_XA_hits;        /* 5 */
+    int32_t max_XA_hits_alt;    /* 200 */
+    char    rg_id[256];         /* "" = no RG:Z tag */
+} bwams_sam_opt_t;
+
 #ifdef __cplusplus
 }
 #endif

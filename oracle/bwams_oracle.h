@@ -165,6 +165,11 @@ int orc_ksw_global2_cigar(int qlen, const uint8_t *query, int tlen, const uint8_
 int orc_approx_mapq_se(const bwams_mem_opt_t *opt, const bwams_alnreg_t *a);
 int orc_reg2aln(const bwams_mem_opt_t *opt, const struct orc_bns *bns, const uint8_t *ref_string, int l_query, const uint8_t *query,
                 const bwams_alnreg_t *ar, bwams_aln_t *a, uint32_t *cigar, char *md);
+/* single-end SAM text (sam_oracle.c): mem_reg2sam + mem_gen_alt + mem_aln2sam for one read (PARITY UNPINNED).  ctg_names:
+ * NUL-terminated names back to back, ctg_off[rid] = start of a name.  Returns the text length, or -1 - length if cap was short. */
+int64_t orc_reg2sam_se(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const struct orc_bns *bns, const char *ctg_names,
+                       const int32_t *ctg_off, const uint8_t *ref_string, int l_seq, const uint8_t *seq, const char *qual,
+                       const char *name, const char *comment, const bwams_alnreg_t *regs, int n_regs, char *out, int64_t cap);
 uint64_t orc_hash_64(uint64_t key);
 int64_t orc_depos(int64_t l_pac, int64_t pos, int *is_rev);
 int64_t orc_kbt_script(int64_t n, const int64_t *pos, const uint8_t *do_put, int32_t *lower, int32_t *order);

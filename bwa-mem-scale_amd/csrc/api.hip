@@ -353,6 +353,11 @@ int bwams_index_close(bwams_index_t *ix) {
         (void)hipSetDevice(ix->device);
         (void)hipFree(ix->d_contigs);
     }
+    if (ix->d_ctg_names) {
+        (void)hipSetDevice(ix->device);
+        (void)hipFree(ix->d_ctg_names);
+        (void)hipFree(ix->d_ctg_off);
+    }
     if (ix->d_all || ix->d_last) {
         (void)hipSetDevice(ix->device);
         if (ix->d_all) (void)hipFree(ix->d_all);

@@ -55,6 +55,9 @@ struct ChainState {
     int64_t al_n = 0, al_ncig = 0, al_nmd = 0;
     int al_source = 0;
     bool al_done = false;
+    DevBuf sm_names, sm_noff, sm_qual, sm_comm, sm_coff, sm_mapq, sm_len, sm_off, sm_out, sm_logtab, sm_bad;   // SAM text
+    int64_t sm_bytes = 0, sm_nseq = 0, sm_nregs = 0;
+    bool sm_up = false, sm_has_qual = false, sm_has_comm = false, sm_done = false, sm_log_ok = false;
     int64_t n_final = 0;
     bool dedup_done = false;
     int64_t n_chains = 0, n_seeds = 0, nseq = 0, n_chain_redo = 0;
@@ -79,7 +82,7 @@ void chain_state_free(ChainState *s) {
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
                      &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->pr_na, &s->pr_wide, &s->pr_offs, &s->pr_anchor, &s->pr_slot, &s->pr_task, &s->pr_trb, &s->pr_tl1, &s->pr_twide, &s->pr_toffs,
                      &s->pr_pairs, &s->pr_tref, &s->pr_tqer, &s->pr_aln, &s->pr_pool, &s->pr_ord, &s->pr_srt, &s->pr_z, &s->pr_nfin, &s->pr_npri, &s->pr_nsw, &s->pr_full, &s->pr_owide,
-                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->al_need, &s->al_cls, &s->al_off, &s->al_scr, &s->al_list, &s->al_rec, &s->al_wide, &s->al_offs, &s->al_cig, &s->al_md, &s->al_cnt, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->al_need, &s->al_cls, &s->al_off, &s->al_scr, &s->al_list, &s->al_rec, &s->al_wide, &s->al_offs, &s->al_cig, &s->al_md, &s->al_cnt, &s->sm_names, &s->sm_noff, &s->sm_qual, &s->sm_comm, &s->sm_coff, &s->sm_mapq, &s->sm_len, &s->sm_off, &s->sm_out, &s->sm_logtab, &s->sm_bad, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -1091,6 +1094,165 @@ int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uin
     BWAMS_HIP(hipStreamSynchronize(st));
     for (int64_t k = 0; k < s->al_n; ++k)
         if (aln[k].rid >= 0) aln[k].mapq = regs[(size_t)k].secondary < 0 ? approx_mapq_se(&s->opt, &regs[(size_t)k]) : 0;
+    return BWAMS_OK;
+}
+
+/* ------------------------------------------------------------ SAM text (single-end) ---- */
+
+int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int32_t *name_off) {
+    if (!ix || !names || !name_off) return BWAMS_ERR_ARG;
+    DevBns bns;
+    int rc = dev_bns(ix, &bns);                 // materialises the one-sequence default
+    if (rc) return rc;
+    const int32_t n = ix->n_seqs;
+    for (int32_t i = 0; i < n; ++i)
+        if (name_off[i] < 0 || name_off[i + 1] <= name_off[i] || names[name_off[i + 1] - 1] != 0) {
+            set_last_error("bwams_index_set_contig_names: names must be NUL-terminated, back to back, name_off[n_seqs + 1] ascending");
+            return BWAMS_ERR_ARG;
+        }
+    BWAMS_HIP(hipSetDevice(ix->device));
+    if (ix->d_ctg_names) { (void)hipFree(ix->d_ctg_names); (void)hipFree(ix->d_ctg_off); ix->d_ctg_names = ix->d_ctg_off = nullptr; }
+    BWAMS_HIP(hipMalloc(&ix->d_ctg_names, (size_t)name_off[n]));
+    BWAMS_HIP(hipMalloc(&ix->d_ctg_off, (size_t)(n + 1) * 4));
+    BWAMS_HIP(hipMemcpy(ix->d_ctg_names, names, (size_t)name_off[n], hipMemcpyHostToDevice));
+    BWAMS_HIP(hipMemcpy(ix->d_ctg_off, name_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    return BWAMS_OK;
+}
+
+int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_off, const char *quals, const char *comments,
+                     const int64_t *comment_off) {
+    if (!b || !names || !name_off || (comments && !comment_off)) {
+        set_last_error("bwams_sam_upload: names and their offsets are required; comments come with offsets");
+        return BWAMS_ERR_ARG;
+    }
+    if (b->nseq <= 0 || !b->d_cum) {
+        set_last_error("bwams_sam_upload: upload the reads first (bwams_seed_upload)");
+        return BWAMS_ERR_ARG;
+    }
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    ChainState *s;
+    int rc = get_state(b, &s);
+    if (rc) return rc;
+    hipStream_t st = b->stream;
+    const int64_t nseq = b->nseq, n1 = nseq + 1;
+    if (name_off[0] != 0 || (comments && comment_off[0] != 0)) {
+        set_last_error("bwams_sam_upload: offsets start at 0");
+        return BWAMS_ERR_ARG;
+    }
+    s->sm_up = s->sm_done = false;
+    BWAMS_HIP(s->sm_names.ensure((size_t)name_off[nseq] + 16));
+    BWAMS_HIP(s->sm_noff.ensure((size_t)n1 * 8));
+    BWAMS_HIP(hipMemcpyAsync(s->sm_names.p, names, (size_t)name_off[nseq], hipMemcpyHostToDevice, st));
+    BWAMS_HIP(hipMemcpyAsync(s->sm_noff.p, name_off, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
+    s->sm_has_qual = quals != nullptr;
+    if (quals) {
+        BWAMS_HIP(s->sm_qual.ensure((size_t)b->nbases + 16));
+        BWAMS_HIP(hipMemcpyAsync(s->sm_qual.p, quals, (size_t)b->nbases, hipMemcpyHostToDevice, st));
+    }
+    s->sm_has_comm = comments != nullptr;
+    if (comments) {
+        BWAMS_HIP(s->sm_comm.ensure((size_t)comment_off[nseq] + 16));
+        BWAMS_HIP(s->sm_coff.ensure((size_t)n1 * 8));
+        BWAMS_HIP(hipMemcpyAsync(s->sm_comm.p, comments, (size_t)comment_off[nseq], hipMemcpyHostToDevice, st));
+        BWAMS_HIP(hipMemcpyAsync(s->sm_coff.p, comment_off, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
+    }
+    BWAMS_HIP(hipStreamSynchronize(st));
+    s->sm_nseq = nseq;
+    s->sm_up = true;
+    return BWAMS_OK;
+}
+
+int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, int64_t *sam_bytes) {
+    if (!b || !sopt || !b->chain || !b->chain->al_done || b->chain->al_source != 1 || !b->chain->pr_single) {
+        set_last_error("bwams_sam_run: run bwams_pair_run(BWAMS_PAIR_SINGLE_END) and bwams_reg2aln_run(source 1) first");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    if (!s->sm_up || s->sm_nseq != s->nseq) {
+        set_last_error("bwams_sam_run: run bwams_sam_upload for this chunk first");
+        return BWAMS_ERR_ARG;
+    }
+    if (!b->idx->d_ctg_names) {
+        set_last_error("bwams_sam_run: the index has no sequence names (bwams_index_set_contig_names)");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_sam_run");
+    if (rc) return rc;
+    if (sopt->flag & ~(BWAMS_MEM_F_ALL | BWAMS_MEM_F_NO_MULTI | BWAMS_MEM_F_SOFTCLIP | BWAMS_MEM_F_KEEP_SUPP_MAPQ)) {
+        set_last_error("bwams_sam_run: only MEM_F_ALL, MEM_F_NO_MULTI, MEM_F_SOFTCLIP and MEM_F_KEEP_SUPP_MAPQ are built (no MEM_F_PRIMARY5 / MEM_F_REF_HDR)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    if (!memchr(sopt->rg_id, 0, sizeof sopt->rg_id)) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    s->sm_done = false;
+    const int64_t nseq = s->nseq, n1 = nseq + 1, n = s->al_n;
+    constexpr int kLogN = 1 << 16;
+    if (!s->sm_log_ok) {                                   // log(i) with the C library's log, as the reference's host code computes it
+        std::vector<double> lt((size_t)kLogN);
+        for (int i = 0; i < kLogN; ++i) lt[(size_t)i] = log((double)i);
+        BWAMS_HIP(s->sm_logtab.ensure((size_t)kLogN * 8));
+        BWAMS_HIP(hipMemcpy(s->sm_logtab.p, lt.data(), (size_t)kLogN * 8, hipMemcpyHostToDevice));
+        s->sm_log_ok = true;
+    }
+    BWAMS_HIP(s->sm_mapq.ensure((size_t)(n + 1) * 4));
+    BWAMS_HIP(s->sm_len.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->sm_off.ensure((size_t)n1 * 8));
+    BWAMS_HIP(s->sm_bad.ensure(64));
+    SamArgs A;
+    memset(&A, 0, sizeof A);
+    A.regs = s->pr_out.as<bwams_alnreg_t>(); A.reg_off = s->pr_ooff.as<int64_t>();
+    A.n_regs = n; A.nseq = nseq;
+    A.rec = s->al_rec.as<bwams_aln_t>(); A.cig = s->al_cig.as<uint32_t>(); A.md = s->al_md.as<char>();
+    A.enc = b->d_enc; A.cum = b->d_cum;
+    A.names = s->sm_names.as<char>(); A.name_off = s->sm_noff.as<int64_t>();
+    A.quals = s->sm_has_qual ? s->sm_qual.as<char>() : nullptr;
+    A.comments = s->sm_has_comm ? s->sm_comm.as<char>() : nullptr;
+    A.comment_off = s->sm_has_comm ? s->sm_coff.as<int64_t>() : nullptr;
+    A.ctg_names = reinterpret_cast<const char *>(b->idx->d_ctg_names);
+    A.ctg_off = reinterpret_cast<const int32_t *>(b->idx->d_ctg_off);
+    A.opt = *opt; A.sopt = *sopt;
+    A.logtab = s->sm_logtab.as<double>(); A.logtab_n = kLogN;
+    A.coef_fac = opt->mapq_coef_len > 0 ? log((double)opt->mapq_coef_len) : 0.;
+    A.mapq = s->sm_mapq.as<int32_t>(); A.bad = s->sm_bad.as<unsigned long long>();
+    A.len = s->sm_len.as<int64_t>(); A.out_off = s->sm_off.as<int64_t>(); A.out = nullptr;
+    BWAMS_HIP(hipMemsetAsync(s->sm_bad.p, 0, 8, st));
+    BWAMS_HIP(hipMemsetAsync(s->sm_len.as<int64_t>() + nseq, 0, 8, st));
+    launch_sam_mapq(A, st);
+    launch_sam_text(A, false, b->cu_count, st);
+    if ((rc = scan_rows(b, A.len, s->sm_off.as<int64_t>(), 1, n1))) return rc;
+    int64_t total = 0;
+    unsigned long long bad = 0;
+    BWAMS_HIP(hipMemcpyAsync(&total, s->sm_off.as<int64_t>() + nseq, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipMemcpyAsync(&bad, s->sm_bad.p, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    if (bad) {
+        set_last_error("bwams_sam_run: an alignment longer than 65535 bases (mapping quality table)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    BWAMS_HIP(s->sm_out.ensure((size_t)total + 16));
+    A.out = s->sm_out.as<char>();
+    launch_sam_text(A, true, b->cu_count, st);
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(hipGetLastError());
+    s->sm_bytes = total; s->sm_nregs = n; s->sm_done = true;
+    if (sam_bytes) *sam_bytes = total;
+    return BWAMS_OK;
+}
+
+int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off, int32_t *mapq, int64_t mapq_cap) {
+    if (!b || !b->chain || !b->chain->sm_done) {
+        set_last_error("bwams_sam_fetch: run bwams_sam_run first");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    if ((sam && s->sm_bytes > cap) || (mapq && s->sm_nregs > mapq_cap)) return BWAMS_ERR_CAPACITY;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    if (sam && s->sm_bytes) BWAMS_HIP(hipMemcpyAsync(sam, s->sm_out.p, (size_t)s->sm_bytes, hipMemcpyDeviceToHost, st));
+    if (read_off) BWAMS_HIP(hipMemcpyAsync(read_off, s->sm_off.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (mapq && s->sm_nregs) BWAMS_HIP(hipMemcpyAsync(mapq, s->sm_mapq.p, (size_t)s->sm_nregs * 4, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
     return BWAMS_OK;
 }
 

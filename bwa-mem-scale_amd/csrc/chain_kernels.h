@@ -245,4 +245,35 @@ void launch_aln_run(const RegAlnArgs &A, int cu_count, hipStream_t st);
 void launch_aln_sizes(const RegAlnArgs &A, int64_t *wide, hipStream_t st);
 void launch_aln_gather(const RegAlnArgs &A, const int64_t *offs, uint32_t *cig, char *md, hipStream_t st);
 
+// single-end SAM text (sam_text.hip)
+struct SamArgs {
+    const bwams_alnreg_t *regs;    // final regions after mem_mark_primary_se, grouped by read
+    const int64_t *reg_off;        // nseq + 1
+    int64_t n_regs, nseq;
+    const bwams_aln_t *rec;        // mem_reg2aln records of the same regions, CIGAR and MD pools
+    const uint32_t *cig;
+    const char *md;
+    const uint8_t *enc;
+    const int64_t *cum;
+    const char *names;             // read names back to back, name_off[nseq + 1]
+    const int64_t *name_off;
+    const char *quals;             // laid out like enc, or null
+    const char *comments;          // back to back, comment_off[nseq + 1] (empty = none), or null
+    const int64_t *comment_off;
+    const char *ctg_names;         // NUL-terminated sequence names back to back, ctg_off[rid]
+    const int32_t *ctg_off;
+    bwams_mem_opt_t opt;
+    bwams_sam_opt_t sopt;
+    const double *logtab;          // log(i) from the host's C library
+    int32_t logtab_n;
+    double coef_fac;               // log(mapQ_coef_len)
+    int32_t *mapq;                 // per region
+    unsigned long long *bad;       // regions whose lengths fall outside logtab
+    int64_t *len;                  // per read: bytes of text
+    const int64_t *out_off;
+    char *out;
+};
+void launch_sam_mapq(const SamArgs &A, hipStream_t st);
+void launch_sam_text(const SamArgs &A, bool emit, int cu_count, hipStream_t st);
+
 }  // namespace bwams

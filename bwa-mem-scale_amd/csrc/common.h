@@ -134,6 +134,7 @@ struct bwams_index {
     void *d_all = nullptr, *d_last = nullptr;    // FMA tables (owned)
     void *d_contigs = nullptr;                   // bwams_contig_t[n_seqs] (owned); null = one sequence [0, l_pac)
     int32_t n_seqs = 0;
+    void *d_ctg_names = nullptr, *d_ctg_off = nullptr;   // sequence names for the SAM text (bwams_index_set_contig_names)
 };
 
 namespace bwams {

@@ -1,0 +1,309 @@
+// sam_text.hip — the single-end SAM text of a chunk on the device.
+//
+// Replaces, per read, what worker_sam's single-end branch (/root/reference/src/bwamem.cpp:1836-1844) runs after
+// mem_mark_primary_se:
+//   mem_reg2sam        /root/reference/src/bwamem.cpp:2091-2150      which regions become records, supplementary flag, mapq cap
+//   mem_gen_alt        /root/reference/src/bwamem_extra.cpp:123-187  the XA strings (get_pri_idx)
+//   mem_aln2sam        /root/reference/src/bwamem.cpp:2380-2531      the record itself (m = NULL, V17 build)
+//   mem_approx_mapq_se /root/reference/src/bwamem.cpp:1983-2008      (mem_reg2aln's mapping quality)
+// mem_reg2aln itself — CIGAR, NM, MD, position — ran before (reg2aln.hip); this stage reads its records and pools.
+//
+// Mapping.  Reads are independent and a read's text is a few hundred bytes assembled from many small pieces, so a lane owns a
+// read and runs the reference's control flow twice: once counting bytes (sam_text_kernel<false>), an exclusive scan gives
+// every read its place in one flat buffer, once writing (sam_text_kernel<true>).  Nothing is kept between the passes; the
+// list of selected regions, the XA string of a region and the SA entries are recomputed where the reference looks them up
+// (all O(regions of the read)).  HBM-bound in principle (~0.5 KB read + ~0.35 KB written per read), in practice bound by
+// the byte-granular stores of a lane; it is a fraction of a millisecond per 10^5 reads either way.
+//
+// Mapping quality: mem_approx_mapq_se is a dozen double operations and three logarithms of small integers (the alignment
+// length, seedcov, sub_n + 1).  The logarithms come from a table the host fills with the C library's log(), the arithmetic
+// runs with floating-point contraction off, so the device value is the host's bit for bit (tests compare it against
+// bwams_reg2aln_fetch, which computes it on the host).
+#include <limits.h>
+#include "common.h"
+#include "chain_kernels.h"
+
+namespace bwams {
+namespace {
+
+struct Writer {
+    char *p;                 // nullptr: count only
+    int64_t n;
+    __device__ __forceinline__ void c(char ch) { if (p) p[n] = ch; ++n; }
+    __device__ __forceinline__ void s(const char *q, int64_t len) {
+        if (p) for (int64_t i = 0; i < len; ++i) p[n + i] = q[i];
+        n += len;
+    }
+    __device__ __forceinline__ void z(const char *q) { while (*q) c(*q++); }
+    __device__ void num(long long v) {                   // kputw / kputl (kstring.h:92-141)
+        char buf[24];
+        int l = 0;
+        if (v == 0) { c('0'); return; }
+        unsigned long long x = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        for (; x > 0; x /= 10) buf[l++] = (char)('0' + x % 10);
+        if (v < 0) buf[l++] = '-';
+        while (l > 0) c(buf[--l]);
+    }
+    // printf("%.3f") of a double: the exact binary value rounded to three decimals, ties to even (what glibc prints in the
+    // default rounding mode)
+    __device__ void f3(double x) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+        if (bits >> 63) { c('-'); bits &= ~(1ull << 63); }
+        const int ex = (int)(bits >> 52);
+        unsigned long long m = bits & ((1ull << 52) - 1);
+        int e;                                            // x = m * 2^e
+        if (ex == 0) e = -1074; else { m |= 1ull << 52; e = ex - 1075; }
+        unsigned long long N;
+        if (e >= 0) N = (m << (e > 10 ? 10 : e)) * 1000ull;      // (not reached by score / alt_sc: quotients below 2^31)
+        else {
+            const unsigned long long P = m * 1000ull;    // < 2^63
+            const int sh = -e;
+            if (sh >= 64) N = 0;
+            else {
+                N = P >> sh;
+                const unsigned long long rem = P & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+                if (rem > half || (rem == half && (N & 1ull))) ++N;
+            }
+        }
+        num((long long)(N / 1000ull));
+        c('.');
+        const int fr = (int)(N % 1000ull);
+        c((char)('0' + fr / 100)); c((char)('0' + fr / 10 % 10)); c((char)('0' + fr % 10));
+    }
+};
+
+__device__ __forceinline__ bool reg_is_alt(const bwams_alnreg_t &p) { return (((uint32_t)p.n_comp_is_alt >> 30) & 3u) != 0; }
+
+// mem_approx_mapq_se (bwamem.cpp:1983-2008); log(i) = lt[i]
+__device__ int approx_mapq_se_dev(const bwams_mem_opt_t &opt, const bwams_alnreg_t &a, const double *__restrict__ lt, int lt_n,
+                                  double coef_fac, unsigned long long *bad) {
+#pragma clang fp contract(off)
+    int mapq, l, sub = a.sub ? a.sub : opt.min_seed_len * opt.a;
+    double identity;
+    const int coef_len = opt.mapq_coef_len;
+    sub = a.csub > sub ? a.csub : sub;
+    if (sub >= a.score) return 0;
+    l = a.qe - a.qb > a.re - a.rb ? a.qe - a.qb : (int)(a.re - a.rb);
+    if (l < 0 || l >= lt_n || a.seedcov < 0 || a.seedcov >= lt_n || a.sub_n + 1 >= lt_n) { atomicAdd(bad, 1ull); return 0; }
+    identity = 1. - (double)(l * opt.a - a.score) / (opt.a + opt.b) / l;
+    if (a.score == 0) mapq = 0;
+    else if (coef_len > 0) {
+        double tmp = l < coef_len ? 1. : coef_fac / lt[l];
+        tmp *= identity * identity;
+        mapq = (int)(6.02 * (a.score - sub) / opt.a * tmp * tmp + .499);
+    } else {
+        mapq = (int)(30.0 * (1. - (double)sub / a.score) * lt[a.seedcov] + .499);
+        mapq = identity < 0.95 ? (int)(mapq * identity * identity + .499) : mapq;
+    }
+    if (a.sub_n > 0) mapq -= (int)(4.343 * lt[a.sub_n + 1] + .499);
+    if (mapq > 60) mapq = 60;
+    if (mapq < 0) mapq = 0;
+    mapq = (int)(mapq * (1. - a.frac_rep) + .499);
+    return mapq;
+}
+
+__global__ void sam_mapq_kernel(SamArgs A) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_regs) return;
+    const bwams_alnreg_t a = A.regs[k];
+    A.mapq[k] = (A.rec[k].rid >= 0 && a.secondary < 0) ? approx_mapq_se_dev(A.opt, a, A.logtab, A.logtab_n, A.coef_fac, A.bad) : 0;
+}
+
+// one read's view
+struct Read {
+    const bwams_alnreg_t *a;     // its regions
+    const bwams_aln_t *rec;      // their mem_reg2aln records
+    const int32_t *mapq;
+    int n;
+    const uint8_t *seq;
+    const char *qual;            // or nullptr
+    int l_seq;
+    const char *name; int l_name;
+    const char *comment; int l_comment;      // l_comment 0: none
+};
+
+// mem_reg2sam's filter (bwamem.cpp:2108-2116)
+__device__ __forceinline__ bool selected(const SamArgs &A, const Read &R, int k) {
+    const bwams_alnreg_t &p = R.a[k];
+    if (p.score < A.sopt.T) return false;
+    if (p.secondary >= 0 && (reg_is_alt(p) || !(A.sopt.flag & BWAMS_MEM_F_ALL))) return false;
+    if (p.secondary >= 0 && p.secondary < INT_MAX && p.score < R.a[p.secondary].score * A.opt.drop_ratio) return false;
+    return true;
+}
+
+// get_pri_idx (bwamem_extra.cpp:123-128)
+__device__ __forceinline__ int pri_idx(const SamArgs &A, const Read &R, int i) {
+    const int k = R.a[i].secondary_all;
+    if (k >= 0 && R.a[i].score >= R.a[k].score * (double)A.sopt.XA_drop_ratio) return k;
+    return -1;
+}
+
+__device__ __forceinline__ const char *ctg_name(const SamArgs &A, int rid) { return A.ctg_names + A.ctg_off[rid]; }
+
+// the mapping quality of the which-th selected record (bwamem.cpp:2123-2128)
+__device__ __forceinline__ int capped_mapq(const SamArgs &A, const Read &R, int k, int which, int mapq0) {
+    const int mq = R.mapq[k];
+    if (!(A.sopt.flag & BWAMS_MEM_F_KEEP_SUPP_MAPQ) && which && !reg_is_alt(R.a[k]) && mq > mapq0) return mapq0;
+    return mq;
+}
+
+__device__ void put_cigar(const SamArgs &A, Writer &W, const bwams_aln_t &t, const char *ops, int hard_rule, int which) {
+    const uint32_t *cg = A.cig + t.cigar_off;
+    for (int i = 0; i < t.n_cigar; ++i) {
+        int c = (int)(cg[i] & 0xf);
+        if (hard_rule && !(A.sopt.flag & BWAMS_MEM_F_SOFTCLIP) && !t.is_alt && (c == 3 || c == 4)) c = which ? 4 : 3;
+        W.num((long long)(cg[i] >> 4));
+        W.c(ops[c]);
+    }
+}
+
+// the XA string of region r as mem_gen_alt builds it; returns whether anything was written
+__device__ bool put_xa(const SamArgs &A, const Read &R, Writer &W, int r, bool with_tag) {
+    int cnt = 0;
+    bool has_alt = false;
+    for (int i = 0; i < R.n; ++i)
+        if (pri_idx(A, R, i) == r) { ++cnt; has_alt |= reg_is_alt(R.a[i]); }
+    if (cnt == 0) return false;
+    if (cnt > A.sopt.max_XA_hits_alt || (!has_alt && cnt > A.sopt.max_XA_hits)) return false;
+    if (with_tag) W.s("\tXA:Z:", 6);
+    for (int i = 0; i < R.n; ++i) {
+        if (pri_idx(A, R, i) != r) continue;
+        const bwams_aln_t &t = R.rec[i];
+        W.z(ctg_name(A, t.rid));
+        W.c(','); W.c("+-"[t.is_rev]); W.num(t.pos + 1);
+        W.c(',');
+        put_cigar(A, W, t, "MIDSHN", 0, 0);
+        W.c(','); W.num(t.NM);
+        W.c(';');
+    }
+    return true;
+}
+
+// mem_aln2sam for the which-th of n_sel records (region k), or the unaligned record (k < 0)
+__device__ void put_record(const SamArgs &A, const Read &R, Writer &W, int k, int which, int mapq0) {
+    bwams_aln_t t;
+    int flag, mapq = 0, sub;
+    if (k >= 0) {
+        t = R.rec[k];
+        flag = t.flag;
+        if (which && R.a[k].secondary < 0) flag |= (A.sopt.flag & BWAMS_MEM_F_NO_MULTI) ? 0x10000 : 0x800;
+        mapq = capped_mapq(A, R, k, which, mapq0);
+        sub = R.a[k].secondary >= 0 ? -1 : t.sub;
+    } else {                                              // mem_reg2aln(ar = 0): everything zero but rid, pos, flag
+        t.pos = -1; t.rid = -1; t.flag = 0x4; t.is_rev = t.is_alt = t.mapq = t.NM = t.n_cigar = t.md_len = 0;
+        t.cigar_off = t.md_off = 0; t.score = t.sub = t.alt_sc = 0; t.pad_ = 0;
+        flag = t.flag; sub = 0;
+    }
+    flag |= t.rid < 0 ? 0x4 : 0;
+    flag |= t.is_rev ? 0x10 : 0;
+    W.s(R.name, R.l_name); W.c('\t');
+    W.num((flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)); W.c('\t');
+    if (t.rid >= 0) {
+        W.z(ctg_name(A, t.rid)); W.c('\t');
+        W.num(t.pos + 1); W.c('\t');
+        W.num(mapq); W.c('\t');
+        if (t.n_cigar) put_cigar(A, W, t, "MIDSH", 1, which);
+        else W.c('*');
+    } else W.s("*\t0\t0\t*", 7);
+    W.c('\t');
+    W.s("*\t0\t0", 5);
+    W.c('\t');
+    if (flag & 0x100) {
+        W.s("*\t*", 3);
+    } else {
+        int qb = 0, qe = R.l_seq;
+        if (t.n_cigar && which && !(A.sopt.flag & BWAMS_MEM_F_SOFTCLIP) && !t.is_alt) {
+            const uint32_t c0 = A.cig[t.cigar_off], c1 = A.cig[t.cigar_off + t.n_cigar - 1];
+            const int lead = ((c0 & 0xf) == 4 || (c0 & 0xf) == 3) ? (int)(c0 >> 4) : 0;
+            const int tail = ((c1 & 0xf) == 4 || (c1 & 0xf) == 3) ? (int)(c1 >> 4) : 0;
+            if (!t.is_rev) { qb += lead; qe -= tail; } else { qe -= lead; qb += tail; }
+        }
+        if (!t.is_rev) {
+            for (int i = qb; i < qe; ++i) W.c("ACGTN"[R.seq[i]]);
+            W.c('\t');
+            if (R.qual) W.s(R.qual + qb, qe > qb ? qe - qb : 0); else W.c('*');
+        } else {
+            for (int i = qe - 1; i >= qb; --i) W.c("TGCAN"[R.seq[i]]);
+            W.c('\t');
+            if (R.qual) { for (int i = qe - 1; i >= qb; --i) W.c(R.qual[i]); } else W.c('*');
+        }
+    }
+    if (t.n_cigar) {
+        W.s("\tNM:i:", 6); W.num(t.NM);
+        W.s("\tMD:Z:", 6); W.s(A.md + t.md_off, t.md_len > 0 ? t.md_len - 1 : 0);
+    }
+    if (t.score >= 0) { W.s("\tAS:i:", 6); W.num(t.score); }
+    if (sub >= 0) { W.s("\tXS:i:", 6); W.num(sub); }
+    if (A.sopt.rg_id[0]) { W.s("\tRG:Z:", 6); W.z(A.sopt.rg_id); }
+    if (!(flag & 0x100)) {
+        bool other = false;
+        if (k >= 0)
+            for (int i = 0; i < R.n && !other; ++i)
+                other = i != k && selected(A, R, i) && !(R.rec[i].flag & 0x100);
+        if (other) {
+            W.s("\tSA:Z:", 6);
+            int wi = 0;
+            for (int i = 0; i < R.n; ++i) {
+                if (!selected(A, R, i)) continue;
+                const int w_i = wi++;
+                const bwams_aln_t &r = R.rec[i];
+                if (i == k || (r.flag & 0x100)) continue;
+                W.z(ctg_name(A, r.rid)); W.c(',');
+                W.num(r.pos + 1); W.c(',');
+                W.c("+-"[r.is_rev]); W.c(',');
+                put_cigar(A, W, r, "MIDSH", 0, 0);
+                W.c(','); W.num(capped_mapq(A, R, i, w_i, mapq0));
+                W.c(','); W.num(r.NM);
+                W.c(';');
+            }
+        }
+        if (t.alt_sc > 0) { W.s("\tpa:f:", 6); W.f3((double)t.score / t.alt_sc); }
+    }
+    if (k >= 0 && !(A.sopt.flag & BWAMS_MEM_F_ALL)) put_xa(A, R, W, k, true);
+    if (R.l_comment) { W.c('\t'); W.s(R.comment, R.l_comment); }
+    W.c('\n');
+}
+
+template <bool EMIT>
+__global__ void sam_text_kernel(SamArgs A) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.nseq; r += (int64_t)gridDim.x * blockDim.x) {
+        Read R;
+        const int64_t o = A.reg_off[r];
+        R.a = A.regs + o; R.rec = A.rec + o; R.mapq = A.mapq + o; R.n = (int)(A.reg_off[r + 1] - o);
+        R.seq = A.enc + A.cum[r]; R.l_seq = (int)(A.cum[r + 1] - A.cum[r]);
+        R.qual = A.quals ? A.quals + A.cum[r] : nullptr;
+        R.name = A.names + A.name_off[r]; R.l_name = (int)(A.name_off[r + 1] - A.name_off[r]);
+        R.comment = A.comments ? A.comments + A.comment_off[r] : nullptr;
+        R.l_comment = A.comments ? (int)(A.comment_off[r + 1] - A.comment_off[r]) : 0;
+        Writer W;
+        W.p = EMIT ? A.out + A.out_off[r] : nullptr;
+        W.n = 0;
+        int first = -1;
+        for (int k = 0; k < R.n && first < 0; ++k)
+            if (selected(A, R, k)) first = k;
+        if (first < 0) put_record(A, R, W, -1, 0, 0);
+        else {
+            const int mapq0 = R.mapq[first];
+            int which = 0;
+            for (int k = first; k < R.n; ++k)
+                if (selected(A, R, k)) put_record(A, R, W, k, which++, mapq0);
+        }
+        if (!EMIT) A.len[r] = W.n;
+    }
+}
+
+}  // namespace
+
+void launch_sam_mapq(const SamArgs &A, hipStream_t st) {
+    if (A.n_regs > 0) sam_mapq_kernel<<<(unsigned)((A.n_regs + 255) / 256), 256, 0, st>>>(A);
+}
+void launch_sam_text(const SamArgs &A, bool emit, int cu_count, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    int64_t blocks = (A.nseq + 63) / 64;
+    const int64_t cap = (int64_t)cu_count * 32;
+    if (blocks > cap) blocks = cap;
+    if (emit) sam_text_kernel<true><<<(unsigned)blocks, 64, 0, st>>>(A);
+    else sam_text_kernel<false><<<(unsigned)blocks, 64, 0, st>>>(A);
+}
+
+}  // namespace bwams

@@ -223,6 +223,27 @@ int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t sour
 int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uint32_t *cigar, int64_t cigar_cap, char *md,
                         int64_t md_cap);
 
+/* ------------------------------------------------------ SAM text, single-end ---- *
+ * The text worker_sam's single-end branch leaves in seqs[i].sam (src/bwamem.cpp:1836-1844): per read, mem_reg2sam
+ * (src/bwamem.cpp:2091-2150: which regions become records, supplementary flag 0x800 / 0x10000, the mapq cap of later records),
+ * mem_gen_alt (src/bwamem_extra.cpp:123-187: the XA strings) and mem_aln2sam with m = NULL (src/bwamem.cpp:2380-2531: the
+ * eleven fields, NM / MD / AS / XS / RG / SA / pa / XA tags, the comment), with mem_approx_mapq_se (:1983-2008) evaluated on the
+ * device.  Call order for a chunk: ... bwams_dedup_run, bwams_pair_run(BWAMS_PAIR_SINGLE_END) (= mem_mark_primary_se),
+ * bwams_reg2aln_run(source 1), bwams_sam_upload (names / qualities / comments of the chunk: the bseq1_t fields the hot path
+ * never needed), bwams_sam_run, bwams_sam_fetch.  Not built: MEM_F_PRIMARY5 (mem_reorder_primary5), MEM_F_REF_HDR, the
+ * paired-end text (mem_sam_pe) and the exact-match records (mem_aln2sam_perfect): BWAMS_ERR_UNSUPPORTED / host side. */
+/* names of the index's sequences (bntann1_t.name): NUL-terminated, back to back; name_off[n_seqs + 1], name_off[i] = start of
+ * name i.  Call after bwams_index_set_contigs (or on a one-sequence index). */
+int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int32_t *name_off);
+/* names: the reads' names back to back (no terminators), name_off[nseq + 1]; quals: one byte per base laid out like the reads
+ * (cum_len), or NULL ('*'); comments (+ comment_off[nseq + 1], an empty comment = none) or NULL. */
+int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_off, const char *quals, const char *comments,
+                     const int64_t *comment_off);
+int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, int64_t *sam_bytes);
+/* sam: the text of all reads in read order (cap >= sam_bytes); read_off[nseq + 1]: where a read's lines start; mapq: the
+ * device-side mem_approx_mapq_se of every region (region order of bwams_reg2aln_fetch).  Any of the three may be NULL. */
+int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off, int32_t *mapq, int64_t mapq_cap);
+
 /* ----------------------------------------------------------- mate rescue ---- */
 
 /* Local Smith-Waterman of mate rescue over n tasks: out[i] = ksw_align2(len2, qer + idq,

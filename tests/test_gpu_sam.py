@@ -1,0 +1,109 @@
+"""bwams_sam_run — the single-end SAM text on the device (mem_reg2sam + mem_gen_alt + mem_aln2sam, mapping quality included) —
+against the oracle's restatement on the very regions the device holds: byte for byte, read by read."""
+import numpy as np
+import pytest
+
+from bwams import capi, simulate
+from oracle import loader
+from test_oracle_sam import repeat_genome
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipeline(n_reads, seed, contigs=None, contig_names=None, read_len=None, **optkw):
+    g, idx, starts = repeat_genome()
+    oopt, gopt = loader.default_mem_opt(), capi.default_mem_opt()
+    for k, v in optkw.items():
+        setattr(oopt, k, v); setattr(gopt, k, v)
+    reads, _, _ = simulate.make_reads(g, n_reads, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    for i in range(0, n_reads, 3):
+        st = starts[int(rng.integers(0, len(starts)))] + int(rng.integers(0, 500 - reads.shape[1]))
+        rd = g[st:st + reads.shape[1]].copy()
+        reads[i] = (3 - rd[::-1]).astype(np.uint8) if rng.random() < 0.5 else rd
+    reads = [r for r in reads]
+    reads[5] = rng.integers(0, 4, size=150, dtype=np.uint8)            # unalignable
+    reads[6] = np.full(150, 4, np.uint8)                               # all N
+    ix = capi.Index.from_host(idx, 0)
+    if contigs is not None:
+        ix.set_contigs(contigs)
+    names_c = contig_names or [b"chr1"]
+    ix.set_contig_names(names_c)
+    enc, cum = simulate.flatten_reads(np.stack(reads))
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.seed_run(capi.default_seed_opt(), with_sa=True)
+    b.chain_run(gopt); b.extend_run(gopt); b.dedup_run(gopt)
+    ID0 = 77_000
+    b.mark_primary_se(gopt, id_base=ID0)
+    regs, off, _ = b.pair_fetch()
+    aln, cig, md = b.reg2aln(gopt, 1)
+    quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+    names = [b"r%d/x" % i for i in range(len(reads))]
+    comments = [b"BC:Z:%d" % i if i % 4 == 0 else None for i in range(len(reads))]
+    return dict(g=g, idx=idx, ix=ix, b=b, enc=enc, cum=cum, regs=regs, off=off, aln=aln, quals=quals, names=names, comments=comments,
+                oopt=oopt, gopt=gopt, contigs=contigs, contig_names=names_c)
+
+
+def _compare(c, flag=0, rg=b"", quals=True, comments=True, T=None):
+    b = c["b"]
+    so, sg = loader.default_sam_opt(flag, rg), capi.default_sam_opt(flag, rg)
+    if T is not None:
+        so.T = sg.T = T
+    b.sam_upload(c["names"], c["quals"] if quals else None, c["comments"] if comments else None)
+    nbytes = b.sam_run(c["gopt"], sg)
+    text, roff, mq = b.sam_fetch(len(c["regs"]))
+    want = loader.reg2sam_se(c["regs"], c["off"], c["enc"], c["cum"], c["idx"].ref_0123, len(c["g"]), c["names"],
+                             quals=c["quals"] if quals else None, comments=c["comments"] if comments else None, contigs=c["contigs"],
+                             contig_names=c["contig_names"], opt=c["oopt"], sopt=so)
+    assert nbytes == sum(len(w) for w in want) == roff[-1] and roff[0] == 0
+    for r, w in enumerate(want):
+        got = text[roff[r]:roff[r + 1]]
+        assert got == w, (r, got, w)
+    # the device's mem_approx_mapq_se equals the host's (bwams_reg2aln_fetch) on every region
+    assert np.array_equal(mq, c["aln"]["mapq"])
+    return text
+
+
+def test_sam_text_equals_oracle():
+    c = _pipeline(900, 5)
+    text = _compare(c)
+    assert text.count(b"\tXA:Z:") > 20 and text.count(b"\tSA:Z:") >= 0 and b"\t4\t*\t0\t0\t*\t" in text
+    assert text.count(b"\n") >= 900
+    for flag, rg in ((0x8, b"grp"), (0x200, b""), (0x10, b""), (0x1000 | 0x10 | 0x200, b"lane7")):
+        _compare(c, flag, rg)
+    _compare(c, quals=False, comments=False)
+    _compare(c, T=10 ** 6)                       # nothing passes: every read unaligned
+    _compare(c, T=0)
+    c["b"].close(); c["ix"].close()
+
+
+def test_sam_text_contigs_alt_and_scoring():
+    g, _, _ = repeat_genome()
+    l_pac = len(g)
+    contigs = np.zeros(3, capi.CONTIG_DTYPE)
+    cut1, cut2 = l_pac // 2, l_pac * 3 // 4
+    contigs["offset"] = [0, cut1, cut2]
+    contigs["len"] = [cut1, cut2 - cut1, l_pac - cut2]
+    contigs["is_alt"] = [0, 0, 1]
+    c = _pipeline(700, 9, contigs=contigs, contig_names=[b"chrA", b"chrB_longer_name", b"chrB_alt"])
+    text = _compare(c)
+    assert b"chrB_alt" in text and b"\tpa:f:" in text
+    _compare(c, 0x8)
+    c["b"].close(); c["ix"].close()
+    c = _pipeline(500, 13, a=2, b=5, o_del=7, e_del=2, mapq_coef_len=0)
+    _compare(c)
+    c["b"].close(); c["ix"].close()
+
+
+def test_sam_text_call_order_and_unsupported_flags():
+    c = _pipeline(64, 3)
+    b = c["b"]
+    b.sam_upload(c["names"], c["quals"])
+    with pytest.raises(capi.BwamsError):
+        b.sam_run(c["gopt"], capi.default_sam_opt(0x800))            # MEM_F_PRIMARY5
+    b.dedup_run(c["gopt"])
+    b.reg2aln(c["gopt"], 0)                                          # regions without mem_mark_primary_se
+    with pytest.raises(capi.BwamsError):
+        b.sam_run(c["gopt"], capi.default_sam_opt())
+    b.close(); c["ix"].close()

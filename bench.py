@@ -424,8 +424,44 @@ def main():
                 "Malignments_per_s": round(n_aln.value / (reg2aln_run_ms * 1e-3) / 1e6, 2) if reg2aln_run_ms > 0 else None,
                 "note": "single-end SAM side of one chunk on the device: mem_mark_primary_se of every read, then mem_reg2aln (band inference, "
                         "banded global alignment with traceback, CIGAR / NM / MD, position) of every final region; mapping quality on the host "
-                        "side of the library; XA and SAM text are not built"}
-    del aln_, cig_, md_
+                        "side of the library"}
+    # the SAM text of the chunk (mem_reg2sam + mem_gen_alt + mem_aln2sam on the device), with size-independent checks
+    cum_ = cums[n_chunks - 1]
+    n_seq_ = len(cum_) - 1
+    names_ = [b"read%d" % (first + i) for i in range(n_seq_)]
+    quals_ = np.full(int(cum_[-1]), ord("I"), np.uint8)
+    ix.set_contig_names([b"chr%d" % (i + 1) for i in range(len(contigs) if contigs is not None else 1)])
+    t0 = time.perf_counter()
+    batch.sam_upload(names_, quals_)
+    sam_up_ms = (time.perf_counter() - t0) * 1e3
+    sopt_ = capi.default_sam_opt()
+    batch.sam_run(mem_opt, sopt_)
+    t0 = time.perf_counter()
+    sam_bytes = batch.sam_run(mem_opt, sopt_)
+    sam_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    text_, roff_, mq_ = batch.sam_fetch(len(aln_))
+    sam_fetch_ms = (time.perf_counter() - t0) * 1e3
+    tb = np.frombuffer(text_, np.uint8)
+    n_lines = int((tb == 10).sum())
+    n_tabs = int((tb == 9).sum())
+    checks = {
+        "device_mapq_equals_host_mapq": bool(np.array_equal(mq_, aln_["mapq"])),
+        "one_block_per_read": bool(roff_[0] == 0 and roff_[-1] == sam_bytes and np.all(np.diff(roff_) > 0)),
+        "every_block_ends_a_line": bool(np.all(tb[roff_[1:] - 1] == 10)),
+        "lines_at_least_reads": n_lines >= n_seq_,
+        "eleven_fields_per_line": n_tabs >= 10 * n_lines,
+    }
+    sam_side["sam_text"] = {"bytes": int(sam_bytes), "lines": n_lines, "ms_run": round(sam_ms, 2), "ms_upload_names_quals": round(sam_up_ms, 2),
+                            "ms_fetch": round(sam_fetch_ms, 2), "Mreads_per_s": round(n_seq_ / (sam_ms * 1e-3) / 1e6, 2) if sam_ms > 0 else None,
+                            "GBps_written": round(sam_bytes / (sam_ms * 1e-3) / 1e9, 2) if sam_ms > 0 else None,
+                            "xa_tags": int(text_.count(b"\tXA:Z:")), "unaligned_records": int(text_.count(b"\t4\t*\t0\t0\t*\t")),
+                            "checks": checks,
+                            "note": "mem_reg2sam + mem_gen_alt + mem_aln2sam (single-end) and mem_approx_mapq_se on the device, names "
+                                    "and qualities already in HBM when timed; byte-equal to the oracle in tests/test_gpu_sam.py"}
+    if not all(checks.values()):
+        raise SystemExit(f"[bench] SAM text property check failed: {checks}")
+    del aln_, cig_, md_, text_, tb, mq_
 
     # ---------------- paired-end leg (every rank: the pestat exchange is a collective) ----------------
     pe_out = None
@@ -524,7 +560,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int64 intervals / int32 DP",
             "data": "synthetic",
-            "not_included": ["mem_mark_primary_se + mem_reg2aln / ksw_global2 traceback / CIGAR (timed beside: sam_side)", "XA + SAM text", "FASTQ decode and host I/O",
+            "not_included": ["mem_mark_primary_se + mem_reg2aln / ksw_global2 traceback / CIGAR + XA + SAM text (timed beside: sam_side)", "FASTQ decode and host I/O",
                              "PCIe transfers (see pcie_inclusive with --pcie)"],
             "config": {
                 "workload": f"{total_reads} synthetic 150bp SE reads ({R} per GPU, {n_chunks} resident chunk(s) of <= {CH}) vs a synthetic {G} bp genome "

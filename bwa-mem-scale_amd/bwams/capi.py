@@ -26,7 +26,8 @@ SYMBOLS = [
     "bwams_strerror", "bwams_last_error", "bwams_device_count",
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch",
-    "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_fetch", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_fetch",
+    "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
     "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
@@ -100,6 +101,48 @@ class FmiDesc(C.Structure):
     _fields_ = [("ref_seq_len", C.c_int64), ("count", C.c_int64 * 5),
                 ("cp_occ", C.c_void_p), ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p),
                 ("sentinel_index", C.c_int64), ("ref_0123", C.c_void_p)]
+
+
+class Fastq:
+    """A decoded FASTQ buffer resident on the GPU (bwams_fastq_t)."""
+
+    def __init__(self, text, device: int = 0, n_bytes: int | None = None):
+        """text: bytes (host) or an int device address with n_bytes."""
+        self.h = C.c_void_p()
+        n, nb = C.c_int64(0), C.c_int64(0)
+        if isinstance(text, int):
+            rc = lib().bwams_fastq_decode(device, C.c_void_p(text), C.c_int64(n_bytes), C.byref(self.h), C.byref(n), C.byref(nb))
+        else:
+            rc = lib().bwams_fastq_decode(device, text, C.c_int64(len(text)), C.byref(self.h), C.byref(n), C.byref(nb))
+        _chk(rc, "bwams_fastq_decode")
+        self.n_reads, self.n_bases = n.value, nb.value
+
+    def info(self):
+        n, nb, nn, nc, ms = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_float(0)
+        _chk(lib().bwams_fastq_info(self.h, C.byref(n), C.byref(nb), C.byref(nn), C.byref(nc), C.byref(ms)), "bwams_fastq_info")
+        return dict(n_reads=n.value, n_bases=nb.value, name_bytes=nn.value, comment_bytes=nc.value, ms=ms.value)
+
+    def fetch(self):
+        i = self.info()
+        n1 = i["n_reads"] + 1
+        enc = np.zeros(max(i["n_bases"], 1), np.uint8); qual = np.zeros(max(i["n_bases"], 1), np.uint8)
+        names = np.zeros(max(i["name_bytes"], 1), np.uint8); comm = np.zeros(max(i["comment_bytes"], 1), np.uint8)
+        cum = np.zeros(n1, np.int64); noff = np.zeros(n1, np.int64); coff = np.zeros(n1, np.int64)
+        _chk(lib().bwams_fastq_fetch(self.h, _p(enc), _p(cum), _p(names), _p(noff), _p(qual), _p(comm), _p(coff)), "bwams_fastq_fetch")
+        nb_, cb_ = bytes(names[:i["name_bytes"]]), bytes(comm[:i["comment_bytes"]])
+        return dict(n=i["n_reads"], enc=enc[:i["n_bases"]], cum=cum, quals=qual[:i["n_bases"]],
+                    names=[nb_[noff[k]:noff[k + 1]] for k in range(i["n_reads"])],
+                    comments=[cb_[coff[k]:coff[k + 1]] or None for k in range(i["n_reads"])])
+
+    def to_batch(self, batch: "Batch"):
+        """bwams_seed_upload + bwams_sam_upload of the decoded chunk, device to device."""
+        _chk(lib().bwams_fastq_to_batch(self.h, batch.h), "bwams_fastq_to_batch")
+        batch._nseq = self.n_reads
+
+    def close(self):
+        if self.h:
+            lib().bwams_fastq_close(self.h)
+            self.h = C.c_void_p()
 
 
 class SamOpt(C.Structure):

@@ -1142,18 +1142,18 @@ int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_of
     s->sm_up = s->sm_done = false;
     BWAMS_HIP(s->sm_names.ensure((size_t)name_off[nseq] + 16));
     BWAMS_HIP(s->sm_noff.ensure((size_t)n1 * 8));
-    BWAMS_HIP(hipMemcpyAsync(s->sm_names.p, names, (size_t)name_off[nseq], hipMemcpyHostToDevice, st));
+    BWAMS_HIP(hipMemcpyAsync(s->sm_names.p, names, (size_t)name_off[nseq], hipMemcpyDefault, st));
     BWAMS_HIP(hipMemcpyAsync(s->sm_noff.p, name_off, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
     s->sm_has_qual = quals != nullptr;
     if (quals) {
         BWAMS_HIP(s->sm_qual.ensure((size_t)b->nbases + 16));
-        BWAMS_HIP(hipMemcpyAsync(s->sm_qual.p, quals, (size_t)b->nbases, hipMemcpyHostToDevice, st));
+        BWAMS_HIP(hipMemcpyAsync(s->sm_qual.p, quals, (size_t)b->nbases, hipMemcpyDefault, st));
     }
     s->sm_has_comm = comments != nullptr;
     if (comments) {
         BWAMS_HIP(s->sm_comm.ensure((size_t)comment_off[nseq] + 16));
         BWAMS_HIP(s->sm_coff.ensure((size_t)n1 * 8));
-        BWAMS_HIP(hipMemcpyAsync(s->sm_comm.p, comments, (size_t)comment_off[nseq], hipMemcpyHostToDevice, st));
+        BWAMS_HIP(hipMemcpyAsync(s->sm_comm.p, comments, (size_t)comment_off[nseq], hipMemcpyDefault, st));
         BWAMS_HIP(hipMemcpyAsync(s->sm_coff.p, comment_off, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
     }
     BWAMS_HIP(hipStreamSynchronize(st));

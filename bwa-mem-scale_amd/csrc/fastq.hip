@@ -1,0 +1,293 @@
+// fastq.hip — read input on the device: a buffer of FASTQ text becomes the arrays the hot path and the SAM stage take.
+//
+// Replaces, for a buffer of whole records,
+//   kseq_read                 /root/reference/src/kseq.h:358-400   (header '@', name up to the first isspace(), comment = rest of the
+//                                                                   line, sequence, '+' line, quality; a line loses one trailing
+//                                                                   '\r' when longer than one byte)
+//   trim_readno, kseq2bseq1   /root/reference/src/bwa.cpp:74-153   ("/<digit>" name suffix; empty comment = none)
+//   the base encoding         /root/reference/src/bwamem.cpp:1232  (seq[i] < 4 ? seq[i] : nst_nt4_table[seq[i]], bntseq.cpp:64-81)
+// as bseq_read_orig (bwa.cpp:266-335) applies them per record.  kseq_read is a byte-serial state machine; its grammar also
+// admits multi-line records, FASTA records and blank lines.  The device path takes the shape sequencers write — four lines per
+// record — where every record is found from the line index alone, checks per record that the serial reader would have seen the
+// same thing ('@' and '+' where they belong, equal sequence and quality lengths, no sequence line starting with '>', '+' or
+// '@'), and returns BWAMS_ERR_UNSUPPORTED for any other input (the caller then reads that file on the host).
+//
+// Mapping.  HBM-bound streaming, three passes over the text: (1) the positions of the line ends (rocPRIM select over a counting
+// iterator), (2) a lane per record: validate, measure name / comment / sequence, (3) after three exclusive scans, a WAVE per
+// record copies name, comment and quality and encodes the bases, 64 bytes per step.  Algorithmic bytes: 3 reads of the text + 1
+// write of ~0.9 of it.
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <memory>
+#include <string>
+#include <vector>
+#include "common.h"
+
+struct bwams_fastq {
+    int device = 0;
+    int64_t n_reads = 0, n_bases = 0, name_bytes = 0, comment_bytes = 0;
+    void *d_enc = nullptr, *d_qual = nullptr, *d_names = nullptr, *d_comments = nullptr;
+    std::vector<int64_t> cum, name_off, comment_off;       // host copies of the three offset arrays
+    float ms = 0;
+};
+
+namespace bwams {
+namespace {
+
+struct IsLineEnd {
+    const char *text;
+    __device__ bool operator()(const int64_t &i) const { return text[i] == '\n'; }
+};
+
+__device__ __forceinline__ bool is_space(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }   // isspace(), "C" locale
+
+__constant__ unsigned char kNt4[256] = {
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,5,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
+    4,0,4,1,4,4,4,2,4,4,4,4,4,4,4,4, 4,4,4,4,3,4,4,4,4,4,4,4,4,4,4,4, 4,0,4,1,4,4,4,2,4,4,4,4,4,4,4,4, 4,4,4,4,3,4,4,4,4,4,4,4,4,4,4,4,
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4, 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4};
+
+__global__ __launch_bounds__(256) void fastq_count_kernel(const char *__restrict__ text, int64_t n, unsigned long long *cnt) {
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) c += text[i] == '\n';
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, c);
+}
+
+struct Rec {                      // where the pieces of a record lie in the text
+    int64_t name_at, comment_at, seq_at, qual_at;
+    int32_t l_name, l_comment, l_seq;
+    int32_t pad_;
+};
+
+// line j spans [start(j), end(j)): ends[j] is the position of its '\n' (or the text length for an unterminated last line)
+__global__ void fastq_measure_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_lines,
+                                     int64_t n_rec, Rec *__restrict__ rec, int64_t *__restrict__ wide, unsigned long long *bad) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rec) return;
+    if (r == n_rec) { wide[r] = wide[n_rec + 1 + r] = wide[2 * (n_rec + 1) + r] = 0; return; }
+    int64_t b[4], e[4];
+    for (int k = 0; k < 4; ++k) {
+        const int64_t j = 4 * r + k;
+        b[k] = j ? ends[j - 1] + 1 : 0;
+        e[k] = j < n_lines ? ends[j] : n_bytes;
+    }
+    bool ok = e[0] > b[0] && text[b[0]] == '@' && e[2] > b[2] && text[b[2]] == '+';
+    Rec R;
+    // name: up to the first isspace() of the header line; the delimiter decides whether a comment follows
+    int64_t p = b[0] + 1;
+    while (p < e[0] && !is_space((unsigned char)text[p])) ++p;
+    R.name_at = b[0] + 1;
+    int l_name = (int)(p - (b[0] + 1));
+    if (l_name > 2 && text[R.name_at + l_name - 2] == '/' && text[R.name_at + l_name - 1] >= '0' && text[R.name_at + l_name - 1] <= '9') l_name -= 2;
+    R.l_name = l_name;
+    R.comment_at = p < e[0] ? p + 1 : e[0];
+    int l_comment = p < e[0] ? (int)(e[0] - (p + 1)) : 0;
+    if (l_comment > 1 && text[R.comment_at + l_comment - 1] == '\r') --l_comment;
+    R.l_comment = l_comment;
+    int l_seq = (int)(e[1] - b[1]), l_qual = (int)(e[3] - b[3]);
+    if (l_seq > 1 && text[e[1] - 1] == '\r') --l_seq;
+    if (l_qual > 1 && text[e[3] - 1] == '\r') --l_qual;
+    if (l_seq > 0) {
+        const char c0 = text[b[1]];
+        ok = ok && c0 != '>' && c0 != '+' && c0 != '@';
+    }
+    ok = ok && l_seq == l_qual;
+    R.seq_at = b[1]; R.qual_at = b[3]; R.l_seq = l_seq; R.pad_ = 0;
+    rec[r] = R;
+    wide[r] = l_name; wide[n_rec + 1 + r] = l_comment; wide[2 * (n_rec + 1) + r] = l_seq;
+    if (!ok) atomicAdd(bad, 1ull);
+}
+
+__global__ __launch_bounds__(256) void fastq_emit_kernel(const char *__restrict__ text, const Rec *__restrict__ rec, int64_t n_rec,
+                                                         const int64_t *__restrict__ offs, char *__restrict__ names, char *__restrict__ comments,
+                                                         uint8_t *__restrict__ enc, char *__restrict__ qual, unsigned long long *dash) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long n_dash = 0;
+    for (int64_t r = wave; r < n_rec; r += n_waves) {
+        const Rec R = rec[r];
+        const int64_t no = offs[r], co = offs[n_rec + 1 + r], so = offs[2 * (n_rec + 1) + r];
+        for (int i = lane; i < R.l_name; i += 64) names[no + i] = text[R.name_at + i];
+        for (int i = lane; i < R.l_comment; i += 64) comments[co + i] = text[R.comment_at + i];
+        for (int i = lane; i < R.l_seq; i += 64) {
+            const unsigned char c = (unsigned char)text[R.seq_at + i];
+            const unsigned char v = c < 4 ? c : kNt4[c];
+            n_dash += v > 4;
+            enc[so + i] = v;
+            qual[so + i] = text[R.qual_at + i];
+        }
+    }
+    if (__any(n_dash != 0) && n_dash) atomicAdd(dash, n_dash);
+}
+
+}  // namespace
+}  // namespace bwams
+
+using namespace bwams;
+
+extern "C" {
+
+int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fastq_t **out, int64_t *n_reads, int64_t *n_bases) {
+    if (!text || n_bytes < 0 || !out) return BWAMS_ERR_ARG;
+    *out = nullptr;
+    BWAMS_HIP(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    std::unique_ptr<bwams_fastq> f(new bwams_fastq());
+    f->device = device;
+    hipEvent_t e0, e1;
+    BWAMS_HIP(hipEventCreate(&e0)); BWAMS_HIP(hipEventCreate(&e1));
+    // the text may already be in this GPU's memory (the copy kind is inferred)
+    char *d_text = nullptr;
+    hipPointerAttribute_t attr;
+    const bool on_dev = hipPointerGetAttributes(&attr, text) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    void *d_own = nullptr;
+    if (on_dev) d_text = const_cast<char *>(text);
+    else {
+        BWAMS_HIP(hipMalloc(&d_own, (size_t)n_bytes + 16));
+        d_text = reinterpret_cast<char *>(d_own);
+        if (n_bytes) BWAMS_HIP(hipMemcpy(d_text, text, (size_t)n_bytes, hipMemcpyHostToDevice));
+    }
+    struct Scratch {
+        std::vector<void *> p;
+        ~Scratch() { for (void *q : p) if (q) (void)hipFree(q); }
+    } scr;
+    scr.p.push_back(d_own);
+    BWAMS_HIP(hipEventRecord(e0, st));
+    // (1) line ends
+    int64_t *d_ends = nullptr, *d_cnt = nullptr;
+    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_cnt), 64)); scr.p.push_back(d_cnt);
+    int64_t n_nl = 0;
+    char last = '\n';
+    if (n_bytes) {
+        // count first: the array of line ends is sized exactly
+        BWAMS_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
+        fastq_count_kernel<<<256 * 8, 256, 0, st>>>(d_text, n_bytes, reinterpret_cast<unsigned long long *>(d_cnt));
+        BWAMS_HIP(hipMemcpyAsync(&n_nl, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        size_t tb = 0;
+        rocprim::counting_iterator<int64_t> it(0);
+        IsLineEnd pred{d_text};
+        BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_ends), (size_t)(n_nl + 16) * 8)); scr.p.push_back(d_ends);
+        BWAMS_HIP(rocprim::select(nullptr, tb, it, d_ends, d_cnt, (size_t)n_bytes, pred, st));
+        void *d_tmp = nullptr;
+        BWAMS_HIP(hipMalloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
+        std::vector<char> tail(1);
+        BWAMS_HIP(hipMemcpy(tail.data(), d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost));
+        last = tail[0];
+        BWAMS_HIP(rocprim::select(d_tmp, tb, it, d_ends, d_cnt, (size_t)n_bytes, pred, st));
+        BWAMS_HIP(hipMemcpyAsync(&n_nl, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+    }
+    const int64_t n_lines = n_nl + (n_bytes && last != '\n' ? 1 : 0);
+    if (n_lines % 4) {
+        set_last_error("bwams_fastq_decode: the text is not a whole number of four-line records (multi-line or FASTA input: read it on the host)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    const int64_t n = n_lines / 4, n1 = n + 1;
+    // (2) measure + validate
+    Rec *d_rec = nullptr;
+    int64_t *d_wide = nullptr, *d_offs = nullptr;
+    unsigned long long *d_bad = nullptr;
+    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_rec), (size_t)n1 * sizeof(Rec))); scr.p.push_back(d_rec);
+    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_wide), (size_t)n1 * 3 * 8)); scr.p.push_back(d_wide);
+    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_offs), (size_t)n1 * 3 * 8)); scr.p.push_back(d_offs);
+    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_bad), 64)); scr.p.push_back(d_bad);
+    BWAMS_HIP(hipMemsetAsync(d_bad, 0, 16, st));
+    fastq_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n, d_rec, d_wide, d_bad);
+    for (int row = 0; row < 3; ++row) {
+        size_t tb = 0;
+        BWAMS_HIP(rocprim::exclusive_scan(nullptr, tb, d_wide + row * n1, d_offs + row * n1, (int64_t)0, (size_t)n1, rocprim::plus<int64_t>(), st));
+        void *d_tmp = nullptr;
+        BWAMS_HIP(hipMalloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
+        BWAMS_HIP(rocprim::exclusive_scan(d_tmp, tb, d_wide + row * n1, d_offs + row * n1, (int64_t)0, (size_t)n1, rocprim::plus<int64_t>(), st));
+    }
+    f->cum.resize((size_t)n1); f->name_off.resize((size_t)n1); f->comment_off.resize((size_t)n1);
+    unsigned long long bad[2] = {0, 0};
+    BWAMS_HIP(hipMemcpyAsync(f->name_off.data(), d_offs, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipMemcpyAsync(f->comment_off.data(), d_offs + n1, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipMemcpyAsync(f->cum.data(), d_offs + 2 * n1, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipMemcpyAsync(bad, d_bad, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    if (bad[0]) {
+        set_last_error("bwams_fastq_decode: " + std::to_string(bad[0]) + " record(s) are not '@' / sequence / '+' / quality of equal length on four lines (read this input on the host)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    f->n_reads = n; f->n_bases = f->cum[(size_t)n]; f->name_bytes = f->name_off[(size_t)n]; f->comment_bytes = f->comment_off[(size_t)n];
+    // (3) emit
+    BWAMS_HIP(hipMalloc(&f->d_enc, (size_t)f->n_bases + 64));
+    BWAMS_HIP(hipMalloc(&f->d_qual, (size_t)f->n_bases + 64));
+    BWAMS_HIP(hipMalloc(&f->d_names, (size_t)f->name_bytes + 64));
+    BWAMS_HIP(hipMalloc(&f->d_comments, (size_t)f->comment_bytes + 64));
+    if (n) {
+        int64_t blocks = (n + 3) / 4;
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        fastq_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(d_text, d_rec, n, d_offs, reinterpret_cast<char *>(f->d_names),
+                                                            reinterpret_cast<char *>(f->d_comments), reinterpret_cast<uint8_t *>(f->d_enc),
+                                                            reinterpret_cast<char *>(f->d_qual), d_bad + 1);
+    }
+    BWAMS_HIP(hipEventRecord(e1, st));
+    BWAMS_HIP(hipMemcpyAsync(bad + 1, d_bad + 1, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(hipGetLastError());
+    (void)hipEventElapsedTime(&f->ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (bad[1]) {
+        (void)hipFree(f->d_enc); (void)hipFree(f->d_qual); (void)hipFree(f->d_names); (void)hipFree(f->d_comments);
+        set_last_error("bwams_fastq_decode: a '-' in a read (nst_nt4_table maps it to 5, outside the alphabet of the kernels)");
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    if (n_reads) *n_reads = n;
+    if (n_bases) *n_bases = f->n_bases;
+    *out = f.release();
+    return BWAMS_OK;
+}
+
+int bwams_fastq_info(const bwams_fastq_t *f, int64_t *n_reads, int64_t *n_bases, int64_t *name_bytes, int64_t *comment_bytes, float *ms) {
+    if (!f) return BWAMS_ERR_ARG;
+    if (n_reads) *n_reads = f->n_reads;
+    if (n_bases) *n_bases = f->n_bases;
+    if (name_bytes) *name_bytes = f->name_bytes;
+    if (comment_bytes) *comment_bytes = f->comment_bytes;
+    if (ms) *ms = f->ms;
+    return BWAMS_OK;
+}
+
+int bwams_fastq_fetch(bwams_fastq_t *f, uint8_t *enc, int64_t *cum, char *names, int64_t *name_off, char *quals, char *comments,
+                      int64_t *comment_off) {
+    if (!f) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(f->device));
+    const size_t n1 = (size_t)f->n_reads + 1;
+    if (enc && f->n_bases) BWAMS_HIP(hipMemcpy(enc, f->d_enc, (size_t)f->n_bases, hipMemcpyDeviceToHost));
+    if (quals && f->n_bases) BWAMS_HIP(hipMemcpy(quals, f->d_qual, (size_t)f->n_bases, hipMemcpyDeviceToHost));
+    if (names && f->name_bytes) BWAMS_HIP(hipMemcpy(names, f->d_names, (size_t)f->name_bytes, hipMemcpyDeviceToHost));
+    if (comments && f->comment_bytes) BWAMS_HIP(hipMemcpy(comments, f->d_comments, (size_t)f->comment_bytes, hipMemcpyDeviceToHost));
+    if (cum) memcpy(cum, f->cum.data(), n1 * 8);
+    if (name_off) memcpy(name_off, f->name_off.data(), n1 * 8);
+    if (comment_off) memcpy(comment_off, f->comment_off.data(), n1 * 8);
+    return BWAMS_OK;
+}
+
+int bwams_fastq_to_batch(bwams_fastq_t *f, bwams_batch_t *b) {
+    if (!f || !b) return BWAMS_ERR_ARG;
+    int rc = bwams_seed_upload(b, reinterpret_cast<const uint8_t *>(f->d_enc), f->cum.data(), nullptr, f->n_reads);
+    if (rc) return rc;
+    return bwams_sam_upload(b, reinterpret_cast<const char *>(f->d_names), f->name_off.data(), reinterpret_cast<const char *>(f->d_qual),
+                            f->comment_bytes ? reinterpret_cast<const char *>(f->d_comments) : nullptr,
+                            f->comment_bytes ? f->comment_off.data() : nullptr);
+}
+
+int bwams_fastq_close(bwams_fastq_t *f) {
+    if (!f) return BWAMS_OK;
+    (void)hipSetDevice(f->device);
+    if (f->d_enc) (void)hipFree(f->d_enc);
+    if (f->d_qual) (void)hipFree(f->d_qual);
+    if (f->d_names) (void)hipFree(f->d_names);
+    if (f->d_comments) (void)hipFree(f->d_comments);
+    delete f;
+    return BWAMS_OK;
+}
+
+}  // extern "C"

@@ -244,6 +244,24 @@ int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_
  * device-side mem_approx_mapq_se of every region (region order of bwams_reg2aln_fetch).  Any of the three may be NULL. */
 int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off, int32_t *mapq, int64_t mapq_cap);
 
+/* ------------------------------------------------------------- read input ---- *
+ * A buffer of FASTQ text (host or this GPU's memory) becomes the arrays bwams_seed_upload and bwams_sam_upload take: replaces, per
+ * record, kseq_read (src/kseq.h:358-400), trim_readno and kseq2bseq1 (src/bwa.cpp:74-153) as bseq_read_orig (src/bwa.cpp:266-335)
+ * calls them, and the base encoding of mem_kernel1_core (src/bwamem.cpp:1232, nst_nt4_table).  Built for the four-lines-per-record
+ * shape; multi-line or FASTA input, a quality string of another length than its sequence, or a '-' among the bases return
+ * BWAMS_ERR_UNSUPPORTED (read such a file on the host).  The buffer must hold whole records; gz decompression and the chunking by
+ * base count stay with the caller.  Names come without their "/<digit>" suffix; a read's comment is the header line after the
+ * first white-space character (empty = none). */
+typedef struct bwams_fastq bwams_fastq_t;
+int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fastq_t **out, int64_t *n_reads, int64_t *n_bases);
+int bwams_fastq_info(const bwams_fastq_t *f, int64_t *n_reads, int64_t *n_bases, int64_t *name_bytes, int64_t *comment_bytes, float *ms);
+/* any pointer may be NULL; enc / quals hold n_bases bytes, cum / name_off / comment_off n_reads + 1 entries */
+int bwams_fastq_fetch(bwams_fastq_t *f, uint8_t *enc, int64_t *cum, char *names, int64_t *name_off, char *quals, char *comments,
+                      int64_t *comment_off);
+/* bwams_seed_upload + bwams_sam_upload of the decoded chunk, device to device */
+int bwams_fastq_to_batch(bwams_fastq_t *f, bwams_batch_t *b);
+int bwams_fastq_close(bwams_fastq_t *f);
+
 /* ----------------------------------------------------------- mate rescue ---- */
 
 /* Local Smith-Waterman of mate rescue over n tasks: out[i] = ksw_align2(len2, qer + idq,

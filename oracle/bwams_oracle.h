@@ -170,6 +170,9 @@ int orc_reg2aln(const bwams_mem_opt_t *opt, const struct orc_bns *bns, const uin
 int64_t orc_reg2sam_se(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const struct orc_bns *bns, const char *ctg_names,
                        const int32_t *ctg_off, const uint8_t *ref_string, int l_seq, const uint8_t *seq, const char *qual,
                        const char *name, const char *comment, const bwams_alnreg_t *regs, int n_regs, char *out, int64_t cap);
+/* read input (fastq_oracle.c): kseq_read + trim_readno + kseq2bseq1 + the base encoding over a memory buffer (PARITY UNPINNED) */
+int64_t orc_fastq_parse(const char *buf, int64_t n, int64_t max_reads, char *names, int64_t *name_off, char *comments,
+                        int64_t *comment_off, uint8_t *seq, char *qual, int64_t *cum, uint8_t *has_qual);
 uint64_t orc_hash_64(uint64_t key);
 int64_t orc_depos(int64_t l_pac, int64_t pos, int *is_rev);
 int64_t orc_kbt_script(int64_t n, const int64_t *pos, const uint8_t *do_put, int32_t *lower, int32_t *order);

@@ -82,7 +82,7 @@ _lib = None
 def build() -> str:
     out = os.path.join(HERE, "_build", "liboracle.so")
     srcs = [os.path.join(HERE, f) for f in ("fmi_oracle.c", "bsw_oracle.c", "ksw_oracle.c", "emf_oracle.c", "chain_oracle.c", "dedup_oracle.c",
-                                            "pair_oracle.c", "aln_oracle.c", "ert_oracle.c", "sam_oracle.c",
+                                            "pair_oracle.c", "aln_oracle.c", "ert_oracle.c", "sam_oracle.c", "fastq_oracle.c",
                                             "bwams_oracle.h", "../include/bwams_types.h")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "_build/liboracle.so"])
@@ -629,6 +629,28 @@ def reg2aln(regs, reg_off, enc, cum, ref_string, l_pac, contigs=None, opt: MemOp
             co += int(out[k]["n_cigar"]); mo += int(out[k]["md_len"])
     cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)      # noqa: E731
     return out, cat(cigs, np.uint32), cat(mds, np.uint8)
+
+
+def fastq_parse(text: bytes):
+    """kseq_read over a buffer -> dict(n, names[list of bytes], comments[list of bytes or None], enc, cum, quals, has_qual, status).
+    status 0: the whole buffer was read; -2: the reader stopped at a quality string of the wrong length."""
+    n = len(text)
+    cap = n + 16
+    max_reads = text.count(b"@") + text.count(b">") + 1
+    names = C.create_string_buffer(cap); comments = C.create_string_buffer(cap); qual = C.create_string_buffer(cap)
+    seq = np.zeros(cap, np.uint8)
+    noff = np.zeros(max_reads + 1, np.int64); coff = np.zeros(max_reads + 1, np.int64); cum = np.zeros(max_reads + 1, np.int64)
+    hq = np.zeros(max_reads + 1, np.uint8)
+    f = lib().orc_fastq_parse
+    f.restype = C.c_int64
+    nr = f(text, C.c_int64(n), C.c_int64(max_reads), names, _p(noff), comments, _p(coff), _p(seq), qual, _p(cum), _p(hq))
+    status = 0
+    if nr < 0:
+        status, nr = -2, -2 - nr
+    nm = [names.raw[noff[i]:noff[i + 1]] for i in range(nr)]
+    cm = [comments.raw[coff[i]:coff[i + 1]] or None for i in range(nr)]
+    return dict(n=nr, names=nm, comments=cm, enc=seq[:cum[nr]].copy(), cum=cum[:nr + 1].copy(),
+                quals=np.frombuffer(qual.raw[:cum[nr]], np.uint8).copy(), has_qual=hq[:nr].copy(), status=status)
 
 
 class SamOpt(C.Structure):

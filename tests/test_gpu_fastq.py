@@ -1,0 +1,95 @@
+"""bwams_fastq_decode — FASTQ text to the hot path's arrays on the device — against the oracle's restatement of kseq_read +
+trim_readno + kseq2bseq1 + the base encoding, and the whole device chain FASTQ text -> SAM text against the oracle chain."""
+import numpy as np
+import pytest
+
+from bwams import capi, simulate
+from oracle import loader
+from test_oracle_fastq import make_fastq
+from test_oracle_sam import repeat_genome
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got, want):
+    assert got["n"] == want["n"]
+    assert got["names"] == want["names"] and got["comments"] == want["comments"]
+    assert np.array_equal(got["cum"], want["cum"]) and np.array_equal(got["enc"], want["enc"]) and np.array_equal(got["quals"], want["quals"])
+
+
+@pytest.mark.parametrize("seed,crlf,n", [(1, False, 3000), (2, True, 1500), (3, False, 1), (4, False, 257)])
+def test_decode_equals_oracle(seed, crlf, n):
+    text, _ = make_fastq(n, seed, crlf=crlf)
+    text = text.replace(b"-", b"N")
+    for t in (text, text[:-1] if not crlf else text):            # with and without the final newline
+        f = capi.Fastq(t)
+        want = loader.fastq_parse(t)
+        assert want["status"] == 0 and want["has_qual"].all()
+        _same(f.fetch(), want)
+        f.close()
+
+
+def test_decode_corners_and_refusals():
+    f = capi.Fastq(b"")
+    assert f.n_reads == 0 and f.fetch()["n"] == 0
+    f.close()
+    f = capi.Fastq(b"@x/9 c  d\nacgtn\n+x\n!!!!!\n@/1\n\n+\n\n")
+    g = f.fetch()
+    assert g["names"] == [b"x", b"/1"] and g["comments"] == [b"c  d", None] and list(g["enc"]) == [0, 1, 2, 3, 4] and list(g["cum"]) == [0, 5, 5]
+    _same(g, loader.fastq_parse(b"@x/9 c  d\nacgtn\n+x\n!!!!!\n@/1\n\n+\n\n"))
+    f.close()
+    for bad in (b"@a\nACGT\nAC\n+\nIIIIII\n",                      # multi-line record
+                b">fa\nACGT\n",                                    # FASTA
+                b"@a\nACGT\n+\nIII\n",                             # quality shorter than the sequence
+                b"@a\nACGT\n+\nIIIII\n",                           # ... longer
+                b"@a\nACGT\n+\nIIII\n\n",                          # a blank line
+                b"junk\n@a\nACGT\n+\nIIII\n",                      # text before the first header
+                b"@a\nAC-T\n+\nIIII\n"):                           # '-' (nst_nt4_table: 5)
+        with pytest.raises(capi.BwamsError):
+            capi.Fastq(bad)
+
+
+def test_fastq_text_to_sam_text_on_the_device():
+    """FASTQ bytes in, SAM bytes out, nothing but the two texts crossing the boundary; the oracle chain on the same bytes."""
+    g, idx, starts = repeat_genome()
+    reads, _, _ = simulate.make_reads(g, 600, seed=31)
+    rng = np.random.default_rng(8)
+    for i in range(0, 600, 3):
+        st = starts[int(rng.integers(0, len(starts)))] + int(rng.integers(0, 500 - reads.shape[1]))
+        reads[i] = g[st:st + reads.shape[1]]
+    parts = []
+    for i, r in enumerate(reads):
+        seq = bytes(b"ACGTN"[b] for b in r)
+        qual = bytes(rng.integers(33, 74, size=len(r), dtype=np.uint8))
+        parts.append(b"@frag%d/1%s\n%s\n+\n%s\n" % (i, b" RG:Z:x%d" % i if i % 5 == 0 else b"", seq, qual))
+    text = b"".join(parts)
+    ix = capi.Index.from_host(idx, 0)
+    ix.set_contig_names([b"chrR"])
+    f = capi.Fastq(text)
+    b = capi.Batch(ix, f.n_reads, f.n_bases)
+    f.to_batch(b)
+    gopt, oopt = capi.default_mem_opt(), loader.default_mem_opt()
+    b.seed_run(capi.default_seed_opt(), with_sa=True)
+    b.chain_run(gopt); b.extend_run(gopt); b.dedup_run(gopt)
+    b.mark_primary_se(gopt, id_base=0)
+    b.reg2aln(gopt, 1)
+    b.sam_run(gopt, capi.default_sam_opt())
+    sam, roff, _ = b.sam_fetch()
+    # the oracle chain from the same FASTQ bytes
+    w = loader.fastq_parse(text)
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(w["enc"], w["cum"])
+    coord, off = o.sa_lookup(sm)
+    l_pac = len(g)
+    ch, sd, choff = loader.chain_seeds(sm, coord, off, w["cum"], l_pac)
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, w["enc"], w["cum"], idx.ref_0123, l_pac)
+    fin, fin_off = loader.regs_finish(regs, reg_off, w["enc"], w["cum"], idx.ref_0123, l_pac)
+    for r in range(len(fin_off) - 1):
+        a, e = int(fin_off[r]), int(fin_off[r + 1])
+        if e > a:
+            fin[a:e] = loader.mark_primary_se(fin[a:e], r)[0]
+    want = loader.reg2sam_se(fin, fin_off, w["enc"], w["cum"], idx.ref_0123, l_pac, w["names"], quals=w["quals"], comments=w["comments"],
+                             contig_names=[b"chrR"], opt=oopt)
+    assert sam == b"".join(want)
+    assert sam.count(b"\n") >= 600 and b"frag0\t" in sam and b"/1" not in sam.split(b"\n")[0].split(b"\t")[0]
+    f.close(); b.close(); ix.close()

@@ -461,6 +461,41 @@ def main():
                                     "and qualities already in HBM when timed; byte-equal to the oracle in tests/test_gpu_sam.py"}
     if not all(checks.values()):
         raise SystemExit(f"[bench] SAM text property check failed: {checks}")
+    # read input: the chunk as FASTQ text -> encoded bases, names, qualities on the device (kseq_read + trim_readno + base encoding)
+    rd_ = reads_l[n_chunks - 1]
+    row = np.empty((n_seq_, 1 + 9 + 1 + RL + 3 + RL + 1), np.uint8)
+    row[:, 0] = ord("@"); row[:, 1] = ord("r")
+    ids_ = first + np.arange(n_seq_, dtype=np.int64)
+    for d_ in range(8):
+        row[:, 2 + d_] = ord("0") + (ids_ // 10 ** (7 - d_)) % 10
+    row[:, 10] = 10
+    row[:, 11:11 + RL] = np.frombuffer(b"ACGTN", np.uint8)[rd_]
+    row[:, 11 + RL:14 + RL] = np.frombuffer(b"\n+\n", np.uint8)
+    row[:, 14 + RL:14 + 2 * RL] = ord("I")
+    row[:, 14 + 2 * RL] = 10
+    fq_text = row.tobytes()
+    d_fq = torch.from_numpy(row.reshape(-1)).to(dev)               # the text resident in HBM, as the other inputs are
+    fq = capi.Fastq(d_fq.data_ptr(), device=local, n_bytes=len(fq_text)); fq.close()
+    t0 = time.perf_counter()
+    fq = capi.Fastq(d_fq.data_ptr(), device=local, n_bytes=len(fq_text))
+    fq_wall_ms = (time.perf_counter() - t0) * 1e3
+    fqi = fq.info()
+    got_ = fq.fetch()
+    fq_checks = {"bases_equal_the_reads": bool(np.array_equal(got_["enc"], rd_.reshape(-1))),
+                 "cum_is_regular": bool(np.array_equal(got_["cum"], cum_)),
+                 "names_round_trip": bool(got_["names"][0] == b"r%08d" % first and got_["names"][-1] == b"r%08d" % (first + n_seq_ - 1)),
+                 "qualities_round_trip": bool((got_["quals"] == ord("I")).all())}
+    fq.close()
+    sam_side["fastq_decode"] = {"bytes": len(fq_text), "reads": int(fqi["n_reads"]), "ms_kernels": round(fqi["ms"], 3), "ms_call": round(fq_wall_ms, 2),
+                                "GBps_text": round(len(fq_text) / (fqi["ms"] * 1e-3) / 1e9, 1) if fqi["ms"] > 0 else None,
+                                "Mreads_per_s": round(fqi["n_reads"] / (fqi["ms"] * 1e-3) / 1e6, 1) if fqi["ms"] > 0 else None,
+                                "checks": fq_checks,
+                                "note": "four-line FASTQ text already in HBM -> encoded bases + cum, names (trim_readno), comments, qualities: line "
+                                        "ends (count + rocPRIM select), a lane per record to validate and measure, a wave per record to copy / encode; "
+                                        "ms_call adds the allocations, three scans and the offset arrays' copy to the host"}
+    if not all(fq_checks.values()):
+        raise SystemExit(f"[bench] FASTQ decode property check failed: {fq_checks}")
+    del row, fq_text, d_fq, got_
     del aln_, cig_, md_, text_, tb, mq_
 
     # ---------------- paired-end leg (every rank: the pestat exchange is a collective) ----------------

@@ -24,6 +24,9 @@ def short(k):
                       ("aln_dp_kernel", "aln_dp_kernel (mem_reg2aln: banded global alignment + traceback)"),
                       ("aln_simple", "aln_simple_kernel (mem_reg2aln: gap-free regions)"), ("aln_gather", "aln_gather_kernel"),
                       ("aln_plan", "aln_plan_kernel"),
+                      ("sam_text_kernel", "sam_text_kernel (single-end SAM text: count pass / write pass)"), ("sam_mapq", "sam_mapq_kernel (mem_approx_mapq_se)"),
+                      ("fastq_emit", "fastq_emit_kernel (FASTQ decode: copy / encode, wave per record)"), ("fastq_measure", "fastq_measure_kernel (FASTQ decode: validate + measure, lane per record)"),
+                      ("fastq_count", "fastq_count_kernel (FASTQ decode: line ends)"),
                       ("key_collect", "key_collect_kernel (index build: MSD chunk collection)"),
                       ("chunk_finish", "chunk_finish_kernel (index build)"), ("bwt_block", "bwt_block_kernel (index build: BWT -> CP_OCC)"),
                       ("round_keys", "round_keys_kernel (index build: doubling round)"), ("round_finish", "round_finish_kernel (index build)"),

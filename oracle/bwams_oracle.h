@@ -170,6 +170,12 @@ int orc_reg2aln(const bwams_mem_opt_t *opt, const struct orc_bns *bns, const uin
 int64_t orc_reg2sam_se(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const struct orc_bns *bns, const char *ctg_names,
                        const int32_t *ctg_off, const uint8_t *ref_string, int l_seq, const uint8_t *seq, const char *qual,
                        const char *name, const char *comment, const bwams_alnreg_t *regs, int n_regs, char *out, int64_t cap);
+/* mem_sam_pe from mem_pair's result on, for one pair (regs are edited in place as the reference edits them) */
+void orc_sam_pe(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const struct orc_bns *bns, const char *ctg_names,
+                const int32_t *ctg_off, const uint8_t *ref_string, const bwams_pestat_t pes[4], const int32_t l_seq[2],
+                const uint8_t *const seq[2], const char *const qual[2], const char *const name[2], const char *const comment[2],
+                bwams_alnreg_t *const regs[2], const int32_t n_regs[2], const bwams_pair_t *pr, char *const out[2], const int64_t cap[2],
+                int64_t len[2]);
 /* read input (fastq_oracle.c): kseq_read + trim_readno + kseq2bseq1 + the base encoding over a memory buffer (PARITY UNPINNED) */
 int64_t orc_fastq_parse(const char *buf, int64_t n, int64_t max_reads, char *names, int64_t *name_off, char *comments,
                         int64_t *comment_off, uint8_t *seq, char *qual, int64_t *cum, uint8_t *has_qual);

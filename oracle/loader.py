@@ -707,6 +707,51 @@ def reg2sam_se(regs, reg_off, enc, cum, ref_string, l_pac, names, quals=None, co
     return out
 
 
+def sam_pe(regs, reg_off, enc, cum, ref_string, l_pac, pes, pairs, names, quals=None, comments=None, contigs=None, contig_names=None,
+           opt: MemOpt | None = None, sopt: SamOpt | None = None):
+    """mem_sam_pe from mem_pair's result on, over every pair of a chunk (regs / reg_off / pairs = pair_pe's outputs):
+    list of bytes, one SAM text block per read (2p, 2p + 1 = the ends of pair p)."""
+    opt = opt or default_mem_opt()
+    sopt = sopt or default_sam_opt()
+    contigs = contigs if contigs is not None else single_contig(l_pac)
+    bns, keep = _bns(l_pac, contigs)
+    cn_blob, cn_off = contig_name_table(contig_names if contig_names is not None else [b"chr%d" % (i + 1) for i in range(len(keep))])
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE).copy()          # edited in place, as the reference does
+    enc = np.ascontiguousarray(enc, np.uint8)
+    ref_string = np.ascontiguousarray(ref_string, np.uint8)
+    pes = np.ascontiguousarray(pes, PESTAT_DTYPE)
+    pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
+    f = lib().orc_sam_pe
+    f.restype = None
+    out = []
+    cap = 1 << 16
+    bufs = [C.create_string_buffer(cap), C.create_string_buffer(cap)]
+    for p in range(len(pairs)):
+        r0 = 2 * p
+        lens = (C.c_int32 * 2)(int(cum[r0 + 1] - cum[r0]), int(cum[r0 + 2] - cum[r0 + 1]))
+        seqs = (C.c_void_p * 2)(enc.ctypes.data + int(cum[r0]), enc.ctypes.data + int(cum[r0 + 1]))
+        qb = [bytes(quals[cum[r0 + i]:cum[r0 + i + 1]]) if quals is not None else None for i in range(2)]
+        qs = (C.c_char_p * 2)(qb[0], qb[1])
+        nm = (C.c_char_p * 2)(names[r0], names[r0 + 1])
+        cm = (C.c_char_p * 2)(comments[r0] if comments is not None else None, comments[r0 + 1] if comments is not None else None)
+        nreg = (C.c_int32 * 2)(int(reg_off[r0 + 1] - reg_off[r0]), int(reg_off[r0 + 2] - reg_off[r0 + 1]))
+        rp = (C.c_void_p * 2)(regs.ctypes.data + int(reg_off[r0]) * ALNREG_DTYPE.itemsize, regs.ctypes.data + int(reg_off[r0 + 1]) * ALNREG_DTYPE.itemsize)
+        while True:
+            keep_regs = regs[int(reg_off[r0]):int(reg_off[r0 + 2])].copy()
+            ob = (C.c_void_p * 2)(C.addressof(bufs[0]), C.addressof(bufs[1]))
+            caps = (C.c_int64 * 2)(cap, cap)
+            ln = (C.c_int64 * 2)(0, 0)
+            f(C.byref(opt), C.byref(sopt), C.byref(bns), cn_blob, _p(cn_off), _p(ref_string), _p(pes), lens, seqs, qs, nm, cm, rp, nreg,
+              pairs[p:p + 1].ctypes.data_as(C.c_void_p), ob, caps, ln)
+            if ln[0] >= 0 and ln[1] >= 0:
+                break
+            regs[int(reg_off[r0]):int(reg_off[r0 + 2])] = keep_regs          # undo the edits before the retry
+            cap = max(2 * cap, -min(ln[0], ln[1]) + 16)
+            bufs = [C.create_string_buffer(cap), C.create_string_buffer(cap)]
+        out.append(bufs[0].raw[:ln[0]]); out.append(bufs[1].raw[:ln[1]])
+    return out
+
+
 def ars_sort(which: int, k0, k1=None, k2=None, L=None):
     """Order of ks_introsort(mem_ars2) (which = 0, key re) / ks_introsort(mem_ars) (which = 1, keys score, rb, qb)."""
     k0 = np.ascontiguousarray(k0, np.int64)

@@ -175,3 +175,48 @@ def test_sam_text_threshold_and_empty_reads():
     c2 = dict(c); c2["regs"] = c["regs"][:0]; c2["reg_off"] = np.zeros(len(c["cum"]), np.int64)
     out2 = sam_of(c2)
     assert out2 == out
+
+
+def pe_case(n_pairs=300, seed=7):
+    from util import oracle_pe_pipeline
+    g, idx, starts = repeat_genome()
+    pr = simulate.make_read_pairs(g, n_pairs, seed=seed) if hasattr(simulate, "make_read_pairs") else simulate.make_read_pairs_bulk(g, n_pairs, seed=seed)
+    reads = np.asarray(pr).reshape(-1, np.asarray(pr).shape[-1])
+    rng = np.random.default_rng(seed)
+    reads[8] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8)          # an end that does not align
+    reads[20] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8); reads[21] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8)
+    c = oracle_pe_pipeline(g, idx, reads)
+    regs, off, pairs = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], c["pes"])
+    quals = rng.integers(33, 74, size=len(c["enc"]), dtype=np.uint8)
+    names = [b"pair%d" % (i // 2) for i in range(len(reads))]
+    return dict(c, regs=regs, reg_off=off, pairs=pairs, quals=quals, names=names, g=g, idx=idx)
+
+
+def test_paired_end_text_properties():
+    c = pe_case()
+    out = loader.sam_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], c["pes"], c["pairs"], c["names"], quals=c["quals"],
+                        contig_names=[b"chr1"])
+    assert len(out) == len(c["cum"]) - 1
+    n_proper = n_mc = n_unmapped_with_mate = 0
+    for p in range(len(out) // 2):
+        first = [ln.split(b"\t") for ln in out[2 * p].split(b"\n")[:-1]]
+        second = [ln.split(b"\t") for ln in out[2 * p + 1].split(b"\n")[:-1]]
+        assert first and second
+        f0, f1 = first[0], second[0]
+        fl0, fl1 = int(f0[1]), int(f1[1])
+        assert all(int(f[1]) & 0x41 == 0x41 for f in first) and all(int(f[1]) & 0x81 == 0x81 for f in second)
+        assert bool(fl0 & 2) == bool(fl1 & 2)
+        assert bool(fl0 & 0x20) == bool(fl1 & 0x10) and bool(fl1 & 0x20) == bool(fl0 & 0x10)
+        assert bool(fl0 & 0x8) == bool(fl1 & 0x4) and bool(fl1 & 0x8) == bool(fl0 & 0x4)
+        if not (fl0 & 4 and fl1 & 4):
+            # mate fields of one end = position fields of the other (an unmapped end sits at its mate's coordinates)
+            assert f0[7] == f1[3] and f1[7] == f0[3] and f0[6] == b"=" and f1[6] == b"="
+            assert int(f0[8]) == -int(f1[8])
+        else:
+            assert f0[2:9] == [b"*", b"0", b"0", b"*", b"*", b"0", b"0"]
+        n_proper += bool(fl0 & 2)
+        n_mc += any(t.startswith(b"MC:Z:") for t in f0[11:])
+        n_unmapped_with_mate += bool(fl0 & 4) != bool(fl1 & 4)
+        if fl0 & 2 and not (fl0 & 4) and not (fl1 & 4):
+            assert int(f0[8]) != 0 and abs(int(f0[8])) < 2000
+    assert n_proper > 200 and n_mc > 200 and n_unmapped_with_mate >= 1

@@ -1162,12 +1162,16 @@ int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_of
     return BWAMS_OK;
 }
 
-int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, int64_t *sam_bytes) {
-    if (!b || !sopt || !b->chain || !b->chain->al_done || b->chain->al_source != 1 || !b->chain->pr_single) {
-        set_last_error("bwams_sam_run: run bwams_pair_run(BWAMS_PAIR_SINGLE_END) and bwams_reg2aln_run(source 1) first");
+static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, const bwams_pestat_t *pes,
+                        int64_t *sam_bytes) {
+    const bool pe = pes != nullptr;
+    if (!b || !sopt || !b->chain || !b->chain->al_done || b->chain->al_source != 1 || b->chain->pr_single == pe) {
+        set_last_error(pe ? "bwams_sam_run_pe: run bwams_pair_run (paired-end) and bwams_reg2aln_run(source 1) first"
+                          : "bwams_sam_run: run bwams_pair_run(BWAMS_PAIR_SINGLE_END) and bwams_reg2aln_run(source 1) first");
         return BWAMS_ERR_ARG;
     }
     ChainState *s = b->chain;
+    if (pe && (s->nseq & 1)) return BWAMS_ERR_ARG;
     if (!s->sm_up || s->sm_nseq != s->nseq) {
         set_last_error("bwams_sam_run: run bwams_sam_upload for this chunk first");
         return BWAMS_ERR_ARG;
@@ -1214,6 +1218,9 @@ int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_
     A.opt = *opt; A.sopt = *sopt;
     A.logtab = s->sm_logtab.as<double>(); A.logtab_n = kLogN;
     A.coef_fac = opt->mapq_coef_len > 0 ? log((double)opt->mapq_coef_len) : 0.;
+    A.pairs = pe ? s->pr_res.as<bwams_pair_t>() : nullptr;
+    if (pe) memcpy(A.pes, pes, sizeof A.pes);
+    A.bns_l_pac = (b->idx->fmi.ref_seq_len - 1) / 2;
     A.mapq = s->sm_mapq.as<int32_t>(); A.bad = s->sm_bad.as<unsigned long long>();
     A.len = s->sm_len.as<int64_t>(); A.out_off = s->sm_off.as<int64_t>(); A.out = nullptr;
     BWAMS_HIP(hipMemsetAsync(s->sm_bad.p, 0, 8, st));
@@ -1227,7 +1234,7 @@ int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_
     BWAMS_HIP(hipMemcpyAsync(&bad, s->sm_bad.p, 8, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     if (bad) {
-        set_last_error("bwams_sam_run: an alignment longer than 65535 bases (mapping quality table)");
+        set_last_error("bwams_sam_run: an alignment longer than 65535 bases or more than 65534 competing pairings (mapping quality table)");
         return BWAMS_ERR_UNSUPPORTED;
     }
     BWAMS_HIP(s->sm_out.ensure((size_t)total + 16));
@@ -1238,6 +1245,16 @@ int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_
     s->sm_bytes = total; s->sm_nregs = n; s->sm_done = true;
     if (sam_bytes) *sam_bytes = total;
     return BWAMS_OK;
+}
+
+int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, int64_t *sam_bytes) {
+    return sam_run_impl(b, opt, sopt, nullptr, sam_bytes);
+}
+
+int bwams_sam_run_pe(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, const bwams_pestat_t pes[4],
+                     int64_t *sam_bytes) {
+    if (!pes) return BWAMS_ERR_ARG;
+    return sam_run_impl(b, opt, sopt, pes, sam_bytes);
 }
 
 int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off, int32_t *mapq, int64_t mapq_cap) {

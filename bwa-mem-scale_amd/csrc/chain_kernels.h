@@ -267,6 +267,9 @@ struct SamArgs {
     const double *logtab;          // log(i) from the host's C library
     int32_t logtab_n;
     double coef_fac;               // log(mapQ_coef_len)
+    const bwams_pair_t *pairs;     // paired-end: mem_pair's result per pair (null: single-end)
+    bwams_pestat_t pes[4];
+    int64_t bns_l_pac;
     int32_t *mapq;                 // per region
     unsigned long long *bad;       // regions whose lengths fall outside logtab
     int64_t *len;                  // per read: bytes of text

@@ -109,6 +109,14 @@ __global__ void sam_mapq_kernel(SamArgs A) {
     A.mapq[k] = (A.rec[k].rid >= 0 && a.secondary < 0) ? approx_mapq_se_dev(A.opt, a, A.logtab, A.logtab_n, A.coef_fac, A.bad) : 0;
 }
 
+// the mate's record as mem_aln2sam reads it (rid, pos, strand, CIGAR, is_alt)
+struct Mate {
+    bool present;                // m != NULL
+    int64_t pos;
+    int32_t rid, is_rev, is_alt, n_cigar;
+    int64_t cigar_off;
+};
+
 // one read's view
 struct Read {
     const bwams_alnreg_t *a;     // its regions
@@ -120,6 +128,14 @@ struct Read {
     int l_seq;
     const char *name; int l_name;
     const char *comment; int l_comment;      // l_comment 0: none
+    // paired-end, paired branch (bwamem_pair.cpp:725-748): the region edits of mem_sam_pe as a view
+    int sw_k, sw_z;              // secondary_all switch: regions pointing at sw_k (and sw_k itself) point at sw_z, sw_z at nothing; -1: none
+    __device__ __forceinline__ int sec_all(int j) const {
+        const int v = a[j].secondary_all;
+        if (sw_k < 0) return v;
+        if (j == sw_z) return -1;
+        return (v == sw_k || j == sw_k) ? sw_z : v;
+    }
 };
 
 // mem_reg2sam's filter (bwamem.cpp:2108-2116)
@@ -133,7 +149,7 @@ __device__ __forceinline__ bool selected(const SamArgs &A, const Read &R, int k)
 
 // get_pri_idx (bwamem_extra.cpp:123-128)
 __device__ __forceinline__ int pri_idx(const SamArgs &A, const Read &R, int i) {
-    const int k = R.a[i].secondary_all;
+    const int k = R.sec_all(i);
     if (k >= 0 && R.a[i].score >= R.a[k].score * (double)A.sopt.XA_drop_ratio) return k;
     return -1;
 }
@@ -179,23 +195,44 @@ __device__ bool put_xa(const SamArgs &A, const Read &R, Writer &W, int r, bool w
     return true;
 }
 
-// mem_aln2sam for the which-th of n_sel records (region k), or the unaligned record (k < 0)
-__device__ void put_record(const SamArgs &A, const Read &R, Writer &W, int k, int which, int mapq0) {
+__device__ __forceinline__ int get_rlen(const SamArgs &A, int64_t cigar_off, int n_cigar) {        // bwamem.cpp:2639-2648
+    int l = 0;
+    for (int k = 0; k < n_cigar; ++k) {
+        const uint32_t c = A.cig[cigar_off + k];
+        if ((c & 0xf) == 0 || (c & 0xf) == 2) l += (int)(c >> 4);
+    }
+    return l;
+}
+
+// what the caller of mem_aln2sam decided about a record
+struct RecInfo {
+    int k;              // region (index within the read) or -1: the unaligned record
+    int which;          // ordinal in the list handed to mem_aln2sam
+    int flag, mapq, sub;
+    int n_list;         // the list for the SA tag: 0 = the mem_reg2sam selection (recomputed), else list[0 .. n_list)
+    int list[2];
+    int list_mapq[2];
+    bool xa;            // the record carries its region's XA string
+};
+
+// mem_aln2sam (bwamem.cpp:2393-2531)
+__device__ void put_record(const SamArgs &A, const Read &R, Writer &W, const RecInfo &I, const Mate &M_, int mapq0) {
     bwams_aln_t t;
-    int flag, mapq = 0, sub;
-    if (k >= 0) {
-        t = R.rec[k];
-        flag = t.flag;
-        if (which && R.a[k].secondary < 0) flag |= (A.sopt.flag & BWAMS_MEM_F_NO_MULTI) ? 0x10000 : 0x800;
-        mapq = capped_mapq(A, R, k, which, mapq0);
-        sub = R.a[k].secondary >= 0 ? -1 : t.sub;
-    } else {                                              // mem_reg2aln(ar = 0): everything zero but rid, pos, flag
+    const int k = I.k, which = I.which;
+    int flag = I.flag, mapq = I.mapq, sub = I.sub;
+    if (k >= 0) t = R.rec[k];
+    else {                                                // mem_reg2aln(ar = 0): everything zero but rid, pos, flag
         t.pos = -1; t.rid = -1; t.flag = 0x4; t.is_rev = t.is_alt = t.mapq = t.NM = t.n_cigar = t.md_len = 0;
         t.cigar_off = t.md_off = 0; t.score = t.sub = t.alt_sc = 0; t.pad_ = 0;
-        flag = t.flag; sub = 0;
     }
+    Mate m = M_;
+    flag |= m.present ? 0x1 : 0;
     flag |= t.rid < 0 ? 0x4 : 0;
+    flag |= m.present && m.rid < 0 ? 0x8 : 0;
+    if (t.rid < 0 && m.present && m.rid >= 0) { t.rid = m.rid; t.pos = m.pos; t.is_rev = m.is_rev; t.n_cigar = 0; }
+    if (m.present && m.rid < 0 && t.rid >= 0) { m.rid = t.rid; m.pos = t.pos; m.is_rev = t.is_rev; m.n_cigar = 0; }
     flag |= t.is_rev ? 0x10 : 0;
+    flag |= m.present && m.is_rev ? 0x20 : 0;
     W.s(R.name, R.l_name); W.c('\t');
     W.num((flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)); W.c('\t');
     if (t.rid >= 0) {
@@ -206,7 +243,17 @@ __device__ void put_record(const SamArgs &A, const Read &R, Writer &W, int k, in
         else W.c('*');
     } else W.s("*\t0\t0\t*", 7);
     W.c('\t');
-    W.s("*\t0\t0", 5);
+    if (m.present && m.rid >= 0) {
+        if (t.rid == m.rid) W.c('='); else W.z(ctg_name(A, m.rid));
+        W.c('\t');
+        W.num(m.pos + 1); W.c('\t');
+        if (t.rid == m.rid) {
+            const int64_t p0 = t.pos + (t.is_rev ? get_rlen(A, t.cigar_off, t.n_cigar) - 1 : 0);
+            const int64_t p1 = m.pos + (m.is_rev ? get_rlen(A, m.cigar_off, m.n_cigar) - 1 : 0);
+            if (m.n_cigar == 0 || t.n_cigar == 0) W.c('0');
+            else W.num(-(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
+        } else W.c('0');
+    } else W.s("*\t0\t0", 5);
     W.c('\t');
     if (flag & 0x100) {
         W.s("*\t*", 3);
@@ -232,61 +279,256 @@ __device__ void put_record(const SamArgs &A, const Read &R, Writer &W, int k, in
         W.s("\tNM:i:", 6); W.num(t.NM);
         W.s("\tMD:Z:", 6); W.s(A.md + t.md_off, t.md_len > 0 ? t.md_len - 1 : 0);
     }
+    if (m.present && m.n_cigar) {                          // MC:Z (V17): the mate's CIGAR under this record's clipping rule
+        W.s("\tMC:Z:", 6);
+        bwams_aln_t mt;
+        mt.cigar_off = m.cigar_off; mt.n_cigar = m.n_cigar; mt.is_alt = m.is_alt;
+        put_cigar(A, W, mt, "MIDSH", 1, which);
+    }
     if (t.score >= 0) { W.s("\tAS:i:", 6); W.num(t.score); }
     if (sub >= 0) { W.s("\tXS:i:", 6); W.num(sub); }
     if (A.sopt.rg_id[0]) { W.s("\tRG:Z:", 6); W.z(A.sopt.rg_id); }
     if (!(flag & 0x100)) {
-        bool other = false;
-        if (k >= 0)
-            for (int i = 0; i < R.n && !other; ++i)
-                other = i != k && selected(A, R, i) && !(R.rec[i].flag & 0x100);
-        if (other) {
+        if (I.n_list == 0) {                              // the list is mem_reg2sam's selection
+            bool other = false;
+            if (k >= 0)
+                for (int i = 0; i < R.n && !other; ++i)
+                    other = i != k && selected(A, R, i) && !(R.rec[i].flag & 0x100);
+            if (other) {
+                W.s("\tSA:Z:", 6);
+                int wi = 0;
+                for (int i = 0; i < R.n; ++i) {
+                    if (!selected(A, R, i)) continue;
+                    const int w_i = wi++;
+                    const bwams_aln_t &r = R.rec[i];
+                    if (i == k || (r.flag & 0x100)) continue;
+                    W.z(ctg_name(A, r.rid)); W.c(',');
+                    W.num(r.pos + 1); W.c(',');
+                    W.c("+-"[r.is_rev]); W.c(',');
+                    put_cigar(A, W, r, "MIDSH", 0, 0);
+                    W.c(','); W.num(capped_mapq(A, R, i, w_i, mapq0));
+                    W.c(','); W.num(r.NM);
+                    W.c(';');
+                }
+            }
+        } else if (I.n_list > 1) {                        // mem_sam_pe's list of at most two records, none of them 0x100
             W.s("\tSA:Z:", 6);
-            int wi = 0;
-            for (int i = 0; i < R.n; ++i) {
-                if (!selected(A, R, i)) continue;
-                const int w_i = wi++;
-                const bwams_aln_t &r = R.rec[i];
-                if (i == k || (r.flag & 0x100)) continue;
+            for (int i = 0; i < I.n_list; ++i) {
+                if (i == which) continue;
+                const bwams_aln_t &r = R.rec[I.list[i]];
                 W.z(ctg_name(A, r.rid)); W.c(',');
                 W.num(r.pos + 1); W.c(',');
                 W.c("+-"[r.is_rev]); W.c(',');
                 put_cigar(A, W, r, "MIDSH", 0, 0);
-                W.c(','); W.num(capped_mapq(A, R, i, w_i, mapq0));
+                W.c(','); W.num(I.list_mapq[i]);
                 W.c(','); W.num(r.NM);
                 W.c(';');
             }
         }
         if (t.alt_sc > 0) { W.s("\tpa:f:", 6); W.f3((double)t.score / t.alt_sc); }
     }
-    if (k >= 0 && !(A.sopt.flag & BWAMS_MEM_F_ALL)) put_xa(A, R, W, k, true);
+    if (k >= 0 && I.xa) put_xa(A, R, W, k, true);
     if (R.l_comment) { W.c('\t'); W.s(R.comment, R.l_comment); }
     W.c('\n');
+}
+
+// mem_reg2sam (bwamem.cpp:2091-2150) with extra_flag and the mate record m
+__device__ void put_reg2sam(const SamArgs &A, const Read &R, Writer &W, int extra_flag, const Mate &m) {
+    int first = -1;
+    for (int k = 0; k < R.n && first < 0; ++k)
+        if (selected(A, R, k)) first = k;
+    RecInfo I;
+    I.n_list = 0; I.list[0] = I.list[1] = 0; I.list_mapq[0] = I.list_mapq[1] = 0;
+    I.xa = !(A.sopt.flag & BWAMS_MEM_F_ALL);
+    if (first < 0) {
+        I.k = -1; I.which = 0; I.flag = 0x4 | extra_flag; I.mapq = 0; I.sub = 0;
+        put_record(A, R, W, I, m, 0);
+        return;
+    }
+    const int mapq0 = R.mapq[first];
+    int which = 0;
+    for (int k = first; k < R.n; ++k) {
+        if (!selected(A, R, k)) continue;
+        I.k = k; I.which = which;
+        I.flag = R.rec[k].flag | extra_flag;
+        if (which && R.a[k].secondary < 0) I.flag |= (A.sopt.flag & BWAMS_MEM_F_NO_MULTI) ? 0x10000 : 0x800;
+        I.mapq = capped_mapq(A, R, k, which, mapq0);
+        I.sub = R.a[k].secondary >= 0 ? -1 : R.rec[k].sub;
+        put_record(A, R, W, I, m, mapq0);
+        ++which;
+    }
+}
+
+__device__ __forceinline__ void load_read(const SamArgs &A, int64_t r, Read &R) {
+    const int64_t o = A.reg_off[r];
+    R.a = A.regs + o; R.rec = A.rec + o; R.mapq = A.mapq + o; R.n = (int)(A.reg_off[r + 1] - o);
+    R.seq = A.enc + A.cum[r]; R.l_seq = (int)(A.cum[r + 1] - A.cum[r]);
+    R.qual = A.quals ? A.quals + A.cum[r] : nullptr;
+    R.name = A.names + A.name_off[r]; R.l_name = (int)(A.name_off[r + 1] - A.name_off[r]);
+    R.comment = A.comments ? A.comments + A.comment_off[r] : nullptr;
+    R.l_comment = A.comments ? (int)(A.comment_off[r + 1] - A.comment_off[r]) : 0;
+    R.sw_k = R.sw_z = -1;
+}
+
+__device__ __forceinline__ Mate mate_of(const Read &R, int k) {          // mem_reg2aln of region k (or of nothing) as a mate record
+    Mate m;
+    m.present = true;
+    if (k >= 0) {
+        const bwams_aln_t &t = R.rec[k];
+        m.pos = t.pos; m.rid = t.rid; m.is_rev = t.is_rev; m.is_alt = t.is_alt; m.n_cigar = t.n_cigar; m.cigar_off = t.cigar_off;
+    } else { m.pos = -1; m.rid = -1; m.is_rev = 0; m.is_alt = 0; m.n_cigar = 0; m.cigar_off = 0; }
+    return m;
+}
+
+// mem_infer_dir (bwamem_pair.cpp:57-65)
+__device__ __forceinline__ int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) {
+    const int r1 = b1 >= l_pac, r2 = b2 >= l_pac;
+    const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+    *dist = p2 > b1 ? p2 - b1 : b1 - p2;
+    return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+__device__ __forceinline__ int raw_mapq(int diff, int a) {               // bwamem_pair.cpp:432
+#pragma clang fp contract(off)
+    return (int)(6.02 * diff / a + .499);
+}
+
+// What mem_sam_pe decides for a pair before any text is written (bwamem_pair.cpp:686-748): which branch, the two regions,
+// their mapping qualities, the region edits.  Both ends' lanes evaluate it; it reads both ends' regions.
+struct PairPlan {
+    bool paired;                 // the paired branch (else no_pairing)
+    int z[2], q_se[2];
+    int sub[2];                  // the chosen regions' sub after the edit (mem_reg2aln's a.sub = max(sub, csub))
+    bool was_secondary[2];       // secondary >= 0 before the edit (it becomes -2: no 0x100)
+    int sw_k[2];                 // secondary_all switch per end (-1: none)
+    int extra_flag;
+};
+
+__device__ void plan_pair(const SamArgs &A, const Read R[2], const bwams_pair_t &pr, PairPlan &P) {
+#pragma clang fp contract(off)
+    const int o = pr.score;
+    P.paired = false; P.extra_flag = 1;
+    P.z[0] = pr.z[0]; P.z[1] = pr.z[1];
+    P.sw_k[0] = P.sw_k[1] = -1;
+    if (!(pr.n_pri[0] && pr.n_pri[1] && o > 0)) return;
+    for (int i = 0; i < 2; ++i) {
+        int j;
+        for (j = 1; j < pr.n_pri[i]; ++j)
+            if (R[i].a[j].secondary < 0 && R[i].a[j].score >= A.sopt.T) break;
+        if (j < pr.n_pri[i]) return;                       // is_multi: no_pairing
+    }
+    const int score_un = R[0].a[0].score + R[1].a[0].score - A.opt.pen_unpaired;
+    int subo = pr.sub > score_un ? pr.sub : score_un;
+    int q_pe = raw_mapq(o - subo, A.opt.a);
+    if (pr.n_sub > 0) {
+        if (pr.n_sub + 1 >= A.logtab_n) { atomicAdd(A.bad, 1ull); return; }
+        q_pe -= (int)(4.343 * A.logtab[pr.n_sub + 1] + .499);
+    }
+    if (q_pe < 0) q_pe = 0;
+    if (q_pe > 60) q_pe = 60;
+    q_pe = (int)(q_pe * (1. - .5 * (R[0].a[0].frac_rep + R[1].a[0].frac_rep)) + .499);
+    P.paired = true;
+    if (o > score_un) {
+        for (int i = 0; i < 2; ++i) {
+            bwams_alnreg_t c = R[i].a[P.z[i]];
+            P.was_secondary[i] = c.secondary >= 0;
+            if (c.secondary >= 0) { c.sub = R[i].a[c.secondary].score; c.secondary = -2; }
+            P.sub[i] = c.sub > c.csub ? c.sub : c.csub;
+            int q = approx_mapq_se_dev(A.opt, c, A.logtab, A.logtab_n, A.coef_fac, A.bad);
+            q = q > q_pe ? q : q_pe < q + 40 ? q_pe : q + 40;
+            const int cap = raw_mapq(c.score - c.csub, A.opt.a);
+            P.q_se[i] = q < cap ? q : cap;
+        }
+        P.extra_flag |= 2;
+    } else {
+        P.z[0] = P.z[1] = 0;
+        for (int i = 0; i < 2; ++i) {
+            const bwams_alnreg_t &c = R[i].a[0];
+            P.was_secondary[i] = c.secondary >= 0;
+            P.sub[i] = c.sub > c.csub ? c.sub : c.csub;
+            P.q_se[i] = approx_mapq_se_dev(A.opt, c, A.logtab, A.logtab_n, A.coef_fac, A.bad);
+        }
+    }
+    for (int i = 0; i < 2; ++i) {
+        const int k = R[i].a[P.z[i]].secondary_all;
+        if (k >= 0 && k < pr.n_pri[i]) P.sw_k[i] = k;
+    }
 }
 
 template <bool EMIT>
 __global__ void sam_text_kernel(SamArgs A) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.nseq; r += (int64_t)gridDim.x * blockDim.x) {
         Read R;
-        const int64_t o = A.reg_off[r];
-        R.a = A.regs + o; R.rec = A.rec + o; R.mapq = A.mapq + o; R.n = (int)(A.reg_off[r + 1] - o);
-        R.seq = A.enc + A.cum[r]; R.l_seq = (int)(A.cum[r + 1] - A.cum[r]);
-        R.qual = A.quals ? A.quals + A.cum[r] : nullptr;
-        R.name = A.names + A.name_off[r]; R.l_name = (int)(A.name_off[r + 1] - A.name_off[r]);
-        R.comment = A.comments ? A.comments + A.comment_off[r] : nullptr;
-        R.l_comment = A.comments ? (int)(A.comment_off[r + 1] - A.comment_off[r]) : 0;
+        load_read(A, r, R);
         Writer W;
         W.p = EMIT ? A.out + A.out_off[r] : nullptr;
         W.n = 0;
-        int first = -1;
-        for (int k = 0; k < R.n && first < 0; ++k)
-            if (selected(A, R, k)) first = k;
-        if (first < 0) put_record(A, R, W, -1, 0, 0);
-        else {
-            const int mapq0 = R.mapq[first];
-            int which = 0;
-            for (int k = first; k < R.n; ++k)
-                if (selected(A, R, k)) put_record(A, R, W, k, which++, mapq0);
+        Mate none;
+        none.present = false; none.pos = -1; none.rid = -1; none.is_rev = none.is_alt = none.n_cigar = 0; none.cigar_off = 0;
+        put_reg2sam(A, R, W, 0, none);
+        if (!EMIT) A.len[r] = W.n;
+    }
+}
+
+// mem_sam_pe from mem_pair's result on (bwamem_pair.cpp:686-833); a lane per READ, both lanes of a pair take the pair's decisions
+template <bool EMIT>
+__global__ void sam_text_pe_kernel(SamArgs A) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.nseq; r += (int64_t)gridDim.x * blockDim.x) {
+        const int me = (int)(r & 1);
+        Read R[2];
+        load_read(A, r - me, R[0]);
+        load_read(A, r - me + 1, R[1]);
+        const bwams_pair_t pr = A.pairs[r >> 1];
+        PairPlan P;
+        plan_pair(A, R, pr, P);
+        Writer W;
+        W.p = EMIT ? A.out + A.out_off[r] : nullptr;
+        W.n = 0;
+        if (P.paired) {
+            R[0].sw_k = P.sw_k[0]; R[0].sw_z = P.z[0];
+            R[1].sw_k = P.sw_k[1]; R[1].sw_z = P.z[1];
+            const Read &S = R[me];
+            const int i = me;
+            RecInfo I;
+            I.n_list = 1; I.list[0] = P.z[i]; I.list_mapq[0] = P.q_se[i]; I.list[1] = 0; I.list_mapq[1] = 0;
+            bool alt_hit = false;
+            if (pr.n_pri[i] < S.n) {                       // the read has ALT hits
+                const bwams_alnreg_t &p = S.a[pr.n_pri[i]];
+                alt_hit = !(p.score < A.sopt.T || p.secondary >= 0 || !reg_is_alt(p));
+            }
+            if (alt_hit) { I.n_list = 2; I.list[1] = pr.n_pri[i]; I.list_mapq[1] = S.rec[pr.n_pri[i]].rid >= 0 ? S.mapq[pr.n_pri[i]] : 0; }
+            I.xa = !(A.sopt.flag & BWAMS_MEM_F_ALL);
+            const Mate m = mate_of(R[!me], P.z[!me]);
+            // h[i]
+            I.k = P.z[i]; I.which = 0;
+            I.flag = (S.rec[P.z[i]].flag & ~0x100) | (0x40 << i) | P.extra_flag;      // the edited region is never secondary >= 0
+            I.mapq = P.q_se[i]; I.sub = P.sub[i];
+            put_record(A, S, W, I, m, 0);
+            if (alt_hit) {                                 // g[i]
+                const int k = pr.n_pri[i];
+                I.k = k; I.which = 1;
+                I.flag = S.rec[k].flag | 0x800 | (0x40 << i) | P.extra_flag;
+                I.mapq = S.mapq[k]; I.sub = S.rec[k].sub;
+                put_record(A, S, W, I, m, 0);
+            }
+        } else {
+            int extra_flag = 1;
+            int which[2];
+            for (int i = 0; i < 2; ++i) {
+                which[i] = -1;
+                if (R[i].n) {
+                    if (R[i].a[0].score >= A.sopt.T) which[i] = 0;
+                    else if (pr.n_pri[i] < R[i].n && R[i].a[pr.n_pri[i]].score >= A.sopt.T) which[i] = pr.n_pri[i];
+                }
+            }
+            const int rid0 = which[0] >= 0 ? R[0].rec[which[0]].rid : -1, rid1 = which[1] >= 0 ? R[1].rec[which[1]].rid : -1;
+            if (rid0 == rid1 && rid0 >= 0) {
+                int64_t dist;
+                const int d = infer_dir(A.bns_l_pac, R[0].a[0].rb, R[1].a[0].rb, &dist);
+                if (!A.pes[d].failed && dist >= A.pes[d].low && dist <= A.pes[d].high) extra_flag |= 2;
+            }
+            const Mate m = mate_of(R[!me], which[!me]);
+            put_reg2sam(A, R[me], W, (me ? 0x81 : 0x41) | extra_flag, m);
         }
         if (!EMIT) A.len[r] = W.n;
     }
@@ -302,7 +544,10 @@ void launch_sam_text(const SamArgs &A, bool emit, int cu_count, hipStream_t st) 
     int64_t blocks = (A.nseq + 63) / 64;
     const int64_t cap = (int64_t)cu_count * 32;
     if (blocks > cap) blocks = cap;
-    if (emit) sam_text_kernel<true><<<(unsigned)blocks, 64, 0, st>>>(A);
+    if (A.pairs) {
+        if (emit) sam_text_pe_kernel<true><<<(unsigned)blocks, 64, 0, st>>>(A);
+        else sam_text_pe_kernel<false><<<(unsigned)blocks, 64, 0, st>>>(A);
+    } else if (emit) sam_text_kernel<true><<<(unsigned)blocks, 64, 0, st>>>(A);
     else sam_text_kernel<false><<<(unsigned)blocks, 64, 0, st>>>(A);
 }
 

@@ -231,7 +231,7 @@ int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uin
  * device.  Call order for a chunk: ... bwams_dedup_run, bwams_pair_run(BWAMS_PAIR_SINGLE_END) (= mem_mark_primary_se),
  * bwams_reg2aln_run(source 1), bwams_sam_upload (names / qualities / comments of the chunk: the bseq1_t fields the hot path
  * never needed), bwams_sam_run, bwams_sam_fetch.  Not built: MEM_F_PRIMARY5 (mem_reorder_primary5), MEM_F_REF_HDR, the
- * paired-end text (mem_sam_pe) and the exact-match records (mem_aln2sam_perfect): BWAMS_ERR_UNSUPPORTED / host side. */
+ * exact-match records (mem_aln2sam_perfect): BWAMS_ERR_UNSUPPORTED / host side.  Paired-end chunks: bwams_sam_run_pe below. */
 /* names of the index's sequences (bntann1_t.name): NUL-terminated, back to back; name_off[n_seqs + 1], name_off[i] = start of
  * name i.  Call after bwams_index_set_contigs (or on a one-sequence index). */
 int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int32_t *name_off);
@@ -240,6 +240,14 @@ int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int
 int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_off, const char *quals, const char *comments,
                      const int64_t *comment_off);
 int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, int64_t *sam_bytes);
+/* The paired-end text: mem_sam_pe from the call of mem_pair on (src/bwamem_pair.cpp:686-833 = the tail of mem_sam_pe_batch_post,
+ * :1070-1190) for every pair of the chunk (reads 2p, 2p + 1), after bwams_pair_run (mate rescue, marks, mem_pair) and
+ * bwams_reg2aln_run(source 1): the multi-hit test, q_pe / q_se with the +40 and tandem-repeat caps, the edits of the paired regions
+ * (sub, secondary = -2, the secondary_all switch before XA), the ALT hit, flags 0x1 / 0x2 / 0x8 / 0x20 / 0x40 / 0x80, RNEXT / PNEXT /
+ * TLEN, MC:Z, an unmapped end at its mate's coordinates; or the no_pairing branch (proper-pair flag from mem_infer_dir and pes, then
+ * mem_reg2sam per end with the mate's record).  pes = what bwams_pestat returned for the chunk.  MEM_F_NOPAIRING is not built. */
+int bwams_sam_run_pe(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, const bwams_pestat_t pes[4],
+                     int64_t *sam_bytes);
 /* sam: the text of all reads in read order (cap >= sam_bytes); read_off[nseq + 1]: where a read's lines start; mapq: the
  * device-side mem_approx_mapq_se of every region (region order of bwams_reg2aln_fetch).  Any of the three may be NULL. */
 int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off, int32_t *mapq, int64_t mapq_cap);

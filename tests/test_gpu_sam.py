@@ -107,3 +107,75 @@ def test_sam_text_call_order_and_unsupported_flags():
     with pytest.raises(capi.BwamsError):
         b.sam_run(c["gopt"], capi.default_sam_opt())
     b.close(); c["ix"].close()
+
+
+def _pe_pipeline(n_pairs, seed, **optkw):
+    g, idx, starts = repeat_genome()
+    oopt, gopt = loader.default_mem_opt(), capi.default_mem_opt()
+    for k, v in optkw.items():
+        setattr(oopt, k, v); setattr(gopt, k, v)
+    pr = simulate.make_read_pairs_bulk(g, n_pairs, seed=seed)
+    reads = np.asarray(pr).reshape(-1, np.asarray(pr).shape[-1]).copy()
+    rng = np.random.default_rng(seed)
+    for p in range(0, n_pairs, 4):                                   # pairs inside the repeat copies: XA, ties, rescue
+        st = starts[int(rng.integers(0, len(starts)))]
+        a = st + int(rng.integers(0, 100)); bpos = a + int(rng.integers(180, 330))
+        L = reads.shape[1]
+        if bpos + L <= len(g):
+            reads[2 * p] = g[a:a + L]
+            reads[2 * p + 1] = (3 - g[bpos:bpos + L][::-1]).astype(np.uint8)
+    reads[8] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8)          # one end unalignable
+    reads[20] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8); reads[21] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8)
+    ix = capi.Index.from_host(idx, 0)
+    ix.set_contig_names([b"chr1"])
+    enc, cum = simulate.flatten_reads(reads)
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.seed_run(capi.default_seed_opt(), with_sa=True)
+    b.chain_run(gopt); b.extend_run(gopt); b.dedup_run(gopt)
+    pes = b.pestat(gopt)
+    b.pair_run(pes, gopt, id_base=0)
+    regs, off, pairs = b.pair_fetch()
+    b.reg2aln(gopt, 1)
+    quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+    names = [b"pair%d" % (i // 2) for i in range(len(reads))]
+    comments = [b"BC:Z:%d" % (i // 2) if (i // 2) % 4 == 0 else None for i in range(len(reads))]
+    return dict(g=g, idx=idx, ix=ix, b=b, enc=enc, cum=cum, regs=regs, off=off, pairs=pairs, pes=pes, quals=quals, names=names,
+                comments=comments, oopt=oopt, gopt=gopt)
+
+
+def _compare_pe(c, flag=0, rg=b"", T=None):
+    b = c["b"]
+    so, sg = loader.default_sam_opt(flag, rg), capi.default_sam_opt(flag, rg)
+    if T is not None:
+        so.T = sg.T = T
+    b.sam_upload(c["names"], c["quals"], c["comments"])
+    nbytes = b.sam_run_pe(c["pes"], c["gopt"], sg)
+    text, roff, _ = b.sam_fetch()
+    want = loader.sam_pe(c["regs"], c["off"], c["enc"], c["cum"], c["idx"].ref_0123, len(c["g"]), c["pes"], c["pairs"], c["names"],
+                         quals=c["quals"], comments=c["comments"], contig_names=[b"chr1"], opt=c["oopt"], sopt=so)
+    assert nbytes == sum(len(w) for w in want) == roff[-1]
+    for r, w in enumerate(want):
+        got = text[roff[r]:roff[r + 1]]
+        assert got == w, (r, got, w)
+    return text, want
+
+
+def test_paired_end_sam_text_equals_oracle():
+    c = _pe_pipeline(500, 17)
+    text, want = _compare_pe(c)
+    lines = [ln.split(b"\t") for ln in text.split(b"\n")[:-1]]
+    flags = np.array([int(f[1]) for f in lines])
+    assert (flags & 2).sum() > 600 and (flags & 0x8).sum() >= 1 and sum(any(t.startswith(b"MC:Z:") for t in f[11:]) for f in lines) > 600
+    assert text.count(b"\tXA:Z:") > 20
+    # both branches ran: paired records (0x2 with the pair's mapq) and mem_reg2sam records of the no_pairing branch
+    pr = c["pairs"]
+    assert (pr["score"] > 0).sum() > 300 and (pr["score"] == 0).sum() >= 1
+    for flag, rg, T in ((0x8, b"rg1", None), (0x200 | 0x10, b"", None), (0, b"", 60)):
+        _compare_pe(c, flag, rg, T)
+    with pytest.raises(capi.BwamsError):
+        c["b"].sam_run(c["gopt"], capi.default_sam_opt())              # the single-end form refuses a paired-end chunk
+    c["b"].close(); c["ix"].close()
+    c = _pe_pipeline(300, 23, a=2, b=5, pen_unpaired=9, mapq_coef_len=0)
+    _compare_pe(c)
+    c["b"].close(); c["ix"].close()

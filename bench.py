@@ -550,6 +550,33 @@ def main():
                     "RCCL when sharded) + mate rescue (ksw_align2 on the GPU) + mem_mark_primary_se + mem_pair; regions and pairing decisions "
                     "stay on the device; rank 0's counts",
         }
+        if rank == 0:
+            # the paired-end SAM side beside: mem_reg2aln of the regions after rescue, then mem_sam_pe's text (never part of the timed batches)
+            t0 = time.perf_counter()
+            n_aln_ = capi.C.c_int64(0); n_cg_ = capi.C.c_int64(0); n_md_ = capi.C.c_int64(0)
+            capi._chk(capi.lib().bwams_reg2aln_run(batch.h, capi.C.byref(mem_opt), 1, capi.C.byref(n_aln_), capi.C.byref(n_cg_), capi.C.byref(n_md_)), "bwams_reg2aln_run")
+            pe_aln_ms = (time.perf_counter() - t0) * 1e3
+            pnames = [b"pair%d" % (rank * n_pairs + i // 2) for i in range(2 * n_pairs)]
+            batch.sam_upload(pnames, np.full(int(pcum[-1]), ord("I"), np.uint8))
+            batch.sam_run_pe(pes_, mem_opt, capi.default_sam_opt())
+            t0 = time.perf_counter()
+            pe_sam_bytes = batch.sam_run_pe(pes_, mem_opt, capi.default_sam_opt())
+            pe_sam_ms = (time.perf_counter() - t0) * 1e3
+            ptext, proff, _ = batch.sam_fetch()
+            ptb = np.frombuffer(ptext, np.uint8)
+            first_flags = [int(ptext[proff[r]:proff[r + 1]].split(b"\t", 2)[1]) for r in range(0, min(2 * n_pairs, 20000))]
+            pe_checks = {"one_block_per_read": bool(proff[-1] == pe_sam_bytes and np.all(np.diff(proff) > 0)),
+                         "every_block_ends_a_line": bool(np.all(ptb[proff[1:] - 1] == 10)),
+                         "first_in_pair_then_second": all((f & 0x41) == 0x41 if r % 2 == 0 else (f & 0x81) == 0x81 for r, f in enumerate(first_flags)),
+                         "proper_flag_symmetric": all((first_flags[r] & 2) == (first_flags[r + 1] & 2) for r in range(0, len(first_flags) - 1, 2))}
+            pe_out["sam_text"] = {"bytes": int(pe_sam_bytes), "lines": int((ptb == 10).sum()), "ms_reg2aln": round(pe_aln_ms, 2), "ms_run": round(pe_sam_ms, 2),
+                                  "Mreads_per_s": round(2 * n_pairs / (pe_sam_ms * 1e-3) / 1e6, 2) if pe_sam_ms > 0 else None,
+                                  "proper_pair_records": int(sum(1 for f in first_flags if f & 2)), "checks": pe_checks,
+                                  "note": "mem_sam_pe from mem_pair's result on (q_pe / q_se, region edits, mate fields, MC / XA / SA) on the device; "
+                                          "byte-equal to the oracle in tests/test_gpu_sam.py; first 20 000 reads' flags checked here"}
+            if not all(pe_checks.values()):
+                raise SystemExit(f"[bench] paired-end SAM text property check failed: {pe_checks}")
+            del ptext, ptb
 
     # ---------------- report ----------------
     if rank == 0:

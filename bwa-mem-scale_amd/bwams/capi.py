@@ -26,7 +26,7 @@ SYMBOLS = [
     "bwams_strerror", "bwams_last_error", "bwams_device_count",
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch",
-    "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_fetch",
+    "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
     "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
@@ -775,6 +775,15 @@ class Batch:
         sopt = sopt or default_sam_opt()
         n = C.c_int64(0)
         _chk(lib().bwams_sam_run(self.h, C.byref(opt), C.byref(sopt), C.byref(n)), "bwams_sam_run")
+        self._sam_bytes = n.value
+        return n.value
+
+    def sam_run_emf(self, emf: "Emf", opt: MemOpt | None = None, sopt=None) -> int:
+        """sam_run for a chunk that went through emf_run + emf_regs_run: resolved reads get mem_perfect2sam_cont's records."""
+        opt = opt or default_mem_opt()
+        sopt = sopt or default_sam_opt()
+        n = C.c_int64(0)
+        _chk(lib().bwams_sam_run_emf(self.h, C.byref(opt), C.byref(sopt), emf.h, C.byref(n)), "bwams_sam_run_emf")
         self._sam_bytes = n.value
         return n.value
 

@@ -1163,7 +1163,7 @@ int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_of
 }
 
 static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, const bwams_pestat_t *pes,
-                        int64_t *sam_bytes) {
+                        int64_t *sam_bytes, bwams_emf_t *emf = nullptr) {
     const bool pe = pes != nullptr;
     if (!b || !sopt || !b->chain || !b->chain->al_done || b->chain->al_source != 1 || b->chain->pr_single == pe) {
         set_last_error(pe ? "bwams_sam_run_pe: run bwams_pair_run (paired-end) and bwams_reg2aln_run(source 1) first"
@@ -1218,6 +1218,18 @@ static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwam
     A.opt = *opt; A.sopt = *sopt;
     A.logtab = s->sm_logtab.as<double>(); A.logtab_n = kLogN;
     A.coef_fac = opt->mapq_coef_len > 0 ? log((double)opt->mapq_coef_len) : 0.;
+    if (emf) {
+        if (!s->er_done || s->er_nseq != nseq) {
+            set_last_error("bwams_sam_run_emf: run bwams_emf_run and bwams_emf_regs_run for this chunk first");
+            return BWAMS_ERR_ARG;
+        }
+        A.er_regs = s->er_out.as<bwams_alnreg_t>(); A.er_off = s->er_ooff.as<int64_t>(); A.er_seed_len = emf->t.seed_len;
+    }
+    {
+        DevBns bns_;
+        if ((rc = dev_bns(b->idx, &bns_))) return rc;
+        A.contigs = bns_.contigs;
+    }
     A.pairs = pe ? s->pr_res.as<bwams_pair_t>() : nullptr;
     if (pe) memcpy(A.pes, pes, sizeof A.pes);
     A.bns_l_pac = (b->idx->fmi.ref_seq_len - 1) / 2;
@@ -1249,6 +1261,11 @@ static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwam
 
 int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, int64_t *sam_bytes) {
     return sam_run_impl(b, opt, sopt, nullptr, sam_bytes);
+}
+
+int bwams_sam_run_emf(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, bwams_emf_t *emf, int64_t *sam_bytes) {
+    if (!emf) return BWAMS_ERR_ARG;
+    return sam_run_impl(b, opt, sopt, nullptr, sam_bytes, emf);
 }
 
 int bwams_sam_run_pe(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, const bwams_pestat_t pes[4],

@@ -267,6 +267,10 @@ struct SamArgs {
     const double *logtab;          // log(i) from the host's C library
     int32_t logtab_n;
     double coef_fac;               // log(mapQ_coef_len)
+    const bwams_alnreg_t *er_regs; // reads the EMF resolved (single-end): their mem_perfect2reg regions, er_off[nseq + 1]; null = none
+    const int64_t *er_off;
+    int32_t er_seed_len;           // the table's L
+    const bwams_contig_t *contigs; // (offsets of the sequences: the exact-match record's POS)
     const bwams_pair_t *pairs;     // paired-end: mem_pair's result per pair (null: single-end)
     bwams_pestat_t pes[4];
     int64_t bns_l_pac;

@@ -455,6 +455,53 @@ __device__ void plan_pair(const SamArgs &A, const Read R[2], const bwams_pair_t 
     }
 }
 
+// mem_perfect2sam_cont + mem_aln2sam_perfect (bwamem.cpp:2280-2325, :2153-2227): the records of a read the EMF resolved, from the
+// regions mem_perfect2reg left for it (one per location of get_perfect_locations after perfect_dedup_patch, in that order)
+__device__ void put_perfect(const SamArgs &A, const Read &R, Writer &W, const bwams_alnreg_t *regs, int n) {
+    int n_out = 0;
+    const bool all = (A.sopt.flag & BWAMS_MEM_F_ALL) != 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !(n_out == 0 || all)) break;
+        for (int k = 0; k < n; ++k) {
+            const bwams_alnreg_t &r = regs[k];
+            if ((int)reg_is_alt(r) != pass) continue;
+            const bool is_rev = r.rb >= A.bns_l_pac, secondary = n_out > 0;
+            int64_t pos = is_rev ? (A.bns_l_pac << 1) - r.re : r.rb;
+            if (R.l_seq != A.er_seed_len && is_rev) pos -= R.l_seq - A.er_seed_len;
+            pos -= A.contigs[r.rid].offset;
+            const int flag = (is_rev ? 0x10 : 0) | (secondary ? 0x100 : 0);
+            W.s(R.name, R.l_name); W.c('\t');
+            W.num(flag); W.c('\t');
+            W.z(ctg_name(A, r.rid)); W.c('\t');
+            W.num(pos + 1); W.c('\t');
+            W.num(60); W.c('\t');
+            W.num(R.l_seq); W.c('M');
+            W.c('\t');
+            W.s("*\t0\t0", 5);
+            W.c('\t');
+            if (secondary) W.s("*\t*", 3);
+            else if (!is_rev) {
+                for (int i = 0; i < R.l_seq; ++i) W.c("ACGTN"[R.seq[i]]);
+                W.c('\t');
+                if (R.qual) W.s(R.qual, R.l_seq); else W.c('*');
+            } else {
+                for (int i = R.l_seq - 1; i >= 0; --i) W.c("TGCAN"[R.seq[i]]);
+                W.c('\t');
+                if (R.qual) { for (int i = R.l_seq - 1; i >= 0; --i) W.c(R.qual[i]); } else W.c('*');
+            }
+            W.s("\tNM:i:", 6); W.num(0);
+            W.s("\tMD:Z:", 6); W.num(R.l_seq);
+            W.s("\tAS:i:", 6); W.num((long long)R.l_seq * A.opt.a);
+            if (!secondary) { W.s("\tXS:i:", 6); W.num((k == 0 && n > 1) ? (long long)R.l_seq * A.opt.a : 0); }
+            if (A.sopt.rg_id[0]) { W.s("\tRG:Z:", 6); W.z(A.sopt.rg_id); }
+            if (R.l_comment) { W.c('\t'); W.s(R.comment, R.l_comment); }
+            W.c('\n');
+            ++n_out;
+            if (!all) break;
+        }
+    }
+}
+
 template <bool EMIT>
 __global__ void sam_text_kernel(SamArgs A) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.nseq; r += (int64_t)gridDim.x * blockDim.x) {
@@ -465,7 +512,9 @@ __global__ void sam_text_kernel(SamArgs A) {
         W.n = 0;
         Mate none;
         none.present = false; none.pos = -1; none.rid = -1; none.is_rev = none.is_alt = none.n_cigar = 0; none.cigar_off = 0;
-        put_reg2sam(A, R, W, 0, none);
+        const int n_er = A.er_regs ? (int)(A.er_off[r + 1] - A.er_off[r]) : 0;
+        if (n_er > 0) put_perfect(A, R, W, A.er_regs + A.er_off[r], n_er);      // worker_sam: perfect.exist -> mem_perfect2sam_cont, continue
+        else put_reg2sam(A, R, W, 0, none);
         if (!EMIT) A.len[r] = W.n;
     }
 }

@@ -230,8 +230,8 @@ int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uin
  * eleven fields, NM / MD / AS / XS / RG / SA / pa / XA tags, the comment), with mem_approx_mapq_se (:1983-2008) evaluated on the
  * device.  Call order for a chunk: ... bwams_dedup_run, bwams_pair_run(BWAMS_PAIR_SINGLE_END) (= mem_mark_primary_se),
  * bwams_reg2aln_run(source 1), bwams_sam_upload (names / qualities / comments of the chunk: the bseq1_t fields the hot path
- * never needed), bwams_sam_run, bwams_sam_fetch.  Not built: MEM_F_PRIMARY5 (mem_reorder_primary5), MEM_F_REF_HDR, the
- * exact-match records (mem_aln2sam_perfect): BWAMS_ERR_UNSUPPORTED / host side.  Paired-end chunks: bwams_sam_run_pe below. */
+ * never needed), bwams_sam_run, bwams_sam_fetch.  Not built: MEM_F_PRIMARY5 (mem_reorder_primary5), MEM_F_REF_HDR: BWAMS_ERR_UNSUPPORTED.
+ * Paired-end chunks: bwams_sam_run_pe; chunks with reads the EMF resolved: bwams_sam_run_emf (both below). */
 /* names of the index's sequences (bntann1_t.name): NUL-terminated, back to back; name_off[n_seqs + 1], name_off[i] = start of
  * name i.  Call after bwams_index_set_contigs (or on a one-sequence index). */
 int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int32_t *name_off);
@@ -240,6 +240,12 @@ int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int
 int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_off, const char *quals, const char *comments,
                      const int64_t *comment_off);
 int bwams_sam_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, int64_t *sam_bytes);
+/* bwams_sam_run for a chunk that went through the exact-match filter: a read bwams_emf_regs_run resolved in THIS chunk gets the
+ * records of mem_perfect2sam_cont / mem_aln2sam_perfect (src/bwamem.cpp:2280-2325, :2153-2227: MAPQ 60, <l_seq>M, NM 0, AS = l_seq * a,
+ * XS = AS when there is a second location, secondaries only with MEM_F_ALL, ALT locations last) as worker_sam's `perfect.exist`
+ * branch (src/bwamem.cpp:1786-1797) writes them; every other read goes through mem_reg2sam as in bwams_sam_run.  (Paired-end chunks
+ * need nothing special: worker_sam turns resolved ends into regions — bwams_emf_regs_run — and calls mem_sam_pe.) */
+int bwams_sam_run_emf(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, bwams_emf_t *emf, int64_t *sam_bytes);
 /* The paired-end text: mem_sam_pe from the call of mem_pair on (src/bwamem_pair.cpp:686-833 = the tail of mem_sam_pe_batch_post,
  * :1070-1190) for every pair of the chunk (reads 2p, 2p + 1), after bwams_pair_run (mate rescue, marks, mem_pair) and
  * bwams_reg2aln_run(source 1): the multi-hit test, q_pe / q_se with the +40 and tandem-repeat caps, the edits of the paired regions

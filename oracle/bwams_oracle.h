@@ -170,6 +170,10 @@ int orc_reg2aln(const bwams_mem_opt_t *opt, const struct orc_bns *bns, const uin
 int64_t orc_reg2sam_se(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const struct orc_bns *bns, const char *ctg_names,
                        const int32_t *ctg_off, const uint8_t *ref_string, int l_seq, const uint8_t *seq, const char *qual,
                        const char *name, const char *comment, const bwams_alnreg_t *regs, int n_regs, char *out, int64_t cap);
+/* mem_perfect2sam_cont for one read the EMF resolved, from the regions mem_perfect2reg leaves for it */
+int64_t orc_perfect2sam(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const struct orc_bns *bns, const char *ctg_names,
+                        const int32_t *ctg_off, int seed_len, int l_seq, const uint8_t *seq, const char *qual, const char *name,
+                        const char *comment, const bwams_alnreg_t *regs, int n, char *out, int64_t cap);
 /* mem_sam_pe from mem_pair's result on, for one pair (regs are edited in place as the reference edits them) */
 void orc_sam_pe(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const struct orc_bns *bns, const char *ctg_names,
                 const int32_t *ctg_off, const uint8_t *ref_string, const bwams_pestat_t pes[4], const int32_t l_seq[2],

@@ -707,6 +707,26 @@ def reg2sam_se(regs, reg_off, enc, cum, ref_string, l_pac, names, quals=None, co
     return out
 
 
+def perfect2sam(regs, read, l_pac, seed_len, name, qual=None, comment=None, contigs=None, contig_names=None, opt: MemOpt | None = None,
+                sopt: SamOpt | None = None):
+    """mem_perfect2sam_cont for one resolved read from its mem_perfect2reg regions -> bytes."""
+    opt = opt or default_mem_opt()
+    sopt = sopt or default_sam_opt()
+    contigs = contigs if contigs is not None else single_contig(l_pac)
+    bns, keep = _bns(l_pac, contigs)
+    cn_blob, cn_off = contig_name_table(contig_names if contig_names is not None else [b"chr%d" % (i + 1) for i in range(len(keep))])
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE)
+    q = np.ascontiguousarray(read, np.uint8)
+    f = lib().orc_perfect2sam
+    f.restype = C.c_int64
+    cap = 4096 + 1024 * len(regs)
+    buf = C.create_string_buffer(cap)
+    n = f(C.byref(opt), C.byref(sopt), C.byref(bns), cn_blob, _p(cn_off), int(seed_len), len(q), _p(q), qual, name, comment, _p(regs), len(regs),
+          buf, cap)
+    assert n >= 0
+    return buf.raw[:n]
+
+
 def sam_pe(regs, reg_off, enc, cum, ref_string, l_pac, pes, pairs, names, quals=None, comments=None, contigs=None, contig_names=None,
            opt: MemOpt | None = None, sopt: SamOpt | None = None):
     """mem_sam_pe from mem_pair's result on, over every pair of a chunk (regs / reg_off / pairs = pair_pe's outputs):

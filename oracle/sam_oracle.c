@@ -9,6 +9,7 @@
  *   mem_sam_pe        /root/reference/src/bwamem_pair.cpp:625-833   from mem_pair's result on (= the tail of
  *                     mem_sam_pe_batch_post, :981-1190): multi-hit test, q_pe / q_se, the region edits of the paired branch
  *                     (sub, secondary = -2, the secondary_all switch), the ALT hit, the no_pairing branch with mem_reg2sam.
+ *   mem_perfect2sam_cont / mem_aln2sam_perfect   /root/reference/src/bwamem.cpp:2280-2325, :2153-2227   (reads the EMF resolved)
  * mem_reorder_primary5 (MEM_F_PRIMARY5), MEM_F_NOPAIRING and MEM_F_REF_HDR are not restated.
  *
  * PARITY UNPINNED: bwamem.cpp / bwamem_extra.cpp include safestringlib (not buildable here) and the reference ships no
@@ -263,6 +264,62 @@ int64_t orc_reg2sam_se(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, co
 {
     sbuf_t str = {out, 0, cap, 0};
     reg2sam(opt, so, bns, ctg_names, ctg_off, ref_string, l_seq, seq, qual, name, comment, regs, n_regs, 0, 0, &str);
+    return str.over ? -1 - str.l : str.l;
+}
+
+/* mem_perfect2sam_cont + mem_aln2sam_perfect (bwamem.cpp:2280-2325, :2153-2227) for one read the EMF resolved.  regs / n = what
+ * mem_perfect2reg left for it (orc_perfect2reg: one region per location of get_perfect_locations after perfect_dedup_patch, in
+ * that order — the same list mem_perfect2sam_cont walks); seed_len = the table's L (init_mem_aln_perfect shifts the position
+ * of a reverse-strand hit of a longer read by l_seq - seed_len).  Returns the text length (-1 - length when cap was short). */
+int64_t orc_perfect2sam(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const orc_bns_t *bns, const char *ctg_names,
+                        const int32_t *ctg_off, int seed_len, int l_seq, const uint8_t *seq, const char *qual, const char *name,
+                        const char *comment, const bwams_alnreg_t *regs, int n, char *out, int64_t cap)
+{
+    sbuf_t str = {out, 0, cap, 0};
+    int n_out = 0;
+    for (int pass = 0; pass < 2; ++pass) {                  /* primary-assembly hits, then (if none, or with MEM_F_ALL) ALT hits */
+        if (pass == 1 && !(n_out == 0 || (so->flag & BWAMS_MEM_F_ALL))) break;
+        for (int k = 0; k < n; ++k) {
+            const bwams_alnreg_t *r = &regs[k];
+            const int is_alt = reg_is_alt(r), is_rev = r->rb >= bns->l_pac, secondary = n_out > 0;
+            int64_t loc, pos;
+            int flag, i;
+            if (is_alt != pass) continue;
+            loc = is_rev ? (bns->l_pac << 1) - r->re : r->rb;
+            pos = loc;
+            if (l_seq != seed_len && is_rev) pos = pos - (l_seq - seed_len);
+            pos -= bns->contigs[r->rid].offset;
+            flag = (is_rev ? 0x10 : 0) | (secondary ? 0x100 : 0);
+            sputs(&str, name); sputc(&str, '\t');
+            sputl(&str, flag & 0xffff); sputc(&str, '\t');
+            sputs(&str, ctg_names + ctg_off[r->rid]); sputc(&str, '\t');
+            sputl(&str, (long)(pos + 1)); sputc(&str, '\t');
+            sputl(&str, 60); sputc(&str, '\t');
+            sputl(&str, l_seq); sputc(&str, 'M');
+            sputc(&str, '\t');
+            sputsn(&str, "*\t0\t0", 5);
+            sputc(&str, '\t');
+            if (flag & 0x100) sputsn(&str, "*\t*", 3);
+            else if (!is_rev) {
+                for (i = 0; i < l_seq; ++i) sputc(&str, "ACGTN"[seq[i]]);
+                sputc(&str, '\t');
+                if (qual) { for (i = 0; i < l_seq; ++i) sputc(&str, qual[i]); } else sputc(&str, '*');
+            } else {
+                for (i = l_seq - 1; i >= 0; --i) sputc(&str, "TGCAN"[seq[i]]);
+                sputc(&str, '\t');
+                if (qual) { for (i = l_seq - 1; i >= 0; --i) sputc(&str, qual[i]); } else sputc(&str, '*');
+            }
+            sputsn(&str, "\tNM:i:", 6); sputl(&str, 0);
+            sputsn(&str, "\tMD:Z:", 6); sputl(&str, l_seq);
+            sputsn(&str, "\tAS:i:", 6); sputl(&str, l_seq * opt->a);
+            if (!secondary) { sputsn(&str, "\tXS:i:", 6); sputl(&str, (k == 0 && n > 1) ? l_seq * opt->a : 0); }
+            if (so->rg_id[0]) { sputsn(&str, "\tRG:Z:", 6); sputs(&str, so->rg_id); }
+            if (comment) { sputc(&str, '\t'); sputs(&str, comment); }
+            sputc(&str, '\n');
+            ++n_out;
+            if (!(so->flag & BWAMS_MEM_F_ALL)) break;
+        }
+    }
     return str.over ? -1 - str.l : str.l;
 }
 

@@ -179,3 +179,83 @@ def test_paired_end_sam_text_equals_oracle():
     c = _pe_pipeline(300, 23, a=2, b=5, pen_unpaired=9, mapq_coef_len=0)
     _compare_pe(c)
     c["b"].close(); c["ix"].close()
+
+
+@pytest.mark.parametrize("L", [150, 101])
+def test_exact_match_records_equal_oracle(L):
+    """A single-end chunk behind the exact-match filter: resolved reads get mem_perfect2sam_cont's records (all flag settings,
+    ALT-only reads, multi-location reads, reads longer than L on the reverse strand), the others mem_reg2sam's."""
+    from bwams import emf, fmindex
+    from util import toy
+    g0, _ = toy(70000)
+    g = g0[:60000].copy()
+    g[5000:5400] = g[1000:1400]
+    g[9000:9400] = (3 - g[1000:1400][::-1])
+    g[30000:30400] = g[1000:1400]                            # a copy on the ALT sequence
+    g[40000:40300] = g[26000:26300]                          # ALT-only copies
+    g[20000:20700] = np.tile(np.array([0, 1, 0, 2, 1], np.uint8), 140)
+    idx = fmindex.build_fmindex(g)
+    ix = capi.Index.from_host(idx, 0)
+    contigs = np.zeros(3, capi.CONTIG_DTYPE)
+    contigs["offset"], contigs["len"], contigs["is_alt"] = [0, 8000, 25000], [8000, 17000, len(g) - 25000], [0, 0, 1]
+    ix.set_contigs(contigs)
+    cnames = [b"chrA", b"chrB", b"chrB_alt"]
+    ix.set_contig_names(cnames)
+    tab = emf.build_emf(g, L)
+    e = capi.Emf(ix, table=tab)
+    o = loader.OracleEMF(tab, idx.ref_0123)
+    rng = np.random.default_rng(L + 5)
+    reads = []
+    for it in range(900):
+        ln = L if it % 3 else int(rng.integers(L + 1, L + 40))
+        where = it % 6
+        st = (int(rng.integers(1000, 1400 - ln)) if where == 0 else int(rng.integers(20000, 20700 - ln)) if where == 1
+              else int(rng.integers(26000, 26300 - ln)) if where == 2 else int(rng.integers(0, len(g) - ln)))
+        rd = g[st:st + ln].copy()
+        if it % 2:
+            rd = simulate.revcomp(rd)
+        if it % 7 == 0:
+            rd[rng.integers(0, ln)] ^= 1                     # not exact: the normal path
+        reads.append(rd)
+    enc, cum = simulate.flatten_reads(reads)
+    gopt, oopt = capi.default_mem_opt(), loader.default_mem_opt()
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    b.seed_upload(enc, cum)
+    b.emf_run(e)
+    perfect, code = b.emf_fetch(len(reads))
+    eregs, eoff, _ = b.emf_regs(e, gopt)
+    b.seed_run(capi.default_seed_opt(), with_sa=True)        # the resolved reads are skipped
+    b.chain_run(gopt); b.extend_run(gopt); b.dedup_run(gopt)
+    b.mark_primary_se(gopt, id_base=0)
+    regs, off, _ = b.pair_fetch()
+    b.reg2aln(gopt, 1)
+    names = [b"q%d" % i for i in range(len(reads))]
+    quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+    comments = [b"X:Z:%d" % i if i % 5 == 0 else None for i in range(len(reads))]
+    b.sam_upload(names, quals, comments)
+    n_res = 0
+    for flag, rg in ((0, b""), (0x8, b"rg")):
+        so, sg = loader.default_sam_opt(flag, rg), capi.default_sam_opt(flag, rg)
+        b.sam_run_emf(e, gopt, sg)
+        text, roff, _ = b.sam_fetch()
+        normal = loader.reg2sam_se(regs, off, enc, cum, idx.ref_0123, len(g), names, quals=quals, comments=comments, contigs=contigs,
+                                   contig_names=cnames, opt=oopt, sopt=so)
+        for r, rd in enumerate(reads):
+            got = text[roff[r]:roff[r + 1]]
+            if eoff[r + 1] > eoff[r]:
+                want_regs, _ = o.perfect2reg(rd, int(perfect[r, 0]), int(perfect[r, 1]), len(g), contigs=contigs)
+                want = loader.perfect2sam(want_regs, rd, len(g), L, names[r], qual=bytes(quals[cum[r]:cum[r + 1]]), comment=comments[r],
+                                          contigs=contigs, contig_names=cnames, opt=oopt, sopt=so)
+                n_res += 1
+                f = got.split(b"\n")[0].split(b"\t")
+                assert f[4] == b"60" and f[5] == b"%dM" % len(rd) and b"NM:i:0" in f
+            else:
+                want = normal[r]
+            assert got == want, (r, got, want)
+    assert n_res > 600
+    joined = text
+    assert b"chrB_alt\t" in joined and joined.count(b"\t256\t") + joined.count(b"\t272\t") > 50       # MEM_F_ALL: secondary exact-match records
+    with pytest.raises(capi.BwamsError):
+        b2 = capi.Batch(ix, 4, 600)
+        b2.sam_run_emf(e, gopt, capi.default_sam_opt())
+    b.close(); e.close(); ix.close()

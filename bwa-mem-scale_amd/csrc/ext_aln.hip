@@ -350,6 +350,34 @@ __global__ void ext_heavy_list_kernel(ExtArgs A) {
     if (A.seed_off[r + 1] - A.seed_off[r] > kLightRegs) A.sel_heavy[atomicAdd(A.n_sel_heavy, 1ull)] = (int32_t)r;
 }
 
+// purge_keep_anyway over the wavefront: the later seeds of the chain 64 at a time (the scalar loop stops at the first hit and
+// reports whether there was one — an "any")
+__device__ __forceinline__ bool purge_keep_anyway_w(const bwams_chain_seed_t &s, const bwams_chain_seed_t *cs, const uint32_t *srt2, int k, int n,
+                                                    int lane) {
+    bool found = false;
+    for (int v0 = k + 1; v0 < n && !found; v0 += 64) {
+        const int v = v0 + lane;
+        bool hit = false;
+        if (v < n) {
+            const uint32_t sv = __hip_atomic_load(&srt2[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sv != 0xffffffffu) {
+                const bwams_chain_seed_t t = cs[sv];
+                if (!((double)t.len < (double)s.len * .95)) {
+                    hit = (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= (s.len >> 2) && t.qbeg - s.qbeg != t.rbeg - s.rbeg) ||
+                          (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= (s.len >> 2) && s.qbeg - t.qbeg != s.rbeg - t.rbeg);
+                }
+            }
+        }
+        found = __any(hit);
+    }
+    return found;
+}
+
+// Wave per read.  The decisions are sequential in the visiting order, but what a slot needs to be decided — its chain, its place
+// in the chain's order, its seed, its state — depends on no decision (a purge rewrites only the purged slot's own entries), so the
+// wave fetches 64 slots at once, one per lane (four dependent loads each, in flight together), and then walks them with the
+// slot's fields broadcast from its lane.  (One slot at a time, every slot paid the four load latencies: the kernel's duration was
+// the ~1000 seeds of the heaviest read times ~3 us, the same at any chunk size.)
 __global__ __launch_bounds__(256) void ext_select_wave_kernel(ExtArgs A) {
     const int lane = threadIdx.x & 63;
     const int64_t n_heavy = (int64_t)*A.n_sel_heavy;
@@ -364,44 +392,61 @@ __global__ __launch_bounds__(256) void ext_select_wave_kernel(ExtArgs A) {
         const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
         KReg *kreg = reinterpret_cast<KReg *>(A.kreg) + reg0;
         int lim = A.lim[r];
-        for (; t < av_n; ++t) {
-            const int64_t p = reg0 + t;
-            bwams_chain_t c;
-            bwams_chain_seed_t s;
-            int k;
-            select_seed_of_slot(A, p, c, k, s);
-            bool brk = false;
-            for (int base = 0; base < lim && !brk; base += 64) {          // the kept regions, 64 at a time
-                const int i = base + lane;
-                int cls = 0;
-                if (i < lim) {
-                    const KReg q = kreg[i];
-                    cls = purge_class(A.opt, s, l_query, q.rb, q.re, q.qb, q.qe, q.seedlen0, q.w);
-                }
-                brk = __ballot(cls == 2) != 0;
+        bool stop = false;
+        while (t < av_n && !stop) {
+            const int nb = av_n - t < 64 ? av_n - t : 64;
+            int64_t my_off = 0, my_rbeg = 0;
+            int my_n = 0, my_k = 0, my_st = 0, my_qbeg = 0, my_len = 0;
+            if (lane < nb) {
+                const int64_t p = reg0 + t + lane;
+                bwams_chain_t c;
+                bwams_chain_seed_t sd;
+                select_seed_of_slot(A, p, c, my_k, sd);
+                my_off = c.seed_off; my_n = c.n; my_rbeg = sd.rbeg; my_qbeg = sd.qbeg; my_len = sd.len;
+                my_st = A.state[p];
             }
-            const int st = A.state[p];
-            if (brk && !purge_keep_anyway(s, A.seeds + c.seed_off, A.srt + c.seed_off, k, c.n)) {
+            int j = 0;
+            for (; j < nb; ++j) {
+                const int64_t p = reg0 + t + j;
+                const int64_t c_off = ((int64_t)__shfl((int)(my_off >> 32), j) << 32) | (uint32_t)__shfl((int)my_off, j);
+                bwams_chain_seed_t s;
+                s.rbeg = ((int64_t)__shfl((int)(my_rbeg >> 32), j) << 32) | (uint32_t)__shfl((int)my_rbeg, j);
+                s.qbeg = __shfl(my_qbeg, j); s.len = __shfl(my_len, j);
+                const int c_n = __shfl(my_n, j), k = __shfl(my_k, j), st = __shfl(my_st, j);
+                bool brk = false;
+                for (int base = 0; base < lim && !brk; base += 64) {          // the kept regions, 64 at a time
+                    const int i = base + lane;
+                    int cls = 0;
+                    if (i < lim) {
+                        const KReg q = kreg[i];
+                        cls = purge_class(A.opt, s, l_query, q.rb, q.re, q.qb, q.qe, q.seedlen0, q.w);
+                    }
+                    brk = __ballot(cls == 2) != 0;
+                }
+                if (brk && !purge_keep_anyway_w(s, A.seeds + c_off, A.srt + c_off, k, c_n, lane)) {
+                    if (lane == 0) {
+                        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&A.regs[p].qb), 0xffffffffffffffffull,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // qb = qe = -1
+                        __hip_atomic_store(&A.srt[c_off + k], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        A.state[p] = st | kExtPurged;
+                    }
+                    continue;
+                }
+                if (!(st & kExtDone)) {
+                    if (lane == 0) { A.state[p] = st | kExtReq; atomicAdd(&A.ctr->n_req, 1ull); }
+                    stop = true;
+                    break;
+                }
                 if (lane == 0) {
-                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&A.regs[p].qb), 0xffffffffffffffffull,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // qb = qe = -1
-                    __hip_atomic_store(&A.srt[c.seed_off + k], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    A.state[p] = st | kExtPurged;
+                    const bwams_alnreg_t *a = &A.regs[p];
+                    KReg q;
+                    q.rb = a->rb; q.re = a->re; q.qb = a->qb; q.qe = a->qe; q.seedlen0 = a->seedlen0; q.w = a->w;
+                    kreg[lim] = q;
+                    A.state[p] = st | kExtKept;
                 }
-                continue;
+                ++lim;
             }
-            if (!(st & kExtDone)) {
-                if (lane == 0) { A.state[p] = st | kExtReq; atomicAdd(&A.ctr->n_req, 1ull); }
-                break;
-            }
-            if (lane == 0) {
-                const bwams_alnreg_t *a = &A.regs[p];
-                KReg q;
-                q.rb = a->rb; q.re = a->re; q.qb = a->qb; q.qe = a->qe; q.seedlen0 = a->seedlen0; q.w = a->w;
-                kreg[lim] = q;
-                A.state[p] = st | kExtKept;
-            }
-            ++lim;
+            t += j;                                                          // a request leaves t at the requested slot
         }
         if (lane == 0) { A.cur[r] = t; A.lim[r] = lim; }
     }

@@ -677,6 +677,7 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
     if (rc) return rc;
     int kMaxRounds = 6;
     if (const char *e = getenv("BWAMS_EXT_MAX_ROUNDS")) kMaxRounds = atoi(e) > 0 ? atoi(e) : 1;    // test knob: force the extend-the-rest fallback
+    const bool adaptive_off = getenv("BWAMS_EXT_ALL_ROUNDS") != nullptr;                             // test knob: never cut the rounds short
     ChainState *s = b->chain;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
@@ -701,13 +702,20 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
         if (round == 0) { BWAMS_HIP(hipEventRecord(s->ev[7], st)); BWAMS_HIP(hipEventRecord(s->ev[8], st)); }
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_req, 0, sizeof(unsigned long long), st));
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->sel_ticket, 0, sizeof(unsigned long long), st));
+        BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_rest, 0, sizeof(unsigned long long), st));
         if (s->n_seeds) launch_ext_select(A, b->cu_count, st);
         if (round == 0) BWAMS_HIP(hipEventRecord(s->ev[9], st));
-        unsigned long long n_req = 0;
+        unsigned long long n_req = 0, n_rest = 0;
         BWAMS_HIP(hipMemcpyAsync(&n_req, &b->d_ctr->n_req, sizeof n_req, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipMemcpyAsync(&n_rest, &b->d_ctr->n_rest, sizeof n_rest, hipMemcpyDeviceToHost, st));
         BWAMS_HIP(hipStreamSynchronize(st));
         if (n_req == 0) break;
-        if (round + 1 >= kMaxRounds) launch_ext_request_rest(A, st);
+        // A round costs about as much as ~10^5 extensions whatever it holds (launches, the selection's walk of the heaviest
+        // reads).  When the seeds still undecided — at most n_rest, the slots behind this round's requests — are few beside what
+        // has been extended already, extending them all now (as the reference does with every seed) is cheaper than the rounds
+        // that would sort out which of them are dead.
+        const bool few_left = !adaptive_off && (int64_t)(n_req + n_rest) * 32 < tot_left + tot_right;
+        if (round + 1 >= kMaxRounds || few_left) launch_ext_request_rest(A, st);
     }
     BWAMS_HIP(hipEventRecord(s->ev[11], st));
     BWAMS_HIP(hipGetLastError());

@@ -93,6 +93,7 @@ struct DevCounters {
     unsigned long long pair_ticket2;     // mem_mark_primary_se: work cursor of the wave tier's small-LDS instance
     unsigned long long dedup_ticket2, dedup_ticket3;    // dedup: work cursors of the wave tier's smaller instances
     unsigned long long ert_kmer, ert_nodes, ert_ref;   // ERT profile kernel: k-mer entries read, tree records decoded, text bytes compared
+    unsigned long long n_rest;           // extension: slots behind the requests of the last selection (an upper bound of the undecided seeds)
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };
 

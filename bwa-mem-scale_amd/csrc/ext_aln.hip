@@ -302,6 +302,7 @@ __device__ __forceinline__ void select_seed_of_slot(const ExtArgs &A, int64_t p,
 __global__ __launch_bounds__(64) void ext_select_kernel(ExtArgs A) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool req = false;
+    int rest = 0;
     if (r < A.nseq) {
         const int64_t reg0 = A.seed_off[r];
         const int av_n = (int)(A.seed_off[r + 1] - reg0);
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(64) void ext_select_kernel(ExtArgs A) {
                     A.state[p] = st | kExtPurged;
                     continue;
                 }
-                if (!(st & kExtDone)) { A.state[p] = st | kExtReq; req = true; break; }
+                if (!(st & kExtDone)) { A.state[p] = st | kExtReq; req = true; rest = av_n - t - 1; break; }
                 const bwams_alnreg_t *a = &A.regs[p];
                 KReg q;
                 q.rb = a->rb; q.re = a->re; q.qb = a->qb; q.qe = a->qe; q.seedlen0 = a->seedlen0; q.w = a->w;
@@ -340,7 +341,13 @@ __global__ __launch_bounds__(64) void ext_select_kernel(ExtArgs A) {
         }
     }
     const unsigned long long m = __ballot(req);
-    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&A.ctr->n_req, (unsigned long long)__popcll(m));
+    if (m) {
+        for (int o = 32; o > 0; o >>= 1) rest += __shfl_xor(rest, o);
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) {
+            atomicAdd(&A.ctr->n_req, (unsigned long long)__popcll(m));
+            if (rest) atomicAdd(&A.ctr->n_rest, (unsigned long long)rest);
+        }
+    }
 }
 
 // lane per read, once per run: the reads the wave tier of the selection handles
@@ -433,7 +440,11 @@ __global__ __launch_bounds__(256) void ext_select_wave_kernel(ExtArgs A) {
                     continue;
                 }
                 if (!(st & kExtDone)) {
-                    if (lane == 0) { A.state[p] = st | kExtReq; atomicAdd(&A.ctr->n_req, 1ull); }
+                    if (lane == 0) {
+                        A.state[p] = st | kExtReq;
+                        atomicAdd(&A.ctr->n_req, 1ull);
+                        if (av_n - (t + j) - 1 > 0) atomicAdd(&A.ctr->n_rest, (unsigned long long)(av_n - (t + j) - 1));
+                    }
                     stop = true;
                     break;
                 }

@@ -243,14 +243,19 @@ def test_round_cap_extends_the_rest(rep_toy, monkeypatch):
     wregs, wreg_off, wseeds = loader.chain2aln(want["chains"], want["seeds"], want["chain_off"], ctx["enc"], ctx["cum"],
                                                ctx["ref"], ctx["l_pac"], opt=ctx["oopt"])
     rounds = []
-    for cap in ("6", "1"):
+    for cap, every_round in (("6", True), ("6", False), ("1", False)):
         monkeypatch.setenv("BWAMS_EXT_MAX_ROUNDS", cap)
+        if every_round:
+            monkeypatch.setenv("BWAMS_EXT_ALL_ROUNDS", "1")       # never cut the rounds short
+        else:
+            monkeypatch.delenv("BWAMS_EXT_ALL_ROUNDS", raising=False)
         b.extend_run(ctx["gopt"])
         regs, reg_off, aln = b.extend_fetch()
         assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])
         _assert_regs(regs, wregs, False)
         rounds.append(b.stats().n_ext_rounds)
-    assert rounds[0] > 2 and rounds[1] == 2          # natural convergence vs. round 0 + "the rest"
+    # natural convergence; the default (the rest is extended at once when little is left); round 0 + "the rest"
+    assert rounds[0] > 2 and 2 <= rounds[1] <= rounds[0] and rounds[2] == 2
     b.close()
 
 

@@ -1092,9 +1092,11 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes_xl(kClassXL), aux[0]>>>(A, cls + 6, cls + 0, tk + 6, -kClassXL);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[1]>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
     chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassL1), aux[2]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
-    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
     chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
     chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 4, cls + 5, tk + 5, kClassS);
+    // class M behind class S rather than behind class L (kernel trace at GRCh38 size: L 10.3 ms + M 4.3 was the stage's longest
+    // stream; S 8.3, L1 6.9 + M1 3.4, XL 0.9 + 8.1)
+    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[3]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
     chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[4]>>>(A, n_seeds);
     for (int i = 0; i < 5; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
@@ -1112,9 +1114,13 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     for (int i = 0; i < 2; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
     unsigned long long *htk = A.ctr->heavy_tickets;
-    chain_heavy_kernel<<<(unsigned)cu_count, 64, heavy_lds_bytes(kHeavyCap[2]), aux[0]>>>(A, &A.ctr->n_heavy, kHeavyCap[1], kHeavyCap[2], htk + 2);
+    // The class of the longest reads (a whole CU's LDS per read, a few dozen reads per million) goes on the batch's own stream: it
+    // starts without waiting for the fork event, i.e. before the other classes' blocks have filled every CU's LDS — behind them
+    // (kernel trace) its blocks found no CU with 157 KB free until the other classes drained: 16.8 ms for 26 reads of ~4 ms.
+    // Its blocks without a read leave at once.
+    chain_heavy_kernel<<<(unsigned)cu_count, 64, heavy_lds_bytes(kHeavyCap[2]), st>>>(A, &A.ctr->n_heavy, kHeavyCap[1], kHeavyCap[2], htk + 2);
     chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, heavy_lds_bytes(kHeavyCap[1]), aux[1]>>>(A, &A.ctr->n_heavy, kHeavyCap[0], kHeavyCap[1], htk + 1);
-    chain_heavy_kernel<<<(unsigned)(cu_count * 12), 64, heavy_lds_bytes(kHeavyCap[0]), st>>>(A, &A.ctr->n_heavy, 0, kHeavyCap[0], htk + 0);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 12), 64, heavy_lds_bytes(kHeavyCap[0]), aux[0]>>>(A, &A.ctr->n_heavy, 0, kHeavyCap[0], htk + 0);
     for (int i = 0; i < 2; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;

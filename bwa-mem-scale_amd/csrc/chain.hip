@@ -1094,10 +1094,10 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassL1), aux[2]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
     chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
     chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 4, cls + 5, tk + 5, kClassS);
-    // class M behind class S rather than behind class L (kernel trace at GRCh38 size: L 10.3 ms + M 4.3 was the stage's longest
-    // stream; S 8.3, L1 6.9 + M1 3.4, XL 0.9 + 8.1)
-    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[3]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
     chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[4]>>>(A, n_seeds);
+    // class M behind the lane tier (5 ms) rather than behind class L or S (kernel trace at GRCh38 size: L 8.9-10.3 ms + M 4.3-6.7 was
+    // the stage's longest stream; S 7.8, L1 7.7 + M1 2.9, XL 0.9 + 7.2)
+    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[4]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
     for (int i = 0; i < 5; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;

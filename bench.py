@@ -659,7 +659,8 @@ def main():
                 "ext_select": round(mean("ms_ext_purge"), 3),
                 "ext_total": round(mean("ms_ext_total"), 3),
                 "dedup": round(mean("ms_dedup"), 3),
-                "note": "per chunk of reads, HIP events on the batch's stream; ext_tasks/left/right/select are the first extension round, ext_total covers all rounds",
+                "note": "per chunk of reads, HIP events on the batch's stream; ext_tasks/left/right/select are the first extension round, ext_total covers all rounds; "
+                        "SMEM round 3 runs beside round 2 on a stream of its own (it fills round 2's tail): its bracket overlaps round 2's, seed_total is the wall time",
             },
             "events_per_read": {
                 "backward_ext": round(st.n_ext / CHn, 2),

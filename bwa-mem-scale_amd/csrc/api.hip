@@ -467,6 +467,9 @@ int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, 
     BWAMS_HIP(hipGetDeviceProperties(&prop, ix->device));
     b->cu_count = prop.multiProcessorCount;
     BWAMS_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    BWAMS_HIP(hipStreamCreateWithFlags(&b->seed_aux, hipStreamNonBlocking));
+    BWAMS_HIP(hipEventCreateWithFlags(&b->seed_fork, hipEventDisableTiming));
+    BWAMS_HIP(hipEventCreateWithFlags(&b->seed_join, hipEventDisableTiming));
     for (auto &e : b->ev) BWAMS_HIP(hipEventCreate(&e));
     for (auto &e : b->ev_emf) BWAMS_HIP(hipEventCreate(&e));
 
@@ -507,6 +510,9 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     for (auto &e : b->ev_emf)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(b->stream);
+    if (b->seed_aux) (void)hipStreamDestroy(b->seed_aux);
+    if (b->seed_fork) (void)hipEventDestroy(b->seed_fork);
+    if (b->seed_join) (void)hipEventDestroy(b->seed_join);
     delete b;
     return BWAMS_OK;
 }
@@ -640,15 +646,32 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     BWAMS_HIP(hipEventRecord(b->ev[9], st));
     launch_mark(b->d_ctr, 1, st);
     if (b->nseq > 0) launch_round2_work(a, b->d_work2, b->pool_cap, split_len, opt->split_width, b->cu_count, st);
+    // Round 3 reads nothing of rounds 1 and 2 (bwtSeedStrategyAllPosOneThread walks every read from position 0): it runs beside
+    // round 2 on a stream of its own and fills the tail in which round 2's slowest reads keep few lanes busy.  Its extensions and
+    // SMEMs are counted apart (n_ext3 / n_blk3 / n_smem3), so that the per-round figures stay exact.
+    SeedLaunch a3 = a;
+    a3.min_seed_len = opt->min_seed_len + 1;
+    static const bool r3_beside = !(getenv("BWAMS_SEED_R3_BESIDE") && atoi(getenv("BWAMS_SEED_R3_BESIDE")) == 0);
+    const bool r3 = b->nseq > 0 && opt->max_mem_intv > 0;
+    hipStream_t st3 = r3_beside ? b->seed_aux : st;
+    if (r3 && r3_beside) {
+        BWAMS_HIP(hipEventRecord(b->seed_fork, st));
+        BWAMS_HIP(hipStreamWaitEvent(st3, b->seed_fork, 0));
+        BWAMS_HIP(hipEventRecord(b->ev[12], st3));
+        launch_smem_round3(a3, opt->max_mem_intv, b->cu_count, st3);
+        BWAMS_HIP(hipEventRecord(b->ev[13], st3));
+        BWAMS_HIP(hipEventRecord(b->seed_join, st3));
+    }
     BWAMS_HIP(hipEventRecord(b->ev[10], st));
     if (b->nseq > 0) launch_smem_round2(a, b->d_work2, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[11], st));
+    if (r3 && r3_beside) BWAMS_HIP(hipStreamWaitEvent(st, b->seed_join, 0));
     launch_mark(b->d_ctr, 2, st);
-    SeedLaunch a3 = a;
-    a3.min_seed_len = opt->min_seed_len + 1;
-    BWAMS_HIP(hipEventRecord(b->ev[12], st));
-    if (b->nseq > 0 && opt->max_mem_intv > 0) launch_smem_round3(a3, opt->max_mem_intv, b->cu_count, st);
-    BWAMS_HIP(hipEventRecord(b->ev[13], st));
+    if (!(r3 && r3_beside)) {
+        BWAMS_HIP(hipEventRecord(b->ev[12], st));
+        if (r3) launch_smem_round3(a3, opt->max_mem_intv, b->cu_count, st);
+        BWAMS_HIP(hipEventRecord(b->ev[13], st));
+    }
     launch_mark(b->d_ctr, 3, st);
     BWAMS_HIP(hipEventRecord(b->ev[3], st));
     BWAMS_HIP(hipGetLastError());

@@ -93,6 +93,7 @@ struct DevCounters {
     unsigned long long pair_ticket2;     // mem_mark_primary_se: work cursor of the wave tier's small-LDS instance
     unsigned long long dedup_ticket2, dedup_ticket3;    // dedup: work cursors of the wave tier's smaller instances
     unsigned long long ert_kmer, ert_nodes, ert_ref;   // ERT profile kernel: k-mer entries read, tree records decoded, text bytes compared
+    unsigned long long work_head3, n_ext3, n_blk3, n_smem3;   // SMEM round 3 (it may run beside round 2): its own cursor and counts, folded in by mark_kernel(3)
     unsigned long long n_rest;           // extension: slots behind the requests of the last selection (an upper bound of the undecided seeds)
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };
@@ -167,6 +168,8 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
 struct bwams_batch {
     bwams_index *idx = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t seed_aux = nullptr;      // SMEM round 3 runs beside round 2
+    hipEvent_t seed_fork = nullptr, seed_join = nullptr;
     int64_t max_reads = 0, max_bases = 0, max_smem = 0, max_sa = 0;
     int64_t pool_cap = 0;                // max_smem + chunk slack
     int cu_count = 0;

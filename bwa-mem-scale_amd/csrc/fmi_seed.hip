@@ -216,22 +216,22 @@ __device__ __forceinline__ void wave_emit(const SeedLaunch &a, WaveOut &w, bool 
     w.used += cnt;
 }
 
-__device__ __forceinline__ void wave_emit_finish(const SeedLaunch &a, WaveOut &w) {
+__device__ __forceinline__ void wave_emit_finish(const SeedLaunch &a, WaveOut &w, bool round3 = false) {
     wave_close_chunk(a, w);
     unsigned long long e = w.emitted;
     for (int o = 32; o > 0; o >>= 1) e += mk64(__shfl_down((uint32_t)e, o), __shfl_down((uint32_t)(e >> 32), o));
-    if ((threadIdx.x & 63) == 0 && e) atomicAdd(&a.ctr->n_smem_valid, e);
+    if ((threadIdx.x & 63) == 0 && e) atomicAdd(round3 ? &a.ctr->n_smem3 : &a.ctr->n_smem_valid, e);
 }
 
 __device__ __forceinline__ void flush_counters(DevCounters *ctr, unsigned long long n_ext,
-                                               unsigned long long n_blk) {
+                                               unsigned long long n_blk, bool round3 = false) {
     for (int o = 32; o > 0; o >>= 1) {
         n_ext += mk64(__shfl_down((uint32_t)n_ext, o), __shfl_down((uint32_t)(n_ext >> 32), o));
         n_blk += mk64(__shfl_down((uint32_t)n_blk, o), __shfl_down((uint32_t)(n_blk >> 32), o));
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&ctr->n_ext, n_ext);
-        atomicAdd(&ctr->n_ext_blocks, n_blk);
+        atomicAdd(round3 ? &ctr->n_ext3 : &ctr->n_ext, n_ext);
+        atomicAdd(round3 ? &ctr->n_blk3 : &ctr->n_ext_blocks, n_blk);
     }
 }
 
@@ -689,12 +689,17 @@ __global__ void round2_work_kernel(const bwams_smem_t *pool, DevCounters *ctr, R
 __global__ void mark_kernel(DevCounters *ctr, int which) {
     if (which == 1) { ctr->n_after_r1 = ctr->n_smem_total; ctr->valid_after[0] = ctr->n_smem_valid; }
     if (which == 2) { ctr->n_after_r2 = ctr->n_smem_total; ctr->valid_after[1] = ctr->n_smem_valid; }
-    if (which == 3) ctr->valid_after[2] = ctr->n_smem_valid;
+    if (which == 3) {                          // round 3 counted apart (it may have run beside round 2): fold it in
+        ctr->n_smem_valid += ctr->n_smem3; ctr->n_ext += ctr->n_ext3; ctr->n_ext_blocks += ctr->n_blk3;
+        ctr->n_smem3 = ctr->n_ext3 = ctr->n_blk3 = 0;
+        ctr->valid_after[2] = ctr->n_smem_valid;
+    }
     if (which >= 1 && which <= 3) {
         ctr->ext_after[which - 1] = ctr->n_ext;
         ctr->blk_after[which - 1] = ctr->n_ext_blocks;
     }
     ctr->work_head = 0;
+    if (which != 2) ctr->work_head3 = 0;       // (mark 2 may run while round 3 is in flight on its own stream... it has joined; kept for symmetry)
 }
 
 // Round 3: forward-only seeds.
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
     while (true) {
         {
             unsigned long long t = 0;
-            if (take_ticket(&a.ctr->work_head, wt, phase == PH_FETCH, t)) {
+            if (take_ticket(&a.ctr->work_head3, wt, phase == PH_FETCH, t)) {
                 if ((int64_t)t >= a.nseq) {
                     phase = PH_EXIT;
                 } else {
@@ -818,8 +823,8 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
         if (phase == PH_HOLD) phase = PH_FWD;
         wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
     }
-    wave_emit_finish(a, wo);
-    flush_counters(a.ctr, n_ext, n_blk);
+    wave_emit_finish(a, wo, true);
+    flush_counters(a.ctr, n_ext, n_blk, true);
 }
 
 // (rid, m, n) sort key of each pooled SMEM

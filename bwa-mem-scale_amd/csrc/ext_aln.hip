@@ -148,52 +148,76 @@ __global__ void ext_widen_kernel(const int32_t *cnt, const int32_t *state, int64
     wide[g] = (i < n && (state[i] & kExtReq)) ? (int64_t)cnt[row * n + i] : 0;
 }
 
-// wave per region: SeqPair records and sequence copies
+// SeqPair records and sequence copies.  A wavefront takes 64 slots at a time: every lane looks at one slot's state (most slots are
+// not requested in a round), a requested slot's lane fetches what the slot needs — chain, place in the chain's order, seed, offsets:
+// dependent loads, in flight for all the requested slots of the 64 together — and writes its SeqPair records; then the wave copies
+// the bytes of one requested slot after the other, the slot's fields broadcast from its lane.  (A wave per slot paid the chain of
+// dependent loads once per slot: 5.2 ms per step for 3.6 M tasks among 21.9 M slots.)
+__device__ __forceinline__ int64_t shfl64(int64_t v, int src) {
+    return ((int64_t)__shfl((int)(v >> 32), src) << 32) | (uint32_t)__shfl((int)v, src);
+}
 __global__ __launch_bounds__(256) void ext_build_kernel(ExtArgs A, const int64_t *__restrict__ offs, bwams_seqpair_t *left,
                                                         uint8_t *lref, uint8_t *lqer, bwams_seqpair_t *right, uint8_t *rref,
                                                         uint8_t *rqer) {
     const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t N = A.n_seeds, n1 = N + 1;
-    for (int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < N; p += stride) {
-        const int st = A.state[p];
-        if (!(st & kExtReq)) continue;
-        const int nl = A.cnt[0 * N + p], nr = A.cnt[3 * N + p];
-        if (lane == 0) A.state[p] = (st & ~kExtReq) | kExtDone;      // extended by the time the next selection runs
-        const int64_t j = A.regs[p].chain;
-        const bwams_chain_t c = A.chains[j];
-        const int k = c.n - 1 - (int)(p - c.seed_off);
-        const bwams_chain_seed_t s = A.seeds[c.seed_off + A.srt[c.seed_off + k]];
-        const int r = c.seqid;
-        const int64_t qoff = A.cum[r];
-        const int l_query = (int)(A.cum[r + 1] - qoff);
-        const int64_t r0 = A.rmax[2 * j];
-        if (nl) {
-            const int64_t ti = offs[0 * n1 + p], qo = offs[1 * n1 + p], ro = offs[2 * n1 + p];
-            const int ql = s.qbeg, rl = (int)(s.rbeg - r0);
-            for (int t = lane; t < ql; t += 64) lqer[qo + t] = A.enc[qoff + s.qbeg - 1 - t];
-            for (int t = lane; t < rl; t += 64) lref[ro + t] = A.ref[s.rbeg - 1 - t];
-            if (lane == 0) {
+    for (int64_t p0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; p0 < N; p0 += n_waves * 64) {
+        const int64_t p = p0 + lane;
+        const int st = p < N ? A.state[p] : 0;
+        const bool req = (st & kExtReq) != 0;
+        // left: query bytes enc[l_qsrc - t], t < l_ql, to lqer[l_qo + t]; reference bytes ref[l_rsrc - t], t < l_rl, to lref[l_ro + t]
+        int64_t l_qsrc = 0, l_rsrc = 0, l_qo = 0, l_ro = 0, r_qsrc = 0, r_rsrc = 0, r_qo = 0, r_ro = 0;
+        int l_ql = 0, l_rl = 0, r_ql = 0, r_rl = 0;
+        if (req) {
+            const int nl = A.cnt[0 * N + p], nr = A.cnt[3 * N + p];
+            A.state[p] = (st & ~kExtReq) | kExtDone;      // extended by the time the next selection runs
+            const int64_t j = A.regs[p].chain;
+            const bwams_chain_t c = A.chains[j];
+            const int k = c.n - 1 - (int)(p - c.seed_off);
+            const bwams_chain_seed_t sd = A.seeds[c.seed_off + A.srt[c.seed_off + k]];
+            const int r = c.seqid;
+            const int64_t qoff = A.cum[r];
+            const int l_query = (int)(A.cum[r + 1] - qoff);
+            const int64_t r0 = A.rmax[2 * j];
+            if (nl) {
+                const int64_t ti = offs[0 * n1 + p];
+                l_qo = offs[1 * n1 + p]; l_ro = offs[2 * n1 + p];
+                l_ql = sd.qbeg; l_rl = (int)(sd.rbeg - r0);
+                l_qsrc = qoff + sd.qbeg - 1; l_rsrc = sd.rbeg - 1;
                 bwams_seqpair_t sp;
-                sp.idr = (int32_t)ro; sp.idq = (int32_t)qo; sp.id = (int32_t)ti;
-                sp.len1 = rl; sp.len2 = ql; sp.h0 = s.len * A.opt.a; sp.seqid = r; sp.regid = s.aln;
+                sp.idr = (int32_t)l_ro; sp.idq = (int32_t)l_qo; sp.id = (int32_t)ti;
+                sp.len1 = l_rl; sp.len2 = l_ql; sp.h0 = sd.len * A.opt.a; sp.seqid = r; sp.regid = sd.aln;
                 sp.score = sp.tle = sp.gtle = sp.qle = sp.gscore = sp.max_off = 0;
                 left[ti] = sp;
             }
-        }
-        if (nr) {
-            const int64_t ti = offs[3 * n1 + p], qo = offs[4 * n1 + p], ro = offs[5 * n1 + p];
-            const int qe = s.qbeg + s.len;
-            const int ql = l_query - qe, rl = A.cnt[5 * N + p];
-            const int64_t rs = s.rbeg + s.len;
-            for (int t = lane; t < ql; t += 64) rqer[qo + t] = A.enc[qoff + qe + t];
-            for (int t = lane; t < rl; t += 64) rref[ro + t] = A.ref[rs + t];
-            if (lane == 0) {
+            if (nr) {
+                const int64_t ti = offs[3 * n1 + p];
+                r_qo = offs[4 * n1 + p]; r_ro = offs[5 * n1 + p];
+                const int qe = sd.qbeg + sd.len;
+                r_ql = l_query - qe; r_rl = A.cnt[5 * N + p];
+                r_qsrc = qoff + qe; r_rsrc = sd.rbeg + sd.len;
                 bwams_seqpair_t sp;
-                sp.idr = (int32_t)ro; sp.idq = (int32_t)qo; sp.id = (int32_t)ti;
-                sp.len1 = rl; sp.len2 = ql; sp.h0 = H0_; sp.seqid = r; sp.regid = s.aln;
+                sp.idr = (int32_t)r_ro; sp.idq = (int32_t)r_qo; sp.id = (int32_t)ti;
+                sp.len1 = r_rl; sp.len2 = r_ql; sp.h0 = H0_; sp.seqid = r; sp.regid = sd.aln;
                 sp.score = sp.tle = sp.gtle = sp.qle = sp.gscore = sp.max_off = 0;
                 right[ti] = sp;
+            }
+        }
+        unsigned long long m = __ballot(req);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int ql = __shfl(l_ql, src), rl = __shfl(l_rl, src), qr = __shfl(r_ql, src), rr = __shfl(r_rl, src);
+            if (ql | rl) {
+                const int64_t qs = shfl64(l_qsrc, src), rs = shfl64(l_rsrc, src), qo = shfl64(l_qo, src), ro = shfl64(l_ro, src);
+                for (int t = lane; t < ql; t += 64) lqer[qo + t] = A.enc[qs - t];
+                for (int t = lane; t < rl; t += 64) lref[ro + t] = A.ref[rs - t];
+            }
+            if (qr | rr) {
+                const int64_t qs = shfl64(r_qsrc, src), rs = shfl64(r_rsrc, src), qo = shfl64(r_qo, src), ro = shfl64(r_ro, src);
+                for (int t = lane; t < qr; t += 64) rqer[qo + t] = A.enc[qs + t];
+                for (int t = lane; t < rr; t += 64) rref[ro + t] = A.ref[rs + t];
             }
         }
     }
@@ -484,7 +508,7 @@ void launch_ext_widen(const ExtArgs &A, int64_t *wide, hipStream_t st) {
 void launch_ext_build(const ExtArgs &A, const int64_t *offs, bwams_seqpair_t *left, uint8_t *lref, uint8_t *lqer,
                       bwams_seqpair_t *right, uint8_t *rref, uint8_t *rqer, int cu_count, hipStream_t st) {
     if (A.n_seeds <= 0) return;
-    int64_t blocks = (A.n_seeds + 3) / 4;
+    int64_t blocks = (A.n_seeds + 255) / 256;              // a wave per 64 slots
     if (blocks > (int64_t)cu_count * 16) blocks = (int64_t)cu_count * 16;
     ext_build_kernel<<<(unsigned)blocks, 256, 0, st>>>(A, offs, left, lref, lqer, right, rref, rqer);
 }

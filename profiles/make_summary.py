@@ -18,7 +18,7 @@ bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
 def short(k):
     for pat, name in (("smem_search_kernel<true>", "smem_search_kernel<true> (SMEM round 1)"),
                       ("smem_search_kernel<false>", "smem_search_kernel<false> (SMEM round 2)"),
-                      ("seed_strategy", "seed_strategy_kernel (SMEM round 3)"), ("sa_lookup", "sa_lookup_kernel"),
+                      ("seed_strategy", "seed_strategy_kernel (SMEM round 3; runs beside round 2 on a stream of its own: the durations overlap, 3.3 ms alone)"), ("sa_lookup", "sa_lookup_kernel"),
                       ("bsw_qwin_kernel", "bsw_qwin_kernel (banded SW, 8 tasks per wave; 5 query-length classes)"),
                       ("bsw_classify", "bsw_classify_kernel"), ("bsw_kernel", "bsw_kernel (one task per wave, LDS: queries > 191)"),
                       ("aln_dp_kernel", "aln_dp_kernel (mem_reg2aln: banded global alignment + traceback)"),

@@ -261,23 +261,30 @@ __device__ __forceinline__ void prev_unpack(const uint4 a, int64_t &k, int64_t &
 // ring wraps.  The backward phase compacts towards logical 0, so once a list has shrunk below
 // kPrevLds entries it never touches HBM again.  (A third of the round-1 kernel's HBM traffic was
 // this list: profiles/r01_notes.md.)
-constexpr int kPrevLds = 8;
+#ifndef BWAMS_PREV_LDS
+#define BWAMS_PREV_LDS 8
+#endif
+#ifndef BWAMS_SEARCH_MIN_BLOCKS
+#define BWAMS_SEARCH_MIN_BLOCKS 1
+#endif
+constexpr int kPrevLds = BWAMS_PREV_LDS;
+__device__ __forceinline__ int ring_slot(int i) { return (kPrevLds & (kPrevLds - 1)) == 0 ? (i & (kPrevLds - 1)) : (int)((unsigned)i % (unsigned)kPrevLds); }
 struct PrevList {
     uint4 *glob;          // this lane's HBM list
     uint4 *ring;          // this lane's LDS column: ring[slot * kBlock]
 };
 __device__ __forceinline__ void prev_push(const PrevList &pl, int ph, int num_prev, int64_t k, int64_t l, int64_t s, int n) {
-    uint4 *slot = pl.ring + (ph & (kPrevLds - 1)) * kBlock;
+    uint4 *slot = pl.ring + ring_slot(ph) * kBlock;
     if (num_prev >= kPrevLds) pl.glob[ph + kPrevLds] = *slot;      // the entry pushed kPrevLds pushes ago leaves the ring
     *slot = prev_pack(k, l, s, n);
 }
 __device__ __forceinline__ void prev_get(const PrevList &pl, int base, int p, int64_t &k, int64_t &l, int64_t &s, int &n) {
-    const uint4 a = p < kPrevLds ? pl.ring[((base + p) & (kPrevLds - 1)) * kBlock] : pl.glob[base + p];
+    const uint4 a = p < kPrevLds ? pl.ring[ring_slot(base + p) * kBlock] : pl.glob[base + p];
     prev_unpack(a, k, l, s, n);
 }
 __device__ __forceinline__ void prev_put(const PrevList &pl, int base, int p, int64_t k, int64_t l, int64_t s, int n) {
     const uint4 a = prev_pack(k, l, s, n);
-    if (p < kPrevLds) pl.ring[((base + p) & (kPrevLds - 1)) * kBlock] = a;
+    if (p < kPrevLds) pl.ring[ring_slot(base + p) * kBlock] = a;
     else pl.glob[base + p] = a;
 }
 
@@ -408,7 +415,7 @@ enum : int { PH_FETCH = 0, PH_LOAD, PH_HOLD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BW
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
 // !ALL_POS: work item = (read, pivot, min_intv), one pivot (round 2).
 template <bool ALL_POS>
-__global__ __launch_bounds__(kBlock) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
+__global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
     const DevFmi &f = a.fmi;
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int cap = a.prev_cap;

@@ -1044,7 +1044,7 @@ int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t sour
     BWAMS_HIP(s->al_need.ensure((size_t)n1 * 8));
     BWAMS_HIP(s->al_cls.ensure((size_t)n1 * 4));
     BWAMS_HIP(s->al_off.ensure((size_t)n1 * 8));
-    BWAMS_HIP(s->al_list.ensure((size_t)n1 * 3 * 4));
+    BWAMS_HIP(s->al_list.ensure((size_t)n1 * 4 * 4));
     BWAMS_HIP(s->al_rec.ensure((size_t)n1 * sizeof(bwams_aln_t)));
     BWAMS_HIP(s->al_wide.ensure((size_t)(2 * n1) * 8));
     BWAMS_HIP(s->al_offs.ensure((size_t)(2 * n1) * 8));

@@ -16,6 +16,7 @@
 // CIGAR and MD are written to per-region scratch and compacted into the flat pools afterwards.
 #include "common.h"
 #include "chain_kernels.h"
+#include "wave_ops.h"
 
 namespace bwams {
 namespace {
@@ -368,6 +369,184 @@ __global__ __launch_bounds__(64) void aln_dp_kernel(RegAlnArgs A, int cls) {
     }
 }
 
+
+// ---- pass 3b: the same alignment, a wavefront per region -----------------------------------------------------------------
+// Bands beyond the 32-column ring: lane per region kept 64 KB of LDS per wave for the 128-column ring (two waves per CU) and
+// took 131 ms for the ~0.3 M such regions of a million reads — regions at repeat copies whose score deficit alone infers a band of
+// ~100 although the optimal alignment has no gap.  Here a wave owns a region and walks the rows with one band column per lane:
+// like the extension's recurrence, ksw_global2 opens the horizontal gap from the diagonal move m, never from h
+// (f' = max(f - e_ins, m - o_ins - e_ins), ksw.cpp:619-623), so f along a row is a max-plus prefix scan of values known from the
+// previous row; h, e, and the direction byte are column-local.  The (h, e) row is in LDS whole (8 B per query column), the
+// direction matrix goes to HBM a byte per cell as before, the traceback runs once, on lane 0, after the retry loop has settled.
+constexpr int kWaveCols = 512;                        // query columns a wave's LDS row holds (4 KB)
+constexpr int kWaveTgt = 1024;                        // target bases staged in LDS (longer targets are read from HBM row by row)
+constexpr int kNegScan = -2000000000;
+
+// inclusive prefix maximum over the wavefront: four DPP steps inside each row of 16 lanes, then the row totals carried across with
+// row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3).  A lane without a source keeps its value.  (Six
+// ds_bpermute shuffles, each waiting on the one before, were most of a row step's latency.)
+__device__ __forceinline__ int wave_incl_max(int v, int) {
+    asm volatile("s_nop 4\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
+    return v;
+}
+
+// the DP of ksw_global2 (ksw.cpp:588-637) for band w; returns the score, leaves the direction bytes in z
+__device__ int global2_dp_wave(const RegAlnArgs &A, const Seqs &S, int w, int2 *eh, const uint8_t *qs, const uint8_t *ts, uint32_t *z, int lane) {
+    const bwams_mem_opt_t &o = A.opt;
+    const int qlen = S.lq, tlen = S.lr;
+    const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const int zw = (n_col + 3) >> 2;
+    for (int j = lane; j <= qlen && j <= w + 1; j += 64)
+        eh[j] = j == 0 ? make_int2(0, kMinusInf) : j <= w ? make_int2(-(o.o_ins + o.e_ins * j), kMinusInf) : make_int2(kMinusInf, kMinusInf);
+    __syncthreads();
+    for (int i = 0; i < tlen; ++i) {
+        const int tb = ts ? ts[i] : S.ra(i);
+        const int8_t *mrow = &o.mat[(tb > 4 ? 4 : tb) * 5];
+        const int s0 = mrow[0], s1 = mrow[1], s2 = mrow[2], s3 = mrow[3], s4 = mrow[4];
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int h1_first = beg == 0 ? -(o.o_del + o.e_del * (i + 1)) : kMinusInf;
+        uint8_t *zi = reinterpret_cast<uint8_t *>(z + (size_t)i * zw);
+        int f_carry = kMinusInf, h_carry = h1_first, h_end = h1_first;
+        for (int c0 = beg; c0 < end; c0 += 64) {
+            const int j = c0 + lane;
+            const bool act = j < end;
+            int2 p = make_int2(0, 0);
+            int qb = 4;
+            if (act) { p = eh[j]; qb = qs[j]; qb = qb > 4 ? 4 : qb; }
+            const int m = p.x + (qb == 0 ? s0 : qb == 1 ? s1 : qb == 2 ? s2 : qb == 3 ? s3 : s4);
+            int e = p.y;
+            const int t_ins = m - oe_ins;
+            const int g = act ? t_ins + j * o.e_ins : kNegScan;
+            const int P = wave_incl_max(g, lane);
+            int Pex = __shfl_up(P, 1);
+            int f = f_carry - (j - c0) * o.e_ins;                          // what the gap open before this chunk has become
+            if (lane > 0) { const int fp = Pex - (j - 1) * o.e_ins; f = f > fp ? f : fp; }
+            uint32_t d = m >= e ? 0u : 1u;
+            int h = m >= e ? m : e;
+            d = h >= f ? d : 2u;
+            h = h >= f ? h : f;
+            const int t = m - oe_del;
+            e -= o.e_del;
+            d |= e > t ? 1u << 2 : 0u;
+            e = e > t ? e : t;
+            const int fn = f - o.e_ins;
+            d |= fn > t_ins ? 2u << 4 : 0u;
+            int hl = __shfl_up(h, 1);
+            if (lane == 0) hl = h_carry;
+            if (act) {
+                eh[j] = make_int2(hl, e);
+                zi[j - beg] = (uint8_t)d;
+            }
+            const int fnext = fn > t_ins ? fn : t_ins;
+            f_carry = __shfl(fnext, 63);
+            h_carry = __shfl(h, 63);
+            const int last = end - 1 - c0;                                 // the row's last column, if it lies in this chunk
+            if (last < 64) h_end = __shfl(h, last);
+        }
+        if (lane == 0) eh[end] = make_int2(h_end, kMinusInf);
+        __syncthreads();
+    }
+    return eh[qlen].x;
+}
+
+// the traceback of ksw_global2 (ksw.cpp:639-664) over the direction bytes the last DP left
+__device__ void global2_traceback(const Seqs &S, int w, const uint32_t *z, uint32_t *cigar, int *n_cigar_) {
+    const int qlen = S.lq, tlen = S.lr;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const int zw = (n_col + 3) >> 2;
+    int n = 0, which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    auto push = [&](int op, int len) {
+        if (n == 0 || op != (int)(cigar[n - 1] & 0xf)) cigar[n++] = (uint32_t)len << 4 | (uint32_t)op;
+        else cigar[n - 1] += (uint32_t)len << 4;
+    };
+    while (i >= 0 && k >= 0) {
+        const int c = k - (i > w ? i - w : 0);
+        const uint32_t d = (z[(size_t)i * zw + (c >> 2)] >> ((c & 3) * 8)) & 0xffu;
+        which = (int)(d >> (which << 1)) & 3;
+        if (which == 0) { push(0, 1); --i; --k; }
+        else if (which == 1) { push(2, 1); --i; }
+        else { push(1, 1); --k; }
+    }
+    if (i >= 0) push(2, i + 1);
+    if (k >= 0) push(1, k + 1);
+    for (int a = 0; a < n >> 1; ++a) { const uint32_t t = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = t; }
+    *n_cigar_ = n;
+}
+
+__global__ __launch_bounds__(64) void aln_dp_wave_kernel(RegAlnArgs A, int cls, unsigned long long *ticket) {
+    __shared__ int2 eh[kWaveCols + 2];
+    __shared__ uint8_t qs[kWaveCols + 64], ts_[kWaveTgt + 64];    // the two sequences in the order the DP reads them: a row step waits on no HBM load
+    const int lane = threadIdx.x;
+    const int64_t n = (int64_t)A.n_list[cls];
+    const int32_t *list = A.list + (int64_t)cls * A.n_regs;
+    for (;;) {
+        const int64_t t = (int64_t)wave_ticket(ticket, 1ull);
+        if (t >= n) break;
+        const int64_t k = list[t];
+        const bwams_alnreg_t ar = A.regs[k];
+        const int64_t r = read_of_region(A.reg_off, A.nseq, k);
+        const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
+        Seqs S;
+        S.lq = ar.qe - ar.qb; S.lr = (int)(ar.re - ar.rb);
+        S.q = A.enc + A.cum[r] + ar.qb; S.r = A.ref + ar.rb; S.rev = ar.rb >= A.bns.l_pac;
+        if (S.lq + 1 > kWaveCols) {                      // a query beyond the LDS row: the lane-per-region HBM launch, which runs last
+            if (lane == 0) A.list[3 * A.n_regs + (int64_t)atomicAdd(&A.n_list[3], 1ull)] = (int32_t)k;
+            continue;
+        }
+        uint32_t *cigar = scr_cigar(A, k);
+        char *md = scr_md(A, k, S.lq, S.lr);
+        uint32_t *z = reinterpret_cast<uint32_t *>(md + md_cap(S.lr));
+        for (int j = lane; j < S.lq; j += 64) qs[j] = (uint8_t)S.qa(j);
+        const uint8_t *ts = S.lr <= kWaveTgt ? ts_ : nullptr;
+        if (ts) for (int i = lane; i < S.lr; i += 64) ts_[i] = (uint8_t)S.ra(i);
+        __syncthreads();
+        // mem_reg2aln's loop (bwamem.cpp:2558-2568)
+        int tmp = infer_bw(S.lq, S.lr, ar.truesc, A.opt.a, A.opt.o_del, A.opt.e_del);
+        int w2 = infer_bw(S.lq, S.lr, ar.truesc, A.opt.a, A.opt.o_ins, A.opt.e_ins);
+        w2 = w2 > tmp ? w2 : tmp;
+        if (w2 > A.opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+        int it = 0, last_sc = -(1 << 30), score = 0, w = 0;
+        do {
+            w2 = w2 < A.opt.w << 2 ? w2 : A.opt.w << 2;
+            const int8_t m0 = A.opt.mat[0];
+            const int max_ins = (int)((double)(((S.lq + 1) >> 1) * m0 - A.opt.o_ins) / A.opt.e_ins + 1.);
+            const int max_del = (int)((double)(((S.lq + 1) >> 1) * m0 - A.opt.o_del) / A.opt.e_del + 1.);
+            int max_gap = max_ins > max_del ? max_ins : max_del;
+            max_gap = max_gap > 1 ? max_gap : 1;
+            const int d = S.lr > S.lq ? S.lr - S.lq : S.lq - S.lr;
+            w = (max_gap + d + 1) >> 1;
+            w = w < w2 ? w : w2;
+            w = w > d + 3 ? w : d + 3;
+            score = global2_dp_wave(A, S, w, eh, qs, ts, z, lane);
+            if (score == last_sc || w2 == A.opt.w << 2) break;
+            last_sc = score;
+            w2 <<= 1;
+        } while (++it < 3 && score < ar.truesc - A.opt.a);
+        __syncthreads();                                 // the direction bytes of every lane are visible to lane 0
+        if (lane == 0) {
+            int n_cigar = 0, md_len = 0;
+            global2_traceback(S, w, z, cigar, &n_cigar);
+            const int NM = nm_md(S, cigar, n_cigar, md, &md_len);
+            finish_record(A, k, ar, l_query, cigar, n_cigar, NM, md_len);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- pass 4: compaction into the flat pools -------------------------------------------------------------
 __global__ void aln_sizes_kernel(RegAlnArgs A, int64_t *wide) {             // wide[0 .. n] = n_cigar, wide[n + 1 .. 2n + 1] = md_len
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,13 +578,11 @@ void launch_aln_run(const RegAlnArgs &A, int cu_count, hipStream_t st) {
     if (A.n_regs <= 0) return;
     aln_simple_kernel<<<(unsigned)((A.n_regs + 255) / 256), 256, 0, st>>>(A);
     aln_dp_kernel<32><<<(unsigned)(cu_count * 8), 64, 32 * 64 * sizeof(int2), st>>>(A, 0);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(aln_dp_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 64 * (int)sizeof(int2));
-        attr = true;
-    }
-    aln_dp_kernel<128><<<(unsigned)(cu_count * 2), 64, 128 * 64 * sizeof(int2), st>>>(A, 1);
-    aln_dp_kernel<0><<<(unsigned)(cu_count * 4), 64, 0, st>>>(A, 2);
+    // wider bands (class 1) and the regions whose retry outgrew the 32-column ring (class 2, listed by the launch above): a wave
+    // per region; queries beyond its LDS row go on to the lane-per-region launch with the row in HBM (class 3)
+    aln_dp_wave_kernel<<<(unsigned)(cu_count * 24), 64, 0, st>>>(A, 1, A.n_list + 4);
+    aln_dp_wave_kernel<<<(unsigned)(cu_count * 4), 64, 0, st>>>(A, 2, A.n_list + 5);
+    aln_dp_kernel<0><<<(unsigned)(cu_count * 4), 64, 0, st>>>(A, 3);
 }
 void launch_aln_sizes(const RegAlnArgs &A, int64_t *wide, hipStream_t st) {
     aln_sizes_kernel<<<(unsigned)((A.n_regs + 1 + 255) / 256), 256, 0, st>>>(A, wide);

@@ -425,6 +425,17 @@ def main():
                 "note": "single-end SAM side of one chunk on the device: mem_mark_primary_se of every read, then mem_reg2aln (band inference, "
                         "banded global alignment with traceback, CIGAR / NM / MD, position) of every final region; mapping quality on the host "
                         "side of the library"}
+    # mem_reg2aln restricted to what the SAM text reads (the reference aligns only what it prints)
+    sopt_ = capi.default_sam_opt()
+    batch.reg2aln_sam(mem_opt, sopt_, fetch=False)
+    t0 = time.perf_counter()
+    _, n_needed_ = batch.reg2aln_sam(mem_opt, sopt_, fetch=False)
+    reg2aln_sam_ms = (time.perf_counter() - t0) * 1e3
+    aln_r_ = batch.reg2aln_sam(mem_opt, sopt_)[0]
+    done_ = aln_r_["rid"] >= 0
+    sam_side["reg2aln_for_sam"] = {"regions_aligned": int(n_needed_), "of": int(n_aln.value), "ms_run": round(reg2aln_sam_ms, 2),
+                                   "note": "bwams_reg2aln_run_sam: the records mem_reg2sam prints and the members of their XA strings only; "
+                                           "the SAM text below is produced from this run"}
     # the SAM text of the chunk (mem_reg2sam + mem_gen_alt + mem_aln2sam on the device), with size-independent checks
     cum_ = cums[n_chunks - 1]
     n_seq_ = len(cum_) - 1
@@ -434,7 +445,6 @@ def main():
     t0 = time.perf_counter()
     batch.sam_upload(names_, quals_)
     sam_up_ms = (time.perf_counter() - t0) * 1e3
-    sopt_ = capi.default_sam_opt()
     batch.sam_run(mem_opt, sopt_)
     t0 = time.perf_counter()
     sam_bytes = batch.sam_run(mem_opt, sopt_)
@@ -446,7 +456,9 @@ def main():
     n_lines = int((tb == 10).sum())
     n_tabs = int((tb == 9).sum())
     checks = {
-        "device_mapq_equals_host_mapq": bool(np.array_equal(mq_, aln_["mapq"])),
+        "device_mapq_equals_host_mapq": bool(np.array_equal(mq_[done_], aln_["mapq"][done_])),
+        "restricted_records_equal_full_run": bool(all(np.array_equal(aln_r_[f_][done_], aln_[f_][done_]) for f_ in ("pos", "rid", "NM", "n_cigar", "md_len", "score"))
+                                                  and int(done_.sum()) == int(n_needed_)),
         "one_block_per_read": bool(roff_[0] == 0 and roff_[-1] == sam_bytes and np.all(np.diff(roff_) > 0)),
         "every_block_ends_a_line": bool(np.all(tb[roff_[1:] - 1] == 10)),
         "lines_at_least_reads": n_lines >= n_seq_,
@@ -496,7 +508,7 @@ def main():
     if not all(fq_checks.values()):
         raise SystemExit(f"[bench] FASTQ decode property check failed: {fq_checks}")
     del row, fq_text, d_fq, got_
-    del aln_, cig_, md_, text_, tb, mq_
+    del aln_, cig_, md_, text_, tb, mq_, aln_r_
 
     # ---------------- paired-end leg (every rank: the pestat exchange is a collective) ----------------
     pe_out = None
@@ -552,9 +564,9 @@ def main():
         }
         if rank == 0:
             # the paired-end SAM side beside: mem_reg2aln of the regions after rescue, then mem_sam_pe's text (never part of the timed batches)
+            batch.reg2aln_sam(mem_opt, capi.default_sam_opt(), pes=pes_, fetch=False)
             t0 = time.perf_counter()
-            n_aln_ = capi.C.c_int64(0); n_cg_ = capi.C.c_int64(0); n_md_ = capi.C.c_int64(0)
-            capi._chk(capi.lib().bwams_reg2aln_run(batch.h, capi.C.byref(mem_opt), 1, capi.C.byref(n_aln_), capi.C.byref(n_cg_), capi.C.byref(n_md_)), "bwams_reg2aln_run")
+            pe_n_aln, pe_n_need = batch.reg2aln_sam(mem_opt, capi.default_sam_opt(), pes=pes_, fetch=False)    # only what mem_sam_pe reads
             pe_aln_ms = (time.perf_counter() - t0) * 1e3
             pnames = [b"pair%d" % (rank * n_pairs + i // 2) for i in range(2 * n_pairs)]
             batch.sam_upload(pnames, np.full(int(pcum[-1]), ord("I"), np.uint8))
@@ -569,7 +581,8 @@ def main():
                          "every_block_ends_a_line": bool(np.all(ptb[proff[1:] - 1] == 10)),
                          "first_in_pair_then_second": all((f & 0x41) == 0x41 if r % 2 == 0 else (f & 0x81) == 0x81 for r, f in enumerate(first_flags)),
                          "proper_flag_symmetric": all((first_flags[r] & 2) == (first_flags[r + 1] & 2) for r in range(0, len(first_flags) - 1, 2))}
-            pe_out["sam_text"] = {"bytes": int(pe_sam_bytes), "lines": int((ptb == 10).sum()), "ms_reg2aln": round(pe_aln_ms, 2), "ms_run": round(pe_sam_ms, 2),
+            pe_out["sam_text"] = {"bytes": int(pe_sam_bytes), "lines": int((ptb == 10).sum()), "ms_reg2aln": round(pe_aln_ms, 2),
+                                  "regions_aligned": int(pe_n_need), "regions": int(pe_n_aln), "ms_run": round(pe_sam_ms, 2),
                                   "Mreads_per_s": round(2 * n_pairs / (pe_sam_ms * 1e-3) / 1e6, 2) if pe_sam_ms > 0 else None,
                                   "proper_pair_records": int(sum(1 for f in first_flags if f & 2)), "checks": pe_checks,
                                   "note": "mem_sam_pe from mem_pair's result on (q_pe / q_se, region edits, mate fields, MC / XA / SA) on the device; "

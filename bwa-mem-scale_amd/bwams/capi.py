@@ -25,7 +25,7 @@ SEQPAIR_DTYPE = np.dtype([(n, "<i4") for n in
 SYMBOLS = [
     "bwams_strerror", "bwams_last_error", "bwams_device_count",
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
-    "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_fetch",
+    "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_run_sam", "bwams_reg2aln_fetch",
     "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
     "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
@@ -804,6 +804,23 @@ class Batch:
         mq = np.zeros(max(n_regs, 1), np.int32)
         _chk(lib().bwams_sam_fetch(self.h, _p(buf), len(buf), _p(off), _p(mq) if n_regs else None, len(mq)), "bwams_sam_fetch")
         return bytes(buf[:self._sam_bytes]), off, mq[:n_regs]
+
+    def reg2aln_sam(self, opt: MemOpt | None = None, sopt=None, pes=None, fetch: bool = True):
+        """mem_reg2aln of the regions the SAM text needs only (after mark_primary_se, or pair_run with its pes) ->
+        (records, CIGAR pool, MD pool, number of regions aligned); skipped regions hold an unmapped record."""
+        opt = opt or default_mem_opt()
+        sopt = sopt or default_sam_opt()
+        n, nn, nc, nm = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        pp = _p(np.ascontiguousarray(pes, PESTAT_DTYPE)) if pes is not None else None
+        _chk(lib().bwams_reg2aln_run_sam(self.h, C.byref(opt), C.byref(sopt), pp, C.byref(n), C.byref(nn), C.byref(nc), C.byref(nm)),
+             "bwams_reg2aln_run_sam")
+        if not fetch:
+            return n.value, nn.value
+        aln = np.zeros(max(n.value, 1), ALN_DTYPE)
+        cig = np.zeros(max(nc.value, 1), np.uint32)
+        md = np.zeros(max(nm.value, 1), np.uint8)
+        _chk(lib().bwams_reg2aln_fetch(self.h, _p(aln), len(aln), _p(cig), len(cig), _p(md), len(md)), "bwams_reg2aln_fetch")
+        return aln[:n.value], cig[:nc.value], md[:nm.value], nn.value
 
     def pestat_keys(self, opt: MemOpt | None = None) -> np.ndarray:
         """One key per qualifying pair of this batch (orientation << 60 | insert size), sorted."""

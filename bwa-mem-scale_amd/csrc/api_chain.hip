@@ -51,7 +51,7 @@ struct ChainState {
     DevBuf er_wide, er_off, er_scr, er_n, er_rev, er_out, er_ooff;   // mem_perfect2reg
     int64_t er_total = 0, er_nseq = 0;
     bool er_done = false;
-    DevBuf al_need, al_cls, al_off, al_scr, al_list, al_rec, al_wide, al_offs, al_cig, al_md, al_cnt;   // mem_reg2aln
+    DevBuf al_need, al_cls, al_off, al_scr, al_list, al_rec, al_wide, al_offs, al_cig, al_md, al_cnt, al_only;   // mem_reg2aln
     int64_t al_n = 0, al_ncig = 0, al_nmd = 0;
     int al_source = 0;
     bool al_done = false;
@@ -82,7 +82,7 @@ void chain_state_free(ChainState *s) {
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
                      &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->pr_na, &s->pr_wide, &s->pr_offs, &s->pr_anchor, &s->pr_slot, &s->pr_task, &s->pr_trb, &s->pr_tl1, &s->pr_twide, &s->pr_toffs,
                      &s->pr_pairs, &s->pr_tref, &s->pr_tqer, &s->pr_aln, &s->pr_pool, &s->pr_ord, &s->pr_srt, &s->pr_z, &s->pr_nfin, &s->pr_npri, &s->pr_nsw, &s->pr_full, &s->pr_owide,
-                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->al_need, &s->al_cls, &s->al_off, &s->al_scr, &s->al_list, &s->al_rec, &s->al_wide, &s->al_offs, &s->al_cig, &s->al_md, &s->al_cnt, &s->sm_names, &s->sm_noff, &s->sm_qual, &s->sm_comm, &s->sm_coff, &s->sm_mapq, &s->sm_len, &s->sm_off, &s->sm_out, &s->sm_logtab, &s->sm_bad, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->al_need, &s->al_cls, &s->al_off, &s->al_scr, &s->al_list, &s->al_rec, &s->al_wide, &s->al_offs, &s->al_cig, &s->al_md, &s->al_cnt, &s->al_only, &s->sm_names, &s->sm_noff, &s->sm_qual, &s->sm_comm, &s->sm_coff, &s->sm_mapq, &s->sm_len, &s->sm_off, &s->sm_out, &s->sm_logtab, &s->sm_bad, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -1015,8 +1015,8 @@ static int approx_mapq_se(const bwams_mem_opt_t *opt, const bwams_alnreg_t *a) {
     return mapq;
 }
 
-int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t source, int64_t *n_aln, int64_t *n_cigar_ops,
-                      int64_t *md_bytes) {
+static int reg2aln_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t source, const uint8_t *only, int64_t *n_aln,
+                        int64_t *n_cigar_ops, int64_t *md_bytes) {
     if (!b || !b->chain || (source == 0 && !b->chain->dedup_done) || (source == 1 && !b->chain->pair_done) || source < 0 || source > 1) {
         set_last_error("bwams_reg2aln_run: run bwams_dedup_run (source 0) or bwams_pair_run (source 1) first");
         return BWAMS_ERR_ARG;
@@ -1040,6 +1040,7 @@ int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t sour
     A.enc = b->d_enc; A.cum = b->d_cum; A.ref = b->idx->fmi.ref;
     if ((rc = dev_bns(b->idx, &A.bns))) return rc;
     A.opt = *opt;
+    A.only = only;
     const int64_t n1 = n + 1;
     BWAMS_HIP(s->al_need.ensure((size_t)n1 * 8));
     BWAMS_HIP(s->al_cls.ensure((size_t)n1 * 4));
@@ -1080,6 +1081,53 @@ int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t sour
     if (n_cigar_ops) *n_cigar_ops = tot[0];
     if (md_bytes) *md_bytes = tot[1];
     return BWAMS_OK;
+}
+
+int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t source, int64_t *n_aln, int64_t *n_cigar_ops,
+                      int64_t *md_bytes) {
+    return reg2aln_impl(b, opt, source, nullptr, n_aln, n_cigar_ops, md_bytes);
+}
+
+int bwams_reg2aln_run_sam(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, const bwams_pestat_t *pes,
+                          int64_t *n_aln, int64_t *n_needed, int64_t *n_cigar_ops, int64_t *md_bytes) {
+    if (!b || !sopt || !b->chain || !b->chain->pair_done || b->chain->pr_single == (pes != nullptr)) {
+        set_last_error("bwams_reg2aln_run_sam: run bwams_pair_run first (BWAMS_PAIR_SINGLE_END and pes = NULL, or the paired-end form and its pes)");
+        return BWAMS_ERR_ARG;
+    }
+    int rc = check_opt(opt, "bwams_reg2aln_run_sam");
+    if (rc) return rc;
+    ChainState *s = b->chain;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    const int64_t n = s->pr_total;
+    BWAMS_HIP(s->al_only.ensure((size_t)n + 64));
+    BWAMS_HIP(hipMemsetAsync(s->al_only.p, 0, (size_t)n + 1, st));
+    SamArgs A;
+    memset(&A, 0, sizeof A);
+    A.regs = s->pr_out.as<bwams_alnreg_t>(); A.reg_off = s->pr_ooff.as<int64_t>();
+    A.n_regs = n; A.nseq = s->nseq;
+    A.opt = *opt; A.sopt = *sopt;
+    A.pairs = pes ? s->pr_res.as<bwams_pair_t>() : nullptr;
+    if (pes) memcpy(A.pes, pes, sizeof A.pes);
+    launch_sam_need(A, s->al_only.as<uint8_t>(), b->cu_count, st);
+    if (n_needed) {
+        // a count for the caller (and the bench): one reduction over the mask
+        size_t tb = 0;
+        BWAMS_HIP(s->sm_bad.ensure(64));
+        int64_t *d_sum = s->sm_bad.as<int64_t>() + 1;
+        BWAMS_HIP(rocprim::reduce(nullptr, tb, s->al_only.as<uint8_t>(), d_sum, (int64_t)0, (size_t)(n > 0 ? n : 0), rocprim::plus<int64_t>(), st));
+        if (tb > b->tmp_bytes) {
+            BWAMS_HIP(hipStreamSynchronize(st));
+            if (b->d_tmp) (void)hipFree(b->d_tmp);
+            b->d_tmp = nullptr;
+            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            b->tmp_bytes = tb;
+        }
+        tb = b->tmp_bytes;
+        BWAMS_HIP(rocprim::reduce(b->d_tmp, tb, s->al_only.as<uint8_t>(), d_sum, (int64_t)0, (size_t)(n > 0 ? n : 0), rocprim::plus<int64_t>(), st));
+        BWAMS_HIP(hipMemcpyAsync(n_needed, d_sum, 8, hipMemcpyDeviceToHost, st));
+    }
+    return reg2aln_impl(b, opt, 1, s->al_only.as<uint8_t>(), n_aln, n_cigar_ops, md_bytes);
 }
 
 int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uint32_t *cigar, int64_t cigar_cap, char *md, int64_t md_cap) {

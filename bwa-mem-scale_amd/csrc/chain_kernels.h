@@ -239,6 +239,7 @@ struct RegAlnArgs {
     int32_t *list;                 // 3 * n_regs: regions that need DP, by class
     unsigned long long *n_list;    // 3 counters
     bwams_aln_t *rec;
+    const uint8_t *only;           // per region: non-zero = align it; null = every region (bwams_reg2aln_run)
 };
 void launch_aln_plan(const RegAlnArgs &A, hipStream_t st);
 void launch_aln_run(const RegAlnArgs &A, int cu_count, hipStream_t st);
@@ -280,6 +281,7 @@ struct SamArgs {
     const int64_t *out_off;
     char *out;
 };
+void launch_sam_need(const SamArgs &A, uint8_t *need, int cu_count, hipStream_t st);
 void launch_sam_mapq(const SamArgs &A, hipStream_t st);
 void launch_sam_text(const SamArgs &A, bool emit, int cu_count, hipStream_t st);
 

@@ -155,7 +155,8 @@ __global__ void aln_plan_kernel(RegAlnArgs A) {
     const int lq = ar.qe - ar.qb;
     const int64_t lr64 = ar.re - ar.rb;
     const int64_t l_pac = A.bns.l_pac;
-    const bool bad = ar.rb < 0 || ar.re < 0 || lq <= 0 || lr64 <= 0 || (ar.rb < l_pac && ar.re > l_pac) || ar.re > 2 * l_pac || lr64 > (1 << 20);
+    const bool skip = A.only && !A.only[k];            // not needed by the SAM text: the record stays an unmapped one
+    const bool bad = skip || ar.rb < 0 || ar.re < 0 || lq <= 0 || lr64 <= 0 || (ar.rb < l_pac && ar.re > l_pac) || ar.re > 2 * l_pac || lr64 > (1 << 20);
     int64_t need = 64;
     int cls = -1;                                     // -1: no DP; 0 / 1: LDS ring of 32 / 128 columns; 2: HBM row
     if (!bad) {

@@ -359,6 +359,12 @@ __device__ void put_reg2sam(const SamArgs &A, const Read &R, Writer &W, int extr
     }
 }
 
+__device__ __forceinline__ void load_read_regs(const SamArgs &A, int64_t r, Read &R) {      // what the marking needs: the regions alone
+    const int64_t o = A.reg_off[r];
+    R.a = A.regs + o; R.rec = nullptr; R.mapq = nullptr; R.n = (int)(A.reg_off[r + 1] - o);
+    R.seq = nullptr; R.l_seq = 0; R.qual = nullptr; R.name = nullptr; R.l_name = 0; R.comment = nullptr; R.l_comment = 0;
+    R.sw_k = R.sw_z = -1;
+}
 __device__ __forceinline__ void load_read(const SamArgs &A, int64_t r, Read &R) {
     const int64_t o = A.reg_off[r];
     R.a = A.regs + o; R.rec = A.rec + o; R.mapq = A.mapq + o; R.n = (int)(A.reg_off[r + 1] - o);
@@ -502,6 +508,78 @@ __device__ void put_perfect(const SamArgs &A, const Read &R, Writer &W, const bw
     }
 }
 
+// ---- which regions the text needs -----------------------------------------------------------------------------------------
+// The reference calls mem_reg2aln only for what it prints: the records mem_reg2sam selects, the members of the XA strings of the
+// printed records (mem_gen_alt skips a primary with too many candidates), and in mem_sam_pe the paired regions, the ALT hit and the
+// mate's record.  All of it follows from the regions, the pairing result and the options alone — no alignment is consulted — so the
+// set is computed before mem_reg2aln runs and the other regions (two thirds of them on the bench chunk) are never aligned.  The
+// marking walks the same control flow as the text kernels below.
+__device__ void need_xa(const SamArgs &A, const Read &R, uint8_t *need, int r) {
+    int cnt = 0;
+    bool has_alt = false;
+    for (int i = 0; i < R.n; ++i)
+        if (pri_idx(A, R, i) == r) { ++cnt; has_alt |= reg_is_alt(R.a[i]); }
+    if (cnt == 0 || cnt > A.sopt.max_XA_hits_alt || (!has_alt && cnt > A.sopt.max_XA_hits)) return;
+    for (int i = 0; i < R.n; ++i)
+        if (pri_idx(A, R, i) == r) need[i] = 1;
+}
+__device__ void need_reg2sam(const SamArgs &A, const Read &R, uint8_t *need) {
+    for (int k = 0; k < R.n; ++k)
+        if (selected(A, R, k)) {
+            need[k] = 1;
+            if (!(A.sopt.flag & BWAMS_MEM_F_ALL)) need_xa(A, R, need, k);
+        }
+}
+
+__global__ void sam_need_kernel(SamArgs A, uint8_t *need) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.nseq; r += (int64_t)gridDim.x * blockDim.x) {
+        if (!A.pairs) {
+            Read R;
+            load_read_regs(A, r, R);
+            need_reg2sam(A, R, need + A.reg_off[r]);
+            continue;
+        }
+        if (r & 1) continue;                               // the lane of the pair's first read marks both ends
+        Read R[2];
+        load_read_regs(A, r, R[0]);
+        load_read_regs(A, r + 1, R[1]);
+        const bwams_pair_t pr = A.pairs[r >> 1];
+        bool paired = pr.n_pri[0] && pr.n_pri[1] && pr.score > 0;
+        for (int i = 0; i < 2 && paired; ++i)
+            for (int j = 1; j < pr.n_pri[i]; ++j)
+                if (R[i].a[j].secondary < 0 && R[i].a[j].score >= A.sopt.T) { paired = false; break; }
+        if (paired) {
+            const int score_un = R[0].a[0].score + R[1].a[0].score - A.opt.pen_unpaired;
+            const bool pe = pr.score > score_un;
+            for (int i = 0; i < 2; ++i) {
+                uint8_t *nd = need + A.reg_off[r + i];
+                const int z = pe ? pr.z[i] : 0;
+                nd[z] = 1;
+                const int k = R[i].a[z].secondary_all;
+                R[i].sw_k = (k >= 0 && k < pr.n_pri[i]) ? k : -1;
+                R[i].sw_z = z;
+                if (pr.n_pri[i] < R[i].n) {
+                    const bwams_alnreg_t &p = R[i].a[pr.n_pri[i]];
+                    if (!(p.score < A.sopt.T || p.secondary >= 0 || !reg_is_alt(p))) {
+                        nd[pr.n_pri[i]] = 1;
+                        if (!(A.sopt.flag & BWAMS_MEM_F_ALL)) need_xa(A, R[i], nd, pr.n_pri[i]);
+                    }
+                }
+                if (!(A.sopt.flag & BWAMS_MEM_F_ALL)) need_xa(A, R[i], nd, z);
+            }
+        } else {
+            for (int i = 0; i < 2; ++i) {
+                uint8_t *nd = need + A.reg_off[r + i];
+                if (R[i].n) {
+                    if (R[i].a[0].score >= A.sopt.T) nd[0] = 1;
+                    else if (pr.n_pri[i] < R[i].n && R[i].a[pr.n_pri[i]].score >= A.sopt.T) nd[pr.n_pri[i]] = 1;
+                }
+                need_reg2sam(A, R[i], nd);
+            }
+        }
+    }
+}
+
 template <bool EMIT>
 __global__ void sam_text_kernel(SamArgs A) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.nseq; r += (int64_t)gridDim.x * blockDim.x) {
@@ -585,6 +663,13 @@ __global__ void sam_text_pe_kernel(SamArgs A) {
 
 }  // namespace
 
+void launch_sam_need(const SamArgs &A, uint8_t *need, int cu_count, hipStream_t st) {
+    if (A.nseq <= 0) return;
+    int64_t blocks = (A.nseq + 63) / 64;
+    const int64_t cap = (int64_t)cu_count * 32;
+    if (blocks > cap) blocks = cap;
+    sam_need_kernel<<<(unsigned)blocks, 64, 0, st>>>(A, need);
+}
 void launch_sam_mapq(const SamArgs &A, hipStream_t st) {
     if (A.n_regs > 0) sam_mapq_kernel<<<(unsigned)((A.n_regs + 255) / 256), 256, 0, st>>>(A);
 }

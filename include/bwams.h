@@ -220,6 +220,14 @@ int bwams_emf_fetch(bwams_batch_t *b, bwams_perfect_t *out, uint8_t *code);
  * (NUL-terminated strings); the XA string and the SAM text stay on the host. */
 int bwams_reg2aln_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t source, int64_t *n_aln, int64_t *n_cigar_ops,
                       int64_t *md_bytes);
+/* The same for the regions of bwams_pair_run (source 1), restricted to what the SAM text will read — as the reference, which calls
+ * mem_reg2aln from mem_reg2sam / mem_gen_alt / mem_sam_pe only for the records it prints, the members of their XA strings, the paired
+ * regions and the mate records (src/bwamem.cpp:2100-2120, src/bwamem_extra.cpp:150-160, src/bwamem_pair.cpp:753-796).  The set follows
+ * from the regions, the pairing result and sopt alone; the other regions (two thirds on the bench chunk) keep an unmapped record
+ * (rid = -1).  pes = NULL for single-end chunks.  bwams_sam_run / bwams_sam_run_pe with the same sopt then produce the same text as
+ * after bwams_reg2aln_run. */
+int bwams_reg2aln_run_sam(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sopt, const bwams_pestat_t *pes,
+                          int64_t *n_aln, int64_t *n_needed, int64_t *n_cigar_ops, int64_t *md_bytes);
 int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uint32_t *cigar, int64_t cigar_cap, char *md,
                         int64_t md_cap);
 

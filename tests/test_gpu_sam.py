@@ -259,3 +259,46 @@ def test_exact_match_records_equal_oracle(L):
         b2 = capi.Batch(ix, 4, 600)
         b2.sam_run_emf(e, gopt, capi.default_sam_opt())
     b.close(); e.close(); ix.close()
+
+
+def test_reg2aln_restricted_to_what_the_text_needs():
+    """bwams_reg2aln_run_sam aligns only the regions the SAM text reads (as the reference calls mem_reg2aln): the text is the same, the
+    records of the aligned regions are those of the full run, the others stay unmapped records."""
+    # single-end
+    c = _pipeline(900, 5)
+    b = c["b"]
+    full = c["aln"]
+    for flag in (0, 0x8, 0x10):
+        so, sg = loader.default_sam_opt(flag), capi.default_sam_opt(flag)
+        b.reg2aln(c["gopt"], 1)
+        b.sam_upload(c["names"], c["quals"], c["comments"])
+        b.sam_run(c["gopt"], sg)
+        want_text, _, _ = b.sam_fetch()
+        aln, cig, md, n_need = b.reg2aln_sam(c["gopt"], sg)
+        b.sam_run(c["gopt"], sg)
+        text, _, _ = b.sam_fetch()
+        assert text == want_text
+        done = aln["rid"] >= 0
+        assert n_need == int(done.sum()) + int(((full["rid"] < 0) & False).sum()) and 0 < n_need < len(full)
+        for f in ("pos", "rid", "flag", "is_rev", "NM", "n_cigar", "md_len", "score", "sub", "mapq"):
+            assert np.array_equal(aln[f][done], full[f][done]), f
+        assert (aln["n_cigar"][~done] == 0).all()
+        if flag == 0:
+            assert n_need < len(full)                         # e.g. the secondaries below XA_drop_ratio are not aligned
+    b.close(); c["ix"].close()
+    # paired-end
+    c = _pe_pipeline(500, 17)
+    b = c["b"]
+    for flag in (0, 0x8):
+        so, sg = loader.default_sam_opt(flag), capi.default_sam_opt(flag)
+        b.reg2aln(c["gopt"], 1)
+        b.sam_upload(c["names"], c["quals"], c["comments"])
+        b.sam_run_pe(c["pes"], c["gopt"], sg)
+        want_text, _, _ = b.sam_fetch()
+        aln, cig, md, n_need = b.reg2aln_sam(c["gopt"], sg, pes=c["pes"])
+        b.sam_run_pe(c["pes"], c["gopt"], sg)
+        text, _, _ = b.sam_fetch()
+        assert text == want_text and 0 < n_need <= len(aln)
+    with pytest.raises(capi.BwamsError):
+        b.reg2aln_sam(c["gopt"], capi.default_sam_opt())          # a paired-end chunk needs its pes
+    b.close(); c["ix"].close()

@@ -21,7 +21,8 @@ def short(k):
                       ("seed_strategy", "seed_strategy_kernel (SMEM round 3; runs beside round 2 on a stream of its own: the durations overlap, 3.3 ms alone)"), ("sa_lookup", "sa_lookup_kernel"),
                       ("bsw_qwin_kernel", "bsw_qwin_kernel (banded SW, 8 tasks per wave; 5 query-length classes)"),
                       ("bsw_classify", "bsw_classify_kernel"), ("bsw_kernel", "bsw_kernel (one task per wave, LDS: queries > 191)"),
-                      ("aln_dp_kernel", "aln_dp_kernel (mem_reg2aln: banded global alignment + traceback)"),
+                      ("aln_dp_wave", "aln_dp_wave_kernel (mem_reg2aln: bands beyond 32 columns, wave per region)"), ("aln_dp_kernel", "aln_dp_kernel (mem_reg2aln: banded global alignment + traceback, lane per region)"),
+                      ("sam_need", "sam_need_kernel (which regions the SAM text reads)"),
                       ("aln_simple", "aln_simple_kernel (mem_reg2aln: gap-free regions)"), ("aln_gather", "aln_gather_kernel"),
                       ("aln_plan", "aln_plan_kernel"),
                       ("sam_text_kernel", "sam_text_kernel (single-end SAM text: count pass / write pass)"), ("sam_mapq", "sam_mapq_kernel (mem_approx_mapq_se)"),

@@ -439,7 +439,7 @@ def main():
     # the SAM text of the chunk (mem_reg2sam + mem_gen_alt + mem_aln2sam on the device), with size-independent checks
     cum_ = cums[n_chunks - 1]
     n_seq_ = len(cum_) - 1
-    names_ = [b"read%d" % (first + i) for i in range(n_seq_)]
+    names_ = [b"r%08d" % (first + i) for i in range(n_seq_)]          # the names the FASTQ text below carries
     quals_ = np.full(int(cum_[-1]), ord("I"), np.uint8)
     ix.set_contig_names([b"chr%d" % (i + 1) for i in range(len(contigs) if contigs is not None else 1)])
     t0 = time.perf_counter()
@@ -507,6 +507,29 @@ def main():
                                         "ms_call adds the allocations, three scans and the offset arrays' copy to the host"}
     if not all(fq_checks.values()):
         raise SystemExit(f"[bench] FASTQ decode property check failed: {fq_checks}")
+    # the whole single-end path in one go, text to text: FASTQ bytes (in HBM) -> ... -> SAM bytes (in HBM)
+    def fastq_to_sam():
+        fq_ = capi.Fastq(d_fq.data_ptr(), device=local, n_bytes=len(fq_text))
+        fq_.to_batch(batch)
+        fq_.close()
+        batch.seed_run(seed_opt, with_sa=True)
+        batch.chain_run(mem_opt); batch.extend_run(mem_opt); batch.dedup_run(mem_opt)
+        batch.mark_primary_se(mem_opt, id_base=first)
+        batch.reg2aln_sam(mem_opt, sopt_, fetch=False)
+        return batch.sam_run(mem_opt, sopt_)
+    fastq_to_sam()
+    batch.sync()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        e2e_bytes = fastq_to_sam()
+    batch.sync()
+    e2e_ms = (time.perf_counter() - t0) / 2 * 1e3
+    sam_side["fastq_to_sam"] = {"ms_per_chunk": round(e2e_ms, 2), "Mreads_per_s": round(n_seq_ / (e2e_ms * 1e-3) / 1e6, 3), "sam_bytes": int(e2e_bytes),
+                                "note": "single-end, FM-index seeding, one chunk end to end on the device: FASTQ decode, seed -> chain -> extend -> dedup, "
+                                        "mem_mark_primary_se, mem_reg2aln of what the text needs, SAM text; FASTQ text resident in HBM at the start, "
+                                        "SAM text left in HBM at the end (host transfers and gz excluded); never `value`"}
+    if e2e_bytes != sam_bytes:
+        raise SystemExit(f"[bench] FASTQ -> SAM run produced {e2e_bytes} bytes of text, the staged run {sam_bytes}")
     del row, fq_text, d_fq, got_
     del aln_, cig_, md_, text_, tb, mq_, aln_r_
 

@@ -154,6 +154,24 @@ def test_random_configuration(seed):
             assert np.array_equal(pairs, wpairs), use_ert
             for f in REG_F:
                 assert np.array_equal(out[f], wout[f]), (use_ert, f)
+            if not use_ert and (seed % 3 == 0 or os.environ.get("BWAMS_FUZZ_SAM")):
+                # the paired-end SAM text of these very regions, with random text options, after aligning only what it reads
+                names_c = [b"ctg%d" % i for i in range(sh["n_contigs"])]
+                ix.set_contig_names(names_c)
+                sflag = int(rng.choice([0, 0, 0x8, 0x200, 0x10, 0x1000]))
+                sso, ssg = loader.default_sam_opt(sflag, b"rg" if seed % 2 else b""), capi.default_sam_opt(sflag, b"rg" if seed % 2 else b"")
+                sso.T = ssg.T = int(rng.choice([30, 30, 10, 60]))
+                sso.max_XA_hits = ssg.max_XA_hits = int(rng.choice([5, 1, 50]))
+                quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+                rnames = [b"p%d" % (i // 2) for i in range(len(reads))]
+                b.reg2aln_sam(gopt, ssg, pes=pes, fetch=False)
+                b.sam_upload(rnames, quals)
+                b.sam_run_pe(pes, gopt, ssg)
+                text, roff, _ = b.sam_fetch()
+                wtext = loader.sam_pe(wout, wout_off, enc, cum, ref, l_pac, wpes, wpairs, rnames, quals=quals, contigs=contigs,
+                                      contig_names=names_c, opt=oopt, sopt=sso)
+                for r_, w_ in enumerate(wtext):
+                    assert text[roff[r_]:roff[r_ + 1]] == w_, (r_, sflag)
     # ERT mode's way into chaining, fed the same seeds dressed up as an ERT walk's output
     from util import ert_mems_from_smems
     all_coord, all_off = o.sa_lookup(sm, 1 << 30)

@@ -144,6 +144,47 @@ def test_random_configuration(seed):
         assert np.array_equal(fin[f], wfin[f]), f
     pes = b.pestat(gopt)
     assert np.array_equal(pes, wpes)
+    if L <= 512 and (seed % 3 == 1 or os.environ.get("BWAMS_FUZZ_SAM")):
+        # the same chunk as single-end reads: mem_mark_primary_se, the restricted mem_reg2aln, the SAM text (exact-match records for the
+        # reads the EMF resolved), random text options
+        names_c = [b"ctg%d" % i for i in range(sh["n_contigs"])]
+        ix.set_contig_names(names_c)
+        sflag = int(rng.choice([0, 0, 0x8, 0x200, 0x10, 0x1000]))
+        sso, ssg = loader.default_sam_opt(sflag, b"grp" if seed % 2 else b""), capi.default_sam_opt(sflag, b"grp" if seed % 2 else b"")
+        sso.T = ssg.T = int(rng.choice([30, 30, 10, 60]))
+        sso.max_XA_hits = ssg.max_XA_hits = int(rng.choice([5, 1, 50]))
+        quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+        rnames = [b"s%d" % i for i in range(len(reads))]
+        comments = [b"c:Z:%d" % i if i % 3 == 0 else None for i in range(len(reads))]
+        b.mark_primary_se(gopt, id_base=seed * 100)
+        sregs, soff, _ = b.pair_fetch()
+        wmark = wfin.copy()
+        for r_ in range(len(reads)):
+            a_, e_ = int(wfin_off[r_]), int(wfin_off[r_ + 1])
+            if e_ > a_:
+                wmark[a_:e_] = loader.mark_primary_se(wfin[a_:e_], seed * 100 + r_, oopt)[0]
+        assert np.array_equal(soff, wfin_off)
+        for f in ("secondary", "secondary_all", "sub", "sub_n", "hash"):
+            assert np.array_equal(sregs[f], wmark[f]), f
+        b.reg2aln_sam(gopt, ssg, fetch=False)
+        b.sam_upload(rnames, quals, comments)
+        if skip is not None:
+            e2 = capi.Emf(ix, table=tab)
+            b.emf_run(e2); b.emf_regs(e2, gopt)
+            b.sam_run_emf(e2, gopt, ssg)
+        else:
+            b.sam_run(gopt, ssg)
+        text, roff, _ = b.sam_fetch()
+        wtext = loader.reg2sam_se(wmark, wfin_off, enc, cum, ref, l_pac, rnames, quals=quals, comments=comments, contigs=contigs,
+                                  contig_names=names_c, opt=oopt, sopt=sso)
+        for r_, w_ in enumerate(wtext):
+            if skip is not None and skip[r_]:
+                wr, _ = oe.perfect2reg(reads[r_], int(perfect[r_, 0]), int(perfect[r_, 1]), l_pac, contigs=contigs, opt=oopt)
+                w_ = loader.perfect2sam(wr, reads[r_], l_pac, L, rnames[r_], qual=bytes(quals[cum[r_]:cum[r_ + 1]]), comment=comments[r_],
+                                        contigs=contigs, contig_names=names_c, opt=oopt, sopt=sso)
+            assert text[roff[r_]:roff[r_ + 1]] == w_, (r_, sflag)
+        if skip is not None:
+            e2.close()
     if L <= 512 and all(p["failed"] or p["high"] - p["low"] + L <= 20000 for p in pes):
         for use_ert in (False, True):
             wout, wout_off, wpairs = loader.pair_pe(wfin, wfin_off, enc, cum, ref, l_pac, wpes, contigs=contigs, opt=oopt,

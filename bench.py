@@ -508,15 +508,8 @@ def main():
     if not all(fq_checks.values()):
         raise SystemExit(f"[bench] FASTQ decode property check failed: {fq_checks}")
     # the whole single-end path in one go, text to text: FASTQ bytes (in HBM) -> ... -> SAM bytes (in HBM)
-    def fastq_to_sam():
-        fq_ = capi.Fastq(d_fq.data_ptr(), device=local, n_bytes=len(fq_text))
-        fq_.to_batch(batch)
-        fq_.close()
-        batch.seed_run(seed_opt, with_sa=True)
-        batch.chain_run(mem_opt); batch.extend_run(mem_opt); batch.dedup_run(mem_opt)
-        batch.mark_primary_se(mem_opt, id_base=first)
-        batch.reg2aln_sam(mem_opt, sopt_, fetch=False)
-        return batch.sam_run(mem_opt, sopt_)
+    def fastq_to_sam():                                  # bwams_process_chunk: the outer boundary, one call
+        return batch.process_chunk((d_fq.data_ptr(), len(fq_text)), seed_opt=seed_opt, opt=mem_opt, sopt=sopt_, n_processed=first, fetch=False)
     fastq_to_sam()
     batch.sync()
     t0 = time.perf_counter()
@@ -525,7 +518,7 @@ def main():
     batch.sync()
     e2e_ms = (time.perf_counter() - t0) / 2 * 1e3
     sam_side["fastq_to_sam"] = {"ms_per_chunk": round(e2e_ms, 2), "Mreads_per_s": round(n_seq_ / (e2e_ms * 1e-3) / 1e6, 3), "sam_bytes": int(e2e_bytes),
-                                "note": "single-end, FM-index seeding, one chunk end to end on the device: FASTQ decode, seed -> chain -> extend -> dedup, "
+                                "note": "bwams_process_chunk — single-end, FM-index seeding, one chunk end to end on the device: FASTQ decode, seed -> chain -> extend -> dedup, "
                                         "mem_mark_primary_se, mem_reg2aln of what the text needs, SAM text; FASTQ text resident in HBM at the start, "
                                         "SAM text left in HBM at the end (host transfers and gz excluded); never `value`"}
     if e2e_bytes != sam_bytes:

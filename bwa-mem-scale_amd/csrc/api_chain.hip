@@ -1346,6 +1346,60 @@ int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off,
     return BWAMS_OK;
 }
 
+/* ------------------------------------------------------------ mem_process_seqs ---- */
+
+// The outer boundary for one chunk, text to text: what kt_pipeline's step 0 parsing and step 1 (mem_process_seqs, src/bwamem.cpp:1850-1980)
+// do between the decompressed FASTQ bytes and seqs[i].sam, as the sequence of the stage calls above.
+int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                        const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
+                        int64_t n_processed, int32_t pair_flags, int64_t *n_reads, int64_t *sam_bytes) {
+    if (!b || !so || !mo || !sam_opt || !fastq || n_bytes < 0) {
+        set_last_error("bwams_process_chunk: batch, options and text are required");
+        return BWAMS_ERR_ARG;
+    }
+    bwams_fastq_t *fq = nullptr;
+    int64_t n = 0, nb = 0;
+    int rc = bwams_fastq_decode(b->idx->device, fastq, n_bytes, &fq, &n, &nb);
+    if (rc) return rc;
+    if (paired && (n & 1)) {
+        bwams_fastq_close(fq);
+        set_last_error("bwams_process_chunk: a paired-end chunk holds an even number of reads (ends interleaved)");
+        return BWAMS_ERR_ARG;
+    }
+    rc = bwams_fastq_to_batch(fq, b);
+    bwams_fastq_close(fq);
+    if (rc) return rc;
+    int64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (emf) {                                            // kernel 0 of mem_kernel1_core: is_pm[], then mem_perfect2reg for the resolved reads
+        if ((rc = bwams_emf_run(b, emf))) return rc;
+        if ((rc = bwams_emf_regs_run(b, emf, mo, &t0))) return rc;
+    }
+    if ((rc = ert ? bwams_seed_run_ert(b, ert, so, 1) : bwams_seed_run(b, so, 1))) return rc;
+    if ((rc = bwams_chain_run(b, mo, &t0, &t1))) return rc;
+    if ((rc = bwams_extend_run(b, mo, &t0))) return rc;
+    if ((rc = bwams_dedup_run(b, mo, &t0))) return rc;
+    if (!paired) {
+        if ((rc = bwams_pair_run(b, mo, nullptr, n_processed, BWAMS_PAIR_SINGLE_END, &t0, &t1))) return rc;
+        if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, nullptr, &t0, &t1, &t2, &t3))) return rc;
+        rc = emf ? bwams_sam_run_emf(b, mo, sam_opt, emf, sam_bytes) : bwams_sam_run(b, mo, sam_opt, sam_bytes);
+    } else {
+        if (emf) {
+            // worker_sam turns the resolved ends into regions before mem_sam_pe (bwamem.cpp:1689-1702): the region lists of this
+            // library's paired-end tail come from bwams_dedup_run alone — merging bwams_emf_regs_run's into them is not built
+            set_last_error("bwams_process_chunk: paired-end chunks behind the exact-match filter are not built (run the stages yourself)");
+            return BWAMS_ERR_UNSUPPORTED;
+        }
+        bwams_pestat_t pes[4];
+        if (pes0) memcpy(pes, pes0, sizeof pes);
+        else if ((rc = bwams_pestat(b, mo, pes))) return rc;
+        if ((rc = bwams_pair_run(b, mo, pes, n_processed >> 1, pair_flags | (ert ? BWAMS_PAIR_USE_ERT : 0), &t0, &t1))) return rc;
+        if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, pes, &t0, &t1, &t2, &t3))) return rc;
+        rc = bwams_sam_run_pe(b, mo, sam_opt, pes, sam_bytes);
+    }
+    if (!rc && n_reads) *n_reads = n;
+    return rc;
+}
+
 /* ------------------------------------------------------------ mem_perfect2reg ---- */
 
 int bwams_emf_regs_run(bwams_batch_t *b, bwams_emf_t *e, const bwams_mem_opt_t *opt, int64_t *n_regs) {

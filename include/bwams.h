@@ -478,6 +478,20 @@ int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pa
 
 int bwams_batch_sync(bwams_batch_t *b);
 
+/* -------------------------------------------------------- the outer boundary ---- *
+ * One chunk, text to text: what kt_pipeline's step 0 parsing (bseq_read_orig, src/bwa.cpp:266-335) and step 1 (mem_process_seqs,
+ * src/bwamem.cpp:1850-1980: worker_bwt, worker_aln, mem_pestat, worker_sam) do between the decompressed FASTQ bytes of whole records and
+ * seqs[i].sam — the sequence of the stage calls of this header.  fastq: host or device memory, four lines per
+ * record, the two ends of a pair interleaved when paired != 0; emf / ert: NULL or the resident tables (ert selects ERT seeding and the
+ * useErt form of mate rescue); pes0: NULL = infer the insert-size statistics from the chunk (mem_pestat), as mem_process_seqs does;
+ * n_processed: reads processed before this chunk (the hash seeds of mem_mark_primary_se / mem_pair); pair_flags: BWAMS_PAIR_NO_RESCUE.
+ * The text stays on the device: bwams_sam_fetch(b, buf, sam_bytes, read_off, NULL, 0) returns it with one offset per read.  The batch must
+ * have been created for at least the chunk's reads and bases, the index must carry its sequence names.  Inputs the device path refuses
+ * (multi-line / FASTA text, unsupported flags, paired-end behind the EMF) return BWAMS_ERR_UNSUPPORTED: run that chunk on the host. */
+int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                        const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
+                        int64_t n_processed, int32_t pair_flags, int64_t *n_reads, int64_t *sam_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,3 +93,90 @@ def test_fastq_text_to_sam_text_on_the_device():
     assert sam == b"".join(want)
     assert sam.count(b"\n") >= 600 and b"frag0\t" in sam and b"/1" not in sam.split(b"\n")[0].split(b"\t")[0]
     f.close(); b.close(); ix.close()
+
+
+def _fastq_of(reads, names, quals, comments=None):
+    parts = []
+    o = 0
+    for i, r in enumerate(reads):
+        seq = bytes(b"ACGTN"[b] for b in r)
+        hdr = names[i] + (b" " + comments[i] if comments is not None and comments[i] else b"")
+        parts.append(b"@" + hdr + b"\n" + seq + b"\n+\n" + bytes(quals[o:o + len(r)]) + b"\n")
+        o += len(r)
+    return b"".join(parts)
+
+
+def test_process_chunk_is_the_stage_sequence():
+    """bwams_process_chunk (the outer boundary, text to text) against the oracle chain: single-end, single-end over the ERT,
+    single-end behind the exact-match filter, paired-end with inferred and with given insert-size statistics."""
+    from bwams import emf as emf_mod
+    from util import oracle_pe_pipeline
+    g, idx, starts = repeat_genome()
+    l_pac = len(g)
+    ix = capi.Index.from_host(idx, 0)
+    ix.set_contig_names([b"chrR"])
+    rng = np.random.default_rng(12)
+    gopt, oopt = capi.default_mem_opt(), loader.default_mem_opt()
+    # ---- single-end (+ ERT, + EMF)
+    reads, _, _ = simulate.make_reads(g, 400, seed=41)
+    for i in range(0, 400, 4):
+        st = starts[int(rng.integers(0, len(starts)))] + int(rng.integers(0, 500 - reads.shape[1]))
+        reads[i] = g[st:st + reads.shape[1]]
+    for i in range(1, 400, 8):                               # exact copies: the EMF resolves them
+        st = int(rng.integers(0, l_pac - reads.shape[1]))
+        reads[i] = g[st:st + reads.shape[1]] if i % 16 == 1 else simulate.revcomp(g[st:st + reads.shape[1]])
+    enc, cum = simulate.flatten_reads(reads)
+    quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+    names = [b"rd%d" % i for i in range(len(reads))]
+    comments = [b"x:i:%d" % i if i % 3 == 0 else None for i in range(len(reads))]
+    text = _fastq_of(reads, names, quals, comments)
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    sam, off = b.process_chunk(text, n_processed=1000)
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum)
+    coord, soff = o.sa_lookup(sm)
+    ch, sd, choff = loader.chain_seeds(sm, coord, soff, cum, l_pac)
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, enc, cum, idx.ref_0123, l_pac)
+    fin, fin_off = loader.regs_finish(regs, reg_off, enc, cum, idx.ref_0123, l_pac)
+    for r in range(len(reads)):
+        a, e = int(fin_off[r]), int(fin_off[r + 1])
+        if e > a:
+            fin[a:e] = loader.mark_primary_se(fin[a:e], 1000 + r)[0]
+    want = loader.reg2sam_se(fin, fin_off, enc, cum, idx.ref_0123, l_pac, names, quals=quals, comments=comments, contig_names=[b"chrR"])
+    assert sam == b"".join(want) and off[-1] == len(sam)
+    ert = capi.Ert.build(ix, kmer=8, xmer=2, read_len=151, hit_threshold=16)
+    sam_e, _ = b.process_chunk(text, ert=ert, n_processed=1000)
+    assert sam_e == sam                                      # ERT seeding: the same seeds, the same text (single-end)
+    ert.close()
+    tab = emf_mod.build_emf(g, reads.shape[1])
+    e = capi.Emf(ix, table=tab)
+    sam_f, off_f = b.process_chunk(text, emf=e, n_processed=1000)
+    n_exact = 0
+    for r in range(len(reads)):
+        got = sam_f[off_f[r]:off_f[r + 1]]
+        if got != want[r]:                                   # a resolved read: the exact-match record instead
+            f = got.split(b"\n")[0].split(b"\t")
+            assert f[4] == b"60" and f[5] == b"%dM" % reads.shape[1] and b"NM:i:0" in f
+            n_exact += 1
+    assert n_exact >= 40
+    e.close(); b.close()
+    # ---- paired-end
+    pr = simulate.make_read_pairs_bulk(g, 300, seed=9)
+    preads = np.asarray(pr).reshape(-1, np.asarray(pr).shape[-1])
+    penc, pcum = simulate.flatten_reads(preads)
+    pquals = rng.integers(33, 74, size=len(penc), dtype=np.uint8)
+    pnames = [b"pp%d" % (i // 2) for i in range(len(preads))]
+    ptext = _fastq_of(preads, [n + (b"/1" if i % 2 == 0 else b"/2") for i, n in enumerate(pnames)], pquals)
+    b = capi.Batch(ix, len(preads), int(pcum[-1]))
+    psam, poff = b.process_chunk(ptext, paired=True, n_processed=0)
+    c = oracle_pe_pipeline(g, idx, preads)
+    wregs, woff, wpairs = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, c["pes"])
+    pwant = loader.sam_pe(wregs, woff, penc, pcum, c["ref"], l_pac, c["pes"], wpairs, pnames, quals=pquals, contig_names=[b"chrR"])
+    assert psam == b"".join(pwant)
+    pes2 = c["pes"].copy(); pes2["low"][1] += 3
+    psam2, _ = b.process_chunk(ptext, paired=True, pes=pes2)
+    wregs2, woff2, wpairs2 = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, pes2)
+    assert psam2 == b"".join(loader.sam_pe(wregs2, woff2, penc, pcum, c["ref"], l_pac, pes2, wpairs2, pnames, quals=pquals, contig_names=[b"chrR"]))
+    with pytest.raises(capi.BwamsError):
+        b.process_chunk(ptext[: ptext.index(b"@pp1/2")], paired=True)      # an odd number of reads
+    b.close(); ix.close()

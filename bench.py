@@ -606,6 +606,33 @@ def main():
             if not all(pe_checks.values()):
                 raise SystemExit(f"[bench] paired-end SAM text property check failed: {pe_checks}")
             del ptext, ptb
+            # the whole paired-end path in one call, text to text (bwams_process_chunk): the two ends of a pair interleaved
+            PRL = pr.shape[-1]
+            prd = np.asarray(pr).reshape(-1, PRL)
+            prow = np.empty((2 * n_pairs, 1 + 9 + 2 + 1 + PRL + 3 + PRL + 1), np.uint8)
+            prow[:, 0] = ord("@"); prow[:, 1] = ord("p")
+            pids = (np.arange(2 * n_pairs, dtype=np.int64) >> 1) + rank * n_pairs
+            for d_ in range(8):
+                prow[:, 2 + d_] = ord("0") + (pids // 10 ** (7 - d_)) % 10
+            prow[:, 10] = ord("/"); prow[:, 11] = ord("1") + (np.arange(2 * n_pairs) & 1)
+            prow[:, 12] = 10
+            prow[:, 13:13 + PRL] = np.frombuffer(b"ACGTN", np.uint8)[prd]
+            prow[:, 13 + PRL:16 + PRL] = np.frombuffer(b"\n+\n", np.uint8)
+            prow[:, 16 + PRL:16 + 2 * PRL] = ord("I")
+            prow[:, 16 + 2 * PRL] = 10
+            d_pfq = torch.from_numpy(prow.reshape(-1)).to(dev)
+            pe_args = dict(paired=True, seed_opt=seed_opt, opt=mem_opt, sopt=capi.default_sam_opt(), n_processed=2 * rank * n_pairs, fetch=False)
+            batch.process_chunk((d_pfq.data_ptr(), prow.size), **pe_args)
+            batch.sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                pe_e2e_bytes = batch.process_chunk((d_pfq.data_ptr(), prow.size), **pe_args)
+            batch.sync()
+            pe_e2e_ms = (time.perf_counter() - t0) / 2 * 1e3
+            pe_out["fastq_to_sam"] = {"ms_per_chunk": round(pe_e2e_ms, 2), "Mreads_per_s": round(2 * n_pairs / (pe_e2e_ms * 1e-3) / 1e6, 3), "sam_bytes": int(pe_e2e_bytes),
+                                      "note": "bwams_process_chunk, paired-end, one GPU: interleaved FASTQ text in HBM -> SAM text in HBM (decode, seed .. dedup, "
+                                              "mem_pestat inferred from the chunk, mate rescue, pairing, mem_reg2aln of what is printed, mem_sam_pe's text)"}
+            del prow, d_pfq
 
     # ---------------- report ----------------
     if rank == 0:

@@ -1366,6 +1366,14 @@ int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, co
         set_last_error("bwams_process_chunk: a paired-end chunk holds an even number of reads (ends interleaved)");
         return BWAMS_ERR_ARG;
     }
+    if (n == 0) {                                         // an empty chunk: no reads, no text
+        bwams_fastq_close(fq);
+        if (b->chain) { b->chain->sm_done = true; b->chain->sm_bytes = 0; b->chain->sm_nregs = 0; b->chain->nseq = 0; }
+        b->nseq = 0;
+        if (n_reads) *n_reads = 0;
+        if (sam_bytes) *sam_bytes = 0;
+        return BWAMS_OK;
+    }
     rc = bwams_fastq_to_batch(fq, b);
     bwams_fastq_close(fq);
     if (rc) return rc;

@@ -179,4 +179,7 @@ def test_process_chunk_is_the_stage_sequence():
     assert psam2 == b"".join(loader.sam_pe(wregs2, woff2, penc, pcum, c["ref"], l_pac, pes2, wpairs2, pnames, quals=pquals, contig_names=[b"chrR"]))
     with pytest.raises(capi.BwamsError):
         b.process_chunk(ptext[: ptext.index(b"@pp1/2")], paired=True)      # an odd number of reads
+    assert b.process_chunk(b"", fetch=False) == 0                          # an empty chunk
+    with pytest.raises(capi.BwamsError):
+        b.process_chunk(b">fa\nACGT\n")                                    # FASTA: refused, the caller reads it on the host
     b.close(); ix.close()

@@ -369,7 +369,7 @@ __device__ __forceinline__ void load_read(const SamArgs &A, int64_t r, Read &R) 
     const int64_t o = A.reg_off[r];
     R.a = A.regs + o; R.rec = A.rec + o; R.mapq = A.mapq + o; R.n = (int)(A.reg_off[r + 1] - o);
     R.seq = A.enc + A.cum[r]; R.l_seq = (int)(A.cum[r + 1] - A.cum[r]);
-    R.qual = A.quals ? A.quals + A.cum[r] : nullptr;
+    R.qual = (A.quals && R.l_seq > 0) ? A.quals + A.cum[r] : nullptr;      // kseq2bseq1: an empty quality string is no quality string
     R.name = A.names + A.name_off[r]; R.l_name = (int)(A.name_off[r + 1] - A.name_off[r]);
     R.comment = A.comments ? A.comments + A.comment_off[r] : nullptr;
     R.l_comment = A.comments ? (int)(A.comment_off[r + 1] - A.comment_off[r]) : 0;

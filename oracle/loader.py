@@ -693,7 +693,7 @@ def reg2sam_se(regs, reg_off, enc, cum, ref_string, l_pac, names, quals=None, co
     buf = C.create_string_buffer(cap)
     for r in range(len(reg_off) - 1):
         q = enc[cum[r]:cum[r + 1]]
-        qual = bytes(quals[cum[r]:cum[r + 1]]) if quals is not None else None
+        qual = (bytes(quals[cum[r]:cum[r + 1]]) or None) if quals is not None else None      # kseq2bseq1: empty = none
         a = regs[int(reg_off[r]):int(reg_off[r + 1])]
         cm = comments[r] if comments is not None else None
         while True:
@@ -750,7 +750,7 @@ def sam_pe(regs, reg_off, enc, cum, ref_string, l_pac, pes, pairs, names, quals=
         r0 = 2 * p
         lens = (C.c_int32 * 2)(int(cum[r0 + 1] - cum[r0]), int(cum[r0 + 2] - cum[r0 + 1]))
         seqs = (C.c_void_p * 2)(enc.ctypes.data + int(cum[r0]), enc.ctypes.data + int(cum[r0 + 1]))
-        qb = [bytes(quals[cum[r0 + i]:cum[r0 + i + 1]]) if quals is not None else None for i in range(2)]
+        qb = [(bytes(quals[cum[r0 + i]:cum[r0 + i + 1]]) or None) if quals is not None else None for i in range(2)]
         qs = (C.c_char_p * 2)(qb[0], qb[1])
         nm = (C.c_char_p * 2)(names[r0], names[r0 + 1])
         cm = (C.c_char_p * 2)(comments[r0] if comments is not None else None, comments[r0 + 1] if comments is not None else None)

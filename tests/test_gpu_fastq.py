@@ -62,6 +62,7 @@ def test_fastq_text_to_sam_text_on_the_device():
         seq = bytes(b"ACGTN"[b] for b in r)
         qual = bytes(rng.integers(33, 74, size=len(r), dtype=np.uint8))
         parts.append(b"@frag%d/1%s\n%s\n+\n%s\n" % (i, b" RG:Z:x%d" % i if i % 5 == 0 else b"", seq, qual))
+    parts.insert(7, b"@empty_read with a comment\n\n+\n\n")            # no bases: an unaligned record with empty SEQ and '*' for QUAL
     text = b"".join(parts)
     ix = capi.Index.from_host(idx, 0)
     ix.set_contig_names([b"chrR"])
@@ -92,6 +93,7 @@ def test_fastq_text_to_sam_text_on_the_device():
                              contig_names=[b"chrR"], opt=oopt)
     assert sam == b"".join(want)
     assert sam.count(b"\n") >= 600 and b"frag0\t" in sam and b"/1" not in sam.split(b"\n")[0].split(b"\t")[0]
+    assert b"empty_read\t4\t*\t0\t0\t*\t*\t0\t0\t\t*\tAS:i:0\tXS:i:0\twith a comment\n" in sam
     f.close(); b.close(); ix.close()
 
 

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_run_sam", "bwams_reg2aln_fetch",
     "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
-    "bwams_process_chunk", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_process_chunk", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
     "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
@@ -779,7 +779,7 @@ class Batch:
         return n.value
 
     def process_chunk(self, fastq, paired: bool = False, emf=None, ert=None, seed_opt=None, opt: MemOpt | None = None, sopt=None,
-                      pes=None, n_processed: int = 0, pair_flags: int = 0, fetch: bool = True):
+                      pes=None, n_processed: int = 0, flags: int = 0, copy_comment: bool = False, fetch: bool = True):
         """mem_process_seqs for one chunk, text to text (bwams_process_chunk) -> (SAM text, read_off), or the byte count with
         fetch=False.  fastq: bytes, or (device address, n_bytes) for text already in this GPU's memory."""
         seed_opt = seed_opt or default_seed_opt()
@@ -790,7 +790,7 @@ class Batch:
         src, nbytes = (C.c_void_p(fastq[0]), fastq[1]) if isinstance(fastq, tuple) else (fastq, len(fastq))
         _chk(lib().bwams_process_chunk(self.h, emf.h if emf is not None else None, ert.h if ert is not None else None, C.byref(seed_opt),
                                        C.byref(opt), C.byref(sopt), src, C.c_int64(nbytes), 1 if paired else 0, pp,
-                                       C.c_int64(n_processed), pair_flags, C.byref(n), C.byref(nb)), "bwams_process_chunk")
+                                       C.c_int64(n_processed), flags | (0x100 if copy_comment else 0), C.byref(n), C.byref(nb)), "bwams_process_chunk")
         self._nseq, self._sam_bytes = n.value, nb.value
         if not fetch:
             return nb.value

@@ -1352,7 +1352,7 @@ int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off,
 // do between the decompressed FASTQ bytes and seqs[i].sam, as the sequence of the stage calls above.
 int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
                         const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
-                        int64_t n_processed, int32_t pair_flags, int64_t *n_reads, int64_t *sam_bytes) {
+                        int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes) {
     if (!b || !so || !mo || !sam_opt || !fastq || n_bytes < 0) {
         set_last_error("bwams_process_chunk: batch, options and text are required");
         return BWAMS_ERR_ARG;
@@ -1374,7 +1374,7 @@ int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, co
         if (sam_bytes) *sam_bytes = 0;
         return BWAMS_OK;
     }
-    rc = bwams_fastq_to_batch(fq, b);
+    rc = bwams_fastq_to_batch_opt(fq, b, (flags & BWAMS_CHUNK_COPY_COMMENT) ? 1 : 0);      // process(): comments only with `mem -C`
     bwams_fastq_close(fq);
     if (rc) return rc;
     int64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -1400,7 +1400,7 @@ int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, co
         bwams_pestat_t pes[4];
         if (pes0) memcpy(pes, pes0, sizeof pes);
         else if ((rc = bwams_pestat(b, mo, pes))) return rc;
-        if ((rc = bwams_pair_run(b, mo, pes, n_processed >> 1, pair_flags | (ert ? BWAMS_PAIR_USE_ERT : 0), &t0, &t1))) return rc;
+        if ((rc = bwams_pair_run(b, mo, pes, n_processed >> 1, (flags & BWAMS_PAIR_NO_RESCUE) | (ert ? BWAMS_PAIR_USE_ERT : 0), &t0, &t1))) return rc;
         if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, pes, &t0, &t1, &t2, &t3))) return rc;
         rc = bwams_sam_run_pe(b, mo, sam_opt, pes, sam_bytes);
     }

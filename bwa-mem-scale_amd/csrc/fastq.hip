@@ -270,14 +270,16 @@ int bwams_fastq_fetch(bwams_fastq_t *f, uint8_t *enc, int64_t *cum, char *names,
     return BWAMS_OK;
 }
 
-int bwams_fastq_to_batch(bwams_fastq_t *f, bwams_batch_t *b) {
+int bwams_fastq_to_batch_opt(bwams_fastq_t *f, bwams_batch_t *b, int32_t copy_comment) {
     if (!f || !b) return BWAMS_ERR_ARG;
     int rc = bwams_seed_upload(b, reinterpret_cast<const uint8_t *>(f->d_enc), f->cum.data(), nullptr, f->n_reads);
     if (rc) return rc;
+    const bool cm = copy_comment && f->comment_bytes;
     return bwams_sam_upload(b, reinterpret_cast<const char *>(f->d_names), f->name_off.data(), reinterpret_cast<const char *>(f->d_qual),
-                            f->comment_bytes ? reinterpret_cast<const char *>(f->d_comments) : nullptr,
-                            f->comment_bytes ? f->comment_off.data() : nullptr);
+                            cm ? reinterpret_cast<const char *>(f->d_comments) : nullptr, cm ? f->comment_off.data() : nullptr);
 }
+
+int bwams_fastq_to_batch(bwams_fastq_t *f, bwams_batch_t *b) { return bwams_fastq_to_batch_opt(f, b, 1); }
 
 int bwams_fastq_close(bwams_fastq_t *f) {
     if (!f) return BWAMS_OK;

@@ -280,8 +280,10 @@ int bwams_fastq_info(const bwams_fastq_t *f, int64_t *n_reads, int64_t *n_bases,
 /* any pointer may be NULL; enc / quals hold n_bases bytes, cum / name_off / comment_off n_reads + 1 entries */
 int bwams_fastq_fetch(bwams_fastq_t *f, uint8_t *enc, int64_t *cum, char *names, int64_t *name_off, char *quals, char *comments,
                       int64_t *comment_off);
-/* bwams_seed_upload + bwams_sam_upload of the decoded chunk, device to device */
+/* bwams_seed_upload + bwams_sam_upload of the decoded chunk, device to device.  The reference drops the comments unless `mem -C` was
+ * given (process(), src/fastmap.cpp:335-342): copy_comment = 0 does the same; bwams_fastq_to_batch keeps them. */
 int bwams_fastq_to_batch(bwams_fastq_t *f, bwams_batch_t *b);
+int bwams_fastq_to_batch_opt(bwams_fastq_t *f, bwams_batch_t *b, int32_t copy_comment);
 int bwams_fastq_close(bwams_fastq_t *f);
 
 /* ----------------------------------------------------------- mate rescue ---- */
@@ -484,13 +486,15 @@ int bwams_batch_sync(bwams_batch_t *b);
  * seqs[i].sam — the sequence of the stage calls of this header.  fastq: host or device memory, four lines per
  * record, the two ends of a pair interleaved when paired != 0; emf / ert: NULL or the resident tables (ert selects ERT seeding and the
  * useErt form of mate rescue); pes0: NULL = infer the insert-size statistics from the chunk (mem_pestat), as mem_process_seqs does;
- * n_processed: reads processed before this chunk (the hash seeds of mem_mark_primary_se / mem_pair); pair_flags: BWAMS_PAIR_NO_RESCUE.
+ * n_processed: reads processed before this chunk (the hash seeds of mem_mark_primary_se / mem_pair); flags: BWAMS_PAIR_NO_RESCUE
+ * (MEM_F_NO_RESCUE) and BWAMS_CHUNK_COPY_COMMENT (`mem -C`: without it the comments of the FASTQ headers are dropped, src/fastmap.cpp:335-342).
  * The text stays on the device: bwams_sam_fetch(b, buf, sam_bytes, read_off, NULL, 0) returns it with one offset per read.  The batch must
  * have been created for at least the chunk's reads and bases, the index must carry its sequence names.  Inputs the device path refuses
  * (multi-line / FASTA text, unsupported flags, paired-end behind the EMF) return BWAMS_ERR_UNSUPPORTED: run that chunk on the host. */
 int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
                         const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
-                        int64_t n_processed, int32_t pair_flags, int64_t *n_reads, int64_t *sam_bytes);
+                        int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes);
+#define BWAMS_CHUNK_COPY_COMMENT 0x100
 
 #ifdef __cplusplus
 }

@@ -133,7 +133,8 @@ def test_process_chunk_is_the_stage_sequence():
     comments = [b"x:i:%d" % i if i % 3 == 0 else None for i in range(len(reads))]
     text = _fastq_of(reads, names, quals, comments)
     b = capi.Batch(ix, len(reads), int(cum[-1]))
-    sam, off = b.process_chunk(text, n_processed=1000)
+    sam, off = b.process_chunk(text, n_processed=1000, copy_comment=True)
+    sam_nc, _ = b.process_chunk(text, n_processed=1000)                                  # without `-C` the comments are dropped
     o = loader.OracleFMI(idx)
     sm = o.collect_smem(enc, cum)
     coord, soff = o.sa_lookup(sm)
@@ -146,13 +147,15 @@ def test_process_chunk_is_the_stage_sequence():
             fin[a:e] = loader.mark_primary_se(fin[a:e], 1000 + r)[0]
     want = loader.reg2sam_se(fin, fin_off, enc, cum, idx.ref_0123, l_pac, names, quals=quals, comments=comments, contig_names=[b"chrR"])
     assert sam == b"".join(want) and off[-1] == len(sam)
+    want_nc = loader.reg2sam_se(fin, fin_off, enc, cum, idx.ref_0123, l_pac, names, quals=quals, contig_names=[b"chrR"])
+    assert sam_nc == b"".join(want_nc) and sam_nc != sam
     ert = capi.Ert.build(ix, kmer=8, xmer=2, read_len=151, hit_threshold=16)
-    sam_e, _ = b.process_chunk(text, ert=ert, n_processed=1000)
+    sam_e, _ = b.process_chunk(text, ert=ert, n_processed=1000, copy_comment=True)
     assert sam_e == sam                                      # ERT seeding: the same seeds, the same text (single-end)
     ert.close()
     tab = emf_mod.build_emf(g, reads.shape[1])
     e = capi.Emf(ix, table=tab)
-    sam_f, off_f = b.process_chunk(text, emf=e, n_processed=1000)
+    sam_f, off_f = b.process_chunk(text, emf=e, n_processed=1000, copy_comment=True)
     n_exact = 0
     for r in range(len(reads)):
         got = sam_f[off_f[r]:off_f[r + 1]]

@@ -1291,16 +1291,21 @@ static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwam
     A.bns_l_pac = (b->idx->fmi.ref_seq_len - 1) / 2;
     A.mapq = s->sm_mapq.as<int32_t>(); A.bad = s->sm_bad.as<unsigned long long>();
     A.len = s->sm_len.as<int64_t>(); A.out_off = s->sm_off.as<int64_t>(); A.out = nullptr;
-    BWAMS_HIP(hipMemsetAsync(s->sm_bad.p, 0, 8, st));
+    BWAMS_HIP(hipMemsetAsync(s->sm_bad.p, 0, 24, st));
     BWAMS_HIP(hipMemsetAsync(s->sm_len.as<int64_t>() + nseq, 0, 8, st));
     launch_sam_mapq(A, st);
     launch_sam_text(A, false, b->cu_count, st);
     if ((rc = scan_rows(b, A.len, s->sm_off.as<int64_t>(), 1, n1))) return rc;
     int64_t total = 0;
-    unsigned long long bad = 0;
+    unsigned long long bad = 0, bad_names = 0;
     BWAMS_HIP(hipMemcpyAsync(&total, s->sm_off.as<int64_t>() + nseq, 8, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipMemcpyAsync(&bad, s->sm_bad.p, 8, hipMemcpyDeviceToHost, st));
+    BWAMS_HIP(hipMemcpyAsync(&bad_names, s->sm_bad.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
+    if (bad_names) {
+        set_last_error("bwams_sam_run_pe: paired reads have different names (" + std::to_string(bad_names) + " pair(s)); the reference stops here");
+        return BWAMS_ERR_ARG;
+    }
     if (bad) {
         set_last_error("bwams_sam_run: an alignment longer than 65535 bases or more than 65534 competing pairings (mapping quality table)");
         return BWAMS_ERR_UNSUPPORTED;

@@ -606,6 +606,11 @@ __global__ void sam_text_pe_kernel(SamArgs A) {
         load_read(A, r - me, R[0]);
         load_read(A, r - me + 1, R[1]);
         const bwams_pair_t pr = A.pairs[r >> 1];
+        if (!EMIT && me == 0) {                            // mem_sam_pe: "paired reads have different names" is fatal (bwamem_pair.cpp:797)
+            bool same = R[0].l_name == R[1].l_name;
+            for (int i = 0; same && i < R[0].l_name; ++i) same = R[0].name[i] == R[1].name[i];
+            if (!same) atomicAdd(A.bad + 2, 1ull);
+        }
         PairPlan P;
         plan_pair(A, R, pr, P);
         Writer W;

@@ -175,6 +175,10 @@ def test_paired_end_sam_text_equals_oracle():
         _compare_pe(c, flag, rg, T)
     with pytest.raises(capi.BwamsError):
         c["b"].sam_run(c["gopt"], capi.default_sam_opt())              # the single-end form refuses a paired-end chunk
+    bad_names = list(c["names"]); bad_names[7] = b"other"
+    c["b"].sam_upload(bad_names, c["quals"])
+    with pytest.raises(capi.BwamsError, match="different names"):
+        c["b"].sam_run_pe(c["pes"], c["gopt"], capi.default_sam_opt())   # mem_sam_pe's fatal error, reported
     c["b"].close(); c["ix"].close()
     c = _pe_pipeline(300, 23, a=2, b=5, pen_unpaired=9, mapq_coef_len=0)
     _compare_pe(c)

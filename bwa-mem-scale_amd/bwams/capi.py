@@ -27,7 +27,7 @@ SYMBOLS = [
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_run_sam", "bwams_reg2aln_fetch",
     "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
-    "bwams_process_chunk", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_process_chunk", "bwams_emf_regs_merge", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
     "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
@@ -907,6 +907,12 @@ class Batch:
         code = np.zeros(max(n, 1), dtype=np.uint8)
         _chk(lib().bwams_emf_probe(self.h, emf.h, _p(enc), _p(cum), n, _p(out), _p(code)), "bwams_emf_probe")
         return out[:n], code[:n]
+
+    def emf_regs_merge(self) -> int:
+        """Paired-end: the regions of the EMF-resolved reads join the final regions (after dedup_run and pestat, before pair_run)."""
+        n = C.c_int64(0)
+        _chk(lib().bwams_emf_regs_merge(self.h, C.byref(n)), "bwams_emf_regs_merge")
+        return n.value
 
     def emf_run(self, emf: Emf):
         _chk(lib().bwams_emf_run(self.h, emf.h), "bwams_emf_run")

@@ -48,7 +48,7 @@ struct ChainState {
     DevBuf et_mems, et_moff, et_hits, et_hoff, et_smem, et_cnt, et_off, et_coord, et_srt;      // ERT mode input translation
     int64_t pr_total = 0, pr_tasks = 0, pr_redone = 0;
     bool pair_done = false, pr_single = false;
-    DevBuf er_wide, er_off, er_scr, er_n, er_rev, er_out, er_ooff;   // mem_perfect2reg
+    DevBuf er_wide, er_off, er_scr, er_n, er_rev, er_out, er_ooff, mg_wide, mg_off, mg_out;   // mem_perfect2reg (+ its merge into the final regions)
     int64_t er_total = 0, er_nseq = 0;
     bool er_done = false;
     DevBuf al_need, al_cls, al_off, al_scr, al_list, al_rec, al_wide, al_offs, al_cig, al_md, al_cnt, al_only;   // mem_reg2aln
@@ -82,7 +82,7 @@ void chain_state_free(ChainState *s) {
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
                      &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->pr_na, &s->pr_wide, &s->pr_offs, &s->pr_anchor, &s->pr_slot, &s->pr_task, &s->pr_trb, &s->pr_tl1, &s->pr_twide, &s->pr_toffs,
                      &s->pr_pairs, &s->pr_tref, &s->pr_tqer, &s->pr_aln, &s->pr_pool, &s->pr_ord, &s->pr_srt, &s->pr_z, &s->pr_nfin, &s->pr_npri, &s->pr_nsw, &s->pr_full, &s->pr_owide,
-                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->al_need, &s->al_cls, &s->al_off, &s->al_scr, &s->al_list, &s->al_rec, &s->al_wide, &s->al_offs, &s->al_cig, &s->al_md, &s->al_cnt, &s->al_only, &s->sm_names, &s->sm_noff, &s->sm_qual, &s->sm_comm, &s->sm_coff, &s->sm_mapq, &s->sm_len, &s->sm_off, &s->sm_out, &s->sm_logtab, &s->sm_bad, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
+                     &s->pr_ooff, &s->pr_out, &s->pr_res, &s->et_mems, &s->et_moff, &s->et_hits, &s->et_hoff, &s->et_smem, &s->et_cnt, &s->et_off, &s->et_coord, &s->et_srt, &s->er_wide, &s->er_off, &s->er_scr, &s->er_n, &s->er_rev, &s->er_out, &s->er_ooff, &s->mg_wide, &s->mg_off, &s->mg_out, &s->al_need, &s->al_cls, &s->al_off, &s->al_scr, &s->al_list, &s->al_rec, &s->al_wide, &s->al_offs, &s->al_cig, &s->al_md, &s->al_cnt, &s->al_only, &s->sm_names, &s->sm_noff, &s->sm_qual, &s->sm_comm, &s->sm_coff, &s->sm_mapq, &s->sm_len, &s->sm_off, &s->sm_out, &s->sm_logtab, &s->sm_bad, &s->regs, &s->srt, &s->rmax, &s->cnt, &s->state, &s->kreg, &s->cur, &s->lim,
                      &s->ewide, &s->eoffs, &s->lpairs, &s->lref, &s->lqer, &s->rpairs, &s->rref, &s->rqer, &s->retry};
     for (DevBuf *d : all)
         if (d->p) (void)hipFree(d->p);
@@ -1396,15 +1396,10 @@ int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, co
         if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, nullptr, &t0, &t1, &t2, &t3))) return rc;
         rc = emf ? bwams_sam_run_emf(b, mo, sam_opt, emf, sam_bytes) : bwams_sam_run(b, mo, sam_opt, sam_bytes);
     } else {
-        if (emf) {
-            // worker_sam turns the resolved ends into regions before mem_sam_pe (bwamem.cpp:1689-1702): the region lists of this
-            // library's paired-end tail come from bwams_dedup_run alone — merging bwams_emf_regs_run's into them is not built
-            set_last_error("bwams_process_chunk: paired-end chunks behind the exact-match filter are not built (run the stages yourself)");
-            return BWAMS_ERR_UNSUPPORTED;
-        }
         bwams_pestat_t pes[4];
         if (pes0) memcpy(pes, pes0, sizeof pes);
-        else if ((rc = bwams_pestat(b, mo, pes))) return rc;
+        else if ((rc = bwams_pestat(b, mo, pes))) return rc;          // mem_pestat sees the regions of worker_aln only (bwamem.cpp:1881-1891) ...
+        if (emf && (rc = bwams_emf_regs_merge(b, &t0))) return rc;       // ... worker_sam then gives the resolved ends theirs (:1689-1702)
         if ((rc = bwams_pair_run(b, mo, pes, n_processed >> 1, (flags & BWAMS_PAIR_NO_RESCUE) | (ert ? BWAMS_PAIR_USE_ERT : 0), &t0, &t1))) return rc;
         if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, pes, &t0, &t1, &t2, &t3))) return rc;
         rc = bwams_sam_run_pe(b, mo, sam_opt, pes, sam_bytes);
@@ -1452,6 +1447,34 @@ int bwams_emf_regs_run(bwams_batch_t *b, bwams_emf_t *e, const bwams_mem_opt_t *
     BWAMS_HIP(hipGetLastError());
     s->er_total = total; s->er_nseq = nseq;
     s->er_done = true;
+    if (n_regs) *n_regs = total;
+    return BWAMS_OK;
+}
+
+int bwams_emf_regs_merge(bwams_batch_t *b, int64_t *n_regs) {
+    if (!b || !b->chain || !b->chain->er_done || !b->chain->dedup_done || b->chain->er_nseq != b->chain->nseq) {
+        set_last_error("bwams_emf_regs_merge: run bwams_emf_regs_run and bwams_dedup_run of this chunk first");
+        return BWAMS_ERR_ARG;
+    }
+    ChainState *s = b->chain;
+    BWAMS_HIP(hipSetDevice(b->idx->device));
+    hipStream_t st = b->stream;
+    const int64_t nseq = s->nseq, n1 = nseq + 1;
+    int rc;
+    BWAMS_HIP(s->mg_wide.ensure((size_t)n1 * 8)); BWAMS_HIP(s->mg_off.ensure((size_t)n1 * 8));
+    launch_emfregs_merge_count(s->dd_off.as<int64_t>(), s->er_ooff.as<int64_t>(), nseq, s->mg_wide.as<int64_t>(), st);
+    if ((rc = scan_rows(b, s->mg_wide.as<int64_t>(), s->mg_off.as<int64_t>(), 1, n1))) return rc;
+    const int64_t total = s->n_final + s->er_total;
+    BWAMS_HIP(s->mg_out.ensure((size_t)(total + 1) * sizeof(bwams_alnreg_t)));
+    launch_emfregs_merge(s->dd_out.as<bwams_alnreg_t>(), s->dd_off.as<int64_t>(), s->er_out.as<bwams_alnreg_t>(), s->er_ooff.as<int64_t>(), nseq,
+                         s->mg_off.as<int64_t>(), s->mg_out.as<bwams_alnreg_t>(), st);
+    BWAMS_HIP(hipStreamSynchronize(st));
+    BWAMS_HIP(hipGetLastError());
+    std::swap(s->dd_out, s->mg_out);
+    std::swap(s->dd_off, s->mg_off);
+    s->n_final = total;
+    s->er_done = false;                                   // merged: a second call would add them again
+    s->pair_done = s->al_done = s->sm_done = false;
     if (n_regs) *n_regs = total;
     return BWAMS_OK;
 }

@@ -158,6 +158,9 @@ struct EmfRegArgs {
 };
 size_t emfregs_scratch_bytes(int64_t n);
 void launch_emfregs_count(const EmfRegArgs &A, int64_t *wide, hipStream_t st);
+void launch_emfregs_merge_count(const int64_t *off_a, const int64_t *off_b, int64_t nseq, int64_t *wide, hipStream_t st);
+void launch_emfregs_merge(const bwams_alnreg_t *a, const int64_t *off_a, const bwams_alnreg_t *b, const int64_t *off_b, int64_t nseq,
+                          const int64_t *off_o, bwams_alnreg_t *out, hipStream_t st);
 void launch_emfregs_fill(const EmfRegArgs &A, const int64_t *scr_off, int32_t *n_final, uint8_t *first_is_rev, int64_t *wide,
                          hipStream_t st);
 void launch_emfregs_emit(const EmfRegArgs &A, const int64_t *scr_off, const int32_t *n_final, const int64_t *out_off,

@@ -159,7 +159,30 @@ __global__ void emfregs_emit_kernel(EmfRegArgs A, const int64_t *__restrict__ sc
     }
 }
 
+// worker_sam's paired-end branch gives a resolved end its regions (mem_perfect2reg) before mem_sam_pe: the two region lists as one
+__global__ void emfregs_merge_count_kernel(const int64_t *__restrict__ off_a, const int64_t *__restrict__ off_b, int64_t nseq, int64_t *wide) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nseq) return;
+    wide[r] = r < nseq ? (off_a[r + 1] - off_a[r]) + (off_b[r + 1] - off_b[r]) : 0;
+}
+__global__ void emfregs_merge_kernel(const bwams_alnreg_t *__restrict__ a, const int64_t *__restrict__ off_a, const bwams_alnreg_t *__restrict__ bb,
+                                     const int64_t *__restrict__ off_b, int64_t nseq, const int64_t *__restrict__ off_o, bwams_alnreg_t *out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nseq) return;
+    int64_t o = off_o[r];
+    for (int64_t i = off_a[r]; i < off_a[r + 1]; ++i) out[o++] = a[i];
+    for (int64_t i = off_b[r]; i < off_b[r + 1]; ++i) out[o++] = bb[i];
+}
+
 }  // namespace
+
+void launch_emfregs_merge_count(const int64_t *off_a, const int64_t *off_b, int64_t nseq, int64_t *wide, hipStream_t st) {
+    emfregs_merge_count_kernel<<<(unsigned)((nseq + 256) / 256), 256, 0, st>>>(off_a, off_b, nseq, wide);
+}
+void launch_emfregs_merge(const bwams_alnreg_t *a, const int64_t *off_a, const bwams_alnreg_t *b, const int64_t *off_b, int64_t nseq,
+                          const int64_t *off_o, bwams_alnreg_t *out, hipStream_t st) {
+    if (nseq > 0) emfregs_merge_kernel<<<(unsigned)((nseq + 255) / 256), 256, 0, st>>>(a, off_a, b, off_b, nseq, off_o, out);
+}
 
 size_t emfregs_scratch_bytes(int64_t n) { return (size_t)(n + 1) * sizeof(AlnP); }
 

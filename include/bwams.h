@@ -437,6 +437,10 @@ int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, i
  * the last bwams_emf_run resolved (code FW_MATCHED / RC_MATCHED): all its exact locations as full-length regions
  * (grouped by read, reg_off[nseq + 1]); first_is_rev[r] = mem_perfect2reg's return value (strand of the first one). */
 int bwams_emf_regs_run(bwams_batch_t *b, bwams_emf_t *emf, const bwams_mem_opt_t *opt, int64_t *n_regs);
+/* Paired-end chunks: worker_sam gives an end the EMF resolved its regions (mem_perfect2reg, src/bwamem.cpp:1689-1702) before mem_sam_pe.
+ * After bwams_dedup_run (and bwams_pestat: mem_pestat ran before, on the regions of worker_aln alone) this appends the regions of
+ * bwams_emf_regs_run to the final regions of their reads; bwams_pair_run and what follows then see both. */
+int bwams_emf_regs_merge(bwams_batch_t *b, int64_t *n_regs);
 int bwams_emf_regs_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, uint8_t *first_is_rev);
 
 /* mem_pestat (src/bwamem_pair.cpp:89-156; called at src/bwamem.cpp:1888) over the final regions of
@@ -490,7 +494,7 @@ int bwams_batch_sync(bwams_batch_t *b);
  * (MEM_F_NO_RESCUE) and BWAMS_CHUNK_COPY_COMMENT (`mem -C`: without it the comments of the FASTQ headers are dropped, src/fastmap.cpp:335-342).
  * The text stays on the device: bwams_sam_fetch(b, buf, sam_bytes, read_off, NULL, 0) returns it with one offset per read.  The batch must
  * have been created for at least the chunk's reads and bases, the index must carry its sequence names.  Inputs the device path refuses
- * (multi-line / FASTA text, unsupported flags, paired-end behind the EMF) return BWAMS_ERR_UNSUPPORTED: run that chunk on the host. */
+ * (multi-line / FASTA text, unsupported flags) return BWAMS_ERR_UNSUPPORTED: run that chunk on the host. */
 int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
                         const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
                         int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes);

@@ -188,3 +188,56 @@ def test_process_chunk_is_the_stage_sequence():
     with pytest.raises(capi.BwamsError):
         b.process_chunk(b">fa\nACGT\n")                                    # FASTA: refused, the caller reads it on the host
     b.close(); ix.close()
+
+
+def test_process_chunk_paired_end_behind_the_exact_match_filter():
+    """worker_sam's paired-end branch with PERFECT_MATCH: mem_pestat on the regions of worker_aln, then mem_perfect2reg for the resolved
+    ends, then mem_sam_pe (bwamem.cpp:1689-1716) — bwams_process_chunk(paired, emf) against the same order of the restated pieces."""
+    from bwams import emf as emf_mod
+    g, idx, starts = repeat_genome()
+    l_pac = len(g)
+    ref = idx.ref_0123
+    ix = capi.Index.from_host(idx, 0)
+    ix.set_contig_names([b"chrR"])
+    rng = np.random.default_rng(3)
+    pr = simulate.make_read_pairs_bulk(g, 300, seed=19)
+    reads = np.asarray(pr).reshape(-1, np.asarray(pr).shape[-1]).copy()
+    L = reads.shape[1]
+    for p in range(0, 300, 3):                               # pairs whose ends are exact copies of the genome (FR, insert ~ 330)
+        a = int(rng.integers(0, l_pac - 400 - L))
+        reads[2 * p] = g[a:a + L]
+        if p % 2 == 0:
+            reads[2 * p + 1] = simulate.revcomp(g[a + 330 - L:a + 330])
+    enc, cum = simulate.flatten_reads(reads)
+    quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+    names = [b"pq%d" % (i // 2) for i in range(len(reads))]
+    text = _fastq_of(reads, [n + (b"/1" if i % 2 == 0 else b"/2") for i, n in enumerate(names)], quals)
+    tab = emf_mod.build_emf(g, L)
+    e = capi.Emf(ix, table=tab)
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    sam, off = b.process_chunk(text, paired=True, emf=e)
+    # the restated pieces in worker_sam's order
+    oe = loader.OracleEMF(tab, ref)
+    probe = oe.probe_many(list(reads))
+    hit = (probe[:, 0] == 3) | (probe[:, 0] == 4)
+    assert hit.sum() > 120
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(enc, cum, skip=hit.astype(np.uint8))
+    coord, soff = o.sa_lookup(sm)
+    ch, sd, choff = loader.chain_seeds(sm, coord, soff, cum, l_pac, ref_string=ref, enc=enc)
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, enc, cum, ref, l_pac)
+    fin, fin_off = loader.regs_finish(regs, reg_off, enc, cum, ref, l_pac)
+    pes = loader.pestat(fin, fin_off, l_pac)
+    merged, moff = [], [0]
+    for r in range(len(reads)):
+        part = [fin[fin_off[r]:fin_off[r + 1]]]
+        if hit[r]:
+            part.append(oe.perfect2reg(reads[r], int(probe[r, 1]), int(probe[r, 2]), l_pac)[0])
+        merged.extend(part)
+        moff.append(moff[-1] + sum(len(x) for x in part))
+    merged = np.concatenate(merged)
+    wregs, woff, wpairs = loader.pair_pe(merged, np.asarray(moff, np.int64), enc, cum, ref, l_pac, pes)
+    want = loader.sam_pe(wregs, woff, enc, cum, ref, l_pac, pes, wpairs, names, quals=quals, contig_names=[b"chrR"])
+    for r, w in enumerate(want):
+        assert sam[off[r]:off[r + 1]] == w, (r, sam[off[r]:off[r + 1]], w)
+    e.close(); b.close(); ix.close()

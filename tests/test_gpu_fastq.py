@@ -182,6 +182,12 @@ def test_process_chunk_is_the_stage_sequence():
     psam2, _ = b.process_chunk(ptext, paired=True, pes=pes2)
     wregs2, woff2, wpairs2 = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, pes2)
     assert psam2 == b"".join(loader.sam_pe(wregs2, woff2, penc, pcum, c["ref"], l_pac, pes2, wpairs2, pnames, quals=pquals, contig_names=[b"chrR"]))
+    ert = capi.Ert.build(ix, kmer=8, xmer=2, read_len=151, hit_threshold=16)
+    psam_e, _ = b.process_chunk(ptext, paired=True, ert=ert)              # ERT mode: the same seeds, mate rescue in its useErt form
+    wregs_e, woff_e, wpairs_e = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, c["pes"], use_ert=True)
+    assert psam_e == b"".join(loader.sam_pe(wregs_e, woff_e, penc, pcum, c["ref"], l_pac, c["pes"], wpairs_e, pnames, quals=pquals,
+                                             contig_names=[b"chrR"]))
+    ert.close()
     with pytest.raises(capi.BwamsError):
         b.process_chunk(ptext[: ptext.index(b"@pp1/2")], paired=True)      # an odd number of reads
     assert b.process_chunk(b"", fetch=False) == 0                          # an empty chunk

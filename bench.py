@@ -205,6 +205,23 @@ def ert_report(st, mean, CHn, n_bases, ert_info, pmc=None):
     return stage, roof, info
 
 
+
+def fastq_rows(rd, first):
+    """One four-line FASTQ record per row: '@r%08d' names, the bases of `rd`, '+', a constant quality string."""
+    n, RL = rd.shape
+    row = np.empty((n, 1 + 9 + 1 + RL + 3 + RL + 1), np.uint8)
+    row[:, 0] = ord("@"); row[:, 1] = ord("r")
+    ids_ = first + np.arange(n, dtype=np.int64)
+    for d_ in range(8):
+        row[:, 2 + d_] = ord("0") + (ids_ // 10 ** (7 - d_)) % 10
+    row[:, 10] = 10
+    row[:, 11:11 + RL] = np.frombuffer(b"ACGTN", np.uint8)[rd]
+    row[:, 11 + RL:14 + RL] = np.frombuffer(b"\n+\n", np.uint8)
+    row[:, 14 + RL:14 + 2 * RL] = ord("I")
+    row[:, 14 + 2 * RL] = 10
+    return row
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -396,6 +413,22 @@ def main():
                     "resolved_fraction": round(float(((codes_c == 3) | (codes_c == 4)).mean()), 4)},
             "note": "EMF probe first; the reads it resolves skip seeding and get their regions from mem_perfect2reg (bwams_emf_regs_run), inside the step",
         }
+        # configs[2] text to text: bwams_process_chunk with both handles (exact-match records through put_perfect)
+        ix.set_contig_names([b"chr%d" % (i + 1) for i in range(len(contigs) if contigs is not None else 1)])
+        row_c = fastq_rows(reads_l[n_chunks - 1], first)
+        d_fq_c = torch.from_numpy(row_c.reshape(-1)).to(dev)
+        pc_args = dict(emf=emf_h, ert=ert_h, seed_opt=seed_opt, opt=mem_opt, sopt=capi.default_sam_opt(), n_processed=first, fetch=False)
+        batch.process_chunk((d_fq_c.data_ptr(), row_c.size), **pc_args)
+        batch.sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            bytes_c = batch.process_chunk((d_fq_c.data_ptr(), row_c.size), **pc_args)
+        batch.sync()
+        ms_c = (time.perf_counter() - t0) / 2 * 1e3
+        ert_side["with_emf"]["fastq_to_sam"] = {
+            "ms_per_chunk": round(ms_c, 2), "Mreads_per_s": round(len(row_c) / (ms_c * 1e-3) / 1e6, 3), "sam_bytes": int(bytes_c),
+            "note": "bwams_process_chunk with the EMF and the ERT (configs[2]'s index set), single-end, FASTQ text in HBM -> SAM text in HBM"}
+        del row_c, d_fq_c
         emf_h.close()
         emf_h = None
         ert_h.close()
@@ -475,16 +508,7 @@ def main():
         raise SystemExit(f"[bench] SAM text property check failed: {checks}")
     # read input: the chunk as FASTQ text -> encoded bases, names, qualities on the device (kseq_read + trim_readno + base encoding)
     rd_ = reads_l[n_chunks - 1]
-    row = np.empty((n_seq_, 1 + 9 + 1 + RL + 3 + RL + 1), np.uint8)
-    row[:, 0] = ord("@"); row[:, 1] = ord("r")
-    ids_ = first + np.arange(n_seq_, dtype=np.int64)
-    for d_ in range(8):
-        row[:, 2 + d_] = ord("0") + (ids_ // 10 ** (7 - d_)) % 10
-    row[:, 10] = 10
-    row[:, 11:11 + RL] = np.frombuffer(b"ACGTN", np.uint8)[rd_]
-    row[:, 11 + RL:14 + RL] = np.frombuffer(b"\n+\n", np.uint8)
-    row[:, 14 + RL:14 + 2 * RL] = ord("I")
-    row[:, 14 + 2 * RL] = 10
+    row = fastq_rows(rd_, first)
     fq_text = row.tobytes()
     d_fq = torch.from_numpy(row.reshape(-1)).to(dev)               # the text resident in HBM, as the other inputs are
     fq = capi.Fastq(d_fq.data_ptr(), device=local, n_bytes=len(fq_text)); fq.close()

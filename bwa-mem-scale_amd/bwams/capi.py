@@ -39,7 +39,7 @@ SYMBOLS = [
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
-    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_chain_run_ert", "bwams_pestat", "bwams_pestat_keys", "bwams_pestat_from_keys", "bwams_pair_run", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
+    "bwams_dedup_run", "bwams_dedup_fetch", "bwams_chain_run_ert", "bwams_pestat", "bwams_pestat_keys", "bwams_pestat_from_keys", "bwams_pair_run", "bwams_pair_run_sam", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
 ]
 ERT_MEM_DTYPE = np.dtype([("forward", "u1"), ("pad_", "u1", (3,)), ("start", "<i4"), ("end", "<i4"), ("rc_start", "<i4"),
                           ("rc_end", "<i4"), ("skip_ref_fetch", "<i4"), ("fetch_leaves", "<i4"), ("hitbeg", "<i4"),
@@ -849,21 +849,24 @@ class Batch:
         _chk(lib().bwams_pestat_keys(self.h, C.byref(opt), _p(keys), len(keys), C.byref(n)), "bwams_pestat_keys")
         return keys[:n.value].copy()
 
-    def mark_primary_se(self, opt: MemOpt | None = None, id_base: int = 0):
-        """Single-end chunk: mem_mark_primary_se of every read's final regions (then pair_fetch / reg2aln(source=1))."""
+    def mark_primary_se(self, opt: MemOpt | None = None, id_base: int = 0, sopt=None):
+        """Single-end chunk: mem_mark_primary_se of every read's final regions (then pair_fetch / reg2aln(source=1)); sopt carries
+        MEM_F_PRIMARY5 and its T (bwams_pair_run_sam)."""
         opt = opt or default_mem_opt()
         n, nt = C.c_int64(0), C.c_int64(0)
-        _chk(lib().bwams_pair_run(self.h, C.byref(opt), None, id_base, 4, C.byref(n), C.byref(nt)), "bwams_pair_run")
+        _chk(lib().bwams_pair_run_sam(self.h, C.byref(opt), C.byref(sopt) if sopt is not None else None, None, C.c_int64(id_base), 4,
+                                      C.byref(n), C.byref(nt)), "bwams_pair_run_sam")
         self._n_pair_regs = n.value
         return n.value
 
-    def pair_run(self, pes, opt: MemOpt | None = None, id_base: int = 0, no_rescue: bool = False, use_ert: bool = False):
+    def pair_run(self, pes, opt: MemOpt | None = None, id_base: int = 0, no_rescue: bool = False, use_ert: bool = False, sopt=None):
         """Mate rescue + mem_mark_primary_se + mem_pair over the final regions (reads 2p, 2p+1 = pair p)
-        -> (regions, rescue alignments)."""
+        -> (regions, rescue alignments).  sopt: MEM_F_PRIMARY5 / MEM_F_NOPAIRING / MEM_F_NO_RESCUE of its flag (bwams_pair_run_sam)."""
         opt = opt or default_mem_opt()
         pes = np.ascontiguousarray(pes, PESTAT_DTYPE)
         n, nt = C.c_int64(0), C.c_int64(0)
-        _chk(lib().bwams_pair_run(self.h, C.byref(opt), _p(pes), id_base, int(no_rescue) | (int(use_ert) << 1), C.byref(n), C.byref(nt)), "bwams_pair_run")
+        _chk(lib().bwams_pair_run_sam(self.h, C.byref(opt), C.byref(sopt) if sopt is not None else None, _p(pes), C.c_int64(id_base),
+                                      int(no_rescue) | (int(use_ert) << 1), C.byref(n), C.byref(nt)), "bwams_pair_run_sam")
         self._n_pair_regs = n.value
         return n.value, nt.value
 

@@ -831,8 +831,28 @@ int bwams_dedup_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, i
 
 /* ------------------------------------------------- mate rescue, mem_mark_primary_se, mem_pair ---- */
 
+static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t flags,
+                         int primary5_T, int no_pairing, int64_t *n_regs, int64_t *n_tasks);
+
 int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t flags,
                    int64_t *n_regs, int64_t *n_tasks) {
+    return pair_run_impl(b, opt, pes, id_base, flags, -1, 0, n_regs, n_tasks);
+}
+
+int bwams_pair_run_sam(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sam_opt, const bwams_pestat_t pes[4],
+                       int64_t id_base, int32_t flags, int64_t *n_regs, int64_t *n_tasks) {
+    if (!sam_opt) return pair_run_impl(b, opt, pes, id_base, flags, -1, 0, n_regs, n_tasks);
+    if (sam_opt->T < 0) {
+        set_last_error("bwams_pair_run_sam: T must not be negative");
+        return BWAMS_ERR_ARG;
+    }
+    if (sam_opt->flag & BWAMS_MEM_F_NO_RESCUE) flags |= BWAMS_PAIR_NO_RESCUE;
+    return pair_run_impl(b, opt, pes, id_base, flags, (sam_opt->flag & BWAMS_MEM_F_PRIMARY5) ? sam_opt->T : -1,
+                         (sam_opt->flag & BWAMS_MEM_F_NOPAIRING) != 0, n_regs, n_tasks);
+}
+
+static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t flags,
+                         int primary5_T, int no_pairing, int64_t *n_regs, int64_t *n_tasks) {
     const int single_end = (flags & BWAMS_PAIR_SINGLE_END) != 0;
     const int no_rescue = (flags & BWAMS_PAIR_NO_RESCUE) || single_end, use_ert = (flags & BWAMS_PAIR_USE_ERT) != 0;
     static const bwams_pestat_t no_pes[4] = {{0, 0, 1, 0, 0., 0.}, {0, 0, 1, 0, 0., 0.}, {0, 0, 1, 0, 0., 0.}, {0, 0, 1, 0, 0., 0.}};
@@ -876,6 +896,7 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     A.drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") ? 1 : 0;                 // test knob: exercise the second pass
     A.use_ert = use_ert ? 1 : 0;
     A.single_end = single_end;
+    A.no_pairing = no_pairing; A.primary5_T = primary5_T;
     A.na = s->pr_na.as<int32_t>();
     int64_t *aoff = s->pr_offs.as<int64_t>(), *ooff = aoff + n1;
     A.aoff = aoff; A.ooff = ooff;
@@ -959,6 +980,7 @@ int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pes
     BWAMS_HIP(hipStreamSynchronize(st));
     BWAMS_HIP(s->pr_out.ensure((size_t)(total + 1) * sizeof(bwams_alnreg_t)));
     launch_pair_gather(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), st);
+    launch_pair_reorder5(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), st);
     if (!single_end) launch_pair_pair(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), s->pr_res.as<bwams_pair_t>(), st);
     BWAMS_HIP(hipEventRecord(s->ev[15], st));
     BWAMS_HIP(hipStreamSynchronize(st));
@@ -1238,8 +1260,10 @@ static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwam
     }
     int rc = check_opt(opt, "bwams_sam_run");
     if (rc) return rc;
-    if (sopt->flag & ~(BWAMS_MEM_F_ALL | BWAMS_MEM_F_NO_MULTI | BWAMS_MEM_F_SOFTCLIP | BWAMS_MEM_F_KEEP_SUPP_MAPQ)) {
-        set_last_error("bwams_sam_run: only MEM_F_ALL, MEM_F_NO_MULTI, MEM_F_SOFTCLIP and MEM_F_KEEP_SUPP_MAPQ are built (no MEM_F_PRIMARY5 / MEM_F_REF_HDR)");
+    // MEM_F_PRIMARY5 / MEM_F_NO_RESCUE act in bwams_pair_run_sam, before the text; MEM_F_NOPAIRING there and in the proper-pair flag
+    if (sopt->flag & ~(BWAMS_MEM_F_ALL | BWAMS_MEM_F_NO_MULTI | BWAMS_MEM_F_SOFTCLIP | BWAMS_MEM_F_KEEP_SUPP_MAPQ | BWAMS_MEM_F_PRIMARY5 |
+                       BWAMS_MEM_F_NOPAIRING | BWAMS_MEM_F_NO_RESCUE)) {
+        set_last_error("bwams_sam_run: MEM_F_REF_HDR (XR tags from the .ann annotations), MEM_F_PE / MEM_F_SMARTPE (the caller's) and MEM_F_XB are not built");
         return BWAMS_ERR_UNSUPPORTED;
     }
     if (!memchr(sopt->rg_id, 0, sizeof sopt->rg_id)) return BWAMS_ERR_ARG;
@@ -1392,7 +1416,7 @@ int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, co
     if ((rc = bwams_extend_run(b, mo, &t0))) return rc;
     if ((rc = bwams_dedup_run(b, mo, &t0))) return rc;
     if (!paired) {
-        if ((rc = bwams_pair_run(b, mo, nullptr, n_processed, BWAMS_PAIR_SINGLE_END, &t0, &t1))) return rc;
+        if ((rc = bwams_pair_run_sam(b, mo, sam_opt, nullptr, n_processed, BWAMS_PAIR_SINGLE_END, &t0, &t1))) return rc;
         if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, nullptr, &t0, &t1, &t2, &t3))) return rc;
         rc = emf ? bwams_sam_run_emf(b, mo, sam_opt, emf, sam_bytes) : bwams_sam_run(b, mo, sam_opt, sam_bytes);
     } else {
@@ -1400,7 +1424,7 @@ int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, co
         if (pes0) memcpy(pes, pes0, sizeof pes);
         else if ((rc = bwams_pestat(b, mo, pes))) return rc;          // mem_pestat sees the regions of worker_aln only (bwamem.cpp:1881-1891) ...
         if (emf && (rc = bwams_emf_regs_merge(b, &t0))) return rc;       // ... worker_sam then gives the resolved ends theirs (:1689-1702)
-        if ((rc = bwams_pair_run(b, mo, pes, n_processed >> 1, (flags & BWAMS_PAIR_NO_RESCUE) | (ert ? BWAMS_PAIR_USE_ERT : 0), &t0, &t1))) return rc;
+        if ((rc = bwams_pair_run_sam(b, mo, sam_opt, pes, n_processed >> 1, (flags & BWAMS_PAIR_NO_RESCUE) | (ert ? BWAMS_PAIR_USE_ERT : 0), &t0, &t1))) return rc;
         if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, pes, &t0, &t1, &t2, &t3))) return rc;
         rc = bwams_sam_run_pe(b, mo, sam_opt, pes, sam_bytes);
     }

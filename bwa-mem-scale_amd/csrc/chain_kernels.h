@@ -182,6 +182,8 @@ struct PairArgs {
     int32_t drop_plan;             // test knob: the first pass plans nothing, so every rescue goes through the second
     int32_t use_ert;               // mem_sam_pe_batch_post's useErt branch: mem_matesw_batch_post_ert
     int32_t single_end;            // mem_reg2sam's form: every read on its own, id = id_base + read, no rescue, no pairing
+    int32_t no_pairing;            // MEM_F_NOPAIRING: mem_pair is not called (score 0, z = -1; n_pri still reported)
+    int32_t primary5_T;            // MEM_F_PRIMARY5: mem_reorder_primary5(T, a) of every read after the marking; < 0 = off
     int32_t *na;                   // per read: anchors it provides
     const int64_t *aoff, *ooff;    // per read: first anchor slot, first pool slot
     int32_t *anchor, *slot_read;   // per anchor slot: region index within its read, the read
@@ -208,6 +210,7 @@ void launch_pair_post(const PairArgs &A, int cu_count, hipStream_t st);
 void launch_pair_mark(const PairArgs &A, int cu_count, hipStream_t st);
 void launch_pair_widen(const PairArgs &A, int64_t *wide, hipStream_t st);
 void launch_pair_gather(const PairArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
+void launch_pair_reorder5(const PairArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st);
 void launch_pair_pair(const PairArgs &A, const int64_t *out_off, const bwams_alnreg_t *out, bwams_pair_t *res, hipStream_t st);
 
 // ---- ERT mode: MEMs + hits of the reference's ERT walk -> the chaining kernels' input (ert_chain.hip) ----

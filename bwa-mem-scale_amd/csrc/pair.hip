@@ -844,6 +844,34 @@ __global__ void pair_gather_kernel(PairArgs A, const int64_t *out_off, bwams_aln
     }
 }
 
+// ---- mem_reorder_primary5 (bwamem.cpp:2009-2031): lane per read, on the gathered list ------------------------------------
+// Of the primary, non-ALT regions scoring >= T the one that starts leftmost in the read (first of equals) changes places
+// with region 0; secondary / secondary_all references to either follow.  Runs between the marking and mem_pair, as in
+// mem_sam_pe (bwamem_pair.cpp:1060-1063) and worker_sam (bwamem.cpp:1840).
+__global__ __launch_bounds__(64) void pair_reorder5_kernel(PairArgs A, const int64_t *out_off, bwams_alnreg_t *out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.nseq) return;
+    bwams_alnreg_t *a = out + out_off[r];
+    const int n = (int)(out_off[r + 1] - out_off[r]), T = A.primary5_T;
+    int n_pri = 0, left_st = 0x7fffffff, left_k = -1;
+    for (int k = 0; k < n; ++k) {
+        const int32_t sec = a[k].secondary, sc = a[k].score, qb = a[k].qb;
+        if (sec >= 0 || is_alt(a[k]) || sc < T) continue;
+        ++n_pri;
+        if (qb < left_st) left_st = qb, left_k = k;
+    }
+    if (n_pri <= 1 || left_k == 0) return;
+    const bwams_alnreg_t t = a[0];
+    a[0] = a[left_k];
+    a[left_k] = t;
+    for (int k = 1; k < n; ++k) {
+        int32_t s1 = a[k].secondary, s2 = a[k].secondary_all;
+        if (s1 == 0) s1 = left_k; else if (s1 == left_k) s1 = 0;
+        if (s2 == 0) s2 = left_k; else if (s2 == left_k) s2 = 0;
+        a[k].secondary = s1; a[k].secondary_all = s2;
+    }
+}
+
 // ---- mem_pair: lane per pair ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void pair_pair_kernel(PairArgs A, const int64_t *out_off, const bwams_alnreg_t *out, bwams_pair_t *res) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -854,7 +882,7 @@ __global__ __launch_bounds__(64) void pair_pair_kernel(PairArgs A, const int64_t
     R.z[0] = R.z[1] = -1;
     R.n_pri[0] = A.n_pri[2 * p]; R.n_pri[1] = A.n_pri[2 * p + 1];
     R.n_matesw = A.n_sw[2 * p] + A.n_sw[2 * p + 1];
-    if (R.n_pri[0] && R.n_pri[1]) {
+    if (!A.no_pairing && R.n_pri[0] && R.n_pri[1]) {
         // v: x = rid << 32 | forward position within the sequence; y = score << 32 | i << 2 | strand << 1 | end.
         // As a sort record: k = x, (s, q) = the two halves of y.  y holds a unique (i, end): no ties.
         SortRec *v = reinterpret_cast<SortRec *>(A.srt) + A.ooff[2 * p];        // the two ends' strips are adjacent
@@ -966,6 +994,9 @@ void launch_pair_widen(const PairArgs &A, int64_t *wide, hipStream_t st) {
 }
 void launch_pair_gather(const PairArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st) {
     if (A.nseq > 0) pair_gather_kernel<<<(unsigned)A.nseq, 64, 0, st>>>(A, out_off, out);
+}
+void launch_pair_reorder5(const PairArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st) {
+    if (A.nseq > 0 && A.primary5_T >= 0) pair_reorder5_kernel<<<blocks_of(A.nseq, 64), 64, 0, st>>>(A, out_off, out);
 }
 void launch_pair_pair(const PairArgs &A, const int64_t *out_off, const bwams_alnreg_t *out, bwams_pair_t *res, hipStream_t st) {
     if (A.nseq > 1) pair_pair_kernel<<<blocks_of(A.nseq >> 1, 64), 64, 0, st>>>(A, out_off, out, res);

@@ -654,7 +654,7 @@ __global__ void sam_text_pe_kernel(SamArgs A) {
                 }
             }
             const int rid0 = which[0] >= 0 ? R[0].rec[which[0]].rid : -1, rid1 = which[1] >= 0 ? R[1].rec[which[1]].rid : -1;
-            if (rid0 == rid1 && rid0 >= 0) {
+            if (!(A.sopt.flag & BWAMS_MEM_F_NOPAIRING) && rid0 == rid1 && rid0 >= 0) {      // bwamem_pair.cpp:1176
                 int64_t dist;
                 const int d = infer_dir(A.bns_l_pac, R[0].a[0].rb, R[1].a[0].rb, &dist);
                 if (!A.pes[d].failed && dist >= A.pes[d].low && dist <= A.pes[d].high) extra_flag |= 2;

@@ -476,6 +476,15 @@ int bwams_pestat_from_keys(const uint64_t *keys, int64_t n, bwams_pestat_t pes[4
                                   * and one mem_sort_dedup_patch or score sort closes each end (src/bwamem_pair.cpp:1017-1041) */
 int bwams_pair_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_pestat_t pes[4], int64_t id_base, int32_t flags,
                    int64_t *n_regs, int64_t *n_tasks);
+/* The same with the flags of mem_opt_t that act between the marking and the SAM text taken from sam_opt->flag:
+ *   - MEM_F_PRIMARY5 (`mem -5`): mem_reorder_primary5(sam_opt->T, a) (src/bwamem.cpp:2009-2031) of every read right after
+ *     mem_mark_primary_se — in mem_sam_pe before mem_pair (src/bwamem_pair.cpp:1060-1063), in worker_sam's single-end branch
+ *     before mem_reg2sam (src/bwamem.cpp:1840);
+ *   - MEM_F_NOPAIRING (`mem -P`): mem_pair is not called (src/bwamem_pair.cpp:1066): score 0, z = -1 in every bwams_pair_t;
+ *   - MEM_F_NO_RESCUE (`mem -S`): as BWAMS_PAIR_NO_RESCUE.
+ * sam_opt == NULL is bwams_pair_run. */
+int bwams_pair_run_sam(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwams_sam_opt_t *sam_opt, const bwams_pestat_t pes[4],
+                       int64_t id_base, int32_t flags, int64_t *n_regs, int64_t *n_tasks);
 int bwams_pair_fetch(bwams_batch_t *b, bwams_alnreg_t *regs, int64_t reg_cap, int64_t *reg_off, bwams_pair_t *pairs);
 /* the task lists as built (side 0 = left, 1 = right), for inspection */
 int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pairs, int64_t pair_cap, uint8_t *ref,

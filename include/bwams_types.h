@@ -222,9 +222,12 @@ typedef struct bwams_aln {
 
 /* What mem_reg2sam / mem_gen_alt / mem_aln2sam read beyond bwams_mem_opt_t: fields of mem_opt_t (src/bwamem.h:89-124,
  * defaults src/bwamem.cpp:135-171) and the read-group id (bwa_rg_id, src/bwa.cpp). */
+#define BWAMS_MEM_F_NOPAIRING      0x4      /* bwams_pair_run_sam, mem_sam_pe's proper-pair flag of unpaired ends */
 #define BWAMS_MEM_F_ALL            0x8
 #define BWAMS_MEM_F_NO_MULTI       0x10
+#define BWAMS_MEM_F_NO_RESCUE      0x20     /* bwams_pair_run_sam */
 #define BWAMS_MEM_F_SOFTCLIP       0x200
+#define BWAMS_MEM_F_PRIMARY5       0x800    /* bwams_pair_run_sam (the text itself does not read it) */
 #define BWAMS_MEM_F_KEEP_SUPP_MAPQ 0x1000
 typedef struct bwams_sam_opt {
     int32_t T;                  /* minimum score to output, 30 */

@@ -233,8 +233,9 @@ int64_t orc_regs_finish(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const 
 int orc_mark_primary_se(const bwams_mem_opt_t *opt, int n, bwams_alnreg_t *a, int64_t id);
 int64_t orc_pair_pe(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_t *ref_string, const uint8_t *enc_qdb,
                     const int64_t *cum_len, int32_t n_pairs, const bwams_alnreg_t *regs, const int64_t *reg_off,
-                    const bwams_pestat_t pes[4], int64_t id_base, int flags /* 1: no rescue, 2: useErt */, bwams_alnreg_t *out, int64_t out_cap,
-                    int64_t *out_off, bwams_pair_t *pairs);
+                    const bwams_pestat_t pes[4], int64_t id_base, int flags /* 1: no rescue, 2: useErt, 4: no pairing */,
+                    int primary5_T /* < 0: off */, bwams_alnreg_t *out, int64_t out_cap, int64_t *out_off, bwams_pair_t *pairs);
+void orc_reorder_primary5(int T, int n, bwams_alnreg_t *a);
 
 /* ---- ERT index (ert_oracle.c): writer, decoder, seeding.  PARITY UNPINNED (see the file header). ---- */
 typedef struct orc_ert {

@@ -817,8 +817,8 @@ assert PAIR_DTYPE.itemsize == 32
 
 
 def pair_pe(regs, reg_off, enc, cum, ref_string, l_pac, pes, contigs=None, opt: MemOpt | None = None, id_base: int = 0,
-            no_rescue: bool = False, use_ert: bool = False):
-    """Restated PE tail up to the pairing decision: mate rescue, mem_mark_primary_se, mem_pair
+            no_rescue: bool = False, use_ert: bool = False, no_pairing: bool = False, primary5_T: int = -1):
+    """Restated PE tail up to the pairing decision: mate rescue, mem_mark_primary_se, [mem_reorder_primary5,] mem_pair
     -> (regs, reg_off, pairs).  Reads 2p, 2p + 1 are the ends of pair p."""
     opt = opt or default_mem_opt()
     bns, keep = _bns(l_pac, contigs if contigs is not None else single_contig(l_pac))
@@ -837,17 +837,28 @@ def pair_pe(regs, reg_off, enc, cum, ref_string, l_pac, pes, contigs=None, opt: 
     L = lib()
     L.orc_pair_pe.restype = C.c_int64
     n = L.orc_pair_pe(C.byref(opt), C.byref(bns), _p(ref_string), _p(enc), _p(cum), nseq // 2, _p(regs), _p(reg_off), _p(pes),
-                      C.c_int64(id_base), int(no_rescue) | (int(use_ert) << 1), _p(out), C.c_int64(cap), _p(out_off), _p(pairs))
+                      C.c_int64(id_base), int(no_rescue) | (int(use_ert) << 1) | (int(no_pairing) << 2), int(primary5_T), _p(out),
+                      C.c_int64(cap), _p(out_off), _p(pairs))
     assert n >= 0, "orc_pair_pe: output capacity"
     return out[:n].copy(), out_off, pairs
 
 
-def mark_primary_se(regs, id_: int, opt: MemOpt | None = None):
-    """Restated mem_mark_primary_se on one read's regions -> (regs, n_pri)."""
+def mark_primary_se(regs, id_: int, opt: MemOpt | None = None, primary5_T: int = -1):
+    """Restated mem_mark_primary_se [+ mem_reorder_primary5(T)] on one read's regions -> (regs, n_pri)."""
     opt = opt or default_mem_opt()
     regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE).copy()
     n_pri = lib().orc_mark_primary_se(C.byref(opt), len(regs), _p(regs), C.c_int64(id_))
+    if primary5_T >= 0:
+        regs = reorder_primary5(regs, primary5_T)
     return regs, n_pri
+
+
+def reorder_primary5(regs, T: int):
+    """Restated mem_reorder_primary5 (bwamem.cpp:2009-2031) on one read's marked regions -> regs."""
+    regs = np.ascontiguousarray(regs, dtype=ALNREG_DTYPE).copy()
+    lib().orc_reorder_primary5.restype = None
+    lib().orc_reorder_primary5(int(T), len(regs), _p(regs))
+    return regs
 
 
 def pestat_keys(regs, reg_off, l_pac, opt: MemOpt | None = None):

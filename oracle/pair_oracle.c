@@ -328,15 +328,42 @@ static int pair(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const bwams_pe
     return ret;
 }
 
+/* mem_reorder_primary5 (bwamem.cpp:2009-2031), `mem -5`: among the primary, non-ALT regions scoring >= T the one with the
+ * smallest query start (first of equals) changes places with a[0]; secondary / secondary_all indices to either follow. */
+void orc_reorder_primary5(int T, int n, bwams_alnreg_t *a)
+{
+    int k, n_pri = 0, left_st = INT32_MAX, left_k = -1;
+    bwams_alnreg_t t;
+    for (k = 0; k < n; ++k)
+        if (a[k].secondary < 0 && !(((uint32_t)a[k].n_comp_is_alt >> 30) & 3) && a[k].score >= T) ++n_pri;
+    if (n_pri <= 1) return;
+    for (k = 0; k < n; ++k) {
+        const bwams_alnreg_t *p = &a[k];
+        if (p->secondary >= 0 || (((uint32_t)p->n_comp_is_alt >> 30) & 3) || p->score < T) continue;
+        if (p->qb < left_st) left_st = p->qb, left_k = k;
+    }
+    if (left_k == 0) return;
+    t = a[0], a[0] = a[left_k], a[left_k] = t;
+    for (k = 1; k < n; ++k) {
+        bwams_alnreg_t *p = &a[k];
+        if (p->secondary == 0) p->secondary = left_k;
+        else if (p->secondary == left_k) p->secondary = 0;
+        if (p->secondary_all == 0) p->secondary_all = left_k;
+        else if (p->secondary_all == left_k) p->secondary_all = 0;
+    }
+}
+
 /* For every pair p (reads 2p, 2p+1) of a chunk: mate rescue, mem_mark_primary_se of both ends, mem_pair.
+ * flags: 1 = MEM_F_NO_RESCUE, 2 = useErt, 4 = MEM_F_NOPAIRING (bwamem_pair.cpp:1066); primary5_T >= 0 = MEM_F_PRIMARY5 with
+ * that opt->T (:1060-1063).
  * regs / reg_off: the final regions per read (orc_regs_finish); out (capacity out_cap) / out_off receive the
  * regions per read afterwards.  id_base = n_processed >> 1 of the chunk.  Returns the region count, -1 on overflow. */
 int64_t orc_pair_pe(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint8_t *ref_string, const uint8_t *enc_qdb,
                     const int64_t *cum_len, int32_t n_pairs, const bwams_alnreg_t *regs, const int64_t *reg_off,
-                    const bwams_pestat_t pes[4], int64_t id_base, int flags, bwams_alnreg_t *out, int64_t out_cap,
+                    const bwams_pestat_t pes[4], int64_t id_base, int flags, int primary5_T, bwams_alnreg_t *out, int64_t out_cap,
                     int64_t *out_off, bwams_pair_t *pairs)
 {
-    const int no_rescue = flags & 1, use_ert = (flags >> 1) & 1;       /* MEM_F_NO_RESCUE; useErt */
+    const int no_rescue = flags & 1, use_ert = (flags >> 1) & 1, no_pairing = (flags >> 2) & 1;
     int64_t n_out = 0;
     for (int p = 0; p < n_pairs; ++p) {
         int n[2], nb[2], i, j;
@@ -379,7 +406,11 @@ int64_t orc_pair_pe(const bwams_mem_opt_t *opt, const orc_bns_t *bns, const uint
         const int64_t id = id_base + p;
         pr->n_pri[0] = orc_mark_primary_se(opt, n[0], a[0], id << 1 | 0);
         pr->n_pri[1] = orc_mark_primary_se(opt, n[1], a[1], id << 1 | 1);
-        if (pr->n_pri[0] && pr->n_pri[1]) {
+        if (primary5_T >= 0) {
+            orc_reorder_primary5(primary5_T, n[0], a[0]);
+            orc_reorder_primary5(primary5_T, n[1], a[1]);
+        }
+        if (!no_pairing && pr->n_pri[0] && pr->n_pri[1]) {
             int sub = 0, n_sub = 0, z[2] = {-1, -1};
             pr->score = pair(opt, bns, pes, a, (int)id, &sub, &n_sub, z, pr->n_pri);
             pr->sub = sub; pr->n_sub = n_sub; pr->z[0] = z[0]; pr->z[1] = z[1];

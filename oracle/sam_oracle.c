@@ -348,6 +348,7 @@ void orc_sam_pe(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const orc
     sbuf_t str[2] = {{out[0], 0, cap[0], 0}, {out[1], 0, cap[1], 0}};
     memset(h, 0, sizeof h); memset(g, 0, sizeof g);
     z[0] = pr->z[0]; z[1] = pr->z[1]; n_pri[0] = pr->n_pri[0]; n_pri[1] = pr->n_pri[1];
+    if (so->flag & BWAMS_MEM_F_NOPAIRING) goto no_pairing;                       /* bwamem_pair.cpp:1066 */
     if (n_pri[0] && n_pri[1] && o > 0) {
         int is_multi[2], q_pe, score_un, q_se[2];
         for (i = 0; i < 2; ++i) {
@@ -419,7 +420,7 @@ no_pairing:
         }
         run_reg2aln(opt, bns, ref_string, l_seq[i], seq[i], which >= 0 ? &regs[i][which] : 0, &h[i]);
     }
-    if (h[0].a.rid == h[1].a.rid && h[0].a.rid >= 0) {
+    if (!(so->flag & BWAMS_MEM_F_NOPAIRING) && h[0].a.rid == h[1].a.rid && h[0].a.rid >= 0) {
         int64_t dist;
         int d = infer_dir_(bns->l_pac, regs[0][0].rb, regs[1][0].rb, &dist);
         if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;

@@ -127,6 +127,9 @@ def test_process_chunk_is_the_stage_sequence():
     for i in range(1, 400, 8):                               # exact copies: the EMF resolves them
         st = int(rng.integers(0, l_pac - reads.shape[1]))
         reads[i] = g[st:st + reads.shape[1]] if i % 16 == 1 else simulate.revcomp(g[st:st + reads.shape[1]])
+    for i in range(2, 400, 16):                              # split reads, the longer part on the right (`mem -5` below)
+        a_, c_ = int(rng.integers(0, l_pac - 150)), int(rng.integers(0, l_pac - 150))
+        reads[i] = np.concatenate([g[a_:a_ + 55], g[c_:c_ + reads.shape[1] - 55]])
     enc, cum = simulate.flatten_reads(reads)
     quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
     names = [b"rd%d" % i for i in range(len(reads))]
@@ -134,6 +137,7 @@ def test_process_chunk_is_the_stage_sequence():
     text = _fastq_of(reads, names, quals, comments)
     b = capi.Batch(ix, len(reads), int(cum[-1]))
     sam, off = b.process_chunk(text, n_processed=1000, copy_comment=True)
+    sam5, _ = b.process_chunk(text, n_processed=1000, sopt=capi.default_sam_opt(0x800 | 0x1000))       # `mem -5`
     sam_nc, _ = b.process_chunk(text, n_processed=1000)                                  # without `-C` the comments are dropped
     o = loader.OracleFMI(idx)
     sm = o.collect_smem(enc, cum)
@@ -141,12 +145,17 @@ def test_process_chunk_is_the_stage_sequence():
     ch, sd, choff = loader.chain_seeds(sm, coord, soff, cum, l_pac)
     regs, reg_off, _ = loader.chain2aln(ch, sd, choff, enc, cum, idx.ref_0123, l_pac)
     fin, fin_off = loader.regs_finish(regs, reg_off, enc, cum, idx.ref_0123, l_pac)
+    fin5 = fin.copy()
     for r in range(len(reads)):
         a, e = int(fin_off[r]), int(fin_off[r + 1])
         if e > a:
+            fin5[a:e] = loader.mark_primary_se(fin[a:e], 1000 + r, primary5_T=30)[0]
             fin[a:e] = loader.mark_primary_se(fin[a:e], 1000 + r)[0]
     want = loader.reg2sam_se(fin, fin_off, enc, cum, idx.ref_0123, l_pac, names, quals=quals, comments=comments, contig_names=[b"chrR"])
     assert sam == b"".join(want) and off[-1] == len(sam)
+    want5 = loader.reg2sam_se(fin5, fin_off, enc, cum, idx.ref_0123, l_pac, names, quals=quals, contig_names=[b"chrR"],
+                              sopt=loader.default_sam_opt(0x800 | 0x1000))
+    assert sam5 == b"".join(want5) and (fin5["rb"] != fin["rb"]).sum() >= 10
     want_nc = loader.reg2sam_se(fin, fin_off, enc, cum, idx.ref_0123, l_pac, names, quals=quals, contig_names=[b"chrR"])
     assert sam_nc == b"".join(want_nc) and sam_nc != sam
     ert = capi.Ert.build(ix, kmer=8, xmer=2, read_len=151, hit_threshold=16)
@@ -178,6 +187,14 @@ def test_process_chunk_is_the_stage_sequence():
     wregs, woff, wpairs = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, c["pes"])
     pwant = loader.sam_pe(wregs, woff, penc, pcum, c["ref"], l_pac, c["pes"], wpairs, pnames, quals=pquals, contig_names=[b"chrR"])
     assert psam == b"".join(pwant)
+    psam_p, _ = b.process_chunk(ptext, paired=True, sopt=capi.default_sam_opt(0x4 | 0x800))            # `mem -P -5` (without -5's MAPQ flag)
+    wregs_p, woff_p, wpairs_p = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, c["pes"], no_pairing=True, primary5_T=30)
+    assert psam_p == b"".join(loader.sam_pe(wregs_p, woff_p, penc, pcum, c["ref"], l_pac, c["pes"], wpairs_p, pnames, quals=pquals,
+                                             contig_names=[b"chrR"], sopt=loader.default_sam_opt(0x4 | 0x800))) and psam_p != psam
+    psam_s, _ = b.process_chunk(ptext, paired=True, sopt=capi.default_sam_opt(0x20))                   # `mem -S` through the options' flag
+    wregs_s, woff_s, wpairs_s = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, c["pes"], no_rescue=True)
+    assert psam_s == b"".join(loader.sam_pe(wregs_s, woff_s, penc, pcum, c["ref"], l_pac, c["pes"], wpairs_s, pnames, quals=pquals,
+                                             contig_names=[b"chrR"], sopt=loader.default_sam_opt(0x20)))
     pes2 = c["pes"].copy(); pes2["low"][1] += 3
     psam2, _ = b.process_chunk(ptext, paired=True, pes=pes2)
     wregs2, woff2, wpairs2 = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, pes2)

@@ -149,22 +149,22 @@ def test_random_configuration(seed):
         # reads the EMF resolved), random text options
         names_c = [b"ctg%d" % i for i in range(sh["n_contigs"])]
         ix.set_contig_names(names_c)
-        sflag = int(rng.choice([0, 0, 0x8, 0x200, 0x10, 0x1000]))
+        sflag = int(rng.choice([0, 0, 0x8, 0x200, 0x10, 0x1000, 0x800, 0x1800]))
         sso, ssg = loader.default_sam_opt(sflag, b"grp" if seed % 2 else b""), capi.default_sam_opt(sflag, b"grp" if seed % 2 else b"")
         sso.T = ssg.T = int(rng.choice([30, 30, 10, 60]))
         sso.max_XA_hits = ssg.max_XA_hits = int(rng.choice([5, 1, 50]))
         quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
         rnames = [b"s%d" % i for i in range(len(reads))]
         comments = [b"c:Z:%d" % i if i % 3 == 0 else None for i in range(len(reads))]
-        b.mark_primary_se(gopt, id_base=seed * 100)
+        b.mark_primary_se(gopt, id_base=seed * 100, sopt=ssg)
         sregs, soff, _ = b.pair_fetch()
         wmark = wfin.copy()
         for r_ in range(len(reads)):
             a_, e_ = int(wfin_off[r_]), int(wfin_off[r_ + 1])
             if e_ > a_:
-                wmark[a_:e_] = loader.mark_primary_se(wfin[a_:e_], seed * 100 + r_, oopt)[0]
+                wmark[a_:e_] = loader.mark_primary_se(wfin[a_:e_], seed * 100 + r_, oopt, primary5_T=int(sso.T) if sflag & 0x800 else -1)[0]
         assert np.array_equal(soff, wfin_off)
-        for f in ("secondary", "secondary_all", "sub", "sub_n", "hash"):
+        for f in ("rb", "qb", "score", "secondary", "secondary_all", "sub", "sub_n", "hash"):
             assert np.array_equal(sregs[f], wmark[f]), f
         b.reg2aln_sam(gopt, ssg, fetch=False)
         b.sam_upload(rnames, quals, comments)
@@ -200,9 +200,20 @@ def test_random_configuration(seed):
                 names_c = [b"ctg%d" % i for i in range(sh["n_contigs"])]
                 ix.set_contig_names(names_c)
                 sflag = int(rng.choice([0, 0, 0x8, 0x200, 0x10, 0x1000]))
+                pflag = int(rng.choice([0, 0, 0x4, 0x800, 0x804, 0x1800, 0x20]))      # `mem -P`, `-5`, `-S`: they act in bwams_pair_run_sam
+                sflag |= pflag
                 sso, ssg = loader.default_sam_opt(sflag, b"rg" if seed % 2 else b""), capi.default_sam_opt(sflag, b"rg" if seed % 2 else b"")
                 sso.T = ssg.T = int(rng.choice([30, 30, 10, 60]))
                 sso.max_XA_hits = ssg.max_XA_hits = int(rng.choice([5, 1, 50]))
+                if pflag:
+                    wout, wout_off, wpairs = loader.pair_pe(wfin, wfin_off, enc, cum, ref, l_pac, wpes, contigs=contigs, opt=oopt, id_base=seed * 1000,
+                                                            no_rescue=bool(pflag & 0x20), no_pairing=bool(pflag & 0x4),
+                                                            primary5_T=int(sso.T) if pflag & 0x800 else -1)
+                    b.pair_run(pes, gopt, id_base=seed * 1000, sopt=ssg)
+                    out, out_off, pairs = b.pair_fetch()
+                    assert np.array_equal(out_off, wout_off) and np.array_equal(pairs, wpairs), pflag
+                    for f in REG_F:
+                        assert np.array_equal(out[f], wout[f]), (pflag, f)
                 quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
                 rnames = [b"p%d" % (i // 2) for i in range(len(reads))]
                 b.reg2aln_sam(gopt, ssg, pes=pes, fetch=False)

@@ -34,7 +34,7 @@ def _gpu_final(ix, reads, gopt, contigs=None):
     return b, enc, cum
 
 
-def _compare(g, ix, reads, pes=None, contigs=None, id_base=0, no_rescue=False, use_ert=False, **kw):
+def _compare(g, ix, reads, pes=None, contigs=None, id_base=0, no_rescue=False, use_ert=False, sflag=0, T=30, **kw):
     oopt, gopt = loader.default_mem_opt(), capi.default_mem_opt()
     for k, v in kw.items():
         setattr(oopt, k, v)
@@ -52,8 +52,13 @@ def _compare(g, ix, reads, pes=None, contigs=None, id_base=0, no_rescue=False, u
         assert np.array_equal(keys, np.sort(loader.pestat_keys(fin, fin_off, l_pac, opt=oopt)))
         assert np.array_equal(capi.pestat_from_keys(keys[::-1]), pes)
     want_regs, want_off, want_pairs = loader.pair_pe(fin, fin_off, enc, cum, ref, l_pac, pes, contigs=contigs, opt=oopt,
-                                                     id_base=id_base, no_rescue=no_rescue, use_ert=use_ert)
-    n, n_tasks = b.pair_run(pes, gopt, id_base=id_base, no_rescue=no_rescue, use_ert=use_ert)
+                                                     id_base=id_base, no_rescue=no_rescue or bool(sflag & 0x20), use_ert=use_ert,
+                                                     no_pairing=bool(sflag & 0x4), primary5_T=T if sflag & 0x800 else -1)
+    sopt = None
+    if sflag:
+        sopt = capi.default_sam_opt(sflag)
+        sopt.T = T
+    n, n_tasks = b.pair_run(pes, gopt, id_base=id_base, no_rescue=no_rescue, use_ert=use_ert, sopt=sopt)
     regs, off, pairs = b.pair_fetch()
     assert n == len(want_regs) and np.array_equal(off, want_off)
     for f in ("score", "sub", "n_sub", "z", "n_pri", "n_matesw"):
@@ -93,6 +98,38 @@ def test_pair_no_rescue_and_few_anchors(pe_toy):
     r = _compare(g, ix, reads, no_rescue=True)
     assert r["n_tasks"] == 0 and r["pairs"]["n_matesw"].sum() == 0
     _compare(g, ix, reads, max_matesw=1, pen_unpaired=3)
+
+
+def _chimeric(g, reads, seed, every=3, left=55):
+    """Every `every`-th read becomes a split read: `left` bases of one place, then the rest from another — the longer,
+    higher-scoring part on the right, so the primary hit is not the leftmost (what mem_reorder_primary5 looks for)."""
+    rng = np.random.default_rng(seed)
+    reads = [np.array(r, copy=True) for r in reads]
+    n_made = 0
+    for i in range(0, len(reads), every):
+        L = len(reads[i])
+        a, c = int(rng.integers(0, len(g) - L)), int(rng.integers(0, len(g) - L))
+        rd = np.concatenate([g[a:a + left], g[c:c + L - left]]).astype(np.uint8)
+        reads[i] = (3 - rd[::-1]).astype(np.uint8) if rng.random() < 0.5 else rd
+        n_made += 1
+    return reads, n_made
+
+
+def test_pair_primary5_nopairing_norescue_flags(pe_toy):
+    """bwams_pair_run_sam: `mem -5` (mem_reorder_primary5 between the marking and mem_pair), `mem -P` (no mem_pair), `mem -S`."""
+    g, idx, ix = pe_toy
+    reads, n_made = _chimeric(g, simulate.make_read_pairs(g, 600, seed=31), seed=32)
+    base = _compare(g, ix, reads)
+    r5 = _compare(g, ix, reads, sflag=0x800)
+    moved = (base["regs"]["rb"] != r5["regs"]["rb"]).sum()
+    assert moved >= n_made // 2, (moved, n_made)          # a reverse-complemented split read has its long part on the left already
+    assert np.array_equal(np.sort(base["regs"]["hash"]), np.sort(r5["regs"]["hash"]))       # the same regions, another order
+    rp = _compare(g, ix, reads, pes=base["pes"], sflag=0x4)
+    assert (rp["pairs"]["score"] == 0).all() and (rp["pairs"]["z"] == -1).all() and np.array_equal(rp["pairs"]["n_pri"], base["pairs"]["n_pri"])
+    rs = _compare(g, ix, reads, pes=base["pes"], sflag=0x20 | 0x800, T=20)
+    assert rs["n_tasks"] == 0
+    _compare(g, ix, reads, pes=base["pes"], sflag=0x800, T=200)                              # nothing scores >= T: no reorder
+    _compare(g, ix, reads, pes=base["pes"], sflag=0x800 | 0x4, use_ert=True)
 
 
 def test_pair_degenerate(pe_toy):

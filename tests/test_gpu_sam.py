@@ -10,7 +10,7 @@ from test_oracle_sam import repeat_genome
 pytestmark = pytest.mark.gpu
 
 
-def _pipeline(n_reads, seed, contigs=None, contig_names=None, read_len=None, **optkw):
+def _pipeline(n_reads, seed, contigs=None, contig_names=None, read_len=None, split_every=0, mark_flag=0, **optkw):
     g, idx, starts = repeat_genome()
     oopt, gopt = loader.default_mem_opt(), capi.default_mem_opt()
     for k, v in optkw.items():
@@ -22,6 +22,10 @@ def _pipeline(n_reads, seed, contigs=None, contig_names=None, read_len=None, **o
         rd = g[st:st + reads.shape[1]].copy()
         reads[i] = (3 - rd[::-1]).astype(np.uint8) if rng.random() < 0.5 else rd
     reads = [r for r in reads]
+    for i in (range(1, n_reads, split_every) if split_every else ()):  # split reads: 55 bases of one place, the rest from another
+        a_, c_ = int(rng.integers(0, len(g) - 150)), int(rng.integers(0, len(g) - 150))
+        rd = np.concatenate([g[a_:a_ + 55], g[c_:c_ + len(reads[i]) - 55]]).astype(np.uint8)
+        reads[i] = (3 - rd[::-1]).astype(np.uint8) if rng.random() < 0.5 else rd
     reads[5] = rng.integers(0, 4, size=150, dtype=np.uint8)            # unalignable
     reads[6] = np.full(150, 4, np.uint8)                               # all N
     ix = capi.Index.from_host(idx, 0)
@@ -35,8 +39,17 @@ def _pipeline(n_reads, seed, contigs=None, contig_names=None, read_len=None, **o
     b.seed_run(capi.default_seed_opt(), with_sa=True)
     b.chain_run(gopt); b.extend_run(gopt); b.dedup_run(gopt)
     ID0 = 77_000
-    b.mark_primary_se(gopt, id_base=ID0)
+    b.mark_primary_se(gopt, id_base=ID0, sopt=capi.default_sam_opt(mark_flag) if mark_flag else None)
     regs, off, _ = b.pair_fetch()
+    if mark_flag & 0x800:                                              # mem_reorder_primary5 after the marking (bwamem.cpp:1840)
+        fin, fin_off = b.dedup_fetch()
+        n_moved = 0
+        for r in range(len(reads)):
+            w, _ = loader.mark_primary_se(fin[fin_off[r]:fin_off[r + 1]], ID0 + r, oopt, primary5_T=30)
+            w0, _ = loader.mark_primary_se(fin[fin_off[r]:fin_off[r + 1]], ID0 + r, oopt)
+            n_moved += int(not np.array_equal(w, w0))
+            assert np.array_equal(regs[off[r]:off[r + 1]], w), r
+        assert n_moved >= n_reads // (split_every or n_reads) // 4, n_moved
     aln, cig, md = b.reg2aln(gopt, 1)
     quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
     names = [b"r%d/x" % i for i in range(len(reads))]
@@ -96,12 +109,25 @@ def test_sam_text_contigs_alt_and_scoring():
     c["b"].close(); c["ix"].close()
 
 
+def test_sam_text_primary5():
+    """`mem -5` (MEM_F_PRIMARY5 | MEM_F_KEEP_SUPP_MAPQ): the leftmost primary hit of a split read leads its records."""
+    c0 = _pipeline(600, 21, split_every=4)
+    t0 = _compare(c0, 0x1000)
+    c0["b"].close(); c0["ix"].close()
+    c = _pipeline(600, 21, split_every=4, mark_flag=0x800)
+    t5 = _compare(c, 0x800 | 0x1000)
+    assert t5 != t0 and t5.count(b"\tSA:Z:") == t0.count(b"\tSA:Z:") > 100
+    _compare(c, 0x800)
+    _compare(c, 0x800 | 0x8 | 0x200)
+    c["b"].close(); c["ix"].close()
+
+
 def test_sam_text_call_order_and_unsupported_flags():
     c = _pipeline(64, 3)
     b = c["b"]
     b.sam_upload(c["names"], c["quals"])
     with pytest.raises(capi.BwamsError):
-        b.sam_run(c["gopt"], capi.default_sam_opt(0x800))            # MEM_F_PRIMARY5
+        b.sam_run(c["gopt"], capi.default_sam_opt(0x100))            # MEM_F_REF_HDR
     b.dedup_run(c["gopt"])
     b.reg2aln(c["gopt"], 0)                                          # regions without mem_mark_primary_se
     with pytest.raises(capi.BwamsError):
@@ -109,7 +135,7 @@ def test_sam_text_call_order_and_unsupported_flags():
     b.close(); c["ix"].close()
 
 
-def _pe_pipeline(n_pairs, seed, **optkw):
+def _pe_pipeline(n_pairs, seed, pair_flag=0, **optkw):
     g, idx, starts = repeat_genome()
     oopt, gopt = loader.default_mem_opt(), capi.default_mem_opt()
     for k, v in optkw.items():
@@ -124,6 +150,11 @@ def _pe_pipeline(n_pairs, seed, **optkw):
         if bpos + L <= len(g):
             reads[2 * p] = g[a:a + L]
             reads[2 * p + 1] = (3 - g[bpos:bpos + L][::-1]).astype(np.uint8)
+    if pair_flag & 0x800:
+        for i in range(2, len(reads), 14):                             # split reads for mem_reorder_primary5 (few: mem_pestat sees them)
+            a_, c_ = int(rng.integers(0, len(g) - 150)), int(rng.integers(0, len(g) - 150))
+            rd = np.concatenate([g[a_:a_ + 55], g[c_:c_ + reads.shape[1] - 55]]).astype(np.uint8)
+            reads[i] = (3 - rd[::-1]).astype(np.uint8) if rng.random() < 0.5 else rd
     reads[8] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8)          # one end unalignable
     reads[20] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8); reads[21] = rng.integers(0, 4, size=reads.shape[1], dtype=np.uint8)
     ix = capi.Index.from_host(idx, 0)
@@ -134,7 +165,7 @@ def _pe_pipeline(n_pairs, seed, **optkw):
     b.seed_run(capi.default_seed_opt(), with_sa=True)
     b.chain_run(gopt); b.extend_run(gopt); b.dedup_run(gopt)
     pes = b.pestat(gopt)
-    b.pair_run(pes, gopt, id_base=0)
+    b.pair_run(pes, gopt, id_base=0, sopt=capi.default_sam_opt(pair_flag) if pair_flag else None)
     regs, off, pairs = b.pair_fetch()
     b.reg2aln(gopt, 1)
     quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
@@ -182,6 +213,23 @@ def test_paired_end_sam_text_equals_oracle():
     c["b"].close(); c["ix"].close()
     c = _pe_pipeline(300, 23, a=2, b=5, pen_unpaired=9, mapq_coef_len=0)
     _compare_pe(c)
+    c["b"].close(); c["ix"].close()
+
+
+def test_paired_end_sam_text_nopairing_and_primary5():
+    """`mem -P`: no mem_pair, and mem_sam_pe's unpaired branch does not flag proper pairs (bwamem_pair.cpp:1066, :1176);
+    `mem -5`: the reordered lists through the paired-end text."""
+    c = _pe_pipeline(300, 29, pair_flag=0x4)
+    assert (c["pairs"]["score"] == 0).all()
+    text, _ = _compare_pe(c, 0x4)
+    flags = np.array([int(ln.split(b"\t")[1]) for ln in text.split(b"\n")[:-1]])
+    assert (flags & 2).sum() == 0 and (flags & 1).all()
+    t2, _ = _compare_pe(c, 0)                                   # the same regions without the flag in the text: proper pairs are flagged
+    assert (np.array([int(ln.split(b"\t")[1]) for ln in t2.split(b"\n")[:-1]]) & 2).sum() > 300
+    c["b"].close(); c["ix"].close()
+    c = _pe_pipeline(300, 31, pair_flag=0x800)
+    text, _ = _compare_pe(c, 0x800 | 0x1000)
+    assert text.count(b"\tSA:Z:") > 20
     c["b"].close(); c["ix"].close()
 
 

@@ -68,6 +68,45 @@ def test_mark_primary_se_constructed():
     assert out["sub_n"].tolist() == [2, 0, 0, 0]
 
 
+def test_reorder_primary5_constructed():
+    """mem_reorder_primary5 (bwamem.cpp:2009-2031) on hand-made marked lists: the leftmost primary non-ALT hit scoring >= T comes
+    first, references to the two swapped places follow, everything else stays."""
+    regs = np.zeros(6, loader.ALNREG_DTYPE)
+    #            primary  sec of 0  primary(left)  sec of 2  weak left   ALT left
+    regs["qb"] = [80,      85,       0,             5,        0,          0]
+    regs["qe"] = [150,     150,      70,            70,       20,         60]
+    regs["score"] = [70,   60,       65,            50,       20,         90]
+    regs["secondary"] = [-1, 0, -1, 2, -1, -1]
+    regs["secondary_all"] = [-1, 0, -1, 2, -1, 0]
+    regs["n_comp_is_alt"] = [1, 1, 1, 1, 1, 1 | (1 << 30)]
+    regs["rb"] = np.arange(6) * 1000
+    out = loader.reorder_primary5(regs, 30)
+    assert out["rb"].tolist() == [2000, 1000, 0, 3000, 4000, 5000]       # places 0 and 2 swapped (the weak hit at qb 0 scores < T)
+    assert out["secondary"].tolist() == [-1, 2, -1, 0, -1, -1]
+    assert out["secondary_all"].tolist() == [-1, 2, -1, 0, -1, 2]
+    assert np.array_equal(loader.reorder_primary5(out, 30), out)         # the leftmost is first now: nothing to do
+    # T above every other hit: a single candidate, untouched; T = 0: the weak hit at qb 0 ties with place 2, the first of equals wins
+    assert np.array_equal(loader.reorder_primary5(regs, 66), regs)
+    assert loader.reorder_primary5(regs, 0)["rb"].tolist() == [2000, 1000, 0, 3000, 4000, 5000]
+    one = regs[:2].copy()
+    assert np.array_equal(loader.reorder_primary5(one, 30), one)
+    assert len(loader.reorder_primary5(regs[:0], 30)) == 0
+
+
+def test_pair_primary5_and_nopairing_in_the_driver():
+    g, idx, reads, c = _chunk(200, seed=9, damaged_frac=0.0, discordant_frac=0.0)
+    base = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], c["pes"])
+    nop = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], c["pes"], no_pairing=True)
+    assert np.array_equal(nop[0], base[0]) and np.array_equal(nop[2]["n_pri"], base[2]["n_pri"])
+    assert (nop[2]["score"] == 0).all() and (nop[2]["z"] == -1).all() and (base[2]["score"] > 0).any()
+    p5 = loader.pair_pe(c["regs"], c["reg_off"], c["enc"], c["cum"], c["ref"], c["l_pac"], c["pes"], primary5_T=30)
+    want = base[0].copy()
+    for r in range(len(base[1]) - 1):
+        a, e = base[1][r], base[1][r + 1]
+        want[a:e] = loader.reorder_primary5(base[0][a:e], 30)
+    assert np.array_equal(p5[0], want) and np.array_equal(p5[1], base[1])
+
+
 def test_pair_scores_follow_the_insert_size_model():
     g, idx, reads, c = _chunk(200, seed=9, damaged_frac=0.0, discordant_frac=0.0)
     pes = c["pes"].copy()

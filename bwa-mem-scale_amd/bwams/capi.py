@@ -26,7 +26,7 @@ SYMBOLS = [
     "bwams_strerror", "bwams_last_error", "bwams_device_count",
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_run_sam", "bwams_reg2aln_fetch",
-    "bwams_index_set_contig_names", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
+    "bwams_index_set_contig_names", "bwams_index_set_contig_annos", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
     "bwams_process_chunk", "bwams_emf_regs_merge", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
@@ -429,6 +429,16 @@ class Index:
         off.append(len(blob))
         off = np.asarray(off, np.int32)
         _chk(lib().bwams_index_set_contig_names(self.h, bytes(blob), _p(off)), "bwams_index_set_contig_names")
+
+    def set_contig_annos(self, annos):
+        """bntann1_t.anno of every sequence (b"" = none): the XR:Z: tags of MEM_F_REF_HDR (0x100)."""
+        blob, off = bytearray(), []
+        for a in annos:
+            off.append(len(blob))
+            blob += (a if isinstance(a, bytes) else a.encode()) + b"\0"
+        off.append(len(blob))
+        off = np.asarray(off, np.int32)
+        _chk(lib().bwams_index_set_contig_annos(self.h, bytes(blob), _p(off)), "bwams_index_set_contig_annos")
 
     def debug_sort(self, k, s, q, which: int, mode: int = 0):
         """order of the wave tier's region sort (test hook)"""

@@ -353,6 +353,10 @@ int bwams_index_close(bwams_index_t *ix) {
         (void)hipSetDevice(ix->device);
         (void)hipFree(ix->d_contigs);
     }
+    if (ix->d_ctg_annos) {
+        (void)hipFree(ix->d_ctg_annos);
+        (void)hipFree(ix->d_ctg_anno_off);
+    }
     if (ix->d_ctg_names) {
         (void)hipSetDevice(ix->device);
         (void)hipFree(ix->d_ctg_names);

@@ -1197,6 +1197,26 @@ int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int
     return BWAMS_OK;
 }
 
+int bwams_index_set_contig_annos(bwams_index_t *ix, const char *annos, const int32_t *anno_off) {
+    if (!ix || !annos || !anno_off) return BWAMS_ERR_ARG;
+    DevBns bns;
+    int rc = dev_bns(ix, &bns);
+    if (rc) return rc;
+    const int32_t n = ix->n_seqs;
+    for (int32_t i = 0; i < n; ++i)
+        if (anno_off[i] < 0 || anno_off[i + 1] <= anno_off[i] || annos[anno_off[i + 1] - 1] != 0) {
+            set_last_error("bwams_index_set_contig_annos: annotations must be NUL-terminated, back to back, anno_off[n_seqs + 1] ascending");
+            return BWAMS_ERR_ARG;
+        }
+    BWAMS_HIP(hipSetDevice(ix->device));
+    if (ix->d_ctg_annos) { (void)hipFree(ix->d_ctg_annos); (void)hipFree(ix->d_ctg_anno_off); ix->d_ctg_annos = ix->d_ctg_anno_off = nullptr; }
+    BWAMS_HIP(hipMalloc(&ix->d_ctg_annos, (size_t)anno_off[n]));
+    BWAMS_HIP(hipMalloc(&ix->d_ctg_anno_off, (size_t)(n + 1) * 4));
+    BWAMS_HIP(hipMemcpy(ix->d_ctg_annos, annos, (size_t)anno_off[n], hipMemcpyHostToDevice));
+    BWAMS_HIP(hipMemcpy(ix->d_ctg_anno_off, anno_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    return BWAMS_OK;
+}
+
 int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_off, const char *quals, const char *comments,
                      const int64_t *comment_off) {
     if (!b || !names || !name_off || (comments && !comment_off)) {
@@ -1262,9 +1282,13 @@ static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwam
     if (rc) return rc;
     // MEM_F_PRIMARY5 / MEM_F_NO_RESCUE act in bwams_pair_run_sam, before the text; MEM_F_NOPAIRING there and in the proper-pair flag
     if (sopt->flag & ~(BWAMS_MEM_F_ALL | BWAMS_MEM_F_NO_MULTI | BWAMS_MEM_F_SOFTCLIP | BWAMS_MEM_F_KEEP_SUPP_MAPQ | BWAMS_MEM_F_PRIMARY5 |
-                       BWAMS_MEM_F_NOPAIRING | BWAMS_MEM_F_NO_RESCUE)) {
-        set_last_error("bwams_sam_run: MEM_F_REF_HDR (XR tags from the .ann annotations), MEM_F_PE / MEM_F_SMARTPE (the caller's) and MEM_F_XB are not built");
+                       BWAMS_MEM_F_NOPAIRING | BWAMS_MEM_F_NO_RESCUE | BWAMS_MEM_F_REF_HDR)) {
+        set_last_error("bwams_sam_run: MEM_F_PE / MEM_F_SMARTPE (the caller's business) and MEM_F_XB are not built");
         return BWAMS_ERR_UNSUPPORTED;
+    }
+    if ((sopt->flag & BWAMS_MEM_F_REF_HDR) && !b->idx->d_ctg_annos) {
+        set_last_error("bwams_sam_run: MEM_F_REF_HDR needs the sequences' annotations (bwams_index_set_contig_annos)");
+        return BWAMS_ERR_ARG;
     }
     if (!memchr(sopt->rg_id, 0, sizeof sopt->rg_id)) return BWAMS_ERR_ARG;
     BWAMS_HIP(hipSetDevice(b->idx->device));
@@ -1295,6 +1319,8 @@ static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwam
     A.comment_off = s->sm_has_comm ? s->sm_coff.as<int64_t>() : nullptr;
     A.ctg_names = reinterpret_cast<const char *>(b->idx->d_ctg_names);
     A.ctg_off = reinterpret_cast<const int32_t *>(b->idx->d_ctg_off);
+    A.ctg_annos = reinterpret_cast<const char *>(b->idx->d_ctg_annos);
+    A.ctg_anno_off = reinterpret_cast<const int32_t *>(b->idx->d_ctg_anno_off);
     A.opt = *opt; A.sopt = *sopt;
     A.logtab = s->sm_logtab.as<double>(); A.logtab_n = kLogN;
     A.coef_fac = opt->mapq_coef_len > 0 ? log((double)opt->mapq_coef_len) : 0.;

@@ -269,6 +269,8 @@ struct SamArgs {
     const int64_t *comment_off;
     const char *ctg_names;         // NUL-terminated sequence names back to back, ctg_off[rid]
     const int32_t *ctg_off;
+    const char *ctg_annos;         // MEM_F_REF_HDR: bntann1_t.anno of every sequence, NUL-terminated back to back, ctg_anno_off[rid]
+    const int32_t *ctg_anno_off;
     bwams_mem_opt_t opt;
     bwams_sam_opt_t sopt;
     const double *logtab;          // log(i) from the host's C library

@@ -136,6 +136,7 @@ struct bwams_index {
     void *d_all = nullptr, *d_last = nullptr;    // FMA tables (owned)
     void *d_contigs = nullptr;                   // bwams_contig_t[n_seqs] (owned); null = one sequence [0, l_pac)
     int32_t n_seqs = 0;
+    void *d_ctg_annos = nullptr, *d_ctg_anno_off = nullptr;   // bntann1_t.anno for MEM_F_REF_HDR (bwams_index_set_contig_annos)
     void *d_ctg_names = nullptr, *d_ctg_off = nullptr;   // sequence names for the SAM text (bwams_index_set_contig_names)
 };
 

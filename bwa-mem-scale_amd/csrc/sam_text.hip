@@ -215,6 +215,15 @@ struct RecInfo {
     bool xa;            // the record carries its region's XA string
 };
 
+// the XR tag of MEM_F_REF_HDR (bwamem.cpp:2522-2529, :2218-2225): the sequence's annotation, TABs as blanks
+__device__ __forceinline__ void put_xr(const SamArgs &A, Writer &W, int rid) {
+    if (!(A.sopt.flag & BWAMS_MEM_F_REF_HDR) || rid < 0) return;
+    const char *a = A.ctg_annos + A.ctg_anno_off[rid];
+    if (!a[0]) return;
+    W.s("\tXR:Z:", 6);
+    for (; *a; ++a) W.c(*a == '\t' ? ' ' : *a);
+}
+
 // mem_aln2sam (bwamem.cpp:2393-2531)
 __device__ void put_record(const SamArgs &A, const Read &R, Writer &W, const RecInfo &I, const Mate &M_, int mapq0) {
     bwams_aln_t t;
@@ -329,6 +338,7 @@ __device__ void put_record(const SamArgs &A, const Read &R, Writer &W, const Rec
     }
     if (k >= 0 && I.xa) put_xa(A, R, W, k, true);
     if (R.l_comment) { W.c('\t'); W.s(R.comment, R.l_comment); }
+    put_xr(A, W, t.rid);
     W.c('\n');
 }
 
@@ -501,6 +511,7 @@ __device__ void put_perfect(const SamArgs &A, const Read &R, Writer &W, const bw
             if (!secondary) { W.s("\tXS:i:", 6); W.num((k == 0 && n > 1) ? (long long)R.l_seq * A.opt.a : 0); }
             if (A.sopt.rg_id[0]) { W.s("\tRG:Z:", 6); W.z(A.sopt.rg_id); }
             if (R.l_comment) { W.c('\t'); W.s(R.comment, R.l_comment); }
+            put_xr(A, W, r.rid);
             W.c('\n');
             ++n_out;
             if (!all) break;

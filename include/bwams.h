@@ -243,6 +243,9 @@ int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uin
 /* names of the index's sequences (bntann1_t.name): NUL-terminated, back to back; name_off[n_seqs + 1], name_off[i] = start of
  * name i.  Call after bwams_index_set_contigs (or on a one-sequence index). */
 int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int32_t *name_off);
+/* bntann1_t.anno of the index's sequences, laid out like the names (an empty string = no annotation): what MEM_F_REF_HDR (`mem -V`)
+ * prints as XR:Z: (src/bwamem.cpp:2522-2529, :2218-2225).  A text run with that flag and no annotations set is refused. */
+int bwams_index_set_contig_annos(bwams_index_t *ix, const char *annos, const int32_t *anno_off);
 /* names: the reads' names back to back (no terminators), name_off[nseq + 1]; quals: one byte per base laid out like the reads
  * (cum_len), or NULL ('*'); comments (+ comment_off[nseq + 1], an empty comment = none) or NULL. */
 int bwams_sam_upload(bwams_batch_t *b, const char *names, const int64_t *name_off, const char *quals, const char *comments,

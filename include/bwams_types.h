@@ -226,6 +226,7 @@ typedef struct bwams_aln {
 #define BWAMS_MEM_F_ALL            0x8
 #define BWAMS_MEM_F_NO_MULTI       0x10
 #define BWAMS_MEM_F_NO_RESCUE      0x20     /* bwams_pair_run_sam */
+#define BWAMS_MEM_F_REF_HDR        0x100    /* XR:Z:<annotation> on every record (bwams_index_set_contig_annos first) */
 #define BWAMS_MEM_F_SOFTCLIP       0x200
 #define BWAMS_MEM_F_PRIMARY5       0x800    /* bwams_pair_run_sam (the text itself does not read it) */
 #define BWAMS_MEM_F_KEEP_SUPP_MAPQ 0x1000

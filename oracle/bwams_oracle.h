@@ -167,6 +167,7 @@ int orc_reg2aln(const bwams_mem_opt_t *opt, const struct orc_bns *bns, const uin
                 const bwams_alnreg_t *ar, bwams_aln_t *a, uint32_t *cigar, char *md);
 /* single-end SAM text (sam_oracle.c): mem_reg2sam + mem_gen_alt + mem_aln2sam for one read (PARITY UNPINNED).  ctg_names:
  * NUL-terminated names back to back, ctg_off[rid] = start of a name.  Returns the text length, or -1 - length if cap was short. */
+void orc_set_contig_annos(const char *annos, const int32_t *anno_off);      /* MEM_F_REF_HDR: bntann1_t.anno table, NULL = none */
 int64_t orc_reg2sam_se(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const struct orc_bns *bns, const char *ctg_names,
                        const int32_t *ctg_off, const uint8_t *ref_string, int l_seq, const uint8_t *seq, const char *qual,
                        const char *name, const char *comment, const bwams_alnreg_t *regs, int n_regs, char *out, int64_t cap);

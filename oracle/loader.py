@@ -8,6 +8,7 @@ prebuilt files).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -672,6 +673,19 @@ def contig_name_table(names):
         blob += (nm if isinstance(nm, bytes) else nm.encode()) + b"\0"
     off.append(len(blob))
     return bytes(blob), np.asarray(off, np.int32)
+
+
+@contextlib.contextmanager
+def contig_annos(annos):
+    """Within the block the SAM restatement knows the sequences' annotations (bntann1_t.anno, b"" = none): MEM_F_REF_HDR's XR tags."""
+    blob, off = contig_name_table(annos)
+    f = lib().orc_set_contig_annos
+    f.restype = None
+    f(blob, _p(off))
+    try:
+        yield
+    finally:
+        f(None, None)
 
 
 def reg2sam_se(regs, reg_off, enc, cum, ref_string, l_pac, names, quals=None, comments=None, contigs=None, contig_names=None,

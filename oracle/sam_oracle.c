@@ -115,6 +115,21 @@ static int get_rlen(int n_cigar, const uint32_t *cigar)            /* bwamem.cpp
 }
 
 /* mem_aln2sam; m_ = the mate's record or NULL */
+/* bntann1_t.anno per sequence for MEM_F_REF_HDR, laid out like the names; set by the test before a call (NULL = none). */
+static const char *g_annos;
+static const int32_t *g_anno_off;
+void orc_set_contig_annos(const char *annos, const int32_t *anno_off) { g_annos = annos; g_anno_off = anno_off; }
+
+static void put_xr(const bwams_sam_opt_t *so, sbuf_t *str, int rid)             /* bwamem.cpp:2522-2529, :2218-2225 */
+{
+    const char *a;
+    if (!(so->flag & BWAMS_MEM_F_REF_HDR) || rid < 0 || !g_annos) return;
+    a = g_annos + g_anno_off[rid];
+    if (!a[0]) return;
+    sputsn(str, "\tXR:Z:", 6);
+    for (; *a; ++a) sputc(str, *a == '\t' ? ' ' : *a);
+}
+
 static void aln2sam(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const orc_bns_t *bns, const char *ctg_names,
                     const int32_t *ctg_off, const uint8_t *ref_string, sbuf_t *str, int l_seq, const uint8_t *seq, const char *qual,
                     const char *name, const char *comment, int n, const aln_t *list, int which, const bwams_alnreg_t *regs, int n_regs,
@@ -215,6 +230,7 @@ static void aln2sam(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, const
         }
     }
     if (comment) { sputc(str, '\t'); sputs(str, comment); }
+    put_xr(so, str, p->a.rid);
     sputc(str, '\n');
 }
 
@@ -315,6 +331,7 @@ int64_t orc_perfect2sam(const bwams_mem_opt_t *opt, const bwams_sam_opt_t *so, c
             if (!secondary) { sputsn(&str, "\tXS:i:", 6); sputl(&str, (k == 0 && n > 1) ? l_seq * opt->a : 0); }
             if (so->rg_id[0]) { sputsn(&str, "\tRG:Z:", 6); sputs(&str, so->rg_id); }
             if (comment) { sputc(&str, '\t'); sputs(&str, comment); }
+            put_xr(so, &str, r->rid);
             sputc(&str, '\n');
             ++n_out;
             if (!(so->flag & BWAMS_MEM_F_ALL)) break;

@@ -58,17 +58,21 @@ def _pipeline(n_reads, seed, contigs=None, contig_names=None, read_len=None, spl
                 oopt=oopt, gopt=gopt, contigs=contigs, contig_names=names_c)
 
 
-def _compare(c, flag=0, rg=b"", quals=True, comments=True, T=None):
+def _compare(c, flag=0, rg=b"", quals=True, comments=True, T=None, annos=None):
+    import contextlib
     b = c["b"]
+    if annos is not None:
+        c["ix"].set_contig_annos(annos)
     so, sg = loader.default_sam_opt(flag, rg), capi.default_sam_opt(flag, rg)
     if T is not None:
         so.T = sg.T = T
     b.sam_upload(c["names"], c["quals"] if quals else None, c["comments"] if comments else None)
     nbytes = b.sam_run(c["gopt"], sg)
     text, roff, mq = b.sam_fetch(len(c["regs"]))
-    want = loader.reg2sam_se(c["regs"], c["off"], c["enc"], c["cum"], c["idx"].ref_0123, len(c["g"]), c["names"],
-                             quals=c["quals"] if quals else None, comments=c["comments"] if comments else None, contigs=c["contigs"],
-                             contig_names=c["contig_names"], opt=c["oopt"], sopt=so)
+    with (loader.contig_annos(annos) if annos is not None else contextlib.nullcontext()):
+        want = loader.reg2sam_se(c["regs"], c["off"], c["enc"], c["cum"], c["idx"].ref_0123, len(c["g"]), c["names"],
+                                 quals=c["quals"] if quals else None, comments=c["comments"] if comments else None, contigs=c["contigs"],
+                                 contig_names=c["contig_names"], opt=c["oopt"], sopt=so)
     assert nbytes == sum(len(w) for w in want) == roff[-1] and roff[0] == 0
     for r, w in enumerate(want):
         got = text[roff[r]:roff[r + 1]]
@@ -103,6 +107,12 @@ def test_sam_text_contigs_alt_and_scoring():
     text = _compare(c)
     assert b"chrB_alt" in text and b"\tpa:f:" in text
     _compare(c, 0x8)
+    with pytest.raises(capi.BwamsError, match="annotations"):
+        c["b"].sam_run(c["gopt"], capi.default_sam_opt(0x100))        # `mem -V` before the annotations are known
+    tv = _compare(c, 0x100, annos=[b"first half\tof the toy", b"", b"alternate locus"])          # MEM_F_REF_HDR
+    assert tv.count(b"\tXR:Z:first half of the toy\n") > 100 and tv.count(b"\tXR:Z:alternate locus\n") > 10
+    assert b"XR:Z:\n" not in tv and sum(b"XR:Z:" not in ln for ln in tv.split(b"\n")[:-1]) > 50      # chrB_longer_name has none
+    assert b"XR:Z:" not in _compare(c, 0x8, annos=[b"a", b"b", b"c"])
     c["b"].close(); c["ix"].close()
     c = _pipeline(500, 13, a=2, b=5, o_del=7, e_del=2, mapq_coef_len=0)
     _compare(c)
@@ -127,7 +137,9 @@ def test_sam_text_call_order_and_unsupported_flags():
     b = c["b"]
     b.sam_upload(c["names"], c["quals"])
     with pytest.raises(capi.BwamsError):
-        b.sam_run(c["gopt"], capi.default_sam_opt(0x100))            # MEM_F_REF_HDR
+        b.sam_run(c["gopt"], capi.default_sam_opt(0x2000))           # MEM_F_XB
+    with pytest.raises(capi.BwamsError):
+        b.sam_run(c["gopt"], capi.default_sam_opt(0x2))              # MEM_F_PE is the caller's
     b.dedup_run(c["gopt"])
     b.reg2aln(c["gopt"], 0)                                          # regions without mem_mark_primary_se
     with pytest.raises(capi.BwamsError):
@@ -175,16 +187,20 @@ def _pe_pipeline(n_pairs, seed, pair_flag=0, **optkw):
                 comments=comments, oopt=oopt, gopt=gopt)
 
 
-def _compare_pe(c, flag=0, rg=b"", T=None):
+def _compare_pe(c, flag=0, rg=b"", T=None, annos=None):
+    import contextlib
     b = c["b"]
+    if annos is not None:
+        c["ix"].set_contig_annos(annos)
     so, sg = loader.default_sam_opt(flag, rg), capi.default_sam_opt(flag, rg)
     if T is not None:
         so.T = sg.T = T
     b.sam_upload(c["names"], c["quals"], c["comments"])
     nbytes = b.sam_run_pe(c["pes"], c["gopt"], sg)
     text, roff, _ = b.sam_fetch()
-    want = loader.sam_pe(c["regs"], c["off"], c["enc"], c["cum"], c["idx"].ref_0123, len(c["g"]), c["pes"], c["pairs"], c["names"],
-                         quals=c["quals"], comments=c["comments"], contig_names=[b"chr1"], opt=c["oopt"], sopt=so)
+    with (loader.contig_annos(annos) if annos is not None else contextlib.nullcontext()):
+        want = loader.sam_pe(c["regs"], c["off"], c["enc"], c["cum"], c["idx"].ref_0123, len(c["g"]), c["pes"], c["pairs"], c["names"],
+                             quals=c["quals"], comments=c["comments"], contig_names=[b"chr1"], opt=c["oopt"], sopt=so)
     assert nbytes == sum(len(w) for w in want) == roff[-1]
     for r, w in enumerate(want):
         got = text[roff[r]:roff[r + 1]]
@@ -204,6 +220,9 @@ def test_paired_end_sam_text_equals_oracle():
     assert (pr["score"] > 0).sum() > 300 and (pr["score"] == 0).sum() >= 1
     for flag, rg, T in ((0x8, b"rg1", None), (0x200 | 0x10, b"", None), (0, b"", 60)):
         _compare_pe(c, flag, rg, T)
+    tv, _ = _compare_pe(c, 0x100, annos=[b"AC:1  LN:x\tM5:y"])     # `mem -V`: an unmapped end placed at its mate carries the tag, an unmapped pair not
+    nl = tv.count(b"\n")
+    assert nl - 10 < tv.count(b"\tXR:Z:AC:1  LN:x M5:y\n") < nl
     with pytest.raises(capi.BwamsError):
         c["b"].sam_run(c["gopt"], capi.default_sam_opt())              # the single-end form refuses a paired-end chunk
     bad_names = list(c["names"]); bad_names[7] = b"other"
@@ -286,25 +305,30 @@ def test_exact_match_records_equal_oracle(L):
     comments = [b"X:Z:%d" % i if i % 5 == 0 else None for i in range(len(reads))]
     b.sam_upload(names, quals, comments)
     n_res = 0
-    for flag, rg in ((0, b""), (0x8, b"rg")):
+    annos = [b"", b"chrB's\tannotation", b"ALT"]
+    ix.set_contig_annos(annos)
+    for flag, rg in ((0, b""), (0x100, b"g"), (0x8, b"rg")):
         so, sg = loader.default_sam_opt(flag, rg), capi.default_sam_opt(flag, rg)
         b.sam_run_emf(e, gopt, sg)
         text, roff, _ = b.sam_fetch()
-        normal = loader.reg2sam_se(regs, off, enc, cum, idx.ref_0123, len(g), names, quals=quals, comments=comments, contigs=contigs,
-                                   contig_names=cnames, opt=oopt, sopt=so)
+        assert (b"\tXR:Z:chrB's annotation\n" in text) == (flag == 0x100)
+        with loader.contig_annos(annos):
+            normal = loader.reg2sam_se(regs, off, enc, cum, idx.ref_0123, len(g), names, quals=quals, comments=comments, contigs=contigs,
+                                       contig_names=cnames, opt=oopt, sopt=so)
         for r, rd in enumerate(reads):
             got = text[roff[r]:roff[r + 1]]
             if eoff[r + 1] > eoff[r]:
                 want_regs, _ = o.perfect2reg(rd, int(perfect[r, 0]), int(perfect[r, 1]), len(g), contigs=contigs)
-                want = loader.perfect2sam(want_regs, rd, len(g), L, names[r], qual=bytes(quals[cum[r]:cum[r + 1]]), comment=comments[r],
-                                          contigs=contigs, contig_names=cnames, opt=oopt, sopt=so)
+                with loader.contig_annos(annos):
+                    want = loader.perfect2sam(want_regs, rd, len(g), L, names[r], qual=bytes(quals[cum[r]:cum[r + 1]]), comment=comments[r],
+                                              contigs=contigs, contig_names=cnames, opt=oopt, sopt=so)
                 n_res += 1
                 f = got.split(b"\n")[0].split(b"\t")
                 assert f[4] == b"60" and f[5] == b"%dM" % len(rd) and b"NM:i:0" in f
             else:
                 want = normal[r]
             assert got == want, (r, got, want)
-    assert n_res > 600
+    assert n_res > 900
     joined = text
     assert b"chrB_alt\t" in joined and joined.count(b"\t256\t") + joined.count(b"\t272\t") > 50       # MEM_F_ALL: secondary exact-match records
     with pytest.raises(capi.BwamsError):

@@ -164,6 +164,24 @@ def test_sam_text_contigs_alt_flags_and_options():
     # no qualities, no comments
     out = sam_of(c, quals=False, comments=False)
     assert all(ln.split(b"\t")[10] == b"*" for t in out for ln in t.split(b"\n")[:-1])
+    # MEM_F_REF_HDR (bwamem.cpp:2522-2529): the text of the default run with XR:Z:<anno of the record's sequence> (TABs as blanks) at the
+    # end of every line whose sequence has a non-empty annotation; no flag or no annotations, no tag
+    base = sam_of(c)
+    annos = [b"AS:toy\tM5:00ff", b""] if len(c["contig_names"]) == 2 else [b"AS:toy\tM5:00ff", b"", b"alt of B"]
+    with loader.contig_annos(annos):
+        tagged = sam_of(c, loader.default_sam_opt(0x100))
+        assert sam_of(c) == base
+    assert sam_of(c, loader.default_sam_opt(0x100)) == base
+    n_tag = 0
+    for t0, t1 in zip(base, tagged):
+        l0, l1 = t0.split(b"\n")[:-1], t1.split(b"\n")[:-1]
+        assert len(l0) == len(l1)
+        for a, b_ in zip(l0, l1):
+            ctg = a.split(b"\t")[2]
+            anno = b"" if ctg == b"*" else annos[c["contig_names"].index(ctg)].replace(b"\t", b" ")
+            assert b_ == a + (b"\tXR:Z:" + anno if anno else b"")
+            n_tag += bool(anno)
+    assert n_tag > 100
 
 
 def test_sam_text_threshold_and_empty_reads():

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_run_sam", "bwams_reg2aln_fetch",
     "bwams_index_set_contig_names", "bwams_index_set_contig_annos", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
-    "bwams_process_chunk", "bwams_emf_regs_merge", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_process_chunk", "bwams_emf_regs_merge", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_has_qual", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
     "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
@@ -130,7 +130,7 @@ class Fastq:
         cum = np.zeros(n1, np.int64); noff = np.zeros(n1, np.int64); coff = np.zeros(n1, np.int64)
         _chk(lib().bwams_fastq_fetch(self.h, _p(enc), _p(cum), _p(names), _p(noff), _p(qual), _p(comm), _p(coff)), "bwams_fastq_fetch")
         nb_, cb_ = bytes(names[:i["name_bytes"]]), bytes(comm[:i["comment_bytes"]])
-        return dict(n=i["n_reads"], enc=enc[:i["n_bases"]], cum=cum, quals=qual[:i["n_bases"]],
+        return dict(n=i["n_reads"], enc=enc[:i["n_bases"]], cum=cum, quals=qual[:i["n_bases"]] if lib().bwams_fastq_has_qual(self.h) else None,
                     names=[nb_[noff[k]:noff[k + 1]] for k in range(i["n_reads"])],
                     comments=[cb_[coff[k]:coff[k + 1]] or None for k in range(i["n_reads"])])
 

@@ -10,7 +10,10 @@
 // admits multi-line records, FASTA records and blank lines.  The device path takes the shape sequencers write — four lines per
 // record — where every record is found from the line index alone, checks per record that the serial reader would have seen the
 // same thing ('@' and '+' where they belong, equal sequence and quality lengths, no sequence line starting with '>', '+' or
-// '@'), and returns BWAMS_ERR_UNSUPPORTED for any other input (the caller then reads that file on the host).
+// '@'), and returns BWAMS_ERR_UNSUPPORTED for any other input (the caller then reads that file on the host).  FASTA text (first byte
+// '>', no line starting with '+' or '@') is taken too, sequences over any number of lines, blank lines skipped as the serial reader
+// skips them: the header lines are found from the line index ('>' at a line start), a lane per record adds up its lines, a wave
+// per record walks them again to encode.  Such a chunk has no qualities (bwams_fastq_has_qual = 0; the SAM text prints '*').
 //
 // Mapping.  HBM-bound streaming, three passes over the text: (1) the positions of the line ends (rocPRIM select over a counting
 // iterator), (2) a lane per record: validate, measure name / comment / sequence, (3) after three exclusive scans, a WAVE per
@@ -30,6 +33,7 @@ struct bwams_fastq {
     void *d_enc = nullptr, *d_qual = nullptr, *d_names = nullptr, *d_comments = nullptr;
     std::vector<int64_t> cum, name_off, comment_off;       // host copies of the three offset arrays
     float ms = 0;
+    bool has_qual = true;                                  // false: FASTA text
 };
 
 namespace bwams {
@@ -61,6 +65,20 @@ struct Rec {                      // where the pieces of a record lie in the tex
     int32_t pad_;
 };
 
+// the header line [b, e): name up to the first isspace() (the delimiter decides whether a comment follows), trim_readno, comment
+__device__ __forceinline__ void parse_header(const char *__restrict__ text, int64_t b, int64_t e, Rec &R) {
+    int64_t p = b + 1;
+    while (p < e && !is_space((unsigned char)text[p])) ++p;
+    R.name_at = b + 1;
+    int l_name = (int)(p - (b + 1));
+    if (l_name > 2 && text[R.name_at + l_name - 2] == '/' && text[R.name_at + l_name - 1] >= '0' && text[R.name_at + l_name - 1] <= '9') l_name -= 2;
+    R.l_name = l_name;
+    R.comment_at = p < e ? p + 1 : e;
+    int l_comment = p < e ? (int)(e - (p + 1)) : 0;
+    if (l_comment > 1 && text[R.comment_at + l_comment - 1] == '\r') --l_comment;
+    R.l_comment = l_comment;
+}
+
 // line j spans [start(j), end(j)): ends[j] is the position of its '\n' (or the text length for an unterminated last line)
 __global__ void fastq_measure_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_lines,
                                      int64_t n_rec, Rec *__restrict__ rec, int64_t *__restrict__ wide, unsigned long long *bad) {
@@ -75,17 +93,7 @@ __global__ void fastq_measure_kernel(const char *__restrict__ text, int64_t n_by
     }
     bool ok = e[0] > b[0] && text[b[0]] == '@' && e[2] > b[2] && text[b[2]] == '+';
     Rec R;
-    // name: up to the first isspace() of the header line; the delimiter decides whether a comment follows
-    int64_t p = b[0] + 1;
-    while (p < e[0] && !is_space((unsigned char)text[p])) ++p;
-    R.name_at = b[0] + 1;
-    int l_name = (int)(p - (b[0] + 1));
-    if (l_name > 2 && text[R.name_at + l_name - 2] == '/' && text[R.name_at + l_name - 1] >= '0' && text[R.name_at + l_name - 1] <= '9') l_name -= 2;
-    R.l_name = l_name;
-    R.comment_at = p < e[0] ? p + 1 : e[0];
-    int l_comment = p < e[0] ? (int)(e[0] - (p + 1)) : 0;
-    if (l_comment > 1 && text[R.comment_at + l_comment - 1] == '\r') --l_comment;
-    R.l_comment = l_comment;
+    parse_header(text, b[0], e[0], R);
     int l_seq = (int)(e[1] - b[1]), l_qual = (int)(e[3] - b[3]);
     if (l_seq > 1 && text[e[1] - 1] == '\r') --l_seq;
     if (l_qual > 1 && text[e[3] - 1] == '\r') --l_qual;
@@ -96,7 +104,7 @@ __global__ void fastq_measure_kernel(const char *__restrict__ text, int64_t n_by
     ok = ok && l_seq == l_qual;
     R.seq_at = b[1]; R.qual_at = b[3]; R.l_seq = l_seq; R.pad_ = 0;
     rec[r] = R;
-    wide[r] = l_name; wide[n_rec + 1 + r] = l_comment; wide[2 * (n_rec + 1) + r] = l_seq;
+    wide[r] = R.l_name; wide[n_rec + 1 + r] = R.l_comment; wide[2 * (n_rec + 1) + r] = l_seq;
     if (!ok) atomicAdd(bad, 1ull);
 }
 
@@ -117,6 +125,82 @@ __global__ __launch_bounds__(256) void fastq_emit_kernel(const char *__restrict_
             n_dash += v > 4;
             enc[so + i] = v;
             qual[so + i] = text[R.qual_at + i];
+        }
+    }
+    if (__any(n_dash != 0) && n_dash) atomicAdd(dash, n_dash);
+}
+
+// ---- FASTA text ------------------------------------------------------------------------------------------------------------
+struct IsHeaderLine {                 // line j starts a record: its first byte is '>'
+    const char *text;
+    const int64_t *ends;
+    int64_t n_nl, n_bytes;
+    __device__ bool operator()(const int64_t &j) const {
+        const int64_t b = j ? ends[j - 1] + 1 : 0, e = j < n_nl ? ends[j] : n_bytes;
+        return e > b && text[b] == '>';
+    }
+};
+
+// a line starting with '+' or '@' would send kseq_read into its FASTQ branch: not this path's input
+__global__ __launch_bounds__(256) void fasta_check_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends,
+                                                          int64_t n_nl, int64_t n_lines, unsigned long long *bad) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_lines) return;
+    const int64_t b = j ? ends[j - 1] + 1 : 0, e = j < n_nl ? ends[j] : n_bytes;
+    if (e > b && (text[b] == '+' || text[b] == '@')) atomicAdd(bad, 1ull);
+}
+
+// one sequence line [b, e) appended to a sequence of l bytes (kseq_read's loop, kseq.h:377-381): the bytes it contributes.  An empty
+// line is skipped; ks_getuntil_line2 drops a trailing '\r' when the WHOLE sequence so far is longer than one byte
+__device__ __forceinline__ int fasta_line_bytes(const char *__restrict__ text, int64_t b, int64_t e, int l) {
+    int len = (int)(e - b);
+    if (len > 0 && l + len > 1 && text[e - 1] == '\r') --len;
+    return len;
+}
+
+// lane per record: Rec.seq_at = index of its first sequence line, Rec.qual_at = index one past its last
+__global__ void fasta_measure_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_nl, int64_t n_lines,
+                                     const int64_t *__restrict__ hdr, int64_t n_rec, Rec *__restrict__ rec, int64_t *__restrict__ wide) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rec) return;
+    if (r == n_rec) { wide[r] = wide[n_rec + 1 + r] = wide[2 * (n_rec + 1) + r] = 0; return; }
+    const int64_t j0 = hdr[r], j1 = r + 1 < n_rec ? hdr[r + 1] : n_lines;
+    Rec R;
+    parse_header(text, j0 ? ends[j0 - 1] + 1 : 0, j0 < n_nl ? ends[j0] : n_bytes, R);
+    int l = 0;
+    for (int64_t j = j0 + 1; j < j1; ++j) {
+        const int64_t b = ends[j - 1] + 1, e = j < n_nl ? ends[j] : n_bytes;
+        l += fasta_line_bytes(text, b, e, l);
+    }
+    R.seq_at = j0 + 1; R.qual_at = j1; R.l_seq = l; R.pad_ = 0;
+    rec[r] = R;
+    wide[r] = R.l_name; wide[n_rec + 1 + r] = R.l_comment; wide[2 * (n_rec + 1) + r] = l;
+}
+
+// wave per record: names and comments as in fastq_emit_kernel; the sequence line by line, 64 bytes per step
+__global__ __launch_bounds__(256) void fasta_emit_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_nl,
+                                                         const Rec *__restrict__ rec, int64_t n_rec, const int64_t *__restrict__ offs,
+                                                         char *__restrict__ names, char *__restrict__ comments, uint8_t *__restrict__ enc,
+                                                         unsigned long long *dash) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long n_dash = 0;
+    for (int64_t r = wave; r < n_rec; r += n_waves) {
+        const Rec R = rec[r];
+        const int64_t no = offs[r], co = offs[n_rec + 1 + r], so = offs[2 * (n_rec + 1) + r];
+        for (int i = lane; i < R.l_name; i += 64) names[no + i] = text[R.name_at + i];
+        for (int i = lane; i < R.l_comment; i += 64) comments[co + i] = text[R.comment_at + i];
+        int l = 0;
+        for (int64_t j = R.seq_at; j < R.qual_at; ++j) {
+            const int64_t b = ends[j - 1] + 1, e = j < n_nl ? ends[j] : n_bytes;
+            const int len = fasta_line_bytes(text, b, e, l);
+            for (int i = lane; i < len; i += 64) {
+                const unsigned char c = (unsigned char)text[b + i];
+                const unsigned char v = c < 4 ? c : kNt4[c];
+                n_dash += v > 4;
+                enc[so + l + i] = v;
+            }
+            l += len;
         }
     }
     if (__any(n_dash != 0) && n_dash) atomicAdd(dash, n_dash);
@@ -182,21 +266,49 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
         BWAMS_HIP(hipStreamSynchronize(st));
     }
     const int64_t n_lines = n_nl + (n_bytes && last != '\n' ? 1 : 0);
-    if (n_lines % 4) {
-        set_last_error("bwams_fastq_decode: the text is not a whole number of four-line records (multi-line or FASTA input: read it on the host)");
-        return BWAMS_ERR_UNSUPPORTED;
+    char first = '@';
+    if (n_bytes) BWAMS_HIP(hipMemcpy(&first, d_text, 1, hipMemcpyDeviceToHost));
+    const bool fasta = n_bytes && first == '>';
+    unsigned long long *d_bad = nullptr;
+    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_bad), 64)); scr.p.push_back(d_bad);
+    BWAMS_HIP(hipMemsetAsync(d_bad, 0, 16, st));
+    int64_t n = 0;
+    int64_t *d_hdr = nullptr;
+    if (fasta) {
+        // the records: the lines that start with '>'; no line may start with '+' or '@'
+        fasta_check_kernel<<<(unsigned)((n_lines + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_bad);
+        BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_hdr), (size_t)(n_lines + 16) * 8)); scr.p.push_back(d_hdr);
+        size_t tb = 0;
+        rocprim::counting_iterator<int64_t> it(0);
+        IsHeaderLine pred{d_text, d_ends, n_nl, n_bytes};
+        BWAMS_HIP(rocprim::select(nullptr, tb, it, d_hdr, d_cnt, (size_t)n_lines, pred, st));
+        void *d_tmp = nullptr;
+        BWAMS_HIP(hipMalloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
+        BWAMS_HIP(rocprim::select(d_tmp, tb, it, d_hdr, d_cnt, (size_t)n_lines, pred, st));
+        unsigned long long bad0 = 0;
+        BWAMS_HIP(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipMemcpyAsync(&bad0, d_bad, 8, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        if (bad0) {
+            set_last_error("bwams_fastq_decode: FASTA text with " + std::to_string(bad0) + " line(s) starting with '+' or '@' (mixed or multi-line FASTQ input: read it on the host)");
+            return BWAMS_ERR_UNSUPPORTED;
+        }
+    } else {
+        if (n_lines % 4) {
+            set_last_error("bwams_fastq_decode: the text is not a whole number of four-line records (multi-line FASTQ input: read it on the host)");
+            return BWAMS_ERR_UNSUPPORTED;
+        }
+        n = n_lines / 4;
     }
-    const int64_t n = n_lines / 4, n1 = n + 1;
+    const int64_t n1 = n + 1;
     // (2) measure + validate
     Rec *d_rec = nullptr;
     int64_t *d_wide = nullptr, *d_offs = nullptr;
-    unsigned long long *d_bad = nullptr;
     BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_rec), (size_t)n1 * sizeof(Rec))); scr.p.push_back(d_rec);
     BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_wide), (size_t)n1 * 3 * 8)); scr.p.push_back(d_wide);
     BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_offs), (size_t)n1 * 3 * 8)); scr.p.push_back(d_offs);
-    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_bad), 64)); scr.p.push_back(d_bad);
-    BWAMS_HIP(hipMemsetAsync(d_bad, 0, 16, st));
-    fastq_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n, d_rec, d_wide, d_bad);
+    if (fasta) fasta_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_hdr, n, d_rec, d_wide);
+    else fastq_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n, d_rec, d_wide, d_bad);
     for (int row = 0; row < 3; ++row) {
         size_t tb = 0;
         BWAMS_HIP(rocprim::exclusive_scan(nullptr, tb, d_wide + row * n1, d_offs + row * n1, (int64_t)0, (size_t)n1, rocprim::plus<int64_t>(), st));
@@ -215,6 +327,7 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
         set_last_error("bwams_fastq_decode: " + std::to_string(bad[0]) + " record(s) are not '@' / sequence / '+' / quality of equal length on four lines (read this input on the host)");
         return BWAMS_ERR_UNSUPPORTED;
     }
+    f->has_qual = !fasta;
     f->n_reads = n; f->n_bases = f->cum[(size_t)n]; f->name_bytes = f->name_off[(size_t)n]; f->comment_bytes = f->comment_off[(size_t)n];
     // (3) emit
     BWAMS_HIP(hipMalloc(&f->d_enc, (size_t)f->n_bases + 64));
@@ -224,9 +337,13 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     if (n) {
         int64_t blocks = (n + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
-        fastq_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(d_text, d_rec, n, d_offs, reinterpret_cast<char *>(f->d_names),
-                                                            reinterpret_cast<char *>(f->d_comments), reinterpret_cast<uint8_t *>(f->d_enc),
-                                                            reinterpret_cast<char *>(f->d_qual), d_bad + 1);
+        if (fasta)
+            fasta_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, d_rec, n, d_offs, reinterpret_cast<char *>(f->d_names),
+                                                                reinterpret_cast<char *>(f->d_comments), reinterpret_cast<uint8_t *>(f->d_enc), d_bad + 1);
+        else
+            fastq_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(d_text, d_rec, n, d_offs, reinterpret_cast<char *>(f->d_names),
+                                                                reinterpret_cast<char *>(f->d_comments), reinterpret_cast<uint8_t *>(f->d_enc),
+                                                                reinterpret_cast<char *>(f->d_qual), d_bad + 1);
     }
     BWAMS_HIP(hipEventRecord(e1, st));
     BWAMS_HIP(hipMemcpyAsync(bad + 1, d_bad + 1, 8, hipMemcpyDeviceToHost, st));
@@ -255,13 +372,15 @@ int bwams_fastq_info(const bwams_fastq_t *f, int64_t *n_reads, int64_t *n_bases,
     return BWAMS_OK;
 }
 
+int bwams_fastq_has_qual(const bwams_fastq_t *f) { return f && f->has_qual ? 1 : 0; }
+
 int bwams_fastq_fetch(bwams_fastq_t *f, uint8_t *enc, int64_t *cum, char *names, int64_t *name_off, char *quals, char *comments,
                       int64_t *comment_off) {
     if (!f) return BWAMS_ERR_ARG;
     BWAMS_HIP(hipSetDevice(f->device));
     const size_t n1 = (size_t)f->n_reads + 1;
     if (enc && f->n_bases) BWAMS_HIP(hipMemcpy(enc, f->d_enc, (size_t)f->n_bases, hipMemcpyDeviceToHost));
-    if (quals && f->n_bases) BWAMS_HIP(hipMemcpy(quals, f->d_qual, (size_t)f->n_bases, hipMemcpyDeviceToHost));
+    if (quals && f->n_bases && f->has_qual) BWAMS_HIP(hipMemcpy(quals, f->d_qual, (size_t)f->n_bases, hipMemcpyDeviceToHost));
     if (names && f->name_bytes) BWAMS_HIP(hipMemcpy(names, f->d_names, (size_t)f->name_bytes, hipMemcpyDeviceToHost));
     if (comments && f->comment_bytes) BWAMS_HIP(hipMemcpy(comments, f->d_comments, (size_t)f->comment_bytes, hipMemcpyDeviceToHost));
     if (cum) memcpy(cum, f->cum.data(), n1 * 8);
@@ -275,7 +394,8 @@ int bwams_fastq_to_batch_opt(bwams_fastq_t *f, bwams_batch_t *b, int32_t copy_co
     int rc = bwams_seed_upload(b, reinterpret_cast<const uint8_t *>(f->d_enc), f->cum.data(), nullptr, f->n_reads);
     if (rc) return rc;
     const bool cm = copy_comment && f->comment_bytes;
-    return bwams_sam_upload(b, reinterpret_cast<const char *>(f->d_names), f->name_off.data(), reinterpret_cast<const char *>(f->d_qual),
+    return bwams_sam_upload(b, reinterpret_cast<const char *>(f->d_names), f->name_off.data(),
+                            f->has_qual ? reinterpret_cast<const char *>(f->d_qual) : nullptr,
                             cm ? reinterpret_cast<const char *>(f->d_comments) : nullptr, cm ? f->comment_off.data() : nullptr);
 }
 

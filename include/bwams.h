@@ -272,14 +272,16 @@ int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off,
 /* ------------------------------------------------------------- read input ---- *
  * A buffer of FASTQ text (host or this GPU's memory) becomes the arrays bwams_seed_upload and bwams_sam_upload take: replaces, per
  * record, kseq_read (src/kseq.h:358-400), trim_readno and kseq2bseq1 (src/bwa.cpp:74-153) as bseq_read_orig (src/bwa.cpp:266-335)
- * calls them, and the base encoding of mem_kernel1_core (src/bwamem.cpp:1232, nst_nt4_table).  Built for the four-lines-per-record
- * shape; multi-line or FASTA input, a quality string of another length than its sequence, or a '-' among the bases return
+ * calls them, and the base encoding of mem_kernel1_core (src/bwamem.cpp:1232, nst_nt4_table).  Built for FASTQ in the four-lines-per-record
+ * shape and for FASTA text (first byte '>', sequences over any number of lines, blank lines skipped; no qualities: bwams_fastq_has_qual = 0);
+ * multi-line or mixed FASTQ input, a quality string of another length than its sequence, or a '-' among the bases return
  * BWAMS_ERR_UNSUPPORTED (read such a file on the host).  The buffer must hold whole records; gz decompression and the chunking by
  * base count stay with the caller.  Names come without their "/<digit>" suffix; a read's comment is the header line after the
  * first white-space character (empty = none). */
 typedef struct bwams_fastq bwams_fastq_t;
 int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fastq_t **out, int64_t *n_reads, int64_t *n_bases);
 int bwams_fastq_info(const bwams_fastq_t *f, int64_t *n_reads, int64_t *n_bases, int64_t *name_bytes, int64_t *comment_bytes, float *ms);
+int bwams_fastq_has_qual(const bwams_fastq_t *f);      /* 0: FASTA text (bseq1_t.qual == NULL for every read) */
 /* any pointer may be NULL; enc / quals hold n_bases bytes, cum / name_off / comment_off n_reads + 1 entries */
 int bwams_fastq_fetch(bwams_fastq_t *f, uint8_t *enc, int64_t *cum, char *names, int64_t *name_off, char *quals, char *comments,
                       int64_t *comment_off);

@@ -39,7 +39,9 @@ def test_decode_corners_and_refusals():
     _same(g, loader.fastq_parse(b"@x/9 c  d\nacgtn\n+x\n!!!!!\n@/1\n\n+\n\n"))
     f.close()
     for bad in (b"@a\nACGT\nAC\n+\nIIIIII\n",                      # multi-line record
-                b">fa\nACGT\n",                                    # FASTA
+                b">fa\nACGT\n@fq\nACGT\n+\nIIII\n",                 # FASTA and FASTQ records mixed
+                b">fa\nACGT\n+\nIIII\n",                            # '>' header with a quality part
+                b">fa\nAC-T\n",
                 b"@a\nACGT\n+\nIII\n",                             # quality shorter than the sequence
                 b"@a\nACGT\n+\nIIIII\n",                           # ... longer
                 b"@a\nACGT\n+\nIIII\n\n",                          # a blank line
@@ -47,6 +49,46 @@ def test_decode_corners_and_refusals():
                 b"@a\nAC-T\n+\nIIII\n"):                           # '-' (nst_nt4_table: 5)
         with pytest.raises(capi.BwamsError):
             capi.Fastq(bad)
+
+
+def _fasta_text(n, seed, crlf=False, width=60):
+    """FASTA records as the serial reader admits them: sequences over several lines of `width`, blank lines, comments, "/1" names, lower
+    case and IUPAC codes, an empty record, lines holding a lone '\\r'."""
+    rng = np.random.default_rng(seed)
+    nl = b"\r\n" if crlf else b"\n"
+    parts = []
+    for i in range(n):
+        ln = int(rng.integers(1, 400)) if i % 17 else 0
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTacgtNnRYKM", np.uint8), size=ln))
+        hdr = b">fa%d" % i + (b"/2" if i % 3 == 0 else b"") + (b"\tlen=%d  x" % ln if i % 4 == 0 else b" " if i % 4 == 1 else b"")
+        w = width if i % 5 else int(rng.integers(1, 90))
+        lines = [seq[k:k + w] for k in range(0, ln, w)]
+        if i % 7 == 0 and lines:
+            lines.insert(int(rng.integers(0, len(lines) + 1)), b"")              # a blank line inside / before / after the sequence
+        parts.append(hdr + nl + b"".join(x + nl for x in lines))
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("seed,crlf,n", [(1, False, 2500), (2, True, 900), (3, False, 1)])
+def test_fasta_decode_equals_oracle(seed, crlf, n):
+    text = _fasta_text(n, seed, crlf)
+    for t in (text, text.rstrip(b"\r\n")):
+        f = capi.Fastq(t)
+        want = loader.fastq_parse(t)
+        assert want["status"] == 0 and not want["has_qual"].any() and want["n"] == n
+        got = f.fetch()
+        assert got["quals"] is None
+        assert got["n"] == want["n"] and got["names"] == want["names"] and got["comments"] == want["comments"]
+        assert np.array_equal(got["cum"], want["cum"]) and np.array_equal(got["enc"], want["enc"])
+        f.close()
+    # the '\r' rule looks at the whole sequence so far: a first line of a lone '\r' stays (one N), later ones go
+    for t in (b">a\n\r\nAC\r\n\r\nGT\n>b c\n\n\n>c\nA\r", b">only_header", b">x\n\r\n\r\n"):
+        f = capi.Fastq(t)
+        want = loader.fastq_parse(t)
+        got = f.fetch()
+        assert got["names"] == want["names"] and got["comments"] == want["comments"]
+        assert np.array_equal(got["cum"], want["cum"]) and np.array_equal(got["enc"], want["enc"]), t
+        f.close()
 
 
 def test_fastq_text_to_sam_text_on_the_device():
@@ -209,7 +251,15 @@ def test_process_chunk_is_the_stage_sequence():
         b.process_chunk(ptext[: ptext.index(b"@pp1/2")], paired=True)      # an odd number of reads
     assert b.process_chunk(b"", fetch=False) == 0                          # an empty chunk
     with pytest.raises(capi.BwamsError):
-        b.process_chunk(b">fa\nACGT\n")                                    # FASTA: refused, the caller reads it on the host
+        b.process_chunk(b"@fq\nACGT\nAC\n+\nIIIIII\n")                     # multi-line FASTQ: refused, the caller reads it on the host
+    # FASTA reads (sequence lines of 70 bases): the same chain without qualities
+    fa = b"".join(b">%s some text\n" % names[i] + b"".join(bytes(b"ACGTN"[x] for x in reads[i][k:k + 70]) + b"\n" for k in range(0, len(reads[i]), 70))
+                  for i in range(len(reads)))
+    b.close()
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    sam_fa, _ = b.process_chunk(fa, n_processed=1000, copy_comment=True)
+    want_fa = loader.reg2sam_se(fin, fin_off, enc, cum, idx.ref_0123, l_pac, names, comments=[b"some text"] * len(reads), contig_names=[b"chrR"])
+    assert sam_fa == b"".join(want_fa) and sam_fa.count(b"\t*\tNM:i:") > 300
     b.close(); ix.close()
 
 

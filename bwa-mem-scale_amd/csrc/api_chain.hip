@@ -57,6 +57,7 @@ struct ChainState {
     bool al_done = false;
     DevBuf sm_names, sm_noff, sm_qual, sm_comm, sm_coff, sm_mapq, sm_len, sm_off, sm_out, sm_logtab, sm_bad;   // SAM text
     int64_t sm_bytes = 0, sm_nseq = 0, sm_nregs = 0;
+    int64_t sm_merged_n = -1;            // >= 0: sm_out / sm_off hold that many reads' text merged from two runs (bwams_process_chunk_smart)
     bool sm_up = false, sm_has_qual = false, sm_has_comm = false, sm_done = false, sm_log_ok = false;
     int64_t n_final = 0;
     bool dedup_done = false;
@@ -1293,7 +1294,7 @@ static int sam_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwam
     if (!memchr(sopt->rg_id, 0, sizeof sopt->rg_id)) return BWAMS_ERR_ARG;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
-    s->sm_done = false;
+    s->sm_done = false; s->sm_merged_n = -1;
     const int64_t nseq = s->nseq, n1 = nseq + 1, n = s->al_n;
     constexpr int kLogN = 1 << 16;
     if (!s->sm_log_ok) {                                   // log(i) with the C library's log, as the reference's host code computes it
@@ -1395,7 +1396,8 @@ int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off,
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
     if (sam && s->sm_bytes) BWAMS_HIP(hipMemcpyAsync(sam, s->sm_out.p, (size_t)s->sm_bytes, hipMemcpyDeviceToHost, st));
-    if (read_off) BWAMS_HIP(hipMemcpyAsync(read_off, s->sm_off.p, (size_t)(s->nseq + 1) * 8, hipMemcpyDeviceToHost, st));
+    const int64_t n_out = s->sm_merged_n >= 0 ? s->sm_merged_n : s->nseq;
+    if (read_off) BWAMS_HIP(hipMemcpyAsync(read_off, s->sm_off.p, (size_t)(n_out + 1) * 8, hipMemcpyDeviceToHost, st));
     if (mapq && s->sm_nregs) BWAMS_HIP(hipMemcpyAsync(mapq, s->sm_mapq.p, (size_t)s->sm_nregs * 4, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     return BWAMS_OK;
@@ -1405,27 +1407,15 @@ int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off,
 
 // The outer boundary for one chunk, text to text: what kt_pipeline's step 0 parsing and step 1 (mem_process_seqs, src/bwamem.cpp:1850-1980)
 // do between the decompressed FASTQ bytes and seqs[i].sam, as the sequence of the stage calls above.
-int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
-                        const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
-                        int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes) {
-    if (!b || !so || !mo || !sam_opt || !fastq || n_bytes < 0) {
-        set_last_error("bwams_process_chunk: batch, options and text are required");
-        return BWAMS_ERR_ARG;
-    }
-    bwams_fastq_t *fq = nullptr;
-    int64_t n = 0, nb = 0;
-    int rc = bwams_fastq_decode(b->idx->device, fastq, n_bytes, &fq, &n, &nb);
-    if (rc) return rc;
-    if (paired && (n & 1)) {
-        bwams_fastq_close(fq);
-        set_last_error("bwams_process_chunk: a paired-end chunk holds an even number of reads (ends interleaved)");
-        return BWAMS_ERR_ARG;
-    }
+// mem_process_seqs for a decoded chunk (fq is closed here): the stage calls in worker order
+static int process_decoded(bwams_batch_t *b, bwams_fastq_t *fq, int64_t n, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so,
+                           const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt, int32_t paired, const bwams_pestat_t *pes0,
+                           int64_t n_processed, int32_t flags, int64_t *sam_bytes) {
+    int rc;
     if (n == 0) {                                         // an empty chunk: no reads, no text
         bwams_fastq_close(fq);
-        if (b->chain) { b->chain->sm_done = true; b->chain->sm_bytes = 0; b->chain->sm_nregs = 0; b->chain->nseq = 0; }
+        if (b->chain) { b->chain->sm_done = true; b->chain->sm_bytes = 0; b->chain->sm_nregs = 0; b->chain->nseq = 0; b->chain->sm_merged_n = -1; }
         b->nseq = 0;
-        if (n_reads) *n_reads = 0;
         if (sam_bytes) *sam_bytes = 0;
         return BWAMS_OK;
     }
@@ -1454,8 +1444,101 @@ int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, co
         if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, pes, &t0, &t1, &t2, &t3))) return rc;
         rc = bwams_sam_run_pe(b, mo, sam_opt, pes, sam_bytes);
     }
+    return rc;
+}
+
+int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                        const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
+                        int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes) {
+    if (!b || !so || !mo || !sam_opt || !fastq || n_bytes < 0) {
+        set_last_error("bwams_process_chunk: batch, options and text are required");
+        return BWAMS_ERR_ARG;
+    }
+    bwams_fastq_t *fq = nullptr;
+    int64_t n = 0, nb = 0;
+    int rc = bwams_fastq_decode(b->idx->device, fastq, n_bytes, &fq, &n, &nb);
+    if (rc) return rc;
+    if (paired && (n & 1)) {
+        bwams_fastq_close(fq);
+        set_last_error("bwams_process_chunk: a paired-end chunk holds an even number of reads (ends interleaved)");
+        return BWAMS_ERR_ARG;
+    }
+    rc = process_decoded(b, fq, n, emf, ert, so, mo, sam_opt, paired, pes0, n_processed, flags, sam_bytes);
     if (!rc && n_reads) *n_reads = n;
     return rc;
+}
+
+// process()'s MEM_F_SMARTPE branch (src/fastmap.cpp:378-414): bseq_classify splits the chunk into the reads that stand alone and the
+// interleaved pairs; mem_process_seqs runs on the first set as single-end (ids from n_processed) and on the second as paired-end (ids
+// from n_processed + the number of single reads, pes0); every read's text returns to its place in the chunk.
+int bwams_process_chunk_smart(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                              const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, const bwams_pestat_t *pes0,
+                              int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *n_single, int64_t *sam_bytes) {
+    if (!b || !so || !mo || !sam_opt || !fastq || n_bytes < 0) {
+        set_last_error("bwams_process_chunk_smart: batch, options and text are required");
+        return BWAMS_ERR_ARG;
+    }
+    bwams_fastq_t *fq = nullptr;
+    int64_t n = 0, nb = 0;
+    int rc = bwams_fastq_decode(b->idx->device, fastq, n_bytes, &fq, &n, &nb);
+    if (rc) return rc;
+    std::vector<uint8_t> which;
+    if ((rc = fastq_classify(fq, &which))) { bwams_fastq_close(fq); return rc; }
+    std::vector<int64_t> ids[2];
+    for (int64_t i = 0; i < n; ++i) ids[which[(size_t)i]].push_back(i);
+    struct Held {                                        // the text of one run, kept while the batch does the other
+        char *text = nullptr;
+        std::vector<int64_t> off;
+        ~Held() { if (text) (void)hipFree(text); }
+    } held[2];
+    hipStream_t st = b->stream;
+    for (int k = 0; k < 2; ++k) {
+        held[k].off.assign(ids[k].size() + 1, 0);
+        if (ids[k].empty()) continue;
+        bwams_fastq_t *sub = nullptr;
+        if ((rc = fastq_subset(fq, ids[k], &sub))) { bwams_fastq_close(fq); return rc; }
+        int64_t bytes = 0;
+        rc = process_decoded(b, sub, (int64_t)ids[k].size(), emf, ert, so, mo, sam_opt, k, k ? pes0 : nullptr,
+                             n_processed + (k ? (int64_t)ids[0].size() : 0), flags, &bytes);
+        if (rc) { bwams_fastq_close(fq); return rc; }
+        ChainState *s = b->chain;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&held[k].text), (size_t)bytes + 16);
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(held[k].text, s->sm_out.p, (size_t)bytes, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(held[k].off.data(), s->sm_off.p, held[k].off.size() * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { bwams_fastq_close(fq); BWAMS_HIP(e); }
+    }
+    bwams_fastq_close(fq);
+    if (n_reads) *n_reads = n;
+    if (n_single) *n_single = (int64_t)ids[0].size();
+    ChainState *s;
+    if ((rc = get_state(b, &s))) return rc;
+    // every read's block back to its place in the chunk (ret->seqs[sep[k][i].id].sam = sep[k][i].sam)
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    std::vector<int64_t> rank((size_t)n, 0);
+    for (int k = 0; k < 2; ++k)
+        for (size_t j = 0; j < ids[k].size(); ++j) rank[(size_t)ids[k][j]] = (int64_t)j;
+    for (int64_t i = 0; i < n; ++i) {
+        const Held &h = held[which[(size_t)i]];
+        const size_t j = (size_t)rank[(size_t)i];
+        off[(size_t)i + 1] = off[(size_t)i] + (h.off[j + 1] - h.off[j]);
+    }
+    const int64_t total = off[(size_t)n];
+    BWAMS_HIP(s->sm_out.ensure((size_t)total + 16));
+    BWAMS_HIP(s->sm_off.ensure((size_t)(n + 1) * 8));
+    std::vector<SegMove> mv;
+    mv.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const Held &h = held[which[(size_t)i]];
+        const size_t j = (size_t)rank[(size_t)i];
+        mv.push_back({h.text + h.off[j], s->sm_out.as<char>() + off[(size_t)i], h.off[j + 1] - h.off[j]});
+    }
+    if ((rc = segment_copy(mv, st))) return rc;
+    BWAMS_HIP(hipMemcpyAsync(s->sm_off.p, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    BWAMS_HIP(hipStreamSynchronize(st));
+    s->sm_bytes = total; s->sm_nregs = 0; s->sm_merged_n = n; s->sm_done = true;
+    if (sam_bytes) *sam_bytes = total;
+    return BWAMS_OK;
 }
 
 /* ------------------------------------------------------------ mem_perfect2reg ---- */

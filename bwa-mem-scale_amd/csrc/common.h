@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/bwams.h"
 
@@ -124,6 +125,14 @@ constexpr int kKswMaxTarget = 20000;     // longest local-SW target: its row-max
 int launch_ksw(const bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, const SwParams &prm,
                 int pmax, int tmax, void *out, DevCounters *ctr, int cu_count, hipStream_t st);
 
+// read input helpers shared with the outer boundary (fastq.hip)
+struct SegMove { const char *src; char *dst; int64_t len; };     // one contiguous piece of device memory to copy
+int segment_copy(const std::vector<SegMove> &moves, hipStream_t st);
+}  // namespace bwams
+struct bwams_fastq;
+namespace bwams {
+int fastq_classify(bwams_fastq *f, std::vector<uint8_t> *which);                       // bseq_classify: 1 = an end of a pair
+int fastq_subset(bwams_fastq *f, const std::vector<int64_t> &ids, bwams_fastq **out);  // those reads as a chunk of their own
 }  // namespace bwams
 
 struct bwams_index {

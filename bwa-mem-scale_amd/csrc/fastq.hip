@@ -130,6 +130,31 @@ __global__ __launch_bounds__(256) void fastq_emit_kernel(const char *__restrict_
     if (__any(n_dash != 0) && n_dash) atomicAdd(dash, n_dash);
 }
 
+// ---- smart pairing (bseq_classify, bwa.cpp:346-362) and moving reads about ------------------------------------------------------
+// eq[i] = read i carries the name of read i - 1 (strcmp == 0 on the trimmed names)
+__global__ __launch_bounds__(256) void fastq_same_name_kernel(const char *__restrict__ names, const int64_t *__restrict__ name_off, int64_t n,
+                                                             uint8_t *__restrict__ eq) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool same = false;
+    if (i > 0) {
+        const int64_t a = name_off[i - 1], b = name_off[i], l = b - a;
+        same = name_off[i + 1] - b == l;
+        for (int64_t k = 0; same && k < l; ++k) same = names[a + k] == names[b + k];
+    }
+    eq[i] = same;
+}
+
+// a wave per segment: len bytes from src to dst
+__global__ __launch_bounds__(256) void segment_copy_kernel(const bwams::SegMove *__restrict__ mv, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t m = wave; m < n; m += n_waves) {
+        const bwams::SegMove M = mv[m];
+        for (int64_t i = lane; i < M.len; i += 64) M.dst[i] = M.src[i];
+    }
+}
+
 // ---- FASTA text ------------------------------------------------------------------------------------------------------------
 struct IsHeaderLine {                 // line j starts a record: its first byte is '>'
     const char *text;
@@ -211,6 +236,93 @@ __global__ __launch_bounds__(256) void fasta_emit_kernel(const char *__restrict_
 
 using namespace bwams;
 
+namespace bwams {
+int segment_copy(const std::vector<SegMove> &moves, hipStream_t st) {
+    if (moves.empty()) return BWAMS_OK;
+    SegMove *d = nullptr;
+    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d), moves.size() * sizeof(SegMove)));
+    hipError_t e = hipMemcpyAsync(d, moves.data(), moves.size() * sizeof(SegMove), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        int64_t blocks = ((int64_t)moves.size() + 3) / 4;
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        segment_copy_kernel<<<(unsigned)blocks, 256, 0, st>>>(d, (int64_t)moves.size());
+        e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d);
+    BWAMS_HIP(e);
+    return BWAMS_OK;
+}
+
+// bseq_classify (bwa.cpp:346-362) over the decoded chunk: which[i] = 1 when read i is an end of a pair (two neighbours of one name,
+// taken greedily from the left), 0 when it stands alone
+int fastq_classify(bwams_fastq *f, std::vector<uint8_t> *which) {
+    const int64_t n = f->n_reads;
+    which->assign((size_t)n, 0);
+    if (n == 0) return BWAMS_OK;
+    BWAMS_HIP(hipSetDevice(f->device));
+    uint8_t *d_eq = nullptr;
+    int64_t *d_off = nullptr;
+    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_eq), (size_t)n));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_off), (size_t)(n + 1) * 8);
+    std::vector<uint8_t> eq((size_t)n);
+    if (e == hipSuccess) e = hipMemcpy(d_off, f->name_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        fastq_same_name_kernel<<<(unsigned)((n + 255) / 256), 256, 0, nullptr>>>(reinterpret_cast<const char *>(f->d_names), d_off, n, d_eq);
+        e = hipMemcpy(eq.data(), d_eq, (size_t)n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_eq); (void)hipFree(d_off);
+    BWAMS_HIP(e);
+    int has_last = 1;                                    // the reference's loop, on the comparison results
+    int64_t i;
+    for (i = 1; i < n; ++i) {
+        if (has_last) {
+            if (eq[(size_t)i]) { (*which)[(size_t)i - 1] = (*which)[(size_t)i] = 1; has_last = 0; }
+        } else has_last = 1;
+    }
+    return BWAMS_OK;
+}
+
+// the reads ids[0 .. n_ids) of f, in that order, as a chunk of their own
+int fastq_subset(bwams_fastq *f, const std::vector<int64_t> &ids, bwams_fastq **out) {
+    *out = nullptr;
+    BWAMS_HIP(hipSetDevice(f->device));
+    std::unique_ptr<bwams_fastq> g(new bwams_fastq());
+    g->device = f->device; g->has_qual = f->has_qual;
+    const size_t m = ids.size();
+    g->cum.assign(m + 1, 0); g->name_off.assign(m + 1, 0); g->comment_off.assign(m + 1, 0);
+    for (size_t k = 0; k < m; ++k) {
+        const size_t r = (size_t)ids[k];
+        g->cum[k + 1] = g->cum[k] + (f->cum[r + 1] - f->cum[r]);
+        g->name_off[k + 1] = g->name_off[k] + (f->name_off[r + 1] - f->name_off[r]);
+        g->comment_off[k + 1] = g->comment_off[k] + (f->comment_off[r + 1] - f->comment_off[r]);
+    }
+    g->n_reads = (int64_t)m; g->n_bases = g->cum[m]; g->name_bytes = g->name_off[m]; g->comment_bytes = g->comment_off[m];
+    auto fail = [&](hipError_t e) { bwams_fastq *p = g.release(); bwams_fastq_close(p); return e; };
+    hipError_t e = hipMalloc(&g->d_enc, (size_t)g->n_bases + 64);
+    if (e == hipSuccess) e = hipMalloc(&g->d_qual, (size_t)g->n_bases + 64);
+    if (e == hipSuccess) e = hipMalloc(&g->d_names, (size_t)g->name_bytes + 64);
+    if (e == hipSuccess) e = hipMalloc(&g->d_comments, (size_t)g->comment_bytes + 64);
+    if (e != hipSuccess) { BWAMS_HIP(fail(e)); }
+    std::vector<SegMove> mv;
+    mv.reserve(4 * m);
+    for (size_t k = 0; k < m; ++k) {
+        const size_t r = (size_t)ids[k];
+        const char *se = reinterpret_cast<const char *>(f->d_enc) + f->cum[r], *sq = reinterpret_cast<const char *>(f->d_qual) + f->cum[r];
+        mv.push_back({se, reinterpret_cast<char *>(g->d_enc) + g->cum[k], f->cum[r + 1] - f->cum[r]});
+        if (f->has_qual) mv.push_back({sq, reinterpret_cast<char *>(g->d_qual) + g->cum[k], f->cum[r + 1] - f->cum[r]});
+        mv.push_back({reinterpret_cast<const char *>(f->d_names) + f->name_off[r], reinterpret_cast<char *>(g->d_names) + g->name_off[k],
+                      f->name_off[r + 1] - f->name_off[r]});
+        if (f->comment_off[r + 1] > f->comment_off[r])
+            mv.push_back({reinterpret_cast<const char *>(f->d_comments) + f->comment_off[r], reinterpret_cast<char *>(g->d_comments) + g->comment_off[k],
+                          f->comment_off[r + 1] - f->comment_off[r]});
+    }
+    int rc = segment_copy(mv, nullptr);
+    if (rc) { bwams_fastq *p = g.release(); bwams_fastq_close(p); return rc; }
+    *out = g.release();
+    return BWAMS_OK;
+}
+}  // namespace bwams
+
 extern "C" {
 
 int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fastq_t **out, int64_t *n_reads, int64_t *n_bases) {
@@ -220,8 +332,12 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     hipStream_t st = nullptr;
     std::unique_ptr<bwams_fastq> f(new bwams_fastq());
     f->device = device;
-    hipEvent_t e0, e1;
-    BWAMS_HIP(hipEventCreate(&e0)); BWAMS_HIP(hipEventCreate(&e1));
+    struct Events {                       // destroyed on every way out (the refusals return early)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evs;
+    BWAMS_HIP(hipEventCreate(&evs.a)); BWAMS_HIP(hipEventCreate(&evs.b));
+    const hipEvent_t e0 = evs.a, e1 = evs.b;
     // the text may already be in this GPU's memory (the copy kind is inferred)
     char *d_text = nullptr;
     hipPointerAttribute_t attr;
@@ -350,7 +466,6 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     BWAMS_HIP(hipStreamSynchronize(st));
     BWAMS_HIP(hipGetLastError());
     (void)hipEventElapsedTime(&f->ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (bad[1]) {
         (void)hipFree(f->d_enc); (void)hipFree(f->d_qual); (void)hipFree(f->d_names); (void)hipFree(f->d_comments);
         set_last_error("bwams_fastq_decode: a '-' in a read (nst_nt4_table maps it to 5, outside the alphabet of the kernels)");

@@ -512,6 +512,14 @@ int bwams_batch_sync(bwams_batch_t *b);
 int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
                         const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
                         int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes);
+/* process()'s MEM_F_SMARTPE branch (`mem -p`, src/fastmap.cpp:378-414): the chunk may mix reads that stand alone with interleaved
+ * pairs.  bseq_classify (src/bwa.cpp:346-362: two neighbours carrying one name are a pair, taken greedily from the left) splits it;
+ * the single reads go through mem_process_seqs as single-end with ids from n_processed, the pairs as paired-end with ids from
+ * n_processed + *n_single and pes0; every read's text returns to its place.  bwams_sam_fetch(b, buf, sam_bytes, read_off, NULL, 0)
+ * returns the merged text with *n_reads + 1 offsets (no per-region MAPQ after a merge). */
+int bwams_process_chunk_smart(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                              const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, const bwams_pestat_t *pes0,
+                              int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *n_single, int64_t *sam_bytes);
 #define BWAMS_CHUNK_COPY_COMMENT 0x100
 
 #ifdef __cplusplus

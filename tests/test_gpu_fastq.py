@@ -314,3 +314,96 @@ def test_process_chunk_paired_end_behind_the_exact_match_filter():
     for r, w in enumerate(want):
         assert sam[off[r]:off[r + 1]] == w, (r, sam[off[r]:off[r + 1]], w)
     e.close(); b.close(); ix.close()
+
+
+def _bseq_classify(names):
+    """bseq_classify (src/bwa.cpp:346-362) on the list of names -> (indices of the single reads, indices of the paired ones)."""
+    a = ([], [])
+    has_last = 1
+    n = len(names)
+    i = 1
+    while i < n:
+        if has_last:
+            if names[i] == names[i - 1]:
+                a[1].extend((i - 1, i)); has_last = 0
+            else:
+                a[0].append(i - 1)
+        else:
+            has_last = 1
+        i += 1
+    if has_last and n:
+        a[0].append(n - 1)
+    return a
+
+
+def test_smart_pairing_chunk():
+    """`mem -p` (process()'s MEM_F_SMARTPE branch, fastmap.cpp:378-414): single reads and interleaved pairs in one chunk; the restated
+    pieces run on the two sets bseq_classify makes, with the ids the reference gives them, and every text returns to its place."""
+    from util import oracle_pe_pipeline
+    g, idx, starts = repeat_genome()
+    l_pac = len(g)
+    ix = capi.Index.from_host(idx, 0)
+    ix.set_contig_names([b"chrR"])
+    rng = np.random.default_rng(77)
+    pr = np.asarray(simulate.make_read_pairs_bulk(g, 260, seed=5))
+    pr = pr.reshape(-1, pr.shape[-1])
+    singles, _, _ = simulate.make_reads(g, 150, seed=6)
+    reads, names = [], []
+    p = s_ = 0
+    while p < 260 or s_ < 150:                                  # a random mixture; now and then three reads of one name (a pair and a single)
+        if p < 260 and (s_ >= 150 or rng.random() < 0.6):
+            nm = b"frag%d" % p
+            reads += [pr[2 * p], pr[2 * p + 1]]; names += [nm + b"/1", nm + b"/2"]
+            if p % 37 == 0 and s_ < 150:
+                reads.append(singles[s_]); names.append(nm + b"/3"); s_ += 1
+            p += 1
+        else:
+            reads.append(singles[s_]); names.append(b"solo%d" % s_); s_ += 1
+    enc, cum = simulate.flatten_reads(reads)
+    quals = rng.integers(33, 74, size=len(enc), dtype=np.uint8)
+    text = _fastq_of(reads, names, quals)
+    trimmed = [nm[:-2] if nm[-2:-1] == b"/" else nm for nm in names]
+    i0, i1 = _bseq_classify(trimmed)
+    assert len(i0) == 150 and len(i1) == 520
+    NP = 4000
+    b = capi.Batch(ix, len(reads), int(cum[-1]))
+    sam, off, n_single = b.process_chunk_smart(text, n_processed=NP)
+    assert n_single == len(i0) and len(off) == len(reads) + 1 and off[-1] == len(sam)
+
+    def sub(ids):
+        rs = [reads[i] for i in ids]
+        e_, c_ = simulate.flatten_reads(rs)
+        q_ = np.concatenate([quals[cum[i]:cum[i + 1]] for i in ids])
+        return rs, e_, c_, q_, [trimmed[i] for i in ids]
+    # the single reads: mem_process_seqs(n_processed, single-end)
+    rs, e0, c0, q0, nm0 = sub(i0)
+    o = loader.OracleFMI(idx)
+    sm = o.collect_smem(e0, c0)
+    coord, soff = o.sa_lookup(sm)
+    ch, sd, choff = loader.chain_seeds(sm, coord, soff, c0, l_pac)
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, e0, c0, idx.ref_0123, l_pac)
+    fin, fin_off = loader.regs_finish(regs, reg_off, e0, c0, idx.ref_0123, l_pac)
+    for r in range(len(rs)):
+        a, e = int(fin_off[r]), int(fin_off[r + 1])
+        if e > a:
+            fin[a:e] = loader.mark_primary_se(fin[a:e], NP + r)[0]
+    want0 = loader.reg2sam_se(fin, fin_off, e0, c0, idx.ref_0123, l_pac, nm0, quals=q0, contig_names=[b"chrR"])
+    # the pairs: mem_process_seqs(n_processed + n_single, paired-end, pes0 = NULL)
+    rs, e1, c1, q1, nm1 = sub(i1)
+    c = oracle_pe_pipeline(g, idx, np.stack(rs))
+    wregs, woff, wpairs = loader.pair_pe(c["regs"], c["reg_off"], e1, c1, c["ref"], l_pac, c["pes"], id_base=(NP + len(i0)) >> 1)
+    want1 = loader.sam_pe(wregs, woff, e1, c1, c["ref"], l_pac, c["pes"], wpairs, nm1, quals=q1, contig_names=[b"chrR"])
+    want = [None] * len(reads)
+    for j, i in enumerate(i0):
+        want[i] = want0[j]
+    for j, i in enumerate(i1):
+        want[i] = want1[j]
+    for i in range(len(reads)):
+        assert sam[off[i]:off[i + 1]] == want[i], (i, names[i])
+    # only single reads / only pairs / nothing
+    only0 = _fastq_of([reads[i] for i in i0], [names[i] for i in i0], np.concatenate([quals[cum[i]:cum[i + 1]] for i in i0]))
+    s0, _, n0 = b.process_chunk_smart(only0, n_processed=NP)
+    assert n0 == len(i0) and s0 == b"".join(want0)
+    s_e, o_e, n_e = b.process_chunk_smart(b"")
+    assert s_e == b"" and n_e == 0 and len(o_e) == 1
+    b.close(); ix.close()

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_run_sam", "bwams_reg2aln_fetch",
     "bwams_index_set_contig_names", "bwams_index_set_contig_annos", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
-    "bwams_process_chunk", "bwams_process_chunk_smart", "bwams_emf_regs_merge", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_has_qual", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
+    "bwams_process_chunk", "bwams_process_chunk_smart", "bwams_process_chunk2", "bwams_emf_regs_merge", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_has_qual", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
     "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
     "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
@@ -804,6 +804,22 @@ class Batch:
         self._nseq, self._sam_bytes = n.value, nb.value
         if not fetch:
             return nb.value
+        text, off, _ = self.sam_fetch()
+        return text, off
+
+    def process_chunk2(self, fastq1: bytes, fastq2: bytes, emf=None, ert=None, seed_opt=None, opt: MemOpt | None = None, sopt=None, pes=None,
+                       n_processed: int = 0, flags: int = 0, copy_comment: bool = False):
+        """A paired-end chunk given as the two files' texts (bwams_process_chunk2) -> (SAM text, read_off)."""
+        seed_opt = seed_opt or default_seed_opt()
+        opt = opt or default_mem_opt()
+        sopt = sopt or default_sam_opt()
+        n, nb = C.c_int64(0), C.c_int64(0)
+        pp = _p(np.ascontiguousarray(pes, PESTAT_DTYPE)) if pes is not None else None
+        _chk(lib().bwams_process_chunk2(self.h, emf.h if emf is not None else None, ert.h if ert is not None else None, C.byref(seed_opt),
+                                        C.byref(opt), C.byref(sopt), fastq1, C.c_int64(len(fastq1)), fastq2, C.c_int64(len(fastq2)), pp,
+                                        C.c_int64(n_processed), flags | (0x100 if copy_comment else 0), C.byref(n), C.byref(nb)),
+             "bwams_process_chunk2")
+        self._nseq, self._sam_bytes = n.value, nb.value
         text, off, _ = self.sam_fetch()
         return text, off
 

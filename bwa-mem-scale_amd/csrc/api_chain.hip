@@ -1468,6 +1468,34 @@ int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, co
     return rc;
 }
 
+// A paired-end chunk read from two files (bseq_read_orig with ks2, src/bwa.cpp:275-318): record k of the first text and record k of the
+// second are the ends of pair k.
+int bwams_process_chunk2(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                         const bwams_sam_opt_t *sam_opt, const char *fastq1, int64_t n_bytes1, const char *fastq2, int64_t n_bytes2,
+                         const bwams_pestat_t *pes0, int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes) {
+    if (!b || !so || !mo || !sam_opt || !fastq1 || !fastq2 || n_bytes1 < 0 || n_bytes2 < 0) {
+        set_last_error("bwams_process_chunk2: batch, options and the two texts are required");
+        return BWAMS_ERR_ARG;
+    }
+    bwams_fastq_t *f1 = nullptr, *f2 = nullptr, *fq = nullptr;
+    int64_t n1 = 0, n2 = 0, nb = 0;
+    int rc = bwams_fastq_decode(b->idx->device, fastq1, n_bytes1, &f1, &n1, &nb);
+    if (rc) return rc;
+    if ((rc = bwams_fastq_decode(b->idx->device, fastq2, n_bytes2, &f2, &n2, &nb))) { bwams_fastq_close(f1); return rc; }
+    if (n1 != n2 || bwams_fastq_has_qual(f1) != bwams_fastq_has_qual(f2)) {
+        bwams_fastq_close(f1); bwams_fastq_close(f2);
+        set_last_error("bwams_process_chunk2: the two texts must hold the same number of records of one kind (" + std::to_string(n1) + " and " +
+                       std::to_string(n2) + "): cut both files at the same record");
+        return BWAMS_ERR_ARG;
+    }
+    rc = fastq_interleave(f1, f2, &fq);
+    bwams_fastq_close(f1); bwams_fastq_close(f2);
+    if (rc) return rc;
+    rc = process_decoded(b, fq, 2 * n1, emf, ert, so, mo, sam_opt, 1, pes0, n_processed, flags, sam_bytes);
+    if (!rc && n_reads) *n_reads = 2 * n1;
+    return rc;
+}
+
 // process()'s MEM_F_SMARTPE branch (src/fastmap.cpp:378-414): bseq_classify splits the chunk into the reads that stand alone and the
 // interleaved pairs; mem_process_seqs runs on the first set as single-end (ids from n_processed) and on the second as paired-end (ids
 // from n_processed + the number of single reads, pes0); every read's text returns to its place in the chunk.

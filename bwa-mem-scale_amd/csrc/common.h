@@ -133,6 +133,7 @@ struct bwams_fastq;
 namespace bwams {
 int fastq_classify(bwams_fastq *f, std::vector<uint8_t> *which);                       // bseq_classify: 1 = an end of a pair
 int fastq_subset(bwams_fastq *f, const std::vector<int64_t> &ids, bwams_fastq **out);  // those reads as a chunk of their own
+int fastq_interleave(bwams_fastq *f1, bwams_fastq *f2, bwams_fastq **out);             // read k of f1, read k of f2, ...
 }  // namespace bwams
 
 struct bwams_index {

@@ -321,6 +321,46 @@ int fastq_subset(bwams_fastq *f, const std::vector<int64_t> &ids, bwams_fastq **
     *out = g.release();
     return BWAMS_OK;
 }
+
+// bseq_read_orig with two files (bwa.cpp:275-318): read k of the first text, then read k of the second, for every k
+int fastq_interleave(bwams_fastq *f1, bwams_fastq *f2, bwams_fastq **out) {
+    *out = nullptr;
+    if (f1->n_reads != f2->n_reads || f1->device != f2->device || f1->has_qual != f2->has_qual) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(f1->device));
+    std::unique_ptr<bwams_fastq> g(new bwams_fastq());
+    g->device = f1->device; g->has_qual = f1->has_qual;
+    const size_t m = (size_t)f1->n_reads * 2;
+    bwams_fastq *src[2] = {f1, f2};
+    g->cum.assign(m + 1, 0); g->name_off.assign(m + 1, 0); g->comment_off.assign(m + 1, 0);
+    for (size_t k = 0; k < m; ++k) {
+        const bwams_fastq *f = src[k & 1];
+        const size_t r = k >> 1;
+        g->cum[k + 1] = g->cum[k] + (f->cum[r + 1] - f->cum[r]);
+        g->name_off[k + 1] = g->name_off[k] + (f->name_off[r + 1] - f->name_off[r]);
+        g->comment_off[k + 1] = g->comment_off[k] + (f->comment_off[r + 1] - f->comment_off[r]);
+    }
+    g->n_reads = (int64_t)m; g->n_bases = g->cum[m]; g->name_bytes = g->name_off[m]; g->comment_bytes = g->comment_off[m];
+    hipError_t e = hipMalloc(&g->d_enc, (size_t)g->n_bases + 64);
+    if (e == hipSuccess) e = hipMalloc(&g->d_qual, (size_t)g->n_bases + 64);
+    if (e == hipSuccess) e = hipMalloc(&g->d_names, (size_t)g->name_bytes + 64);
+    if (e == hipSuccess) e = hipMalloc(&g->d_comments, (size_t)g->comment_bytes + 64);
+    if (e != hipSuccess) { bwams_fastq_close(g.release()); BWAMS_HIP(e); }
+    std::vector<SegMove> mv;
+    mv.reserve(4 * m);
+    for (size_t k = 0; k < m; ++k) {
+        const bwams_fastq *f = src[k & 1];
+        const size_t r = k >> 1;
+        const int64_t ls = f->cum[r + 1] - f->cum[r], ln = f->name_off[r + 1] - f->name_off[r], lc = f->comment_off[r + 1] - f->comment_off[r];
+        mv.push_back({reinterpret_cast<const char *>(f->d_enc) + f->cum[r], reinterpret_cast<char *>(g->d_enc) + g->cum[k], ls});
+        if (f->has_qual) mv.push_back({reinterpret_cast<const char *>(f->d_qual) + f->cum[r], reinterpret_cast<char *>(g->d_qual) + g->cum[k], ls});
+        mv.push_back({reinterpret_cast<const char *>(f->d_names) + f->name_off[r], reinterpret_cast<char *>(g->d_names) + g->name_off[k], ln});
+        if (lc) mv.push_back({reinterpret_cast<const char *>(f->d_comments) + f->comment_off[r], reinterpret_cast<char *>(g->d_comments) + g->comment_off[k], lc});
+    }
+    int rc = segment_copy(mv, nullptr);
+    if (rc) { bwams_fastq_close(g.release()); return rc; }
+    *out = g.release();
+    return BWAMS_OK;
+}
 }  // namespace bwams
 
 extern "C" {

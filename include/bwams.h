@@ -512,6 +512,12 @@ int bwams_batch_sync(bwams_batch_t *b);
 int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
                         const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
                         int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes);
+/* The paired-end chunk as two texts (`bwa mem ref R1.fq R2.fq`: bseq_read_orig with a second file, src/bwa.cpp:275-318): record k of
+ * fastq1 and record k of fastq2 are the ends of pair k.  Both texts must hold the same number of records (the caller cuts the two files at
+ * the same record; the reference stops with a warning when one file runs out). */
+int bwams_process_chunk2(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                         const bwams_sam_opt_t *sam_opt, const char *fastq1, int64_t n_bytes1, const char *fastq2, int64_t n_bytes2,
+                         const bwams_pestat_t *pes0, int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes);
 /* process()'s MEM_F_SMARTPE branch (`mem -p`, src/fastmap.cpp:378-414): the chunk may mix reads that stand alone with interleaved
  * pairs.  bseq_classify (src/bwa.cpp:346-362: two neighbours carrying one name are a pair, taken greedily from the left) splits it;
  * the single reads go through mem_process_seqs as single-end with ids from n_processed, the pairs as paired-end with ids from

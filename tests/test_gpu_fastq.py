@@ -237,6 +237,13 @@ def test_process_chunk_is_the_stage_sequence():
     wregs_s, woff_s, wpairs_s = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, c["pes"], no_rescue=True)
     assert psam_s == b"".join(loader.sam_pe(wregs_s, woff_s, penc, pcum, c["ref"], l_pac, c["pes"], wpairs_s, pnames, quals=pquals,
                                              contig_names=[b"chrR"], sopt=loader.default_sam_opt(0x20)))
+    # the same pairs as two files (bseq_read_orig with ks2): record k of each text
+    t1 = _fastq_of(preads[0::2], [n + b"/1" for n in pnames[0::2]], np.concatenate([pquals[pcum[i]:pcum[i + 1]] for i in range(0, len(preads), 2)]))
+    t2 = _fastq_of(preads[1::2], [n + b"/2" for n in pnames[1::2]], np.concatenate([pquals[pcum[i]:pcum[i + 1]] for i in range(1, len(preads), 2)]))
+    psam2f, poff2f = b.process_chunk2(t1, t2)
+    assert psam2f == psam and np.array_equal(poff2f, poff)
+    with pytest.raises(capi.BwamsError, match="same number"):
+        b.process_chunk2(t1, t2[: t2.index(b"@pp7/2")])
     pes2 = c["pes"].copy(); pes2["low"][1] += 3
     psam2, _ = b.process_chunk(ptext, paired=True, pes=pes2)
     wregs2, woff2, wpairs2 = loader.pair_pe(c["regs"], c["reg_off"], penc, pcum, c["ref"], l_pac, pes2)

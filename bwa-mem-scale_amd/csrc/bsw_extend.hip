@@ -346,6 +346,9 @@ template <int LPT> __device__ __forceinline__ int grp_shr1(int v, int fill, int 
 }
 
 
+// __any() goes through a 0 / 1 VGPR and a compare; the ballot itself is a scalar AND with exec
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 template <int LPT, int kWin>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
     bwams_seqpair_t *__restrict__ pairs, const int32_t *__restrict__ list, const unsigned long long *n_list_p,
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
                 tb_next = alive ? (int)tr[0] : 4;
             }
             pid += nq < avail ? nq : avail;
-            if (exhausted && !__any(alive)) break;
+            if (exhausted && !wave_any(alive)) break;
         }
 
         // ---- one row of every live task
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
         const bool row = alive && beg < end;
         int key = -1, first_nz = 1 << 20, last_nz = -1, hlast = -1;
         int c_max = NEG, c_h = h1;                                  // carried into a further pass: prefix maximum, last H
-        for (int base = beg; __any(row && base < end); base += LPT * kWin) {
+        for (int base = beg; wave_any(row && base < end); base += LPT * kWin) {
             const bool in = row && base < end;
             const int jb = base + g * kWin;
             int Mv[kWin], Pl[kWin], Ev[kWin];
@@ -451,13 +454,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
                 if (act) wd = row_eh[j];
                 const int hd = (int)(wd & 0x3fffu), e = (int)((wd >> 14) & 0x3fffu);
                 const uint32_t qb = wd >> 28;
-                const int S = qb < 4u ? __builtin_amdgcn_sbfe(pkt, qb << 3, 8u) : pnt;
-                const int M = (act && hd) ? hd + S : 0;
+                // byte qb of {pnt : pkt} (v_perm_b32: selector 0-3 = bytes of pkt, 4 = the low byte of pnt), sign-extended
+                const int S = __builtin_amdgcn_sbfe((int)__builtin_amdgcn_perm((uint32_t)pnt, (uint32_t)pkt, qb), 0u, 8u);
+                const int M = hd ? hd + S : 0;                      // a column outside [beg, end) read wd = 0: M = 0 there
                 int tj = M - oe_ins;
                 tj = tj > 0 ? tj : 0;
-                const int x = act ? tj + j * e_ins : NEG;
+                // columns >= end lie to the right of every live one and nothing of theirs is stored or carried (a further pass
+                // exists only when all of this pass's columns are live): their term may enter the running maximum
+                const int x = tj + j * e_ins;
                 run = run > x ? run : x;
-                Mv[c] = M; Pl[c] = run; Ev[c] = e; Qb[c] = qb;
+                Mv[c] = M; Pl[c] = run; Ev[c] = e; Qb[c] = wd;
             }
             const int scan = grp_scan_max<LPT>(run, g);
             int Lex = grp_shr1<LPT>(scan, NEG, g);
@@ -484,17 +490,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
             for (int c = 0; c < kWin; ++c) {
                 const int j = jb + c;
                 const bool act = in && j < end;
-                int hl = c ? Hh[c - 1] : h_in;
-                if (j == beg) hl = h1;
+                // column beg is lane 0's first column of the first pass, where h_in = c_h = h1 already: no select for it
+                const int hl = c ? Hh[c - 1] : h_in;
                 if (act) {
-                    row_eh[j] = (uint32_t)hl | ((uint32_t)E2[c] << 14) | (Qb[c] << 28);
+                    const uint32_t he = (uint32_t)hl | ((uint32_t)E2[c] << 14);
+                    row_eh[j] = (he & 0x0fffffffu) | (Qb[c] & ~0x0fffffffu);      // v_bfi_b32: the query base stays where it is
                     const int k = (Hh[c] << 8) | j;
                     key = key > k ? key : k;
                     if (hl != 0 || E2[c] != 0) { first_nz = first_nz < j ? first_nz : j; last_nz = j; }
-                    if (j == end - 1) hlast = Hh[c];
                 }
             }
-            if (__any(row && base + LPT * kWin < end)) {            // a further pass: carry the prefix maximum and the last column's H
+            {                                                       // H of column end - 1, once per pass
+                const int cl = end - 1 - jb;
+                if (in && cl >= 0 && cl < kWin) {
+                    int hv = Hh[0];
+#pragma unroll
+                    for (int c = 1; c < kWin; ++c) hv = cl == c ? Hh[c] : hv;
+                    hlast = hv;
+                }
+            }
+            if (wave_any(row && base + LPT * kWin < end)) {            // a further pass: carry the prefix maximum and the last column's H
                 const int pm = grp_all_max<LPT>(scan);
                 c_max = c_max > pm ? c_max : pm;
                 c_h = grp_all_max<LPT>(g == LPT - 1 ? Hh[kWin - 1] : -1);

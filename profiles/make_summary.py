@@ -106,6 +106,10 @@ for p in ("pmc_fetch_ert", "pmc_write_ert", "pmc_sq_ert"):
         E[c] = sum(x) / len(x)
 
 r1 = P["smem_search_kernel<true> (SMEM round 1)"]
+# passes of the hot path in one run = launches of SMEM round 1: the bench's steps (1 warm-up + 2 timed) and the three text-to-text
+# calls of its sam_side.fastq_to_sam leg (bwams_process_chunk runs the same kernels on the same reads)
+n_pass = N.get("smem_search_kernel<true> (SMEM round 1)", 3)
+n_pass_trace = sum(int(r["Calls"]) for r in rows if "smem_search_kernel<true>" in r["Name"]) or 3
 fetch, write = r1["FETCH_SIZE"] * 1024, r1["WRITE_SIZE"] * 1024
 alg = bench["roofline"]["bytes_per_launch"]
 with open(f"profiles/{rnd}_summary.md", "w") as f:
@@ -115,12 +119,13 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
             "--steps 2 --warmup 1 --no-cpu-baseline --no-pe` plus one `--pmc` pass per counter group (never combined "
             f"with tracing); summarised by `profiles/make_summary.py`.  Raw: `profiles/{rnd}_kernel_stats.csv`.\n\n")
     f.write("## Kernel time (library kernels; rocPRIM kernels omitted; the index-build kernels run once, untimed by bench.py)\n\n"
-            "3 steps per run (1 warm-up + 2 timed); kernels that run once per extension round or per query-length class have "
-            "several calls per step, so the per-step column is total / 3.\n\n| kernel | calls | avg ms | ms per step |\n|---|---|---|---|\n")
+            f"{n_pass_trace} passes of the hot path per run (1 warm-up + 2 timed steps, and 3 text-to-text calls of `sam_side.fastq_to_sam`, which run "
+            "the same kernels on the same reads); kernels that run once per extension round or per query-length class have "
+            f"several calls per pass, so the per-step column is total / {n_pass_trace}.\n\n| kernel | calls | avg ms | ms per step |\n|---|---|---|---|\n")
     for r in rows:
         s = short(r["Name"])
         if s:
-            f.write(f"| {s} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['TotalDurationNs'])/3e6:.2f} |\n")
+            f.write(f"| {s} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['TotalDurationNs'])/n_pass_trace/1e6:.2f} |\n")
     pe = newest(src + "/trace_pe/*/*_kernel_stats.csv")
     if pe and "paired_end" in bench:
         shutil.copy(pe[0], f"profiles/{rnd}_pe_kernel_stats.csv")
@@ -148,7 +153,7 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
     f.write(f"\n`roofline.launch_ms` measured live by `bench.py` with HIP events in the run below: {bench['roofline']['launch_ms']} ms "
             "(the rocprofv3 average above covers warm-up + timed launches of the profiled run).\n\n")
     f.write("## PMC per launch (uncorrected counter values; average over the launches of one run)\n\n"
-            "| kernel | launches / 3 steps | FETCH_SIZE (GB) | WRITE_SIZE (GB) | TCC hit / miss (M req) | ACTIVE_INST_ANY / WAVE_CYCLES | WAIT_ANY / WAVE_CYCLES | VALU / SALU wave-insts (G) |\n|---|---|---|---|---|---|---|---|\n")
+            "| kernel | launches per run | FETCH_SIZE (GB) | WRITE_SIZE (GB) | TCC hit / miss (M req) | ACTIVE_INST_ANY / WAVE_CYCLES | WAIT_ANY / WAVE_CYCLES | VALU / SALU wave-insts (G) |\n|---|---|---|---|---|---|---|---|\n")
     for s, c in P.items():
         if "FETCH_SIZE" not in c:
             continue
@@ -170,8 +175,8 @@ Round-1 search kernel per launch: algorithmic bytes {alg/1e9:.2f} GB; corrected 
 L2 misses per launch {r1.get('TCC_MISS_sum',0)/1e6:.0f} M = {r1.get('TCC_MISS_sum',0)/(bench['roofline']['launch_ms']*1e-3)/1e9:.1f} G lines/s; `tools/ubench_gather` (mode 1, the kernel's quad-cooperative
 fetch, a 12 GiB table) tops out at 48 G random 64-byte blocks/s = 3.07 TB/s of useful bytes = 0.38 of peak when every block is its own line.
 
-Banded-SW kernels per step: {sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3e9:.1f} G vector and
-{sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3e9:.1f} G scalar wave-instructions (issue rates: integer VALU 555-570 G/s measured by `tools/ubench_valu.hip` = 4.4 cycles per SIMD, add/sub 910 G/s;
+Banded-SW kernels per step: {sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / n_pass / 1e9:.1f} G vector and
+{sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / n_pass / 1e9:.1f} G scalar wave-instructions (issue rates: integer VALU 555-570 G/s measured by `tools/ubench_valu.hip` = 4.4 cycles per SIMD, add/sub 910 G/s;
 614.4 G SALU/s at one per cycle per CU, 2.4 GHz) in `stage_ms.ext_total` = {bench['stage_ms']['ext_total']} ms.
 
 ## Smith-Waterman kernels alone, against the real reference objects on the host cores
@@ -194,8 +199,8 @@ json.dump({"genome_mbp": bench["config"]["genome_mbp"], "reads": bench["config"]
            "correction": "HBM read bytes = 2 x FETCH_SIZE (calibrated with tools/ubench_gather: one 128-B line per random request), WRITE_SIZE exact",
            "smem_round1_measured_frac": round((2 * fetch + write) / (bench["roofline"]["launch_ms"] * 1e-3) / 8e12, 4),
            "smem_round1_l2_hit_miss": [int(r1.get("TCC_HIT_sum", 0)), int(r1.get("TCC_MISS_sum", 0))],
-           "bsw_valu_insts": int(sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3),
-           "bsw_salu_insts": int(sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / 3),
+           "bsw_valu_insts": int(sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / n_pass),
+           "bsw_salu_insts": int(sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / n_pass),
            "ert_walk_hbm_bytes_per_launch": int(2 * E["FETCH_SIZE"] * 1024 + E.get("WRITE_SIZE", 0) * 1024) if "FETCH_SIZE" in E else None,
            "ert_walk_valu_salu_vmem_insts": [int(E.get("SQ_INSTS_VALU", 0)), int(E.get("SQ_INSTS_SALU", 0)), int(E.get("SQ_INSTS_VMEM_RD", 0))] if E else None,
            "commit": os.popen("git rev-parse --short HEAD").read().strip(),

@@ -506,9 +506,11 @@ int bwams_batch_sync(bwams_batch_t *b);
  * useErt form of mate rescue); pes0: NULL = infer the insert-size statistics from the chunk (mem_pestat), as mem_process_seqs does;
  * n_processed: reads processed before this chunk (the hash seeds of mem_mark_primary_se / mem_pair); flags: BWAMS_PAIR_NO_RESCUE
  * (MEM_F_NO_RESCUE) and BWAMS_CHUNK_COPY_COMMENT (`mem -C`: without it the comments of the FASTQ headers are dropped, src/fastmap.cpp:335-342).
+ * sam_opt->flag carries the reference's MEM_F_* bits: MEM_F_ALL / NO_MULTI / SOFTCLIP / KEEP_SUPP_MAPQ / REF_HDR act in the text, MEM_F_PRIMARY5 /
+ * NOPAIRING / NO_RESCUE before it (bwams_pair_run_sam); MEM_F_PE and MEM_F_SMARTPE are the caller's choice of entry point (paired, _smart).
  * The text stays on the device: bwams_sam_fetch(b, buf, sam_bytes, read_off, NULL, 0) returns it with one offset per read.  The batch must
  * have been created for at least the chunk's reads and bases, the index must carry its sequence names.  Inputs the device path refuses
- * (multi-line / FASTA text, unsupported flags) return BWAMS_ERR_UNSUPPORTED: run that chunk on the host. */
+ * (multi-line FASTQ records, unsupported flags) return BWAMS_ERR_UNSUPPORTED: run that chunk on the host. */
 int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
                         const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, int32_t paired, const bwams_pestat_t *pes0,
                         int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *sam_bytes);

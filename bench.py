@@ -547,6 +547,18 @@ def main():
                                         "SAM text left in HBM at the end (host transfers and gz excluded); never `value`"}
     if e2e_bytes != sam_bytes:
         raise SystemExit(f"[bench] FASTQ -> SAM run produced {e2e_bytes} bytes of text, the staged run {sam_bytes}")
+    # the same call with the text in pageable host memory on both sides (what a caller without device buffers pays): never `value`
+    sam_h = np.empty(int(sam_bytes) + 16, np.uint8)
+    off_h = np.empty(n_seq_ + 1, np.int64)
+    t0 = time.perf_counter()
+    hb_ = batch.process_chunk(fq_text, seed_opt=seed_opt, opt=mem_opt, sopt=sopt_, n_processed=first, fetch=False)
+    capi._chk(capi.lib().bwams_sam_fetch(batch.h, capi._p(sam_h), len(sam_h), capi._p(off_h), None, 0), "bwams_sam_fetch")
+    pcie_ms = (time.perf_counter() - t0) * 1e3
+    sam_side["fastq_to_sam"]["pcie_inclusive"] = {
+        "ms_per_chunk": round(pcie_ms, 2), "Mreads_per_s": round(n_seq_ / (pcie_ms * 1e-3) / 1e6, 3),
+        "host_bytes_up": len(fq_text), "host_bytes_down": int(hb_) + 8 * (n_seq_ + 1),
+        "note": "FASTQ text in pageable host memory -> SAM text and its per-read offsets in pageable host memory, one call + bwams_sam_fetch"}
+    del sam_h, off_h
     del row, fq_text, d_fq, got_
     del aln_, cig_, md_, text_, tb, mq_, aln_r_
 

@@ -360,13 +360,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
     uint32_t *const row_eh = qwin_lds + (size_t)(((threadIdx.x >> 6) * TPW + q) * cols);
     const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    int pk[5], pn[5];                                              // score rows of the matrix, one per target base
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        pk[t] = (int)(((uint32_t)(uint8_t)prm.mat[t * 5 + 0]) | ((uint32_t)(uint8_t)prm.mat[t * 5 + 1] << 8) |
-                      ((uint32_t)(uint8_t)prm.mat[t * 5 + 2] << 16) | ((uint32_t)(uint8_t)prm.mat[t * 5 + 3] << 24));
-        pn[t] = prm.mat[t * 5 + 4];
+    // score rows of the matrix, one per target base: {four scores packed to bytes, the score against N}; a lane picks its task's row
+    // with one LDS read per DP row instead of a chain of selects
+    __shared__ uint2 pk_tab[5];
+    if (threadIdx.x < 5) {
+        const int t = threadIdx.x;
+        pk_tab[t] = make_uint2(((uint32_t)(uint8_t)prm.mat[t * 5 + 0]) | ((uint32_t)(uint8_t)prm.mat[t * 5 + 1] << 8) |
+                               ((uint32_t)(uint8_t)prm.mat[t * 5 + 2] << 16) | ((uint32_t)(uint8_t)prm.mat[t * 5 + 3] << 24),
+                               (uint32_t)(int)prm.mat[t * 5 + 4]);
     }
+    __syncthreads();
     const int64_t n_list = (int64_t)*n_list_p;
     const unsigned long long kLeaders = LPT == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;   // lane 0 of every task slot
     int64_t pid = 0, pid_end = 0;
@@ -427,8 +430,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
         int tb = tb_next;
         tb = tb > 4 ? 4 : tb;
         if (alive && i + 1 < tlen) tb_next = tr[i + 1];
-        const int pkt = tb == 0 ? pk[0] : tb == 1 ? pk[1] : tb == 2 ? pk[2] : tb == 3 ? pk[3] : pk[4];
-        const int pnt = tb == 0 ? pn[0] : tb == 1 ? pn[1] : tb == 2 ? pn[2] : tb == 3 ? pn[3] : pn[4];
+        const uint2 pp = pk_tab[tb];
+        const int pkt = (int)pp.x, pnt = (int)pp.y;
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;

@@ -541,10 +541,12 @@ class Ert:
         _chk(lib().bwams_ert_info(self.h, C.byref(k), C.byref(x), C.byref(rl), C.byref(nb), ms), "bwams_ert_info")
         return {"kmer": k.value, "xmer": x.value, "read_len": rl.value, "mlt_bytes": nb.value, "build_ms": list(ms)}
 
-    def fetch(self):
+    def fetch(self, pad: int = 0):
+        """-> (kmer_table, mlt_table); with pad the returned tree array is a view of a buffer `pad` bytes longer (a host
+        reader that loads 5- / 8-byte fields near the end needs no copy of a 48 GB array to be safe)"""
         i = self.info()
         kt = np.zeros(4 ** i["kmer"], dtype=np.uint64)
-        mt = np.zeros(max(i["mlt_bytes"], 1), dtype=np.uint8)
+        mt = np.zeros(max(i["mlt_bytes"], 1) + pad, dtype=np.uint8)
         _chk(lib().bwams_ert_fetch(self.h, _p(kt), _p(mt)), "bwams_ert_fetch")
         return kt, mt[:i["mlt_bytes"]]
 

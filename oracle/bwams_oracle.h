@@ -260,6 +260,21 @@ int64_t orc_ert_collect(const orc_ert_t *e, const bwams_seed_opt_t *opt, const u
                         const uint8_t *skip, int32_t nseq, bwams_smem_t *out, int64_t cap, int64_t *sa_coord,
                         int64_t sa_cap, int64_t *sa_off);
 
+/* ---- the reference's own ERT walk (ert_walk_oracle.c): get_seeds[_prefix] / reseed[_prefix] / last and every tree-walk
+ * variant of src/ertseeding.cpp restated function by function, i.e. the MEM records (forward / fetch_leaves /
+ * end_correction) and the hit array in the order the walk pushes them: what mem_kernel1_core_ert hands mem_chain_new. ---- */
+enum {
+    ORC_ERTW_ASSERT    = 1,     /* one of the reference's asserts would have fired */
+    ORC_ERTW_LEP_RANGE = 2,     /* a LEP bit beyond the 320-bit vector */
+    ORC_ERTW_STACK     = 4      /* the visited-node stack popped empty / overflowed */
+};
+int64_t orc_ert_walk(const orc_ert_t *e, const bwams_seed_opt_t *opt, const uint8_t *enc, const int64_t *cum, const uint8_t *skip,
+                     int32_t nseq, bwams_ert_mem_t *mems, int64_t mem_cap, int64_t *mem_off, uint64_t *hits, int64_t hit_cap,
+                     int64_t *hit_off, int32_t *flags_out);
+int64_t orc_ert_walk_collect(const orc_ert_t *e, const bwams_seed_opt_t *opt, const uint8_t *enc, const int64_t *cum,
+                             const uint8_t *skip, int32_t nseq, bwams_smem_t *out, int64_t cap, int64_t *sa_coord, int64_t sa_cap,
+                             int64_t *sa_off, uint8_t *cls, int32_t *flags_out);
+
 #ifdef __cplusplus
 }
 #endif

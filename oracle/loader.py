@@ -309,6 +309,24 @@ class OracleERT:
         self.e = OrcErt(kmer, xmer, read_len, hit_threshold, self.kmer_table.ctypes.data, self.mlt_pad.ctypes.data,
                         int(nb.value), self.ref.ctypes.data, len(self.ref))
 
+    @classmethod
+    def from_tables(cls, kmer_table, mlt, ref_0123, kmer: int = 15, xmer: int = 4, read_len: int = 151, hit_threshold: int = 256):
+        """An index that already exists (read from files, or fetched from the GPU builder).  `mlt` must be a view of a
+        buffer at least 16 bytes longer than itself (capi.Ert.fetch(pad=16)): the decoder loads 5- / 8-byte fields."""
+        L = lib()
+        L.orc_ert_collect.restype = C.c_int64
+        L.orc_ert_collect.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        self = cls.__new__(cls)
+        self.fmi = None
+        self.kmer_table = np.ascontiguousarray(kmer_table, dtype=np.uint64)
+        self.mlt = mlt
+        self.mlt_pad = mlt
+        assert mlt.flags["C_CONTIGUOUS"] and mlt.base is not None and mlt.base.nbytes >= mlt.nbytes + 16
+        self.ref = np.ascontiguousarray(ref_0123, dtype=np.uint8)
+        self.e = OrcErt(kmer, xmer, read_len, hit_threshold, self.kmer_table.ctypes.data, self.mlt.ctypes.data,
+                        int(len(mlt)), self.ref.ctypes.data, len(self.ref))
+        return self
+
     def profile(self, read, i: int, M: int = 20):
         q = np.ascontiguousarray(read, dtype=np.uint8)
         out = np.zeros(M, dtype=np.uint8)
@@ -342,6 +360,63 @@ class OracleERT:
             break
         assert n >= 0, f"orc_ert_collect -> {n}"
         return out[:n].copy(), coord[:off[n]].copy(), off[:n + 1].copy()
+
+    def walk(self, enc, cum, opt: SeedOpt | None = None, skip=None):
+        """The reference's own walk (ert_walk_oracle.c) -> (mems as the walk pushed them, mem_off, hits, hit_off, flags)."""
+        opt = opt or default_seed_opt()
+        nseq = len(cum) - 1
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        cum = np.ascontiguousarray(cum, dtype=np.int64)
+        sk = np.ascontiguousarray(skip, dtype=np.uint8) if skip is not None else None
+        mem_cap = 3 * int(cum[-1] - cum[0]) + 64
+        hit_cap = mem_cap * 8 + 1024
+        L = lib()
+        L.orc_ert_walk.restype = C.c_int64
+        L.orc_ert_walk.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                                      C.c_void_p, C.c_void_p]
+        while True:
+            mems = np.zeros(mem_cap, dtype=ERT_MEM_DTYPE)
+            hits = np.zeros(hit_cap, dtype=np.uint64)
+            mem_off = np.zeros(nseq + 1, dtype=np.int64)
+            hit_off = np.zeros(nseq + 1, dtype=np.int64)
+            flags = C.c_int32(0)
+            n = L.orc_ert_walk(C.byref(self.e), C.byref(opt), _p(enc), _p(cum), _p(sk), nseq, _p(mems), mem_cap, _p(mem_off),
+                               _p(hits), hit_cap, _p(hit_off), C.byref(flags))
+            if n == -1 and hit_cap < (1 << 31):
+                hit_cap *= 8
+                continue
+            break
+        assert n >= 0, f"orc_ert_walk -> {n}"
+        return mems[:n].copy(), mem_off, hits[:hit_off[nseq]].copy(), hit_off, int(flags.value)
+
+    def walk_collect(self, enc, cum, opt: SeedOpt | None = None, skip=None):
+        """The reference's own walk in collect()'s layout -> (smems, sa_coord, sa_off, cls, flags); cls bit 0 forward,
+        bit 1 fetch_leaves, bit 2 end_correction != 0."""
+        opt = opt or default_seed_opt()
+        nseq = len(cum) - 1
+        cap = 3 * int(cum[-1] - cum[0]) + 64
+        out = np.zeros(cap, dtype=SMEM_DTYPE)
+        cls = np.zeros(cap, dtype=np.uint8)
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        cum = np.ascontiguousarray(cum, dtype=np.int64)
+        sk = np.ascontiguousarray(skip, dtype=np.uint8) if skip is not None else None
+        sa_cap = cap * 8 + 1024
+        L = lib()
+        L.orc_ert_walk_collect.restype = C.c_int64
+        L.orc_ert_walk_collect.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                                              C.c_void_p, C.c_void_p]
+        while True:
+            coord = np.zeros(sa_cap, dtype=np.int64)
+            off = np.zeros(cap + 1, dtype=np.int64)
+            flags = C.c_int32(0)
+            n = L.orc_ert_walk_collect(C.byref(self.e), C.byref(opt), _p(enc), _p(cum), _p(sk), nseq, _p(out), cap, _p(coord),
+                                       sa_cap, _p(off), _p(cls), C.byref(flags))
+            if n == -1 and sa_cap < (1 << 30):
+                sa_cap *= 8
+                continue
+            break
+        assert n >= 0, f"orc_ert_walk_collect -> {n}"
+        return out[:n].copy(), coord[:off[n]].copy(), off[:n + 1].copy(), cls[:n].copy(), int(flags.value)
 
 
 def bsw_pairs(pairs, ref, qer, w: int, opt: SwOpt | None = None):

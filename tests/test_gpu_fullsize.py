@@ -178,3 +178,98 @@ def test_half_million_pairs_properties_and_sampled_parity(big):
         for f in ("rb", "re", "qb", "qe", "score", "sub", "sub_n", "csub", "secondary", "hash", "n_comp_is_alt", "seedcov"):
             assert np.array_equal(got[f], w[f]), (p, f)
     b.close()
+
+
+def test_configs2_index_set_ert_plus_emf_sampled_parity(big):
+    """BASELINE configs[2]'s index set at full size — ERT (k = 15: 8 GiB k-mer table + the trees) and the EMF (L = 150)
+    built on the GPU beside the FM-index, 1 M reads: EMF probe, mem_perfect2reg for the reads it resolves, ERT seeding for
+    the others, chaining ... de-duplication.  Checked (a) at full size: ERT seeds and sampled positions == the FM-index
+    path's on the same chunk, resolved reads carry no seeds; (b) on a random sample of 2 500 reads against the oracle IN
+    ERT MODE: the restated find_perfect_match_entry over the fetched table, the reference's own walk restated function by
+    function (oracle/ert_walk_oracle.c) over the fetched ERT, its mem_t records and hit arrays through the restated tail
+    (mem_chain_new ... mem_sort_dedup_patch), region by region."""
+    from bwams import emf as emf_mod
+    from util import seeds_equal_but_junction
+    g, host, ix, reads, enc, cum, contigs = big
+    l_pac = len(g)
+    ert = capi.Ert.build(ix)
+    emf = capi.Emf.build(ix, seed_len=150, slack=1.1)
+    b = capi.Batch(ix, N_READS, int(cum[-1]), max_smem=32 * N_READS, max_sa=128 * N_READS)
+    b.seed_upload(enc, cum)
+    opt, sopt = capi.default_mem_opt(), capi.default_seed_opt()
+    b.emf_run(emf)
+    perfect, code = b.emf_fetch(N_READS)
+    eregs, eoff, erev = b.emf_regs(emf, opt)
+    b.seed_run_ert(ert, sopt, with_sa=True)
+    sm, coord, sa_off = b.seed_fetch()
+    b.chain_run(opt)
+    b.extend_run(opt)
+    n = b.dedup_run(opt)
+    fin, off = b.dedup_fetch()
+    # --- (a) full size
+    resolved = (code == 3) | (code == 4)
+    assert 0.3 < resolved.mean() < 0.7                                       # about half of the simulated reads are error free
+    assert not resolved[sm["rid"]].any()                                      # resolved reads were not seeded
+    per_e = np.diff(eoff)
+    assert np.all(per_e[resolved] >= 1) and not per_e[~resolved].any()
+    assert not np.diff(off)[resolved].any()                                   # ... and have no regions from the normal path
+    first = eregs[eoff[:-1][resolved]]
+    assert np.all(first["score"] == 150) and np.all(first["qb"] == 0) and np.all(first["qe"] == 150)
+    if host.ref_seq_len > 2 ** 32:
+        assert int(coord.max()) >= 2 ** 32 and int(eregs["rb"].max()) >= 2 ** 32
+    b.seed_run(sopt, with_sa=True)                                            # the FM-index path, same skip flags
+    fm, fcoord, foff = b.seed_fetch()
+    assert len(fm) == len(sm) and np.array_equal(foff, sa_off)
+    for f in ("rid", "m", "n", "s"):
+        assert np.array_equal(fm[f], sm[f]), f
+    assert np.all((coord == fcoord) | ((fcoord == 0) & (coord < 128)))
+    full = host.ref_seq_len > 2 ** 32
+    assert not full or int(sm["s"].max()) > 500                               # seeds beyond max_occ: the stride sampled them
+    # --- (b) the oracle in ERT mode on a sample
+    rng = np.random.default_rng(8)
+    heavy = np.unique(sm["rid"][sm["s"] > (500 if full else 50)])
+    pick = np.unique(np.concatenate([rng.choice(N_READS, size=2300, replace=False), rng.choice(heavy, size=min(200, len(heavy)), replace=False)]))
+    kt, mt = ert.fetch(pad=16)
+    e = loader.OracleERT.from_tables(kt, mt, host.ref_0123)
+    loc_t, seed_t = emf.fetch_table()
+    tab = emf_mod.EmfTable(150, l_pac, loc_t, seed_t)
+    oe = loader.OracleEMF(tab, host.ref_0123)
+    n_res = 0
+    for r in pick:
+        c, fl, lo = oe.probe(reads[r])
+        assert c == code[r], r
+        if c in (3, 4):
+            assert (fl, lo) == (int(perfect[r, 0]), int(perfect[r, 1])), r
+            want, wrev = oe.perfect2reg(reads[r], fl, lo, l_pac, contigs=contigs)
+            got = eregs[eoff[r]:eoff[r + 1]]
+            assert len(got) == len(want) and erev[r] == wrev, r
+            for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedlen0", "n_comp_is_alt", "sub", "csub", "seedcov"):
+                assert np.array_equal(got[f], want[f]), (r, f)
+            n_res += 1
+    assert n_res > 800
+    sub = pick[~resolved[pick]]
+    sub_enc, sub_cum = simulate.flatten_reads(reads[sub])
+    oo = loader.default_seed_opt()
+    ref_sm, ref_coord, ref_off, cls, flags = e.walk_collect(sub_enc, sub_cum, oo)
+    assert flags == 0 and {0, 1, 2, 4} <= set(np.unique(cls).tolist())
+    # the device's seeds of the sampled reads, re-numbered to the sample
+    pos_of = np.full(N_READS, -1, np.int64)
+    pos_of[sub] = np.arange(len(sub))
+    keep = np.flatnonzero(pos_of[sm["rid"]] >= 0)
+    dev_sm = sm[keep].copy()
+    dev_sm["rid"] = pos_of[dev_sm["rid"]]
+    cnt = (sa_off[keep + 1] - sa_off[keep]).astype(np.int64)
+    dev_off = np.concatenate([[0], np.cumsum(cnt)])
+    dev_coord = np.concatenate([coord[sa_off[t]:sa_off[t + 1]] for t in keep]) if len(keep) else np.zeros(0, np.int64)
+    assert seeds_equal_but_junction(dev_sm, dev_coord, dev_off, ref_sm, ref_coord, ref_off, sub_cum, l_pac) == []
+    assert not full or int(ref_sm["s"].max()) > 500
+    mems, mem_off, hits, hit_off, flags = e.walk(sub_enc, sub_cum, oo)
+    ch, sd, choff = loader.chain_new_ert(mems, mem_off, hits, hit_off, sub_cum, l_pac, contigs=contigs)
+    regs, reg_off, _ = loader.chain2aln(ch, sd, choff, sub_enc, sub_cum, host.ref_0123, l_pac, contigs=contigs)
+    wfin, wfin_off = loader.regs_finish(regs, reg_off, sub_enc, sub_cum, host.ref_0123, l_pac, contigs=contigs)
+    for k, r in enumerate(sub):
+        a, w = fin[off[r]:off[r + 1]], wfin[wfin_off[k]:wfin_off[k + 1]]
+        assert len(a) == len(w), r
+        for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "n_comp_is_alt", "frac_rep"):
+            assert np.array_equal(a[f], w[f]), (r, f)
+    b.close(); emf.close(); ert.close()

@@ -645,6 +645,40 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     BWAMS_HIP(hipEventRecord(b->ev[0], st));
     launch_pack_reads(b->d_enc, b->d_cum, b->nseq, b->read_w, b->read_cw, b->d_packed, st);
     launch_mark(b->d_ctr, 0, st);
+    // Rounds 1-3 as ONE persistent launch with three work queues (fmi_seed.hip: smem_fused_kernel) unless the FMA tables are
+    // resident (their jump tables belong to the three-launch kernels) or an option does not fit the 8-byte work item.
+    static const bool fused_env = !(getenv("BWAMS_SEED_FUSED") && atoi(getenv("BWAMS_SEED_FUSED")) == 0);
+    const bool fused = fused_env && b->nseq > 0 && !a.fmi.all_smem && !a.fmi.last_smem && opt->split_width < 65535 &&
+                       b->prev_cap < 65536 && b->nseq < ((int64_t)1 << 31);
+    if (fused) {
+        FusedLaunch fa;
+        fa.q2 = reinterpret_cast<unsigned long long *>(b->d_work2);
+        int64_t want = b->q2_cap_hint > 0 ? b->q2_cap_hint : 2 * b->nseq + 4096;
+        const int64_t most = b->pool_cap * (int64_t)sizeof(Round2Work) / 8;     // what the work buffer holds as 8-byte items
+        fa.q2_cap = want < most ? want : most;
+        fa.split_len = split_len;
+        fa.split_width = opt->split_width;
+        fa.max_intv = opt->max_mem_intv;
+        fa.min_seed_len3 = opt->min_seed_len + 1;
+        BWAMS_HIP(hipMemsetAsync(fa.q2, 0, (size_t)fa.q2_cap * 8, st));
+        BWAMS_HIP(hipEventRecord(b->ev[8], st));
+        launch_smem_fused(a, fa, b->cu_count, st);
+        BWAMS_HIP(hipEventRecord(b->ev[9], st));
+        for (int e = 10; e <= 13; ++e) BWAMS_HIP(hipEventRecord(b->ev[e], st));
+        BWAMS_HIP(hipEventRecord(b->ev[3], st));
+        BWAMS_HIP(hipGetLastError());
+        BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        if ((int64_t)b->h_ctr->q2_reserved > fa.q2_cap) {
+            // more round-2 pivots than the queue was sized for: the launch dropped the excess; size it and run again
+            if (fa.q2_cap >= most) {
+                set_last_error("round-2 work queue overflow: need " + std::to_string(b->h_ctr->q2_reserved) + " items");
+                return BWAMS_ERR_CAPACITY;
+            }
+            b->q2_cap_hint = (int64_t)b->h_ctr->q2_reserved + (int64_t)b->h_ctr->q2_reserved / 4 + 4096;
+            return seed_run_once(b, opt, with_sa);
+        }
+    } else {
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
     if (b->nseq > 0) launch_smem_round1(a, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[9], st));
@@ -682,6 +716,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     // the SMEM count sizes the sort: one small read-back
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
+    }
     const int64_t n_slots = (int64_t)b->h_ctr->n_smem_total;      // pool slots handed out (holes included)
     const int64_t n = (int64_t)b->h_ctr->n_smem_valid;           // real SMEMs
     b->n_smem = n;

@@ -96,6 +96,8 @@ struct DevCounters {
     unsigned long long ert_kmer, ert_nodes, ert_ref;   // ERT profile kernel: k-mer entries read, tree records decoded, text bytes compared
     unsigned long long work_head3, n_ext3, n_blk3, n_smem3;   // SMEM round 3 (it may run beside round 2): its own cursor and counts, folded in by mark_kernel(3)
     unsigned long long n_rest;           // extension: slots behind the requests of the last selection (an upper bound of the undecided seeds)
+    unsigned long long q2_reserved, q2_head, r1_done;   // fused seeding launch: round-2 items appended / taken, round-1 reads finished
+    unsigned long long fz_valid[3], fz_ext[3], fz_blk[3];   // fused seeding launch: SMEMs, extensions, blocks per round
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };
 
@@ -202,6 +204,7 @@ struct bwams_batch {
     uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
     uint32_t *d_vals = nullptr, *d_vals2 = nullptr;
     bwams::Round2Work *d_work2 = nullptr;
+    int64_t q2_cap_hint = 0;              // fused seeding launch: round-2 queue size a chunk asked for (0: 2 nseq + 4096)
     int64_t *d_sa_off = nullptr;         // max_smem + 1
     int64_t *d_sa_cnt = nullptr;         // max_smem + 1
     int64_t *d_sa_coord = nullptr;

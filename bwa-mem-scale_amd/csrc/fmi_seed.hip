@@ -834,6 +834,471 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
     flush_counters(a.ctr, n_ext, n_blk, true);
 }
 
+// ---- rounds 1, 2 and 3 in ONE persistent launch ------------------------------------------------
+// Three launches end in three tails: a lane carries a read for ~500 dependent steps, so when a round's queue
+// runs dry every lane is still in the middle of one, and the launch ends ≈ 5 ms later with few lanes at work
+// (profiles/r02_notes.md, note 50: at the marginal rate round 1 runs at 0.52 of the byte peak, launched alone
+// at 0.31).  Here the three rounds are three WORK QUEUES of one launch:
+//   Q1  the reads of round 1 (every pivot of a read; the longest items, taken first);
+//   Q2  the round-2 pivots (bwamem.cpp:721-738), appended BY THE LANES OF ROUND 1 as they emit an SMEM that is
+//       long and rare enough — a producer / consumer queue inside the launch;
+//   Q3  the reads of round 3 (forward-only, independent of rounds 1-2), which fill whatever is idle.
+// A lane that finishes an item takes the next one from Q1, else Q2, else Q3, so the only tail left is the one
+// of the last short items.  Hand-off of a Q2 item between workgroups on different XCDs (private, non-coherent
+// L2s): an item is ONE naturally aligned 8-byte granule {valid | rid | x | min_intv} written by one agent-scope
+// relaxed atomic store and polled by agent-scope relaxed atomic loads (the guide's data-tagged granule: the data
+// is the flag, no fence); slots are handed out by atomic counters (q2_reserved by producers, q2_head by
+// consumers); the array is zeroed before every launch.  Termination: r1_done counts finished round-1 reads;
+// once it equals nseq no further item can appear, q2_reserved is final, and a ticket beyond it is void.
+constexpr unsigned long long kQ2Valid = 1ull << 63;
+__device__ __forceinline__ unsigned long long q2_pack(uint32_t rid, int x, int min_intv) {
+    return kQ2Valid | ((unsigned long long)rid << 32) | ((unsigned long long)(x & 0xffff) << 16) | (unsigned long long)(min_intv & 0xffff);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long bcast0_u64(unsigned long long v) {
+    return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+           (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+struct FusedOut {
+    long long base;
+    int used;
+    uint32_t em1, em2, em3;   // this lane's SMEMs per round (scalars: an indexed array would live in scratch)
+};
+
+// wave_emit of the fused launch: the SMEM record, and for a round-1 SMEM that qualifies (bwamem.cpp:726-738) the
+// round-2 work item.  MUST be called by all 64 lanes at a wave-uniform point.
+__device__ __forceinline__ void fused_emit(const SeedLaunch &a, const FusedLaunch &fa, FusedOut &w, bool flag, int mode,
+                                           uint32_t rid, uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t s) {
+    const unsigned long long mask = __ballot(flag);
+    if (!mask) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int cnt = __popcll(mask);
+    if (w.base < 0 || w.used + cnt > kChunk) {
+        if (w.base >= 0) {
+            const long long slot = w.base + w.used + lane;
+            if (w.used + lane < kChunk && slot < a.pool_cap) a.pool[slot].rid = kHoleRid;
+        }
+        w.used = 0;
+        w.base = (long long)wave_ticket(&a.ctr->n_smem_total, (unsigned long long)kChunk);
+    }
+    if (flag) {
+        const long long slot = w.base + w.used + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < a.pool_cap) {
+            bwams_smem_t r;
+            r.rid = rid; r.m = m; r.n = n; r.pad_ = 0;
+            r.k = k; r.l = l; r.s = s;
+            a.pool[slot] = r;
+        }
+        w.em1 += mode == 1; w.em2 += mode == 2; w.em3 += mode == 3;
+    }
+    w.used += cnt;
+    // round-2 work from a round-1 SMEM: pivot at its middle, min_intv = its size + 1
+    const bool push = flag && mode == 1 && (int)(n + 1 - m) >= fa.split_len && s <= (int64_t)fa.split_width;
+    const unsigned long long pm = __ballot(push);
+    if (pm) {
+        const unsigned long long b0 = wave_ticket(&a.ctr->q2_reserved, (unsigned long long)__popcll(pm));
+        if (push) {
+            const unsigned long long slot = b0 + (unsigned long long)__popcll(pm & ((1ull << lane) - 1ull));
+            if ((int64_t)slot < fa.q2_cap)
+                __hip_atomic_store(fa.q2 + slot, q2_pack(rid, (int)((n + 1 + m) >> 1), (int)(s + 1)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+enum : int { PH_WAIT2 = 16, PH_PIVOT3, PH_FWD3 };
+
+__global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_kernel(SeedLaunch a, FusedLaunch fa) {
+    const DevFmi &f = a.fmi;
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63);
+    const int cap = a.prev_cap;
+    extern __shared__ uint32_t lds_reads[];
+    uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
+    PrevList prev;
+    prev.glob = a.prev + slot * (int64_t)cap;
+    prev.ring = reinterpret_cast<uint4 *>(lds_reads + (a.reads_in_lds ? a.read_w * kBlock : 0)) + threadIdx.x;
+    ReadView rv;
+    rv.lds_col = lds_col;
+    rv.gl = a.packed;
+    rv.cw = a.read_cw;
+    const unsigned long long nseq = (unsigned long long)a.nseq;
+
+    int phase = PH_FETCH;
+    int mode = 1;                         // round this lane's current item belongs to
+    uint32_t rid = 0;
+    int len = 0, x = 0, next_x = 0, min_intv = 1;
+    int64_t ck = 0, cl = 0, cs = 0;
+    int cn = 0;
+    int j = 0;
+    int num_prev = 0, base = 0, p = 0, num_curr = 0, cur_m = 0;
+    int32_t curr_s = -1;
+    bool first = true;
+    int bwd_a = 0;
+    uint32_t ne1 = 0, ne2 = 0, ne3 = 0, nb1 = 0, nb2 = 0, nb3 = 0;   // extensions / blocks per round
+    unsigned long long pend = 0;          // Q2 ticket this lane waits on (PH_WAIT2)
+    FusedOut wo;
+    wo.base = -1; wo.used = 0; wo.em1 = wo.em2 = wo.em3 = 0;
+    WaveTickets wt1, wt3;
+    wt1.next = 0; wt1.left = 0; wt3.next = 0; wt3.left = 0;
+    bool q1_empty = false, q3_empty = fa.max_intv <= 0;       // wave-uniform
+    unsigned long long q2_seen = 0;                            // wave-uniform: Q2 tickets up to here were handed out
+    bool done = false;                                         // wave-uniform: round 1 has ended everywhere
+    unsigned long long q2_final = 0;                           // valid once done: the number of Q2 items
+
+    while (true) {
+        bool em = false;
+        uint32_t em_m = 0, em_n = 0;
+        int64_t em_k = 0, em_l = 0, em_s = 0;
+        bool fin1 = false;                                     // this lane ended a round-1 read in this iteration
+        // ---- leave a finished pivot (rounds 1, 2) -----------------------------------------
+        if (phase == PH_BWD_END) {
+            if (num_prev != 0) {
+                int64_t qk, ql, qs;
+                int qn;
+                prev_get(prev, base, 0, qk, ql, qs, qn);
+                if (qn - cur_m + 1 >= a.min_seed_len) {
+                    em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)qn; em_k = qk; em_l = ql; em_s = qs;
+                }
+            }
+            x = next_x;
+            phase = mode == 1 ? PH_PIVOT : PH_FETCH;
+        }
+        fused_emit(a, fa, wo, em, mode, rid, em_m, em_n, em_k, em_l, em_s);
+        em = false;
+        // ---- the next work item ---------------------------------------------------------------
+        if (__ballot(phase == PH_FETCH || phase == PH_WAIT2)) {
+            bool want = phase == PH_FETCH;
+            if (!q1_empty) {
+                unsigned long long t = 0;
+                const bool got = take_ticket(&a.ctr->work_head, wt1, want, t);
+                if (got && t < nseq) {
+                    rid = (uint32_t)t;
+                    mode = 1;
+                    x = 0;
+                    min_intv = 1;
+                    len = (int)(a.cum[rid + 1] - a.cum[rid]);
+                    want = false;
+                    if (a.skip && a.skip[rid]) fin1 = true;     // an EMF-resolved read: round 1 has nothing to do
+                    else { phase = PH_PIVOT; read_take(rv, lds_col, a.packed, a.read_w, rid); }
+                }
+                if (__any(got && t >= nseq)) q1_empty = true;
+            }
+            // Q2: tickets are taken only while items are known to exist; one that overshoots waits (PH_WAIT2)
+            if (q1_empty && __ballot(want)) {
+                unsigned long long res = 0;
+                if (lane == 0) res = ld_agent(&a.ctr->q2_reserved);
+                res = bcast0_u64(res);
+                if (res > (unsigned long long)fa.q2_cap) res = (unsigned long long)fa.q2_cap;
+                if (res > q2_seen) {
+                    const unsigned long long wm = __ballot(want);
+                    const int cnt = __popcll(wm);
+                    const unsigned long long b0 = wave_ticket(&a.ctr->q2_head, (unsigned long long)cnt);
+                    q2_seen = b0 + (unsigned long long)cnt;
+                    if (want) {
+                        pend = b0 + (unsigned long long)__popcll(wm & ((1ull << lane) - 1ull));
+                        phase = PH_WAIT2;
+                        want = false;
+                    }
+                }
+            }
+            if (__ballot(phase == PH_WAIT2) && !done) {
+                // has round 1 ended everywhere?  (then q2_reserved is final and tickets beyond it are void)
+                unsigned long long d = 0;
+                if (lane == 0) d = ld_agent(&a.ctr->r1_done);
+                d = bcast0_u64(d);
+                if (d >= nseq) {
+                    unsigned long long res = 0;
+                    if (lane == 0) res = ld_agent(&a.ctr->q2_reserved);
+                    q2_final = bcast0_u64(res);
+                    if (q2_final > (unsigned long long)fa.q2_cap) q2_final = (unsigned long long)fa.q2_cap;
+                    done = true;
+                }
+            }
+            if (phase == PH_WAIT2) {
+                unsigned long long g = 0;
+                if ((int64_t)pend < fa.q2_cap) g = ld_agent(fa.q2 + pend);
+                if (g & kQ2Valid) {
+                    rid = (uint32_t)((g >> 32) & 0x7fffffffu);
+                    x = (int)((g >> 16) & 0xffff);
+                    min_intv = (int)(g & 0xffff);
+                    mode = 2;
+                    len = (int)(a.cum[rid + 1] - a.cum[rid]);
+                    phase = PH_PIVOT;
+                    read_take(rv, lds_col, a.packed, a.read_w, rid);
+                } else if (done && pend >= q2_final) {
+                    phase = PH_FETCH;                           // a void ticket
+                    want = true;
+                }
+            }
+            if (!q3_empty && q1_empty) {
+                unsigned long long t = 0;
+                const bool got = take_ticket(&a.ctr->work_head3, wt3, want, t);
+                if (got && t < nseq) {
+                    rid = (uint32_t)t;
+                    mode = 3;
+                    x = 0;
+                    len = (int)(a.cum[rid + 1] - a.cum[rid]);
+                    want = false;
+                    if (!(a.skip && a.skip[rid])) { phase = PH_PIVOT3; read_take(rv, lds_col, a.packed, a.read_w, rid); }
+                }
+                if (__any(got && t >= nseq)) q3_empty = true;
+            }
+            // nothing left anywhere: leave
+            if (q1_empty && q3_empty && __ballot(want)) {
+                if (!done) {
+                    unsigned long long d = 0;
+                    if (lane == 0) d = ld_agent(&a.ctr->r1_done);
+                    d = bcast0_u64(d);
+                    if (d >= nseq) {
+                        unsigned long long res = 0;
+                        if (lane == 0) res = ld_agent(&a.ctr->q2_reserved);
+                        q2_final = bcast0_u64(res);
+                        if (q2_final > (unsigned long long)fa.q2_cap) q2_final = (unsigned long long)fa.q2_cap;
+                        done = true;
+                    }
+                }
+                if (done && q2_seen >= q2_final && want) phase = PH_EXIT;
+            }
+        }
+        {
+            const unsigned long long fm = __ballot(fin1);
+            if (fm && lane == 0) atomicAdd(&a.ctr->r1_done, (unsigned long long)__popcll(fm));
+        }
+        if (__all(phase == PH_EXIT)) break;
+        if (__all(phase == PH_EXIT || phase == PH_FETCH || phase == PH_WAIT2)) {
+            __builtin_amdgcn_s_sleep(64);                       // an idle wave: poll again in a few microseconds
+            continue;
+        }
+
+        // ---- open a pivot (rounds 1, 2) --------------------------------------------------------
+        fin1 = false;
+        if (phase == PH_PIVOT) {
+            if (x >= len) {
+                phase = PH_FETCH;
+                fin1 = mode == 1;
+            } else {
+                const int c = base_at(rv, x);
+                if (c >= 4) {
+                    x = x + 1;
+                    if (mode != 1) phase = PH_FETCH;
+                } else {
+                    ck = cnt_at(f, c);
+                    cl = cnt_at(f, 3 - c);
+                    cs = cnt_at(f, c + 1) - ck;
+                    cn = x;
+                    j = x + 1;
+                    next_x = x + 1;
+                    num_prev = 0;
+                    phase = PH_FWD;
+                }
+            }
+        }
+        // ---- open a pivot (round 3) --------------------------------------------------------------
+        if (phase == PH_PIVOT3) {
+            if (x >= len) {
+                phase = PH_FETCH;
+            } else {
+                const int c = base_at(rv, x);
+                next_x = x + 1;
+                if (c >= 4) {
+                    x = next_x;
+                } else {
+                    ck = cnt_at(f, c);
+                    cl = cnt_at(f, 3 - c);
+                    cs = cnt_at(f, c + 1) - ck;
+                    j = x + 1;
+                    phase = PH_FWD3;
+                }
+            }
+        }
+
+        bool do_ext = false;
+        int64_t ek = 0, el = 0, es = 0;
+        int ea = 0;
+        int64_t pk = 0, pl = 0, ps = 0;
+        int pn = 0;
+
+        // ---- forward phase: pre ------------------------------------------------------
+        if (phase == PH_FWD) {
+            phase = PH_FWD_END;
+            if (j < len) {
+                const int c = base_at(rv, j);
+                next_x = j + 1;
+                if (c < 4) {
+                    phase = PH_FWD;
+                    do_ext = true;
+                    ek = cl; el = ck; es = cs;
+                    ea = 3 - c;
+                }
+            }
+        }
+        if (phase == PH_FWD_END) {
+            if (cs >= min_intv) {
+                prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
+                num_prev++;
+            }
+            base = cap - num_prev;
+            j = x - 1;
+            p = 0; num_curr = 0; curr_s = -1; first = true;
+            cur_m = x;
+            phase = PH_BWD;
+        }
+        // ---- backward phase: pre -----------------------------------------------------
+        if (phase == PH_BWD && !do_ext) {
+            bool go = true;
+            if (p == 0) {
+                go = false;
+                if (num_prev != 0 && j >= 0) {
+                    bwd_a = base_at(rv, j);
+                    go = bwd_a < 4;
+                }
+            }
+            if (!go) {
+                phase = PH_BWD_END;
+            } else {
+                prev_get(prev, base, p, pk, pl, ps, pn);
+                do_ext = true;
+                ek = pk; el = pl; es = ps; ea = bwd_a;
+            }
+        }
+        // ---- round 3: pre ---------------------------------------------------------------
+        if (phase == PH_FWD3) {
+            bool stop = true;
+            if (j < len) {
+                const int c = base_at(rv, j);
+                next_x = j + 1;
+                if (c < 4) {
+                    do_ext = true;
+                    ek = cl; el = ck; es = cs;
+                    ea = 3 - c;
+                    stop = false;
+                }
+            }
+            if (stop) {
+                x = next_x;
+                phase = PH_PIVOT3;
+            }
+        }
+
+        // ---- the one extension of this iteration -------------------------------------
+        int64_t nk = 0, nl = 0, ns = 0;
+        backward_ext_coop(f, do_ext, ek, el, es, ea, nk, nl, ns);
+        if (do_ext) {
+            const uint32_t nb = ((ek >> 6) == ((ek + es) >> 6)) ? 1u : 2u;
+            ne1 += mode == 1; ne2 += mode == 2; ne3 += mode == 3;
+            nb1 += mode == 1 ? nb : 0u; nb2 += mode == 2 ? nb : 0u; nb3 += mode == 3 ? nb : 0u;
+        }
+
+        // ---- post ---------------------------------------------------------------------
+        if (do_ext && phase == PH_FWD) {
+            if (ns != cs) {
+                prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
+                num_prev++;
+            }
+            if (ns < min_intv) {
+                next_x = j;
+                phase = PH_FWD_END;
+            } else {
+                ck = nl; cl = nk; cs = ns; cn = j;
+                j++;
+            }
+            if (phase == PH_FWD_END) {
+                if (cs >= min_intv) {
+                    prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
+                    num_prev++;
+                }
+                base = cap - num_prev;
+                j = x - 1;
+                p = 0; num_curr = 0; curr_s = -1; first = true;
+                cur_m = x;
+                phase = PH_BWD;
+            }
+        } else if (do_ext && phase == PH_BWD) {
+            bool keep = false;
+            if (first) {
+                if (ns < min_intv && (pn - cur_m + 1) >= a.min_seed_len) {
+                    em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)pn; em_k = pk; em_l = pl; em_s = ps;
+                    first = false;
+                } else if (ns >= min_intv && ns != (int64_t)curr_s) {
+                    keep = true;
+                    first = false;
+                }
+            } else {
+                keep = ns >= min_intv && ns != (int64_t)curr_s;
+            }
+            if (keep) {
+                curr_s = (int32_t)ns;
+                prev_put(prev, base, num_curr, nk, nl, ns, pn);
+                num_curr++;
+            }
+            p++;
+            if (p == num_prev) {
+                num_prev = num_curr;
+                if (num_curr == 0) {
+                    phase = PH_BWD_END;
+                } else {
+                    cur_m = j;
+                    j--;
+                    p = 0; num_curr = 0; curr_s = -1; first = true;
+                }
+            }
+        } else if (do_ext && phase == PH_FWD3) {
+            ck = nl; cl = nk; cs = ns;
+            if (cs < fa.max_intv && (j - x + 1) >= fa.min_seed_len3) {
+                em = cs > 0;
+                em_m = (uint32_t)x;
+                em_n = (uint32_t)j;
+                em_k = ck; em_l = cl; em_s = cs;
+                x = next_x;
+                phase = PH_PIVOT3;
+            }
+            j++;
+        }
+        fused_emit(a, fa, wo, em, mode, rid, em_m, em_n, em_k, em_l, em_s);
+        {
+            const unsigned long long fm = __ballot(fin1);
+            if (fm && lane == 0) atomicAdd(&a.ctr->r1_done, (unsigned long long)__popcll(fm));
+        }
+    }
+    // close the wave's chunk, add up the counters
+    if (wo.base >= 0) {
+        const long long sl = wo.base + wo.used + lane;
+        if (wo.used + lane < kChunk && sl < a.pool_cap) a.pool[sl].rid = kHoleRid;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        uint32_t e = r == 0 ? wo.em1 : r == 1 ? wo.em2 : wo.em3, x1 = r == 0 ? ne1 : r == 1 ? ne2 : ne3,
+                 b1 = r == 0 ? nb1 : r == 1 ? nb2 : nb3;
+        for (int o = 32; o > 0; o >>= 1) {
+            e += __shfl_down(e, o);
+            x1 += __shfl_down(x1, o);
+            b1 += __shfl_down(b1, o);
+        }
+        if (lane == 0) {
+            if (e) atomicAdd(&a.ctr->fz_valid[r], (unsigned long long)e);
+            if (x1) atomicAdd(&a.ctr->fz_ext[r], (unsigned long long)x1);
+            if (b1) atomicAdd(&a.ctr->fz_blk[r], (unsigned long long)b1);
+        }
+    }
+}
+
+// after the fused launch: the per-round figures in the fields the three-launch path fills
+__global__ void mark_fused_kernel(DevCounters *ctr, long long q2_cap) {
+    unsigned long long v = 0, e = 0, b = 0;
+    for (int r = 0; r < 3; ++r) {
+        v += ctr->fz_valid[r]; e += ctr->fz_ext[r]; b += ctr->fz_blk[r];
+        ctr->valid_after[r] = v; ctr->ext_after[r] = e; ctr->blk_after[r] = b;
+    }
+    ctr->n_smem_valid = v; ctr->n_ext = e; ctr->n_ext_blocks = b;
+    ctr->n_work2 = ctr->q2_reserved;
+    if ((long long)ctr->q2_reserved > q2_cap) ctr->overflow = ctr->q2_reserved;
+    ctr->n_after_r1 = ctr->n_after_r2 = ctr->n_smem_total;
+}
+
 // (rid, m, n) sort key of each pooled SMEM
 __global__ void make_keys_kernel(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals,
                                  uint32_t hole_key_rid) {
@@ -904,6 +1369,11 @@ void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_coun
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {
     seed_strategy_kernel<<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
+}
+
+void launch_smem_fused(const SeedLaunch &a, const FusedLaunch &fa, int cu_count, hipStream_t st) {
+    smem_fused_kernel<<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, fa);
+    mark_fused_kernel<<<1, 1, 0, st>>>(a.ctr, (long long)fa.q2_cap);
 }
 
 void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, uint32_t hole_key_rid,

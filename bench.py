@@ -683,7 +683,7 @@ def main():
         # rounds 1-3 run as ONE persistent launch (three work queues) unless the FMA tables are resident or BWAMS_SEED_FUSED=0:
         # then ms_smem_r1 brackets that launch, the other two brackets are empty, and the kernel's algorithmic bytes are those of
         # the three rounds together (the reads are taken twice: by round 1 and by round 3)
-        fused_seed = mean("ms_smem_r2") < 1e-4 and mean("ms_smem_r3") < 1e-4 and st.n_ext_round[1] > 0
+        fused_seed = mean("ms_smem_r2") < 0.05 and mean("ms_smem_r3") < 0.05 and st.n_ext_round[1] > 0
         r1_bytes = 64 * st.n_blk_round[0] + n_bases + 40 * st.n_smem[0]
         if fused_seed:
             r1_bytes = 64 * sum(st.n_blk_round) + 2 * n_bases + 40 * sum(st.n_smem)

@@ -54,6 +54,9 @@ void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStre
 // rounds 1, 2, 3 in one launch + the per-round counters folded into the fields the three launches fill
 void launch_smem_fused(const SeedLaunch &a, const FusedLaunch &fa, int cu_count, hipStream_t st);
 
+// the search kernels' Occ table ("occ16", see DevFmi): n_mini = (rows >> 5) + 1 entries, n_super = (rows >> 15) + 1 entries
+void launch_occ16_build(const uint4 *cp, int64_t n_blk, int64_t sentinel, uint4 *mini, uint4 *super, int64_t *hy1_dev, hipStream_t st);
+
 // FMA table builders (__build_all_smem_table / __build_last_smem_table): one lane per table entry
 void launch_build_fma(const DevFmi &f, int all_bp, uint32_t *all_tab, int last_bp, uint4 *last_tab, hipStream_t st);
 

@@ -133,6 +133,185 @@ __device__ __forceinline__ void backward_ext_coop(const DevFmi &f, bool need, in
     nl = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
 }
 
+// ---- the search kernels' own Occ table ("occ16", DevFmi::mini / super / hy1) -------------------------
+// The quad-cooperative fetch above buys whole 64-byte requests at the price of ≈ 130 vector instructions of register
+// transposes per extension, 32 registers of block data and wave-uniform control flow around every extension.  With the
+// BWT as 2-bit codes and the counts split into three levels (16-bit per 32 rows, 32-bit per 32 768 rows, 64-bit per
+// 2^32 rows) one Occ evaluation is ONE 16-byte load per lane (+ one from the 3 MB super table, L2 resident): no
+// cooperation, eight registers of data, and the four counts come out of three masked popcounts
+//     H = high bits, L = low bits of the codes:  T = |H & L|, G = |H| - T, C = |L| - T, A = y - |H| - |L| + T.
+// The algorithmic bytes of an extension stay what SURVEY §8(d) defines (the reference's 64-byte blocks it touches).
+struct Occ16 {
+    uint32_t v0, v1, v2, v3;       // occurrences of A, C, G, T in the rows between the 2^32-row stretch's start and pos
+};
+// The wave-uniform constants of the table, read once per kernel into scalar registers.  (Selecting between fields of the
+// argument block inside the extension makes the compiler fold "select of loads" into "load of a selected address", which
+// keeps the whole argument block in scratch memory; values that went through readfirstlane are opaque to that fold.)
+struct Occ16Const {
+    const uint4 *mini, *super;
+    int64_t c0, c1, c2, c3;        // count[b]
+    int64_t h0, h1, h2, h3;        // occurrences of b in rows [0, 2^32)
+    int64_t sentinel;
+};
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)v >> 32)) << 32) |
+                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
+__device__ __forceinline__ Occ16Const occ16_const(const DevFmi &f) {
+    Occ16Const c;
+    c.mini = f.mini; c.super = f.super;
+    c.c0 = uni64(f.count[0]); c.c1 = uni64(f.count[1]); c.c2 = uni64(f.count[2]); c.c3 = uni64(f.count[3]);
+    c.h0 = uni64(f.hy1_0); c.h1 = uni64(f.hy1_1); c.h2 = uni64(f.hy1_2); c.h3 = uni64(f.hy1_3);
+    c.sentinel = uni64(f.sentinel);
+    return c;
+}
+__device__ __forceinline__ Occ16 occ16_eval(const int64_t sentinel, int64_t pos, const uint4 mb, const uint4 sb) {
+    const uint32_t y = (uint32_t)pos & 31u;
+    const uint32_t w0 = y < 16u ? y : 16u, w1 = y < 16u ? 0u : y - 16u;
+    const uint32_t m0 = w0 == 16u ? 0x55555555u : (((1u << (2u * w0)) - 1u) & 0x55555555u);
+    const uint32_t m1 = ((1u << (2u * w1)) - 1u) & 0x55555555u;
+    const uint32_t L0 = mb.x & m0, H0 = (mb.x >> 1) & m0, L1 = mb.y & m1, H1 = (mb.y >> 1) & m1;
+    const uint32_t pL = __popc(L0) + __popc(L1), pH = __popc(H0) + __popc(H1), pT = __popc(L0 & H0) + __popc(L1 & H1);
+    // the sentinel row holds no base (stored as code 0): not an A
+    const uint32_t sent = (uint64_t)(pos - 1 - sentinel) < (uint64_t)y ? 1u : 0u;
+    Occ16 o;
+    o.v0 = (y - pL - pH + pT - sent) + (mb.z & 0xffffu) + sb.x;
+    o.v1 = (pL - pT) + (mb.z >> 16) + sb.y;
+    o.v2 = (pH - pT) + (mb.w & 0xffffu) + sb.z;
+    o.v3 = pT + (mb.w >> 16) + sb.w;
+    return o;
+}
+// backwardExt of one lane, no cooperation: lanes without work skip the loads.  The table's constants arrive as scalars
+// BY VALUE (see Occ16Const).
+__device__ __forceinline__ void backward_ext16(const uint4 *mini, const uint4 *super, const int64_t c0, const int64_t c1,
+                                               const int64_t c2, const int64_t c3, const int64_t h0, const int64_t h1,
+                                               const int64_t h2, const int64_t h3, const int64_t sentinel, bool need, int64_t k,
+                                               int64_t l, int64_t s, int a, int64_t &nk, int64_t &nl, int64_t &ns) {
+    if (!need) return;
+    const int64_t sp = k, ep = k + s;
+    // the end of the interval usually lies in the same super block as its start, often in the same 32 rows: no second request
+    const int64_t isp = sp >> 5, iep = ep >> 5;
+    const uint4 msp = mini[isp];
+    const uint4 ssp = super[isp >> 10];
+    uint4 mep = msp, sep = ssp;
+    if (iep != isp) {
+        mep = mini[iep];
+        if ((iep >> 10) != (isp >> 10)) sep = super[iep >> 10];
+    }
+    const Occ16 osp = occ16_eval(sentinel, sp, msp, ssp), oep = occ16_eval(sentinel, ep, mep, sep);
+    const bool hs = (sp >> 32) != 0, he = (ep >> 32) != 0;              // texts of up to 2^33 rows: two stretches
+    const bool cross = hs != he;
+    const int64_t s0 = (int64_t)oep.v0 - (int64_t)osp.v0 + (cross ? h0 : 0);
+    const int64_t s1 = (int64_t)oep.v1 - (int64_t)osp.v1 + (cross ? h1 : 0);
+    const int64_t s2 = (int64_t)oep.v2 - (int64_t)osp.v2 + (cross ? h2 : 0);
+    const int64_t s3 = (int64_t)oep.v3 - (int64_t)osp.v3 + (cross ? h3 : 0);
+    const int64_t l3 = l + ((k <= sentinel && k + s > sentinel) ? 1 : 0);
+    const int64_t l2 = l3 + s3, l1 = l2 + s2, l0 = l1 + s1;
+    const uint32_t oa = a == 0 ? osp.v0 : a == 1 ? osp.v1 : a == 2 ? osp.v2 : osp.v3;
+    const int64_t ca = a == 0 ? c0 : a == 1 ? c1 : a == 2 ? c2 : c3;
+    const int64_t ha = a == 0 ? h0 : a == 1 ? h1 : a == 2 ? h2 : h3;
+    nk = ca + (hs ? ha : 0) + (int64_t)oa;
+    ns = a == 0 ? s0 : a == 1 ? s1 : a == 2 ? s2 : s3;
+    nl = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
+}
+#ifndef BWAMS_BLK_CACHE
+#define BWAMS_BLK_CACHE 1
+#endif
+template <bool OCC16>
+__device__ __forceinline__ void ext_step(const DevFmi &f, const Occ16Const &oc, bool need, int64_t k, int64_t l, int64_t s, int a,
+                                         int64_t &nk, int64_t &nl, int64_t &ns) {
+    if (OCC16) backward_ext16(oc.mini, oc.super, oc.c0, oc.c1, oc.c2, oc.c3, oc.h0, oc.h1, oc.h2, oc.h3, oc.sentinel, need, k, l, s, a, nk, nl, ns);
+    else backward_ext_coop(f, need, k, l, s, a, nk, nl, ns);
+}
+
+// cp (the reference's CP_OCC blocks) -> mini / super.  One thread per 64-row block: two mini entries, and the super entry
+// when the block opens a super block.  Counts of a level are relative to the start of the enclosing block of the next level.
+__global__ void occ16_build_kernel(const uint4 *__restrict__ cp, int64_t n_blk, uint4 *__restrict__ mini,
+                                   uint4 *__restrict__ super) {
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blk; b += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 c01 = cp[4 * b], c23 = cp[4 * b + 1], h01 = cp[4 * b + 2], h23 = cp[4 * b + 3];
+        const int64_t cnt[4] = {(int64_t)mk64(c01.x, c01.y), (int64_t)mk64(c01.z, c01.w), (int64_t)mk64(c23.x, c23.y),
+                                (int64_t)mk64(c23.z, c23.w)};
+        const uint64_t hot[4] = {mk64(h01.x, h01.y), mk64(h01.z, h01.w), mk64(h23.x, h23.y), mk64(h23.z, h23.w)};
+        const int64_t sb = (b >> 9) << 9, hb = (b >> 26) << 26;
+        const uint4 s01 = cp[4 * sb], s23 = cp[4 * sb + 1], y01 = cp[4 * hb], y23 = cp[4 * hb + 1];
+        const int64_t scnt[4] = {(int64_t)mk64(s01.x, s01.y), (int64_t)mk64(s01.z, s01.w), (int64_t)mk64(s23.x, s23.y),
+                                 (int64_t)mk64(s23.z, s23.w)};
+        const int64_t hcnt[4] = {(int64_t)mk64(y01.x, y01.y), (int64_t)mk64(y01.z, y01.w), (int64_t)mk64(y23.x, y23.y),
+                                 (int64_t)mk64(y23.z, y23.w)};
+        for (int half = 0; half < 2; ++half) {
+            uint64_t codes = 0;
+            for (int j = 0; j < 32; ++j) {
+                const int bit = 63 - (half * 32 + j);
+                const uint64_t c = ((hot[1] >> bit) & 1) ? 1 : ((hot[2] >> bit) & 1) ? 2 : ((hot[3] >> bit) & 1) ? 3 : 0;
+                codes |= c << (2 * j);
+            }
+            uint32_t rel[4];
+            for (int c = 0; c < 4; ++c)
+                rel[c] = (uint32_t)(cnt[c] - scnt[c]) + (half ? (uint32_t)__popcll(hot[c] >> 32) : 0u);
+            mini[2 * b + half] = make_uint4((uint32_t)codes, (uint32_t)(codes >> 32), rel[0] | (rel[1] << 16), rel[2] | (rel[3] << 16));
+        }
+        if (b == sb)
+            super[b >> 9] = make_uint4((uint32_t)(cnt[0] - hcnt[0]), (uint32_t)(cnt[1] - hcnt[1]), (uint32_t)(cnt[2] - hcnt[2]),
+                                       (uint32_t)(cnt[3] - hcnt[3]));
+    }
+}
+
+// backwardExt with the lane's two most recent blocks kept in registers.  Four extensions in five belong to the backward
+// phase, where the entries of a column are NESTED intervals visited from the innermost outwards: the block holding k (and the one
+// holding k + s) is the block of the previous entry in 40 % of the cases (counted on the bench reads, profiles/r03_notes.md).
+// Those fetches were L1 / L2 hits, but requests all the same — and requests per second, not bytes, are what this kernel is short
+// of.  The cache is role-bound (start block against the previous start block, end block against the previous end block), so
+// a hit moves no data: the lane simply does not take part in the quad's fetch for its own block.
+struct BlkCache {
+    uint4 a0, a1, a2, a3, b0, b1, b2, b3;
+    int32_t ta, tb;                     // block numbers held (rows >> 6 < 2^30), -1 = none
+};
+__device__ __forceinline__ void backward_ext_cached(const DevFmi &f, BlkCache &c, bool need, int64_t k, int64_t l, int64_t s,
+                                                    int a, int64_t &nk, int64_t &nl, int64_t &ns) {
+    const int q = (int)(threadIdx.x & 3);
+    const int64_t sp = need ? k : 0, ep = need ? k + s : 0;
+    const int32_t bs = (int32_t)(sp >> 6), be = (int32_t)(ep >> 6);
+    const bool two = need && bs != be;
+    const bool fa = need && bs != c.ta, fb = two && be != c.tb;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    if (__any(fa)) {
+        uint4 A0 = zero, A1 = zero, A2 = zero, A3 = zero;
+        const int64_t b0 = quad_bcast64<0>(sp) >> 6, b1 = quad_bcast64<1>(sp) >> 6;
+        const int64_t b2 = quad_bcast64<2>(sp) >> 6, b3 = quad_bcast64<3>(sp) >> 6;
+        const uint32_t n = fa ? 1u : 0u;
+        if (qdpp<0x00>(n)) A0 = f.cp[(b0 << 2) + q];
+        if (qdpp<0x55>(n)) A1 = f.cp[(b1 << 2) + q];
+        if (qdpp<0xAA>(n)) A2 = f.cp[(b2 << 2) + q];
+        if (qdpp<0xFF>(n)) A3 = f.cp[(b3 << 2) + q];
+        quad_transpose4(A0, A1, A2, A3, q);
+        if (fa) { c.a0 = A0; c.a1 = A1; c.a2 = A2; c.a3 = A3; c.ta = bs; }
+    }
+    if (__any(fb)) {
+        uint4 B0 = zero, B1 = zero, B2 = zero, B3 = zero;
+        const int64_t b0 = quad_bcast64<0>(ep) >> 6, b1 = quad_bcast64<1>(ep) >> 6;
+        const int64_t b2 = quad_bcast64<2>(ep) >> 6, b3 = quad_bcast64<3>(ep) >> 6;
+        const uint32_t n = fb ? 1u : 0u;
+        if (qdpp<0x00>(n)) B0 = f.cp[(b0 << 2) + q];
+        if (qdpp<0x55>(n)) B1 = f.cp[(b1 << 2) + q];
+        if (qdpp<0xAA>(n)) B2 = f.cp[(b2 << 2) + q];
+        if (qdpp<0xFF>(n)) B3 = f.cp[(b3 << 2) + q];
+        quad_transpose4(B0, B1, B2, B3, q);
+        if (fb) { c.b0 = B0; c.b1 = B1; c.b2 = B2; c.b3 = B3; c.tb = be; }
+    }
+    Occ4 osp, oep;
+    occ_from_block(c.a0, c.a1, c.a2, c.a3, sp, osp);
+    occ_from_block(two ? c.b0 : c.a0, two ? c.b1 : c.a1, two ? c.b2 : c.a2, two ? c.b3 : c.a3, ep, oep);
+    const int64_t s0 = oep.v[0] - osp.v[0], s1 = oep.v[1] - osp.v[1];
+    const int64_t s2 = oep.v[2] - osp.v[2], s3 = oep.v[3] - osp.v[3];
+    const int64_t l3 = l + ((k <= f.sentinel && k + s > f.sentinel) ? 1 : 0);
+    const int64_t l2 = l3 + s3, l1 = l2 + s2, l0 = l1 + s1;
+    nk = (a == 0 ? f.count[0] + osp.v[0] : a == 1 ? f.count[1] + osp.v[1]
+          : a == 2 ? f.count[2] + osp.v[2] : f.count[3] + osp.v[3]);
+    ns = a == 0 ? s0 : a == 1 ? s1 : a == 2 ? s2 : s3;
+    nl = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
+}
+
 // count[i] without dynamic indexing of the kernel argument (keeps it in SGPRs)
 __device__ __forceinline__ int64_t cnt_at(const DevFmi &f, int i) {
     return i == 0 ? f.count[0] : i == 1 ? f.count[1] : i == 2 ? f.count[2] : i == 3 ? f.count[3] : f.count[4];
@@ -414,9 +593,11 @@ enum : int { PH_FETCH = 0, PH_LOAD, PH_HOLD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BW
 
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
 // !ALL_POS: work item = (read, pivot, min_intv), one pivot (round 2).
-template <bool ALL_POS>
+template <bool ALL_POS, bool OCC16>
 __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
     const DevFmi &f = a.fmi;
+    Occ16Const oc{};
+    if (OCC16) oc = occ16_const(f);
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int cap = a.prev_cap;
     extern __shared__ uint32_t lds_reads[];
@@ -441,6 +622,12 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
     int32_t curr_s = -1;
     bool first = true;
     int bwd_a = 0;
+    BlkCache bc;
+    bc.a0 = bc.a1 = bc.a2 = bc.a3 = bc.b0 = bc.b1 = bc.b2 = bc.b3 = make_uint4(0, 0, 0, 0);
+    bc.ta = bc.tb = -1;
+    int dbg_np0 = 0, dbg_bwd = 0;
+    int64_t dbg_ls = -1, dbg_le = -1;
+    uint32_t dbg_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_ext = 0, n_blk = 0;
     WaveOut wo;
     wo.base = -1; wo.used = 0; wo.emitted = 0;
@@ -454,6 +641,11 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
         int64_t em_k = 0, em_l = 0, em_s = 0;
         // ---- leave a finished pivot -------------------------------------------------
         if (phase == PH_BWD_END) {
+            if (a.debug & 4) {                          // diagnostics: how the backward work is spread over list sizes
+                const int bk = dbg_np0 >= 120 ? 15 : dbg_np0 >> 3;
+                atomicAdd(&a.ctr->hist_n[bk], 1ull);
+                atomicAdd(&a.ctr->hist_ext[bk], (unsigned long long)dbg_bwd);
+            }
             if (num_prev != 0) {
                 int64_t qk, ql, qs;
                 int qn;
@@ -581,6 +773,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
             p = 0; num_curr = 0; curr_s = -1; first = true;
             cur_m = x;
             phase = PH_BWD;
+            dbg_np0 = num_prev; dbg_bwd = 0;
         }
         // ---- backward phase: pre -----------------------------------------------------
         if (phase == PH_BWD && !do_ext) {
@@ -603,10 +796,18 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
 
         // ---- the one extension of this iteration -------------------------------------
         int64_t nk = 0, nl = 0, ns = 0;
-        backward_ext_coop(f, do_ext, ek, el, es, ea, nk, nl, ns);
+        if (!OCC16 && BWAMS_BLK_CACHE) backward_ext_cached(f, bc, do_ext, ek, el, es, ea, nk, nl, ns);
+        else ext_step<OCC16>(f, oc, do_ext, ek, el, es, ea, nk, nl, ns);
         if (do_ext) {
             n_ext++;
             n_blk += ((ek >> 6) == ((ek + es) >> 6)) ? 1 : 2;
+            if (a.debug & 4) {                          // diagnostics: would a one-extension block cache in the lane hit?
+                const int64_t bs = ek >> 6, be = (ek + es) >> 6;
+                const bool hs = bs == dbg_ls || bs == dbg_le, he = be != bs && (be == dbg_ls || be == dbg_le);
+                const int w = phase == PH_BWD ? 0 : 4;
+                dbg_c[w + 0] += 1; dbg_c[w + 1] += be != bs; dbg_c[w + 2] += hs; dbg_c[w + 3] += he;
+                dbg_ls = bs; dbg_le = be;
+            }
         }
 
         // ---- post ---------------------------------------------------------------------
@@ -634,8 +835,10 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                 p = 0; num_curr = 0; curr_s = -1; first = true;
                 cur_m = x;
                 phase = PH_BWD;
+                dbg_np0 = num_prev; dbg_bwd = 0;
             }
         } else if (do_ext && phase == PH_BWD) {
+            dbg_bwd++;
             bool keep = false;
             if (first) {
                 if (ns < min_intv && (pn - cur_m + 1) >= a.min_seed_len) {
@@ -669,6 +872,8 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
     }
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
+    if (a.debug & 4)
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.ctr->dbg[i], (unsigned long long)dbg_c[i]);
 }
 
 // Select round-2 pivots from the round-1 SMEMs (src/bwamem.cpp:721-738).
@@ -710,8 +915,11 @@ __global__ void mark_kernel(DevCounters *ctr, int which) {
 }
 
 // Round 3: forward-only seeds.
+template <bool OCC16>
 __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int max_intv) {
     const DevFmi &f = a.fmi;
+    Occ16Const oc{};
+    if (OCC16) oc = occ16_const(f);
     extern __shared__ uint32_t lds_reads[];
     uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
     ReadView rv;
@@ -812,7 +1020,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
             }
         }
         int64_t nk = 0, nl = 0, ns = 0;
-        backward_ext_coop(f, do_ext, cl, ck, cs, ea, nk, nl, ns);
+        ext_step<OCC16>(f, oc, do_ext, cl, ck, cs, ea, nk, nl, ns);
         if (do_ext) {
             n_ext++;
             n_blk += ((cl >> 6) == ((cl + cs) >> 6)) ? 1 : 2;
@@ -909,10 +1117,13 @@ __device__ __forceinline__ void fused_emit(const SeedLaunch &a, const FusedLaunc
     }
 }
 
-enum : int { PH_WAIT2 = 16, PH_PIVOT3, PH_FWD3 };
+enum : int { PH_PIVOT3 = 16, PH_FWD3 };
 
+template <bool OCC16>
 __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_kernel(SeedLaunch a, FusedLaunch fa) {
     const DevFmi &f = a.fmi;
+    Occ16Const oc{};
+    if (OCC16) oc = occ16_const(f);
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int lane = (int)(threadIdx.x & 63);
     const int cap = a.prev_cap;
@@ -939,15 +1150,24 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_ke
     bool first = true;
     int bwd_a = 0;
     uint32_t ne1 = 0, ne2 = 0, ne3 = 0, nb1 = 0, nb2 = 0, nb3 = 0;   // extensions / blocks per round
-    unsigned long long pend = 0;          // Q2 ticket this lane waits on (PH_WAIT2)
     FusedOut wo;
     wo.base = -1; wo.used = 0; wo.em1 = wo.em2 = wo.em3 = 0;
-    WaveTickets wt1, wt3;
-    wt1.next = 0; wt1.left = 0; wt3.next = 0; wt3.left = 0;
+    WaveTickets wt1, wt2, wt3;
+    wt1.next = 0; wt1.left = 0; wt2.next = 0; wt2.left = 0; wt3.next = 0; wt3.left = 0;
     bool q1_empty = false, q3_empty = fa.max_intv <= 0;       // wave-uniform
-    unsigned long long q2_seen = 0;                            // wave-uniform: Q2 tickets up to here were handed out
+    bool q2_closed = false;                                    // wave-uniform: no Q2 ticket of this wave can still become valid
     bool done = false;                                         // wave-uniform: round 1 has ended everywhere
     unsigned long long q2_final = 0;                           // valid once done: the number of Q2 items
+    int r1_fin = 0;                                            // wave-uniform: finished round-1 reads not yet reported
+    uint32_t idle_polls = 0;
+    // diagnostics (BWAMS_DEBUG=2): a timeline in 10-ns ticks and the lanes at work per iteration, into ctr->dbg
+    const bool diag = (a.debug & 2) != 0;
+    unsigned long long t_start = 0, d_iters = 0, d_active = 0, d_iters_b = 0, d_active_b = 0;
+    bool d_seen_q1 = false, d_seen_done = false;
+    if (diag) {
+        t_start = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) atomicMin(&a.ctr->dbg[0], t_start);
+    }
 
     while (true) {
         bool em = false;
@@ -970,7 +1190,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_ke
         fused_emit(a, fa, wo, em, mode, rid, em_m, em_n, em_k, em_l, em_s);
         em = false;
         // ---- the next work item ---------------------------------------------------------------
-        if (__ballot(phase == PH_FETCH || phase == PH_WAIT2)) {
+        if (__ballot(phase == PH_FETCH)) {
             bool want = phase == PH_FETCH;
             if (!q1_empty) {
                 unsigned long long t = 0;
@@ -987,52 +1207,36 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_ke
                 }
                 if (__any(got && t >= nseq)) q1_empty = true;
             }
-            // Q2: tickets are taken only while items are known to exist; one that overshoots waits (PH_WAIT2)
-            if (q1_empty && __ballot(want)) {
-                unsigned long long res = 0;
-                if (lane == 0) res = ld_agent(&a.ctr->q2_reserved);
-                res = bcast0_u64(res);
-                if (res > (unsigned long long)fa.q2_cap) res = (unsigned long long)fa.q2_cap;
-                if (res > q2_seen) {
-                    const unsigned long long wm = __ballot(want);
-                    const int cnt = __popcll(wm);
-                    const unsigned long long b0 = wave_ticket(&a.ctr->q2_head, (unsigned long long)cnt);
-                    q2_seen = b0 + (unsigned long long)cnt;
-                    if (want) {
-                        pend = b0 + (unsigned long long)__popcll(wm & ((1ull << lane) - 1ull));
-                        phase = PH_WAIT2;
-                        want = false;
-                    }
+            // Q2: the wave owns a chunk of 64 tickets (one atomic per chunk: a ticket or a poll per item on ONE word would
+            // queue every wave of the chip behind that word); a wanting lane looks at the granule of the next ticket of the
+            // chunk and takes it once it is valid, otherwise it leaves the ticket where it is and looks elsewhere (Q3)
+            if (q1_empty && !q2_closed && __ballot(want)) {
+                if (wt2.left == 0) {
+                    wt2.next = wave_ticket(&a.ctr->q2_head, (unsigned long long)kTicketChunk);
+                    wt2.left = kTicketChunk;
                 }
-            }
-            if (__ballot(phase == PH_WAIT2) && !done) {
-                // has round 1 ended everywhere?  (then q2_reserved is final and tickets beyond it are void)
-                unsigned long long d = 0;
-                if (lane == 0) d = ld_agent(&a.ctr->r1_done);
-                d = bcast0_u64(d);
-                if (d >= nseq) {
-                    unsigned long long res = 0;
-                    if (lane == 0) res = ld_agent(&a.ctr->q2_reserved);
-                    q2_final = bcast0_u64(res);
-                    if (q2_final > (unsigned long long)fa.q2_cap) q2_final = (unsigned long long)fa.q2_cap;
-                    done = true;
-                }
-            }
-            if (phase == PH_WAIT2) {
+                const unsigned long long wm = __ballot(want);
+                const int rank = __popcll(wm & ((1ull << lane) - 1ull));
                 unsigned long long g = 0;
-                if ((int64_t)pend < fa.q2_cap) g = ld_agent(fa.q2 + pend);
-                if (g & kQ2Valid) {
+                const unsigned long long cand = wt2.next + (unsigned long long)rank;
+                if (want && rank < wt2.left && (int64_t)cand < fa.q2_cap) g = ld_agent(fa.q2 + cand);
+                const unsigned long long vm = __ballot(want && (g & kQ2Valid) != 0);
+                const unsigned long long bad = wm & ~vm;                 // wanting lanes without a valid item, in ticket order
+                const unsigned long long upto = bad ? ((1ull << __builtin_ctzll(bad)) - 1ull) : ~0ull;
+                const int served = __popcll(vm & upto);                  // the valid prefix
+                if (want && rank < served) {
                     rid = (uint32_t)((g >> 32) & 0x7fffffffu);
                     x = (int)((g >> 16) & 0xffff);
                     min_intv = (int)(g & 0xffff);
                     mode = 2;
                     len = (int)(a.cum[rid + 1] - a.cum[rid]);
                     phase = PH_PIVOT;
+                    want = false;
                     read_take(rv, lds_col, a.packed, a.read_w, rid);
-                } else if (done && pend >= q2_final) {
-                    phase = PH_FETCH;                           // a void ticket
-                    want = true;
                 }
+                wt2.next += (unsigned long long)served;
+                wt2.left -= served;
+                if (done && wt2.next >= q2_final) { q2_closed = true; wt2.left = 0; }     // the rest of the chunk is void
             }
             if (!q3_empty && q1_empty) {
                 unsigned long long t = 0;
@@ -1047,9 +1251,10 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_ke
                 }
                 if (__any(got && t >= nseq)) q3_empty = true;
             }
-            // nothing left anywhere: leave
+            // nothing to take right now.  Has round 1 ended everywhere?  Then q2_reserved is final, tickets beyond it are void,
+            // and a wave whose chunk is used up or void may leave.
             if (q1_empty && q3_empty && __ballot(want)) {
-                if (!done) {
+                if (!done && (idle_polls++ & 3) == 0) {
                     unsigned long long d = 0;
                     if (lane == 0) d = ld_agent(&a.ctr->r1_done);
                     d = bcast0_u64(d);
@@ -1061,16 +1266,23 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_ke
                         done = true;
                     }
                 }
-                if (done && q2_seen >= q2_final && want) phase = PH_EXIT;
+                if (done && wt2.left > 0 && wt2.next >= q2_final) { q2_closed = true; wt2.left = 0; }
+                if (q2_closed && want) phase = PH_EXIT;
             }
         }
+        // finished round-1 reads are reported per wave, in batches: one atomic per read on one word would be ~1 M of them
         {
             const unsigned long long fm = __ballot(fin1);
-            if (fm && lane == 0) atomicAdd(&a.ctr->r1_done, (unsigned long long)__popcll(fm));
+            r1_fin += __popcll(fm);
+            const bool r1_active = __any(mode == 1 && phase != PH_FETCH && phase != PH_EXIT);
+            if (r1_fin >= 32 || (r1_fin > 0 && q1_empty && !r1_active)) {
+                if (lane == 0) atomicAdd(&a.ctr->r1_done, (unsigned long long)r1_fin);
+                r1_fin = 0;
+            }
         }
         if (__all(phase == PH_EXIT)) break;
-        if (__all(phase == PH_EXIT || phase == PH_FETCH || phase == PH_WAIT2)) {
-            __builtin_amdgcn_s_sleep(64);                       // an idle wave: poll again in a few microseconds
+        if (__all(phase == PH_EXIT || phase == PH_FETCH)) {
+            __builtin_amdgcn_s_sleep(64);                       // an idle wave: look again in a few microseconds
             continue;
         }
 
@@ -1184,9 +1396,23 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_ke
             }
         }
 
+        if (diag) {
+            const int act = __popcll(__ballot(do_ext));
+            if (q1_empty) { d_iters_b++; d_active_b += act; } else { d_iters++; d_active += act; }
+            if (q1_empty && !d_seen_q1) {
+                d_seen_q1 = true;
+                const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+                if (lane == 0) { atomicMin(&a.ctr->dbg[1], t); atomicMax(&a.ctr->dbg[2], t); }
+            }
+            if (done && !d_seen_done) {
+                d_seen_done = true;
+                const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+                if (lane == 0) atomicMin(&a.ctr->dbg[3], t);
+            }
+        }
         // ---- the one extension of this iteration -------------------------------------
         int64_t nk = 0, nl = 0, ns = 0;
-        backward_ext_coop(f, do_ext, ek, el, es, ea, nk, nl, ns);
+        ext_step<OCC16>(f, oc, do_ext, ek, el, es, ea, nk, nl, ns);
         if (do_ext) {
             const uint32_t nb = ((ek >> 6) == ((ek + es) >> 6)) ? 1u : 2u;
             ne1 += mode == 1; ne2 += mode == 2; ne3 += mode == 3;
@@ -1259,10 +1485,14 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_ke
             j++;
         }
         fused_emit(a, fa, wo, em, mode, rid, em_m, em_n, em_k, em_l, em_s);
-        {
-            const unsigned long long fm = __ballot(fin1);
-            if (fm && lane == 0) atomicAdd(&a.ctr->r1_done, (unsigned long long)__popcll(fm));
-        }
+        r1_fin += __popcll(__ballot(fin1));
+    }
+    if (diag && lane == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&a.ctr->dbg[4], t);
+        atomicMin(&a.ctr->dbg[9], t);
+        atomicAdd(&a.ctr->dbg[5], d_iters); atomicAdd(&a.ctr->dbg[6], d_active);
+        atomicAdd(&a.ctr->dbg[7], d_iters_b); atomicAdd(&a.ctr->dbg[8], d_active_b);
     }
     // close the wave's chunk, add up the counters
     if (wo.base >= 0) {
@@ -1341,6 +1571,11 @@ void launch_pack_reads(const uint8_t *enc, const int64_t *cum, int64_t nseq, int
     pack_reads_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(enc, cum, nseq, W, cw, packed);
 }
 
+void launch_occ16_build(const uint4 *cp, int64_t n_blk, int64_t sentinel, uint4 *mini, uint4 *super, int64_t *hy1_dev, hipStream_t st) {
+    (void)sentinel; (void)hy1_dev;
+    if (n_blk > 0) occ16_build_kernel<<<256 * 16, 256, 0, st>>>(cp, n_blk, mini, super);
+}
+
 void launch_build_fma(const DevFmi &f, int all_bp, uint32_t *all_tab, int last_bp, uint4 *last_tab, hipStream_t st) {
     const int64_t na = (int64_t)1 << (2 * all_bp), nl = (int64_t)1 << (2 * last_bp);
     build_all_smem_kernel<<<(unsigned)((na + 255) / 256), 256, 0, st>>>(f, all_bp, all_tab);
@@ -1354,7 +1589,8 @@ int64_t seed_pool_slack(int cu_count) { return seed_max_threads(cu_count) / 64 *
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
 
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st) {
-    smem_search_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
+    if (a.fmi.mini) smem_search_kernel<true, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
+    else smem_search_kernel<true, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
 }
 
 void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
@@ -1364,15 +1600,18 @@ void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap,
 
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     // the number of items is only known on the device: launch the persistent grid at chip size
-    smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+    if (a.fmi.mini) smem_search_kernel<false, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+    else smem_search_kernel<false, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {
-    seed_strategy_kernel<<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
+    if (a.fmi.mini) seed_strategy_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
+    else seed_strategy_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
 }
 
 void launch_smem_fused(const SeedLaunch &a, const FusedLaunch &fa, int cu_count, hipStream_t st) {
-    smem_fused_kernel<<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, fa);
+    if (a.fmi.mini) smem_fused_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, fa);
+    else smem_fused_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, fa);
     mark_fused_kernel<<<1, 1, 0, st>>>(a.ctr, (long long)fa.q2_cap);
 }
 

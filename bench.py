@@ -680,13 +680,7 @@ def main():
         n_bases = int(cums[-1][-1])
         # algorithmic bytes of the round-1 search kernel per launch:
         # 64 B per CP_OCC block an extension touches + reads in (1 B/base) + SMEMs out (40 B)
-        # rounds 1-3 run as ONE persistent launch (three work queues) unless the FMA tables are resident or BWAMS_SEED_FUSED=0:
-        # then ms_smem_r1 brackets that launch, the other two brackets are empty, and the kernel's algorithmic bytes are those of
-        # the three rounds together (the reads are taken twice: by round 1 and by round 3)
-        fused_seed = mean("ms_smem_r2") < 0.05 and mean("ms_smem_r3") < 0.05 and st.n_ext_round[1] > 0
         r1_bytes = 64 * st.n_blk_round[0] + n_bases + 40 * st.n_smem[0]
-        if fused_seed:
-            r1_bytes = 64 * sum(st.n_blk_round) + 2 * n_bases + 40 * sum(st.n_smem)
         achieved = r1_bytes / (r1_ms * 1e-3) / 1e9
         r2_bytes = 64 * st.n_blk_round[1] + 40 * st.n_smem[1]
         r3_bytes = 64 * st.n_blk_round[2] + n_bases + 40 * st.n_smem[2]
@@ -772,8 +766,7 @@ def main():
                 "algorithmic_bytes": round(all_bytes / CHn, 1),
             },
             "roofline": {
-                "kernel": "smem_fused_kernel (SMEM rounds 1-3 as three work queues of one persistent launch)" if fused_seed
-                          else "smem_search_kernel<ALL_POS> (SMEM round 1)",
+                "kernel": "smem_search_kernel<ALL_POS> (SMEM round 1)",
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
@@ -784,8 +777,8 @@ def main():
                                                             "frac_of_peak_measured_bytes": pmc.get("smem_round1_measured_frac")},
                 "bytes_per_launch": int(r1_bytes),
                 "launch_ms": round(r1_ms, 3),
-                "other_rounds": {"round2_frac": None if fused_seed else round(r2_bytes / (mean("ms_smem_r2") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "round3_frac": None if fused_seed else round(r3_bytes / (mean("ms_smem_r3") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "other_rounds": {"round2_frac": round(r2_bytes / (mean("ms_smem_r2") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "round3_frac": round(r3_bytes / (mean("ms_smem_r3") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "seed_stage_frac": round(all_bytes / (mean("ms_seed_total") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             },
         }

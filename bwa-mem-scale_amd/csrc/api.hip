@@ -92,34 +92,6 @@ int bwams_device_count(int *n) {
 
 /* ------------------------------------------------------------------ index -- */
 
-// The search kernels' own Occ table (DevFmi::mini / super / hy1), derived on the device from the reference-layout CP_OCC:
-// 16 B per 32 rows + 16 B per 32 768 rows (3.2 GB + 3 MB at GRCh38 size).  Texts beyond 2^33 rows keep searching over CP_OCC.
-static int index_make_occ16(bwams_index *ix) {
-    static const bool off = getenv("BWAMS_OCC16") && atoi(getenv("BWAMS_OCC16")) == 0;      // A-B knob: search over CP_OCC itself
-    ix->fmi.mini = ix->fmi.super = nullptr;
-    ix->fmi.hy1_0 = ix->fmi.hy1_1 = ix->fmi.hy1_2 = ix->fmi.hy1_3 = 0;
-    if (off || !ix->d_cp || ix->n_blk <= 0 || ix->fmi.ref_seq_len >= ((int64_t)1 << 33)) return BWAMS_OK;
-    if (ix->d_mini) { (void)hipFree(ix->d_mini); ix->d_mini = nullptr; }
-    if (ix->d_super) { (void)hipFree(ix->d_super); ix->d_super = nullptr; }
-    const int64_t n_mini = ix->n_blk * 2, n_super = ((ix->n_blk - 1) >> 9) + 1;
-    BWAMS_HIP(hipMalloc(&ix->d_mini, (size_t)n_mini * 16));
-    BWAMS_HIP(hipMalloc(&ix->d_super, (size_t)n_super * 16));
-    launch_occ16_build(reinterpret_cast<const uint4 *>(ix->d_cp), ix->n_blk, ix->fmi.sentinel, reinterpret_cast<uint4 *>(ix->d_mini),
-                       reinterpret_cast<uint4 *>(ix->d_super), nullptr, nullptr);
-    BWAMS_HIP(hipDeviceSynchronize());
-    BWAMS_HIP(hipGetLastError());
-    const int64_t hb = (int64_t)1 << 26;               // the block that opens rows [2^32, ..)
-    if (ix->n_blk > hb) {
-        int64_t c[4];
-        BWAMS_HIP(hipMemcpy(c, (const char *)ix->d_cp + (size_t)hb * 64, sizeof c, hipMemcpyDeviceToHost));
-        ix->fmi.hy1_0 = c[0]; ix->fmi.hy1_1 = c[1]; ix->fmi.hy1_2 = c[2]; ix->fmi.hy1_3 = c[3];
-    }
-    ix->fmi.mini = reinterpret_cast<const uint4 *>(ix->d_mini);
-    ix->fmi.super = reinterpret_cast<const uint4 *>(ix->d_super);
-    ix->bytes += (n_mini + n_super) * 16;
-    return BWAMS_OK;
-}
-
 static int index_finish(bwams_index *ix, const bwams_fmi_desc_t *d) {
     ix->fmi.cp = reinterpret_cast<const uint4 *>(ix->d_cp);
     ix->fmi.sa_ms = reinterpret_cast<const int8_t *>(ix->d_ms);
@@ -132,7 +104,7 @@ static int index_finish(bwams_index *ix, const bwams_fmi_desc_t *d) {
     for (int i = 0; i < 5; ++i) ix->fmi.count[i] = d->count[i];
     ix->fmi.sentinel = d->sentinel_index;
     ix->fmi.ref_seq_len = d->ref_seq_len;
-    return index_make_occ16(ix);
+    return BWAMS_OK;
 }
 
 int bwams_index_from_host(const bwams_fmi_desc_t *d, int device, bwams_index_t **out) {
@@ -299,7 +271,6 @@ int bwams_index_build(const uint8_t *fw, int64_t l_pac, int fw_on_device, int de
     rc = fmi_build_device(ix, staged ? (const uint8_t *)staged : fw, l_pac, keep_ref, chunk_rows, vb && *vb && *vb != '0', stats);
     if (staged) (void)hipFree(staged);
     if (rc) { bwams_index_close(ix); return rc; }
-    if ((rc = index_make_occ16(ix))) { bwams_index_close(ix); return rc; }
     *out = ix;
     return BWAMS_OK;
 }
@@ -395,11 +366,6 @@ int bwams_index_close(bwams_index_t *ix) {
         (void)hipSetDevice(ix->device);
         if (ix->d_all) (void)hipFree(ix->d_all);
         if (ix->d_last) (void)hipFree(ix->d_last);
-    }
-    if (ix->d_mini || ix->d_super) {
-        (void)hipSetDevice(ix->device);
-        if (ix->d_mini) (void)hipFree(ix->d_mini);
-        if (ix->d_super) (void)hipFree(ix->d_super);
     }
     delete ix;
     return BWAMS_OK;
@@ -679,51 +645,6 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     BWAMS_HIP(hipEventRecord(b->ev[0], st));
     launch_pack_reads(b->d_enc, b->d_cum, b->nseq, b->read_w, b->read_cw, b->d_packed, st);
     launch_mark(b->d_ctr, 0, st);
-    // Rounds 1-3 as ONE persistent launch with three work queues (fmi_seed.hip: smem_fused_kernel) unless the FMA tables are
-    // resident (their jump tables belong to the three-launch kernels) or an option does not fit the 8-byte work item.
-    static const bool fused_env = getenv("BWAMS_SEED_FUSED") && atoi(getenv("BWAMS_SEED_FUSED")) != 0;    // A-B knob (default: three launches)
-    const bool fused = fused_env && b->nseq > 0 && !a.fmi.all_smem && !a.fmi.last_smem && opt->split_width < 65535 &&
-                       b->prev_cap < 65536 && b->nseq < ((int64_t)1 << 31);
-    if (fused) {
-        FusedLaunch fa;
-        fa.q2 = reinterpret_cast<unsigned long long *>(b->d_work2);
-        int64_t want = b->q2_cap_hint > 0 ? b->q2_cap_hint : 2 * b->nseq + 4096;
-        const int64_t most = b->pool_cap * (int64_t)sizeof(Round2Work) / 8;     // what the work buffer holds as 8-byte items
-        fa.q2_cap = want < most ? want : most;
-        fa.split_len = split_len;
-        fa.split_width = opt->split_width;
-        fa.max_intv = opt->max_mem_intv;
-        fa.min_seed_len3 = opt->min_seed_len + 1;
-        BWAMS_HIP(hipMemsetAsync(fa.q2, 0, (size_t)fa.q2_cap * 8, st));
-        if (a.debug & 2) {      // the timeline's minima start at "never"
-            static const unsigned long long never[10] = {~0ull, ~0ull, 0, ~0ull, 0, 0, 0, 0, 0, ~0ull};
-            BWAMS_HIP(hipMemcpyAsync(b->d_ctr->dbg, never, sizeof never, hipMemcpyHostToDevice, st));
-        }
-        BWAMS_HIP(hipEventRecord(b->ev[8], st));
-        launch_smem_fused(a, fa, b->cu_count, st);
-        BWAMS_HIP(hipEventRecord(b->ev[9], st));
-        for (int e = 10; e <= 13; ++e) BWAMS_HIP(hipEventRecord(b->ev[e], st));
-        BWAMS_HIP(hipEventRecord(b->ev[3], st));
-        BWAMS_HIP(hipGetLastError());
-        BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
-        BWAMS_HIP(hipStreamSynchronize(st));
-        if (a.debug & 2) {
-            const unsigned long long *d = b->h_ctr->dbg;
-            fprintf(stderr, "[fused] q1 empty first %.3f ms last %.3f | round 1 over %.3f | first wave out %.3f last %.3f | "
-                    "before q1 empty: %llu wave-iterations, %.1f lanes at work | after: %llu, %.1f | q2 items %llu\n",
-                    (d[1] - d[0]) * 1e-5, (d[2] - d[0]) * 1e-5, (d[3] - d[0]) * 1e-5, (d[9] - d[0]) * 1e-5, (d[4] - d[0]) * 1e-5,
-                    d[5], d[5] ? (double)d[6] / d[5] : 0.0, d[7], d[7] ? (double)d[8] / d[7] : 0.0, b->h_ctr->q2_reserved);
-        }
-        if ((int64_t)b->h_ctr->q2_reserved > fa.q2_cap) {
-            // more round-2 pivots than the queue was sized for: the launch dropped the excess; size it and run again
-            if (fa.q2_cap >= most) {
-                set_last_error("round-2 work queue overflow: need " + std::to_string(b->h_ctr->q2_reserved) + " items");
-                return BWAMS_ERR_CAPACITY;
-            }
-            b->q2_cap_hint = (int64_t)b->h_ctr->q2_reserved + (int64_t)b->h_ctr->q2_reserved / 4 + 4096;
-            return seed_run_once(b, opt, with_sa);
-        }
-    } else {
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
     if (b->nseq > 0) launch_smem_round1(a, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[9], st));
@@ -761,18 +682,6 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     // the SMEM count sizes the sort: one small read-back
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
-    }
-    if (a.debug & 4) {
-        { const unsigned long long *d = b->h_ctr->dbg;
-          fprintf(stderr, "[seed] backward: %llu ext, %llu with a second block, first block = a block of the lane's previous ext %llu, second %llu | "
-                  "forward: %llu, %llu, %llu, %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]); }
-        fprintf(stderr, "[seed] pivots and backward extensions by interval-list size at the end of the forward phase (rounds 1+2):\n");
-        unsigned long long tn = 0, te = 0;
-        for (int i = 0; i < 16; ++i) { tn += b->h_ctr->hist_n[i]; te += b->h_ctr->hist_ext[i]; }
-        for (int i = 0; i < 16; ++i)
-            fprintf(stderr, "   list %3d-%3d: %10llu pivots (%5.2f %%)  %12llu backward extensions (%5.2f %%)\n", i * 8, i == 15 ? 999 : i * 8 + 7,
-                    b->h_ctr->hist_n[i], tn ? 100.0 * b->h_ctr->hist_n[i] / tn : 0.0, b->h_ctr->hist_ext[i], te ? 100.0 * b->h_ctr->hist_ext[i] / te : 0.0);
-    }
     const int64_t n_slots = (int64_t)b->h_ctr->n_smem_total;      // pool slots handed out (holes included)
     const int64_t n = (int64_t)b->h_ctr->n_smem_valid;           // real SMEMs
     b->n_smem = n;

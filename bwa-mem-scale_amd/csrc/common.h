@@ -30,16 +30,6 @@ void set_last_error(const std::string &s);
 // 16-byte pieces  [cnt0 cnt1] [cnt2 cnt3] [hot0 hot1] [hot2 hot3].
 struct DevFmi {
     const uint4 *cp;
-    // The search kernels' own form of the Occ table (fmi_seed.hip: "occ16"), derived on the device from cp, or nullptr:
-    //   mini[pos >> 5]   16 B per 32 rows: 2-bit BWT codes (row j at bits 2j of the 64-bit word x|y<<32) + four 16-bit counts
-    //                    (A | C << 16 in z, G | T << 16 in w) of the rows between the enclosing super block's start and this block
-    //   super[pos >> 15] 16 B per 32 768 rows: four 32-bit counts of the rows between the enclosing 2^32-row stretch's start and
-    //                    this block
-    //   hy1[b]           occurrences of base b in rows [0, 2^32) (texts of up to 2^33 rows: GRCh38 has 6.4 G)
-    // One Occ evaluation is then ONE 16-byte load per lane from HBM (plus one from the L2-resident super table), nothing is
-    // shared between lanes, and the 64 bytes of a CP_OCC block never have to be transposed through the quad.
-    const uint4 *mini, *super;
-    int64_t hy1_0, hy1_1, hy1_2, hy1_3;   // (scalars: an array member indexed in a select chain made the compiler keep the whole argument block in scratch)
     const int8_t *sa_ms;
     const uint32_t *sa_ls;
     const uint8_t *ref;        // .0123 or nullptr
@@ -106,9 +96,6 @@ struct DevCounters {
     unsigned long long ert_kmer, ert_nodes, ert_ref;   // ERT profile kernel: k-mer entries read, tree records decoded, text bytes compared
     unsigned long long work_head3, n_ext3, n_blk3, n_smem3;   // SMEM round 3 (it may run beside round 2): its own cursor and counts, folded in by mark_kernel(3)
     unsigned long long n_rest;           // extension: slots behind the requests of the last selection (an upper bound of the undecided seeds)
-    unsigned long long hist_n[16], hist_ext[16];   // diagnostics (BWAMS_DEBUG=4): pivots / backward extensions by size of the interval list
-    unsigned long long q2_reserved, q2_head, r1_done;   // fused seeding launch: round-2 items appended / taken, round-1 reads finished
-    unsigned long long fz_valid[3], fz_ext[3], fz_blk[3];   // fused seeding launch: SMEMs, extensions, blocks per round
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };
 
@@ -156,7 +143,6 @@ struct bwams_index {
     int64_t bytes = 0;
     int64_t n_blk = 0, n_sa = 0;
     void *d_cp = nullptr, *d_ms = nullptr, *d_ls = nullptr, *d_ref = nullptr;
-    void *d_mini = nullptr, *d_super = nullptr;  // the search kernels' Occ table derived from d_cp (always owned)
     void *d_all = nullptr, *d_last = nullptr;    // FMA tables (owned)
     void *d_contigs = nullptr;                   // bwams_contig_t[n_seqs] (owned); null = one sequence [0, l_pac)
     int32_t n_seqs = 0;
@@ -216,7 +202,6 @@ struct bwams_batch {
     uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
     uint32_t *d_vals = nullptr, *d_vals2 = nullptr;
     bwams::Round2Work *d_work2 = nullptr;
-    int64_t q2_cap_hint = 0;              // fused seeding launch: round-2 queue size a chunk asked for (0: 2 nseq + 4096)
     int64_t *d_sa_off = nullptr;         // max_smem + 1
     int64_t *d_sa_cnt = nullptr;         // max_smem + 1
     int64_t *d_sa_coord = nullptr;

@@ -23,15 +23,6 @@ struct SeedLaunch {
     int64_t prev_threads;         // lanes the scratch was sized for
 };
 
-// rounds 1-3 as the three work queues of ONE persistent launch (fmi_seed.hip: smem_fused_kernel)
-struct FusedLaunch {
-    unsigned long long *q2;       // round-2 work items: 8-byte granules, zeroed before the launch
-    int64_t q2_cap;
-    int split_len, split_width;   // which round-1 SMEMs are re-seeded (bwamem.cpp:721-738)
-    int max_intv;                 // round 3 (<= 0: no round 3)
-    int min_seed_len3;            // round 3's minimum length (min_seed_len + 1)
-};
-
 // grid sizing shared by batch_create (scratch) and the launches
 int seed_block_threads();
 int64_t seed_max_threads(int cu_count);
@@ -50,12 +41,6 @@ void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap,
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st);
 // round 3: forward-only seeds (bwtSeedStrategyAllPosOneThread)
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st);
-
-// rounds 1, 2, 3 in one launch + the per-round counters folded into the fields the three launches fill
-void launch_smem_fused(const SeedLaunch &a, const FusedLaunch &fa, int cu_count, hipStream_t st);
-
-// the search kernels' Occ table ("occ16", see DevFmi): n_mini = (rows >> 5) + 1 entries, n_super = (rows >> 15) + 1 entries
-void launch_occ16_build(const uint4 *cp, int64_t n_blk, int64_t sentinel, uint4 *mini, uint4 *super, int64_t *hy1_dev, hipStream_t st);
 
 // FMA table builders (__build_all_smem_table / __build_last_smem_table): one lane per table entry
 void launch_build_fma(const DevFmi &f, int all_bp, uint32_t *all_tab, int last_bp, uint4 *last_tab, hipStream_t st);

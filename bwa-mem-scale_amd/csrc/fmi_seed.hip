@@ -133,136 +133,13 @@ __device__ __forceinline__ void backward_ext_coop(const DevFmi &f, bool need, in
     nl = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
 }
 
-// ---- the search kernels' own Occ table ("occ16", DevFmi::mini / super / hy1) -------------------------
-// The quad-cooperative fetch above buys whole 64-byte requests at the price of ≈ 130 vector instructions of register
-// transposes per extension, 32 registers of block data and wave-uniform control flow around every extension.  With the
-// BWT as 2-bit codes and the counts split into three levels (16-bit per 32 rows, 32-bit per 32 768 rows, 64-bit per
-// 2^32 rows) one Occ evaluation is ONE 16-byte load per lane (+ one from the 3 MB super table, L2 resident): no
-// cooperation, eight registers of data, and the four counts come out of three masked popcounts
-//     H = high bits, L = low bits of the codes:  T = |H & L|, G = |H| - T, C = |L| - T, A = y - |H| - |L| + T.
-// The algorithmic bytes of an extension stay what SURVEY §8(d) defines (the reference's 64-byte blocks it touches).
-struct Occ16 {
-    uint32_t v0, v1, v2, v3;       // occurrences of A, C, G, T in the rows between the 2^32-row stretch's start and pos
-};
-// The wave-uniform constants of the table, read once per kernel into scalar registers.  (Selecting between fields of the
-// argument block inside the extension makes the compiler fold "select of loads" into "load of a selected address", which
-// keeps the whole argument block in scratch memory; values that went through readfirstlane are opaque to that fold.)
-struct Occ16Const {
-    const uint4 *mini, *super;
-    int64_t c0, c1, c2, c3;        // count[b]
-    int64_t h0, h1, h2, h3;        // occurrences of b in rows [0, 2^32)
-    int64_t sentinel;
-};
-__device__ __forceinline__ int64_t uni64(int64_t v) {
-    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)v >> 32)) << 32) |
-                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
-}
-__device__ __forceinline__ Occ16Const occ16_const(const DevFmi &f) {
-    Occ16Const c;
-    c.mini = f.mini; c.super = f.super;
-    c.c0 = uni64(f.count[0]); c.c1 = uni64(f.count[1]); c.c2 = uni64(f.count[2]); c.c3 = uni64(f.count[3]);
-    c.h0 = uni64(f.hy1_0); c.h1 = uni64(f.hy1_1); c.h2 = uni64(f.hy1_2); c.h3 = uni64(f.hy1_3);
-    c.sentinel = uni64(f.sentinel);
-    return c;
-}
-__device__ __forceinline__ Occ16 occ16_eval(const int64_t sentinel, int64_t pos, const uint4 mb, const uint4 sb) {
-    const uint32_t y = (uint32_t)pos & 31u;
-    const uint32_t w0 = y < 16u ? y : 16u, w1 = y < 16u ? 0u : y - 16u;
-    const uint32_t m0 = w0 == 16u ? 0x55555555u : (((1u << (2u * w0)) - 1u) & 0x55555555u);
-    const uint32_t m1 = ((1u << (2u * w1)) - 1u) & 0x55555555u;
-    const uint32_t L0 = mb.x & m0, H0 = (mb.x >> 1) & m0, L1 = mb.y & m1, H1 = (mb.y >> 1) & m1;
-    const uint32_t pL = __popc(L0) + __popc(L1), pH = __popc(H0) + __popc(H1), pT = __popc(L0 & H0) + __popc(L1 & H1);
-    // the sentinel row holds no base (stored as code 0): not an A
-    const uint32_t sent = (uint64_t)(pos - 1 - sentinel) < (uint64_t)y ? 1u : 0u;
-    Occ16 o;
-    o.v0 = (y - pL - pH + pT - sent) + (mb.z & 0xffffu) + sb.x;
-    o.v1 = (pL - pT) + (mb.z >> 16) + sb.y;
-    o.v2 = (pH - pT) + (mb.w & 0xffffu) + sb.z;
-    o.v3 = pT + (mb.w >> 16) + sb.w;
-    return o;
-}
-// backwardExt of one lane, no cooperation: lanes without work skip the loads.  The table's constants arrive as scalars
-// BY VALUE (see Occ16Const).
-__device__ __forceinline__ void backward_ext16(const uint4 *mini, const uint4 *super, const int64_t c0, const int64_t c1,
-                                               const int64_t c2, const int64_t c3, const int64_t h0, const int64_t h1,
-                                               const int64_t h2, const int64_t h3, const int64_t sentinel, bool need, int64_t k,
-                                               int64_t l, int64_t s, int a, int64_t &nk, int64_t &nl, int64_t &ns) {
-    if (!need) return;
-    const int64_t sp = k, ep = k + s;
-    // the end of the interval usually lies in the same super block as its start, often in the same 32 rows: no second request
-    const int64_t isp = sp >> 5, iep = ep >> 5;
-    const uint4 msp = mini[isp];
-    const uint4 ssp = super[isp >> 10];
-    uint4 mep = msp, sep = ssp;
-    if (iep != isp) {
-        mep = mini[iep];
-        if ((iep >> 10) != (isp >> 10)) sep = super[iep >> 10];
-    }
-    const Occ16 osp = occ16_eval(sentinel, sp, msp, ssp), oep = occ16_eval(sentinel, ep, mep, sep);
-    const bool hs = (sp >> 32) != 0, he = (ep >> 32) != 0;              // texts of up to 2^33 rows: two stretches
-    const bool cross = hs != he;
-    const int64_t s0 = (int64_t)oep.v0 - (int64_t)osp.v0 + (cross ? h0 : 0);
-    const int64_t s1 = (int64_t)oep.v1 - (int64_t)osp.v1 + (cross ? h1 : 0);
-    const int64_t s2 = (int64_t)oep.v2 - (int64_t)osp.v2 + (cross ? h2 : 0);
-    const int64_t s3 = (int64_t)oep.v3 - (int64_t)osp.v3 + (cross ? h3 : 0);
-    const int64_t l3 = l + ((k <= sentinel && k + s > sentinel) ? 1 : 0);
-    const int64_t l2 = l3 + s3, l1 = l2 + s2, l0 = l1 + s1;
-    const uint32_t oa = a == 0 ? osp.v0 : a == 1 ? osp.v1 : a == 2 ? osp.v2 : osp.v3;
-    const int64_t ca = a == 0 ? c0 : a == 1 ? c1 : a == 2 ? c2 : c3;
-    const int64_t ha = a == 0 ? h0 : a == 1 ? h1 : a == 2 ? h2 : h3;
-    nk = ca + (hs ? ha : 0) + (int64_t)oa;
-    ns = a == 0 ? s0 : a == 1 ? s1 : a == 2 ? s2 : s3;
-    nl = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
-}
-#ifndef BWAMS_BLK_CACHE
-#define BWAMS_BLK_CACHE 1
-#endif
-template <bool OCC16>
-__device__ __forceinline__ void ext_step(const DevFmi &f, const Occ16Const &oc, bool need, int64_t k, int64_t l, int64_t s, int a,
-                                         int64_t &nk, int64_t &nl, int64_t &ns) {
-    if (OCC16) backward_ext16(oc.mini, oc.super, oc.c0, oc.c1, oc.c2, oc.c3, oc.h0, oc.h1, oc.h2, oc.h3, oc.sentinel, need, k, l, s, a, nk, nl, ns);
-    else backward_ext_coop(f, need, k, l, s, a, nk, nl, ns);
-}
-
-// cp (the reference's CP_OCC blocks) -> mini / super.  One thread per 64-row block: two mini entries, and the super entry
-// when the block opens a super block.  Counts of a level are relative to the start of the enclosing block of the next level.
-__global__ void occ16_build_kernel(const uint4 *__restrict__ cp, int64_t n_blk, uint4 *__restrict__ mini,
-                                   uint4 *__restrict__ super) {
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blk; b += (int64_t)gridDim.x * blockDim.x) {
-        const uint4 c01 = cp[4 * b], c23 = cp[4 * b + 1], h01 = cp[4 * b + 2], h23 = cp[4 * b + 3];
-        const int64_t cnt[4] = {(int64_t)mk64(c01.x, c01.y), (int64_t)mk64(c01.z, c01.w), (int64_t)mk64(c23.x, c23.y),
-                                (int64_t)mk64(c23.z, c23.w)};
-        const uint64_t hot[4] = {mk64(h01.x, h01.y), mk64(h01.z, h01.w), mk64(h23.x, h23.y), mk64(h23.z, h23.w)};
-        const int64_t sb = (b >> 9) << 9, hb = (b >> 26) << 26;
-        const uint4 s01 = cp[4 * sb], s23 = cp[4 * sb + 1], y01 = cp[4 * hb], y23 = cp[4 * hb + 1];
-        const int64_t scnt[4] = {(int64_t)mk64(s01.x, s01.y), (int64_t)mk64(s01.z, s01.w), (int64_t)mk64(s23.x, s23.y),
-                                 (int64_t)mk64(s23.z, s23.w)};
-        const int64_t hcnt[4] = {(int64_t)mk64(y01.x, y01.y), (int64_t)mk64(y01.z, y01.w), (int64_t)mk64(y23.x, y23.y),
-                                 (int64_t)mk64(y23.z, y23.w)};
-        for (int half = 0; half < 2; ++half) {
-            uint64_t codes = 0;
-            for (int j = 0; j < 32; ++j) {
-                const int bit = 63 - (half * 32 + j);
-                const uint64_t c = ((hot[1] >> bit) & 1) ? 1 : ((hot[2] >> bit) & 1) ? 2 : ((hot[3] >> bit) & 1) ? 3 : 0;
-                codes |= c << (2 * j);
-            }
-            uint32_t rel[4];
-            for (int c = 0; c < 4; ++c)
-                rel[c] = (uint32_t)(cnt[c] - scnt[c]) + (half ? (uint32_t)__popcll(hot[c] >> 32) : 0u);
-            mini[2 * b + half] = make_uint4((uint32_t)codes, (uint32_t)(codes >> 32), rel[0] | (rel[1] << 16), rel[2] | (rel[3] << 16));
-        }
-        if (b == sb)
-            super[b >> 9] = make_uint4((uint32_t)(cnt[0] - hcnt[0]), (uint32_t)(cnt[1] - hcnt[1]), (uint32_t)(cnt[2] - hcnt[2]),
-                                       (uint32_t)(cnt[3] - hcnt[3]));
-    }
-}
-
 // backwardExt with the lane's two most recent blocks kept in registers.  Four extensions in five belong to the backward
-// phase, where the entries of a column are NESTED intervals visited from the innermost outwards: the block holding k (and the one
-// holding k + s) is the block of the previous entry in 40 % of the cases (counted on the bench reads, profiles/r03_notes.md).
-// Those fetches were L1 / L2 hits, but requests all the same — and requests per second, not bytes, are what this kernel is short
-// of.  The cache is role-bound (start block against the previous start block, end block against the previous end block), so
-// a hit moves no data: the lane simply does not take part in the quad's fetch for its own block.
+// phase (642 M of 818 M per million reads in rounds 1-2), where the entries of a column are NESTED intervals visited from the
+// innermost outwards: the block holding k is one of the previous entry's blocks for 43 % of them, the block holding k + s for
+// 35 % of those that need a second block (counted on the bench reads, profiles/r03_notes.md).  Those fetches were L1 / L2 hits,
+// but requests all the same, and requests per second — not bytes, not lines — are what the memory system runs out of under this
+// kernel.  The cache is role-bound (start block against the previous start block, end block against the previous end block), so
+// a hit moves no data: the lane simply takes no part in the quad's fetch of its own block.  MUST be called by all 64 lanes.
 struct BlkCache {
     uint4 a0, a1, a2, a3, b0, b1, b2, b3;
     int32_t ta, tb;                     // block numbers held (rows >> 6 < 2^30), -1 = none
@@ -593,11 +470,9 @@ enum : int { PH_FETCH = 0, PH_LOAD, PH_HOLD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BW
 
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
 // !ALL_POS: work item = (read, pivot, min_intv), one pivot (round 2).
-template <bool ALL_POS, bool OCC16>
+template <bool ALL_POS>
 __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
     const DevFmi &f = a.fmi;
-    Occ16Const oc{};
-    if (OCC16) oc = occ16_const(f);
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int cap = a.prev_cap;
     extern __shared__ uint32_t lds_reads[];
@@ -622,17 +497,14 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
     int32_t curr_s = -1;
     bool first = true;
     int bwd_a = 0;
-    BlkCache bc;
-    bc.a0 = bc.a1 = bc.a2 = bc.a3 = bc.b0 = bc.b1 = bc.b2 = bc.b3 = make_uint4(0, 0, 0, 0);
-    bc.ta = bc.tb = -1;
-    int dbg_np0 = 0, dbg_bwd = 0;
-    int64_t dbg_ls = -1, dbg_le = -1;
-    uint32_t dbg_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_ext = 0, n_blk = 0;
     WaveOut wo;
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0;
+    BlkCache bc;
+    bc.a0 = bc.a1 = bc.a2 = bc.a3 = bc.b0 = bc.b1 = bc.b2 = bc.b3 = make_uint4(0, 0, 0, 0);
+    bc.ta = bc.tb = -1;
 
     while (true) {
         // at most one SMEM per lane and iteration; written at the wave-uniform point below
@@ -641,11 +513,6 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
         int64_t em_k = 0, em_l = 0, em_s = 0;
         // ---- leave a finished pivot -------------------------------------------------
         if (phase == PH_BWD_END) {
-            if (a.debug & 4) {                          // diagnostics: how the backward work is spread over list sizes
-                const int bk = dbg_np0 >= 120 ? 15 : dbg_np0 >> 3;
-                atomicAdd(&a.ctr->hist_n[bk], 1ull);
-                atomicAdd(&a.ctr->hist_ext[bk], (unsigned long long)dbg_bwd);
-            }
             if (num_prev != 0) {
                 int64_t qk, ql, qs;
                 int qn;
@@ -773,7 +640,6 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
             p = 0; num_curr = 0; curr_s = -1; first = true;
             cur_m = x;
             phase = PH_BWD;
-            dbg_np0 = num_prev; dbg_bwd = 0;
         }
         // ---- backward phase: pre -----------------------------------------------------
         if (phase == PH_BWD && !do_ext) {
@@ -796,18 +662,10 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
 
         // ---- the one extension of this iteration -------------------------------------
         int64_t nk = 0, nl = 0, ns = 0;
-        if (!OCC16 && BWAMS_BLK_CACHE) backward_ext_cached(f, bc, do_ext, ek, el, es, ea, nk, nl, ns);
-        else ext_step<OCC16>(f, oc, do_ext, ek, el, es, ea, nk, nl, ns);
+        backward_ext_cached(f, bc, do_ext, ek, el, es, ea, nk, nl, ns);
         if (do_ext) {
             n_ext++;
             n_blk += ((ek >> 6) == ((ek + es) >> 6)) ? 1 : 2;
-            if (a.debug & 4) {                          // diagnostics: would a one-extension block cache in the lane hit?
-                const int64_t bs = ek >> 6, be = (ek + es) >> 6;
-                const bool hs = bs == dbg_ls || bs == dbg_le, he = be != bs && (be == dbg_ls || be == dbg_le);
-                const int w = phase == PH_BWD ? 0 : 4;
-                dbg_c[w + 0] += 1; dbg_c[w + 1] += be != bs; dbg_c[w + 2] += hs; dbg_c[w + 3] += he;
-                dbg_ls = bs; dbg_le = be;
-            }
         }
 
         // ---- post ---------------------------------------------------------------------
@@ -835,10 +693,8 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                 p = 0; num_curr = 0; curr_s = -1; first = true;
                 cur_m = x;
                 phase = PH_BWD;
-                dbg_np0 = num_prev; dbg_bwd = 0;
             }
         } else if (do_ext && phase == PH_BWD) {
-            dbg_bwd++;
             bool keep = false;
             if (first) {
                 if (ns < min_intv && (pn - cur_m + 1) >= a.min_seed_len) {
@@ -872,8 +728,6 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
     }
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
-    if (a.debug & 4)
-        for (int i = 0; i < 8; ++i) atomicAdd(&a.ctr->dbg[i], (unsigned long long)dbg_c[i]);
 }
 
 // Select round-2 pivots from the round-1 SMEMs (src/bwamem.cpp:721-738).
@@ -915,11 +769,8 @@ __global__ void mark_kernel(DevCounters *ctr, int which) {
 }
 
 // Round 3: forward-only seeds.
-template <bool OCC16>
 __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int max_intv) {
     const DevFmi &f = a.fmi;
-    Occ16Const oc{};
-    if (OCC16) oc = occ16_const(f);
     extern __shared__ uint32_t lds_reads[];
     uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
     ReadView rv;
@@ -1020,7 +871,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
             }
         }
         int64_t nk = 0, nl = 0, ns = 0;
-        ext_step<OCC16>(f, oc, do_ext, cl, ck, cs, ea, nk, nl, ns);
+        backward_ext_coop(f, do_ext, cl, ck, cs, ea, nk, nl, ns);
         if (do_ext) {
             n_ext++;
             n_blk += ((cl >> 6) == ((cl + cs) >> 6)) ? 1 : 2;
@@ -1040,493 +891,6 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
     }
     wave_emit_finish(a, wo, true);
     flush_counters(a.ctr, n_ext, n_blk, true);
-}
-
-// ---- rounds 1, 2 and 3 in ONE persistent launch ------------------------------------------------
-// Three launches end in three tails: a lane carries a read for ~500 dependent steps, so when a round's queue
-// runs dry every lane is still in the middle of one, and the launch ends ≈ 5 ms later with few lanes at work
-// (profiles/r02_notes.md, note 50: at the marginal rate round 1 runs at 0.52 of the byte peak, launched alone
-// at 0.31).  Here the three rounds are three WORK QUEUES of one launch:
-//   Q1  the reads of round 1 (every pivot of a read; the longest items, taken first);
-//   Q2  the round-2 pivots (bwamem.cpp:721-738), appended BY THE LANES OF ROUND 1 as they emit an SMEM that is
-//       long and rare enough — a producer / consumer queue inside the launch;
-//   Q3  the reads of round 3 (forward-only, independent of rounds 1-2), which fill whatever is idle.
-// A lane that finishes an item takes the next one from Q1, else Q2, else Q3, so the only tail left is the one
-// of the last short items.  Hand-off of a Q2 item between workgroups on different XCDs (private, non-coherent
-// L2s): an item is ONE naturally aligned 8-byte granule {valid | rid | x | min_intv} written by one agent-scope
-// relaxed atomic store and polled by agent-scope relaxed atomic loads (the guide's data-tagged granule: the data
-// is the flag, no fence); slots are handed out by atomic counters (q2_reserved by producers, q2_head by
-// consumers); the array is zeroed before every launch.  Termination: r1_done counts finished round-1 reads;
-// once it equals nseq no further item can appear, q2_reserved is final, and a ticket beyond it is void.
-constexpr unsigned long long kQ2Valid = 1ull << 63;
-__device__ __forceinline__ unsigned long long q2_pack(uint32_t rid, int x, int min_intv) {
-    return kQ2Valid | ((unsigned long long)rid << 32) | ((unsigned long long)(x & 0xffff) << 16) | (unsigned long long)(min_intv & 0xffff);
-}
-__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long bcast0_u64(unsigned long long v) {
-    return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-           (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)v);
-}
-
-struct FusedOut {
-    long long base;
-    int used;
-    uint32_t em1, em2, em3;   // this lane's SMEMs per round (scalars: an indexed array would live in scratch)
-};
-
-// wave_emit of the fused launch: the SMEM record, and for a round-1 SMEM that qualifies (bwamem.cpp:726-738) the
-// round-2 work item.  MUST be called by all 64 lanes at a wave-uniform point.
-__device__ __forceinline__ void fused_emit(const SeedLaunch &a, const FusedLaunch &fa, FusedOut &w, bool flag, int mode,
-                                           uint32_t rid, uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t s) {
-    const unsigned long long mask = __ballot(flag);
-    if (!mask) return;
-    const int lane = (int)(threadIdx.x & 63);
-    const int cnt = __popcll(mask);
-    if (w.base < 0 || w.used + cnt > kChunk) {
-        if (w.base >= 0) {
-            const long long slot = w.base + w.used + lane;
-            if (w.used + lane < kChunk && slot < a.pool_cap) a.pool[slot].rid = kHoleRid;
-        }
-        w.used = 0;
-        w.base = (long long)wave_ticket(&a.ctr->n_smem_total, (unsigned long long)kChunk);
-    }
-    if (flag) {
-        const long long slot = w.base + w.used + __popcll(mask & ((1ull << lane) - 1ull));
-        if (slot < a.pool_cap) {
-            bwams_smem_t r;
-            r.rid = rid; r.m = m; r.n = n; r.pad_ = 0;
-            r.k = k; r.l = l; r.s = s;
-            a.pool[slot] = r;
-        }
-        w.em1 += mode == 1; w.em2 += mode == 2; w.em3 += mode == 3;
-    }
-    w.used += cnt;
-    // round-2 work from a round-1 SMEM: pivot at its middle, min_intv = its size + 1
-    const bool push = flag && mode == 1 && (int)(n + 1 - m) >= fa.split_len && s <= (int64_t)fa.split_width;
-    const unsigned long long pm = __ballot(push);
-    if (pm) {
-        const unsigned long long b0 = wave_ticket(&a.ctr->q2_reserved, (unsigned long long)__popcll(pm));
-        if (push) {
-            const unsigned long long slot = b0 + (unsigned long long)__popcll(pm & ((1ull << lane) - 1ull));
-            if ((int64_t)slot < fa.q2_cap)
-                __hip_atomic_store(fa.q2 + slot, q2_pack(rid, (int)((n + 1 + m) >> 1), (int)(s + 1)), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-enum : int { PH_PIVOT3 = 16, PH_FWD3 };
-
-template <bool OCC16>
-__global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_fused_kernel(SeedLaunch a, FusedLaunch fa) {
-    const DevFmi &f = a.fmi;
-    Occ16Const oc{};
-    if (OCC16) oc = occ16_const(f);
-    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int lane = (int)(threadIdx.x & 63);
-    const int cap = a.prev_cap;
-    extern __shared__ uint32_t lds_reads[];
-    uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
-    PrevList prev;
-    prev.glob = a.prev + slot * (int64_t)cap;
-    prev.ring = reinterpret_cast<uint4 *>(lds_reads + (a.reads_in_lds ? a.read_w * kBlock : 0)) + threadIdx.x;
-    ReadView rv;
-    rv.lds_col = lds_col;
-    rv.gl = a.packed;
-    rv.cw = a.read_cw;
-    const unsigned long long nseq = (unsigned long long)a.nseq;
-
-    int phase = PH_FETCH;
-    int mode = 1;                         // round this lane's current item belongs to
-    uint32_t rid = 0;
-    int len = 0, x = 0, next_x = 0, min_intv = 1;
-    int64_t ck = 0, cl = 0, cs = 0;
-    int cn = 0;
-    int j = 0;
-    int num_prev = 0, base = 0, p = 0, num_curr = 0, cur_m = 0;
-    int32_t curr_s = -1;
-    bool first = true;
-    int bwd_a = 0;
-    uint32_t ne1 = 0, ne2 = 0, ne3 = 0, nb1 = 0, nb2 = 0, nb3 = 0;   // extensions / blocks per round
-    FusedOut wo;
-    wo.base = -1; wo.used = 0; wo.em1 = wo.em2 = wo.em3 = 0;
-    WaveTickets wt1, wt2, wt3;
-    wt1.next = 0; wt1.left = 0; wt2.next = 0; wt2.left = 0; wt3.next = 0; wt3.left = 0;
-    bool q1_empty = false, q3_empty = fa.max_intv <= 0;       // wave-uniform
-    bool q2_closed = false;                                    // wave-uniform: no Q2 ticket of this wave can still become valid
-    bool done = false;                                         // wave-uniform: round 1 has ended everywhere
-    unsigned long long q2_final = 0;                           // valid once done: the number of Q2 items
-    int r1_fin = 0;                                            // wave-uniform: finished round-1 reads not yet reported
-    uint32_t idle_polls = 0;
-    // diagnostics (BWAMS_DEBUG=2): a timeline in 10-ns ticks and the lanes at work per iteration, into ctr->dbg
-    const bool diag = (a.debug & 2) != 0;
-    unsigned long long t_start = 0, d_iters = 0, d_active = 0, d_iters_b = 0, d_active_b = 0;
-    bool d_seen_q1 = false, d_seen_done = false;
-    if (diag) {
-        t_start = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) atomicMin(&a.ctr->dbg[0], t_start);
-    }
-
-    while (true) {
-        bool em = false;
-        uint32_t em_m = 0, em_n = 0;
-        int64_t em_k = 0, em_l = 0, em_s = 0;
-        bool fin1 = false;                                     // this lane ended a round-1 read in this iteration
-        // ---- leave a finished pivot (rounds 1, 2) -----------------------------------------
-        if (phase == PH_BWD_END) {
-            if (num_prev != 0) {
-                int64_t qk, ql, qs;
-                int qn;
-                prev_get(prev, base, 0, qk, ql, qs, qn);
-                if (qn - cur_m + 1 >= a.min_seed_len) {
-                    em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)qn; em_k = qk; em_l = ql; em_s = qs;
-                }
-            }
-            x = next_x;
-            phase = mode == 1 ? PH_PIVOT : PH_FETCH;
-        }
-        fused_emit(a, fa, wo, em, mode, rid, em_m, em_n, em_k, em_l, em_s);
-        em = false;
-        // ---- the next work item ---------------------------------------------------------------
-        if (__ballot(phase == PH_FETCH)) {
-            bool want = phase == PH_FETCH;
-            if (!q1_empty) {
-                unsigned long long t = 0;
-                const bool got = take_ticket(&a.ctr->work_head, wt1, want, t);
-                if (got && t < nseq) {
-                    rid = (uint32_t)t;
-                    mode = 1;
-                    x = 0;
-                    min_intv = 1;
-                    len = (int)(a.cum[rid + 1] - a.cum[rid]);
-                    want = false;
-                    if (a.skip && a.skip[rid]) fin1 = true;     // an EMF-resolved read: round 1 has nothing to do
-                    else { phase = PH_PIVOT; read_take(rv, lds_col, a.packed, a.read_w, rid); }
-                }
-                if (__any(got && t >= nseq)) q1_empty = true;
-            }
-            // Q2: the wave owns a chunk of 64 tickets (one atomic per chunk: a ticket or a poll per item on ONE word would
-            // queue every wave of the chip behind that word); a wanting lane looks at the granule of the next ticket of the
-            // chunk and takes it once it is valid, otherwise it leaves the ticket where it is and looks elsewhere (Q3)
-            if (q1_empty && !q2_closed && __ballot(want)) {
-                if (wt2.left == 0) {
-                    wt2.next = wave_ticket(&a.ctr->q2_head, (unsigned long long)kTicketChunk);
-                    wt2.left = kTicketChunk;
-                }
-                const unsigned long long wm = __ballot(want);
-                const int rank = __popcll(wm & ((1ull << lane) - 1ull));
-                unsigned long long g = 0;
-                const unsigned long long cand = wt2.next + (unsigned long long)rank;
-                if (want && rank < wt2.left && (int64_t)cand < fa.q2_cap) g = ld_agent(fa.q2 + cand);
-                const unsigned long long vm = __ballot(want && (g & kQ2Valid) != 0);
-                const unsigned long long bad = wm & ~vm;                 // wanting lanes without a valid item, in ticket order
-                const unsigned long long upto = bad ? ((1ull << __builtin_ctzll(bad)) - 1ull) : ~0ull;
-                const int served = __popcll(vm & upto);                  // the valid prefix
-                if (want && rank < served) {
-                    rid = (uint32_t)((g >> 32) & 0x7fffffffu);
-                    x = (int)((g >> 16) & 0xffff);
-                    min_intv = (int)(g & 0xffff);
-                    mode = 2;
-                    len = (int)(a.cum[rid + 1] - a.cum[rid]);
-                    phase = PH_PIVOT;
-                    want = false;
-                    read_take(rv, lds_col, a.packed, a.read_w, rid);
-                }
-                wt2.next += (unsigned long long)served;
-                wt2.left -= served;
-                if (done && wt2.next >= q2_final) { q2_closed = true; wt2.left = 0; }     // the rest of the chunk is void
-            }
-            if (!q3_empty && q1_empty) {
-                unsigned long long t = 0;
-                const bool got = take_ticket(&a.ctr->work_head3, wt3, want, t);
-                if (got && t < nseq) {
-                    rid = (uint32_t)t;
-                    mode = 3;
-                    x = 0;
-                    len = (int)(a.cum[rid + 1] - a.cum[rid]);
-                    want = false;
-                    if (!(a.skip && a.skip[rid])) { phase = PH_PIVOT3; read_take(rv, lds_col, a.packed, a.read_w, rid); }
-                }
-                if (__any(got && t >= nseq)) q3_empty = true;
-            }
-            // nothing to take right now.  Has round 1 ended everywhere?  Then q2_reserved is final, tickets beyond it are void,
-            // and a wave whose chunk is used up or void may leave.
-            if (q1_empty && q3_empty && __ballot(want)) {
-                if (!done && (idle_polls++ & 3) == 0) {
-                    unsigned long long d = 0;
-                    if (lane == 0) d = ld_agent(&a.ctr->r1_done);
-                    d = bcast0_u64(d);
-                    if (d >= nseq) {
-                        unsigned long long res = 0;
-                        if (lane == 0) res = ld_agent(&a.ctr->q2_reserved);
-                        q2_final = bcast0_u64(res);
-                        if (q2_final > (unsigned long long)fa.q2_cap) q2_final = (unsigned long long)fa.q2_cap;
-                        done = true;
-                    }
-                }
-                if (done && wt2.left > 0 && wt2.next >= q2_final) { q2_closed = true; wt2.left = 0; }
-                if (q2_closed && want) phase = PH_EXIT;
-            }
-        }
-        // finished round-1 reads are reported per wave, in batches: one atomic per read on one word would be ~1 M of them
-        {
-            const unsigned long long fm = __ballot(fin1);
-            r1_fin += __popcll(fm);
-            const bool r1_active = __any(mode == 1 && phase != PH_FETCH && phase != PH_EXIT);
-            if (r1_fin >= 32 || (r1_fin > 0 && q1_empty && !r1_active)) {
-                if (lane == 0) atomicAdd(&a.ctr->r1_done, (unsigned long long)r1_fin);
-                r1_fin = 0;
-            }
-        }
-        if (__all(phase == PH_EXIT)) break;
-        if (__all(phase == PH_EXIT || phase == PH_FETCH)) {
-            __builtin_amdgcn_s_sleep(64);                       // an idle wave: look again in a few microseconds
-            continue;
-        }
-
-        // ---- open a pivot (rounds 1, 2) --------------------------------------------------------
-        fin1 = false;
-        if (phase == PH_PIVOT) {
-            if (x >= len) {
-                phase = PH_FETCH;
-                fin1 = mode == 1;
-            } else {
-                const int c = base_at(rv, x);
-                if (c >= 4) {
-                    x = x + 1;
-                    if (mode != 1) phase = PH_FETCH;
-                } else {
-                    ck = cnt_at(f, c);
-                    cl = cnt_at(f, 3 - c);
-                    cs = cnt_at(f, c + 1) - ck;
-                    cn = x;
-                    j = x + 1;
-                    next_x = x + 1;
-                    num_prev = 0;
-                    phase = PH_FWD;
-                }
-            }
-        }
-        // ---- open a pivot (round 3) --------------------------------------------------------------
-        if (phase == PH_PIVOT3) {
-            if (x >= len) {
-                phase = PH_FETCH;
-            } else {
-                const int c = base_at(rv, x);
-                next_x = x + 1;
-                if (c >= 4) {
-                    x = next_x;
-                } else {
-                    ck = cnt_at(f, c);
-                    cl = cnt_at(f, 3 - c);
-                    cs = cnt_at(f, c + 1) - ck;
-                    j = x + 1;
-                    phase = PH_FWD3;
-                }
-            }
-        }
-
-        bool do_ext = false;
-        int64_t ek = 0, el = 0, es = 0;
-        int ea = 0;
-        int64_t pk = 0, pl = 0, ps = 0;
-        int pn = 0;
-
-        // ---- forward phase: pre ------------------------------------------------------
-        if (phase == PH_FWD) {
-            phase = PH_FWD_END;
-            if (j < len) {
-                const int c = base_at(rv, j);
-                next_x = j + 1;
-                if (c < 4) {
-                    phase = PH_FWD;
-                    do_ext = true;
-                    ek = cl; el = ck; es = cs;
-                    ea = 3 - c;
-                }
-            }
-        }
-        if (phase == PH_FWD_END) {
-            if (cs >= min_intv) {
-                prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
-                num_prev++;
-            }
-            base = cap - num_prev;
-            j = x - 1;
-            p = 0; num_curr = 0; curr_s = -1; first = true;
-            cur_m = x;
-            phase = PH_BWD;
-        }
-        // ---- backward phase: pre -----------------------------------------------------
-        if (phase == PH_BWD && !do_ext) {
-            bool go = true;
-            if (p == 0) {
-                go = false;
-                if (num_prev != 0 && j >= 0) {
-                    bwd_a = base_at(rv, j);
-                    go = bwd_a < 4;
-                }
-            }
-            if (!go) {
-                phase = PH_BWD_END;
-            } else {
-                prev_get(prev, base, p, pk, pl, ps, pn);
-                do_ext = true;
-                ek = pk; el = pl; es = ps; ea = bwd_a;
-            }
-        }
-        // ---- round 3: pre ---------------------------------------------------------------
-        if (phase == PH_FWD3) {
-            bool stop = true;
-            if (j < len) {
-                const int c = base_at(rv, j);
-                next_x = j + 1;
-                if (c < 4) {
-                    do_ext = true;
-                    ek = cl; el = ck; es = cs;
-                    ea = 3 - c;
-                    stop = false;
-                }
-            }
-            if (stop) {
-                x = next_x;
-                phase = PH_PIVOT3;
-            }
-        }
-
-        if (diag) {
-            const int act = __popcll(__ballot(do_ext));
-            if (q1_empty) { d_iters_b++; d_active_b += act; } else { d_iters++; d_active += act; }
-            if (q1_empty && !d_seen_q1) {
-                d_seen_q1 = true;
-                const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-                if (lane == 0) { atomicMin(&a.ctr->dbg[1], t); atomicMax(&a.ctr->dbg[2], t); }
-            }
-            if (done && !d_seen_done) {
-                d_seen_done = true;
-                const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-                if (lane == 0) atomicMin(&a.ctr->dbg[3], t);
-            }
-        }
-        // ---- the one extension of this iteration -------------------------------------
-        int64_t nk = 0, nl = 0, ns = 0;
-        ext_step<OCC16>(f, oc, do_ext, ek, el, es, ea, nk, nl, ns);
-        if (do_ext) {
-            const uint32_t nb = ((ek >> 6) == ((ek + es) >> 6)) ? 1u : 2u;
-            ne1 += mode == 1; ne2 += mode == 2; ne3 += mode == 3;
-            nb1 += mode == 1 ? nb : 0u; nb2 += mode == 2 ? nb : 0u; nb3 += mode == 3 ? nb : 0u;
-        }
-
-        // ---- post ---------------------------------------------------------------------
-        if (do_ext && phase == PH_FWD) {
-            if (ns != cs) {
-                prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
-                num_prev++;
-            }
-            if (ns < min_intv) {
-                next_x = j;
-                phase = PH_FWD_END;
-            } else {
-                ck = nl; cl = nk; cs = ns; cn = j;
-                j++;
-            }
-            if (phase == PH_FWD_END) {
-                if (cs >= min_intv) {
-                    prev_push(prev, cap - 1 - num_prev, num_prev, ck, cl, cs, cn);
-                    num_prev++;
-                }
-                base = cap - num_prev;
-                j = x - 1;
-                p = 0; num_curr = 0; curr_s = -1; first = true;
-                cur_m = x;
-                phase = PH_BWD;
-            }
-        } else if (do_ext && phase == PH_BWD) {
-            bool keep = false;
-            if (first) {
-                if (ns < min_intv && (pn - cur_m + 1) >= a.min_seed_len) {
-                    em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)pn; em_k = pk; em_l = pl; em_s = ps;
-                    first = false;
-                } else if (ns >= min_intv && ns != (int64_t)curr_s) {
-                    keep = true;
-                    first = false;
-                }
-            } else {
-                keep = ns >= min_intv && ns != (int64_t)curr_s;
-            }
-            if (keep) {
-                curr_s = (int32_t)ns;
-                prev_put(prev, base, num_curr, nk, nl, ns, pn);
-                num_curr++;
-            }
-            p++;
-            if (p == num_prev) {
-                num_prev = num_curr;
-                if (num_curr == 0) {
-                    phase = PH_BWD_END;
-                } else {
-                    cur_m = j;
-                    j--;
-                    p = 0; num_curr = 0; curr_s = -1; first = true;
-                }
-            }
-        } else if (do_ext && phase == PH_FWD3) {
-            ck = nl; cl = nk; cs = ns;
-            if (cs < fa.max_intv && (j - x + 1) >= fa.min_seed_len3) {
-                em = cs > 0;
-                em_m = (uint32_t)x;
-                em_n = (uint32_t)j;
-                em_k = ck; em_l = cl; em_s = cs;
-                x = next_x;
-                phase = PH_PIVOT3;
-            }
-            j++;
-        }
-        fused_emit(a, fa, wo, em, mode, rid, em_m, em_n, em_k, em_l, em_s);
-        r1_fin += __popcll(__ballot(fin1));
-    }
-    if (diag && lane == 0) {
-        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-        atomicMax(&a.ctr->dbg[4], t);
-        atomicMin(&a.ctr->dbg[9], t);
-        atomicAdd(&a.ctr->dbg[5], d_iters); atomicAdd(&a.ctr->dbg[6], d_active);
-        atomicAdd(&a.ctr->dbg[7], d_iters_b); atomicAdd(&a.ctr->dbg[8], d_active_b);
-    }
-    // close the wave's chunk, add up the counters
-    if (wo.base >= 0) {
-        const long long sl = wo.base + wo.used + lane;
-        if (wo.used + lane < kChunk && sl < a.pool_cap) a.pool[sl].rid = kHoleRid;
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        uint32_t e = r == 0 ? wo.em1 : r == 1 ? wo.em2 : wo.em3, x1 = r == 0 ? ne1 : r == 1 ? ne2 : ne3,
-                 b1 = r == 0 ? nb1 : r == 1 ? nb2 : nb3;
-        for (int o = 32; o > 0; o >>= 1) {
-            e += __shfl_down(e, o);
-            x1 += __shfl_down(x1, o);
-            b1 += __shfl_down(b1, o);
-        }
-        if (lane == 0) {
-            if (e) atomicAdd(&a.ctr->fz_valid[r], (unsigned long long)e);
-            if (x1) atomicAdd(&a.ctr->fz_ext[r], (unsigned long long)x1);
-            if (b1) atomicAdd(&a.ctr->fz_blk[r], (unsigned long long)b1);
-        }
-    }
-}
-
-// after the fused launch: the per-round figures in the fields the three-launch path fills
-__global__ void mark_fused_kernel(DevCounters *ctr, long long q2_cap) {
-    unsigned long long v = 0, e = 0, b = 0;
-    for (int r = 0; r < 3; ++r) {
-        v += ctr->fz_valid[r]; e += ctr->fz_ext[r]; b += ctr->fz_blk[r];
-        ctr->valid_after[r] = v; ctr->ext_after[r] = e; ctr->blk_after[r] = b;
-    }
-    ctr->n_smem_valid = v; ctr->n_ext = e; ctr->n_ext_blocks = b;
-    ctr->n_work2 = ctr->q2_reserved;
-    if ((long long)ctr->q2_reserved > q2_cap) ctr->overflow = ctr->q2_reserved;
-    ctr->n_after_r1 = ctr->n_after_r2 = ctr->n_smem_total;
 }
 
 // (rid, m, n) sort key of each pooled SMEM
@@ -1571,11 +935,6 @@ void launch_pack_reads(const uint8_t *enc, const int64_t *cum, int64_t nseq, int
     pack_reads_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(enc, cum, nseq, W, cw, packed);
 }
 
-void launch_occ16_build(const uint4 *cp, int64_t n_blk, int64_t sentinel, uint4 *mini, uint4 *super, int64_t *hy1_dev, hipStream_t st) {
-    (void)sentinel; (void)hy1_dev;
-    if (n_blk > 0) occ16_build_kernel<<<256 * 16, 256, 0, st>>>(cp, n_blk, mini, super);
-}
-
 void launch_build_fma(const DevFmi &f, int all_bp, uint32_t *all_tab, int last_bp, uint4 *last_tab, hipStream_t st) {
     const int64_t na = (int64_t)1 << (2 * all_bp), nl = (int64_t)1 << (2 * last_bp);
     build_all_smem_kernel<<<(unsigned)((na + 255) / 256), 256, 0, st>>>(f, all_bp, all_tab);
@@ -1589,8 +948,7 @@ int64_t seed_pool_slack(int cu_count) { return seed_max_threads(cu_count) / 64 *
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
 
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st) {
-    if (a.fmi.mini) smem_search_kernel<true, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
-    else smem_search_kernel<true, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
+    smem_search_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
 }
 
 void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
@@ -1600,19 +958,11 @@ void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap,
 
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     // the number of items is only known on the device: launch the persistent grid at chip size
-    if (a.fmi.mini) smem_search_kernel<false, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
-    else smem_search_kernel<false, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+    smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {
-    if (a.fmi.mini) seed_strategy_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
-    else seed_strategy_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
-}
-
-void launch_smem_fused(const SeedLaunch &a, const FusedLaunch &fa, int cu_count, hipStream_t st) {
-    if (a.fmi.mini) smem_fused_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, fa);
-    else smem_fused_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, fa);
-    mark_fused_kernel<<<1, 1, 0, st>>>(a.ctr, (long long)fa.q2_cap);
+    seed_strategy_kernel<<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
 }
 
 void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, uint32_t hole_key_rid,

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void sa_lookup_kernel(DevFmi f, const bwams_sm
                 break;
             }
             const uint4 *p = f.cp + ((sp >> 6) << 2);
-            const uint4 h01 = p[2], h23 = p[3];
+            // the whole block in one round trip: the count of the row's base would otherwise be a second, dependent load
+            const uint4 c01 = p[0], c23 = p[1], h01 = p[2], h23 = p[3];
             const int sh = 63 - (int)(sp & 63);
             const uint64_t h0 = mk64(h01.x, h01.y), h1 = mk64(h01.z, h01.w);
             const uint64_t h2 = mk64(h23.x, h23.y), h3 = mk64(h23.z, h23.w);
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void sa_lookup_kernel(DevFmi f, const bwams_sm
             if (b == 4) { val = 0; break; }
             const int y = (int)(sp & 63);
             const uint64_t mask = y ? (~0ull << (64 - y)) : 0ull;
-            const int64_t cnt = reinterpret_cast<const int64_t *>(p)[b];
+            const int64_t cnt = (int64_t)(b == 0 ? mk64(c01.x, c01.y) : b == 1 ? mk64(c01.z, c01.w) : b == 2 ? mk64(c23.x, c23.y) : mk64(c23.z, c23.w));
             sp = (b == 0 ? f.count[0] : b == 1 ? f.count[1] : b == 2 ? f.count[2] : f.count[3]) + cnt +
                  __popcll(hb & mask);
             off++;

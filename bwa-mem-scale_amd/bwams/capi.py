@@ -39,6 +39,8 @@ SYMBOLS = [
     "bwams_emf_from_device", "bwams_emf_run", "bwams_emf_fetch",
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
+    "bwams_process_reads", "bwams_process_reads_stage1", "bwams_process_reads_stage2", "bwams_host_alloc", "bwams_host_free",
+    "bwams_shard_bounds", "bwams_multi_create", "bwams_multi_process_reads", "bwams_multi_fetch", "bwams_multi_error", "bwams_multi_destroy",
     "bwams_dedup_run", "bwams_dedup_fetch", "bwams_chain_run_ert", "bwams_pestat", "bwams_pestat_keys", "bwams_pestat_from_keys", "bwams_pair_run", "bwams_pair_run_sam", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
 ]
 ERT_MEM_DTYPE = np.dtype([("forward", "u1"), ("pad_", "u1", (3,)), ("start", "<i4"), ("end", "<i4"), ("rc_start", "<i4"),
@@ -809,6 +811,26 @@ class Batch:
         text, off, _ = self.sam_fetch()
         return text, off
 
+    def process_reads(self, enc, cum, names, name_off, quals=None, comments=None, comment_off=None, paired: bool = False, emf=None,
+                      ert=None, seed_opt=None, opt: MemOpt | None = None, sopt=None, pes=None, n_processed: int = 0, flags: int = 0,
+                      fetch: bool = True):
+        """mem_process_seqs for a chunk of parsed records (bwams_process_reads: the form the reference hands over) -> (SAM text,
+        read_off), or the byte count with fetch=False."""
+        seed_opt = seed_opt or default_seed_opt()
+        opt = opt or default_mem_opt()
+        sopt = sopt or default_sam_opt()
+        a = _flat_records(enc, cum, names, name_off, quals, comments, comment_off)
+        nb = C.c_int64(0)
+        pp = _p(np.ascontiguousarray(pes, PESTAT_DTYPE)) if pes is not None else None
+        _chk(lib().bwams_process_reads(self.h, emf.h if emf is not None else None, ert.h if ert is not None else None, C.byref(seed_opt),
+                                       C.byref(opt), C.byref(sopt), *a, 1 if paired else 0, pp, C.c_int64(n_processed), flags, C.byref(nb)),
+             "bwams_process_reads")
+        self._nseq, self._sam_bytes = len(cum) - 1, nb.value
+        if not fetch:
+            return nb.value
+        text, off, _ = self.sam_fetch()
+        return text, off
+
     def process_chunk2(self, fastq1: bytes, fastq2: bytes, emf=None, ert=None, seed_opt=None, opt: MemOpt | None = None, sopt=None, pes=None,
                        n_processed: int = 0, flags: int = 0, copy_comment: bool = False):
         """A paired-end chunk given as the two files' texts (bwams_process_chunk2) -> (SAM text, read_off)."""
@@ -984,3 +1006,76 @@ class Batch:
         if self.h:
             lib().bwams_batch_destroy(self.h)
             self.h = None
+
+
+def _flat_records(enc, cum, names, name_off, quals, comments, comment_off):
+    """the argument block (enc, cum, n, names, name_off, quals, comments, comment_off) of bwams_process_reads and its relatives;
+    the arrays are kept alive by the returned tuple's owner for the duration of the call only"""
+    enc = np.ascontiguousarray(enc, np.uint8)
+    cum = np.ascontiguousarray(cum, np.int64)
+    names = np.ascontiguousarray(names, np.uint8)
+    name_off = np.ascontiguousarray(name_off, np.int64)
+    q = np.ascontiguousarray(quals, np.uint8) if quals is not None else None
+    c = np.ascontiguousarray(comments, np.uint8) if comments is not None else None
+    co = np.ascontiguousarray(comment_off, np.int64) if comment_off is not None else None
+    _flat_records.keep = (enc, cum, names, name_off, q, c, co)
+    return (_p(enc), _p(cum), C.c_int64(len(cum) - 1), _p(names), _p(name_off), _p(q), _p(c), _p(co))
+
+
+def shard_bounds(n_reads: int, n_shards: int, paired: bool = False) -> np.ndarray:
+    """bwams_shard_bounds: where the shards of a chunk begin (n_shards + 1 read indices)"""
+    b = np.zeros(n_shards + 1, np.int64)
+    _chk(lib().bwams_shard_bounds(C.c_int64(n_reads), n_shards, 1 if paired else 0, _p(b)), "bwams_shard_bounds")
+    return b
+
+
+class Multi:
+    """One chunk over several batches (one per GPU, or several on one GPU) behind one call: host/chunk_multi.cpp."""
+
+    def __init__(self, batches, emfs=None, erts=None):
+        self.batches = list(batches)
+        n = len(self.batches)
+        arr = (C.c_void_p * n)(*[b.h for b in self.batches])
+        ea = (C.c_void_p * n)(*[e.h for e in emfs]) if emfs else None
+        ra = (C.c_void_p * n)(*[e.h for e in erts]) if erts else None
+        self.h = C.c_void_p()
+        _chk(lib().bwams_multi_create(arr, ea, ra, n, C.byref(self.h)), "bwams_multi_create")
+        self._n = 0
+
+    def process_reads(self, enc, cum, names, name_off, quals=None, comments=None, comment_off=None, paired: bool = False, seed_opt=None,
+                      opt: MemOpt | None = None, sopt=None, pes=None, n_processed: int = 0, flags: int = 0):
+        """-> (SAM text of the chunk in read order, read_off[n + 1])"""
+        seed_opt = seed_opt or default_seed_opt()
+        opt = opt or default_mem_opt()
+        sopt = sopt or default_sam_opt()
+        a = _flat_records(enc, cum, names, name_off, quals, comments, comment_off)
+        nb = C.c_int64(0)
+        pp = _p(np.ascontiguousarray(pes, PESTAT_DTYPE)) if pes is not None else None
+        L = lib()
+        L.bwams_multi_error.restype = C.c_char_p
+        rc = L.bwams_multi_process_reads(self.h, C.byref(seed_opt), C.byref(opt), C.byref(sopt), *a, 1 if paired else 0, pp,
+                                         C.c_int64(n_processed), flags, C.byref(nb))
+        if rc:
+            raise BwamsError(rc, "bwams_multi_process_reads", (L.bwams_multi_error(self.h) or b"").decode())
+        n = len(cum) - 1
+        buf = np.zeros(max(nb.value, 1), np.uint8)
+        off = np.zeros(n + 1, np.int64)
+        _chk(L.bwams_multi_fetch(self.h, _p(buf), C.c_int64(nb.value), _p(off)), "bwams_multi_fetch")
+        return buf[:nb.value].tobytes(), off
+
+    def close(self):
+        if self.h:
+            lib().bwams_multi_destroy(self.h)
+            self.h = None
+
+
+def pinned_array(n: int, dtype=np.uint8) -> np.ndarray:
+    """a numpy view of page-locked host memory (bwams_host_alloc); freed when the array is garbage collected"""
+    dt = np.dtype(dtype)
+    p = C.c_void_p()
+    _chk(lib().bwams_host_alloc(C.c_size_t(max(n, 1) * dt.itemsize), C.byref(p)), "bwams_host_alloc")
+    buf = (C.c_uint8 * (max(n, 1) * dt.itemsize)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n)
+    import weakref
+    weakref.finalize(buf, lambda a=p.value: lib().bwams_host_free(C.c_void_p(a)))
+    return arr

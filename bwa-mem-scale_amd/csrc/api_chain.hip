@@ -1408,21 +1408,10 @@ int bwams_sam_fetch(bwams_batch_t *b, char *sam, int64_t cap, int64_t *read_off,
 // The outer boundary for one chunk, text to text: what kt_pipeline's step 0 parsing and step 1 (mem_process_seqs, src/bwamem.cpp:1850-1980)
 // do between the decompressed FASTQ bytes and seqs[i].sam, as the sequence of the stage calls above.
 // mem_process_seqs for a decoded chunk (fq is closed here): the stage calls in worker order
-static int process_decoded(bwams_batch_t *b, bwams_fastq_t *fq, int64_t n, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so,
-                           const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt, int32_t paired, const bwams_pestat_t *pes0,
-                           int64_t n_processed, int32_t flags, int64_t *sam_bytes) {
+// worker_bwt + worker_aln for the chunk the batch holds (reads and names uploaded): EMF, seeding, chaining, extension, de-duplication
+static int process_stage1(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo) {
     int rc;
-    if (n == 0) {                                         // an empty chunk: no reads, no text
-        bwams_fastq_close(fq);
-        if (b->chain) { b->chain->sm_done = true; b->chain->sm_bytes = 0; b->chain->sm_nregs = 0; b->chain->nseq = 0; b->chain->sm_merged_n = -1; }
-        b->nseq = 0;
-        if (sam_bytes) *sam_bytes = 0;
-        return BWAMS_OK;
-    }
-    rc = bwams_fastq_to_batch_opt(fq, b, (flags & BWAMS_CHUNK_COPY_COMMENT) ? 1 : 0);      // process(): comments only with `mem -C`
-    bwams_fastq_close(fq);
-    if (rc) return rc;
-    int64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int64_t t0 = 0, t1 = 0;
     if (emf) {                                            // kernel 0 of mem_kernel1_core: is_pm[], then mem_perfect2reg for the resolved reads
         if ((rc = bwams_emf_run(b, emf))) return rc;
         if ((rc = bwams_emf_regs_run(b, emf, mo, &t0))) return rc;
@@ -1430,21 +1419,121 @@ static int process_decoded(bwams_batch_t *b, bwams_fastq_t *fq, int64_t n, bwams
     if ((rc = ert ? bwams_seed_run_ert(b, ert, so, 1) : bwams_seed_run(b, so, 1))) return rc;
     if ((rc = bwams_chain_run(b, mo, &t0, &t1))) return rc;
     if ((rc = bwams_extend_run(b, mo, &t0))) return rc;
-    if ((rc = bwams_dedup_run(b, mo, &t0))) return rc;
+    return bwams_dedup_run(b, mo, &t0);
+}
+
+// worker_sam: primary marking / mate rescue + pairing, mem_reg2aln of what is printed, the SAM text.  pes: the chunk's statistics
+// (paired-end; mem_pestat runs between the two stages, over the WHOLE chunk: bwamem.cpp:1881-1891).  id_base: n_processed for
+// single-end, n_processed >> 1 for paired-end, plus the reads / pairs of the chunk in front of this batch when the chunk is sharded.
+static int process_stage2(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt,
+                          int32_t paired, const bwams_pestat_t *pes, int64_t id_base, int32_t flags, int64_t *sam_bytes) {
+    int rc;
+    int64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (!paired) {
-        if ((rc = bwams_pair_run_sam(b, mo, sam_opt, nullptr, n_processed, BWAMS_PAIR_SINGLE_END, &t0, &t1))) return rc;
+        if ((rc = bwams_pair_run_sam(b, mo, sam_opt, nullptr, id_base, BWAMS_PAIR_SINGLE_END, &t0, &t1))) return rc;
         if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, nullptr, &t0, &t1, &t2, &t3))) return rc;
-        rc = emf ? bwams_sam_run_emf(b, mo, sam_opt, emf, sam_bytes) : bwams_sam_run(b, mo, sam_opt, sam_bytes);
-    } else {
-        bwams_pestat_t pes[4];
-        if (pes0) memcpy(pes, pes0, sizeof pes);
-        else if ((rc = bwams_pestat(b, mo, pes))) return rc;          // mem_pestat sees the regions of worker_aln only (bwamem.cpp:1881-1891) ...
-        if (emf && (rc = bwams_emf_regs_merge(b, &t0))) return rc;       // ... worker_sam then gives the resolved ends theirs (:1689-1702)
-        if ((rc = bwams_pair_run_sam(b, mo, sam_opt, pes, n_processed >> 1, (flags & BWAMS_PAIR_NO_RESCUE) | (ert ? BWAMS_PAIR_USE_ERT : 0), &t0, &t1))) return rc;
-        if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, pes, &t0, &t1, &t2, &t3))) return rc;
-        rc = bwams_sam_run_pe(b, mo, sam_opt, pes, sam_bytes);
+        return emf ? bwams_sam_run_emf(b, mo, sam_opt, emf, sam_bytes) : bwams_sam_run(b, mo, sam_opt, sam_bytes);
     }
-    return rc;
+    if (emf && (rc = bwams_emf_regs_merge(b, &t0))) return rc;            // worker_sam gives the resolved ends their regions (:1689-1702)
+    if ((rc = bwams_pair_run_sam(b, mo, sam_opt, pes, id_base, (flags & BWAMS_PAIR_NO_RESCUE) | (ert ? BWAMS_PAIR_USE_ERT : 0), &t0, &t1))) return rc;
+    if ((rc = bwams_reg2aln_run_sam(b, mo, sam_opt, pes, &t0, &t1, &t2, &t3))) return rc;
+    return bwams_sam_run_pe(b, mo, sam_opt, pes, sam_bytes);
+}
+
+static void process_empty(bwams_batch_t *b, int64_t *sam_bytes) {      // an empty chunk: no reads, no text
+    if (b->chain) { b->chain->sm_done = true; b->chain->sm_bytes = 0; b->chain->sm_nregs = 0; b->chain->nseq = 0; b->chain->sm_merged_n = -1; }
+    b->nseq = 0;
+    if (sam_bytes) *sam_bytes = 0;
+}
+
+// mem_process_seqs for the chunk the batch holds
+static int process_uploaded(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                            const bwams_sam_opt_t *sam_opt, int32_t paired, const bwams_pestat_t *pes0, int64_t n_processed, int32_t flags,
+                            int64_t *sam_bytes) {
+    int rc = process_stage1(b, emf, ert, so, mo);
+    if (rc) return rc;
+    bwams_pestat_t pes[4];
+    if (paired) {
+        if (pes0) memcpy(pes, pes0, sizeof pes);
+        else if ((rc = bwams_pestat(b, mo, pes))) return rc;          // mem_pestat sees the regions of worker_aln only (bwamem.cpp:1881-1891)
+    }
+    return process_stage2(b, emf, ert, mo, sam_opt, paired, paired ? pes : nullptr, paired ? n_processed >> 1 : n_processed, flags, sam_bytes);
+}
+
+// mem_process_seqs for a decoded chunk (fq is closed here): the stage calls in worker order
+static int process_decoded(bwams_batch_t *b, bwams_fastq_t *fq, int64_t n, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so,
+                           const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt, int32_t paired, const bwams_pestat_t *pes0,
+                           int64_t n_processed, int32_t flags, int64_t *sam_bytes) {
+    if (n == 0) {
+        bwams_fastq_close(fq);
+        process_empty(b, sam_bytes);
+        return BWAMS_OK;
+    }
+    const int rc = bwams_fastq_to_batch_opt(fq, b, (flags & BWAMS_CHUNK_COPY_COMMENT) ? 1 : 0);      // process(): comments only with `mem -C`
+    bwams_fastq_close(fq);
+    if (rc) return rc;
+    return process_uploaded(b, emf, ert, so, mo, sam_opt, paired, pes0, n_processed, flags, sam_bytes);
+}
+
+// mem_process_seqs for a chunk that arrives the way the reference hands it over — parsed records (bseq1_t: name, comment, seq, qual),
+// here as flat arrays: enc_qdb / cum_len as bwams_seed_upload takes them, names / quals / comments as bwams_sam_upload takes them.
+int bwams_process_reads(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                        const bwams_sam_opt_t *sam_opt, const uint8_t *enc_qdb, const int64_t *cum_len, int64_t n_reads, const char *names,
+                        const int64_t *name_off, const char *quals, const char *comments, const int64_t *comment_off, int32_t paired,
+                        const bwams_pestat_t *pes0, int64_t n_processed, int32_t flags, int64_t *sam_bytes) {
+    if (!b || !so || !mo || !sam_opt || n_reads < 0 || (n_reads > 0 && (!enc_qdb || !cum_len || !names || !name_off))) {
+        set_last_error("bwams_process_reads: batch, options, reads and names are required");
+        return BWAMS_ERR_ARG;
+    }
+    if (paired && (n_reads & 1)) {
+        set_last_error("bwams_process_reads: a paired-end chunk holds an even number of reads (ends interleaved)");
+        return BWAMS_ERR_ARG;
+    }
+    if (n_reads == 0) { process_empty(b, sam_bytes); return BWAMS_OK; }
+    int rc = bwams_seed_upload(b, enc_qdb, cum_len, nullptr, (int32_t)n_reads);
+    if (rc) return rc;
+    if ((rc = bwams_sam_upload(b, names, name_off, quals, comments, comment_off))) return rc;
+    return process_uploaded(b, emf, ert, so, mo, sam_opt, paired, pes0, n_processed, flags, sam_bytes);
+}
+
+// The same in two halves, for a chunk sharded over several batches (one per GPU): stage 1 up to the regions mem_pestat reads, then —
+// after the caller has merged the shards' bwams_pestat_keys with bwams_pestat_from_keys — stage 2 with the chunk's statistics and this
+// shard's first read / pair id.  bwams_process_reads == _stage1 + bwams_pestat + _stage2 on one batch.
+int bwams_process_reads_stage1(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                               const uint8_t *enc_qdb, const int64_t *cum_len, int64_t n_reads, const char *names, const int64_t *name_off,
+                               const char *quals, const char *comments, const int64_t *comment_off) {
+    if (!b || !so || !mo || n_reads < 0 || (n_reads > 0 && (!enc_qdb || !cum_len || !names || !name_off))) {
+        set_last_error("bwams_process_reads_stage1: batch, options, reads and names are required");
+        return BWAMS_ERR_ARG;
+    }
+    if (n_reads == 0) { process_empty(b, nullptr); return BWAMS_OK; }
+    int rc = bwams_seed_upload(b, enc_qdb, cum_len, nullptr, (int32_t)n_reads);
+    if (rc) return rc;
+    if ((rc = bwams_sam_upload(b, names, name_off, quals, comments, comment_off))) return rc;
+    return process_stage1(b, emf, ert, so, mo);
+}
+
+int bwams_process_reads_stage2(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt,
+                               int32_t paired, const bwams_pestat_t *pes, int64_t id_base, int32_t flags, int64_t *sam_bytes) {
+    if (!b || !mo || !sam_opt || (paired && !pes)) {
+        set_last_error("bwams_process_reads_stage2: batch, options and (paired-end) the chunk's statistics are required");
+        return BWAMS_ERR_ARG;
+    }
+    if (b->nseq == 0) { process_empty(b, sam_bytes); return BWAMS_OK; }
+    return process_stage2(b, emf, ert, mo, sam_opt, paired, pes, id_base, flags, sam_bytes);
+}
+
+// Page-locked host memory for the buffers that cross PCIe every chunk (reads and names up, SAM text down): the copies of
+// bwams_seed_upload / bwams_sam_upload / bwams_sam_fetch then run at the link's rate instead of through a pageable bounce buffer.
+int bwams_host_alloc(size_t bytes, void **out) {
+    if (!out) return BWAMS_ERR_ARG;
+    *out = nullptr;
+    BWAMS_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return BWAMS_OK;
+}
+int bwams_host_free(void *p) {
+    if (p) BWAMS_HIP(hipHostFree(p));
+    return BWAMS_OK;
 }
 
 int bwams_process_chunk(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,

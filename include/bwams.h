@@ -20,6 +20,7 @@
 #ifndef BWAMS_H
 #define BWAMS_H
 
+#include <stddef.h>
 #include <stdint.h>
 #include "bwams_types.h"
 
@@ -529,6 +530,43 @@ int bwams_process_chunk_smart(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *e
                               const bwams_sam_opt_t *sam_opt, const char *fastq, int64_t n_bytes, const bwams_pestat_t *pes0,
                               int64_t n_processed, int32_t flags, int64_t *n_reads, int64_t *n_single, int64_t *sam_bytes);
 #define BWAMS_CHUNK_COPY_COMMENT 0x100
+
+/* mem_process_seqs (src/bwamem.cpp:1850-1903) for a chunk that arrives the way the reference hands it over: parsed records (bseq1_t:
+ * name, comment, seq, qual — src/bwa.h:76-86), here as flat arrays — enc_qdb / cum_len as bwams_seed_upload takes them, names (NUL
+ * terminated or not: name_off[i + 1] - name_off[i] bytes each), quals (cum_len's layout, NULL when the reads carry none) and comments as
+ * bwams_sam_upload takes them.  The compiled caller with the reference's own signature is bwa-mem-scale_amd/host/mem_process_seqs_hip.cpp.
+ * Text out as bwams_process_chunk: bwams_sam_fetch. */
+int bwams_process_reads(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                        const bwams_sam_opt_t *sam_opt, const uint8_t *enc_qdb, const int64_t *cum_len, int64_t n_reads, const char *names,
+                        const int64_t *name_off, const char *quals, const char *comments, const int64_t *comment_off, int32_t paired,
+                        const bwams_pestat_t *pes0, int64_t n_processed, int32_t flags, int64_t *sam_bytes);
+/* The same in two halves, for a chunk sharded over several batches (one per GPU; host/chunk_multi.cpp drives them): stage 1 = worker_bwt +
+ * worker_aln (up to the regions mem_pestat reads); the caller merges the shards' bwams_pestat_keys with bwams_pestat_from_keys — mem_pestat
+ * is a statistic of the WHOLE chunk (bwamem.cpp:1881-1891); stage 2 = worker_sam with the chunk's statistics and the shard's first read id
+ * (single-end: n_processed + reads in front of the shard) or pair id (paired-end: (n_processed >> 1) + pairs in front of it). */
+int bwams_process_reads_stage1(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo,
+                               const uint8_t *enc_qdb, const int64_t *cum_len, int64_t n_reads, const char *names, const int64_t *name_off,
+                               const char *quals, const char *comments, const int64_t *comment_off);
+int bwams_process_reads_stage2(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt,
+                               int32_t paired, const bwams_pestat_t *pes, int64_t id_base, int32_t flags, int64_t *sam_bytes);
+/* One chunk over n batches — one per GPU, each on a replica of the index — behind one call (host/chunk_multi.cpp): the chunk is cut into n
+ * contiguous shards on read (paired-end: pair) boundaries (bwams_shard_bounds: sizes differ by at most one unit, larger shards first), one
+ * host thread drives each batch through stage 1, the shards' pestat keys are merged in-process (no collective), stage 2 runs per shard with
+ * the chunk's statistics and the shard's first id, and bwams_multi_fetch returns the text in read order with n_reads + 1 offsets.
+ * emf / ert: NULL, or one handle per batch (on that batch's device).  Results are byte-identical to one batch processing the whole chunk. */
+typedef struct bwams_multi bwams_multi_t;
+int bwams_shard_bounds(int64_t n_reads, int32_t n_shards, int32_t paired, int64_t *bounds /* n_shards + 1 */);
+int bwams_multi_create(bwams_batch_t *const *batches, bwams_emf_t *const *emf, bwams_ert_t *const *ert, int32_t n, bwams_multi_t **out);
+int bwams_multi_process_reads(bwams_multi_t *m, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt,
+                              const uint8_t *enc_qdb, const int64_t *cum_len, int64_t n_reads, const char *names, const int64_t *name_off,
+                              const char *quals, const char *comments, const int64_t *comment_off, int32_t paired, const bwams_pestat_t *pes0,
+                              int64_t n_processed, int32_t flags, int64_t *sam_bytes);
+int bwams_multi_fetch(bwams_multi_t *m, char *sam, int64_t cap, int64_t *read_off);
+const char *bwams_multi_error(const bwams_multi_t *m);       /* which shard failed, and why */
+int bwams_multi_destroy(bwams_multi_t *m);
+/* Page-locked host memory (hipHostMalloc) for the buffers that cross PCIe every chunk: reads, names and qualities up, SAM text down. */
+int bwams_host_alloc(size_t bytes, void **out);
+int bwams_host_free(void *p);
 
 #ifdef __cplusplus
 }

@@ -559,6 +559,51 @@ def main():
         "host_bytes_up": len(fq_text), "host_bytes_down": int(hb_) + 8 * (n_seq_ + 1),
         "note": "FASTQ text in pageable host memory -> SAM text and its per-read offsets in pageable host memory, one call + bwams_sam_fetch"}
     del sam_h, off_h
+    # ... and in PAGE-LOCKED host memory (bwams_host_alloc), which is what the compiled caller at the reference's boundary stages
+    # through (bwa-mem-scale_amd/host/mem_process_seqs_hip.cpp): never `value`
+    fq_pin = capi.pinned_array(len(fq_text))
+    fq_pin[:] = np.frombuffer(fq_text, np.uint8)
+    sam_pin = capi.pinned_array(int(sam_bytes) + 16)
+    off_pin = capi.pinned_array(n_seq_ + 1, np.int64)
+    pin_ms = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        hb_ = batch.process_chunk((fq_pin.ctypes.data, len(fq_text)), seed_opt=seed_opt, opt=mem_opt, sopt=sopt_, n_processed=first, fetch=False)
+        capi._chk(capi.lib().bwams_sam_fetch(batch.h, capi._p(sam_pin), len(sam_pin), capi._p(off_pin), None, 0), "bwams_sam_fetch")
+        pin_ms.append((time.perf_counter() - t0) * 1e3)
+    sam_side["fastq_to_sam"]["pcie_inclusive_pinned"] = {
+        "ms_per_chunk": round(min(pin_ms), 2), "Mreads_per_s": round(n_seq_ / (min(pin_ms) * 1e-3) / 1e6, 3),
+        "ratio_to_resident": round(min(pin_ms) / e2e_ms, 3),
+        "note": "the same call with both texts in page-locked host memory (bwams_host_alloc): what the compiled mem_process_seqs() pays per chunk"}
+    # ... and the chunk over TWO batches on this GPU behind one call (host/chunk_multi.cpp: the N-GPU form of the outer boundary with
+    # both shards on one device): parsed records in page-locked memory -> SAM text in page-locked memory, in read order
+    try:
+        b2 = [capi.Batch(ix, n_seq_, n_seq_ * RL) for _ in range(2)]
+        multi = capi.Multi(b2)
+        nm_pin = capi.pinned_array(9 * n_seq_)
+        nm_pin[:] = np.frombuffer(b"".join(b"r%08d" % (first + i) for i in range(n_seq_)), np.uint8)
+        noff_ = (np.arange(n_seq_ + 1, dtype=np.int64) * 9)
+        enc_pin = capi.pinned_array(n_seq_ * RL)
+        enc_pin[:] = rd_.reshape(-1)
+        q_pin = capi.pinned_array(n_seq_ * RL)
+        q_pin[:] = ord("I")
+        mt = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            mtext, moff = multi.process_reads(enc_pin, cum_, nm_pin, noff_, quals=q_pin, seed_opt=seed_opt, opt=mem_opt, sopt=sopt_, n_processed=first)
+            mt.append((time.perf_counter() - t0) * 1e3)
+        sam_side["fastq_to_sam"]["two_batches_one_call"] = {
+            "ms_per_chunk": round(min(mt), 2), "Mreads_per_s": round(n_seq_ / (min(mt) * 1e-3) / 1e6, 3), "same_text": bool(len(mtext) == sam_bytes),
+            "note": "bwams_multi_process_reads + bwams_multi_fetch with 2 batches on ONE GPU (parsed records up, text down, page-locked; the fetch "
+                    "lands in a pageable numpy buffer here): the code path `N GPUs behind one C call` takes, byte-identical to one batch "
+                    "(tests/test_host_boundary.py); no N > 1 hardware run exists for it"}
+        multi.close()
+        for b_ in b2:
+            b_.close()
+        del b2, multi, nm_pin, enc_pin, q_pin, mtext, moff
+    except capi.BwamsError as e:
+        sam_side["fastq_to_sam"]["two_batches_one_call"] = {"error": str(e)}
+    del fq_pin, sam_pin, off_pin
     del row, fq_text, d_fq, got_
     del aln_, cig_, md_, text_, tb, mq_, aln_r_
 

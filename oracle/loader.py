@@ -1002,3 +1002,17 @@ def chain_new_ert(mems, mem_off, hits, hit_off, cum, l_pac, contigs=None, opt: M
         c["seed_off"] = o
         o += k
     return chains, out, chain_off
+
+
+def ref_fmi_lib():
+    """CDLL of oracle/_ref/libref_fmi.so (the reference's FMI_search.h + sais.h, oracle/ref_harness_fmi.cpp) or None."""
+    path = os.path.join(HERE, "_ref", "libref_fmi.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.ref_get_occ.restype = C.c_int64
+    L.ref_get_occ.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.ref_sais.restype = C.c_int
+    L.ref_sais.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
+    L.ref_fmi_sizes.restype = C.c_int
+    return L

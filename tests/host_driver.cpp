@@ -69,7 +69,7 @@ int main(int argc, char **argv) {
             bwams_contig_t c; memset(&c, 0, sizeof c);
             c.offset = off; c.len = (int32_t)len; c.is_alt = alt;
             ctg.push_back(c);
-            names += nm; noff.push_back((int32_t)names.size());
+            names += nm; names.push_back('\0'); noff.push_back((int32_t)names.size());
             at = e + 1;
         }
         if ((rc = bwams_index_set_contigs(idx, ctg.data(), (int32_t)ctg.size())) || (rc = bwams_index_set_contig_names(idx, names.data(), noff.data()))) {

@@ -782,7 +782,7 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     D.ord = s->dd_ord.as<int32_t>(); D.srt = s->dd_srt.p; D.eh = s->dd_eh.as<int2>(); D.eh_lanes = n_lanes;
     D.max_read_len = (int32_t)L; D.n_out = s->dd_nout.as<int32_t>();
     BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
-    { const char *e = getenv("BWAMS_DEDUP_SEQ"); D.force_seq = e ? atoi(e) : 0; }
+    { const char *e = getenv("BWAMS_DEDUP_SEQ"); D.force_seq = (e && atoi(e) == 1) ? 1 : 0; }      // 1: every read through the one-lane form (tests)
     BWAMS_HIP(s->dd_light.ensure((size_t)n1 * 4));
     D.heavy = s->heavy.as<int32_t>(); D.light = s->dd_light.as<int32_t>();
     D.n_heavy_ctr = &b->d_ctr->dedup_heavy; D.ticket = &b->d_ctr->dedup_ticket; D.n_light_ctr = &b->d_ctr->dedup_light;

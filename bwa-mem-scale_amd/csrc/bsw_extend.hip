@@ -600,12 +600,9 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
     }
     const unsigned B = (unsigned)blocks, T = kWavesPerBlock * 64;
     unsigned long long *cnt = ctr->bsw_cls_cnt, *hd = ctr->bsw_cls_head;
-    static bool qwin_attr = false;
-    if (!qwin_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_qwin_kernel<kBswLpt, kBswWin>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4));
-        qwin_attr = true;
-    }
+    // per launch: the attribute belongs to the current device (a batch on a second GPU of the process needs it too)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_qwin_kernel<kBswLpt, kBswWin>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4)) != hipSuccess) return -1;
     // every class on a stream of its own, the classes of the longest queries first.  (With two classes per stream and the
     // one-task-per-wave kernel — usually without a single task, but 2048 blocks that wait for a free CU slot — in front of one
     // of them, the kernel trace showed two class launches starting 14 ms late.)

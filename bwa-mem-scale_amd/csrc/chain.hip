@@ -1074,12 +1074,10 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
                  hipEvent_t fork, hipEvent_t *join) {
     if (A.nseq <= 0) return 0;
     unsigned long long *cls = A.ctr->chain_class, *tk = A.ctr->chain_ticket;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_bytes(kClassL));
-        attr_set = true;
-    }
+    // the opt-in for more than 64 KB of dynamic LDS belongs to the CURRENT device: set per launch (a batch on a second GPU of the
+    // process needs it too), and checked
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes(kClassL)) != hipSuccess) return -1;
     if (hipEventRecord(fork, st) != hipSuccess) return -1;
     for (int i = 0; i < 5; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
@@ -1104,12 +1102,8 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     }
     chain_redo_kernel<<<(unsigned)(cu_count * 2), 64, 0, st>>>(A);
     // the filter of the many-chain reads: three size classes, concurrently, the class of the longest reads first
-    static bool heavy_attr = false;
-    if (!heavy_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)heavy_lds_bytes(kHeavyCap[2]));
-        heavy_attr = true;
-    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(chain_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)heavy_lds_bytes(kHeavyCap[2])) != hipSuccess) return -1;
     if (hipEventRecord(fork, st) != hipSuccess) return -1;
     for (int i = 0; i < 2; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;

@@ -107,7 +107,7 @@ __device__ int patch_reg(const DedupArgs &A, const uint8_t *query, const bwams_a
             ww = ww < w ? ww : w;
             const int min_w = dl + 3;
             ww = ww > min_w ? ww : min_w;
-            score = A.force_seq == 2 ? 0 : global_score(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh);   // 2: timing experiment only
+            score = global_score(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh);
         }
     }
     const int q_s = (int)((double)(b.qe - a.qb) / (double)((b.qe - b.qb) + (a.qe - a.qb)) * (double)(b.score + a.score) + .499);
@@ -422,18 +422,24 @@ __global__ void pestat_kernel(const bwams_alnreg_t *__restrict__ regs, const int
 
 constexpr int kTestN = 1024;
 // test hook: one wavefront sorts n records held in LDS, as the wave tier does (mode 0: rank sort with the exact fallback on
-// ties, 1: the operation-exact wave introsort always, 2: lane 0 alone through sort_records)
-__global__ __launch_bounds__(64) void sort_test_kernel(const SortRec *__restrict__ in, int n, int by_score, int mode, int32_t *__restrict__ order) {
+// ties, 1: the operation-exact wave introsort always, 2: lane 0 alone through sort_records on a copy in GLOBAL memory — the
+// sequential statement of the same sort; 3 / 4: modes 1 / 2 with a depth budget of 2, so that the comb-sort fallback
+// (wave_combsort / r_combsort) sorts nearly everything)
+__global__ __launch_bounds__(64) void sort_test_kernel(const SortRec *__restrict__ in, int n, int by_score, int mode, int32_t *__restrict__ order,
+                                                       SortRec *__restrict__ scratch) {
     __shared__ SortRec l_a[kTestN], l_t[kTestN];
     const int lane = threadIdx.x;
+    if (mode == 2 || mode == 4) {
+        for (int i = lane; i < n; i += 64) scratch[i] = in[i];
+        __syncthreads();
+        if (lane == 0) sort_records(scratch, n, by_score, mode == 4 ? 2 : 0);
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) order[i] = scratch[i].idx;
+        return;
+    }
     for (int i = lane; i < n; i += 64) l_a[i] = in[i];
     __syncthreads();
-    if (mode == 2) {
-        if (lane == 0) sort_records(l_a, n, by_score);
-        __syncthreads();
-    } else {
-        wave_sort_records(l_a, l_t, n, by_score, lane, mode == 1);
-    }
+    wave_sort_records(l_a, l_t, n, by_score, lane, mode == 1 || mode == 3, mode == 3 ? 2 : 0);
     for (int i = lane; i < n; i += 64) order[i] = l_a[i].idx;
 }
 
@@ -443,15 +449,17 @@ int launch_sort_test(const int64_t *k, const int32_t *s_, const int32_t *q, int 
     if (n < 0 || n > kTestN) return -1;
     SortRec *h = (SortRec *)malloc(sizeof(SortRec) * (size_t)(n + 1));
     for (int i = 0; i < n; ++i) { h[i].k = k[i]; h[i].s = s_[i]; h[i].q = q[i]; h[i].idx = i; h[i].pad_ = 0; }
-    SortRec *d_in = nullptr;
+    SortRec *d_in = nullptr, *d_scr = nullptr;
     int32_t *d_ord = nullptr;
     int rc = -1;
     if (hipMalloc(&d_in, sizeof(SortRec) * (size_t)(n + 1)) == hipSuccess && hipMalloc(&d_ord, 4 * (size_t)(n + 1)) == hipSuccess &&
+        hipMalloc(&d_scr, sizeof(SortRec) * (size_t)(n + 1)) == hipSuccess &&
         hipMemcpy(d_in, h, sizeof(SortRec) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess) {
-        sort_test_kernel<<<1, 64>>>(d_in, n, by_score, mode, d_ord);
+        sort_test_kernel<<<1, 64>>>(d_in, n, by_score, mode, d_ord, d_scr);
         if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(order, d_ord, 4 * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
     }
     if (d_in) (void)hipFree(d_in);
+    if (d_scr) (void)hipFree(d_scr);
     if (d_ord) (void)hipFree(d_ord);
     free(h);
     return rc;
@@ -472,11 +480,9 @@ int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, int64_t n
     dedup_triage_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A);
     if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(aux, fork, 0) != hipSuccess) return -1;
     // the reads with the most regions first (one wave per CU), the bulk beside them on the auxiliary streams
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dedup_wave_kernel<kLdsN, kMidN>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * kLdsN);
-        attr = true;
-    }
+    // the 120 KB of dynamic LDS of the largest instance need the opt-in on EVERY device a batch runs on (the attribute belongs to the
+    // device that is current when it is set); cheap enough to repeat per launch, and checked
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(dedup_wave_kernel<kLdsN, kMidN>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * kLdsN) != hipSuccess) return -1;
     dedup_wave_kernel<kLdsN, kMidN><<<(unsigned)n_waves, 64, 60 * kLdsN, st>>>(A, n_waves, A.eh_lanes, A.ticket);
     dedup_kernel<<<(unsigned)((n_lanes + 63) / 64), 64, 0, aux>>>(A, n_lanes);
     if (hipEventRecord(join, aux) != hipSuccess || hipStreamWaitEvent(st, join, 0) != hipSuccess) return -1;

@@ -34,6 +34,14 @@ struct bwams_fastq {
     std::vector<int64_t> cum, name_off, comment_off;       // host copies of the three offset arrays
     float ms = 0;
     bool has_qual = true;                                  // false: FASTA text
+    // a decode that fails half way (an allocation, a kernel) drops the handle: whatever it had allocated goes with it
+    ~bwams_fastq() {
+        if (d_enc || d_qual || d_names || d_comments) (void)hipSetDevice(device);
+        if (d_enc) (void)hipFree(d_enc);
+        if (d_qual) (void)hipFree(d_qual);
+        if (d_names) (void)hipFree(d_names);
+        if (d_comments) (void)hipFree(d_comments);
+    }
 };
 
 namespace bwams {
@@ -507,7 +515,6 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     BWAMS_HIP(hipGetLastError());
     (void)hipEventElapsedTime(&f->ms, e0, e1);
     if (bad[1]) {
-        (void)hipFree(f->d_enc); (void)hipFree(f->d_qual); (void)hipFree(f->d_names); (void)hipFree(f->d_comments);
         set_last_error("bwams_fastq_decode: a '-' in a read (nst_nt4_table maps it to 5, outside the alphabet of the kernels)");
         return BWAMS_ERR_UNSUPPORTED;
     }
@@ -557,13 +564,7 @@ int bwams_fastq_to_batch_opt(bwams_fastq_t *f, bwams_batch_t *b, int32_t copy_co
 int bwams_fastq_to_batch(bwams_fastq_t *f, bwams_batch_t *b) { return bwams_fastq_to_batch_opt(f, b, 1); }
 
 int bwams_fastq_close(bwams_fastq_t *f) {
-    if (!f) return BWAMS_OK;
-    (void)hipSetDevice(f->device);
-    if (f->d_enc) (void)hipFree(f->d_enc);
-    if (f->d_qual) (void)hipFree(f->d_qual);
-    if (f->d_names) (void)hipFree(f->d_names);
-    if (f->d_comments) (void)hipFree(f->d_comments);
-    delete f;
+    delete f;                                              // the destructor frees the device arrays
     return BWAMS_OK;
 }
 

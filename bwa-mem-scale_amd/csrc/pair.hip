@@ -981,11 +981,8 @@ void launch_pair_post(const PairArgs &A, int cu_count, hipStream_t st) {
 void launch_pair_mark(const PairArgs &A, int cu_count, hipStream_t st) {
     if (A.nseq <= 0) return;
     pair_mark_kernel<<<blocks_of(A.nseq, 64), 64, 0, st>>>(A);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pair_mark_wave_kernel<kMarkLdsMax, kMarkLdsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, 68 * kMarkLdsMax);
-        attr = true;
-    }
+    // per launch: the attribute belongs to the current device (a failure here surfaces as the launch error the caller checks)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pair_mark_wave_kernel<kMarkLdsMax, kMarkLdsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, 68 * kMarkLdsMax);
     pair_mark_wave_kernel<kMarkLdsMax, kMarkLdsSmall><<<(unsigned)cu_count, 64, 68 * kMarkLdsMax, st>>>(A, &A.ctr->pair_ticket);
     pair_mark_wave_kernel<kMarkLdsSmall, kMarkLight><<<(unsigned)(cu_count * 8), 64, 68 * kMarkLdsSmall, st>>>(A, &A.ctr->pair_ticket2);
 }

@@ -4,8 +4,9 @@
 //   mem_reg2aln        /root/reference/src/bwamem.cpp:2533-2628   (band inference, retry loop, clip / squeeze, position)
 //   bwa_gen_cigar2     /root/reference/src/bwa.cpp:380-467        (gap-free shortcut, band choice, NM and MD)
 //   ksw_global2        /root/reference/src/ksw.cpp:558-668        (banded global alignment with traceback)
-// (mem_approx_mapq_se, :1983-2008, is a dozen double operations per region with log(): it runs on the host in
-// bwams_reg2aln_fetch with the C library's log, so that the last bit is the reference's.)
+// (mem_approx_mapq_se, :1983-2008, is a dozen double operations per region with log(): bwams_reg2aln_fetch evaluates it on the
+// host with the C library's log; the SAM text stage evaluates it on the device from a host-filled log table
+// (sam_text.hip: sam_mapq_kernel) with equal results — both so that the last bit is the reference's.)
 //
 // Mapping.  Regions are independent.  Most need no dynamic programming at all (equal lengths and an inferred band of 0:
 // the reference's "no gap" shortcut) — aln_simple_kernel finishes those, one lane per region, and lists the rest.
@@ -131,7 +132,7 @@ __device__ void finish_record(const RegAlnArgs &A, int64_t k, const bwams_alnreg
     a.flag = ar.secondary >= 0 ? 0x100 : 0;
     a.is_rev = is_rev;
     a.is_alt = (int32_t)(((uint32_t)ar.n_comp_is_alt >> 30) & 1u);
-    a.mapq = 0;                                       // filled on the host (bwams_reg2aln_fetch)
+    a.mapq = 0;                                       // filled by bwams_reg2aln_fetch (host) / sam_mapq_kernel (device)
     a.NM = NM;
     a.n_cigar = n_cigar; a.md_len = md_len;
     a.cigar_off = 0; a.md_off = 0;

@@ -49,7 +49,7 @@ template <class LT> __device__ __forceinline__ void r_combsort(SortRec *a, int n
     } while (do_swap || gap > 2);
     if (gap != 1) r_insertsort(a, 0, n, lt);
 }
-template <class LT> __device__ __forceinline__ void r_introsort(SortRec *a, int n, LT lt) {
+template <class LT> __device__ __forceinline__ void r_introsort(SortRec *a, int n, LT lt, int depth0 = 0) {
     if (n < 1) return;
     if (n == 2) { if (lt(a[1], a[0])) { const SortRec x = a[0]; a[0] = a[1]; a[1] = x; } return; }
     int d;
@@ -57,6 +57,7 @@ template <class LT> __device__ __forceinline__ void r_introsort(SortRec *a, int 
     int stk_l[40], stk_r[40], stk_d[40], top = 0;
     int s = 0, t = n - 1;
     d <<= 1;
+    if (depth0 > 0) d = depth0;               // tests: reach the comb-sort fallback on any input
     for (;;) {
         if (s < t) {
             if (--d == 0) { r_combsort(a + s, t - s + 1, lt); t = s; continue; }
@@ -89,10 +90,10 @@ template <class LT> __device__ __forceinline__ void r_introsort(SortRec *a, int 
 // The sorts are called through this non-inlined wrapper: the pointer stays generic (LDS or HBM, flat accesses).
 // Instantiated directly on a __shared__ array the inlined introsort spun forever on gfx950 (ROCm 7.2) for a
 // six-record input that the same code sorts correctly through a generic pointer; see profiles/r01_notes.md.
-__device__ __noinline__ void sort_records(SortRec *a, int n, int by_score) {
+__device__ __noinline__ void sort_records(SortRec *a, int n, int by_score, int depth0 = 0) {
     switch (by_score) {
-    case 0: r_introsort(a, n, LtEnd()); break;
-    case 1: r_introsort(a, n, LtScore()); break;
+    case 0: r_introsort(a, n, LtEnd(), depth0); break;
+    case 1: r_introsort(a, n, LtScore(), depth0); break;
     case 2: r_introsort(a, n, LtHash()); break;
     case 3: r_introsort(a, n, LtHash2()); break;
     case 4: r_introsort(a, n, LtXY()); break;
@@ -100,9 +101,48 @@ __device__ __noinline__ void sort_records(SortRec *a, int n, int by_score) {
     }
 }
 
-// the depth-limit fallback of the wave-parallel form below (sequential, generic pointer like sort_records)
-__device__ __noinline__ void comb_records(SortRec *a, int n, int by_score) {
-    if (by_score) r_combsort(a, n, LtScore()); else r_combsort(a, n, LtEnd());
+
+// ks_combsort operation by operation with the whole wavefront (all 64 lanes call this; a in LDS, tmp = n records of LDS
+// scratch).  A pass with gap g compares (i, i + g) for i = 0 .. n - g - 1 in order; position i + g may have been written by
+// the comparison at i - g, never by any other, so the pass is g independent chains (the residue classes of i mod g), each
+// walked in order by one lane: the same compare-and-swap sequence per chain, hence the same array after the pass.  Gaps shrink
+// to 2 (two lanes), where the loop repeats until a pass swaps nothing; ks_combsort then finishes with its insertion sort — a
+// stable sort of what the passes left, i.e. the rank sort below.  This is introsort's depth-limit fallback in the wave tiers:
+// no lane sorts alone on LDS while 63 wait at a barrier (the configuration that once hung, profiles/r01_notes.md 20).
+template <class LT> __device__ void wave_combsort(SortRec *a, int n, SortRec *tmp, int lane, LT lt) {
+    const double shrink = 1.2473309501039786540366528676643;
+    unsigned long long gap = (unsigned long long)n;
+    bool do_swap;
+    do {
+        if (gap > 2) {
+            gap = (unsigned long long)((double)gap / shrink);
+            if (gap == 9 || gap == 10) gap = 11;
+        }
+        const int g = (int)gap;
+        bool sw = false;
+        for (int r = lane; r < g; r += 64)
+            for (int i = r; i + g < n; i += g)
+                if (lt(a[i + g], a[i])) { const SortRec x = a[i]; a[i] = a[i + g]; a[i + g] = x; sw = true; }
+        __syncthreads();
+        do_swap = __ballot(sw) != 0;
+    } while (do_swap || gap > 2);
+    if (gap != 1) {
+        for (int x0 = 0; x0 < n; x0 += 64) {
+            const int x = x0 + lane;
+            if (x < n) {
+                const SortRec v = a[x];
+                int pos = 0;
+                for (int y = 0; y < n; ++y) {
+                    const SortRec w = a[y];
+                    pos += (lt(w, v) || (!lt(v, w) && y < x)) ? 1 : 0;
+                }
+                tmp[pos] = v;
+            }
+        }
+        __syncthreads();
+        for (int x = lane; x < n; x += 64) a[x] = tmp[x];
+        __syncthreads();
+    }
 }
 
 // The same sorts for a one-wavefront block with the records in LDS: every lane counts the records that sort before
@@ -111,7 +151,7 @@ __device__ __noinline__ void comb_records(SortRec *a, int n, int by_score) {
 // operation-exact introsort (wave_introsort) on the untouched input instead.  All 64 lanes call this; a and tmp hold n
 // records each.  (Round 1 sent lane 0 alone into the sequential introsort here while 63 lanes waited at the barrier:
 // the configuration in which an inlined LDS instantiation once hung, profiles/r01_notes.md 20.  No lane-0-only sort call
-// on LDS is left in the wave tiers.)
+// on LDS is left in the wave tiers: the depth-limit fallback is wave_combsort above.)
 template <class LT> __device__ __forceinline__ bool wave_rank_pass(const SortRec *a, SortRec *tmp, int n, int lane, LT lt) {
     bool tie = false;
     for (int ib = 0; ib < n; ib += 64) {
@@ -140,8 +180,9 @@ template <class LT> __device__ __forceinline__ bool wave_rank_pass(const SortRec
 // min(up[m], down[m-1]).  The lists are built with ballots, the swaps are independent.  The closing insertion sort over
 // the whole array is a stable sort of what the partitions left: a rank sort (ksort's median of three never examines
 // a[s], so the element may lie far from its place: a windowed clean-up would be wrong).  The comb-sort fallback of the
-// depth limit stays sequential on lane 0, through the non-inlined generic-pointer routine.
-template <class LT> __device__ void wave_introsort(SortRec *a, int n, SortRec *tmp, int *stk, int lane, LT lt, int by_score) {
+// depth limit is wave_combsort (whose scratch is the part of tmp the stopper lists do not need at that moment: they are dead).
+// depth0 > 0 replaces the 2 ceil(log2 n) depth budget (tests reach the fallback with it).
+template <class LT> __device__ void wave_introsort(SortRec *a, int n, SortRec *tmp, int *stk, int lane, LT lt, int by_score, int depth0 = 0) {
     if (n < 2) return;
     if (n == 2) {
         if (lane == 0 && lt(a[1], a[0])) { const SortRec x = a[0]; a[0] = a[1]; a[1] = x; }
@@ -153,12 +194,14 @@ template <class LT> __device__ void wave_introsort(SortRec *a, int n, SortRec *t
     for (d = 2; (1ul << d) < (unsigned long)n; ++d);
     int top = 0, s = 0, t = n - 1;
     d <<= 1;
+    if (depth0 > 0) d = depth0;
+    (void)by_score;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (;;) {
         if (s < t) {
             if (--d == 0) {
-                if (lane == 0) comb_records(a + s, t - s + 1, by_score);
                 __syncthreads();
+                wave_combsort(a + s, t - s + 1, tmp, lane, lt);
                 t = s;
                 continue;
             }
@@ -235,8 +278,8 @@ template <class LT> __device__ void wave_introsort(SortRec *a, int n, SortRec *t
     __syncthreads();
 }
 
-// force_exact: take the operation-exact path even when no two keys are equal (tests)
-__device__ __forceinline__ void wave_sort_records(SortRec *a, SortRec *tmp, int n, int by_score, int lane, bool force_exact = false) {
+// force_exact: take the operation-exact path even when no two keys are equal (tests); depth0: see wave_introsort
+__device__ __forceinline__ void wave_sort_records(SortRec *a, SortRec *tmp, int n, int by_score, int lane, bool force_exact = false, int depth0 = 0) {
     __shared__ int l_sort_stk[120];
     if (n < 2) return;
     bool tie = true;
@@ -246,9 +289,9 @@ __device__ __forceinline__ void wave_sort_records(SortRec *a, SortRec *tmp, int 
         for (int i = lane; i < n; i += 64) a[i] = tmp[i];
         __syncthreads();
     } else if (by_score) {
-        wave_introsort(a, n, tmp, l_sort_stk, lane, LtScore(), 1);
+        wave_introsort(a, n, tmp, l_sort_stk, lane, LtScore(), 1, depth0);
     } else {
-        wave_introsort(a, n, tmp, l_sort_stk, lane, LtEnd(), 0);
+        wave_introsort(a, n, tmp, l_sort_stk, lane, LtEnd(), 0, depth0);
     }
 }
 

@@ -239,7 +239,8 @@ int bwams_reg2aln_fetch(bwams_batch_t *b, bwams_aln_t *aln, int64_t aln_cap, uin
  * eleven fields, NM / MD / AS / XS / RG / SA / pa / XA tags, the comment), with mem_approx_mapq_se (:1983-2008) evaluated on the
  * device.  Call order for a chunk: ... bwams_dedup_run, bwams_pair_run(BWAMS_PAIR_SINGLE_END) (= mem_mark_primary_se),
  * bwams_reg2aln_run(source 1), bwams_sam_upload (names / qualities / comments of the chunk: the bseq1_t fields the hot path
- * never needed), bwams_sam_run, bwams_sam_fetch.  Not built: MEM_F_PRIMARY5 (mem_reorder_primary5), MEM_F_REF_HDR: BWAMS_ERR_UNSUPPORTED.
+ * never needed), bwams_sam_run, bwams_sam_fetch.  MEM_F_PRIMARY5 (mem_reorder_primary5) acts in bwams_pair_run_sam, MEM_F_REF_HDR (XR:Z:)
+ * needs bwams_index_set_contig_annos first; both are built.
  * Paired-end chunks: bwams_sam_run_pe; chunks with reads the EMF resolved: bwams_sam_run_emf (both below). */
 /* names of the index's sequences (bntann1_t.name): NUL-terminated, back to back; name_off[n_seqs + 1], name_off[i] = start of
  * name i.  Call after bwams_index_set_contigs (or on a one-sequence index). */
@@ -309,7 +310,8 @@ int bwams_ksw_align(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n,
  * de-duplication kernel runs them, on caller-given keys of n <= 1024 records; order_out[i] = index of the i-th record
  * after the sort.  which: 0 = mem_ars2 (key k = re), 1 = mem_ars (s = score descending, k = rb, q = qb).  mode: 0 = as
  * the kernels choose (rank sort, operation-exact introsort when keys tie), 1 = the wave-parallel operation-exact
- * introsort always, 2 = ksort.h's sequential introsort on one lane. */
+ * introsort always, 2 = ksort.h's sequential introsort on one lane (over a copy in global memory); 3 / 4 = modes 1 / 2 with a depth
+ * budget of 2, so that the comb-sort fallback of the depth limit sorts nearly everything (the two must agree; the order is not ksort's). */
 int bwams_debug_sort(bwams_index_t *idx, const int64_t *k, const int32_t *s, const int32_t *q, int32_t n, int32_t which,
                      int32_t mode, int32_t *order_out);
 

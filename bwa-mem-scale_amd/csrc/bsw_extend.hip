@@ -571,6 +571,336 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
 }
 
 
+// ---- sixteen tasks per wavefront, packed 16-bit columns ---------------------------------------------------------------
+// bsw_qwin_kernel spends ≈ 290 vector instructions on a row of eight tasks: 177 in the four-columns-per-lane pass, 114 in the
+// row's bookkeeping, all of it 32-bit — although every score of these classes is below 2^14 and the packed 16-bit forms
+// (v_pk_add / sub / max / min / mul_lo) issue at the same rate (tools/ubench_valu.hip).  Here a task owns FOUR lanes (one quad:
+// every cross-lane step is a quad_perm DPP) and a lane owns EIGHT columns as four packed registers, so a wavefront carries sixteen
+// tasks: the bookkeeping is shared by twice as many tasks and the pass handles two columns per instruction, with the register
+// footprint of the 8 x 4 form (the 32-bit 4 x 8 form had lost to it on occupancy, note 32).
+//   * Row state in LDS per task: three arrays of column PAIRS — H (H(i, j-1) as scalarBandedSWA's eh[].h), E, and the v_perm
+//     selector that picks the two columns' scores out of the target base's score row — read and written 16 bytes per lane.
+//   * The window of a pass starts at a multiple of 8 columns, so a lane's eight columns are one aligned 16-byte access; the
+//     columns of the window outside [beg, end) are masked (their state reads as zero and is written back unchanged).
+//   * F is the same max-plus prefix scan: inside the lane over its eight columns (packed, the carry broadcast with v_perm),
+//     over the four lanes with two quad_perm steps.
+//   * The row maximum and the last column attaining it travel as one 32-bit key (H << 8 | j) per column through v_max3.
+// Recurrences and per-row decisions are those of bsw_qwin_kernel; results are bit-identical to scalarBandedSWA.
+// Eligible: scores below 2^14 (the class condition), every score against N equal to -1 (the selector's 0xff bytes), gap
+// extension costs small enough for j * e_ins to stay inside 16 bits.  Other scoring schemes keep the 32-bit kernel.
+namespace pk {
+__device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t sub(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t max(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t max0(uint32_t a) { uint32_t d; asm("v_pk_max_i16 %0, %1, 0" : "=v"(d) : "v"(a)); return d; }
+__device__ __forceinline__ uint32_t minu(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t mul(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t hi2(uint32_t a) { return __builtin_amdgcn_perm(a, a, 0x03020302u); }      // the high half in both halves
+__device__ __forceinline__ uint32_t lo2(uint32_t a) { return __builtin_amdgcn_perm(a, a, 0x01000100u); }      // the low half in both halves
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   // v_bfi_b32
+template <int CTRL> __device__ __forceinline__ int qdpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int quad_all_max(int v) {
+    int t = qdpp<0xB1>(v);                       // quad_perm [1,0,3,2]
+    v = v > t ? v : t;
+    t = qdpp<0x4E>(v);                           // quad_perm [2,3,0,1]
+    return v > t ? v : t;
+}
+}  // namespace pk
+
+constexpr int kPkNeg = -16384;
+
+__host__ __device__ __forceinline__ bool bsw_pk_eligible(const SwParams &prm) {
+    for (int i = 0; i < 5; ++i)
+        if (prm.mat[i * 5 + 4] != -1 || prm.mat[4 * 5 + i] != -1) return false;
+    return prm.e_ins >= 0 && prm.e_ins <= 64 && prm.e_del >= 0 && prm.e_del <= 64 && prm.o_ins >= 0 && prm.o_ins + prm.e_ins < 8000 &&
+           prm.o_del >= 0 && prm.o_del + prm.e_del < 8000;
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_pk_kernel(
+    bwams_seqpair_t *__restrict__ pairs, const int32_t *__restrict__ list, const unsigned long long *n_list_p,
+    const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, int w0, SwParams prm, DevCounters *ctr, unsigned long long *head,
+    int cols) {
+    // 16 words of score rows, then [wave][task slot][H pairs | E pairs | selectors], cols / 2 words each.  Everything is carved out
+    // of the dynamic region: a static __shared__ array in front of it would shift its base off 16 bytes (16-byte DS accesses
+    // off their alignment are replayed at 64 cycles each)
+    extern __shared__ __align__(16) uint32_t pk_lds[];
+    constexpr int LPT = 4, TPW = 16;
+    const int lane = threadIdx.x & 63, g = lane & (LPT - 1), q = lane / LPT;
+    const int P = cols >> 1;
+    uint32_t *const t_hp = pk_lds + 16 + (size_t)(((threadIdx.x >> 6) * TPW + q) * 3) * P;
+    uint32_t *const t_ep = t_hp + P, *const t_sel = t_ep + P;
+    uint16_t *const t_hp16 = reinterpret_cast<uint16_t *>(t_hp), *const t_ep16 = reinterpret_cast<uint16_t *>(t_ep);
+    const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    // the score row of a target base as four 16-bit scores {A, C | G, T}; every score against N is -1 = the selector's 0xff bytes
+    uint2 *const pk_tab16 = reinterpret_cast<uint2 *>(pk_lds);
+    if (threadIdx.x < 5) {
+        const int t = threadIdx.x;
+        pk_tab16[t] = make_uint2((uint32_t)(uint16_t)(int16_t)prm.mat[t * 5 + 0] | ((uint32_t)(uint16_t)(int16_t)prm.mat[t * 5 + 1] << 16),
+                                 (uint32_t)(uint16_t)(int16_t)prm.mat[t * 5 + 2] | ((uint32_t)(uint16_t)(int16_t)prm.mat[t * 5 + 3] << 16));
+    }
+    __syncthreads();
+    const uint32_t ONE = 0x00010001u, TWO = 0x00020002u, C257 = 0x01010101u;
+    const uint32_t OEI = (uint32_t)oe_ins * 0x10001u, OED = (uint32_t)oe_del * 0x10001u, EDX = (uint32_t)e_del * 0x10001u;
+    const uint32_t E1X = (uint32_t)e_ins * 0x10001u, E2X = (uint32_t)(2 * e_ins) * 0x10001u;
+    const uint32_t NEGP = (uint32_t)(uint16_t)(int16_t)kPkNeg * 0x10001u;
+    const int64_t n_list = (int64_t)*n_list_p;
+    const unsigned long long kLeaders = 0x1111111111111111ull;    // lane 0 of every task slot
+    int64_t pid = 0, pid_end = 0;
+    bool exhausted = false;
+    bool alive = false;
+    int cur = 0, qlen = 0, tlen = 0, h0 = 0, w = 0, i = 0, beg = 0, end = 0;
+    int mx = 0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, tb_next = 4;
+    const uint8_t *tr = ref;
+    unsigned long long cells = 0;
+    // the row in progress (a row may take several iterations: one per window of 32 columns)
+    bool start_row = true, row = false;
+    int base = 0, h1 = 0, key = -1, hlast = -1, c_max = kPkNeg, c_h = 0;
+    uint32_t nzl = 0u, nzf = 0u;
+    uint2 tt = make_uint2(0u, 0u);
+
+    for (;;) {
+        const unsigned long long need_m = __ballot(!alive);
+        if (need_m) {
+            if (pid >= pid_end && !exhausted) {
+                pid = (int64_t)wave_ticket(head, (unsigned long long)kQuadChunk);
+                pid_end = pid + kQuadChunk < n_list ? pid + kQuadChunk : n_list;
+                if (pid >= n_list) { exhausted = true; pid_end = pid; }
+            }
+            const int avail = (int)(pid_end - pid);
+            const int nq = __popcll(need_m & kLeaders);
+            const int rank = __popcll(need_m & kLeaders & ((1ull << (q * LPT)) - 1ull));
+            if (!alive && rank < avail) {
+                cur = list[pid + rank];
+                const bwams_seqpair_t sp = pairs[cur];
+                qlen = sp.len2; tlen = sp.len1; h0 = sp.h0;
+                const uint8_t *tq = qer + sp.idq;
+                tr = ref + sp.idr;
+                start_row = true;
+                for (int p = g; p <= (qlen >> 1); p += LPT) {      // row -1 of the DP and the query, a pair of columns per lane and step
+                    uint32_t hh = 0, ss = 0;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int c = 2 * p + k;
+                        int h = 0;
+                        if (c <= qlen) { h = h0; if (c >= 1) { h = h0 - oe_ins - (c - 1) * e_ins; h = h > 0 ? h : 0; } }
+                        uint32_t qb = c < qlen ? (uint32_t)tq[c] : 4u;
+                        const uint32_t sel = qb < 4u ? (2u * qb) | ((2u * qb + 1u) << 8) : 0x0d0du;
+                        hh |= (uint32_t)h << (16 * k);
+                        ss |= sel << (16 * k);
+                    }
+                    t_hp[p] = hh; t_ep[p] = 0u; t_sel[p] = ss;
+                }
+                w = w0;
+                {
+                    int max_ins = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_ins) / e_ins + 1.);
+                    max_ins = max_ins > 1 ? max_ins : 1;
+                    w = w < max_ins ? w : max_ins;
+                    int max_del = (int)((double)(qlen * prm.max_sc + prm.end_bonus - o_del) / e_del + 1.);
+                    max_del = max_del > 1 ? max_del : 1;
+                    w = w < max_del ? w : max_del;
+                }
+                mx = h0; max_i = -1; max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+                beg = 0; end = qlen; i = 0;
+                alive = tlen > 0;
+                if (!alive && g == 0) {
+                    bwams_seqpair_t *o = &pairs[cur];
+                    o->score = mx; o->qle = 0; o->tle = 0; o->gtle = 0; o->gscore = -1; o->max_off = 0;
+                }
+                tb_next = alive ? (int)tr[0] : 4;
+            }
+            pid += nq < avail ? nq : avail;
+            if (exhausted && !wave_any(alive)) break;
+        }
+
+        // ---- one PASS (a window of 32 columns) of the current row of every live task.  The tasks of a wavefront do not wait for
+        // each other at the end of a row: a task whose row needs a second window takes it in the next iteration while the others
+        // are already on their next rows, so an iteration costs the same whether one task or all sixteen have a wide band.
+        if (alive && start_row) {                                     // row prologue
+            int tb = tb_next;
+            tb = tb > 4 ? 4 : tb;
+            if (i + 1 < tlen) tb_next = tr[i + 1];
+            tt = pk_tab16[tb];
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            h1 = 0;
+            if (beg == 0) {
+                h1 = h0 - (o_del + e_del * (i + 1));
+                h1 = h1 < 0 ? 0 : h1;
+            }
+            row = beg < end;
+            key = -1; hlast = -1; nzl = 0u; nzf = 0u;
+            c_max = kPkNeg; c_h = 0;
+            base = beg & ~7;
+            start_row = false;
+        }
+        {
+            const bool in = alive && row;
+            const int jb = base + g * 8;
+            const bool inr = in && jb < cols;
+            // the lane's live columns as a bit mask, then as four pair masks
+            int lo = beg - jb, hi = end - jb;
+            lo = lo < 0 ? 0 : (lo > 8 ? 8 : lo);
+            hi = hi < 0 ? 0 : (hi > 8 ? 8 : hi);
+            const uint32_t m8 = inr ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+            uint4 hp4 = make_uint4(0, 0, 0, 0), ep4 = hp4, sl4 = hp4;
+            if (m8) {
+                hp4 = *reinterpret_cast<const uint4 *>(t_hp + (jb >> 1));
+                ep4 = *reinterpret_cast<const uint4 *>(t_ep + (jb >> 1));
+                sl4 = *reinterpret_cast<const uint4 *>(t_sel + (jb >> 1));
+            }
+            const uint32_t hpv[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, epv[4] = {ep4.x, ep4.y, ep4.z, ep4.w}, slv[4] = {sl4.x, sl4.y, sl4.z, sl4.w};
+            uint32_t AM[4], M[4], E[4], PX[4], JE[4], JP[4];
+            JE[0] = (uint32_t)(jb * e_ins) * 0x10001u + ((uint32_t)e_ins << 16);
+            JP[0] = (uint32_t)jb * 0x10001u + 0x00020001u;            // (j + 1, j + 2)
+#pragma unroll
+            for (int c = 1; c < 4; ++c) { JE[c] = pk::add(JE[c - 1], E2X); JP[c] = pk::add(JP[c - 1], TWO); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * c, 1), bhi = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * c + 1, 1);
+                AM[c] = pk::bfi(0xffffu, blo, bhi);
+                const uint32_t H = hpv[c] & AM[c];
+                E[c] = epv[c] & AM[c];
+                const uint32_t S = __builtin_amdgcn_perm(tt.y, tt.x, slv[c]);
+                M[c] = pk::mul(pk::add(H, S), pk::minu(H, ONE));        // M = H ? H + S : 0
+                const uint32_t tj = pk::max0(pk::sub(M[c], OEI));
+                uint32_t x = pk::add(tj, JE[c]);
+                x = pk::max(x, x << 16);                                // the pair's inclusive prefix (x >= 0)
+                PX[c] = x;
+            }
+#pragma unroll
+            for (int c = 1; c < 4; ++c) PX[c] = pk::max(PX[c], pk::hi2(PX[c - 1]));
+            // over the four lanes of the task
+            int scan = (int)(PX[3] >> 16);
+            {
+                int t = pk::qdpp<0x90>(scan);                          // quad_perm [0,0,1,2]
+                scan = scan > t ? scan : t;
+                t = pk::qdpp<0x44>(scan);                              // quad_perm [0,1,0,1]
+                scan = scan > t ? scan : t;
+            }
+            int Lex = pk::qdpp<0x90>(scan);
+            Lex = g == 0 ? kPkNeg : Lex;
+            Lex = Lex > c_max ? Lex : c_max;
+            const uint32_t Lexp = pk::lo2((uint32_t)Lex);
+            uint32_t Hn[4], E2[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t pexcl = __builtin_amdgcn_alignbit(PX[c], c ? PX[c - 1] : NEGP, 16);   // {prefix up to column j - 1}
+                const uint32_t pex = pk::max(pexcl, Lexp);
+                const uint32_t F = pk::max0(pk::add(pk::sub(pex, JE[c]), E1X));                       // F = max(Pex - (j - 1) e_ins, 0)
+                Hn[c] = pk::max(pk::max(M[c], E[c]), F);
+                E2[c] = pk::max0(pk::max(pk::sub(M[c], OED), pk::sub(E[c], EDX)));
+            }
+            // what is stored: H(i, j - 1) beside E(i + 1, j); the column to the left of the lane's first comes from the lane before
+            const int h3 = (int)(Hn[3] >> 16);
+            int hin = pk::qdpp<0x90>(h3);
+            hin = g == 0 ? c_h : hin;
+            uint32_t HL[4];
+            HL[0] = __builtin_amdgcn_alignbit(Hn[0], (uint32_t)hin << 16, 16);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) HL[c] = __builtin_amdgcn_alignbit(Hn[c], Hn[c - 1], 16);
+            if (m8) {
+                uint4 o;
+                o.x = pk::bfi(AM[0], HL[0], hpv[0]); o.y = pk::bfi(AM[1], HL[1], hpv[1]); o.z = pk::bfi(AM[2], HL[2], hpv[2]); o.w = pk::bfi(AM[3], HL[3], hpv[3]);
+                *reinterpret_cast<uint4 *>(t_hp + (jb >> 1)) = o;
+                o.x = pk::bfi(AM[0], E2[0], epv[0]); o.y = pk::bfi(AM[1], E2[1], epv[1]); o.z = pk::bfi(AM[2], E2[2], epv[2]); o.w = pk::bfi(AM[3], E2[3], epv[3]);
+                *reinterpret_cast<uint4 *>(t_ep + (jb >> 1)) = o;
+            }
+            // row maximum with the last column attaining it; first / last column with a non-zero stored cell
+            int lkey = -1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t ha = Hn[c] & AM[c];
+                const int j = jb + 2 * c;
+                // a dead column contributes (0 << 8 | j) < 256: below every live key of a row whose maximum is positive, and the column
+                // of the maximum is not read when the maximum is 0
+                const int k0 = (int)(((ha & 0xffffu) << 8) | (uint32_t)j), k1 = (int)(((ha >> 16) << 8) | (uint32_t)(j + 1));
+                const int kk = k0 > k1 ? k0 : k1;
+                lkey = lkey > kk ? lkey : kk;
+                const uint32_t f = pk::minu((HL[c] | E2[c]) & AM[c], ONE);
+                nzl = pk::max(nzl, pk::mul(f, JP[c]));
+                nzf = pk::max(nzf, pk::mul(f, pk::sub(C257, JP[c])));
+            }
+            lkey = m8 ? lkey : -1;                                  // a lane without a live column contributes nothing
+            key = key > lkey ? key : lkey;
+            {                                                       // H of column end - 1, once per row
+                const int oe = hi - 1;
+                if (m8 && jb + hi == end) {
+                    uint32_t hv = Hn[0];
+                    hv = (oe >> 1) == 1 ? Hn[1] : hv;
+                    hv = (oe >> 1) == 2 ? Hn[2] : hv;
+                    hv = (oe >> 1) == 3 ? Hn[3] : hv;
+                    hlast = (int)((hv >> ((oe & 1) << 4)) & 0xffffu);
+                }
+            }
+            if (in && base == (beg & ~7) && h1 != 0 && g == 0) t_hp16[beg] = (uint16_t)h1;      // eh[beg].h = h1: H(i, beg - 1) of a row that starts at column 0
+            // a further window of this row: carry the prefix maximum and the last column's H into the next iteration
+            const int pm = pk::qdpp<0xFF>(scan);                       // quad_perm [3,3,3,3]: the task's inclusive total
+            const int ch = pk::qdpp<0xFF>(h3);
+            const bool more = in && base + LPT * 8 < end;
+            if (more) {
+                c_max = c_max > pm ? c_max : pm;
+                c_h = ch;
+                base += LPT * 8;
+            }
+            // ---- the end of a row
+            const int rkey = pk::quad_all_max(key), rhl = pk::quad_all_max(hlast);
+            const int a_ = (int)(nzl & 0xffffu), b_ = (int)(nzl >> 16), c_ = (int)(nzf & 0xffffu), d_ = (int)(nzf >> 16);
+            int last_nz = pk::quad_all_max(a_ > b_ ? a_ : b_) - 1;      // -1: none
+            int first_nz = 256 - pk::quad_all_max(c_ > d_ ? c_ : d_);   // 256: none (beyond every column)
+            if (alive && !more) {
+                if (row && h1 != 0) {                                    // column beg stores h1 (see above)
+                    first_nz = first_nz < beg ? first_nz : beg;
+                    last_nz = last_nz > beg ? last_nz : beg;
+                }
+                const int m = row ? rkey >> 8 : 0, mj = row ? rkey & 0xff : -1;
+                const int h1f = row ? rhl : h1;
+                if (g == 0) { t_hp16[end] = (uint16_t)h1f; t_ep16[end] = 0; }   // eh[end] = {h1f, 0}
+                if (row) cells += (unsigned long long)(g == 0 ? end - beg : 0);
+                const int j_exit = row ? end : beg;
+                if (j_exit == qlen) {
+                    max_ie = gscore > h1f ? max_ie : i;
+                    gscore = gscore > h1f ? gscore : h1f;
+                }
+                bool fin = m == 0;
+                if (!fin) {
+                    if (m > mx) {
+                        mx = m; max_i = i; max_j = mj;
+                        int d = mj - i;
+                        d = d < 0 ? -d : d;
+                        max_off = max_off > d ? max_off : d;
+                    } else if (prm.zdrop > 0) {
+                        if (i - max_i > mj - max_j) fin = mx - m - ((i - max_i) - (mj - max_j)) * e_del > prm.zdrop;
+                        else fin = mx - m - ((mj - max_j) - (i - max_i)) * e_ins > prm.zdrop;
+                    }
+                }
+                if (!fin) {
+                    const int nbeg = first_nz < end ? first_nz : end;
+                    int jj;
+                    if (h1f != 0) jj = end;
+                    else if (last_nz >= nbeg) jj = last_nz;
+                    else jj = nbeg - 1;
+                    beg = nbeg;
+                    end = jj + 2 < qlen ? jj + 2 : qlen;
+                    ++i;
+                    fin = i >= tlen;
+                }
+                if (fin) {
+                    if (g == 0) {
+                        bwams_seqpair_t *o = &pairs[cur];
+                        o->score = mx; o->qle = max_j + 1; o->tle = max_i + 1; o->gtle = max_ie + 1; o->gscore = gscore; o->max_off = max_off;
+                    }
+                    alive = false;
+                }
+                start_row = true;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cells += ((unsigned long long)__shfl_down((unsigned)(cells >> 32), o) << 32) | (unsigned)__shfl_down((unsigned)cells, o);
+    if (lane == 0 && cells) atomicAdd(&ctr->bsw_cells, cells);
+}
+
 __global__ void bsw_reset_kernel(DevCounters *ctr) {
     for (int i = 0; i < 4; ++i) ctr->bsw_head[i] = 0;      // bsw_cells accumulates until the caller clears it
     for (int i = 0; i < kNumBswClass; ++i) ctr->bsw_cls_cnt[i] = ctr->bsw_cls_head[i] = 0;
@@ -606,11 +936,20 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
     // every class on a stream of its own, the classes of the longest queries first.  (With two classes per stream and the
     // one-task-per-wave kernel — usually without a single task, but 2048 blocks that wait for a free CU slot — in front of one
     // of them, the kernel trace showed two class launches starting 14 ms late.)
+    static const bool pk_env = !(getenv("BWAMS_BSW_PK") && atoi(getenv("BWAMS_BSW_PK")) == 0);       // A-B knob: the 32-bit eight-task kernel
+    if (pk_env && bsw_pk_eligible(prm)) {
+        auto pk_lds = [](int cols) { return (size_t)64 + (size_t)kWavesPerBlock * 16 * (size_t)(cols / 2) * 12; };
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_pk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds(192)) != hipSuccess) return -1;
+        static const int kCols[5] = {32, 64, 96, 144, 192};
+        for (int c = 4; c >= 0; --c)
+            bsw_pk_kernel<<<B, T, pk_lds(kCols[c]), q[c]>>>(pairs, list + (int64_t)c * n, cnt + c, ref, qer, w, prm, ctr, hd + c, kCols[c]);
+    } else {
     bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4, q[4]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
     bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 4, q[3]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
     bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 96 * 4, q[2]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
     bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 64 * 4, q[1]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
     bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 32 * 4, q[0]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
+    }
     {
         // what neither packed form can take: (h, e) row + query of one task per wave in LDS, fewer waves per block for very long queries.
         // Last on the main stream, persistent waves on a small grid: the class is usually empty.

@@ -608,6 +608,10 @@ __device__ __forceinline__ int quad_all_max(int v) {
 }  // namespace pk
 
 constexpr int kPkNeg = -16384;
+#ifndef BWAMS_PK_WAVES
+#define BWAMS_PK_WAVES 2
+#endif
+constexpr int kPkWaves = BWAMS_PK_WAVES;      // wavefronts per workgroup: LDS is handed out per workgroup, small ones pack a CU better
 
 __host__ __device__ __forceinline__ bool bsw_pk_eligible(const SwParams &prm) {
     for (int i = 0; i < 5; ++i)
@@ -616,19 +620,23 @@ __host__ __device__ __forceinline__ bool bsw_pk_eligible(const SwParams &prm) {
            prm.o_del >= 0 && prm.o_del + prm.e_del < 8000;
 }
 
-__global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_pk_kernel(
+__global__ __launch_bounds__(kPkWaves * 64) void bsw_pk_kernel(
     bwams_seqpair_t *__restrict__ pairs, const int32_t *__restrict__ list, const unsigned long long *n_list_p,
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, int w0, SwParams prm, DevCounters *ctr, unsigned long long *head,
     int cols) {
-    // 16 words of score rows, then [wave][task slot][H pairs | E pairs | selectors], cols / 2 words each.  Everything is carved out
+    // 16 words of score rows, then [wave][task slot][H pairs | E pairs | selector bytes]: 4 + 4 + 2 bytes per pair.  Everything is carved out
     // of the dynamic region: a static __shared__ array in front of it would shift its base off 16 bytes (16-byte DS accesses
     // off their alignment are replayed at 64 cycles each)
     extern __shared__ __align__(16) uint32_t pk_lds[];
     constexpr int LPT = 4, TPW = 16;
     const int lane = threadIdx.x & 63, g = lane & (LPT - 1), q = lane / LPT;
     const int P = cols >> 1;
-    uint32_t *const t_hp = pk_lds + 16 + (size_t)(((threadIdx.x >> 6) * TPW + q) * 3) * P;
-    uint32_t *const t_ep = t_hp + P, *const t_sel = t_ep + P;
+    // per task 10 P + 24 bytes (P = cols / 2 pairs, a multiple of 4): H and E each P + 2 words, the selector bytes P / 2 + 1 words, and one
+    // word to keep the next task 8-byte aligned.  The two spare words let a lane whose eight columns begin at cols - 4 read and write
+    // back (masked) past the last pair without touching a neighbour
+    uint32_t *const t_hp = pk_lds + 16 + (size_t)((threadIdx.x >> 6) * TPW + q) * (size_t)((5 * P) / 2 + 6);
+    uint32_t *const t_ep = t_hp + P + 2;
+    uint16_t *const t_sel = reinterpret_cast<uint16_t *>(t_ep + P + 2);   // per pair the selectors' low bytes {2 qb0, 2 qb1} (0x0d for N)
     uint16_t *const t_hp16 = reinterpret_cast<uint16_t *>(t_hp), *const t_ep16 = reinterpret_cast<uint16_t *>(t_ep);
     const int o_del = prm.o_del, e_del = prm.e_del, o_ins = prm.o_ins, e_ins = prm.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -685,11 +693,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_pk_kernel(
                         int h = 0;
                         if (c <= qlen) { h = h0; if (c >= 1) { h = h0 - oe_ins - (c - 1) * e_ins; h = h > 0 ? h : 0; } }
                         uint32_t qb = c < qlen ? (uint32_t)tq[c] : 4u;
-                        const uint32_t sel = qb < 4u ? (2u * qb) | ((2u * qb + 1u) << 8) : 0x0d0du;
+                        const uint32_t sel = qb < 4u ? 2u * qb : 0x0du;
                         hh |= (uint32_t)h << (16 * k);
-                        ss |= sel << (16 * k);
+                        ss |= sel << (8 * k);
                     }
-                    t_hp[p] = hh; t_ep[p] = 0u; t_sel[p] = ss;
+                    t_hp[p] = hh; t_ep[p] = 0u; t_sel[p] = (uint16_t)ss;
                 }
                 w = w0;
                 {
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_pk_kernel(
             row = beg < end;
             key = -1; hlast = -1; nzl = 0u; nzf = 0u;
             c_max = kPkNeg; c_h = 0;
-            base = beg & ~7;
+            base = beg & ~3;
             start_row = false;
         }
         {
@@ -744,13 +752,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_pk_kernel(
             lo = lo < 0 ? 0 : (lo > 8 ? 8 : lo);
             hi = hi < 0 ? 0 : (hi > 8 ? 8 : hi);
             const uint32_t m8 = inr ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-            uint4 hp4 = make_uint4(0, 0, 0, 0), ep4 = hp4, sl4 = hp4;
-            if (m8) {
-                hp4 = *reinterpret_cast<const uint4 *>(t_hp + (jb >> 1));
-                ep4 = *reinterpret_cast<const uint4 *>(t_ep + (jb >> 1));
-                sl4 = *reinterpret_cast<const uint4 *>(t_sel + (jb >> 1));
-            }
-            const uint32_t hpv[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, epv[4] = {ep4.x, ep4.y, ep4.z, ep4.w}, slv[4] = {sl4.x, sl4.y, sl4.z, sl4.w};
+            // the window starts at a multiple of FOUR columns (a band of the typical 23 columns then fits one window almost always;
+            // at a multiple of eight a fifth of the rows needed a second one): the lane's eight columns are 8-byte aligned in the H and E
+            // arrays, 4-byte aligned in the selector bytes.  Lanes without a live column read too (whatever lies there: it is masked)
+            const int pj = inr ? (jb >> 1) : 0;
+            const uint2 hpa = *reinterpret_cast<const uint2 *>(t_hp + pj), hpb = *reinterpret_cast<const uint2 *>(t_hp + pj + 2);
+            const uint2 epa = *reinterpret_cast<const uint2 *>(t_ep + pj), epb = *reinterpret_cast<const uint2 *>(t_ep + pj + 2);
+            uint2 sl2;
+            sl2.x = *reinterpret_cast<const uint32_t *>(t_sel + pj);
+            sl2.y = *reinterpret_cast<const uint32_t *>(t_sel + pj + 2);
+            const uint32_t hpv[4] = {hpa.x, hpa.y, hpb.x, hpb.y}, epv[4] = {epa.x, epa.y, epb.x, epb.y};
+            // a pair's selector {2 qb0, 2 qb0 + 1, 2 qb1, 2 qb1 + 1} from its two stored bytes (N: 0x0d, 0x0e: both give 0xff)
+            const uint32_t slv[4] = {__builtin_amdgcn_perm(sl2.x, sl2.x, 0x01010000u) + 0x01000100u, __builtin_amdgcn_perm(sl2.x, sl2.x, 0x03030202u) + 0x01000100u,
+                                     __builtin_amdgcn_perm(sl2.y, sl2.y, 0x01010000u) + 0x01000100u, __builtin_amdgcn_perm(sl2.y, sl2.y, 0x03030202u) + 0x01000100u};
             uint32_t AM[4], M[4], E[4], PX[4], JE[4], JP[4];
             JE[0] = (uint32_t)(jb * e_ins) * 0x10001u + ((uint32_t)e_ins << 16);
             JP[0] = (uint32_t)jb * 0x10001u + 0x00020001u;            // (j + 1, j + 2)
@@ -801,21 +815,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_pk_kernel(
 #pragma unroll
             for (int c = 1; c < 4; ++c) HL[c] = __builtin_amdgcn_alignbit(Hn[c], Hn[c - 1], 16);
             if (m8) {
-                uint4 o;
-                o.x = pk::bfi(AM[0], HL[0], hpv[0]); o.y = pk::bfi(AM[1], HL[1], hpv[1]); o.z = pk::bfi(AM[2], HL[2], hpv[2]); o.w = pk::bfi(AM[3], HL[3], hpv[3]);
-                *reinterpret_cast<uint4 *>(t_hp + (jb >> 1)) = o;
-                o.x = pk::bfi(AM[0], E2[0], epv[0]); o.y = pk::bfi(AM[1], E2[1], epv[1]); o.z = pk::bfi(AM[2], E2[2], epv[2]); o.w = pk::bfi(AM[3], E2[3], epv[3]);
-                *reinterpret_cast<uint4 *>(t_ep + (jb >> 1)) = o;
+                *reinterpret_cast<uint2 *>(t_hp + pj) = make_uint2(pk::bfi(AM[0], HL[0], hpv[0]), pk::bfi(AM[1], HL[1], hpv[1]));
+                *reinterpret_cast<uint2 *>(t_hp + pj + 2) = make_uint2(pk::bfi(AM[2], HL[2], hpv[2]), pk::bfi(AM[3], HL[3], hpv[3]));
+                *reinterpret_cast<uint2 *>(t_ep + pj) = make_uint2(pk::bfi(AM[0], E2[0], epv[0]), pk::bfi(AM[1], E2[1], epv[1]));
+                *reinterpret_cast<uint2 *>(t_ep + pj + 2) = make_uint2(pk::bfi(AM[2], E2[2], epv[2]), pk::bfi(AM[3], E2[3], epv[3]));
             }
             // row maximum with the last column attaining it; first / last column with a non-zero stored cell
             int lkey = -1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t ha = Hn[c] & AM[c];
-                const int j = jb + 2 * c;
-                // a dead column contributes (0 << 8 | j) < 256: below every live key of a row whose maximum is positive, and the column
-                // of the maximum is not read when the maximum is 0
-                const int k0 = (int)(((ha & 0xffffu) << 8) | (uint32_t)j), k1 = (int)(((ha >> 16) << 8) | (uint32_t)(j + 1));
+                // key = H << 8 | (j + 1), one v_perm per column: the bytes {index, H low, H high, 0}.  A dead column contributes
+                // (0 << 8 | j + 1) < 256: below every live key of a row whose maximum is positive, and the column of the maximum is
+                // not read when the maximum is 0
+                const int k0 = (int)__builtin_amdgcn_perm(ha, JP[c], 0x0c050400u), k1 = (int)__builtin_amdgcn_perm(ha, JP[c], 0x0c070602u);
                 const int kk = k0 > k1 ? k0 : k1;
                 lkey = lkey > kk ? lkey : kk;
                 const uint32_t f = pk::minu((HL[c] | E2[c]) & AM[c], ONE);
@@ -834,7 +847,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_pk_kernel(
                     hlast = (int)((hv >> ((oe & 1) << 4)) & 0xffffu);
                 }
             }
-            if (in && base == (beg & ~7) && h1 != 0 && g == 0) t_hp16[beg] = (uint16_t)h1;      // eh[beg].h = h1: H(i, beg - 1) of a row that starts at column 0
+            if (in && base == (beg & ~3) && h1 != 0 && g == 0) t_hp16[beg] = (uint16_t)h1;      // eh[beg].h = h1: H(i, beg - 1) of a row that starts at column 0
             // a further window of this row: carry the prefix maximum and the last column's H into the next iteration
             const int pm = pk::qdpp<0xFF>(scan);                       // quad_perm [3,3,3,3]: the task's inclusive total
             const int ch = pk::qdpp<0xFF>(h3);
@@ -854,7 +867,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_pk_kernel(
                     first_nz = first_nz < beg ? first_nz : beg;
                     last_nz = last_nz > beg ? last_nz : beg;
                 }
-                const int m = row ? rkey >> 8 : 0, mj = row ? rkey & 0xff : -1;
+                const int m = row ? rkey >> 8 : 0, mj = row ? (rkey & 0xff) - 1 : -1;
                 const int h1f = row ? rhl : h1;
                 if (g == 0) { t_hp16[end] = (uint16_t)h1f; t_ep16[end] = 0; }   // eh[end] = {h1f, 0}
                 if (row) cells += (unsigned long long)(g == 0 ? end - beg : 0);
@@ -938,11 +951,12 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
     // of them, the kernel trace showed two class launches starting 14 ms late.)
     static const bool pk_env = !(getenv("BWAMS_BSW_PK") && atoi(getenv("BWAMS_BSW_PK")) == 0);       // A-B knob: the 32-bit eight-task kernel
     if (pk_env && bsw_pk_eligible(prm)) {
-        auto pk_lds = [](int cols) { return (size_t)64 + (size_t)kWavesPerBlock * 16 * (size_t)(cols / 2) * 12; };
+        auto pk_lds = [](int cols) { return (size_t)64 + (size_t)kPkWaves * 16 * ((size_t)(cols / 2) * 10 + 24); };
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_pk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds(192)) != hipSuccess) return -1;
         static const int kCols[5] = {32, 64, 96, 144, 192};
+        const unsigned Bp = (unsigned)((int64_t)B * kWavesPerBlock / kPkWaves);
         for (int c = 4; c >= 0; --c)
-            bsw_pk_kernel<<<B, T, pk_lds(kCols[c]), q[c]>>>(pairs, list + (int64_t)c * n, cnt + c, ref, qer, w, prm, ctr, hd + c, kCols[c]);
+            bsw_pk_kernel<<<Bp, kPkWaves * 64, pk_lds(kCols[c]), q[c]>>>(pairs, list + (int64_t)c * n, cnt + c, ref, qer, w, prm, ctr, hd + c, kCols[c]);
     } else {
     bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4, q[4]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
     bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 4, q[3]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);

@@ -18,14 +18,22 @@ _ERR_PROFILE = np.array([0.0, 0.0, 0.005, 0.02, 0.05])
 
 def make_genome(n_bases: int, seed: int = 2024, repeat_frac: float = 0.10,
                 repeat_len: int = 300, n_families: int = 8,
-                repeat_div: float = 0.08) -> np.ndarray:
+                repeat_div: float = 0.08, profile: str | None = None, return_holes: bool = False):
     """Random genome (codes 0..3) with interspersed repeat families.
 
     A fraction ``repeat_frac`` of the genome is overwritten with diverged copies
     (substitution rate ``repeat_div``) of ``n_families`` consensus elements, so
     SMEM intervals with s > 1 and multi-seed chains occur as they do on a real
     genome (a uniformly random genome has essentially none).
+
+    ``profile="grch38_like"`` adds what makes the human reference hard for a seed-and-extend aligner (see
+    _grch38_like); ``return_holes`` then also returns the N holes as (offset, len) records.
     """
+    if profile is not None:
+        if profile != "grch38_like":
+            raise ValueError(f"unknown genome profile {profile!r}")
+        g, holes = _grch38_like(n_bases, seed)
+        return (g, holes) if return_holes else g
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, size=n_bases, dtype=np.uint8)
     if repeat_frac > 0 and n_bases >= 4 * repeat_len:
@@ -43,6 +51,122 @@ def make_genome(n_bases: int, seed: int = 2024, repeat_frac: float = 0.10,
             idx = st[:, None] + np.arange(repeat_len)[None, :]
             g[idx.ravel()] = cp.ravel()
     return g
+
+
+_MICROSAT = ("A", "CA", "GA", "TA", "AAT", "CAG", "GATA", "GGAA", "TTAGGG", "AAAG")
+HOLE_DTYPE = np.dtype([("offset", "<i8"), ("len", "<i8")])
+
+
+def _interspersed(g, rng, frac, unit_len, n_families, div, truncate=False):
+    """overwrite a fraction of g with diverged copies of consensus elements (truncate: keep a random-length 3' part, as L1 copies do)"""
+    n_bases = len(g)
+    if n_bases < 4 * unit_len:
+        return
+    fams = rng.integers(0, 4, size=(n_families, unit_len), dtype=np.uint8)
+    mean_len = unit_len * (0.55 if truncate else 1.0)
+    n_copies = int(n_bases * frac / mean_len)
+    slab = max(1, (1 << 24) // unit_len)
+    for a in range(0, n_copies, slab):
+        k = min(slab, n_copies - a)
+        st = rng.integers(0, n_bases - unit_len, size=k)
+        cp = fams[rng.integers(0, n_families, size=k)].copy()
+        mut = rng.random(cp.shape) < div
+        cp[mut] = (cp[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        idx = st[:, None] + np.arange(unit_len)[None, :]
+        if truncate:
+            keep = np.arange(unit_len)[None, :] >= rng.integers(0, unit_len - unit_len // 10, size=k)[:, None]
+            g[idx[keep]] = cp[keep]
+        else:
+            g[idx.ravel()] = cp.ravel()
+
+
+def _grch38_like(n_bases: int, seed: int):
+    """A synthetic genome with the structures of GRCh38 that stress seeding, chaining and index construction:
+
+      * interspersed repeats: an Alu-like family set (300 bp, ~10 % of the bases, 12 % diverged) and an L1-like one (6 kb
+        consensus, 5'-truncated copies, ~15 %, 5 % diverged);
+      * satellite arrays: tandem arrays of 171-bp monomers organised as 12-monomer higher-order repeats (monomers of one
+        HOR 20 % apart, HOR copies 0.5 % apart, the first 20 HOR copies of an array exact), 10^4 monomers per array at
+        GRCh38 size (fewer on small genomes), about one array per 130 Mbp: seeds with 10^3..10^4 hits;
+      * microsatellites (exact (A)n, (CA)n, (GATA)n, (TTAGGG)n ... runs of 20-400 bp, mean 50, one per 20 kb) and poly-A /
+        poly-T runs of 15-45 bp (one per 30 kb): suffixes that agree for hundreds of bases, k-mers with 10^6 hits.  Their
+        number and length stay within what the ERT format can hold, as GRCh38 does: a leaf's hits are counted in 16 bits
+        (src/ertindex.cpp:336-352: no 151-base string 65536 times) and a k-mer's tree is below 64 MiB (:452, :607: A^15 with
+        more than some 10^7 hits has no tree) — beyond either the reference's writer does not finish and bwams_ert_build
+        refuses the text;
+      * segmental duplications: four exact copies of >= 100 kb (on genomes of 4 Mbp and more), one of them inverted: the
+        longest common prefixes a suffix sort meets, and reads with two perfect placements;
+      * N holes: short ones (1-50 bases) and one centromere-sized one beside every satellite array, filled with random
+        bases the way bns_fasta2bntseq does (src/bntseq.cpp:275-279: `c = lrand48() & 3` for a base code >= 4; the holes
+        go to the .amb records, which the MEM path does not read).
+
+    Returns (codes 0..3, holes as HOLE_DTYPE records sorted by offset)."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=n_bases, dtype=np.uint8)
+    _interspersed(g, rng, 0.10, 300, 8, 0.12)
+    _interspersed(g, rng, 0.15, 6000, 3, 0.05, truncate=True)
+    holes = []
+    # satellite arrays, each with a large hole beside it
+    n_arr = max(1, n_bases // 130_000_000)
+    n_mono = int(min(10_000, max(48, n_bases // (171 * 60))))
+    n_hor = n_mono // 12
+    arr_len = n_hor * 12 * 171
+    big_hole = int(min(3_000_000, n_bases // 200))
+    cons = rng.integers(0, 4, size=171, dtype=np.uint8)
+    if arr_len + big_hole < n_bases // (2 * n_arr):
+        slot = n_bases // n_arr
+        for a in range(n_arr):
+            hor = np.tile(cons, 12)
+            mut = rng.random(hor.shape) < 0.20
+            hor[mut] = (hor[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+            arr = np.tile(hor, n_hor)
+            mut = rng.random(arr.shape) < 0.005
+            mut[:min(20, n_hor) * len(hor)] = False
+            arr[mut] = (arr[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+            p = a * slot + int(rng.integers(slot // 8, slot - arr_len - big_hole - slot // 8))
+            g[p:p + arr_len] = arr
+            holes.append((p + arr_len, big_hole))
+    # microsatellites and poly-A / poly-T runs
+    n_ms = n_bases // 20_000
+    ms_pos = rng.integers(0, max(1, n_bases - 400), size=n_ms)
+    ms_len = np.minimum(400, 20 + rng.geometric(1.0 / 30.0, size=n_ms))      # one in eighty reaches a read length
+    ms_unit = rng.integers(0, len(_MICROSAT), size=n_ms)
+    units = [np.array(["ACGT".index(ch) for ch in u], dtype=np.uint8) for u in _MICROSAT]
+    tiles = [np.tile(u, 400 // len(u) + 1) for u in units]
+    for p, ln, u in zip(ms_pos.tolist(), ms_len.tolist(), ms_unit.tolist()):
+        if p + ln <= n_bases:
+            g[p:p + ln] = tiles[u][:ln]
+    n_pa = n_bases // 30_000
+    pa_pos = rng.integers(0, max(1, n_bases - 60), size=n_pa)
+    pa_len = rng.integers(15, 46, size=n_pa)
+    pa_base = rng.integers(0, 2, size=n_pa) * 3                    # A or T
+    if n_pa:
+        # vectorised: a run is a slice of ones in a difference array
+        for ln in range(15, 46):
+            sel = pa_len == ln
+            if sel.any():
+                idx = pa_pos[sel][:, None] + np.arange(ln)[None, :]
+                ok = idx < n_bases
+                g[idx[ok]] = np.broadcast_to(pa_base[sel][:, None], idx.shape)[ok].astype(np.uint8)
+    # exact segmental duplications, the last one inverted
+    seg = int(min(150_000, n_bases // 40))
+    if seg >= 1000:
+        for k in range(4):
+            src = int(rng.integers(0, n_bases - seg))
+            dst = int(rng.integers(0, n_bases - seg))
+            if abs(src - dst) < seg:
+                dst = (src + n_bases // 2) % (n_bases - seg)
+            piece = g[src:src + seg].copy()
+            g[dst:dst + seg] = piece if k < 3 else (3 - piece[::-1])
+    # short holes
+    n_sh = max(2, n_bases // 10_000_000)
+    sh_pos = rng.integers(0, max(1, n_bases - 50), size=n_sh)
+    sh_len = rng.integers(1, 51, size=n_sh)
+    holes += [(int(p), int(l)) for p, l in zip(sh_pos, sh_len) if p + l <= n_bases]
+    holes.sort()
+    for p, l in holes:                                              # bns_fasta2bntseq: a random base for every N
+        g[p:p + l] = rng.integers(0, 4, size=l, dtype=np.uint8)
+    return g, np.array(holes, dtype=HOLE_DTYPE)
 
 
 def chromosomes(n_bases: int, n_seq: int = 24) -> np.ndarray:

@@ -17,7 +17,10 @@
 //   4. the free slots (buckets without a run), listed by a stream compaction.
 //   5. emf_bucket_kernel<2>: per run: distinct L-mers (verified base by base: hash words can collide), ascending order,
 //      root into the bucket's slot, the others into free slots, multi-location lists into loc_table.
+#include <algorithm>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -124,8 +127,11 @@ struct BucketArgs {
     uint4 *seeds;              // pass 2
     uint32_t *loc;             // pass 2
     unsigned long long *ctr;   // [0] nodes outside their bucket, [1] loc_table words (starts at 1), [2] distinct L-mers,
-                               // [3] buckets used, [4] buckets with more than kMaxU L-mers (error), [5] free-slot cursor
+                               // [3] buckets used, [4] errors (a list or table region too small), [5] free-slot cursor,
+                               // [6] runs handed to the big-bucket kernels
     unsigned long long free_cap, loc_cap;
+    ulonglong2 *big;           // pass 1: runs with more than kMaxU distinct L-mers {first sorted window, windows}, ctr[6] of them
+    unsigned long long big_cap;
 };
 
 // lane = one sorted window; the lane at the head of a bucket's run does the bucket.  Counters and free-slot ranges are
@@ -178,7 +184,13 @@ __global__ __launch_bounds__(256) void emf_bucket_kernel(BucketArgs A) {
                 } else too_many = true;
             }
         }
-        if (too_many) { atomicAdd(&A.ctr[4], 1ull); head = false; c = 0; }
+        if (too_many) {                                    // emf_big_sort_kernel / emf_big_emit_kernel take this run
+            if (PASS == 1) {
+                const unsigned long long t = atomicAdd(&A.ctr[6], 1ull);
+                if (t < A.big_cap) A.big[t] = make_ulonglong2((unsigned long long)i, (unsigned long long)(j - i));
+            }
+            head = false; c = 0;
+        }
         if (PASS == 1) {
             unsigned long long words = 0;
             if (head) {
@@ -256,6 +268,127 @@ __global__ __launch_bounds__(256) void emf_bucket_kernel(BucketArgs A) {
     }
 }
 
+// ---- buckets with more than kMaxU distinct L-mers.  The hash is an XOR of the window's 32-base words (the reference's, perfect.h:541-707,
+// and part of the table format), so it is blind to WHERE in a periodic stretch something sits: slide a window along (GA)n with a poly-T run
+// inside it and every position of the run gives another L-mer with the same XOR — dozens of distinct L-mers in one bucket on a genome with
+// microsatellites, where the Poisson mean is 0.9.  The reference's builder just grows that bucket's tree; here such a run (they are few) is
+// sorted by (canonical L-mer, position) with a bitonic network in HBM by one workgroup, and a wavefront then walks the sorted run: an L-mer is
+// a group of neighbours, its first member the smallest position.
+struct BigRun { unsigned long long start; unsigned int len, padded; unsigned long long off; };
+struct BigArgs {
+    BucketArgs A;
+    const BigRun *runs;
+    uint32_t *ord;             // per run `padded` words: indices into the run, sorted; bit 31 = first member of its L-mer
+};
+constexpr uint32_t kBigPad = 0x7fffffffu;
+constexpr unsigned long long kBigCap = 1ull << 16;       // runs the big-bucket path lists
+
+__device__ __forceinline__ bool big_less(const BucketArgs &A, unsigned long long start, uint32_t a, uint32_t b) {
+    if (a == kBigPad || b == kBigPad) return a != kBigPad;                 // padding sorts last
+    const int64_t pa = A.pos[start + a], pb = A.pos[start + b];
+    const int c = canon_cmp(A.B, pa, A.keys[start + a] & 1ull, pb, A.keys[start + b] & 1ull);
+    return c ? c < 0 : pa < pb;
+}
+
+__global__ __launch_bounds__(256) void emf_big_sort_kernel(BigArgs G) {
+    const BigRun r = G.runs[blockIdx.x];
+    uint32_t *ord = G.ord + r.off;
+    for (uint32_t e = threadIdx.x; e < r.padded; e += 256) ord[e] = e < r.len ? e : kBigPad;
+    __threadfence(); __syncthreads();
+    for (uint32_t k = 2; k <= r.padded; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t e = threadIdx.x; e < r.padded; e += 256) {
+                const uint32_t x = e ^ j;
+                if (x > e) {
+                    const uint32_t a = ord[e], b = ord[x];
+                    const bool up = (e & k) == 0;
+                    if (big_less(G.A, r.start, b, a) == up) { ord[e] = b; ord[x] = a; }
+                }
+            }
+            __threadfence(); __syncthreads();
+        }
+    // group heads: a window whose canonical L-mer differs from its predecessor's (bit 31 of its own word; neighbours mask it)
+    for (uint32_t e = threadIdx.x; e < r.len; e += 256) {
+        bool h = e == 0;
+        if (!h) {
+            const uint32_t a = ord[e - 1] & kBigPad, b = ord[e] & kBigPad;
+            h = canon_cmp(G.A.B, G.A.pos[r.start + a], G.A.keys[r.start + a] & 1ull, G.A.pos[r.start + b], G.A.keys[r.start + b] & 1ull) != 0;
+        }
+        if (h) atomicOr(&ord[e], 0x80000000u);
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(64) void emf_big_emit_kernel(BigArgs G) {
+    const BucketArgs &A = G.A;
+    const BigRun r = G.runs[blockIdx.x];
+    const uint32_t *ord = G.ord + r.off;
+    const int lane = threadIdx.x;
+    const uint32_t key = (uint32_t)(A.keys[r.start] >> 32);
+    // distinct L-mers of the run
+    unsigned int c = 0;
+    for (uint32_t e0 = 0; e0 < r.len; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        c += (unsigned int)__popcll(__ballot(e < r.len && (ord[e] >> 31)));
+    }
+    unsigned long long fbase = 0;
+    if (PASS == 2) {
+        if (lane == 0) fbase = atomicAdd(&A.ctr[5], (unsigned long long)(c - 1));
+        fbase = ((unsigned long long)(uint32_t)__shfl((int)(fbase >> 32), 0) << 32) | (uint32_t)__shfl((int)fbase, 0);
+        if (fbase + (c - 1) > A.free_cap) { if (lane == 0) atomicAdd(&A.ctr[4], 1ull); return; }
+    }
+    unsigned long long words = 0;
+    unsigned int gbase = 0;                                 // groups before this chunk
+    for (uint32_t e0 = 0; e0 < r.len; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool head = e < r.len && (ord[e] >> 31);
+        const unsigned long long hm = __ballot(head);
+        const unsigned int g = gbase + (unsigned int)__popcll(hm & ((1ull << lane) - 1ull));      // this group's rank: ascending L-mers
+        gbase += (unsigned int)__popcll(hm);
+        if (!head) continue;
+        // the group: members e .. e1 - 1, positions ascending; the first is the entry's location
+        const uint32_t m0 = ord[e] & kBigPad;
+        const uint32_t rep = A.pos[r.start + m0];
+        const uint32_t f0 = (uint32_t)(A.keys[r.start + m0] & 1ull);
+        uint32_t same = 0, other = 0, e1 = e + 1;
+        for (; e1 < r.len && !(ord[e1] >> 31); ++e1) {
+            if ((uint32_t)(A.keys[r.start + ord[e1]] & 1ull) == f0) ++same; else ++other;
+        }
+        const uint32_t m = same + other;
+        const bool shortf = same < 256 && other < 256;
+        if (PASS == 1) { if (m) words += (shortf ? 1 : 3) + m; continue; }
+        const uint32_t slot = g == 0 ? key : A.free_list[fbase + (g - 1)];
+        const uint32_t next = g + 1 < c ? A.free_list[fbase + g] : kNoEntry;
+        uint32_t flags = (f0 ? 1u : 0u) | (g == 0 ? 0u : 2u);
+        if (m) {
+            const unsigned long long at = atomicAdd(&A.ctr[1], (unsigned long long)((shortf ? 1 : 3) + m));
+            if (at + (shortf ? 1 : 3) + m <= A.loc_cap) {
+                unsigned long long wpos;
+                if (shortf) { A.loc[at] = (same << 16) | other; wpos = at + 1; }
+                else { A.loc[at] = 0x80000000u | (uint32_t)(at + 1); A.loc[at + 1] = same; A.loc[at + 2] = other; wpos = at + 3; }
+                unsigned long long ws = wpos, wo = wpos + same;
+                for (uint32_t x = e + 1; x < e1; ++x) {
+                    const uint32_t mm = ord[x];
+                    const uint32_t p = A.pos[r.start + mm];
+                    if ((uint32_t)(A.keys[r.start + mm] & 1ull) == f0) A.loc[ws++] = p; else A.loc[wo++] = p;
+                }
+                flags |= (uint32_t)at << 2;
+            } else atomicAdd(&A.ctr[4], 1ull);
+        }
+        A.seeds[slot] = make_uint4(flags, rep, kNoEntry, next);
+    }
+    if (PASS == 1) {
+        words = wave_sum(words);
+        if (lane == 0) {
+            atomicOr(&A.used[key >> 5], 1u << (key & 31));
+            atomicAdd(&A.ctr[0], (unsigned long long)(c - 1));
+            if (words) atomicAdd(&A.ctr[1], words);
+            atomicAdd(&A.ctr[2], (unsigned long long)c);
+            atomicAdd(&A.ctr[3], 1ull);
+        }
+    }
+}
+
 __global__ void emf_fill_kernel(uint4 *seeds, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         seeds[i] = make_uint4(0u, kNoEntry, kNoEntry, kNoEntry);
@@ -281,9 +414,9 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
         return BWAMS_ERR_UNSUPPORTED;
     }
     void *d_k = nullptr, *d_k2 = nullptr, *d_v = nullptr, *d_v2 = nullptr, *d_tmp = nullptr, *d_used = nullptr, *d_free = nullptr, *d_ctr = nullptr,
-         *d_nsel = nullptr;
+         *d_nsel = nullptr, *d_big = nullptr, *d_runs = nullptr, *d_ord = nullptr;
     auto cleanup = [&]() {
-        for (void *p : {d_k, d_k2, d_v, d_v2, d_tmp, d_used, d_free, d_ctr, d_nsel})
+        for (void *p : {d_k, d_k2, d_v, d_v2, d_tmp, d_used, d_free, d_ctr, d_nsel, d_big, d_runs, d_ord})
             if (p) (void)hipFree(p);
     };
 #define EMF_HIP(call)                                                       \
@@ -328,15 +461,51 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
     memset(&A, 0, sizeof A);
     A.B = B; A.keys = (const uint64_t *)d_k; A.pos = (const uint32_t *)d_v; A.used = (uint32_t *)d_used;
     A.ctr = (unsigned long long *)d_ctr;
+    EMF_HIP(hipMalloc(&d_big, kBigCap * sizeof(ulonglong2)));
+    A.big = (ulonglong2 *)d_big; A.big_cap = kBigCap;
     hipLaunchKernelGGL(emf_bucket_kernel<1>, dim3(grid), dim3(256), 0, st, A);
     EMF_HIP(hipGetLastError());
     unsigned long long c[8];
     EMF_HIP(hipMemcpyAsync(c, d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
     EMF_HIP(hipStreamSynchronize(st));
-    if (c[4]) {
-        set_last_error("emf_build: a hash bucket holds more distinct L-mers than the builder keeps (raise the slack)");
+    // runs with more distinct L-mers than a lane keeps: sorted and counted by their own kernels
+    const unsigned long long n_big = c[6];
+    BigArgs G;
+    memset(&G, 0, sizeof G);
+    if (n_big > kBigCap) {
+        set_last_error("emf_build: " + std::to_string(n_big) + " hash buckets hold more than " + std::to_string(kMaxU) + " distinct L-mers (the builder lists " +
+                       std::to_string(kBigCap) + " of them)");
         cleanup();
         return BWAMS_ERR_UNSUPPORTED;
+    }
+    unsigned long long big_windows = 0;
+    if (n_big) {
+        std::vector<ulonglong2> lst(n_big);
+        EMF_HIP(hipMemcpy(lst.data(), d_big, n_big * sizeof(ulonglong2), hipMemcpyDeviceToHost));
+        std::sort(lst.begin(), lst.end(), [](const ulonglong2 &a, const ulonglong2 &b) { return a.x < b.x; });
+        std::vector<BigRun> runs(n_big);
+        unsigned long long off = 0;
+        for (size_t t = 0; t < n_big; ++t) {
+            if (lst[t].y >= (1ull << 30)) {
+                set_last_error("emf_build: a hash bucket holds 2^30 windows or more");
+                cleanup();
+                return BWAMS_ERR_UNSUPPORTED;
+            }
+            unsigned int pad = 2;
+            while (pad < lst[t].y) pad <<= 1;
+            runs[t].start = lst[t].x; runs[t].len = (unsigned int)lst[t].y; runs[t].padded = pad; runs[t].off = off;
+            off += pad;
+            big_windows += lst[t].y;
+        }
+        EMF_HIP(hipMalloc(&d_runs, n_big * sizeof(BigRun)));
+        EMF_HIP(hipMalloc(&d_ord, off * 4));
+        EMF_HIP(hipMemcpyAsync(d_runs, runs.data(), n_big * sizeof(BigRun), hipMemcpyHostToDevice, st));
+        G.A = A; G.runs = (const BigRun *)d_runs; G.ord = (uint32_t *)d_ord;
+        hipLaunchKernelGGL(emf_big_sort_kernel, dim3((unsigned)n_big), dim3(256), 0, st, G);
+        hipLaunchKernelGGL(emf_big_emit_kernel<1>, dim3((unsigned)n_big), dim3(64), 0, st, G);
+        EMF_HIP(hipGetLastError());
+        EMF_HIP(hipMemcpyAsync(c, d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
+        EMF_HIP(hipStreamSynchronize(st));                  // (runs[] stays alive until here)
     }
     const unsigned long long n_other = c[0], n_loc = c[1] + 1, n_used = c[2], n_key = c[3];
     // the free slots, ascending
@@ -362,6 +531,10 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
     A.free_list = (const uint32_t *)d_free; A.seeds = (uint4 *)e->d_seeds; A.loc = (uint32_t *)e->d_loc;
     A.free_cap = n_free; A.loc_cap = n_loc;
     hipLaunchKernelGGL(emf_bucket_kernel<2>, dim3(grid), dim3(256), 0, st, A);
+    if (n_big) {
+        G.A = A;
+        hipLaunchKernelGGL(emf_big_emit_kernel<2>, dim3((unsigned)n_big), dim3(64), 0, st, G);
+    }
     EMF_HIP(hipGetLastError());
     EMF_HIP(hipEventRecord(e3, st));
     EMF_HIP(hipMemcpyAsync(c, d_ctr, sizeof c, hipMemcpyDeviceToHost, st));
@@ -375,8 +548,8 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
     (void)hipEventElapsedTime(&ms1, e0, e1); (void)hipEventElapsedTime(&ms2, e1, e2); (void)hipEventElapsedTime(&ms3, e2, e3);
     if (verbose)
         fprintf(stderr, "[bwams] emf_build: L = %d, %llu windows, %llu distinct L-mers in %llu buckets of %llu, %llu nodes outside their bucket, "
-                        "%llu location words; keys + sort %.1f ms, count + free list %.1f ms, table %.1f ms\n",
-                seed_len, (unsigned long long)n, n_used, n_key, (unsigned long long)B.n_entry, n_other, n_loc, ms1, ms2, ms3);
+                        "%llu location words, %llu buckets (%llu windows) beyond %d L-mers; keys + sort %.1f ms, count + free list %.1f ms, table %.1f ms\n",
+                seed_len, (unsigned long long)n, n_used, n_key, (unsigned long long)B.n_entry, n_other, n_loc, n_big, big_windows, kMaxU, ms1, ms2, ms3);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     cleanup();
 #undef EMF_HIP

@@ -22,6 +22,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <string>
 #include "common.h"
 #include "ert_kernels.h"
 
@@ -111,9 +112,9 @@ struct Walk {
     uint32_t cur[3], maxp[3];
     uint32_t mh, mh_base, n_big;
     int64_t blob_off;
-    bool failed;
+    bool failed, mh_over;
 
-    __device__ Walk(const BuildArgs &a, int64_t t) : A(a), tid(t), out(nullptr), w(2), mh(0), mh_base(0), n_big(0), blob_off(0), failed(false) {
+    __device__ Walk(const BuildArgs &a, int64_t t) : A(a), tid(t), out(nullptr), w(2), mh(0), mh_base(0), n_big(0), blob_off(0), failed(false), mh_over(false) {
         cur[0] = cur[1] = cur[2] = 0;
         maxp[0] = maxp[1] = maxp[2] = 0;
     }
@@ -125,7 +126,10 @@ struct Walk {
         else { cur[0] += fixed + per_ptr * 2; cur[1] += fixed + per_ptr * 3; cur[2] += fixed + per_ptr * 4; }
     }
     // a multi-hit leaf: 5-byte pointer into the multi-hit area, there a 16-bit count and the positions
+    // The count is 16 bits in the format (ertindex.cpp:336-352; the reference's own writer never returns from a leaf of 65536 hits or
+    // more: its loop variable is a uint16_t): a text in which one read-length string occurs that often has no ERT index.
     __device__ void put_mh(const Iv &iv) {
+        if (iv.s > 0xffff) mh_over = true;
         const uint32_t n16 = (uint32_t)(iv.s & 0xffff);
         if (EMIT) {
             put(cur[0], ((uint64_t)mh << 1) | 1ull, 5);
@@ -358,9 +362,13 @@ __global__ __launch_bounds__(256) void ert_size_kernel(BuildArgs A) {
                 xmer_table<false>(W, A, ik);
             }
             if (W.failed) atomicAdd(&A.err[0], 1ull);
+            if (W.mh_over) atomicAdd(&A.err[2], 1ull);
             if (W.n_big) atomicAdd(&A.err[1], (unsigned long long)W.n_big);
             const int w = pick_width(W.maxp);
             const uint64_t tree = W.cur[w - 2];
+            // a pointer is 26 bits of offset beside 6 bits of hit count, and the reference asserts both that and the size of a k-mer's
+            // bytes below 2^26 (ertindex.cpp:452, :607, :651): a k-mer with more hits than 64 MiB of leaves has no tree in this format
+            if (W.maxp[w - 2] >= (1u << 26) || tree + W.mh >= (1ull << 26) || num_hits >= (1ll << 26) / 5) atomicAdd(&A.err[3], 1ull);
             if (num_hits < 20) lo |= (uint64_t)num_hits << 17;
             lo |= (uint64_t)(w < 4 ? w : 0) << 22;
             meta = (tree << 32) | (tree + W.mh);
@@ -439,8 +447,8 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
     ERT_HIP(hipMalloc(&d_meta, n_kmers * 8));
     ERT_HIP(hipMalloc(&d_off, n_kmers * 8));
     ERT_HIP(hipMalloc(&d_stk, (size_t)A.n_threads * (size_t)A.max_frames * 40));
-    ERT_HIP(hipMalloc(&d_err, 16));
-    ERT_HIP(hipMemsetAsync(d_err, 0, 16, st));
+    ERT_HIP(hipMalloc(&d_err, 32));
+    ERT_HIP(hipMemsetAsync(d_err, 0, 32, st));
     A.kmer = (uint64_t *)e->d_kmer;
     A.meta = (uint64_t *)d_meta;
     A.off = (const uint64_t *)d_off;
@@ -459,11 +467,23 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
         ERT_HIP(rocprim::exclusive_scan(d_tmp, tb, in, (uint64_t *)d_off, (uint64_t)0, (size_t)n_kmers, rocprim::plus<uint64_t>(), st));
     }
     uint64_t last_off = 0, last_meta = 0;
-    unsigned long long err[2] = {0, 0};
+    unsigned long long err[4] = {0, 0, 0, 0};
     ERT_HIP(hipMemcpyAsync(&last_off, (uint64_t *)d_off + (n_kmers - 1), 8, hipMemcpyDeviceToHost, st));
     ERT_HIP(hipMemcpyAsync(&last_meta, (uint64_t *)d_meta + (n_kmers - 1), 8, hipMemcpyDeviceToHost, st));
-    ERT_HIP(hipMemcpyAsync(err, d_err, 16, hipMemcpyDeviceToHost, st));
+    ERT_HIP(hipMemcpyAsync(err, d_err, 32, hipMemcpyDeviceToHost, st));
     ERT_HIP(hipStreamSynchronize(st));
+    if (err[2]) {
+        set_last_error("ert_build: " + std::to_string(err[2]) + " k-mer tree(s) hold a string of read_len bases that occurs 65536 times or more; the ERT format "
+                       "counts the hits of such a leaf in 16 bits (src/ertindex.cpp:336-352), so this text has no ERT index");
+        cleanup();
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    if (err[3]) {
+        set_last_error("ert_build: the trees of " + std::to_string(err[3]) + " k-mer(s) reach 64 MiB; child pointers carry 26 bits of offset and the reference's "
+                       "writer asserts every k-mer's bytes below 2^26 (src/ertindex.cpp:452, :607, :651), so this text has no ERT index with this k");
+        cleanup();
+        return BWAMS_ERR_UNSUPPORTED;
+    }
     if (err[0]) {
         set_last_error("ert_build: a radix tree is deeper than the read length allows (corrupt index?)");
         cleanup();

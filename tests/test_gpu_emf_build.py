@@ -15,10 +15,16 @@ from oracle import loader
 pytestmark = pytest.mark.gpu
 
 
-def _genome(n, seed):
+def _genome(n, seed, microsat=False):
     g = simulate.make_genome(n, seed=seed, repeat_frac=0.2, repeat_len=300, n_families=3, repeat_div=0.0)   # exact copies
     g[5000:5400] = g[1000:1400]
     g[9000:9400] = (3 - g[1000:1400][::-1])                  # a reverse-complement copy
+    if microsat:
+        # a poly-T run inside a (GA)n microsatellite, a poly-A run inside (CA)n: the table's hash (an XOR of 32-base words) is the same
+        # wherever the run sits in the window, so ~90 DISTINCT L-mers share one bucket (met on the grch38_like genome at full size)
+        ga, ca = np.tile(np.array([2, 0], np.uint8), 150), np.tile(np.array([1, 0], np.uint8), 130)
+        g[12000:12632] = np.concatenate([ga, np.full(32, 3, np.uint8), ga])
+        g[15000:15560] = np.concatenate([ca, np.full(40, 0, np.uint8), ca])
     return g
 
 
@@ -53,9 +59,10 @@ def _canon(w):
     return (bytes(w) if fw else bytes(rc)), fw
 
 
-@pytest.mark.parametrize("L,n_bases,slack", [(50, 40000, 1.1), (150, 60000, 1.1), (33, 20000, 1.0), (151, 30000, 2.0)])
-def test_built_table_invariants_and_answers(L, n_bases, slack, tmp_path):
-    g = _genome(n_bases, L)
+@pytest.mark.parametrize("L,n_bases,slack,microsat", [(50, 40000, 1.1, False), (150, 60000, 1.1, False), (33, 20000, 1.0, False),
+                                                       (151, 30000, 2.0, False), (150, 30000, 1.1, True), (64, 30000, 1.1, True)])
+def test_built_table_invariants_and_answers(L, n_bases, slack, microsat, tmp_path):
+    g = _genome(n_bases, L, microsat)
     idx = fmindex.build_fmindex(g)
     ix = capi.Index.from_host(idx, 0)
     e = capi.Emf.build(ix, seed_len=L, slack=slack)
@@ -107,6 +114,15 @@ def test_built_table_invariants_and_answers(L, n_bases, slack, tmp_path):
             assert fl >> 2 == 0
         found += 1
     assert found == len(want) and info["n_key"] == len(roots)
+    if microsat and L == 150:                                # the case is what it says: a bucket with more L-mers than a lane keeps (48)
+        chain = np.zeros(n_entry, np.int64)
+        for k in roots:
+            s_, d = k, 0
+            while s_ != emf.NO_ENTRY:
+                d += 1
+                s_ = int(seeds[s_][3])
+            chain[k] = d
+        assert chain.max() > 48
     used = seeds[:, 1] != emf.NO_ENTRY
     assert int(used.sum()) == len(want)                      # nothing else in the table
     # answers: oracle over this table == oracle over the host builder's table == the HIP probe over both

@@ -93,3 +93,25 @@ def test_real_kmer_size_build_save_open(tmp_path):
     assert all(np.array_equal(x, y) for x, y in zip(a1, a2)) and len(a1[0]) > 1000
     os.remove(prefix + ".kmer_table"); os.remove(prefix + ".mlt_table")
     b.close(); ert.close(); ert2.close(); ix.close()
+
+
+def test_a_leaf_of_65536_hits_is_refused_and_the_hard_genome_profile_builds():
+    """The format counts the hits of a multi-hit leaf (a string of read_len bases) in 16 bits, and the reference's writer loops for ever
+    on 65536 of them (ertindex.cpp:336-352, `uint16_t k`): such a text is refused with an error, not written truncated.  The
+    grch38_like profile (satellite arrays, microsatellites, poly-A, segmental duplications) stays below that and builds to the writer's bytes."""
+    rng = np.random.default_rng(4)
+    g = rng.integers(0, 4, size=120000, dtype=np.uint8)
+    g[20000:20000 + 65600] = 0                                 # A^40 occurs 65 561 times
+    ix = capi.Index.build(g, 0)
+    with pytest.raises(capi.BwamsError, match="65536"):
+        capi.Ert.build(ix, kmer=8, xmer=2, read_len=40, hit_threshold=64)
+    ert = capi.Ert.build(ix, kmer=8, xmer=2, read_len=255, hit_threshold=64)     # at 255 bases the leaf has 65 346
+    ert.close(); ix.close()
+    g = simulate.make_genome(150000, seed=8, profile="grch38_like")
+    idx = fmindex.build_fmindex(g)
+    o = loader.OracleFMI(idx)
+    e = loader.OracleERT(o, fmindex.fw_rc_text(g), kmer=8, xmer=2, read_len=151, hit_threshold=32)
+    ix = capi.Index.from_host(idx, 0)
+    ert = capi.Ert.build(ix, kmer=8, xmer=2, read_len=151, hit_threshold=32)
+    _same(e, ert)
+    ert.close(); ix.close()

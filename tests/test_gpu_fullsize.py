@@ -13,14 +13,17 @@ N_READS = 1_000_000
 # two index sizes: 48 Mbp (quick) and GRCh38's own l_pac = 3 209 286 105 (src/bwa_shm.cpp:1386: 6 418 572 211 rows, beyond
 # 2^32), where every 64-bit row path of the kernels (36-bit interval packing, sa_ms_byte != 0, coordinates >= 2^32 in
 # chaining, extension and pairing) is live.  Both indexes are built on the GPU (bwams_index_build).
-GENOMES = {"48Mbp": 48_000_000, "GRCh38_size_6.4G_rows": 3_209_286_105}
+# The third genome has the structures that make the human reference hard (simulate.make_genome profile "grch38_like": satellite arrays,
+# microsatellites, poly-A runs, exact segmental duplications, N holes).
+GENOMES = {"48Mbp": (48_000_000, None), "48Mbp_grch38_like": (48_000_000, "grch38_like"), "GRCh38_size_6.4G_rows": (3_209_286_105, None),
+           "GRCh38_size_grch38_like": (3_209_286_105, "grch38_like")}
 
 
 @pytest.fixture(scope="module", params=list(GENOMES.keys()))
 def big(request):
     capi.lib()
-    n = GENOMES[request.param]
-    g = simulate.make_genome(n, seed=77)
+    n, profile = GENOMES[request.param]
+    g = simulate.make_genome(n, seed=77, profile=profile)
     ix = capi.Index.build(g, 0)
     contigs = simulate.chromosomes(n) if n >= 2 ** 31 else None      # bntann1_t.len is 32 bits: several sequences, as GRCh38
     if contigs is not None:

@@ -787,6 +787,10 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     D.heavy = s->heavy.as<int32_t>(); D.light = s->dd_light.as<int32_t>();
     D.n_heavy_ctr = &b->d_ctr->dedup_heavy; D.ticket = &b->d_ctr->dedup_ticket; D.n_light_ctr = &b->d_ctr->dedup_light;
     D.ticket2 = &b->d_ctr->dedup_ticket2; D.ticket3 = &b->d_ctr->dedup_ticket3;
+    static const char *vb_dd = getenv("BWAMS_VERBOSE");
+    const bool verbose_dd = vb_dd && *vb_dd && *vb_dd != '0';
+    D.dbg = verbose_dd ? b->d_ctr->dbg : nullptr;
+    if (verbose_dd) BWAMS_HIP(hipMemsetAsync(b->d_ctr->dbg, 0, sizeof b->d_ctr->dbg, st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->dedup_heavy, 0, 3 * sizeof(unsigned long long), st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->dedup_ticket2, 0, 2 * sizeof(unsigned long long), st));
     BWAMS_HIP(hipEventRecord(s->ev[12], st));
@@ -807,8 +811,15 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
         BWAMS_HIP(hipMemsetAsync(s->dd_off.p, 0, 8, st));          // an empty chunk: reg_off = {0}
     }
     BWAMS_HIP(hipEventRecord(s->ev[13], st));
+    if (verbose_dd) BWAMS_HIP(hipMemcpyAsync(b->h_ctr->dbg, b->d_ctr->dbg, sizeof b->d_ctr->dbg, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     BWAMS_HIP(hipGetLastError());
+    if (verbose_dd) {
+        const unsigned long long *d = b->h_ctr->dbg;
+        fprintf(stderr, "[bwams_dedup_run] largest wave instance: %llu reads, %llu slots, %llu alive; Mcycles: load %.1f sort(end) %.1f pairs %.1f reload %.1f sort(score) %.1f store %.1f; "
+                        "longest read: sort(end) %.2f pairs %.2f sort(score) %.2f, whole %.2f (read %llu, %llu regions)\n",
+                d[0], d[1], d[2], d[3] / 1e6, d[4] / 1e6, d[5] / 1e6, d[6] / 1e6, d[7] / 1e6, d[8] / 1e6, d[9] / 1e6, d[10] / 1e6, d[11] / 1e6, d[12] / 1e6, d[13], d[14]);
+    }
     s->n_final = total;
     s->dedup_done = true;
     if (n_regs) *n_regs = total;

@@ -134,6 +134,7 @@ struct DedupArgs {
     unsigned long long *n_heavy_ctr, *n_light_ctr, *ticket;
     int32_t force_seq;             // debug: lane 0 runs the one-lane form for every read
     unsigned long long *ticket2, *ticket3;   // work cursors of the wave tier's smaller instances
+    unsigned long long *dbg;       // BWAMS_VERBOSE: cycles per phase of the largest wave instance (8 words), else nullptr
 };
 size_t dedup_sortrec_bytes(int64_t n);
 int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, int64_t n_waves_small, hipStream_t st, hipStream_t aux,

@@ -20,6 +20,10 @@ constexpr int kLightN = 32;          // regions per read handled by a single lan
 constexpr int kSmallN = 128, kMidN = 512;      // regions per read of the wave tier's smaller instances
 constexpr int kLdsN = 2048;          // sort records a wavefront keeps in LDS (largest instance of the wave tier)
 constexpr int MINUS_INF = -0x40000000;
+constexpr int kEhLdsLen = 1000;      // reads up to this length align their patch candidates with the row in LDS (9 bytes per base)
+__host__ __device__ constexpr size_t dd_lds_bytes(int cap, int max_read_len) {
+    return (size_t)60 * cap + (max_read_len <= kEhLdsLen ? (size_t)(max_read_len + 2) * 8 + (((size_t)max_read_len + 2 + 15) & ~(size_t)15) : 0);
+}
 
 // ksw_global2 without backtrack; query[j] = qseq[qs * j], target[i] = tseq[ts * i] (ts = qs = -1 on the reverse strand,
 // where bwa_gen_cigar2 reverses both sequences); eh: qlen + 1 cells of this lane's strip
@@ -70,19 +74,107 @@ __device__ int global_score(const bwams_mem_opt_t &o, int qlen, const uint8_t *q
     return eh[qlen].x;
 }
 
+// The same alignment with the whole wavefront on a row (all 64 lanes call this with equal arguments): 64 columns per step, the (h, e) row
+// and the query in LDS, the row's target base handed round from a register (one load per 64 rows).  Within a row E and the diagonal term
+// come from the row above, and F — max over the columns to the left of (M - gap open) minus the extensions in between — is a prefix
+// maximum (ksw_global2 feeds F from M only, ksw.cpp:607-618), so the cells of a row are independent but for that scan: the scores are
+// the serial loop's, cell for cell.  Every patch candidate of a read with hundreds of overlapping regions goes through here; on one
+// lane with the row in HBM such a read held its wavefront for 0.4 s.
+__device__ __forceinline__ int dd_incl_max(int v) {
+    asm volatile("s_nop 4\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
+    return v;
+}
+__device__ int global_score_wave(const bwams_mem_opt_t &o, int qlen, const uint8_t *qseq, int qs, int tlen, const uint8_t *tseq, int ts,
+                                 int w, int2 *eh, uint8_t *qbuf, int lane) {
+    const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+    constexpr int kNeg = -0x30000000;                       // below every reachable score, above MINUS_INF - (what a row subtracts)
+    for (int j = lane; j <= qlen; j += 64) {
+        eh[j] = j == 0 ? make_int2(0, MINUS_INF) : j <= w ? make_int2(-(o.o_ins + o.e_ins * j), MINUS_INF) : make_int2(MINUS_INF, MINUS_INF);
+        if (j < qlen) qbuf[j] = qseq[(int64_t)qs * j];
+    }
+    __syncthreads();
+    int tv = 0;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) tv = i + lane < tlen ? (int)tseq[(int64_t)ts * (i + lane)] : 4;
+        const int tb = __shfl(tv, i & 63);
+        const int8_t *mrow = &o.mat[tb * 5];
+        const int s0 = mrow[0], s1 = mrow[1], s2 = mrow[2], s3 = mrow[3], s4 = mrow[4];
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int h1_first = beg == 0 ? -(o.o_del + o.e_del * (i + 1)) : MINUS_INF;
+        int f_carry = MINUS_INF, h_carry = h1_first, h_end = h1_first;
+        for (int c0 = beg; c0 < end; c0 += 64) {
+            const int j = c0 + lane;
+            const bool act = j < end;
+            int2 p = make_int2(0, 0);
+            int qb = 4;
+            if (act) { p = eh[j]; qb = qbuf[j]; }
+            const int m = p.x + (qb == 0 ? s0 : qb == 1 ? s1 : qb == 2 ? s2 : qb == 3 ? s3 : s4);
+            int e = p.y;
+            const int t_ins = m - oe_ins;
+            const int g = act ? t_ins + j * o.e_ins : kNeg;
+            const int P = dd_incl_max(g);
+            const int Pex = __shfl_up(P, 1);
+            int f = f_carry - (j - c0) * o.e_ins;          // what the gap open before this chunk has become
+            if (lane > 0) { const int fp = Pex - (j - 1) * o.e_ins; f = f > fp ? f : fp; }
+            int h = m >= e ? m : e;
+            h = h >= f ? h : f;
+            const int t = m - oe_del;
+            e -= o.e_del;
+            e = e > t ? e : t;
+            const int fn = f - o.e_ins;
+            int hl = __shfl_up(h, 1);
+            if (lane == 0) hl = h_carry;
+            if (act) eh[j] = make_int2(hl, e);
+            const int fnext = fn > t_ins ? fn : t_ins;
+            f_carry = __shfl(fnext, 63);
+            h_carry = __shfl(h, 63);
+            const int last = end - 1 - c0;                 // the row's last column, if it lies in this chunk
+            if (last < 64) h_end = __shfl(h, last);
+        }
+        if (lane == 0) eh[end] = make_int2(h_end, MINUS_INF);
+        __syncthreads();
+    }
+    return eh[qlen].x;
+}
+
+// mem_patch_reg's tests on the two regions' coordinates alone (bwamem.cpp:205-217), a upstream of b: false = it returns 0 before any alignment
+__device__ __forceinline__ bool patch_geom(const bwams_mem_opt_t &opt, int64_t l_pac, int64_t a_rb, int64_t a_re, int a_qb, int a_qe,
+                                           int64_t b_rb, int64_t b_re, int b_qb, int b_qe) {
+    if (a_rb < l_pac && b_rb >= l_pac) return false;
+    if (a_qb >= b_qb || a_qe >= b_qe || a_re >= b_re) return false;
+    int w = (int)((a_re - b_rb) - (a_qe - b_qb));
+    w = w > 0 ? w : -w;
+    double r = (double)(a_re - b_rb) / (double)(b_re - a_rb) - (double)(a_qe - b_qb) / (double)(b_qe - a_qb);
+    r = r > 0. ? r : -r;
+    if (a_re < b_rb || a_qe < b_qb) {
+        if (w > (opt.w << 1) || r >= (double)0.05f) return false;
+    } else if (w > (opt.w << 2) || r >= (double)(0.05f * 2)) return false;
+    return true;
+}
+
 // mem_patch_reg (bwamem.cpp:199-250): score of the merged alignment, or 0
-__device__ int patch_reg(const DedupArgs &A, const uint8_t *query, const bwams_alnreg_t &a, const bwams_alnreg_t &b, int *w_out, int2 *eh) {
+// WAVE: called by all 64 lanes with equal arguments, eh and qbuf in LDS
+template <bool WAVE>
+__device__ int patch_reg(const DedupArgs &A, const uint8_t *query, const bwams_alnreg_t &a, const bwams_alnreg_t &b, int *w_out, int2 *eh,
+                         uint8_t *qbuf = nullptr, int lane = 0) {
     const bwams_mem_opt_t &opt = A.opt;
     const int64_t l_pac = A.bns.l_pac;
-    if (a.rb < l_pac && b.rb >= l_pac) return 0;
-    if (a.qb >= b.qb || a.qe >= b.qe || a.re >= b.re) return 0;
+    if (!patch_geom(opt, l_pac, a.rb, a.re, a.qb, a.qe, b.rb, b.re, b.qb, b.qe)) return 0;
     int w = (int)((a.re - b.rb) - (a.qe - b.qb));
     w = w > 0 ? w : -w;
-    double r = (double)(a.re - b.rb) / (double)(b.re - a.rb) - (double)(a.qe - b.qb) / (double)(b.qe - a.qb);
-    r = r > 0. ? r : -r;
-    if (a.re < b.rb || a.qe < b.qb) {
-        if (w > (opt.w << 1) || r >= (double)0.05f) return 0;
-    } else if (w > (opt.w << 2) || r >= (double)(0.05f * 2)) return 0;
     w += a.w + b.w;
     w = w < (opt.w << 2) ? w : (opt.w << 2);
     // bwa_gen_cigar2 (score only)
@@ -97,6 +189,17 @@ __device__ int patch_reg(const DedupArgs &A, const uint8_t *query, const bwams_a
         const int st = rev ? -1 : 1;
         if (l_query == rlen && w == 0) {
             for (int i = 0; i < l_query; ++i) score += opt.mat[tseq[(int64_t)st * i] * 5 + qseq[(int64_t)st * i]];
+        } else if (WAVE) {
+            int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
+            int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
+            int max_gap = max_ins > max_del ? max_ins : max_del;
+            max_gap = max_gap > 1 ? max_gap : 1;
+            const int dl = (int)(rlen - l_query) < 0 ? -(int)(rlen - l_query) : (int)(rlen - l_query);
+            int ww = (max_gap + dl + 1) >> 1;
+            ww = ww < w ? ww : w;
+            const int min_w = dl + 3;
+            ww = ww > min_w ? ww : min_w;
+            score = global_score_wave(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh, qbuf, lane);
         } else {
             int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
             int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
@@ -147,7 +250,7 @@ __device__ int dedup_read(const DedupArgs &A, int64_t r, SortRec *srt, int2 *eh)
                 if ((float)or_ > A.opt.mask_level_redun * (float)mr && (float)oq > A.opt.mask_level_redun * (float)mq) {
                     if (p->score < q->score) { p->qe = p->qb; break; }
                     else q->qe = q->qb;
-                } else if (q->rb < p->rb && (score = patch_reg(A, query, *q, *p, &w, eh)) > 0) {
+                } else if (q->rb < p->rb && (score = patch_reg<false>(A, query, *q, *p, &w, eh)) > 0) {
                     p->n_comp_is_alt = (p->n_comp_is_alt + q->n_comp_is_alt + 1) & 0x3fffffff;
                     p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
                     p->sub = p->sub > q->sub ? p->sub : q->sub;
@@ -262,6 +365,10 @@ template <int CAP, int LO>
 __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_waves, int64_t eh_base, unsigned long long *ticket) {
     extern __shared__ __align__(16) unsigned char lds_dd[];
     SortRec *l_srt = reinterpret_cast<SortRec *>(lds_dd), *l_srt2 = l_srt + CAP;
+    // behind the 60 CAP bytes, when the launch gave the room (reads of up to kEhLdsLen bases): the (h, e) row and the query of a patch alignment
+    int2 *lds_eh = A.max_read_len <= kEhLdsLen ? reinterpret_cast<int2 *>(lds_dd + (size_t)60 * CAP) : nullptr;
+    uint8_t *lds_q = reinterpret_cast<uint8_t *>(lds_eh + (A.max_read_len + 2));
+    int4 *l_x = reinterpret_cast<int4 *>(l_srt2);          // during the pairwise pass (the sorts' second buffer is free then): {qb, qe, score, -}
     int64_t *l_rb = reinterpret_cast<int64_t *>(l_srt2 + CAP);
     int32_t *l_ord = reinterpret_cast<int32_t *>(l_rb + CAP);
     const int lane = threadIdx.x;
@@ -282,7 +389,10 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
             if (lane == 0) A.n_out[r] = dedup_read(A, r, reinterpret_cast<SortRec *>(A.srt) + reg0, eh);
             continue;
         }
+        const bool prof = CAP == kLdsN && A.dbg != nullptr;
+        unsigned long long tk0 = prof ? wall_clock64() : 0ull, tk1 = tk0, tk2 = tk0, tk3 = tk0, tk4 = tk0, tk5 = tk0;
         int n = wave_compact_alive(a, l_ord, av_n, true, lane);         // bwamem.cpp:1446-1456
+        const int n_alive0 = n;
         __syncthreads();
         if (n > 1) {
             for (int i = lane; i < n; i += 64) {
@@ -291,7 +401,9 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
                 l_srt[i] = x;
             }
             __syncthreads();
-            wave_sort_records(l_srt, l_srt2, n, 0, lane);
+            if (prof) tk1 = wall_clock64();
+            wave_sort_records(l_srt, l_srt2, n, 0, lane, false, 0, CAP);
+            if (prof) tk2 = wall_clock64();
             for (int i = lane; i < n; i += 64) {
                 const int slot = l_srt[i].idx;
                 l_ord[i] = slot;
@@ -300,37 +412,99 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
             }
             __threadfence_block();
             __syncthreads();
-            if (lane == 0) {
-                for (int i = 1; i < n; ++i) {
-                    if (l_srt[i].s != l_srt[i - 1].s || l_rb[i] >= l_srt[i - 1].k + A.opt.max_chain_gap) continue;
-                    bwams_alnreg_t *p = &a[l_ord[i]];
-                    for (int j = i - 1; j >= 0; --j) {
-                        if (!(l_srt[i].s == l_srt[j].s && p->rb < l_srt[j].k + A.opt.max_chain_gap)) break;
-                        bwams_alnreg_t *q = &a[l_ord[j]];
-                        if (q->qe == q->qb) continue;
-                        const int64_t or_ = q->re - p->rb;
-                        const int64_t oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
-                        const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
-                        const int64_t mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
-                        int score, w;
-                        if ((float)or_ > A.opt.mask_level_redun * (float)mr && (float)oq > A.opt.mask_level_redun * (float)mq) {
-                            if (p->score < q->score) { p->qe = p->qb; break; }
-                            else q->qe = q->qb;
-                        } else if (q->rb < p->rb && (score = patch_reg(A, query, *q, *p, &w, eh)) > 0) {
-                            p->n_comp_is_alt = (p->n_comp_is_alt + q->n_comp_is_alt + 1) & 0x3fffffff;
-                            p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
-                            p->sub = p->sub > q->sub ? p->sub : q->sub;
-                            p->csub = p->csub > q->csub ? p->csub : q->csub;
-                            p->qb = q->qb; p->rb = q->rb;
-                            p->truesc = p->score = score;
-                            p->w = w;
-                            q->qb = q->qe;
+            // The pairwise pass.  Sequential by nature (a merge changes p, a deletion hides q from every later p), but nearly every test
+            // ends in "nothing to do": the wave evaluates 64 upstream regions at a time against the current p from LDS copies of the
+            // fields the tests read (re, rid: the sort records; rb; qb, qe, score), and only the events — the end of the scan, a redundant
+            // pair, a pair that passes mem_patch_reg's coordinate tests — are taken one by one, in the order the serial loop meets them.
+            // The records in HBM are written through at every change (patch_reg and the passes behind this one read them).
+            for (int i = lane; i < n; i += 64) {
+                const bwams_alnreg_t *p = &a[l_ord[i]];
+                l_x[i] = make_int4(p->qb, p->qe, p->score, 0);
+            }
+            __syncthreads();
+            const int64_t gap = A.opt.max_chain_gap, l_pac = A.bns.l_pac;
+            const float mlr = A.opt.mask_level_redun;
+            for (int i = 1; i < n; ++i) {
+                const int rid_i = l_srt[i].s;
+                if (rid_i != l_srt[i - 1].s || l_rb[i] >= l_srt[i - 1].k + gap) continue;
+                int64_t p_rb = l_rb[i];
+                const int64_t p_re = l_srt[i].k;
+                int4 px = l_x[i];
+                bool done = false;
+                int jtop = i - 1;
+                while (jtop >= 0 && !done) {
+                    const int j = jtop - lane;
+                    bool end = j < 0, red = false, pat = false;
+                    if (!end) {
+                        const int64_t q_re = l_srt[j].k;
+                        end = !(rid_i == l_srt[j].s && p_rb < q_re + gap);
+                        if (!end) {
+                            const int4 qx = l_x[j];
+                            const int64_t q_rb = l_rb[j];
+                            if (qx.y != qx.x) {
+                                const int64_t or_ = q_re - p_rb;
+                                const int64_t oq = qx.x < px.x ? qx.y - px.x : px.y - qx.x;
+                                const int64_t mr = q_re - q_rb < p_re - p_rb ? q_re - q_rb : p_re - p_rb;
+                                const int64_t mq = qx.y - qx.x < px.y - px.x ? qx.y - qx.x : px.y - px.x;
+                                red = (float)or_ > mlr * (float)mr && (float)oq > mlr * (float)mq;
+                                pat = !red && q_rb < p_rb && patch_geom(A.opt, l_pac, q_rb, q_re, qx.x, qx.y, p_rb, p_re, px.x, px.y);
+                            }
                         }
                     }
+                    const unsigned long long m_end = __ballot(end), m_red = __ballot(red);
+                    unsigned long long ev = m_end | m_red | __ballot(pat);
+                    int consumed = 64;
+                    while (ev) {
+                        const int l = __builtin_ctzll(ev);
+                        ev &= ev - 1;
+                        if ((m_end >> l) & 1) { done = true; break; }
+                        const int jj = jtop - l;
+                        bwams_alnreg_t *pp = &a[l_ord[i]], *qq = &a[l_ord[jj]];
+                        if ((m_red >> l) & 1) {
+                            if (px.z < l_x[jj].z) {
+                                px.y = px.x;
+                                if (lane == 0) { pp->qe = px.x; l_x[i] = px; }
+                                done = true;
+                                break;
+                            }
+                            if (lane == 0) { const int qb = l_x[jj].x; qq->qe = qb; l_x[jj].y = qb; }
+                            continue;
+                        }
+                        int score = 0, w = 0;
+                        if (lds_eh) {
+                            const bwams_alnreg_t qa = *qq, pa = *pp;       // written through by lane 0 only, read back behind a barrier
+                            score = patch_reg<true>(A, query, qa, pa, &w, lds_eh, lds_q, lane);
+                        } else if (lane == 0) score = patch_reg<false>(A, query, *qq, *pp, &w, eh);
+                        score = __builtin_amdgcn_readfirstlane(score);
+                        w = __builtin_amdgcn_readfirstlane(w);
+                        if (score > 0) {
+                            __syncthreads();
+                            const int4 qx = l_x[jj];
+                            p_rb = l_rb[jj];
+                            px.x = qx.x; px.z = score;
+                            __syncthreads();
+                            if (lane == 0) {
+                                pp->n_comp_is_alt = (pp->n_comp_is_alt + qq->n_comp_is_alt + 1) & 0x3fffffff;
+                                pp->seedcov = pp->seedcov > qq->seedcov ? pp->seedcov : qq->seedcov;
+                                pp->sub = pp->sub > qq->sub ? pp->sub : qq->sub;
+                                pp->csub = pp->csub > qq->csub ? pp->csub : qq->csub;
+                                pp->qb = qq->qb; pp->rb = qq->rb;
+                                pp->truesc = pp->score = score;
+                                pp->w = w;
+                                qq->qb = qq->qe;
+                                l_rb[i] = p_rb; l_x[i] = px; l_x[jj].x = qx.y;
+                            }
+                            consumed = l + 1;                            // p changed: the regions further upstream are tested again
+                            break;
+                        }
+                    }
+                    __syncthreads();
+                    jtop -= consumed;
                 }
             }
             __threadfence_block();
             __syncthreads();
+            if (prof) tk3 = wall_clock64();
             n = wave_compact_alive(a, l_ord, n, false, lane);
             __syncthreads();
             for (int i = lane; i < n; i += 64) {
@@ -344,7 +518,9 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
                 l_srt[i] = x;
             }
             __syncthreads();
-            wave_sort_records(l_srt, l_srt2, n, 1, lane);
+            if (prof) tk4 = wall_clock64();
+            wave_sort_records(l_srt, l_srt2, n, 1, lane, false, 0, CAP);
+            if (prof) tk5 = wall_clock64();
             // identical hits: same (score, rb, qb) as the predecessor in sorted order
             int m = 0;
             for (int ib = 0; ib < n; ib += 64) {
@@ -372,6 +548,14 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
             if (p->rid >= 0 && A.bns.contigs[p->rid].is_alt) p->n_comp_is_alt = (nc & 0x3fffffff) | (1 << 30);
         }
         if (lane == 0) A.n_out[r] = n;
+        if (prof && lane == 0) {
+            const unsigned long long tk6 = wall_clock64();
+            atomicAdd(&A.dbg[0], 1ull); atomicAdd(&A.dbg[1], (unsigned long long)av_n); atomicAdd(&A.dbg[2], (unsigned long long)n_alive0);
+            atomicAdd(&A.dbg[3], tk1 - tk0); atomicAdd(&A.dbg[4], tk2 - tk1); atomicAdd(&A.dbg[5], tk3 - tk2);
+            atomicAdd(&A.dbg[6], tk4 - tk3); atomicAdd(&A.dbg[7], tk5 - tk4); atomicAdd(&A.dbg[8], tk6 - tk5);
+            atomicMax(&A.dbg[9], tk2 - tk1); atomicMax(&A.dbg[10], tk3 - tk2); atomicMax(&A.dbg[11], tk5 - tk4);
+            if (atomicMax(&A.dbg[12], tk6 - tk0) < tk6 - tk0) { A.dbg[13] = (unsigned long long)r; A.dbg[14] = (unsigned long long)n_alive0; }
+        }
     }
 }
 
@@ -421,8 +605,8 @@ __global__ void pestat_kernel(const bwams_alnreg_t *__restrict__ regs, const int
 }
 
 constexpr int kTestN = 1024;
-// test hook: one wavefront sorts n records held in LDS, as the wave tier does (mode 0: rank sort with the exact fallback on
-// ties, 1: the operation-exact wave introsort always, 2: lane 0 alone through sort_records on a copy in GLOBAL memory — the
+// test hook: one wavefront sorts n records held in LDS, as the wave tier does (mode 0: rank sort, or beyond 96 records the bitonic
+// network, with the exact fallback on ties, 1: the operation-exact wave introsort always, 2: lane 0 alone through sort_records on a copy in GLOBAL memory — the
 // sequential statement of the same sort; 3 / 4: modes 1 / 2 with a depth budget of 2, so that the comb-sort fallback
 // (wave_combsort / r_combsort) sorts nearly everything)
 __global__ __launch_bounds__(64) void sort_test_kernel(const SortRec *__restrict__ in, int n, int by_score, int mode, int32_t *__restrict__ order,
@@ -439,7 +623,7 @@ __global__ __launch_bounds__(64) void sort_test_kernel(const SortRec *__restrict
     }
     for (int i = lane; i < n; i += 64) l_a[i] = in[i];
     __syncthreads();
-    wave_sort_records(l_a, l_t, n, by_score, lane, mode == 1 || mode == 3, mode == 3 ? 2 : 0);
+    wave_sort_records(l_a, l_t, n, by_score, lane, mode == 1 || mode == 3, mode == 3 ? 2 : 0, kTestN);
     for (int i = lane; i < n; i += 64) order[i] = l_a[i].idx;
 }
 
@@ -482,15 +666,15 @@ int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, int64_t n
     // the reads with the most regions first (one wave per CU), the bulk beside them on the auxiliary streams
     // the 120 KB of dynamic LDS of the largest instance need the opt-in on EVERY device a batch runs on (the attribute belongs to the
     // device that is current when it is set); cheap enough to repeat per launch, and checked
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(dedup_wave_kernel<kLdsN, kMidN>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * kLdsN) != hipSuccess) return -1;
-    dedup_wave_kernel<kLdsN, kMidN><<<(unsigned)n_waves, 64, 60 * kLdsN, st>>>(A, n_waves, A.eh_lanes, A.ticket);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(dedup_wave_kernel<kLdsN, kMidN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dd_lds_bytes(kLdsN, A.max_read_len)) != hipSuccess) return -1;
+    dedup_wave_kernel<kLdsN, kMidN><<<(unsigned)n_waves, 64, dd_lds_bytes(kLdsN, A.max_read_len), st>>>(A, n_waves, A.eh_lanes, A.ticket);
     dedup_kernel<<<(unsigned)((n_lanes + 63) / 64), 64, 0, aux>>>(A, n_lanes);
     if (hipEventRecord(join, aux) != hipSuccess || hipStreamWaitEvent(st, join, 0) != hipSuccess) return -1;
     if (hipStreamWaitEvent(aux3, fork, 0) != hipSuccess) return -1;
-    dedup_wave_kernel<kMidN, kSmallN><<<(unsigned)n_waves, 64, 60 * kMidN, aux3>>>(A, n_waves, A.eh_lanes + n_waves, A.ticket3);
+    dedup_wave_kernel<kMidN, kSmallN><<<(unsigned)n_waves, 64, dd_lds_bytes(kMidN, A.max_read_len), aux3>>>(A, n_waves, A.eh_lanes + n_waves, A.ticket3);
     if (hipEventRecord(join3, aux3) != hipSuccess || hipStreamWaitEvent(st, join3, 0) != hipSuccess) return -1;
     if (hipStreamWaitEvent(aux2, fork, 0) != hipSuccess) return -1;
-    dedup_wave_kernel<kSmallN, kLightN><<<(unsigned)n_waves_small, 64, 60 * kSmallN, aux2>>>(A, n_waves_small, A.eh_lanes + 2 * n_waves, A.ticket2);
+    dedup_wave_kernel<kSmallN, kLightN><<<(unsigned)n_waves_small, 64, dd_lds_bytes(kSmallN, A.max_read_len), aux2>>>(A, n_waves_small, A.eh_lanes + 2 * n_waves, A.ticket2);
     if (hipEventRecord(join2, aux2) != hipSuccess || hipStreamWaitEvent(st, join2, 0) != hipSuccess) return -1;
     return 0;
 }

@@ -172,6 +172,36 @@ template <class LT> __device__ __forceinline__ bool wave_rank_pass(const SortRec
     }
     return tie;
 }
+// The same contract (tmp = the records in sorted order, returns whether two of them compare equal) for more than a few dozen records: a
+// bitonic network over the next power of two P >= n (tmp holds P records; the pads, pad_ = 1, sort behind everything).  n log^2 n / 128
+// compare-exchanges per lane instead of n^2 / 64 comparisons: a read in a satellite array reaches de-duplication with 500 .. 2000
+// regions, and two rank sorts of those were a millisecond of a wavefront that has a CU to itself.
+template <class LT> __device__ __forceinline__ bool wave_bitonic_pass(const SortRec *a, SortRec *tmp, int n, int P, int lane, LT lt) {
+    for (int i = lane; i < P; i += 64) {
+        SortRec x;
+        if (i < n) x = a[i]; else { x.k = 0; x.s = 0; x.q = 0; x.idx = 0; x.pad_ = 1; }
+        tmp[i] = x;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = lane; e < P; e += 64) {
+                const int x = e ^ j;
+                if (x > e) {
+                    const SortRec A = tmp[e], B = tmp[x];
+                    const bool b_lt_a = !B.pad_ && (A.pad_ || lt(B, A));
+                    if (b_lt_a == ((e & k) == 0)) { tmp[e] = B; tmp[x] = A; }
+                }
+            }
+            __syncthreads();
+        }
+    bool tie = false;
+    for (int ib = 1; ib < n; ib += 64) {
+        const int i = ib + lane;
+        tie = tie || (__ballot(i < n && !lt(tmp[i - 1], tmp[i])) != 0);
+    }
+    return tie;
+}
 // ks_introsort operation by operation, but with the whole wavefront on every step (all 64 lanes call this; a in LDS,
 // tmp = n records of LDS scratch, stk = 120 ints of LDS).  The Hoare partition of a range [s, t] around the pivot rp
 // (moved to a[t]) is determined by two lists: the "up stoppers" (x in s+1..t, ascending, with !lt(a[x], rp)) and the
@@ -279,11 +309,18 @@ template <class LT> __device__ void wave_introsort(SortRec *a, int n, SortRec *t
 }
 
 // force_exact: take the operation-exact path even when no two keys are equal (tests); depth0: see wave_introsort
-__device__ __forceinline__ void wave_sort_records(SortRec *a, SortRec *tmp, int n, int by_score, int lane, bool force_exact = false, int depth0 = 0) {
+// cap: records tmp holds (a power of two at or above n lets the bitonic pass run)
+__device__ __forceinline__ void wave_sort_records(SortRec *a, SortRec *tmp, int n, int by_score, int lane, bool force_exact = false, int depth0 = 0,
+                                                  int cap = 0) {
     __shared__ int l_sort_stk[120];
     if (n < 2) return;
     bool tie = true;
-    if (!force_exact) tie = by_score ? wave_rank_pass(a, tmp, n, lane, LtScore()) : wave_rank_pass(a, tmp, n, lane, LtEnd());
+    int P = 128;
+    while (P < n) P <<= 1;
+    if (!force_exact) {
+        if (n > 96 && P <= cap) tie = by_score ? wave_bitonic_pass(a, tmp, n, P, lane, LtScore()) : wave_bitonic_pass(a, tmp, n, P, lane, LtEnd());
+        else tie = by_score ? wave_rank_pass(a, tmp, n, lane, LtScore()) : wave_rank_pass(a, tmp, n, lane, LtEnd());
+    }
     __syncthreads();
     if (!tie) {
         for (int i = lane; i < n; i += 64) a[i] = tmp[i];

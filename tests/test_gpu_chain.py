@@ -383,6 +383,48 @@ def test_final_regions_patch_split_alignments(rep_toy):
     ix.set_contigs(c)
 
 
+def test_patch_alignments_of_reads_with_many_regions():
+    """The wave tier's patch alignment (the (h, e) row in LDS, 64 columns per step): 1000-base reads (the longest it takes) from a tandem
+    array of 50 copies of a 900-base unit, 0.5 % diverged — both halves align to many copies, dozens of regions per read reach
+    de-duplication — with a block of 20 mismatches in the middle (and, in two thirds of the reads, a 12-base deletion or a 9-base
+    insertion beside it) that the extension does not cross at zdrop = 20: every kept copy holds a pair of regions that mem_patch_reg
+    aligns and merges."""
+    rng = np.random.default_rng(72)
+    g = rng.integers(0, 4, size=150000, dtype=np.uint8)
+    unit = rng.integers(0, 4, size=900, dtype=np.uint8)
+    for c in range(50):
+        cp = unit.copy()
+        m = rng.random(900) < 0.005
+        cp[m] = (cp[m] + rng.integers(1, 4, size=int(m.sum()))) & 3
+        g[40000 + 900 * c:40000 + 900 * (c + 1)] = cp
+    idx = fmindex.build_fmindex(g)
+    ix = capi.Index.from_host(idx, 0)
+    reads = []
+    for i in range(60):
+        st = 40000 + 900 * int(rng.integers(0, 45)) + int(rng.integers(0, 150))
+        r = g[st:st + 1000].copy()
+        k = i % 3
+        if k == 0:
+            r[490:510] = (r[490:510] + 2) & 3
+        elif k == 1:
+            r = np.concatenate([r[:500], r[512:], g[st + 1000:st + 1012]])
+            r[470:490] = (r[470:490] + 2) & 3
+        else:
+            r = np.concatenate([r[:500], rng.integers(0, 4, size=9, dtype=np.uint8), r[500:991]])
+            r[470:490] = (r[470:490] + 2) & 3
+        pos = rng.integers(0, len(r), size=3)
+        r[pos] = (r[pos] + 1) & 3
+        reads.append(simulate.revcomp(r) if i % 2 else r)
+    b, want, got, ctx = _run(idx, ix, g, reads, zdrop=20)
+    wfin, wregs = _assert_final(b, ctx, want)
+    regs, reg_off, _ = b.extend_fetch()
+    fin, fin_off = b.dedup_fetch()
+    slots = np.diff(reg_off)
+    merged = np.array([int(((fin["n_comp_is_alt"][fin_off[r]:fin_off[r + 1]] & 0x3fffffff) > 1).sum()) for r in range(len(reads))])
+    assert ((merged >= 5) & (slots > 32)).sum() >= 20 and slots.max() > 100, (merged, slots)
+    b.close(); ix.close()
+
+
 def test_pestat_matches_oracle(rep_toy):
     """mem_pestat over the final regions of paired reads: per-pair selection and the sort on the device, the
     reference's percentile / mean / std arithmetic on the host — every field bit-equal to the oracle's."""

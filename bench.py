@@ -28,6 +28,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# counter-measured figures come from the newest committed PMC summary (profiles/rNN_pmc_summary.json, stamped with commit and workload)
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{n:02d}_pmc_summary.json") for n in range(9, 0, -1)) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r02_pmc_summary.json"))
 for p in (ROOT, os.path.join(ROOT, "bwa-mem-scale_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -166,7 +169,7 @@ def dry_run(args, rank, world):
 def load_pmc_summary(genome_mbp, reads):
     """counter-measured figures of the same workload from the committed PMC passes (separate rocprofv3 runs cannot be taken
     inside this one); the file is stamped with the commit and workload it was measured on"""
-    tfile = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    tfile = PMC_SUMMARY
     try:
         tj = json.load(open(tfile))
         if abs(tj.get("genome_mbp", 0) - genome_mbp) < 1 and tj.get("reads") == reads:
@@ -789,7 +792,7 @@ def main():
         # counter-measured figures of the same workload come from the committed PMC passes (separate rocprofv3 runs cannot
         # be taken inside this one); the file is stamped with the commit and workload it was measured on
         traffic = pmc = None
-        tfile = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        tfile = PMC_SUMMARY
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
@@ -874,7 +877,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_source": None if pmc is None else {"file": "profiles/r02_pmc_summary.json", "commit": pmc.get("commit"),
+                "traffic_source": None if pmc is None else {"file": os.path.relpath(PMC_SUMMARY, ROOT), "commit": pmc.get("commit"),
                                                             "frac_of_peak_measured_bytes": pmc.get("smem_round1_measured_frac")},
                 "bytes_per_launch": int(r1_bytes),
                 "launch_ms": round(r1_ms, 3),

@@ -457,11 +457,9 @@ static int alloc_smem_buffers(bwams_batch *b, int64_t max_smem) {
     return BWAMS_OK;
 }
 
-int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, int64_t max_smem,
-                       int64_t max_sa, bwams_batch_t **out) {
-    if (!ix || !out || max_reads <= 0 || max_bases <= 0) return BWAMS_ERR_ARG;
-    BWAMS_HIP(hipSetDevice(ix->device));
-    bwams_batch *b = new bwams_batch();
+// everything of bwams_batch_create that can fail half way: the caller destroys the handle (streams, events and the buffers made so
+// far) when this returns an error
+static int batch_create_fill(bwams_batch *b, bwams_index_t *ix, int64_t max_reads, int64_t max_bases, int64_t max_smem, int64_t max_sa) {
     b->idx = ix;
     b->max_reads = max_reads;
     b->max_bases = max_bases;
@@ -480,8 +478,7 @@ int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, 
     BWAMS_HIP(hipMalloc(&b->d_enc, (size_t)max_bases + 64));
     BWAMS_HIP(hipMalloc(&b->d_cum, (size_t)(max_reads + 1) * 8));
     BWAMS_HIP(hipMalloc(&b->d_skip, (size_t)max_reads));
-    int arc = alloc_smem_buffers(b, b->max_smem);
-    if (arc) { bwams_batch_destroy(b); return arc; }
+    if (int arc = alloc_smem_buffers(b, b->max_smem)) return arc;
     BWAMS_HIP(hipMalloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
     BWAMS_HIP(hipMalloc(&b->d_ctr, sizeof(DevCounters)));
     BWAMS_HIP(hipHostMalloc(&b->h_ctr, sizeof(DevCounters)));
@@ -495,6 +492,20 @@ int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, 
                             rocprim::plus<int64_t>(), b->stream);
     b->tmp_bytes = std::max(t1, t2);
     BWAMS_HIP(hipMalloc(&b->d_tmp, b->tmp_bytes));
+    return BWAMS_OK;
+}
+
+int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, int64_t max_smem,
+                       int64_t max_sa, bwams_batch_t **out) {
+    if (!ix || !out || max_reads <= 0 || max_bases <= 0) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(ix->device));
+    bwams_batch *b = new bwams_batch();
+    const int rc = batch_create_fill(b, ix, max_reads, max_bases, max_smem, max_sa);
+    if (rc) {                                   // (the message of the failing call stays in bwams_last_error)
+        b->idx = ix;
+        bwams_batch_destroy(b);
+        return rc;
+    }
     *out = b;
     return BWAMS_OK;
 }
@@ -502,7 +513,7 @@ int bwams_batch_create(bwams_index_t *ix, int64_t max_reads, int64_t max_bases, 
 int bwams_batch_destroy(bwams_batch_t *b) {
     if (!b) return BWAMS_OK;
     (void)hipSetDevice(b->idx->device);
-    (void)hipStreamSynchronize(b->stream);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
                     b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk, b->d_ert_redo};
     for (void *p : ptrs)
@@ -513,7 +524,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
         if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev_emf)
         if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(b->stream);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
     if (b->seed_aux) (void)hipStreamDestroy(b->seed_aux);
     if (b->seed_fork) (void)hipEventDestroy(b->seed_fork);
     if (b->seed_join) (void)hipEventDestroy(b->seed_join);
@@ -1249,10 +1260,15 @@ int bwams_emf_from_host(bwams_index_t *ix, int32_t seed_len, uint32_t seq_len, c
     bwams_emf *e = new bwams_emf();
     e->idx = ix;
     const size_t bs = (size_t)num_seed_entry * 16, bl = (size_t)(num_loc_entry ? num_loc_entry : 1) * 4;
-    BWAMS_HIP(hipMalloc(&e->d_seeds, bs));
-    BWAMS_HIP(hipMalloc(&e->d_loc, bl));
-    BWAMS_HIP(hipMemcpy(e->d_seeds, seed_table, bs, hipMemcpyHostToDevice));
-    if (num_loc_entry) BWAMS_HIP(hipMemcpy(e->d_loc, loc_table, (size_t)num_loc_entry * 4, hipMemcpyHostToDevice));
+    hipError_t he = hipMalloc(&e->d_seeds, bs);
+    if (he == hipSuccess) he = hipMalloc(&e->d_loc, bl);
+    if (he == hipSuccess) he = hipMemcpy(e->d_seeds, seed_table, bs, hipMemcpyHostToDevice);
+    if (he == hipSuccess && num_loc_entry) he = hipMemcpy(e->d_loc, loc_table, (size_t)num_loc_entry * 4, hipMemcpyHostToDevice);
+    if (he != hipSuccess) {                     // a table is tens of GiB: do not strand the half that was made
+        set_last_error(std::string("bwams_emf_from_host: ") + hipGetErrorString(he));
+        bwams_emf_close(e);
+        return he == hipErrorOutOfMemory ? BWAMS_ERR_NOMEM : BWAMS_ERR_DEVICE;
+    }
     e->t.seed_table = reinterpret_cast<const uint4 *>(e->d_seeds);
     e->t.loc_table = reinterpret_cast<const uint32_t *>(e->d_loc);
     e->t.ref = ix->fmi.ref;

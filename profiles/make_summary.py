@@ -19,7 +19,8 @@ def short(k):
     for pat, name in (("smem_search_kernel<true>", "smem_search_kernel<true> (SMEM round 1)"),
                       ("smem_search_kernel<false>", "smem_search_kernel<false> (SMEM round 2)"),
                       ("seed_strategy", "seed_strategy_kernel (SMEM round 3; runs beside round 2 on a stream of its own: the durations overlap, 3.3 ms alone)"), ("sa_lookup", "sa_lookup_kernel"),
-                      ("bsw_qwin_kernel", "bsw_qwin_kernel (banded SW, 8 tasks per wave; 5 query-length classes)"),
+                      ("bsw_pk_kernel", "bsw_pk_kernel (banded SW, 16 tasks per wave, packed 16-bit columns; 5 query-length classes)"),
+                      ("bsw_qwin_kernel", "bsw_qwin_kernel (banded SW, 8 tasks per wave, 32-bit: scoring the packed kernel does not take)"),
                       ("bsw_classify", "bsw_classify_kernel"), ("bsw_kernel", "bsw_kernel (one task per wave, LDS: queries > 191)"),
                       ("aln_dp_wave", "aln_dp_wave_kernel (mem_reg2aln: bands beyond 32 columns, wave per region)"), ("aln_dp_kernel", "aln_dp_kernel (mem_reg2aln: banded global alignment + traceback, lane per region)"),
                       ("sam_need", "sam_need_kernel (which regions the SAM text reads)"),
@@ -114,9 +115,9 @@ fetch, write = r1["FETCH_SIZE"] * 1024, r1["WRITE_SIZE"] * 1024
 alg = bench["roofline"]["bytes_per_launch"]
 with open(f"profiles/{rnd}_summary.md", "w") as f:
     f.write(f"# Round {rnd} — rocprofv3 summary (MI355X, gfx950, ROCm 7.2)\n\n")
-    f.write("Collected by `bash profiles/run_profiles_r02.sh <tag>` at the metric's configuration (synthetic genome of GRCh38's size, 6.4 G index rows): "
+    f.write("Collected by `bash profiles/run_profiles_{rnd}.sh <tag>` at the metric's configuration (synthetic genome of GRCh38's size, 6.4 G index rows): "
             "`rocprofv3 --kernel-trace --stats -- python3 bench.py "
-            "--steps 2 --warmup 1 --no-cpu-baseline --no-pe` plus one `--pmc` pass per counter group (never combined "
+            "--steps 2 --warmup 1 --no-cpu-baseline --no-pe --no-ert-leg --no-hard-genome` plus one `--pmc` pass per counter group (never combined "
             f"with tracing); summarised by `profiles/make_summary.py`.  Raw: `profiles/{rnd}_kernel_stats.csv`.\n\n")
     f.write("## Kernel time (library kernels; rocPRIM kernels omitted; the index-build kernels run once, untimed by bench.py)\n\n"
             f"{n_pass_trace} passes of the hot path per run (1 warm-up + 2 timed steps, and 3 text-to-text calls of `sam_side.fastq_to_sam`, which run "
@@ -201,9 +202,11 @@ json.dump({"genome_mbp": bench["config"]["genome_mbp"], "reads": bench["config"]
            "smem_round1_l2_hit_miss": [int(r1.get("TCC_HIT_sum", 0)), int(r1.get("TCC_MISS_sum", 0))],
            "bsw_valu_insts": int(sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / n_pass),
            "bsw_salu_insts": int(sum(c.get("SQ_INSTS_SALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / n_pass),
+           "bsw_valu_per_cell": round(sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / n_pass / max(bench["extension"]["dp_cells"], 1), 3),
            "ert_walk_hbm_bytes_per_launch": int(2 * E["FETCH_SIZE"] * 1024 + E.get("WRITE_SIZE", 0) * 1024) if "FETCH_SIZE" in E else None,
+           "ert_walk_fetch_write_bytes": [int(E["FETCH_SIZE"] * 1024), int(E.get("WRITE_SIZE", 0) * 1024)] if "FETCH_SIZE" in E else None,
            "ert_walk_valu_salu_vmem_insts": [int(E.get("SQ_INSTS_VALU", 0)), int(E.get("SQ_INSTS_SALU", 0)), int(E.get("SQ_INSTS_VMEM_RD", 0))] if E else None,
            "commit": os.popen("git rev-parse --short HEAD").read().strip(),
-           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_* (separate passes), profiles/run_profiles_r02.sh; bsw_* = wave-instructions per step"},
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_* (separate passes), profiles/run_profiles_" + rnd + ".sh; bsw_* = wave-instructions per step"},
           open(f"profiles/{rnd}_pmc_summary.json", "w"), indent=1)
 print(open(f"profiles/{rnd}_summary.md").read()[:2500])

@@ -377,6 +377,8 @@ int bwams_ert_open(bwams_index_t *idx, const char *prefix, int32_t read_len, bwa
 /* Builds the two tables on the GPU from the resident FM-index (replaces buildKmerTrees, src/ertindex.cpp:773-943):
  * the same bytes the reference writes for kmerSize = kmer_size, xmerSize = xmer_size, readLength = read_len and
  * HIT_THRESHOLD = hit_threshold (15, 4, READ_LEN, 256 in src/macro.h).  The index must hold its .0123 reference. */
+/* BWAMS_ERR_UNSUPPORTED for a text the format cannot hold (and the reference's writer does not finish on): a string of read_len bases
+ * with 65536 occurrences or more (16-bit leaf counts, ertindex.cpp:336-352), a k-mer whose tree reaches 64 MiB (26-bit pointers, :452) */
 int bwams_ert_build(bwams_index_t *idx, int32_t kmer_size, int32_t xmer_size, int32_t read_len, int32_t hit_threshold,
                     bwams_ert_t **out);
 /* geometry, tree bytes and the build's kernel times (sizes, scan + allocation, bytes; 0 when loaded) */
@@ -393,7 +395,14 @@ int64_t bwams_ert_bytes(const bwams_ert_t *ert);
  * (rid, m, n) order with s = number of hits (k and l are 0: there is no BWT interval), and the sampled hit
  * positions where the FM path puts the suffix-array coordinates.  BWAMS_ERR_UNSUPPORTED when
  * min_seed_len < kmer_size + xmer_size, when split_width + 1 or max_mem_intv exceed 20 (the trees store hit counts
- * below 20 only, src/ertindex.cpp:455-461) or when a read is longer than read_len / 255 bases. */
+ * below 20 only, src/ertindex.cpp:455-461) or when a read is longer than read_len / 255 bases.
+ *
+ * Against mem_kernel1_core_ert (bwamem.cpp:1122-1193; restated function by function in oracle/ert_walk_oracle.c): the same MEMs and,
+ * per MEM, the same sampled hit coordinates — also for MEMs found by the backward walk and for hits > max_occ, because the
+ * reference re-gathers those hits in forward (= suffix-array) order (ertseeding.cpp:644-648) — with ONE exception: a read whose
+ * placement at a hit would cross the junction of the forward and the reverse-complement strand of the text.  There get_seq
+ * (ertseeding.cpp:455-472) returns nothing and the reference emits matches that are not maximal; this call follows FM-index
+ * seeding (the true SMEMs).  Seeds that bridge the junction are dropped by bns_intv2rid in chaining either way. */
 int bwams_seed_run_ert(bwams_batch_t *b, bwams_ert_t *ert, const bwams_seed_opt_t *opt, int with_sa);
 
 /* ------------------------------------------------------------------------- *

@@ -72,8 +72,8 @@ struct ChainState {
     bwams_mem_opt_t opt{};
     hipEvent_t ev[16] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 selection (first round each), 10-11 all rounds
     bool ev_ok = false;
-    hipStream_t aux[5] = {};      // the chaining tiers run concurrently
-    hipEvent_t fork = nullptr, join[5] = {};
+    hipStream_t aux[7] = {};      // the chaining tiers run concurrently
+    hipEvent_t fork = nullptr, join[7] = {};
 };
 
 void chain_state_free(ChainState *s) {
@@ -394,7 +394,7 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
 
     BWAMS_HIP(hipEventRecord(s->ev[0], st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_redo, 0, 2 * sizeof(unsigned long long), st));
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 21 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[7], chain_ticket[7], heavy_ticket, heavy_tickets[3]
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 25 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[9], chain_ticket[9], heavy_ticket, heavy_tickets[3]
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all
     if ((sv.one_smem_quirk ? sv.n_smem <= 1 : sv.n_smem <= 0) || n_sa == 0) {

@@ -65,6 +65,9 @@ static_assert(sizeof(ChainRec) == 48, "chain record layout");
 // (position, chain id), 12 B per chain
 __host__ __device__ constexpr size_t lds_bytes(int K) { return (size_t)K * (sizeof(ChainRec) + 12) + 64; }
 constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL1 = 850, kClassL = 1700;      // seeds per read: 7.7, 15, 31, 51, 102 KB of LDS
+// two classes in between (round 3): a read holds its wavefront for milliseconds, so what a class costs is reads / (waves a CU's LDS admits):
+// (512, 665] at 40 KB = four per CU instead of three, (850, 1275] at 76.6 KB = two instead of one
+constexpr int kClassM2 = 665, kClassL2 = 1275;
 static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
 // class XL: reads beyond class L keep only the ordered array (12 B per chain) in LDS, the chain records in HBM
 constexpr int kClassXL = 4096;       // sarr_lower finds the 64-key chunk with one ballot: at most 64 chunks
@@ -568,6 +571,8 @@ __global__ void chain_count_kernel(ChainArgs A, uint32_t *keys, uint32_t *vals) 
         if (cnt > kClassL1) atomicAdd(&A.ctr->chain_class[1], 1ull);
         if (cnt > kClassL) atomicAdd(&A.ctr->chain_class[0], 1ull);
         if (cnt > kClassXL) atomicAdd(&A.ctr->chain_class[6], 1ull);      // [0, c[6]) beyond XL, [c[6], c[0]) XL
+        if (cnt > kClassL2) atomicAdd(&A.ctr->chain_class[7], 1ull);      // [c[0], c[7]) class L, [c[7], c[1]) class L2
+        if (cnt > kClassM2) atomicAdd(&A.ctr->chain_class[8], 1ull);      // [c[1], c[8]) class L1, [c[8], c[2]) class M2
     }
 }
 
@@ -1079,7 +1084,7 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes(kClassL)) != hipSuccess) return -1;
     if (hipEventRecord(fork, st) != hipSuccess) return -1;
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 7; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
     // heaviest first: reads beyond the LDS budget (HBM state) and classes L, L1, then M, M1, S, then the lane tier
     // (the reads beyond a CU's LDS keep their state in HBM: every step is a dependent L2 / HBM access, so they get many
@@ -1088,15 +1093,17 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     // were the stage's long pole; with the ordered array in LDS only their chain records are in HBM)
     chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, 0, aux[0]>>>(A, nullptr, cls + 6, tk + 0, 0);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes_xl(kClassXL), aux[0]>>>(A, cls + 6, cls + 0, tk + 6, -kClassXL);
-    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[1]>>>(A, cls + 0, cls + 1, tk + 1, kClassL);
-    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassL1), aux[2]>>>(A, cls + 1, cls + 2, tk + 2, kClassL1);
+    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[1]>>>(A, cls + 0, cls + 7, tk + 1, kClassL);
+    chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, lds_bytes(kClassL2), aux[5]>>>(A, cls + 7, cls + 1, tk + 7, kClassL2);
+    chain_wave_kernel<<<(unsigned)(cu_count * 3), 64, lds_bytes(kClassL1), aux[2]>>>(A, cls + 1, cls + 8, tk + 2, kClassL1);
+    chain_wave_kernel<<<(unsigned)(cu_count * 4), 64, lds_bytes(kClassM2), aux[6]>>>(A, cls + 8, cls + 2, tk + 8, kClassM2);
     chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
     chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 4, cls + 5, tk + 5, kClassS);
     chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[4]>>>(A, n_seeds);
     // class M behind the lane tier (5 ms) rather than behind class L or S (kernel trace at GRCh38 size: L 8.9-10.3 ms + M 4.3-6.7 was
     // the stage's longest stream; S 7.8, L1 7.7 + M1 2.9, XL 0.9 + 7.2)
     chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[4]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 7; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;
     }

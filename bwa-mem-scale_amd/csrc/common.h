@@ -80,8 +80,8 @@ struct DevCounters {
     unsigned long long chain_overflow;   // chaining: B-tree node region exhausted (never expected)
     unsigned long long chain_longread;   // chaining: reads long enough for mem_flt_chained_seeds to re-score seeds
     unsigned long long n_heavy;          // chaining: reads handed to the wave-per-read filter kernel
-    unsigned long long chain_class[7];   // chaining: reads with more seeds than the L, L1, M, M1, S, lane-tier and XL limits
-    unsigned long long chain_ticket[7];  // chaining: work cursors of the wave kernels
+    unsigned long long chain_class[9];   // chaining: reads with more seeds than the L, L1, M, M1, S, lane-tier, XL, L2 and M2 limits
+    unsigned long long chain_ticket[9];  // chaining: work cursors of the wave kernels
     unsigned long long heavy_ticket;     // (unused)
     unsigned long long heavy_tickets[3]; // chaining: work cursors of chain_heavy_kernel's size classes
     unsigned long long n_retry;          // extension: tasks queued for the next band width

@@ -44,8 +44,11 @@ def test_random_configuration(seed):
     kw, bmis, sh = _config(1000 + seed)
     capi.lib()
     L = sh["read_len"]
-    g = simulate.make_genome(sh["genome"], seed=seed, repeat_frac=sh["repeat_frac"], repeat_len=sh["repeat_len"],
-                             n_families=sh["n_families"])
+    if seed % 6 == 5:       # every sixth configuration on the harder genome shape (tandem arrays, microsatellites, poly-A, exact duplications)
+        g = simulate.make_genome(sh["genome"], seed=seed, profile="grch38_like")
+    else:
+        g = simulate.make_genome(sh["genome"], seed=seed, repeat_frac=sh["repeat_frac"], repeat_len=sh["repeat_len"],
+                                 n_families=sh["n_families"])
     idx = fmindex.build_fmindex(g)
     ix = capi.Index.from_host(idx, 0)
     l_pac = len(g)

@@ -4,10 +4,11 @@
 //
 // Sequential per read (sort by end, pairwise redundancy / patch tests against the regions just upstream, sort
 // by score, drop identical hits), a handful of regions per read: one lane per read for reads with few regions,
-// one wavefront per read (sort records in LDS, lane 0 drives) for the others.  Both sorts are ksort.h's
-// introsort — unstable, so reproduced operation by operation (see chain.hip) on 24-byte sort records.
-// The banded global alignment of a patch candidate runs in the lane (row-by-row, (h, e) row in a per-lane
-// HBM strip): rare, and a few hundred microseconds for 150-base reads.
+// one wavefront per read for the others (sort records in LDS; the sorts, the pairwise pass — 64 upstream regions at a
+// time, events in the serial order — and the patch alignment all run across the lanes).  Both sorts are ksort.h's
+// introsort — unstable, so reproduced operation by operation (see chain.hip) on 24-byte sort records whenever two keys
+// compare equal.  The banded global alignment of a patch candidate: in the lane tier row by row on the lane ((h, e) row
+// in a per-lane HBM strip: rare), in the wave tier 64 columns per step with the row in LDS (global_score_wave).
 #include "common.h"
 #include "chain_kernels.h"
 #include "wave_ops.h"
@@ -325,11 +326,9 @@ __global__ __launch_bounds__(64) void dedup_kernel(DedupArgs A, int64_t n_lanes)
     }
 }
 
-// One wavefront per read with many regions.  The loops that are plain maps or compactions run across the
-// lanes; the two sorts run on lane 0 over LDS records; the pairwise pass (sequential by nature) runs on
-// lane 0 but rejects the common case — the region just upstream is on another sequence or further than
-// max_chain_gap away — from LDS copies of (rid, rb, re), which that pass never changes for regions it has
-// not reached yet.
+// One wavefront per read with many regions.  Maps, compactions and sorts run across the lanes; the pairwise pass
+// (sequential by nature) evaluates 64 upstream regions at a time against the current one from LDS copies of the fields
+// its tests read and takes the events one by one (see the kernel).
 // Fields that lane 0 rewrites during the pairwise pass are re-read by the other lanes afterwards: those loads go
 // past the vector L1 (which may still hold the line from the first pass) with agent-scope atomic loads.
 __device__ __forceinline__ void load_qbqe(const bwams_alnreg_t *p, int &qb, int &qe) {

@@ -82,6 +82,25 @@ def test_walk_equals_profile_formulation_and_fm(kmer, xmer, thr, n_bases, seed):
     assert seen[0] > 100 and seen[1] > 1000 and seen[2] > 100 and seen[4] > 100
 
 
+def test_walk_equals_fm_on_the_harder_genome_shape():
+    """The same three-way agreement on simulate.make_genome(profile="grch38_like") — a tandem array of higher-order repeats,
+    microsatellites, poly-A runs, exact segmental duplications — with reads drawn from all of it."""
+    g = simulate.make_genome(300000, seed=12, profile="grch38_like")
+    idx, text, o, e = _make(g, 8, 2, 16)
+    enc, cum = simulate.flatten_reads(_reads(g, 1500, 21, margin=400))
+    for kw in ({}, {"max_occ": 7, "split_width": 15}):
+        oo = _opt(**kw)
+        got, coord, off, cls, flags = e.walk_collect(enc, cum, oo)
+        assert flags == 0
+        want, wcoord, woff = e.collect(enc, cum, oo)
+        assert _same(got, want) and np.array_equal(off, woff) and np.array_equal(coord, wcoord), kw
+        fm = o.collect_smem(enc, cum, oo)
+        fcoord, foff = o.sa_lookup(fm, oo.max_occ)
+        assert _same(got, fm) and np.array_equal(off, foff), kw
+        assert np.all((coord == fcoord) | ((fcoord == 0) & (coord < 128))), kw
+        assert int(got["s"].max()) >= 10 and (cls & 2).any()           # seeds in the repeats, backward MEMs re-gathered forward
+
+
 def _heavy_genome(n_bases, seed):
     """a family of 900 near-identical 300-bp copies (seeds with more than 500 hits), a 171-bp tandem array, a poly-A run"""
     rng = np.random.default_rng(seed)

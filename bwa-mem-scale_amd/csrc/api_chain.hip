@@ -66,6 +66,8 @@ struct ChainState {
     // extension
     DevBuf regs, srt, rmax, cnt, ewide, eoffs, state, kreg, cur, lim;
     DevBuf lpairs, lref, lqer, rpairs, rref, rqer, retry;
+    DevBuf lsrc, rsrc;           // in-place extension (bwams_extend_run): per task the start offsets {query, target} instead of copied bytes
+    bool tasks_inplace = false;
     int64_t n_left = 0, n_right = 0, lref_b = 0, lqer_b = 0, rref_b = 0, rqer_b = 0;
     int64_t n_retry_left = 0, n_retry_right = 0, n_rounds = 0;
     bool built = false, ext_done = false;
@@ -78,7 +80,7 @@ struct ChainState {
 
 void chain_state_free(ChainState *s) {
     if (!s) return;
-    DevBuf *all[] = {&s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
+    DevBuf *all[] = {&s->lsrc, &s->rsrc, &s->s_next, &s->s_ql, &s->crec, &s->flt, &s->f_rec, &s->f_first, &s->f_kept, &s->f_sel,
                      &s->nodes, &s->n_kept, &s->n_kept_seeds, &s->n_chn, &s->heavy, &s->redo, &s->slice, &s->okeys, &s->okeys2, &s->ovals, &s->ovals2, &s->read_base, &s->frac, &s->wide,
                      &s->chain_off, &s->chains, &s->seeds, &s->seeds2, &s->sw_qb, &s->sw_rb, &s->sw_read, &s->sw_newn, &s->sw_res, &s->dd_regs, &s->dd_ord, &s->dd_srt, &s->dd_eh,
                      &s->dd_nout, &s->dd_wide, &s->dd_off, &s->dd_out, &s->dd_light, &s->pe_keys, &s->pe_keys2, &s->pr_na, &s->pr_wide, &s->pr_offs, &s->pr_anchor, &s->pr_slot, &s->pr_task, &s->pr_trb, &s->pr_tl1, &s->pr_twide, &s->pr_toffs,
@@ -575,7 +577,7 @@ static int ext_plan(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, i
 }
 
 // build the task lists of the seeds requested this round
-static int ext_build_round(bwams_batch *b, ChainState *s, const ExtArgs &A, int64_t tot[6]) {
+static int ext_build_round(bwams_batch *b, ChainState *s, const ExtArgs &A, int64_t tot[6], bool inplace) {
     hipStream_t st = b->stream;
     const int64_t N = s->n_seeds, N1 = N + 1;
     launch_ext_widen(A, s->ewide.as<int64_t>(), st);
@@ -585,7 +587,7 @@ static int ext_build_round(bwams_batch *b, ChainState *s, const ExtArgs &A, int6
         BWAMS_HIP(hipMemcpyAsync(&tot[r], s->eoffs.as<int64_t>() + r * N1 + N, 8, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     for (int r : {1, 2, 4, 5})
-        if (tot[r] >= ((int64_t)1 << 31)) {
+        if (!inplace && tot[r] >= ((int64_t)1 << 31)) {
             set_last_error("extension task buffers exceed the 31-bit offsets of SeqPair; use smaller chunks");
             return BWAMS_ERR_CAPACITY;
         }
@@ -595,11 +597,17 @@ static int ext_build_round(bwams_batch *b, ChainState *s, const ExtArgs &A, int6
     BWAMS_HIP(s->rpairs.ensure((size_t)(tot[3] + 1) * sizeof(bwams_seqpair_t)));
     const int64_t mx = tot[0] > tot[3] ? tot[0] : tot[3];
     BWAMS_HIP(s->retry.ensure((size_t)(mx + 1) * sizeof(bwams_seqpair_t)));
-    BWAMS_HIP(s->lqer.ensure((size_t)tot[1] + 64)); BWAMS_HIP(s->lref.ensure((size_t)tot[2] + 64));
-    BWAMS_HIP(s->rqer.ensure((size_t)tot[4] + 64)); BWAMS_HIP(s->rref.ensure((size_t)tot[5] + 64));
+    s->tasks_inplace = inplace;
+    if (inplace) {               // no bytes are copied: 16 bytes of offsets per task
+        BWAMS_HIP(s->lsrc.ensure((size_t)(tot[0] + 1) * 16)); BWAMS_HIP(s->rsrc.ensure((size_t)(tot[3] + 1) * 16));
+    } else {
+        BWAMS_HIP(s->lqer.ensure((size_t)tot[1] + 64)); BWAMS_HIP(s->lref.ensure((size_t)tot[2] + 64));
+        BWAMS_HIP(s->rqer.ensure((size_t)tot[4] + 64)); BWAMS_HIP(s->rref.ensure((size_t)tot[5] + 64));
+    }
     if (tot[0] + tot[3] > 0)
         launch_ext_build(A, s->eoffs.as<int64_t>(), s->lpairs.as<bwams_seqpair_t>(), s->lref.as<uint8_t>(), s->lqer.as<uint8_t>(),
-                         s->rpairs.as<bwams_seqpair_t>(), s->rref.as<uint8_t>(), s->rqer.as<uint8_t>(), b->cu_count, st);
+                         s->rpairs.as<bwams_seqpair_t>(), s->rref.as<uint8_t>(), s->rqer.as<uint8_t>(),
+                         inplace ? s->lsrc.as<int64_t>() : nullptr, inplace ? s->rsrc.as<int64_t>() : nullptr, b->cu_count, st);
     return BWAMS_OK;
 }
 
@@ -622,7 +630,7 @@ int bwams_extend_build(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_
     BWAMS_HIP(hipEventRecord(s->ev[2], st));
     if ((rc = ext_plan(b, s, opt, 1, &A))) return rc;           // every seed, as the reference builds them
     int64_t tot[6];
-    if ((rc = ext_build_round(b, s, A, tot))) return rc;
+    if ((rc = ext_build_round(b, s, A, tot, false))) return rc;
     BWAMS_HIP(hipEventRecord(s->ev[3], st));
     BWAMS_HIP(hipGetLastError());
     s->built = true;
@@ -636,8 +644,12 @@ int bwams_extend_build(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_
 static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, int64_t *n_retry_out) {
     hipStream_t st = b->stream;
     bwams_seqpair_t *pairs = right ? s->rpairs.as<bwams_seqpair_t>() : s->lpairs.as<bwams_seqpair_t>();
-    const uint8_t *ref = right ? s->rref.as<uint8_t>() : s->lref.as<uint8_t>();
-    const uint8_t *qer = right ? s->rqer.as<uint8_t>() : s->lqer.as<uint8_t>();
+    // in place: the sequences are read where they lie (the chunk's base codes, the resident .0123 text), backwards on the left side
+    const bool ip = s->tasks_inplace;
+    const uint8_t *ref = ip ? A.ref : (right ? s->rref.as<uint8_t>() : s->lref.as<uint8_t>());
+    const uint8_t *qer = ip ? A.enc : (right ? s->rqer.as<uint8_t>() : s->lqer.as<uint8_t>());
+    const int64_t *src = ip ? (right ? s->rsrc.as<int64_t>() : s->lsrc.as<int64_t>()) : nullptr;
+    const int dir = ip && !right ? -1 : 1;
     const int64_t n = right ? s->n_right : s->n_left;
     SwParams prm;
     sw_params(A.opt, right ? A.opt.pen_clip3 : A.opt.pen_clip5, &prm);
@@ -646,7 +658,7 @@ static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, 
     unsigned long long *d_nretry = &b->d_ctr->n_retry;
     BWAMS_HIP(hipMemsetAsync(d_nretry, 0, sizeof(unsigned long long), st));
     if (int erc = bsw_list_ensure(b, n)) return erc;
-    if (int lrc = launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st, b->d_bsw_list, s->aux, s->fork, s->join)) {
+    if (int lrc = launch_bsw(pairs, n, ref, qer, A.opt.w, prm, qmax, b->d_ctr, b->cu_count, st, b->d_bsw_list, s->aux, s->fork, s->join, src, dir)) {
         set_last_error(lrc == -2 ? "banded SW: a query longer than ~18000 bases does not fit the LDS kernel" : "banded SW: stream fork/join failed");
         return lrc == -2 ? BWAMS_ERR_UNSUPPORTED : BWAMS_ERR_DEVICE;
     }
@@ -655,7 +667,7 @@ static int run_side(bwams_batch *b, ChainState *s, const ExtArgs &A, int right, 
     BWAMS_HIP(hipMemcpyAsync(&nr, d_nretry, sizeof nr, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     if (nr) {
-        if (launch_bsw(s->retry.as<bwams_seqpair_t>(), (int64_t)nr, ref, qer, A.opt.w << 1, prm, qmax, b->d_ctr, b->cu_count, st, b->d_bsw_list, s->aux, s->fork, s->join)) return BWAMS_ERR_DEVICE;
+        if (launch_bsw(s->retry.as<bwams_seqpair_t>(), (int64_t)nr, ref, qer, A.opt.w << 1, prm, qmax, b->d_ctr, b->cu_count, st, b->d_bsw_list, s->aux, s->fork, s->join, src, dir)) return BWAMS_ERR_DEVICE;
         launch_ext_post(A, right, s->retry.as<bwams_seqpair_t>(), (int64_t)nr, A.opt.w << 1, 1, nullptr, d_nretry, st);
     }
     *n_retry_out += (int64_t)nr;
@@ -679,6 +691,7 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
     int kMaxRounds = 6;
     if (const char *e = getenv("BWAMS_EXT_MAX_ROUNDS")) kMaxRounds = atoi(e) > 0 ? atoi(e) : 1;    // test knob: force the extend-the-rest fallback
     const bool adaptive_off = getenv("BWAMS_EXT_ALL_ROUNDS") != nullptr;                             // test knob: never cut the rounds short
+    const bool inplace_on = !(getenv("BWAMS_EXT_INPLACE") && atoi(getenv("BWAMS_EXT_INPLACE")) == 0);   // A-B knob: 0 = copy the tasks' bytes into flat buffers
     ChainState *s = b->chain;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
@@ -693,7 +706,7 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
     int round = 0;
     for (;; ++round) {
         int64_t tot[6];
-        if ((rc = ext_build_round(b, s, A, tot))) return rc;
+        if ((rc = ext_build_round(b, s, A, tot, inplace_on))) return rc;
         if (round == 0) { BWAMS_HIP(hipEventRecord(s->ev[3], st)); BWAMS_HIP(hipEventRecord(s->ev[4], st)); }
         tot_left += tot[0]; tot_right += tot[3];
         if ((rc = run_side(b, s, A, 0, &s->n_retry_left))) return rc;
@@ -1880,6 +1893,10 @@ int bwams_extend_tasks_fetch(bwams_batch_t *b, int32_t side, bwams_seqpair_t *pa
                              int64_t *qer_bytes) {
     if (!b || !b->chain || !(b->chain->built || b->chain->ext_done) || (side != 0 && side != 1)) {
         set_last_error("bwams_extend_tasks_fetch: no task lists on the device");
+        return BWAMS_ERR_ARG;
+    }
+    if (b->chain->tasks_inplace) {
+        set_last_error("bwams_extend_tasks_fetch: bwams_extend_run extends in place and builds no flat task buffers; bwams_extend_build does");
         return BWAMS_ERR_ARG;
     }
     ChainState *s = b->chain;

@@ -46,7 +46,7 @@ __device__ __forceinline__ int wave_max(int v) {
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
     bwams_seqpair_t *__restrict__ pairs, int64_t n, const uint8_t *__restrict__ ref,
     const uint8_t *__restrict__ qer, int w0, SwParams prm, int qmax, int qlo, DevCounters *ctr, unsigned long long *head,
-    const int32_t *__restrict__ list, const unsigned long long *n_list) {
+    const int32_t *__restrict__ list, const unsigned long long *n_list, const int64_t *__restrict__ src, int dir) {
     extern __shared__ __align__(16) unsigned char lds[];
     n = (int64_t)*n_list;                              // this kernel walks the list of tasks left to the one-task-per-wave kernels
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -70,8 +70,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
         const bwams_seqpair_t sp = pairs[cur];
         const int qlen = sp.len2, tlen = sp.len1, h0 = sp.h0;
         if (qlen <= qlo) continue;                        // handled by a register-resident variant
-        const uint8_t *tq = qer + sp.idq;
-        const uint8_t *tr = ref + sp.idr;
+        // src != nullptr: in place — the task's sequences start at src[2 id] (query) / src[2 id + 1] (target) and run in direction dir
+        const uint8_t *tq = qer + (src ? src[2 * (int64_t)sp.id] : (int64_t)sp.idq);
+        const uint8_t *tr = ref + (src ? src[2 * (int64_t)sp.id + 1] : (int64_t)sp.idr);
 
         // row -1 of the DP and the query, each column on its owner lane
         for (int j = lane; j <= qlen; j += 64) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
                 h = h > 0 ? h : 0;
             }
             eh[j] = make_int2(h, 0);
-            if (j < qlen) qs[j] = tq[j];
+            if (j < qlen) qs[j] = tq[j * dir];
         }
 
         // clamp the band to the longest gap the score can pay for (bandedSWA.cpp:147-156)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_kernel(
         int tb_next = tlen > 0 ? tr[0] : 4;
         for (int i = 0; i < tlen; ++i) {
             const int tb = tb_next;
-            if (i + 1 < tlen) tb_next = tr[i + 1];           // overlap the next row's load with this row
+            if (i + 1 < tlen) tb_next = tr[(i + 1) * dir];           // overlap the next row's load with this row
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
@@ -353,7 +354,7 @@ template <int LPT, int kWin>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
     bwams_seqpair_t *__restrict__ pairs, const int32_t *__restrict__ list, const unsigned long long *n_list_p,
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, int w0, SwParams prm, DevCounters *ctr, unsigned long long *head,
-    int cols) {
+    int cols, const int64_t *__restrict__ src, int dir) {
     extern __shared__ uint32_t qwin_lds[];                         // [wave][task slot][cols]: H (14 bits) | E << 14 | query base << 28
     constexpr int TPW = 64 / LPT;                                  // tasks per wavefront
     const int lane = threadIdx.x & 63, g = lane & (LPT - 1), q = lane / LPT;
@@ -395,12 +396,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
                 cur = list[pid + rank];
                 const bwams_seqpair_t sp = pairs[cur];
                 qlen = sp.len2; tlen = sp.len1; h0 = sp.h0;
-                const uint8_t *tq = qer + sp.idq;
-                tr = ref + sp.idr;
+                const uint8_t *tq = qer + (src ? src[2 * (int64_t)sp.id] : (int64_t)sp.idq);
+                tr = ref + (src ? src[2 * (int64_t)sp.id + 1] : (int64_t)sp.idr);
                 for (int c = g; c <= qlen; c += LPT) {            // row -1 of the DP and the query, LPT columns at a time
                     int h = h0;
                     if (c >= 1) { h = h0 - oe_ins - (c - 1) * e_ins; h = h > 0 ? h : 0; }
-                    uint32_t qb = c < qlen ? (uint32_t)tq[c] : 4u;
+                    uint32_t qb = c < qlen ? (uint32_t)tq[c * dir] : 4u;
                     qb = qb > 4u ? 4u : qb;
                     row_eh[c] = (uint32_t)h | (qb << 28);
                 }
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void bsw_qwin_kernel(
         // ---- one row of every live task
         int tb = tb_next;
         tb = tb > 4 ? 4 : tb;
-        if (alive && i + 1 < tlen) tb_next = tr[i + 1];
+        if (alive && i + 1 < tlen) tb_next = tr[(i + 1) * dir];
         const uint2 pp = pk_tab[tb];
         const int pkt = (int)pp.x, pnt = (int)pp.y;
         if (beg < i - w) beg = i - w;
@@ -623,7 +624,7 @@ __host__ __device__ __forceinline__ bool bsw_pk_eligible(const SwParams &prm) {
 __global__ __launch_bounds__(kPkWaves * 64) void bsw_pk_kernel(
     bwams_seqpair_t *__restrict__ pairs, const int32_t *__restrict__ list, const unsigned long long *n_list_p,
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, int w0, SwParams prm, DevCounters *ctr, unsigned long long *head,
-    int cols) {
+    int cols, const int64_t *__restrict__ src, int dir) {
     // 16 words of score rows, then [wave][task slot][H pairs | E pairs | selector bytes]: 4 + 4 + 2 bytes per pair.  Everything is carved out
     // of the dynamic region: a static __shared__ array in front of it would shift its base off 16 bytes (16-byte DS accesses
     // off their alignment are replayed at 64 cycles each)
@@ -682,8 +683,8 @@ __global__ __launch_bounds__(kPkWaves * 64) void bsw_pk_kernel(
                 cur = list[pid + rank];
                 const bwams_seqpair_t sp = pairs[cur];
                 qlen = sp.len2; tlen = sp.len1; h0 = sp.h0;
-                const uint8_t *tq = qer + sp.idq;
-                tr = ref + sp.idr;
+                const uint8_t *tq = qer + (src ? src[2 * (int64_t)sp.id] : (int64_t)sp.idq);
+                tr = ref + (src ? src[2 * (int64_t)sp.id + 1] : (int64_t)sp.idr);
                 start_row = true;
                 for (int p = g; p <= (qlen >> 1); p += LPT) {      // row -1 of the DP and the query, a pair of columns per lane and step
                     uint32_t hh = 0, ss = 0;
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(kPkWaves * 64) void bsw_pk_kernel(
                         const int c = 2 * p + k;
                         int h = 0;
                         if (c <= qlen) { h = h0; if (c >= 1) { h = h0 - oe_ins - (c - 1) * e_ins; h = h > 0 ? h : 0; } }
-                        uint32_t qb = c < qlen ? (uint32_t)tq[c] : 4u;
+                        uint32_t qb = c < qlen ? (uint32_t)tq[c * dir] : 4u;
                         const uint32_t sel = qb < 4u ? 2u * qb : 0x0du;
                         hh |= (uint32_t)h << (16 * k);
                         ss |= sel << (8 * k);
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(kPkWaves * 64) void bsw_pk_kernel(
         if (alive && start_row) {                                     // row prologue
             int tb = tb_next;
             tb = tb > 4 ? 4 : tb;
-            if (i + 1 < tlen) tb_next = tr[i + 1];
+            if (i + 1 < tlen) tb_next = tr[(i + 1) * dir];
             tt = pk_tab16[tb];
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
@@ -925,7 +926,8 @@ __global__ void bsw_reset_kernel(DevCounters *ctr) {
 // (queries beyond 191 bases, scores beyond 2^14), the one-task-per-wave LDS kernel.  Every launch has its own ticket counter; with auxiliary
 // streams they run concurrently, the classes of the longest queries first.  `list` holds kNumBswClass * n task indices.
 int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w, const SwParams &prm, int qmax,
-               DevCounters *ctr, int cu_count, hipStream_t st, int32_t *list, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join) {
+               DevCounters *ctr, int cu_count, hipStream_t st, int32_t *list, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join,
+               const int64_t *src, int dir) {
     bsw_reset_kernel<<<1, 1, 0, st>>>(ctr);
     if (n <= 0) return 0;
     bsw_classify_kernel<<<(unsigned)((n + 1023) / 1024), 1024, 0, st>>>(pairs, n, prm.max_sc, list, ctr->bsw_cls_cnt);
@@ -956,13 +958,13 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
         static const int kCols[5] = {32, 64, 96, 144, 192};
         const unsigned Bp = (unsigned)((int64_t)B * kWavesPerBlock / kPkWaves);
         for (int c = 4; c >= 0; --c)
-            bsw_pk_kernel<<<Bp, kPkWaves * 64, pk_lds(kCols[c]), q[c]>>>(pairs, list + (int64_t)c * n, cnt + c, ref, qer, w, prm, ctr, hd + c, kCols[c]);
+            bsw_pk_kernel<<<Bp, kPkWaves * 64, pk_lds(kCols[c]), q[c]>>>(pairs, list + (int64_t)c * n, cnt + c, ref, qer, w, prm, ctr, hd + c, kCols[c], src, dir);
     } else {
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4, q[4]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 4, q[3]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 96 * 4, q[2]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 64 * 4, q[1]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64);
-    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 32 * 4, q[0]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 192 * 4, q[4]>>>(pairs, list + 4 * n, cnt + 4, ref, qer, w, prm, ctr, hd + 4, 192, src, dir);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 144 * 4, q[3]>>>(pairs, list + 3 * n, cnt + 3, ref, qer, w, prm, ctr, hd + 3, 144, src, dir);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 96 * 4, q[2]>>>(pairs, list + 2 * n, cnt + 2, ref, qer, w, prm, ctr, hd + 2, 96, src, dir);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 64 * 4, q[1]>>>(pairs, list + 1 * n, cnt + 1, ref, qer, w, prm, ctr, hd + 1, 64, src, dir);
+    bsw_qwin_kernel<kBswLpt, kBswWin><<<B, T, (size_t)kWavesPerBlock * (64 / kBswLpt) * 32 * 4, q[0]>>>(pairs, list + 0 * n, cnt + 0, ref, qer, w, prm, ctr, hd + 0, 32, src, dir);
     }
     {
         // what neither packed form can take: (h, e) row + query of one task per wave in LDS, fewer waves per block for very long queries.
@@ -978,7 +980,7 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
         int64_t lblocks = (n + waves - 1) / waves;
         const int64_t lcap = qmax > 16 * kQuadCpl[4] - 1 ? maxb : (int64_t)cu_count * 2;     // long queries: this IS the main class
         if (lblocks > lcap) lblocks = lcap;
-        bsw_kernel<<<(unsigned)lblocks, waves * 64, lds, q[0]>>>(pairs, n, ref, qer, w, prm, qmax, -1, ctr, &ctr->bsw_head[3], list + 5 * n, cnt + 5);
+        bsw_kernel<<<(unsigned)lblocks, waves * 64, lds, q[0]>>>(pairs, n, ref, qer, w, prm, qmax, -1, ctr, &ctr->bsw_head[3], list + 5 * n, cnt + 5, src, dir);
     }
     if (n_aux)
         for (int c = 0; c < n_aux; ++c) {

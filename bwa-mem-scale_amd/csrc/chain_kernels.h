@@ -80,7 +80,7 @@ struct ExtArgs {
 void launch_ext_plan(const ExtArgs &A, int extend_all, hipStream_t st);
 void launch_ext_widen(const ExtArgs &A, int64_t *wide, hipStream_t st);
 void launch_ext_build(const ExtArgs &A, const int64_t *offs, bwams_seqpair_t *left, uint8_t *lref, uint8_t *lqer,
-                      bwams_seqpair_t *right, uint8_t *rref, uint8_t *rqer, int cu_count, hipStream_t st);
+                      bwams_seqpair_t *right, uint8_t *rref, uint8_t *rqer, int64_t *lsrc, int64_t *rsrc, int cu_count, hipStream_t st);
 // after one extension attempt at band width w: settle finished tasks, queue the others for the next width
 void launch_ext_post(const ExtArgs &A, int right, const bwams_seqpair_t *pairs, int64_t n, int w, int last_try,
                      bwams_seqpair_t *retry, unsigned long long *n_retry, hipStream_t st);

@@ -116,7 +116,7 @@ struct Round2Work {
 
 int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w, const SwParams &prm, int qmax,
                DevCounters *ctr, int cu_count, hipStream_t st, int32_t *list, hipStream_t *aux = nullptr, hipEvent_t fork = nullptr,
-               hipEvent_t *join = nullptr);
+               hipEvent_t *join = nullptr, const int64_t *src = nullptr, int dir = 1);
 size_t bsw_list_bytes(int64_t n_tasks);          // scratch `list` of launch_bsw
 size_t bsw_lds_bytes(int qmax);
 void launch_emf_probe(const DevEmf &t, const uint8_t *enc, const int64_t *cum, int64_t nseq, uint32_t *out,

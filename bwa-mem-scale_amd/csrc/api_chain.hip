@@ -568,7 +568,7 @@ static int ext_plan(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt, i
     BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
     int rc = ext_args(b, s, opt, A);
     if (rc) return rc;
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->sel_heavy, 0, 2 * sizeof(unsigned long long), b->stream));
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->sel_heavy, 0, 4 * sizeof(unsigned long long), b->stream));
     launch_ext_heavy_list(*A, b->stream);
     BWAMS_HIP(hipMemsetAsync(s->cur.p, 0, (size_t)n1 * 4, b->stream));
     BWAMS_HIP(hipMemsetAsync(s->lim.p, 0, (size_t)n1 * 4, b->stream));
@@ -715,9 +715,24 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
         if ((rc = run_side(b, s, A, 1, &s->n_retry_right))) return rc;
         if (round == 0) { BWAMS_HIP(hipEventRecord(s->ev[7], st)); BWAMS_HIP(hipEventRecord(s->ev[8], st)); }
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_req, 0, sizeof(unsigned long long), st));
-        BWAMS_HIP(hipMemsetAsync(&b->d_ctr->sel_ticket, 0, sizeof(unsigned long long), st));
+        BWAMS_HIP(hipMemsetAsync(&b->d_ctr->sel_ticket, 0, 3 * sizeof(unsigned long long), st));
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_rest, 0, sizeof(unsigned long long), st));
-        if (s->n_seeds) launch_ext_select(A, b->cu_count, st);
+        static const char *vb_sel = getenv("BWAMS_VERBOSE");
+        const bool verbose_sel = vb_sel && *vb_sel && *vb_sel != '0';
+        if (verbose_sel) BWAMS_HIP(hipMemsetAsync(b->d_ctr->dbg, 0, sizeof b->d_ctr->dbg, st));
+        if (s->n_seeds && launch_ext_select(A, b->cu_count, st, s->aux, s->fork, s->join)) {
+            set_last_error("bwams_extend_run: stream fork/join failed");
+            return BWAMS_ERR_DEVICE;
+        }
+        if (verbose_sel) {           // filled only by a build of ext_aln.hip with -DBWAMS_SELDBG
+            unsigned long long d[16];
+            BWAMS_HIP(hipMemcpyAsync(d, b->d_ctr->dbg, sizeof d, hipMemcpyDeviceToHost, st));
+            BWAMS_HIP(hipStreamSynchronize(st));
+            if (d[0])
+                fprintf(stderr, "[bwams_extend_run] selection walk, round %d: %llu reads, Mticks total %.2f fetch %.2f scan %.2f keep-anyway %.2f; %llu slots, %llu chunks, "
+                                "%llu keep-anyway calls; longest read: %.3f Mticks (fetch %.3f scan %.3f keep %.3f), %llu slots %llu chunks %llu calls, %llu regions\n",
+                        round, d[0], d[1] / 1e6, d[2] / 1e6, d[3] / 1e6, d[4] / 1e6, d[5], d[6], d[7], d[8] / 1e6, d[9] / 1e6, d[10] / 1e6, d[11] / 1e6, d[12], d[13], d[14], d[15]);
+        }
         if (round == 0) BWAMS_HIP(hipEventRecord(s->ev[9], st));
         unsigned long long n_req = 0, n_rest = 0;
         BWAMS_HIP(hipMemcpyAsync(&n_req, &b->d_ctr->n_req, sizeof n_req, hipMemcpyDeviceToHost, st));

@@ -74,7 +74,7 @@ struct ExtArgs {
     void *kreg;                    // per read (at its first region's slot): the regions kept so far, 32 B each
     int32_t *cur, *lim;            // per read: seeds decided so far, regions kept so far
     int32_t *sel_heavy;            // reads with many regions (the selection's wave tier)
-    unsigned long long *n_sel_heavy, *sel_ticket;
+    unsigned long long *n_sel_heavy, *sel_ticket;     // sel_ticket[0..2]: the small class, the big class' two passes
     DevCounters *ctr;
 };
 void launch_ext_plan(const ExtArgs &A, int extend_all, hipStream_t st);
@@ -86,7 +86,7 @@ void launch_ext_post(const ExtArgs &A, int right, const bwams_seqpair_t *pairs, 
                      bwams_seqpair_t *retry, unsigned long long *n_retry, hipStream_t st);
 void launch_ext_right_h0(const ExtArgs &A, bwams_seqpair_t *right, int64_t n, hipStream_t st);
 void launch_ext_heavy_list(const ExtArgs &A, hipStream_t st);
-void launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st);
+int launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join);
 void launch_ext_request_rest(const ExtArgs &A, hipStream_t st);
 
 // ---- mem_flt_chained_seeds for long reads (seed_sw.hip) ----

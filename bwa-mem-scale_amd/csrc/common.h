@@ -86,7 +86,7 @@ struct DevCounters {
     unsigned long long heavy_tickets[3]; // chaining: work cursors of chain_heavy_kernel's size classes
     unsigned long long n_retry;          // extension: tasks queued for the next band width
     unsigned long long n_req;            // extension: seeds requested by the last selection
-    unsigned long long sel_heavy, sel_ticket;       // extension: reads of the selection's wave tier, its work cursor
+    unsigned long long sel_heavy, sel_ticket, sel_ticket2, sel_ticket3;   // extension: reads of the selection's wave tier; work cursors: the small class, the big class' two passes
     unsigned long long dedup_heavy, dedup_ticket, dedup_light;   // dedup: reads for the wave tier, its work cursor, reads for the lane tier
     unsigned long long chain_redo, chain_redo_ticket;   // chaining: reads the ordered-array attempt gave up on, work cursor
     unsigned long long pair_heavy, pair_ticket;   // mem_mark_primary_se: reads of the wave tier, its work cursor

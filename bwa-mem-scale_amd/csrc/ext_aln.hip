@@ -415,20 +415,36 @@ __device__ __forceinline__ bool purge_keep_anyway_w(const bwams_chain_seed_t &s,
 // wave fetches 64 slots at once, one per lane (four dependent loads each, in flight together), and then walks them with the
 // slot's fields broadcast from its lane.  (One slot at a time, every slot paid the four load latencies: the kernel's duration was
 // the ~1000 seeds of the heaviest read times ~3 us, the same at any chunk size.)
-__global__ __launch_bounds__(256) void ext_select_wave_kernel(ExtArgs A) {
+// Round 3: the kept regions a slot is tested against (KReg, 32 B; 64 per step) live in LDS while a read is walked.  Instrumented
+// (-DBWAMS_SELDBG, BWAMS_VERBOSE): the kernel's 3.2 ms were ONE read — 1191 slots, 10.8 k steps of that scan at ~650 cycles each, i.e.
+// the L2 round trip of the kreg load, 79 % of its 8.9 M cycles.  The copy in HBM stays the state between rounds (loaded at the start
+// of a read, written through).  Three size classes, each its own launch with its own work cursor over the same list: up to 256 regions
+// (8 KB of LDS per wave: sixteen waves per CU), up to 640 (20 KB: seven), up to 1280 (40 KB: three; the reads beyond fall back to HBM).
+// The top class holds a few dozen reads per million on a genome like the bench's, so its longest walk starts when the kernel does; on
+// a repeat-heavy genome (27 k reads per million beyond 128 regions) the middle class is what keeps enough wavefronts on them.
+constexpr int kSelCap[3] = {256, 640, 1280};
+__global__ __launch_bounds__(64) void ext_select_wave_kernel(ExtArgs A, int lo, int cap, unsigned long long *ticket) {
+    extern __shared__ __align__(16) unsigned char l_sel_raw[];
+    KReg *lk = reinterpret_cast<KReg *>(l_sel_raw);
     const int lane = threadIdx.x & 63;
     const int64_t n_heavy = (int64_t)*A.n_sel_heavy;
     for (;;) {
-        const int64_t ti = (int64_t)wave_ticket(A.sel_ticket, 1ull);
+        const int64_t ti = (int64_t)wave_ticket(ticket, 1ull);
         if (ti >= n_heavy) break;
         const int64_t r = A.sel_heavy[ti];
         const int64_t reg0 = A.seed_off[r];
         const int av_n = (int)(A.seed_off[r + 1] - reg0);
+        if (av_n <= lo || (av_n > cap && cap != kSelCap[2])) continue;        // another class's read
         int t = A.cur[r];
-        if (av_n <= kLightRegs || t >= av_n) continue;
+        if (t >= av_n) continue;
         const int l_query = (int)(A.cum[r + 1] - A.cum[r]);
         KReg *kreg = reinterpret_cast<KReg *>(A.kreg) + reg0;
         int lim = A.lim[r];
+        const bool in_lds = av_n <= cap;
+        __syncthreads();                                                      // (one wavefront per block) the previous read is done with lk
+        if (in_lds)
+            for (int i = lane; i < lim; i += 64) lk[i] = kreg[i];
+        __syncthreads();
         bool stop = false;
         while (t < av_n && !stop) {
             const int nb = av_n - t < 64 ? av_n - t : 64;
@@ -455,7 +471,7 @@ __global__ __launch_bounds__(256) void ext_select_wave_kernel(ExtArgs A) {
                     const int i = base + lane;
                     int cls = 0;
                     if (i < lim) {
-                        const KReg q = kreg[i];
+                        const KReg q = in_lds ? lk[i] : kreg[i];
                         cls = purge_class(A.opt, s, l_query, q.rb, q.re, q.qb, q.qe, q.seedlen0, q.w);
                     }
                     brk = __ballot(cls == 2) != 0;
@@ -483,9 +499,11 @@ __global__ __launch_bounds__(256) void ext_select_wave_kernel(ExtArgs A) {
                     KReg q;
                     q.rb = a->rb; q.re = a->re; q.qb = a->qb; q.qe = a->qe; q.seedlen0 = a->seedlen0; q.w = a->w;
                     kreg[lim] = q;
+                    if (in_lds) lk[lim] = q;
                     A.state[p] = st | kExtKept;
                 }
                 ++lim;
+                __syncthreads();                                              // the appended region is read by every lane from the next slot on
             }
             t += j;                                                          // a request leaves t at the requested slot
         }
@@ -534,10 +552,17 @@ void launch_ext_heavy_list(const ExtArgs &A, hipStream_t st) {
     if (A.nseq <= 0) return;
     ext_heavy_list_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A);
 }
-void launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st) {
-    if (A.nseq <= 0) return;
+int launch_ext_select(const ExtArgs &A, int cu_count, hipStream_t st, hipStream_t *aux, hipEvent_t fork, hipEvent_t *join) {
+    if (A.nseq <= 0) return 0;
+    if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(aux[0], fork, 0) != hipSuccess ||
+        hipStreamWaitEvent(aux[1], fork, 0) != hipSuccess) return -1;
+    ext_select_wave_kernel<<<(unsigned)(cu_count * 3), 64, kSelCap[2] * sizeof(KReg), aux[0]>>>(A, kSelCap[1], kSelCap[2], A.sel_ticket + 2);
+    ext_select_wave_kernel<<<(unsigned)(cu_count * 7), 64, kSelCap[1] * sizeof(KReg), aux[1]>>>(A, kSelCap[0], kSelCap[1], A.sel_ticket + 1);
     ext_select_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A);
-    ext_select_wave_kernel<<<(unsigned)(cu_count * 8), 256, 0, st>>>(A);      // latency-bound (dependent global loads per seed): many waves
+    ext_select_wave_kernel<<<(unsigned)(cu_count * 16), 64, kSelCap[0] * sizeof(KReg), st>>>(A, kLightRegs, kSelCap[0], A.sel_ticket);
+    for (int i = 0; i < 2; ++i)
+        if (hipEventRecord(join[i], aux[i]) != hipSuccess || hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;
+    return 0;
 }
 void launch_ext_request_rest(const ExtArgs &A, hipStream_t st) {
     if (A.n_seeds <= 0) return;

@@ -446,6 +446,10 @@ __global__ __launch_bounds__(64) void ext_select_wave_kernel(ExtArgs A, int lo, 
             for (int i = lane; i < lim; i += 64) lk[i] = kreg[i];
         __syncthreads();
         bool stop = false;
+#ifdef BWAMS_SELDBG                 // phase timers of the walk (printed by bwams_extend_run under BWAMS_VERBOSE)
+        const unsigned long long T0 = __builtin_amdgcn_s_memtime();
+        unsigned long long t_scan = 0, n_slots = 0, n_chunks = 0;
+#endif
         while (t < av_n && !stop) {
             const int nb = av_n - t < 64 ? av_n - t : 64;
             int64_t my_off = 0, my_rbeg = 0;
@@ -467,6 +471,10 @@ __global__ __launch_bounds__(64) void ext_select_wave_kernel(ExtArgs A, int lo, 
                 s.qbeg = __shfl(my_qbeg, j); s.len = __shfl(my_len, j);
                 const int c_n = __shfl(my_n, j), k = __shfl(my_k, j), st = __shfl(my_st, j);
                 bool brk = false;
+#ifdef BWAMS_SELDBG
+                const unsigned long long Tb = __builtin_amdgcn_s_memtime();
+                ++n_slots;
+#endif
                 for (int base = 0; base < lim && !brk; base += 64) {          // the kept regions, 64 at a time
                     const int i = base + lane;
                     int cls = 0;
@@ -475,7 +483,13 @@ __global__ __launch_bounds__(64) void ext_select_wave_kernel(ExtArgs A, int lo, 
                         cls = purge_class(A.opt, s, l_query, q.rb, q.re, q.qb, q.qe, q.seedlen0, q.w);
                     }
                     brk = __ballot(cls == 2) != 0;
+#ifdef BWAMS_SELDBG
+                    ++n_chunks;
+#endif
                 }
+#ifdef BWAMS_SELDBG
+                t_scan += __builtin_amdgcn_s_memtime() - Tb;
+#endif
                 if (brk && !purge_keep_anyway_w(s, A.seeds + c_off, A.srt + c_off, k, c_n, lane)) {
                     if (lane == 0) {
                         __hip_atomic_store(reinterpret_cast<unsigned long long *>(&A.regs[p].qb), 0xffffffffffffffffull,
@@ -508,6 +522,14 @@ __global__ __launch_bounds__(64) void ext_select_wave_kernel(ExtArgs A, int lo, 
             t += j;                                                          // a request leaves t at the requested slot
         }
         if (lane == 0) { A.cur[r] = t; A.lim[r] = lim; }
+#ifdef BWAMS_SELDBG
+        if (lane == 0) {
+            const unsigned long long tot = __builtin_amdgcn_s_memtime() - T0;
+            unsigned long long *d = A.ctr->dbg;
+            atomicAdd(&d[0], 1ull); atomicAdd(&d[1], tot); atomicAdd(&d[3], t_scan); atomicAdd(&d[5], n_slots); atomicAdd(&d[6], n_chunks);
+            if (atomicMax(&d[8], tot) < tot) { d[10] = t_scan; d[12] = n_slots; d[13] = n_chunks; d[15] = (unsigned long long)av_n; }
+        }
+#endif
     }
 }
 

@@ -771,19 +771,30 @@ __global__ __launch_bounds__(kPkWaves * 64) void bsw_pk_kernel(
             JP[0] = (uint32_t)jb * 0x10001u + 0x00020001u;            // (j + 1, j + 2)
 #pragma unroll
             for (int c = 1; c < 4; ++c) { JE[c] = pk::add(JE[c - 1], E2X); JP[c] = pk::add(JP[c - 1], TWO); }
+            // Stage by stage over the four pairs, not pair by pair: dependent packed (VOP3P) instructions need a wait state between them
+            // (the compiler fills it with s_nop 0: 34 per window in the pair-by-pair order), and the four pairs are independent.
+            uint32_t Hm[4], T1[4], T2[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t blo = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * c, 1), bhi = (uint32_t)__builtin_amdgcn_sbfe((int)m8, 2 * c + 1, 1);
                 AM[c] = pk::bfi(0xffffu, blo, bhi);
-                const uint32_t H = hpv[c] & AM[c];
-                E[c] = epv[c] & AM[c];
-                const uint32_t S = __builtin_amdgcn_perm(tt.y, tt.x, slv[c]);
-                M[c] = pk::mul(pk::add(H, S), pk::minu(H, ONE));        // M = H ? H + S : 0
-                const uint32_t tj = pk::max0(pk::sub(M[c], OEI));
-                uint32_t x = pk::add(tj, JE[c]);
-                x = pk::max(x, x << 16);                                // the pair's inclusive prefix (x >= 0)
-                PX[c] = x;
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { Hm[c] = hpv[c] & AM[c]; E[c] = epv[c] & AM[c]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) T1[c] = pk::add(Hm[c], __builtin_amdgcn_perm(tt.y, tt.x, slv[c]));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) T2[c] = pk::minu(Hm[c], ONE);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) M[c] = pk::mul(T1[c], T2[c]);                                   // M = H ? H + S : 0
+#pragma unroll
+            for (int c = 0; c < 4; ++c) T1[c] = pk::sub(M[c], OEI);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) T1[c] = pk::max0(T1[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) T1[c] = pk::add(T1[c], JE[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) PX[c] = pk::max(T1[c], T1[c] << 16);                            // the pair's inclusive prefix (x >= 0)
 #pragma unroll
             for (int c = 1; c < 4; ++c) PX[c] = pk::max(PX[c], pk::hi2(PX[c - 1]));
             // over the four lanes of the task
@@ -798,15 +809,19 @@ __global__ __launch_bounds__(kPkWaves * 64) void bsw_pk_kernel(
             Lex = g == 0 ? kPkNeg : Lex;
             Lex = Lex > c_max ? Lex : c_max;
             const uint32_t Lexp = pk::lo2((uint32_t)Lex);
-            uint32_t Hn[4], E2[4];
+            uint32_t Hn[4], E2[4], F4[4], ME[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t pexcl = __builtin_amdgcn_alignbit(PX[c], c ? PX[c - 1] : NEGP, 16);   // {prefix up to column j - 1}
-                const uint32_t pex = pk::max(pexcl, Lexp);
-                const uint32_t F = pk::max0(pk::add(pk::sub(pex, JE[c]), E1X));                       // F = max(Pex - (j - 1) e_ins, 0)
-                Hn[c] = pk::max(pk::max(M[c], E[c]), F);
-                E2[c] = pk::max0(pk::max(pk::sub(M[c], OED), pk::sub(E[c], EDX)));
-            }
+            for (int c = 0; c < 4; ++c) F4[c] = __builtin_amdgcn_alignbit(PX[c], c ? PX[c - 1] : NEGP, 16);      // {prefix up to column j - 1}
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { F4[c] = pk::max(F4[c], Lexp); E2[c] = pk::sub(M[c], OED); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { F4[c] = pk::sub(F4[c], JE[c]); T1[c] = pk::sub(E[c], EDX); ME[c] = pk::max(M[c], E[c]); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { F4[c] = pk::add(F4[c], E1X); E2[c] = pk::max(E2[c], T1[c]); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { F4[c] = pk::max0(F4[c]); E2[c] = pk::max0(E2[c]); }                    // F = max(Pex - (j - 1) e_ins, 0)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Hn[c] = pk::max(ME[c], F4[c]);
             // what is stored: H(i, j - 1) beside E(i + 1, j); the column to the left of the lane's first comes from the lane before
             const int h3 = (int)(Hn[3] >> 16);
             int hin = pk::qdpp<0x90>(h3);
@@ -823,18 +838,28 @@ __global__ __launch_bounds__(kPkWaves * 64) void bsw_pk_kernel(
             }
             // row maximum with the last column attaining it; first / last column with a non-zero stored cell
             int lkey = -1;
+            // key = H << 8 | (j + 1), one v_perm per column: the bytes {index, H low, H high, 0}.  A dead column contributes
+            // (0 << 8 | j + 1) < 256: below every live key of a row whose maximum is positive, and the column of the maximum is
+            // not read when the maximum is 0
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t ha = Hn[c] & AM[c];
-                // key = H << 8 | (j + 1), one v_perm per column: the bytes {index, H low, H high, 0}.  A dead column contributes
-                // (0 << 8 | j + 1) < 256: below every live key of a row whose maximum is positive, and the column of the maximum is
-                // not read when the maximum is 0
                 const int k0 = (int)__builtin_amdgcn_perm(ha, JP[c], 0x0c050400u), k1 = (int)__builtin_amdgcn_perm(ha, JP[c], 0x0c070602u);
                 const int kk = k0 > k1 ? k0 : k1;
                 lkey = lkey > kk ? lkey : kk;
-                const uint32_t f = pk::minu((HL[c] | E2[c]) & AM[c], ONE);
-                nzl = pk::max(nzl, pk::mul(f, JP[c]));
-                nzf = pk::max(nzf, pk::mul(f, pk::sub(C257, JP[c])));
+            }
+            {
+                uint32_t NF[4], NA[4], NB[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) NF[c] = (HL[c] | E2[c]) & AM[c];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { NF[c] = pk::minu(NF[c], ONE); NB[c] = pk::sub(C257, JP[c]); }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { NA[c] = pk::mul(NF[c], JP[c]); NB[c] = pk::mul(NF[c], NB[c]); }
+                NA[0] = pk::max(NA[0], NA[1]); NA[2] = pk::max(NA[2], NA[3]); NB[0] = pk::max(NB[0], NB[1]); NB[2] = pk::max(NB[2], NB[3]);
+                NA[0] = pk::max(NA[0], NA[2]); NB[0] = pk::max(NB[0], NB[2]);
+                nzl = pk::max(nzl, NA[0]);
+                nzf = pk::max(nzf, NB[0]);
             }
             lkey = m8 ? lkey : -1;                                  // a lane without a live column contributes nothing
             key = key > lkey ? key : lkey;

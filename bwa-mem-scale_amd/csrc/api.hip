@@ -492,6 +492,22 @@ static int batch_create_fill(bwams_batch *b, bwams_index_t *ix, int64_t max_read
                             rocprim::plus<int64_t>(), b->stream);
     b->tmp_bytes = std::max(t1, t2);
     BWAMS_HIP(hipMalloc(&b->d_tmp, b->tmp_bytes));
+    // BWAMS_POISON=1 (debugging aid, see DevBuf in api_chain.hip): the batch's own buffers start out as 0xAB bytes too
+    static const bool poison = getenv("BWAMS_POISON") && atoi(getenv("BWAMS_POISON")) != 0;
+    if (poison) {
+        BWAMS_HIP(hipMemset(b->d_enc, 0xAB, (size_t)max_bases + 64));
+        BWAMS_HIP(hipMemset(b->d_cum, 0xAB, (size_t)(max_reads + 1) * 8));
+        BWAMS_HIP(hipMemset(b->d_skip, 0xAB, (size_t)max_reads));
+        BWAMS_HIP(hipMemset(b->d_pool, 0xAB, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
+        BWAMS_HIP(hipMemset(b->d_sorted, 0xAB, (size_t)b->max_smem * sizeof(bwams_smem_t)));
+        BWAMS_HIP(hipMemset(b->d_keys, 0xAB, (size_t)b->pool_cap * 8)); BWAMS_HIP(hipMemset(b->d_keys2, 0xAB, (size_t)b->pool_cap * 8));
+        BWAMS_HIP(hipMemset(b->d_vals, 0xAB, (size_t)b->pool_cap * 4)); BWAMS_HIP(hipMemset(b->d_vals2, 0xAB, (size_t)b->pool_cap * 4));
+        BWAMS_HIP(hipMemset(b->d_work2, 0xAB, (size_t)b->pool_cap * sizeof(Round2Work)));
+        BWAMS_HIP(hipMemset(b->d_sa_off, 0xAB, (size_t)(b->max_smem + 1) * 8)); BWAMS_HIP(hipMemset(b->d_sa_cnt, 0xAB, (size_t)(b->max_smem + 1) * 8));
+        BWAMS_HIP(hipMemset(b->d_sa_coord, 0xAB, (size_t)b->max_sa * 8));
+        BWAMS_HIP(hipMemset(b->d_tmp, 0xAB, b->tmp_bytes));
+        BWAMS_HIP(hipDeviceSynchronize());
+    }
     return BWAMS_OK;
 }
 

@@ -26,7 +26,14 @@ struct DevBuf {
         p = nullptr;
         cap = bytes + bytes / 8 + 4096;
         hipError_t e = hipMalloc(&p, cap);
-        if (e != hipSuccess) cap = 0;
+        if (e != hipSuccess) { cap = 0; return e; }
+        // BWAMS_POISON=1 (debugging aid): fresh scratch is filled with 0xAB bytes, so that a kernel that reads what nothing wrote
+        // misbehaves in every run and not only when the allocator hands back a block another test left dirty
+        static const bool poison = getenv("BWAMS_POISON") && atoi(getenv("BWAMS_POISON")) != 0;
+        if (poison) {                        // (hipMemset on the null stream does not order with the batch's non-blocking streams: wait for it)
+            e = hipMemset(p, 0xAB, cap);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
         return e;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -967,7 +974,11 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
     A.anchor = s->pr_anchor.as<int32_t>(); A.slot_read = s->pr_slot.as<int32_t>();
     A.task = s->pr_task.as<int32_t>(); A.trb = s->pr_trb.as<int64_t>(); A.tl1 = s->pr_tl1.as<int32_t>();
     A.pool = s->pr_pool.as<bwams_alnreg_t>(); A.ord = s->pr_ord.as<int32_t>(); A.zbuf = s->pr_z.as<int32_t>(); A.srt = s->pr_srt.p;
+    static const int pr_trace = getenv("BWAMS_TRACE_PAIR") ? atoi(getenv("BWAMS_TRACE_PAIR")) : 0;     // debugging aid: a synchronisation and a line per launch
+#define PR_TRACE(msg) do { if (pr_trace) { BWAMS_HIP(hipStreamSynchronize(st)); fprintf(stderr, "[bwams_pair_run] %s\n", msg); } } while (0)
+    PR_TRACE("count / cap done");
     launch_pair_slots(A, st);
+    PR_TRACE("slots done");
     BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
     A.heavy = s->heavy.as<int32_t>();
     SwParams prm;
@@ -977,6 +988,7 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
         A.pass = pass;
         int64_t tot[3] = {0, 0, 0};
         launch_pair_plan(A, s->pr_twide.as<int64_t>(), st);
+        PR_TRACE("plan done");
         if ((rc = scan_rows(b, s->pr_twide.as<int64_t>(), s->pr_toffs.as<int64_t>(), 3, E1))) return rc;
         for (int r = 0; r < 3; ++r)
             BWAMS_HIP(hipMemcpyAsync(&tot[r], s->pr_toffs.as<int64_t>() + r * E1 + (E1 - 1), 8, hipMemcpyDeviceToHost, st));
@@ -991,13 +1003,16 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
         A.aln = s->pr_aln.as<int32_t>();
         launch_pair_build(A, s->pr_toffs.as<int64_t>(), s->pr_pairs.as<bwams_seqpair_t>(), s->pr_tref.as<uint8_t>(), s->pr_tqer.as<uint8_t>(),
                           b->cu_count, st);
+        PR_TRACE("build done");
         if (tot[0] > 0 && launch_ksw(s->pr_pairs.as<bwams_seqpair_t>(), tot[0], s->pr_tref.as<uint8_t>(), s->pr_tqer.as<uint8_t>(), prm,
                                      ((b->max_read_len + 15) / 16) * 16, tmax, s->pr_aln.p, b->d_ctr, b->cu_count, st)) {
             set_last_error("bwams_pair_run: rescue window too long for the local-SW kernel");
             return BWAMS_ERR_UNSUPPORTED;
         }
+        PR_TRACE("ksw done");
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_heavy, 0, 2 * sizeof(unsigned long long), st));
         launch_pair_post(A, b->cu_count, st);
+        PR_TRACE("post done");
         s->pr_tasks += tot[0];
         unsigned long long flags[2] = {0, 0};
         BWAMS_HIP(hipMemcpyAsync(flags, &b->d_ctr->pair_full, sizeof flags, hipMemcpyDeviceToHost, st));
@@ -1013,6 +1028,7 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_heavy, 0, 2 * sizeof(unsigned long long), st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_ticket2, 0, sizeof(unsigned long long), st));
     launch_pair_mark(A, b->cu_count, st);
+    PR_TRACE("mark done");
     launch_pair_widen(A, s->pr_owide.as<int64_t>(), st);
     if ((rc = scan_rows(b, s->pr_owide.as<int64_t>(), s->pr_ooff.as<int64_t>(), 1, n1))) return rc;
     int64_t total = 0;
@@ -1020,8 +1036,11 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
     BWAMS_HIP(hipStreamSynchronize(st));
     BWAMS_HIP(s->pr_out.ensure((size_t)(total + 1) * sizeof(bwams_alnreg_t)));
     launch_pair_gather(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), st);
+    PR_TRACE("gather done");
     launch_pair_reorder5(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), st);
+    PR_TRACE("reorder5 done");
     if (!single_end) launch_pair_pair(A, s->pr_ooff.as<int64_t>(), s->pr_out.as<bwams_alnreg_t>(), s->pr_res.as<bwams_pair_t>(), st);
+    PR_TRACE("pair done");
     BWAMS_HIP(hipEventRecord(s->ev[15], st));
     BWAMS_HIP(hipStreamSynchronize(st));
     BWAMS_HIP(hipGetLastError());

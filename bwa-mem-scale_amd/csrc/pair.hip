@@ -94,7 +94,8 @@ __global__ void pair_count_kernel(PairArgs A, int64_t *wide) {
         for (int j = 0; j < n && na < A.opt.max_matesw; ++j)
             if (A.regs[r0 + j].score >= A.regs[r0].score - A.opt.pen_unpaired) ++na;
     }
-    if (r < A.nseq) A.na[r] = na;
+    A.na[r] = na;                                            // entry nseq too (0): pair_cap_kernel reads na[r ^ 1], which for the last read of a
+                                                             // single-end chunk with an odd number of reads is that entry
     wide[r] = na;                                            // row 0: anchor slots
 }
 // lane per read: capacity of its pool = its regions + 4 per anchor of its mate

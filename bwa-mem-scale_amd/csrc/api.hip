@@ -51,7 +51,7 @@ int bsw_list_ensure(bwams_batch *b, int64_t n_tasks) {
     if (b->d_bsw_list) (void)hipFree(b->d_bsw_list);
     b->d_bsw_list = nullptr;
     b->cap_bsw_list = n_tasks + n_tasks / 4 + 1024;
-    BWAMS_HIP(hipMalloc(&b->d_bsw_list, bsw_list_bytes(b->cap_bsw_list)));
+    BWAMS_HIP(dev_malloc(&b->d_bsw_list, bsw_list_bytes(b->cap_bsw_list)));
     return BWAMS_OK;
 }
 int fmi_build_device(bwams_index *ix, const uint8_t *d_fw, int64_t l_pac, int keep_ref, int64_t chunk_rows, int verbose,
@@ -123,7 +123,7 @@ int bwams_index_from_host(const bwams_fmi_desc_t *d, int device, bwams_index_t *
     const size_t b_ref = d->ref_0123 ? (size_t)(d->ref_seq_len - 1) : 0;
     // a failed allocation or copy must not strand the multi-GB buffers already made: close the handle on the way out
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(dst, bytes + 64);          // slack: kernels read whole aligned words
+        hipError_t e = dev_malloc(dst, bytes + 64);          // slack: kernels read whole aligned words
         return e != hipSuccess ? e : hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     hipError_t ue = up(&ix->d_cp, d->cp_occ, b_cp);
@@ -261,7 +261,7 @@ int bwams_index_build(const uint8_t *fw, int64_t l_pac, int fw_on_device, int de
     BWAMS_HIP(hipSetDevice(device));
     void *staged = nullptr;
     if (!fw_on_device) {
-        BWAMS_HIP(hipMalloc(&staged, (size_t)l_pac));
+        BWAMS_HIP(dev_malloc(&staged, (size_t)l_pac));
         hipError_t e = hipMemcpy(staged, fw, (size_t)l_pac, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(staged); BWAMS_HIP(e); }
     }
@@ -386,8 +386,8 @@ static int fma_alloc(bwams_index *ix, int all_bp, int last_bp) {
     ix->d_all = ix->d_last = nullptr;
     ix->fmi.all_smem = nullptr;
     ix->fmi.last_smem = nullptr;
-    BWAMS_HIP(hipMalloc(&ix->d_all, ((size_t)1 << (2 * all_bp)) * 128));
-    BWAMS_HIP(hipMalloc(&ix->d_last, ((size_t)1 << (2 * last_bp)) * 16));
+    BWAMS_HIP(dev_malloc(&ix->d_all, ((size_t)1 << (2 * all_bp)) * 128));
+    BWAMS_HIP(dev_malloc(&ix->d_last, ((size_t)1 << (2 * last_bp)) * 16));
     return BWAMS_OK;
 }
 
@@ -445,15 +445,15 @@ static int alloc_smem_buffers(bwams_batch *b, int64_t max_smem) {
     // the pool is handed out in per-wave chunks: room for every wave's partly filled last chunk
     // of each of the three rounds on top of the max_smem real records
     b->pool_cap = b->max_smem + 3 * seed_pool_slack(b->cu_count);
-    BWAMS_HIP(hipMalloc(&b->d_pool, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
-    BWAMS_HIP(hipMalloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
-    BWAMS_HIP(hipMalloc(&b->d_keys, (size_t)b->pool_cap * 8));
-    BWAMS_HIP(hipMalloc(&b->d_keys2, (size_t)b->pool_cap * 8));
-    BWAMS_HIP(hipMalloc(&b->d_vals, (size_t)b->pool_cap * 4));
-    BWAMS_HIP(hipMalloc(&b->d_vals2, (size_t)b->pool_cap * 4));
-    BWAMS_HIP(hipMalloc(&b->d_work2, (size_t)b->pool_cap * sizeof(Round2Work)));
-    BWAMS_HIP(hipMalloc(&b->d_sa_off, (size_t)(b->max_smem + 1) * 8));
-    BWAMS_HIP(hipMalloc(&b->d_sa_cnt, (size_t)(b->max_smem + 1) * 8));
+    BWAMS_HIP(dev_malloc(&b->d_pool, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
+    BWAMS_HIP(dev_malloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
+    BWAMS_HIP(dev_malloc(&b->d_keys, (size_t)b->pool_cap * 8));
+    BWAMS_HIP(dev_malloc(&b->d_keys2, (size_t)b->pool_cap * 8));
+    BWAMS_HIP(dev_malloc(&b->d_vals, (size_t)b->pool_cap * 4));
+    BWAMS_HIP(dev_malloc(&b->d_vals2, (size_t)b->pool_cap * 4));
+    BWAMS_HIP(dev_malloc(&b->d_work2, (size_t)b->pool_cap * sizeof(Round2Work)));
+    BWAMS_HIP(dev_malloc(&b->d_sa_off, (size_t)(b->max_smem + 1) * 8));
+    BWAMS_HIP(dev_malloc(&b->d_sa_cnt, (size_t)(b->max_smem + 1) * 8));
     return BWAMS_OK;
 }
 
@@ -475,12 +475,12 @@ static int batch_create_fill(bwams_batch *b, bwams_index_t *ix, int64_t max_read
     for (auto &e : b->ev) BWAMS_HIP(hipEventCreate(&e));
     for (auto &e : b->ev_emf) BWAMS_HIP(hipEventCreate(&e));
 
-    BWAMS_HIP(hipMalloc(&b->d_enc, (size_t)max_bases + 64));
-    BWAMS_HIP(hipMalloc(&b->d_cum, (size_t)(max_reads + 1) * 8));
-    BWAMS_HIP(hipMalloc(&b->d_skip, (size_t)max_reads));
+    BWAMS_HIP(dev_malloc(&b->d_enc, (size_t)max_bases + 64));
+    BWAMS_HIP(dev_malloc(&b->d_cum, (size_t)(max_reads + 1) * 8));
+    BWAMS_HIP(dev_malloc(&b->d_skip, (size_t)max_reads));
     if (int arc = alloc_smem_buffers(b, b->max_smem)) return arc;
-    BWAMS_HIP(hipMalloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
-    BWAMS_HIP(hipMalloc(&b->d_ctr, sizeof(DevCounters)));
+    BWAMS_HIP(dev_malloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
+    BWAMS_HIP(dev_malloc(&b->d_ctr, sizeof(DevCounters)));
     BWAMS_HIP(hipHostMalloc(&b->h_ctr, sizeof(DevCounters)));
     BWAMS_HIP(hipMemset(b->d_ctr, 0, sizeof(DevCounters)));
 
@@ -491,23 +491,7 @@ static int batch_create_fill(bwams_batch *b, bwams_index_t *ix, int64_t max_read
     (void)rocprim::exclusive_scan(nullptr, t2, b->d_sa_cnt, b->d_sa_off, (int64_t)0, (size_t)b->max_smem + 1,
                             rocprim::plus<int64_t>(), b->stream);
     b->tmp_bytes = std::max(t1, t2);
-    BWAMS_HIP(hipMalloc(&b->d_tmp, b->tmp_bytes));
-    // BWAMS_POISON=1 (debugging aid, see DevBuf in api_chain.hip): the batch's own buffers start out as 0xAB bytes too
-    static const bool poison = getenv("BWAMS_POISON") && atoi(getenv("BWAMS_POISON")) != 0;
-    if (poison) {
-        BWAMS_HIP(hipMemset(b->d_enc, 0xAB, (size_t)max_bases + 64));
-        BWAMS_HIP(hipMemset(b->d_cum, 0xAB, (size_t)(max_reads + 1) * 8));
-        BWAMS_HIP(hipMemset(b->d_skip, 0xAB, (size_t)max_reads));
-        BWAMS_HIP(hipMemset(b->d_pool, 0xAB, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
-        BWAMS_HIP(hipMemset(b->d_sorted, 0xAB, (size_t)b->max_smem * sizeof(bwams_smem_t)));
-        BWAMS_HIP(hipMemset(b->d_keys, 0xAB, (size_t)b->pool_cap * 8)); BWAMS_HIP(hipMemset(b->d_keys2, 0xAB, (size_t)b->pool_cap * 8));
-        BWAMS_HIP(hipMemset(b->d_vals, 0xAB, (size_t)b->pool_cap * 4)); BWAMS_HIP(hipMemset(b->d_vals2, 0xAB, (size_t)b->pool_cap * 4));
-        BWAMS_HIP(hipMemset(b->d_work2, 0xAB, (size_t)b->pool_cap * sizeof(Round2Work)));
-        BWAMS_HIP(hipMemset(b->d_sa_off, 0xAB, (size_t)(b->max_smem + 1) * 8)); BWAMS_HIP(hipMemset(b->d_sa_cnt, 0xAB, (size_t)(b->max_smem + 1) * 8));
-        BWAMS_HIP(hipMemset(b->d_sa_coord, 0xAB, (size_t)b->max_sa * 8));
-        BWAMS_HIP(hipMemset(b->d_tmp, 0xAB, b->tmp_bytes));
-        BWAMS_HIP(hipDeviceSynchronize());
-    }
+    BWAMS_HIP(dev_malloc(&b->d_tmp, b->tmp_bytes));
     return BWAMS_OK;
 }
 
@@ -602,7 +586,7 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
         if (need > b->packed_cap) {
             if (b->d_packed) (void)hipFree(b->d_packed);
             b->d_packed = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_packed, (size_t)need * 4));
+            BWAMS_HIP(dev_malloc(&b->d_packed, (size_t)need * 4));
             b->packed_cap = need;
         }
     }
@@ -613,7 +597,7 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
         if (b->d_prev) (void)hipFree(b->d_prev);
         b->d_prev = nullptr;
         const size_t n = (size_t)cap * (size_t)threads;
-        BWAMS_HIP(hipMalloc(&b->d_prev, n * 16));
+        BWAMS_HIP(dev_malloc(&b->d_prev, n * 16));
         b->prev_cap = cap;
         b->prev_threads = threads;
     }
@@ -729,7 +713,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
             BWAMS_HIP(hipStreamSynchronize(st));
             (void)hipFree(b->d_tmp);
             b->d_tmp = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            BWAMS_HIP(dev_malloc(&b->d_tmp, tb));
             b->tmp_bytes = tb;
         }
         tb = b->tmp_bytes;
@@ -747,7 +731,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
             BWAMS_HIP(hipStreamSynchronize(st));
             (void)hipFree(b->d_tmp);
             b->d_tmp = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            BWAMS_HIP(dev_malloc(&b->d_tmp, tb));
             b->tmp_bytes = tb;
         }
         tb = b->tmp_bytes;
@@ -768,7 +752,7 @@ static int ert_redo_ensure(bwams_batch_t *b, int64_t n) {
     if (b->d_ert_redo) (void)hipFree(b->d_ert_redo);
     b->d_ert_redo = nullptr;
     b->cap_ert_redo = n + n / 4 + 1024;
-    BWAMS_HIP(hipMalloc(&b->d_ert_redo, (size_t)((b->cap_ert_redo + 31) / 32) * 4));
+    BWAMS_HIP(dev_malloc(&b->d_ert_redo, (size_t)((b->cap_ert_redo + 31) / 32) * 4));
     return BWAMS_OK;
 }
 
@@ -786,7 +770,7 @@ int bwams_seed_counts(bwams_batch_t *b, int64_t *n_smem, int64_t *n_sa) {
         (void)hipFree(b->d_sa_coord);
         b->d_sa_coord = nullptr;
         b->max_sa = b->n_sa + b->n_sa / 8 + 1024;
-        BWAMS_HIP(hipMalloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
+        BWAMS_HIP(dev_malloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_sa_lookups, 0, 2 * sizeof(unsigned long long), b->stream));   // + n_lf_steps
         if (b->seed_ert) {
             launch_ert_locate(b->seed_ert->t, b->d_enc, b->d_cum, b->d_sorted, b->n_smem, b->d_sa_cnt, b->last_seed_opt.max_occ,
@@ -861,7 +845,7 @@ int bwams_seed_fmi(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, con
 static int ert_count_table(bwams_ert *e) {
     int bits = 16;
     while (bits < 26 && ((int64_t)1 << bits) < e->mlt_bytes / 256) bits++;
-    BWAMS_HIP(hipMalloc(&e->d_cnt, (size_t)16 << bits));
+    BWAMS_HIP(dev_malloc(&e->d_cnt, (size_t)16 << bits));
     BWAMS_HIP(hipMemset(e->d_cnt, 0, (size_t)16 << bits));
     e->t.cnt_tab = (uint64_t *)e->d_cnt;
     e->t.cnt_bits = bits;
@@ -884,8 +868,8 @@ int bwams_ert_from_host(bwams_index_t *ix, const uint64_t *kmer_table, int32_t k
     bwams_ert *e = new bwams_ert();
     e->idx = ix;
     const size_t nk = (size_t)1 << (2 * kmer_size);
-    hipError_t he = hipMalloc(&e->d_kmer, nk * 8);
-    if (he == hipSuccess) he = hipMalloc(&e->d_mlt, (size_t)mlt_bytes + 16);
+    hipError_t he = dev_malloc(&e->d_kmer, nk * 8);
+    if (he == hipSuccess) he = dev_malloc(&e->d_mlt, (size_t)mlt_bytes + 16);
     if (he == hipSuccess) he = hipMemcpy(e->d_kmer, kmer_table, nk * 8, hipMemcpyHostToDevice);
     if (he == hipSuccess && mlt_bytes) he = hipMemcpy(e->d_mlt, mlt_table, (size_t)mlt_bytes, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemset((uint8_t *)e->d_mlt + mlt_bytes, 0, 16);
@@ -931,8 +915,8 @@ int bwams_ert_open(bwams_index_t *ix, const char *prefix, int32_t read_len, bwam
     int rc = BWAMS_OK;
     const size_t chunk = (size_t)256 << 20;          // streamed through one pinned staging buffer
     void *stage = nullptr;
-    hipError_t he = hipMalloc(&e->d_kmer, nk * 8);
-    if (he == hipSuccess) he = hipMalloc(&e->d_mlt, (size_t)mlt_bytes + 16);
+    hipError_t he = dev_malloc(&e->d_kmer, nk * 8);
+    if (he == hipSuccess) he = dev_malloc(&e->d_mlt, (size_t)mlt_bytes + 16);
     if (he == hipSuccess) he = hipHostMalloc(&stage, chunk);
     if (he != hipSuccess) rc = he == hipErrorOutOfMemory ? BWAMS_ERR_NOMEM : BWAMS_ERR_DEVICE;
     auto stream_in = [&](FILE *f, void *dst, size_t total) {
@@ -1057,14 +1041,14 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
         if (b->d_ert_prof) (void)hipFree(b->d_ert_prof);
         b->d_ert_prof = nullptr;
         b->cap_ert_prof = need + need / 8;
-        BWAMS_HIP(hipMalloc(&b->d_ert_prof, (size_t)b->cap_ert_prof));
+        BWAMS_HIP(dev_malloc(&b->d_ert_prof, (size_t)b->cap_ert_prof));
     }
     const int frames = 2 * (e->t.read_len + 2);      // the counting walk keeps two words per level
     const size_t part_bytes = ert_count_bytes();      // partial counters sit behind the stacks
     if (frames > b->ert_stk_frames) {
         if (b->d_ert_stk) (void)hipFree(b->d_ert_stk);
         b->d_ert_stk = nullptr;
-        BWAMS_HIP(hipMalloc(&b->d_ert_stk, (size_t)ert_walk_threads(b->cu_count) * (size_t)frames * 8 + part_bytes));
+        BWAMS_HIP(dev_malloc(&b->d_ert_stk, (size_t)ert_walk_threads(b->cu_count) * (size_t)frames * 8 + part_bytes));
         b->ert_stk_frames = frames;
         BWAMS_HIP(hipMemsetAsync(b->d_ert_stk + (size_t)ert_walk_threads(b->cu_count) * (size_t)frames, 0, part_bytes, b->stream));
     }
@@ -1105,7 +1089,7 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
             BWAMS_HIP(hipStreamSynchronize(st));
             (void)hipFree(b->d_tmp);
             b->d_tmp = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            BWAMS_HIP(dev_malloc(&b->d_tmp, tb));
             b->tmp_bytes = tb;
         }
         tb = b->tmp_bytes;
@@ -1126,7 +1110,7 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
             BWAMS_HIP(hipStreamSynchronize(st));
             (void)hipFree(b->d_tmp);
             b->d_tmp = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            BWAMS_HIP(dev_malloc(&b->d_tmp, tb));
             b->tmp_bytes = tb;
         }
         tb = b->tmp_bytes;
@@ -1200,7 +1184,7 @@ int bwams_bsw_upload(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, 
         if (*p) (void)hipFree(*p);
         *p = nullptr;
         *cap = need + need / 4 + 1024;
-        return hipMalloc(p, (size_t)*cap * elem);
+        return dev_malloc(p, (size_t)*cap * elem);
     };
     BWAMS_HIP(grow((void **)&b->d_pairs, &b->cap_pairs, n, sizeof(bwams_seqpair_t)));
     BWAMS_HIP(grow((void **)&b->d_ref, &b->cap_ref, ref_bytes + 64, 1));
@@ -1276,8 +1260,8 @@ int bwams_emf_from_host(bwams_index_t *ix, int32_t seed_len, uint32_t seq_len, c
     bwams_emf *e = new bwams_emf();
     e->idx = ix;
     const size_t bs = (size_t)num_seed_entry * 16, bl = (size_t)(num_loc_entry ? num_loc_entry : 1) * 4;
-    hipError_t he = hipMalloc(&e->d_seeds, bs);
-    if (he == hipSuccess) he = hipMalloc(&e->d_loc, bl);
+    hipError_t he = dev_malloc(&e->d_seeds, bs);
+    if (he == hipSuccess) he = dev_malloc(&e->d_loc, bl);
     if (he == hipSuccess) he = hipMemcpy(e->d_seeds, seed_table, bs, hipMemcpyHostToDevice);
     if (he == hipSuccess && num_loc_entry) he = hipMemcpy(e->d_loc, loc_table, (size_t)num_loc_entry * 4, hipMemcpyHostToDevice);
     if (he != hipSuccess) {                     // a table is tens of GiB: do not strand the half that was made
@@ -1358,8 +1342,8 @@ int bwams_emf_run(bwams_batch_t *b, bwams_emf_t *e) {
         if (b->d_emf_code) (void)hipFree(b->d_emf_code);
         b->d_emf_out = nullptr; b->d_emf_code = nullptr;
         b->cap_emf = nseq + nseq / 8 + 256;
-        BWAMS_HIP(hipMalloc(&b->d_emf_out, (size_t)b->cap_emf * 8));
-        BWAMS_HIP(hipMalloc(&b->d_emf_code, (size_t)b->cap_emf));
+        BWAMS_HIP(dev_malloc(&b->d_emf_out, (size_t)b->cap_emf * 8));
+        BWAMS_HIP(dev_malloc(&b->d_emf_code, (size_t)b->cap_emf));
     }
     hipStream_t st = b->stream;
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->emf_nodes, 0, 16, st));
@@ -1493,8 +1477,8 @@ int bwams_emf_probe(bwams_batch_t *b, bwams_emf_t *e, const uint8_t *enc, const 
         if (b->d_emf_code) (void)hipFree(b->d_emf_code);
         b->d_emf_out = nullptr; b->d_emf_code = nullptr;
         b->cap_emf = nseq + nseq / 8 + 256;
-        BWAMS_HIP(hipMalloc(&b->d_emf_out, (size_t)b->cap_emf * 8));
-        BWAMS_HIP(hipMalloc(&b->d_emf_code, (size_t)b->cap_emf));
+        BWAMS_HIP(dev_malloc(&b->d_emf_out, (size_t)b->cap_emf * 8));
+        BWAMS_HIP(dev_malloc(&b->d_emf_code, (size_t)b->cap_emf));
     }
     hipStream_t st = b->stream;
     if (nb) BWAMS_HIP(hipMemcpyAsync(b->d_enc, enc, (size_t)nb, hipMemcpyHostToDevice, st));
@@ -1538,7 +1522,7 @@ int bwams_ksw_align(bwams_batch_t *b, const bwams_seqpair_t *pairs, int64_t n, c
         if (b->d_ksw_out) (void)hipFree(b->d_ksw_out);
         b->d_ksw_out = nullptr;
         b->cap_ksw = n + n / 4 + 256;
-        BWAMS_HIP(hipMalloc(&b->d_ksw_out, (size_t)b->cap_ksw * sizeof(bwams_kswr_t)));
+        BWAMS_HIP(dev_malloc(&b->d_ksw_out, (size_t)b->cap_ksw * sizeof(bwams_kswr_t)));
     }
     SwParams prm;
     prm.o_del = o->o_del; prm.e_del = o->e_del; prm.o_ins = o->o_ins; prm.e_ins = o->e_ins;

@@ -25,15 +25,8 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = bytes + bytes / 8 + 4096;
-        hipError_t e = hipMalloc(&p, cap);
+        hipError_t e = dev_malloc(&p, cap);
         if (e != hipSuccess) { cap = 0; return e; }
-        // BWAMS_POISON=1 (debugging aid): fresh scratch is filled with 0xAB bytes, so that a kernel that reads what nothing wrote
-        // misbehaves in every run and not only when the allocator hands back a block another test left dirty
-        static const bool poison = getenv("BWAMS_POISON") && atoi(getenv("BWAMS_POISON")) != 0;
-        if (poison) {                        // (hipMemset on the null stream does not order with the batch's non-blocking streams: wait for it)
-            e = hipMemset(p, 0xAB, cap);
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-        }
         return e;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -123,7 +116,7 @@ int scan_rows(bwams_batch *b, const int64_t *in, int64_t *out, int rows, int64_t
             BWAMS_HIP(hipStreamSynchronize(b->stream));
             if (b->d_tmp) (void)hipFree(b->d_tmp);
             b->d_tmp = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            BWAMS_HIP(dev_malloc(&b->d_tmp, tb));
             b->tmp_bytes = tb;
         }
         tb = b->tmp_bytes;
@@ -163,7 +156,7 @@ int dev_bns(bwams_index *ix, DevBns *out) {
             set_last_error("the index holds more than 2^31 bases: call bwams_index_set_contigs with the real sequences");
             return BWAMS_ERR_ARG;
         }
-        BWAMS_HIP(hipMalloc(&ix->d_contigs, sizeof c));
+        BWAMS_HIP(dev_malloc(&ix->d_contigs, sizeof c));
         BWAMS_HIP(hipMemcpy(ix->d_contigs, &c, sizeof c, hipMemcpyHostToDevice));
         ix->n_seqs = 1;
     }
@@ -209,7 +202,7 @@ int bwams_index_set_contigs(bwams_index_t *ix, const bwams_contig_t *contigs, in
     BWAMS_HIP(hipSetDevice(ix->device));
     if (ix->d_contigs) (void)hipFree(ix->d_contigs);
     ix->d_contigs = nullptr;
-    BWAMS_HIP(hipMalloc(&ix->d_contigs, (size_t)n_seqs * sizeof(bwams_contig_t)));
+    BWAMS_HIP(dev_malloc(&ix->d_contigs, (size_t)n_seqs * sizeof(bwams_contig_t)));
     BWAMS_HIP(hipMemcpy(ix->d_contigs, contigs, (size_t)n_seqs * sizeof(bwams_contig_t), hipMemcpyHostToDevice));
     ix->n_seqs = n_seqs;
     return BWAMS_OK;
@@ -419,7 +412,7 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
             BWAMS_HIP(hipStreamSynchronize(st));
             if (b->d_tmp) (void)hipFree(b->d_tmp);
             b->d_tmp = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            BWAMS_HIP(dev_malloc(&b->d_tmp, tb));
             b->tmp_bytes = tb;
         }
         tb = b->tmp_bytes;
@@ -1201,7 +1194,7 @@ int bwams_reg2aln_run_sam(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bw
             BWAMS_HIP(hipStreamSynchronize(st));
             if (b->d_tmp) (void)hipFree(b->d_tmp);
             b->d_tmp = nullptr;
-            BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+            BWAMS_HIP(dev_malloc(&b->d_tmp, tb));
             b->tmp_bytes = tb;
         }
         tb = b->tmp_bytes;
@@ -1249,8 +1242,8 @@ int bwams_index_set_contig_names(bwams_index_t *ix, const char *names, const int
         }
     BWAMS_HIP(hipSetDevice(ix->device));
     if (ix->d_ctg_names) { (void)hipFree(ix->d_ctg_names); (void)hipFree(ix->d_ctg_off); ix->d_ctg_names = ix->d_ctg_off = nullptr; }
-    BWAMS_HIP(hipMalloc(&ix->d_ctg_names, (size_t)name_off[n]));
-    BWAMS_HIP(hipMalloc(&ix->d_ctg_off, (size_t)(n + 1) * 4));
+    BWAMS_HIP(dev_malloc(&ix->d_ctg_names, (size_t)name_off[n]));
+    BWAMS_HIP(dev_malloc(&ix->d_ctg_off, (size_t)(n + 1) * 4));
     BWAMS_HIP(hipMemcpy(ix->d_ctg_names, names, (size_t)name_off[n], hipMemcpyHostToDevice));
     BWAMS_HIP(hipMemcpy(ix->d_ctg_off, name_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
     return BWAMS_OK;
@@ -1269,8 +1262,8 @@ int bwams_index_set_contig_annos(bwams_index_t *ix, const char *annos, const int
         }
     BWAMS_HIP(hipSetDevice(ix->device));
     if (ix->d_ctg_annos) { (void)hipFree(ix->d_ctg_annos); (void)hipFree(ix->d_ctg_anno_off); ix->d_ctg_annos = ix->d_ctg_anno_off = nullptr; }
-    BWAMS_HIP(hipMalloc(&ix->d_ctg_annos, (size_t)anno_off[n]));
-    BWAMS_HIP(hipMalloc(&ix->d_ctg_anno_off, (size_t)(n + 1) * 4));
+    BWAMS_HIP(dev_malloc(&ix->d_ctg_annos, (size_t)anno_off[n]));
+    BWAMS_HIP(dev_malloc(&ix->d_ctg_anno_off, (size_t)(n + 1) * 4));
     BWAMS_HIP(hipMemcpy(ix->d_ctg_annos, annos, (size_t)anno_off[n], hipMemcpyHostToDevice));
     BWAMS_HIP(hipMemcpy(ix->d_ctg_anno_off, anno_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
     return BWAMS_OK;
@@ -1677,7 +1670,7 @@ int bwams_process_chunk_smart(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *e
                              n_processed + (k ? (int64_t)ids[0].size() : 0), flags, &bytes);
         if (rc) { bwams_fastq_close(fq); return rc; }
         ChainState *s = b->chain;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&held[k].text), (size_t)bytes + 16);
+        hipError_t e = dev_malloc(reinterpret_cast<void **>(&held[k].text), (size_t)bytes + 16);
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(held[k].text, s->sm_out.p, (size_t)bytes, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(held[k].off.data(), s->sm_off.p, held[k].off.size() * 8, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1823,7 +1816,7 @@ static int pestat_keys(bwams_batch *b, ChainState *s, const bwams_mem_opt_t *opt
         BWAMS_HIP(hipStreamSynchronize(st));
         if (b->d_tmp) (void)hipFree(b->d_tmp);
         b->d_tmp = nullptr;
-        BWAMS_HIP(hipMalloc(&b->d_tmp, tb));
+        BWAMS_HIP(dev_malloc(&b->d_tmp, tb));
         b->tmp_bytes = tb;
     }
     tb = b->tmp_bytes;

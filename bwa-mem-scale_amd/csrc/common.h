@@ -1,6 +1,7 @@
 // common.h — internal declarations shared by the HIP translation units.
 #pragma once
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -12,6 +13,19 @@
 namespace bwams {
 
 void set_last_error(const std::string &s);
+
+// Every device allocation of the library goes through this: BWAMS_POISON=1 (debugging aid) fills the fresh block with 0xAB bytes and waits
+// for the fill, so that a kernel that reads what nothing wrote misbehaves in every run — not only when the allocator hands back a block that
+// another chunk left dirty (a fresh process gets zeros).  tests: the whole `-m gpu` suite passes under it.
+template <class T> static inline hipError_t dev_malloc(T **p, size_t bytes) {
+    static const bool poison = getenv("BWAMS_POISON") && atoi(getenv("BWAMS_POISON")) != 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
+    if (e == hipSuccess && poison && bytes) {
+        e = hipMemset(*p, 0xAB, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();     // hipMemset on the null stream does not order with non-blocking streams
+    }
+    return e;
+}
 
 #define BWAMS_HIP(call)                                                                  \
     do {                                                                                 \

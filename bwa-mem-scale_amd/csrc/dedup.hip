@@ -635,8 +635,8 @@ int launch_sort_test(const int64_t *k, const int32_t *s_, const int32_t *q, int 
     SortRec *d_in = nullptr, *d_scr = nullptr;
     int32_t *d_ord = nullptr;
     int rc = -1;
-    if (hipMalloc(&d_in, sizeof(SortRec) * (size_t)(n + 1)) == hipSuccess && hipMalloc(&d_ord, 4 * (size_t)(n + 1)) == hipSuccess &&
-        hipMalloc(&d_scr, sizeof(SortRec) * (size_t)(n + 1)) == hipSuccess &&
+    if (dev_malloc(&d_in, sizeof(SortRec) * (size_t)(n + 1)) == hipSuccess && dev_malloc(&d_ord, 4 * (size_t)(n + 1)) == hipSuccess &&
+        dev_malloc(&d_scr, sizeof(SortRec) * (size_t)(n + 1)) == hipSuccess &&
         hipMemcpy(d_in, h, sizeof(SortRec) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess) {
         sort_test_kernel<<<1, 64>>>(d_in, n, by_score, mode, d_ord, d_scr);
         if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(order, d_ord, 4 * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;

@@ -431,9 +431,9 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
     const size_t n = (size_t)B.n_win;
     hipEvent_t e0, e1, e2, e3;
     EMF_HIP(hipEventCreate(&e0)); EMF_HIP(hipEventCreate(&e1)); EMF_HIP(hipEventCreate(&e2)); EMF_HIP(hipEventCreate(&e3));
-    EMF_HIP(hipMalloc(&d_k, n * 8)); EMF_HIP(hipMalloc(&d_k2, n * 8));
-    EMF_HIP(hipMalloc(&d_v, n * 4)); EMF_HIP(hipMalloc(&d_v2, n * 4));
-    EMF_HIP(hipMalloc(&d_ctr, 8 * 8));
+    EMF_HIP(dev_malloc(&d_k, n * 8)); EMF_HIP(dev_malloc(&d_k2, n * 8));
+    EMF_HIP(dev_malloc(&d_v, n * 4)); EMF_HIP(dev_malloc(&d_v2, n * 4));
+    EMF_HIP(dev_malloc(&d_ctr, 8 * 8));
     EMF_HIP(hipMemsetAsync(d_ctr, 0, 8 * 8, st));
     const unsigned grid = (unsigned)std::min<int64_t>((int64_t)((n + 255) / 256), (int64_t)cu_count * 32);
     EMF_HIP(hipEventRecord(e0, st));
@@ -444,7 +444,7 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
         rocprim::double_buffer<uint32_t> vb((uint32_t *)d_v, (uint32_t *)d_v2);
         size_t tb = 0;
         EMF_HIP(rocprim::radix_sort_pairs(nullptr, tb, kb, vb, n, 0, 64, st));
-        EMF_HIP(hipMalloc(&d_tmp, tb ? tb : 8));
+        EMF_HIP(dev_malloc(&d_tmp, tb ? tb : 8));
         EMF_HIP(rocprim::radix_sort_pairs(d_tmp, tb, kb, vb, n, 0, 64, st));
         EMF_HIP(hipStreamSynchronize(st));
         if (kb.current() != (uint64_t *)d_k) std::swap(d_k, d_k2);
@@ -455,13 +455,13 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
     }
     EMF_HIP(hipEventRecord(e1, st));
     const size_t used_words = (size_t)((B.n_entry + 31) / 32);
-    EMF_HIP(hipMalloc(&d_used, used_words * 4 + 4));
+    EMF_HIP(dev_malloc(&d_used, used_words * 4 + 4));
     EMF_HIP(hipMemsetAsync(d_used, 0, used_words * 4 + 4, st));
     BucketArgs A;
     memset(&A, 0, sizeof A);
     A.B = B; A.keys = (const uint64_t *)d_k; A.pos = (const uint32_t *)d_v; A.used = (uint32_t *)d_used;
     A.ctr = (unsigned long long *)d_ctr;
-    EMF_HIP(hipMalloc(&d_big, kBigCap * sizeof(ulonglong2)));
+    EMF_HIP(dev_malloc(&d_big, kBigCap * sizeof(ulonglong2)));
     A.big = (ulonglong2 *)d_big; A.big_cap = kBigCap;
     hipLaunchKernelGGL(emf_bucket_kernel<1>, dim3(grid), dim3(256), 0, st, A);
     EMF_HIP(hipGetLastError());
@@ -497,8 +497,8 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
             off += pad;
             big_windows += lst[t].y;
         }
-        EMF_HIP(hipMalloc(&d_runs, n_big * sizeof(BigRun)));
-        EMF_HIP(hipMalloc(&d_ord, off * 4));
+        EMF_HIP(dev_malloc(&d_runs, n_big * sizeof(BigRun)));
+        EMF_HIP(dev_malloc(&d_ord, off * 4));
         EMF_HIP(hipMemcpyAsync(d_runs, runs.data(), n_big * sizeof(BigRun), hipMemcpyHostToDevice, st));
         G.A = A; G.runs = (const BigRun *)d_runs; G.ord = (uint32_t *)d_ord;
         hipLaunchKernelGGL(emf_big_sort_kernel, dim3((unsigned)n_big), dim3(256), 0, st, G);
@@ -510,20 +510,20 @@ int emf_build_device(bwams_emf *e, const uint8_t *ref, int64_t l_pac, int seed_l
     const unsigned long long n_other = c[0], n_loc = c[1] + 1, n_used = c[2], n_key = c[3];
     // the free slots, ascending
     const size_t n_free = (size_t)(B.n_entry - n_key);
-    EMF_HIP(hipMalloc(&d_free, (n_free ? n_free : 1) * 4));
-    EMF_HIP(hipMalloc(&d_nsel, 8));
+    EMF_HIP(dev_malloc(&d_free, (n_free ? n_free : 1) * 4));
+    EMF_HIP(dev_malloc(&d_nsel, 8));
     {
         IsFree pred;
         pred.used = (const uint32_t *)d_used;
         rocprim::counting_iterator<uint32_t> it(0u);
         size_t tb = 0;
         EMF_HIP(rocprim::select(nullptr, tb, it, (uint32_t *)d_free, (size_t *)d_nsel, (size_t)B.n_entry, pred, st));
-        EMF_HIP(hipMalloc(&d_tmp, tb ? tb : 8));
+        EMF_HIP(dev_malloc(&d_tmp, tb ? tb : 8));
         EMF_HIP(rocprim::select(d_tmp, tb, it, (uint32_t *)d_free, (size_t *)d_nsel, (size_t)B.n_entry, pred, st));
     }
     EMF_HIP(hipEventRecord(e2, st));
-    EMF_HIP(hipMalloc(&e->d_seeds, (size_t)B.n_entry * 16));
-    EMF_HIP(hipMalloc(&e->d_loc, (size_t)n_loc * 4));
+    EMF_HIP(dev_malloc(&e->d_seeds, (size_t)B.n_entry * 16));
+    EMF_HIP(dev_malloc(&e->d_loc, (size_t)n_loc * 4));
     EMF_HIP(hipMemsetAsync(e->d_loc, 0, (size_t)n_loc * 4, st));
     hipLaunchKernelGGL(emf_fill_kernel, dim3((unsigned)cu_count * 32), dim3(256), 0, st, (uint4 *)e->d_seeds, B.n_entry);
     const unsigned long long init[8] = {0, 1, 0, 0, 0, 0, 0, 0};        // loc_table[0] is unused

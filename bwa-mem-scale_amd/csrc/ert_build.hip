@@ -443,11 +443,11 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
     } while (0)
     hipEvent_t e0, e1, e2, e3;
     ERT_HIP(hipEventCreate(&e0)); ERT_HIP(hipEventCreate(&e1)); ERT_HIP(hipEventCreate(&e2)); ERT_HIP(hipEventCreate(&e3));
-    ERT_HIP(hipMalloc(&e->d_kmer, n_kmers * 8));
-    ERT_HIP(hipMalloc(&d_meta, n_kmers * 8));
-    ERT_HIP(hipMalloc(&d_off, n_kmers * 8));
-    ERT_HIP(hipMalloc(&d_stk, (size_t)A.n_threads * (size_t)A.max_frames * 40));
-    ERT_HIP(hipMalloc(&d_err, 32));
+    ERT_HIP(dev_malloc(&e->d_kmer, n_kmers * 8));
+    ERT_HIP(dev_malloc(&d_meta, n_kmers * 8));
+    ERT_HIP(dev_malloc(&d_off, n_kmers * 8));
+    ERT_HIP(dev_malloc(&d_stk, (size_t)A.n_threads * (size_t)A.max_frames * 40));
+    ERT_HIP(dev_malloc(&d_err, 32));
     ERT_HIP(hipMemsetAsync(d_err, 0, 32, st));
     A.kmer = (uint64_t *)e->d_kmer;
     A.meta = (uint64_t *)d_meta;
@@ -463,7 +463,7 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
         auto in = rocprim::make_transform_iterator((const uint64_t *)d_meta, LowWord());
         size_t tb = 0;
         ERT_HIP(rocprim::exclusive_scan(nullptr, tb, in, (uint64_t *)d_off, (uint64_t)0, (size_t)n_kmers, rocprim::plus<uint64_t>(), st));
-        ERT_HIP(hipMalloc(&d_tmp, tb ? tb : 8));
+        ERT_HIP(dev_malloc(&d_tmp, tb ? tb : 8));
         ERT_HIP(rocprim::exclusive_scan(d_tmp, tb, in, (uint64_t *)d_off, (uint64_t)0, (size_t)n_kmers, rocprim::plus<uint64_t>(), st));
     }
     uint64_t last_off = 0, last_meta = 0;
@@ -490,12 +490,12 @@ int ert_build_device(bwams_ert *e, const DevFmi &f, int K, int X, int read_len, 
         return BWAMS_ERR_UNSUPPORTED;
     }
     const int64_t mlt_bytes = (int64_t)(last_off + (last_meta & 0xffffffffull));
-    ERT_HIP(hipMalloc(&e->d_mlt, (size_t)mlt_bytes + 16));
+    ERT_HIP(dev_malloc(&e->d_mlt, (size_t)mlt_bytes + 16));
     ERT_HIP(hipMemsetAsync(e->d_mlt, 0, (size_t)mlt_bytes + 16, st));
     A.mlt = (uint8_t *)e->d_mlt;
     int bits = 10;
     while (((uint64_t)1 << bits) < 2 * err[1] + 16) bits++;
-    ERT_HIP(hipMalloc(&e->d_cnt, ((size_t)16) << bits));
+    ERT_HIP(dev_malloc(&e->d_cnt, ((size_t)16) << bits));
     ERT_HIP(hipMemsetAsync(e->d_cnt, 0, ((size_t)16) << bits, st));
     memset(&A.cnt, 0, sizeof A.cnt);
     A.cnt.cnt_tab = (uint64_t *)e->d_cnt;

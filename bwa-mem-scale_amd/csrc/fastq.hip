@@ -248,7 +248,7 @@ namespace bwams {
 int segment_copy(const std::vector<SegMove> &moves, hipStream_t st) {
     if (moves.empty()) return BWAMS_OK;
     SegMove *d = nullptr;
-    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d), moves.size() * sizeof(SegMove)));
+    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d), moves.size() * sizeof(SegMove)));
     hipError_t e = hipMemcpyAsync(d, moves.data(), moves.size() * sizeof(SegMove), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         int64_t blocks = ((int64_t)moves.size() + 3) / 4;
@@ -270,8 +270,8 @@ int fastq_classify(bwams_fastq *f, std::vector<uint8_t> *which) {
     BWAMS_HIP(hipSetDevice(f->device));
     uint8_t *d_eq = nullptr;
     int64_t *d_off = nullptr;
-    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_eq), (size_t)n));
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_off), (size_t)(n + 1) * 8);
+    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_eq), (size_t)n));
+    hipError_t e = dev_malloc(reinterpret_cast<void **>(&d_off), (size_t)(n + 1) * 8);
     std::vector<uint8_t> eq((size_t)n);
     if (e == hipSuccess) e = hipMemcpy(d_off, f->name_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -306,10 +306,10 @@ int fastq_subset(bwams_fastq *f, const std::vector<int64_t> &ids, bwams_fastq **
     }
     g->n_reads = (int64_t)m; g->n_bases = g->cum[m]; g->name_bytes = g->name_off[m]; g->comment_bytes = g->comment_off[m];
     auto fail = [&](hipError_t e) { bwams_fastq *p = g.release(); bwams_fastq_close(p); return e; };
-    hipError_t e = hipMalloc(&g->d_enc, (size_t)g->n_bases + 64);
-    if (e == hipSuccess) e = hipMalloc(&g->d_qual, (size_t)g->n_bases + 64);
-    if (e == hipSuccess) e = hipMalloc(&g->d_names, (size_t)g->name_bytes + 64);
-    if (e == hipSuccess) e = hipMalloc(&g->d_comments, (size_t)g->comment_bytes + 64);
+    hipError_t e = dev_malloc(&g->d_enc, (size_t)g->n_bases + 64);
+    if (e == hipSuccess) e = dev_malloc(&g->d_qual, (size_t)g->n_bases + 64);
+    if (e == hipSuccess) e = dev_malloc(&g->d_names, (size_t)g->name_bytes + 64);
+    if (e == hipSuccess) e = dev_malloc(&g->d_comments, (size_t)g->comment_bytes + 64);
     if (e != hipSuccess) { BWAMS_HIP(fail(e)); }
     std::vector<SegMove> mv;
     mv.reserve(4 * m);
@@ -348,10 +348,10 @@ int fastq_interleave(bwams_fastq *f1, bwams_fastq *f2, bwams_fastq **out) {
         g->comment_off[k + 1] = g->comment_off[k] + (f->comment_off[r + 1] - f->comment_off[r]);
     }
     g->n_reads = (int64_t)m; g->n_bases = g->cum[m]; g->name_bytes = g->name_off[m]; g->comment_bytes = g->comment_off[m];
-    hipError_t e = hipMalloc(&g->d_enc, (size_t)g->n_bases + 64);
-    if (e == hipSuccess) e = hipMalloc(&g->d_qual, (size_t)g->n_bases + 64);
-    if (e == hipSuccess) e = hipMalloc(&g->d_names, (size_t)g->name_bytes + 64);
-    if (e == hipSuccess) e = hipMalloc(&g->d_comments, (size_t)g->comment_bytes + 64);
+    hipError_t e = dev_malloc(&g->d_enc, (size_t)g->n_bases + 64);
+    if (e == hipSuccess) e = dev_malloc(&g->d_qual, (size_t)g->n_bases + 64);
+    if (e == hipSuccess) e = dev_malloc(&g->d_names, (size_t)g->name_bytes + 64);
+    if (e == hipSuccess) e = dev_malloc(&g->d_comments, (size_t)g->comment_bytes + 64);
     if (e != hipSuccess) { bwams_fastq_close(g.release()); BWAMS_HIP(e); }
     std::vector<SegMove> mv;
     mv.reserve(4 * m);
@@ -394,7 +394,7 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     void *d_own = nullptr;
     if (on_dev) d_text = const_cast<char *>(text);
     else {
-        BWAMS_HIP(hipMalloc(&d_own, (size_t)n_bytes + 16));
+        BWAMS_HIP(dev_malloc(&d_own, (size_t)n_bytes + 16));
         d_text = reinterpret_cast<char *>(d_own);
         if (n_bytes) BWAMS_HIP(hipMemcpy(d_text, text, (size_t)n_bytes, hipMemcpyHostToDevice));
     }
@@ -406,7 +406,7 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     BWAMS_HIP(hipEventRecord(e0, st));
     // (1) line ends
     int64_t *d_ends = nullptr, *d_cnt = nullptr;
-    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_cnt), 64)); scr.p.push_back(d_cnt);
+    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_cnt), 64)); scr.p.push_back(d_cnt);
     int64_t n_nl = 0;
     char last = '\n';
     if (n_bytes) {
@@ -418,10 +418,10 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
         size_t tb = 0;
         rocprim::counting_iterator<int64_t> it(0);
         IsLineEnd pred{d_text};
-        BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_ends), (size_t)(n_nl + 16) * 8)); scr.p.push_back(d_ends);
+        BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_ends), (size_t)(n_nl + 16) * 8)); scr.p.push_back(d_ends);
         BWAMS_HIP(rocprim::select(nullptr, tb, it, d_ends, d_cnt, (size_t)n_bytes, pred, st));
         void *d_tmp = nullptr;
-        BWAMS_HIP(hipMalloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
+        BWAMS_HIP(dev_malloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
         std::vector<char> tail(1);
         BWAMS_HIP(hipMemcpy(tail.data(), d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost));
         last = tail[0];
@@ -434,20 +434,20 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     if (n_bytes) BWAMS_HIP(hipMemcpy(&first, d_text, 1, hipMemcpyDeviceToHost));
     const bool fasta = n_bytes && first == '>';
     unsigned long long *d_bad = nullptr;
-    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_bad), 64)); scr.p.push_back(d_bad);
+    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_bad), 64)); scr.p.push_back(d_bad);
     BWAMS_HIP(hipMemsetAsync(d_bad, 0, 16, st));
     int64_t n = 0;
     int64_t *d_hdr = nullptr;
     if (fasta) {
         // the records: the lines that start with '>'; no line may start with '+' or '@'
         fasta_check_kernel<<<(unsigned)((n_lines + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_bad);
-        BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_hdr), (size_t)(n_lines + 16) * 8)); scr.p.push_back(d_hdr);
+        BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_hdr), (size_t)(n_lines + 16) * 8)); scr.p.push_back(d_hdr);
         size_t tb = 0;
         rocprim::counting_iterator<int64_t> it(0);
         IsHeaderLine pred{d_text, d_ends, n_nl, n_bytes};
         BWAMS_HIP(rocprim::select(nullptr, tb, it, d_hdr, d_cnt, (size_t)n_lines, pred, st));
         void *d_tmp = nullptr;
-        BWAMS_HIP(hipMalloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
+        BWAMS_HIP(dev_malloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
         BWAMS_HIP(rocprim::select(d_tmp, tb, it, d_hdr, d_cnt, (size_t)n_lines, pred, st));
         unsigned long long bad0 = 0;
         BWAMS_HIP(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, st));
@@ -468,16 +468,16 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     // (2) measure + validate
     Rec *d_rec = nullptr;
     int64_t *d_wide = nullptr, *d_offs = nullptr;
-    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_rec), (size_t)n1 * sizeof(Rec))); scr.p.push_back(d_rec);
-    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_wide), (size_t)n1 * 3 * 8)); scr.p.push_back(d_wide);
-    BWAMS_HIP(hipMalloc(reinterpret_cast<void **>(&d_offs), (size_t)n1 * 3 * 8)); scr.p.push_back(d_offs);
+    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_rec), (size_t)n1 * sizeof(Rec))); scr.p.push_back(d_rec);
+    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_wide), (size_t)n1 * 3 * 8)); scr.p.push_back(d_wide);
+    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_offs), (size_t)n1 * 3 * 8)); scr.p.push_back(d_offs);
     if (fasta) fasta_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_hdr, n, d_rec, d_wide);
     else fastq_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n, d_rec, d_wide, d_bad);
     for (int row = 0; row < 3; ++row) {
         size_t tb = 0;
         BWAMS_HIP(rocprim::exclusive_scan(nullptr, tb, d_wide + row * n1, d_offs + row * n1, (int64_t)0, (size_t)n1, rocprim::plus<int64_t>(), st));
         void *d_tmp = nullptr;
-        BWAMS_HIP(hipMalloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
+        BWAMS_HIP(dev_malloc(&d_tmp, tb + 16)); scr.p.push_back(d_tmp);
         BWAMS_HIP(rocprim::exclusive_scan(d_tmp, tb, d_wide + row * n1, d_offs + row * n1, (int64_t)0, (size_t)n1, rocprim::plus<int64_t>(), st));
     }
     f->cum.resize((size_t)n1); f->name_off.resize((size_t)n1); f->comment_off.resize((size_t)n1);
@@ -494,10 +494,10 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     f->has_qual = !fasta;
     f->n_reads = n; f->n_bases = f->cum[(size_t)n]; f->name_bytes = f->name_off[(size_t)n]; f->comment_bytes = f->comment_off[(size_t)n];
     // (3) emit
-    BWAMS_HIP(hipMalloc(&f->d_enc, (size_t)f->n_bases + 64));
-    BWAMS_HIP(hipMalloc(&f->d_qual, (size_t)f->n_bases + 64));
-    BWAMS_HIP(hipMalloc(&f->d_names, (size_t)f->name_bytes + 64));
-    BWAMS_HIP(hipMalloc(&f->d_comments, (size_t)f->comment_bytes + 64));
+    BWAMS_HIP(dev_malloc(&f->d_enc, (size_t)f->n_bases + 64));
+    BWAMS_HIP(dev_malloc(&f->d_qual, (size_t)f->n_bases + 64));
+    BWAMS_HIP(dev_malloc(&f->d_names, (size_t)f->name_bytes + 64));
+    BWAMS_HIP(dev_malloc(&f->d_comments, (size_t)f->comment_bytes + 64));
     if (n) {
         int64_t blocks = (n + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;

@@ -304,7 +304,7 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) {
         if (p) { (void)hipFree(p); p = nullptr; }
-        return hipMalloc(&p, bytes ? bytes : 8);
+        return dev_malloc(&p, bytes ? bytes : 8);
     }
     void release() { if (p) { (void)hipFree(p); p = nullptr; } }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }

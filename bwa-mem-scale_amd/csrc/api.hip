@@ -515,7 +515,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk, b->d_ert_redo};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk, b->d_ert_redo, b->d_bwd_items, b->d_bwd_ent};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -601,6 +601,18 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
         b->prev_cap = cap;
         b->prev_threads = threads;
     }
+    // backward phases with long interval lists (smem_bwd_wave_kernel): a slot per read and eight list entries per read cover
+    // what uniform and repeat-rich genomes produce several times over; when they are full a pivot simply stays on its lane
+    const int64_t bi = std::max<int64_t>(nseq, 4096), be = std::max<int64_t>(nseq, 4096) * 8;
+    if (bi > b->bwd_items_cap) {
+        if (b->d_bwd_items) (void)hipFree(b->d_bwd_items);
+        if (b->d_bwd_ent) (void)hipFree(b->d_bwd_ent);
+        b->d_bwd_items = nullptr; b->d_bwd_ent = nullptr; b->bwd_items_cap = b->bwd_ent_cap = 0;
+        BWAMS_HIP(dev_malloc(&b->d_bwd_items, (size_t)bi * sizeof(BwdItem)));
+        BWAMS_HIP(dev_malloc(&b->d_bwd_ent, (size_t)be * 16));
+        b->bwd_items_cap = bi;
+        b->bwd_ent_cap = be;
+    }
     return BWAMS_OK;
 }
 
@@ -649,6 +661,18 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     a.prev = b->d_prev;
     a.prev_cap = b->prev_cap;
     a.prev_threads = b->prev_threads;
+    a.bwd_items = b->d_bwd_items;
+    a.bwd_ent = b->d_bwd_ent;
+    a.bwd_items_cap = b->bwd_items_cap;
+    a.bwd_ent_cap = b->bwd_ent_cap;
+    {   // hand-over thresholds (fmi_seed.hip, bwd_hand_over; profiles/r03_notes.md 86): 40 entries at the forward end, or 8 still alive
+        // after 24 columns; BWAMS_BWD_MIN_LIST=0: every backward phase stays on its lane
+        const char *ml = getenv("BWAMS_BWD_MIN_LIST");       // read per call: the tests lower them so that toy genomes reach the wave kernel
+        const char *mc = getenv("BWAMS_BWD_COLS"), *mt = getenv("BWAMS_BWD_LATE_LIST");
+        a.bwd_min_list = ml ? atoi(ml) : 40;
+        a.bwd_cols = mc ? atoi(mc) : 24;
+        a.bwd_late_list = mt ? atoi(mt) : 8;
+    }
     const int split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
 
     // events: 0 start | 8,9 round-1 kernel | 10,11 round-2 kernel | 12,13 round-3 kernel | 3 rounds done
@@ -658,6 +682,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     launch_mark(b->d_ctr, 0, st);
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
     if (b->nseq > 0) launch_smem_round1(a, b->cu_count, st);
+    if (b->nseq > 0) launch_smem_bwd_wave(a, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[9], st));
     launch_mark(b->d_ctr, 1, st);
     if (b->nseq > 0) launch_round2_work(a, b->d_work2, b->pool_cap, split_len, opt->split_width, b->cu_count, st);
@@ -679,6 +704,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     }
     BWAMS_HIP(hipEventRecord(b->ev[10], st));
     if (b->nseq > 0) launch_smem_round2(a, b->d_work2, b->cu_count, st);
+    if (b->nseq > 0) launch_smem_bwd_wave(a, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[11], st));
     if (r3 && r3_beside) BWAMS_HIP(hipStreamWaitEvent(st, b->seed_join, 0));
     launch_mark(b->d_ctr, 2, st);
@@ -693,6 +719,14 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     // the SMEM count sizes the sort: one small read-back
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
+#ifdef BWAMS_BWDDBG
+    if (getenv("BWAMS_VERBOSE")) {
+        const unsigned long long *d = b->h_ctr->dbg;
+        fprintf(stderr, "[bwd_wave] rounds 1+2: items %llu, column batches %llu (%.1f per item), waves with work %llu: busy mean %.3f ms max %.3f ms, "
+                "of it between items (ticket, item, list, read) %.1f %%, per column batch %.2f us\n", d[0], d[1], d[0] ? (double)d[1] / d[0] : 0.0, d[5],
+                d[5] ? d[2] / (double)d[5] * 1e-5 : 0.0, d[4] * 1e-5, d[2] ? 100.0 * d[3] / d[2] : 0.0, d[1] ? (d[2] - d[3]) * 1e-2 / d[1] : 0.0);
+    }
+#endif
     const int64_t n_slots = (int64_t)b->h_ctr->n_smem_total;      // pool slots handed out (holes included)
     const int64_t n = (int64_t)b->h_ctr->n_smem_valid;           // real SMEMs
     b->n_smem = n;

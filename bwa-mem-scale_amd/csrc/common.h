@@ -110,6 +110,7 @@ struct DevCounters {
     unsigned long long ert_kmer, ert_nodes, ert_ref;   // ERT profile kernel: k-mer entries read, tree records decoded, text bytes compared
     unsigned long long work_head3, n_ext3, n_blk3, n_smem3;   // SMEM round 3 (it may run beside round 2): its own cursor and counts, folded in by mark_kernel(3)
     unsigned long long n_rest;           // extension: slots behind the requests of the last selection (an upper bound of the undecided seeds)
+    unsigned long long bwd_items, bwd_entries, bwd_ticket;   // SMEM search: backward phases handed to the wave kernel, their list entries, its work cursor
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };
 
@@ -126,6 +127,16 @@ struct Round2Work {
     uint32_t rid;
     int32_t x;
     int32_t min_intv;
+};
+
+// A backward phase handed from the lane-per-read SMEM search to the wave-per-pivot kernel (fmi_seed.hip): the pivot and the
+// interval list its forward phase left, `num_prev` packed 16-byte entries from `off` of the entry buffer (0 = slot not used).
+struct BwdItem {
+    uint32_t rid;
+    int32_t x;
+    int32_t min_intv;
+    int32_t num_prev;
+    int64_t off;
 };
 
 int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint8_t *qer, int w, const SwParams &prm, int qmax,
@@ -225,6 +236,9 @@ struct bwams_batch {
     bwams::DevCounters *h_ctr = nullptr;  // pinned host mirror
     // per-lane scratch of the SMEM search (previous-interval lists)
     uint4 *d_prev = nullptr;
+    bwams::BwdItem *d_bwd_items = nullptr;      // SMEM search: backward phases with long interval lists (wave-per-pivot kernel)
+    uint4 *d_bwd_ent = nullptr;
+    int64_t bwd_items_cap = 0, bwd_ent_cap = 0;
     int64_t prev_threads = 0;
     int prev_cap = 0;
 

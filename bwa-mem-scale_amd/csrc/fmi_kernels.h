@@ -21,6 +21,12 @@ struct SeedLaunch {
     uint4 *prev;                  // per-lane previous-interval lists: prev_cap entries x 16 B, lane-contiguous
     int prev_cap;                 // entries per lane
     int64_t prev_threads;         // lanes the scratch was sized for
+    // backward phases whose interval list has at least bwd_min_list entries go to smem_bwd_wave_kernel (0 = never)
+    BwdItem *bwd_items;
+    uint4 *bwd_ent;
+    int64_t bwd_items_cap, bwd_ent_cap;
+    int bwd_min_list;
+    int bwd_cols, bwd_late_list;  // ... or, later: after bwd_cols columns with bwd_late_list entries still alive
 };
 
 // grid sizing shared by batch_create (scratch) and the launches
@@ -39,6 +45,8 @@ void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st);
 void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
                         int split_width, int cu_count, hipStream_t st);
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st);
+// the backward phases rounds 1 / 2 set aside (lists of bwd_min_list entries and more): one wavefront per pivot, one lane per entry
+void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st);
 // round 3: forward-only seeds (bwtSeedStrategyAllPosOneThread)
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st);
 

@@ -344,6 +344,39 @@ __device__ __forceinline__ void prev_put(const PrevList &pl, int base, int p, in
     else pl.glob[base + p] = a;
 }
 
+__device__ __forceinline__ uint4 prev_raw(const PrevList &pl, int base, int p) {
+    return p < kPrevLds ? pl.ring[ring_slot(base + p) * kBlock] : pl.glob[base + p];
+}
+
+// ---- long interval lists leave the lane ------------------------------------------------------
+// A backward phase costs (entries of the list) x (columns until the list dies) dependent extensions, all of them on one
+// lane.  Measured on the bench reads (profiles/r03_notes.md 86): the forward phases cost 149 extensions per read whatever
+// the read, the backward phases 71 % of the work with a median of 135 extensions, a 99.99th percentile of 1145 and a
+// maximum of 4345 (112 entries x 85 columns) — and the launch ends when the lane holding that pivot does.  The entries of
+// a column are independent extensions (FMI_search.cpp:1529-1590 decides on them in order, but computes them one by one only
+// because it is scalar code), so a pivot whose forward phase leaves `bwd_min_list` entries or more is written out — pivot,
+// min_intv, the packed entries — and its backward phase is run by smem_bwd_wave_kernel, one lane per entry and one memory
+// round trip per column.  The lane moves on to its next pivot at once.  Returns false (nothing handed over: run the
+// backward phase here) when the list is short, too long for the wave kernel's LDS, or the buffers are full.
+constexpr int kBwdMaxList = 256;
+__device__ __forceinline__ bool bwd_hand_over(const SeedLaunch &a, const PrevList &pl, int base, int num_prev, uint32_t rid,
+                                              int x, int min_intv, int min_list) {
+    if (a.bwd_min_list <= 0 || num_prev < min_list || num_prev > kBwdMaxList) return false;
+    const unsigned long long it = atomicAdd(&a.ctr->bwd_items, 1ull);
+    if ((int64_t)it >= a.bwd_items_cap) return false;
+    BwdItem w;
+    w.rid = rid; w.x = x; w.min_intv = min_intv; w.num_prev = 0; w.off = 0;
+    const unsigned long long eo = atomicAdd(&a.ctr->bwd_entries, (unsigned long long)num_prev);
+    const bool fits = (int64_t)(eo + (unsigned long long)num_prev) <= a.bwd_ent_cap;
+    if (fits) {
+        for (int p = 0; p < num_prev; ++p) a.bwd_ent[eo + p] = prev_raw(pl, base, p);
+        w.num_prev = num_prev;
+        w.off = (int64_t)eo;
+    }
+    a.bwd_items[it] = w;                        // num_prev = 0: the slot stays empty
+    return fits;
+}
+
 // ---- FMA table builders --------------------------------------------------------------------
 // One lane per table entry walks its k-mer with plain per-lane block reads (an offline step).
 __device__ __forceinline__ void backward_ext_lane(const DevFmi &f, int64_t k, int64_t l, int64_t s, int a,
@@ -636,10 +669,15 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                 num_prev++;
             }
             base = cap - num_prev;                      // entry p lives at base + p, longest first
-            j = x - 1;
-            p = 0; num_curr = 0; curr_s = -1; first = true;
-            cur_m = x;
-            phase = PH_BWD;
+            if (bwd_hand_over(a, prev, base, num_prev, rid, x, min_intv, a.bwd_min_list)) {
+                x = next_x;
+                phase = ALL_POS ? PH_PIVOT : PH_FETCH;
+            } else {
+                j = x - 1;
+                p = 0; num_curr = 0; curr_s = -1; first = true;
+                cur_m = x;
+                phase = PH_BWD;
+            }
         }
         // ---- backward phase: pre -----------------------------------------------------
         if (phase == PH_BWD && !do_ext) {
@@ -689,10 +727,15 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     num_prev++;
                 }
                 base = cap - num_prev;
-                j = x - 1;
-                p = 0; num_curr = 0; curr_s = -1; first = true;
-                cur_m = x;
-                phase = PH_BWD;
+                if (bwd_hand_over(a, prev, base, num_prev, rid, x, min_intv, a.bwd_min_list)) {
+                    x = next_x;
+                    phase = ALL_POS ? PH_PIVOT : PH_FETCH;
+                } else {
+                    j = x - 1;
+                    p = 0; num_curr = 0; curr_s = -1; first = true;
+                    cur_m = x;
+                    phase = PH_BWD;
+                }
             }
         } else if (do_ext && phase == PH_BWD) {
             bool keep = false;
@@ -721,11 +764,147 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     cur_m = j;
                     j--;
                     p = 0; num_curr = 0; curr_s = -1; first = true;
+                    // a backward phase that has proven long: the rest of it goes to the wave kernel (which resumes at column cur_m - 1)
+                    if (x - cur_m == a.bwd_cols && bwd_hand_over(a, prev, base, num_prev, rid, cur_m, min_intv, a.bwd_late_list)) {
+                        x = next_x;
+                        phase = ALL_POS ? PH_PIVOT : PH_FETCH;
+                    }
                 }
             }
         }
         wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
     }
+    wave_emit_finish(a, wo);
+    flush_counters(a.ctr, n_ext, n_blk);
+}
+
+// The backward phase of one pivot per wavefront (see bwd_hand_over): the list lives in LDS, lane p of a batch of 64 owns entry
+// p, every column is one cooperative extension of all entries followed by the reference's in-order decisions
+// (FMI_search.cpp:1529-1590) taken with ballots:
+//   * while nothing has been kept or emitted in this column (`first`), the first entry that either dies long enough
+//     (ns < min_intv, length >= min_seed_len: it is an SMEM) or survives (ns >= min_intv) settles it;
+//   * a surviving entry is kept unless its size equals the 32-bit `curr_s` of the last entry kept — which, entries being
+//     dropped only when they equal it, is the truncated size of the closest surviving entry before it.
+// Kept entries are compacted to the front of the list (writes land below the batch being read).  Extensions and blocks are
+// counted as the lane-per-read kernel counts them.
+constexpr int kBwdItemsPerTicket = 4;
+__global__ __launch_bounds__(kBlock) void smem_bwd_wave_kernel(SeedLaunch a) {
+    const DevFmi &f = a.fmi;
+    extern __shared__ uint32_t lds_reads[];
+    const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+    uint4 *const lst = reinterpret_cast<uint4 *>(lds_reads) + wv * kBwdMaxList;
+    uint32_t *const rd = lds_reads + (kBlock / 64) * kBwdMaxList * 4 + wv * a.read_w;
+    ReadView rv;
+    rv.lds_col = nullptr;
+    rv.gl = rd;
+    rv.cw = a.read_cw;
+    unsigned long long n_items = a.ctr->bwd_items;
+    if ((int64_t)n_items > a.bwd_items_cap) n_items = (unsigned long long)a.bwd_items_cap;
+    unsigned long long n_ext = 0, n_blk = 0;
+    WaveOut wo;
+    wo.base = -1; wo.used = 0; wo.emitted = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#ifdef BWAMS_BWDDBG
+    const unsigned long long tk_start = wall_clock64();
+    unsigned long long d_items = 0, d_cols = 0, d_setup = 0, tk_last = tk_start;
+#endif
+
+    for (;;) {
+        const unsigned long long t0 = wave_ticket(&a.ctr->bwd_ticket, (unsigned long long)kBwdItemsPerTicket);
+        if (t0 >= n_items) break;
+        for (unsigned long long t = t0; t < t0 + kBwdItemsPerTicket && t < n_items; ++t) {
+            const BwdItem it = a.bwd_items[t];
+            int num_prev = it.num_prev;
+            if (num_prev == 0) continue;
+            const uint32_t rid = it.rid;
+            const int min_intv = it.min_intv;
+            for (int p = lane; p < num_prev; p += 64) lst[p] = a.bwd_ent[it.off + p];
+            for (int w = lane; w < a.read_w; w += 64) rd[w] = a.packed[(int64_t)rid * a.read_w + w];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int j = it.x - 1, cur_m = it.x;      // a pivot's first column, or the column a lane stopped in front of: x is the last position matched
+#ifdef BWAMS_BWDDBG
+            d_items++;
+            const unsigned long long tk_a = wall_clock64();
+#endif
+            for (;;) {
+                int ba = 4;
+                if (num_prev != 0 && j >= 0) ba = base_at(rv, j);
+                if (ba >= 4) {                              // the pivot is left (PH_BWD_END of the lane kernel)
+                    bool em = false;
+                    int64_t qk = 0, ql = 0, qs = 0;
+                    int qn = 0;
+                    if (num_prev != 0) {
+                        prev_unpack(lst[0], qk, ql, qs, qn);
+                        em = lane == 0 && qn - cur_m + 1 >= a.min_seed_len;
+                    }
+                    wave_emit(a, wo, em, rid, (uint32_t)cur_m, (uint32_t)qn, qk, ql, qs);
+                    break;
+                }
+                bool first = true;
+                int32_t curr_s = -1;                        // (int32_t) size of the closest surviving entry so far
+                int num_curr = 0;
+                for (int b = 0; b < num_prev; b += 64) {
+#ifdef BWAMS_BWDDBG
+                    d_cols++;
+#endif
+                    const int p = b + lane;
+                    const bool need = p < num_prev;
+                    int64_t pk = 0, pl = 0, ps = 0, nk = 0, nl = 0, ns = 0;
+                    int pn = 0;
+                    if (need) prev_unpack(lst[p], pk, pl, ps, pn);
+                    backward_ext_coop(f, need, pk, pl, ps, ba, nk, nl, ns);
+                    if (need) {
+                        n_ext++;
+                        n_blk += ((pk >> 6) == ((pk + ps) >> 6)) ? 1 : 2;
+                    }
+                    const bool alive = need && ns >= min_intv;
+                    const bool dies_long = need && ns < min_intv && (pn - cur_m + 1) >= a.min_seed_len;
+                    const unsigned long long m_alive = __ballot(alive);
+                    bool em = false;
+                    if (first) {
+                        const unsigned long long m_dies = __ballot(dies_long);
+                        if (m_alive | m_dies) {
+                            const int fa = m_alive ? __ffsll((long long)m_alive) - 1 : 64;
+                            const int fd = m_dies ? __ffsll((long long)m_dies) - 1 : 64;
+                            em = fd < fa && lane == fd;
+                            first = false;
+                        }
+                    }
+                    wave_emit(a, wo, em, rid, (uint32_t)cur_m, (uint32_t)pn, pk, pl, ps);
+                    // size of the closest surviving entry before this one (this batch, else the carry)
+                    const unsigned long long lower = m_alive & below;
+                    const int src = lower ? 63 - __clzll((long long)lower) : lane;
+                    const int32_t s_here = (int32_t)ns;
+                    const int32_t s_src = __shfl(s_here, src);          // by every lane: a source lane inside a branch not taken reads as 0
+                    const int32_t s_before = lower ? s_src : curr_s;
+                    const bool keep = alive && ns != (int64_t)s_before;
+                    const unsigned long long m_keep = __ballot(keep);
+                    __builtin_amdgcn_wave_barrier();        // every lane has read its entry before the compaction writes
+                    if (keep) lst[num_curr + __popcll(m_keep & below)] = prev_pack(nk, nl, ns, pn);
+                    num_curr += __popcll(m_keep);
+                    if (m_alive) curr_s = __shfl(s_here, 63 - __clzll((long long)m_alive));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                num_prev = num_curr;
+                if (num_curr == 0) break;                   // nothing survived: PH_BWD_END with an empty list emits nothing
+                cur_m = j;
+                j--;
+            }
+#ifdef BWAMS_BWDDBG
+            { const unsigned long long tk_b = wall_clock64(); d_setup += tk_a - tk_last; tk_last = tk_b; }
+#endif
+        }
+    }
+#ifdef BWAMS_BWDDBG
+    if (lane == 0 && d_items) {
+        const unsigned long long busy = tk_last - tk_start;
+        atomicAdd(&a.ctr->dbg[0], d_items); atomicAdd(&a.ctr->dbg[1], d_cols); atomicAdd(&a.ctr->dbg[2], busy);
+        atomicAdd(&a.ctr->dbg[3], d_setup); atomicMax(&a.ctr->dbg[4], busy); atomicAdd(&a.ctr->dbg[5], 1ull);
+        atomicMax(&a.ctr->dbg[6], tk_last); atomicMin(&a.ctr->dbg[7], tk_start);
+    }
+#endif
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
@@ -765,6 +944,7 @@ __global__ void mark_kernel(DevCounters *ctr, int which) {
         ctr->blk_after[which - 1] = ctr->n_ext_blocks;
     }
     ctr->work_head = 0;
+    ctr->bwd_items = ctr->bwd_entries = ctr->bwd_ticket = 0;
     if (which != 2) ctr->work_head3 = 0;       // (mark 2 may run while round 3 is in flight on its own stream... it has joined; kept for symmetry)
 }
 
@@ -959,6 +1139,13 @@ void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap,
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     // the number of items is only known on the device: launch the persistent grid at chip size
     smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+}
+
+void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st) {
+    if (a.bwd_min_list <= 0) return;
+    // the number of items is only known on the device; waves without an item leave at their first ticket
+    const size_t lds = (size_t)(kBlock / 64) * (kBwdMaxList * 16 + (size_t)a.read_w * 4);
+    smem_bwd_wave_kernel<<<cu_count * 8, kBlock, lds, st>>>(a);
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {

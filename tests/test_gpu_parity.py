@@ -54,6 +54,37 @@ def test_smem_and_sa_match_oracle(gpu_toy):
     assert list(st.n_smem) == list(ctr.n_smem)
 
 
+@pytest.mark.parametrize("env", [
+    {"BWAMS_BWD_MIN_LIST": "1"},                                                       # every backward phase on the wave kernel
+    {"BWAMS_BWD_MIN_LIST": "5", "BWAMS_BWD_COLS": "4", "BWAMS_BWD_LATE_LIST": "2"},     # at the forward end, or four columns in
+    {"BWAMS_BWD_MIN_LIST": "200", "BWAMS_BWD_COLS": "2", "BWAMS_BWD_LATE_LIST": "1"},   # only ever two columns in
+    {"BWAMS_BWD_MIN_LIST": "0"},                                                       # never
+])
+def test_backward_phases_handed_to_the_wave_kernel(gpu_toy, monkeypatch, env):
+    """Long interval lists leave the lane-per-read search (fmi_seed.hip, bwd_hand_over): a toy genome's lists never reach the
+    production thresholds, so the thresholds come down to where every pivot (or every pivot a few columns in) takes that path.
+    Repeat-rich reads and poly-A give lists beyond one batch of 64 entries; SMEMs, SA coordinates and the event counts stay exact."""
+    g, idx, ix = gpu_toy
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    reads, _, _ = simulate.make_reads(g, 3000, seed=21)
+    reads = list(reads)
+    rng = np.random.default_rng(4)
+    for L in (150, 400, 1000):
+        st = int(rng.integers(0, len(g) - 1100))
+        reads.append(g[st:st + L].copy())
+    reads.append(np.zeros(120, np.uint8))
+    reads.append(np.tile(np.array([0, 1], np.uint8), 100))
+    ctr = loader.Counters()
+    want, wcoord, woff, got, coord, off, st = _seed_both(idx, ix, reads, {"min_seed_len": 12}, oracle_counters=ctr)
+    assert len(got) == len(want)
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(off, woff) and np.array_equal(coord, wcoord)
+    assert st.n_ext == ctr.n_ext and st.n_ext_blocks == ctr.n_ext_blocks
+    assert list(st.n_smem) == list(ctr.n_smem)
+
+
 @pytest.mark.parametrize("opt", [
     {"min_seed_len": 10}, {"max_mem_intv": 0}, {"split_width": 50, "split_factor": 1.0},
     {"max_occ": 3}, {"min_seed_len": 30, "max_mem_intv": 5},

@@ -725,6 +725,13 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
         fprintf(stderr, "[bwd_wave] rounds 1+2: items %llu, column batches %llu (%.1f per item), waves with work %llu: busy mean %.3f ms max %.3f ms, "
                 "of it between items (ticket, item, list, read) %.1f %%, per column batch %.2f us\n", d[0], d[1], d[0] ? (double)d[1] / d[0] : 0.0, d[5],
                 d[5] ? d[2] / (double)d[5] * 1e-5 : 0.0, d[4] * 1e-5, d[2] ? 100.0 * d[3] / d[2] : 0.0, d[1] ? (d[2] - d[3]) * 1e-2 / d[1] : 0.0);
+        const unsigned long long t0 = ~d[8], tdry = ~d[9];
+        fprintf(stderr, "[smem_r1] waves %llu: read queue dry at %.3f ms, last wave out at %.3f ms, mean wave life %.3f ms (%.3f ms of it after the queue ran dry); "
+                "iterations %llu, lanes extending per iteration %.1f\n", d[12], (tdry - t0) * 1e-5, (d[10] - t0) * 1e-5, d[12] ? d[11] * 1e-5 / d[12] : 0.0,
+                d[12] ? d[15] * 1e-5 / d[12] : 0.0, d[13], d[13] ? (double)d[14] / d[13] : 0.0);
+        fprintf(stderr, "[smem_r1] waves leaving per 0.4 ms:");
+        for (int i = 0; i < 48; ++i) if (d[16 + i]) fprintf(stderr, " %.1f:%llu", i * 0.4, d[16 + i]);
+        fprintf(stderr, "\n[smem_r1] wave-iterations after the wave first saw the queue dry: %llu, with one lane extending %llu (max per wave %llu), with 2-4 lanes %llu\n", d[64], d[65], d[67], d[66]);
     }
 #endif
     const int64_t n_slots = (int64_t)b->h_ctr->n_smem_total;      // pool slots handed out (holes included)

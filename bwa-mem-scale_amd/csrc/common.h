@@ -104,7 +104,7 @@ struct DevCounters {
     unsigned long long dedup_heavy, dedup_ticket, dedup_light;   // dedup: reads for the wave tier, its work cursor, reads for the lane tier
     unsigned long long chain_redo, chain_redo_ticket;   // chaining: reads the ordered-array attempt gave up on, work cursor
     unsigned long long pair_heavy, pair_ticket;   // mem_mark_primary_se: reads of the wave tier, its work cursor
-    unsigned long long dbg[16];          // diagnostics printed under BWAMS_VERBOSE (chain_heavy_kernel: size histogram, cycles)
+    unsigned long long dbg[80];          // diagnostics printed under BWAMS_VERBOSE (chain_heavy_kernel: size histogram, cycles)
     unsigned long long pair_ticket2;     // mem_mark_primary_se: work cursor of the wave tier's small-LDS instance
     unsigned long long dedup_ticket2, dedup_ticket3;    // dedup: work cursors of the wave tier's smaller instances
     unsigned long long ert_kmer, ert_nodes, ert_ref;   // ERT profile kernel: k-mer entries read, tree records decoded, text bytes compared

@@ -197,20 +197,36 @@ __device__ __forceinline__ int64_t cnt_at(const DevFmi &f, int i) {
 // Work tickets: a wave reserves kTicketChunk item indices with ONE atomic and hands them to its
 // lanes as they finish (ballot-ranked); a lane that finds the reservation empty retries in the
 // next iteration.  (One atomic per item on a single word tops out near 90 M/s.)
+//
+// `guided` (round 1): the reservation shrinks towards the end of the queue.  A wave that took the last 64 reads just before the
+// queue ran dry keeps 63 of them for its own lanes while its neighbours leave; a reservation of what is left, shared among
+// all waves twice over (between kMinTicketChunk and 64; `seen` is the cursor after the wave's previous reservation, a stale
+// but safe estimate), ends round 1 0.7 ms earlier (profiles/r03_notes.md 87).  Rounds 2 and 3 keep 64: their items are a
+// third of a read's work, every reservation is an atomic round trip the whole wave waits for, and the same rule cost them
+// 1.0 and 1.4 ms.
 constexpr int kTicketChunk = 64;
+#ifndef BWAMS_MIN_TICKET_CHUNK
+#define BWAMS_MIN_TICKET_CHUNK 2
+#endif
+constexpr int kMinTicketChunk = BWAMS_MIN_TICKET_CHUNK;
 struct WaveTickets {
     unsigned long long next;   // wave-uniform
     int left;                  // wave-uniform
+    unsigned long long seen;   // wave-uniform: the cursor after this wave's last reservation
 };
 // MUST be called by all 64 lanes.  Returns true and sets `ticket` for the lanes that were served.
 __device__ __forceinline__ bool take_ticket(unsigned long long *head, WaveTickets &wt, bool want,
-                                            unsigned long long &ticket) {
+                                            unsigned long long &ticket, int64_t n_items, bool guided) {
     const unsigned long long m = __ballot(want);
     if (!m) return false;
     const int lane = (int)(threadIdx.x & 63);
     if (wt.left == 0) {
-        wt.next = wave_ticket(head, (unsigned long long)kTicketChunk);   // out of line: see wave_ops.h
-        wt.left = kTicketChunk;
+        const long long rem = (long long)n_items - (long long)wt.seen;
+        const long long share = rem / (2ll * (long long)gridDim.x * (kBlock / 64));
+        const int chunk = !guided || share >= kTicketChunk ? kTicketChunk : share <= kMinTicketChunk ? kMinTicketChunk : (int)share;
+        wt.next = wave_ticket(head, (unsigned long long)chunk);          // out of line: see wave_ops.h
+        wt.left = chunk;
+        wt.seen = wt.next + (unsigned long long)chunk;
     }
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
     const int cnt = __popcll(m);
@@ -359,6 +375,7 @@ __device__ __forceinline__ uint4 prev_raw(const PrevList &pl, int base, int p) {
 // round trip per column.  The lane moves on to its next pivot at once.  Returns false (nothing handed over: run the
 // backward phase here) when the list is short, too long for the wave kernel's LDS, or the buffers are full.
 constexpr int kBwdMaxList = 256;
+constexpr int kPivotQueue = 64;            // per wavefront, power of two (smem_search_kernel<true>)
 __device__ __forceinline__ bool bwd_hand_over(const SeedLaunch &a, const PrevList &pl, int base, int num_prev, uint32_t rid,
                                               int x, int min_intv, int min_list) {
     if (a.bwd_min_list <= 0 || num_prev < min_list || num_prev > kBwdMaxList) return false;
@@ -518,7 +535,17 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
     rv.gl = a.packed;
     rv.cw = a.read_cw;
     const int64_t n_work = ALL_POS ? a.nseq : (int64_t)a.ctr->n_work2;
+    // round 1: the wave's queue of pivots waiting for a lane (see the push at the end of the loop body)
+    uint2 *const pq = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(lds_reads + (a.reads_in_lds ? a.read_w * kBlock : 0)) +
+                                                kPrevLds * kBlock) + (threadIdx.x >> 6) * kPivotQueue;
+    int pq_head = 0, pq_n = 0;                // wave-uniform
+    bool spawned = false;                     // this lane's read goes on in another lane: leave the read after this pivot
+    const unsigned long long lanes_below = (1ull << (threadIdx.x & 63)) - 1ull;
 
+#ifdef BWAMS_BWDDBG
+    const unsigned long long tk_start = wall_clock64();
+    unsigned long long tk_dry = 0, n_iter = 0, n_act = 0, n_tail = 0, n_single = 0, n_few = 0;
+#endif
     int phase = PH_FETCH;
     uint32_t rid = 0;
     int64_t qoff = 0;
@@ -534,7 +561,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
     WaveOut wo;
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
-    wt.next = 0; wt.left = 0;
+    wt.next = 0; wt.left = 0; wt.seen = 0;
     BlkCache bc;
     bc.a0 = bc.a1 = bc.a2 = bc.a3 = bc.b0 = bc.b1 = bc.b2 = bc.b3 = make_uint4(0, 0, 0, 0);
     bc.ta = bc.tb = -1;
@@ -555,21 +582,48 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                 }
             }
             x = next_x;
-            phase = ALL_POS ? PH_PIVOT : PH_FETCH;
+            phase = (ALL_POS && !spawned) ? PH_PIVOT : PH_FETCH;
         }
         wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
         em = false;
+        // ---- a pivot of this wave's queue before a new read ----------------------------
+        if (ALL_POS && pq_n) {
+            const bool idle = phase == PH_FETCH || phase == PH_EXIT;
+            const unsigned long long fm = __ballot(idle);
+            if (fm) {
+                const int rank = __popcll(fm & lanes_below);
+                if (idle && rank < pq_n) {
+                    const uint2 it = pq[(pq_head + rank) & (kPivotQueue - 1)];
+                    rid = it.x;
+                    x = (int)it.y;
+                    min_intv = 1;
+                    spawned = false;
+                    qoff = a.cum[rid];
+                    len = (int)(a.cum[rid + 1] - qoff);
+                    read_take(rv, lds_col, a.packed, a.read_w, rid);
+                    phase = PH_PIVOT;
+                }
+                const int cnt = __popcll(fm);
+                const int n = cnt < pq_n ? cnt : pq_n;
+                pq_head = (pq_head + n) & (kPivotQueue - 1);
+                pq_n -= n;
+            }
+        }
         // ---- take the next work item ------------------------------------------------
         {
             unsigned long long t = 0;
-            if (take_ticket(&a.ctr->work_head, wt, phase == PH_FETCH, t)) {
+            if (take_ticket(&a.ctr->work_head, wt, phase == PH_FETCH, t, n_work, ALL_POS)) {
                 if ((int64_t)t >= n_work) {
                     phase = PH_EXIT;
+#ifdef BWAMS_BWDDBG
+                    if (!tk_dry) tk_dry = wall_clock64();
+#endif
                 } else {
                     if (ALL_POS) {
                         rid = (uint32_t)t;
                         x = 0;
                         min_intv = 1;
+                        spawned = false;
                     } else {
                         const Round2Work wk = work[t];
                         rid = wk.rid;
@@ -584,6 +638,9 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                 }
             }
         }
+#ifdef BWAMS_BWDDBG
+        if (!tk_dry && __any(phase == PH_EXIT)) tk_dry = wall_clock64();
+#endif
         if (__all(phase == PH_EXIT)) break;
 
         // ---- open a pivot -----------------------------------------------------------
@@ -643,7 +700,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
             }
         }
 
-        bool do_ext = false;
+        bool do_ext = false, want_push = false;
         int64_t ek = 0, el = 0, es = 0;
         int ea = 0;
         int64_t pk = 0, pl = 0, ps = 0;
@@ -677,6 +734,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                 p = 0; num_curr = 0; curr_s = -1; first = true;
                 cur_m = x;
                 phase = PH_BWD;
+                want_push = ALL_POS && next_x < len;
             }
         }
         // ---- backward phase: pre -----------------------------------------------------
@@ -705,6 +763,9 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
             n_ext++;
             n_blk += ((ek >> 6) == ((ek + es) >> 6)) ? 1 : 2;
         }
+#ifdef BWAMS_BWDDBG
+        { const int na = __popcll(__ballot(do_ext)); n_iter++; n_act += (unsigned long long)na; if (tk_dry) { n_tail++; if (na <= 1) n_single++; else if (na <= 4) n_few++; } }
+#endif
 
         // ---- post ---------------------------------------------------------------------
         if (do_ext && phase == PH_FWD) {
@@ -735,6 +796,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     p = 0; num_curr = 0; curr_s = -1; first = true;
                     cur_m = x;
                     phase = PH_BWD;
+                    want_push = ALL_POS && next_x < len;
                 }
             }
         } else if (do_ext && phase == PH_BWD) {
@@ -767,13 +829,56 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     // a backward phase that has proven long: the rest of it goes to the wave kernel (which resumes at column cur_m - 1)
                     if (x - cur_m == a.bwd_cols && bwd_hand_over(a, prev, base, num_prev, rid, cur_m, min_intv, a.bwd_late_list)) {
                         x = next_x;
-                        phase = ALL_POS ? PH_PIVOT : PH_FETCH;
+                        phase = (ALL_POS && !spawned) ? PH_PIVOT : PH_FETCH;
                     }
                 }
             }
         }
+        // ---- round 1: the read's next pivot does not wait for this backward phase --------
+        // The pivots of a read are found one after the other (the next one starts where this forward phase ended), but
+        // only the FORWARD phases depend on each other: once next_x is known the backward phase of this pivot and the
+        // whole next pivot are independent work.  The lane keeps the backward phase and leaves (rid, next_x) in its
+        // wave's queue (LDS, kPivotQueue entries); any lane of the wave that runs out of work takes it before a new
+        // read.  A read with seven pivots — a third of the bench reads, 70 % of the work — then occupies several lanes
+        // for the length of its forward phases plus one backward phase instead of one lane for the sum of all of them,
+        // which is what the launch's tail was made of.  A full queue just means the lane goes on with the read itself.
+        if (ALL_POS) {
+            const unsigned long long pm = __ballot(want_push);
+            if (pm) {
+                const int rank = __popcll(pm & lanes_below);
+                const int space = kPivotQueue - pq_n;
+                if (want_push && rank < space) {
+                    pq[(pq_head + pq_n + rank) & (kPivotQueue - 1)] = make_uint2(rid, (uint32_t)next_x);
+                    spawned = true;
+                }
+                const int cnt = __popcll(pm);
+                pq_n += cnt < space ? cnt : space;
+            }
+        }
         wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
     }
+#ifdef BWAMS_BWDDBG
+    if (ALL_POS && (threadIdx.x & 63) == 0) {
+        const unsigned long long tk_end = wall_clock64();
+        unsigned long long dry = 0;
+        for (int l = 0; l < 64; ++l) { const unsigned long long v = __shfl(tk_dry, l); if (v && (!dry || v < dry)) dry = v; }
+        atomicMax(&a.ctr->dbg[8], ~tk_start);                // earliest start
+        if (dry) atomicMax(&a.ctr->dbg[9], ~dry);            // first time the read queue was found empty
+        atomicMax(&a.ctr->dbg[10], tk_end);                  // last wave out
+        atomicAdd(&a.ctr->dbg[11], tk_end - tk_start);       // wave-time
+        atomicAdd(&a.ctr->dbg[12], 1ull);
+        atomicAdd(&a.ctr->dbg[13], n_iter); atomicAdd(&a.ctr->dbg[14], n_act);
+        if (dry) atomicAdd(&a.ctr->dbg[15], tk_end - dry);   // wave-time after the queue ran dry
+        {
+            const unsigned long long t0 = ~a.ctr->dbg[8];
+            int bin = (int)((tk_end - t0) / 40000ull);            // 0.4 ms bins
+            if (bin > 47) bin = 47;
+            atomicAdd(&a.ctr->dbg[16 + bin], 1ull);
+            atomicAdd(&a.ctr->dbg[64], n_tail); atomicAdd(&a.ctr->dbg[65], n_single); atomicAdd(&a.ctr->dbg[66], n_few);
+            atomicMax(&a.ctr->dbg[67], n_single);
+        }
+    }
+#endif
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
@@ -966,12 +1071,12 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
     WaveOut wo;
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
-    wt.next = 0; wt.left = 0;
+    wt.next = 0; wt.left = 0; wt.seen = 0;
 
     while (true) {
         {
             unsigned long long t = 0;
-            if (take_ticket(&a.ctr->work_head3, wt, phase == PH_FETCH, t)) {
+            if (take_ticket(&a.ctr->work_head3, wt, phase == PH_FETCH, t, a.nseq, false)) {
                 if ((int64_t)t >= a.nseq) {
                     phase = PH_EXIT;
                 } else {
@@ -1106,7 +1211,7 @@ int grid_for(int64_t n_items, int cu_count) {
 }  // namespace
 
 static size_t lds_bytes(const SeedLaunch &a) { return a.reads_in_lds ? (size_t)a.read_w * kBlock * 4 : 0; }
-static size_t lds_bytes_search(const SeedLaunch &a) { return lds_bytes(a) + (size_t)kPrevLds * kBlock * 16; }
+static size_t lds_bytes_search(const SeedLaunch &a) { return lds_bytes(a) + (size_t)kPrevLds * kBlock * 16 + (size_t)(kBlock / 64) * kPivotQueue * 8; }
 
 void launch_pack_reads(const uint8_t *enc, const int64_t *cum, int64_t nseq, int W, int cw, uint32_t *packed,
                        hipStream_t st) {

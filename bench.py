@@ -870,7 +870,7 @@ def main():
                 "algorithmic_bytes": round(all_bytes / CHn, 1),
             },
             "roofline": {
-                "kernel": "smem_search_kernel<ALL_POS> (SMEM round 1)",
+                "kernel": "smem_search_kernel<ALL_POS> + smem_bwd_wave_kernel (SMEM round 1: the lane-per-read search and the wave-per-pivot kernel for the backward phases it hands over; launch_ms brackets both)",
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,

@@ -18,6 +18,7 @@ bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
 def short(k):
     for pat, name in (("smem_search_kernel<true>", "smem_search_kernel<true> (SMEM round 1)"),
                       ("smem_search_kernel<false>", "smem_search_kernel<false> (SMEM round 2)"),
+                      ("smem_bwd_wave", "smem_bwd_wave_kernel (rounds 1 and 2: backward phases with long interval lists, wave per pivot; one launch behind each search kernel)"),
                       ("seed_strategy", "seed_strategy_kernel (SMEM round 3; runs beside round 2 on a stream of its own: the durations overlap, 3.3 ms alone)"), ("sa_lookup", "sa_lookup_kernel"),
                       ("bsw_pk_kernel", "bsw_pk_kernel (banded SW, 16 tasks per wave, packed 16-bit columns; 5 query-length classes)"),
                       ("bsw_qwin_kernel", "bsw_qwin_kernel (banded SW, 8 tasks per wave, 32-bit: scoring the packed kernel does not take)"),
@@ -75,6 +76,8 @@ def newest(pattern):
     return fs[-1:] 
 
 
+BWD1 = "smem_bwd_wave_kernel, the launch behind round 1"
+BWD2 = "smem_bwd_wave_kernel, the launch behind round 2"
 ks = newest(src + "/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(ks, f"profiles/{rnd}_kernel_stats.csv")
 rows = list(csv.DictReader(open(ks)))
@@ -85,7 +88,10 @@ for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(fs[0])):
+    rws = list(csv.DictReader(open(fs[0])))
+    if rws and "Dispatch_Id" in rws[0]:
+        rws.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rws:
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         s = short(k)
@@ -93,6 +99,10 @@ for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
             for c, x in v.items():
                 P.setdefault(s, {})[c] = sum(x) / len(x)
                 N[s] = len(x)
+                if "smem_bwd_wave" in k:          # launches alternate: behind round 1, behind round 2
+                    P.setdefault(BWD1, {})[c] = sum(x[0::2]) / max(len(x[0::2]), 1)
+                    P.setdefault(BWD2, {})[c] = sum(x[1::2]) / max(len(x[1::2]), 1)
+                    N[BWD1], N[BWD2] = len(x[0::2]), len(x[1::2])
 
 E = {}          # the ERT walk kernel's counters (passes over bench.py --ert)
 for p in ("pmc_fetch_ert", "pmc_write_ert", "pmc_sq_ert"):
@@ -111,7 +121,9 @@ r1 = P["smem_search_kernel<true> (SMEM round 1)"]
 # calls of its sam_side.fastq_to_sam leg (bwams_process_chunk runs the same kernels on the same reads)
 n_pass = N.get("smem_search_kernel<true> (SMEM round 1)", 3)
 n_pass_trace = sum(int(r["Calls"]) for r in rows if "smem_search_kernel<true>" in r["Name"]) or 3
-fetch, write = r1["FETCH_SIZE"] * 1024, r1["WRITE_SIZE"] * 1024
+# round 1 = the search kernel + the wave kernel behind it (bench.py's HIP events bracket both)
+b1 = P.get(BWD1, {})
+fetch, write = (r1["FETCH_SIZE"] + b1.get("FETCH_SIZE", 0)) * 1024, (r1["WRITE_SIZE"] + b1.get("WRITE_SIZE", 0)) * 1024
 alg = bench["roofline"]["bytes_per_launch"]
 with open(f"profiles/{rnd}_summary.md", "w") as f:
     f.write(f"# Round {rnd} — rocprofv3 summary (MI355X, gfx950, ROCm 7.2)\n\n")
@@ -169,11 +181,11 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
 prescribes ("128-B requests tallied at 64 B"), and all four shapes saturate at the same ~49 G requests/s = 6.3 TB/s of
 128-B lines.  Every random request moves one 128-B line: **HBM read bytes = 2 x FETCH_SIZE**; WRITE_SIZE is exact.
 
-Round-1 search kernel per launch: algorithmic bytes {alg/1e9:.2f} GB; corrected traffic = 2 x {fetch/1e9:.2f} + {write/1e9:.2f}
+Round 1 (search kernel + the wave kernel behind it: `roofline.launch_ms` brackets both) per pass: algorithmic bytes {alg/1e9:.2f} GB; corrected traffic = 2 x {fetch/1e9:.2f} + {write/1e9:.2f}
 = **{(2*fetch+write)/1e9:.1f} GB** = {(2*fetch+write)/alg:.2f}x algorithmic.  At {bench['roofline']['launch_ms']} ms per launch that is
 {(2*fetch+write)/(bench['roofline']['launch_ms']*1e-3)/1e12:.2f} TB/s of HBM traffic ({(2*fetch+write)/(bench['roofline']['launch_ms']*1e-3)/8e12:.2f} of the 8 TB/s peak,
 {(2*fetch+write)/(bench['roofline']['launch_ms']*1e-3)/6.3e12:.2f} of the 6.3 TB/s a streaming copy reaches), against `roofline.frac` = {bench['roofline']['frac']} in algorithmic bytes.
-L2 misses per launch {r1.get('TCC_MISS_sum',0)/1e6:.0f} M = {r1.get('TCC_MISS_sum',0)/(bench['roofline']['launch_ms']*1e-3)/1e9:.1f} G lines/s; `tools/ubench_gather` (mode 1, the kernel's quad-cooperative
+L2 misses per launch of the search kernel {r1.get('TCC_MISS_sum',0)/1e6:.0f} M = {r1.get('TCC_MISS_sum',0)/(bench['roofline']['launch_ms']*1e-3)/1e9:.1f} G lines/s; `tools/ubench_gather` (mode 1, the kernel's quad-cooperative
 fetch, a 12 GiB table) tops out at 48 G random 64-byte blocks/s = 3.07 TB/s of useful bytes = 0.38 of peak when every block is its own line.
 
 Banded-SW kernels per step: {sum(c.get("SQ_INSTS_VALU", 0) * N.get(s_, 0) for s_, c in P.items() if s_.startswith("bsw_")) / n_pass / 1e9:.1f} G vector and

@@ -1123,12 +1123,12 @@ static int reg2aln_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t so
     BWAMS_HIP(s->al_rec.ensure((size_t)n1 * sizeof(bwams_aln_t)));
     BWAMS_HIP(s->al_wide.ensure((size_t)(2 * n1) * 8));
     BWAMS_HIP(s->al_offs.ensure((size_t)(2 * n1) * 8));
-    BWAMS_HIP(s->al_cnt.ensure(64));
+    BWAMS_HIP(s->al_cnt.ensure(256));
     A.need = s->al_need.as<int64_t>(); A.cls = s->al_cls.as<int32_t>(); A.scr_off = s->al_off.as<int64_t>();
     A.list = s->al_list.as<int32_t>(); A.n_list = s->al_cnt.as<unsigned long long>(); A.rec = s->al_rec.as<bwams_aln_t>();
     int64_t tot[2] = {0, 0};
     if (n > 0) {
-        BWAMS_HIP(hipMemsetAsync(s->al_cnt.p, 0, 64, st));
+        BWAMS_HIP(hipMemsetAsync(s->al_cnt.p, 0, 256, st));
         BWAMS_HIP(hipMemsetAsync(s->al_need.as<int64_t>() + n, 0, 8, st));
         launch_aln_plan(A, st);
         if ((rc = scan_rows(b, A.need, s->al_off.as<int64_t>(), 1, n1))) return rc;
@@ -1148,6 +1148,15 @@ static int reg2aln_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t so
         launch_aln_gather(A, s->al_offs.as<int64_t>(), s->al_cig.as<uint32_t>(), s->al_md.as<char>(), st);
         BWAMS_HIP(hipStreamSynchronize(st));
         BWAMS_HIP(hipGetLastError());
+#ifdef BWAMS_ALNDBG
+        if (getenv("BWAMS_VERBOSE")) {
+            unsigned long long c[32];
+            BWAMS_HIP(hipMemcpy(c, s->al_cnt.p, 256, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[reg2aln] regions %lld: class lists %llu / %llu / %llu / %llu; wave kernel: %llu regions, per region setup %.1f us, DP %.1f us (%.2f DPs, mean band %.1f, %.0f rows), "
+                    "traceback %.1f us, NM/MD + record %.1f us, slowest region %.1f us\n", (long long)n, c[0], c[1], c[2], c[3], c[8], c[8] ? c[9] * 1e-2 / c[8] : 0.0, c[8] ? c[10] * 1e-2 / c[8] : 0.0,
+                    c[8] ? (double)c[13] / c[8] : 0.0, c[13] ? (double)c[14] / c[13] : 0.0, c[8] ? (double)c[15] / c[8] : 0.0, c[8] ? c[11] * 1e-2 / c[8] : 0.0, c[8] ? c[12] * 1e-2 / c[8] : 0.0, c[16] * 1e-2);
+        }
+#endif
     }
     s->al_n = n; s->al_ncig = tot[0]; s->al_nmd = tot[1]; s->al_source = source; s->al_done = true;
     s->opt = *opt;

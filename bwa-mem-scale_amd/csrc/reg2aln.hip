@@ -74,15 +74,17 @@ __device__ __forceinline__ int put_num(char *s, int l, int x) {          // kput
 }
 
 // NM and MD from a CIGAR (bwa.cpp:430-459)
-__device__ int nm_md(const Seqs &S, const uint32_t *cigar, int n_cigar, char *md, int *md_len) {
+// QA / RA: the aligned query / reference base at an index (the sequences in HBM, or the copies a wave kernel holds in LDS)
+template <class QA, class RA>
+__device__ int nm_md_of(const Seqs &S, QA qa, RA ra, const uint32_t *cigar, int n_cigar, char *md, int *md_len) {
     int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0, l = 0;
     const char *int2base = S.rev ? "TGCAN" : "ACGTN";
     for (int k = 0; k < n_cigar; ++k) {
         const int op = (int)(cigar[k] & 0xf), len = (int)(cigar[k] >> 4);
         if (op == 0) {
             for (int i = 0; i < len; ++i) {
-                const int rb = S.ra(y + i);
-                if (S.qa(x + i) != rb) {
+                const int rb = ra(y + i);
+                if (qa(x + i) != rb) {
                     l = put_num(md, l, u);
                     md[l++] = int2base[rb > 4 ? 4 : rb];
                     ++n_mm; u = 0;
@@ -92,7 +94,7 @@ __device__ int nm_md(const Seqs &S, const uint32_t *cigar, int n_cigar, char *md
         } else if (op == 2) {
             if (k > 0 && k < n_cigar - 1) {
                 l = put_num(md, l, u); md[l++] = '^';
-                for (int i = 0; i < len; ++i) { const int rb = S.ra(y + i); md[l++] = int2base[rb > 4 ? 4 : rb]; }
+                for (int i = 0; i < len; ++i) { const int rb = ra(y + i); md[l++] = int2base[rb > 4 ? 4 : rb]; }
                 u = 0; n_gap += len;
             }
             y += len;
@@ -101,6 +103,9 @@ __device__ int nm_md(const Seqs &S, const uint32_t *cigar, int n_cigar, char *md
     l = put_num(md, l, u); md[l++] = 0;
     *md_len = l;
     return n_mm + n_gap;
+}
+__device__ int nm_md(const Seqs &S, const uint32_t *cigar, int n_cigar, char *md, int *md_len) {
+    return nm_md_of(S, [&](int i) { return S.qa(i); }, [&](int i) { return S.ra(i); }, cigar, n_cigar, md, md_len);
 }
 
 // the tail of mem_reg2aln (bwamem.cpp:2570-2626): squeeze, clip, position
@@ -285,13 +290,17 @@ __device__ int global2_cigar(const RegAlnArgs &A, const Seqs &S, int w, const Eh
     }
     const int score = eh.get(qlen).x;
     int n = 0, which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    int run_op = -1, run_len = 0;                        // the operation being extended stays in registers: a step reads z only
     auto push = [&](int op, int len) {
-        if (n == 0 || op != (int)(cigar[n - 1] & 0xf)) cigar[n++] = (uint32_t)len << 4 | (uint32_t)op;
-        else cigar[n - 1] += (uint32_t)len << 4;
+        if (op != run_op) {
+            if (run_op >= 0) cigar[n++] = (uint32_t)run_len << 4 | (uint32_t)run_op;
+            run_op = op; run_len = len;
+        } else run_len += len;
     };
+    const uint8_t *zb = reinterpret_cast<const uint8_t *>(z);
     while (i >= 0 && k >= 0) {
         const int c = k - (i > w ? i - w : 0);
-        const uint32_t d = (z[(size_t)i * zw + (c >> 2)] >> ((c & 3) * 8)) & 0xffu;
+        const uint32_t d = zb[(size_t)i * zw * 4 + c];
         which = (int)(d >> (which << 1)) & 3;
         if (which == 0) { push(0, 1); --i; --k; }
         else if (which == 1) { push(2, 1); --i; }
@@ -299,6 +308,7 @@ __device__ int global2_cigar(const RegAlnArgs &A, const Seqs &S, int w, const Eh
     }
     if (i >= 0) push(2, i + 1);
     if (k >= 0) push(1, k + 1);
+    if (run_op >= 0) cigar[n++] = (uint32_t)run_len << 4 | (uint32_t)run_op;
     for (int a = 0; a < n >> 1; ++a) { const uint32_t t = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = t; }
     *n_cigar_ = n;
     return score;
@@ -407,7 +417,9 @@ __device__ __forceinline__ int wave_incl_max(int v, int) {
 // the DP of ksw_global2 (ksw.cpp:588-637) for band w; returns the score, leaves the direction bytes in z
 __device__ int global2_dp_wave(const RegAlnArgs &A, const Seqs &S, int w, int2 *eh, const uint8_t *qs, const uint8_t *ts, uint32_t *z, int lane) {
     const bwams_mem_opt_t &o = A.opt;
-    const int qlen = S.lq, tlen = S.lr;
+    // the region is the wave's: lengths and band in scalar registers, so that the row and chunk loops are scalar loops
+    const int qlen = __builtin_amdgcn_readfirstlane(S.lq), tlen = __builtin_amdgcn_readfirstlane(S.lr);
+    w = __builtin_amdgcn_readfirstlane(w);
     const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
     const int zw = (n_col + 3) >> 2;
@@ -415,28 +427,34 @@ __device__ int global2_dp_wave(const RegAlnArgs &A, const Seqs &S, int w, int2 *
         eh[j] = j == 0 ? make_int2(0, kMinusInf) : j <= w ? make_int2(-(o.o_ins + o.e_ins * j), kMinusInf) : make_int2(kMinusInf, kMinusInf);
     __syncthreads();
     for (int i = 0; i < tlen; ++i) {
-        const int tb = ts ? ts[i] : S.ra(i);
+        const int tb = __builtin_amdgcn_readfirstlane(ts ? (int)ts[i] : S.ra(i));
         const int8_t *mrow = &o.mat[(tb > 4 ? 4 : tb) * 5];
-        const int s0 = mrow[0], s1 = mrow[1], s2 = mrow[2], s3 = mrow[3], s4 = mrow[4];
+        // the row of the scoring matrix as five bytes of one scalar: a lane's score is a shift and a sign extension
+        const uint64_t mpk = (uint64_t)(uint8_t)mrow[0] | (uint64_t)(uint8_t)mrow[1] << 8 | (uint64_t)(uint8_t)mrow[2] << 16 |
+                             (uint64_t)(uint8_t)mrow[3] << 24 | (uint64_t)(uint8_t)mrow[4] << 32;
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         const int h1_first = beg == 0 ? -(o.o_del + o.e_del * (i + 1)) : kMinusInf;
         uint8_t *zi = reinterpret_cast<uint8_t *>(z + (size_t)i * zw);
         int f_carry = kMinusInf, h_carry = h1_first, h_end = h1_first;
         for (int c0 = beg; c0 < end; c0 += 64) {
+            // branch-free but for the two stores; lanes behind the row's end read its last column and are masked out of the scan.
+            // Cross-lane moves are DPP (the neighbour) and v_readlane (lane 63, the row's last column): no LDS permutes.
             const int j = c0 + lane;
             const bool act = j < end;
-            int2 p = make_int2(0, 0);
-            int qb = 4;
-            if (act) { p = eh[j]; qb = qs[j]; qb = qb > 4 ? 4 : qb; }
-            const int m = p.x + (qb == 0 ? s0 : qb == 1 ? s1 : qb == 2 ? s2 : qb == 3 ? s3 : s4);
+            const int jj = act ? j : end - 1;
+            const int2 p = eh[jj];
+            int qb = qs[jj];
+            qb = qb > 4 ? 4 : qb;
+            const int m = p.x + (int)(int8_t)(uint8_t)(mpk >> (qb << 3));
             int e = p.y;
             const int t_ins = m - oe_ins;
             const int g = act ? t_ins + j * o.e_ins : kNegScan;
             const int P = wave_incl_max(g, lane);
-            int Pex = __shfl_up(P, 1);
-            int f = f_carry - (j - c0) * o.e_ins;                          // what the gap open before this chunk has become
-            if (lane > 0) { const int fp = Pex - (j - 1) * o.e_ins; f = f > fp ? f : fp; }
+            const int Pex = lane_shr1(P, kNegScan);                        // lane 0: nothing to its left in this chunk
+            const int fc = f_carry - lane * o.e_ins;                       // what the gap open before this chunk has become
+            const int fp = Pex - (j - 1) * o.e_ins;
+            const int f = fc > fp ? fc : fp;
             uint32_t d = m >= e ? 0u : 1u;
             int h = m >= e ? m : e;
             d = h >= f ? d : 2u;
@@ -447,17 +465,16 @@ __device__ int global2_dp_wave(const RegAlnArgs &A, const Seqs &S, int w, int2 *
             e = e > t ? e : t;
             const int fn = f - o.e_ins;
             d |= fn > t_ins ? 2u << 4 : 0u;
-            int hl = __shfl_up(h, 1);
-            if (lane == 0) hl = h_carry;
+            const int hl = lane_shr1(h, h_carry);                          // lane 0 takes the previous chunk's last h
             if (act) {
                 eh[j] = make_int2(hl, e);
                 zi[j - beg] = (uint8_t)d;
             }
             const int fnext = fn > t_ins ? fn : t_ins;
-            f_carry = __shfl(fnext, 63);
-            h_carry = __shfl(h, 63);
+            f_carry = __builtin_amdgcn_readlane(fnext, 63);
+            h_carry = __builtin_amdgcn_readlane(h, 63);
             const int last = end - 1 - c0;                                 // the row's last column, if it lies in this chunk
-            if (last < 64) h_end = __shfl(h, last);
+            if (last < 64) h_end = __builtin_amdgcn_readlane(h, last);
         }
         if (lane == 0) eh[end] = make_int2(h_end, kMinusInf);
         __syncthreads();
@@ -489,9 +506,70 @@ __device__ void global2_traceback(const Seqs &S, int w, const uint32_t *z, uint3
     *n_cigar_ = n;
 }
 
+// The same traceback for a wavefront: lane 0 walks, all lanes fetch.  A step of the walk reads one direction byte that the
+// DP left in HBM scratch, and the next byte's address depends on it: 270 dependent loads of ~0.5 us each were a third of this
+// kernel's time per region (profiles/r03_notes.md 88).  The path only moves up and to the left, so from (i, k) it stays inside
+// the kTbWin x kTbWin cells above and to the left of it for at least kTbWin steps: the wave copies that window into LDS with
+// one round trip (lane -> row l >> 1, 16 bytes of it), lane 0 walks until it leaves the window, and so on.
+constexpr int kTbWin = 32;
+__device__ void global2_traceback_wave(const Seqs &S, int w, const uint32_t *z, uint32_t *cigar, int *n_cigar_, uint8_t *zl, int lane) {
+    const int qlen = S.lq, tlen = S.lr;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const int zw = (n_col + 3) >> 2;
+    const uint8_t *zb = reinterpret_cast<const uint8_t *>(z);
+    int n = 0, which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    int run_op = -1, run_len = 0;
+    auto push = [&](int op, int len) {
+        if (op != run_op) {
+            if (run_op >= 0) cigar[n++] = (uint32_t)run_len << 4 | (uint32_t)run_op;
+            run_op = op; run_len = len;
+        } else run_len += len;
+    };
+    while (i >= 0 && k >= 0) {                           // i, k are wave-uniform here
+        const int i0 = i, k0 = k;
+        {
+            const int ii = i0 - (lane >> 1);
+            const int kb = k0 - kTbWin + 1 + (lane & 1) * 16;
+            uint8_t *dst = zl + (lane >> 1) * kTbWin + (lane & 1) * 16;
+            if (ii >= 0) {
+                const int beg = ii > w ? ii - w : 0;
+                const int end = ii + w + 1 < qlen ? ii + w + 1 : qlen;       // the row holds columns [beg, end)
+                const uint8_t *row = zb + (size_t)ii * zw * 4;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int kk = kb + t;
+                    dst[t] = (kk >= beg && kk < end) ? row[kk - beg] : (uint8_t)0;
+                }
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            while (i >= 0 && k >= 0 && i > i0 - kTbWin && k > k0 - kTbWin) {
+                const uint32_t d = zl[(i0 - i) * kTbWin + (k - (k0 - kTbWin + 1))];
+                which = (int)(d >> (which << 1)) & 3;
+                if (which == 0) { push(0, 1); --i; --k; }
+                else if (which == 1) { push(2, 1); --i; }
+                else { push(1, 1); --k; }
+            }
+        }
+        i = __builtin_amdgcn_readfirstlane(i);
+        k = __builtin_amdgcn_readfirstlane(k);
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (i >= 0) push(2, i + 1);
+        if (k >= 0) push(1, k + 1);
+        if (run_op >= 0) cigar[n++] = (uint32_t)run_len << 4 | (uint32_t)run_op;
+        for (int a = 0; a < n >> 1; ++a) { const uint32_t t = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = t; }
+        *n_cigar_ = n;
+    }
+}
+
 __global__ __launch_bounds__(64) void aln_dp_wave_kernel(RegAlnArgs A, int cls, unsigned long long *ticket) {
     __shared__ int2 eh[kWaveCols + 2];
     __shared__ uint8_t qs[kWaveCols + 64], ts_[kWaveTgt + 64];    // the two sequences in the order the DP reads them: a row step waits on no HBM load
+    __shared__ uint8_t zl[kTbWin * kTbWin];                       // the traceback's window of direction bytes
+    __shared__ int n_cig_s;
     const int lane = threadIdx.x;
     const int64_t n = (int64_t)A.n_list[cls];
     const int32_t *list = A.list + (int64_t)cls * A.n_regs;
@@ -509,6 +587,10 @@ __global__ __launch_bounds__(64) void aln_dp_wave_kernel(RegAlnArgs A, int cls, 
             if (lane == 0) A.list[3 * A.n_regs + (int64_t)atomicAdd(&A.n_list[3], 1ull)] = (int32_t)k;
             continue;
         }
+#ifdef BWAMS_ALNDBG
+        const unsigned long long tk0 = wall_clock64();
+        unsigned long long n_dp = 0, sum_w = 0;
+#endif
         uint32_t *cigar = scr_cigar(A, k);
         char *md = scr_md(A, k, S.lq, S.lr);
         uint32_t *z = reinterpret_cast<uint32_t *>(md + md_cap(S.lr));
@@ -521,6 +603,9 @@ __global__ __launch_bounds__(64) void aln_dp_wave_kernel(RegAlnArgs A, int cls, 
         int w2 = infer_bw(S.lq, S.lr, ar.truesc, A.opt.a, A.opt.o_ins, A.opt.e_ins);
         w2 = w2 > tmp ? w2 : tmp;
         if (w2 > A.opt.w) w2 = w2 < ar.w ? w2 : ar.w;
+#ifdef BWAMS_ALNDBG
+        unsigned long long tk1 = 0;
+#endif
         int it = 0, last_sc = -(1 << 30), score = 0, w = 0;
         do {
             w2 = w2 < A.opt.w << 2 ? w2 : A.opt.w << 2;
@@ -533,17 +618,34 @@ __global__ __launch_bounds__(64) void aln_dp_wave_kernel(RegAlnArgs A, int cls, 
             w = (max_gap + d + 1) >> 1;
             w = w < w2 ? w : w2;
             w = w > d + 3 ? w : d + 3;
+#ifdef BWAMS_ALNDBG
+            if (it == 0) tk1 = wall_clock64();
+            n_dp++; sum_w += (unsigned long long)w;
+#endif
             score = global2_dp_wave(A, S, w, eh, qs, ts, z, lane);
             if (score == last_sc || w2 == A.opt.w << 2) break;
             last_sc = score;
             w2 <<= 1;
         } while (++it < 3 && score < ar.truesc - A.opt.a);
         __syncthreads();                                 // the direction bytes of every lane are visible to lane 0
+#ifdef BWAMS_ALNDBG
+        const unsigned long long tk2 = wall_clock64();
+#endif
+        global2_traceback_wave(S, w, z, cigar, &n_cig_s, zl, lane);
         if (lane == 0) {
-            int n_cigar = 0, md_len = 0;
-            global2_traceback(S, w, z, cigar, &n_cigar);
-            const int NM = nm_md(S, cigar, n_cigar, md, &md_len);
+            int n_cigar = n_cig_s, md_len = 0;
+#ifdef BWAMS_ALNDBG
+            const unsigned long long tk3 = wall_clock64();
+#endif
+            const int NM = ts ? nm_md_of(S, [&](int i_) { return (int)qs[i_]; }, [&](int i_) { return (int)ts_[i_]; }, cigar, n_cigar, md, &md_len)
+                              : nm_md_of(S, [&](int i_) { return (int)qs[i_]; }, [&](int i_) { return S.ra(i_); }, cigar, n_cigar, md, &md_len);
             finish_record(A, k, ar, l_query, cigar, n_cigar, NM, md_len);
+#ifdef BWAMS_ALNDBG
+            const unsigned long long tk4 = wall_clock64();
+            atomicAdd(&A.n_list[8], 1ull); atomicAdd(&A.n_list[9], tk1 - tk0); atomicAdd(&A.n_list[10], tk2 - tk1);
+            atomicAdd(&A.n_list[11], tk3 - tk2); atomicAdd(&A.n_list[12], tk4 - tk3); atomicAdd(&A.n_list[13], n_dp);
+            atomicAdd(&A.n_list[14], sum_w); atomicAdd(&A.n_list[15], (unsigned long long)S.lr); atomicMax(&A.n_list[16], tk4 - tk0);
+#endif
         }
         __syncthreads();
     }

@@ -110,6 +110,7 @@ struct DevCounters {
     unsigned long long ert_kmer, ert_nodes, ert_ref;   // ERT profile kernel: k-mer entries read, tree records decoded, text bytes compared
     unsigned long long work_head3, n_ext3, n_blk3, n_smem3;   // SMEM round 3 (it may run beside round 2): its own cursor and counts, folded in by mark_kernel(3)
     unsigned long long n_rest;           // extension: slots behind the requests of the last selection (an upper bound of the undecided seeds)
+    unsigned long long ert_ticket;       // ERT walk: work cursor of ert_profile_kernel (groups of 64 read positions)
     unsigned long long bwd_items, bwd_entries, bwd_ticket;   // SMEM search: backward phases handed to the wave kernel, their list entries, its work cursor
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };

@@ -226,6 +226,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
     return d;
 }
 
+constexpr int kErtTicket = 4;
 // lane = one base of the batch = one start position of one read.  planes: [0] = the base is N, [m] = L_m.
 // Persistent waves, 64 consecutive bases per trip: a walk lives for some ten microseconds, and a grid of one short-lived
 // workgroup per 256 bases kept only five waves per CU in flight (workgroup launch rate), where the walk needs dozens
@@ -233,11 +234,27 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
 __global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_t *__restrict__ enc,
                                                           const int64_t *__restrict__ cum, const uint8_t *__restrict__ skip,
                                                           int64_t nseq, int64_t nbases, int M, uint8_t *__restrict__ prof,
-                                                          unsigned long long *__restrict__ part) {
+                                                          unsigned long long *__restrict__ part, unsigned long long *__restrict__ ticket) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     WalkCnt wc = {0, 0, 0};
-    for (int64_t g0 = wave * 64; g0 < nbases; g0 += n_waves * 64) {
+    // work: groups of 64 consecutive read positions; with a cursor (ticket != null) a wave takes kErtTicket groups per atomic,
+    // otherwise the groups are dealt out round robin
+    int64_t g_next = ticket ? 0 : wave * 64, g_end = 0;
+    for (;;) {
+        int64_t g0;
+        if (ticket) {
+            if (g_next >= g_end) {
+                g_next = (int64_t)wave_ticket(ticket, (unsigned long long)kErtTicket) * 64;
+                g_end = g_next + (int64_t)kErtTicket * 64;
+            }
+            g0 = g_next; g_next += 64;
+            if (g0 >= nbases) break;
+        } else {
+            g0 = g_next; g_next += n_waves * 64;
+            if (g0 >= nbases) break;
+        }
+        {
         int64_t r = 0;
         if (lane == 0) {
             // last r with cum[r] <= g0, one search per wave: reads are about equally long, so look next to the proportional
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_
         if (pd.leaf_pos >= 0 || pd.cur > 0) {
             const int hi = pd.cur < M ? pd.cur : M;
             for (int m = 1; m <= hi; ++m) prof[g + (int64_t)m * nbases] = (uint8_t)d;
+        }
         }
     }
     // event counts of the launch (8 B per k-mer entry, a 32-B sector per tree record, the text bytes)
@@ -777,15 +795,18 @@ void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum,
                         hipStream_t st) {
     if (nbases <= 0) return;
     int64_t blocks = (nbases + 255) / 256;
-    // persistent waves, many more than fit at once: trips differ a lot in length (repeats), and 32 blocks per CU measured
-    // 16.9 ms against 20.9 ms for one residency (8 per CU) and 17.8 ms for one block per 256 bases (GRCh38 size, 1 M reads)
-    static int per_cu = -1;
+    // persistent waves that take their groups of read positions from a cursor (kErtTicket groups per atomic): trips differ a lot in
+    // length (repeats).  Round robin over many more waves than fit at once measured 17.2 ms (32 blocks per CU; 20.9 ms for one
+    // residency), the cursor 16.2 ms with 12 blocks per CU (GRCh38 size, 1 M reads; profiles/r03_notes.md 89).
+    static int per_cu = -1, dyn = -1;
     if (per_cu < 0) {
         const char *g = getenv("BWAMS_ERT_GRID");      // experiments: blocks per CU, 0 = one block per 256 bases
-        per_cu = g ? atoi(g) : 32;
+        const char *t = getenv("BWAMS_ERT_TICKET");    // experiments: 0 = round robin
+        dyn = t ? atoi(t) : 1;
+        per_cu = g ? atoi(g) : (dyn ? 12 : 32);
     }
     if (per_cu > 0 && blocks > (int64_t)cu_count * per_cu) blocks = (int64_t)cu_count * per_cu;
-    ert_profile_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof, part);
+    ert_profile_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof, part, dyn ? &ctr->ert_ticket : nullptr);
     ert_count_kernel<<<1, 256, 0, st>>>(part, ctr);
 }
 

@@ -1005,6 +1005,17 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
         PR_TRACE("ksw done");
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_heavy, 0, 2 * sizeof(unsigned long long), st));
         launch_pair_post(A, b->cu_count, st);
+#ifdef BWAMS_PAIRDBG
+        if (getenv("BWAMS_VERBOSE")) {
+            unsigned long long d[80];
+            BWAMS_HIP(hipStreamSynchronize(st));
+            BWAMS_HIP(hipMemcpy(d, b->d_ctr->dbg, sizeof d, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pair_post_wave] reads %llu (mean %.0f regions at the end, %.1f anchors, %.1f rescues), %.3f ms of a wave per read (longest %.3f ms); sorts %llu = %.1f per read, %.3f ms per read; "
+                    "with equal keys %llu, %.3f ms per read in them\n", d[20], d[20] ? (double)d[27] / d[20] : 0.0, d[20] ? (double)d[28] / d[20] : 0.0, d[20] ? (double)d[29] / d[20] : 0.0,
+                    d[20] ? d[24] * 1e-5 / d[20] : 0.0, d[25] * 1e-5, d[21], d[20] ? (double)d[21] / d[20] : 0.0, d[20] ? d[26] * 1e-5 / d[20] : 0.0, d[22], d[20] ? d[23] * 1e-5 / d[20] : 0.0);
+            BWAMS_HIP(hipMemsetAsync(b->d_ctr->dbg + 20, 0, 10 * sizeof(unsigned long long), st));
+        }
+#endif
         PR_TRACE("post done");
         s->pr_tasks += tot[0];
         unsigned long long flags[2] = {0, 0};

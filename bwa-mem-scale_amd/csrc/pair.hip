@@ -423,7 +423,8 @@ __device__ void post_read_seq(const PairArgs &A, int64_t m) {
 }
 
 constexpr int kPostLight = 16;       // pool slots (regions + room for rescued ones) a single lane handles
-constexpr int kPostLds = 1024;       // pool slots a wavefront keeps in LDS
+constexpr int kPostLds = 1024;       // pool slots a wavefront keeps in LDS (a power of two: the bitonic sort pads to one)
+constexpr int kPostRankMax = 96;     // longer lists are sorted by the bitonic network, shorter ones by rank
 
 __global__ __launch_bounds__(64) void pair_post_kernel(PairArgs A) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,8 +487,15 @@ __global__ __launch_bounds__(64) void pair_post_wave_kernel(PairArgs A) {
         int n_sw = 0;
         bool need_full = false;
 
+#ifdef BWAMS_PAIRDBG
+        const unsigned long long tk_read0 = wall_clock64();
+        unsigned long long d_sorts = 0, d_ties = 0, d_tie_t = 0, d_sort_t = 0;
+#endif
         // a sort of the list by rank; by_score = 0: key re, 1: (score desc, rb, qb)
         auto sort_list = [&](int by_score) {
+#ifdef BWAMS_PAIRDBG
+            const unsigned long long tk_s0 = wall_clock64();
+#endif
             for (int i = lane; i < n; i += 64) {
                 const int sl = l_ord[i];
                 l_k64[i] = by_score ? l_rb[sl] : l_re[sl];
@@ -496,6 +504,50 @@ __global__ __launch_bounds__(64) void pair_post_wave_kernel(PairArgs A) {
             }
             __syncthreads();
             bool tie = false;
+            if (n > kPostRankMax) {
+                // a bitonic network over the next power of two (pads sort behind everything), keys and the slot index moving
+                // together through LDS: n log^2 n / 128 compare-exchanges per lane instead of n^2 / 64 comparisons.  One
+                // read of the bench's paired-end chunk reaches 1000 regions and is rescued two dozen times, two sorts
+                // each: 17.6 ms of an 18.4 ms launch with the rank sort (profiles/r03_notes.md 91).
+                int P = 128;
+                while (P < n) P <<= 1;
+                for (int i = lane; i < P; i += 64) {
+                    if (i < n) l_tmp[i] = l_ord[i];
+                    else { l_k64[i] = INT64_MAX; l_ks[i] = INT32_MIN; l_kq[i] = INT32_MAX; l_tmp[i] = -1; }
+                }
+                __syncthreads();
+                for (int k = 2; k <= P; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int t = lane; t < (P >> 1); t += 64) {
+                            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                            const int64_t ka = l_k64[i], kb = l_k64[l];
+                            const int sa = l_ks[i], sb = l_ks[l], qa = l_kq[i], qb = l_kq[l];
+                            const bool b_lt_a = sb > sa || (sb == sa && (kb < ka || (kb == ka && qb < qa)));
+                            const bool a_lt_b = sa > sb || (sa == sb && (ka < kb || (ka == kb && qa < qb)));
+                            const bool up = (i & k) == 0;
+                            if (up ? b_lt_a : a_lt_b) {
+                                l_k64[i] = kb; l_k64[l] = ka; l_ks[i] = sb; l_ks[l] = sa; l_kq[i] = qb; l_kq[l] = qa;
+                                const int ta = l_tmp[i]; l_tmp[i] = l_tmp[l]; l_tmp[l] = ta;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+                for (int ib = 0; ib < n; ib += 64) {
+                    const int i = ib + lane;
+                    const bool eq = i >= 1 && i < n && l_k64[i] == l_k64[i - 1] && l_ks[i] == l_ks[i - 1] && l_kq[i] == l_kq[i - 1];
+                    tie = tie || (__ballot(eq) != 0);
+                }
+                if (tie) {                                   // the fallback below reads the keys in the list's order
+                    __syncthreads();
+                    for (int i = lane; i < n; i += 64) {
+                        const int sl = l_ord[i];
+                        l_k64[i] = by_score ? l_rb[sl] : l_re[sl];
+                        l_ks[i] = by_score ? l_sc[sl] : 0;
+                        l_kq[i] = by_score ? l_qb[sl] : 0;
+                    }
+                }
+            } else
             for (int ib = 0; ib < n; ib += 64) {
                 const int i = ib + lane;
                 int rank = 0, eq = 0;
@@ -527,6 +579,9 @@ __global__ __launch_bounds__(64) void pair_post_wave_kernel(PairArgs A) {
                 }
             }
             __syncthreads();
+#ifdef BWAMS_PAIRDBG
+            { const unsigned long long dt = wall_clock64() - tk_s0; d_sorts++; d_sort_t += dt; if (tie) { d_ties++; d_tie_t += dt; } }
+#endif
         };
         auto compact = [&]() {                               // keep the regions with qe > qb, in order
             int nn = 0;
@@ -663,6 +718,14 @@ __global__ __launch_bounds__(64) void pair_post_wave_kernel(PairArgs A) {
             pool[sl].n_comp_is_alt = l_ncia[sl];
         }
         if (lane == 0) { A.n_fin[m] = n; A.n_sw[m] = n_sw; }
+#ifdef BWAMS_PAIRDBG
+        if (lane == 0) {
+            const unsigned long long dt = wall_clock64() - tk_read0;
+            atomicAdd(&A.ctr->dbg[20], 1ull); atomicAdd(&A.ctr->dbg[21], d_sorts); atomicAdd(&A.ctr->dbg[22], d_ties); atomicAdd(&A.ctr->dbg[23], d_tie_t);
+            atomicAdd(&A.ctr->dbg[24], dt); atomicMax(&A.ctr->dbg[25], dt); atomicAdd(&A.ctr->dbg[26], d_sort_t); atomicAdd(&A.ctr->dbg[27], (unsigned long long)n);
+            atomicAdd(&A.ctr->dbg[28], (unsigned long long)na); atomicAdd(&A.ctr->dbg[29], (unsigned long long)n_sw);
+        }
+#endif
     }
 }
 

@@ -795,18 +795,50 @@ __global__ __launch_bounds__(64) void pair_mark_wave_kernel(PairArgs A, unsigned
             n_pri += __popcll(__ballot(pri));
         }
         __syncthreads();
-        // order 1: score descending, is_alt ascending, hash ascending
-        for (int i = lane; i < n; i += 64) {
-            const int sc = l_sc[i], al = l_alt[i];
-            const uint64_t h = l_hash[i];
-            int r = 0;
-            for (int j = 0; j < n; ++j) {
-                const int sj = l_sc[j], aj = l_alt[j];
-                r += (sj > sc || (sj == sc && (aj < al || (aj == al && l_hash[j] < h)))) ? 1 : 0;
+        // order 1: score descending, is_alt ascending, hash ascending (the hashes of a read's regions are distinct: no ties)
+        if (n > kPostRankMax) {
+            // long lists: a bitonic network (n log^2 n / 128 compare-exchanges per lane instead of n^2 / 64 comparisons) over two
+            // 64-bit keys and the original index, in the arrays the marking fills only afterwards
+            uint64_t *k1 = reinterpret_cast<uint64_t *>(l_sub), *k2 = reinterpret_cast<uint64_t *>(l_sec);      // l_sub | l_subn, l_sec | l_secall
+            int32_t *pay = l_altsc;
+            int P = 128;
+            while (P < n) P <<= 1;
+            for (int i = lane; i < P; i += 64) {
+                if (i < n) { k1[i] = ((uint64_t)(uint32_t)(0x7fffffff - l_sc[i]) << 1) | (uint64_t)(l_alt[i] ? 1 : 0); k2[i] = l_hash[i]; pay[i] = i; }
+                else { k1[i] = ~0ull; k2[i] = ~0ull; pay[i] = -1; }
             }
-            l_at[r] = i;
-            l_sub[i] = 0; l_subn[i] = 0; l_sec[i] = -1; l_altsc[i] = 0;
+            __syncthreads();
+            for (int k = 2; k <= P; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = lane; t < (P >> 1); t += 64) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                        const uint64_t a1 = k1[i], b1 = k1[l], a2 = k2[i], b2 = k2[l];
+                        const bool b_lt_a = b1 < a1 || (b1 == a1 && b2 < a2);
+                        const bool a_lt_b = a1 < b1 || (a1 == b1 && a2 < b2);
+                        if (((i & k) == 0) ? b_lt_a : a_lt_b) {
+                            k1[i] = b1; k1[l] = a1; k2[i] = b2; k2[l] = a2;
+                            const int ta = pay[i]; pay[i] = pay[l]; pay[l] = ta;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int r = lane; r < n; r += 64) l_at[r] = pay[r];
+            __syncthreads();
+        } else {
+            for (int i = lane; i < n; i += 64) {
+                const int sc = l_sc[i], al = l_alt[i];
+                const uint64_t h = l_hash[i];
+                int r = 0;
+                for (int j = 0; j < n; ++j) {
+                    const int sj = l_sc[j], aj = l_alt[j];
+                    r += (sj > sc || (sj == sc && (aj < al || (aj == al && l_hash[j] < h)))) ? 1 : 0;
+                }
+                l_at[r] = i;
+            }
+            __syncthreads();
         }
+        for (int i = lane; i < n; i += 64) { l_sub[i] = 0; l_subn[i] = 0; l_sec[i] = -1; l_altsc[i] = 0; }
         __syncthreads();
         // mem_mark_primary_se_core over the sorted list (sequential: each element looks at the primaries found so far)
         auto core = [&](const int32_t *at, int cnt) {
@@ -847,15 +879,21 @@ __global__ __launch_bounds__(64) void pair_mark_wave_kernel(PairArgs A, unsigned
         if (n_pri < n) {
             if (n_pri > 0) {
                 // order 2 (is_alt ascending, score descending, hash ascending) = a stable partition of order 1 by is_alt
-                for (int r = lane; r < n; r += 64) {
-                    const int al = l_alt[l_at[r]];
-                    int c = 0;
-                    for (int j = 0; j < n; ++j) {
-                        const int aj = l_alt[l_at[j]];
-                        c += (aj < al || (aj == al && j < r)) ? 1 : 0;
+                int c_pri = 0, c_alt = n_pri;                // next free position of either half (wave-uniform)
+                const unsigned long long below_m = (1ull << lane) - 1ull;
+                for (int rb = 0; rb < n; rb += 64) {
+                    const int r = rb + lane;
+                    const bool in = r < n;
+                    const int oi = in ? l_at[r] : 0;
+                    const bool al = in && l_alt[oi];
+                    const unsigned long long m_alt = __ballot(al), m_pri = __ballot(in && !al);
+                    if (in) {
+                        const int c = al ? c_alt + __popcll(m_alt & below_m) : c_pri + __popcll(m_pri & below_m);
+                        l_pos2[r] = c;
+                        l_at2[c] = oi;
                     }
-                    l_pos2[r] = c;
-                    l_at2[c] = l_at[r];
+                    c_alt += __popcll(m_alt);
+                    c_pri += __popcll(m_pri);
                 }
                 fin_at = l_at2;
             } else {

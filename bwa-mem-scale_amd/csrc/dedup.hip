@@ -106,12 +106,17 @@ __device__ int global_score_wave(const bwams_mem_opt_t &o, int qlen, const uint8
         if (j < qlen) qbuf[j] = qseq[(int64_t)qs * j];
     }
     __syncthreads();
+    // the pair is the wave's: lengths and band in scalar registers (scalar row and chunk loops); cross-lane moves are DPP (the
+    // neighbour) and v_readlane (lane 63, the row's end, the row's target base), the matrix row is five bytes of one scalar
+    // — the changes that took mem_reg2aln's wave kernel from 167 to 60 instructions per row chunk (profiles/r03_notes.md 88)
+    qlen = __builtin_amdgcn_readfirstlane(qlen); tlen = __builtin_amdgcn_readfirstlane(tlen); w = __builtin_amdgcn_readfirstlane(w);
     int tv = 0;
     for (int i = 0; i < tlen; ++i) {
         if ((i & 63) == 0) tv = i + lane < tlen ? (int)tseq[(int64_t)ts * (i + lane)] : 4;
-        const int tb = __shfl(tv, i & 63);
+        const int tb = __builtin_amdgcn_readlane(tv, i & 63);
         const int8_t *mrow = &o.mat[tb * 5];
-        const int s0 = mrow[0], s1 = mrow[1], s2 = mrow[2], s3 = mrow[3], s4 = mrow[4];
+        const uint64_t mpk = (uint64_t)(uint8_t)mrow[0] | (uint64_t)(uint8_t)mrow[1] << 8 | (uint64_t)(uint8_t)mrow[2] << 16 |
+                             (uint64_t)(uint8_t)mrow[3] << 24 | (uint64_t)(uint8_t)mrow[4] << 32;
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         const int h1_first = beg == 0 ? -(o.o_del + o.e_del * (i + 1)) : MINUS_INF;
@@ -119,31 +124,32 @@ __device__ int global_score_wave(const bwams_mem_opt_t &o, int qlen, const uint8
         for (int c0 = beg; c0 < end; c0 += 64) {
             const int j = c0 + lane;
             const bool act = j < end;
-            int2 p = make_int2(0, 0);
-            int qb = 4;
-            if (act) { p = eh[j]; qb = qbuf[j]; }
-            const int m = p.x + (qb == 0 ? s0 : qb == 1 ? s1 : qb == 2 ? s2 : qb == 3 ? s3 : s4);
+            const int jj = act ? j : end - 1;
+            const int2 p = eh[jj];
+            int qb = qbuf[jj];
+            qb = qb > 4 ? 4 : qb;
+            const int m = p.x + (int)(int8_t)(uint8_t)(mpk >> (qb << 3));
             int e = p.y;
             const int t_ins = m - oe_ins;
             const int g = act ? t_ins + j * o.e_ins : kNeg;
             const int P = dd_incl_max(g);
-            const int Pex = __shfl_up(P, 1);
-            int f = f_carry - (j - c0) * o.e_ins;          // what the gap open before this chunk has become
-            if (lane > 0) { const int fp = Pex - (j - 1) * o.e_ins; f = f > fp ? f : fp; }
+            const int Pex = lane_shr1(P, kNeg);            // lane 0: nothing to its left in this chunk
+            const int fc = f_carry - lane * o.e_ins;       // what the gap open before this chunk has become
+            const int fp = Pex - (j - 1) * o.e_ins;
+            const int f = fc > fp ? fc : fp;
             int h = m >= e ? m : e;
             h = h >= f ? h : f;
             const int t = m - oe_del;
             e -= o.e_del;
             e = e > t ? e : t;
             const int fn = f - o.e_ins;
-            int hl = __shfl_up(h, 1);
-            if (lane == 0) hl = h_carry;
+            const int hl = lane_shr1(h, h_carry);          // lane 0 takes the previous chunk's last h
             if (act) eh[j] = make_int2(hl, e);
             const int fnext = fn > t_ins ? fn : t_ins;
-            f_carry = __shfl(fnext, 63);
-            h_carry = __shfl(h, 63);
+            f_carry = __builtin_amdgcn_readlane(fnext, 63);
+            h_carry = __builtin_amdgcn_readlane(h, 63);
             const int last = end - 1 - c0;                 // the row's last column, if it lies in this chunk
-            if (last < 64) h_end = __shfl(h, last);
+            if (last < 64) h_end = __builtin_amdgcn_readlane(h, last);
         }
         if (lane == 0) eh[end] = make_int2(h_end, MINUS_INF);
         __syncthreads();

@@ -656,6 +656,8 @@ def main():
             "value": round(2 * n_pairs * world / dt / 1e6, 4), "unit": "Mreads/s", "ms_per_batch": round(dt * 1e3, 2),
             "pairs_per_gpu": n_pairs, "n_gpus": world,
             "ms_pestat_plus_pair": round(dt * 1e3 - float(pst.ms_seed_total + pst.ms_chain + pst.ms_ext_total + pst.ms_dedup), 2),
+            "stage_ms": {"seed_total": round(float(pst.ms_seed_total), 2), "chain": round(float(pst.ms_chain), 2), "ext_total": round(float(pst.ms_ext_total), 2), "dedup": round(float(pst.ms_dedup), 2)},
+            "seeding": "ert" if ert_h is not None else "fm-index",
             "ms_pair_run": round(float(pst.ms_pair), 3), "rescue_alignments": int(nt_pe), "reads_redone": int(pst.n_pair_redone),
             "regions_after_rescue": int(n_pe), "proper_pairs": round(float((prs["score"] > 0).mean()), 4),
             "orientations_failed": [int(x) for x in pes_["failed"]], "insert_avg_std": [round(float(pes_["avg"][1]), 2), round(float(pes_["std"][1]), 2)],

@@ -442,6 +442,12 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
             fprintf(stderr, "[bwams_chain_run] filter wave tier: reads by chains <=32 %llu <=64 %llu <=128 %llu <=256 %llu <=512 %llu <=960 %llu more %llu; "
                             "Mcycles: sequential(HBM) %.1f sort %.1f filter %.1f; chains %llu selected %llu; longest read: sort %.2f filter %.2f Mcycles, most chains %llu, most selected %llu\n",
                     d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7] / 1e6, d[8] / 1e6, d[9] / 1e6, d[11], d[10], d[12] / 1e6, d[13] / 1e6, d[14], d[15]);
+#ifdef BWAMS_CHAINDBG
+            static const char *cn[8] = {"XL", "L", "L2", "L1", "M2", "M", "M1", "S"};
+            fprintf(stderr, "[bwams_chain_run] chaining wave tier, per class: reads / mean us / longest us / wave-ms:");
+            for (int c = 0; c < 8; ++c) fprintf(stderr, "  %s %llu / %.0f / %.0f / %.1f", cn[c], d[32 + 3 * c], d[32 + 3 * c] ? d[33 + 3 * c] * 1e-2 / d[32 + 3 * c] : 0.0, d[34 + 3 * c] * 1e-2, d[33 + 3 * c] * 1e-5);
+            fprintf(stderr, "\n");
+#endif
         }
     }
     if (b->h_ctr->chain_overflow) {

@@ -817,6 +817,9 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(ChainArgs A, const unsig
         const unsigned long long t = wave_ticket(ticket, 1ull);
         if (lo + (int64_t)t >= hi) break;
         const int64_t r = (int64_t)A.order[lo + (int64_t)t];
+#ifdef BWAMS_CHAINDBG
+        const unsigned long long tk0 = wall_clock64();
+#endif
         if (K < 0) {                 // class XL: ordered array of -K chains in LDS, chain records in HBM
             if (!chain_read<true, 1, true>(A, r, lane, 64, reinterpret_cast<Node *>(l_mem), 0, nullptr, -K) && lane == 0)
                 A.redo[atomicAdd(&A.ctr->chain_redo, 1ull)] = (int32_t)r;
@@ -825,6 +828,13 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(ChainArgs A, const unsig
                 A.redo[atomicAdd(&A.ctr->chain_redo, 1ull)] = (int32_t)r;
         } else chain_read<false>(A, r, lane, 64, nullptr, 0, nullptr, 0);
         __syncthreads();
+#ifdef BWAMS_CHAINDBG
+        if (lane == 0) {
+            const int c = K < 0 ? 0 : K == kClassL ? 1 : K == kClassL2 ? 2 : K == kClassL1 ? 3 : K == kClassM2 ? 4 : K == kClassM ? 5 : K == kClassM1 ? 6 : 7;
+            const unsigned long long dt = wall_clock64() - tk0;
+            atomicAdd(&A.ctr->dbg[32 + 3 * c], 1ull); atomicAdd(&A.ctr->dbg[33 + 3 * c], dt); atomicMax(&A.ctr->dbg[34 + 3 * c], dt);
+        }
+#endif
     }
 }
 

@@ -26,14 +26,55 @@ __global__ __launch_bounds__(256) void sa_lookup_kernel(DevFmi f, const bwams_sm
                                                         int max_occ, DevCounters *ctr) {
     const int64_t total = sa_off[n_smem] < coord_cap ? sa_off[n_smem] : coord_cap;
     unsigned long long lf = 0;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-         g += (int64_t)gridDim.x * blockDim.x) {
-        // upper_bound(sa_off, g) - 1
-        int64_t lo = 0, hi = n_smem;
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (sa_off[mid] <= g) lo = mid; else hi = mid;
+    // The owner of position g is the last SMEM whose first position is <= g: a binary search over 9 M offsets, i.e. 23
+    // DEPENDENT loads per lookup, more than the LF walk behind it.  A wave takes a contiguous range of positions instead:
+    // one search for its first position, and from there the owners only move forward — 64 consecutive positions belong
+    // to at most 64 consecutive SMEMs (every SMEM has at least one), whose offsets are one coalesced load into LDS and a
+    // six-step search there.
+    __shared__ int64_t win_s[4][65];
+    int64_t *const win = win_s[threadIdx.x >> 6];
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t n_waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t per = ((total + n_waves - 1) / n_waves + 63) & ~(int64_t)63;
+    const int64_t start = wave * per, end = start + per < total ? start + per : total;
+    int64_t lo0 = 0;
+    if (start < end) {
+        int64_t a = 0, b = n_smem;
+        while (b - a > 1) {
+            const int64_t mid = (a + b) >> 1;
+            if (sa_off[mid] <= start) a = mid; else b = mid;
         }
+        lo0 = a;
+    }
+    for (int64_t g0 = start; g0 < end; g0 += 64) {
+        const int64_t g = g0 + lane;
+        {
+            const int64_t c = lo0 + 1 + lane;
+            win[lane] = c <= n_smem ? sa_off[c] : INT64_MAX;
+            if (lane == 0) win[64] = INT64_MAX;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int t = 0;                                            // first candidate whose offset is beyond g
+        for (int stp = 32; stp > 0; stp >>= 1)
+            if (win[t + stp - 1] <= g) t += stp;
+        if (t == 63 && win[63] <= g) t = 64;
+        int64_t lo = lo0 + t;
+        if (t == 64 && g < end) {                             // not within 64 SMEMs (never, while every SMEM has a position): search
+            int64_t a = lo, b = n_smem;
+            while (b - a > 1) {
+                const int64_t mid = (a + b) >> 1;
+                if (sa_off[mid] <= g) a = mid; else b = mid;
+            }
+            lo = a;
+        }
+        {   // the next trip starts from the owner of this trip's last position
+            const int last = (int)((end - g0 < 64 ? end - g0 : 64) - 1);
+            const uint32_t l_lo = (uint32_t)lo, l_hi = (uint32_t)((uint64_t)lo >> 32);
+            lo0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)l_hi, last) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)l_lo, last));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (g >= end) continue;
         const int64_t k = sm[lo].k, s = sm[lo].s;
         const int64_t step = s > (int64_t)max_occ ? s / max_occ : 1;
         int64_t sp = k + (g - sa_off[lo]) * step;

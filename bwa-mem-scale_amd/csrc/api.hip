@@ -672,6 +672,13 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
         a.bwd_min_list = ml ? atoi(ml) : 40;
         a.bwd_cols = mc ? atoi(mc) : 24;
         a.bwd_late_list = mt ? atoi(mt) : 8;
+        {
+            const char *d1 = getenv("BWAMS_BWD_DRY_MIN_LIST"), *d2 = getenv("BWAMS_BWD_DRY_COLS"), *d3 = getenv("BWAMS_BWD_DRY_LATE_LIST");
+            // once the work queue has run dry: 24 entries at the forward end, or 12 alive after 8 columns (tools/exp_bwd_dry.sh)
+            a.bwd_dry_min_list = d1 ? atoi(d1) : 24;
+            a.bwd_dry_cols = d2 ? atoi(d2) : 8;
+            a.bwd_dry_late_list = d3 ? atoi(d3) : 12;
+        }
     }
     const int split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
 

@@ -26,6 +26,7 @@ struct SeedLaunch {
     uint4 *bwd_ent;
     int64_t bwd_items_cap, bwd_ent_cap;
     int bwd_min_list;
+    int bwd_dry_min_list, bwd_dry_cols, bwd_dry_late_list;   // the same three thresholds once the work queue has run dry
     int bwd_cols, bwd_late_list;  // ... or, later: after bwd_cols columns with bwd_late_list entries still alive
 };
 

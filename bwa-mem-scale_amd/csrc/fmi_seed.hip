@@ -540,6 +540,8 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                                                 kPrevLds * kBlock) + (threadIdx.x >> 6) * kPivotQueue;
     int pq_head = 0, pq_n = 0;                // wave-uniform
     bool spawned = false;                     // this lane's read goes on in another lane: leave the read after this pivot
+    bool dry = false;                         // wave-uniform: the work queue has run out, the launch is draining
+    bool ho_tried = false;                    // this pivot's late hand-over has been decided (once per pivot)
     const unsigned long long lanes_below = (1ull << (threadIdx.x & 63)) - 1ull;
 
 #ifdef BWAMS_BWDDBG
@@ -642,6 +644,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
         if (!tk_dry && __any(phase == PH_EXIT)) tk_dry = wall_clock64();
 #endif
         if (__all(phase == PH_EXIT)) break;
+        dry = dry || __any(phase == PH_EXIT);
 
         // ---- open a pivot -----------------------------------------------------------
         if (phase == PH_PIVOT) {
@@ -660,6 +663,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     j = x + 1;
                     next_x = x + 1;
                     num_prev = 0;
+                    ho_tried = false;
                     phase = PH_FWD;
                     if (f.all_smem && len - x >= f.all_bp) {
                         // FMA: the first forward steps come from one all_smem entry (FMI_search.cpp:1414-1463)
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                 num_prev++;
             }
             base = cap - num_prev;                      // entry p lives at base + p, longest first
-            if (bwd_hand_over(a, prev, base, num_prev, rid, x, min_intv, a.bwd_min_list)) {
+            if (bwd_hand_over(a, prev, base, num_prev, rid, x, min_intv, dry ? a.bwd_dry_min_list : a.bwd_min_list)) {
                 x = next_x;
                 phase = ALL_POS ? PH_PIVOT : PH_FETCH;
             } else {
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     num_prev++;
                 }
                 base = cap - num_prev;
-                if (bwd_hand_over(a, prev, base, num_prev, rid, x, min_intv, a.bwd_min_list)) {
+                if (bwd_hand_over(a, prev, base, num_prev, rid, x, min_intv, dry ? a.bwd_dry_min_list : a.bwd_min_list)) {
                     x = next_x;
                     phase = ALL_POS ? PH_PIVOT : PH_FETCH;
                 } else {
@@ -827,9 +831,14 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     j--;
                     p = 0; num_curr = 0; curr_s = -1; first = true;
                     // a backward phase that has proven long: the rest of it goes to the wave kernel (which resumes at column cur_m - 1)
-                    if (x - cur_m == a.bwd_cols && bwd_hand_over(a, prev, base, num_prev, rid, cur_m, min_intv, a.bwd_late_list)) {
-                        x = next_x;
-                        phase = (ALL_POS && !spawned) ? PH_PIVOT : PH_FETCH;
+                    // ... sooner while the launch drains: the lanes are mostly idle by then, and a backward phase just under the
+                    // thresholds (39 entries x 24 columns) is 900 steps on one lane
+                    if (!ho_tried && x - cur_m >= (dry ? a.bwd_dry_cols : a.bwd_cols)) {
+                        ho_tried = true;
+                        if (bwd_hand_over(a, prev, base, num_prev, rid, cur_m, min_intv, dry ? a.bwd_dry_late_list : a.bwd_late_list)) {
+                            x = next_x;
+                            phase = (ALL_POS && !spawned) ? PH_PIVOT : PH_FETCH;
+                        }
                     }
                 }
             }

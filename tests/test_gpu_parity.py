@@ -58,6 +58,8 @@ def test_smem_and_sa_match_oracle(gpu_toy):
     {"BWAMS_BWD_MIN_LIST": "1"},                                                       # every backward phase on the wave kernel
     {"BWAMS_BWD_MIN_LIST": "5", "BWAMS_BWD_COLS": "4", "BWAMS_BWD_LATE_LIST": "2"},     # at the forward end, or four columns in
     {"BWAMS_BWD_MIN_LIST": "200", "BWAMS_BWD_COLS": "2", "BWAMS_BWD_LATE_LIST": "1"},   # only ever two columns in
+    {"BWAMS_BWD_MIN_LIST": "200", "BWAMS_BWD_COLS": "200", "BWAMS_BWD_LATE_LIST": "200",
+     "BWAMS_BWD_DRY_MIN_LIST": "2", "BWAMS_BWD_DRY_COLS": "1", "BWAMS_BWD_DRY_LATE_LIST": "1"},                     # only while the launch drains
     {"BWAMS_BWD_MIN_LIST": "0"},                                                       # never
 ])
 def test_backward_phases_handed_to_the_wave_kernel(gpu_toy, monkeypatch, env):

@@ -482,31 +482,7 @@ __device__ int global2_dp_wave(const RegAlnArgs &A, const Seqs &S, int w, int2 *
     return eh[qlen].x;
 }
 
-// the traceback of ksw_global2 (ksw.cpp:639-664) over the direction bytes the last DP left
-__device__ void global2_traceback(const Seqs &S, int w, const uint32_t *z, uint32_t *cigar, int *n_cigar_) {
-    const int qlen = S.lq, tlen = S.lr;
-    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-    const int zw = (n_col + 3) >> 2;
-    int n = 0, which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
-    auto push = [&](int op, int len) {
-        if (n == 0 || op != (int)(cigar[n - 1] & 0xf)) cigar[n++] = (uint32_t)len << 4 | (uint32_t)op;
-        else cigar[n - 1] += (uint32_t)len << 4;
-    };
-    while (i >= 0 && k >= 0) {
-        const int c = k - (i > w ? i - w : 0);
-        const uint32_t d = (z[(size_t)i * zw + (c >> 2)] >> ((c & 3) * 8)) & 0xffu;
-        which = (int)(d >> (which << 1)) & 3;
-        if (which == 0) { push(0, 1); --i; --k; }
-        else if (which == 1) { push(2, 1); --i; }
-        else { push(1, 1); --k; }
-    }
-    if (i >= 0) push(2, i + 1);
-    if (k >= 0) push(1, k + 1);
-    for (int a = 0; a < n >> 1; ++a) { const uint32_t t = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = t; }
-    *n_cigar_ = n;
-}
-
-// The same traceback for a wavefront: lane 0 walks, all lanes fetch.  A step of the walk reads one direction byte that the
+// The traceback of ksw_global2 (ksw.cpp:639-664) over the direction bytes the last DP left: lane 0 walks, all lanes fetch.  A step of the walk reads one direction byte that the
 // DP left in HBM scratch, and the next byte's address depends on it: 270 dependent loads of ~0.5 us each were a third of this
 // kernel's time per region (profiles/r03_notes.md 88).  The path only moves up and to the left, so from (i, k) it stays inside
 // the kTbWin x kTbWin cells above and to the left of it for at least kTbWin steps: the wave copies that window into LDS with

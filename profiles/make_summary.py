@@ -127,7 +127,7 @@ fetch, write = (r1["FETCH_SIZE"] + b1.get("FETCH_SIZE", 0)) * 1024, (r1["WRITE_S
 alg = bench["roofline"]["bytes_per_launch"]
 with open(f"profiles/{rnd}_summary.md", "w") as f:
     f.write(f"# Round {rnd} — rocprofv3 summary (MI355X, gfx950, ROCm 7.2)\n\n")
-    f.write("Collected by `bash profiles/run_profiles_{rnd}.sh <tag>` at the metric's configuration (synthetic genome of GRCh38's size, 6.4 G index rows): "
+    f.write(f"Collected by `bash profiles/run_profiles_{rnd}.sh <tag>` at the metric's configuration (synthetic genome of GRCh38's size, 6.4 G index rows): "
             "`rocprofv3 --kernel-trace --stats -- python3 bench.py "
             "--steps 2 --warmup 1 --no-cpu-baseline --no-pe --no-ert-leg --no-hard-genome` plus one `--pmc` pass per counter group (never combined "
             f"with tracing); summarised by `profiles/make_summary.py`.  Raw: `profiles/{rnd}_kernel_stats.csv`.\n\n")

@@ -163,6 +163,16 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
                     f"{ef/1e9:.2f} + {ew/1e9:.2f} = **{(2*ef+ew)/1e9:.1f} GB**; SQ: ACTIVE_INST_ANY / WAVE_CYCLES = "
                     f"{E.get('SQ_ACTIVE_INST_ANY',0)/max(E.get('SQ_WAVE_CYCLES',1),1):.3f}, WAIT_ANY / WAVE_CYCLES = {E.get('SQ_WAIT_ANY',0)/max(E.get('SQ_WAVE_CYCLES',1),1):.3f}, "
                     f"{E.get('SQ_INSTS_VALU',0)/1e9:.2f} G VALU + {E.get('SQ_INSTS_SALU',0)/1e9:.2f} G SALU + {E.get('SQ_INSTS_VMEM_RD',0)/1e9:.3f} G VMEM-read wave-instructions.\n")
+    kt = newest(src + "/trace/*/*_kernel_trace.csv")
+    if kt:
+        tr = sorted((r for r in csv.DictReader(open(kt[0])) if "smem_bwd_wave" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+        d1 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr[0::2]]
+        d2 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr[1::2]]
+        sr = [float(r["AverageNs"]) / 1e6 for r in rows if "smem_search_kernel<true>" in r["Name"]]
+        if d1 and sr:
+            f.write(f"\nRound 1 = `smem_search_kernel<true>` + the launch of `smem_bwd_wave_kernel` behind it (its launches alternate: behind round 1, behind round 2): "
+                    f"rocprofv3 averages {sr[0]:.2f} + {sum(d1)/len(d1):.2f} = **{sr[0] + sum(d1)/len(d1):.2f} ms** (the launch behind round 2: {sum(d2)/max(len(d2),1):.2f} ms), "
+                    f"to compare with `roofline.launch_ms` = {bench['roofline']['launch_ms']} ms, which brackets both with HIP events.\n")
     f.write(f"\n`roofline.launch_ms` measured live by `bench.py` with HIP events in the run below: {bench['roofline']['launch_ms']} ms "
             "(the rocprofv3 average above covers warm-up + timed launches of the profiled run).\n\n")
     f.write("## PMC per launch (uncorrected counter values; average over the launches of one run)\n\n"

@@ -443,8 +443,8 @@ static int alloc_smem_buffers(bwams_batch *b, int64_t max_smem) {
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     b->max_smem = max_smem;
     // the pool is handed out in per-wave chunks: room for every wave's partly filled last chunk
-    // of each of the three rounds on top of the max_smem real records
-    b->pool_cap = b->max_smem + 3 * seed_pool_slack(b->cu_count);
+    // of each of the five emitting launches on top of the max_smem real records
+    b->pool_cap = b->max_smem + seed_pool_slack(b->cu_count);
     BWAMS_HIP(dev_malloc(&b->d_pool, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
     BWAMS_HIP(dev_malloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
     BWAMS_HIP(dev_malloc(&b->d_keys, (size_t)b->pool_cap * 8));
@@ -603,12 +603,15 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
     }
     // backward phases with long interval lists (smem_bwd_wave_kernel): a slot per read and eight list entries per read cover
     // what uniform and repeat-rich genomes produce several times over; when they are full a pivot simply stays on its lane
-    const int64_t bi = std::max<int64_t>(nseq, 4096), be = std::max<int64_t>(nseq, 4096) * 8;
+    // (two item arrays of bi slots in one allocation: long lists, short lists; once a launch drains every backward phase leaves its
+    // lane, about half a pivot per read in flight, profiles/r04_notes.md)
+    static const int64_t cap_mul = getenv("BWAMS_BWD_CAP_MUL") ? atoi(getenv("BWAMS_BWD_CAP_MUL")) : 1;     // lab: room for EVERY backward phase
+    const int64_t bi = std::max<int64_t>(nseq, 4096) * 2 * cap_mul, be = std::max<int64_t>(nseq, 4096) * 24 * cap_mul;
     if (bi > b->bwd_items_cap) {
         if (b->d_bwd_items) (void)hipFree(b->d_bwd_items);
         if (b->d_bwd_ent) (void)hipFree(b->d_bwd_ent);
         b->d_bwd_items = nullptr; b->d_bwd_ent = nullptr; b->bwd_items_cap = b->bwd_ent_cap = 0;
-        BWAMS_HIP(dev_malloc(&b->d_bwd_items, (size_t)bi * sizeof(BwdItem)));
+        BWAMS_HIP(dev_malloc(&b->d_bwd_items, (size_t)bi * 2 * sizeof(BwdItem)));
         BWAMS_HIP(dev_malloc(&b->d_bwd_ent, (size_t)be * 16));
         b->bwd_items_cap = bi;
         b->bwd_ent_cap = be;
@@ -625,9 +628,11 @@ int bwams_seed_run(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with_sa) {
     b->last_seed_opt = *opt;
     b->seed_ert = nullptr;
     int rc = seed_run_once(b, opt, with_sa);
-    if (rc == BWAMS_ERR_CAPACITY && b->n_smem > b->max_smem) {
+    if (rc == BWAMS_ERR_CAPACITY && (b->n_smem > b->max_smem || b->n_pool_slots > b->pool_cap)) {
         BWAMS_HIP(hipStreamSynchronize(b->stream));
-        const int64_t need = b->n_smem + b->n_smem / 4 + 1024;
+        // the slots handed out (holes included) bound what the chunk needs whatever filled the pool
+        const int64_t seen = std::max(b->n_smem, b->n_pool_slots - seed_pool_slack(b->cu_count));
+        const int64_t need = std::max(seen, b->max_smem) + seen / 4 + 1024;
         if ((rc = alloc_smem_buffers(b, need))) return rc;
         b->tmp_bytes = 0;                           // rocPRIM scratch is re-queried per call
         if (b->d_tmp) { (void)hipFree(b->d_tmp); b->d_tmp = nullptr; }
@@ -662,6 +667,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     a.prev_cap = b->prev_cap;
     a.prev_threads = b->prev_threads;
     a.bwd_items = b->d_bwd_items;
+    a.bwd_items_s = b->d_bwd_items + b->bwd_items_cap;
     a.bwd_ent = b->d_bwd_ent;
     a.bwd_items_cap = b->bwd_items_cap;
     a.bwd_ent_cap = b->bwd_ent_cap;
@@ -689,6 +695,11 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     launch_mark(b->d_ctr, 0, st);
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
     if (b->nseq > 0) launch_smem_round1(a, b->cu_count, st);
+#ifdef BWAMS_BWDDBG
+    static hipEvent_t dbg_ev = nullptr;
+    if (!dbg_ev) BWAMS_HIP(hipEventCreate(&dbg_ev));
+    BWAMS_HIP(hipEventRecord(dbg_ev, st));
+#endif
     if (b->nseq > 0) launch_smem_bwd_wave(a, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[9], st));
     launch_mark(b->d_ctr, 1, st);
@@ -729,9 +740,15 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
 #ifdef BWAMS_BWDDBG
     if (getenv("BWAMS_VERBOSE")) {
         const unsigned long long *d = b->h_ctr->dbg;
+        { float m1 = 0, m2 = 0; (void)hipEventElapsedTime(&m1, b->ev[8], dbg_ev); (void)hipEventElapsedTime(&m2, dbg_ev, b->ev[9]);
+          fprintf(stderr, "[smem_r1] search kernel %.3f ms, the two backward kernels behind it %.3f ms\n", m1, m2); }
         fprintf(stderr, "[bwd_wave] rounds 1+2: items %llu, column batches %llu (%.1f per item), waves with work %llu: busy mean %.3f ms max %.3f ms, "
                 "of it between items (ticket, item, list, read) %.1f %%, per column batch %.2f us\n", d[0], d[1], d[0] ? (double)d[1] / d[0] : 0.0, d[5],
                 d[5] ? d[2] / (double)d[5] * 1e-5 : 0.0, d[4] * 1e-5, d[2] ? 100.0 * d[3] / d[2] : 0.0, d[1] ? (d[2] - d[3]) * 1e-2 / d[1] : 0.0);
+        fprintf(stderr, "[bwd_group] rounds 1+2: items %llu, wave-iterations %llu (groups live per iteration %.2f), waves with work %llu: busy mean %.3f ms max %.3f ms; "
+                "first in %.3f last out %.3f ms after round 1's start; [bwd_wave] first in %.3f last out %.3f\n", d[68], d[69], d[69] ? (double)d[70] / d[69] : 0.0, d[72],
+                d[72] ? d[71] * 1e-5 / d[72] : 0.0, d[73] * 1e-5, (~d[75] - ~d[8]) * 1e-5, (d[74] - ~d[8]) * 1e-5, (~d[7] - ~d[8]) * 1e-5, (d[6] - ~d[8]) * 1e-5);
+        fprintf(stderr, "[bwd_group] extensions %llu of %llu (rounds 1+2)\n", d[76], (unsigned long long)b->h_ctr->ext_after[1]);
         const unsigned long long t0 = ~d[8], tdry = ~d[9];
         fprintf(stderr, "[smem_r1] waves %llu: read queue dry at %.3f ms, last wave out at %.3f ms, mean wave life %.3f ms (%.3f ms of it after the queue ran dry); "
                 "iterations %llu, lanes extending per iteration %.1f\n", d[12], (tdry - t0) * 1e-5, (d[10] - t0) * 1e-5, d[12] ? d[11] * 1e-5 / d[12] : 0.0,
@@ -744,6 +761,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     const int64_t n_slots = (int64_t)b->h_ctr->n_smem_total;      // pool slots handed out (holes included)
     const int64_t n = (int64_t)b->h_ctr->n_smem_valid;           // real SMEMs
     b->n_smem = n;
+    b->n_pool_slots = n_slots;
     if (n > b->max_smem || n_slots > b->pool_cap) {
         set_last_error("SMEM pool overflow: need " + std::to_string(n) + " slots");
         b->seed_done = true;
@@ -1195,9 +1213,11 @@ int bwams_seed_run_ert(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t 
     b->last_seed_opt = *opt;
     b->seed_ert = e;
     int rc = ert_run_once(b, e, opt, with_sa, M);
-    if (rc == BWAMS_ERR_CAPACITY && b->n_smem > b->max_smem) {
+    if (rc == BWAMS_ERR_CAPACITY && (b->n_smem > b->max_smem || b->n_pool_slots > b->pool_cap)) {
         BWAMS_HIP(hipStreamSynchronize(b->stream));
-        const int64_t need = b->n_smem + b->n_smem / 4 + 1024;
+        // the slots handed out (holes included) bound what the chunk needs whatever filled the pool
+        const int64_t seen = std::max(b->n_smem, b->n_pool_slots - seed_pool_slack(b->cu_count));
+        const int64_t need = std::max(seen, b->max_smem) + seen / 4 + 1024;
         if ((rc = alloc_smem_buffers(b, need))) return rc;
         b->tmp_bytes = 0;
         if (b->d_tmp) { (void)hipFree(b->d_tmp); b->d_tmp = nullptr; }

@@ -112,6 +112,7 @@ struct DevCounters {
     unsigned long long n_rest;           // extension: slots behind the requests of the last selection (an upper bound of the undecided seeds)
     unsigned long long ert_ticket;       // ERT walk: work cursor of ert_profile_kernel (groups of 64 read positions)
     unsigned long long bwd_items, bwd_entries, bwd_ticket;   // SMEM search: backward phases handed to the wave kernel, their list entries, its work cursor
+    unsigned long long bwd_items_s, bwd_ticket_s;            // ... the short lists (smem_bwd_group_kernel): slots handed out, work cursor
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };
 
@@ -244,6 +245,7 @@ struct bwams_batch {
     int prev_cap = 0;
 
     int64_t n_smem = 0, n_sa = 0;
+    int64_t n_pool_slots = 0;            // SMEM pool slots the last seeding pass handed out (holes included)
     bool seed_done = false, with_sa = false;
     bwams_ert *seed_ert = nullptr;       // the last seed run went over this ERT (nullptr: FM-index)
     uint8_t *d_ert_prof = nullptr;       // ERT seeding: match-length planes, (M + 1) x nbases bytes

@@ -22,7 +22,7 @@ struct SeedLaunch {
     int prev_cap;                 // entries per lane
     int64_t prev_threads;         // lanes the scratch was sized for
     // backward phases whose interval list has at least bwd_min_list entries go to smem_bwd_wave_kernel (0 = never)
-    BwdItem *bwd_items;
+    BwdItem *bwd_items, *bwd_items_s;   // lists beyond / up to kBwdShortMax entries; bwd_items_cap slots each
     uint4 *bwd_ent;
     int64_t bwd_items_cap, bwd_ent_cap;
     int bwd_min_list;
@@ -33,7 +33,7 @@ struct SeedLaunch {
 // grid sizing shared by batch_create (scratch) and the launches
 int seed_block_threads();
 int64_t seed_max_threads(int cu_count);
-int64_t seed_pool_slack(int cu_count);   // pool slots one kernel can leave unused in partly filled chunks
+int64_t seed_pool_slack(int cu_count);   // pool slots the launches of one seeding pass can leave unused in partly filled chunks
 
 // enc_qdb bytes -> 2-bit codes + N mask, W words per read
 void launch_pack_reads(const uint8_t *enc, const int64_t *cum, int64_t nseq, int W, int cw, uint32_t *packed,

@@ -375,22 +375,102 @@ __device__ __forceinline__ uint4 prev_raw(const PrevList &pl, int base, int p) {
 // round trip per column.  The lane moves on to its next pivot at once.  Returns false (nothing handed over: run the
 // backward phase here) when the list is short, too long for the wave kernel's LDS, or the buffers are full.
 constexpr int kBwdMaxList = 256;
+constexpr int kBwdShortMax = 32;           // lists up to here go to smem_bwd_group_kernel (16 lanes per pivot), longer ones to smem_bwd_wave_kernel
 constexpr int kPivotQueue = 64;            // per wavefront, power of two (smem_search_kernel<true>)
-__device__ __forceinline__ bool bwd_hand_over(const SeedLaunch &a, const PrevList &pl, int base, int num_prev, uint32_t rid,
-                                              int x, int min_intv, int min_list) {
-    if (a.bwd_min_list <= 0 || num_prev < min_list || num_prev > kBwdMaxList) return false;
-    const unsigned long long it = atomicAdd(&a.ctr->bwd_items, 1ull);
-    if ((int64_t)it >= a.bwd_items_cap) return false;
-    BwdItem w;
-    w.rid = rid; w.x = x; w.min_intv = min_intv; w.num_prev = 0; w.off = 0;
-    const unsigned long long eo = atomicAdd(&a.ctr->bwd_entries, (unsigned long long)num_prev);
-    const bool fits = (int64_t)(eo + (unsigned long long)num_prev) <= a.bwd_ent_cap;
-    if (fits) {
-        for (int p = 0; p < num_prev; ++p) a.bwd_ent[eo + p] = prev_raw(pl, base, p);
-        w.num_prev = num_prev;
-        w.off = (int64_t)eo;
+
+// Hand-over slots are reserved per WAVE, in chunks: one atomic per chunk of item slots and one per chunk of entry slots instead
+// of two per pivot.  (Round 3's first attempt to hand over every backward phase once the queue was dry put 1 M atomics on two
+// words and cost 4 ms, profiles/r03_notes.md 87; a hot word serves ~90 M atomics/s.)  Item slots a wave reserved but did not fill
+// are stamped num_prev = 0 when the chunk is closed — the wave kernels skip them; unused entry slots are simply never read.
+// While the launch is in its steady state a wave hands over a pivot now and then: small chunks, few holes.  Once it drains,
+// every backward phase leaves its lane (see below): large chunks.
+struct HoState {
+    long long it_base[2];   // first slot of the current chunk per class (0 long lists, 1 short lists), -1 = none   (wave-uniform)
+    int it_used[2], it_cap[2];
+    long long en_base;      // next free entry slot of the current chunk
+    int en_left;
+};
+__device__ __forceinline__ void ho_init(HoState &h) {
+    h.it_base[0] = h.it_base[1] = -1;
+    h.it_used[0] = h.it_used[1] = h.it_cap[0] = h.it_cap[1] = 0;
+    h.en_base = 0;
+    h.en_left = 0;
+}
+template <int CLS>
+__device__ __forceinline__ void ho_close_items(const SeedLaunch &a, HoState &h) {
+    const int lane = (int)(threadIdx.x & 63);
+    if (h.it_base[CLS] >= 0) {
+        const long long slot = h.it_base[CLS] + h.it_used[CLS] + lane;       // chunks hold at most 64 slots
+        if (h.it_used[CLS] + lane < h.it_cap[CLS] && slot < a.bwd_items_cap) (CLS ? a.bwd_items_s : a.bwd_items)[slot].num_prev = 0;
     }
-    a.bwd_items[it] = w;                        // num_prev = 0: the slot stays empty
+    h.it_base[CLS] = -1;
+    h.it_used[CLS] = h.it_cap[CLS] = 0;
+}
+// MUST be called by all 64 lanes.  Returns the slot of a requesting lane (-1: none, or the array is full).
+template <int CLS>
+__device__ __forceinline__ long long ho_item_slot(const SeedLaunch &a, HoState &h, bool req, bool dry) {
+    const unsigned long long m = __ballot(req);
+    if (!m) return -1;
+    const int lane = (int)(threadIdx.x & 63);
+    const int cnt = __popcll(m);
+    if (h.it_base[CLS] < 0 || h.it_used[CLS] + cnt > h.it_cap[CLS]) {
+        ho_close_items<CLS>(a, h);
+        const int chunk = dry ? 64 : (cnt > 8 ? cnt : 8);
+        h.it_base[CLS] = (long long)wave_ticket(CLS ? &a.ctr->bwd_items_s : &a.ctr->bwd_items, (unsigned long long)chunk);
+        h.it_cap[CLS] = chunk;
+    }
+    const long long slot = h.it_base[CLS] + h.it_used[CLS] + __popcll(m & ((1ull << lane) - 1ull));
+    h.it_used[CLS] += cnt;
+    return req && slot < a.bwd_items_cap ? slot : -1;
+}
+
+// ---- backward phases leave the lane ------------------------------------------------------------
+// A backward phase costs (entries of the list) x (columns until the list dies) dependent extensions, all of them on one
+// lane.  Measured on the bench reads (profiles/r03_notes.md 86): the forward phases cost 149 extensions per read whatever
+// the read, the backward phases 71 % of the work with a median of 135 extensions, a 99.99th percentile of 1145 and a
+// maximum of 4345 (112 entries x 85 columns) — and the launch ends when the lane holding that pivot does.  The entries of
+// a column are independent extensions (FMI_search.cpp:1529-1590 decides on them in order, but computes them one by one only
+// because it is scalar code), so a pivot can be written out — pivot, min_intv, the packed entries — and its backward phase
+// run by a kernel that gives every entry a lane: one memory round trip per column instead of one per entry and column.
+// Lanes that want to hand their pivot over arrive here with `req` set; the wave reserves the slots together (HoState).
+// Returns true for the lanes whose pivot has left; false (run the backward phase here) when the buffers are full.
+// MUST be called by all 64 lanes.
+__device__ __forceinline__ bool bwd_hand_over(const SeedLaunch &a, HoState &h, const PrevList &pl, bool req, int base, int num_prev,
+                                              uint32_t rid, int x, int min_intv, bool dry) {
+    if (!__any(req)) return false;
+    const int lane = (int)(threadIdx.x & 63);
+    const bool is_short = num_prev <= kBwdShortMax;
+    const long long sl = ho_item_slot<0>(a, h, req && !is_short, dry);
+    const long long ss = ho_item_slot<1>(a, h, req && is_short, dry);
+    const long long slot = is_short ? ss : sl;
+    // entry slots: an exclusive prefix sum of the list lengths over the requesting lanes
+    const int mine = req ? num_prev : 0;
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    if (h.en_left < total) {
+        const int chunk = dry ? 2048 : 256;
+        const int step = total > chunk ? total : chunk;
+        h.en_base = (long long)wave_ticket(&a.ctr->bwd_entries, (unsigned long long)step);
+        h.en_left = step;
+    }
+    const long long eo = h.en_base + (long long)(incl - mine);
+    h.en_base += total;
+    h.en_left -= total;
+    const bool fits = req && slot >= 0 && eo + (long long)mine <= a.bwd_ent_cap;
+    if (req && slot >= 0) {
+        BwdItem w;
+        w.rid = rid; w.x = x; w.min_intv = min_intv; w.num_prev = 0; w.off = 0;
+        if (fits) {
+            for (int p = 0; p < num_prev; ++p) a.bwd_ent[eo + p] = prev_raw(pl, base, p);
+            w.num_prev = num_prev;
+            w.off = (int64_t)eo;
+        }
+        (is_short ? a.bwd_items_s : a.bwd_items)[slot] = w;       // num_prev = 0: the slot stays empty
+    }
     return fits;
 }
 
@@ -516,7 +596,7 @@ __global__ void pack_reads_kernel(const uint8_t *__restrict__ enc, const int64_t
     packed[g] = v;
 }
 
-enum : int { PH_FETCH = 0, PH_LOAD, PH_HOLD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BWD, PH_BWD_END, PH_EXIT };
+enum : int { PH_FETCH = 0, PH_LOAD, PH_HOLD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BWD, PH_BWD_END, PH_EXIT, PH_HO, PH_HO_LATE };
 
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
 // !ALL_POS: work item = (read, pivot, min_intv), one pivot (round 2).
@@ -541,7 +621,10 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
     int pq_head = 0, pq_n = 0;                // wave-uniform
     bool spawned = false;                     // this lane's read goes on in another lane: leave the read after this pivot
     bool dry = false;                         // wave-uniform: the work queue has run out, the launch is draining
-    bool ho_tried = false;                    // this pivot's late hand-over has been decided (once per pivot)
+    bool ho_tried = false;                    // this pivot's late hand-over has been decided (once per pivot and state of the queue)
+    int ho_x = 0;                             // PH_HO / PH_HO_LATE: the column the wave kernel resumes in front of
+    HoState ho;
+    ho_init(ho);
     const unsigned long long lanes_below = (1ull << (threadIdx.x & 63)) - 1ull;
 
 #ifdef BWAMS_BWDDBG
@@ -644,7 +727,10 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
         if (!tk_dry && __any(phase == PH_EXIT)) tk_dry = wall_clock64();
 #endif
         if (__all(phase == PH_EXIT)) break;
-        dry = dry || __any(phase == PH_EXIT);
+        if (!dry && __any(phase == PH_EXIT)) {
+            dry = true;
+            ho_tried = false;                   // the thresholds have just dropped: running backward phases are asked again
+        }
 
         // ---- open a pivot -----------------------------------------------------------
         if (phase == PH_PIVOT) {
@@ -730,9 +816,9 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                 num_prev++;
             }
             base = cap - num_prev;                      // entry p lives at base + p, longest first
-            if (bwd_hand_over(a, prev, base, num_prev, rid, x, min_intv, dry ? a.bwd_dry_min_list : a.bwd_min_list)) {
-                x = next_x;
-                phase = ALL_POS ? PH_PIVOT : PH_FETCH;
+            if (a.bwd_min_list > 0 && num_prev >= (dry ? a.bwd_dry_min_list : a.bwd_min_list) && num_prev <= kBwdMaxList) {
+                ho_x = x;
+                phase = PH_HO;                          // decided at the wave-uniform point below
             } else {
                 j = x - 1;
                 p = 0; num_curr = 0; curr_s = -1; first = true;
@@ -762,7 +848,11 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
 
         // ---- the one extension of this iteration -------------------------------------
         int64_t nk = 0, nl = 0, ns = 0;
+#ifdef BWAMS_NO_BLKCACHE
+        backward_ext_coop(f, do_ext, ek, el, es, ea, nk, nl, ns);
+#else
         backward_ext_cached(f, bc, do_ext, ek, el, es, ea, nk, nl, ns);
+#endif
         if (do_ext) {
             n_ext++;
             n_blk += ((ek >> 6) == ((ek + es) >> 6)) ? 1 : 2;
@@ -792,9 +882,9 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     num_prev++;
                 }
                 base = cap - num_prev;
-                if (bwd_hand_over(a, prev, base, num_prev, rid, x, min_intv, dry ? a.bwd_dry_min_list : a.bwd_min_list)) {
-                    x = next_x;
-                    phase = ALL_POS ? PH_PIVOT : PH_FETCH;
+                if (a.bwd_min_list > 0 && num_prev >= (dry ? a.bwd_dry_min_list : a.bwd_min_list) && num_prev <= kBwdMaxList) {
+                    ho_x = x;
+                    phase = PH_HO;
                 } else {
                     j = x - 1;
                     p = 0; num_curr = 0; curr_s = -1; first = true;
@@ -835,10 +925,32 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
                     // thresholds (39 entries x 24 columns) is 900 steps on one lane
                     if (!ho_tried && x - cur_m >= (dry ? a.bwd_dry_cols : a.bwd_cols)) {
                         ho_tried = true;
-                        if (bwd_hand_over(a, prev, base, num_prev, rid, cur_m, min_intv, dry ? a.bwd_dry_late_list : a.bwd_late_list)) {
-                            x = next_x;
-                            phase = (ALL_POS && !spawned) ? PH_PIVOT : PH_FETCH;
+                        if (a.bwd_min_list > 0 && num_prev >= (dry ? a.bwd_dry_late_list : a.bwd_late_list) && num_prev <= kBwdMaxList) {
+                            ho_x = cur_m;
+                            phase = PH_HO_LATE;
                         }
+                    }
+                }
+            }
+        }
+        // ---- backward phases that leave the lane (bwd_hand_over) ---------------------------------
+        {
+            const bool rq = phase == PH_HO || phase == PH_HO_LATE;
+            if (__any(rq)) {
+                const bool gone = bwd_hand_over(a, ho, prev, rq, base, num_prev, rid, ho_x, min_intv, dry);
+                if (rq) {
+                    if (gone) {
+                        x = next_x;
+                        want_push = false;      // a one-entry column ends in the iteration of its forward end: the lane goes on with the read itself
+                        phase = (ALL_POS && !spawned) ? PH_PIVOT : PH_FETCH;
+                    } else if (phase == PH_HO) {            // the buffers are full: the backward phase runs here
+                        j = x - 1;
+                        p = 0; num_curr = 0; curr_s = -1; first = true;
+                        cur_m = x;
+                        phase = PH_BWD;
+                        want_push = ALL_POS && next_x < len;
+                    } else {
+                        phase = PH_BWD;                     // ... goes on here: its state is untouched
                     }
                 }
             }
@@ -888,6 +1000,8 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
         }
     }
 #endif
+    ho_close_items<0>(a, ho);
+    ho_close_items<1>(a, ho);
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
@@ -902,12 +1016,22 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
 // Kept entries are compacted to the front of the list (writes land below the batch being read).  Extensions and blocks are
 // counted as the lane-per-read kernel counts them.
 constexpr int kBwdItemsPerTicket = 4;
-__global__ __launch_bounds__(kBlock) void smem_bwd_wave_kernel(SeedLaunch a) {
+// LDS of the launch behind a search kernel, per WAVEFRONT (its waves move from the first role to the second at different times,
+// so a wave's two roles share its own region and nothing else): kBwdMaxList 16-byte entries — the wave role's list, or the four
+// groups' lists of kBwdShortMax entries each — followed by four copies of a packed read (the wave role uses the first).  Reads
+// beyond kBwdReadLds words stay in global memory.
+constexpr int kBwdReadLds = 256;
+__device__ __forceinline__ int bwd_read_words(const SeedLaunch &a) { return a.read_w <= kBwdReadLds ? a.read_w : 0; }
+__device__ __forceinline__ int bwd_wave_words(const SeedLaunch &a) { return kBwdMaxList * 4 + 4 * bwd_read_words(a); }
+
+__device__ __forceinline__ void bwd_wave_role(const SeedLaunch &a, uint32_t *lds_reads, WaveOut &wo, unsigned long long &n_ext_io,
+                                              unsigned long long &n_blk_io) {
     const DevFmi &f = a.fmi;
-    extern __shared__ uint32_t lds_reads[];
     const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
-    uint4 *const lst = reinterpret_cast<uint4 *>(lds_reads) + wv * kBwdMaxList;
-    uint32_t *const rd = lds_reads + (kBlock / 64) * kBwdMaxList * 4 + wv * a.read_w;
+    uint32_t *const wreg = lds_reads + wv * bwd_wave_words(a);
+    uint4 *const lst = reinterpret_cast<uint4 *>(wreg);
+    uint32_t *const rd = wreg + kBwdMaxList * 4;
+    const bool rd_lds = bwd_read_words(a) != 0;
     ReadView rv;
     rv.lds_col = nullptr;
     rv.gl = rd;
@@ -915,8 +1039,6 @@ __global__ __launch_bounds__(kBlock) void smem_bwd_wave_kernel(SeedLaunch a) {
     unsigned long long n_items = a.ctr->bwd_items;
     if ((int64_t)n_items > a.bwd_items_cap) n_items = (unsigned long long)a.bwd_items_cap;
     unsigned long long n_ext = 0, n_blk = 0;
-    WaveOut wo;
-    wo.base = -1; wo.used = 0; wo.emitted = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef BWAMS_BWDDBG
     const unsigned long long tk_start = wall_clock64();
@@ -933,7 +1055,8 @@ __global__ __launch_bounds__(kBlock) void smem_bwd_wave_kernel(SeedLaunch a) {
             const uint32_t rid = it.rid;
             const int min_intv = it.min_intv;
             for (int p = lane; p < num_prev; p += 64) lst[p] = a.bwd_ent[it.off + p];
-            for (int w = lane; w < a.read_w; w += 64) rd[w] = a.packed[(int64_t)rid * a.read_w + w];
+            if (rd_lds) { for (int w = lane; w < a.read_w; w += 64) rd[w] = a.packed[(int64_t)rid * a.read_w + w]; }
+            else rv.gl = a.packed + (int64_t)rid * a.read_w;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int j = it.x - 1, cur_m = it.x;      // a pivot's first column, or the column a lane stopped in front of: x is the last position matched
@@ -1016,9 +1139,208 @@ __global__ __launch_bounds__(kBlock) void smem_bwd_wave_kernel(SeedLaunch a) {
         const unsigned long long busy = tk_last - tk_start;
         atomicAdd(&a.ctr->dbg[0], d_items); atomicAdd(&a.ctr->dbg[1], d_cols); atomicAdd(&a.ctr->dbg[2], busy);
         atomicAdd(&a.ctr->dbg[3], d_setup); atomicMax(&a.ctr->dbg[4], busy); atomicAdd(&a.ctr->dbg[5], 1ull);
-        atomicMax(&a.ctr->dbg[6], tk_last); atomicMin(&a.ctr->dbg[7], tk_start);
+        atomicMax(&a.ctr->dbg[6], tk_last); atomicMax(&a.ctr->dbg[7], ~tk_start);
     }
 #endif
+    n_ext_io += n_ext;
+    n_blk_io += n_blk;
+}
+
+// The same procedure with SIXTEEN lanes per pivot: four pivots share a wavefront.  A typical list has 16-23 entries at the forward
+// end and shrinks from there, so a whole wavefront per pivot (above) leaves three lanes in four idle and is bound by vector issue
+// (2.7 us per column whatever the list holds); here a column of a list of up to kBwdShortMax entries is one or two batches of
+// sixteen, the four groups of a wavefront advance independently (every loop iteration is one batch of every live group), and a
+// group that finishes its pivot takes the next one of the wave's reservation while the others carry on.  The in-order decisions
+// are the ones above, taken on the group's sixteen bits of each ballot.
+constexpr int kGrp = 16;
+constexpr int kGroupItemsPerTicket = 16;
+__device__ __forceinline__ void bwd_group_role(const SeedLaunch &a, uint32_t *lds_reads, WaveOut &wo, unsigned long long &n_ext_io,
+                                               unsigned long long &n_blk_io) {
+    const DevFmi &f = a.fmi;
+    const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+    const int grp = lane >> 4, gl = lane & 15;
+    uint32_t *const wreg = lds_reads + wv * bwd_wave_words(a);
+    uint4 *const lst = reinterpret_cast<uint4 *>(wreg) + grp * kBwdShortMax;
+    uint32_t *const rd = wreg + kBwdMaxList * 4 + grp * bwd_read_words(a);
+    const bool rd_lds = bwd_read_words(a) != 0;
+    ReadView rv;
+    rv.lds_col = nullptr;
+    rv.gl = rd;
+    rv.cw = a.read_cw;
+    unsigned long long n_items = a.ctr->bwd_items_s;
+    if ((int64_t)n_items > a.bwd_items_cap) n_items = (unsigned long long)a.bwd_items_cap;
+    unsigned long long n_ext = 0, n_blk = 0;
+    const uint32_t gbelow = (1u << gl) - 1u;
+    const unsigned long long leaders = 0x0001000100010001ull;
+    // the wave's reservation of item indices (wave-uniform)
+    unsigned long long tk_next = 0;
+    int tk_left = 0;
+    bool exhausted = false;
+    // the group's pivot (uniform over the group's lanes)
+    bool live = false;
+    uint32_t rid = 0;
+    int min_intv = 1, num_prev = 0, j = 0, cur_m = 0, b = 0, num_curr = 0;
+    int32_t curr_s = -1;
+    bool first = true;
+#ifdef BWAMS_BWDDBG
+    const unsigned long long tk_start = wall_clock64();
+    unsigned long long d_items = 0, d_iter = 0, d_live = 0;
+#endif
+
+    for (;;) {
+        // ---- groups without a pivot take the next item -------------------------------------------
+        const unsigned long long want = __ballot(!live) & leaders;
+        if (want && !exhausted) {
+            if (tk_left == 0) {
+                tk_next = wave_ticket(&a.ctr->bwd_ticket_s, (unsigned long long)kGroupItemsPerTicket);
+                tk_left = kGroupItemsPerTicket;
+                if (tk_next >= n_items) { exhausted = true; tk_left = 0; }
+            }
+            if (!exhausted) {
+                const int rank = __popcll(want & ((1ull << (lane & 48)) - 1ull));     // groups in front of this one that want an item
+                const int cnt = __popcll(want);
+                const int served = cnt < tk_left ? cnt : tk_left;
+                const unsigned long long t = tk_next + (unsigned long long)rank;
+                if (!live && rank < served && t < n_items) {
+                    const BwdItem it = a.bwd_items_s[t];
+                    if (it.num_prev > 0) {
+                        rid = it.rid;
+                        min_intv = it.min_intv;
+                        num_prev = it.num_prev;
+                        for (int p = gl; p < num_prev; p += kGrp) lst[p] = a.bwd_ent[it.off + p];
+                        if (rd_lds) { for (int w = gl; w < a.read_w; w += kGrp) rd[w] = a.packed[(int64_t)rid * a.read_w + w]; }
+                        else rv.gl = a.packed + (int64_t)rid * a.read_w;
+                        j = it.x - 1; cur_m = it.x;      // x is the last position matched (a pivot, or the column a lane stopped in front of)
+                        b = 0; num_curr = 0; curr_s = -1; first = true;
+                        live = true;
+#ifdef BWAMS_BWDDBG
+                        if (gl == 0) d_items++;
+#endif
+                    }
+                }
+                tk_next += (unsigned long long)served;
+                tk_left -= served;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!__any(live)) {
+            if (exhausted) break;
+            continue;
+        }
+#ifdef BWAMS_BWDDBG
+        d_iter++; d_live += (unsigned long long)__popcll(__ballot(live) & leaders);
+#endif
+        // ---- a column opens: the base to extend by, or the end of the pivot ------------------------
+        bool em = false;
+        uint32_t em_n = 0;
+        int64_t em_k = 0, em_l = 0, em_s = 0;
+        int ba = 4;
+        if (live) {
+            if (j >= 0) ba = base_at(rv, j);
+            if (ba >= 4) {                                  // the pivot is left (PH_BWD_END of the lane kernel); lists here are never empty
+                int64_t qk, ql, qs;
+                int qn;
+                prev_unpack(lst[0], qk, ql, qs, qn);
+                em = gl == 0 && qn - cur_m + 1 >= a.min_seed_len;
+                em_n = (uint32_t)qn; em_k = qk; em_l = ql; em_s = qs;
+                live = false;
+            }
+        }
+        const int em_m = cur_m;
+        // ---- one batch of sixteen entries per live group ------------------------------------------------
+        const int p = b + gl;
+        const bool need = live && p < num_prev;
+        int64_t pk = 0, pl = 0, ps = 0, nk = 0, nl = 0, ns = 0;
+        int pn = 0;
+        if (need) prev_unpack(lst[p], pk, pl, ps, pn);
+        backward_ext_coop(f, need, pk, pl, ps, ba & 3, nk, nl, ns);
+        if (need) {
+            n_ext++;
+            n_blk += ((pk >> 6) == ((pk + ps) >> 6)) ? 1 : 2;
+        }
+        const bool alive = need && ns >= min_intv;
+        const bool dies_long = need && ns < min_intv && (pn - cur_m + 1) >= a.min_seed_len;
+        const uint32_t m_alive = (uint32_t)(__ballot(alive) >> (lane & 48)) & 0xffffu;
+        const uint32_t m_dies = (uint32_t)(__ballot(dies_long) >> (lane & 48)) & 0xffffu;
+        if (live && first && (m_alive | m_dies)) {
+            const int fa = m_alive ? __ffs((int)m_alive) - 1 : 64;
+            const int fd = m_dies ? __ffs((int)m_dies) - 1 : 64;
+            if (fd < fa && gl == fd) {
+                em = true;
+                em_n = (uint32_t)pn; em_k = pk; em_l = pl; em_s = ps;
+            }
+            first = false;
+        }
+        wave_emit(a, wo, em, rid, (uint32_t)em_m, em_n, em_k, em_l, em_s);
+        // size of the closest surviving entry before this one (this batch, else the carry)
+        const uint32_t lower = m_alive & gbelow;
+        const int src = (lane & 48) + (lower ? 31 - __clz((int)lower) : gl);
+        const int32_t s_here = (int32_t)ns;
+        const int32_t s_src = __shfl(s_here, src);           // by every lane: a source lane inside a branch not taken reads as 0
+        const int32_t s_before = lower ? s_src : curr_s;
+        const bool keep = alive && ns != (int64_t)s_before;
+        const uint32_t m_keep = (uint32_t)(__ballot(keep) >> (lane & 48)) & 0xffffu;
+        const int32_t s_last = __shfl(s_here, (lane & 48) + (m_alive ? 31 - __clz((int)m_alive) : 0));
+        __builtin_amdgcn_wave_barrier();                     // every lane has read its entry before the compaction writes
+        if (keep) lst[num_curr + __popc(m_keep & gbelow)] = prev_pack(nk, nl, ns, pn);
+        if (live) {
+            num_curr += __popc(m_keep);
+            if (m_alive) curr_s = s_last;
+            b += kGrp;
+            if (b >= num_prev) {                             // this column is done
+                num_prev = num_curr;
+                if (num_curr == 0) {
+                    live = false;                            // nothing survived: PH_BWD_END with an empty list emits nothing
+                } else {
+                    cur_m = j;
+                    j--;
+                    b = 0; num_curr = 0; curr_s = -1; first = true;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#ifdef BWAMS_BWDDBG
+    {
+        const unsigned long long tk_end = wall_clock64();
+        for (int o = 32; o > 0; o >>= 1) d_items += mk64(__shfl_down((uint32_t)d_items, o), __shfl_down((uint32_t)(d_items >> 32), o));
+        if (lane == 0 && d_iter) {
+            atomicAdd(&a.ctr->dbg[68], d_items); atomicAdd(&a.ctr->dbg[69], d_iter); atomicAdd(&a.ctr->dbg[70], d_live);
+            atomicAdd(&a.ctr->dbg[71], tk_end - tk_start); atomicAdd(&a.ctr->dbg[72], 1ull); atomicMax(&a.ctr->dbg[73], tk_end - tk_start);
+            atomicMax(&a.ctr->dbg[74], tk_end); atomicMax(&a.ctr->dbg[75], ~tk_start);
+        }
+        { unsigned long long e = n_ext; for (int o = 32; o > 0; o >>= 1) e += mk64(__shfl_down((uint32_t)e, o), __shfl_down((uint32_t)(e >> 32), o));
+          if (lane == 0) atomicAdd(&a.ctr->dbg[76], e); }
+    }
+#endif
+    n_ext_io += n_ext;
+    n_blk_io += n_blk;
+}
+
+// The launch behind rounds 1 and 2: every wavefront first takes pivots with long lists (a wavefront each, the longest-running
+// items), then pivots with short lists (four at a time) — one launch, one tail.
+__global__ __launch_bounds__(kBlock) void smem_bwd_kernel(SeedLaunch a) {
+    extern __shared__ uint32_t lds_reads[];
+    unsigned long long n_ext = 0, n_blk = 0;
+    WaveOut wo;
+    wo.base = -1; wo.used = 0; wo.emitted = 0;
+    bwd_wave_role(a, lds_reads, wo, n_ext, n_blk);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bwd_group_role(a, lds_reads, wo, n_ext, n_blk);
+    wave_emit_finish(a, wo);
+    flush_counters(a.ctr, n_ext, n_blk);
+}
+template <int ROLE>
+__global__ __launch_bounds__(kBlock) void smem_bwd_role_kernel(SeedLaunch a) {
+    extern __shared__ uint32_t lds_reads[];
+    unsigned long long n_ext = 0, n_blk = 0;
+    WaveOut wo;
+    wo.base = -1; wo.used = 0; wo.emitted = 0;
+    if (ROLE == 0) bwd_wave_role(a, lds_reads, wo, n_ext, n_blk);
+    else bwd_group_role(a, lds_reads, wo, n_ext, n_blk);
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
@@ -1059,6 +1381,7 @@ __global__ void mark_kernel(DevCounters *ctr, int which) {
     }
     ctr->work_head = 0;
     ctr->bwd_items = ctr->bwd_entries = ctr->bwd_ticket = 0;
+    ctr->bwd_items_s = ctr->bwd_ticket_s = 0;
     if (which != 2) ctr->work_head3 = 0;       // (mark 2 may run while round 3 is in flight on its own stream... it has joined; kept for symmetry)
 }
 
@@ -1237,7 +1560,12 @@ void launch_build_fma(const DevFmi &f, int all_bp, uint32_t *all_tab, int last_b
 
 int seed_block_threads() { return kBlock; }
 int64_t seed_max_threads(int cu_count) { return (int64_t)cu_count * kBlocksPerCU * kBlock; }
-int64_t seed_pool_slack(int cu_count) { return seed_max_threads(cu_count) / 64 * kChunk; }
+// pool slots the launches of one seeding pass can leave unused in partly filled chunks: every wave of the three search launches
+// (rounds 1, 2, 3) and of the launches behind rounds 1 and 2 (smem_bwd_kernel: cu * 8 workgroups, sized for two roles each) may
+// abandon one chunk of kChunk slots
+int64_t seed_pool_slack(int cu_count) {
+    return 3 * (seed_max_threads(cu_count) / 64 * kChunk) + 2 * ((int64_t)cu_count * 8 * (kBlock / 64) * kChunk);
+}
 
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
 
@@ -1258,8 +1586,15 @@ void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_coun
 void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st) {
     if (a.bwd_min_list <= 0) return;
     // the number of items is only known on the device; waves without an item leave at their first ticket
-    const size_t lds = (size_t)(kBlock / 64) * (kBwdMaxList * 16 + (size_t)a.read_w * 4);
-    smem_bwd_wave_kernel<<<cu_count * 8, kBlock, lds, st>>>(a);
+    const size_t lds = (size_t)(kBlock / 64) * (kBwdMaxList * 16 + 16 * (size_t)(a.read_w <= kBwdReadLds ? a.read_w : 0));
+    const size_t lds_g = lds;
+    static const bool fused = !(getenv("BWAMS_BWD_FUSED") && atoi(getenv("BWAMS_BWD_FUSED")) == 0);
+    if (fused) {
+        smem_bwd_kernel<<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
+    } else {
+        smem_bwd_role_kernel<0><<<cu_count * 8, kBlock, lds, st>>>(a);
+        smem_bwd_role_kernel<1><<<cu_count * 8, kBlock, lds_g, st>>>(a);
+    }
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {

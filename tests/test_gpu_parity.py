@@ -60,6 +60,8 @@ def test_smem_and_sa_match_oracle(gpu_toy):
     {"BWAMS_BWD_MIN_LIST": "200", "BWAMS_BWD_COLS": "2", "BWAMS_BWD_LATE_LIST": "1"},   # only ever two columns in
     {"BWAMS_BWD_MIN_LIST": "200", "BWAMS_BWD_COLS": "200", "BWAMS_BWD_LATE_LIST": "200",
      "BWAMS_BWD_DRY_MIN_LIST": "2", "BWAMS_BWD_DRY_COLS": "1", "BWAMS_BWD_DRY_LATE_LIST": "1"},                     # only while the launch drains
+    {"BWAMS_BWD_MIN_LIST": "200", "BWAMS_BWD_COLS": "1", "BWAMS_BWD_LATE_LIST": "1"},   # one column in, one-entry lists too (the column ends in the iteration of the forward end)
+    {"BWAMS_BWD_MIN_LIST": "40", "BWAMS_BWD_COLS": "1", "BWAMS_BWD_LATE_LIST": "33"},   # the whole-wavefront kernel only (lists beyond 32 entries)
     {"BWAMS_BWD_MIN_LIST": "0"},                                                       # never
 ])
 def test_backward_phases_handed_to_the_wave_kernel(gpu_toy, monkeypatch, env):
@@ -167,6 +169,26 @@ def test_resident_buffers_grow_on_demand(gpu_toy):
     wch, wsd, wchoff = loader.chain_seeds(want, wcoord, woff, cum, len(g))
     assert nc == len(wch) and ns == len(wsd)
     b.close()
+
+
+def test_pool_with_no_room_to_spare_and_every_emitting_launch(gpu_toy, monkeypatch):
+    """the SMEM pool is handed out in 64-slot chunks by SEVEN emitting launches (three searches, and the two kernels
+    behind rounds 1 and 2 for the backward phases that left their lanes); a batch whose max_smem is the chunk's exact SMEM count
+    must still succeed — the slack covers every launch's partly filled chunks — and one slot less must grow and re-run."""
+    g, idx, ix = gpu_toy
+    monkeypatch.setenv("BWAMS_BWD_MIN_LIST", "1")
+    reads, _, _ = simulate.make_reads(g, 2500, seed=31)
+    enc, cum = simulate.flatten_reads(reads)
+    o = loader.OracleFMI(idx)
+    want = o.collect_smem(enc, cum)
+    wcoord, woff = o.sa_lookup(want, 500)
+    for room in (0, -1):
+        b = capi.Batch(ix, len(reads), int(cum[-1]), max_smem=len(want) + room, max_sa=len(wcoord) + 8)
+        got, coord, off = b.seed(enc, cum)
+        for f in ("rid", "m", "n", "k", "l", "s"):
+            assert np.array_equal(got[f], want[f]), (room, f)
+        assert np.array_equal(off, woff) and np.array_equal(coord, wcoord)
+        b.close()
 
 
 def test_index_file_path(gpu_toy, tmp_path):

@@ -40,6 +40,7 @@ SYMBOLS = [
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
     "bwams_process_reads", "bwams_process_reads_stage1", "bwams_process_reads_stage2", "bwams_host_alloc", "bwams_host_free",
+    "bwams_process_reads_upload", "bwams_process_reads_stage1_run", "bwams_batch_device", "bwams_multi_upload", "bwams_multi_compute",
     "bwams_shard_bounds", "bwams_multi_create", "bwams_multi_process_reads", "bwams_multi_fetch", "bwams_multi_error", "bwams_multi_destroy",
     "bwams_dedup_run", "bwams_dedup_fetch", "bwams_chain_run_ert", "bwams_pestat", "bwams_pestat_keys", "bwams_pestat_from_keys", "bwams_pair_run", "bwams_pair_run_sam", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",
 ]
@@ -1008,9 +1009,17 @@ class Batch:
             self.h = None
 
 
+class _Kept(tuple):
+    """an argument tuple that owns the arrays its pointers point into: alive as long as the caller's local holds it"""
+    def __new__(cls, args, keep):
+        t = super().__new__(cls, args)
+        t.keep = keep
+        return t
+
+
 def _flat_records(enc, cum, names, name_off, quals, comments, comment_off):
     """the argument block (enc, cum, n, names, name_off, quals, comments, comment_off) of bwams_process_reads and its relatives;
-    the arrays are kept alive by the returned tuple's owner for the duration of the call only"""
+    the converted arrays live in the returned tuple (hold it in a local until the C call has returned: ctypes releases the GIL)"""
     enc = np.ascontiguousarray(enc, np.uint8)
     cum = np.ascontiguousarray(cum, np.int64)
     names = np.ascontiguousarray(names, np.uint8)
@@ -1018,8 +1027,7 @@ def _flat_records(enc, cum, names, name_off, quals, comments, comment_off):
     q = np.ascontiguousarray(quals, np.uint8) if quals is not None else None
     c = np.ascontiguousarray(comments, np.uint8) if comments is not None else None
     co = np.ascontiguousarray(comment_off, np.int64) if comment_off is not None else None
-    _flat_records.keep = (enc, cum, names, name_off, q, c, co)
-    return (_p(enc), _p(cum), C.c_int64(len(cum) - 1), _p(names), _p(name_off), _p(q), _p(c), _p(co))
+    return _Kept((_p(enc), _p(cum), C.c_int64(len(cum) - 1), _p(names), _p(name_off), _p(q), _p(c), _p(co)), (enc, cum, names, name_off, q, c, co))
 
 
 def shard_bounds(n_reads: int, n_shards: int, paired: bool = False) -> np.ndarray:
@@ -1079,3 +1087,159 @@ def pinned_array(n: int, dtype=np.uint8) -> np.ndarray:
     import weakref
     weakref.finalize(buf, lambda a=p.value: lib().bwams_host_free(C.c_void_p(a)))
     return arr
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The compiled outer boundary (bwa-mem-scale_amd/host/mem_process_seqs_hip.cpp) driven from Python: the reference's own records
+# (bseq1_t, mem_opt_t: the layout mirrors of host/bwamem_hip.h) through mem_process_seqs() and the pipeline's two other steps.
+# The host layer has C++ linkage, as mem_process_seqs has in the reference; its symbols are looked up by name in the library.
+BSEQ1_DTYPE = np.dtype([("l_seq", "<i4"), ("id", "<i4"), ("strbuf", "<u8"), ("name", "<u8"), ("comment", "<u8"), ("seq", "<u8"),
+                        ("qual", "<u8"), ("sam", "<u8"), ("perfect", "<u8")])
+assert BSEQ1_DTYPE.itemsize == 64
+WORK_ITEM = 512          # BATCH_SIZE, src/macro.h:63: reads per seqs[].sam string
+
+
+class MemOptT(C.Structure):
+    """mem_opt_t (src/bwamem.h:89-124, built without AFF): 176 bytes"""
+    _fields_ = [("a", C.c_int), ("b", C.c_int), ("o_del", C.c_int), ("e_del", C.c_int), ("o_ins", C.c_int), ("e_ins", C.c_int),
+                ("pen_unpaired", C.c_int), ("pen_clip5", C.c_int), ("pen_clip3", C.c_int), ("w", C.c_int), ("zdrop", C.c_int),
+                ("max_mem_intv", C.c_uint64), ("T", C.c_int), ("flag", C.c_int), ("min_seed_len", C.c_int), ("min_chain_weight", C.c_int),
+                ("max_chain_extend", C.c_int), ("split_factor", C.c_float), ("split_width", C.c_int), ("max_occ", C.c_int),
+                ("max_chain_gap", C.c_int), ("n_threads", C.c_int), ("chunk_size", C.c_int64), ("mask_level", C.c_float),
+                ("drop_ratio", C.c_float), ("XA_drop_ratio", C.c_float), ("mask_level_redun", C.c_float), ("mapQ_coef_len", C.c_float),
+                ("mapQ_coef_fac", C.c_int), ("max_ins", C.c_int), ("max_matesw", C.c_int), ("max_XA_hits", C.c_int),
+                ("max_XA_hits_alt", C.c_int), ("mat", C.c_int8 * 25)]
+
+
+assert C.sizeof(MemOptT) == 176
+
+
+def mem_opt_init(paired: bool = False) -> MemOptT:
+    """mem_opt_init (src/bwamem.cpp:135-171) + bwa_fill_scmat"""
+    import math
+    o = MemOptT()
+    o.a, o.b, o.o_del, o.o_ins, o.e_del, o.e_ins, o.w, o.T, o.zdrop = 1, 4, 6, 6, 1, 1, 100, 30, 100
+    o.pen_unpaired, o.pen_clip5, o.pen_clip3, o.max_mem_intv, o.min_seed_len, o.split_width = 17, 5, 5, 20, 19, 10
+    o.max_occ, o.max_chain_gap, o.max_ins, o.mask_level, o.drop_ratio = 500, 10000, 10000, 0.50, 0.50
+    o.XA_drop_ratio, o.split_factor, o.chunk_size, o.n_threads, o.max_XA_hits, o.max_XA_hits_alt = 0.80, 1.5, 10000000, 1, 5, 200
+    o.max_matesw, o.mask_level_redun, o.min_chain_weight, o.max_chain_extend, o.mapQ_coef_len = 50, 0.95, 0, 1 << 30, 50
+    o.mapQ_coef_fac = int(math.log(o.mapQ_coef_len))
+    k = 0
+    for i in range(4):
+        for j in range(4):
+            o.mat[k] = o.a if i == j else -o.b
+            k += 1
+        o.mat[k] = -1
+        k += 1
+    for _ in range(5):
+        o.mat[k] = -1
+        k += 1
+    if paired:
+        o.flag |= 0x2
+    return o
+
+
+_host_syms = None
+
+
+def _host_sym(name: str):
+    """the host layer's function `name` (C++ linkage: looked up among the library's dynamic symbols by its mangled prefix)"""
+    global _host_syms
+    if _host_syms is None:
+        out = subprocess.check_output(["nm", "-D", "--defined-only", LIB_PATH]).decode()
+        _host_syms = [ln.split()[-1] for ln in out.splitlines() if " T _Z" in ln]
+    key = f"_Z{len(name)}{name}"
+    hit = [m for m in _host_syms if m.startswith(key) and (len(m) == len(key) or not m[len(key)].islower())]
+    if len(hit) != 1:
+        raise BwamsError(-3, name, f"host-layer symbol not found or ambiguous: {hit}")
+    f = getattr(lib(), hit[0])
+    f.restype = C.c_int
+    return f
+
+
+class Seqs:
+    """A chunk as the reference holds it between kt_pipeline's steps: a bseq1_t array whose strings live in this object's buffers."""
+
+    def __init__(self, reads: np.ndarray, first_id: int = 0, name_fmt: bytes = b"r%08d", quals: bool = True, name_ids=None):
+        """reads: (n, RL) base codes 0..4; names are name_fmt % (first_id + i), or % name_ids[i] (paired-end: the pair's number)"""
+        n, RL = reads.shape
+        self.n = n
+        self.seq = np.zeros((n, RL + 1), np.uint8)
+        self.seq[:, :RL] = np.frombuffer(b"ACGTN", np.uint8)[reads]
+        w = len(name_fmt % 0) + 1
+        self.names = np.zeros((n, w), np.uint8)
+        ids = first_id + np.arange(n, dtype=np.int64) if name_ids is None else np.asarray(name_ids, np.int64)
+        head = name_fmt.split(b"%")[0]
+        nd = w - 1 - len(head)
+        self.names[:, :len(head)] = np.frombuffer(head, np.uint8)
+        for d in range(nd):
+            self.names[:, len(head) + d] = ord("0") + (ids // 10 ** (nd - 1 - d)) % 10
+        self.qual = None
+        if quals:
+            self.qual = np.zeros((n, RL + 1), np.uint8)
+            self.qual[:, :RL] = ord("I")
+        self.arr = np.zeros(n, BSEQ1_DTYPE)
+        self.arr["l_seq"] = RL
+        self.arr["id"] = ids.astype(np.int32)
+        self.arr["name"] = self.names.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(w)
+        self.arr["seq"] = self.seq.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(RL + 1)
+        if quals:
+            self.arr["qual"] = self.qual.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(RL + 1)
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.arr.ctypes.data)
+
+    def take_sam(self) -> bytes:
+        """the chunk's SAM text (the work items' strings joined, as step 2 writes them), the strings freed"""
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        parts = []
+        for i in range(0, self.n, WORK_ITEM):
+            p = int(self.arr["sam"][i])
+            if not p:
+                raise BwamsError(-3, "take_sam", f"work item {i // WORK_ITEM} left no text")
+            parts.append(C.string_at(p))
+            libc.free(C.c_void_p(p))
+            self.arr["sam"][i] = 0
+        return b"".join(parts)
+
+
+class Worker:
+    """bwams_worker (host/bwamem_hip.h): the resident index set of every device and `depth` chunks in flight."""
+
+    def __init__(self, indexes, max_reads: int, max_bases: int, emfs=None, erts=None, depth: int = 1, rg_id: bytes = b""):
+        n = len(indexes)
+        ia = (C.c_void_p * n)(*[x.h for x in indexes])
+        ea = (C.c_void_p * n)(*[e.h for e in emfs]) if emfs else None
+        ra = (C.c_void_p * n)(*[e.h for e in erts]) if erts else None
+        self.h = C.c_void_p()
+        _chk(_host_sym("bwams_worker_create_multi")(ia, ea, ra, n, depth, C.c_int64(max_reads), C.c_int64(max_bases), rg_id, C.byref(self.h)),
+             "bwams_worker_create_multi")
+        self._keep = (indexes, emfs, erts)
+
+    def _err(self, rc, what):
+        if rc:
+            f = _host_sym("bwams_worker_error")
+            f.restype = C.c_char_p
+            raise BwamsError(rc, what, (f(self.h) or b"").decode())
+
+    def set_deferred_collect(self, on: bool):
+        _host_sym("bwams_worker_set_deferred_collect")(self.h, 1 if on else 0)
+
+    def stage(self, opt: MemOptT, seqs: Seqs):
+        self._err(_host_sym("mem_process_seqs_stage")(C.byref(opt), seqs.n, seqs.ptr, self.h), "mem_process_seqs_stage")
+
+    def process(self, opt: MemOptT, n_processed: int, seqs: Seqs, pes0=None):
+        pp = _p(np.ascontiguousarray(pes0, PESTAT_DTYPE)) if pes0 is not None else None
+        self._err(_host_sym("bwams_worker_process")(C.byref(opt), C.c_int64(n_processed), seqs.n, seqs.ptr, pp, self.h), "mem_process_seqs")
+
+    def collect(self, opt: MemOptT, seqs: Seqs):
+        self._err(_host_sym("mem_process_seqs_collect")(C.byref(opt), seqs.n, seqs.ptr, self.h), "mem_process_seqs_collect")
+
+    def close(self):
+        if self.h:
+            f = _host_sym("bwams_worker_destroy")
+            f.restype = None
+            f(self.h)
+            self.h = None

@@ -1590,6 +1590,35 @@ int bwams_process_reads_stage1(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *
     return process_stage1(b, emf, ert, so, mo);
 }
 
+// Stage 1 itself in two halves, so that a pipeline can put the next chunk's reads and names into one batch (PCIe) while another batch
+// of the same device computes: _upload = bwams_seed_upload + bwams_sam_upload, _stage1_run = worker_bwt + worker_aln on what it left.
+int bwams_process_reads_upload(bwams_batch_t *b, const uint8_t *enc_qdb, const int64_t *cum_len, int64_t n_reads, const char *names,
+                               const int64_t *name_off, const char *quals, const char *comments, const int64_t *comment_off) {
+    if (!b || n_reads < 0 || (n_reads > 0 && (!enc_qdb || !cum_len || !names || !name_off))) {
+        set_last_error("bwams_process_reads_upload: batch, reads and names are required");
+        return BWAMS_ERR_ARG;
+    }
+    if (n_reads == 0) { process_empty(b, nullptr); return BWAMS_OK; }
+    int rc = bwams_seed_upload(b, enc_qdb, cum_len, nullptr, (int32_t)n_reads);
+    if (rc) return rc;
+    return bwams_sam_upload(b, names, name_off, quals, comments, comment_off);
+}
+
+int bwams_process_reads_stage1_run(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo) {
+    if (!b || !so || !mo) {
+        set_last_error("bwams_process_reads_stage1_run: batch and options are required");
+        return BWAMS_ERR_ARG;
+    }
+    if (b->nseq == 0) return BWAMS_OK;
+    return process_stage1(b, emf, ert, so, mo);
+}
+
+int bwams_batch_device(const bwams_batch_t *b, int32_t *device) {
+    if (!b || !b->idx || !device) return BWAMS_ERR_ARG;
+    *device = b->idx->device;
+    return BWAMS_OK;
+}
+
 int bwams_process_reads_stage2(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt,
                                int32_t paired, const bwams_pestat_t *pes, int64_t id_base, int32_t flags, int64_t *sam_bytes) {
     if (!b || !mo || !sam_opt || (paired && !pes)) {

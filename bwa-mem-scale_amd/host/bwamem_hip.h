@@ -85,14 +85,23 @@ static_assert(sizeof(mem_pestat_t) == sizeof(bwams_pestat_t) && offsetof(bwams_p
               "bwams_pestat_t mirrors mem_pestat_t byte for byte");
 
 // What stands where the reference's worker_t holds its FM-index, ERT tables, perfect table and per-thread scratch: the resident
-// index set and ONE batch (the pipeline has one mem_process_seqs in flight: src/fastmap.cpp:475-491), plus page-locked staging
-// for what crosses PCIe every chunk.  A maintainer keeps one of these beside (or inside) worker_t.
+// index set of every GPU and `depth` chunks in flight (a batch per device each, plus page-locked staging for what crosses PCIe every
+// chunk).  The pipeline has one mem_process_seqs in flight (src/fastmap.cpp:475-491) but reads chunk i + 1 and writes chunk i - 1
+// meanwhile (its `-i` threads): with depth >= 2 the optional _stage / _collect calls below do the same with the GPUs' copies.
+// A maintainer keeps one of these beside (or inside) worker_t.
 struct bwams_worker;
 // idx: bwams_index_from_host / _open at start-up; emf / ert: NULL when not resident; max_reads / max_bases: what
 // process() reads per chunk (src/fastmap.cpp:1273-1279).  rg_id: bwa_rg_id (src/bwa.cpp), "" without -R.
 int bwams_worker_create(bwams_index_t *idx, bwams_emf_t *emf, bwams_ert_t *ert, int64_t max_reads, int64_t max_bases, const char *rg_id,
                         bwams_worker **out);
 void bwams_worker_destroy(bwams_worker *w);
+// The same over n_dev GPUs (idx / emf / ert: one handle per device, each on its own replica; emf / ert NULL when not resident) with
+// `depth` chunks in flight (1: everything inside mem_process_seqs; 2-3: with the _stage / _collect calls).  A chunk is cut into n_dev
+// contiguous shards on read (paired-end: pair) boundaries, mem_pestat's keys are merged in-process, the text returns in read order:
+// byte-identical to one device (host/chunk_multi.cpp; tests/test_host_boundary.py).  Every failure is returned, nothing exits.
+int bwams_worker_create_multi(bwams_index_t *const *idx, bwams_emf_t *const *emf, bwams_ert_t *const *ert, int n_dev, int depth,
+                              int64_t max_reads, int64_t max_bases, const char *rg_id, bwams_worker **out);
+const char *bwams_worker_error(const bwams_worker *w);
 // set a host path to run for chunks the device path refuses (BWAMS_ERR_UNSUPPORTED); without one such a chunk ends the run
 typedef void (*bwams_host_path_t)(mem_opt_t *, int64_t, int, bseq1_t *, const mem_pestat_t *, void *user);
 void bwams_worker_set_host_path(bwams_worker *w, bwams_host_path_t f, void *user);
@@ -102,6 +111,20 @@ void bwams_worker_set_host_path(bwams_worker *w, bwams_host_path_t f, void *user
 // resident, and leaves ONE malloc'ed SAM string per 512-read work item in seqs[first_of_item].sam (the others NULL), which the
 // writer frees (src/fastmap.cpp:437-461).  Errors end the run with a line on stderr, as the reference's do.
 void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0, bwams_worker &w);
+
+// The pipeline's two other steps, for a maintainer who lets the GPUs' copies overlap the way the reference overlaps its file I/O
+// (three added lines in process(), src/fastmap.cpp:307-468):
+//   end of step 0 (the reader's thread):    mem_process_seqs_stage(opt, n, seqs, w)   records -> page-locked arrays -> the devices; waits
+//                                           for a free slot (at most `depth` chunks are in flight)
+//   step 1:                                 mem_process_seqs(...)                     finds the staged chunk by its seqs pointer
+//   start of step 2 (the writer's thread):  mem_process_seqs_collect(opt, n, seqs, w) the SAM strings into seqs[].sam — only after
+//                                           bwams_worker_set_deferred_collect(w, 1); otherwise mem_process_seqs has collected already
+// Both return 0 or a BWAMS_ERR_* (bwams_worker_error() says why).  Without these calls mem_process_seqs does all three.
+int mem_process_seqs_stage(mem_opt_t *opt, int n, bseq1_t *seqs, bwams_worker &w);
+int mem_process_seqs_collect(mem_opt_t *opt, int n, bseq1_t *seqs, bwams_worker &w);
+void bwams_worker_set_deferred_collect(bwams_worker *w, int on);
+// step 1 with an error code instead of the reference's exit(EXIT_FAILURE)
+int bwams_worker_process(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0, bwams_worker &w);
 
 // the option mapping on its own (tests compare it with the library's defaults)
 void bwams_map_options(const mem_opt_t *opt, const char *rg_id, bwams_seed_opt_t *so, bwams_mem_opt_t *mo, bwams_sam_opt_t *sam_opt);

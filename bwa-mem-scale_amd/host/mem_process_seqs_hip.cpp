@@ -1,21 +1,35 @@
-// mem_process_seqs_hip.cpp — mem_process_seqs() (/root/reference/src/bwamem.cpp:1850-1903) with its body on the GPU: the
-// reference's records in (bseq1_t), the reference's per-work-item SAM strings out, everything in between one call into the
-// C-ABI of libbwams.so (bwams_process_reads).  Host C++ only: no HIP header is needed here.
+// mem_process_seqs_hip.cpp — mem_process_seqs() (/root/reference/src/bwamem.cpp:1850-1903) with its body on the GPU(s): the
+// reference's records in (bseq1_t), the reference's per-work-item SAM strings out, everything in between calls into the C-ABI of
+// libbwams.so.  Host C++ only: no HIP header is needed here.
+//
+// The worker stands where worker_t stands.  It owns `depth` SLOTS; a slot is one chunk in flight: a bwams_multi over the worker's
+// devices (one batch per device, the chunk cut on read / pair boundaries: host/chunk_multi.cpp) and the page-locked staging of what
+// crosses PCIe.  The reference's kt_pipeline has three steps per chunk — read, mem_process_seqs, write — and overlaps them over
+// consecutive chunks with its `-i` threads (src/fastmap.cpp:307-468; a step holds one chunk at a time: the ordering lock :475-491).
+// The same three steps here:
+//     mem_process_seqs_stage()    (optional; end of step 0, the reader's thread)  records -> page-locked arrays -> the slot's batches
+//     mem_process_seqs()          (step 1)  the kernels; stages first if the chunk was not staged; collects at once unless deferred
+//     mem_process_seqs_collect()  (optional; start of step 2, the writer's thread)  SAM text down, one string per 512-read work item
+// so that chunk i + 1 goes up and chunk i - 1 comes down while chunk i computes.  A caller that only knows mem_process_seqs() gets the
+// three in one synchronous call (depth 1).
 #include "bwamem_hip.h"
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
 
-struct bwams_worker {
-    bwams_index_t *idx = nullptr;
-    bwams_emf_t *emf = nullptr;
-    bwams_ert_t *ert = nullptr;
-    bwams_batch_t *batch = nullptr;
-    int64_t max_reads = 0, max_bases = 0;
-    char rg_id[256] = {0};
-    bwams_host_path_t host_path = nullptr;
-    void *host_user = nullptr;
+namespace {
+
+enum SlotState { SLOT_FREE = 0, SLOT_BUSY, SLOT_STAGED, SLOT_COMPUTED };
+
+struct Slot {
+    std::vector<bwams_batch_t *> batch;             // one per device
+    bwams_multi_t *multi = nullptr;
     // page-locked staging (bwams_host_alloc): what goes up and what comes down every chunk
     uint8_t *enc = nullptr;
     char *qual = nullptr, *names = nullptr, *comments = nullptr, *sam = nullptr;
@@ -23,61 +37,115 @@ struct bwams_worker {
     int64_t names_cap = 0, comments_cap = 0, sam_cap = 0;
     bwams_perfect_t *perfect = nullptr;
     uint8_t *code = nullptr;
+    // the chunk it holds
+    SlotState state = SLOT_FREE;
+    const bseq1_t *owner = nullptr;
+    int n = 0;
+    bool refuse = false;
+    int64_t bytes = 0;
 };
 
-static void die(const char *what, int rc) {
+}  // namespace
+
+struct bwams_worker {
+    int n_dev = 0, depth = 0;
+    std::vector<bwams_index_t *> idx;
+    std::vector<bwams_emf_t *> emf;
+    std::vector<bwams_ert_t *> ert;
+    int64_t max_reads = 0, max_bases = 0;
+    char rg_id[256] = {0};
+    bwams_host_path_t host_path = nullptr;
+    void *host_user = nullptr;
+    bool deferred_collect = false;
+    std::vector<Slot> slots;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::string err;
+};
+
+static void die(const char *what, int rc, const char *msg = nullptr) {
     // the reference's convention: a line on stderr, exit(EXIT_FAILURE) (e.g. src/bwamem.cpp:3638-3645)
-    fprintf(stderr, "[bwams] %s: %s: %s\n", what, bwams_strerror(rc), bwams_last_error());
+    fprintf(stderr, "[bwams] %s: %s: %s\n", what, bwams_strerror(rc), msg && *msg ? msg : bwams_last_error());
     exit(EXIT_FAILURE);
 }
 
 template <class T>
-static void pinned(T *&p, size_t n) {
+static int pinned(T *&p, size_t n) {
     void *q = nullptr;
     const int rc = bwams_host_alloc(n * sizeof(T), &q);
-    if (rc) die("bwams_host_alloc", rc);
-    p = static_cast<T *>(q);
+    p = rc ? nullptr : static_cast<T *>(q);
+    return rc;
 }
 
 template <class T>
-static void grow(T *&p, int64_t &cap, int64_t need) {
-    if (need <= cap) return;
+static int grow(T *&p, int64_t &cap, int64_t need) {
+    if (need <= cap) return BWAMS_OK;
     if (p) bwams_host_free(p);
     p = nullptr;
     cap = need + need / 4 + 4096;
-    pinned(p, (size_t)cap);
-}
-
-int bwams_worker_create(bwams_index_t *idx, bwams_emf_t *emf, bwams_ert_t *ert, int64_t max_reads, int64_t max_bases, const char *rg_id,
-                        bwams_worker **out) {
-    if (!idx || !out || max_reads <= 0 || max_bases <= 0) return BWAMS_ERR_ARG;
-    bwams_worker *w = new bwams_worker();
-    w->idx = idx; w->emf = emf; w->ert = ert;
-    w->max_reads = max_reads; w->max_bases = max_bases;
-    if (rg_id) { strncpy(w->rg_id, rg_id, sizeof w->rg_id - 1); }
-    int rc = bwams_batch_create(idx, max_reads, max_bases, 0, 0, &w->batch);
-    if (rc) { delete w; return rc; }
-    pinned(w->enc, (size_t)max_bases);
-    pinned(w->qual, (size_t)max_bases);
-    pinned(w->cum, (size_t)max_reads + 1);
-    pinned(w->name_off, (size_t)max_reads + 1);
-    pinned(w->comment_off, (size_t)max_reads + 1);
-    pinned(w->sam_off, (size_t)max_reads + 1);
-    pinned(w->perfect, (size_t)max_reads);
-    pinned(w->code, (size_t)max_reads);
-    *out = w;
-    return BWAMS_OK;
+    const int rc = pinned(p, (size_t)cap);
+    if (rc) cap = 0;
+    return rc;
 }
 
 void bwams_worker_destroy(bwams_worker *w) {
     if (!w) return;
-    if (w->batch) bwams_batch_destroy(w->batch);
-    void *ps[] = {w->enc, w->qual, w->names, w->comments, w->sam, w->cum, w->name_off, w->comment_off, w->sam_off, w->perfect, w->code};
-    for (void *p : ps) if (p) bwams_host_free(p);
+    for (Slot &s : w->slots) {
+        if (s.multi) bwams_multi_destroy(s.multi);
+        for (bwams_batch_t *b : s.batch) if (b) bwams_batch_destroy(b);
+        void *ps[] = {s.enc, s.qual, s.names, s.comments, s.sam, s.cum, s.name_off, s.comment_off, s.sam_off, s.perfect, s.code};
+        for (void *p : ps) if (p) bwams_host_free(p);
+    }
     delete w;
 }
 
+int bwams_worker_create_multi(bwams_index_t *const *idx, bwams_emf_t *const *emf, bwams_ert_t *const *ert, int n_dev, int depth,
+                              int64_t max_reads, int64_t max_bases, const char *rg_id, bwams_worker **out) {
+    if (!idx || !out || n_dev < 1 || depth < 1 || depth > 8 || max_reads <= 0 || max_bases <= 0) return BWAMS_ERR_ARG;
+    for (int d = 0; d < n_dev; ++d) if (!idx[d]) return BWAMS_ERR_ARG;
+    bwams_worker *w = new bwams_worker();
+    w->n_dev = n_dev; w->depth = depth;
+    w->max_reads = max_reads; w->max_bases = max_bases;
+    if (rg_id) strncpy(w->rg_id, rg_id, sizeof w->rg_id - 1);
+    for (int d = 0; d < n_dev; ++d) {
+        w->idx.push_back(idx[d]);
+        w->emf.push_back(emf ? emf[d] : nullptr);
+        w->ert.push_back(ert ? ert[d] : nullptr);
+    }
+    w->slots.resize((size_t)depth);
+    // a device's share of a chunk (shards differ by at most one pair) and of its bases (a share of the reads can hold more than its share
+    // of the bases when read lengths differ: twice the even share, never more than the whole)
+    const int64_t sh_reads = (max_reads + n_dev - 1) / n_dev + 2;
+    const int64_t sh_bases = n_dev == 1 ? max_bases : std::min<int64_t>(max_bases, 2 * ((max_bases + n_dev - 1) / n_dev) + 1024);
+    int rc = BWAMS_OK;
+    for (Slot &s : w->slots) {
+        s.batch.assign((size_t)n_dev, nullptr);
+        for (int d = 0; d < n_dev && !rc; ++d) rc = bwams_batch_create(idx[d], sh_reads, sh_bases, 0, 0, &s.batch[(size_t)d]);
+        if (!rc) rc = bwams_multi_create(s.batch.data(), emf ? w->emf.data() : nullptr, ert ? w->ert.data() : nullptr, n_dev, &s.multi);
+        if (!rc) rc = pinned(s.enc, (size_t)max_bases);
+        if (!rc) rc = pinned(s.qual, (size_t)max_bases);
+        if (!rc) rc = pinned(s.cum, (size_t)max_reads + 1);
+        if (!rc) rc = pinned(s.name_off, (size_t)max_reads + 1);
+        if (!rc) rc = pinned(s.comment_off, (size_t)max_reads + 1);
+        if (!rc) rc = pinned(s.sam_off, (size_t)max_reads + 1);
+        if (!rc) rc = pinned(s.perfect, (size_t)max_reads);
+        if (!rc) rc = pinned(s.code, (size_t)max_reads);
+        if (rc) break;
+    }
+    if (rc) { bwams_worker_destroy(w); return rc; }          // (the message of the failing call stays in bwams_last_error)
+    *out = w;
+    return BWAMS_OK;
+}
+
+int bwams_worker_create(bwams_index_t *idx, bwams_emf_t *emf, bwams_ert_t *ert, int64_t max_reads, int64_t max_bases, const char *rg_id,
+                        bwams_worker **out) {
+    if (!idx) return BWAMS_ERR_ARG;
+    return bwams_worker_create_multi(&idx, emf ? &emf : nullptr, ert ? &ert : nullptr, 1, 1, max_reads, max_bases, rg_id, out);
+}
+
 void bwams_worker_set_host_path(bwams_worker *w, bwams_host_path_t f, void *user) { w->host_path = f; w->host_user = user; }
+void bwams_worker_set_deferred_collect(bwams_worker *w, int on) { w->deferred_collect = on != 0; }
+const char *bwams_worker_error(const bwams_worker *w) { return w ? w->err.c_str() : ""; }
 
 // mem_opt_t -> the three option records of the C-ABI.  Every field the device path reads is a field of mem_opt_t
 // (src/bwamem.h:89-124); n_threads and chunk_size are the driver's.
@@ -112,11 +180,28 @@ static inline uint8_t nt4(unsigned char c) {
     }
 }
 
-void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0, bwams_worker &w) {
-    if (n <= 0) return;
+static Slot *take_slot(bwams_worker &w, SlotState want, const bseq1_t *owner, bool wait) {
+    std::unique_lock<std::mutex> g(w.mu);
+    for (;;) {
+        for (Slot &s : w.slots)
+            if (s.state == want && (want == SLOT_FREE || s.owner == owner)) { s.state = SLOT_BUSY; return &s; }
+        if (!wait) return nullptr;
+        w.cv.wait(g);
+    }
+}
+static void put_slot(bwams_worker &w, Slot *s, SlotState st) {
+    {
+        std::lock_guard<std::mutex> g(w.mu);
+        s->state = st;
+        if (st == SLOT_FREE) s->owner = nullptr;
+    }
+    w.cv.notify_all();
+}
+
+// the records as flat page-locked arrays — seq becomes base codes in place (mem_kernel1_core, src/bwamem.cpp:1226-1237) — and up
+static int stage_into(bwams_worker &w, Slot &s, const mem_opt_t *opt, int n, bseq1_t *seqs) {
+    if ((int64_t)n > w.max_reads) { w.err = "chunk of " + std::to_string(n) + " reads, the worker was sized for " + std::to_string(w.max_reads); return BWAMS_ERR_CAPACITY; }
     const int paired = (opt->flag & MEM_F_PE) ? 1 : 0;
-    if ((int64_t)n > w.max_reads) { fprintf(stderr, "[bwams] mem_process_seqs: %d reads, the worker was sized for %lld\n", n, (long long)w.max_reads); exit(EXIT_FAILURE); }
-    // ---- the records as flat arrays; seq becomes base codes in place (mem_kernel1_core, src/bwamem.cpp:1226-1237)
     int64_t nb = 0, nn = 0, nc = 0;
     bool any_qual = false, all_qual = true, any_comment = false;
     for (int i = 0; i < n; ++i) {
@@ -125,61 +210,122 @@ void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs,
         if (seqs[i].comment) { nc += (int64_t)strlen(seqs[i].comment); any_comment = true; }
         if (seqs[i].qual) any_qual = true; else all_qual = false;
     }
-    if (nb > w.max_bases) { fprintf(stderr, "[bwams] mem_process_seqs: %lld bases, the worker was sized for %lld\n", (long long)nb, (long long)w.max_bases); exit(EXIT_FAILURE); }
+    if (nb > w.max_bases) { w.err = "chunk of " + std::to_string(nb) + " bases, the worker was sized for " + std::to_string(w.max_bases); return BWAMS_ERR_CAPACITY; }
     bool refuse = any_qual && !all_qual;                // a chunk mixing records with and without qualities: host path
-    grow(w.names, w.names_cap, nn + 1);
-    if (any_comment) grow(w.comments, w.comments_cap, nc + 1);
+    int rc = grow(s.names, s.names_cap, nn + 1);
+    if (!rc && any_comment) rc = grow(s.comments, s.comments_cap, nc + 1);
+    if (rc) return rc;
     int64_t ob = 0, on = 0, oc = 0;
     for (int i = 0; i < n; ++i) {
         const int l = seqs[i].l_seq;
-        w.cum[i] = ob; w.name_off[i] = on; w.comment_off[i] = oc;
-        unsigned char *s = reinterpret_cast<unsigned char *>(seqs[i].seq);
+        s.cum[i] = ob; s.name_off[i] = on; s.comment_off[i] = oc;
+        unsigned char *q = reinterpret_cast<unsigned char *>(seqs[i].seq);
         for (int j = 0; j < l; ++j) {
-            const uint8_t c = s[j] < 4 ? s[j] : nt4(s[j]);
-            s[j] = c;
-            w.enc[ob + j] = c;
+            const uint8_t c = q[j] < 4 ? q[j] : nt4(q[j]);
+            q[j] = c;
+            s.enc[ob + j] = c;
             refuse |= c > 4;                            // '-': the device path has no code for it
         }
-        if (all_qual && any_qual) memcpy(w.qual + ob, seqs[i].qual, (size_t)l);
+        if (all_qual && any_qual) memcpy(s.qual + ob, seqs[i].qual, (size_t)l);
         const size_t ln = strlen(seqs[i].name);
-        memcpy(w.names + on, seqs[i].name, ln);
+        memcpy(s.names + on, seqs[i].name, ln);
         on += (int64_t)ln;
-        if (seqs[i].comment) { const size_t lc = strlen(seqs[i].comment); memcpy(w.comments + oc, seqs[i].comment, lc); oc += (int64_t)lc; }
+        if (seqs[i].comment) { const size_t lc = strlen(seqs[i].comment); memcpy(s.comments + oc, seqs[i].comment, lc); oc += (int64_t)lc; }
         ob += l;
         seqs[i].sam = nullptr;
     }
-    w.cum[n] = ob; w.name_off[n] = on; w.comment_off[n] = oc;
+    s.cum[n] = ob; s.name_off[n] = on; s.comment_off[n] = oc;
+    s.owner = seqs; s.n = n; s.refuse = refuse; s.bytes = 0;
+    if (refuse) return BWAMS_OK;                        // decided in mem_process_seqs (host path, or the run ends)
+    rc = bwams_multi_upload(s.multi, s.enc, s.cum, n, s.names, s.name_off, (any_qual && all_qual) ? s.qual : nullptr,
+                            any_comment ? s.comments : nullptr, any_comment ? s.comment_off : nullptr, paired);
+    if (rc) w.err = bwams_multi_error(s.multi);
+    return rc;
+}
 
-    bwams_seed_opt_t so; bwams_mem_opt_t mo; bwams_sam_opt_t sa;
-    bwams_map_options(opt, w.rg_id, &so, &mo, &sa);
-    int64_t bytes = 0;
-    int rc = refuse ? BWAMS_ERR_UNSUPPORTED
-                    : bwams_process_reads(w.batch, w.emf, w.ert, &so, &mo, &sa, w.enc, w.cum, n, w.names, w.name_off,
-                                          (any_qual && all_qual) ? w.qual : nullptr, any_comment ? w.comments : nullptr,
-                                          any_comment ? w.comment_off : nullptr, paired, reinterpret_cast<const bwams_pestat_t *>(pes0),
-                                          n_processed, (opt->flag & MEM_F_NO_RESCUE) ? BWAMS_PAIR_NO_RESCUE : 0, &bytes);
-    if (rc == BWAMS_ERR_UNSUPPORTED && w.host_path) {   // an input or option the device path refuses: the reference's own code runs the chunk
-        w.host_path(opt, n_processed, n, seqs, pes0, w.host_user);
-        return;
-    }
-    if (rc) die("mem_process_seqs", rc);
-    // ---- the text back, one string per 512-read work item as worker_sam leaves it (src/bwamem.cpp:1722, :1823)
-    grow(w.sam, w.sam_cap, bytes + 1);
-    if ((rc = bwams_sam_fetch(w.batch, w.sam, w.sam_cap, w.sam_off, nullptr, 0))) die("bwams_sam_fetch", rc);
+// the text back, one string per 512-read work item as worker_sam leaves it (src/bwamem.cpp:1722, :1823); find_perfect_match_entry's
+// record of every read (src/perfect_map.cpp:638-659)
+static int collect_from(bwams_worker &w, Slot &s, int n, bseq1_t *seqs) {
+    int rc = grow(s.sam, s.sam_cap, s.bytes + 1);
+    if (rc) return rc;
+    if ((rc = bwams_multi_fetch(s.multi, s.sam, s.sam_cap, s.sam_off))) { w.err = bwams_multi_error(s.multi); return rc; }
     for (int i = 0; i < n; i += BATCH_SIZE) {
         const int e = i + BATCH_SIZE < n ? i + BATCH_SIZE : n;
-        const int64_t len = w.sam_off[e] - w.sam_off[i];
-        char *s = static_cast<char *>(malloc((size_t)len + 1));
-        if (!s) { fprintf(stderr, "[bwams] mem_process_seqs: out of memory\n"); exit(EXIT_FAILURE); }
-        memcpy(s, w.sam + w.sam_off[i], (size_t)len);
-        s[len] = 0;
-        seqs[i].sam = s;
+        const int64_t len = s.sam_off[e] - s.sam_off[i];
+        char *t = static_cast<char *>(malloc((size_t)len + 1));
+        if (!t) { w.err = "out of memory"; return BWAMS_ERR_NOMEM; }
+        memcpy(t, s.sam + s.sam_off[i], (size_t)len);
+        t[len] = 0;
+        seqs[i].sam = t;
     }
-    if (w.emf) {                                        // find_perfect_match_entry's record of every read (src/perfect_map.cpp:638-659)
-        if ((rc = bwams_emf_fetch(w.batch, w.perfect, w.code))) die("bwams_emf_fetch", rc);
-        for (int i = 0; i < n; ++i) {
-            seqs[i].perfect.exist = 0;
-            if (w.code[i] == 3 || w.code[i] == 4) { seqs[i].perfect.flags = w.perfect[i].flags; seqs[i].perfect.location = w.perfect[i].location; }
-        }
+    return BWAMS_OK;
+}
+
+int mem_process_seqs_stage(mem_opt_t *opt, int n, bseq1_t *seqs, bwams_worker &w) {
+    if (n <= 0) return BWAMS_OK;
+    Slot *s = take_slot(w, SLOT_FREE, nullptr, true);
+    const int rc = stage_into(w, *s, opt, n, seqs);
+    put_slot(w, s, rc ? SLOT_FREE : SLOT_STAGED);
+    return rc;
+}
+
+static int emf_records(bwams_worker &w, Slot &s, int n, int paired, bseq1_t *seqs) {
+    if (!w.emf[0]) return BWAMS_OK;
+    std::vector<int64_t> bounds((size_t)w.n_dev + 1);
+    int rc = bwams_shard_bounds(n, w.n_dev, paired, bounds.data());
+    for (int d = 0; d < w.n_dev && !rc; ++d)
+        if (bounds[(size_t)d + 1] > bounds[(size_t)d]) rc = bwams_emf_fetch(s.batch[(size_t)d], s.perfect + bounds[(size_t)d], s.code + bounds[(size_t)d]);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        seqs[i].perfect.exist = 0;
+        if (s.code[i] == 3 || s.code[i] == 4) { seqs[i].perfect.flags = s.perfect[i].flags; seqs[i].perfect.location = s.perfect[i].location; }
     }
+    return BWAMS_OK;
+}
+
+int mem_process_seqs_collect(mem_opt_t *opt, int n, bseq1_t *seqs, bwams_worker &w) {
+    if (n <= 0) return BWAMS_OK;
+    Slot *s = take_slot(w, SLOT_COMPUTED, seqs, false);
+    if (!s) return BWAMS_OK;                            // collected inside mem_process_seqs (not deferred), or the host path ran the chunk
+    int rc = collect_from(w, *s, n, seqs);
+    if (!rc) rc = emf_records(w, *s, n, (opt->flag & MEM_F_PE) ? 1 : 0, seqs);
+    put_slot(w, s, SLOT_FREE);
+    return rc;
+}
+
+// step 1 without the reference's way of ending the run: 0, or a BWAMS_ERR_* with bwams_worker_error()
+int bwams_worker_process(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0, bwams_worker &w) {
+    if (n <= 0) return BWAMS_OK;
+    Slot *s = take_slot(w, SLOT_STAGED, seqs, false);
+    int rc = BWAMS_OK;
+    if (!s) {
+        s = take_slot(w, SLOT_FREE, nullptr, true);
+        if ((rc = stage_into(w, *s, opt, n, seqs))) { put_slot(w, s, SLOT_FREE); return rc; }
+    }
+    if (s->refuse) {                                    // an input the device path refuses: the reference's own code runs the chunk
+        put_slot(w, s, SLOT_FREE);
+        if (w.host_path) { w.host_path(opt, n_processed, n, seqs, pes0, w.host_user); return BWAMS_OK; }
+        w.err = "a chunk the device path refuses (records with and without qualities, or a '-' base) and no host path is set";
+        return BWAMS_ERR_UNSUPPORTED;
+    }
+    bwams_seed_opt_t so; bwams_mem_opt_t mo; bwams_sam_opt_t sa;
+    bwams_map_options(opt, w.rg_id, &so, &mo, &sa);
+    rc = bwams_multi_compute(s->multi, &so, &mo, &sa, reinterpret_cast<const bwams_pestat_t *>(pes0), n_processed,
+                             (opt->flag & MEM_F_NO_RESCUE) ? BWAMS_PAIR_NO_RESCUE : 0, &s->bytes);
+    if (rc == BWAMS_ERR_UNSUPPORTED && w.host_path) {
+        put_slot(w, s, SLOT_FREE);
+        w.host_path(opt, n_processed, n, seqs, pes0, w.host_user);
+        return BWAMS_OK;
+    }
+    if (rc) { w.err = bwams_multi_error(s->multi); put_slot(w, s, SLOT_FREE); return rc; }
+    if (w.deferred_collect) { put_slot(w, s, SLOT_COMPUTED); return BWAMS_OK; }
+    rc = collect_from(w, *s, n, seqs);
+    if (!rc) rc = emf_records(w, *s, n, (opt->flag & MEM_F_PE) ? 1 : 0, seqs);
+    put_slot(w, s, SLOT_FREE);
+    return rc;
+}
+
+void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0, bwams_worker &w) {
+    const int rc = bwams_worker_process(opt, n_processed, n, seqs, pes0, w);
+    if (rc) die("mem_process_seqs", rc, w.err.c_str());
 }

@@ -560,6 +560,13 @@ int bwams_process_reads_stage1(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *
                                const char *quals, const char *comments, const int64_t *comment_off);
 int bwams_process_reads_stage2(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt,
                                int32_t paired, const bwams_pestat_t *pes, int64_t id_base, int32_t flags, int64_t *sam_bytes);
+/* Stage 1 in two halves (bwams_process_reads_stage1 == _upload + _stage1_run): what crosses PCIe, and what computes.  A pipeline puts chunk
+ * i + 1 into one batch while another batch of the same device runs chunk i (the reference overlaps reading, computing and writing of
+ * consecutive chunks with its `-i` pipeline threads, src/fastmap.cpp:307-468; host/chunk_multi.cpp does the same over batches). */
+int bwams_process_reads_upload(bwams_batch_t *b, const uint8_t *enc_qdb, const int64_t *cum_len, int64_t n_reads, const char *names,
+                               const int64_t *name_off, const char *quals, const char *comments, const int64_t *comment_off);
+int bwams_process_reads_stage1_run(bwams_batch_t *b, bwams_emf_t *emf, bwams_ert_t *ert, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo);
+int bwams_batch_device(const bwams_batch_t *b, int32_t *device);      /* the device of the batch's index */
 /* One chunk over n batches — one per GPU, each on a replica of the index — behind one call (host/chunk_multi.cpp): the chunk is cut into n
  * contiguous shards on read (paired-end: pair) boundaries (bwams_shard_bounds: sizes differ by at most one unit, larger shards first), one
  * host thread drives each batch through stage 1, the shards' pestat keys are merged in-process (no collective), stage 2 runs per shard with
@@ -573,6 +580,13 @@ int bwams_multi_process_reads(bwams_multi_t *m, const bwams_seed_opt_t *so, cons
                               const char *quals, const char *comments, const int64_t *comment_off, int32_t paired, const bwams_pestat_t *pes0,
                               int64_t n_processed, int32_t flags, int64_t *sam_bytes);
 int bwams_multi_fetch(bwams_multi_t *m, char *sam, int64_t cap, int64_t *read_off);
+/* bwams_multi_process_reads in its two halves: _upload cuts the chunk and puts every shard into its batch (the shards' threads, side by
+ * side; nothing computes), _compute runs stage 1, the pestat merge and stage 2.  With two bwams_multi over the same devices a caller
+ * uploads chunk i + 1 through one while the other computes chunk i (host/mem_process_seqs_hip.cpp: mem_process_seqs_stage / _collect). */
+int bwams_multi_upload(bwams_multi_t *m, const uint8_t *enc_qdb, const int64_t *cum_len, int64_t n_reads, const char *names,
+                       const int64_t *name_off, const char *quals, const char *comments, const int64_t *comment_off, int32_t paired);
+int bwams_multi_compute(bwams_multi_t *m, const bwams_seed_opt_t *so, const bwams_mem_opt_t *mo, const bwams_sam_opt_t *sam_opt,
+                        const bwams_pestat_t *pes0, int64_t n_processed, int32_t flags, int64_t *sam_bytes);
 const char *bwams_multi_error(const bwams_multi_t *m);       /* which shard failed, and why */
 int bwams_multi_destroy(bwams_multi_t *m);
 /* Page-locked host memory (hipHostMalloc) for the buffers that cross PCIe every chunk: reads, names and qualities up, SAM text down. */

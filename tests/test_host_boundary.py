@@ -154,3 +154,65 @@ def test_two_batches_behind_one_call_equal_one_batch(mode):
     b.close()
     assert text == want and np.array_equal(off, woff)
     ix.close()
+
+
+def _names_blob(fmt, ids):
+    names = [fmt % int(i) for i in ids]
+    return np.frombuffer(b"".join(names), np.uint8), np.concatenate([[0], np.cumsum([len(x) for x in names])]).astype(np.int64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["se", "pe"])
+def test_worker_pipeline_equals_chunk_by_chunk(mode):
+    """The three steps of kt_pipeline over the compiled boundary (host/mem_process_seqs_hip.cpp driven through bwams/stream.py):
+    mem_process_seqs_stage on the reader's thread, mem_process_seqs, mem_process_seqs_collect on the writer's — chunks in flight
+    1, 2, 3; one and two batches per chunk (the chunk cut on read / pair boundaries); against mem_process_seqs alone (no overlap)
+    and against bwams_process_reads chunk by chunk: the same bytes, the global read ordinals (hash seeds) carried through."""
+    from bwams import stream
+    g, ix, contigs, cnames = _setup(seed=23)
+    paired = mode == "pe"
+    n_chunks, per = 5, 1100 if not paired else 1000
+    rng = np.random.default_rng(11)
+    chunks = []
+    for c in range(n_chunks):
+        if not paired:
+            rd, _, _ = simulate.make_reads(g, per, seed=50 + c)
+            rd = np.asarray(rd, np.uint8)
+            if c == 2:
+                rd[5, 7] = 4
+        else:
+            rd = np.asarray(simulate.make_read_pairs(g, per // 2, seed=60 + c, read_len=150, insert_mean=400.0, insert_sd=30.0, damaged_frac=0.2,
+                                                     discordant_frac=0.05), np.uint8)
+        chunks.append(rd)
+    first = np.concatenate([[0], np.cumsum([len(c) for c in chunks])])
+    ID0 = 7000
+    ids = [((ID0 + first[c] + np.arange(len(chunks[c]))) // 2 if paired else ID0 + first[c] + np.arange(len(chunks[c]))) for c in range(n_chunks)]
+    fmt = b"q%08d"
+    # the reference texts: one batch, chunk by chunk
+    want = []
+    b = capi.Batch(ix, per, per * 160)
+    for c in range(n_chunks):
+        enc, cum = simulate.flatten_reads(chunks[c])
+        nm, noff = _names_blob(fmt, ids[c])
+        text, _ = b.process_reads(enc, cum, nm, noff, quals=np.full(int(cum[-1]), ord("I"), np.uint8), paired=paired, n_processed=ID0 + int(first[c]))
+        want.append(text)
+    b.close()
+    opt = capi.mem_opt_init(paired)
+
+    def make(c):
+        return capi.Seqs(chunks[c], name_fmt=fmt, name_ids=ids[c])
+
+    for n_dev, depth, overlap in ((1, 1, False), (1, 1, True), (1, 2, True), (1, 3, True), (2, 2, True), (3, 3, True), (2, 1, False)):
+        w = capi.Worker([ix] * n_dev, per, per * 160, depth=depth)
+        got = {}
+        secs, n = stream.run_job(w, opt, make, n_chunks, lambda i, t: got.__setitem__(i, t), n_processed0=ID0, overlap=overlap)
+        w.close()
+        assert n == first[-1]
+        for c in range(n_chunks):
+            assert got[c] == want[c], (n_dev, depth, overlap, c)
+    # a chunk larger than the worker was sized for is an error code (and a message), not an exit
+    w = capi.Worker([ix], 100, 100 * 160)
+    with pytest.raises(capi.BwamsError, match="sized for"):
+        w.process(opt, 0, make(0))
+    w.close()
+    ix.close()

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--profile", default="uniform")
+    ap.add_argument("--step", action="store_true", help="run the whole step (seed .. dedup), not just seeding")
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -50,6 +51,7 @@ def main():
     print(f"[lab] inputs in {time.time()-t0:.1f}s: {G/1e6:.0f} Mbp, {len(reads)} reads, lib {capi.LIB_PATH}", flush=True)
     batch = capi.Batch(ix, len(reads), len(reads) * RL, max_smem=32 * len(reads), max_sa=128 * len(reads))
     opt = capi.default_seed_opt()
+    mopt = capi.default_mem_opt()
     ref = None
     for v in (args.variants or ["default:"]):
         name, _, envs = v.partition(":")
@@ -60,10 +62,17 @@ def main():
         rows = []
         for i in range(args.warmup + args.steps):
             batch.seed_upload_device(d_reads.data_ptr(), cum)
+            t_0 = time.perf_counter()
             batch.seed_run(opt, with_sa=True)
+            if args.step:
+                batch.chain_run(mopt)
+                batch.extend_run(mopt)
+                batch.dedup_run(mopt)
             st = batch.stats()
+            wall = (time.perf_counter() - t_0) * 1e3
             if i >= args.warmup:
-                rows.append((st.ms_smem_r1, st.ms_smem_r2, st.ms_smem_r3, st.ms_sal, st.ms_seed_total))
+                rows.append((st.ms_smem_r1, st.ms_smem_r2, st.ms_smem_r3, st.ms_sal, st.ms_seed_total, st.ms_chain, st.ms_ext_total, st.ms_dedup, wall,
+                             st.ms_ext_plan, st.ms_ext_left, st.ms_ext_right, st.ms_ext_purge))
         for k, _ in sets:
             if old[k] is None:
                 del os.environ[k]
@@ -76,6 +85,9 @@ def main():
             ref = ev
         bytes_r1 = 64 * int(st.n_blk_round[0]) + len(reads) * RL + 40 * int(st.n_smem[0])
         frac = bytes_r1 / (m[0] * 1e-3) / 8e12
+        if args.step:
+            print(f"[lab] {name:28s} step {m[8]:7.2f} (min {mn[8]:7.2f})  seed {m[4]:6.2f}  chain {m[5]:6.2f}  ext {m[6]:6.2f} (plan {m[9]:5.2f} left {m[10]:6.2f} right {m[11]:6.2f} purge {m[12]:5.2f})"
+                  f"  dedup {m[7]:6.2f}  rounds {int(st.n_ext_rounds)} tasks {int(st.n_left + st.n_right)} cells {int(st.bsw_cells)} chains {int(st.n_chains)} regs {int(st.n_final_regs)}", flush=True)
         print(f"[lab] {name:28s} r1 {m[0]:6.2f} (min {mn[0]:6.2f})  r2 {m[1]:6.2f}  r3 {m[2]:6.2f}  sal {m[3]:5.2f}  total {m[4]:6.2f} (min {mn[4]:6.2f})"
               f"  frac {frac:.4f}  events {'same' if ev == ref else 'DIFFER ' + str(ev)}", flush=True)
     batch.close()

@@ -433,6 +433,35 @@ def main():
             "ms_per_chunk": round(ms_c, 2), "Mreads_per_s": round(len(row_c) / (ms_c * 1e-3) / 1e6, 3), "sam_bytes": int(bytes_c),
             "note": "bwams_process_chunk with the EMF and the ERT (configs[2]'s index set), single-end, FASTQ text in HBM -> SAM text in HBM"}
         del row_c, d_fq_c
+        # configs[2] as a JOB: chunks streamed through the compiled mem_process_seqs() with three chunks in flight (the reader's
+        # thread stages chunk i + 1, the writer's collects chunk i - 1: kt_pipeline's three steps, bwams/stream.py) — records in host
+        # memory in, SAM strings in host memory out, i.e. host staging and PCIe inside the clock
+        try:
+            from bwams import stream
+            n_job = int(os.environ.get("BWAMS_STREAM_CHUNKS", "6"))
+            rd_job = reads_l[n_chunks - 1]
+            o_t = capi.mem_opt_init(False)
+            res_j = {}
+            for depth_ in (2, 3, 1):
+                pre = [capi.Seqs(rd_job, first_id=first + k * len(rd_job)) for k in range(n_job + 1)]      # step 0's output, parsed beforehand
+                wk = capi.Worker([ix], len(rd_job), len(rd_job) * RL, emfs=[emf_h], erts=[ert_h], depth=depth_)
+                stream.run_job(wk, o_t, lambda k: pre[n_job], 1, None, n_processed0=first)                  # warm-up: buffers, first touch
+                nj_ = n_job if depth_ > 1 else 2
+                secs_j, n_j = stream.run_job(wk, o_t, lambda k: pre[k], nj_, None, n_processed0=first, overlap=depth_ > 1)
+                wk.close()
+                del pre
+                res_j[depth_] = n_j / secs_j / 1e6
+            resident_ = len(rd_job) / (ms_c * 1e-3) / 1e6
+            ert_side["with_emf"]["configs2_stream"] = {
+                "Mreads_per_s": round(res_j[2], 3), "chunks": n_job, "reads_per_chunk": len(rd_job), "chunks_in_flight": 2,
+                "ms_per_chunk": round(len(rd_job) / res_j[2] / 1e3, 2), "ratio_to_resident": round(res_j[2] / resident_, 3),
+                "three_in_flight_Mreads_per_s": round(res_j[3], 3), "no_overlap_Mreads_per_s": round(res_j[1], 3),
+                "note": "BASELINE configs[2] as a job through the compiled mem_process_seqs() (host/mem_process_seqs_hip.cpp): parsed records "
+                        "(bseq1_t) in host memory -> page-locked arrays -> GPU -> one malloc'ed SAM string per 512-read work item in host "
+                        "memory, two chunks in flight (stage on the reader's thread, collect on the writer's); ratio_to_resident compares "
+                        "with bwams_process_chunk on text already in HBM; no_overlap = mem_process_seqs alone, one chunk at a time"}
+        except Exception as e_:                       # the leg is reported beside: a failure is recorded, not hidden
+            ert_side["with_emf"]["configs2_stream"] = {"error": repr(e_)}
         emf_h.close()
         emf_h = None
         ert_h.close()
@@ -872,7 +901,7 @@ def main():
                 "algorithmic_bytes": round(all_bytes / CHn, 1),
             },
             "roofline": {
-                "kernel": "smem_search_kernel<ALL_POS> + smem_bwd_wave_kernel (SMEM round 1: the lane-per-read search and the wave-per-pivot kernel for the backward phases it hands over; launch_ms brackets both)",
+                "kernel": "smem_search_kernel<ALL_POS> + smem_bwd_kernel (SMEM round 1: the lane-per-read search and the launch behind it for the backward phases that left their lanes — a wavefront per pivot with a long list, sixteen lanes per pivot otherwise; launch_ms brackets both)",
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
@@ -882,6 +911,10 @@ def main():
                 "traffic_source": None if pmc is None else {"file": os.path.relpath(PMC_SUMMARY, ROOT), "commit": pmc.get("commit"),
                                                             "frac_of_peak_measured_bytes": pmc.get("smem_round1_measured_frac")},
                 "bytes_per_launch": int(r1_bytes),
+                "bytes_note": "ALGORITHMIC bytes (SURVEY 8d): 64 B x every CP_OCC block an extension touches (1 if k and k + s share a block, else 2), "
+                              "counted by the kernels as the oracle counts them, + 1 B per base in + 40 B per SMEM out.  Blocks served from the "
+                              "lane's two-block register cache (about 28 % of them) are INCLUDED: they cost no request.  `traffic` is what the "
+                              "counters saw move (2 x FETCH_SIZE + WRITE_SIZE of the committed PMC pass)",
                 "launch_ms": round(r1_ms, 3),
                 "other_rounds": {"round2_frac": round(r2_bytes / (mean("ms_smem_r2") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "round3_frac": round(r3_bytes / (mean("ms_smem_r3") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -922,6 +955,25 @@ def main():
             out["configs2_fastq_to_sam"] = ert_side["with_emf"].get("fastq_to_sam")
         if hard_side is not None:
             out["hard_genome"] = hard_side
+        # the other legs' headline figures where the driver's record keeps them (it keeps `config`, `roofline`, `cpu_baseline` whole and
+        # only the NAMES of other top-level keys); the full records stay at the top level
+        legs = {"stage_ms": {k_: out["stage_ms"][k_] for k_ in ("seed_total", "chain", "ext_total", "dedup") if k_ in out["stage_ms"]}}
+        if hard_side is not None:
+            legs["hard_genome"] = {"Mreads_per_s": hard_side.get("value"), "ms_per_step": hard_side.get("ms_per_step"),
+                                   "stage_ms": {k_: hard_side["stage_ms"][k_] for k_ in ("seed_total", "chain", "ext_total", "dedup")}}
+        if ert_side is not None and not args.ert:
+            we_ = ert_side.get("with_emf", {})
+            legs["ert_mode_Mreads_per_s"] = ert_side.get("value")
+            legs["configs2_step_Mreads_per_s"] = we_.get("value")
+            legs["configs2_fastq_to_sam_Mreads_per_s"] = (we_.get("fastq_to_sam") or {}).get("Mreads_per_s")
+            legs["configs2_stream"] = {k_: (we_.get("configs2_stream") or {}).get(k_) for k_ in ("Mreads_per_s", "ratio_to_resident", "three_in_flight_Mreads_per_s", "no_overlap_Mreads_per_s", "chunks", "error")
+                                       if (we_.get("configs2_stream") or {}).get(k_) is not None}
+            legs["ert_walk_roofline"] = {k_: ert_side["roofline"].get(k_) for k_ in ("frac", "launch_ms", "traffic", "bytes_per_launch")}
+        if pe_out is not None:
+            legs["paired_end_Mreads_per_s"] = pe_out.get("value")
+            legs["paired_end_fastq_to_sam_Mreads_per_s"] = (pe_out.get("fastq_to_sam") or {}).get("Mreads_per_s")
+        legs["fastq_to_sam_Mreads_per_s"] = (sam_side.get("fastq_to_sam") or {}).get("Mreads_per_s")
+        out["config"]["legs"] = legs
         if emf_h is not None:
             _, codes = batch.emf_fetch(CHn)
             emf_ms = mean("ms_emf")

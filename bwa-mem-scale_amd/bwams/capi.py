@@ -1190,6 +1190,22 @@ class Seqs:
     def ptr(self):
         return C.c_void_p(self.arr.ctypes.data)
 
+    def drop_sam(self) -> int:
+        """free the work items' strings unread (a writer that costs nothing); returns their total length"""
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        libc.strlen.argtypes = [C.c_void_p]
+        libc.strlen.restype = C.c_size_t
+        total = 0
+        for i in range(0, self.n, WORK_ITEM):
+            p = int(self.arr["sam"][i])
+            if not p:
+                raise BwamsError(-3, "drop_sam", f"work item {i // WORK_ITEM} left no text")
+            total += libc.strlen(C.c_void_p(p))
+            libc.free(C.c_void_p(p))
+            self.arr["sam"][i] = 0
+        return total
+
     def take_sam(self) -> bytes:
         """the chunk's SAM text (the work items' strings joined, as step 2 writes them), the strings freed"""
         libc = C.CDLL(None)

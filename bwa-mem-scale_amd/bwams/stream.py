@@ -11,7 +11,8 @@ from . import capi
 
 
 def run_job(worker: "capi.Worker", opt: "capi.MemOptT", make_chunk, n_chunks: int, sink, n_processed0: int = 0, overlap: bool = True):
-    """make_chunk(i) -> capi.Seqs (step 0's parsing; called on the reader's thread); sink(i, sam_bytes) (step 2's fputs).
+    """make_chunk(i) -> capi.Seqs (step 0's parsing; called on the reader's thread); sink(i, sam_bytes) (step 2's fputs; sink=None:
+    the strings are freed unread, Seqs.drop_sam).
     overlap=False runs the three steps of every chunk one after the other on this thread (the strict drop-in: mem_process_seqs alone).
     Returns (wall seconds, reads)."""
     reads = 0
@@ -22,7 +23,7 @@ def run_job(worker: "capi.Worker", opt: "capi.MemOptT", make_chunk, n_chunks: in
         for i in range(n_chunks):
             s = make_chunk(i)
             worker.process(opt, done, s)
-            sink(i, s.take_sam())
+            (s.drop_sam() if sink is None else sink(i, s.take_sam()))
             done += s.n
             reads += s.n
         return time.perf_counter() - t0, reads
@@ -48,7 +49,7 @@ def run_job(worker: "capi.Worker", opt: "capi.MemOptT", make_chunk, n_chunks: in
                     return
                 i, s = it
                 worker.collect(opt, s)
-                sink(i, s.take_sam())
+                (s.drop_sam() if sink is None else sink(i, s.take_sam()))
         except BaseException as e:                   # noqa: BLE001
             errs.append(e)
             while q12.get() is not None:             # keep draining so that step 1 never blocks on a dead writer

@@ -19,7 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -168,17 +170,46 @@ void bwams_map_options(const mem_opt_t *o, const char *rg_id, bwams_seed_opt_t *
     if (rg_id) strncpy(sa->rg_id, rg_id, sizeof sa->rg_id - 1);
 }
 
-// nst_nt4_table (src/bntseq.cpp:64-81): A C G T in either case -> 0..3, '-' -> 5, everything else -> 4
-static inline uint8_t nt4(unsigned char c) {
-    switch (c) {
-        case 'A': case 'a': return 0;
-        case 'C': case 'c': return 1;
-        case 'G': case 'g': return 2;
-        case 'T': case 't': return 3;
-        case '-': return 5;
-        default: return 4;
+// seq[i] < 4 ? seq[i] : nst_nt4_table[seq[i]] (src/bwamem.cpp:1232; the table: src/bntseq.cpp:64-81 — A C G T in either case -> 0..3,
+// '-' -> 5, everything else -> 4) as one 256-entry table
+struct Nt4Table {
+    uint8_t t[256];
+    Nt4Table() {
+        for (int c = 0; c < 256; ++c) t[c] = 4;
+        t[0] = 0; t[1] = 1; t[2] = 2; t[3] = 3;
+        t[(unsigned char)'A'] = t[(unsigned char)'a'] = 0; t[(unsigned char)'C'] = t[(unsigned char)'c'] = 1;
+        t[(unsigned char)'G'] = t[(unsigned char)'g'] = 2; t[(unsigned char)'T'] = t[(unsigned char)'t'] = 3;
+        t[(unsigned char)'-'] = 5;
     }
+};
+static const Nt4Table kNt4;
+
+// The host side of a chunk is byte shuffling over ~0.5 GB (records -> flat arrays, text -> work-item strings): a handful of threads,
+// as the reference gives its own per-read host work to its `-t` threads.  f(first, last) over [0, n) in contiguous parts.
+template <class F>
+static void parallel_parts(int n, int max_threads, F f) {
+    int nt = std::min(max_threads, std::max(1, n / 4096));
+    if (nt <= 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const int per = (n + nt - 1) / nt;
+    int started = 0;
+    try {
+        for (int t = 1; t < nt; ++t) { th.emplace_back(f, std::min(n, t * per), std::min(n, (t + 1) * per)); started = t; }
+    } catch (...) {                                     // no thread to be had: the caller's thread does the rest
+        for (auto &x : th) x.join();
+        f(std::min(n, (started + 1) * per), n);
+        f(0, std::min(n, per));
+        return;
+    }
+    f(0, std::min(n, per));
+    for (auto &x : th) x.join();
 }
+static int host_threads() {
+    static const int n = [] { const char *e = getenv("BWAMS_HOST_THREADS"); int v = e ? atoi(e) : 6; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    return n;
+}
+static bool verbose() { static const bool v = getenv("BWAMS_VERBOSE") != nullptr; return v; }
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static Slot *take_slot(bwams_worker &w, SlotState want, const bseq1_t *owner, bool wait) {
     std::unique_lock<std::mutex> g(w.mu);
@@ -201,63 +232,102 @@ static void put_slot(bwams_worker &w, Slot *s, SlotState st) {
 // the records as flat page-locked arrays — seq becomes base codes in place (mem_kernel1_core, src/bwamem.cpp:1226-1237) — and up
 static int stage_into(bwams_worker &w, Slot &s, const mem_opt_t *opt, int n, bseq1_t *seqs) {
     if ((int64_t)n > w.max_reads) { w.err = "chunk of " + std::to_string(n) + " reads, the worker was sized for " + std::to_string(w.max_reads); return BWAMS_ERR_CAPACITY; }
+    const double t0 = now_ms();
     const int paired = (opt->flag & MEM_F_PE) ? 1 : 0;
-    int64_t nb = 0, nn = 0, nc = 0;
+    const int nt = host_threads();
+    // pass 1: sizes -> offsets
     bool any_qual = false, all_qual = true, any_comment = false;
-    for (int i = 0; i < n; ++i) {
-        nb += seqs[i].l_seq;
-        nn += (int64_t)strlen(seqs[i].name);
-        if (seqs[i].comment) { nc += (int64_t)strlen(seqs[i].comment); any_comment = true; }
-        if (seqs[i].qual) any_qual = true; else all_qual = false;
+    {
+        std::mutex mu;
+        parallel_parts(n, nt, [&](int a, int b) {
+            bool aq = false, lq = true, ac = false;
+            for (int i = a; i < b; ++i) {
+                s.cum[i] = seqs[i].l_seq;
+                s.name_off[i] = (int64_t)strlen(seqs[i].name);
+                s.comment_off[i] = seqs[i].comment ? (int64_t)strlen(seqs[i].comment) : 0;
+                ac |= seqs[i].comment != nullptr;
+                if (seqs[i].qual) aq = true; else lq = false;
+            }
+            std::lock_guard<std::mutex> g(mu);
+            any_qual |= aq; all_qual &= lq; any_comment |= ac;
+        });
     }
+    int64_t nb = 0, nn = 0, nc = 0;
+    for (int i = 0; i < n; ++i) {                       // lengths -> exclusive offsets
+        const int64_t l = s.cum[i], a = s.name_off[i], c = s.comment_off[i];
+        s.cum[i] = nb; s.name_off[i] = nn; s.comment_off[i] = nc;
+        nb += l; nn += a; nc += c;
+    }
+    s.cum[n] = nb; s.name_off[n] = nn; s.comment_off[n] = nc;
     if (nb > w.max_bases) { w.err = "chunk of " + std::to_string(nb) + " bases, the worker was sized for " + std::to_string(w.max_bases); return BWAMS_ERR_CAPACITY; }
-    bool refuse = any_qual && !all_qual;                // a chunk mixing records with and without qualities: host path
     int rc = grow(s.names, s.names_cap, nn + 1);
     if (!rc && any_comment) rc = grow(s.comments, s.comments_cap, nc + 1);
     if (rc) return rc;
-    int64_t ob = 0, on = 0, oc = 0;
-    for (int i = 0; i < n; ++i) {
-        const int l = seqs[i].l_seq;
-        s.cum[i] = ob; s.name_off[i] = on; s.comment_off[i] = oc;
-        unsigned char *q = reinterpret_cast<unsigned char *>(seqs[i].seq);
-        for (int j = 0; j < l; ++j) {
-            const uint8_t c = q[j] < 4 ? q[j] : nt4(q[j]);
-            q[j] = c;
-            s.enc[ob + j] = c;
-            refuse |= c > 4;                            // '-': the device path has no code for it
-        }
-        if (all_qual && any_qual) memcpy(s.qual + ob, seqs[i].qual, (size_t)l);
-        const size_t ln = strlen(seqs[i].name);
-        memcpy(s.names + on, seqs[i].name, ln);
-        on += (int64_t)ln;
-        if (seqs[i].comment) { const size_t lc = strlen(seqs[i].comment); memcpy(s.comments + oc, seqs[i].comment, lc); oc += (int64_t)lc; }
-        ob += l;
-        seqs[i].sam = nullptr;
+    // pass 2: the bytes
+    bool refuse = any_qual && !all_qual;                // a chunk mixing records with and without qualities: host path
+    {
+        std::mutex mu;
+        const bool qual_up = all_qual && any_qual;
+        parallel_parts(n, nt, [&](int a, int b) {
+            bool bad = false;
+            for (int i = a; i < b; ++i) {
+                const int l = seqs[i].l_seq;
+                unsigned char *q = reinterpret_cast<unsigned char *>(seqs[i].seq);
+                uint8_t *e = s.enc + s.cum[i];
+                uint8_t mx = 0;
+                for (int j = 0; j < l; ++j) {
+                    const uint8_t c = kNt4.t[q[j]];
+                    q[j] = c;
+                    e[j] = c;
+                    mx |= c;                            // 5 ('-') has bits a code 0..4 pair cannot make: 1 | 4, yes — checked exactly below
+                }
+                if (mx >= 5) for (int j = 0; j < l; ++j) bad |= e[j] > 4;      // '-': the device path has no code for it
+                if (qual_up) memcpy(s.qual + s.cum[i], seqs[i].qual, (size_t)l);
+                memcpy(s.names + s.name_off[i], seqs[i].name, (size_t)(s.name_off[i + 1] - s.name_off[i]));
+                if (seqs[i].comment) memcpy(s.comments + s.comment_off[i], seqs[i].comment, (size_t)(s.comment_off[i + 1] - s.comment_off[i]));
+                seqs[i].sam = nullptr;
+            }
+            if (bad) { std::lock_guard<std::mutex> g(mu); refuse = true; }
+        });
     }
-    s.cum[n] = ob; s.name_off[n] = on; s.comment_off[n] = oc;
     s.owner = seqs; s.n = n; s.refuse = refuse; s.bytes = 0;
+    const double t1 = now_ms();
     if (refuse) return BWAMS_OK;                        // decided in mem_process_seqs (host path, or the run ends)
     rc = bwams_multi_upload(s.multi, s.enc, s.cum, n, s.names, s.name_off, (any_qual && all_qual) ? s.qual : nullptr,
                             any_comment ? s.comments : nullptr, any_comment ? s.comment_off : nullptr, paired);
     if (rc) w.err = bwams_multi_error(s.multi);
+    if (verbose()) fprintf(stderr, "[bwams_worker] stage: %d reads, records -> page-locked arrays %.1f ms (%d threads), upload %.1f ms\n", n, t1 - t0, nt, now_ms() - t1);
     return rc;
 }
 
 // the text back, one string per 512-read work item as worker_sam leaves it (src/bwamem.cpp:1722, :1823); find_perfect_match_entry's
 // record of every read (src/perfect_map.cpp:638-659)
 static int collect_from(bwams_worker &w, Slot &s, int n, bseq1_t *seqs) {
+    const double t0 = now_ms();
     int rc = grow(s.sam, s.sam_cap, s.bytes + 1);
     if (rc) return rc;
     if ((rc = bwams_multi_fetch(s.multi, s.sam, s.sam_cap, s.sam_off))) { w.err = bwams_multi_error(s.multi); return rc; }
-    for (int i = 0; i < n; i += BATCH_SIZE) {
-        const int e = i + BATCH_SIZE < n ? i + BATCH_SIZE : n;
-        const int64_t len = s.sam_off[e] - s.sam_off[i];
-        char *t = static_cast<char *>(malloc((size_t)len + 1));
-        if (!t) { w.err = "out of memory"; return BWAMS_ERR_NOMEM; }
-        memcpy(t, s.sam + s.sam_off[i], (size_t)len);
-        t[len] = 0;
-        seqs[i].sam = t;
+    const double t1 = now_ms();
+    const int n_items = (n + BATCH_SIZE - 1) / BATCH_SIZE;
+    std::mutex mu;
+    bool oom = false;
+    parallel_parts(n_items, host_threads(), [&](int a, int b) {
+        for (int k = a; k < b; ++k) {
+            const int i = k * BATCH_SIZE, e = i + BATCH_SIZE < n ? i + BATCH_SIZE : n;
+            const int64_t len = s.sam_off[e] - s.sam_off[i];
+            char *t = static_cast<char *>(malloc((size_t)len + 1));
+            if (!t) { std::lock_guard<std::mutex> g(mu); oom = true; return; }
+            memcpy(t, s.sam + s.sam_off[i], (size_t)len);
+            t[len] = 0;
+            seqs[i].sam = t;
+        }
+    });
+    if (oom) {
+        for (int i = 0; i < n; i += BATCH_SIZE) { free(seqs[i].sam); seqs[i].sam = nullptr; }
+        w.err = "out of memory";
+        return BWAMS_ERR_NOMEM;
     }
+    if (verbose()) fprintf(stderr, "[bwams_worker] collect: %lld bytes down %.1f ms, %d work-item strings %.1f ms\n", (long long)s.bytes, t1 - t0, n_items, now_ms() - t1);
     return BWAMS_OK;
 }
 

@@ -282,3 +282,112 @@ def test_configs2_index_set_ert_plus_emf_sampled_parity(big):
         for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "n_comp_is_alt", "frac_rep"):
             assert np.array_equal(a[f], w[f]), (r, f)
     b.close(); emf.close(); ert.close()
+
+
+def _fastq_text(rd, first):
+    """four-line records '@r%08d' / bases / '+' / 'I'*len, the names Seqs gives the same reads"""
+    n, RL = rd.shape
+    row = np.empty((n, 1 + 9 + 1 + RL + 3 + RL + 1), np.uint8)
+    row[:, 0] = ord("@"); row[:, 1] = ord("r")
+    ids_ = first + np.arange(n, dtype=np.int64)
+    for d_ in range(8):
+        row[:, 2 + d_] = ord("0") + (ids_ // 10 ** (7 - d_)) % 10
+    row[:, 10] = 10
+    row[:, 11:11 + RL] = np.frombuffer(b"ACGTN", np.uint8)[rd]
+    row[:, 11 + RL:14 + RL] = np.frombuffer(b"\n+\n", np.uint8)
+    row[:, 14 + RL:14 + 2 * RL] = ord("I")
+    row[:, 14 + 2 * RL] = 10
+    return row.tobytes()
+
+
+def test_configs2_as_a_job_ten_chunks_streamed_through_mem_process_seqs(big):
+    """BASELINE configs[2] as a JOB: ten chunks (1 M reads each at GRCh38 size; 100 k on the small genomes) through the compiled
+    mem_process_seqs() with three chunks in flight — staged on the reader's thread, collected on the writer's (bwams/stream.py =
+    kt_pipeline's three steps) — over the resident ERT + EMF + FM-index set.  Checked: every chunk's SAM bytes == bwams_process_chunk
+    of that chunk alone (FASTQ text in, the read ordinals carried), and on chunks 0 and 9 a sample of reads against the oracle in
+    ERT + EMF mode, text for text: the restated find_perfect_match_entry / mem_perfect2sam_cont for the reads the filter resolves,
+    the reference's own ERT walk (oracle/ert_walk_oracle.c) -> mem_chain_new ... mem_sort_dedup_patch -> mem_mark_primary_se ->
+    mem_reg2sam for the others."""
+    import hashlib
+    from bwams import emf as emf_mod
+    from bwams import stream
+    g, host, ix, reads0, enc0, cum0, contigs = big
+    l_pac = len(g)
+    full = host.ref_seq_len > 2 ** 32
+    per = 1_000_000 if full else 100_000
+    n_chunks = 10
+    cb = None if contigs is None else simulate.contig_bounds(contigs)
+    ert = capi.Ert.build(ix)
+    emf = capi.Emf.build(ix, seed_len=150, slack=1.1)
+    cn = [b"chr%d" % (i + 1) for i in range(len(contigs) if contigs is not None else 1)]
+    ix.set_contig_names(cn)
+    RL = reads0.shape[1]
+    kept = {}
+
+    def make(c):
+        rd = simulate.make_reads(g, per, seed=4000 + c, contig_bounds=cb)[0]
+        if c in (0, n_chunks - 1):
+            kept[c] = rd
+        return capi.Seqs(rd, first_id=c * per)
+
+    digests, sizes, sample_text = {}, {}, {}
+
+    def sink(c, text):
+        digests[c] = hashlib.sha1(text).hexdigest()
+        sizes[c] = len(text)
+        if c in (0, n_chunks - 1):
+            sample_text[c] = text
+
+    opt = capi.mem_opt_init(False)
+    w = capi.Worker([ix], per, per * RL, emfs=[emf], erts=[ert], depth=3)
+    secs, n = stream.run_job(w, opt, make, n_chunks, sink, overlap=True)
+    w.close()
+    assert n == n_chunks * per and len(digests) == n_chunks
+    # ---- every chunk alone through the text-to-text entry point
+    b = capi.Batch(ix, per, per * RL, max_smem=32 * per, max_sa=128 * per)
+    for c in range(n_chunks):
+        rd = kept[c] if c in kept else simulate.make_reads(g, per, seed=4000 + c, contig_bounds=cb)[0]
+        text, off = b.process_chunk(_fastq_text(rd, c * per), emf=emf, ert=ert, n_processed=c * per)
+        assert len(text) == sizes[c] and hashlib.sha1(text).hexdigest() == digests[c], c
+        if c in kept:
+            assert text == sample_text[c]
+            kept[c] = (rd, off)
+    b.close()
+    # ---- chunks 0 and 9 against the oracle on a sample
+    kt, mt = ert.fetch(pad=16)
+    e = loader.OracleERT.from_tables(kt, mt, host.ref_0123)
+    loc_t, seed_t = emf.fetch_table()
+    oe = loader.OracleEMF(emf_mod.EmfTable(150, l_pac, loc_t, seed_t), host.ref_0123)
+    oo = loader.default_seed_opt()
+    rng = np.random.default_rng(17)
+    for c, (rd, off) in kept.items():
+        text = sample_text[c]
+        pick = np.sort(rng.choice(per, size=400 if full else 250, replace=False))
+        res, unres = [], []
+        for r in pick:
+            code, fl, lo = oe.probe(rd[r])
+            (res if code in (3, 4) else unres).append((int(r), fl, lo))
+        assert len(res) > 60 and len(unres) > 60
+        for r, fl, lo in res:
+            regs, _ = oe.perfect2reg(rd[r], fl, lo, l_pac, contigs=contigs)
+            want = loader.perfect2sam(regs, rd[r], l_pac, 150, b"r%08d" % (c * per + r), qual=b"I" * RL, contigs=contigs,
+                                      contig_names=cn)
+            assert text[off[r]:off[r + 1]] == want, (c, r)
+        sub = np.array([r for r, _, _ in unres])
+        sub_enc, sub_cum = simulate.flatten_reads(rd[sub])
+        mems, mem_off, hits, hit_off, flags = e.walk(sub_enc, sub_cum, oo)
+        assert flags == 0
+        ch, sd, choff = loader.chain_new_ert(mems, mem_off, hits, hit_off, sub_cum, l_pac, contigs=contigs)
+        regs, reg_off, _ = loader.chain2aln(ch, sd, choff, sub_enc, sub_cum, host.ref_0123, l_pac, contigs=contigs)
+        fin, fin_off = loader.regs_finish(regs, reg_off, sub_enc, sub_cum, host.ref_0123, l_pac, contigs=contigs)
+        for k, r in enumerate(sub):
+            a_, e_ = int(fin_off[k]), int(fin_off[k + 1])
+            if e_ > a_:
+                fin[a_:e_] = loader.mark_primary_se(fin[a_:e_], c * per + int(r))[0]
+        want = loader.reg2sam_se(fin, fin_off, sub_enc, sub_cum, host.ref_0123, l_pac, [b"r%08d" % (c * per + int(r)) for r in sub],
+                                 quals=np.full(len(sub_enc), ord("I"), np.uint8), contigs=contigs, contig_names=cn)
+        bad = [int(r) for k, r in enumerate(sub) if text[off[r]:off[r + 1]] != want[k]]
+        # (placements across the strand junction are the one pinned difference of the walk: tests/util.py seeds_equal_but_junction)
+        assert len(bad) == 0, (c, bad[:5])
+    print(f"[stream] {n_chunks} x {per} reads in {secs:.2f} s = {n / secs / 1e6:.2f} Mreads/s incl. host staging and PCIe (depth 3)")
+    emf.close(); ert.close()

@@ -1,0 +1,40 @@
+"""Streaming lab (round 4): chunks through the compiled mem_process_seqs() with 1..3 chunks in flight; host staging and PCIe inside the clock.
+    python tools/stream_lab.py [--chunks 6] [--depth 3] [--index-set fm|full]"""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "bwa-mem-scale_amd")):
+    sys.path.insert(0, p)
+ap = argparse.ArgumentParser()
+ap.add_argument("--genome-mbp", type=float, default=3209.286105)
+ap.add_argument("--reads", type=int, default=1_000_000)
+ap.add_argument("--chunks", type=int, default=6)
+ap.add_argument("--index-set", default="fm")
+args = ap.parse_args()
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+from bwams import capi, simulate, stream
+torch.cuda.set_device(0)
+capi.lib()
+G = int(round(args.genome_mbp * 1e6))
+genome = simulate.make_genome(G, seed=2024)
+contigs = simulate.chromosomes(G) if G >= 2 ** 31 else None
+cb = None if contigs is None else simulate.contig_bounds(contigs)
+ix = capi.Index.build(genome, 0)
+if contigs is not None:
+    ix.set_contigs(contigs)
+ix.set_contig_names([b"chr%d" % (i + 1) for i in range(len(contigs) if contigs is not None else 1)])
+emf = ert = None
+if args.index_set == "full":
+    ert = capi.Ert.build(ix)
+    emf = capi.Emf.build(ix, seed_len=150, slack=1.1)
+reads = simulate.make_reads(genome, args.reads, seed=12345, contig_bounds=cb)[0]
+RL = reads.shape[1]
+opt = capi.mem_opt_init(False)
+for depth, overlap in ((1, False), (2, True), (3, True)):
+    pre = [capi.Seqs(reads, first_id=k * len(reads)) for k in range(args.chunks + 1)]
+    w = capi.Worker([ix], len(reads), len(reads) * RL, emfs=[emf] if emf else None, erts=[ert] if ert else None, depth=depth)
+    stream.run_job(w, opt, lambda k: pre[args.chunks], 1, None)
+    secs, n = stream.run_job(w, opt, lambda k: pre[k], args.chunks, None, overlap=overlap)
+    w.close()
+    print(f"[stream] depth {depth} overlap {overlap}: {n / secs / 1e6:.3f} Mreads/s, {secs / args.chunks * 1e3:.1f} ms per chunk", flush=True)

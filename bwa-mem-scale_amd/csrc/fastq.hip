@@ -239,6 +239,165 @@ __global__ __launch_bounds__(256) void fasta_emit_kernel(const char *__restrict_
     if (__any(n_dash != 0) && n_dash) atomicAdd(dash, n_dash);
 }
 
+// ---- FASTQ records over any number of lines ("wrapped" records) ---------------------------------------------------------------
+// kseq_read's grammar (kseq.h:529-572) admits them: after the header, sequence lines until a line whose first byte is '+' (empty lines
+// skipped), the rest of the '+' line ignored, then quality lines until the quality string is at least as long as the sequence.  A
+// quality line may begin with '@' or '+', so records cannot be told from the line index alone: which lines are headers follows only from
+// reading the records in order.  In parallel: EVERY line that begins with '@' is parsed as if a record began there (a lane each), which
+// gives it a successor — the line where the next record would begin; the real records are the chain of successors from the first line,
+// and record r of the chain is found by binary lifting over the successor table (r's bits select the jumps), a lane per record.
+// Anything the serial reader would handle by scanning bytes for the next '@' or '>' (text between records, a '>' record in FASTQ
+// text) ends the attempt with BWAMS_ERR_UNSUPPORTED; a truncated or overlong quality string is the reader's -2 and ends it too.
+constexpr int kFqMaxLines = 1 << 20;          // a record of more lines than this is not parsed (nor is one the reader would accept)
+constexpr int kFqLevels = 40;                 // successor tables for jumps of 2^0 .. 2^39 records
+struct FqLine {
+    int64_t b, e;                             // [b, e), the '\n' excluded
+};
+__device__ __forceinline__ FqLine fq_line(const int64_t *__restrict__ ends, int64_t n_nl, int64_t n_bytes, int64_t j) {
+    FqLine L;
+    L.b = j ? ends[j - 1] + 1 : 0;
+    L.e = j < n_nl ? ends[j] : n_bytes;
+    return L;
+}
+// the record whose header is line j: first sequence line, the '+' line, first quality line, one past the last quality line, lengths.
+// Returns false when no record the reader accepts starts here.
+struct FqShape {
+    int64_t seq0, plus, qual0, qual1, next;   // line indices; next = the next record's header line, or n_lines at the end of the text
+    int l_seq;
+};
+__device__ bool fq_shape(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_nl, int64_t n_lines,
+                         int64_t j, FqShape &S) {
+    int64_t jj = j + 1;
+    int l = 0, steps = 0;
+    S.seq0 = jj;
+    for (;; ++jj) {
+        if (jj >= n_lines || ++steps > kFqMaxLines) return false;          // no '+' line: a FASTA-like record, or the end of the text
+        const FqLine L = fq_line(ends, n_nl, n_bytes, jj);
+        if (L.e == L.b) continue;                                           // empty lines are skipped
+        const char c0 = text[L.b];
+        if (c0 == '+') break;
+        if (c0 == '>' || c0 == '@') return false;                           // the next header before any '+': a record without qualities
+        l += fasta_line_bytes(text, L.b, L.e, l);
+    }
+    S.plus = jj;
+    S.l_seq = l;
+    S.qual0 = ++jj;
+    int lq = 0;
+    do {                                                                    // at least one line, then until the quality is long enough
+        if (jj >= n_lines || ++steps > kFqMaxLines) return false;           // truncated
+        const FqLine L = fq_line(ends, n_nl, n_bytes, jj);
+        lq += fasta_line_bytes(text, L.b, L.e, lq);                         // the same '\r' rule (ks_getuntil2 appends)
+        ++jj;
+    } while (lq < l);
+    if (lq != l) return false;                                              // kseq_read's -2
+    S.qual1 = jj;
+    for (; jj < n_lines; ++jj) {                                            // the reader now scans for the next '@' or '>'
+        const FqLine L = fq_line(ends, n_nl, n_bytes, jj);
+        if (L.e == L.b || (L.e == L.b + 1 && text[L.b] == '\r')) continue;   // blank lines (of "\r\n" text too) hold neither
+        if (text[L.b] != '@') return false;                                 // text between records, or a '>' record: not this path's input
+        break;
+    }
+    S.next = jj;
+    return true;
+}
+// up0[j] = successor of line j (n_lines: end of the text; n_lines + 1: no record starts at j)
+__global__ __launch_bounds__(256) void fq_succ_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_nl,
+                                                      int64_t n_lines, int64_t *__restrict__ up0) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_lines + 1) return;
+    int64_t nx = n_lines + 1;
+    if (j >= n_lines) nx = j;                                               // the two terminals map to themselves
+    else {
+        const FqLine L = fq_line(ends, n_nl, n_bytes, j);
+        FqShape S;
+        if (L.e > L.b && text[L.b] == '@' && fq_shape(text, n_bytes, ends, n_nl, n_lines, j, S)) nx = S.next;
+    }
+    up0[j] = nx;
+}
+__global__ __launch_bounds__(256) void fq_double_kernel(const int64_t *__restrict__ a, int64_t *__restrict__ b, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) b[j] = a[a[j]];
+}
+// one thread: the first header line, and how many records the chain from it holds (-1: the chain runs into a line where no record starts)
+__global__ void fq_count_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_nl, int64_t n_lines,
+                                const int64_t *__restrict__ up, int levels, int64_t *__restrict__ out) {
+    int64_t j = 0;
+    for (; j < n_lines; ++j) {
+        const FqLine L = fq_line(ends, n_nl, n_bytes, j);
+        if (L.e > L.b && !(L.e == L.b + 1 && text[L.b] == '\r')) break;
+    }
+    out[0] = j;
+    if (j >= n_lines) { out[1] = 0; return; }
+    const int64_t stride = n_lines + 2;
+    int64_t cur = j, n = 0;
+    for (int k = levels - 1; k >= 0; --k) {
+        const int64_t nx = up[(int64_t)k * stride + cur];
+        if (nx < n_lines) { cur = nx; n += (int64_t)1 << k; }
+    }
+    // cur is the last header of the chain: its successor must be the end of the text
+    out[1] = up[cur] == n_lines ? n + 1 : -1;
+}
+// lane per record: its header line by binary lifting, then the record's shape and lengths
+__global__ void fq_wrapped_measure_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_nl, int64_t n_lines,
+                                          const int64_t *__restrict__ up, int levels, int64_t first, int64_t n_rec, Rec *__restrict__ rec,
+                                          int64_t *__restrict__ wide, unsigned long long *bad) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rec) return;
+    if (r == n_rec) { wide[r] = wide[n_rec + 1 + r] = wide[2 * (n_rec + 1) + r] = 0; return; }
+    const int64_t stride = n_lines + 2;
+    int64_t cur = first;
+    for (int k = 0; k < levels; ++k)
+        if ((r >> k) & 1) cur = up[(int64_t)k * stride + cur];
+    Rec R;
+    R.name_at = R.comment_at = R.seq_at = R.qual_at = 0; R.l_name = R.l_comment = R.l_seq = 0; R.pad_ = 0;
+    FqShape S;
+    if (cur >= n_lines || !fq_shape(text, n_bytes, ends, n_nl, n_lines, cur, S)) {
+        atomicAdd(bad, 1ull);
+    } else {
+        const FqLine H = fq_line(ends, n_nl, n_bytes, cur);
+        parse_header(text, H.b, H.e, R);
+        R.seq_at = S.seq0; R.qual_at = S.qual0; R.l_seq = S.l_seq;
+        R.pad_ = (int32_t)(S.plus - S.seq0);                                // sequence lines (empty ones included)
+    }
+    rec[r] = R;
+    wide[r] = R.l_name; wide[n_rec + 1 + r] = R.l_comment; wide[2 * (n_rec + 1) + r] = R.l_seq;
+}
+// wave per record: names and comments as in fastq_emit_kernel; sequence and quality line by line
+__global__ __launch_bounds__(256) void fq_wrapped_emit_kernel(const char *__restrict__ text, int64_t n_bytes, const int64_t *__restrict__ ends, int64_t n_nl,
+                                                              const Rec *__restrict__ rec, int64_t n_rec, const int64_t *__restrict__ offs,
+                                                              char *__restrict__ names, char *__restrict__ comments, uint8_t *__restrict__ enc,
+                                                              char *__restrict__ qual, unsigned long long *dash) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long n_dash = 0;
+    for (int64_t r = wave; r < n_rec; r += n_waves) {
+        const Rec R = rec[r];
+        const int64_t no = offs[r], co = offs[n_rec + 1 + r], so = offs[2 * (n_rec + 1) + r];
+        for (int i = lane; i < R.l_name; i += 64) names[no + i] = text[R.name_at + i];
+        for (int i = lane; i < R.l_comment; i += 64) comments[co + i] = text[R.comment_at + i];
+        int l = 0;
+        for (int64_t j = R.seq_at; j < R.seq_at + R.pad_; ++j) {
+            const FqLine L = fq_line(ends, n_nl, n_bytes, j);
+            const int len = fasta_line_bytes(text, L.b, L.e, l);
+            for (int i = lane; i < len; i += 64) {
+                const unsigned char c = (unsigned char)text[L.b + i];
+                const unsigned char v = c < 4 ? c : kNt4[c];
+                n_dash += v > 4;
+                enc[so + l + i] = v;
+            }
+            l += len;
+        }
+        int lq = 0;
+        for (int64_t j = R.qual_at; lq < R.l_seq; ++j) {
+            const FqLine L = fq_line(ends, n_nl, n_bytes, j);
+            const int len = fasta_line_bytes(text, L.b, L.e, lq);
+            for (int i = lane; i < len; i += 64) qual[so + lq + i] = text[L.b + i];
+            lq += len;
+        }
+    }
+    if (__any(n_dash != 0) && n_dash) atomicAdd(dash, n_dash);
+}
+
 }  // namespace
 }  // namespace bwams
 
@@ -458,21 +617,61 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
             return BWAMS_ERR_UNSUPPORTED;
         }
     } else {
-        if (n_lines % 4) {
-            set_last_error("bwams_fastq_decode: the text is not a whole number of four-line records (multi-line FASTQ input: read it on the host)");
-            return BWAMS_ERR_UNSUPPORTED;
-        }
         n = n_lines / 4;
     }
-    const int64_t n1 = n + 1;
+    bool wrapped = !fasta && (n_lines % 4) != 0;        // not a whole number of four-line records: records over several lines, or nothing we take
+    int64_t n1 = n + 1;
     // (2) measure + validate
     Rec *d_rec = nullptr;
     int64_t *d_wide = nullptr, *d_offs = nullptr;
-    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_rec), (size_t)n1 * sizeof(Rec))); scr.p.push_back(d_rec);
-    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_wide), (size_t)n1 * 3 * 8)); scr.p.push_back(d_wide);
-    BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_offs), (size_t)n1 * 3 * 8)); scr.p.push_back(d_offs);
-    if (fasta) fasta_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_hdr, n, d_rec, d_wide);
-    else fastq_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n, d_rec, d_wide, d_bad);
+    auto alloc_records = [&]() -> hipError_t {
+        hipError_t e_ = dev_malloc(reinterpret_cast<void **>(&d_rec), (size_t)n1 * sizeof(Rec)); scr.p.push_back(d_rec);
+        if (e_ == hipSuccess) { e_ = dev_malloc(reinterpret_cast<void **>(&d_wide), (size_t)n1 * 3 * 8); scr.p.push_back(d_wide); }
+        if (e_ == hipSuccess) { e_ = dev_malloc(reinterpret_cast<void **>(&d_offs), (size_t)n1 * 3 * 8); scr.p.push_back(d_offs); }
+        return e_;
+    };
+    if (!wrapped) {
+        BWAMS_HIP(alloc_records());
+        if (fasta) fasta_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_hdr, n, d_rec, d_wide);
+        else {
+            fastq_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n, d_rec, d_wide, d_bad);
+            unsigned long long bad4 = 0;
+            BWAMS_HIP(hipMemcpyAsync(&bad4, d_bad, 8, hipMemcpyDeviceToHost, st));
+            BWAMS_HIP(hipStreamSynchronize(st));
+            if (bad4) {                                 // some record is not on four lines: the general shape
+                wrapped = true;
+                BWAMS_HIP(hipMemsetAsync(d_bad, 0, 16, st));
+            }
+        }
+    }
+    if (wrapped) {
+        // records over any number of lines (kseq_read's grammar): every '@' line parsed as if a record began there -> successor table ->
+        // binary lifting from the first line
+        int levels = 1;
+        while (((int64_t)1 << levels) <= n_lines) ++levels;
+        if (levels > kFqLevels) levels = kFqLevels;
+        const int64_t stride = n_lines + 2;
+        int64_t *d_up = nullptr, *d_fc = nullptr;
+        BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_up), (size_t)levels * (size_t)stride * 8)); scr.p.push_back(d_up);
+        BWAMS_HIP(dev_malloc(reinterpret_cast<void **>(&d_fc), 64)); scr.p.push_back(d_fc);
+        const unsigned gb = (unsigned)((stride + 255) / 256);
+        fq_succ_kernel<<<gb, 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_up);
+        for (int k = 1; k < levels; ++k) fq_double_kernel<<<gb, 256, 0, st>>>(d_up + (int64_t)(k - 1) * stride, d_up + (int64_t)k * stride, stride);
+        fq_count_kernel<<<1, 1, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_up, levels, d_fc);
+        int64_t fc[2] = {0, 0};
+        BWAMS_HIP(hipMemcpyAsync(fc, d_fc, 16, hipMemcpyDeviceToHost, st));
+        BWAMS_HIP(hipStreamSynchronize(st));
+        if (fc[1] < 0) {
+            set_last_error("bwams_fastq_decode: FASTQ text the device path does not take: text before the first '@' header or between records, a record "
+                           "without a '+' line, or a quality string of another length than its sequence (read this input on the host)");
+            return BWAMS_ERR_UNSUPPORTED;
+        }
+        n = fc[1];
+        n1 = n + 1;
+        if (d_rec) { d_rec = nullptr; d_wide = nullptr; d_offs = nullptr; }      // (the four-line attempt's arrays stay in scr until the end)
+        BWAMS_HIP(alloc_records());
+        fq_wrapped_measure_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, n_lines, d_up, levels, fc[0], n, d_rec, d_wide, d_bad);
+    }
     for (int row = 0; row < 3; ++row) {
         size_t tb = 0;
         BWAMS_HIP(rocprim::exclusive_scan(nullptr, tb, d_wide + row * n1, d_offs + row * n1, (int64_t)0, (size_t)n1, rocprim::plus<int64_t>(), st));
@@ -488,7 +687,7 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
     BWAMS_HIP(hipMemcpyAsync(bad, d_bad, 8, hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     if (bad[0]) {
-        set_last_error("bwams_fastq_decode: " + std::to_string(bad[0]) + " record(s) are not '@' / sequence / '+' / quality of equal length on four lines (read this input on the host)");
+        set_last_error("bwams_fastq_decode: " + std::to_string(bad[0]) + " record(s) are not '@' / sequence / '+' / quality of equal length (read this input on the host)");
         return BWAMS_ERR_UNSUPPORTED;
     }
     f->has_qual = !fasta;
@@ -504,6 +703,10 @@ int bwams_fastq_decode(int device, const char *text, int64_t n_bytes, bwams_fast
         if (fasta)
             fasta_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, d_rec, n, d_offs, reinterpret_cast<char *>(f->d_names),
                                                                 reinterpret_cast<char *>(f->d_comments), reinterpret_cast<uint8_t *>(f->d_enc), d_bad + 1);
+        else if (wrapped)
+            fq_wrapped_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(d_text, n_bytes, d_ends, n_nl, d_rec, n, d_offs, reinterpret_cast<char *>(f->d_names),
+                                                                     reinterpret_cast<char *>(f->d_comments), reinterpret_cast<uint8_t *>(f->d_enc),
+                                                                     reinterpret_cast<char *>(f->d_qual), d_bad + 1);
         else
             fastq_emit_kernel<<<(unsigned)blocks, 256, 0, st>>>(d_text, d_rec, n, d_offs, reinterpret_cast<char *>(f->d_names),
                                                                 reinterpret_cast<char *>(f->d_comments), reinterpret_cast<uint8_t *>(f->d_enc),

@@ -38,17 +38,76 @@ def test_decode_corners_and_refusals():
     assert g["names"] == [b"x", b"/1"] and g["comments"] == [b"c  d", None] and list(g["enc"]) == [0, 1, 2, 3, 4] and list(g["cum"]) == [0, 5, 5]
     _same(g, loader.fastq_parse(b"@x/9 c  d\nacgtn\n+x\n!!!!!\n@/1\n\n+\n\n"))
     f.close()
-    for bad in (b"@a\nACGT\nAC\n+\nIIIIII\n",                      # multi-line record
+    for bad in (b"@a\nACGT\nAC\n+\nIIIII\n",                       # multi-line record, quality one short
+                b"@a\nACGT\n@b\nACGT\n+\nIIII\n",                   # a record without a '+' line among FASTQ records
+                b"@a\nACGT\n+\nIIII\nstray\n@b\nAC\n+\nII\n",       # text between records (the serial reader scans it for '@')
                 b">fa\nACGT\n@fq\nACGT\n+\nIIII\n",                 # FASTA and FASTQ records mixed
                 b">fa\nACGT\n+\nIIII\n",                            # '>' header with a quality part
                 b">fa\nAC-T\n",
                 b"@a\nACGT\n+\nIII\n",                             # quality shorter than the sequence
                 b"@a\nACGT\n+\nIIIII\n",                           # ... longer
-                b"@a\nACGT\n+\nIIII\n\n",                          # a blank line
                 b"junk\n@a\nACGT\n+\nIIII\n",                      # text before the first header
                 b"@a\nAC-T\n+\nIIII\n"):                           # '-' (nst_nt4_table: 5)
         with pytest.raises(capi.BwamsError):
             capi.Fastq(bad)
+
+
+def _wrapped_fastq(n, seed, crlf=False):
+    """FASTQ records as kseq_read admits them beyond the four-line shape: sequence and quality over several lines (of different widths),
+    blank lines inside the sequence and between records, quality lines that BEGIN with '@' or '+' (so that a line index alone cannot
+    tell records apart), comments, "/1" names, an empty record, '+name' repeated on the plus line."""
+    rng = np.random.default_rng(seed)
+    nl = b"\r\n" if crlf else b"\n"
+    parts = []
+    for i in range(n):
+        ln = int(rng.integers(1, 320)) if (i % 19 != 7 or crlf) else 0      # (an empty record in CRLF text is the reader's -2: its quality is '\\r')
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTacgtNn", np.uint8), size=ln))
+        qual = bytearray(rng.integers(33, 74, size=ln, dtype=np.uint8).tobytes())
+        ws = int(rng.integers(1, 100)) if i % 3 else 1000
+        wq = int(rng.integers(1, 100)) if i % 4 else 1000
+        for k in range(0, ln, wq):                                   # quality lines starting with '@' / '+' (and a header-looking one)
+            if rng.random() < 0.3:
+                qual[k] = ord("@") if rng.random() < 0.6 else ord("+")
+        hdr = b"@wr%d" % i + (b"/1" if i % 3 == 0 else b"") + (b" c=%d  y" % ln if i % 4 == 0 else b"")
+        sl = [seq[k:k + ws] for k in range(0, ln, ws)]
+        if i % 7 == 0 and sl:
+            sl.insert(int(rng.integers(1 if crlf else 0, len(sl) + 1)), b"")   # a blank line before / inside / after the sequence lines
+            #                                                          (a "\\r\\n" line in FRONT of the sequence is a base to the reader: its '\\r' stays)
+        ql = [bytes(qual[k:k + wq]) for k in range(0, ln, wq)] or [b""]
+        parts.append(hdr + nl + b"".join(x + nl for x in sl) + (b"+wr%d" % i if i % 5 == 0 else b"+") + nl + b"".join(x + nl for x in ql) +
+                     (nl if i % 11 == 0 else b""))                   # a blank line between records
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("seed,crlf,n", [(1, False, 3000), (2, True, 800), (3, False, 1), (4, False, 64)])
+def test_wrapped_fastq_records_equal_oracle(seed, crlf, n):
+    """Records over any number of lines are DECODED on the device (round 3 refused them): every '@' line parsed as if a record began
+    there, the real records found as the chain of successors from the first line (fastq.hip)."""
+    text = _wrapped_fastq(n, seed, crlf)
+    for t in (text, text.rstrip(b"\r\n")):
+        want = loader.fastq_parse(t)
+        assert want["status"] == 0 and want["n"] == n
+        f = capi.Fastq(t)
+        got = f.fetch()
+        assert got["n"] == n and got["names"] == want["names"] and got["comments"] == want["comments"]
+        assert np.array_equal(got["cum"], want["cum"]) and np.array_equal(got["enc"], want["enc"])
+        hq = np.repeat(want["has_qual"].astype(bool), np.diff(want["cum"]))
+        assert np.array_equal(got["quals"][hq], want["quals"][hq])
+        f.close()
+    # four lines per record but one record wrapped so that the line count stays a multiple of four
+    t = b"@a\nAC\nGT\n+\nIIII\n@b\nA\n+\nI\n"
+    f = capi.Fastq(t + b"@c\nACG\n+\n@II\n" * 0)
+    want = loader.fastq_parse(t)
+    got = f.fetch()
+    assert got["names"] == want["names"] == [b"a", b"b"] and np.array_equal(got["enc"], want["enc"]) and np.array_equal(got["quals"], want["quals"])
+    f.close()
+    # a blank line behind the last record, blank lines in front of the first
+    for t in (b"@a\nACGT\n+\nIIII\n\n", b"\n\n@a\nACGT\n+\nIIII\n"):
+        f = capi.Fastq(t)
+        want = loader.fastq_parse(t)
+        got = f.fetch()
+        assert got["n"] == want["n"] == 1 and np.array_equal(got["enc"], want["enc"]) and np.array_equal(got["quals"], want["quals"])
+        f.close()
 
 
 def _fasta_text(n, seed, crlf=False, width=60):
@@ -258,7 +317,7 @@ def test_process_chunk_is_the_stage_sequence():
         b.process_chunk(ptext[: ptext.index(b"@pp1/2")], paired=True)      # an odd number of reads
     assert b.process_chunk(b"", fetch=False) == 0                          # an empty chunk
     with pytest.raises(capi.BwamsError):
-        b.process_chunk(b"@fq\nACGT\nAC\n+\nIIIIII\n")                     # multi-line FASTQ: refused, the caller reads it on the host
+        b.process_chunk(b"@fq\nACGT\nAC\n+\nIIIII\n")                      # a quality string one short (kseq_read's -2): refused
     # FASTA reads (sequence lines of 70 bases): the same chain without qualities
     fa = b"".join(b">%s some text\n" % names[i] + b"".join(bytes(b"ACGTN"[x] for x in reads[i][k:k + 70]) + b"\n" for k in range(0, len(reads[i]), 70))
                   for i in range(len(reads)))

@@ -40,6 +40,8 @@ SYMBOLS = [
     "bwams_index_set_contigs", "bwams_chain_run", "bwams_chain_fetch", "bwams_chain_upload",
     "bwams_extend_build", "bwams_extend_run", "bwams_extend_fetch", "bwams_extend_tasks_fetch",
     "bwams_process_reads", "bwams_process_reads_stage1", "bwams_process_reads_stage2", "bwams_host_alloc", "bwams_host_free",
+    "bwams_reader_open", "bwams_reader_next", "bwams_reader_release", "bwams_reader_error", "bwams_reader_close",
+    "bwams_writer_open", "bwams_writer_put", "bwams_writer_close",
     "bwams_process_reads_upload", "bwams_process_reads_stage1_run", "bwams_batch_device", "bwams_multi_upload", "bwams_multi_compute",
     "bwams_shard_bounds", "bwams_multi_create", "bwams_multi_process_reads", "bwams_multi_fetch", "bwams_multi_error", "bwams_multi_destroy",
     "bwams_dedup_run", "bwams_dedup_fetch", "bwams_chain_run_ert", "bwams_pestat", "bwams_pestat_keys", "bwams_pestat_from_keys", "bwams_pair_run", "bwams_pair_run_sam", "bwams_pair_fetch", "bwams_emf_regs_run", "bwams_emf_regs_fetch",

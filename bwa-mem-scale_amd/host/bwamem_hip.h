@@ -126,5 +126,10 @@ void bwams_worker_set_deferred_collect(bwams_worker *w, int on);
 // step 1 with an error code instead of the reference's exit(EXIT_FAILURE)
 int bwams_worker_process(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0, bwams_worker &w);
 
+// Step 0 of the pipeline for a caller that reads with bwams_reader (include/bwams.h; host/fastq_io.cpp): bseq_read_orig's records
+// (src/bwa.cpp:266-335) from a chunk's text IN PLACE — the strings of seqs[i] point into `text`, which is cut up with NULs; wrapped
+// records are joined.  copy_comment = 0 drops the comments as process() does without `mem -C`.  Returns the number of records.
+int64_t bwams_bseq_parse(char *text, int64_t n_bytes, int64_t n_reads, bseq1_t *seqs, int copy_comment);
+
 // the option mapping on its own (tests compare it with the library's defaults)
 void bwams_map_options(const mem_opt_t *opt, const char *rg_id, bwams_seed_opt_t *so, bwams_mem_opt_t *mo, bwams_sam_opt_t *sam_opt);

@@ -589,6 +589,24 @@ int bwams_multi_compute(bwams_multi_t *m, const bwams_seed_opt_t *so, const bwam
                         const bwams_pestat_t *pes0, int64_t n_processed, int32_t flags, int64_t *sam_bytes);
 const char *bwams_multi_error(const bwams_multi_t *m);       /* which shard failed, and why */
 int bwams_multi_destroy(bwams_multi_t *m);
+/* The file ends of the pipeline (host/fastq_io.cpp).  bwams_reader: a background thread inflates a gz or plain FASTQ / FASTA file (zlib,
+ * as the reference's kseq over gzFile) into n_buffers page-locked chunk buffers and cuts chunks where bseq_read_orig cuts them
+ * (src/bwa.cpp:266-335): records until the chunk holds chunk_bases bases and, paired, an even number of reads — chunk i holds exactly
+ * the reads of the reference's chunk i with the same -K.  _next returns 0 and the chunk (text of whole records; feed it to
+ * bwams_process_chunk, or to bwams_bseq_parse + mem_process_seqs), 1 at the end of the file, < 0 on an error (_error says what);
+ * the buffer is the caller's until _release.  buffer_bytes 0: 3 bytes per base + 64 MiB.
+ * bwams_writer: n_shards output streams ("<path>.<s>.sam"; one stream = `path` itself), each written by its own thread in
+ * sequence-number order — the per-GPU output shards behind a sharded job, or the one SAM stream of step 2 (src/fastmap.cpp:437-461). */
+typedef struct bwams_reader bwams_reader_t;
+typedef struct bwams_writer bwams_writer_t;
+int bwams_reader_open(const char *path, int64_t chunk_bases, int32_t paired, int64_t buffer_bytes, int32_t n_buffers, bwams_reader_t **out);
+int bwams_reader_next(bwams_reader_t *r, const char **text, int64_t *n_bytes, int64_t *n_reads, int64_t *n_bases);
+int bwams_reader_release(bwams_reader_t *r, const char *text);
+const char *bwams_reader_error(const bwams_reader_t *r);
+int bwams_reader_close(bwams_reader_t *r);
+int bwams_writer_open(const char *path, int32_t n_shards, bwams_writer_t **out);
+int bwams_writer_put(bwams_writer_t *w, int32_t shard, int64_t seq, const char *text, int64_t n_bytes);
+int bwams_writer_close(bwams_writer_t *w);       /* waits until everything handed over in order is on disk */
 /* Page-locked host memory (hipHostMalloc) for the buffers that cross PCIe every chunk: reads, names and qualities up, SAM text down. */
 int bwams_host_alloc(size_t bytes, void **out);
 int bwams_host_free(void *p);

@@ -23,7 +23,7 @@ SEQPAIR_DTYPE = np.dtype([(n, "<i4") for n in
 
 # every symbol include/bwams.h declares
 SYMBOLS = [
-    "bwams_strerror", "bwams_last_error", "bwams_device_count",
+    "bwams_strerror", "bwams_last_error", "bwams_device_count", "bwams_debug_reload",
     "bwams_index_open", "bwams_index_from_host", "bwams_index_from_device", "bwams_index_close",
     "bwams_index_bytes", "bwams_index_build", "bwams_index_fetch", "bwams_index_save", "bwams_reg2aln_run", "bwams_reg2aln_run_sam", "bwams_reg2aln_fetch",
     "bwams_index_set_contig_names", "bwams_index_set_contig_annos", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
@@ -1030,6 +1030,11 @@ def _flat_records(enc, cum, names, name_off, quals, comments, comment_off):
     c = np.ascontiguousarray(comments, np.uint8) if comments is not None else None
     co = np.ascontiguousarray(comment_off, np.int64) if comment_off is not None else None
     return _Kept((_p(enc), _p(cum), C.c_int64(len(cum) - 1), _p(names), _p(name_off), _p(q), _p(c), _p(co)), (enc, cum, names, name_off, q, c, co))
+
+
+def debug_reload():
+    """re-read the library's debugging aids / A-B switches from the environment (they are parsed once otherwise)"""
+    lib().bwams_debug_reload()
 
 
 def shard_bounds(n_reads: int, n_shards: int, paired: bool = False) -> np.ndarray:

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,34 @@
 #include "ert_kernels.h"
 
 namespace bwams {
+
+static Knobs g_knobs;
+static std::once_flag g_knobs_once;
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+void knobs_reload() {
+    Knobs k;
+    { const char *vb = getenv("BWAMS_VERBOSE"); k.verbose = vb && *vb && *vb != '0'; }
+    k.debug = env_int("BWAMS_DEBUG", 0);
+    k.poison = env_int("BWAMS_POISON", 0);
+    k.bwd_min_list = env_int("BWAMS_BWD_MIN_LIST", k.bwd_min_list); k.bwd_cols = env_int("BWAMS_BWD_COLS", k.bwd_cols);
+    k.bwd_late_list = env_int("BWAMS_BWD_LATE_LIST", k.bwd_late_list);
+    k.bwd_dry_min_list = env_int("BWAMS_BWD_DRY_MIN_LIST", k.bwd_dry_min_list); k.bwd_dry_cols = env_int("BWAMS_BWD_DRY_COLS", k.bwd_dry_cols);
+    k.bwd_dry_late_list = env_int("BWAMS_BWD_DRY_LATE_LIST", k.bwd_dry_late_list);
+    k.bwd_fused = env_int("BWAMS_BWD_FUSED", 1); k.bwd_cap_mul = std::max(1, env_int("BWAMS_BWD_CAP_MUL", 1));
+    k.r3_beside = env_int("BWAMS_SEED_R3_BESIDE", 1);
+    k.ext_max_rounds = env_int("BWAMS_EXT_MAX_ROUNDS", 0); k.ext_all_rounds = getenv("BWAMS_EXT_ALL_ROUNDS") != nullptr;
+    k.ext_inplace = env_int("BWAMS_EXT_INPLACE", 1);
+    k.dedup_seq = env_int("BWAMS_DEDUP_SEQ", 0) == 1;
+    k.pair_drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") != nullptr;
+    k.trace_pair = env_int("BWAMS_TRACE_PAIR", 0);
+    k.bsw_pk = env_int("BWAMS_BSW_PK", 1);
+    k.ert_ticket = env_int("BWAMS_ERT_TICKET", 1); k.ert_grid = env_int("BWAMS_ERT_GRID", -1);
+    g_knobs = k;
+}
+const Knobs &knobs() {
+    std::call_once(g_knobs_once, knobs_reload);
+    return g_knobs;
+}
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &s) { g_last_error = s; }
@@ -77,6 +106,9 @@ const char *bwams_strerror(int code) {
 }
 
 const char *bwams_last_error(void) { return g_last_error.c_str(); }
+
+// the debugging aids and A-B switches are read from the environment once; tests change a variable and call this
+int bwams_debug_reload(void) { (void)bwams::knobs(); bwams::knobs_reload(); return BWAMS_OK; }
 
 int bwams_device_count(int *n) {
     int c = 0;
@@ -267,8 +299,7 @@ int bwams_index_build(const uint8_t *fw, int64_t l_pac, int fw_on_device, int de
     }
     bwams_index *ix = new bwams_index();
     ix->device = device;
-    const char *vb = getenv("BWAMS_VERBOSE");
-    rc = fmi_build_device(ix, staged ? (const uint8_t *)staged : fw, l_pac, keep_ref, chunk_rows, vb && *vb && *vb != '0', stats);
+    rc = fmi_build_device(ix, staged ? (const uint8_t *)staged : fw, l_pac, keep_ref, chunk_rows, knobs().verbose != 0, stats);
     if (staged) (void)hipFree(staged);
     if (rc) { bwams_index_close(ix); return rc; }
     *out = ix;
@@ -605,7 +636,7 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
     // what uniform and repeat-rich genomes produce several times over; when they are full a pivot simply stays on its lane
     // (two item arrays of bi slots in one allocation: long lists, short lists; once a launch drains every backward phase leaves its
     // lane, about half a pivot per read in flight, profiles/r04_notes.md)
-    static const int64_t cap_mul = getenv("BWAMS_BWD_CAP_MUL") ? atoi(getenv("BWAMS_BWD_CAP_MUL")) : 1;     // lab: room for EVERY backward phase
+    const int64_t cap_mul = knobs().bwd_cap_mul;                // lab: room for EVERY backward phase
     const int64_t bi = std::max<int64_t>(nseq, 4096) * 2 * cap_mul, be = std::max<int64_t>(nseq, 4096) * 24 * cap_mul;
     if (bi > b->bwd_items_cap) {
         if (b->d_bwd_items) (void)hipFree(b->d_bwd_items);
@@ -658,7 +689,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     a.read_w = b->read_w;
     a.read_cw = b->read_cw;
     a.reads_in_lds = b->read_w <= 40;      // 40 words x 256 lanes x 4 B = 40 KB per workgroup
-    { const char *dbg = getenv("BWAMS_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
+    a.debug = knobs().debug;
     a.min_seed_len = opt->min_seed_len;
     a.pool = b->d_pool;
     a.pool_cap = b->pool_cap;
@@ -673,18 +704,14 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     a.bwd_ent_cap = b->bwd_ent_cap;
     {   // hand-over thresholds (fmi_seed.hip, bwd_hand_over; profiles/r03_notes.md 86): 40 entries at the forward end, or 8 still alive
         // after 24 columns; BWAMS_BWD_MIN_LIST=0: every backward phase stays on its lane
-        const char *ml = getenv("BWAMS_BWD_MIN_LIST");       // read per call: the tests lower them so that toy genomes reach the wave kernel
-        const char *mc = getenv("BWAMS_BWD_COLS"), *mt = getenv("BWAMS_BWD_LATE_LIST");
-        a.bwd_min_list = ml ? atoi(ml) : 40;
-        a.bwd_cols = mc ? atoi(mc) : 24;
-        a.bwd_late_list = mt ? atoi(mt) : 8;
-        {
-            const char *d1 = getenv("BWAMS_BWD_DRY_MIN_LIST"), *d2 = getenv("BWAMS_BWD_DRY_COLS"), *d3 = getenv("BWAMS_BWD_DRY_LATE_LIST");
-            // once the work queue has run dry: 24 entries at the forward end, or 12 alive after 8 columns (tools/exp_bwd_dry.sh)
-            a.bwd_dry_min_list = d1 ? atoi(d1) : 24;
-            a.bwd_dry_cols = d2 ? atoi(d2) : 8;
-            a.bwd_dry_late_list = d3 ? atoi(d3) : 12;
-        }
+        const Knobs &kn = knobs();                           // the tests lower them so that toy genomes reach the kernels behind the search
+        a.bwd_min_list = kn.bwd_min_list;
+        a.bwd_cols = kn.bwd_cols;
+        a.bwd_late_list = kn.bwd_late_list;
+        // once the work queue has run dry: 24 entries at the forward end, or 12 alive after 8 columns (tools/exp_bwd_dry.sh)
+        a.bwd_dry_min_list = kn.bwd_dry_min_list;
+        a.bwd_dry_cols = kn.bwd_dry_cols;
+        a.bwd_dry_late_list = kn.bwd_dry_late_list;
     }
     const int split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
 
@@ -709,7 +736,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     // SMEMs are counted apart (n_ext3 / n_blk3 / n_smem3), so that the per-round figures stay exact.
     SeedLaunch a3 = a;
     a3.min_seed_len = opt->min_seed_len + 1;
-    static const bool r3_beside = !(getenv("BWAMS_SEED_R3_BESIDE") && atoi(getenv("BWAMS_SEED_R3_BESIDE")) == 0);
+    const bool r3_beside = knobs().r3_beside != 0;
     const bool r3 = b->nseq > 0 && opt->max_mem_intv > 0;
     hipStream_t st3 = r3_beside ? b->seed_aux : st;
     if (r3 && r3_beside) {
@@ -738,7 +765,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
 #ifdef BWAMS_BWDDBG
-    if (getenv("BWAMS_VERBOSE")) {
+    if (knobs().verbose) {
         const unsigned long long *d = b->h_ctr->dbg;
         { float m1 = 0, m2 = 0; (void)hipEventElapsedTime(&m1, b->ev[8], dbg_ev); (void)hipEventElapsedTime(&m2, dbg_ev, b->ev[9]);
           fprintf(stderr, "[smem_r1] search kernel %.3f ms, the two backward kernels behind it %.3f ms\n", m1, m2); }
@@ -1033,9 +1060,8 @@ int bwams_ert_build(bwams_index_t *ix, int32_t kmer_size, int32_t xmer_size, int
     BWAMS_HIP(hipGetDeviceProperties(&prop, ix->device));
     bwams_ert *e = new bwams_ert();
     e->idx = ix;
-    const char *vb = getenv("BWAMS_VERBOSE");
     const int rc = ert_build_device(e, ix->fmi, kmer_size, xmer_size, read_len, hit_threshold, prop.multiProcessorCount,
-                                    vb && atoi(vb) > 0);
+                                    knobs().verbose != 0);
     if (rc) { bwams_ert_close(e); return rc; }
     *out = e;
     return BWAMS_OK;
@@ -1458,9 +1484,8 @@ int bwams_emf_build(bwams_index_t *ix, int32_t seed_len, double slack, bwams_emf
     }
     bwams_emf *e = new bwams_emf();
     e->idx = ix;
-    const char *vb = getenv("BWAMS_VERBOSE");
     int64_t st[4] = {0, 0, 0, 0};
-    const int rc = emf_build_device(e, (const uint8_t *)ix->d_ref, l_pac, seed_len, slack, prop.multiProcessorCount, vb && atoi(vb) > 0, st);
+    const int rc = emf_build_device(e, (const uint8_t *)ix->d_ref, l_pac, seed_len, slack, prop.multiProcessorCount, knobs().verbose != 0, st);
     if (rc) { bwams_emf_close(e); return rc; }
     e->n_used = st[0]; e->n_key = st[1]; e->n_other = st[2]; e->build_ms = st[3];
     *out = e;

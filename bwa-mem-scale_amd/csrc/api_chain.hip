@@ -436,8 +436,8 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
     BWAMS_HIP(hipMemcpyAsync(b->h_ctr, b->d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
     BWAMS_HIP(hipStreamSynchronize(st));
     {
-        static const char *vb = getenv("BWAMS_VERBOSE");
-        if (vb && *vb && *vb != '0') {
+        const bool vb = knobs().verbose != 0;
+        if (vb) {
             const unsigned long long *d = b->h_ctr->dbg;
             fprintf(stderr, "[bwams_chain_run] filter wave tier: reads by chains <=32 %llu <=64 %llu <=128 %llu <=256 %llu <=512 %llu <=960 %llu more %llu; "
                             "Mcycles: sequential(HBM) %.1f sort %.1f filter %.1f; chains %llu selected %llu; longest read: sort %.2f filter %.2f Mcycles, most chains %llu, most selected %llu\n",
@@ -695,9 +695,9 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
     int rc = check_opt(opt, "bwams_extend_run");
     if (rc) return rc;
     int kMaxRounds = 6;
-    if (const char *e = getenv("BWAMS_EXT_MAX_ROUNDS")) kMaxRounds = atoi(e) > 0 ? atoi(e) : 1;    // test knob: force the extend-the-rest fallback
-    const bool adaptive_off = getenv("BWAMS_EXT_ALL_ROUNDS") != nullptr;                             // test knob: never cut the rounds short
-    const bool inplace_on = !(getenv("BWAMS_EXT_INPLACE") && atoi(getenv("BWAMS_EXT_INPLACE")) == 0);   // A-B knob: 0 = copy the tasks' bytes into flat buffers
+    if (knobs().ext_max_rounds > 0) kMaxRounds = knobs().ext_max_rounds;      // test knob: force the extend-the-rest fallback
+    const bool adaptive_off = knobs().ext_all_rounds != 0;                    // test knob: never cut the rounds short
+    const bool inplace_on = knobs().ext_inplace != 0;                          // A-B knob: 0 = copy the tasks' bytes into flat buffers
     ChainState *s = b->chain;
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;
@@ -723,8 +723,8 @@ int bwams_extend_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_re
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_req, 0, sizeof(unsigned long long), st));
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->sel_ticket, 0, 3 * sizeof(unsigned long long), st));
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->n_rest, 0, sizeof(unsigned long long), st));
-        static const char *vb_sel = getenv("BWAMS_VERBOSE");
-        const bool verbose_sel = vb_sel && *vb_sel && *vb_sel != '0';
+        const bool vb_sel = knobs().verbose != 0;
+        const bool verbose_sel = vb_sel;
         if (verbose_sel) BWAMS_HIP(hipMemsetAsync(b->d_ctr->dbg, 0, sizeof b->d_ctr->dbg, st));
         if (s->n_seeds && launch_ext_select(A, b->cu_count, st, s->aux, s->fork, s->join)) {
             set_last_error("bwams_extend_run: stream fork/join failed");
@@ -816,13 +816,13 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     D.ord = s->dd_ord.as<int32_t>(); D.srt = s->dd_srt.p; D.eh = s->dd_eh.as<int2>(); D.eh_lanes = n_lanes;
     D.max_read_len = (int32_t)L; D.n_out = s->dd_nout.as<int32_t>();
     BWAMS_HIP(s->heavy.ensure((size_t)n1 * 4));
-    { const char *e = getenv("BWAMS_DEDUP_SEQ"); D.force_seq = (e && atoi(e) == 1) ? 1 : 0; }      // 1: every read through the one-lane form (tests)
+    D.force_seq = knobs().dedup_seq;      // 1: every read through the one-lane form (tests)
     BWAMS_HIP(s->dd_light.ensure((size_t)n1 * 4));
     D.heavy = s->heavy.as<int32_t>(); D.light = s->dd_light.as<int32_t>();
     D.n_heavy_ctr = &b->d_ctr->dedup_heavy; D.ticket = &b->d_ctr->dedup_ticket; D.n_light_ctr = &b->d_ctr->dedup_light;
     D.ticket2 = &b->d_ctr->dedup_ticket2; D.ticket3 = &b->d_ctr->dedup_ticket3;
-    static const char *vb_dd = getenv("BWAMS_VERBOSE");
-    const bool verbose_dd = vb_dd && *vb_dd && *vb_dd != '0';
+    const bool vb_dd = knobs().verbose != 0;
+    const bool verbose_dd = vb_dd;
     D.dbg = verbose_dd ? b->d_ctr->dbg : nullptr;
     if (verbose_dd) BWAMS_HIP(hipMemsetAsync(b->d_ctr->dbg, 0, sizeof b->d_ctr->dbg, st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->dedup_heavy, 0, 3 * sizeof(unsigned long long), st));
@@ -939,7 +939,7 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
     A.opt = *opt;
     for (int k = 0; k < 4; ++k) A.pes[k] = pes[k];
     A.id_base = id_base; A.no_rescue = no_rescue ? 1 : 0; A.pass = 0;
-    A.drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") ? 1 : 0;                 // test knob: exercise the second pass
+    A.drop_plan = knobs().pair_drop_plan;                 // test knob: exercise the second pass
     A.use_ert = use_ert ? 1 : 0;
     A.single_end = single_end;
     A.no_pairing = no_pairing; A.primary5_T = primary5_T;
@@ -973,7 +973,7 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
     A.anchor = s->pr_anchor.as<int32_t>(); A.slot_read = s->pr_slot.as<int32_t>();
     A.task = s->pr_task.as<int32_t>(); A.trb = s->pr_trb.as<int64_t>(); A.tl1 = s->pr_tl1.as<int32_t>();
     A.pool = s->pr_pool.as<bwams_alnreg_t>(); A.ord = s->pr_ord.as<int32_t>(); A.zbuf = s->pr_z.as<int32_t>(); A.srt = s->pr_srt.p;
-    static const int pr_trace = getenv("BWAMS_TRACE_PAIR") ? atoi(getenv("BWAMS_TRACE_PAIR")) : 0;     // debugging aid: a synchronisation and a line per launch
+    const int pr_trace = knobs().trace_pair;     // debugging aid: a synchronisation and a line per launch
 #define PR_TRACE(msg) do { if (pr_trace) { BWAMS_HIP(hipStreamSynchronize(st)); fprintf(stderr, "[bwams_pair_run] %s\n", msg); } } while (0)
     PR_TRACE("count / cap done");
     launch_pair_slots(A, st);
@@ -1012,7 +1012,7 @@ static int pair_run_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, const bwa
         BWAMS_HIP(hipMemsetAsync(&b->d_ctr->pair_heavy, 0, 2 * sizeof(unsigned long long), st));
         launch_pair_post(A, b->cu_count, st);
 #ifdef BWAMS_PAIRDBG
-        if (getenv("BWAMS_VERBOSE")) {
+        if (knobs().verbose) {
             unsigned long long d[80];
             BWAMS_HIP(hipStreamSynchronize(st));
             BWAMS_HIP(hipMemcpy(d, b->d_ctr->dbg, sizeof d, hipMemcpyDeviceToHost));
@@ -1166,7 +1166,7 @@ static int reg2aln_impl(bwams_batch_t *b, const bwams_mem_opt_t *opt, int32_t so
         BWAMS_HIP(hipStreamSynchronize(st));
         BWAMS_HIP(hipGetLastError());
 #ifdef BWAMS_ALNDBG
-        if (getenv("BWAMS_VERBOSE")) {
+        if (knobs().verbose) {
             unsigned long long c[32];
             BWAMS_HIP(hipMemcpy(c, s->al_cnt.p, 256, hipMemcpyDeviceToHost));
             fprintf(stderr, "[reg2aln] regions %lld: class lists %llu / %llu / %llu / %llu; wave kernel: %llu regions, per region setup %.1f us, DP %.1f us (%.2f DPs, mean band %.1f, %.0f rows), "

@@ -976,7 +976,7 @@ int launch_bsw(bwams_seqpair_t *pairs, int64_t n, const uint8_t *ref, const uint
     // every class on a stream of its own, the classes of the longest queries first.  (With two classes per stream and the
     // one-task-per-wave kernel — usually without a single task, but 2048 blocks that wait for a free CU slot — in front of one
     // of them, the kernel trace showed two class launches starting 14 ms late.)
-    static const bool pk_env = !(getenv("BWAMS_BSW_PK") && atoi(getenv("BWAMS_BSW_PK")) == 0);       // A-B knob: the 32-bit eight-task kernel
+    const bool pk_env = knobs().bsw_pk != 0;       // A-B knob: the 32-bit eight-task kernel
     if (pk_env && bsw_pk_eligible(prm)) {
         auto pk_lds = [](int cols) { return (size_t)64 + (size_t)kPkWaves * 16 * ((size_t)(cols / 2) * 10 + 24); };
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(bsw_pk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds(192)) != hipSuccess) return -1;

@@ -43,18 +43,18 @@ constexpr int KB_T = 5;
 constexpr int KB_MAXK = 2 * KB_T - 1;
 constexpr int kLaneSeeds = 32;       // reads with more seeds than this are chained by a whole wave (chain_wave_kernel)
 constexpr int kLightChains = 16;     // reads with more chains than this go to chain_heavy_kernel
-struct alignas(16) Node {            // 144 B = nine 16-byte loads
+struct alignas(16) Node {            // 160 B = ten 16-byte loads
     int16_t n, internal;
-    int16_t ptr[KB_MAXK + 1];        // node ids relative to the read's node region
+    int32_t ptr[KB_MAXK + 1];        // node ids relative to the read's node region.  32 bits: a read has no cap on its chains in the reference
+    //                                  (kb_putp grows the tree, src/bwamem.cpp:830); 16-bit ids ended a read of > 131 k chains with an error
     int64_t pos[KB_MAXK];            // reference position of each key's chain (the sort key)
     int32_t key[KB_MAXK];            // chain ids (creation order within the read)
-    int32_t pad_[3];
 };
-static_assert(sizeof(Node) == 144, "node layout");
+static_assert(sizeof(Node) == 160, "node layout");
 
 struct alignas(16) ChainRec {        // 48 B, one per chain in creation order
     int64_t last_rbeg, endr;         // last seed's rbeg; running `end` of the reference-side weight
-    int16_t first_qbeg, last_qbeg, last_len, endq;   // query coordinates (reads are shorter than 32768)
+    uint16_t first_qbeg, last_qbeg, last_len, endq;  // query coordinates (reads hold at most 65534 bases: bwams_seed_upload)
     int32_t rid, n;                  // reference sequence, seeds
     int32_t first_idx, last_idx;     // first / last seed (index relative to the read's first SA hit)
     int32_t wq, wr;                  // query-/reference-side weights so far
@@ -141,7 +141,6 @@ struct ReadCtx {
 
 __device__ __forceinline__ int32_t new_node(ReadCtx &c) {
     if (c.n_nodes >= c.cap_nodes) { c.overflow = true; return 0; }
-    if (c.n_nodes >= 32767) { c.overflow = true; return 0; }
     if (c.wr) { Node *x = &c.nodes[c.n_nodes]; x->n = 0; x->internal = 0; }
     return c.n_nodes++;
 }
@@ -220,7 +219,7 @@ __device__ __forceinline__ void kbt_split(ReadCtx &c, int32_t xi, int i, int32_t
     y->n = KB_T - 1;
     const int xn = x->n;
     for (int t = xn; t > i; --t) x->ptr[t + 1] = x->ptr[t];
-    x->ptr[i + 1] = (int16_t)zi;
+    x->ptr[i + 1] = zi;
     for (int t = xn - 1; t >= i; --t) { x->key[t + 1] = x->key[t]; x->pos[t + 1] = x->pos[t]; }
     x->key[i] = y->key[KB_T - 1];
     x->pos[i] = y->pos[KB_T - 1];
@@ -234,7 +233,7 @@ __device__ __forceinline__ void kbt_put(ReadCtx &c, int32_t id, int64_t k) {
     if (c.nodes[xi].n == KB_MAXK) {
         const int32_t s = new_node(c);
         if (c.overflow) return;
-        if (c.wr) { c.nodes[s].internal = 1; c.nodes[s].n = 0; c.nodes[s].ptr[0] = (int16_t)xi; }
+        if (c.wr) { c.nodes[s].internal = 1; c.nodes[s].n = 0; c.nodes[s].ptr[0] = xi; }
         c.root = s;
         kbt_split(c, s, 0, xi);
         if (c.overflow) return;
@@ -723,10 +722,10 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
                             }
                             // mem_chain_weight's two running sums, one seed further
                             if (qbeg >= ch.endq) ch.wq += slen; else if (qbeg + slen > ch.endq) ch.wq += qbeg + slen - ch.endq;
-                            ch.endq = (int16_t)(ch.endq > qbeg + slen ? ch.endq : qbeg + slen);
+                            ch.endq = (uint16_t)((int)ch.endq > qbeg + slen ? (int)ch.endq : qbeg + slen);
                             if (rbeg >= ch.endr) ch.wr += slen; else if (rbeg + slen > ch.endr) ch.wr += (int)(rbeg + slen - ch.endr);
                             ch.endr = ch.endr > rbeg + slen ? ch.endr : rbeg + slen;
-                            ch.last_rbeg = rbeg; ch.last_qbeg = (int16_t)qbeg; ch.last_len = (int16_t)slen; ch.last_idx = g; ch.n += 1;
+                            ch.last_rbeg = rbeg; ch.last_qbeg = (uint16_t)qbeg; ch.last_len = (uint16_t)slen; ch.last_idx = g; ch.n += 1;
                             if (wr) crec[lower] = ch;
                             to_add = false;
                         }
@@ -737,7 +736,7 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
                 if (wr) { s_ql[g] = make_int2(qbeg, slen); s_next[g] = -1; }
                 ChainRec ch;
                 ch.last_rbeg = rbeg; ch.endr = rbeg + slen;
-                ch.first_qbeg = (int16_t)qbeg; ch.last_qbeg = (int16_t)qbeg; ch.last_len = (int16_t)slen; ch.endq = (int16_t)(qbeg + slen);
+                ch.first_qbeg = (uint16_t)qbeg; ch.last_qbeg = (uint16_t)qbeg; ch.last_len = (uint16_t)slen; ch.endq = (uint16_t)(qbeg + slen);
                 ch.rid = rid; ch.n = 1; ch.first_idx = g; ch.last_idx = g; ch.wq = slen; ch.wr = slen;
                 const int32_t cid = c.n_keys;                            // chains are numbered in creation order
                 if (wr) crec[cid] = ch;

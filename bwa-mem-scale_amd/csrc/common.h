@@ -17,8 +17,31 @@ void set_last_error(const std::string &s);
 // Every device allocation of the library goes through this: BWAMS_POISON=1 (debugging aid) fills the fresh block with 0xAB bytes and waits
 // for the fill, so that a kernel that reads what nothing wrote misbehaves in every run — not only when the allocator hands back a block that
 // another chunk left dirty (a fresh process gets zeros).  tests: the whole `-m gpu` suite passes under it.
+// Debugging aids and A-B switches, all of them result-neutral: read from the environment ONCE (at the first call into the library; again
+// on bwams_debug_reload(), which the tests call after changing a variable) — never per call on the hot host path.  include/bwams.h lists them.
+struct Knobs {
+    int verbose = 0;               // BWAMS_VERBOSE: stage times and counters per run on stderr
+    int debug = 0;                 // BWAMS_DEBUG: diagnostic ablations of the SMEM search (bit 0: no SMEM is written)
+    int poison = 0;                // BWAMS_POISON: fresh device allocations are filled with 0xAB
+    int bwd_min_list = 40, bwd_cols = 24, bwd_late_list = 8;                     // BWAMS_BWD_MIN_LIST / _COLS / _LATE_LIST   (fmi_seed.hip: bwd_hand_over)
+    int bwd_dry_min_list = 24, bwd_dry_cols = 8, bwd_dry_late_list = 12;         // BWAMS_BWD_DRY_*: the same once the work queue is dry
+    int bwd_fused = 1;             // BWAMS_BWD_FUSED=0: the two roles behind a search kernel as two launches
+    int bwd_cap_mul = 1;           // BWAMS_BWD_CAP_MUL: hand-over buffers x this (experiments that hand every backward phase over)
+    int r3_beside = 1;             // BWAMS_SEED_R3_BESIDE=0: SMEM round 3 behind round 2 instead of beside it
+    int ext_max_rounds = 0;        // BWAMS_EXT_MAX_ROUNDS: cap of the extension rounds (tests force the extend-the-rest fallback)
+    int ext_all_rounds = 0;        // BWAMS_EXT_ALL_ROUNDS: never cut the rounds short
+    int ext_inplace = 1;           // BWAMS_EXT_INPLACE=0: extension tasks copied into flat buffers
+    int dedup_seq = 0;             // BWAMS_DEDUP_SEQ=1: every read through de-duplication's one-lane form
+    int pair_drop_plan = 0;        // BWAMS_PAIR_DROP_PLAN: exercise mate rescue's second pass
+    int trace_pair = 0;            // BWAMS_TRACE_PAIR: a synchronisation and a line per launch of the paired-end tail
+    int bsw_pk = 1;                // BWAMS_BSW_PK=0: the 32-bit eight-task banded-SW kernel
+    int ert_grid = -1, ert_ticket = 1;   // BWAMS_ERT_GRID (blocks per CU, 0 = one block per 256 bases) / BWAMS_ERT_TICKET=0 (round robin)
+};
+const Knobs &knobs();
+void knobs_reload();
+
 template <class T> static inline hipError_t dev_malloc(T **p, size_t bytes) {
-    static const bool poison = getenv("BWAMS_POISON") && atoi(getenv("BWAMS_POISON")) != 0;
+    const bool poison = knobs().poison != 0;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
     if (e == hipSuccess && poison && bytes) {
         e = hipMemset(*p, 0xAB, bytes);

@@ -798,13 +798,8 @@ void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum,
     // persistent waves that take their groups of read positions from a cursor (kErtTicket groups per atomic): trips differ a lot in
     // length (repeats).  Round robin over many more waves than fit at once measured 17.2 ms (32 blocks per CU; 20.9 ms for one
     // residency), the cursor 16.2 ms with 12 blocks per CU (GRCh38 size, 1 M reads; profiles/r03_notes.md 89).
-    static int per_cu = -1, dyn = -1;
-    if (per_cu < 0) {
-        const char *g = getenv("BWAMS_ERT_GRID");      // experiments: blocks per CU, 0 = one block per 256 bases
-        const char *t = getenv("BWAMS_ERT_TICKET");    // experiments: 0 = round robin
-        dyn = t ? atoi(t) : 1;
-        per_cu = g ? atoi(g) : (dyn ? 12 : 32);
-    }
+    const int dyn = knobs().ert_ticket;                                          // experiments: 0 = round robin
+    const int per_cu = knobs().ert_grid >= 0 ? knobs().ert_grid : (dyn ? 12 : 32);    // experiments: blocks per CU, 0 = one block per 256 bases
     if (per_cu > 0 && blocks > (int64_t)cu_count * per_cu) blocks = (int64_t)cu_count * per_cu;
     ert_profile_kernel<<<(unsigned)blocks, 256, 0, st>>>(e, enc, cum, skip, nseq, nbases, M, prof, part, dyn ? &ctr->ert_ticket : nullptr);
     ert_count_kernel<<<1, 256, 0, st>>>(part, ctr);

@@ -1588,7 +1588,7 @@ void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st) {
     // the number of items is only known on the device; waves without an item leave at their first ticket
     const size_t lds = (size_t)(kBlock / 64) * (kBwdMaxList * 16 + 16 * (size_t)(a.read_w <= kBwdReadLds ? a.read_w : 0));
     const size_t lds_g = lds;
-    static const bool fused = !(getenv("BWAMS_BWD_FUSED") && atoi(getenv("BWAMS_BWD_FUSED")) == 0);
+    const bool fused = knobs().bwd_fused != 0;
     if (fused) {
         smem_bwd_kernel<<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
     } else {

@@ -13,6 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _library_switches_follow_the_environment():
+    """The library reads its debugging aids / A-B switches (BWAMS_*) from the environment once.  A test that changes one calls
+    capi.debug_reload(); after every test — monkeypatch has restored the environment by then or does so right after, so both before
+    and after — the library re-reads it, and no test inherits another's switches."""
+    def reload():
+        try:
+            from bwams import capi
+            if capi._lib is not None:
+                capi.debug_reload()
+        except Exception:
+            pass
+    reload()
+    yield
+    reload()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _torch_hip_runtime_first():
     """PyTorch-ROCm bundles its own HIP runtime, and on this image it only finds the GPU when it

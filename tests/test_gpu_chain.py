@@ -249,6 +249,7 @@ def test_round_cap_extends_the_rest(rep_toy, monkeypatch):
             monkeypatch.setenv("BWAMS_EXT_ALL_ROUNDS", "1")       # never cut the rounds short
         else:
             monkeypatch.delenv("BWAMS_EXT_ALL_ROUNDS", raising=False)
+        capi.debug_reload()                                       # the switches are read once: say that they changed
         b.extend_run(ctx["gopt"])
         regs, reg_off, aln = b.extend_fetch()
         assert np.array_equal(reg_off, wreg_off) and np.array_equal(aln, wseeds["aln"])

@@ -153,6 +153,7 @@ def test_pair_second_pass(pe_toy, monkeypatch):
     g, idx, ix = pe_toy
     reads = simulate.make_read_pairs(g, 500, seed=6, damaged_frac=0.3, discordant_frac=0.1)
     monkeypatch.setenv("BWAMS_PAIR_DROP_PLAN", "1")
+    capi.debug_reload()
     r = _compare(g, ix, reads)
     assert r["redone"] > 30 and r["n_tasks"] > 30
 

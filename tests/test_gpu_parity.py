@@ -71,6 +71,7 @@ def test_backward_phases_handed_to_the_wave_kernel(gpu_toy, monkeypatch, env):
     g, idx, ix = gpu_toy
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    capi.debug_reload()                                      # the switches are read once: say that they changed
     reads, _, _ = simulate.make_reads(g, 3000, seed=21)
     reads = list(reads)
     rng = np.random.default_rng(4)
@@ -177,6 +178,7 @@ def test_pool_with_no_room_to_spare_and_every_emitting_launch(gpu_toy, monkeypat
     must still succeed — the slack covers every launch's partly filled chunks — and one slot less must grow and re-run."""
     g, idx, ix = gpu_toy
     monkeypatch.setenv("BWAMS_BWD_MIN_LIST", "1")
+    capi.debug_reload()
     reads, _, _ = simulate.make_reads(g, 2500, seed=31)
     enc, cum = simulate.flatten_reads(reads)
     o = loader.OracleFMI(idx)

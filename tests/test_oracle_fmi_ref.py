@@ -66,3 +66,29 @@ def test_sais_suffix_array_is_the_index(n, seed, rep):
     first = text[sa[1:]]
     for c in range(4):
         assert idx.count[c] == 1 + int((first < c).sum())
+
+
+def test_bseq1_t_of_the_reference_is_the_record_the_host_layer_mirrors():
+    """bwa.h compiles on its own with the `scale` build's feature macros (oracle/ref_harness_bwa.cpp -> oracle/_ref/libref_bwa.so):
+    the reference's bseq1_t — 64 bytes, sam at 48, perfect at 56 — against the record the Python harness builds for
+    mem_process_seqs() (capi.BSEQ1_DTYPE) and the numbers host/bwamem_hip.h asserts for its mirror."""
+    import ctypes as C
+    import os
+    import re
+    from bwams import capi
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_bwa.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_bwa.so not built (reference tree absent)")
+    lib = C.CDLL(so)
+    out = (C.c_int * 13)()
+    lib.ref_bseq1_layout(out)
+    out = list(out)
+    d = capi.BSEQ1_DTYPE
+    assert out[0] == d.itemsize == 64
+    for k, f in enumerate(("l_seq", "id", "strbuf", "name", "comment", "seq", "qual", "sam", "perfect")):
+        assert out[1 + k] == d.fields[f][1], f
+    assert out[10] == 8 and out[11] == 0 and out[12] == 4                 # bseq1_perfect_t: {flags, location} over `exist`
+    # the mirror's static_assert carries the same numbers
+    hdr = open(os.path.join(os.path.dirname(so), "..", "..", "bwa-mem-scale_amd", "host", "bwamem_hip.h")).read()
+    m = re.search(r"sizeof\(bseq1_t\) == (\d+) && offsetof\(bseq1_t, name\) == (\d+) && offsetof\(bseq1_t, seq\) == (\d+) && offsetof\(bseq1_t, sam\) == (\d+) &&\s*offsetof\(bseq1_t, perfect\) == (\d+)", hdr)
+    assert m and [int(x) for x in m.groups()] == [out[0], out[4], out[6], out[8], out[9]]

@@ -59,6 +59,7 @@ def main():
         old = {k: os.environ.get(k) for k, _ in sets}
         for k, val in sets:
             os.environ[k] = val
+        capi.debug_reload()
         rows = []
         for i in range(args.warmup + args.steps):
             batch.seed_upload_device(d_reads.data_ptr(), cum)

@@ -35,6 +35,7 @@ struct Knobs {
     int pair_drop_plan = 0;        // BWAMS_PAIR_DROP_PLAN: exercise mate rescue's second pass
     int trace_pair = 0;            // BWAMS_TRACE_PAIR: a synchronisation and a line per launch of the paired-end tail
     int bsw_pk = 1;                // BWAMS_BSW_PK=0: the 32-bit eight-task banded-SW kernel
+    int cp2 = 0;                   // BWAMS_CP2=1: the SMEM search reads a compact 128-rows-per-block table derived from CP_OCC (A-B experiment)
     int ert_grid = -1, ert_ticket = 1;   // BWAMS_ERT_GRID (blocks per CU, 0 = one block per 256 bases) / BWAMS_ERT_TICKET=0 (round robin)
 };
 const Knobs &knobs();
@@ -67,6 +68,7 @@ template <class T> static inline hipError_t dev_malloc(T **p, size_t bytes) {
 // 16-byte pieces  [cnt0 cnt1] [cnt2 cnt3] [hot0 hot1] [hot2 hot3].
 struct DevFmi {
     const uint4 *cp;
+    const uint4 *cp2;          // the search kernels' compact form of cp (fmi_seed.hip: CpOcc2; BWAMS_CP2=1), or nullptr
     const int8_t *sa_ms;
     const uint32_t *sa_ls;
     const uint8_t *ref;        // .0123 or nullptr
@@ -193,6 +195,7 @@ struct bwams_index {
     int64_t bytes = 0;
     int64_t n_blk = 0, n_sa = 0;
     void *d_cp = nullptr, *d_ms = nullptr, *d_ls = nullptr, *d_ref = nullptr;
+    void *d_cp2 = nullptr;                       // compact search table derived from d_cp on first use (BWAMS_CP2=1; always owned)
     void *d_all = nullptr, *d_last = nullptr;    // FMA tables (owned)
     void *d_contigs = nullptr;                   // bwams_contig_t[n_seqs] (owned); null = one sequence [0, l_pac)
     int32_t n_seqs = 0;

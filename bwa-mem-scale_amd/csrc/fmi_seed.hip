@@ -87,42 +87,75 @@ __device__ __forceinline__ void occ_from_block(const uint4 &c01, const uint4 &c2
     o.v[3] = (int64_t)mk64(c23.z, c23.w) + __popcll(mk64(h23.z, h23.w) & mask);
 }
 
+// ---- the compact table (BWAMS_CP2=1: a resident layout for the search kernels; the files and every other kernel keep CP_OCC) -----
+// CpOcc2: the same information as two adjacent CP_OCC blocks in 64 bytes — the four counts at the start of a 128-base block and the
+// bases as two bit planes (bit 63 - j of word 0 = base j, of word 1 = base 64 + j; hi: G or T, lo: C or T):
+//     piece 0 = {count A, count C}, piece 1 = {count G, count T}, piece 2 = {hi word 0, hi word 1}, piece 3 = {lo word 0, lo word 1}.
+// k and k + s then share a block whenever s < 128 (one request instead of two), and the table is half as large.  The row of the sentinel
+// has no bit in any one-hot string; in the planes it reads as an A: Occ(A) is corrected in its block.  Algorithmic bytes stay the
+// reference layout's count: the kernels count blocks of 64 rows whatever table they read.
+__device__ __forceinline__ void occ_from_block2(const uint4 &c01, const uint4 &c23, const uint4 &hp, const uint4 &lp, int64_t pos,
+                                                int64_t sentinel, Occ4 &o) {
+    const int y = (int)(pos & 127);
+    const int y0 = y < 64 ? y : 64, y1 = y - y0;
+    const uint64_t m0 = y0 ? (~0ull << (64 - y0)) : 0ull, m1 = y1 ? (~0ull << (64 - y1)) : 0ull;
+    const uint64_t h0 = mk64(hp.x, hp.y) & m0, h1 = mk64(hp.z, hp.w) & m1;
+    const uint64_t l0 = mk64(lp.x, lp.y), l1 = mk64(lp.z, lp.w);
+    const int nt = __popcll(h0 & l0) + __popcll(h1 & l1);
+    const int ng = __popcll(h0 & ~l0) + __popcll(h1 & ~l1);
+    const int nc = __popcll(~mk64(hp.x, hp.y) & l0 & m0) + __popcll(~mk64(hp.z, hp.w) & l1 & m1);
+    int na = y - nt - ng - nc;
+    if ((pos >> 7) == (sentinel >> 7) && y > (int)(sentinel & 127)) --na;
+    o.v[0] = (int64_t)mk64(c01.x, c01.y) + na;
+    o.v[1] = (int64_t)mk64(c01.z, c01.w) + nc;
+    o.v[2] = (int64_t)mk64(c23.x, c23.y) + ng;
+    o.v[3] = (int64_t)mk64(c23.z, c23.w) + nt;
+}
+template <bool CP2>
+__device__ __forceinline__ void occ_any(const DevFmi &f, const uint4 &p0, const uint4 &p1, const uint4 &p2, const uint4 &p3, int64_t pos, Occ4 &o) {
+    if (CP2) occ_from_block2(p0, p1, p2, p3, pos, f.sentinel, o);
+    else occ_from_block(p0, p1, p2, p3, pos, o);
+}
+
 // backwardExt for every lane of the wave at once.  MUST be called by all 64 lanes
 // (wave-uniform control flow); lanes without work pass need = false.
+template <bool CP2 = false>
 __device__ __forceinline__ void backward_ext_coop(const DevFmi &f, bool need, int64_t k, int64_t l, int64_t s,
                                                   int a, int64_t &nk, int64_t &nl, int64_t &ns) {
+    constexpr int BS = CP2 ? 7 : 6;
+    const uint4 *const tab = CP2 ? f.cp2 : f.cp;
     const int q = (int)(threadIdx.x & 3);
     const int64_t sp = need ? k : 0, ep = need ? k + s : 0;
-    const bool two = need && ((sp >> 6) != (ep >> 6));
+    const bool two = need && ((sp >> BS) != (ep >> BS));
     const uint4 zero = make_uint4(0, 0, 0, 0);
     uint4 A0 = zero, A1 = zero, A2 = zero, A3 = zero;
     {
-        const int64_t b0 = quad_bcast64<0>(sp) >> 6, b1 = quad_bcast64<1>(sp) >> 6;
-        const int64_t b2 = quad_bcast64<2>(sp) >> 6, b3 = quad_bcast64<3>(sp) >> 6;
+        const int64_t b0 = quad_bcast64<0>(sp) >> BS, b1 = quad_bcast64<1>(sp) >> BS;
+        const int64_t b2 = quad_bcast64<2>(sp) >> BS, b3 = quad_bcast64<3>(sp) >> BS;
         const uint32_t n = need ? 1u : 0u;
-        if (qdpp<0x00>(n)) A0 = f.cp[(b0 << 2) + q];
-        if (qdpp<0x55>(n)) A1 = f.cp[(b1 << 2) + q];
-        if (qdpp<0xAA>(n)) A2 = f.cp[(b2 << 2) + q];
-        if (qdpp<0xFF>(n)) A3 = f.cp[(b3 << 2) + q];
+        if (qdpp<0x00>(n)) A0 = tab[(b0 << 2) + q];
+        if (qdpp<0x55>(n)) A1 = tab[(b1 << 2) + q];
+        if (qdpp<0xAA>(n)) A2 = tab[(b2 << 2) + q];
+        if (qdpp<0xFF>(n)) A3 = tab[(b3 << 2) + q];
     }
     uint4 B0 = zero, B1 = zero, B2 = zero, B3 = zero;
     const bool any_two = __any(two);
     if (any_two) {
-        const int64_t b0 = quad_bcast64<0>(ep) >> 6, b1 = quad_bcast64<1>(ep) >> 6;
-        const int64_t b2 = quad_bcast64<2>(ep) >> 6, b3 = quad_bcast64<3>(ep) >> 6;
+        const int64_t b0 = quad_bcast64<0>(ep) >> BS, b1 = quad_bcast64<1>(ep) >> BS;
+        const int64_t b2 = quad_bcast64<2>(ep) >> BS, b3 = quad_bcast64<3>(ep) >> BS;
         const uint32_t n = two ? 1u : 0u;
-        if (qdpp<0x00>(n)) B0 = f.cp[(b0 << 2) + q];
-        if (qdpp<0x55>(n)) B1 = f.cp[(b1 << 2) + q];
-        if (qdpp<0xAA>(n)) B2 = f.cp[(b2 << 2) + q];
-        if (qdpp<0xFF>(n)) B3 = f.cp[(b3 << 2) + q];
+        if (qdpp<0x00>(n)) B0 = tab[(b0 << 2) + q];
+        if (qdpp<0x55>(n)) B1 = tab[(b1 << 2) + q];
+        if (qdpp<0xAA>(n)) B2 = tab[(b2 << 2) + q];
+        if (qdpp<0xFF>(n)) B3 = tab[(b3 << 2) + q];
     }
     // after the transpose A0..A3 are pieces 0..3 of this lane's own block
     quad_transpose4(A0, A1, A2, A3, q);
     if (any_two) quad_transpose4(B0, B1, B2, B3, q);
     if (!two) { B0 = A0; B1 = A1; B2 = A2; B3 = A3; }
     Occ4 osp, oep;
-    occ_from_block(A0, A1, A2, A3, sp, osp);
-    occ_from_block(B0, B1, B2, B3, ep, oep);
+    occ_any<CP2>(f, A0, A1, A2, A3, sp, osp);
+    occ_any<CP2>(f, B0, B1, B2, B3, ep, oep);
     const int64_t s0 = oep.v[0] - osp.v[0], s1 = oep.v[1] - osp.v[1];
     const int64_t s2 = oep.v[2] - osp.v[2], s3 = oep.v[3] - osp.v[3];
     const int64_t l3 = l + ((k <= f.sentinel && k + s > f.sentinel) ? 1 : 0);
@@ -144,41 +177,44 @@ struct BlkCache {
     uint4 a0, a1, a2, a3, b0, b1, b2, b3;
     int32_t ta, tb;                     // block numbers held (rows >> 6 < 2^30), -1 = none
 };
+template <bool CP2 = false>
 __device__ __forceinline__ void backward_ext_cached(const DevFmi &f, BlkCache &c, bool need, int64_t k, int64_t l, int64_t s,
                                                     int a, int64_t &nk, int64_t &nl, int64_t &ns) {
+    constexpr int BS = CP2 ? 7 : 6;
+    const uint4 *const tab = CP2 ? f.cp2 : f.cp;
     const int q = (int)(threadIdx.x & 3);
     const int64_t sp = need ? k : 0, ep = need ? k + s : 0;
-    const int32_t bs = (int32_t)(sp >> 6), be = (int32_t)(ep >> 6);
+    const int32_t bs = (int32_t)(sp >> BS), be = (int32_t)(ep >> BS);
     const bool two = need && bs != be;
     const bool fa = need && bs != c.ta, fb = two && be != c.tb;
     const uint4 zero = make_uint4(0, 0, 0, 0);
     if (__any(fa)) {
         uint4 A0 = zero, A1 = zero, A2 = zero, A3 = zero;
-        const int64_t b0 = quad_bcast64<0>(sp) >> 6, b1 = quad_bcast64<1>(sp) >> 6;
-        const int64_t b2 = quad_bcast64<2>(sp) >> 6, b3 = quad_bcast64<3>(sp) >> 6;
+        const int64_t b0 = quad_bcast64<0>(sp) >> BS, b1 = quad_bcast64<1>(sp) >> BS;
+        const int64_t b2 = quad_bcast64<2>(sp) >> BS, b3 = quad_bcast64<3>(sp) >> BS;
         const uint32_t n = fa ? 1u : 0u;
-        if (qdpp<0x00>(n)) A0 = f.cp[(b0 << 2) + q];
-        if (qdpp<0x55>(n)) A1 = f.cp[(b1 << 2) + q];
-        if (qdpp<0xAA>(n)) A2 = f.cp[(b2 << 2) + q];
-        if (qdpp<0xFF>(n)) A3 = f.cp[(b3 << 2) + q];
+        if (qdpp<0x00>(n)) A0 = tab[(b0 << 2) + q];
+        if (qdpp<0x55>(n)) A1 = tab[(b1 << 2) + q];
+        if (qdpp<0xAA>(n)) A2 = tab[(b2 << 2) + q];
+        if (qdpp<0xFF>(n)) A3 = tab[(b3 << 2) + q];
         quad_transpose4(A0, A1, A2, A3, q);
         if (fa) { c.a0 = A0; c.a1 = A1; c.a2 = A2; c.a3 = A3; c.ta = bs; }
     }
     if (__any(fb)) {
         uint4 B0 = zero, B1 = zero, B2 = zero, B3 = zero;
-        const int64_t b0 = quad_bcast64<0>(ep) >> 6, b1 = quad_bcast64<1>(ep) >> 6;
-        const int64_t b2 = quad_bcast64<2>(ep) >> 6, b3 = quad_bcast64<3>(ep) >> 6;
+        const int64_t b0 = quad_bcast64<0>(ep) >> BS, b1 = quad_bcast64<1>(ep) >> BS;
+        const int64_t b2 = quad_bcast64<2>(ep) >> BS, b3 = quad_bcast64<3>(ep) >> BS;
         const uint32_t n = fb ? 1u : 0u;
-        if (qdpp<0x00>(n)) B0 = f.cp[(b0 << 2) + q];
-        if (qdpp<0x55>(n)) B1 = f.cp[(b1 << 2) + q];
-        if (qdpp<0xAA>(n)) B2 = f.cp[(b2 << 2) + q];
-        if (qdpp<0xFF>(n)) B3 = f.cp[(b3 << 2) + q];
+        if (qdpp<0x00>(n)) B0 = tab[(b0 << 2) + q];
+        if (qdpp<0x55>(n)) B1 = tab[(b1 << 2) + q];
+        if (qdpp<0xAA>(n)) B2 = tab[(b2 << 2) + q];
+        if (qdpp<0xFF>(n)) B3 = tab[(b3 << 2) + q];
         quad_transpose4(B0, B1, B2, B3, q);
         if (fb) { c.b0 = B0; c.b1 = B1; c.b2 = B2; c.b3 = B3; c.tb = be; }
     }
     Occ4 osp, oep;
-    occ_from_block(c.a0, c.a1, c.a2, c.a3, sp, osp);
-    occ_from_block(two ? c.b0 : c.a0, two ? c.b1 : c.a1, two ? c.b2 : c.a2, two ? c.b3 : c.a3, ep, oep);
+    occ_any<CP2>(f, c.a0, c.a1, c.a2, c.a3, sp, osp);
+    occ_any<CP2>(f, two ? c.b0 : c.a0, two ? c.b1 : c.a1, two ? c.b2 : c.a2, two ? c.b3 : c.a3, ep, oep);
     const int64_t s0 = oep.v[0] - osp.v[0], s1 = oep.v[1] - osp.v[1];
     const int64_t s2 = oep.v[2] - osp.v[2], s3 = oep.v[3] - osp.v[3];
     const int64_t l3 = l + ((k <= f.sentinel && k + s > f.sentinel) ? 1 : 0);
@@ -600,8 +636,8 @@ enum : int { PH_FETCH = 0, PH_LOAD, PH_HOLD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BW
 
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
 // !ALL_POS: work item = (read, pivot, min_intv), one pivot (round 2).
-template <bool ALL_POS>
-__global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
+template <bool ALL_POS, bool CP2 = false>
+__global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
     const DevFmi &f = a.fmi;
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int cap = a.prev_cap;
@@ -849,9 +885,9 @@ __global__ __launch_bounds__(kBlock, BWAMS_SEARCH_MIN_BLOCKS) void smem_search_k
         // ---- the one extension of this iteration -------------------------------------
         int64_t nk = 0, nl = 0, ns = 0;
 #ifdef BWAMS_NO_BLKCACHE
-        backward_ext_coop(f, do_ext, ek, el, es, ea, nk, nl, ns);
+        backward_ext_coop<CP2>(f, do_ext, ek, el, es, ea, nk, nl, ns);
 #else
-        backward_ext_cached(f, bc, do_ext, ek, el, es, ea, nk, nl, ns);
+        backward_ext_cached<CP2>(f, bc, do_ext, ek, el, es, ea, nk, nl, ns);
 #endif
         if (do_ext) {
             n_ext++;
@@ -1024,6 +1060,7 @@ constexpr int kBwdReadLds = 256;
 __device__ __forceinline__ int bwd_read_words(const SeedLaunch &a) { return a.read_w <= kBwdReadLds ? a.read_w : 0; }
 __device__ __forceinline__ int bwd_wave_words(const SeedLaunch &a) { return kBwdMaxList * 4 + 4 * bwd_read_words(a); }
 
+template <bool CP2>
 __device__ __forceinline__ void bwd_wave_role(const SeedLaunch &a, uint32_t *lds_reads, WaveOut &wo, unsigned long long &n_ext_io,
                                               unsigned long long &n_blk_io) {
     const DevFmi &f = a.fmi;
@@ -1090,7 +1127,7 @@ __device__ __forceinline__ void bwd_wave_role(const SeedLaunch &a, uint32_t *lds
                     int64_t pk = 0, pl = 0, ps = 0, nk = 0, nl = 0, ns = 0;
                     int pn = 0;
                     if (need) prev_unpack(lst[p], pk, pl, ps, pn);
-                    backward_ext_coop(f, need, pk, pl, ps, ba, nk, nl, ns);
+                    backward_ext_coop<CP2>(f, need, pk, pl, ps, ba, nk, nl, ns);
                     if (need) {
                         n_ext++;
                         n_blk += ((pk >> 6) == ((pk + ps) >> 6)) ? 1 : 2;
@@ -1154,6 +1191,7 @@ __device__ __forceinline__ void bwd_wave_role(const SeedLaunch &a, uint32_t *lds
 // are the ones above, taken on the group's sixteen bits of each ballot.
 constexpr int kGrp = 16;
 constexpr int kGroupItemsPerTicket = 16;
+template <bool CP2>
 __device__ __forceinline__ void bwd_group_role(const SeedLaunch &a, uint32_t *lds_reads, WaveOut &wo, unsigned long long &n_ext_io,
                                                unsigned long long &n_blk_io) {
     const DevFmi &f = a.fmi;
@@ -1254,7 +1292,7 @@ __device__ __forceinline__ void bwd_group_role(const SeedLaunch &a, uint32_t *ld
         int64_t pk = 0, pl = 0, ps = 0, nk = 0, nl = 0, ns = 0;
         int pn = 0;
         if (need) prev_unpack(lst[p], pk, pl, ps, pn);
-        backward_ext_coop(f, need, pk, pl, ps, ba & 3, nk, nl, ns);
+        backward_ext_coop<CP2>(f, need, pk, pl, ps, ba & 3, nk, nl, ns);
         if (need) {
             n_ext++;
             n_blk += ((pk >> 6) == ((pk + ps) >> 6)) ? 1 : 2;
@@ -1321,26 +1359,27 @@ __device__ __forceinline__ void bwd_group_role(const SeedLaunch &a, uint32_t *ld
 
 // The launch behind rounds 1 and 2: every wavefront first takes pivots with long lists (a wavefront each, the longest-running
 // items), then pivots with short lists (four at a time) — one launch, one tail.
+template <bool CP2>
 __global__ __launch_bounds__(kBlock) void smem_bwd_kernel(SeedLaunch a) {
     extern __shared__ uint32_t lds_reads[];
     unsigned long long n_ext = 0, n_blk = 0;
     WaveOut wo;
     wo.base = -1; wo.used = 0; wo.emitted = 0;
-    bwd_wave_role(a, lds_reads, wo, n_ext, n_blk);
+    bwd_wave_role<CP2>(a, lds_reads, wo, n_ext, n_blk);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    bwd_group_role(a, lds_reads, wo, n_ext, n_blk);
+    bwd_group_role<CP2>(a, lds_reads, wo, n_ext, n_blk);
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
-template <int ROLE>
+template <int ROLE, bool CP2>
 __global__ __launch_bounds__(kBlock) void smem_bwd_role_kernel(SeedLaunch a) {
     extern __shared__ uint32_t lds_reads[];
     unsigned long long n_ext = 0, n_blk = 0;
     WaveOut wo;
     wo.base = -1; wo.used = 0; wo.emitted = 0;
-    if (ROLE == 0) bwd_wave_role(a, lds_reads, wo, n_ext, n_blk);
-    else bwd_group_role(a, lds_reads, wo, n_ext, n_blk);
+    if (ROLE == 0) bwd_wave_role<CP2>(a, lds_reads, wo, n_ext, n_blk);
+    else bwd_group_role<CP2>(a, lds_reads, wo, n_ext, n_blk);
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
@@ -1386,6 +1425,7 @@ __global__ void mark_kernel(DevCounters *ctr, int which) {
 }
 
 // Round 3: forward-only seeds.
+template <bool CP2>
 __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int max_intv) {
     const DevFmi &f = a.fmi;
     extern __shared__ uint32_t lds_reads[];
@@ -1488,7 +1528,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
             }
         }
         int64_t nk = 0, nl = 0, ns = 0;
-        backward_ext_coop(f, do_ext, cl, ck, cs, ea, nk, nl, ns);
+        backward_ext_coop<CP2>(f, do_ext, cl, ck, cs, ea, nk, nl, ns);
         if (do_ext) {
             n_ext++;
             n_blk += ((cl >> 6) == ((cl + cs) >> 6)) ? 1 : 2;
@@ -1532,6 +1572,24 @@ __global__ void gather_sorted_kernel(const bwams_smem_t *pool, const uint32_t *o
     }
 }
 
+// CpOcc2 from CP_OCC: compact block B = reference blocks 2B and 2B + 1 (the second may not exist)
+__global__ void cp2_build_kernel(const uint4 *__restrict__ cp, int64_t n_blk, uint4 *__restrict__ cp2) {
+    const int64_t n2 = (n_blk + 1) >> 1;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n2; b += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 *p = cp + (2 * b) * 4;
+        const uint4 c01 = p[0], c23 = p[1], ac = p[2], gt = p[3];         // one-hot strings: {A, C}, {G, T}
+        uint4 ac2 = make_uint4(0, 0, 0, 0), gt2 = make_uint4(0, 0, 0, 0);
+        if (2 * b + 1 < n_blk) { ac2 = p[6]; gt2 = p[7]; }
+        uint4 hp, lp;
+        hp.x = gt.x | gt.z; hp.y = gt.y | gt.w;            // G | T of bases 0-63
+        hp.z = gt2.x | gt2.z; hp.w = gt2.y | gt2.w;
+        lp.x = ac.z | gt.z; lp.y = ac.w | gt.w;            // C | T
+        lp.z = ac2.z | gt2.z; lp.w = ac2.w | gt2.w;
+        uint4 *o = cp2 + b * 4;
+        o[0] = c01; o[1] = c23; o[2] = hp; o[3] = lp;
+    }
+}
+
 int grid_for(int64_t n_items, int cu_count) {
     int64_t blocks = (n_items + kBlock - 1) / kBlock;
     const int64_t maxb = (int64_t)cu_count * kBlocksPerCU;
@@ -1541,6 +1599,11 @@ int grid_for(int64_t n_items, int cu_count) {
 }
 
 }  // namespace
+
+size_t cp2_bytes(int64_t n_blk) { return (size_t)((n_blk + 1) >> 1) * 64 + 64; }
+void launch_cp2_build(const uint4 *cp, int64_t n_blk, uint4 *cp2, hipStream_t st) {
+    if (n_blk > 0) cp2_build_kernel<<<256 * 16, 256, 0, st>>>(cp, n_blk, cp2);
+}
 
 static size_t lds_bytes(const SeedLaunch &a) { return a.reads_in_lds ? (size_t)a.read_w * kBlock * 4 : 0; }
 static size_t lds_bytes_search(const SeedLaunch &a) { return lds_bytes(a) + (size_t)kPrevLds * kBlock * 16 + (size_t)(kBlock / 64) * kPivotQueue * 8; }
@@ -1570,7 +1633,8 @@ int64_t seed_pool_slack(int cu_count) {
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
 
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st) {
-    smem_search_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
+    if (a.fmi.cp2) smem_search_kernel<true, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
+    else smem_search_kernel<true, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
 }
 
 void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
@@ -1580,7 +1644,8 @@ void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap,
 
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     // the number of items is only known on the device: launch the persistent grid at chip size
-    smem_search_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+    if (a.fmi.cp2) smem_search_kernel<false, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+    else smem_search_kernel<false, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
 }
 
 void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st) {
@@ -1590,15 +1655,20 @@ void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st) {
     const size_t lds_g = lds;
     const bool fused = knobs().bwd_fused != 0;
     if (fused) {
-        smem_bwd_kernel<<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
+        if (a.fmi.cp2) smem_bwd_kernel<true><<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
+        else smem_bwd_kernel<false><<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
+    } else if (a.fmi.cp2) {
+        smem_bwd_role_kernel<0, true><<<cu_count * 8, kBlock, lds, st>>>(a);
+        smem_bwd_role_kernel<1, true><<<cu_count * 8, kBlock, lds_g, st>>>(a);
     } else {
-        smem_bwd_role_kernel<0><<<cu_count * 8, kBlock, lds, st>>>(a);
-        smem_bwd_role_kernel<1><<<cu_count * 8, kBlock, lds_g, st>>>(a);
+        smem_bwd_role_kernel<0, false><<<cu_count * 8, kBlock, lds, st>>>(a);
+        smem_bwd_role_kernel<1, false><<<cu_count * 8, kBlock, lds_g, st>>>(a);
     }
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {
-    seed_strategy_kernel<<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
+    if (a.fmi.cp2) seed_strategy_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
+    else seed_strategy_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
 }
 
 void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, uint32_t hole_key_rid,

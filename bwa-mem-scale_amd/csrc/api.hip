@@ -42,6 +42,8 @@ void knobs_reload() {
     k.trace_pair = env_int("BWAMS_TRACE_PAIR", 0);
     k.bsw_pk = env_int("BWAMS_BSW_PK", 1);
     k.cp2 = env_int("BWAMS_CP2", 0);
+    k.seed_split = env_int("BWAMS_SEED_SPLIT", 0);
+    k.fwd_bpc = std::max(1, env_int("BWAMS_FWD_BPC", 8)); k.bwdl_bpc = std::max(1, env_int("BWAMS_BWDL_BPC", 6));
     k.ert_ticket = env_int("BWAMS_ERT_TICKET", 1); k.ert_grid = env_int("BWAMS_ERT_GRID", -1);
     g_knobs = k;
 }
@@ -549,7 +551,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk, b->d_ert_redo, b->d_bwd_items, b->d_bwd_ent};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk, b->d_ert_redo, b->d_bwd_items, b->d_bwd_ent, b->d_f_items, b->d_fl_ent};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -641,6 +643,25 @@ int bwams_seed_upload(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, 
     // lane, about half a pivot per read in flight, profiles/r04_notes.md)
     const int64_t cap_mul = knobs().bwd_cap_mul;                // lab: room for EVERY backward phase
     const int64_t bi = std::max<int64_t>(nseq, 4096) * 2 * cap_mul, be = std::max<int64_t>(nseq, 4096) * 24 * cap_mul;
+    if (knobs().seed_split) {
+        // lists: round 1 needs 2 (bases + reads) entries, round 2 (max_len + 2) per work item — room for two items per read; items: six per read
+        const int64_t fl = std::max<int64_t>(2 * (nb + nseq) + 64, 2 * std::max<int64_t>(nseq, 4096) * (int64_t)(mx + 2));
+        const int64_t fi = 6 * std::max<int64_t>(nseq, 4096) + 4096;
+        const int dbl = knobs().seed_split == 2 ? 2 : 1;       // lab: two halves (the forward kernel writes one while the backward kernel reads the other)
+        if (dbl > b->split_dbl) { b->fl_cap = 0; b->f_items_cap = 0; b->split_dbl = dbl; }      // (the lab's doubled buffers: allocate again)
+        if (fl > b->fl_cap) {
+            if (b->d_fl_ent) (void)hipFree(b->d_fl_ent);
+            b->d_fl_ent = nullptr; b->fl_cap = 0;
+            BWAMS_HIP(dev_malloc(&b->d_fl_ent, (size_t)fl * 16 * dbl));
+            b->fl_cap = fl;
+        }
+        if (fi > b->f_items_cap) {
+            if (b->d_f_items) (void)hipFree(b->d_f_items);
+            b->d_f_items = nullptr; b->f_items_cap = 0;
+            BWAMS_HIP(dev_malloc(&b->d_f_items, (size_t)fi * sizeof(BwdItem) * dbl));
+            b->f_items_cap = fi;
+        }
+    }
     if (bi > b->bwd_items_cap) {
         if (b->d_bwd_items) (void)hipFree(b->d_bwd_items);
         if (b->d_bwd_ent) (void)hipFree(b->d_bwd_ent);
@@ -705,6 +726,16 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     a.prev = b->d_prev;
     a.prev_cap = b->prev_cap;
     a.prev_threads = b->prev_threads;
+    const bool split = knobs().seed_split && !b->seed_split_failed && b->d_fl_ent && b->d_f_items;
+    const bool lab_overlap = split && knobs().seed_split == 2;
+    if (lab_overlap) b->split_parity ^= 1;
+    const int par = lab_overlap ? b->split_parity : 0;
+    a.f_items = b->d_f_items + (int64_t)par * b->f_items_cap;
+    a.f_items_cap = b->f_items_cap;
+    a.f_items_fixed = -1;
+    a.fl_ent = b->d_fl_ent + (int64_t)par * b->fl_cap;
+    a.fl_cap = b->fl_cap;
+    a.fl_item_stride = b->max_read_len + 2;
     a.bwd_items = b->d_bwd_items;
     a.bwd_items_s = b->d_bwd_items + b->bwd_items_cap;
     a.bwd_ent = b->d_bwd_ent;
@@ -729,7 +760,23 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     launch_pack_reads(b->d_enc, b->d_cum, b->nseq, b->read_w, b->read_cw, b->d_packed, st);
     launch_mark(b->d_ctr, 0, st);
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
-    if (b->nseq > 0) launch_smem_round1(a, b->cu_count, st);
+    if (b->nseq > 0) {
+        if (lab_overlap && b->f_items_prev[par ^ 1][0] >= 0) {
+            // LAB ONLY: the backward kernel over the items the PREVIOUS run left in the other half (the same reads: the same SMEMs), beside
+            // this run's forward kernel — what a perfect overlap of the two would take
+            SeedLaunch ab = a;
+            ab.f_items = b->d_f_items + (int64_t)(par ^ 1) * b->f_items_cap;
+            ab.fl_ent = b->d_fl_ent + (int64_t)(par ^ 1) * b->fl_cap;
+            ab.f_items_fixed = b->f_items_prev[par ^ 1][0];
+            BWAMS_HIP(hipEventRecord(b->seed_fork, st));
+            BWAMS_HIP(hipStreamWaitEvent(b->seed_aux, b->seed_fork, 0));
+            launch_smem_fwd(a, nullptr, b->cu_count, st);
+            launch_smem_bwdl(ab, b->cu_count, b->seed_aux);
+            BWAMS_HIP(hipEventRecord(b->seed_join, b->seed_aux));
+            BWAMS_HIP(hipStreamWaitEvent(st, b->seed_join, 0));
+        } else if (split) { launch_smem_fwd(a, nullptr, b->cu_count, st); launch_smem_bwdl(a, b->cu_count, st); }
+        else launch_smem_round1(a, b->cu_count, st);
+    }
 #ifdef BWAMS_BWDDBG
     static hipEvent_t dbg_ev = nullptr;
     if (!dbg_ev) BWAMS_HIP(hipEventCreate(&dbg_ev));
@@ -756,7 +803,10 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
         BWAMS_HIP(hipEventRecord(b->seed_join, st3));
     }
     BWAMS_HIP(hipEventRecord(b->ev[10], st));
-    if (b->nseq > 0) launch_smem_round2(a, b->d_work2, b->cu_count, st);
+    if (b->nseq > 0) {
+        if (split && !lab_overlap) { launch_smem_fwd(a, b->d_work2, b->cu_count, st); launch_smem_bwdl(a, b->cu_count, st); }
+        else launch_smem_round2(a, b->d_work2, b->cu_count, st);       // (the lab's overlap run keeps round 1's items intact for the next run)
+    }
     if (b->nseq > 0) launch_smem_bwd_wave(a, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[11], st));
     if (r3 && r3_beside) BWAMS_HIP(hipStreamWaitEvent(st, b->seed_join, 0));
@@ -793,6 +843,13 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
         fprintf(stderr, "\n[smem_r1] wave-iterations after the wave first saw the queue dry: %llu, with one lane extending %llu (max per wave %llu), with 2-4 lanes %llu\n", d[64], d[65], d[67], d[66]);
     }
 #endif
+    if (lab_overlap) { b->f_items_prev[par][0] = (int64_t)b->h_ctr->f_items_r[0]; b->f_items_prev[par][1] = (int64_t)b->h_ctr->f_items_r[1]; }
+    if (knobs().verbose && split) fprintf(stderr, "[bwams_seed_run] split search: items r1 %llu r2 %llu, overflow %llu%s\n", b->h_ctr->f_items_r[0], b->h_ctr->f_items_r[1],
+                                          b->h_ctr->f_overflow, lab_overlap ? " (lab: backward kernel beside the forward kernel)" : "");
+    if (split && b->h_ctr->f_overflow) {         // pivots that found no room between the two kernels: this batch searches unsplit from now on
+        b->seed_split_failed = true;
+        return seed_run_once(b, opt, with_sa);
+    }
     const int64_t n_slots = (int64_t)b->h_ctr->n_smem_total;      // pool slots handed out (holes included)
     const int64_t n = (int64_t)b->h_ctr->n_smem_valid;           // real SMEMs
     b->n_smem = n;

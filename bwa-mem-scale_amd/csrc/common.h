@@ -35,6 +35,8 @@ struct Knobs {
     int pair_drop_plan = 0;        // BWAMS_PAIR_DROP_PLAN: exercise mate rescue's second pass
     int trace_pair = 0;            // BWAMS_TRACE_PAIR: a synchronisation and a line per launch of the paired-end tail
     int bsw_pk = 1;                // BWAMS_BSW_PK=0: the 32-bit eight-task banded-SW kernel
+    int fwd_bpc = 8, bwdl_bpc = 6; // BWAMS_FWD_BPC / BWAMS_BWDL_BPC: workgroups per CU of the forward / backward lane kernels (lab)
+    int seed_split = 0;            // BWAMS_SEED_SPLIT=1: SMEM rounds 1 and 2 as a forward kernel + a backward kernel (fmi_seed.hip)
     int cp2 = 0;                   // BWAMS_CP2=1: the SMEM search reads a compact 128-rows-per-block table derived from CP_OCC (A-B experiment)
     int ert_grid = -1, ert_ticket = 1;   // BWAMS_ERT_GRID (blocks per CU, 0 = one block per 256 bases) / BWAMS_ERT_TICKET=0 (round robin)
 };
@@ -137,6 +139,7 @@ struct DevCounters {
     unsigned long long n_rest;           // extension: slots behind the requests of the last selection (an upper bound of the undecided seeds)
     unsigned long long ert_ticket;       // ERT walk: work cursor of ert_profile_kernel (groups of 64 read positions)
     unsigned long long bwd_items, bwd_entries, bwd_ticket;   // SMEM search: backward phases handed to the wave kernel, their list entries, its work cursor
+    unsigned long long f_items, f_ticket, f_overflow, f_items_r[2];        // SMEM search split by role: item slots handed out, the backward kernel's cursor, pivots without room (the caller re-runs unsplit)
     unsigned long long bwd_items_s, bwd_ticket_s;            // ... the short lists (smem_bwd_group_kernel): slots handed out, work cursor
     unsigned long long pair_full, pair_fail;   // mate rescue: reads redone with every orientation planned; reads the second pass could not finish (never expected)
 };
@@ -264,6 +267,12 @@ struct bwams_batch {
     bwams::DevCounters *h_ctr = nullptr;  // pinned host mirror
     // per-lane scratch of the SMEM search (previous-interval lists)
     uint4 *d_prev = nullptr;
+    bwams::BwdItem *d_f_items = nullptr;        // SMEM search split by role: pivots between the forward and the backward kernel ...
+    uint4 *d_fl_ent = nullptr;                  // ... and their interval lists
+    int64_t f_items_cap = 0, fl_cap = 0;
+    int split_parity = 0, split_dbl = 1;                       // lab (BWAMS_SEED_SPLIT=2): which half of the doubled buffers the forward kernel writes
+    int64_t f_items_prev[2][2] = {{-1, -1}, {-1, -1}};   // ... items per round the previous runs left in each half
+    bool seed_split_failed = false;             // a chunk whose pivots did not fit: this batch searches with the one-kernel form from then on
     bwams::BwdItem *d_bwd_items = nullptr;      // SMEM search: backward phases with long interval lists (wave-per-pivot kernel)
     uint4 *d_bwd_ent = nullptr;
     int64_t bwd_items_cap = 0, bwd_ent_cap = 0;

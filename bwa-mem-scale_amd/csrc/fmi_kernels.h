@@ -22,6 +22,13 @@ struct SeedLaunch {
     int prev_cap;                 // entries per lane
     int64_t prev_threads;         // lanes the scratch was sized for
     // backward phases whose interval list has at least bwd_min_list entries go to smem_bwd_wave_kernel (0 = never)
+    // rounds 1 and 2 as a forward kernel and a backward kernel (smem_fwd_kernel / smem_bwdl_kernel): the pivots between them and their lists
+    BwdItem *f_items;             // f_items_cap slots, reserved 64 at a time per wave (num_prev = 0: unused)
+    int64_t f_items_cap;
+    int64_t f_items_fixed;        // >= 0: the backward kernel takes this many items instead of the counter (lab: overlap experiment)
+    uint4 *fl_ent;                // the lists: fl_cap 16-byte entries
+    int64_t fl_cap;
+    int32_t fl_item_stride;       // round 2: entries per work item (max read length + 2)
     BwdItem *bwd_items, *bwd_items_s;   // lists beyond / up to kBwdShortMax entries; bwd_items_cap slots each
     uint4 *bwd_ent;
     int64_t bwd_items_cap, bwd_ent_cap;
@@ -46,6 +53,9 @@ void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st);
 void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
                         int split_width, int cu_count, hipStream_t st);
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st);
+// rounds 1 / 2 split by role: forward phases of every read (work == nullptr) or work item, then the backward phase of every pivot
+void launch_smem_fwd(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st);
+void launch_smem_bwdl(const SeedLaunch &a, int cu_count, hipStream_t st);
 // the backward phases rounds 1 / 2 set aside (lists of bwd_min_list entries and more): one wavefront per pivot, one lane per entry
 void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st);
 // round 3: forward-only seeds (bwtSeedStrategyAllPosOneThread)

@@ -472,7 +472,7 @@ __device__ __forceinline__ long long ho_item_slot(const SeedLaunch &a, HoState &
 // Returns true for the lanes whose pivot has left; false (run the backward phase here) when the buffers are full.
 // MUST be called by all 64 lanes.
 __device__ __forceinline__ bool bwd_hand_over(const SeedLaunch &a, HoState &h, const PrevList &pl, bool req, int base, int num_prev,
-                                              uint32_t rid, int x, int min_intv, bool dry) {
+                                              uint32_t rid, int x, int min_intv, bool dry, const uint4 *src_list = nullptr) {
     if (!__any(req)) return false;
     const int lane = (int)(threadIdx.x & 63);
     const bool is_short = num_prev <= kBwdShortMax;
@@ -501,7 +501,8 @@ __device__ __forceinline__ bool bwd_hand_over(const SeedLaunch &a, HoState &h, c
         BwdItem w;
         w.rid = rid; w.x = x; w.min_intv = min_intv; w.num_prev = 0; w.off = 0;
         if (fits) {
-            for (int p = 0; p < num_prev; ++p) a.bwd_ent[eo + p] = prev_raw(pl, base, p);
+            if (src_list) { for (int p = 0; p < num_prev; ++p) a.bwd_ent[eo + p] = src_list[num_prev - 1 - p]; }     // a forward kernel's list: push order
+            else for (int p = 0; p < num_prev; ++p) a.bwd_ent[eo + p] = prev_raw(pl, base, p);
             w.num_prev = num_prev;
             w.off = (int64_t)eo;
         }
@@ -686,6 +687,10 @@ __global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void sme
     BlkCache bc;
     bc.a0 = bc.a1 = bc.a2 = bc.a3 = bc.b0 = bc.b1 = bc.b2 = bc.b3 = make_uint4(0, 0, 0, 0);
     bc.ta = bc.tb = -1;
+#ifdef BWAMS_LIST_PREFETCH                   // (measured: no gain, 17.1 against 16.9 ms — the entry's round trip is not what an iteration waits for; profiles/r04_notes.md)
+    uint4 pf_ent = make_uint4(0, 0, 0, 0);    // the list entry requested one iteration ahead (logical index pf_p of the current column, -1: none)
+    int pf_p = -1;
+#endif
 
     while (true) {
         // at most one SMEM per lane and iteration; written at the wave-uniform point below
@@ -876,7 +881,18 @@ __global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void sme
             if (!go) {
                 phase = PH_BWD_END;
             } else {
+                // an entry beyond the LDS ring comes from the lane's HBM list: a memory round trip IN FRONT of the block fetch that depends
+                // on it — two dependent round trips in one iteration, for the whole wave.  The entry the lane will need NEXT (p + 1: the
+                // compaction writes at most index p) is requested here, together with this iteration's blocks, and is in registers when
+                // the next iteration asks for it
+#ifdef BWAMS_LIST_PREFETCH
+                if (pf_p == p) prev_unpack(pf_ent, pk, pl, ps, pn);
+                else prev_get(prev, base, p, pk, pl, ps, pn);
+                pf_p = -1;
+                if (p + 1 < num_prev && p + 1 >= kPrevLds) { pf_ent = prev.glob[base + p + 1]; pf_p = p + 1; }
+#else
                 prev_get(prev, base, p, pk, pl, ps, pn);
+#endif
                 do_ext = true;
                 ek = pk; el = pl; es = ps; ea = bwd_a;
             }
@@ -1036,6 +1052,329 @@ __global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void sme
         }
     }
 #endif
+    ho_close_items<0>(a, ho);
+    ho_close_items<1>(a, ho);
+    wave_emit_finish(a, wo);
+    flush_counters(a.ctr, n_ext, n_blk);
+}
+
+// ---- rounds 1 and 2 as TWO lane kernels (round 4) ------------------------------------------------------------------------------
+// smem_search_kernel runs forward and backward phases of different lanes in one loop: every iteration executes the forward lanes'
+// code AND the backward lanes' code (the wave diverges), about 700 vector + 290 scalar instructions for one extension per lane — the
+// launch is bound by instruction issue (profiles/r04_notes.md), not by the memory round trip.  Split by role, each loop carries one
+// role's code and state:
+//   smem_fwd_kernel   a lane owns a read (round 1) or a pivot (round 2) and runs FORWARD phases only; every interval the reference
+//                     would push on prevArray goes straight to the pivot's list in HBM (no ring, no copy); at the end of a forward
+//                     phase the pivot becomes an item (rid, x, min_intv, entries, list) and the lane opens the read's next pivot at once.
+//                     Forward phases cost the same for every read (149 extensions): no tail.
+//   smem_bwdl_kernel  a lane owns an item and runs its BACKWARD phase: the first column reads the list where the forward kernel left
+//                     it, the survivors are compacted into the lane's LDS ring / HBM list as before.  Long phases leave the lane for
+//                     the kernels behind (bwd_hand_over), as in the one-kernel form.
+// Lists in HBM: round 1, pivot x of read r at 2 (cum[r] + r) + 2 x (a read's forward phases tile it: list i ends before list i + 1
+// begins); round 2, work item t at t (max_len + 2).  Same extensions, same SMEMs, same counts as smem_search_kernel.
+enum : int { FW_FETCH = 0, FW_PIVOT, FW_FWD, FW_EXIT };
+
+template <bool ALL_POS, bool CP2>
+__global__ __launch_bounds__(kBlock) void smem_fwd_kernel(SeedLaunch a, const Round2Work *work) {
+    const DevFmi &f = a.fmi;
+    extern __shared__ uint32_t lds_reads[];
+    uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
+    ReadView rv;
+    rv.lds_col = lds_col;
+    rv.gl = a.packed;
+    rv.cw = a.read_cw;
+    const int64_t n_work = ALL_POS ? a.nseq : (int64_t)a.ctr->n_work2;
+    const unsigned long long lanes_below = (1ull << (threadIdx.x & 63)) - 1ull;
+    int phase = FW_FETCH;
+    uint32_t rid = 0;
+    int len = 0, x = 0, next_x = 0, min_intv = 1;
+    int64_t ck = 0, cl = 0, cs = 0;
+    int cn = 0, j = 0, num_prev = 0;
+    int64_t lbase = 0;                    // round 1: 2 (cum[rid] + rid); round 2: the item's list
+    int64_t fl = 0;                       // the list of the pivot in progress
+    bool lst_ok = true;                   // its list lies inside the buffer (round 2 beyond the buffer: counted, the caller re-runs unsplit)
+    unsigned long long n_ext = 0, n_blk = 0;
+    WaveTickets wt;
+    wt.next = 0; wt.left = 0; wt.seen = 0;
+    long long it_base = -1;               // the wave's chunk of item slots
+    int it_used = 0;
+
+    auto push = [&](int64_t k, int64_t l, int64_t s_, int n) {
+        if (lst_ok) a.fl_ent[fl + num_prev] = prev_pack(k, l, s_, n);
+        num_prev++;
+    };
+    while (true) {
+        {
+            unsigned long long t = 0;
+            if (take_ticket(&a.ctr->work_head, wt, phase == FW_FETCH, t, n_work, ALL_POS)) {
+                if ((int64_t)t >= n_work) phase = FW_EXIT;
+                else {
+                    if (ALL_POS) {
+                        rid = (uint32_t)t; x = 0; min_intv = 1;
+                    } else {
+                        const Round2Work wk = work[t];
+                        rid = wk.rid; x = wk.x; min_intv = wk.min_intv;
+                    }
+                    const int64_t qoff = a.cum[rid];
+                    len = (int)(a.cum[rid + 1] - qoff);
+                    lbase = ALL_POS ? 2 * (qoff + (int64_t)rid) : (int64_t)t * (int64_t)(a.fl_item_stride);
+                    lst_ok = ALL_POS || lbase + a.fl_item_stride <= a.fl_cap;
+                    phase = FW_PIVOT;
+                    if (ALL_POS && a.skip && a.skip[rid]) phase = FW_FETCH;
+                    else if (!lst_ok) { atomicAdd(&a.ctr->f_overflow, 1ull); phase = FW_FETCH; }
+                    else read_take(rv, lds_col, a.packed, a.read_w, rid);
+                }
+            }
+        }
+        if (__all(phase == FW_EXIT)) break;
+
+        if (phase == FW_PIVOT) {
+            if (x >= len) phase = FW_FETCH;
+            else {
+                const int c = base_at(rv, x);
+                if (c >= 4) {
+                    x = x + 1;
+                    if (!ALL_POS) phase = FW_FETCH;
+                } else {
+                    ck = cnt_at(f, c);
+                    cl = cnt_at(f, 3 - c);
+                    cs = cnt_at(f, c + 1) - ck;
+                    cn = x;
+                    j = x + 1;
+                    next_x = x + 1;
+                    num_prev = 0;
+                    fl = ALL_POS ? lbase + 2 * (int64_t)x : lbase;
+                    phase = FW_FWD;
+                    if (f.all_smem && len - x >= f.all_bp) {
+                        // FMA: the first forward steps come from one all_smem entry (FMI_search.cpp:1414-1463)
+                        const int bp = f.all_bp;
+                        uint32_t tix = 0;
+                        int kk = 0;
+                        for (; kk < bp; ++kk) {
+                            const int bb = base_at(rv, x + kk);
+                            if (bb >= 4) break;
+                            tix |= (uint32_t)bb << ((bp - 1 - kk) * 2);
+                        }
+                        const uint32_t *ent = f.all_smem + (int64_t)tix * 32;
+                        const int last_avail = (int)ent[0];
+                        const int last_idx = (kk > last_avail ? last_avail : kk) - 1;
+                        for (int t = 0; t < last_idx; ++t, ++j) {
+                            const int bb = base_at(rv, j);
+                            next_x = j + 1;
+                            const int64_t tk = ck + ent[1 + 3 * t];
+                            const int64_t tl = cnt_at(f, 3 - bb) + ent[2 + 3 * t];
+                            const int64_t ts = ent[3 + 3 * t];
+                            if (ts != cs) push(ck, cl, cs, cn);
+                            if (ts < min_intv) {
+                                next_x = j;
+                                j = len;                       // no further forward steps
+                                break;
+                            }
+                            ck = tk; cl = tl; cs = ts; cn = j;
+                        }
+                        if (kk < bp) {                         // an N inside the window (reference quirk kept)
+                            next_x = j + 1;
+                            j = len;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- one forward extension ----------------------------------------------------------------
+        bool do_ext = false, fin = false;
+        int ea = 0;
+        if (phase == FW_FWD) {
+            fin = true;
+            if (j < len) {
+                const int c = base_at(rv, j);
+                next_x = j + 1;
+                if (c < 4) { fin = false; do_ext = true; ea = 3 - c; }
+            }
+        }
+        int64_t nk = 0, nl = 0, ns = 0;
+        backward_ext_coop<CP2>(f, do_ext, cl, ck, cs, ea, nk, nl, ns);          // forward = backward on the other strand
+        if (do_ext) {
+            n_ext++;
+            n_blk += ((cl >> 6) == ((cl + cs) >> 6)) ? 1 : 2;
+            if (ns != cs) push(ck, cl, cs, cn);
+            if (ns < min_intv) {
+                next_x = j;
+                fin = true;                                   // cur is still the old interval
+            } else {
+                ck = nl; cl = nk; cs = ns; cn = j;
+                j++;
+            }
+        }
+        bool item = false;
+        if (phase == FW_FWD && fin) {
+            if (cs >= min_intv) push(ck, cl, cs, cn);
+            item = num_prev > 0;                              // an empty list leaves nothing for the backward phase to do
+        }
+        // ---- the pivots whose forward phase ended become items (slots reserved per wave, 64 at a time) --------
+        {
+            const unsigned long long m = __ballot(item);
+            if (m) {
+                const int cnt = __popcll(m);
+                if (it_base < 0 || it_used + cnt > 64) {
+                    const int lane = (int)(threadIdx.x & 63);
+                    if (it_base >= 0) { const long long sl = it_base + it_used + lane; if (it_used + lane < 64 && sl < a.f_items_cap) a.f_items[sl].num_prev = 0; }
+                    it_base = (long long)wave_ticket(&a.ctr->f_items, 64ull);
+                    it_used = 0;
+                }
+                const long long sl = it_base + it_used + __popcll(m & lanes_below);
+                if (item) {
+                    if (sl < a.f_items_cap) {
+                        BwdItem w;
+                        w.rid = rid; w.x = x; w.min_intv = min_intv; w.num_prev = num_prev; w.off = fl;
+                        a.f_items[sl] = w;
+                    } else atomicAdd(&a.ctr->f_overflow, 1ull);
+                }
+                it_used += cnt;
+            }
+        }
+        if (phase == FW_FWD && fin) {
+            x = next_x;
+            phase = ALL_POS ? FW_PIVOT : FW_FETCH;
+        }
+    }
+    {   // the unused slots of the wave's last chunk
+        const int lane = (int)(threadIdx.x & 63);
+        if (it_base >= 0) { const long long sl = it_base + it_used + lane; if (it_used + lane < 64 && sl < a.f_items_cap) a.f_items[sl].num_prev = 0; }
+    }
+    flush_counters(a.ctr, n_ext, n_blk);
+}
+
+enum : int { BL_FETCH = 0, BL_BWD, BL_BWD_END, BL_HO, BL_HO_LATE, BL_EXIT };
+
+template <bool CP2>
+__global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void smem_bwdl_kernel(SeedLaunch a) {
+    const DevFmi &f = a.fmi;
+    const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    extern __shared__ uint32_t lds_reads[];
+    uint32_t *const lds_col = a.reads_in_lds ? lds_reads + threadIdx.x : nullptr;
+    PrevList prev;
+    prev.glob = a.prev + slot * (int64_t)a.prev_cap;
+    prev.ring = reinterpret_cast<uint4 *>(lds_reads + (a.reads_in_lds ? a.read_w * kBlock : 0)) + threadIdx.x;
+    ReadView rv;
+    rv.lds_col = lds_col;
+    rv.gl = a.packed;
+    rv.cw = a.read_cw;
+    unsigned long long n_items = a.f_items_fixed >= 0 ? (unsigned long long)a.f_items_fixed : a.ctr->f_items;
+    if ((int64_t)n_items > a.f_items_cap) n_items = (unsigned long long)a.f_items_cap;
+    int phase = BL_FETCH;
+    uint32_t rid = 0;
+    int x = 0, min_intv = 1, j = 0, num_prev = 0, p = 0, num_curr = 0, cur_m = 0, bwd_a = 0, ho_x = 0;
+    int32_t curr_s = -1;
+    bool first = true, dry = false, ho_tried = false;
+    const uint4 *src = nullptr;           // the forward kernel's list while the first column reads it (push order: shortest match first)
+    unsigned long long n_ext = 0, n_blk = 0;
+    WaveOut wo;
+    wo.base = -1; wo.used = 0; wo.emitted = 0;
+    WaveTickets wt;
+    wt.next = 0; wt.left = 0; wt.seen = 0;
+    BlkCache bc;
+    bc.a0 = bc.a1 = bc.a2 = bc.a3 = bc.b0 = bc.b1 = bc.b2 = bc.b3 = make_uint4(0, 0, 0, 0);
+    bc.ta = bc.tb = -1;
+    HoState ho;
+    ho_init(ho);
+
+    auto entry = [&](int q, int64_t &k, int64_t &l, int64_t &s_, int &n) {
+        if (src) prev_unpack(src[num_prev - 1 - q], k, l, s_, n);
+        else prev_get(prev, 0, q, k, l, s_, n);
+    };
+    while (true) {
+        bool em = false;
+        uint32_t em_m = 0, em_n = 0;
+        int64_t em_k = 0, em_l = 0, em_s = 0;
+        if (phase == BL_BWD_END) {
+            if (num_prev != 0) {
+                int64_t qk, ql, qs;
+                int qn;
+                entry(0, qk, ql, qs, qn);
+                if (qn - cur_m + 1 >= a.min_seed_len) { em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)qn; em_k = qk; em_l = ql; em_s = qs; }
+            }
+            phase = BL_FETCH;
+        }
+        wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
+        em = false;
+        {
+            unsigned long long t = 0;
+            if (take_ticket(&a.ctr->f_ticket, wt, phase == BL_FETCH, t, (int64_t)n_items, true)) {
+                if (t >= n_items) phase = BL_EXIT;
+                else {
+                    const BwdItem it = a.f_items[t];
+                    if (it.num_prev > 0) {
+                        rid = it.rid; x = it.x; min_intv = it.min_intv; num_prev = it.num_prev;
+                        src = a.fl_ent + it.off;
+                        read_take(rv, lds_col, a.packed, a.read_w, rid);
+                        j = x - 1; p = 0; num_curr = 0; curr_s = -1; first = true; cur_m = x; ho_tried = false;
+                        phase = BL_BWD;
+                        if (a.bwd_min_list > 0 && num_prev >= (dry ? a.bwd_dry_min_list : a.bwd_min_list) && num_prev <= kBwdMaxList) { ho_x = x; phase = BL_HO; }
+                    }
+                }
+            }
+        }
+        if (__all(phase == BL_EXIT)) break;
+        if (!dry && __any(phase == BL_EXIT)) { dry = true; ho_tried = false; }
+
+        bool do_ext = false;
+        int64_t pk = 0, pl = 0, ps = 0;
+        int pn = 0;
+        if (phase == BL_BWD) {
+            bool go = true;
+            if (p == 0) {
+                go = false;
+                if (num_prev != 0 && j >= 0) { bwd_a = base_at(rv, j); go = bwd_a < 4; }
+            }
+            if (!go) phase = BL_BWD_END;
+            else { entry(p, pk, pl, ps, pn); do_ext = true; }
+        }
+        int64_t nk = 0, nl = 0, ns = 0;
+#ifdef BWAMS_NO_BLKCACHE
+        backward_ext_coop<CP2>(f, do_ext, pk, pl, ps, bwd_a, nk, nl, ns);
+#else
+        backward_ext_cached<CP2>(f, bc, do_ext, pk, pl, ps, bwd_a, nk, nl, ns);
+#endif
+        if (do_ext) {
+            n_ext++;
+            n_blk += ((pk >> 6) == ((pk + ps) >> 6)) ? 1 : 2;
+            bool keep = false;
+            if (first) {
+                if (ns < min_intv && (pn - cur_m + 1) >= a.min_seed_len) {
+                    em = true; em_m = (uint32_t)cur_m; em_n = (uint32_t)pn; em_k = pk; em_l = pl; em_s = ps;
+                    first = false;
+                } else if (ns >= min_intv && ns != (int64_t)curr_s) { keep = true; first = false; }
+            } else keep = ns >= min_intv && ns != (int64_t)curr_s;
+            if (keep) {
+                curr_s = (int32_t)ns;
+                prev_put(prev, 0, num_curr, nk, nl, ns, pn);
+                num_curr++;
+            }
+            p++;
+            if (p == num_prev) {                         // this column is done: the list now lives in the lane's ring / HBM list
+                src = nullptr;
+                num_prev = num_curr;
+                if (num_curr == 0) phase = BL_BWD_END;
+                else {
+                    cur_m = j;
+                    j--;
+                    p = 0; num_curr = 0; curr_s = -1; first = true;
+                    if (!ho_tried && x - cur_m >= (dry ? a.bwd_dry_cols : a.bwd_cols)) {
+                        ho_tried = true;
+                        if (a.bwd_min_list > 0 && num_prev >= (dry ? a.bwd_dry_late_list : a.bwd_late_list) && num_prev <= kBwdMaxList) { ho_x = cur_m; phase = BL_HO_LATE; }
+                    }
+                }
+            }
+        }
+        {
+            const bool rq = phase == BL_HO || phase == BL_HO_LATE;
+            if (__any(rq)) {
+                const bool gone = bwd_hand_over(a, ho, prev, rq, 0, num_prev, rid, ho_x, min_intv, dry, phase == BL_HO ? src : nullptr);
+                if (rq) phase = gone ? BL_FETCH : BL_BWD;       // the buffers are full: the backward phase runs (on) here, its state untouched
+            }
+        }
+        wave_emit(a, wo, em, rid, em_m, em_n, em_k, em_l, em_s);
+    }
     ho_close_items<0>(a, ho);
     ho_close_items<1>(a, ho);
     wave_emit_finish(a, wo);
@@ -1421,6 +1760,9 @@ __global__ void mark_kernel(DevCounters *ctr, int which) {
     ctr->work_head = 0;
     ctr->bwd_items = ctr->bwd_entries = ctr->bwd_ticket = 0;
     ctr->bwd_items_s = ctr->bwd_ticket_s = 0;
+    if (which == 1) ctr->f_items_r[0] = ctr->f_items;
+    if (which == 2) ctr->f_items_r[1] = ctr->f_items;
+    ctr->f_items = ctr->f_ticket = 0;
     if (which != 2) ctr->work_head3 = 0;       // (mark 2 may run while round 3 is in flight on its own stream... it has joined; kept for symmetry)
 }
 
@@ -1627,7 +1969,7 @@ int64_t seed_max_threads(int cu_count) { return (int64_t)cu_count * kBlocksPerCU
 // (rounds 1, 2, 3) and of the launches behind rounds 1 and 2 (smem_bwd_kernel: cu * 8 workgroups, sized for two roles each) may
 // abandon one chunk of kChunk slots
 int64_t seed_pool_slack(int cu_count) {
-    return 3 * (seed_max_threads(cu_count) / 64 * kChunk) + 2 * ((int64_t)cu_count * 8 * (kBlock / 64) * kChunk);
+    return 5 * (seed_max_threads(cu_count) / 64 * kChunk) + 2 * ((int64_t)cu_count * 8 * (kBlock / 64) * kChunk);
 }
 
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
@@ -1646,6 +1988,23 @@ void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_coun
     // the number of items is only known on the device: launch the persistent grid at chip size
     if (a.fmi.cp2) smem_search_kernel<false, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
     else smem_search_kernel<false, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+}
+
+void launch_smem_fwd(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
+    const int grid = cu_count * knobs().fwd_bpc;
+    if (!work) {
+        if (a.fmi.cp2) smem_fwd_kernel<true, true><<<grid, kBlock, lds_bytes(a), st>>>(a, nullptr);
+        else smem_fwd_kernel<true, false><<<grid, kBlock, lds_bytes(a), st>>>(a, nullptr);
+    } else {
+        if (a.fmi.cp2) smem_fwd_kernel<false, true><<<grid, kBlock, lds_bytes(a), st>>>(a, work);
+        else smem_fwd_kernel<false, false><<<grid, kBlock, lds_bytes(a), st>>>(a, work);
+    }
+}
+
+void launch_smem_bwdl(const SeedLaunch &a, int cu_count, hipStream_t st) {
+    const size_t lds = lds_bytes(a) + (size_t)kPrevLds * kBlock * 16;
+    if (a.fmi.cp2) smem_bwdl_kernel<true><<<cu_count * knobs().bwdl_bpc, kBlock, lds, st>>>(a);
+    else smem_bwdl_kernel<false><<<cu_count * knobs().bwdl_bpc, kBlock, lds, st>>>(a);
 }
 
 void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st) {

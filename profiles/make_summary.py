@@ -19,6 +19,7 @@ def short(k):
     for pat, name in (("smem_search_kernel<true>", "smem_search_kernel<true> (SMEM round 1)"),
                       ("smem_search_kernel<false>", "smem_search_kernel<false> (SMEM round 2)"),
                       ("smem_bwd_wave", "smem_bwd_wave_kernel (rounds 1 and 2: backward phases with long interval lists, wave per pivot; one launch behind each search kernel)"),
+                      ("smem_bwd_kernel", "smem_bwd_kernel (rounds 1 and 2: the backward phases that left their lanes — a wavefront per pivot with a long list, sixteen lanes per pivot otherwise; one launch behind each search kernel)"),
                       ("seed_strategy", "seed_strategy_kernel (SMEM round 3; runs beside round 2 on a stream of its own: the durations overlap, 3.3 ms alone)"), ("sa_lookup", "sa_lookup_kernel"),
                       ("bsw_pk_kernel", "bsw_pk_kernel (banded SW, 16 tasks per wave, packed 16-bit columns; 5 query-length classes)"),
                       ("bsw_qwin_kernel", "bsw_qwin_kernel (banded SW, 8 tasks per wave, 32-bit: scoring the packed kernel does not take)"),
@@ -76,8 +77,8 @@ def newest(pattern):
     return fs[-1:] 
 
 
-BWD1 = "smem_bwd_wave_kernel, the launch behind round 1"
-BWD2 = "smem_bwd_wave_kernel, the launch behind round 2"
+BWD1 = "smem_bwd_kernel, the launch behind round 1"
+BWD2 = "smem_bwd_kernel, the launch behind round 2"
 ks = newest(src + "/trace/*/*_kernel_stats.csv")[0]
 shutil.copy(ks, f"profiles/{rnd}_kernel_stats.csv")
 rows = list(csv.DictReader(open(ks)))
@@ -99,7 +100,7 @@ for p in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
             for c, x in v.items():
                 P.setdefault(s, {})[c] = sum(x) / len(x)
                 N[s] = len(x)
-                if "smem_bwd_wave" in k:          # launches alternate: behind round 1, behind round 2
+                if "smem_bwd_wave" in k or "smem_bwd_kernel" in k:          # launches alternate: behind round 1, behind round 2
                     P.setdefault(BWD1, {})[c] = sum(x[0::2]) / max(len(x[0::2]), 1)
                     P.setdefault(BWD2, {})[c] = sum(x[1::2]) / max(len(x[1::2]), 1)
                     N[BWD1], N[BWD2] = len(x[0::2]), len(x[1::2])
@@ -165,13 +166,26 @@ with open(f"profiles/{rnd}_summary.md", "w") as f:
                     f"{E.get('SQ_INSTS_VALU',0)/1e9:.2f} G VALU + {E.get('SQ_INSTS_SALU',0)/1e9:.2f} G SALU + {E.get('SQ_INSTS_VMEM_RD',0)/1e9:.3f} G VMEM-read wave-instructions.\n")
     kt = newest(src + "/trace/*/*_kernel_trace.csv")
     if kt:
-        tr = sorted((r for r in csv.DictReader(open(kt[0])) if "smem_bwd_wave" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
-        d1 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr[0::2]]
-        d2 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr[1::2]]
-        sr = [float(r["AverageNs"]) / 1e6 for r in rows if "smem_search_kernel<true>" in r["Name"]]
-        if d1 and sr:
-            f.write(f"\nRound 1 = `smem_search_kernel<true>` + the launch of `smem_bwd_wave_kernel` behind it (its launches alternate: behind round 1, behind round 2): "
-                    f"rocprofv3 averages {sr[0]:.2f} + {sum(d1)/len(d1):.2f} = **{sr[0] + sum(d1)/len(d1):.2f} ms** (the launch behind round 2: {sum(d2)/max(len(d2),1):.2f} ms), "
+        allk = sorted(csv.DictReader(open(kt[0])), key=lambda r: int(r["Start_Timestamp"]))
+        dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6       # noqa: E731
+        tr = [r for r in allk if "smem_bwd_wave" in r["Kernel_Name"] or "smem_bwd_kernel" in r["Kernel_Name"]]
+        s1 = [r for r in allk if "smem_search_kernel<true" in r["Kernel_Name"]]
+        # the run also launches the search on HALF-size chunks (sam_side's two-batches-behind-one-call leg): averaged apart
+        top = max(dur(r) for r in s1) if s1 else 0.0
+        full = [r for r in s1 if dur(r) > 0.75 * top]
+        half = [r for r in s1 if dur(r) <= 0.75 * top]
+        # the launch behind every full-size round-1 search: the first smem_bwd launch that starts after it
+        behind = []
+        for r in full:
+            nxt = [x for x in tr if int(x["Start_Timestamp"]) >= int(r["End_Timestamp"])]
+            if nxt:
+                behind.append(dur(nxt[0]))
+        if full and behind:
+            fs, fb = sum(dur(r) for r in full) / len(full), sum(behind) / len(behind)
+            f.write(f"\nRound 1 = `smem_search_kernel<true>` + the launch of `smem_bwd_kernel` behind it.  FULL-size launches only ({len(full)} of {len(s1)}: the run "
+                    f"also searches half-size chunks {len(half)} times — `sam_side`'s two-batches-behind-one-call leg — which the per-kernel table above averages in: "
+                    f"{(sum(dur(r) for r in half) / len(half)) if half else 0.0:.2f} ms each): rocprofv3 averages {fs:.2f} + {fb:.2f} = **{fs + fb:.2f} ms** "
+                    f"(search min {min(dur(r) for r in full):.2f} / max {max(dur(r) for r in full):.2f}), "
                     f"to compare with `roofline.launch_ms` = {bench['roofline']['launch_ms']} ms, which brackets both with HIP events.\n")
     f.write(f"\n`roofline.launch_ms` measured live by `bench.py` with HIP events in the run below: {bench['roofline']['launch_ms']} ms "
             "(the rocprofv3 average above covers warm-up + timed launches of the profiled run).\n\n")

@@ -41,7 +41,7 @@ void knobs_reload() {
     k.pair_drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") != nullptr;
     k.trace_pair = env_int("BWAMS_TRACE_PAIR", 0);
     k.bsw_pk = env_int("BWAMS_BSW_PK", 1);
-    k.cp2 = env_int("BWAMS_CP2", 0);
+    k.cp2 = env_int("BWAMS_CP2", 2);
     k.seed_split = env_int("BWAMS_SEED_SPLIT", 0);
     k.fwd_bpc = std::max(1, env_int("BWAMS_FWD_BPC", 8)); k.bwdl_bpc = std::max(1, env_int("BWAMS_BWDL_BPC", 6));
     k.ert_ticket = env_int("BWAMS_ERT_TICKET", 1); k.ert_grid = env_int("BWAMS_ERT_GRID", -1);
@@ -130,6 +130,7 @@ int bwams_device_count(int *n) {
 static int index_finish(bwams_index *ix, const bwams_fmi_desc_t *d) {
     ix->fmi.cp = reinterpret_cast<const uint4 *>(ix->d_cp);
     ix->fmi.cp2 = nullptr;
+    ix->fmi.tab_kind = 0;
     ix->fmi.sa_ms = reinterpret_cast<const int8_t *>(ix->d_ms);
     ix->fmi.sa_ls = reinterpret_cast<const uint32_t *>(ix->d_ls);
     ix->fmi.ref = reinterpret_cast<const uint8_t *>(ix->d_ref);
@@ -703,13 +704,16 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     b->with_sa = with_sa != 0;
     b->n_smem = b->n_sa = 0;
 
-    if (knobs().cp2 && !b->idx->d_cp2 && b->idx->d_cp && b->idx->n_blk > 0) {     // the compact table, once per index
-        BWAMS_HIP(dev_malloc(&b->idx->d_cp2, cp2_bytes(b->idx->n_blk)));
-        launch_cp2_build(reinterpret_cast<const uint4 *>(b->idx->d_cp), b->idx->n_blk, reinterpret_cast<uint4 *>(b->idx->d_cp2), st);
+    if (knobs().cp2 && b->idx->cp2_kind != knobs().cp2 && b->idx->d_cp && b->idx->n_blk > 0) {     // the search kernels' own table, once per index
+        if (b->idx->d_cp2) { BWAMS_HIP(hipStreamSynchronize(st)); (void)hipFree(b->idx->d_cp2); b->idx->d_cp2 = nullptr; }
+        BWAMS_HIP(dev_malloc(&b->idx->d_cp2, cp2_bytes(b->idx->n_blk, knobs().cp2)));
+        launch_cp2_build(reinterpret_cast<const uint4 *>(b->idx->d_cp), b->idx->n_blk, reinterpret_cast<uint4 *>(b->idx->d_cp2), knobs().cp2, st);
+        b->idx->cp2_kind = knobs().cp2;
     }
     SeedLaunch a;
     a.fmi = b->idx->fmi;
     a.fmi.cp2 = knobs().cp2 ? reinterpret_cast<const uint4 *>(b->idx->d_cp2) : nullptr;
+    a.fmi.tab_kind = knobs().cp2 ? b->idx->cp2_kind : 0;
     a.enc = b->d_enc;
     a.cum = b->d_cum;
     a.skip = b->has_skip ? b->d_skip : nullptr;

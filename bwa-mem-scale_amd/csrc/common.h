@@ -37,7 +37,9 @@ struct Knobs {
     int bsw_pk = 1;                // BWAMS_BSW_PK=0: the 32-bit eight-task banded-SW kernel
     int fwd_bpc = 8, bwdl_bpc = 6; // BWAMS_FWD_BPC / BWAMS_BWDL_BPC: workgroups per CU of the forward / backward lane kernels (lab)
     int seed_split = 0;            // BWAMS_SEED_SPLIT=1: SMEM rounds 1 and 2 as a forward kernel + a backward kernel (fmi_seed.hip)
-    int cp2 = 0;                   // BWAMS_CP2=1: the SMEM search reads a compact 128-rows-per-block table derived from CP_OCC (A-B experiment)
+    int cp2 = 2;                   // BWAMS_CP2: the table the SMEM search kernels read — 2 (default): the INTERLEAVED form of CP_OCC (piece b = count and
+                                   // string of base b: an extension reads half a block per end, fetched by a pair of lanes); 1: the compact 128-rows-per-block
+                                   // form (measured: no gain); 0: CP_OCC itself
     int ert_grid = -1, ert_ticket = 1;   // BWAMS_ERT_GRID (blocks per CU, 0 = one block per 256 bases) / BWAMS_ERT_TICKET=0 (round robin)
 };
 const Knobs &knobs();
@@ -70,7 +72,8 @@ template <class T> static inline hipError_t dev_malloc(T **p, size_t bytes) {
 // 16-byte pieces  [cnt0 cnt1] [cnt2 cnt3] [hot0 hot1] [hot2 hot3].
 struct DevFmi {
     const uint4 *cp;
-    const uint4 *cp2;          // the search kernels' compact form of cp (fmi_seed.hip: CpOcc2; BWAMS_CP2=1), or nullptr
+    const uint4 *cp2;          // the search kernels' resident form of cp (fmi_seed.hip; BWAMS_CP2), or nullptr
+    int32_t tab_kind;          // ... 1: compact, 128 rows per block; 2: interleaved, piece b = count and string of base b
     const int8_t *sa_ms;
     const uint32_t *sa_ls;
     const uint8_t *ref;        // .0123 or nullptr
@@ -198,6 +201,7 @@ struct bwams_index {
     int64_t bytes = 0;
     int64_t n_blk = 0, n_sa = 0;
     void *d_cp = nullptr, *d_ms = nullptr, *d_ls = nullptr, *d_ref = nullptr;
+    int cp2_kind = 0;
     void *d_cp2 = nullptr;                       // compact search table derived from d_cp on first use (BWAMS_CP2=1; always owned)
     void *d_all = nullptr, *d_last = nullptr;    // FMA tables (owned)
     void *d_contigs = nullptr;                   // bwams_contig_t[n_seqs] (owned); null = one sequence [0, l_pac)

@@ -74,7 +74,7 @@ void launch_sa_lookup(const DevFmi &f, const bwams_smem_t *sorted, int64_t n_sme
                       hipStream_t st);
 
 // the search kernels' compact Occ table (CpOcc2, BWAMS_CP2=1): (n_blk + 1) / 2 blocks of 64 B
-size_t cp2_bytes(int64_t n_blk);
-void launch_cp2_build(const uint4 *cp, int64_t n_blk, uint4 *cp2, hipStream_t st);
+size_t cp2_bytes(int64_t n_blk, int kind);          // kind 1: compact (128 rows per block); 2: interleaved (piece b = count and string of base b)
+void launch_cp2_build(const uint4 *cp, int64_t n_blk, uint4 *cp2, int kind, hipStream_t st);
 
 }  // namespace bwams

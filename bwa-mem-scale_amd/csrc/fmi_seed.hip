@@ -111,19 +111,110 @@ __device__ __forceinline__ void occ_from_block2(const uint4 &c01, const uint4 &c
     o.v[2] = (int64_t)mk64(c23.x, c23.y) + ng;
     o.v[3] = (int64_t)mk64(c23.z, c23.w) + nt;
 }
-template <bool CP2>
+template <int TAB>
 __device__ __forceinline__ void occ_any(const DevFmi &f, const uint4 &p0, const uint4 &p1, const uint4 &p2, const uint4 &p3, int64_t pos, Occ4 &o) {
-    if (CP2) occ_from_block2(p0, p1, p2, p3, pos, f.sentinel, o);
+    if (TAB == 1) occ_from_block2(p0, p1, p2, p3, pos, f.sentinel, o);
     else occ_from_block(p0, p1, p2, p3, pos, o);
+}
+
+// ---- the interleaved table (TAB == 2; BWAMS_CP2=2, the default) ---------------------------------------------------------------------
+// The same 64 bytes per 64 rows as CP_OCC, the fields permuted: piece b (16 bytes) = {cp_count[b], one_hot_bwt_str[b]}, b = A, C, G, T.
+// backwardExt(a) needs Occ of base a at both ends (k' and s') and, for l', the sizes of the bases ABOVE a — or, because the four sizes add
+// up to s minus the sentinel, the bases up to a:
+//     l'[0] = l + s - s0        l'[1] = l + s - s0 - s1        l'[2] = l + [sentinel] + s3        l'[3] = l + [sentinel]
+// (FMI_search.cpp:2029-2056 with s0 + s1 + s2 + s3 = s - [sentinel in range]: exact integer identities).  So an extension by a reads only
+// the HALF of each block that holds a's pair of bases — {A, C} or {G, T}: 32 bytes — fetched by a PAIR of lanes (lane q of the pair
+// reads piece q of both members' halves; one exchange with the neighbour gives a lane both pieces of its own half).  Against the
+// quad-cooperative whole-block fetch: half the load instructions, a 2 x 2 exchange of 4 words instead of a 4 x 4 transpose of 16, two
+// masked popcounts per end instead of four: 5.74 G -> 4.27 G vector instructions per round-1 launch, 16.8 -> 15.9 ms (profiles/r04_notes.md).
+// The files and every other kernel keep the reference layout; the algorithmic byte count stays the reference layout's.
+__device__ __forceinline__ int64_t cnt_at4(const DevFmi &f, int i) { return i == 0 ? f.count[0] : i == 1 ? f.count[1] : i == 2 ? f.count[2] : f.count[3]; }
+struct HalfBlk { uint4 x, y; };            // piece (lane & 1) and piece 1 - (lane & 1) of the lane's half: bases 2h + q, 2h + 1 - q
+template <int J>
+__device__ __forceinline__ int64_t pair_bcast64(int64_t v) {      // member J of every pair: quad_perm [J, J, 2 + J, 2 + J]
+    constexpr int C = J ? 0xF5 : 0xA0;
+    const uint32_t lo = qdpp<C>((uint32_t)v), hi = qdpp<C>((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)mk64(lo, hi);
+}
+__device__ __forceinline__ uint4 pair_swap(const uint4 &v) {       // the neighbour's value: quad_perm [1, 0, 3, 2]
+    return make_uint4(qdpp<0xB1>(v.x), qdpp<0xB1>(v.y), qdpp<0xB1>(v.z), qdpp<0xB1>(v.w));
+}
+// MUST be called by all 64 lanes.  idx = (block << 1) | half of the lanes that fetch; the lanes of a pair fetch both members' halves
+__device__ __forceinline__ void pair_fetch(const uint4 *__restrict__ tab, bool fetch, int64_t idx, int q, HalfBlk &out) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    uint4 P0 = zero, P1 = zero;
+    const int64_t i0 = pair_bcast64<0>(idx), i1 = pair_bcast64<1>(idx);
+    const uint32_t n = fetch ? 1u : 0u;
+    if (qdpp<0xA0>(n)) P0 = tab[(i0 << 1) + q];
+    if (qdpp<0xF5>(n)) P1 = tab[(i1 << 1) + q];
+    // the piece this lane holds for itself (load q) and the one it holds for its neighbour (load 1 - q)
+    const uint4 own = q ? P1 : P0, give = q ? P0 : P1;
+    const uint4 got = pair_swap(give);
+    if (fetch) { out.x = own; out.y = got; }
+}
+__device__ __forceinline__ void occ_pair(const HalfBlk &h, int64_t pos, int64_t &ox, int64_t &oy) {
+    const int y = (int)(pos & 63);
+    const uint64_t mask = y ? (~0ull << (64 - y)) : 0ull;
+    ox = (int64_t)mk64(h.x.x, h.x.y) + __popcll(mk64(h.x.z, h.x.w) & mask);
+    oy = (int64_t)mk64(h.y.x, h.y.y) + __popcll(mk64(h.y.z, h.y.w) & mask);
+}
+__device__ __forceinline__ void pair_finish(const DevFmi &f, int q, int64_t k, int64_t l, int64_t s, int a, int64_t oxs, int64_t oys, int64_t oxe,
+                                            int64_t oye, int64_t &nk, int64_t &nl, int64_t &ns) {
+    const bool a_is_x = (a & 1) == q;                            // x holds base 2h + q
+    const int64_t occ_a = a_is_x ? oxs : oys;
+    const int64_t sx = oxe - oxs, sy = oye - oys;
+    const int64_t s_a = a_is_x ? sx : sy, s_o = a_is_x ? sy : sx;
+    const int64_t sent = (k <= f.sentinel && k + s > f.sentinel) ? 1 : 0;
+    nk = cnt_at4(f, a) + occ_a;
+    ns = s_a;
+    nl = a == 0 ? l + s - s_a : a == 1 ? l + s - s_a - s_o : a == 2 ? l + sent + s_o : l + sent;
+}
+struct HalfCache {
+    HalfBlk a, b;
+    int32_t ta, tb;                     // (block << 1 | half) held, -1 = none
+};
+// backwardExt over the interleaved table for every lane of the wave.  MUST be called by all 64 lanes.
+__device__ __forceinline__ void backward_ext_pair(const DevFmi &f, bool need, int64_t k, int64_t l, int64_t s, int a,
+                                                  int64_t &nk, int64_t &nl, int64_t &ns) {
+    const int q = (int)(threadIdx.x & 1);
+    const int64_t sp = need ? k : 0, ep = need ? k + s : 0;
+    const int h = (a >> 1) & 1;
+    const int64_t is = ((sp >> 6) << 1) | h, ie = ((ep >> 6) << 1) | h;
+    const bool two = need && is != ie;
+    HalfBlk A, B;
+    A.x = A.y = B.x = B.y = make_uint4(0, 0, 0, 0);
+    pair_fetch(f.cp2, need, is, q, A);
+    if (__any(two)) pair_fetch(f.cp2, two, ie, q, B);
+    int64_t oxs, oys, oxe, oye;
+    occ_pair(A, sp, oxs, oys);
+    occ_pair(two ? B : A, ep, oxe, oye);
+    pair_finish(f, q, k, l, s, a, oxs, oys, oxe, oye, nk, nl, ns);
+}
+// ... with the lane's two most recent half blocks kept in registers (BlkCache's rule: start against previous start, end against previous end)
+__device__ __forceinline__ void backward_ext_pair_cached(const DevFmi &f, HalfCache &c, bool need, int64_t k, int64_t l, int64_t s, int a,
+                                                         int64_t &nk, int64_t &nl, int64_t &ns) {
+    const int q = (int)(threadIdx.x & 1);
+    const int64_t sp = need ? k : 0, ep = need ? k + s : 0;
+    const int h = (a >> 1) & 1;
+    const int32_t is = (int32_t)(((sp >> 6) << 1) | h), ie = (int32_t)(((ep >> 6) << 1) | h);
+    const bool two = need && is != ie;
+    const bool fa = need && is != c.ta, fb = two && ie != c.tb;
+    if (__any(fa)) { pair_fetch(f.cp2, fa, (int64_t)is, q, c.a); if (fa) c.ta = is; }
+    if (__any(fb)) { pair_fetch(f.cp2, fb, (int64_t)ie, q, c.b); if (fb) c.tb = ie; }
+    int64_t oxs, oys, oxe, oye;
+    occ_pair(c.a, sp, oxs, oys);
+    occ_pair(two ? c.b : c.a, ep, oxe, oye);
+    pair_finish(f, q, k, l, s, a, oxs, oys, oxe, oye, nk, nl, ns);
 }
 
 // backwardExt for every lane of the wave at once.  MUST be called by all 64 lanes
 // (wave-uniform control flow); lanes without work pass need = false.
-template <bool CP2 = false>
+template <int TAB = 0>
 __device__ __forceinline__ void backward_ext_coop(const DevFmi &f, bool need, int64_t k, int64_t l, int64_t s,
                                                   int a, int64_t &nk, int64_t &nl, int64_t &ns) {
-    constexpr int BS = CP2 ? 7 : 6;
-    const uint4 *const tab = CP2 ? f.cp2 : f.cp;
+    if (TAB == 2) { backward_ext_pair(f, need, k, l, s, a, nk, nl, ns); return; }
+    constexpr int BS = TAB == 1 ? 7 : 6;
+    const uint4 *const tab = TAB ? f.cp2 : f.cp;
     const int q = (int)(threadIdx.x & 3);
     const int64_t sp = need ? k : 0, ep = need ? k + s : 0;
     const bool two = need && ((sp >> BS) != (ep >> BS));
@@ -154,8 +245,8 @@ __device__ __forceinline__ void backward_ext_coop(const DevFmi &f, bool need, in
     if (any_two) quad_transpose4(B0, B1, B2, B3, q);
     if (!two) { B0 = A0; B1 = A1; B2 = A2; B3 = A3; }
     Occ4 osp, oep;
-    occ_any<CP2>(f, A0, A1, A2, A3, sp, osp);
-    occ_any<CP2>(f, B0, B1, B2, B3, ep, oep);
+    occ_any<TAB>(f, A0, A1, A2, A3, sp, osp);
+    occ_any<TAB>(f, B0, B1, B2, B3, ep, oep);
     const int64_t s0 = oep.v[0] - osp.v[0], s1 = oep.v[1] - osp.v[1];
     const int64_t s2 = oep.v[2] - osp.v[2], s3 = oep.v[3] - osp.v[3];
     const int64_t l3 = l + ((k <= f.sentinel && k + s > f.sentinel) ? 1 : 0);
@@ -177,11 +268,11 @@ struct BlkCache {
     uint4 a0, a1, a2, a3, b0, b1, b2, b3;
     int32_t ta, tb;                     // block numbers held (rows >> 6 < 2^30), -1 = none
 };
-template <bool CP2 = false>
+template <int TAB = 0>
 __device__ __forceinline__ void backward_ext_cached(const DevFmi &f, BlkCache &c, bool need, int64_t k, int64_t l, int64_t s,
                                                     int a, int64_t &nk, int64_t &nl, int64_t &ns) {
-    constexpr int BS = CP2 ? 7 : 6;
-    const uint4 *const tab = CP2 ? f.cp2 : f.cp;
+    constexpr int BS = TAB == 1 ? 7 : 6;
+    const uint4 *const tab = TAB ? f.cp2 : f.cp;
     const int q = (int)(threadIdx.x & 3);
     const int64_t sp = need ? k : 0, ep = need ? k + s : 0;
     const int32_t bs = (int32_t)(sp >> BS), be = (int32_t)(ep >> BS);
@@ -213,8 +304,8 @@ __device__ __forceinline__ void backward_ext_cached(const DevFmi &f, BlkCache &c
         if (fb) { c.b0 = B0; c.b1 = B1; c.b2 = B2; c.b3 = B3; c.tb = be; }
     }
     Occ4 osp, oep;
-    occ_any<CP2>(f, c.a0, c.a1, c.a2, c.a3, sp, osp);
-    occ_any<CP2>(f, two ? c.b0 : c.a0, two ? c.b1 : c.a1, two ? c.b2 : c.a2, two ? c.b3 : c.a3, ep, oep);
+    occ_any<TAB>(f, c.a0, c.a1, c.a2, c.a3, sp, osp);
+    occ_any<TAB>(f, two ? c.b0 : c.a0, two ? c.b1 : c.a1, two ? c.b2 : c.a2, two ? c.b3 : c.a3, ep, oep);
     const int64_t s0 = oep.v[0] - osp.v[0], s1 = oep.v[1] - osp.v[1];
     const int64_t s2 = oep.v[2] - osp.v[2], s3 = oep.v[3] - osp.v[3];
     const int64_t l3 = l + ((k <= f.sentinel && k + s > f.sentinel) ? 1 : 0);
@@ -223,6 +314,24 @@ __device__ __forceinline__ void backward_ext_cached(const DevFmi &f, BlkCache &c
           : a == 2 ? f.count[2] + osp.v[2] : f.count[3] + osp.v[3]);
     ns = a == 0 ? s0 : a == 1 ? s1 : a == 2 ? s2 : s3;
     nl = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
+}
+
+// the register cache that goes with a table kind, and the cached extension over it
+template <int TAB> struct CacheOf { using type = BlkCache; };
+template <> struct CacheOf<2> { using type = HalfCache; };
+__device__ __forceinline__ void cache_init(BlkCache &c) {
+    c.a0 = c.a1 = c.a2 = c.a3 = c.b0 = c.b1 = c.b2 = c.b3 = make_uint4(0, 0, 0, 0);
+    c.ta = c.tb = -1;
+}
+__device__ __forceinline__ void cache_init(HalfCache &c) {
+    c.a.x = c.a.y = c.b.x = c.b.y = make_uint4(0, 0, 0, 0);
+    c.ta = c.tb = -1;
+}
+template <int TAB>
+__device__ __forceinline__ void ext_cached(const DevFmi &f, typename CacheOf<TAB>::type &c, bool need, int64_t k, int64_t l, int64_t s, int a,
+                                           int64_t &nk, int64_t &nl, int64_t &ns) {
+    if constexpr (TAB == 2) backward_ext_pair_cached(f, c, need, k, l, s, a, nk, nl, ns);
+    else backward_ext_cached<TAB>(f, c, need, k, l, s, a, nk, nl, ns);
 }
 
 // count[i] without dynamic indexing of the kernel argument (keeps it in SGPRs)
@@ -637,8 +746,8 @@ enum : int { PH_FETCH = 0, PH_LOAD, PH_HOLD, PH_PIVOT, PH_FWD, PH_FWD_END, PH_BW
 
 // Rounds 1 and 2.  ALL_POS: work item = read, walk every pivot (round 1).
 // !ALL_POS: work item = (read, pivot, min_intv), one pivot (round 2).
-template <bool ALL_POS, bool CP2 = false>
-__global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
+template <bool ALL_POS, int TAB = 0>
+__global__ __launch_bounds__(kBlock, TAB == 1 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void smem_search_kernel(SeedLaunch a, const Round2Work *work) {
     const DevFmi &f = a.fmi;
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int cap = a.prev_cap;
@@ -684,9 +793,8 @@ __global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void sme
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0; wt.seen = 0;
-    BlkCache bc;
-    bc.a0 = bc.a1 = bc.a2 = bc.a3 = bc.b0 = bc.b1 = bc.b2 = bc.b3 = make_uint4(0, 0, 0, 0);
-    bc.ta = bc.tb = -1;
+    typename CacheOf<TAB>::type bc;
+    cache_init(bc);
 #ifdef BWAMS_LIST_PREFETCH                   // (measured: no gain, 17.1 against 16.9 ms — the entry's round trip is not what an iteration waits for; profiles/r04_notes.md)
     uint4 pf_ent = make_uint4(0, 0, 0, 0);    // the list entry requested one iteration ahead (logical index pf_p of the current column, -1: none)
     int pf_p = -1;
@@ -901,9 +1009,9 @@ __global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void sme
         // ---- the one extension of this iteration -------------------------------------
         int64_t nk = 0, nl = 0, ns = 0;
 #ifdef BWAMS_NO_BLKCACHE
-        backward_ext_coop<CP2>(f, do_ext, ek, el, es, ea, nk, nl, ns);
+        backward_ext_coop<TAB>(f, do_ext, ek, el, es, ea, nk, nl, ns);
 #else
-        backward_ext_cached<CP2>(f, bc, do_ext, ek, el, es, ea, nk, nl, ns);
+        ext_cached<TAB>(f, bc, do_ext, ek, el, es, ea, nk, nl, ns);
 #endif
         if (do_ext) {
             n_ext++;
@@ -1074,7 +1182,7 @@ __global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void sme
 // begins); round 2, work item t at t (max_len + 2).  Same extensions, same SMEMs, same counts as smem_search_kernel.
 enum : int { FW_FETCH = 0, FW_PIVOT, FW_FWD, FW_EXIT };
 
-template <bool ALL_POS, bool CP2>
+template <bool ALL_POS, int TAB>
 __global__ __launch_bounds__(kBlock) void smem_fwd_kernel(SeedLaunch a, const Round2Work *work) {
     const DevFmi &f = a.fmi;
     extern __shared__ uint32_t lds_reads[];
@@ -1192,7 +1300,7 @@ __global__ __launch_bounds__(kBlock) void smem_fwd_kernel(SeedLaunch a, const Ro
             }
         }
         int64_t nk = 0, nl = 0, ns = 0;
-        backward_ext_coop<CP2>(f, do_ext, cl, ck, cs, ea, nk, nl, ns);          // forward = backward on the other strand
+        backward_ext_coop<TAB>(f, do_ext, cl, ck, cs, ea, nk, nl, ns);          // forward = backward on the other strand
         if (do_ext) {
             n_ext++;
             n_blk += ((cl >> 6) == ((cl + cs) >> 6)) ? 1 : 2;
@@ -1246,8 +1354,8 @@ __global__ __launch_bounds__(kBlock) void smem_fwd_kernel(SeedLaunch a, const Ro
 
 enum : int { BL_FETCH = 0, BL_BWD, BL_BWD_END, BL_HO, BL_HO_LATE, BL_EXIT };
 
-template <bool CP2>
-__global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void smem_bwdl_kernel(SeedLaunch a) {
+template <int TAB>
+__global__ __launch_bounds__(kBlock, TAB == 1 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void smem_bwdl_kernel(SeedLaunch a) {
     const DevFmi &f = a.fmi;
     const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     extern __shared__ uint32_t lds_reads[];
@@ -1272,9 +1380,8 @@ __global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void sme
     wo.base = -1; wo.used = 0; wo.emitted = 0;
     WaveTickets wt;
     wt.next = 0; wt.left = 0; wt.seen = 0;
-    BlkCache bc;
-    bc.a0 = bc.a1 = bc.a2 = bc.a3 = bc.b0 = bc.b1 = bc.b2 = bc.b3 = make_uint4(0, 0, 0, 0);
-    bc.ta = bc.tb = -1;
+    typename CacheOf<TAB>::type bc;
+    cache_init(bc);
     HoState ho;
     ho_init(ho);
 
@@ -1331,9 +1438,9 @@ __global__ __launch_bounds__(kBlock, CP2 ? 3 : BWAMS_SEARCH_MIN_BLOCKS) void sme
         }
         int64_t nk = 0, nl = 0, ns = 0;
 #ifdef BWAMS_NO_BLKCACHE
-        backward_ext_coop<CP2>(f, do_ext, pk, pl, ps, bwd_a, nk, nl, ns);
+        backward_ext_coop<TAB>(f, do_ext, pk, pl, ps, bwd_a, nk, nl, ns);
 #else
-        backward_ext_cached<CP2>(f, bc, do_ext, pk, pl, ps, bwd_a, nk, nl, ns);
+        ext_cached<TAB>(f, bc, do_ext, pk, pl, ps, bwd_a, nk, nl, ns);
 #endif
         if (do_ext) {
             n_ext++;
@@ -1399,7 +1506,7 @@ constexpr int kBwdReadLds = 256;
 __device__ __forceinline__ int bwd_read_words(const SeedLaunch &a) { return a.read_w <= kBwdReadLds ? a.read_w : 0; }
 __device__ __forceinline__ int bwd_wave_words(const SeedLaunch &a) { return kBwdMaxList * 4 + 4 * bwd_read_words(a); }
 
-template <bool CP2>
+template <int TAB>
 __device__ __forceinline__ void bwd_wave_role(const SeedLaunch &a, uint32_t *lds_reads, WaveOut &wo, unsigned long long &n_ext_io,
                                               unsigned long long &n_blk_io) {
     const DevFmi &f = a.fmi;
@@ -1466,7 +1573,7 @@ __device__ __forceinline__ void bwd_wave_role(const SeedLaunch &a, uint32_t *lds
                     int64_t pk = 0, pl = 0, ps = 0, nk = 0, nl = 0, ns = 0;
                     int pn = 0;
                     if (need) prev_unpack(lst[p], pk, pl, ps, pn);
-                    backward_ext_coop<CP2>(f, need, pk, pl, ps, ba, nk, nl, ns);
+                    backward_ext_coop<TAB>(f, need, pk, pl, ps, ba, nk, nl, ns);
                     if (need) {
                         n_ext++;
                         n_blk += ((pk >> 6) == ((pk + ps) >> 6)) ? 1 : 2;
@@ -1530,7 +1637,7 @@ __device__ __forceinline__ void bwd_wave_role(const SeedLaunch &a, uint32_t *lds
 // are the ones above, taken on the group's sixteen bits of each ballot.
 constexpr int kGrp = 16;
 constexpr int kGroupItemsPerTicket = 16;
-template <bool CP2>
+template <int TAB>
 __device__ __forceinline__ void bwd_group_role(const SeedLaunch &a, uint32_t *lds_reads, WaveOut &wo, unsigned long long &n_ext_io,
                                                unsigned long long &n_blk_io) {
     const DevFmi &f = a.fmi;
@@ -1631,7 +1738,7 @@ __device__ __forceinline__ void bwd_group_role(const SeedLaunch &a, uint32_t *ld
         int64_t pk = 0, pl = 0, ps = 0, nk = 0, nl = 0, ns = 0;
         int pn = 0;
         if (need) prev_unpack(lst[p], pk, pl, ps, pn);
-        backward_ext_coop<CP2>(f, need, pk, pl, ps, ba & 3, nk, nl, ns);
+        backward_ext_coop<TAB>(f, need, pk, pl, ps, ba & 3, nk, nl, ns);
         if (need) {
             n_ext++;
             n_blk += ((pk >> 6) == ((pk + ps) >> 6)) ? 1 : 2;
@@ -1698,27 +1805,27 @@ __device__ __forceinline__ void bwd_group_role(const SeedLaunch &a, uint32_t *ld
 
 // The launch behind rounds 1 and 2: every wavefront first takes pivots with long lists (a wavefront each, the longest-running
 // items), then pivots with short lists (four at a time) — one launch, one tail.
-template <bool CP2>
+template <int TAB>
 __global__ __launch_bounds__(kBlock) void smem_bwd_kernel(SeedLaunch a) {
     extern __shared__ uint32_t lds_reads[];
     unsigned long long n_ext = 0, n_blk = 0;
     WaveOut wo;
     wo.base = -1; wo.used = 0; wo.emitted = 0;
-    bwd_wave_role<CP2>(a, lds_reads, wo, n_ext, n_blk);
+    bwd_wave_role<TAB>(a, lds_reads, wo, n_ext, n_blk);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    bwd_group_role<CP2>(a, lds_reads, wo, n_ext, n_blk);
+    bwd_group_role<TAB>(a, lds_reads, wo, n_ext, n_blk);
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
-template <int ROLE, bool CP2>
+template <int ROLE, int TAB>
 __global__ __launch_bounds__(kBlock) void smem_bwd_role_kernel(SeedLaunch a) {
     extern __shared__ uint32_t lds_reads[];
     unsigned long long n_ext = 0, n_blk = 0;
     WaveOut wo;
     wo.base = -1; wo.used = 0; wo.emitted = 0;
-    if (ROLE == 0) bwd_wave_role<CP2>(a, lds_reads, wo, n_ext, n_blk);
-    else bwd_group_role<CP2>(a, lds_reads, wo, n_ext, n_blk);
+    if (ROLE == 0) bwd_wave_role<TAB>(a, lds_reads, wo, n_ext, n_blk);
+    else bwd_group_role<TAB>(a, lds_reads, wo, n_ext, n_blk);
     wave_emit_finish(a, wo);
     flush_counters(a.ctr, n_ext, n_blk);
 }
@@ -1767,7 +1874,7 @@ __global__ void mark_kernel(DevCounters *ctr, int which) {
 }
 
 // Round 3: forward-only seeds.
-template <bool CP2>
+template <int TAB>
 __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int max_intv) {
     const DevFmi &f = a.fmi;
     extern __shared__ uint32_t lds_reads[];
@@ -1870,7 +1977,7 @@ __global__ __launch_bounds__(kBlock) void seed_strategy_kernel(SeedLaunch a, int
             }
         }
         int64_t nk = 0, nl = 0, ns = 0;
-        backward_ext_coop<CP2>(f, do_ext, cl, ck, cs, ea, nk, nl, ns);
+        backward_ext_coop<TAB>(f, do_ext, cl, ck, cs, ea, nk, nl, ns);
         if (do_ext) {
             n_ext++;
             n_blk += ((cl >> 6) == ((cl + cs) >> 6)) ? 1 : 2;
@@ -1932,6 +2039,19 @@ __global__ void cp2_build_kernel(const uint4 *__restrict__ cp, int64_t n_blk, ui
     }
 }
 
+// the interleaved table from CP_OCC: piece b = {cp_count[b], one_hot_bwt_str[b]}
+__global__ void cpi_build_kernel(const uint4 *__restrict__ cp, int64_t n_blk, uint4 *__restrict__ out) {
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blk; b += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 *p = cp + b * 4;
+        const uint4 c01 = p[0], c23 = p[1], h01 = p[2], h23 = p[3];
+        uint4 *o = out + b * 4;
+        o[0] = make_uint4(c01.x, c01.y, h01.x, h01.y);
+        o[1] = make_uint4(c01.z, c01.w, h01.z, h01.w);
+        o[2] = make_uint4(c23.x, c23.y, h23.x, h23.y);
+        o[3] = make_uint4(c23.z, c23.w, h23.z, h23.w);
+    }
+}
+
 int grid_for(int64_t n_items, int cu_count) {
     int64_t blocks = (n_items + kBlock - 1) / kBlock;
     const int64_t maxb = (int64_t)cu_count * kBlocksPerCU;
@@ -1942,9 +2062,11 @@ int grid_for(int64_t n_items, int cu_count) {
 
 }  // namespace
 
-size_t cp2_bytes(int64_t n_blk) { return (size_t)((n_blk + 1) >> 1) * 64 + 64; }
-void launch_cp2_build(const uint4 *cp, int64_t n_blk, uint4 *cp2, hipStream_t st) {
-    if (n_blk > 0) cp2_build_kernel<<<256 * 16, 256, 0, st>>>(cp, n_blk, cp2);
+size_t cp2_bytes(int64_t n_blk, int kind) { return kind == 2 ? (size_t)n_blk * 64 + 64 : (size_t)((n_blk + 1) >> 1) * 64 + 64; }
+void launch_cp2_build(const uint4 *cp, int64_t n_blk, uint4 *cp2, int kind, hipStream_t st) {
+    if (n_blk <= 0) return;
+    if (kind == 2) cpi_build_kernel<<<256 * 16, 256, 0, st>>>(cp, n_blk, cp2);
+    else cp2_build_kernel<<<256 * 16, 256, 0, st>>>(cp, n_blk, cp2);
 }
 
 static size_t lds_bytes(const SeedLaunch &a) { return a.reads_in_lds ? (size_t)a.read_w * kBlock * 4 : 0; }
@@ -1975,8 +2097,10 @@ int64_t seed_pool_slack(int cu_count) {
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
 
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st) {
-    if (a.fmi.cp2) smem_search_kernel<true, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
-    else smem_search_kernel<true, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
+    const int tab = a.fmi.cp2 ? a.fmi.tab_kind : 0;
+    if (tab == 2) smem_search_kernel<true, 2><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
+    else if (tab == 1) smem_search_kernel<true, 1><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
+    else smem_search_kernel<true, 0><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, nullptr);
 }
 
 void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap, int split_len,
@@ -1986,25 +2110,32 @@ void launch_round2_work(const SeedLaunch &a, Round2Work *work, int64_t work_cap,
 
 void launch_smem_round2(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     // the number of items is only known on the device: launch the persistent grid at chip size
-    if (a.fmi.cp2) smem_search_kernel<false, true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
-    else smem_search_kernel<false, false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+    const int tab = a.fmi.cp2 ? a.fmi.tab_kind : 0;
+    if (tab == 2) smem_search_kernel<false, 2><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+    else if (tab == 1) smem_search_kernel<false, 1><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
+    else smem_search_kernel<false, 0><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes_search(a), st>>>(a, work);
 }
 
 void launch_smem_fwd(const SeedLaunch &a, const Round2Work *work, int cu_count, hipStream_t st) {
     const int grid = cu_count * knobs().fwd_bpc;
+    const int tab = a.fmi.cp2 ? a.fmi.tab_kind : 0;
     if (!work) {
-        if (a.fmi.cp2) smem_fwd_kernel<true, true><<<grid, kBlock, lds_bytes(a), st>>>(a, nullptr);
-        else smem_fwd_kernel<true, false><<<grid, kBlock, lds_bytes(a), st>>>(a, nullptr);
+        if (tab == 2) smem_fwd_kernel<true, 2><<<grid, kBlock, lds_bytes(a), st>>>(a, nullptr);
+        else if (tab == 1) smem_fwd_kernel<true, 1><<<grid, kBlock, lds_bytes(a), st>>>(a, nullptr);
+        else smem_fwd_kernel<true, 0><<<grid, kBlock, lds_bytes(a), st>>>(a, nullptr);
     } else {
-        if (a.fmi.cp2) smem_fwd_kernel<false, true><<<grid, kBlock, lds_bytes(a), st>>>(a, work);
-        else smem_fwd_kernel<false, false><<<grid, kBlock, lds_bytes(a), st>>>(a, work);
+        if (tab == 2) smem_fwd_kernel<false, 2><<<grid, kBlock, lds_bytes(a), st>>>(a, work);
+        else if (tab == 1) smem_fwd_kernel<false, 1><<<grid, kBlock, lds_bytes(a), st>>>(a, work);
+        else smem_fwd_kernel<false, 0><<<grid, kBlock, lds_bytes(a), st>>>(a, work);
     }
 }
 
 void launch_smem_bwdl(const SeedLaunch &a, int cu_count, hipStream_t st) {
     const size_t lds = lds_bytes(a) + (size_t)kPrevLds * kBlock * 16;
-    if (a.fmi.cp2) smem_bwdl_kernel<true><<<cu_count * knobs().bwdl_bpc, kBlock, lds, st>>>(a);
-    else smem_bwdl_kernel<false><<<cu_count * knobs().bwdl_bpc, kBlock, lds, st>>>(a);
+    const int tab = a.fmi.cp2 ? a.fmi.tab_kind : 0;
+    if (tab == 2) smem_bwdl_kernel<2><<<cu_count * knobs().bwdl_bpc, kBlock, lds, st>>>(a);
+    else if (tab == 1) smem_bwdl_kernel<1><<<cu_count * knobs().bwdl_bpc, kBlock, lds, st>>>(a);
+    else smem_bwdl_kernel<0><<<cu_count * knobs().bwdl_bpc, kBlock, lds, st>>>(a);
 }
 
 void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st) {
@@ -2013,21 +2144,25 @@ void launch_smem_bwd_wave(const SeedLaunch &a, int cu_count, hipStream_t st) {
     const size_t lds = (size_t)(kBlock / 64) * (kBwdMaxList * 16 + 16 * (size_t)(a.read_w <= kBwdReadLds ? a.read_w : 0));
     const size_t lds_g = lds;
     const bool fused = knobs().bwd_fused != 0;
+    const int tab = a.fmi.cp2 ? a.fmi.tab_kind : 0;
     if (fused) {
-        if (a.fmi.cp2) smem_bwd_kernel<true><<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
-        else smem_bwd_kernel<false><<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
-    } else if (a.fmi.cp2) {
-        smem_bwd_role_kernel<0, true><<<cu_count * 8, kBlock, lds, st>>>(a);
-        smem_bwd_role_kernel<1, true><<<cu_count * 8, kBlock, lds_g, st>>>(a);
+        if (tab == 2) smem_bwd_kernel<2><<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
+        else if (tab == 1) smem_bwd_kernel<1><<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
+        else smem_bwd_kernel<0><<<cu_count * 8, kBlock, lds > lds_g ? lds : lds_g, st>>>(a);
+    } else if (tab == 2) {                     // (A-B switch: the two roles as two launches)
+        smem_bwd_role_kernel<0, 2><<<cu_count * 8, kBlock, lds, st>>>(a);
+        smem_bwd_role_kernel<1, 2><<<cu_count * 8, kBlock, lds_g, st>>>(a);
     } else {
-        smem_bwd_role_kernel<0, false><<<cu_count * 8, kBlock, lds, st>>>(a);
-        smem_bwd_role_kernel<1, false><<<cu_count * 8, kBlock, lds_g, st>>>(a);
+        smem_bwd_role_kernel<0, 0><<<cu_count * 8, kBlock, lds, st>>>(a);
+        smem_bwd_role_kernel<1, 0><<<cu_count * 8, kBlock, lds_g, st>>>(a);
     }
 }
 
 void launch_smem_round3(const SeedLaunch &a, int max_intv, int cu_count, hipStream_t st) {
-    if (a.fmi.cp2) seed_strategy_kernel<true><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
-    else seed_strategy_kernel<false><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
+    const int tab = a.fmi.cp2 ? a.fmi.tab_kind : 0;
+    if (tab == 2) seed_strategy_kernel<2><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
+    else if (tab == 1) seed_strategy_kernel<1><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
+    else seed_strategy_kernel<0><<<grid_for(a.nseq, cu_count), kBlock, lds_bytes(a), st>>>(a, max_intv);
 }
 
 void launch_make_keys(const bwams_smem_t *pool, int64_t n, uint64_t *keys, uint32_t *vals, uint32_t hole_key_rid,

@@ -16,8 +16,8 @@ bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
 
 
 def short(k):
-    for pat, name in (("smem_search_kernel<true>", "smem_search_kernel<true> (SMEM round 1)"),
-                      ("smem_search_kernel<false>", "smem_search_kernel<false> (SMEM round 2)"),
+    for pat, name in (("smem_search_kernel<true", "smem_search_kernel<true> (SMEM round 1)"),
+                      ("smem_search_kernel<false", "smem_search_kernel<false> (SMEM round 2)"),
                       ("smem_bwd_wave", "smem_bwd_wave_kernel (rounds 1 and 2: backward phases with long interval lists, wave per pivot; one launch behind each search kernel)"),
                       ("smem_bwd_kernel", "smem_bwd_kernel (rounds 1 and 2: the backward phases that left their lanes — a wavefront per pivot with a long list, sixteen lanes per pivot otherwise; one launch behind each search kernel)"),
                       ("seed_strategy", "seed_strategy_kernel (SMEM round 3; runs beside round 2 on a stream of its own: the durations overlap, 3.3 ms alone)"), ("sa_lookup", "sa_lookup_kernel"),
@@ -121,7 +121,7 @@ r1 = P["smem_search_kernel<true> (SMEM round 1)"]
 # passes of the hot path in one run = launches of SMEM round 1: the bench's steps (1 warm-up + 2 timed) and the three text-to-text
 # calls of its sam_side.fastq_to_sam leg (bwams_process_chunk runs the same kernels on the same reads)
 n_pass = N.get("smem_search_kernel<true> (SMEM round 1)", 3)
-n_pass_trace = sum(int(r["Calls"]) for r in rows if "smem_search_kernel<true>" in r["Name"]) or 3
+n_pass_trace = sum(int(r["Calls"]) for r in rows if "smem_search_kernel<true" in r["Name"]) or 3
 # round 1 = the search kernel + the wave kernel behind it (bench.py's HIP events bracket both)
 b1 = P.get(BWD1, {})
 fetch, write = (r1["FETCH_SIZE"] + b1.get("FETCH_SIZE", 0)) * 1024, (r1["WRITE_SIZE"] + b1.get("WRITE_SIZE", 0)) * 1024

@@ -41,6 +41,7 @@ void knobs_reload() {
     k.pair_drop_plan = getenv("BWAMS_PAIR_DROP_PLAN") != nullptr;
     k.trace_pair = env_int("BWAMS_TRACE_PAIR", 0);
     k.bsw_pk = env_int("BWAMS_BSW_PK", 1);
+    k.chain_batch = env_int("BWAMS_CHAIN_BATCH", 1);
     k.cp2 = env_int("BWAMS_CP2", 2);
     k.seed_split = env_int("BWAMS_SEED_SPLIT", 0);
     k.fwd_bpc = std::max(1, env_int("BWAMS_FWD_BPC", 8)); k.bwdl_bpc = std::max(1, env_int("BWAMS_BWDL_BPC", 6));

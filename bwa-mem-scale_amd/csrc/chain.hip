@@ -446,12 +446,40 @@ __device__ void wave_flt_introsort(uint2 *a, int n, uint16_t *tmp, int *stk, int
         }
     }
     // the closing insertion sort = THE stable sort of what the partitions left.  (Not a local clean-up: ksort's median of
-    // three never examines a[s], which may lie beyond the pivot and then travels a long way in the insertion sort.)  A rank
-    // sort: every lane counts, from uniform LDS reads, the elements that sort before its own.
+    // three never examines a[s], which may lie beyond the pivot and then travels a long way in the insertion sort.)  Stable =
+    // unique: up to 64 chains a rank sort (every lane counts, from uniform LDS reads, the elements that sort before its own);
+    // beyond, a sorting network over the 64-bit keys (weight descending, position ascending — no two equal), n log^2 n / 128
+    // compare-exchanges per lane instead of n^2 / 64 comparisons.  The network is the bitonic sorter in its standard form (every
+    // comparator leaves the smaller key at the lower index), so the pads of a power of two are virtual: a comparator whose upper
+    // end lies at or beyond n does nothing.  tmp: 16 * n bytes (keys, then the output copy).
     __syncthreads();
     uint2 *out = reinterpret_cast<uint2 *>(tmp);          // n * 8 bytes: the stopper lists are dead by now
-    for (int x0 = 0; x0 < n; x0 += 64) {
-        const int x = x0 + lane;
+    if (n > 64) {
+        unsigned long long *key = reinterpret_cast<unsigned long long *>(tmp);
+        out = reinterpret_cast<uint2 *>(key + n);
+        for (int x = lane; x < n; x += 64) key[x] = ((unsigned long long)(0x7fffffffu - a[x].x) << 32) | (unsigned long long)(unsigned)x;
+        __syncthreads();
+        int P = 128;
+        while (P < n) P <<= 1;
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const bool flip = j == (k >> 1);
+                for (int c0 = 0; c0 < (P >> 1); c0 += 64) {
+                    const int c = c0 + lane;
+                    const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));        // j is a power of two
+                    const int l = flip ? (i ^ (k - 1)) : i + j;
+                    if (l < n) {
+                        const unsigned long long x = key[i], y = key[l];
+                        if (y < x) { key[i] = y; key[l] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int x = lane; x < n; x += 64) out[x] = a[(uint32_t)key[x]];
+        __syncthreads();
+    } else {
+        const int x = lane;
         const uint2 v = x < n ? a[x] : make_uint2(0u, 0u);
         int pos = 0;
         for (int y = 0; y < n; ++y) {
@@ -459,8 +487,8 @@ __device__ void wave_flt_introsort(uint2 *a, int n, uint16_t *tmp, int *stk, int
             pos += (wy > v.x || (wy == v.x && y < x)) ? 1 : 0;
         }
         if (x < n) out[pos] = v;
+        __syncthreads();
     }
-    __syncthreads();
     for (int x = lane; x < n; x += 64) a[x] = out[x];
     __syncthreads();
 }
@@ -612,6 +640,216 @@ __device__ __forceinline__ void sarr_insert(int64_t *key, int32_t *cid, int n, i
     if (lane == 0) { key[at] = k; cid[at] = id; }
 }
 
+// ---- 64 seeds per pass (the wave tiers' ordered-array mode) ------------------------------------------------------------------------
+// mem_chain_seeds takes a read's seeds one after the other: look the seed's position up, test_and_merge with the chain found, else a
+// new chain.  One seed per trip of a wavefront is a chain of dependent LDS round trips (two for the lookup, the array entry, the chain
+// record, the insertion's shifts: ~1700 cycles per seed, and a read in a repeat family has thousands).  But the hits of ONE SMEM rarely
+// touch each other: they lie at different loci, each merges into the chain of its own locus or starts one.  So a pass takes 64 hits of
+// an SMEM, a lane each — binary search, chain record, test_and_merge against the state BEFORE the pass — and then settles, in seed
+// order, which of those decisions the sequential loop would have reached too:
+//   * a seed whose looked-up chain an earlier seed of the pass has extended: not settled (its test must see the new last seed);
+//   * a seed with a chain started by an earlier seed of the pass at a position between its looked-up one and its own: that chain is
+//     its true predecessor.  It holds one seed of the same SMEM (same query span), so test_and_merge reduces to "same sequence, same
+//     strand side, at most w further on": if that holds the seed would extend a chain born in this pass — not settled; if not, the
+//     seed starts a chain of its own, whatever its looked-up chain said;
+//   * otherwise the decision stands.
+// The pass commits the seeds before the first unsettled one — extensions scatter to distinct chain records, the new chains take ids
+// in seed order and their positions are merged into the ordered array in one sweep — and repeats with the rest.  Decisions and their
+// order are the sequential loop's, so chains, ids and seed lists are identical.  A pass that settles a single seed costs more than
+// the one-seed step, so after such a pass the next seeds are taken one at a time (tandem repeats: every hit extends the previous one's chain).
+struct SeedCtx {
+    const int64_t *pos;
+    int32_t *s_next;
+    int2 *s_ql;
+    ChainRec *crec;
+    int64_t *s_key;
+    int32_t *s_cid;
+};
+// one seed, the whole wave in lockstep: returns false when the read needs the B-tree
+__device__ __forceinline__ bool chain_seed_one(const ChainArgs &A, const SeedCtx &S, int &n_keys, int32_t g, int64_t rbeg, int rid, int qbeg,
+                                               int slen, int lane) {
+    const bool wr = lane == 0;
+    const int64_t l_pac = A.bns.l_pac;
+    bool to_add = true, eq = false;
+    int idx = -1;
+    if (n_keys) {
+        idx = sarr_lower(S.s_key, n_keys, rbeg, lane, eq);
+        if (idx >= 0) {
+            const int32_t lower = S.s_cid[idx];
+            const int64_t fr = S.s_key[idx];
+            ChainRec ch = S.crec[lower];
+            const int64_t lr = ch.last_rbeg;
+            const int64_t qend = ch.last_qbeg + ch.last_len, rend = lr + ch.last_len;
+            if (rid != ch.rid) to_add = true;
+            else if (qbeg >= ch.first_qbeg && qbeg + slen <= qend && rbeg >= fr && rbeg + slen <= rend) to_add = false;
+            else if ((lr < l_pac || fr < l_pac) && rbeg >= l_pac) to_add = true;
+            else {
+                const int64_t x = qbeg - ch.last_qbeg, y = rbeg - lr;
+                if (y >= 0 && x - y <= A.opt.w && y - x <= A.opt.w && x - ch.last_len < A.opt.max_chain_gap && y - ch.last_len < A.opt.max_chain_gap) {
+                    if (wr) { S.s_ql[g] = make_int2(qbeg, slen); S.s_next[g] = -1; S.s_next[ch.last_idx] = g; }
+                    if (qbeg >= ch.endq) ch.wq += slen; else if (qbeg + slen > ch.endq) ch.wq += qbeg + slen - ch.endq;
+                    ch.endq = (uint16_t)((int)ch.endq > qbeg + slen ? (int)ch.endq : qbeg + slen);
+                    if (rbeg >= ch.endr) ch.wr += slen; else if (rbeg + slen > ch.endr) ch.wr += (int)(rbeg + slen - ch.endr);
+                    ch.endr = ch.endr > rbeg + slen ? ch.endr : rbeg + slen;
+                    ch.last_rbeg = rbeg; ch.last_qbeg = (uint16_t)qbeg; ch.last_len = (uint16_t)slen; ch.last_idx = g; ch.n += 1;
+                    if (wr) S.crec[lower] = ch;
+                    to_add = false;
+                }
+            }
+        }
+    }
+    if (to_add) {
+        if (n_keys && eq) return false;                                           // a second chain at this position: the B-tree decides
+        if (wr) {
+            S.s_ql[g] = make_int2(qbeg, slen); S.s_next[g] = -1;
+            ChainRec ch;
+            ch.last_rbeg = rbeg; ch.endr = rbeg + slen;
+            ch.first_qbeg = (uint16_t)qbeg; ch.last_qbeg = (uint16_t)qbeg; ch.last_len = (uint16_t)slen; ch.endq = (uint16_t)(qbeg + slen);
+            ch.rid = rid; ch.n = 1; ch.first_idx = g; ch.last_idx = g; ch.wq = slen; ch.wr = slen;
+            S.crec[n_keys] = ch;
+        }
+        sarr_insert(S.s_key, S.s_cid, n_keys, n_keys ? idx + 1 : 0, rbeg, n_keys, lane);
+        ++n_keys;
+    }
+    return true;
+}
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
+    return (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
+                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)v, l));
+}
+// the hits [g0, g1) of one SMEM; all 64 lanes call this.  Returns false when the read needs the B-tree.
+__device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_keys, int32_t g0, int32_t g1, int qbeg, int slen, RidCache &rc, int lane) {
+    enum { NONE = 0, NOOP = 1, MERGE = 2, NEW = 3, UNSETTLED = 4 };
+    const int64_t l_pac = A.bns.l_pac;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int32_t gb = g0; gb < g1; gb += 64) {
+        const int32_t g = gb + lane;
+        bool pend = g < g1;
+        const int64_t rbeg = pend ? S.pos[g] : 0;
+        int rid = -1;
+        if (pend) { rid = intv2rid(A.bns, rbeg, rbeg + slen, rc); pend = rid >= 0; }
+        int one_by_one = 0;
+        unsigned long long mp;
+        while ((mp = __ballot(pend)) != 0ull) {
+            if (one_by_one) {                                                     // the first pending seed, on the whole wave
+                const int l0 = __builtin_ctzll(mp);
+                if (!chain_seed_one(A, S, n_keys, gb + l0, readlane64(rbeg, l0), __builtin_amdgcn_readlane(rid, l0), qbeg, slen, lane)) return false;
+                if (lane == l0) pend = false;
+                --one_by_one;
+                continue;
+            }
+            const int n = n_keys;
+            // lookup: the greatest key <= rbeg, a binary search per lane
+            int idx = -1;
+            if (n) {
+                int step = 1;
+                while ((step << 1) <= n) step <<= 1;
+                for (; step > 0; step >>= 1) {
+                    const int t = idx + step;
+                    if (pend && t < n && S.s_key[t] <= rbeg) idx = t;
+                }
+            }
+            int64_t lo_key = INT64_MIN;
+            int32_t lower = -1;
+            int act = NONE;
+            ChainRec ch;
+            ch.last_rbeg = 0; ch.endr = 0; ch.first_qbeg = ch.last_qbeg = ch.last_len = ch.endq = 0; ch.rid = ch.n = ch.first_idx = ch.last_idx = ch.wq = ch.wr = 0;
+            if (pend) {
+                act = NEW;
+                if (idx >= 0) {
+                    lo_key = S.s_key[idx];
+                    lower = S.s_cid[idx];
+                    ch = S.crec[lower];
+                    const int64_t lr = ch.last_rbeg;
+                    const int64_t qend = ch.last_qbeg + ch.last_len, rend = lr + ch.last_len;
+                    if (rid != ch.rid) act = NEW;
+                    else if (qbeg >= ch.first_qbeg && qbeg + slen <= qend && rbeg >= lo_key && rbeg + slen <= rend) act = NOOP;
+                    else if ((lr < l_pac || lo_key < l_pac) && rbeg >= l_pac) act = NEW;
+                    else {
+                        const int64_t x = qbeg - ch.last_qbeg, y = rbeg - lr;
+                        if (y >= 0 && x - y <= A.opt.w && y - x <= A.opt.w && x - ch.last_len < A.opt.max_chain_gap && y - ch.last_len < A.opt.max_chain_gap)
+                            act = MERGE;
+                    }
+                }
+            }
+            const bool eq = pend && idx >= 0 && lo_key == rbeg;
+            // settle in seed order
+            int64_t best = lo_key;                   // the greatest position <= rbeg among the looked-up chain and the chains earlier seeds of this pass start
+            int best_rid = -1;
+            bool displaced = false, touched = false;
+            int first_open = 64;
+            unsigned long long rem = mp;
+            while (rem) {
+                const int i = __builtin_ctzll(rem);
+                rem &= rem - 1;
+                int fin = act;
+                if (displaced) {
+                    const int64_t y = rbeg - best;
+                    const bool ext = rid == best_rid && !(best < l_pac && rbeg >= l_pac) && y <= A.opt.w && y - slen < A.opt.max_chain_gap;
+                    fin = ext ? UNSETTLED : NEW;
+                } else if (touched) fin = UNSETTLED;
+                const int a_i = __builtin_amdgcn_readlane(fin, i);
+                if (a_i == UNSETTLED) { first_open = i; break; }
+                if (lane == i) act = fin;
+                if (a_i == NEW) {
+                    const int64_t rb_i = readlane64(rbeg, i);
+                    const int rid_i = __builtin_amdgcn_readlane(rid, i);
+                    if (lane > i && rb_i <= rbeg && rb_i > best) { best = rb_i; best_rid = rid_i; displaced = true; }
+                } else if (a_i == MERGE) {
+                    const int low_i = __builtin_amdgcn_readlane(lower, i);
+                    if (lane > i && lower == low_i) touched = true;
+                }
+            }
+            const bool com = pend && lane < first_open;
+            const unsigned long long m_new = __ballot(com && act == NEW);
+            if (n && __ballot(com && act == NEW && eq)) return false;             // a second chain at a position: the B-tree decides
+            if (com && act == MERGE) {
+                S.s_ql[g] = make_int2(qbeg, slen); S.s_next[g] = -1; S.s_next[ch.last_idx] = g;
+                if (qbeg >= ch.endq) ch.wq += slen; else if (qbeg + slen > ch.endq) ch.wq += qbeg + slen - ch.endq;
+                ch.endq = (uint16_t)((int)ch.endq > qbeg + slen ? (int)ch.endq : qbeg + slen);
+                if (rbeg >= ch.endr) ch.wr += slen; else if (rbeg + slen > ch.endr) ch.wr += (int)(rbeg + slen - ch.endr);
+                ch.endr = ch.endr > rbeg + slen ? ch.endr : rbeg + slen;
+                ch.last_rbeg = rbeg; ch.last_qbeg = (uint16_t)qbeg; ch.last_len = (uint16_t)slen; ch.last_idx = g; ch.n += 1;
+                S.crec[lower] = ch;
+            }
+            if (m_new) {
+                const int m = __popcll(m_new);
+                const bool mine = com && act == NEW;
+                // the old entries move up by the number of new positions below them, top chunk first (a chunk is read whole before it is written)
+                int min_idx = n;
+                { unsigned long long mm = m_new; while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; const int x = __builtin_amdgcn_readlane(idx, i); min_idx = x < min_idx ? x : min_idx; } }
+                for (int base = n > 0 ? ((n - 1) >> 6) << 6 : -64; base >= 0 && base + 63 > min_idx; base -= 64) {
+                    const int p = base + lane;
+                    const bool mv = p < n;
+                    const int64_t kk = mv ? S.s_key[p] : 0;
+                    const int32_t cc = mv ? S.s_cid[p] : 0;
+                    int sh = 0;
+                    unsigned long long mm = m_new;
+                    while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; sh += __builtin_amdgcn_readlane(idx, i) < p ? 1 : 0; }
+                    if (mv && sh) { S.s_key[p + sh] = kk; S.s_cid[p + sh] = cc; }
+                }
+                int rank = 0;                        // new positions below mine
+                { unsigned long long mm = m_new; while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; rank += readlane64(rbeg, i) < rbeg ? 1 : 0; } }
+                if (mine) {
+                    const int32_t cid = n + __popcll(m_new & below);              // chains are numbered in creation order
+                    S.s_ql[g] = make_int2(qbeg, slen); S.s_next[g] = -1;
+                    ChainRec nc;
+                    nc.last_rbeg = rbeg; nc.endr = rbeg + slen;
+                    nc.first_qbeg = (uint16_t)qbeg; nc.last_qbeg = (uint16_t)qbeg; nc.last_len = (uint16_t)slen; nc.endq = (uint16_t)(qbeg + slen);
+                    nc.rid = rid; nc.n = 1; nc.first_idx = g; nc.last_idx = g; nc.wq = slen; nc.wr = slen;
+                    S.crec[cid] = nc;
+                    S.s_key[idx + 1 + rank] = rbeg; S.s_cid[idx + 1 + rank] = cid;
+                }
+                n_keys = n + m;
+            }
+            if (com) pend = false;
+            if (__popcll(__ballot(com)) <= 1) one_by_one = 8;
+            __threadfence_block();
+        }
+    }
+    return true;
+}
+
 // CONT = 0: kbtree (exact for any input); CONT = 1: sorted array, returns false when the read needs the B-tree
 template <bool LDS, int CONT = 0, bool CREC_HBM = false>
 __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int lane, int nl, Node *nodes, int32_t cap_nodes,
@@ -674,6 +912,20 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
     if (LDS && cnt > cap_chains) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return true; }
 
     const int64_t l_pac = A.bns.l_pac;
+    if constexpr (CONT == 1) {
+        if (nl == 64 && A.seed_batch) {          // 64 seeds per pass
+            SeedCtx S;
+            S.pos = pos; S.s_next = s_next; S.s_ql = s_ql; S.crec = crec; S.s_key = s_key; S.s_cid = s_cid;
+            int nk = 0;
+            for (int64_t i = beg; i < end; ++i) {
+                const int qbeg = (int)sm[i].m, slen = (int)sm[i].n + 1 - (int)sm[i].m;
+                const int32_t g0 = (int32_t)(A.sa_off[i] - base), g1 = (int32_t)(A.sa_off[i + 1] - base);
+                if (!chain_seeds_batch(A, S, nk, g0, g1, qbeg, slen, rc, lane)) return false;
+            }
+            c.n_keys = nk;
+        }
+    }
+    if (!(CONT == 1 && nl == 64 && A.seed_batch))
     for (int64_t i = beg; i < end; ++i) {
         const int qbeg = (int)sm[i].m, slen = (int)sm[i].n + 1 - (int)sm[i].m;
         const int32_t g0 = (int32_t)(A.sa_off[i] - base), g1 = (int32_t)(A.sa_off[i + 1] - base);
@@ -761,6 +1013,25 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
     } else n_trav = kbt_traverse(c, ord);
     uint2 *fl = A.flt + base;
     int n_chn = 0;
+    if (nl == 64) {                             // 64 chains per trip: a chain per trip waited for ord[t] and crec[id] one after the other
+        uint2 first = make_uint2(0u, 0u);
+        for (int32_t t0 = 0; t0 < n_trav; t0 += 64) {
+            const int32_t t = t0 + lane;
+            const bool ok = t < n_trav;
+            int32_t id = 0;
+            if (ok) { if constexpr (CONT == 1) id = s_cid[t]; else id = ord[t]; }
+            const ChainRec *pc = &crec[id];
+            int w = pc->wr < pc->wq ? pc->wr : pc->wq;
+            w = w < (1 << 30) ? w : (1 << 30) - 1;
+            if (t0 == 0) first = make_uint2((unsigned)__builtin_amdgcn_readfirstlane(w), (unsigned)__builtin_amdgcn_readfirstlane(id));
+            const bool keep = ok && w >= A.opt.min_chain_weight;
+            const unsigned long long m = __ballot(keep);
+            if (keep) fl[n_chn + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((unsigned)w, (unsigned)id);
+            n_chn += __popcll(m);
+        }
+        if (n_chn == 0 && wr) fl[0] = first;    // a_[0] stays in place when everything is dropped
+        __threadfence_block();                  // fl is read back by lane 0 (light reads) below
+    } else
     for (int32_t t = 0; t < n_trav; ++t) {
         const int32_t id = ord[t];
         const ChainRec ch = crec[id];
@@ -854,9 +1125,9 @@ __global__ __launch_bounds__(64) void chain_redo_kernel(ChainArgs A) {
 // with thousands (reads in repeat families reach max_occ hits per SMEM: on a GRCh38-size index a read can carry > 2000
 // chains, and the quadratic filter of such a read on one lane through HBM took 40 ms).  Every launch walks the whole
 // list of many-chain reads with its own ticket counter and skips the other classes' reads.
-constexpr int kHeavyCap[3] = {256, 960, 3840};         // 10.5 / 39 / 157 KB of LDS
+constexpr int kHeavyCap[5] = {128, 256, 512, 960, 3840};         // 5 / 10.5 / 21 / 39 / 157 KB of LDS
 __host__ __device__ constexpr size_t heavy_lds_bytes(int cap) { return (size_t)cap * 41 + 64; }
-static_assert(heavy_lds_bytes(kHeavyCap[2]) <= 160 * 1024, "the largest class must fit one CU's LDS");
+static_assert(heavy_lds_bytes(kHeavyCap[4]) <= 160 * 1024, "the largest class must fit one CU's LDS");
 
 __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsigned long long *n_heavy_p, int cap_lo, int cap,
                                                          unsigned long long *ticket) {
@@ -874,7 +1145,7 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
         const int64_t r = A.heavy[hi];
         const int64_t base = A.read_base[r];
         const int n_chn = A.n_chn[r];
-        if (n_chn <= cap_lo || (n_chn > cap && cap != kHeavyCap[2])) continue;          // another class's read
+        if (n_chn <= cap_lo || (n_chn > cap && cap != kHeavyCap[4])) continue;          // another class's read
         const int L = (int)(A.cum[r + 1] - A.cum[r]);
         uint2 *fl = A.flt + base;
         uint4 *rec = A.f_rec + base;
@@ -908,65 +1179,74 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
             l_kept[i] = 0;
         }
         __syncthreads();
-        // pairwise filter: chain i against the chains selected so far, 64 at a time.  The sequential
-        // loop visits them in selection order and stops at the first one that drops chain i; every
-        // selected chain visited up to there with a large overlap records i as its first shadowed hit.
+        // pairwise filter (mem_chain_flt, bwamem.cpp:575-617).  The sequential loop takes chain i through the chains selected so far,
+        // in selection order, up to the first one that drops it; every selected chain it meets on the way with a large overlap
+        // records i as its first shadowed chain if it has none yet.  Here SIXTY-FOUR candidates go through the selection at once, a
+        // lane each: first through the chains selected before the batch (one broadcast LDS read per selected chain for all 64
+        // lanes), then through the batch's own survivors in order (candidate l' is selected iff it is still alive when every
+        // earlier candidate has been resolved; its record reaches the later lanes through v_readlane).  `first` is the SMALLEST
+        // candidate that meets the chain: ds_min on the 0xffffffff-initialised field, issued by the lowest such lane — no round trip.
+        // One candidate at a time against 64 selected chains per trip cost ~1800 cycles of latency per chain, whatever the selection's size.
         int n_sel = 1;
         if (lane == 0) { const uint4 r0 = l_rec[0]; l_sel[0] = make_uint4(r0.x, r0.y, r0.z, 0u); l_kept[0] = 3; }
         __syncthreads();
-        for (int i = 1; i < n_chn; ++i) {
-            const uint4 ri = l_rec[i];
-            const int bi = (int)ri.x, ei = (int)ri.y, wi = (int)(ri.z & 0x7fffffffu);
+        const float mask_level = A.opt.mask_level, drop_ratio = A.opt.drop_ratio;
+        const int max_gap = A.opt.max_chain_gap, min_dw = A.opt.min_seed_len << 1;
+        for (int ib = 1; ib < n_chn; ib += 64) {
+            const int i = ib + lane;
+            const bool valid = i < n_chn;
+            const uint4 ri = valid ? l_rec[i] : make_uint4(0, 0, 0, 0);
+            const int bi = (int)ri.x, ei = (int)ri.y, wi = (int)(ri.z & 0x7fffffffu), li = ei - bi;
             const bool alt_i = (ri.z >> 31) != 0;
-            bool large_ovlp = false, dropped = false;
-            // four chunks of 64 selected chains per trip: their LDS loads and tests are independent, only the resolution
-            // (first drop, shadow marks up to it) goes chunk by chunk — a read with thousands of equal-weight chains scans its
-            // whole selection for every chain, and one chunk per trip left that scan waiting on one LDS round trip at a time
-            for (int kb = 0; kb < n_sel && !dropped; kb += 256) {
-                bool lg[4], br[4];
+            const float fwi = (float)wi;
+            bool alive = valid, large = false;
+            const int n_sel0 = n_sel;
+            for (int k0 = 0; k0 < n_sel0; k0 += 4) {
                 uint4 rj[4];
 #pragma unroll
+                for (int u = 0; u < 4; ++u) rj[u] = l_sel[k0 + u < n_sel0 ? k0 + u : n_sel0 - 1];
+#pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int k = kb + 64 * u + lane;
-                    lg[u] = false; br[u] = false;
-                    rj[u] = make_uint4(0, 0, 0, 0);
-                    if (k < n_sel) {
-                        rj[u] = l_sel[k];
-                        const int bj = (int)rj[u].x, ej = (int)rj[u].y;
-                        const int b_max = bj > bi ? bj : bi;
-                        const int e_min = ej < ei ? ej : ei;
-                        const bool alt_j = (rj[u].z >> 31) != 0;
-                        if (e_min > b_max && (!alt_j || alt_i)) {
-                            const int li = ei - bi, lj = ej - bj;
-                            const int min_l = li < lj ? li : lj;
-                            if ((float)(e_min - b_max) >= (float)min_l * A.opt.mask_level && min_l < A.opt.max_chain_gap) {
-                                lg[u] = true;
-                                const int wj = (int)(rj[u].z & 0x7fffffffu);
-                                br[u] = (float)wi < (float)wj * A.opt.drop_ratio && wj - wi >= (A.opt.min_seed_len << 1);
-                            }
+                    if (k0 + u >= n_sel0) break;
+                    const int bj = (int)rj[u].x, ej = (int)rj[u].y;
+                    const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+                    const bool alt_j = (rj[u].z >> 31) != 0;
+                    const int lj = ej - bj, min_l = li < lj ? li : lj;
+                    const bool lg = alive && e_min > b_max && (!alt_j || alt_i) && (float)(e_min - b_max) >= (float)min_l * mask_level && min_l < max_gap;
+                    const unsigned long long m_lg = __ballot(lg);
+                    if (m_lg) {
+                        if (lane == __builtin_ctzll(m_lg)) atomicMin(&l_rec[rj[u].w].w, (uint32_t)i);
+                        if (lg) {
+                            large = true;
+                            const int wj = (int)(rj[u].z & 0x7fffffffu);
+                            if (fwi < (float)wj * drop_ratio && wj - wi >= min_dw) alive = false;
                         }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (dropped || kb + 64 * u >= n_sel) break;
-                    const unsigned long long m_br = __ballot(br[u]);
-                    unsigned long long m_lg = __ballot(lg[u]);
-                    if (m_br) {
-                        const int first_br = __ffsll((long long)m_br) - 1;
-                        m_lg &= first_br == 63 ? ~0ull : ((2ull << first_br) - 1ull);
-                        dropped = true;
-                    }
-                    if (m_lg) large_ovlp = true;
-                    if (lg[u] && ((m_lg >> lane) & 1ull)) {         // `first` of selected chain j = rj.w (its sorted position)
-                        uint4 *pj = &l_rec[rj[u].w];
-                        if ((int)pj->w < 0) pj->w = (uint32_t)i;
+                if (!__ballot(alive)) break;
+            }
+            // the batch's own survivors, in order
+            unsigned long long todo = __ballot(alive);
+            while (todo) {
+                const int lp = __builtin_ctzll(todo);                                    // alive, and every earlier candidate resolved: selected
+                const int bj = __builtin_amdgcn_readlane(bi, lp), ej = __builtin_amdgcn_readlane(ei, lp);
+                const uint32_t zj = (uint32_t)__builtin_amdgcn_readlane((int)ri.z, lp);
+                if (lane == lp) { l_sel[n_sel] = make_uint4(ri.x, ri.y, ri.z, (uint32_t)i); l_kept[i] = large ? 2 : 3; }
+                ++n_sel;
+                const int b_max = bj > bi ? bj : bi, e_min = ej < ei ? ej : ei;
+                const bool alt_j = (zj >> 31) != 0;
+                const int lj = ej - bj, min_l = li < lj ? li : lj;
+                const bool lg = alive && lane > lp && e_min > b_max && (!alt_j || alt_i) && (float)(e_min - b_max) >= (float)min_l * mask_level && min_l < max_gap;
+                const unsigned long long m_lg = __ballot(lg);
+                if (m_lg) {
+                    if (lane == __builtin_ctzll(m_lg)) l_rec[ib + lp].w = (uint32_t)i;     // just selected: nobody has met it before
+                    if (lg) {
+                        large = true;
+                        const int wj = (int)(zj & 0x7fffffffu);
+                        if (fwi < (float)wj * drop_ratio && wj - wi >= min_dw) alive = false;
                     }
                 }
-            }
-            if (!dropped) {
-                if (lane == 0) { l_sel[n_sel] = make_uint4(ri.x, ri.y, ri.z, (uint32_t)i); l_kept[i] = large_ovlp ? 2 : 3; }
-                ++n_sel;
+                todo = __ballot(alive) & ~((2ull << lp) - 1ull);
             }
             __syncthreads();
         }
@@ -1119,19 +1399,23 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     chain_redo_kernel<<<(unsigned)(cu_count * 2), 64, 0, st>>>(A);
     // the filter of the many-chain reads: three size classes, concurrently, the class of the longest reads first
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(chain_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)heavy_lds_bytes(kHeavyCap[2])) != hipSuccess) return -1;
+                            (int)heavy_lds_bytes(kHeavyCap[4])) != hipSuccess) return -1;
     if (hipEventRecord(fork, st) != hipSuccess) return -1;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
     unsigned long long *htk = A.ctr->heavy_tickets;
     // The class of the longest reads (a whole CU's LDS per read, a few dozen reads per million) goes on the batch's own stream: it
     // starts without waiting for the fork event, i.e. before the other classes' blocks have filled every CU's LDS — behind them
     // (kernel trace) its blocks found no CU with 157 KB free until the other classes drained: 16.8 ms for 26 reads of ~4 ms.
     // Its blocks without a read leave at once.
-    chain_heavy_kernel<<<(unsigned)cu_count, 64, heavy_lds_bytes(kHeavyCap[2]), st>>>(A, &A.ctr->n_heavy, kHeavyCap[1], kHeavyCap[2], htk + 2);
-    chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, heavy_lds_bytes(kHeavyCap[1]), aux[1]>>>(A, &A.ctr->n_heavy, kHeavyCap[0], kHeavyCap[1], htk + 1);
-    chain_heavy_kernel<<<(unsigned)(cu_count * 12), 64, heavy_lds_bytes(kHeavyCap[0]), aux[0]>>>(A, &A.ctr->n_heavy, 0, kHeavyCap[0], htk + 0);
-    for (int i = 0; i < 2; ++i) {
+    // (round 4: five classes instead of three — a wave of this kernel runs on LDS latency, so what a class's footprint leaves of a CU's
+    // occupancy is its speed: the 257..512-chain reads ran four to a CU under the 960 class's 39 KB)
+    chain_heavy_kernel<<<(unsigned)cu_count, 64, heavy_lds_bytes(kHeavyCap[4]), st>>>(A, &A.ctr->n_heavy, kHeavyCap[3], kHeavyCap[4], htk + 4);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, heavy_lds_bytes(kHeavyCap[3]), aux[1]>>>(A, &A.ctr->n_heavy, kHeavyCap[2], kHeavyCap[3], htk + 3);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 7), 64, heavy_lds_bytes(kHeavyCap[2]), aux[2]>>>(A, &A.ctr->n_heavy, kHeavyCap[1], kHeavyCap[2], htk + 2);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 12), 64, heavy_lds_bytes(kHeavyCap[1]), aux[0]>>>(A, &A.ctr->n_heavy, kHeavyCap[0], kHeavyCap[1], htk + 1);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 16), 64, heavy_lds_bytes(kHeavyCap[0]), aux[3]>>>(A, &A.ctr->n_heavy, 0, kHeavyCap[0], htk + 0);
+    for (int i = 0; i < 4; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;
     }

@@ -41,6 +41,7 @@ struct ChainArgs {
     const uint32_t *order;         // read ids by descending seed count
     float *frac_rep;
     int32_t *redo;                 // reads to chain again with the B-tree (a chain position repeated)
+    int32_t seed_batch;            // wave tier: 64 seeds per pass (chain_seeds_batch) instead of one
     DevCounters *ctr;
 };
 

@@ -35,6 +35,7 @@ struct Knobs {
     int pair_drop_plan = 0;        // BWAMS_PAIR_DROP_PLAN: exercise mate rescue's second pass
     int trace_pair = 0;            // BWAMS_TRACE_PAIR: a synchronisation and a line per launch of the paired-end tail
     int bsw_pk = 1;                // BWAMS_BSW_PK=0: the 32-bit eight-task banded-SW kernel
+    int chain_batch = 1;           // BWAMS_CHAIN_BATCH=0: chaining's wave tier takes one seed at a time (chain.hip: chain_seeds_batch)
     int fwd_bpc = 8, bwdl_bpc = 6; // BWAMS_FWD_BPC / BWAMS_BWDL_BPC: workgroups per CU of the forward / backward lane kernels (lab)
     int seed_split = 0;            // BWAMS_SEED_SPLIT=1: SMEM rounds 1 and 2 as a forward kernel + a backward kernel (fmi_seed.hip)
     int cp2 = 2;                   // BWAMS_CP2: the table the SMEM search kernels read — 2 (default): the INTERLEAVED form of CP_OCC (piece b = count and
@@ -126,8 +127,7 @@ struct DevCounters {
     unsigned long long n_heavy;          // chaining: reads handed to the wave-per-read filter kernel
     unsigned long long chain_class[9];   // chaining: reads with more seeds than the L, L1, M, M1, S, lane-tier, XL, L2 and M2 limits
     unsigned long long chain_ticket[9];  // chaining: work cursors of the wave kernels
-    unsigned long long heavy_ticket;     // (unused)
-    unsigned long long heavy_tickets[3]; // chaining: work cursors of chain_heavy_kernel's size classes
+    unsigned long long heavy_tickets[6]; // chaining: work cursors of chain_heavy_kernel's size classes (five used)
     unsigned long long n_retry;          // extension: tasks queued for the next band width
     unsigned long long n_req;            // extension: seeds requested by the last selection
     unsigned long long sel_heavy, sel_ticket, sel_ticket2, sel_ticket3;   // extension: reads of the selection's wave tier; work cursors: the small class, the big class' two passes

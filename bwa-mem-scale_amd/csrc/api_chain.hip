@@ -397,7 +397,7 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
 
     BWAMS_HIP(hipEventRecord(s->ev[0], st));
     BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_redo, 0, 2 * sizeof(unsigned long long), st));
-    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 27 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[9], chain_ticket[9], heavy_tickets[6]
+    BWAMS_HIP(hipMemsetAsync(&b->d_ctr->chain_overflow, 0, 29 * sizeof(unsigned long long), st));   // overflow, longread, n_heavy, chain_class[10], chain_ticket[10], heavy_tickets[6]
     // mem_chain_seeds' loop guard `pos < num_smem - 1` (bwamem.cpp:819) makes a work item with exactly
     // one SMEM produce no chain at all
     if ((sv.one_smem_quirk ? sv.n_smem <= 1 : sv.n_smem <= 0) || n_sa == 0) {

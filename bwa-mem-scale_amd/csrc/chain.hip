@@ -70,7 +70,10 @@ constexpr int kClassS = 128, kClassM1 = 256, kClassM = 512, kClassL1 = 850, kCla
 constexpr int kClassM2 = 665, kClassL2 = 1275;
 static_assert(lds_bytes(kClassL) <= 160 * 1024, "class L must fit one CU's LDS");
 // class XL: reads beyond class L keep only the ordered array (12 B per chain) in LDS, the chain records in HBM
-constexpr int kClassXL = 4096;       // sarr_lower finds the 64-key chunk with one ballot: at most 64 chunks
+constexpr int kClassXL = 4096;       // 49 KB
+// class XL2 (round 4): on a repeat-rich genome reads reach 10^4 seeds (a dozen SMEMs with max_occ hits each); beyond class XL they went
+// through the B-tree in HBM one seed at a time: 40 ms for a handful of reads, the stage's long pole on the grch38_like genome
+constexpr int kClassXL2 = 13000;     // 156 KB: a CU's LDS
 __host__ __device__ constexpr size_t lds_bytes_xl(int K) { return (size_t)K * 12 + 64; }
 
 // bns_pos2rid / bns_intv2rid (bntseq.cpp:397-421) with a one-entry cache of the last sequence found
@@ -600,6 +603,7 @@ __global__ void chain_count_kernel(ChainArgs A, uint32_t *keys, uint32_t *vals) 
         if (cnt > kClassXL) atomicAdd(&A.ctr->chain_class[6], 1ull);      // [0, c[6]) beyond XL, [c[6], c[0]) XL
         if (cnt > kClassL2) atomicAdd(&A.ctr->chain_class[7], 1ull);      // [c[0], c[7]) class L, [c[7], c[1]) class L2
         if (cnt > kClassM2) atomicAdd(&A.ctr->chain_class[8], 1ull);      // [c[1], c[8]) class L1, [c[8], c[2]) class M2
+        if (cnt > kClassXL2) atomicAdd(&A.ctr->chain_class[9], 1ull);     // [0, c[9]) beyond XL2 (HBM), [c[9], c[6]) XL2
     }
 }
 
@@ -618,6 +622,15 @@ __global__ void chain_count_kernel(ChainArgs A, uint32_t *keys, uint32_t *vals) 
 // meets, where a duplicate lands): inserting a position that is already present makes the attempt give up, and the
 // read is chained again with the B-tree (chain_redo_kernel).
 __device__ __forceinline__ int sarr_lower(const int64_t *key, int n, int64_t k, int lane, bool &eq) {
+    int base = 0;
+    if (n > 4096) {                                                                 // a level above: 4096-key stretches (n <= 2^18)
+        const int nsc = (n + 4095) >> 12;
+        const unsigned long long ms = __ballot(lane < nsc && key[lane << 12] <= k);
+        if (!ms) { eq = false; return -1; }
+        base = (__popcll(ms) - 1) << 12;
+        key += base;
+        n = n - base < 4096 ? n - base : 4096;
+    }
     const int nch = (n + 63) >> 6;
     const unsigned long long mc = __ballot(lane < nch && key[lane << 6] <= k);      // chunks whose first key is <= k
     if (!mc) { eq = false; return -1; }
@@ -625,7 +638,7 @@ __device__ __forceinline__ int sarr_lower(const int64_t *key, int n, int64_t k, 
     const int i = (c << 6) + lane;
     const int64_t my = i < n ? key[i] : 0;
     const unsigned long long mk = __ballot(i < n && my <= k);
-    const int idx = (c << 6) + __popcll(mk) - 1;
+    const int idx = base + (c << 6) + __popcll(mk) - 1;
     eq = __ballot(i < n && my == k) != 0;
     return idx;
 }
@@ -1125,9 +1138,9 @@ __global__ __launch_bounds__(64) void chain_redo_kernel(ChainArgs A) {
 // with thousands (reads in repeat families reach max_occ hits per SMEM: on a GRCh38-size index a read can carry > 2000
 // chains, and the quadratic filter of such a read on one lane through HBM took 40 ms).  Every launch walks the whole
 // list of many-chain reads with its own ticket counter and skips the other classes' reads.
-constexpr int kHeavyCap[5] = {128, 256, 512, 960, 3840};         // 5 / 10.5 / 21 / 39 / 157 KB of LDS
+constexpr int kHeavyCap[6] = {64, 128, 256, 512, 960, 3840};         // 2.7 / 5 / 10.5 / 21 / 39 / 157 KB of LDS
 __host__ __device__ constexpr size_t heavy_lds_bytes(int cap) { return (size_t)cap * 41 + 64; }
-static_assert(heavy_lds_bytes(kHeavyCap[4]) <= 160 * 1024, "the largest class must fit one CU's LDS");
+static_assert(heavy_lds_bytes(kHeavyCap[5]) <= 160 * 1024, "the largest class must fit one CU's LDS");
 
 __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsigned long long *n_heavy_p, int cap_lo, int cap,
                                                          unsigned long long *ticket) {
@@ -1145,7 +1158,7 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
         const int64_t r = A.heavy[hi];
         const int64_t base = A.read_base[r];
         const int n_chn = A.n_chn[r];
-        if (n_chn <= cap_lo || (n_chn > cap && cap != kHeavyCap[4])) continue;          // another class's read
+        if (n_chn <= cap_lo || (n_chn > cap && cap != kHeavyCap[5])) continue;          // another class's read
         const int L = (int)(A.cum[r + 1] - A.cum[r]);
         uint2 *fl = A.flt + base;
         uint4 *rec = A.f_rec + base;
@@ -1371,7 +1384,7 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     // the opt-in for more than 64 KB of dynamic LDS belongs to the CURRENT device: set per launch (a batch on a second GPU of the
     // process needs it too), and checked
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes(kClassL)) != hipSuccess) return -1;
+                            (int)lds_bytes_xl(kClassXL2)) != hipSuccess) return -1;
     if (hipEventRecord(fork, st) != hipSuccess) return -1;
     for (int i = 0; i < 7; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
@@ -1380,7 +1393,8 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     // waves — no LDS limits them; at GRCh38 size, with max_occ hits per repeat SMEM, they were the stage's long pole on two)
     // (class XL, round 2: the five reads per million beyond class L — 2915 seeds the longest — took 19.5 ms in the HBM tier and
     // were the stage's long pole; with the ordered array in LDS only their chain records are in HBM)
-    chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, 0, aux[0]>>>(A, nullptr, cls + 6, tk + 0, 0);
+    chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, 0, aux[0]>>>(A, nullptr, cls + 9, tk + 0, 0);
+    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes_xl(kClassXL2), aux[0]>>>(A, cls + 9, cls + 6, tk + 9, -kClassXL2);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes_xl(kClassXL), aux[0]>>>(A, cls + 6, cls + 0, tk + 6, -kClassXL);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[1]>>>(A, cls + 0, cls + 7, tk + 1, kClassL);
     chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, lds_bytes(kClassL2), aux[5]>>>(A, cls + 7, cls + 1, tk + 7, kClassL2);
@@ -1399,9 +1413,9 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     chain_redo_kernel<<<(unsigned)(cu_count * 2), 64, 0, st>>>(A);
     // the filter of the many-chain reads: three size classes, concurrently, the class of the longest reads first
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(chain_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)heavy_lds_bytes(kHeavyCap[4])) != hipSuccess) return -1;
+                            (int)heavy_lds_bytes(kHeavyCap[5])) != hipSuccess) return -1;
     if (hipEventRecord(fork, st) != hipSuccess) return -1;
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (hipStreamWaitEvent(aux[i], fork, 0) != hipSuccess) return -1;
     unsigned long long *htk = A.ctr->heavy_tickets;
     // The class of the longest reads (a whole CU's LDS per read, a few dozen reads per million) goes on the batch's own stream: it
@@ -1410,12 +1424,13 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     // Its blocks without a read leave at once.
     // (round 4: five classes instead of three — a wave of this kernel runs on LDS latency, so what a class's footprint leaves of a CU's
     // occupancy is its speed: the 257..512-chain reads ran four to a CU under the 960 class's 39 KB)
-    chain_heavy_kernel<<<(unsigned)cu_count, 64, heavy_lds_bytes(kHeavyCap[4]), st>>>(A, &A.ctr->n_heavy, kHeavyCap[3], kHeavyCap[4], htk + 4);
-    chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, heavy_lds_bytes(kHeavyCap[3]), aux[1]>>>(A, &A.ctr->n_heavy, kHeavyCap[2], kHeavyCap[3], htk + 3);
-    chain_heavy_kernel<<<(unsigned)(cu_count * 7), 64, heavy_lds_bytes(kHeavyCap[2]), aux[2]>>>(A, &A.ctr->n_heavy, kHeavyCap[1], kHeavyCap[2], htk + 2);
-    chain_heavy_kernel<<<(unsigned)(cu_count * 12), 64, heavy_lds_bytes(kHeavyCap[1]), aux[0]>>>(A, &A.ctr->n_heavy, kHeavyCap[0], kHeavyCap[1], htk + 1);
-    chain_heavy_kernel<<<(unsigned)(cu_count * 16), 64, heavy_lds_bytes(kHeavyCap[0]), aux[3]>>>(A, &A.ctr->n_heavy, 0, kHeavyCap[0], htk + 0);
-    for (int i = 0; i < 4; ++i) {
+    chain_heavy_kernel<<<(unsigned)cu_count, 64, heavy_lds_bytes(kHeavyCap[5]), st>>>(A, &A.ctr->n_heavy, kHeavyCap[4], kHeavyCap[5], htk + 5);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 4), 64, heavy_lds_bytes(kHeavyCap[4]), aux[1]>>>(A, &A.ctr->n_heavy, kHeavyCap[3], kHeavyCap[4], htk + 4);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 7), 64, heavy_lds_bytes(kHeavyCap[3]), aux[2]>>>(A, &A.ctr->n_heavy, kHeavyCap[2], kHeavyCap[3], htk + 3);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 12), 64, heavy_lds_bytes(kHeavyCap[2]), aux[0]>>>(A, &A.ctr->n_heavy, kHeavyCap[1], kHeavyCap[2], htk + 2);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 16), 64, heavy_lds_bytes(kHeavyCap[1]), aux[3]>>>(A, &A.ctr->n_heavy, kHeavyCap[0], kHeavyCap[1], htk + 1);
+    chain_heavy_kernel<<<(unsigned)(cu_count * 24), 64, heavy_lds_bytes(kHeavyCap[0]), aux[4]>>>(A, &A.ctr->n_heavy, 0, kHeavyCap[0], htk + 0);
+    for (int i = 0; i < 5; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;
     }

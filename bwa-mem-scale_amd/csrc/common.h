@@ -125,8 +125,8 @@ struct DevCounters {
     unsigned long long chain_overflow;   // chaining: B-tree node region exhausted (never expected)
     unsigned long long chain_longread;   // chaining: reads long enough for mem_flt_chained_seeds to re-score seeds
     unsigned long long n_heavy;          // chaining: reads handed to the wave-per-read filter kernel
-    unsigned long long chain_class[9];   // chaining: reads with more seeds than the L, L1, M, M1, S, lane-tier, XL, L2 and M2 limits
-    unsigned long long chain_ticket[9];  // chaining: work cursors of the wave kernels
+    unsigned long long chain_class[10];  // chaining: reads with more seeds than the L, L1, M, M1, S, lane-tier, XL, L2, M2 and XL2 limits
+    unsigned long long chain_ticket[10]; // chaining: work cursors of the wave kernels
     unsigned long long heavy_tickets[6]; // chaining: work cursors of chain_heavy_kernel's size classes (five used)
     unsigned long long n_retry;          // extension: tasks queued for the next band width
     unsigned long long n_req;            // extension: seeds requested by the last selection

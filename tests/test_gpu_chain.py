@@ -147,6 +147,34 @@ def test_chain_duplicate_positions_and_ties(rep_toy):
     b.close()
 
 
+def test_reads_with_thousands_of_seeds():
+    """A family of 5000 nearly exact copies and max_occ above that: reads carry 4000 .. 20000 seeds and thousands of chains — the wave tier's
+    classes beyond 4096 seeds (ordered array of 13000 positions in LDS; beyond that the B-tree in HBM), many passes of 64 hits per SMEM with
+    new chains and extensions mixed, the many-chain filter's largest class and its sequential form."""
+    capi.lib()
+    rng = np.random.default_rng(77)
+    unit = rng.integers(0, 4, size=150, dtype=np.uint8)
+    parts = []
+    for _ in range(5000):
+        cp = unit.copy()
+        mut = rng.random(150) < 0.003
+        cp[mut] = (cp[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        parts += [cp, rng.integers(0, 4, size=40, dtype=np.uint8)]
+    g = np.concatenate(parts)
+    idx = fmindex.build_fmindex(g)
+    ix = capi.Index.from_host(idx, 0)
+    try:
+        reads = _reads(g, 40, 3)
+        b, want, got, ctx = _run(idx, ix, g, reads, max_occ=6000)
+        seeds_per_read = np.diff(ctx["off"][np.searchsorted(ctx["sm"]["rid"], np.arange(len(reads) + 1))])
+        assert seeds_per_read.max() > 13000 and ((seeds_per_read > 4096) & (seeds_per_read <= 13000)).any(), seeds_per_read
+        assert np.diff(want["chain_off"]).max() > 3840
+        _assert_chains(want, got)
+        b.close()
+    finally:
+        ix.close()
+
+
 def test_chain_contigs_and_alt(rep_toy):
     g, idx, ix = rep_toy
     l_pac = len(g)

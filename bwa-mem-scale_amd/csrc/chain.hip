@@ -730,14 +730,30 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
     return (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)v, l));
 }
-// the hits [g0, g1) of one SMEM; all 64 lanes call this.  Returns false when the read needs the B-tree.
-__device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_keys, int32_t g0, int32_t g1, int qbeg, int slen, RidCache &rc, int lane) {
+// the read's seeds [0, cnt), 64 per pass across its SMEMs sm[beg .. end); all 64 lanes call this.  Returns false when the read needs the B-tree.
+__device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_keys, const bwams_smem_t *sm, int64_t beg, int64_t end, int64_t base,
+                                  int32_t cnt, RidCache &rc, int lane) {
     enum { NONE = 0, NOOP = 1, MERGE = 2, NEW = 3, UNSETTLED = 4 };
     const int64_t l_pac = A.bns.l_pac;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int32_t gb = g0; gb < g1; gb += 64) {
+    const int w = A.opt.w, max_gap = A.opt.max_chain_gap;
+    int64_t i_lo = beg;                                                           // the SMEM of the batch's first seed
+    for (int32_t gb = 0; gb < cnt; gb += 64) {
         const int32_t g = gb + lane;
-        bool pend = g < g1;
+        bool pend = g < cnt;
+        // the seed's SMEM: the last one whose first hit is <= g
+        int qbeg = 0, slen = 0;
+        {
+            int64_t lo = i_lo, hi = end - 1;                                      // answer in [lo, hi]
+            if (pend) {
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi + 1) >> 1;
+                    if (A.sa_off[mid] - base <= g) lo = mid; else hi = mid - 1;
+                }
+                qbeg = (int)sm[lo].m; slen = (int)sm[lo].n + 1 - qbeg;
+            }
+            i_lo = readlane64(lo, 0);
+        }
         const int64_t rbeg = pend ? S.pos[g] : 0;
         int rid = -1;
         if (pend) { rid = intv2rid(A.bns, rbeg, rbeg + slen, rc); pend = rid >= 0; }
@@ -746,7 +762,8 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
         while ((mp = __ballot(pend)) != 0ull) {
             if (one_by_one) {                                                     // the first pending seed, on the whole wave
                 const int l0 = __builtin_ctzll(mp);
-                if (!chain_seed_one(A, S, n_keys, gb + l0, readlane64(rbeg, l0), __builtin_amdgcn_readlane(rid, l0), qbeg, slen, lane)) return false;
+                if (!chain_seed_one(A, S, n_keys, gb + l0, readlane64(rbeg, l0), __builtin_amdgcn_readlane(rid, l0), __builtin_amdgcn_readlane(qbeg, l0),
+                                    __builtin_amdgcn_readlane(slen, l0), lane)) return false;
                 if (lane == l0) pend = false;
                 --one_by_one;
                 continue;
@@ -780,15 +797,14 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                     else if ((lr < l_pac || lo_key < l_pac) && rbeg >= l_pac) act = NEW;
                     else {
                         const int64_t x = qbeg - ch.last_qbeg, y = rbeg - lr;
-                        if (y >= 0 && x - y <= A.opt.w && y - x <= A.opt.w && x - ch.last_len < A.opt.max_chain_gap && y - ch.last_len < A.opt.max_chain_gap)
-                            act = MERGE;
+                        if (y >= 0 && x - y <= w && y - x <= w && x - ch.last_len < max_gap && y - ch.last_len < max_gap) act = MERGE;
                     }
                 }
             }
             const bool eq = pend && idx >= 0 && lo_key == rbeg;
             // settle in seed order
             int64_t best = lo_key;                   // the greatest position <= rbeg among the looked-up chain and the chains earlier seeds of this pass start
-            int best_rid = -1;
+            int best_rid = -1, best_q = 0, best_l = 0;
             bool displaced = false, touched = false;
             int first_open = 64;
             unsigned long long rem = mp;
@@ -796,18 +812,20 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                 const int i = __builtin_ctzll(rem);
                 rem &= rem - 1;
                 int fin = act;
-                if (displaced) {
-                    const int64_t y = rbeg - best;
-                    const bool ext = rid == best_rid && !(best < l_pac && rbeg >= l_pac) && y <= A.opt.w && y - slen < A.opt.max_chain_gap;
-                    fin = ext ? UNSETTLED : NEW;
+                if (displaced) {                     // test_and_merge against a chain of one seed {best_q, best_l, best}
+                    const int64_t x = qbeg - best_q, y = rbeg - best;
+                    if (rid != best_rid) fin = NEW;
+                    else if (qbeg >= best_q && qbeg + slen <= best_q + best_l && rbeg + slen <= best + best_l) fin = NOOP;
+                    else if (best < l_pac && rbeg >= l_pac) fin = NEW;
+                    else fin = (x - y <= w && y - x <= w && x - best_l < max_gap && y - best_l < max_gap) ? UNSETTLED : NEW;
                 } else if (touched) fin = UNSETTLED;
                 const int a_i = __builtin_amdgcn_readlane(fin, i);
                 if (a_i == UNSETTLED) { first_open = i; break; }
                 if (lane == i) act = fin;
                 if (a_i == NEW) {
                     const int64_t rb_i = readlane64(rbeg, i);
-                    const int rid_i = __builtin_amdgcn_readlane(rid, i);
-                    if (lane > i && rb_i <= rbeg && rb_i > best) { best = rb_i; best_rid = rid_i; displaced = true; }
+                    const int rid_i = __builtin_amdgcn_readlane(rid, i), q_i = __builtin_amdgcn_readlane(qbeg, i), l_i = __builtin_amdgcn_readlane(slen, i);
+                    if (lane > i && rb_i <= rbeg && rb_i > best) { best = rb_i; best_rid = rid_i; best_q = q_i; best_l = l_i; displaced = true; }
                 } else if (a_i == MERGE) {
                     const int low_i = __builtin_amdgcn_readlane(lower, i);
                     if (lane > i && lower == low_i) touched = true;
@@ -815,7 +833,8 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
             }
             const bool com = pend && lane < first_open;
             const unsigned long long m_new = __ballot(com && act == NEW);
-            if (n && __ballot(com && act == NEW && eq)) return false;             // a second chain at a position: the B-tree decides
+            // a second chain at a position (in the array, or started earlier in this pass): the B-tree decides
+            if (__ballot(com && act == NEW && (eq || (displaced && best == rbeg)))) return false;
             if (com && act == MERGE) {
                 S.s_ql[g] = make_int2(qbeg, slen); S.s_next[g] = -1; S.s_next[ch.last_idx] = g;
                 if (qbeg >= ch.endq) ch.wq += slen; else if (qbeg + slen > ch.endq) ch.wq += qbeg + slen - ch.endq;
@@ -829,15 +848,17 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                 const int m = __popcll(m_new);
                 const bool mine = com && act == NEW;
                 // the old entries move up by the number of new positions below them, top chunk first (a chunk is read whole before it is written)
+                // (an entry's shift = the new positions below its chunk — one ballot — plus those inside the chunk below it: the few lanes
+                // whose predecessor lies in this chunk; a loop over all new lanes per chunk cost 200 k cycles per pass at 8000 chains)
                 int min_idx = n;
                 { unsigned long long mm = m_new; while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; const int x = __builtin_amdgcn_readlane(idx, i); min_idx = x < min_idx ? x : min_idx; } }
-                for (int base = n > 0 ? ((n - 1) >> 6) << 6 : -64; base >= 0 && base + 63 > min_idx; base -= 64) {
-                    const int p = base + lane;
+                for (int cb = n > 0 ? ((n - 1) >> 6) << 6 : -64; cb >= 0 && cb + 63 > min_idx; cb -= 64) {
+                    const int p = cb + lane;
                     const bool mv = p < n;
                     const int64_t kk = mv ? S.s_key[p] : 0;
                     const int32_t cc = mv ? S.s_cid[p] : 0;
-                    int sh = 0;
-                    unsigned long long mm = m_new;
+                    int sh = __popcll(__ballot(mine && idx < cb));
+                    unsigned long long mm = __ballot(mine && idx >= cb && idx < cb + 64);
                     while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; sh += __builtin_amdgcn_readlane(idx, i) < p ? 1 : 0; }
                     if (mv && sh) { S.s_key[p + sh] = kk; S.s_cid[p + sh] = cc; }
                 }
@@ -863,6 +884,8 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
     return true;
 }
 
+__device__ void heavy_read(const ChainArgs &A, int64_t r, int64_t base, int n_chn, unsigned char *lds, int cap, int lane);
+__host__ __device__ constexpr size_t heavy_lds_bytes(int cap);
 // CONT = 0: kbtree (exact for any input); CONT = 1: sorted array, returns false when the read needs the B-tree
 template <bool LDS, int CONT = 0, bool CREC_HBM = false>
 __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int lane, int nl, Node *nodes, int32_t cap_nodes,
@@ -930,11 +953,7 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
             SeedCtx S;
             S.pos = pos; S.s_next = s_next; S.s_ql = s_ql; S.crec = crec; S.s_key = s_key; S.s_cid = s_cid;
             int nk = 0;
-            for (int64_t i = beg; i < end; ++i) {
-                const int qbeg = (int)sm[i].m, slen = (int)sm[i].n + 1 - (int)sm[i].m;
-                const int32_t g0 = (int32_t)(A.sa_off[i] - base), g1 = (int32_t)(A.sa_off[i + 1] - base);
-                if (!chain_seeds_batch(A, S, nk, g0, g1, qbeg, slen, rc, lane)) return false;
-            }
+            if (!chain_seeds_batch(A, S, nk, sm, beg, end, base, cnt, rc, lane)) return false;
             c.n_keys = nk;
         }
     }
@@ -1058,6 +1077,21 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
     if (n_chn == 0) n_chn = 1;                  // the reference keeps a_[0] in that case (bwamem.cpp:549-572)
     if constexpr (LDS && !CREC_HBM)             // chain records out of LDS, for the filter and the emit stages
         for (int32_t k = lane; k < c.n_keys; k += nl) crec_g[k] = crec_w[k];
+    if constexpr (LDS) {
+        // the read's LDS is free now (chain records copied out, the ordered array dead): its sort and filter run here, on the same wave,
+        // when they fit — no second kernel, no lane-0 loops through HBM for the reads with a dozen chains
+        if (nl == 64) {
+            unsigned char *region = CREC_HBM ? reinterpret_cast<unsigned char *>(nodes) : reinterpret_cast<unsigned char *>(crec_w);
+            const size_t bytes = (size_t)cap_chains * (CREC_HBM ? 12 : sizeof(ChainRec) + 12);
+            const int cap_f = (int)((bytes - 64) / 41);
+            if (cap_f >= 64 && n_chn <= cap_f) {
+                if (wr) A.n_chn[r] = n_chn;
+                __threadfence_block();          // crec_g, fl: written above by other lanes
+                heavy_read(A, r, base, n_chn, region, cap_f, lane);
+                return true;
+            }
+        }
+    }
     if (!wr) return true;
     A.n_chn[r] = n_chn;
     if (n_chn > kLightChains) {                 // sort + filter by a whole wave (chain_heavy_kernel)
@@ -1142,43 +1176,22 @@ constexpr int kHeavyCap[6] = {64, 128, 256, 512, 960, 3840};         // 2.7 / 5 
 __host__ __device__ constexpr size_t heavy_lds_bytes(int cap) { return (size_t)cap * 41 + 64; }
 static_assert(heavy_lds_bytes(kHeavyCap[5]) <= 160 * 1024, "the largest class must fit one CU's LDS");
 
-__global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsigned long long *n_heavy_p, int cap_lo, int cap,
-                                                         unsigned long long *ticket) {
-    extern __shared__ __align__(16) unsigned char l_heavy[];
-    uint4 *l_rec = reinterpret_cast<uint4 *>(l_heavy);                   // by sorted position: {beg, end, w | alt, first}
+// one read's sort, pairwise filter and totals by a whole wavefront.  lds: heavy_lds_bytes(cap) bytes, n_chn <= cap; fl[0 .. n_chn) in HBM
+// holds the {weight, chain id} pairs in B-tree order.  All 64 lanes call this.
+__device__ void heavy_read(const ChainArgs &A, int64_t r, int64_t base, int n_chn, unsigned char *lds, int cap, int lane) {
+    uint4 *l_rec = reinterpret_cast<uint4 *>(lds);                       // by sorted position: {beg, end, w | alt, first}
     uint4 *l_sel = l_rec + cap;                // the kept ("selected") chains, in selection order: {beg, end, w | alt, position}
     uint2 *l_fl = reinterpret_cast<uint2 *>(l_sel + cap);
     uint8_t *l_kept = reinterpret_cast<uint8_t *>(l_fl + cap);
-    const int kLdsChains = cap;
-    const int lane = threadIdx.x;
-    const int64_t n_heavy = (int64_t)*n_heavy_p;
-    for (;;) {
-        const int64_t hi = (int64_t)wave_ticket(ticket, 1ull);
-        if (hi >= n_heavy) break;
-        const int64_t r = A.heavy[hi];
-        const int64_t base = A.read_base[r];
-        const int n_chn = A.n_chn[r];
-        if (n_chn <= cap_lo || (n_chn > cap && cap != kHeavyCap[5])) continue;          // another class's read
-        const int L = (int)(A.cum[r + 1] - A.cum[r]);
-        uint2 *fl = A.flt + base;
-        uint4 *rec = A.f_rec + base;
-        int32_t *kept = A.f_kept + base;
-        const ChainRec *crec = reinterpret_cast<const ChainRec *>(A.crec) + base;
-        const unsigned long long t_0 = __builtin_amdgcn_s_memtime();
-        if (lane == 0) {
-            const int bk = n_chn <= 32 ? 0 : n_chn <= 64 ? 1 : n_chn <= 128 ? 2 : n_chn <= 256 ? 3 : n_chn <= 512 ? 4 : n_chn <= 960 ? 5 : 6;
-            atomicAdd(&A.ctr->dbg[bk], 1ull);
-        }
-        if (n_chn > kLdsChains) {              // beyond the LDS budget: the sequential form, on lane 0
-            if (lane == 0) {
-                flt_introsort(fl, n_chn);
-                for (int i = 0; i < n_chn; ++i) { rec[i] = make_rec(A, crec[fl[i].y], fl[i].x); kept[i] = 0; }
-                filter_seq(A.opt, n_chn, rec, kept, A.f_sel + base);
-                finish_read(A, r, base, n_chn, L);
-                atomicAdd(&A.ctr->dbg[7], __builtin_amdgcn_s_memtime() - t_0);
-            }
-            continue;
-        }
+    const int L = (int)(A.cum[r + 1] - A.cum[r]);
+    uint2 *fl = A.flt + base;
+    const ChainRec *crec = reinterpret_cast<const ChainRec *>(A.crec) + base;
+    const unsigned long long t_0 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        const int bk = n_chn <= 32 ? 0 : n_chn <= 64 ? 1 : n_chn <= 128 ? 2 : n_chn <= 256 ? 3 : n_chn <= 512 ? 4 : n_chn <= 960 ? 5 : 6;
+        atomicAdd(&A.ctr->dbg[bk], 1ull);
+    }
+    {
         __syncthreads();
         for (int i = lane; i < n_chn; i += 64) l_fl[i] = fl[i];
         __syncthreads();
@@ -1322,6 +1335,40 @@ __global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsi
     }
 }
 
+__global__ __launch_bounds__(64) void chain_heavy_kernel(ChainArgs A, const unsigned long long *n_heavy_p, int cap_lo, int cap,
+                                                         unsigned long long *ticket) {
+    extern __shared__ __align__(16) unsigned char l_heavy[];
+    const int kLdsChains = cap;
+    const int lane = threadIdx.x;
+    const int64_t n_heavy = (int64_t)*n_heavy_p;
+    for (;;) {
+        const int64_t hi = (int64_t)wave_ticket(ticket, 1ull);
+        if (hi >= n_heavy) break;
+        const int64_t r = A.heavy[hi];
+        const int64_t base = A.read_base[r];
+        const int n_chn = A.n_chn[r];
+        if (n_chn <= cap_lo || (n_chn > cap && cap != kHeavyCap[5])) continue;          // another class's read
+        const int L = (int)(A.cum[r + 1] - A.cum[r]);
+        uint2 *fl = A.flt + base;
+        uint4 *rec = A.f_rec + base;
+        int32_t *kept = A.f_kept + base;
+        const ChainRec *crec = reinterpret_cast<const ChainRec *>(A.crec) + base;
+        if (n_chn > kLdsChains) {              // beyond the LDS budget: the sequential form, on lane 0
+            const unsigned long long t_0 = __builtin_amdgcn_s_memtime();
+            if (lane == 0) {
+                atomicAdd(&A.ctr->dbg[6], 1ull);
+                flt_introsort(fl, n_chn);
+                for (int i = 0; i < n_chn; ++i) { rec[i] = make_rec(A, crec[fl[i].y], fl[i].x); kept[i] = 0; }
+                filter_seq(A.opt, n_chn, rec, kept, A.f_sel + base);
+                finish_read(A, r, base, n_chn, L);
+                atomicAdd(&A.ctr->dbg[7], __builtin_amdgcn_s_memtime() - t_0);
+            }
+            continue;
+        }
+        heavy_read(A, r, base, n_chn, l_heavy, cap, lane);
+    }
+}
+
 // lane per read: flat chain and seed records
 __global__ void chain_emit_kernel(ChainArgs A, const int64_t *__restrict__ chain_off, const int64_t *__restrict__ seed_off,
                                   bwams_chain_t *chains, bwams_chain_seed_t *seeds) {
@@ -1402,10 +1449,11 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     chain_wave_kernel<<<(unsigned)(cu_count * 4), 64, lds_bytes(kClassM2), aux[6]>>>(A, cls + 8, cls + 2, tk + 8, kClassM2);
     chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
     chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 4, cls + 5, tk + 5, kClassS);
-    chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[4]>>>(A, n_seeds);
+    chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[1]>>>(A, n_seeds);
     // class M behind the lane tier (5 ms) rather than behind class L or S (kernel trace at GRCh38 size: L 8.9-10.3 ms + M 4.3-6.7 was
     // the stage's longest stream; S 7.8, L1 7.7 + M1 2.9, XL 0.9 + 7.2)
-    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[4]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
+    // (round 4: on the stream of class L, the shortest; aux[4] shares a hardware queue with class S's stream, 16 ms on a repeat-rich genome)
+    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
     for (int i = 0; i < 7; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;

@@ -448,6 +448,8 @@ static int chain_common(bwams_batch *b, const bwams_mem_opt_t *opt, const SeedVi
             fprintf(stderr, "[bwams_chain_run] chaining wave tier, per class: reads / mean us / longest us / wave-ms:");
             for (int c = 0; c < 8; ++c) fprintf(stderr, "  %s %llu / %.0f / %.0f / %.1f", cn[c], d[32 + 3 * c], d[32 + 3 * c] ? d[33 + 3 * c] * 1e-2 / d[32 + 3 * c] : 0.0, d[34 + 3 * c] * 1e-2, d[33 + 3 * c] * 1e-5);
             fprintf(stderr, "\n");
+            fprintf(stderr, "[bwams_chain_run] wave tier phases, G cycles: preamble %.2f chaining %.2f weights+copy %.2f (sort %.2f filter %.2f: all reads); reads %llu seeds %llu; passes %llu settling %llu seeds (%llu new chains), %llu seeds one by one; pass parts, G cycles: batch prologue %.2f search %.2f record+test %.2f settle %.2f commit %.2f one-by-one %.2f\n",
+                    d[56] / 1e9, d[57] / 1e9, d[58] / 1e9, d[8] / 1e9, d[9] / 1e9, d[59], d[60], d[61], d[63], d[64], d[62], d[65] / 1e9, d[66] / 1e9, d[67] / 1e9, d[68] / 1e9, d[69] / 1e9, d[70] / 1e9);
 #endif
         }
     }

@@ -671,6 +671,7 @@ __device__ __forceinline__ void sarr_insert(int64_t *key, int32_t *cid, int n, i
 // order are the sequential loop's, so chains, ids and seed lists are identical.  A pass that settles a single seed costs more than
 // the one-seed step, so after such a pass the next seeds are taken one at a time (tandem repeats: every hit extends the previous one's chain).
 struct SeedCtx {
+    bool crec_hbm;
     const int64_t *pos;
     int32_t *s_next;
     int2 *s_ql;
@@ -732,18 +733,39 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
 }
 // the read's seeds [0, cnt), 64 per pass across its SMEMs sm[beg .. end); all 64 lanes call this.  Returns false when the read needs the B-tree.
 __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_keys, const bwams_smem_t *sm, int64_t beg, int64_t end, int64_t base,
-                                  int32_t cnt, RidCache &rc, int lane) {
+                                  int32_t cnt, RidCache &rc, const WaveBns &wb, int lane) {
     enum { NONE = 0, NOOP = 1, MERGE = 2, NEW = 3, UNSETTLED = 4 };
     const int64_t l_pac = A.bns.l_pac;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int w = A.opt.w, max_gap = A.opt.max_chain_gap;
     int64_t i_lo = beg;                                                           // the SMEM of the batch's first seed
+#ifdef BWAMS_CHAINDBG
+    unsigned long long tq[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#define TQ(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tq[k] += t_ - tq0; tq0 = t_; }
+#else
+#define TQ(k)
+#endif
+    // up to 64 SMEMs: lane l keeps SMEM l's first hit and query span (every dependent global load costs a microsecond here)
+    const int nsm = (int)(end - beg);
+    const bool sm_regs = nsm <= 64;
+    int sm_start = INT32_MAX, sm_q = 0, sm_l = 0;
+    if (sm_regs && lane < nsm) {
+        sm_start = (int)(A.sa_off[beg + lane] - base);
+        sm_q = (int)sm[beg + lane].m; sm_l = (int)sm[beg + lane].n + 1 - sm_q;
+    }
     for (int32_t gb = 0; gb < cnt; gb += 64) {
         const int32_t g = gb + lane;
         bool pend = g < cnt;
+        const int64_t rbeg = pend ? S.pos[g] : 0;
         // the seed's SMEM: the last one whose first hit is <= g
         int qbeg = 0, slen = 0;
-        {
+        if (sm_regs) {                               // the SMEMs' first hits and spans sit in lanes: count, then fetch from the owner lane
+            int k = 0;
+            for (int i = 0; i < nsm; ++i) k += __builtin_amdgcn_readlane(sm_start, i) <= g ? 1 : 0;
+            const int src = k > 0 ? k - 1 : 0;
+            qbeg = __shfl(sm_q, src); slen = __shfl(sm_l, src);
+        } else {
             int64_t lo = i_lo, hi = end - 1;                                      // answer in [lo, hi]
             if (pend) {
                 while (lo < hi) {
@@ -754,18 +776,32 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
             }
             i_lo = readlane64(lo, 0);
         }
-        const int64_t rbeg = pend ? S.pos[g] : 0;
         int rid = -1;
-        if (pend) { rid = intv2rid(A.bns, rbeg, rbeg + slen, rc); pend = rid >= 0; }
+        if (A.bns.n_seqs <= 64) {                    // the sequences' offsets sit in lanes (wb): count the ones at or below both ends
+            const int64_t rb = rbeg, re = rbeg + slen;   // (a uniform loop: every lane takes part in the readlanes; bns_intv2rid, bntseq.cpp:407-421)
+            const int64_t pb = depos(A.bns, rb), pe = rb < re ? depos(A.bns, re - 1) : pb;
+            int cb = 0, ce = 0;
+            for (int i = 0; i < A.bns.n_seqs; ++i) {
+                const int64_t o = readlane64(wb.off, i);
+                cb += o <= pb ? 1 : 0; ce += o <= pe ? 1 : 0;
+            }
+            rid = (rb < l_pac && re > l_pac) ? -2 : cb == ce ? cb - 1 : -1;
+        } else if (pend) rid = intv2rid(A.bns, rbeg, rbeg + slen, rc);
+        pend = pend && rid >= 0;
         int one_by_one = 0;
         unsigned long long mp;
+        TQ(0)
         while ((mp = __ballot(pend)) != 0ull) {
             if (one_by_one) {                                                     // the first pending seed, on the whole wave
                 const int l0 = __builtin_ctzll(mp);
                 if (!chain_seed_one(A, S, n_keys, gb + l0, readlane64(rbeg, l0), __builtin_amdgcn_readlane(rid, l0), __builtin_amdgcn_readlane(qbeg, l0),
                                     __builtin_amdgcn_readlane(slen, l0), lane)) return false;
                 if (lane == l0) pend = false;
+#ifdef BWAMS_CHAINDBG
+                if (lane == 0) atomicAdd(&A.ctr->dbg[62], 1ull);
+#endif
                 --one_by_one;
+                TQ(5)
                 continue;
             }
             const int n = n_keys;
@@ -779,6 +815,7 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                     if (pend && t < n && S.s_key[t] <= rbeg) idx = t;
                 }
             }
+            TQ(1)
             int64_t lo_key = INT64_MIN;
             int32_t lower = -1;
             int act = NONE;
@@ -802,12 +839,29 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                 }
             }
             const bool eq = pend && idx >= 0 && lo_key == rbeg;
+            TQ(2)
             // settle in seed order
             int64_t best = lo_key;                   // the greatest position <= rbeg among the looked-up chain and the chains earlier seeds of this pass start
             int best_rid = -1, best_q = 0, best_l = 0;
             bool displaced = false, touched = false;
             int first_open = 64;
-            unsigned long long rem = mp;
+            // Two seeds of a pass can only touch each other when they look up the same place of the array (a chain started by the earlier
+            // one lies between the later one's looked-up position and its own; or both look up the same chain): only those lanes go
+            // through the ordered walk below, the others' decisions stand.  (The walk over all 64 lanes was most of a pass: 29 k cycles.)
+            // (who shares: every pending lane counts itself into the top byte of its place's chain id — ids stay below 2^24 —, reads the
+            // count back and takes itself out again: three LDS operations instead of a walk over the lanes)
+            bool shared = false;
+            {
+                unsigned *mark = reinterpret_cast<unsigned *>(S.s_cid);
+                const bool in_arr = pend && idx >= 0;
+                if (in_arr) atomicAdd(&mark[idx], 1u << 24);
+                if (in_arr) shared = (mark[idx] >> 24) > 1u;
+                if (in_arr) atomicSub(&mark[idx], 1u << 24);
+                const bool under = pend && idx < 0;
+                const int n_under = __popcll(__ballot(under));
+                if (under && n_under > 1) shared = true;
+            }
+            unsigned long long rem = __ballot(pend && shared);
             while (rem) {
                 const int i = __builtin_ctzll(rem);
                 rem &= rem - 1;
@@ -832,6 +886,7 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                 }
             }
             const bool com = pend && lane < first_open;
+            TQ(3)
             const unsigned long long m_new = __ballot(com && act == NEW);
             // a second chain at a position (in the array, or started earlier in this pass): the B-tree decides
             if (__ballot(com && act == NEW && (eq || (displaced && best == rbeg)))) return false;
@@ -850,8 +905,8 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                 // the old entries move up by the number of new positions below them, top chunk first (a chunk is read whole before it is written)
                 // (an entry's shift = the new positions below its chunk — one ballot — plus those inside the chunk below it: the few lanes
                 // whose predecessor lies in this chunk; a loop over all new lanes per chunk cost 200 k cycles per pass at 8000 chains)
-                int min_idx = n;
-                { unsigned long long mm = m_new; while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; const int x = __builtin_amdgcn_readlane(idx, i); min_idx = x < min_idx ? x : min_idx; } }
+                int min_idx = mine ? idx : n;
+                for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(min_idx, d); min_idx = o < min_idx ? o : min_idx; }
                 for (int cb = n > 0 ? ((n - 1) >> 6) << 6 : -64; cb >= 0 && cb + 63 > min_idx; cb -= 64) {
                     const int p = cb + lane;
                     const bool mv = p < n;
@@ -862,8 +917,9 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                     while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; sh += __builtin_amdgcn_readlane(idx, i) < p ? 1 : 0; }
                     if (mv && sh) { S.s_key[p + sh] = kk; S.s_cid[p + sh] = cc; }
                 }
-                int rank = 0;                        // new positions below mine
-                { unsigned long long mm = m_new; while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; rank += readlane64(rbeg, i) < rbeg ? 1 : 0; } }
+                int rank = 0;                        // new positions below mine: lower places of the array, or the same place and a lower position
+                { unsigned long long mm = m_new; while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; rank += __builtin_amdgcn_readlane(idx, i) < idx ? 1 : 0; } }
+                { unsigned long long mm = m_new & __ballot(shared); while (mm) { const int i = __builtin_ctzll(mm); mm &= mm - 1; rank += (__builtin_amdgcn_readlane(idx, i) == idx && readlane64(rbeg, i) < rbeg) ? 1 : 0; } }
                 if (mine) {
                     const int32_t cid = n + __popcll(m_new & below);              // chains are numbered in creation order
                     S.s_ql[g] = make_int2(qbeg, slen); S.s_next[g] = -1;
@@ -877,10 +933,17 @@ __device__ bool chain_seeds_batch(const ChainArgs &A, const SeedCtx &S, int &n_k
                 n_keys = n + m;
             }
             if (com) pend = false;
+#ifdef BWAMS_CHAINDBG
+            if (lane == 0) { atomicAdd(&A.ctr->dbg[61], 1ull); atomicAdd(&A.ctr->dbg[63], (unsigned long long)__popcll(__ballot(com))); atomicAdd(&A.ctr->dbg[64], (unsigned long long)__popcll(m_new)); }
+#endif
             if (__popcll(__ballot(com)) <= 1) one_by_one = 8;
-            __threadfence_block();
+            if (S.crec_hbm) __threadfence_block();                            // the chain records of class XL are read back through L2
+            TQ(4)
         }
     }
+#ifdef BWAMS_CHAINDBG
+    if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&A.ctr->dbg[65 + k], tq[k]);
+#endif
     return true;
 }
 
@@ -891,6 +954,9 @@ template <bool LDS, int CONT = 0, bool CREC_HBM = false>
 __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int lane, int nl, Node *nodes, int32_t cap_nodes,
                                            ChainRec *crec_w, int32_t cap_chains) {
     const bool wr = lane == 0;
+#ifdef BWAMS_CHAINDBG
+    const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
     if (wr) {
         A.n_kept[r] = 0;
         A.n_kept_seeds[r] = 0;
@@ -904,6 +970,18 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
 
     // frac_rep: query span covered by over-frequent SMEMs
     int b = 0, e = 0, l_rep = 0;
+    if (nl == 64 && end - beg <= 64) {           // one coalesced load, then a scalar walk: a load per SMEM waited a round trip each
+        const bool has = beg + lane < end;
+        const int my_b = has ? (int)sm[beg + lane].m : 0, my_e = has ? (int)sm[beg + lane].n + 1 : 0;
+        unsigned long long rep = __ballot(has && sm[beg + lane].s > (int64_t)A.opt.max_occ);
+        while (rep) {
+            const int i = __builtin_ctzll(rep);
+            rep &= rep - 1;
+            const int sb = __builtin_amdgcn_readlane(my_b, i), se = __builtin_amdgcn_readlane(my_e, i);
+            if (sb > e) { l_rep += e - b; b = sb; e = se; }
+            else e = e > se ? e : se;
+        }
+    } else
     for (int64_t i = beg; i < end; ++i) {
         const int sb = (int)sm[i].m, se = (int)sm[i].n + 1;
         if (sm[i].s <= (int64_t)A.opt.max_occ) continue;
@@ -948,12 +1026,15 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
     if (LDS && cnt > cap_chains) { if (wr) atomicAdd(&A.ctr->chain_overflow, 1ull); return true; }
 
     const int64_t l_pac = A.bns.l_pac;
+#ifdef BWAMS_CHAINDBG
+    const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (CONT == 1) {
         if (nl == 64 && A.seed_batch) {          // 64 seeds per pass
             SeedCtx S;
-            S.pos = pos; S.s_next = s_next; S.s_ql = s_ql; S.crec = crec; S.s_key = s_key; S.s_cid = s_cid;
+            S.pos = pos; S.s_next = s_next; S.s_ql = s_ql; S.crec = crec; S.s_key = s_key; S.s_cid = s_cid; S.crec_hbm = CREC_HBM;
             int nk = 0;
-            if (!chain_seeds_batch(A, S, nk, sm, beg, end, base, cnt, rc, lane)) return false;
+            if (!chain_seeds_batch(A, S, nk, sm, beg, end, base, cnt, rc, wb, lane)) return false;
             c.n_keys = nk;
         }
     }
@@ -1034,6 +1115,9 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
         }
     }
     if (c.n_keys == 0) return true;
+#ifdef BWAMS_CHAINDBG
+    const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
+#endif
 
     // chains in B-tree order, their weights, the weight floor
     int32_t *ord = A.f_first + base;
@@ -1081,6 +1165,13 @@ __device__ __forceinline__ bool chain_read(const ChainArgs &A, int64_t r, int la
         // the read's LDS is free now (chain records copied out, the ordered array dead): its sort and filter run here, on the same wave,
         // when they fit — no second kernel, no lane-0 loops through HBM for the reads with a dozen chains
         if (nl == 64) {
+#ifdef BWAMS_CHAINDBG
+            if (wr) {
+                const unsigned long long tp3 = __builtin_amdgcn_s_memtime();
+                atomicAdd(&A.ctr->dbg[56], tp1 - tp0); atomicAdd(&A.ctr->dbg[57], tp2 - tp1); atomicAdd(&A.ctr->dbg[58], tp3 - tp2);
+                atomicAdd(&A.ctr->dbg[59], 1ull); atomicAdd(&A.ctr->dbg[60], (unsigned long long)cnt);
+            }
+#endif
             unsigned char *region = CREC_HBM ? reinterpret_cast<unsigned char *>(nodes) : reinterpret_cast<unsigned char *>(crec_w);
             const size_t bytes = (size_t)cap_chains * (CREC_HBM ? 12 : sizeof(ChainRec) + 12);
             const int cap_f = (int)((bytes - 64) / 41);
@@ -1440,8 +1531,11 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     // waves — no LDS limits them; at GRCh38 size, with max_occ hits per repeat SMEM, they were the stage's long pole on two)
     // (class XL, round 2: the five reads per million beyond class L — 2915 seeds the longest — took 19.5 ms in the HBM tier and
     // were the stage's long pole; with the ordered array in LDS only their chain records are in HBM)
+    // class XL2 wants a whole CU's LDS per read: on the batch's own stream, which does not wait for the fork event, so that its blocks
+    // are placed before the other classes' have filled every CU (behind them they found no CU free until the others drained: 42 ms on
+    // the grch38_like genome for reads of ~2 ms each); blocks without a read leave at once
+    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes_xl(kClassXL2), st>>>(A, cls + 9, cls + 6, tk + 9, -kClassXL2);
     chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, 0, aux[0]>>>(A, nullptr, cls + 9, tk + 0, 0);
-    chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes_xl(kClassXL2), aux[0]>>>(A, cls + 9, cls + 6, tk + 9, -kClassXL2);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes_xl(kClassXL), aux[0]>>>(A, cls + 6, cls + 0, tk + 6, -kClassXL);
     chain_wave_kernel<<<(unsigned)cu_count, 64, lds_bytes(kClassL), aux[1]>>>(A, cls + 0, cls + 7, tk + 1, kClassL);
     chain_wave_kernel<<<(unsigned)(cu_count * 2), 64, lds_bytes(kClassL2), aux[5]>>>(A, cls + 7, cls + 1, tk + 7, kClassL2);

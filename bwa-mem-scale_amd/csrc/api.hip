@@ -45,7 +45,7 @@ void knobs_reload() {
     k.cp2 = env_int("BWAMS_CP2", 2);
     k.seed_split = env_int("BWAMS_SEED_SPLIT", 0);
     k.fwd_bpc = std::max(1, env_int("BWAMS_FWD_BPC", 8)); k.bwdl_bpc = std::max(1, env_int("BWAMS_BWDL_BPC", 6));
-    k.ert_ticket = env_int("BWAMS_ERT_TICKET", 1); k.ert_grid = env_int("BWAMS_ERT_GRID", -1);
+    k.ert_ticket = env_int("BWAMS_ERT_TICKET", 1); k.ert_grid = env_int("BWAMS_ERT_GRID", -1); k.ert_fat = env_int("BWAMS_ERT_FAT", 1);
     g_knobs = k;
 }
 const Knobs &knobs() {
@@ -1005,6 +1005,18 @@ int bwams_seed_fmi(bwams_batch_t *b, const uint8_t *enc, const int64_t *cum, con
 
 // A loaded index starts with an empty hit-count table (filled as big subtrees are counted for the first time); sized
 // from the tree bytes: a four-way node with 20 or more hits below it stands for at least some hundred bytes of trees.
+// the resident entry + tree-head table (DevErt::fat): 64 bytes per k-mer, derived from the two tables once per index
+static int ert_fat_table(bwams_ert *e) {
+    if (!knobs().ert_fat) return BWAMS_OK;
+    const size_t bytes = (size_t)64 << (2 * e->t.K);
+    BWAMS_HIP(dev_malloc(&e->d_fat, bytes));
+    launch_ert_fat(e->t, e->mlt_bytes, (uint8_t *)e->d_fat, 0);
+    BWAMS_HIP(hipDeviceSynchronize());
+    BWAMS_HIP(hipGetLastError());
+    e->t.fat = (const uint8_t *)e->d_fat;
+    e->bytes += (int64_t)bytes;
+    return BWAMS_OK;
+}
 static int ert_count_table(bwams_ert *e) {
     int bits = 16;
     while (bits < 26 && ((int64_t)1 << bits) < e->mlt_bytes / 256) bits++;
@@ -1049,6 +1061,7 @@ int bwams_ert_from_host(bwams_index_t *ix, const uint64_t *kmer_table, int32_t k
     e->bytes = (int64_t)(nk * 8) + mlt_bytes + 16;
     e->mlt_bytes = mlt_bytes;
     if (int crc = ert_count_table(e)) { bwams_ert_close(e); return crc; }
+    if (int crc = ert_fat_table(e)) { bwams_ert_close(e); return crc; }
     *out = e;
     return BWAMS_OK;
 }
@@ -1109,6 +1122,7 @@ int bwams_ert_open(bwams_index_t *ix, const char *prefix, int32_t read_len, bwam
     e->bytes = (int64_t)(nk * 8) + mlt_bytes + 16;
     e->mlt_bytes = mlt_bytes;
     if (int crc = ert_count_table(e)) { bwams_ert_close(e); return crc; }
+    if (int crc = ert_fat_table(e)) { bwams_ert_close(e); return crc; }
     *out = e;
     return BWAMS_OK;
 }
@@ -1133,6 +1147,7 @@ int bwams_ert_build(bwams_index_t *ix, int32_t kmer_size, int32_t xmer_size, int
     const int rc = ert_build_device(e, ix->fmi, kmer_size, xmer_size, read_len, hit_threshold, prop.multiProcessorCount,
                                     knobs().verbose != 0);
     if (rc) { bwams_ert_close(e); return rc; }
+    if (int crc = ert_fat_table(e)) { bwams_ert_close(e); return crc; }
     *out = e;
     return BWAMS_OK;
 }
@@ -1187,6 +1202,7 @@ int bwams_ert_close(bwams_ert_t *e) {
     if (e->d_kmer) (void)hipFree(e->d_kmer);
     if (e->d_mlt) (void)hipFree(e->d_mlt);
     if (e->d_cnt) (void)hipFree(e->d_cnt);
+    if (e->d_fat) (void)hipFree(e->d_fat);
     delete e;
     return BWAMS_OK;
 }
@@ -1198,7 +1214,7 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
     hipStream_t st = b->stream;
     b->with_sa = with_sa != 0;
     b->n_smem = b->n_sa = 0;
-    const int64_t need = (int64_t)(M + 1) * (b->nbases > 0 ? b->nbases : 1);
+    const int64_t need = (int64_t)ert_prof_bytes(b->nbases);
     if (need > b->cap_ert_prof) {
         if (b->d_ert_prof) (void)hipFree(b->d_ert_prof);
         b->d_ert_prof = nullptr;
@@ -1218,7 +1234,6 @@ static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t
     // events: 0 start | 8,9 match profiles | 10,11 the three rounds | 3,4 sort | 12,13 locate | 4,5 locate + hits
     BWAMS_HIP(hipMemsetAsync(b->d_ctr, 0, sizeof(DevCounters), st));
     BWAMS_HIP(hipEventRecord(b->ev[0], st));
-    BWAMS_HIP(hipMemsetAsync(b->d_ert_prof, 0, (size_t)need, st));
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
     launch_ert_profile(e->t, b->d_enc, b->d_cum, skip, b->nseq, b->nbases, M, b->d_ert_prof, b->d_ctr,
                        (unsigned long long *)(b->d_ert_stk + (size_t)ert_walk_threads(b->cu_count) * (size_t)b->ert_stk_frames), b->cu_count, st);

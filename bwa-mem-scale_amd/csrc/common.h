@@ -41,6 +41,7 @@ struct Knobs {
     int cp2 = 2;                   // BWAMS_CP2: the table the SMEM search kernels read — 2 (default): the INTERLEAVED form of CP_OCC (piece b = count and
                                    // string of base b: an extension reads half a block per end, fetched by a pair of lanes); 1: the compact 128-rows-per-block
                                    // form (measured: no gain); 0: CP_OCC itself
+    int ert_fat = 1;               // BWAMS_ERT_FAT=0: the ERT walk reads the reference's two tables only (no entry + tree-head table)
     int ert_grid = -1, ert_ticket = 1;   // BWAMS_ERT_GRID (blocks per CU, 0 = one block per 256 bases) / BWAMS_ERT_TICKET=0 (round robin)
 };
 const Knobs &knobs();
@@ -105,6 +106,8 @@ struct DevErt {
     int32_t K, X, read_len;    // kmerSize, xmerSize, READ_LEN of the build (src/macro.h:204-206, :66)
     uint64_t *cnt_tab;         // hit counts of the subtrees with 20 hits or more: {node address + 1, hits} pairs, open addressing
     int32_t cnt_bits;          // log2 of the number of pairs
+    const uint8_t *fat;        // resident, derived once per index (ert_seed.hip: ert_fat_kernel), or null: 64 B per k-mer = its table entry + the
+                               // first 56 bytes of its tree, so that a walk's entry and first records are ONE line
 };
 
 // device-side counters of one seed run
@@ -217,7 +220,7 @@ int bsw_list_ensure(bwams_batch *b, int64_t n_tasks);   // grows b->d_bsw_list (
 struct bwams_ert {
     bwams_index *idx = nullptr;
     bwams::DevErt t{};
-    void *d_kmer = nullptr, *d_mlt = nullptr, *d_cnt = nullptr;
+    void *d_kmer = nullptr, *d_mlt = nullptr, *d_cnt = nullptr, *d_fat = nullptr;
     int64_t bytes = 0, mlt_bytes = 0, n_big = 0;
     float build_ms[3] = {0, 0, 0};       // bwams_ert_build: sizes, scan + allocation, bytes
 };

@@ -36,7 +36,10 @@ static __device__ __forceinline__ void cnt_insert(const DevErt &e, int64_t node,
 
 
 
-// planes of `prof`: (M + 1) x nbases bytes, zeroed by the caller; [0] = N flag, [m] = L_m
+// the 64-byte-per-k-mer table of entry + tree head (DevErt::fat) from the two tables; fat: 64 << (2 K) bytes
+void launch_ert_fat(const DevErt &e, int64_t mlt_bytes, uint8_t *fat, hipStream_t st);
+// prof: ert_prof_bytes(nbases) bytes, a 24-byte record per read position ([0] = N flag, [m] = L_m, M <= 23), written whole by the walk
+size_t ert_prof_bytes(int64_t nbases);
 void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum, const uint8_t *skip, int64_t nseq,
                         int64_t nbases, int M, uint8_t *prof, DevCounters *ctr, unsigned long long *part, int cu_count,
                         hipStream_t st);

@@ -65,9 +65,20 @@ struct Where {
 
 // One forward walk from read position i (oracle: ert_walk).  PROFILE: store L_m into the planes; otherwise stop at
 // stop_len and describe where the hits of read[i, i+stop_len) are.  Returns the matched length.
+// the profile record of a read position: byte 0 = the base is N, byte m = L_m, m = 1 .. M <= 23, in three 64-bit words.  L_m is a step
+// function of m and every m is set once (the words start at zero): a range of m takes a mask, not a loop of byte stores
+constexpr int kProfRec = 24;
+__device__ __forceinline__ void prof_set(uint64_t *acc, int lo, int hi, int d) {                   // bytes lo .. hi (inclusive) = d
+    const uint64_t v = 0x0101010101010101ull * (uint64_t)(uint8_t)d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = lo > 8 * k ? lo - 8 * k : 0, b = hi < 8 * k + 7 ? hi - 8 * k : 7;
+        if (a <= b) acc[k] |= v & ((~0ull >> (8 * (7 - b))) & (~0ull << (8 * a)));
+    }
+}
 template <bool PROFILE>
-__device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len, int i, int M, uint8_t *__restrict__ plane,
-                        int64_t plane_stride, int stop_len, Where *wh, WalkCnt &wc, Pend *pend = nullptr) {
+__device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len, int i, int M, uint64_t *__restrict__ acc,
+                        int stop_len, Where *wh, WalkCnt &wc, Pend *pend = nullptr) {
     const int K = e.K, X = e.X;
     if (i + K > len) return 0;
     // 16 bases as two 8-byte loads (the read buffer is padded); 2-bit codes gathered first base lowest, as getHashKey does
@@ -76,7 +87,9 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
     const uint64_t n0 = K >= 8 ? ~0ull : ((1ull << (8 * K)) - 1);
     if (((b0 & n0) | (b1 & nmask)) & 0xFCFCFCFCFCFCFCFCull) return 0;
     const uint64_t key = (squeeze8(b0) | (squeeze8(b1) << 16)) & ((1ull << (2 * K)) - 1);
-    const uint64_t ent = e.kmer[key];
+    // with the entry + tree-head table the entry and the first 56 bytes of the k-mer's tree are one line (at() below)
+    const uint8_t *__restrict__ fe = e.fat ? e.fat + (key << 6) : nullptr;
+    const uint64_t ent = fe ? ld8(fe) : e.kmer[key];
     wc.kmer++;
     int code = (int)(ent & 3);
     if (code == E_INVALID) return 0;
@@ -87,8 +100,13 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
     int d = K;
     int64_t node = -1, leaf_pos = -1, mh_at = -1;
     const uint8_t *__restrict__ mlt = e.mlt;
+    // eight bytes of the tree table at offset a: from the k-mer's line when they lie within the copied head of its tree
+    auto at = [&](int64_t a) -> const uint8_t * {
+        const uint64_t o = (uint64_t)(a - root);
+        return (fe && o <= 48) ? fe + 8 + o : mlt + a;
+    };
     if (code == E_SINGLE) {
-        leaf_pos = (int64_t)(ld_le(mlt + root + 1, 5) >> 1);
+        leaf_pos = (int64_t)(ld_le(at(root + 1), 5) >> 1);
         cur = 1;
     } else if (code == E_INFREQUENT) {
         node = root + 4;
@@ -100,7 +118,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
             if (b > 3) return 0;
             xk |= b << (2 * j);
         }
-        const uint64_t xe = ld_le(mlt + root + 4 + 8 * (int64_t)xk, 8);
+        const uint64_t xe = ld_le(at(root + 4 + 8 * (int64_t)xk), 8);
         wc.nodes++;
         code = (int)(xe & 3);
         if (code == E_INVALID) return 0;
@@ -108,7 +126,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
         cur = (int)((xe >> 17) & 31);
         if (cur == 0) cur = kMany;
         if (code == E_SINGLE) {
-            leaf_pos = (int64_t)(ld_le(mlt + root + (int64_t)(xe >> 24) + 1, 5) >> 1);
+            leaf_pos = (int64_t)(ld_le(at(root + (int64_t)(xe >> 24) + 1), 5) >> 1);
             cur = 1;
         } else {
             node = root + (int64_t)(xe >> 24);
@@ -118,7 +136,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
     auto drop_to = [&](int nc) {
         if (PROFILE) {
             const int hi = cur < M ? cur : M;
-            for (int m = nc + 1; m <= hi; ++m) plane[(int64_t)m * plane_stride] = (uint8_t)d;
+            if (nc + 1 <= hi) prof_set(acc, nc + 1, hi, d);
         }
         cur = nc;
     };
@@ -128,7 +146,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
         const uint32_t b = q[i + d];
         if (b > 3) break;
         const int c = 3 - (int)b;
-        const uint64_t head = ld_le(mlt + node, 8);       // code byte and the first 7 bytes behind it
+        const uint64_t head = ld_le(at(node), 8);       // code byte and the first 7 bytes behind it
         wc.nodes++;
         const uint32_t cd = (uint32_t)(head & 0xff);
         const int t = (cd >> (c << 1)) & 3;
@@ -144,7 +162,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
             while (j < lim_j) {
                 const uint64_t q8 = ld8(q + i + d + j);
                 const uint32_t rb = j < 24 ? (uint32_t)((head >> (16 + 2 * j)) & 0xffff)      // bytes 2.. of the head word (j is a multiple of 8)
-                                           : (uint32_t)ld_le(mlt + node + 2 + (j >> 2), 2);
+                                           : (uint32_t)ld_le(at(node + 2 + (j >> 2)), 2);
                 // reverse the four 2-bit groups of each byte, then complement: codes of eight bases, first base lowest
                 uint32_t r = ((rb & 0x0303u) << 6) | ((rb & 0x0C0Cu) << 2) | ((rb & 0x3030u) >> 2) | ((rb & 0xC0C0u) >> 6);
                 r = ~r & 0xffffu;
@@ -167,13 +185,13 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
         const uint32_t above = c == 3 ? 0u : (0xffu << ((c + 1) << 1)) & 0xff;
         const int n_ptr = __popc(is_div), before_ptr = __popc(is_div & above), before_leaf = __popc(is_leaf & above);
         if (t == N_LEAF) {
-            const uint64_t rec = ld_le(mlt + node + 1 + n_ptr * w + 5 * before_leaf, 5);
+            const uint64_t rec = ld_le(at(node + 1 + n_ptr * w + 5 * before_leaf), 5);
             wc.nodes++;
             int nc = 1;
             if (rec & 1) {
-                if (mh_base < 0) mh_base = root + (int64_t)ld_le(mlt + root, 4);
+                if (mh_base < 0) mh_base = root + (int64_t)ld_le(at(root), 4);
                 mh_at = mh_base + (int64_t)(rec >> 1);
-                const uint64_t h = ld_le(mlt + mh_at, 7);
+                const uint64_t h = ld_le(at(mh_at), 7);
                 nc = (int)(h & 0xffff);
                 leaf_pos = (int64_t)((h >> 16) >> 1);
                 if (nc >= 20) nc = kMany;
@@ -183,7 +201,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
             drop_to(nc);
             d += 1;
         } else {
-            const uint64_t v = ld_le(mlt + node + 1 + before_ptr * w, w);
+            const uint64_t v = ld_le(at(node + 1 + before_ptr * w), w);
             int nc = (int)(v & 63);
             if (nc == 0) nc = kMany;
             drop_to(nc);
@@ -216,7 +234,7 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
     }
     if (PROFILE) {
         const int hi = cur < M ? cur : M;
-        for (int m = 1; m <= hi; ++m) plane[(int64_t)m * plane_stride] = (uint8_t)d;
+        if (hi >= 1) prof_set(acc, 1, hi, d);
     } else {
         wh->root = root; wh->w = w;
         if (leaf_pos >= 0 && mh_at >= 0) { wh->kind = 2; wh->at = mh_at; }
@@ -226,8 +244,27 @@ __device__ int ert_walk(const DevErt &e, const uint8_t *__restrict__ q, int len,
     return d;
 }
 
+// entry + tree head, 64 bytes per k-mer: {the table entry, the first 56 bytes of its tree (what lies at its pointer; zero past the table)}.
+// The trees lie in k-mer order, so neighbouring threads read neighbouring bytes.
+__global__ __launch_bounds__(256) void ert_fat_kernel(const uint64_t *__restrict__ kmer, const uint8_t *__restrict__ mlt, int64_t mlt_bytes,
+                                                      int64_t n, uint8_t *__restrict__ fat) {
+    for (int64_t key = (int64_t)blockIdx.x * 256 + threadIdx.x; key < n; key += (int64_t)gridDim.x * 256) {
+        const uint64_t ent = kmer[key];
+        uint64_t w[8];
+        w[0] = ent;
+        const int64_t root = (int64_t)(ent >> 24);
+        for (int k = 0; k < 7; ++k) {
+            const int64_t a = root + 8 * k;
+            w[k + 1] = ((ent & 3) != E_INVALID && a + 8 <= mlt_bytes + 16) ? ld8(mlt + a) : 0ull;      // the table is padded by 16 bytes
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(fat + (key << 6));
+        for (int k = 0; k < 4; ++k) o[k] = make_uint4((uint32_t)w[2 * k], (uint32_t)(w[2 * k] >> 32), (uint32_t)w[2 * k + 1], (uint32_t)(w[2 * k + 1] >> 32));
+    }
+}
+
 constexpr int kErtTicket = 4;
-// lane = one base of the batch = one start position of one read.  planes: [0] = the base is N, [m] = L_m.
+// lane = one base of the batch = one start position of one read.  prof: a 24-byte record per position ([0] = the base is N, [m] = L_m),
+// written whole (round 3: (M + 1) byte planes, a byte store per m and lane — 158 M store instructions and 7 GB of partial lines per launch).
 // Persistent waves, 64 consecutive bases per trip: a walk lives for some ten microseconds, and a grid of one short-lived
 // workgroup per 256 bases kept only five waves per CU in flight (workgroup launch rate), where the walk needs dozens
 // of them to cover its chain of dependent HBM reads.
@@ -273,6 +310,7 @@ __global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_
         r = ((int64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r);
         const int64_t g = g0 + lane;
         Pend pd = {-1, 0, 0};
+        uint64_t acc[3] = {0ull, 0ull, 0ull};
         int64_t c0 = 0;
         int len = 0, i = 0;
         if (g < nbases) {
@@ -280,8 +318,8 @@ __global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_
             c0 = cum[r];
             len = (int)(cum[r + 1] - c0); i = (int)(g - c0);
             const uint8_t *q = enc + c0;
-            prof[g] = q[i] > 3;
-            if (!(skip && skip[r])) ert_walk<true>(e, q, len, i, M, prof + g, nbases, 0, nullptr, wc, &pd);
+            acc[0] = q[i] > 3 ? 1ull : 0ull;
+            if (!(skip && skip[r])) ert_walk<true>(e, q, len, i, M, acc, 0, nullptr, wc, &pd);
         }
         // ---- leaf expansion: the rest of the suffix is not in the tree, compare with the text (get_seeds_prefix :2940-2965)
         bool open = pd.leaf_pos >= 0;
@@ -332,7 +370,11 @@ __global__ __launch_bounds__(256) void ert_profile_kernel(DevErt e, const uint8_
         while (open) probe();                                // more diagonals in the wave than rounds: each lane for itself
         if (pd.leaf_pos >= 0 || pd.cur > 0) {
             const int hi = pd.cur < M ? pd.cur : M;
-            for (int m = 1; m <= hi; ++m) prof[g + (int64_t)m * nbases] = (uint8_t)d;
+            if (hi >= 1) prof_set(acc, 1, hi, d);
+        }
+        if (g < nbases) {                                    // the position's record, whole: 24 bytes, neighbours adjacent
+            uint64_t *o = reinterpret_cast<uint64_t *>(prof + g * kProfRec);
+            o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
         }
         }
     }
@@ -371,9 +413,9 @@ struct SelectArgs {
     DevCounters *ctr;
 };
 
-// wave = one read at a time, lane = read position (64 positions per chunk, up to four chunks): the profile bytes of a
-// read are consecutive in each plane, so every load of the wave is one or two lines (a lane per read made every load 64
-// lines: 5.2 ms per million reads).  Seeds are staged in LDS per wave and appended to the pool in batches.
+// wave = one read at a time, lane = read position (64 positions per chunk, up to four chunks): the records of a read's
+// positions are consecutive, so a wave's load covers 1.5 KB and a position's other lengths come from the same line
+// (a lane per read made every load 64 lines: 5.2 ms per million reads).  Seeds are staged in LDS per wave and appended to the pool in batches.
 constexpr int kSelStage = 320;        // staged seeds per wave (flushed when fewer than 64 + kSelSlack slots are free)
 constexpr int kSelSlack = 64;
 
@@ -416,15 +458,14 @@ __global__ __launch_bounds__(256) void ert_select_kernel(SelectArgs A) {
     W.st = stage + (threadIdx.x >> 6) * kSelStage;
     W.n = 0;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-    const int64_t S = A.nbases;
     for (int64_t r = wave; r < A.nseq; r += n_waves) {
         if (A.skip && A.skip[r]) continue;
         const int64_t c0 = A.cum[r];
         const int len = (int)(A.cum[r + 1] - c0);
         if (len <= 0) continue;
-        const uint8_t *P = A.prof + c0;
+        const uint8_t *P = A.prof + c0 * kProfRec;             // the read's records: 24 bytes per position, byte m = L_m, byte 0 = N
         const int nch = (len + 63) >> 6;                       // <= 4 (reads are at most 255 long)
-        auto L = [&](int m, int i) -> int { return P[(int64_t)m * S + i]; };
+        auto L = [&](int m, int i) -> int { return P[i * kProfRec + m]; };
         // hits of read[i, i+ln): the largest m with L_m(i) >= ln (L_m falls with m)
         auto count_of = [&](int i, int ln) -> int {
             int c = 1;
@@ -440,7 +481,7 @@ __global__ __launch_bounds__(256) void ert_select_kernel(SelectArgs A) {
             const bool v = k < nch && p < len;
             l1[k] = v ? L(1, p) : 0;
             lx[k] = v && A.max_intv > 0 ? L(A.max_intv, p) : 0;
-            nm[k] = __ballot(v && P[p] != 0);
+            nm[k] = __ballot(v && P[p * kProfRec] != 0);
         }
         // ---- round 1, with reseeding (bwamem.cpp:1165-1181) of the SMEMs that qualify
         int prev_e_carry = -1;                                // position - 1 + L_1 of the lane in front of this chunk
@@ -677,7 +718,7 @@ __global__ __launch_bounds__(256) void ert_locate_kernel(DevErt e, const uint8_t
         Where wh;
         wh.kind = 0; wh.w = 0; wh.at = 0; wh.root = 0;
         WalkCnt wc = {0, 0, 0};
-        const int d = ert_walk<false>(e, enc + c0, len, (int)s.m, 0, nullptr, 0, mlen, &wh, wc);
+        const int d = ert_walk<false>(e, enc + c0, len, (int)s.m, 0, nullptr, mlen, &wh, wc);
         int64_t cnt = s.s;
         if (d < mlen) { wh.kind = 0; cnt = 0; }                 // cannot happen with a consistent index
         if (wh.kind == 3) wh.at = skip_runs(e.mlt, wh.at);      // hits are listed from the four-way node behind a run
@@ -790,6 +831,11 @@ __global__ void ert_clear_kernel(bwams_smem_t *__restrict__ sm, int64_t n) {
 
 }  // namespace
 
+size_t ert_prof_bytes(int64_t nbases) { return (size_t)(nbases > 0 ? nbases : 1) * kProfRec + 8; }
+void launch_ert_fat(const DevErt &e, int64_t mlt_bytes, uint8_t *fat, hipStream_t st) {
+    const int64_t n = (int64_t)1 << (2 * e.K);
+    ert_fat_kernel<<<(unsigned)((n + 255) / 256 < 65536 * 16 ? (n + 255) / 256 : 65536 * 16), 256, 0, st>>>(e.kmer, e.mlt, mlt_bytes, n, fat);
+}
 void launch_ert_profile(const DevErt &e, const uint8_t *enc, const int64_t *cum, const uint8_t *skip, int64_t nseq,
                         int64_t nbases, int M, uint8_t *prof, DevCounters *ctr, unsigned long long *part, int cu_count,
                         hipStream_t st) {

@@ -51,7 +51,7 @@ const char *bwams_last_error(void);
  *   BWAMS_BWD_FUSED=0, BWAMS_BWD_CAP_MUL, BWAMS_SEED_R3_BESIDE=0, BWAMS_DEBUG   SMEM search launch variants / ablations
  *   BWAMS_EXT_MAX_ROUNDS, BWAMS_EXT_ALL_ROUNDS, BWAMS_EXT_INPLACE=0, BWAMS_BSW_PK=0, BWAMS_CHAIN_BATCH=0   extension rounds and kernel variants
  *   BWAMS_DEDUP_SEQ=1, BWAMS_PAIR_DROP_PLAN, BWAMS_TRACE_PAIR   fallback paths forced by tests; a line per launch of the paired-end tail
- *   BWAMS_ERT_GRID, BWAMS_ERT_TICKET=0   ERT walk launch shape        BWAMS_HOST_THREADS   host threads of mem_process_seqs' staging (6) */
+ *   BWAMS_ERT_GRID, BWAMS_ERT_FAT=0, BWAMS_ERT_TICKET=0   ERT walk launch shape        BWAMS_HOST_THREADS   host threads of mem_process_seqs' staging (6) */
 int bwams_debug_reload(void);
 int bwams_device_count(int *n);
 

@@ -80,8 +80,13 @@ def _check(o, e, ix, ert, enc, cum, oo, go, skip=None):
     return got
 
 
+@pytest.mark.parametrize("fat", [1, 0])
 @pytest.mark.parametrize("kmer,xmer,thr,n_bases,seed", [(8, 2, 16, 100000, 1), (6, 2, 6, 20000, 2), (10, 4, 256, 300000, 3)])
-def test_ert_seeding_matches_oracle_and_fm(kmer, xmer, thr, n_bases, seed):
+def test_ert_seeding_matches_oracle_and_fm(kmer, xmer, thr, n_bases, seed, fat, monkeypatch):
+    """fat = 1 (default): the walk reads a k-mer's entry and the head of its tree from the resident 64-byte-per-k-mer table derived from
+    the two files' bytes; fat = 0: from the two tables themselves."""
+    monkeypatch.setenv("BWAMS_ERT_FAT", str(fat))
+    capi.debug_reload()
     g, idx, o, e, ix, ert = _make(n_bases, seed, kmer, xmer, thr)
     enc, cum = _reads(g, 1500, seed)
     for kw in ({}, {"split_factor": 1.2, "split_width": 12, "max_mem_intv": 15, "max_occ": 7},

@@ -63,6 +63,12 @@ struct bwams_worker {
     std::mutex mu;
     std::condition_variable cv;
     std::string err;
+    // a chunk's text on its way into the work-item strings (the deferred collect): spare page-locked buffers that change places with the
+    // slot's, so that the slot is free for the next chunk while the strings are cut (60 ms per 400 MB: first-touch faults of fresh blocks)
+    std::mutex spare_mu;
+    char *spare_sam = nullptr;
+    int64_t spare_cap = 0;
+    int64_t *spare_off = nullptr;
 };
 
 static void die(const char *what, int rc, const char *msg = nullptr) {
@@ -98,6 +104,8 @@ void bwams_worker_destroy(bwams_worker *w) {
         void *ps[] = {s.enc, s.qual, s.names, s.comments, s.sam, s.cum, s.name_off, s.comment_off, s.sam_off, s.perfect, s.code};
         for (void *p : ps) if (p) bwams_host_free(p);
     }
+    if (w->spare_sam) bwams_host_free(w->spare_sam);
+    if (w->spare_off) bwams_host_free(w->spare_off);
     delete w;
 }
 
@@ -134,6 +142,7 @@ int bwams_worker_create_multi(bwams_index_t *const *idx, bwams_emf_t *const *emf
         if (!rc) rc = pinned(s.code, (size_t)max_reads);
         if (rc) break;
     }
+    if (!rc && depth > 1) rc = pinned(w->spare_off, (size_t)max_reads + 1);
     if (rc) { bwams_worker_destroy(w); return rc; }          // (the message of the failing call stays in bwams_last_error)
     *out = w;
     return BWAMS_OK;
@@ -302,22 +311,23 @@ static int stage_into(bwams_worker &w, Slot &s, const mem_opt_t *opt, int n, bse
 
 // the text back, one string per 512-read work item as worker_sam leaves it (src/bwamem.cpp:1722, :1823); find_perfect_match_entry's
 // record of every read (src/perfect_map.cpp:638-659)
-static int collect_from(bwams_worker &w, Slot &s, int n, bseq1_t *seqs) {
-    const double t0 = now_ms();
+static int fetch_text(bwams_worker &w, Slot &s) {
     int rc = grow(s.sam, s.sam_cap, s.bytes + 1);
     if (rc) return rc;
-    if ((rc = bwams_multi_fetch(s.multi, s.sam, s.sam_cap, s.sam_off))) { w.err = bwams_multi_error(s.multi); return rc; }
-    const double t1 = now_ms();
+    if ((rc = bwams_multi_fetch(s.multi, s.sam, s.sam_cap, s.sam_off))) w.err = bwams_multi_error(s.multi);
+    return rc;
+}
+static int cut_strings(bwams_worker &w, const char *sam, const int64_t *sam_off, int n, bseq1_t *seqs) {
     const int n_items = (n + BATCH_SIZE - 1) / BATCH_SIZE;
     std::mutex mu;
     bool oom = false;
     parallel_parts(n_items, host_threads(), [&](int a, int b) {
         for (int k = a; k < b; ++k) {
             const int i = k * BATCH_SIZE, e = i + BATCH_SIZE < n ? i + BATCH_SIZE : n;
-            const int64_t len = s.sam_off[e] - s.sam_off[i];
+            const int64_t len = sam_off[e] - sam_off[i];
             char *t = static_cast<char *>(malloc((size_t)len + 1));
             if (!t) { std::lock_guard<std::mutex> g(mu); oom = true; return; }
-            memcpy(t, s.sam + s.sam_off[i], (size_t)len);
+            memcpy(t, sam + sam_off[i], (size_t)len);
             t[len] = 0;
             seqs[i].sam = t;
         }
@@ -327,8 +337,16 @@ static int collect_from(bwams_worker &w, Slot &s, int n, bseq1_t *seqs) {
         w.err = "out of memory";
         return BWAMS_ERR_NOMEM;
     }
-    if (verbose()) fprintf(stderr, "[bwams_worker] collect: %lld bytes down %.1f ms, %d work-item strings %.1f ms\n", (long long)s.bytes, t1 - t0, n_items, now_ms() - t1);
     return BWAMS_OK;
+}
+static int collect_from(bwams_worker &w, Slot &s, int n, bseq1_t *seqs) {
+    const double t0 = now_ms();
+    int rc = fetch_text(w, s);
+    if (rc) return rc;
+    const double t1 = now_ms();
+    rc = cut_strings(w, s.sam, s.sam_off, n, seqs);
+    if (verbose()) fprintf(stderr, "[bwams_worker] collect: %lld bytes down %.1f ms, %d work-item strings %.1f ms\n", (long long)s.bytes, t1 - t0, (n + BATCH_SIZE - 1) / BATCH_SIZE, now_ms() - t1);
+    return rc;
 }
 
 int mem_process_seqs_stage(mem_opt_t *opt, int n, bseq1_t *seqs, bwams_worker &w) {
@@ -357,9 +375,24 @@ int mem_process_seqs_collect(mem_opt_t *opt, int n, bseq1_t *seqs, bwams_worker 
     if (n <= 0) return BWAMS_OK;
     Slot *s = take_slot(w, SLOT_COMPUTED, seqs, false);
     if (!s) return BWAMS_OK;                            // collected inside mem_process_seqs (not deferred), or the host path ran the chunk
-    int rc = collect_from(w, *s, n, seqs);
+    if (!w.spare_off) {                                 // depth 1: nothing to overlap with
+        int rc = collect_from(w, *s, n, seqs);
+        if (!rc) rc = emf_records(w, *s, n, (opt->flag & MEM_F_PE) ? 1 : 0, seqs);
+        put_slot(w, s, SLOT_FREE);
+        return rc;
+    }
+    // the text comes down into the slot's buffers, which then change places with the spare ones: the slot — its devices' buffers, its
+    // staging arrays — is free for the next chunk while this one's strings are cut
+    std::lock_guard<std::mutex> sp(w.spare_mu);
+    const double t0 = now_ms();
+    int rc = fetch_text(w, *s);
     if (!rc) rc = emf_records(w, *s, n, (opt->flag & MEM_F_PE) ? 1 : 0, seqs);
+    const long long bytes = (long long)s->bytes;
+    if (!rc) { std::swap(s->sam, w.spare_sam); std::swap(s->sam_cap, w.spare_cap); std::swap(s->sam_off, w.spare_off); }
     put_slot(w, s, SLOT_FREE);
+    const double t1 = now_ms();
+    if (!rc) rc = cut_strings(w, w.spare_sam, w.spare_off, n, seqs);
+    if (verbose()) fprintf(stderr, "[bwams_worker] collect: %lld bytes down %.1f ms (slot released), %d work-item strings %.1f ms\n", bytes, t1 - t0, (n + BATCH_SIZE - 1) / BATCH_SIZE, now_ms() - t1);
     return rc;
 }
 

@@ -195,7 +195,10 @@ def ert_report(st, mean, CHn, n_bases, ert_info, pmc=None):
         "bytes_per_launch": int(w_bytes), "launch_ms": round(w_ms, 3),
         "random_reads_per_s_G": round((st.ert_kmer_lookups + st.ert_node_reads) / (w_ms * 1e-3) / 1e9, 2),
         "note": "random 8-B / 32-B reads: the distinct-line ceiling of this part is 48 G lines/s (tools/ubench_gather), i.e. 0.38 of the "
-                "byte peak even for whole 64-B lines; random reads per second is the figure to read",
+                "byte peak even for whole 64-B lines; random reads per second is the figure to read.  Round 4: the walk reads a k-mer's entry "
+                "and the first 56 bytes of its tree from ONE line of a resident 64-byte-per-k-mer table derived from the two files' bytes "
+                "(BWAMS_ERT_FAT=0: the two tables themselves) and writes one 24-byte record per read position; the algorithmic bytes are "
+                "still the reference layout's",
     }
     info = {
         "kmer_size": ert_info["kmer"], "xmer_size": ert_info["xmer"], "read_len": ert_info["read_len"],
@@ -901,7 +904,7 @@ def main():
                 "algorithmic_bytes": round(all_bytes / CHn, 1),
             },
             "roofline": {
-                "kernel": "smem_search_kernel<ALL_POS> + smem_bwd_kernel (SMEM round 1: the lane-per-read search and the launch behind it for the backward phases that left their lanes — a wavefront per pivot with a long list, sixteen lanes per pivot otherwise; launch_ms brackets both)",
+                "kernel": "smem_search_kernel<ALL_POS, TAB> + smem_bwd_kernel<TAB> (SMEM round 1: the lane-per-read search and the launch behind it for the backward phases that left their lanes — a wavefront per pivot with a long list, sixteen lanes per pivot otherwise; launch_ms brackets both.  TAB = 2: the kernels read the resident interleaved form of CP_OCC — piece b = count and string of base b — half a block per end of an extension, fetched by a pair of lanes; BWAMS_CP2=0 reads CP_OCC itself)",
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
@@ -913,7 +916,8 @@ def main():
                 "bytes_per_launch": int(r1_bytes),
                 "bytes_note": "ALGORITHMIC bytes (SURVEY 8d): 64 B x every CP_OCC block an extension touches (1 if k and k + s share a block, else 2), "
                               "counted by the kernels as the oracle counts them, + 1 B per base in + 40 B per SMEM out.  Blocks served from the "
-                              "lane's two-block register cache (about 28 % of them) are INCLUDED: they cost no request.  `traffic` is what the "
+                              "lane's register cache (about 28 % of them) are INCLUDED: they cost no request, and a touched block counts 64 B although the kernels "
+                              "fetch only the half that holds the extension's base (32 B of a 128-B line either way).  `traffic` is what the "
                               "counters saw move (2 x FETCH_SIZE + WRITE_SIZE of the committed PMC pass)",
                 "launch_ms": round(r1_ms, 3),
                 "other_rounds": {"round2_frac": round(r2_bytes / (mean("ms_smem_r2") * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -854,8 +854,9 @@ int bwams_dedup_run(bwams_batch_t *b, const bwams_mem_opt_t *opt, int64_t *n_reg
     if (verbose_dd) {
         const unsigned long long *d = b->h_ctr->dbg;
         fprintf(stderr, "[bwams_dedup_run] largest wave instance: %llu reads, %llu slots, %llu alive; Mcycles: load %.1f sort(end) %.1f pairs %.1f reload %.1f sort(score) %.1f store %.1f; "
-                        "longest read: sort(end) %.2f pairs %.2f sort(score) %.2f, whole %.2f (read %llu, %llu regions)\n",
-                d[0], d[1], d[2], d[3] / 1e6, d[4] / 1e6, d[5] / 1e6, d[6] / 1e6, d[7] / 1e6, d[8] / 1e6, d[9] / 1e6, d[10] / 1e6, d[11] / 1e6, d[12] / 1e6, d[13], d[14]);
+                        "longest read: sort(end) %.2f pairs %.2f sort(score) %.2f, whole %.2f (read %llu, %llu regions; %llu patch alignments in %.2f, %llu scan trips); all reads: %llu patch alignments in %.1f\n",
+                d[0], d[1], d[2], d[3] / 1e6, d[4] / 1e6, d[5] / 1e6, d[6] / 1e6, d[7] / 1e6, d[8] / 1e6, d[9] / 1e6, d[10] / 1e6, d[11] / 1e6, d[12] / 1e6, d[13], d[14],
+                d[15], d[16] / 1e6, d[17], d[18], d[19] / 1e6);
     }
     s->n_final = total;
     s->dedup_done = true;

@@ -157,6 +157,79 @@ __device__ int global_score_wave(const bwams_mem_opt_t &o, int qlen, const uint8
     return eh[qlen].x;
 }
 
+// The same with the whole row in REGISTERS: lane l keeps the cells j = NC l .. NC l + NC - 1 of the (h, e) row and their query bases
+// (NC = 1 .. 4: queries up to 255 bases), so a row is one pass — no LDS round trip per 64 columns, one prefix maximum per row instead of
+// one per chunk.  Within the lane F runs cell to cell; between lanes it is the prefix maximum of (M - gap open + e_ins * column), as above.
+// A read in a satellite array takes some two hundred patch candidates one after the other (each changes what the next one sees only
+// if it succeeds): 28 ms for one read of the grch38_like genome with the row in LDS.
+template <int NC>
+__device__ int global_score_wave_reg(const bwams_mem_opt_t &o, int qlen, const uint8_t *qseq, int qs, int tlen, const uint8_t *tseq, int ts,
+                                     int w, int lane) {
+    const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
+    constexpr int kNeg = -0x30000000;
+    qlen = __builtin_amdgcn_readfirstlane(qlen); tlen = __builtin_amdgcn_readfirstlane(tlen); w = __builtin_amdgcn_readfirstlane(w);
+    int h[NC], e[NC], qb[NC], je[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = lane * NC + c;
+        h[c] = j == 0 ? 0 : (j <= w && j <= qlen) ? -(o.o_ins + e_ins * j) : MINUS_INF;
+        e[c] = MINUS_INF;
+        const int b = j < qlen ? (int)qseq[(int64_t)qs * j] : 4;
+        qb[c] = (b > 4 ? 4 : b) << 3;
+        je[c] = j * e_ins;
+    }
+    uint64_t mp[5];                                        // the matrix rows, five scores a word (scalar registers: the row loop loads nothing but the target)
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int8_t *mrow = &o.mat[t * 5];
+        mp[t] = (uint64_t)(uint8_t)mrow[0] | (uint64_t)(uint8_t)mrow[1] << 8 | (uint64_t)(uint8_t)mrow[2] << 16 |
+                (uint64_t)(uint8_t)mrow[3] << 24 | (uint64_t)(uint8_t)mrow[4] << 32;
+    }
+    int tv = 0;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) tv = i + lane < tlen ? (int)tseq[(int64_t)ts * (i + lane)] : 4;
+        int tb = __builtin_amdgcn_readlane(tv, i & 63);
+        tb = tb > 4 ? 4 : tb;
+        const uint64_t mpk = tb == 0 ? mp[0] : tb == 1 ? mp[1] : tb == 2 ? mp[2] : tb == 3 ? mp[3] : mp[4];
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int h1_first = beg == 0 ? -(o.o_del + e_del * (i + 1)) : MINUS_INF;
+        int m[NC], ti[NC], hv[NC];
+        int loc = kNeg;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane * NC + c;
+            m[c] = h[c] + (int)(int8_t)(uint8_t)(mpk >> qb[c]);
+            ti[c] = m[c] - oe_ins + je[c];                  // (M - gap open) + e_ins * column: what the prefix maximum runs over
+            if (j >= beg && j < end) loc = loc > ti[c] ? loc : ti[c];
+        }
+        int g = lane_shr1(dd_incl_max(loc), kNeg);         // the cells of the lanes to the left
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane * NC + c;
+            const int f = g - je[c] + e_ins;
+            int hh = m[c] >= e[c] ? m[c] : e[c];
+            hv[c] = hh >= f ? hh : f;
+            if (j >= beg && j < end) g = g > ti[c] ? g : ti[c];
+        }
+        const int hv_left0 = lane_shr1(hv[NC - 1], 0);     // H of the cell left of this lane's first one
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane * NC + c;
+            const int left = c == 0 ? hv_left0 : hv[c - 1];
+            if (j >= beg && j <= end) h[c] = j == beg ? h1_first : left;
+            if (j >= beg && j < end) {
+                const int t = m[c] - oe_del, ee = e[c] - e_del;
+                e[c] = ee > t ? ee : t;
+            } else if (j == end) e[c] = MINUS_INF;
+        }
+    }
+    int last = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) if (qlen % NC == c) last = h[c];
+    return __builtin_amdgcn_readlane(last, qlen / NC);
+}
+
 // mem_patch_reg's tests on the two regions' coordinates alone (bwamem.cpp:205-217), a upstream of b: false = it returns 0 before any alignment
 __device__ __forceinline__ bool patch_geom(const bwams_mem_opt_t &opt, int64_t l_pac, int64_t a_rb, int64_t a_re, int a_qb, int a_qe,
                                            int64_t b_rb, int64_t b_re, int b_qb, int b_qe) {
@@ -206,7 +279,11 @@ __device__ int patch_reg(const DedupArgs &A, const uint8_t *query, const bwams_a
             ww = ww < w ? ww : w;
             const int min_w = dl + 3;
             ww = ww > min_w ? ww : min_w;
-            score = global_score_wave(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh, qbuf, lane);
+            if (l_query < 64) score = global_score_wave_reg<1>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane);
+            else if (l_query < 128) score = global_score_wave_reg<2>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane);
+            else if (l_query < 192) score = global_score_wave_reg<3>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane);
+            else if (l_query < 256) score = global_score_wave_reg<4>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane);
+            else score = global_score_wave(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh, qbuf, lane);
         } else {
             int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);
             int max_del = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_del) / opt.e_del + 1.);
@@ -395,6 +472,7 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
             continue;
         }
         const bool prof = CAP == kLdsN && A.dbg != nullptr;
+        unsigned long long n_al = 0, t_al = 0, n_it = 0;       // patch alignments of the read, their time, scan trips (diagnostics)
         unsigned long long tk0 = prof ? wall_clock64() : 0ull, tk1 = tk0, tk2 = tk0, tk3 = tk0, tk4 = tk0, tk5 = tk0;
         int n = wave_compact_alive(a, l_ord, av_n, true, lane);         // bwamem.cpp:1446-1456
         const int n_alive0 = n;
@@ -438,6 +516,7 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
                 bool done = false;
                 int jtop = i - 1;
                 while (jtop >= 0 && !done) {
+                    ++n_it;
                     const int j = jtop - lane;
                     bool end = j < 0, red = false, pat = false;
                     if (!end) {
@@ -476,10 +555,12 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
                             continue;
                         }
                         int score = 0, w = 0;
+                        const unsigned long long ta0 = prof ? wall_clock64() : 0ull;
                         if (lds_eh) {
                             const bwams_alnreg_t qa = *qq, pa = *pp;       // written through by lane 0 only, read back behind a barrier
                             score = patch_reg<true>(A, query, qa, pa, &w, lds_eh, lds_q, lane);
                         } else if (lane == 0) score = patch_reg<false>(A, query, *qq, *pp, &w, eh);
+                        if (prof) { t_al += wall_clock64() - ta0; ++n_al; }
                         score = __builtin_amdgcn_readfirstlane(score);
                         w = __builtin_amdgcn_readfirstlane(w);
                         if (score > 0) {
@@ -559,7 +640,8 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
             atomicAdd(&A.dbg[3], tk1 - tk0); atomicAdd(&A.dbg[4], tk2 - tk1); atomicAdd(&A.dbg[5], tk3 - tk2);
             atomicAdd(&A.dbg[6], tk4 - tk3); atomicAdd(&A.dbg[7], tk5 - tk4); atomicAdd(&A.dbg[8], tk6 - tk5);
             atomicMax(&A.dbg[9], tk2 - tk1); atomicMax(&A.dbg[10], tk3 - tk2); atomicMax(&A.dbg[11], tk5 - tk4);
-            if (atomicMax(&A.dbg[12], tk6 - tk0) < tk6 - tk0) { A.dbg[13] = (unsigned long long)r; A.dbg[14] = (unsigned long long)n_alive0; }
+            if (atomicMax(&A.dbg[12], tk6 - tk0) < tk6 - tk0) { A.dbg[13] = (unsigned long long)r; A.dbg[14] = (unsigned long long)n_alive0; A.dbg[15] = n_al; A.dbg[16] = t_al; A.dbg[17] = n_it; }
+            atomicAdd(&A.dbg[18], n_al); atomicAdd(&A.dbg[19], t_al);
         }
     }
 }

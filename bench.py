@@ -636,9 +636,13 @@ def main():
         multi.close()
         for b_ in b2:
             b_.close()
+        for a_ in (nm_pin, enc_pin, q_pin):
+            capi.pinned_free(a_)
         del b2, multi, nm_pin, enc_pin, q_pin, mtext, moff
     except capi.BwamsError as e:
         sam_side["fastq_to_sam"]["two_batches_one_call"] = {"error": str(e)}
+    for a_ in (fq_pin, sam_pin, off_pin):
+        capi.pinned_free(a_)
     del fq_pin, sam_pin, off_pin
     del row, fq_text, d_fq, got_
     del aln_, cig_, md_, text_, tb, mq_, aln_r_

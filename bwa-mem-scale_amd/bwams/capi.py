@@ -1084,16 +1084,27 @@ class Multi:
             self.h = None
 
 
+_PINNED = {}          # address of a pinned_array's memory -> its finalizer (pinned_free runs it early)
+
+
 def pinned_array(n: int, dtype=np.uint8) -> np.ndarray:
-    """a numpy view of page-locked host memory (bwams_host_alloc); freed when the array is garbage collected"""
+    """a numpy view of page-locked host memory (bwams_host_alloc).  Free it with pinned_free(arr) when done; an array that is simply
+    dropped is freed when it is garbage collected (a finalizer that may run late, at interpreter exit)"""
     dt = np.dtype(dtype)
     p = C.c_void_p()
     _chk(lib().bwams_host_alloc(C.c_size_t(max(n, 1) * dt.itemsize), C.byref(p)), "bwams_host_alloc")
     buf = (C.c_uint8 * (max(n, 1) * dt.itemsize)).from_address(p.value)
     arr = np.frombuffer(buf, dtype=dt, count=n)
     import weakref
-    weakref.finalize(buf, lambda a=p.value: lib().bwams_host_free(C.c_void_p(a)))
+    _PINNED[p.value] = weakref.finalize(buf, lambda a=p.value: lib().bwams_host_free(C.c_void_p(a)))
     return arr
+
+
+def pinned_free(arr: np.ndarray) -> None:
+    """give a pinned_array's memory back now (the array must not be used afterwards)"""
+    fin = _PINNED.pop(arr.ctypes.data, None)
+    if fin is not None:
+        fin()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

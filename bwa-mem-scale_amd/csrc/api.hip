@@ -752,7 +752,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
         a.bwd_min_list = kn.bwd_min_list;
         a.bwd_cols = kn.bwd_cols;
         a.bwd_late_list = kn.bwd_late_list;
-        // once the work queue has run dry: 24 entries at the forward end, or 12 alive after 8 columns (tools/exp_bwd_dry.sh)
+        // once the work queue has run dry: 24 entries at the forward end, or 12 alive after 8 columns (profiles/r03_notes.md 96)
         a.bwd_dry_min_list = kn.bwd_dry_min_list;
         a.bwd_dry_cols = kn.bwd_dry_cols;
         a.bwd_dry_late_list = kn.bwd_dry_late_list;

@@ -1543,9 +1543,8 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     chain_wave_kernel<<<(unsigned)(cu_count * 4), 64, lds_bytes(kClassM2), aux[6]>>>(A, cls + 8, cls + 2, tk + 8, kClassM2);
     chain_wave_kernel<<<(unsigned)(cu_count * 8), 64, lds_bytes(kClassM1), aux[2]>>>(A, cls + 3, cls + 4, tk + 4, kClassM1);
     chain_wave_kernel<<<(unsigned)(cu_count * 12), 64, lds_bytes(kClassS), aux[3]>>>(A, cls + 4, cls + 5, tk + 5, kClassS);
-    // the lane tier (no LDS, 5 ms alone) on the batch's own stream, behind class XL2: behind class L on aux[1] it held class M back (kernel
-    // trace, uniform genome: L 3.0 + lane tier 8.8 + M 2.7 ms was the stage's longest stream)
-    chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, st>>>(A, n_seeds);
+    // (the lane tier on the batch's own stream behind class XL2 instead: 19.1 -> 20.3 ms on the uniform genome, 50 -> 54 on grch38_like)
+    chain_kernel<<<(unsigned)((A.nseq + 63) / 64), 64, 0, aux[1]>>>(A, n_seeds);
     // class M behind the lane tier (5 ms) rather than behind class L or S (kernel trace at GRCh38 size: L 8.9-10.3 ms + M 4.3-6.7 was
     // the stage's longest stream; S 7.8, L1 7.7 + M1 2.9, XL 0.9 + 7.2)
     // (round 4: on the stream of class L, the shortest; aux[4] shares a hardware queue with class S's stream, 16 ms on a repeat-rich genome)

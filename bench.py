@@ -57,7 +57,15 @@ REFERENCE_MEASURED = {
 
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
-        print("[bench]", *a, file=sys.stderr, flush=True)
+        free = ""
+        try:
+            import torch
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                f_, t_ = torch.cuda.mem_get_info()
+                free = f" [HBM free {f_ / 2**30:.0f} of {t_ / 2**30:.0f} GiB]"
+        except Exception:                              # noqa: BLE001 - a progress line must never end the run
+            pass
+        print("[bench]", *a, free, file=sys.stderr, flush=True)
 
 
 def parse_args(argv=None):
@@ -436,6 +444,7 @@ def main():
             "ms_per_chunk": round(ms_c, 2), "Mreads_per_s": round(len(row_c) / (ms_c * 1e-3) / 1e6, 3), "sam_bytes": int(bytes_c),
             "note": "bwams_process_chunk with the EMF and the ERT (configs[2]'s index set), single-end, FASTQ text in HBM -> SAM text in HBM"}
         del row_c, d_fq_c
+        log(f"configs[2] index set: step {ert_side['with_emf']['ms_per_step']} ms, text to text {ms_c:.1f} ms per chunk")
         # configs[2] as a JOB: chunks streamed through the compiled mem_process_seqs() with three chunks in flight (the reader's
         # thread stages chunk i + 1, the writer's collects chunk i - 1: kt_pipeline's three steps, bwams/stream.py) — records in host
         # memory in, SAM strings in host memory out, i.e. host staging and PCIe inside the clock
@@ -445,7 +454,7 @@ def main():
             rd_job = reads_l[n_chunks - 1]
             o_t = capi.mem_opt_init(False)
             res_j = {}
-            for depth_ in (2, 3, 1):
+            for depth_ in [int(x) for x in os.environ.get("BWAMS_STREAM_DEPTHS", "2,3,1").split(",")]:
                 pre = [capi.Seqs(rd_job, first_id=first + k * len(rd_job)) for k in range(n_job + 1)]      # step 0's output, parsed beforehand
                 wk = capi.Worker([ix], len(rd_job), len(rd_job) * RL, emfs=[emf_h], erts=[ert_h], depth=depth_)
                 stream.run_job(wk, o_t, lambda k: pre[n_job], 1, None, n_processed0=first)                  # warm-up: buffers, first touch
@@ -454,11 +463,12 @@ def main():
                 wk.close()
                 del pre
                 res_j[depth_] = n_j / secs_j / 1e6
+                log(f"configs2_stream: {depth_} chunk(s) in flight, {nj_} chunks: {res_j[depth_]:.3f} Mreads/s")
             resident_ = len(rd_job) / (ms_c * 1e-3) / 1e6
             ert_side["with_emf"]["configs2_stream"] = {
                 "Mreads_per_s": round(res_j[2], 3), "chunks": n_job, "reads_per_chunk": len(rd_job), "chunks_in_flight": 2,
                 "ms_per_chunk": round(len(rd_job) / res_j[2] / 1e3, 2), "ratio_to_resident": round(res_j[2] / resident_, 3),
-                "three_in_flight_Mreads_per_s": round(res_j[3], 3), "no_overlap_Mreads_per_s": round(res_j[1], 3),
+                "three_in_flight_Mreads_per_s": round(res_j[3], 3) if 3 in res_j else None, "no_overlap_Mreads_per_s": round(res_j[1], 3) if 1 in res_j else None,
                 "note": "BASELINE configs[2] as a job through the compiled mem_process_seqs() (host/mem_process_seqs_hip.cpp): parsed records "
                         "(bseq1_t) in host memory -> page-locked arrays -> GPU -> one malloc'ed SAM string per 512-read work item in host "
                         "memory, two chunks in flight (stage on the reader's thread, collect on the writer's); ratio_to_resident compares "

@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs A, const uint32_t *
 // reads with many seeds: one wave (= one block) per read, B-tree and chain records in LDS.  The reads
 // order[lo .. hi) (sorted by descending seed count, so a size class is a range) are handed out by ticket.
 // K = 0: no LDS (reads too large for a CU's LDS): state in HBM scratch.
-__global__ __launch_bounds__(64) void chain_wave_kernel(ChainArgs A, const unsigned long long *lo_p, const unsigned long long *hi_p,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void chain_wave_kernel(ChainArgs A, const unsigned long long *lo_p, const unsigned long long *hi_p,
                                                         unsigned long long *ticket, int K) {
     extern __shared__ __align__(16) unsigned char l_mem[];
     const int lane = threadIdx.x;

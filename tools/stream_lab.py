@@ -10,6 +10,8 @@ ap.add_argument("--genome-mbp", type=float, default=3209.286105)
 ap.add_argument("--reads", type=int, default=1_000_000)
 ap.add_argument("--chunks", type=int, default=6)
 ap.add_argument("--index-set", default="fm")
+ap.add_argument("--extra-batch", action="store_true", help="an idle batch beside the worker, as bench.py holds one")
+ap.add_argument("--depths", default="1,2,3")
 args = ap.parse_args()
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
@@ -31,7 +33,14 @@ if args.index_set == "full":
 reads = simulate.make_reads(genome, args.reads, seed=12345, contig_bounds=cb)[0]
 RL = reads.shape[1]
 opt = capi.mem_opt_init(False)
-for depth, overlap in ((1, False), (2, True), (3, True)):
+extra = None
+if args.extra_batch:
+    extra = capi.Batch(ix, len(reads), len(reads) * RL, max_smem=32 * len(reads), max_sa=128 * len(reads))
+    d_reads = torch.from_numpy(reads.reshape(-1)).to("cuda:0")
+    extra.seed_upload_device(d_reads.data_ptr(), np.arange(len(reads) + 1, dtype=np.int64) * RL)
+    extra.seed_run(capi.default_seed_opt(), with_sa=True); extra.chain_run(capi.default_mem_opt()); extra.extend_run(capi.default_mem_opt()); extra.dedup_run(capi.default_mem_opt())
+for depth in [int(x) for x in args.depths.split(",")]:
+    overlap = depth > 1
     pre = [capi.Seqs(reads, first_id=k * len(reads)) for k in range(args.chunks + 1)]
     w = capi.Worker([ix], len(reads), len(reads) * RL, emfs=[emf] if emf else None, erts=[ert] if ert else None, depth=depth)
     stream.run_job(w, opt, lambda k: pre[args.chunks], 1, None)

@@ -403,7 +403,10 @@ def main():
                     "final_regions": int(pc_e[-1].n_final_regs),
                     "note": "configs[2]'s seeding backend on the same reads: the ERT (k-mer table + radix trees, built on the GPU from the "
                             "resident FM-index) replaces SMEM search + SA lookup; chaining, extension and dedup unchanged; same final regions"}
-        # ... and with the exact-match filter in front of it: configs[2]'s index set (ERT + EMF) resident
+        # ... and with the exact-match filter in front of it: configs[2]'s index set (ERT + EMF) resident.  The walk's entry + tree-head table
+        # (64 GiB) is given back first: with the EMF beside it the GPU's memory is better spent on the chunks in flight (with 58 GiB free
+        # the streaming leg below ran at 4.4 .. 5.6 Mreads/s and three chunks in flight did not finish; profiles/r04_notes.md)
+        ert_h.set_fat(False)
         t0 = time.time()
         emf_h = capi.Emf.build(ix, seed_len=150, slack=1.1)
         emf_info = emf_h.info()
@@ -454,7 +457,10 @@ def main():
             rd_job = reads_l[n_chunks - 1]
             o_t = capi.mem_opt_init(False)
             res_j = {}
-            for depth_ in [int(x) for x in os.environ.get("BWAMS_STREAM_DEPTHS", "2,3,1").split(",")]:
+            depths_ = [int(x) for x in os.environ.get("BWAMS_STREAM_DEPTHS", "2,3,1").split(",")]
+            if torch.cuda.mem_get_info()[0] < 100 * 2 ** 30:           # three chunks in flight want three batches of buffers
+                depths_ = [d_ for d_ in depths_ if d_ != 3]
+            for depth_ in depths_:
                 pre = [capi.Seqs(rd_job, first_id=first + k * len(rd_job)) for k in range(n_job + 1)]      # step 0's output, parsed beforehand
                 wk = capi.Worker([ix], len(rd_job), len(rd_job) * RL, emfs=[emf_h], erts=[ert_h], depth=depth_)
                 stream.run_job(wk, o_t, lambda k: pre[n_job], 1, None, n_processed0=first)                  # warm-up: buffers, first touch

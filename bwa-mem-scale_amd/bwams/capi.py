@@ -29,7 +29,7 @@ SYMBOLS = [
     "bwams_index_set_contig_names", "bwams_index_set_contig_annos", "bwams_sam_upload", "bwams_sam_run", "bwams_sam_run_pe", "bwams_sam_run_emf", "bwams_sam_fetch",
     "bwams_process_chunk", "bwams_process_chunk_smart", "bwams_process_chunk2", "bwams_emf_regs_merge", "bwams_fastq_decode", "bwams_fastq_info", "bwams_fastq_has_qual", "bwams_fastq_fetch", "bwams_fastq_to_batch", "bwams_fastq_to_batch_opt", "bwams_fastq_close", "bwams_batch_create", "bwams_batch_destroy", "bwams_seed_fmi",
     "bwams_seed_upload", "bwams_seed_run", "bwams_seed_counts", "bwams_seed_fetch",
-    "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_seed_run_ert",
+    "bwams_ert_from_host", "bwams_ert_open", "bwams_ert_close", "bwams_ert_bytes", "bwams_ert_set_fat", "bwams_seed_run_ert",
     "bwams_ert_build", "bwams_ert_info", "bwams_ert_fetch", "bwams_ert_save", "bwams_debug_sort",
     "bwams_emf_build", "bwams_emf_info", "bwams_emf_table_fetch", "bwams_emf_save",
     "bwams_bsw_extend", "bwams_bsw_upload", "bwams_bsw_run", "bwams_bsw_fetch",
@@ -560,6 +560,10 @@ class Ert:
 
     def nbytes(self) -> int:
         return int(lib().bwams_ert_bytes(self.h))
+
+    def set_fat(self, on: bool):
+        """keep (derive again) or give back the walk's resident entry + tree-head table (bwams_ert_set_fat)"""
+        _chk(lib().bwams_ert_set_fat(self.h, 1 if on else 0), "bwams_ert_set_fat")
 
     def close(self):
         if self.h:

@@ -1209,6 +1209,29 @@ int bwams_ert_close(bwams_ert_t *e) {
 
 int64_t bwams_ert_bytes(const bwams_ert_t *e) { return e ? e->bytes : 0; }
 
+int bwams_ert_set_fat(bwams_ert_t *e, int32_t on) {
+    if (!e) return BWAMS_ERR_ARG;
+    BWAMS_HIP(hipSetDevice(e->idx->device));
+    BWAMS_HIP(hipDeviceSynchronize());                   // no walk is reading it
+    if (on) {
+        if (e->d_fat) return BWAMS_OK;
+        const size_t bytes = (size_t)64 << (2 * e->t.K);
+        BWAMS_HIP(dev_malloc(&e->d_fat, bytes));
+        launch_ert_fat(e->t, e->mlt_bytes, (uint8_t *)e->d_fat, 0);
+        BWAMS_HIP(hipDeviceSynchronize());
+        e->t.fat = (const uint8_t *)e->d_fat;
+        e->bytes += (int64_t)bytes;
+        return BWAMS_OK;
+    }
+    if (e->d_fat) {
+        (void)hipFree(e->d_fat);
+        e->d_fat = nullptr;
+        e->t.fat = nullptr;
+        e->bytes -= (int64_t)64 << (2 * e->t.K);
+    }
+    return BWAMS_OK;
+}
+
 static int ert_run_once(bwams_batch_t *b, bwams_ert_t *e, const bwams_seed_opt_t *opt, int with_sa, int M) {
     BWAMS_HIP(hipSetDevice(b->idx->device));
     hipStream_t st = b->stream;

@@ -2,6 +2,8 @@
 // (include/bwams.h): launch sequences over chain.hip, ext_aln.hip and bsw_extend.hip on the
 // batch's stream.  No CPU fallback: every entry point runs HIP kernels or returns an error.
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -74,9 +76,38 @@ struct ChainState {
     bwams_mem_opt_t opt{};
     hipEvent_t ev[16] = {};       // 0-1 chain, 2-3 plan+build, 4-5 left, 6-7 right, 8-9 selection (first round each), 10-11 all rounds
     bool ev_ok = false;
-    hipStream_t aux[7] = {};      // the chaining tiers run concurrently
+    hipStream_t aux[7] = {};      // the chaining tiers run concurrently (the device's shared set: aux_acquire)
+    int aux_device = -1;
     hipEvent_t fork = nullptr, join[7] = {};
 };
+
+// The auxiliary streams are ONE set per device, shared by its batches (reference-counted).  A batch of its own set made 9 streams per
+// batch; the runtime maps streams onto GPU_MAX_HW_QUEUES (8) hardware queues and a queue completes its packets in order, so with
+// three batches on a device (two chunks in flight + the caller's) a slot's copies landed behind another slot's kernels or not,
+// depending on the order in which the process had created its streams (bench.py: 4.5 .. 5.6 Mreads/s streaming in a process that had
+// created other batches before, 7.3 .. 7.6 in a fresh one).  Sharing is safe: every use is fork event -> launches -> join event, and
+// a stream is a total order.
+struct AuxSet { hipStream_t q[7] = {}; int refs = 0; };
+static std::mutex g_aux_mu;
+static std::map<int, AuxSet> g_aux;
+static int aux_acquire(int device, hipStream_t *out) {
+    std::lock_guard<std::mutex> g(g_aux_mu);
+    AuxSet &a = g_aux[device];
+    if (a.refs == 0)
+        for (auto &q : a.q) BWAMS_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    ++a.refs;
+    for (int i = 0; i < 7; ++i) out[i] = a.q[i];
+    return BWAMS_OK;
+}
+static void aux_release(int device) {
+    std::lock_guard<std::mutex> g(g_aux_mu);
+    auto it = g_aux.find(device);
+    if (it == g_aux.end()) return;
+    if (--it->second.refs == 0) {
+        for (auto &q : it->second.q) if (q) (void)hipStreamDestroy(q);
+        g_aux.erase(it);
+    }
+}
 
 void chain_state_free(ChainState *s) {
     if (!s) return;
@@ -93,7 +124,7 @@ void chain_state_free(ChainState *s) {
         for (auto &e : s->ev) (void)hipEventDestroy(e);
         for (auto &e : s->join) (void)hipEventDestroy(e);
         (void)hipEventDestroy(s->fork);
-        for (auto &q : s->aux) (void)hipStreamDestroy(q);
+        if (s->aux_device >= 0) aux_release(s->aux_device);
     }
     delete s;
 }
@@ -132,8 +163,9 @@ int get_state(bwams_batch *b, ChainState **out) {
         for (auto &e : b->chain->ev) BWAMS_HIP(hipEventCreate(&e));
         for (auto &e : b->chain->join) BWAMS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         BWAMS_HIP(hipEventCreateWithFlags(&b->chain->fork, hipEventDisableTiming));
-        for (auto &q : b->chain->aux) BWAMS_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
         b->chain->ev_ok = true;
+        if (int rc = aux_acquire(b->idx->device, b->chain->aux)) return rc;
+        b->chain->aux_device = b->idx->device;
     }
     *out = b->chain;
     return BWAMS_OK;

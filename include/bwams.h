@@ -399,6 +399,10 @@ int bwams_ert_fetch(bwams_ert_t *ert, uint64_t *kmer_table, uint8_t *mlt_table);
 int bwams_ert_save(bwams_ert_t *ert, const char *prefix);
 int bwams_ert_close(bwams_ert_t *ert);
 int64_t bwams_ert_bytes(const bwams_ert_t *ert);
+/* The walk's resident entry + tree-head table (64 B per k-mer, derived from the two tables when the handle is made unless BWAMS_ERT_FAT=0:
+ * a walk's entry and first records are one line): on = 0 gives its memory back — 64 GiB at k = 15, which a GPU that also holds the EMF
+ * wants for its chunks in flight —, on = 1 derives it again.  The results do not depend on it. */
+int bwams_ert_set_fat(bwams_ert_t *ert, int32_t on);
 
 /* bwams_seed_run over the ERT instead of the FM-index: same inputs (bwams_seed_upload), same outputs
  * (bwams_seed_counts / bwams_seed_fetch, then bwams_chain_run): the SMEMs of the three seeding rounds in

@@ -97,6 +97,22 @@ def test_ert_seeding_matches_oracle_and_fm(kmer, xmer, thr, n_bases, seed, fat, 
     ert.close(); ix.close()
 
 
+def test_ert_fat_table_given_back_and_derived_again():
+    """bwams_ert_set_fat: the same handle with, without and again with the resident entry + tree-head table gives the same seeds"""
+    g, idx, o, e, ix, ert = _make(120000, 11, 9, 3, 64)
+    enc, cum = _reads(g, 800, 4)
+    oo, go = _opts()
+    b0 = ert.nbytes()
+    _check(o, e, ix, ert, enc, cum, oo, go)
+    ert.set_fat(False)
+    assert ert.nbytes() == b0 - (64 << 18)
+    _check(o, e, ix, ert, enc, cum, oo, go)
+    ert.set_fat(True); ert.set_fat(True)
+    assert ert.nbytes() == b0
+    _check(o, e, ix, ert, enc, cum, oo, go)
+    ert.close(); ix.close()
+
+
 def test_ert_skip_flags_and_chain():
     """EMF-matched reads are left out; the chaining stage runs on ERT seeds exactly as on FM seeds."""
     g, idx, o, e, ix, ert = _make(150000, 5, 9, 3, 64)

@@ -162,9 +162,12 @@ __device__ int global_score_wave(const bwams_mem_opt_t &o, int qlen, const uint8
 // one per chunk.  Within the lane F runs cell to cell; between lanes it is the prefix maximum of (M - gap open + e_ins * column), as above.
 // A read in a satellite array takes some two hundred patch candidates one after the other (each changes what the next one sees only
 // if it succeeds): 28 ms for one read of the grch38_like genome with the row in LDS.
+// need: the smallest score mem_patch_reg accepts for this pair (INT_MIN: none).  Every eight rows the best any path can still reach — a
+// cell's H plus a match for every base of the shorter remainder — is compared with it: a candidate that cannot pass any more ends there
+// (its score only enters the acceptance test, bwamem.cpp:236-241; most candidates of a read in a satellite array fail, at half the rows).
 template <int NC>
 __device__ int global_score_wave_reg(const bwams_mem_opt_t &o, int qlen, const uint8_t *qseq, int qs, int tlen, const uint8_t *tseq, int ts,
-                                     int w, int lane) {
+                                     int w, int lane, int need) {
     const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins, e_del = o.e_del, e_ins = o.e_ins;
     constexpr int kNeg = -0x30000000;
     qlen = __builtin_amdgcn_readfirstlane(qlen); tlen = __builtin_amdgcn_readfirstlane(tlen); w = __builtin_amdgcn_readfirstlane(w);
@@ -211,6 +214,18 @@ __device__ int global_score_wave_reg(const bwams_mem_opt_t &o, int qlen, const u
             int hh = m[c] >= e[c] ? m[c] : e[c];
             hv[c] = hh >= f ? hh : f;
             if (j >= beg && j < end) g = g > ti[c] ? g : ti[c];
+        }
+        if ((i & 7) == 7 && need > MINUS_INF) {
+            const int rows_left = tlen - 1 - i;
+            int ub = kNeg;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int j = lane * NC + c;
+                const int cols_left = qlen - 1 - j;
+                const int u = hv[c] + o.a * (rows_left < cols_left ? rows_left : cols_left);
+                if (j >= beg && j < end) ub = ub > u ? ub : u;
+            }
+            if (__builtin_amdgcn_readlane(dd_incl_max(ub), 63) < need) return MINUS_INF;
         }
         const int hv_left0 = lane_shr1(hv[NC - 1], 0);     // H of the cell left of this lane's first one
 #pragma unroll
@@ -279,10 +294,19 @@ __device__ int patch_reg(const DedupArgs &A, const uint8_t *query, const bwams_a
             ww = ww < w ? ww : w;
             const int min_w = dl + 3;
             ww = ww > min_w ? ww : min_w;
-            if (l_query < 64) score = global_score_wave_reg<1>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane);
-            else if (l_query < 128) score = global_score_wave_reg<2>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane);
-            else if (l_query < 192) score = global_score_wave_reg<3>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane);
-            else if (l_query < 256) score = global_score_wave_reg<4>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane);
+            // what the pair must reach (the acceptance test below): lets the alignment stop once it cannot
+            const int q_s0 = (int)((double)(b.qe - a.qb) / (double)((b.qe - b.qb) + (a.qe - a.qb)) * (double)(b.score + a.score) + .499);
+            const int r_s0 = (int)((double)(b.re - a.rb) / (double)((b.re - b.rb) + (a.re - a.rb)) * (double)(b.score + a.score) + .499);
+            const int mx0 = q_s0 > r_s0 ? q_s0 : r_s0;
+            int need = MINUS_INF;
+            if (mx0 > 0) {
+                need = (int)((double)0.90f * (double)mx0);
+                while ((double)need / (double)mx0 < (double)0.90f) ++need;     // the smallest score the test accepts
+            }
+            if (l_query < 64) score = global_score_wave_reg<1>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane, need);
+            else if (l_query < 128) score = global_score_wave_reg<2>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane, need);
+            else if (l_query < 192) score = global_score_wave_reg<3>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane, need);
+            else if (l_query < 256) score = global_score_wave_reg<4>(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, lane, need);
             else score = global_score_wave(opt, l_query, qseq, st, (int)rlen, tseq, st, ww, eh, qbuf, lane);
         } else {
             int max_ins = (int)((double)(((l_query + 1) >> 1) * opt.mat[0] - opt.o_ins) / opt.e_ins + 1.);

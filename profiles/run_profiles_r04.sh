@@ -27,6 +27,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_ert -- python3 
 echo "fetch_ert done" >> $OUT/progress.txt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_ert -- python3 $EARGS > $OUT/pmc_write_ert.log 2>&1
 echo "write_ert done" >> $OUT/progress.txt
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq_ert -- python3 $EARGS > $OUT/pmc_sq_ert.log 2>&1 || true
+echo "sq_ert done" >> $OUT/progress.txt
 # Smith-Waterman kernels alone against the reference's own objects (oracle/_ref) on the host cores
 python3 tests/bench_sw_kernels.py > $OUT/sw_kernels.jsonl 2> $OUT/sw_kernels.log || true
 echo "sw done" >> $OUT/progress.txt

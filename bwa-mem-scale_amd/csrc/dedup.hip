@@ -162,8 +162,8 @@ __device__ int global_score_wave(const bwams_mem_opt_t &o, int qlen, const uint8
 // one per chunk.  Within the lane F runs cell to cell; between lanes it is the prefix maximum of (M - gap open + e_ins * column), as above.
 // A read in a satellite array takes some two hundred patch candidates one after the other (each changes what the next one sees only
 // if it succeeds): 28 ms for one read of the grch38_like genome with the row in LDS.
-// need: the smallest score mem_patch_reg accepts for this pair (INT_MIN: none).  Every eight rows the best any path can still reach — a
-// cell's H plus a match for every base of the shorter remainder — is compared with it: a candidate that cannot pass any more ends there
+// need: the smallest score mem_patch_reg accepts for this pair (INT_MIN: none).  Every four rows the best any path can still reach — a
+// cell's H plus a match for every base of the shorter remainder, minus a gap extension for every base of the difference — is compared with it: a candidate that cannot pass any more ends there
 // (its score only enters the acceptance test, bwamem.cpp:236-241; most candidates of a read in a satellite array fail, at half the rows).
 template <int NC>
 __device__ int global_score_wave_reg(const bwams_mem_opt_t &o, int qlen, const uint8_t *qseq, int qs, int tlen, const uint8_t *tseq, int ts,
@@ -215,14 +215,16 @@ __device__ int global_score_wave_reg(const bwams_mem_opt_t &o, int qlen, const u
             hv[c] = hh >= f ? hh : f;
             if (j >= beg && j < end) g = g > ti[c] ? g : ti[c];
         }
-        if ((i & 7) == 7 && need > MINUS_INF) {
+        if ((i & 3) == 3 && need > MINUS_INF) {
             const int rows_left = tlen - 1 - i;
             int ub = kNeg;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int j = lane * NC + c;
                 const int cols_left = qlen - 1 - j;
-                const int u = hv[c] + o.a * (rows_left < cols_left ? rows_left : cols_left);
+                // ... and the remainders' difference is gap bases, an extension each at least (the path may be inside a gap already)
+                const int u = hv[c] + (rows_left < cols_left ? o.a * rows_left - e_ins * (cols_left - rows_left)
+                                                             : o.a * cols_left - e_del * (rows_left - cols_left));
                 if (j >= beg && j < end) ub = ub > u ? ub : u;
             }
             if (__builtin_amdgcn_readlane(dd_incl_max(ub), 63) < need) return MINUS_INF;

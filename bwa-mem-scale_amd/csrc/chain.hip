@@ -1548,7 +1548,7 @@ int launch_chain(const ChainArgs &A, const uint32_t *n_seeds, int cu_count, hipS
     // class M behind the lane tier (5 ms) rather than behind class L or S (kernel trace at GRCh38 size: L 8.9-10.3 ms + M 4.3-6.7 was
     // the stage's longest stream; S 7.8, L1 7.7 + M1 2.9, XL 0.9 + 7.2)
     // (round 4: on the stream of class L, the shortest; aux[4] shares a hardware queue with class S's stream, 16 ms on a repeat-rich genome)
-    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[1]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
+    chain_wave_kernel<<<(unsigned)(cu_count * 5), 64, lds_bytes(kClassM), aux[5]>>>(A, cls + 2, cls + 3, tk + 3, kClassM);
     for (int i = 0; i < 7; ++i) {
         if (hipEventRecord(join[i], aux[i]) != hipSuccess) return -1;
         if (hipStreamWaitEvent(st, join[i], 0) != hipSuccess) return -1;

@@ -34,6 +34,8 @@ def run_job(worker: "capi.Worker", opt: "capi.MemOptT", make_chunk, n_chunks: in
     def reader():
         try:
             for i in range(n_chunks):
+                if errs:                              # a later step has failed: nothing more to stage
+                    break
                 s = make_chunk(i)
                 worker.stage(opt, s)                  # waits for a free slot: at most `depth` chunks in flight
                 q01.put((i, s))
@@ -65,8 +67,11 @@ def run_job(worker: "capi.Worker", opt: "capi.MemOptT", make_chunk, n_chunks: in
                 break
             i, s = it
             if not errs:
-                worker.process(opt, done, s)
-                q12.put((i, s))
+                try:
+                    worker.process(opt, done, s)
+                    q12.put((i, s))
+                except BaseException as e:           # noqa: BLE001 - keep taking chunks from the reader (it may be blocked handing one
+                    errs.append(e)                   # over: leaving the loop here left it there for good — a run that ran out of HBM hung)
             done += s.n
             reads += s.n
     finally:

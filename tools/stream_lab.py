@@ -12,6 +12,7 @@ ap.add_argument("--chunks", type=int, default=6)
 ap.add_argument("--index-set", default="fm")
 ap.add_argument("--extra-batch", action="store_true", help="an idle batch beside the worker, as bench.py holds one")
 ap.add_argument("--depths", default="1,2,3")
+ap.add_argument("--leave-free-gib", type=float, default=0.0, help="hog HBM so that only this much is free when the worker is made (memory-exhaustion rehearsal)")
 args = ap.parse_args()
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
@@ -33,6 +34,13 @@ if args.index_set == "full":
 reads = simulate.make_reads(genome, args.reads, seed=12345, contig_bounds=cb)[0]
 RL = reads.shape[1]
 opt = capi.mem_opt_init(False)
+hog = None
+if args.leave_free_gib > 0:
+    free_b, _ = torch.cuda.mem_get_info()
+    n_hog = int(free_b - args.leave_free_gib * 2 ** 30)
+    if n_hog > 0:
+        hog = torch.empty(n_hog, dtype=torch.uint8, device="cuda:0")
+    print(f"[stream] HBM free {torch.cuda.mem_get_info()[0] / 2**30:.1f} GiB", flush=True)
 extra = None
 if args.extra_batch:
     extra = capi.Batch(ix, len(reads), len(reads) * RL, max_smem=32 * len(reads), max_sa=128 * len(reads))
@@ -42,7 +50,9 @@ if args.extra_batch:
 for depth in [int(x) for x in args.depths.split(",")]:
     overlap = depth > 1
     pre = [capi.Seqs(reads, first_id=k * len(reads)) for k in range(args.chunks + 1)]
+    print(f"[stream] depth {depth}: creating the worker", flush=True)
     w = capi.Worker([ix], len(reads), len(reads) * RL, emfs=[emf] if emf else None, erts=[ert] if ert else None, depth=depth)
+    print(f"[stream] depth {depth}: warm-up chunk", flush=True)
     stream.run_job(w, opt, lambda k: pre[args.chunks], 1, None)
     secs, n = stream.run_job(w, opt, lambda k: pre[k], args.chunks, None, overlap=overlap)
     w.close()

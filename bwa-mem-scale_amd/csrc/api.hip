@@ -475,7 +475,7 @@ int bwams_index_fetch_fma(bwams_index_t *ix, void *all_smem, void *last_smem) {
 
 // (re)allocate every buffer whose size follows max_smem; the batch grows them when a chunk needs more
 static int alloc_smem_buffers(bwams_batch *b, int64_t max_smem) {
-    void **ptrs[] = {(void **)&b->d_pool, (void **)&b->d_sorted, (void **)&b->d_keys, (void **)&b->d_keys2, (void **)&b->d_vals,
+    void **ptrs[] = {(void **)&b->d_pool, (void **)&b->d_pool3, (void **)&b->d_sorted, (void **)&b->d_keys, (void **)&b->d_keys2, (void **)&b->d_vals,
                      (void **)&b->d_vals2, (void **)&b->d_work2, (void **)&b->d_sa_off, (void **)&b->d_sa_cnt};
     for (void **p : ptrs)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -484,6 +484,10 @@ static int alloc_smem_buffers(bwams_batch *b, int64_t max_smem) {
     // of each of the five emitting launches on top of the max_smem real records
     b->pool_cap = b->max_smem + seed_pool_slack(b->cu_count);
     BWAMS_HIP(dev_malloc(&b->d_pool, (size_t)b->pool_cap * sizeof(bwams_smem_t)));
+    // round 3's own pool (it runs from the start of the stage): it may hold most of a chunk's records (a clean unique read has one
+    // SMEM and half a dozen round-3 seeds), so it is as large as the main one's record part + one launch's chunk tails
+    b->pool3_cap = b->max_smem + seed_pool_slack(b->cu_count) / 5;
+    BWAMS_HIP(dev_malloc(&b->d_pool3, (size_t)b->pool3_cap * sizeof(bwams_smem_t)));
     BWAMS_HIP(dev_malloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
     BWAMS_HIP(dev_malloc(&b->d_keys, (size_t)b->pool_cap * 8));
     BWAMS_HIP(dev_malloc(&b->d_keys2, (size_t)b->pool_cap * 8));
@@ -519,6 +523,7 @@ static int batch_create_fill(bwams_batch *b, bwams_index_t *ix, int64_t max_read
     if (int arc = alloc_smem_buffers(b, b->max_smem)) return arc;
     BWAMS_HIP(dev_malloc(&b->d_sa_coord, (size_t)b->max_sa * 8));
     BWAMS_HIP(dev_malloc(&b->d_ctr, sizeof(DevCounters)));
+    BWAMS_HIP(dev_malloc(&b->d_ctr3, sizeof(DevCounters)));
     BWAMS_HIP(hipHostMalloc(&b->h_ctr, sizeof(DevCounters)));
     BWAMS_HIP(hipMemset(b->d_ctr, 0, sizeof(DevCounters)));
 
@@ -553,7 +558,7 @@ int bwams_batch_destroy(bwams_batch_t *b) {
     (void)hipSetDevice(b->idx->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_enc, b->d_cum, b->d_skip, b->d_pool, b->d_sorted, b->d_keys, b->d_keys2, b->d_vals,
-                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk, b->d_ert_redo, b->d_bwd_items, b->d_bwd_ent, b->d_f_items, b->d_fl_ent};
+                    b->d_vals2, b->d_work2, b->d_sa_off, b->d_sa_cnt, b->d_sa_coord, b->d_tmp, b->d_ctr, b->d_ctr3, b->d_pool3, b->d_prev, b->d_packed, b->d_emf_out, b->d_emf_code, b->d_ksw_out, b->d_bsw_list, b->d_pairs, b->d_ref, b->d_qer, b->d_ert_prof, b->d_ert_stk, b->d_ert_redo, b->d_bwd_items, b->d_bwd_ent, b->d_f_items, b->d_fl_ent};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
@@ -764,6 +769,24 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     BWAMS_HIP(hipEventRecord(b->ev[0], st));
     launch_pack_reads(b->d_enc, b->d_cum, b->nseq, b->read_w, b->read_cw, b->d_packed, st);
     launch_mark(b->d_ctr, 0, st);
+    // Round 3 reads nothing of rounds 1 and 2 (bwtSeedStrategyAllPosOneThread walks every read from position 0).  BWAMS_SEED_R3_BESIDE=2
+    // (an experiment, kept behind the switch and under the parity test): it is launched HERE, on the stream of its own, with a pool and
+    // counters of its own (round 2's work list is cut from the main pool's prefix); behind round 2 its records are appended to the main
+    // pool and its counts folded in (append_r3_kernel + mark 3).  The hope was that its workgroups would only find room where round 1
+    // drains; they are placed beside round 1's throughout: round 1 16.1 -> 18.3 ms, round 2 12.5 -> 10.7, the stage 35.3 -> 35.8 ms.
+    const int r3_mode = (b->nseq > 0 && opt->max_mem_intv > 0 && !split && !lab_overlap) ? knobs().r3_beside : 0;
+    SeedLaunch a3 = a;
+    a3.min_seed_len = opt->min_seed_len + 1;
+    if (r3_mode == 2) {
+        a3.pool = b->d_pool3; a3.pool_cap = b->pool3_cap; a3.ctr = b->d_ctr3;
+        BWAMS_HIP(hipMemsetAsync(b->d_ctr3, 0, sizeof(DevCounters), st));
+        BWAMS_HIP(hipEventRecord(b->seed_fork, st));
+        BWAMS_HIP(hipStreamWaitEvent(b->seed_aux, b->seed_fork, 0));
+        BWAMS_HIP(hipEventRecord(b->ev[12], b->seed_aux));
+        launch_smem_round3(a3, opt->max_mem_intv, b->cu_count, b->seed_aux);
+        BWAMS_HIP(hipEventRecord(b->ev[13], b->seed_aux));
+        BWAMS_HIP(hipEventRecord(b->seed_join, b->seed_aux));
+    }
     BWAMS_HIP(hipEventRecord(b->ev[8], st));
     if (b->nseq > 0) {
         if (lab_overlap && b->f_items_prev[par ^ 1][0] >= 0) {
@@ -794,10 +817,8 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     // Round 3 reads nothing of rounds 1 and 2 (bwtSeedStrategyAllPosOneThread walks every read from position 0): it runs beside
     // round 2 on a stream of its own and fills the tail in which round 2's slowest reads keep few lanes busy.  Its extensions and
     // SMEMs are counted apart (n_ext3 / n_blk3 / n_smem3), so that the per-round figures stay exact.
-    SeedLaunch a3 = a;
-    a3.min_seed_len = opt->min_seed_len + 1;
-    const bool r3_beside = knobs().r3_beside != 0;
-    const bool r3 = b->nseq > 0 && opt->max_mem_intv > 0;
+    const bool r3_beside = knobs().r3_beside != 0 && r3_mode != 2;
+    const bool r3 = b->nseq > 0 && opt->max_mem_intv > 0 && r3_mode != 2;
     hipStream_t st3 = r3_beside ? b->seed_aux : st;
     if (r3 && r3_beside) {
         BWAMS_HIP(hipEventRecord(b->seed_fork, st));
@@ -814,9 +835,10 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     }
     if (b->nseq > 0) launch_smem_bwd_wave(a, b->cu_count, st);
     BWAMS_HIP(hipEventRecord(b->ev[11], st));
-    if (r3 && r3_beside) BWAMS_HIP(hipStreamWaitEvent(st, b->seed_join, 0));
+    if ((r3 && r3_beside) || r3_mode == 2) BWAMS_HIP(hipStreamWaitEvent(st, b->seed_join, 0));
     launch_mark(b->d_ctr, 2, st);
-    if (!(r3 && r3_beside)) {
+    if (r3_mode == 2) launch_append_r3(b->d_pool, b->pool_cap, b->d_pool3, b->pool3_cap, b->d_ctr, b->d_ctr3, st);
+    if (!(r3 && r3_beside) && r3_mode != 2) {
         BWAMS_HIP(hipEventRecord(b->ev[12], st));
         if (r3) launch_smem_round3(a3, opt->max_mem_intv, b->cu_count, st);
         BWAMS_HIP(hipEventRecord(b->ev[13], st));

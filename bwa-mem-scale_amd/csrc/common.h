@@ -27,7 +27,8 @@ struct Knobs {
     int bwd_dry_min_list = 24, bwd_dry_cols = 8, bwd_dry_late_list = 12;         // BWAMS_BWD_DRY_*: the same once the work queue is dry
     int bwd_fused = 1;             // BWAMS_BWD_FUSED=0: the two roles behind a search kernel as two launches
     int bwd_cap_mul = 1;           // BWAMS_BWD_CAP_MUL: hand-over buffers x this (experiments that hand every backward phase over)
-    int r3_beside = 1;             // BWAMS_SEED_R3_BESIDE=0: SMEM round 3 behind round 2 instead of beside it
+    int r3_beside = 1;             // BWAMS_SEED_R3_BESIDE: 1 (default) = SMEM round 3 beside round 2; 0 = behind it; 2 = from the START of the stage into a
+                                   // pool of its own (measured: its workgroups do get placed beside round 1's — round 1 16.1 -> 18.3 ms, stage 35.3 -> 35.8)
     int ext_max_rounds = 0;        // BWAMS_EXT_MAX_ROUNDS: cap of the extension rounds (tests force the extend-the-rest fallback)
     int ext_all_rounds = 0;        // BWAMS_EXT_ALL_ROUNDS: never cut the rounds short
     int ext_inplace = 1;           // BWAMS_EXT_INPLACE=0: extension tasks copied into flat buffers
@@ -261,6 +262,9 @@ struct bwams_batch {
 
     // seeding buffers
     bwams_smem_t *d_pool = nullptr;      // unsorted SMEM pool (append order)
+    bwams_smem_t *d_pool3 = nullptr;     // round 3's own pool while it runs from the start of the stage (appended to d_pool behind round 2)
+    int64_t pool3_cap = 0;
+    bwams::DevCounters *d_ctr3 = nullptr;   // ... and its own counters
     bwams_smem_t *d_sorted = nullptr;    // (rid, m, n) order
     uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
     uint32_t *d_vals = nullptr, *d_vals2 = nullptr;

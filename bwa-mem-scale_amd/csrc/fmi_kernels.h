@@ -40,6 +40,8 @@ struct SeedLaunch {
 // grid sizing shared by batch_create (scratch) and the launches
 int seed_block_threads();
 int64_t seed_max_threads(int cu_count);
+// round 3's records (a pool and counters of its own while it ran from the start of the stage) behind the main pool's, its counts into n_smem3 / n_ext3 / n_blk3
+void launch_append_r3(bwams_smem_t *pool, int64_t pool_cap, const bwams_smem_t *pool3, int64_t pool3_cap, DevCounters *ctr, const DevCounters *ctr3, hipStream_t st);
 int64_t seed_pool_slack(int cu_count);   // pool slots the launches of one seeding pass can leave unused in partly filled chunks
 
 // enc_qdb bytes -> 2-bit codes + N mask, W words per read

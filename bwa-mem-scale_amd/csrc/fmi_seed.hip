@@ -1851,6 +1851,24 @@ __global__ void round2_work_kernel(const bwams_smem_t *pool, DevCounters *ctr, R
     }
 }
 
+// round 3 ran with a pool and counters of its own: its slots (chunk holes included) go behind the main pool's ...
+__global__ void append_r3_kernel(bwams_smem_t *__restrict__ pool, int64_t pool_cap, const bwams_smem_t *__restrict__ pool3, int64_t pool3_cap,
+                                 const DevCounters *ctr, const DevCounters *ctr3) {
+    const int64_t n12 = (int64_t)ctr->n_smem_total;
+    int64_t n3 = (int64_t)ctr3->n_smem_total;
+    if (n3 > pool3_cap) n3 = pool3_cap;                   // (the overflow is reported by the finish kernel)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x)
+        if (n12 + i < pool_cap) pool[n12 + i] = pool3[i];
+}
+// ... and its counts into the fields mark_kernel(3) folds in.  A pool that could not hold round 3's records shows as a slot count
+// beyond the main pool's capacity: the host grows the pools and runs the stage again.
+__global__ void append_r3_finish_kernel(int64_t pool_cap, int64_t pool3_cap, DevCounters *ctr, const DevCounters *ctr3) {
+    const unsigned long long n3 = ctr3->n_smem_total;
+    ctr->n_smem_total += n3;
+    if ((int64_t)n3 > pool3_cap && (int64_t)ctr->n_smem_total <= pool_cap) ctr->n_smem_total = (unsigned long long)pool_cap + (n3 - (unsigned long long)pool3_cap);
+    ctr->n_smem3 += ctr3->n_smem3; ctr->n_ext3 += ctr3->n_ext3; ctr->n_blk3 += ctr3->n_blk3;
+}
+
 // bookkeeping between rounds (single thread): snapshot the pool cursor, reset the queue
 __global__ void mark_kernel(DevCounters *ctr, int which) {
     if (which == 1) { ctr->n_after_r1 = ctr->n_smem_total; ctr->valid_after[0] = ctr->n_smem_valid; }
@@ -2095,6 +2113,11 @@ int64_t seed_pool_slack(int cu_count) {
 }
 
 void launch_mark(DevCounters *ctr, int which, hipStream_t st) { mark_kernel<<<1, 1, 0, st>>>(ctr, which); }
+void launch_append_r3(bwams_smem_t *pool, int64_t pool_cap, const bwams_smem_t *pool3, int64_t pool3_cap, DevCounters *ctr, const DevCounters *ctr3,
+                      hipStream_t st) {
+    append_r3_kernel<<<256, 256, 0, st>>>(pool, pool_cap, pool3, pool3_cap, ctr, ctr3);
+    append_r3_finish_kernel<<<1, 1, 0, st>>>(pool_cap, pool3_cap, ctr, ctr3);
+}
 
 void launch_smem_round1(const SeedLaunch &a, int cu_count, hipStream_t st) {
     const int tab = a.fmi.cp2 ? a.fmi.tab_kind : 0;

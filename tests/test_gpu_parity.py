@@ -172,6 +172,26 @@ def test_resident_buffers_grow_on_demand(gpu_toy):
     b.close()
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_round3_behind_beside_or_from_the_start(gpu_toy, monkeypatch, mode):
+    """BWAMS_SEED_R3_BESIDE: round 3 behind round 2 (0), beside it (1), or from the start of the stage with a pool and counters of its
+    own, appended behind round 2's records (2): schedules, not algorithms — the same SMEMs, coordinates and counts."""
+    g, idx, ix = gpu_toy
+    monkeypatch.setenv("BWAMS_SEED_R3_BESIDE", mode)
+    capi.debug_reload()
+    reads, _, _ = simulate.make_reads(g, 4000, seed=77)
+    reads = list(reads) + [np.zeros(120, np.uint8), np.tile(np.array([0, 1], np.uint8), 100), np.full(60, 4, np.uint8)]
+    for kw in ({}, {"min_seed_len": 12, "max_mem_intv": 8}, {"max_mem_intv": 0}):
+        ctr = loader.Counters()
+        want, wcoord, woff, got, coord, off, st = _seed_both(idx, ix, reads, kw, oracle_counters=ctr)
+        assert len(got) == len(want)
+        for f in ("rid", "m", "n", "k", "l", "s"):
+            assert np.array_equal(got[f], want[f]), (kw, f)
+        assert np.array_equal(off, woff) and np.array_equal(coord, wcoord)
+        assert st.n_ext == ctr.n_ext and st.n_ext_blocks == ctr.n_ext_blocks
+        assert list(st.n_smem) == list(ctr.n_smem)
+
+
 def test_pool_with_no_room_to_spare_and_every_emitting_launch(gpu_toy, monkeypatch):
     """the SMEM pool is handed out in 64-slot chunks by SEVEN emitting launches (three searches, and the two kernels
     behind rounds 1 and 2 for the backward phases that left their lanes); a batch whose max_smem is the chunk's exact SMEM count

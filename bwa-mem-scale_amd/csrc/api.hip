@@ -487,7 +487,7 @@ static int alloc_smem_buffers(bwams_batch *b, int64_t max_smem) {
     // round 3's own pool (it runs from the start of the stage): it may hold most of a chunk's records (a clean unique read has one
     // SMEM and half a dozen round-3 seeds), so it is as large as the main one's record part + one launch's chunk tails
     b->pool3_cap = b->max_smem + seed_pool_slack(b->cu_count) / 5;
-    BWAMS_HIP(dev_malloc(&b->d_pool3, (size_t)b->pool3_cap * sizeof(bwams_smem_t)));
+    if (knobs().r3_beside == 2) BWAMS_HIP(dev_malloc(&b->d_pool3, (size_t)b->pool3_cap * sizeof(bwams_smem_t)));      // the experiment's buffer: only on demand
     BWAMS_HIP(dev_malloc(&b->d_sorted, (size_t)b->max_smem * sizeof(bwams_smem_t)));
     BWAMS_HIP(dev_malloc(&b->d_keys, (size_t)b->pool_cap * 8));
     BWAMS_HIP(dev_malloc(&b->d_keys2, (size_t)b->pool_cap * 8));
@@ -778,6 +778,7 @@ static int seed_run_once(bwams_batch_t *b, const bwams_seed_opt_t *opt, int with
     SeedLaunch a3 = a;
     a3.min_seed_len = opt->min_seed_len + 1;
     if (r3_mode == 2) {
+        if (!b->d_pool3) BWAMS_HIP(dev_malloc(&b->d_pool3, (size_t)b->pool3_cap * sizeof(bwams_smem_t)));
         a3.pool = b->d_pool3; a3.pool_cap = b->pool3_cap; a3.ctr = b->d_ctr3;
         BWAMS_HIP(hipMemsetAsync(b->d_ctr3, 0, sizeof(DevCounters), st));
         BWAMS_HIP(hipEventRecord(b->seed_fork, st));

@@ -672,13 +672,23 @@ __global__ __launch_bounds__(64) void dedup_wave_kernel(DedupArgs A, int64_t n_w
     }
 }
 
-// lane per read: the surviving regions, in their final order
-__global__ void dedup_gather_kernel(DedupArgs A, const int64_t *__restrict__ out_off, bwams_alnreg_t *out) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// the surviving regions, in their final order.  Sixteen lanes per read, a 16-byte seventh of a 112-byte region per lane and step: a
+// lane per read copied its regions one after the other, 112 bytes at a time at addresses of its own (1.1 ms per million reads for 0.4 GB)
+static_assert(sizeof(bwams_alnreg_t) == 112, "a region is seven 16-byte pieces");
+__global__ __launch_bounds__(256) void dedup_gather_kernel(DedupArgs A, const int64_t *__restrict__ out_off, bwams_alnreg_t *out) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
     if (r >= A.nseq) return;
     const int64_t reg0 = A.seed_off[r];
     const int n = A.n_out[r];
-    for (int i = 0; i < n; ++i) out[out_off[r] + i] = A.regs[reg0 + A.ord[reg0 + i]];
+    if (n <= 0) return;
+    const int64_t o0 = out_off[r];
+    const uint4 *src = reinterpret_cast<const uint4 *>(A.regs + reg0);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + o0);
+    for (int u = sub; u < n * 7; u += 16) {
+        const int i = u / 7, piece = u - 7 * i;
+        dst[u] = src[(int64_t)A.ord[reg0 + i] * 7 + piece];
+    }
 }
 
 // ---- mem_pestat, the per-pair part (bwamem_pair.cpp:66-108): lane per pair -> key = dir << 60 | insert size, or ~0 ----
@@ -793,7 +803,7 @@ int launch_dedup(const DedupArgs &A, int64_t n_lanes, int64_t n_waves, int64_t n
 }
 void launch_dedup_gather(const DedupArgs &A, const int64_t *out_off, bwams_alnreg_t *out, hipStream_t st) {
     if (A.nseq <= 0) return;
-    dedup_gather_kernel<<<(unsigned)((A.nseq + 255) / 256), 256, 0, st>>>(A, out_off, out);
+    dedup_gather_kernel<<<(unsigned)((A.nseq * 16 + 255) / 256), 256, 0, st>>>(A, out_off, out);
 }
 
 }  // namespace bwams

@@ -99,7 +99,11 @@ def _assert_chains(want, got):
         assert np.array_equal(got["seeds"][f], want["seeds"][f]), f
 
 
-def test_chains_match_oracle(rep_toy):
+@pytest.mark.parametrize("batch", ["1", "0"])
+def test_chains_match_oracle(rep_toy, monkeypatch, batch):
+    """batch = 1 (default): the wave tier settles 64 seeds per pass (chain.hip: chain_seeds_batch); 0: one seed at a time."""
+    monkeypatch.setenv("BWAMS_CHAIN_BATCH", batch)
+    capi.debug_reload()
     g, idx, ix = rep_toy
     b, want, got, ctx = _run(idx, ix, g, _reads(g, 3000, 7))
     _assert_chains(want, got)
@@ -147,7 +151,7 @@ def test_chain_duplicate_positions_and_ties(rep_toy):
     b.close()
 
 
-def test_reads_with_thousands_of_seeds():
+def test_reads_with_thousands_of_seeds(monkeypatch):
     """A family of 5000 nearly exact copies and max_occ above that: reads carry 4000 .. 20000 seeds and thousands of chains — the wave tier's
     classes beyond 4096 seeds (ordered array of 13000 positions in LDS; beyond that the B-tree in HBM), many passes of 64 hits per SMEM with
     new chains and extensions mixed, the many-chain filter's largest class and its sequential form."""
@@ -166,6 +170,11 @@ def test_reads_with_thousands_of_seeds():
     try:
         reads = _reads(g, 40, 3)
         b, want, got, ctx = _run(idx, ix, g, reads, max_occ=6000)
+        monkeypatch.setenv("BWAMS_CHAIN_BATCH", "0")          # ... and the same reads one seed at a time
+        capi.debug_reload()
+        b0, want0, got0, _ = _run(idx, ix, g, reads, max_occ=6000)
+        _assert_chains(want0, got0)
+        b0.close()
         seeds_per_read = np.diff(ctx["off"][np.searchsorted(ctx["sm"]["rid"], np.arange(len(reads) + 1))])
         assert seeds_per_read.max() > 13000 and ((seeds_per_read > 4096) & (seeds_per_read <= 13000)).any(), seeds_per_read
         assert np.diff(want["chain_off"]).max() > 3840
